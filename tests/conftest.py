@@ -1,0 +1,64 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun)")
+
+
+class Fixture(object):
+    """A golden .npz split into its groups: in / p / out / g (+ extras)."""
+
+    def __init__(self, name):
+        self.name = name
+        raw = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.groups = {}
+        for key in raw.files:
+            grp, rest = key.split(".", 1)
+            self.groups.setdefault(grp, {})[rest] = raw[key]
+
+    def __getitem__(self, grp):
+        return self.groups[grp]
+
+    def tensors(self, grp, device="cpu"):
+        import torch
+        return {k: torch.from_numpy(np.asarray(v)).to(device) for k, v in self.groups[grp].items()}
+
+
+@pytest.fixture
+def golden():
+    return Fixture
+
+
+def load_params(module, params):
+    """Load a golden 'p' group (numpy) into a module, strictly."""
+    import torch
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}
+    missing, unexpected = module.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return module
+
+
+def assert_close(a, b, tol=1e-4, what=""):
+    import torch
+    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a)).double()
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, "%s shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    if a.numel() == 0:
+        return
+    err = (a - b).abs().max().item()
+    assert err <= tol, "%s max abs err %.3e > %.1e" % (what, err, tol)
+
+
+def assert_grads_close(module, ggroup, tol=1e-4):
+    for name, p in module.named_parameters():
+        got = p.grad if p.grad is not None else p.new_zeros(p.shape)
+        assert_close(got, ggroup[name], tol, "grad " + name)
