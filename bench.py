@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py -- FM (recbox.ranking) forward+backward on a Criteo-shaped batch.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`
+prints ONE JSON line from rank 0.  A "step" is one pass of the hot path over one
+synthetic batch: zero grads -> FeatureEmbedding gather -> LR + FM interaction ->
+sigmoid + BCE -> backward to DENSE gradients of every table (the reference's
+autograd contract).  No optimiser step: BASELINE.json's metric is fwd+bwd.
+Workload = BASELINE.json configs[1]: 13 dense + 26 sparse fields, dim 16, batch
+65 536 per GPU (weak scaling), cardinalities of SURVEY.md 8(d).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import OrderedDict
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CRITEO_VOCABS = [1460, 583, 1000000, 1000000, 305, 24, 12517, 633, 3, 93145, 5683, 1000000, 3194, 27, 14992,
+                 1000000, 10, 5652, 2173, 4, 1000000, 18, 15, 286181, 105, 142572]
+N_DENSE = 13
+
+
+class CriteoFeatureMap(object):
+    """Minimal ranking FeatureMap carrying the Criteo-shaped schema."""
+
+    def __init__(self, dim):
+        from recbox_amd.ranking.features import FeatureMap
+        self.fm = FeatureMap("criteo_synth", "/tmp")
+        feats = OrderedDict()
+        for i in range(N_DENSE):
+            feats["I%d" % (i + 1)] = {"source": "", "type": "numeric"}
+        for i, v in enumerate(CRITEO_VOCABS):
+            feats["C%d" % (i + 1)] = {"source": "", "type": "categorical", "vocab_size": v + 1, "padding_idx": 0}
+        self.fm.features = feats
+        self.fm.num_fields = len(feats)
+        self.fm.labels = ["label"]
+        self.fm.default_emb_dim = dim
+        self.fm.set_column_index()
+
+
+def synthetic_batch(B, seed, dist, device):
+    """Seeded Criteo-shaped batch.  ids arrive as float64 columns, exactly as the
+    reference's ranking loader delivers them (one hstacked float64 [B, cols] tensor)."""
+    g = torch.Generator().manual_seed(seed)
+    cols = []
+    for _ in range(N_DENSE):
+        cols.append(torch.rand(B, generator=g, dtype=torch.float64))
+    for v in CRITEO_VOCABS:
+        if dist == "zipf":
+            u = torch.rand(B, generator=g, dtype=torch.float64)
+            ids = torch.floor(float(v) ** u).clamp(1, v)
+        else:
+            ids = torch.randint(1, v + 1, (B,), generator=g).double()
+        cols.append(ids)
+    cols.append((torch.rand(B, generator=g) < 0.25).double())
+    batch = torch.stack(cols, dim=1).to(device)          # [B, 40] float64
+    return batch
+
+
+def slice_inputs(fm, batch):
+    X = OrderedDict()
+    for name, spec in fm.features.items():
+        X[name] = batch[:, fm.get_column_index(name)]   # strided column views; kernels read them in place
+    y = batch[:, fm.get_column_index("label")].float().view(-1, 1)
+    return X, y
+
+
+def init_weights(model, seed=0, std=0.1):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
+        for m in model.modules():
+            if isinstance(m, torch.nn.Embedding) and m.padding_idx is not None:
+                m.weight[m.padding_idx].zero_()
+
+
+def cpu_baseline(dim, B, dist, budget_s):
+    """The oracle (a restatement of the reference's op sequence in plain PyTorch CPU ops)
+    timed on this box's host cores, same shapes, fwd+bwd, no optimiser step."""
+    from oracle import torch_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    fmw = CriteoFeatureMap(dim)
+    model = R.RefFMModel(fmw.fm, dim)
+    init_weights(model)
+    batch = synthetic_batch(B, 1, dist, "cpu")
+    X, y = slice_inputs(fmw.fm, batch)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(model(X)), y, reduction="mean")
+        loss.backward()
+
+    step()                                   # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 20:
+            break
+    return {"value": B * n / el, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d full steps of the same workload (B=%d, dim=%d, %s ids) on torch CPU ops, %d threads"
+                      % (n, B, dim, dist, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=65536, help="per-GPU batch")
+    ap.add_argument("--dim", type=int, default=16)
+    ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from recbox_amd import ops
+    from recbox_amd.ranking.pytorch.models import FM
+    ops.config.check_ids = False              # no per-call host sync inside the timed region
+    fmw = CriteoFeatureMap(args.dim)
+    model = FM(fmw.fm, args.dim).to(dev)
+    init_weights(model)
+    B = args.batch
+    batch = synthetic_batch(B, 1 + rank, args.dist, dev)
+    X, y = slice_inputs(fmw.fm, batch)
+    n_fields = len(fmw.fm.features)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        prob = model(X)["y_pred"]
+        loss = torch.nn.functional.binary_cross_entropy(prob, y, reduction="mean")
+        loss.backward()
+        if world > 1:
+            for p in model.parameters():      # data-parallel replicas: dense grads all-reduced
+                torch.distributed.all_reduce(p.grad)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    # dominant kernel: the [B, 39, 16] gather (embed_fwd over all fields at dim 16)
+    timer = ops.KernelTimer(lambda m: m[0] == "embed_fwd" and m[2] == n_fields * args.dim)
+    ops.kernel_timer = timer
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    ops.kernel_timer = None
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        ms = el / args.steps * 1e3
+        # algorithmic bytes of the gather per sample: 26 rows x 64 B
+        # + 26 ids x 8 B (float64 columns) + 13 dense values x 8 B + the [39,16] fp32 slot written
+        n_sparse = len(CRITEO_VOCABS)
+        per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 8 + n_fields * args.dim * 4
+        kms = timer.mean_ms()
+        roof = None
+        if kms:
+            achieved = per_sample * B / (kms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": None, "kernel": "embed_fwd_kernel<4,1,true>",
+                    "kernel_ms": kms, "algorithmic_bytes_per_launch": per_sample * B}
+        out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
+               "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
+                                      "%s ids, dense-grad autograd contract, no optimiser step" % (args.dim, B, args.dist),
+                          "global_batch": B * world, "parallelism": "dp%d" % world},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.dim, B, args.dist, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

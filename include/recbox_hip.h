@@ -1,0 +1,146 @@
+/* recbox_hip.h -- C ABI of librecbox_hip.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary for the embedding-lookup + feature-interaction hot path of
+ * reczoo/RecBox.  The reference has no FFI of its own (it is pure Python on
+ * PyTorch): each entry point below replaces the ATen op
+ * sequence that one reference nn.Module dispatches, and cites that module
+ * (paths relative to /root/reference/recbox).  INTEGRATION.md shows the ctypes
+ * stub a maintainer would add to call these from the reference's own layers.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no C++ or torch types;
+ *   - every pointer named d_* / inside rbx_field_t is a DEVICE pointer, every
+ *     other pointer is a HOST pointer;
+ *   - the caller owns all memory including workspaces (query *_workspace_size);
+ *     the library allocates nothing persistent and keeps no global state but a
+ *     thread-local error string;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL is
+ *     the default stream) and never synchronise; calls are re-entrant across
+ *     streams;
+ *   - return value: 0 on success, a negative rbx_status_t otherwise, message in
+ *     rbx_last_error();
+ *   - all floating point is IEEE fp32; ids are exact (bit-identical row choice).
+ */
+#ifndef RECBOX_HIP_H
+#define RECBOX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBX_VERSION 100          /* 0.1.0 */
+#define RBX_MAX_FIELDS 64        /* fields per call */
+#define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
+
+typedef enum {
+  RBX_OK = 0,
+  RBX_ERR_INVALID = -1,          /* bad argument (ValueError on the Python side) */
+  RBX_ERR_LAUNCH = -2,           /* HIP launch / runtime failure (RuntimeError) */
+  RBX_ERR_WORKSPACE = -3,        /* workspace too small */
+  RBX_ERR_UNSUPPORTED = -4       /* NotImplementedError on the Python side */
+} rbx_status_t;
+
+/* dtype of an id / value column as it reaches the layer (int64,
+ * int32, or float64 when the ranking loader hstacks the split; the kernels do
+ * the reference's `.long()` / `.float()` casts in registers). */
+typedef enum { RBX_I32 = 0, RBX_I64 = 1, RBX_F32 = 2, RBX_F64 = 3 } rbx_dtype_t;
+
+typedef enum {
+  RBX_FIELD_CATEGORICAL = 0,     /* nn.Embedding(vocab, dim)(ids.long()) */
+  RBX_FIELD_NUMERIC = 1,         /* nn.Linear(1, dim, bias=False)(x.float().view(-1,1)) */
+  RBX_FIELD_DENSE = 2            /* rechub DenseFeature: x.float() copied, dim == 1 */
+} rbx_field_kind_t;
+
+typedef enum {
+  RBX_POOL_NONE = 0,             /* one id per sample */
+  RBX_POOL_SUM = 1,              /* recbox MaskedSumPooling: plain sum over L */
+  RBX_POOL_MEAN_VALUE = 2,       /* recbox MaskedAveragePooling: sum / (#rows with sum_d != 0 + eps) */
+  RBX_POOL_MEAN_ID = 3,          /* rechub AveragePooling: sum_{id != mask_id} / (count + eps) */
+  RBX_POOL_SUM_ID = 4,           /* rechub SumPooling with InputMask */
+  RBX_POOL_CONCAT = 5            /* rechub ConcatPooling: keep [L, dim] */
+} rbx_pool_t;
+
+/* One feature of a multi-table lookup.  Output slot of sample b:
+ *   d_out + b * out_stride_b + out_off   (dim floats; L*dim for POOL_CONCAT). */
+typedef struct rbx_field {
+  const void*  ids;              /* [B] or [B, seq_len] ids; numeric/dense: values */
+  const float* table;            /* [vocab, dim] table; numeric: Linear weight as [dim]; dense: NULL */
+  float*       grad;             /* backward only: dense grad, same shape as table (accumulated into) */
+  int64_t      ids_stride_b;     /* element stride between samples */
+  int64_t      ids_stride_l;     /* element stride inside a sequence */
+  int64_t      vocab;
+  int64_t      padding_idx;      /* nn.Embedding.padding_idx: row gets zero grad; RBX_NO_ID if unset */
+  int64_t      mask_id;          /* *_ID pools: lookups equal to it get weight 0; RBX_NO_ID if unset */
+  int64_t      out_off;          /* float offset of the slot inside an output row */
+  int32_t      dim;
+  int32_t      seq_len;          /* 1 unless a sequence feature */
+  int32_t      ids_dtype;        /* rbx_dtype_t */
+  int32_t      kind;             /* rbx_field_kind_t */
+  int32_t      pool;             /* rbx_pool_t */
+  float        eps;              /* MEAN pools: 1e-12 (recbox), 1e-16 (rechub), 1e-8 (RecBole) */
+} rbx_field_t;
+
+const char* rbx_last_error(void);
+int rbx_version(void);
+
+/* ---- K1/K2: multi-table gather (+ fused sequence pooling) ------------------
+ * Replaces, in ONE launch over all fields, the per-feature Python loop of
+ *   core/pytorch/layers/embedding.py:116-138  (EmbeddingDictLayer.forward + callbacks),
+ *   ranking/pytorch/layers/embeddings/feature_embedding.py:188-214 (+ dict2tensor :169-186),
+ *   third_party/rechub/basic/layers.py:66-116 (EmbeddingLayer.forward, InputMask, pooling :176-230),
+ * i.e. nn.Embedding / nn.Linear(1,D) / masked mean|sum pooling / stack|cat.
+ * d_row_scale: [F, B] floats, written for MEAN pools (1/(count+eps)), read by the
+ * backward; may be NULL when no MEAN pool is present.
+ * d_status: optional int32 flag word, set non-zero when an id is out of range
+ * (the reference raises IndexError); out-of-range lookups read as zero rows. */
+int rbx_embed_fwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
+                  float* d_out, int64_t out_stride_b, float* d_row_scale,
+                  int32_t* d_status, void* stream);
+
+/* ---- K3: embedding backward = sorted, segmented, deterministic scatter-add ---
+ * Replaces autograd's embedding_dense_backward (+ pooling / stack backward) of the
+ * modules above.  Two phases so that the id sort can run early (ids are known in
+ * the forward) on another stream:
+ *   rbx_embed_sort   : builds (global row, lookup) pairs for every categorical
+ *                      lookup, drops padding_idx / masked ids, radix-sorts them.
+ *   rbx_embed_bwd    : segment-reduces d_out rows in sorted order and adds each
+ *                      touched row ONCE into fields[f].grad (dense [vocab,dim],
+ *                      caller pre-zeroes or accumulates); numeric fields get
+ *                      grad[d] += sum_b x_b * d_out[b, off+d].  Features that
+ *                      share a table (same `table` pointer) are merged.
+ * Results are run-to-run deterministic (no float atomics). */
+size_t rbx_embed_bwd_workspace_size(const rbx_field_t* fields, int32_t n_fields, int64_t batch);
+int rbx_embed_sort(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
+                   void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream);
+int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
+                  const float* d_dout, int64_t out_stride_b, const float* d_row_scale,
+                  void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K4: InnerProductInteraction / rechub FM on a materialised [B,F,D] tensor ---
+ * ranking/pytorch/layers/interactions/inner_product.py:40-56,
+ * third_party/rechub/basic/layers.py:286-292.
+ * mode 0: product_sum -> [B,1]; 1: bi_interaction -> [B,D];
+ * mode 2: inner_product -> [B,F(F-1)/2]; 3: elementwise_product -> [B,F(F-1)/2,D]. */
+int rbx_interaction_fwd(const float* d_emb, int64_t batch, int32_t n_fields, int32_t dim,
+                        int32_t mode, float* d_out, void* stream);
+int rbx_interaction_bwd(const float* d_emb, const float* d_dout, int64_t batch, int32_t n_fields,
+                        int32_t dim, int32_t mode, float* d_demb, void* stream);
+
+/* ---- pooling of a materialised [B,L,D] tensor (standalone pooling modules) ------
+ * core/pytorch/layers/sequence.py:4-20, ranking/pytorch/layers/pooling.py:22-40,
+ * third_party/rechub/basic/layers.py:176-230.
+ * numer_masked: numerator = sum_l mask[b,l]*E[b,l,:] instead of the plain sum.
+ * denom: 0 none | 1 #rows whose sum_d != 0 (recbox value mask) | 2 sum_l mask | 3 L.
+ * d_inv[B] receives 1/(denom+eps) for the backward. */
+int rbx_pool_fwd(const float* d_emb, const float* d_mask, int64_t batch, int32_t seq_len, int32_t dim,
+                 int32_t numer_masked, int32_t denom, float eps, float* d_out, float* d_inv, void* stream);
+int rbx_pool_bwd(const float* d_dout, const float* d_mask, const float* d_inv, int64_t batch, int32_t seq_len,
+                 int32_t dim, int32_t numer_masked, float* d_demb, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECBOX_HIP_H */

@@ -1,0 +1,64 @@
+"""Host-side planner shared by the three embedding-layer flavours.
+
+A layer call is described as an ordered list of ``Lookup`` items (one per output
+slot); ``make_plan`` lays the slots out back to back in one ``[B, width]`` row,
+dedupes parameter holders (``share_embedding`` / ``shared_with`` alias the same
+module object) and returns an ``ops.EmbedPlan`` plus the holder modules in
+parameter order.  Plans are cached by the caller per call signature.
+"""
+from torch import nn
+
+from . import ops
+from ._lib import FIELD_CATEGORICAL, FIELD_DENSE, FIELD_NUMERIC, POOL_CONCAT, POOL_NONE
+
+
+class Lookup(object):
+    __slots__ = ("name", "kind", "module", "dim", "pool", "seq_len", "mask_id", "eps")
+
+    def __init__(self, name, kind, module=None, dim=1, pool=POOL_NONE, seq_len=1, mask_id=None, eps=0.0):
+        self.name, self.kind, self.module, self.dim = name, kind, module, dim
+        self.pool, self.seq_len, self.mask_id, self.eps = pool, seq_len, mask_id, eps
+
+
+class Plan(object):
+    """ops.EmbedPlan + the parameter holders + slot geometry."""
+
+    def __init__(self, lookups):
+        self.lookups = lookups
+        self.modules = []
+        specs, off = [], 0
+        for lk in lookups:
+            param = -1
+            vocab, padding_idx = 0, None
+            if lk.kind != FIELD_DENSE:
+                for i, m in enumerate(self.modules):
+                    if m is lk.module:
+                        param = i
+                if param < 0:
+                    param = len(self.modules)
+                    self.modules.append(lk.module)
+                if lk.kind == FIELD_CATEGORICAL:
+                    if type(lk.module) is not nn.Embedding and not isinstance(lk.module, nn.Embedding):
+                        raise TypeError("feature '%s': categorical features need an nn.Embedding holder" % lk.name)
+                    vocab, padding_idx = lk.module.num_embeddings, lk.module.padding_idx
+            spec = ops.FieldSpec(lk.name, lk.kind, lk.dim, off, param=param, pool=lk.pool, seq_len=lk.seq_len,
+                                 vocab=vocab, padding_idx=padding_idx, mask_id=lk.mask_id, eps=lk.eps)
+            specs.append(spec)
+            off += spec.width
+        self.specs = specs
+        self.width = off
+        self.plan = ops.EmbedPlan(specs, off)
+        dims = set(s.dim for s in specs)
+        self.uniform_dim = dims.pop() if len(dims) == 1 else None
+
+    def run(self, inputs):
+        params = [m.weight for m in self.modules]
+        return ops.embed_lookup(self.plan, inputs, params)
+
+    def slot(self, out, i):
+        """View of output slot i: [B, dim] or [B, L, dim] for concat pooling."""
+        s = self.specs[i]
+        v = out[:, s.out_off:s.out_off + s.width]
+        if s.pool == POOL_CONCAT:
+            v = v.reshape(out.shape[0], s.seq_len, s.dim)
+        return v

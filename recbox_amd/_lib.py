@@ -1,0 +1,93 @@
+"""ctypes binding of librecbox_hip.so (the C ABI declared in include/recbox_hip.h).
+
+The product path has NO fallback: if the shared library is missing or does not
+export a symbol, importing this module raises.  (``python -m recbox_amd.build``
+or ``__graft_entry__.build()`` produces the library with hipcc for gfx950.)
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "librecbox_hip.so")
+
+RBX_MAX_FIELDS = 64
+RBX_NO_ID = -(1 << 63)
+
+RBX_OK, RBX_ERR_INVALID, RBX_ERR_LAUNCH, RBX_ERR_WORKSPACE, RBX_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+RBX_I32, RBX_I64, RBX_F32, RBX_F64 = 0, 1, 2, 3
+FIELD_CATEGORICAL, FIELD_NUMERIC, FIELD_DENSE = 0, 1, 2
+POOL_NONE, POOL_SUM, POOL_MEAN_VALUE, POOL_MEAN_ID, POOL_SUM_ID, POOL_CONCAT = 0, 1, 2, 3, 4, 5
+INTERACTION_MODES = {"product_sum": 0, "bi_interaction": 1, "inner_product": 2, "elementwise_product": 3}
+
+
+class rbx_field_t(ctypes.Structure):
+    _fields_ = [("ids", ctypes.c_void_p),
+                ("table", ctypes.c_void_p),
+                ("grad", ctypes.c_void_p),
+                ("ids_stride_b", ctypes.c_int64),
+                ("ids_stride_l", ctypes.c_int64),
+                ("vocab", ctypes.c_int64),
+                ("padding_idx", ctypes.c_int64),
+                ("mask_id", ctypes.c_int64),
+                ("out_off", ctypes.c_int64),
+                ("dim", ctypes.c_int32),
+                ("seq_len", ctypes.c_int32),
+                ("ids_dtype", ctypes.c_int32),
+                ("kind", ctypes.c_int32),
+                ("pool", ctypes.c_int32),
+                ("eps", ctypes.c_float)]
+
+
+_P = ctypes.c_void_p
+_FP = ctypes.POINTER(rbx_field_t)
+_i32, _i64, _sz, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/recbox_hip.h
+SIGNATURES = {
+    "rbx_last_error": (ctypes.c_char_p, []),
+    "rbx_version": (ctypes.c_int, []),
+    "rbx_embed_fwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _P, _P, _P]),
+    "rbx_embed_bwd_workspace_size": (_sz, [_FP, _i32, _i64]),
+    "rbx_embed_sort": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P, _P]),
+    "rbx_embed_bwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _P, _P, _sz, _P]),
+    "rbx_interaction_fwd": (ctypes.c_int, [_P, _i64, _i32, _i32, _i32, _P, _P]),
+    "rbx_interaction_bwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _i32, _P, _P]),
+    "rbx_pool_fwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _i32, _i32, _f32, _P, _P, _P]),
+    "rbx_pool_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _P, _P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "recbox_amd: %s is missing. Build it with `python -m recbox_amd.build` (hipcc, gfx950). "
+            "There is no CPU or PyTorch fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError("recbox_amd: %s does not export %s; rebuild the extension" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    msg = lib.rbx_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+    """Map a C status code to the exception type the reference raises."""
+    if rc == RBX_OK:
+        return
+    msg = last_error()
+    if rc == RBX_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == RBX_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError("librecbox_hip: %s (code %d)" % (msg, rc))

@@ -1,0 +1,301 @@
+// rbx_embed_fwd.hip -- K1/K2: multi-table embedding gather with fused sequence
+// pooling, one launch over all features of a layer (gfx950).
+//
+// Reference behaviour replaced (paths relative to /root/reference/recbox):
+//   core/pytorch/layers/embedding.py:116-138, ranking/pytorch/layers/embeddings/
+//   feature_embedding.py:188-214 + dict2tensor :169-186, third_party/rechub/basic/
+//   layers.py:66-116 with the pooling variants of core/.../sequence.py:8-20,
+//   ranking/.../pooling.py:26-40 and rechub/basic/layers.py:187-230.
+//
+// Mapping.  A (sample, field) pair is served by a lane group of G = dim/4 lanes
+// (float4 per lane; G lanes x 1 float on the scalar path), so a 64-wide wavefront
+// keeps 64/G independent row reads in flight per load instruction.  Pairs are
+// numbered p = b*F + f, field fastest: consecutive groups write consecutive
+// slots of the [B, F*D] output row -> fully coalesced stores; the random traffic
+// is the table rows only.  Descriptors arrive through the kernarg segment and are
+// mirrored into LDS once per workgroup because `f` diverges between lane groups.
+// The simple (one id per sample) path is unrolled x4 so that four dependent
+// id->row chains per lane are in flight; sequence pools unroll over L instead.
+// HBM-bound: no LDS tiling of rows (each row is used once), no MFMA.
+#include "rbx_internal.h"
+
+namespace rbx {
+
+template <bool VEC>
+struct Acc;
+template <>
+struct Acc<true> {
+  float4 v;
+  __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ __forceinline__ void add(const Acc& o) { v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w; }
+  __device__ __forceinline__ void scale(float s) { v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+  __device__ __forceinline__ float hsum() const { return (v.x + v.y) + (v.z + v.w); }
+  __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+};
+template <>
+struct Acc<false> {
+  float v;
+  __device__ __forceinline__ void zero() { v = 0.f; }
+  __device__ __forceinline__ void add(const Acc& o) { v += o.v; }
+  __device__ __forceinline__ void scale(float s) { v *= s; }
+  __device__ __forceinline__ float hsum() const { return v; }
+  __device__ __forceinline__ void load(const float* p) { v = *p; }
+  __device__ __forceinline__ void store(float* p) const { *p = v; }
+};
+
+// One lane's share of a row: NV units, unit u covers elements [(lane_g + u*G)*W, +W).
+template <int G, int NV, bool VEC>
+struct RowFrag {
+  static constexpr int W = VEC ? 4 : 1;
+  Acc<VEC> a[NV];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) a[u].zero();
+  }
+  __device__ __forceinline__ void load(const float* row, int dim, int lane_g) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = (lane_g + u * G) * W;
+      if (e < dim) a[u].load(row + e); else a[u].zero();
+    }
+  }
+  __device__ __forceinline__ void store(float* row, int dim, int lane_g) const {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = (lane_g + u * G) * W;
+      if (e < dim) a[u].store(row + e);
+    }
+  }
+  __device__ __forceinline__ void add(const RowFrag& o) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) a[u].add(o.a[u]);
+  }
+  __device__ __forceinline__ void scale(float s) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) a[u].scale(s);
+  }
+  __device__ __forceinline__ float hsum() const {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) s += a[u].hsum();
+    return s;
+  }
+};
+
+template <int G, int NV, bool VEC>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const FieldPack P, const int F, const long long B,
+                                                        float* __restrict__ out, const long long stride_b,
+                                                        float* __restrict__ row_scale,
+                                                        int* __restrict__ status) {
+  __shared__ FieldK sf[RBX_MAX_FIELDS];
+  {
+    const int words = F * static_cast<int>(sizeof(FieldK) / 4);
+    const int* src = reinterpret_cast<const int*>(&P);
+    int* dst = reinterpret_cast<int*>(sf);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  using Frag = RowFrag<G, NV, VEC>;
+  const int lane_g = threadIdx.x % G;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
+  const long long npairs = B * F;
+  constexpr int U = 4;  // independent pairs in flight per lane group
+  const bool small = npairs < (1ll << 32);
+
+  for (long long p0 = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; p0 < npairs;
+       p0 += ngroups * U) {
+    // ---- phase 1: ids / values of up to U pairs -------------------------------
+    long long bb[U];
+    int ff[U];
+    long long id0[U];
+    bool simple[U], live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long p = p0 + u * ngroups;
+      live[u] = p < npairs;
+      const long long pc = live[u] ? p : 0;
+      if (small) {   // 32-bit divide: the 64-bit one costs ~100 VALU ops per pair
+        const unsigned q = static_cast<unsigned>(pc) / static_cast<unsigned>(F);
+        bb[u] = q;
+        ff[u] = static_cast<int>(static_cast<unsigned>(pc) - q * static_cast<unsigned>(F));
+      } else {
+        bb[u] = pc / F;
+        ff[u] = static_cast<int>(pc - bb[u] * F);
+      }
+      const FieldK& fd = sf[ff[u]];
+      simple[u] = live[u] && fd.kind == RBX_FIELD_CATEGORICAL && fd.pool == RBX_POOL_NONE;
+      id0[u] = simple[u] ? load_id(fd.ids, bb[u] * fd.ids_stride_b, fd.ids_dtype) : 0;
+    }
+    // ---- phase 2: row reads of the simple pairs -------------------------------
+    Frag row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      row[u].zero();
+      if (simple[u]) {
+        const FieldK& fd = sf[ff[u]];
+        if (id0[u] >= 0 && id0[u] < fd.vocab) {
+          row[u].load(fd.table + id0[u] * fd.dim, fd.dim, lane_g);
+        } else if (status != nullptr) {
+          atomicOr(status, 1);
+        }
+      }
+    }
+    // ---- phase 3: stores; everything that is not a plain lookup ---------------
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+      const FieldK& fd = sf[ff[u]];
+      float* dst = out + bb[u] * stride_b + fd.out_off;
+      const int dim = fd.dim;
+      if (simple[u]) {
+        row[u].store(dst, dim, lane_g);
+        continue;
+      }
+      if (fd.kind == RBX_FIELD_DENSE) {
+        if (lane_g == 0) dst[0] = load_value(fd.ids, bb[u] * fd.ids_stride_b, fd.ids_dtype);
+        continue;
+      }
+      if (fd.kind == RBX_FIELD_NUMERIC) {
+        const float x = load_value(fd.ids, bb[u] * fd.ids_stride_b, fd.ids_dtype);
+        Frag w;
+        w.load(fd.table, dim, lane_g);
+        w.scale(x);
+        w.store(dst, dim, lane_g);
+        continue;
+      }
+      // sequence feature: L lookups, pooled or kept
+      const int L = fd.seq_len;
+      const int pool = fd.pool;
+      const long long base = bb[u] * fd.ids_stride_b;
+      Frag acc;
+      acc.zero();
+      float count = 0.f;
+      for (int l0 = 0; l0 < L; l0 += U) {
+        long long ids[U];
+        bool ok[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const int l = l0 + j;
+          ok[j] = l < L;
+          ids[j] = ok[j] ? load_id(fd.ids, base + static_cast<long long>(l) * fd.ids_stride_l, fd.ids_dtype) : 0;
+        }
+        Frag r[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          r[j].zero();
+          if (!ok[j]) continue;
+          const bool masked = (pool == RBX_POOL_MEAN_ID || pool == RBX_POOL_SUM_ID) && ids[j] == fd.mask_id;
+          if (ids[j] >= 0 && ids[j] < fd.vocab) {
+            // masked rows are still read by the reference (bmm with a 0 weight); skip the traffic
+            if (!masked) r[j].load(fd.table + ids[j] * dim, dim, lane_g);
+          } else if (status != nullptr) {
+            atomicOr(status, 1);
+          }
+          if (masked) ok[j] = false;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          const int l = l0 + j;
+          if (l >= L) continue;
+          if (pool == RBX_POOL_CONCAT) {
+            r[j].store(dst + static_cast<long long>(l) * dim, dim, lane_g);
+          } else {
+            acc.add(r[j]);
+            if (pool == RBX_POOL_MEAN_VALUE) {
+              const float s = group_sum<G>(r[j].hsum());   // value mask: row sum != 0
+              count += (s != 0.f) ? 1.f : 0.f;
+            } else if (pool == RBX_POOL_MEAN_ID) {
+              count += ok[j] ? 1.f : 0.f;
+            }
+          }
+        }
+      }
+      if (pool == RBX_POOL_CONCAT) continue;
+      if (pool == RBX_POOL_MEAN_VALUE || pool == RBX_POOL_MEAN_ID) {
+        const float inv = 1.0f / (count + fd.eps);
+        // the reference divides; x * (1/(c+eps)) differs from x / (c+eps) by <= 1 ulp
+        acc.scale(inv);
+        if (row_scale != nullptr && lane_g == 0) row_scale[static_cast<long long>(fd.slot) * B + bb[u]] = inv;
+      }
+      acc.store(dst, dim, lane_g);
+    }
+  }
+}
+
+template <int G, int NV, bool VEC>
+static int launch_fwd(const FieldPack& pack, int F, int64_t B, float* out, int64_t stride_b, float* row_scale,
+                      int* status, hipStream_t s) {
+  const long long npairs = B * F;
+  const int groups_per_block = 256 / G;
+  long long blocks = (npairs + groups_per_block - 1) / groups_per_block;
+  const long long cap = static_cast<long long>(kCUs) * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((embed_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, pack, F,
+                     static_cast<long long>(B), out, static_cast<long long>(stride_b), row_scale, status);
+  return check_launch("embed_fwd_kernel");
+}
+
+template <bool VEC>
+static int dispatch_fwd(int units, const FieldPack& pack, int F, int64_t B, float* out, int64_t stride_b,
+                        float* row_scale, int* status, hipStream_t s) {
+  const int g = pow2_ceil(units);
+  switch (g) {
+    case 1: return launch_fwd<1, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    case 2: return launch_fwd<2, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    case 4: return launch_fwd<4, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    case 8: return launch_fwd<8, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    case 16: return launch_fwd<16, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    case 32: return launch_fwd<32, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    case 64: return launch_fwd<64, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    case 128: return launch_fwd<64, 2, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    case 256: return launch_fwd<64, 4, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    default: return fail(RBX_ERR_UNSUPPORTED, "embedding dim too large for one lane group (units=%d)", units);
+  }
+}
+
+static bool field_vec_ok(const rbx_field_t& f, const float* out, int64_t stride_b) {
+  if (f.kind == RBX_FIELD_DENSE) return false;
+  if (f.dim % 4 != 0 || f.out_off % 4 != 0 || stride_b % 4 != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(f.table) & 15) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(out) & 15) != 0) return false;
+  return true;
+}
+
+}  // namespace rbx
+
+extern "C" int rbx_embed_fwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch, float* d_out,
+                             int64_t out_stride_b, float* d_row_scale, int32_t* d_status, void* stream) {
+  using namespace rbx;
+  if (n_fields <= 0 || n_fields > RBX_MAX_FIELDS) return fail(RBX_ERR_INVALID, "n_fields=%d out of range", n_fields);
+  if (batch < 0 || d_out == nullptr) return fail(RBX_ERR_INVALID, "bad batch/out");
+  if (batch == 0) return RBX_OK;
+  // split into a float4 launch and a scalar launch (slot = position in the caller's array)
+  rbx_field_t part[2][RBX_MAX_FIELDS];
+  int slot[2][RBX_MAX_FIELDS];
+  int cnt[2] = {0, 0};
+  int units[2] = {1, 1};
+  for (int i = 0; i < n_fields; ++i) {
+    const int k = field_vec_ok(fields[i], d_out, out_stride_b) ? 0 : 1;
+    part[k][cnt[k]] = fields[i];
+    slot[k][cnt[k]] = i;
+    const int u = (k == 0) ? fields[i].dim / 4 : fields[i].dim;
+    if (u > units[k]) units[k] = u;
+    ++cnt[k];
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (cnt[k] == 0) continue;
+    FieldPack pack;
+    int rc = pack_fields(part[k], cnt[k], batch, false, &pack);
+    if (rc != RBX_OK) return rc;
+    for (int i = 0; i < cnt[k]; ++i) pack.f[i].slot = static_cast<unsigned char>(slot[k][i]);
+    rc = (k == 0) ? dispatch_fwd<true>(units[k], pack, cnt[k], batch, d_out, out_stride_b, d_row_scale, d_status,
+                                       as_stream(stream))
+                  : dispatch_fwd<false>(units[k], pack, cnt[k], batch, d_out, out_stride_b, d_row_scale, d_status,
+                                        as_stream(stream));
+    if (rc != RBX_OK) return rc;
+  }
+  return RBX_OK;
+}

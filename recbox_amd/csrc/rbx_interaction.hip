@@ -1,0 +1,236 @@
+// rbx_interaction.hip -- K4: feature-interaction layer on a materialised
+// [B, F, D] embedding tensor (gfx950).
+//
+// Reference behaviour replaced: InnerProductInteraction.forward
+// (ranking/pytorch/layers/interactions/inner_product.py:40-56) in its four output
+// modes, and rechub FM (third_party/rechub/basic/layers.py:286-292), plus the
+// autograd backward of each.
+//   mode 0 product_sum        out[b]     = 0.5 * sum_d[(sum_f e)^2 - sum_f e^2]
+//   mode 1 bi_interaction     out[b,d]   = 0.5 * [(sum_f e)^2 - sum_f e^2]
+//   mode 2 inner_product      out[b,p]   = <e_i, e_j>, p over i<j row-major
+//   mode 3 elementwise_product out[b,p,:] = e_i * e_j
+// Modes 0/1 are HBM-streaming reductions: a lane group of D/4 lanes (float4 each)
+// owns one sample and walks its F rows, so S = sum_f e lives in registers and the
+// only cross-lane step is the final sum over d.  The backward recomputes S from the
+// (L1/L2-hot) sample block instead of saving it: dE_f = g * (S - e_f).
+// Modes 2/3 stage the sample's [F, D] block in LDS (one wavefront per sample).
+#include "rbx_internal.h"
+
+namespace rbx {
+
+template <int G, int NV, bool VEC>
+__global__ __launch_bounds__(256) void fm_fwd_kernel(const float* __restrict__ emb, const long long B, const int F,
+                                                     const int D, const int mode, float* __restrict__ out) {
+  constexpr int W = VEC ? 4 : 1;
+  const int lane_g = threadIdx.x % G;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
+  for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
+    const float* base = emb + b * F * D;
+    float s[NV * W], q[NV * W];
+#pragma unroll
+    for (int i = 0; i < NV * W; ++i) s[i] = q[i] = 0.f;
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int e = (lane_g + u * G) * W;
+        if (e < D) {
+          if constexpr (VEC) {
+            const float4 t = *reinterpret_cast<const float4*>(base + f * D + e);
+            s[u * 4] += t.x; s[u * 4 + 1] += t.y; s[u * 4 + 2] += t.z; s[u * 4 + 3] += t.w;
+            q[u * 4] += t.x * t.x; q[u * 4 + 1] += t.y * t.y; q[u * 4 + 2] += t.z * t.z; q[u * 4 + 3] += t.w * t.w;
+          } else {
+            const float t = base[f * D + e];
+            s[u] += t;
+            q[u] += t * t;
+          }
+        }
+      }
+    }
+    if (mode == 1) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int e = (lane_g + u * G) * W;
+        if (e < D) {
+#pragma unroll
+          for (int k = 0; k < W; ++k) out[b * D + e + k] = (s[u * W + k] * s[u * W + k] - q[u * W + k]) * 0.5f;
+        }
+      }
+    } else {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV * W; ++i) t += (s[i] * s[i] - q[i]) * 0.5f;
+      t = group_sum<G>(t);
+      if (lane_g == 0) out[b] = t;
+    }
+  }
+}
+
+template <int G, int NV, bool VEC>
+__global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
+                                                     const long long B, const int F, const int D, const int mode,
+                                                     float* __restrict__ demb) {
+  constexpr int W = VEC ? 4 : 1;
+  const int lane_g = threadIdx.x % G;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
+  for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
+    const float* base = emb + b * F * D;
+    float* dbase = demb + b * F * D;
+    float s[NV * W], g[NV * W];
+#pragma unroll
+    for (int i = 0; i < NV * W; ++i) s[i] = 0.f;
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int e = (lane_g + u * G) * W;
+        if (e < D) {
+#pragma unroll
+          for (int k = 0; k < W; ++k) s[u * W + k] += base[f * D + e + k];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = (lane_g + u * G) * W;
+#pragma unroll
+      for (int k = 0; k < W; ++k) g[u * W + k] = (mode == 1) ? ((e < D) ? dout[b * D + e + k] : 0.f) : dout[b];
+    }
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int e = (lane_g + u * G) * W;
+        if (e < D) {
+          if constexpr (VEC) {
+            const float4 t = *reinterpret_cast<const float4*>(base + f * D + e);
+            float4 r;
+            r.x = g[u * 4] * (s[u * 4] - t.x);
+            r.y = g[u * 4 + 1] * (s[u * 4 + 1] - t.y);
+            r.z = g[u * 4 + 2] * (s[u * 4 + 2] - t.z);
+            r.w = g[u * 4 + 3] * (s[u * 4 + 3] - t.w);
+            *reinterpret_cast<float4*>(dbase + f * D + e) = r;
+          } else {
+            dbase[f * D + e] = g[u] * (s[u] - base[f * D + e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ int pair_index(int i, int j, int F) { return i * F - (i * (i + 1)) / 2 + (j - i - 1); }
+
+// one wavefront per sample; the sample's [F, D] block sits in LDS
+__global__ __launch_bounds__(64) void pair_fwd_kernel(const float* __restrict__ emb, const int F, const int D,
+                                                      const int mode, float* __restrict__ out) {
+  extern __shared__ float se[];
+  const long long b = blockIdx.x;
+  const int FD = F * D, P = F * (F - 1) / 2;
+  for (int i = threadIdx.x; i < FD; i += 64) se[i] = emb[b * FD + i];
+  __syncthreads();
+  if (mode == 2) {
+    for (int i = 0; i < F - 1; ++i) {
+      for (int j = i + 1 + threadIdx.x; j < F; j += 64) {
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) acc += se[i * D + d] * se[j * D + d];
+        out[b * P + pair_index(i, j, F)] = acc;
+      }
+    }
+  } else {
+    for (int i = 0; i < F - 1; ++i) {
+      const int n = (F - 1 - i) * D;                  // contiguous run of outputs for row i
+      float* dst = out + (b * P + pair_index(i, i + 1, F)) * D;
+      for (int t = threadIdx.x; t < n; t += 64) {
+        const int j = i + 1 + t / D, d = t % D;
+        dst[t] = se[i * D + d] * se[j * D + d];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void pair_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
+                                                      const int F, const int D, const int mode,
+                                                      float* __restrict__ demb) {
+  extern __shared__ float se[];
+  const long long b = blockIdx.x;
+  const int FD = F * D, P = F * (F - 1) / 2;
+  for (int i = threadIdx.x; i < FD; i += 64) se[i] = emb[b * FD + i];
+  __syncthreads();
+  for (int t = threadIdx.x; t < FD; t += 64) {
+    const int i = t / D, d = t % D;
+    float acc = 0.f;
+    for (int j = 0; j < F; ++j) {
+      if (j == i) continue;
+      const int p = (i < j) ? pair_index(i, j, F) : pair_index(j, i, F);
+      const float g = (mode == 2) ? dout[b * P + p] : dout[(b * P + p) * D + d];
+      acc += g * se[j * D + d];
+    }
+    demb[b * FD + t] = acc;
+  }
+}
+
+template <int G, int NV, bool VEC>
+static int launch_fm(bool bwd, const float* emb, const float* dout, int64_t B, int F, int D, int mode, float* out,
+                     hipStream_t s) {
+  const int gpb = 256 / G;
+  long long blocks = (B + gpb - 1) / gpb;
+  if (blocks > kCUs * 8) blocks = kCUs * 8;
+  if (bwd)
+    hipLaunchKernelGGL((fm_bwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, emb, dout,
+                       static_cast<long long>(B), F, D, mode, out);
+  else
+    hipLaunchKernelGGL((fm_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, emb,
+                       static_cast<long long>(B), F, D, mode, out);
+  return check_launch("fm kernel");
+}
+
+template <bool VEC>
+static int dispatch_fm(bool bwd, const float* emb, const float* dout, int64_t B, int F, int D, int mode, float* out,
+                       hipStream_t s) {
+  const int units = VEC ? D / 4 : D;
+  switch (pow2_ceil(units)) {
+    case 1: return launch_fm<1, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    case 2: return launch_fm<2, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    case 4: return launch_fm<4, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    case 8: return launch_fm<8, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    case 16: return launch_fm<16, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    case 32: return launch_fm<32, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    case 64: return launch_fm<64, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    case 128: return launch_fm<64, 2, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    case 256: return launch_fm<64, 4, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    default: return fail(RBX_ERR_UNSUPPORTED, "interaction dim too large");
+  }
+}
+
+static int run_interaction(bool bwd, const float* emb, const float* dout, int64_t B, int F, int D, int mode, float* out,
+                           void* stream) {
+  if (emb == nullptr || out == nullptr || (bwd && dout == nullptr)) return fail(RBX_ERR_INVALID, "NULL tensor");
+  if (B < 0 || F <= 0 || D <= 0) return fail(RBX_ERR_INVALID, "bad shape B=%lld F=%d D=%d", (long long)B, F, D);
+  if (mode < 0 || mode > 3) return fail(RBX_ERR_INVALID, "InnerProductInteraction output mode %d is not supported", mode);
+  if (B == 0) return RBX_OK;
+  hipStream_t s = as_stream(stream);
+  if (mode <= 1) {
+    const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(emb) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    return vec ? dispatch_fm<true>(bwd, emb, dout, B, F, D, mode, out, s)
+               : dispatch_fm<false>(bwd, emb, dout, B, F, D, mode, out, s);
+  }
+  const size_t lds = static_cast<size_t>(F) * D * sizeof(float);
+  if (lds > 64 * 1024) return fail(RBX_ERR_UNSUPPORTED, "F*D=%d too large for the pairwise modes", F * D);
+  if (F < 2) return RBX_OK;
+  if (bwd)
+    hipLaunchKernelGGL(pair_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), lds, s, emb, dout, F, D, mode, out);
+  else
+    hipLaunchKernelGGL(pair_fwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), lds, s, emb, F, D, mode, out);
+  return check_launch("pair kernel");
+}
+
+}  // namespace rbx
+
+extern "C" int rbx_interaction_fwd(const float* d_emb, int64_t batch, int32_t n_fields, int32_t dim, int32_t mode,
+                                   float* d_out, void* stream) {
+  return rbx::run_interaction(false, d_emb, nullptr, batch, n_fields, dim, mode, d_out, stream);
+}
+
+extern "C" int rbx_interaction_bwd(const float* d_emb, const float* d_dout, int64_t batch, int32_t n_fields,
+                                   int32_t dim, int32_t mode, float* d_demb, void* stream) {
+  return rbx::run_interaction(true, d_emb, d_dout, batch, n_fields, dim, mode, d_demb, stream);
+}

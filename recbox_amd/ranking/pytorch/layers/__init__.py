@@ -1,0 +1,4 @@
+from .pooling import *
+from .embeddings import *
+from .interactions import *
+from .blocks import *
