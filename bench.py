@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", choices=["fused", "layers"], default="fused",
+                    help="fused: FM model body in rbx_fm_fwd/bwd; layers: drop-in layers composed as the reference does")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,7 +141,7 @@ def main():
     from recbox_amd.ranking.pytorch.models import FM
     ops.config.check_ids = False              # no per-call host sync inside the timed region
     fmw = CriteoFeatureMap(args.dim)
-    model = FM(fmw.fm, args.dim).to(dev)
+    model = FM(fmw.fm, args.dim, fused=(args.path == "fused")).to(dev)
     init_weights(model)
     B = args.batch
     batch = synthetic_batch(B, 1 + rank, args.dist, dev)
@@ -158,8 +160,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # dominant kernel: the [B, 39, 16] gather (embed_fwd over all fields at dim 16)
-    timer = ops.KernelTimer(lambda m: m[0] == "embed_fwd" and m[2] == n_fields * args.dim)
+    # dominant kernel = the embedding gather: fm_fused_fwd (fused path) or the [B, 39, 16] embed_fwd (layer path)
+    if args.path == "fused":
+        timer = ops.KernelTimer(lambda m: m[0] == "fm_fwd")
+    else:
+        timer = ops.KernelTimer(lambda m: m[0] == "embed_fwd" and m[2] == n_fields * args.dim)
     ops.kernel_timer = timer
     if world > 1:
         torch.distributed.barrier()
@@ -182,20 +187,26 @@ def main():
         # algorithmic bytes of the gather per sample: 26 rows x 64 B
         # + 26 ids x 8 B (float64 columns) + 13 dense values x 8 B + the [39,16] fp32 slot written
         n_sparse = len(CRITEO_VOCABS)
-        per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 8 + n_fields * args.dim * 4
+        if args.path == "fused":
+            # rows + float64 ids + float64 dense values + LR rows + logit + S kept for backward
+            per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 8 + n_sparse * 4 + 4 + args.dim * 4
+            kname = "fm_fused_fwd_kernel<%d,1,true>" % (args.dim // 4)
+        else:
+            per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 8 + n_fields * args.dim * 4
+            kname = "embed_fwd_kernel<%d,1,true>" % (args.dim // 4)
         kms = timer.mean_ms()
         roof = None
         if kms:
             achieved = per_sample * B / (kms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": None, "kernel": "embed_fwd_kernel<4,1,true>",
+                    "frac": achieved / 8000.0, "traffic": None, "kernel": kname,
                     "kernel_ms": kms, "algorithmic_bytes_per_launch": per_sample * B}
         out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
                "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
-                                      "%s ids, dense-grad autograd contract, no optimiser step" % (args.dim, B, args.dist),
+                                      "%s ids, %s path, dense-grad autograd contract, no optimiser step" % (args.dim, B, args.dist, args.path),
                           "global_batch": B * world, "parallelism": "dp%d" % world},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

@@ -129,6 +129,27 @@ int rbx_interaction_fwd(const float* d_emb, int64_t batch, int32_t n_fields, int
 int rbx_interaction_bwd(const float* d_emb, const float* d_dout, int64_t batch, int32_t n_fields,
                         int32_t dim, int32_t mode, float* d_demb, void* stream);
 
+/* ---- fused FM model body: gather + LR + second-order interaction, [B,F,D] never stored ----
+ * Replaces the op sequence feature_embedding.py:188-214 -> logistic_regression.py:30-35 ->
+ * inner_product.py:41-48 -> factorization_machine.py:30-34 (forward and autograd backward).
+ * emb[i] (dim D, all equal) and lr[i] (dim 1) describe the SAME feature i (same ids); only
+ * one-id-per-sample categorical and numeric features can be fused.  Either array may be NULL
+ * (lr == NULL: interaction only; emb == NULL: LogisticRegression only).
+ *   d_logit[B] = sum_f lr_f + bias + 0.5 * sum_d[(sum_f e_fd)^2 - sum_f e_fd^2]
+ *   d_sum[B,D] = sum_f e_f   (kept for the backward; may be NULL for inference)
+ * Backward: row r of table f gets  dW[r] += sum_b g_b S_b - w_r * sum_b g_b  and
+ * dW_lr[r] += sum_b g_b  over the samples b that looked r up (sorted, segmented,
+ * deterministic); numeric weights and the bias are batch reductions.  Grads accumulate
+ * into emb[i].grad / lr[i].grad (dense) and d_dbias[1]. */
+int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+               const float* d_lr_bias, float* d_logit, float* d_sum, int32_t* d_status, void* stream);
+size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch);
+int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+                void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream);
+int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+               const float* d_dlogit, const float* d_sum, float* d_dbias, void* d_workspace,
+               size_t workspace_bytes, void* stream);
+
 /* ---- pooling of a materialised [B,L,D] tensor (standalone pooling modules) ------
  * core/pytorch/layers/sequence.py:4-20, ranking/pytorch/layers/pooling.py:22-40,
  * third_party/rechub/basic/layers.py:176-230.

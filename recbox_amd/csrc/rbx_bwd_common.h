@@ -1,0 +1,140 @@
+// rbx_bwd_common.h -- plan, sort entry and register-fragment helpers shared by the
+// generic embedding backward (rbx_embed_bwd.hip) and the fused FM backward
+// (rbx_fm_fused.hip).
+#pragma once
+#include "rbx_internal.h"
+
+namespace rbx {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 8;                              // per thread
+constexpr int kSortTile = kSortThreads * kSortItems;       // 2048 pairs per workgroup
+constexpr int kRadix = 256;
+constexpr int kChunk = 32;                                 // sorted pairs per lane group in the reduce
+constexpr unsigned kLocalBits = 26;                        // val = slot << 26 | (b*L + l)
+constexpr unsigned kLocalMask = (1u << kLocalBits) - 1u;
+constexpr int kNumSamples = 256;                            // samples per workgroup in the numeric-feature reduction
+
+struct KeyField {            // 48 B
+  const void* ids;
+  long long stride_b;
+  int stride_l;
+  int vocab;
+  int mask_id;
+  int pad_id;
+  unsigned row_base;
+  unsigned lk_off;           // first lookup index of this field
+  short seq_len;
+  unsigned char dtype, pool;
+  int reserved;
+};
+struct KeyPack { KeyField f[RBX_MAX_FIELDS]; };
+
+struct RedField {            // 40 B
+  float* grad;
+  float* grad2;              // fused FM: the dim-1 LR table's grad (same ids)
+  const float* table;        // fused FM: the embedding table (dW = A - cnt * w)
+  unsigned row_base;
+  int out_off;
+  short dim;
+  short seq_len;
+  unsigned char pool, slot;
+  short reserved;
+};
+struct RedPack { RedField f[RBX_MAX_FIELDS]; };
+
+struct NumField {            // numeric features: grad[d] += sum_b x_b * dY[b, off+d]
+  const void* ids;
+  float* grad;
+  long long stride_b;
+  int out_off;
+  short dim;
+  unsigned char dtype, reserved;
+};
+struct NumPack { NumField f[RBX_MAX_FIELDS]; };
+
+// ---- host-side plan: everything derived from the descriptor array -------------
+struct BwdPlan {
+  int n_cat = 0, n_num = 0;
+  KeyPack keys;
+  RedPack red;
+  NumPack num;
+  unsigned n_lookups = 0;      // pairs to sort
+  unsigned total_rows = 0;     // sentinel key
+  int passes = 0;
+  int max_dim = 1;
+  bool vec = true;
+  // workspace layout (byte offsets)
+  size_t off_keys[2], off_vals[2], off_hist, off_ssum, off_head, off_tail, off_flags, off_fin, off_num, bytes;
+  unsigned n_tiles = 0, n_chunks = 0, num_blocks = 0;
+  int sum_stride = 1;          // floats per chunk summary (max_dim + extra)
+};
+
+
+// Build the plan for `fields` (definition in rbx_embed_bwd.hip).  `extra_dim` floats are
+// reserved behind every chunk summary (the fused FM backward keeps sum(g) there).
+int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, int64_t stride_b, BwdPlan* p,
+              int extra_dim = 0);
+// build_keys + LSD radix passes; sorted pairs end up in key/val buffer (passes & 1).
+int run_sort(const BwdPlan& p, char* ws, int* d_status, hipStream_t s);
+
+// ---- segment reduce ------------------------------------------------------------------
+template <int G, int NV, bool VEC>
+struct Frag {
+  static constexpr int W = VEC ? 4 : 1;
+  float a[NV * W];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < NV * W; ++i) a[i] = 0.f;
+  }
+  __device__ __forceinline__ void fma_from(const float* row, int dim, int lane_g, float w) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = (lane_g + u * G) * W;
+      if (e < dim) {
+        if constexpr (VEC) {
+          const float4 t = *reinterpret_cast<const float4*>(row + e);
+          a[u * 4 + 0] += w * t.x; a[u * 4 + 1] += w * t.y; a[u * 4 + 2] += w * t.z; a[u * 4 + 3] += w * t.w;
+        } else {
+          a[u] += w * row[e];
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void add_from(const float* row, int dim, int lane_g) { fma_from(row, dim, lane_g, 1.0f); }
+  __device__ __forceinline__ void store(float* row, int dim, int lane_g) const {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = (lane_g + u * G) * W;
+      if (e < dim) {
+        if constexpr (VEC) {
+          *reinterpret_cast<float4*>(row + e) = make_float4(a[u * 4], a[u * 4 + 1], a[u * 4 + 2], a[u * 4 + 3]);
+        } else {
+          row[e] = a[u];
+        }
+      }
+    }
+  }
+  // row[e] += a  (each touched row is owned by exactly one lane group per call)
+  __device__ __forceinline__ void accumulate_into(float* row, int dim, int lane_g) const {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = (lane_g + u * G) * W;
+      if (e < dim) {
+        if constexpr (VEC) {
+          float4 t = *reinterpret_cast<float4*>(row + e);
+          t.x += a[u * 4]; t.y += a[u * 4 + 1]; t.z += a[u * 4 + 2]; t.w += a[u * 4 + 3];
+          *reinterpret_cast<float4*>(row + e) = t;
+        } else {
+          row[e] += a[u];
+        }
+      }
+    }
+  }
+};
+
+constexpr int kFlagFin = 1;    // chunk finalises a run that started in an earlier chunk
+constexpr int kFlagPass = 2;   // whole chunk is the middle of one run
+
+
+}  // namespace rbx

@@ -19,73 +19,14 @@
 // No float atomics anywhere: run-to-run bit-identical gradients.
 // All phases stream their inputs once; the random traffic is the dY row gather
 // (L2/MALL resident for [B,F,D] <= 256 MiB) and one RMW per touched row.
-#include "rbx_internal.h"
+#include "rbx_segreduce.h"
 
 namespace rbx {
 
-constexpr int kSortThreads = 256;
-constexpr int kSortItems = 8;                              // per thread
-constexpr int kSortTile = kSortThreads * kSortItems;       // 2048 pairs per workgroup
-constexpr int kRadix = 256;
-constexpr int kChunk = 64;                                 // sorted pairs per lane group in the reduce
-constexpr unsigned kLocalBits = 26;                        // val = slot << 26 | (b*L + l)
-constexpr unsigned kLocalMask = (1u << kLocalBits) - 1u;
-
-struct KeyField {            // 48 B
-  const void* ids;
-  long long stride_b;
-  int stride_l;
-  int vocab;
-  int mask_id;
-  int pad_id;
-  unsigned row_base;
-  unsigned lk_off;           // first lookup index of this field
-  short seq_len;
-  unsigned char dtype, pool;
-  int reserved;
-};
-struct KeyPack { KeyField f[RBX_MAX_FIELDS]; };
-
-struct RedField {            // 24 B
-  float* grad;
-  unsigned row_base;
-  int out_off;
-  short dim;
-  short seq_len;
-  unsigned char pool, slot;
-  short reserved;
-};
-struct RedPack { RedField f[RBX_MAX_FIELDS]; };
-
-struct NumField {            // numeric features: grad[d] += sum_b x_b * dY[b, off+d]
-  const void* ids;
-  float* grad;
-  long long stride_b;
-  int out_off;
-  short dim;
-  unsigned char dtype, reserved;
-};
-struct NumPack { NumField f[RBX_MAX_FIELDS]; };
-
-// ---- host-side plan: everything derived from the descriptor array -------------
-struct BwdPlan {
-  int n_cat = 0, n_num = 0;
-  KeyPack keys;
-  RedPack red;
-  NumPack num;
-  unsigned n_lookups = 0;      // pairs to sort
-  unsigned total_rows = 0;     // sentinel key
-  int passes = 0;
-  int max_dim = 1;
-  bool vec = true;
-  // workspace layout (byte offsets)
-  size_t off_keys[2], off_vals[2], off_hist, off_head, off_tail, off_flags, off_num, bytes;
-  unsigned n_tiles = 0, n_chunks = 0, num_blocks = 0;
-};
-
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, int64_t stride_b, BwdPlan* p) {
+int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, int64_t stride_b, BwdPlan* p,
+              int extra_dim) {
   if (fields == nullptr || n <= 0 || n > RBX_MAX_FIELDS) return fail(RBX_ERR_INVALID, "bad field array");
   FieldPack tmp;
   int rc = pack_fields(fields, n, B, true, &tmp);
@@ -143,6 +84,8 @@ static int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* d
     kf.reserved = 0;
     RedField& rf = p->red.f[c];
     rf.grad = f.grad;
+    rf.grad2 = nullptr;
+    rf.table = f.table;
     rf.row_base = seen_base[hit];
     rf.out_off = static_cast<int>(f.out_off);
     rf.dim = static_cast<short>(f.dim);
@@ -161,7 +104,7 @@ static int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* d
   p->passes = (bits + 7) / 8;
   p->n_tiles = (p->n_lookups + kSortTile - 1) / kSortTile;
   p->n_chunks = (p->n_lookups + kChunk - 1) / kChunk;
-  p->num_blocks = static_cast<unsigned>((B + 1023) / 1024);
+  p->num_blocks = static_cast<unsigned>((B + kNumSamples - 1) / kNumSamples);
   size_t o = 0;
   const size_t nl = align_up(static_cast<size_t>(p->n_lookups) * 4, 256);
   p->off_keys[0] = o; o += nl;
@@ -169,9 +112,12 @@ static int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* d
   p->off_vals[0] = o; o += nl;
   p->off_vals[1] = o; o += nl;
   p->off_hist = o; o += align_up(static_cast<size_t>(p->n_tiles) * kRadix * 4 + 4, 256);
-  p->off_head = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->max_dim * 4, 256);
-  p->off_tail = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->max_dim * 4, 256);
+  p->off_ssum = o; o += align_up((static_cast<size_t>(p->n_tiles) * kRadix / 4096 + 2) * 4, 256);
+  p->sum_stride = p->max_dim + extra_dim;
+  p->off_head = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
+  p->off_tail = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
   p->off_flags = o; o += align_up(static_cast<size_t>(p->n_chunks) * 4, 256);
+  p->off_fin = o; o += align_up((static_cast<size_t>(p->n_chunks) + 1) * 4, 256);   // count, then chunk ids
   p->off_num = o; o += align_up(static_cast<size_t>(p->n_num) * p->num_blocks * p->max_dim * 4, 256);
   p->bytes = o + 256;
   return RBX_OK;
@@ -232,37 +178,67 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const unsigned
   hist[threadIdx.x * n_tiles + blockIdx.x] = cnt[threadIdx.x];   // digit-major for the scan
 }
 
-// ---- exclusive scan of hist[256 * n_tiles] by one workgroup ------------------------
-__global__ __launch_bounds__(1024) void radix_scan_kernel(unsigned* __restrict__ hist, const unsigned len) {
-  __shared__ unsigned wave_tot[16];
-  __shared__ unsigned carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
+// ---- exclusive scan of hist[256 * n_tiles], two levels -------------------------------
+// level 1: every workgroup scans its own 4096-entry slice in place and emits the slice
+// total; level 2: one workgroup scans the slice totals; the scatter kernel adds the
+// slice prefix when it picks up its 256 (digit, tile) offsets.
+constexpr int kScanSlice = 4096;
+
+__device__ __forceinline__ unsigned block_scan_1024x4(unsigned (&v)[4], unsigned* wave_tot, unsigned* total) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (unsigned base = 0; base < len; base += 1024 * 4) {
+  const unsigned mine = v[0] + v[1] + v[2] + v[3];
+  unsigned inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_tot[wid] = inc;
+  __syncthreads();
+  unsigned wbase = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const unsigned t = wave_tot[w];
+    if (w < wid) wbase += t;
+    all += t;
+  }
+  *total = all;
+  return wbase + inc - mine;      // exclusive prefix of this thread's first element
+}
+
+__global__ __launch_bounds__(1024) void radix_scan_local_kernel(unsigned* __restrict__ hist, const unsigned len,
+                                                                unsigned* __restrict__ slice_sum) {
+  __shared__ unsigned wave_tot[16];
+  const unsigned i0 = blockIdx.x * kScanSlice + threadIdx.x * 4;
+  unsigned v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (i0 + k < len) ? hist[i0 + k] : 0u;
+  unsigned total;
+  unsigned run = block_scan_1024x4(v, wave_tot, &total);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i0 + k < len) hist[i0 + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 0) slice_sum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void radix_scan_sums_kernel(unsigned* __restrict__ sums, const unsigned len) {
+  __shared__ unsigned wave_tot[16];
+  unsigned carry = 0;
+  for (unsigned base = 0; base < len; base += kScanSlice) {
     const unsigned i0 = base + threadIdx.x * 4;
     unsigned v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < len) ? hist[i0 + k] : 0u;
-    const unsigned mine = v[0] + v[1] + v[2] + v[3];
-    unsigned inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wave_tot[wid] = inc;
-    __syncthreads();
-    unsigned wbase = 0;
-    for (int w = 0; w < wid; ++w) wbase += wave_tot[w];
-    unsigned run = carry + wbase + inc - mine;
+    for (int k = 0; k < 4; ++k) v[k] = (i0 + k < len) ? sums[i0 + k] : 0u;
+    unsigned total;
+    unsigned run = carry + block_scan_1024x4(v, wave_tot, &total);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (i0 + k < len) hist[i0 + k] = run;
+      if (i0 + k < len) sums[i0 + k] = run;
       run += v[k];
     }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = run;
+    carry += total;
     __syncthreads();
   }
 }
@@ -275,6 +251,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
                                                                      unsigned* __restrict__ keys_out,
                                                                      unsigned* __restrict__ vals_out, const unsigned n,
                                                                      const int shift, const unsigned* __restrict__ hist,
+                                                                     const unsigned* __restrict__ slice_sum,
                                                                      const unsigned n_tiles) {
   constexpr int kWaves = kSortThreads / 64;
   constexpr int kPerWave = kSortTile / kWaves;       // 512
@@ -287,7 +264,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned tile0 = blockIdx.x * kSortTile;
   for (int i = threadIdx.x; i < kWaves * kRadix; i += kSortThreads) (&wcnt[0][0])[i] = 0;
-  gbase[threadIdx.x] = hist[threadIdx.x * n_tiles + blockIdx.x];
+  {
+    const unsigned hi = threadIdx.x * n_tiles + blockIdx.x;
+    gbase[threadIdx.x] = hist[hi] + slice_sum[hi / kScanSlice];
+  }
   __syncthreads();
 
   unsigned k[kSteps], v[kSteps];
@@ -367,194 +347,38 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
   }
 }
 
-// ---- segment reduce ------------------------------------------------------------------
-template <int G, int NV, bool VEC>
-struct Frag {
-  static constexpr int W = VEC ? 4 : 1;
-  float a[NV * W];
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int i = 0; i < NV * W; ++i) a[i] = 0.f;
+// ---- generic policy: a lookup contributes w * dY[b, slot] (the kernels are in rbx_segreduce.h) ----
+struct GenericPolicy {
+  struct Args {
+    const float* dout;
+    long long stride_b;
+    const float* row_scale;
+    long long B;
+  };
+  template <class F>
+  static __device__ __forceinline__ void contribute(const Args& a, const RedField& fd, unsigned local, int lane_g,
+                                                    F& frag, float& cnt) {
+    const unsigned L = static_cast<unsigned>(fd.seq_len);
+    const unsigned b = local / L;
+    const unsigned l = local - b * L;
+    const float* src = a.dout + static_cast<long long>(b) * a.stride_b + fd.out_off +
+                       (fd.pool == RBX_POOL_CONCAT ? static_cast<long long>(l) * fd.dim : 0ll);
+    float w = 1.0f;
+    if (fd.pool == RBX_POOL_MEAN_VALUE || fd.pool == RBX_POOL_MEAN_ID)
+      w = a.row_scale[static_cast<long long>(fd.slot) * a.B + b];
+    frag.fma_from(src, fd.dim, lane_g, w);
+    (void)cnt;
   }
-  __device__ __forceinline__ void fma_from(const float* row, int dim, int lane_g, float w) {
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int e = (lane_g + u * G) * W;
-      if (e < dim) {
-        if constexpr (VEC) {
-          const float4 t = *reinterpret_cast<const float4*>(row + e);
-          a[u * 4 + 0] += w * t.x; a[u * 4 + 1] += w * t.y; a[u * 4 + 2] += w * t.z; a[u * 4 + 3] += w * t.w;
-        } else {
-          a[u] += w * row[e];
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void add_from(const float* row, int dim, int lane_g) { fma_from(row, dim, lane_g, 1.0f); }
-  __device__ __forceinline__ void store(float* row, int dim, int lane_g) const {
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int e = (lane_g + u * G) * W;
-      if (e < dim) {
-        if constexpr (VEC) {
-          *reinterpret_cast<float4*>(row + e) = make_float4(a[u * 4], a[u * 4 + 1], a[u * 4 + 2], a[u * 4 + 3]);
-        } else {
-          row[e] = a[u];
-        }
-      }
-    }
-  }
-  // row[e] += a  (each touched row is owned by exactly one lane group per call)
-  __device__ __forceinline__ void accumulate_into(float* row, int dim, int lane_g) const {
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int e = (lane_g + u * G) * W;
-      if (e < dim) {
-        if constexpr (VEC) {
-          float4 t = *reinterpret_cast<float4*>(row + e);
-          t.x += a[u * 4]; t.y += a[u * 4 + 1]; t.z += a[u * 4 + 2]; t.w += a[u * 4 + 3];
-          *reinterpret_cast<float4*>(row + e) = t;
-        } else {
-          row[e] += a[u];
-        }
-      }
-    }
+  template <class F>
+  static __device__ __forceinline__ void flush(const Args&, const RedField& fd, unsigned row, const F& acc, float,
+                                               int lane_g) {
+    acc.accumulate_into(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);
   }
 };
 
-constexpr int kFlagFin = 1;    // chunk finalises a run that started in an earlier chunk
-constexpr int kFlagPass = 2;   // whole chunk is the middle of one run
-
-template <int G, int NV, bool VEC>
-__global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, const int n_cat, const long long B,
-                                                             const unsigned* __restrict__ keys,
-                                                             const unsigned* __restrict__ vals, const unsigned n,
-                                                             const unsigned sentinel, const float* __restrict__ dout,
-                                                             const long long stride_b,
-                                                             const float* __restrict__ row_scale,
-                                                             float* __restrict__ head, float* __restrict__ tail,
-                                                             int* __restrict__ flags, const int max_dim,
-                                                             const unsigned n_chunks) {
-  __shared__ RedField sf[RBX_MAX_FIELDS];
-  {
-    const int words = n_cat * static_cast<int>(sizeof(RedField) / 4);
-    const int* src = reinterpret_cast<const int*>(&P);
-    int* dst = reinterpret_cast<int*>(sf);
-    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
-  }
-  __syncthreads();
-  using F = Frag<G, NV, VEC>;
-  const int lane_g = threadIdx.x % G;
-  const unsigned c = blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
-  if (c >= n_chunks) return;
-  const unsigned s = c * kChunk;
-  const unsigned e = (s + kChunk < n) ? s + kChunk : n;
-  const unsigned key_before = (s > 0) ? keys[s - 1] : sentinel;
-  const unsigned key_after = (e < n) ? keys[e] : sentinel;
-  unsigned cur = keys[s];
-  const bool open_in = (s > 0) && (cur == key_before) && (cur != sentinel);
-  bool seen_boundary = false;
-  unsigned cur_val = vals[s];
-  F acc;
-  acc.zero();
-  constexpr int U = 4;
-  for (unsigned i0 = s; i0 < e; i0 += U) {
-    unsigned kk[U], vv[U];
-    const float* src[U];
-    float w[U];
-    int dims[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned i = i0 + u;
-      const bool ok = i < e;
-      kk[u] = ok ? keys[i] : sentinel;
-      vv[u] = ok ? vals[i] : 0u;
-      const RedField& fd = sf[vv[u] >> kLocalBits];
-      const unsigned local = vv[u] & kLocalMask;
-      const unsigned L = static_cast<unsigned>(fd.seq_len);
-      const unsigned b = local / L;
-      const unsigned l = local - b * L;
-      dims[u] = fd.dim;
-      src[u] = dout + static_cast<long long>(b) * stride_b + fd.out_off +
-               (fd.pool == RBX_POOL_CONCAT ? static_cast<long long>(l) * fd.dim : 0ll);
-      w[u] = 1.0f;
-      if (ok && kk[u] != sentinel && (fd.pool == RBX_POOL_MEAN_VALUE || fd.pool == RBX_POOL_MEAN_ID))
-        w[u] = row_scale[static_cast<long long>(fd.slot) * B + b];
-    }
-    F rows[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      rows[u].zero();
-      if (kk[u] != sentinel) rows[u].fma_from(src[u], dims[u], lane_g, w[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (i0 + u >= e) break;
-      if (kk[u] != cur) {                               // run boundary
-        if (cur != sentinel) {
-          const RedField& fd = sf[cur_val >> kLocalBits];
-          if (!seen_boundary && open_in) {
-            acc.store(head + static_cast<size_t>(c) * max_dim, fd.dim, lane_g);
-          } else {
-            acc.accumulate_into(fd.grad + static_cast<size_t>(cur - fd.row_base) * fd.dim, fd.dim, lane_g);
-          }
-        }
-        seen_boundary = true;
-        acc.zero();
-        cur = kk[u];
-        cur_val = vv[u];
-      }
-#pragma unroll
-      for (int q = 0; q < NV * F::W; ++q) acc.a[q] += rows[u].a[q];
-    }
-  }
-  int flag = 0;
-  if (cur != sentinel) {
-    const RedField& fd = sf[cur_val >> kLocalBits];
-    const bool open_out = (e < n) && (key_after == cur);
-    const bool is_head = !seen_boundary && open_in;
-    if (open_out) {
-      acc.store(tail + static_cast<size_t>(c) * max_dim, fd.dim, lane_g);
-      if (is_head) flag |= kFlagPass;
-    } else if (is_head) {
-      acc.store(head + static_cast<size_t>(c) * max_dim, fd.dim, lane_g);
-      flag |= kFlagFin;
-    } else {
-      acc.accumulate_into(fd.grad + static_cast<size_t>(cur - fd.row_base) * fd.dim, fd.dim, lane_g);
-    }
-  }
-  if (seen_boundary && open_in) flag |= kFlagFin;
-  if (lane_g == 0) flags[c] = flag;
-}
-
-template <int G, int NV, bool VEC>
-__global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, const int n_cat,
-                                                            const unsigned* __restrict__ keys,
-                                                            const unsigned* __restrict__ vals,
-                                                            const float* __restrict__ head,
-                                                            const float* __restrict__ tail,
-                                                            const int* __restrict__ flags, const int max_dim,
-                                                            const unsigned n_chunks) {
-  using F = Frag<G, NV, VEC>;
-  const int lane_g = threadIdx.x % G;
-  const unsigned c = blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
-  if (c >= n_chunks) return;
-  if (!(flags[c] & kFlagFin)) return;
-  const unsigned s = c * kChunk;
-  const unsigned key = keys[s];
-  const RedField fd = P.f[vals[s] >> kLocalBits];
-  F acc;
-  acc.zero();
-  acc.add_from(head + static_cast<size_t>(c) * max_dim, fd.dim, lane_g);
-  for (unsigned j = c; j-- > 0;) {
-    acc.add_from(tail + static_cast<size_t>(j) * max_dim, fd.dim, lane_g);
-    if (!(flags[j] & kFlagPass)) break;
-  }
-  acc.accumulate_into(fd.grad + static_cast<size_t>(key - fd.row_base) * fd.dim, fd.dim, lane_g);
-}
-
 // ---- numeric features: grad[d] += sum_b x_b * dY[b, off + d] -----------------------------
-// grid (num_blocks, n_num); block: 256 threads = 16 sample lanes x 16 dim lanes per step.
+// grid (num_blocks, n_num); a workgroup reduces kNumSamples samples of one feature:
+// 256 threads = 16 sample lanes x 16 dim lanes per step, LDS tree across sample lanes.
 __global__ __launch_bounds__(256) void numeric_partial_kernel(const NumPack P, const long long B,
                                                               const float* __restrict__ dout, const long long stride_b,
                                                               float* __restrict__ partial, const int max_dim,
@@ -562,8 +386,8 @@ __global__ __launch_bounds__(256) void numeric_partial_kernel(const NumPack P, c
   const NumField fd = P.f[blockIdx.y];
   const int dim = fd.dim;
   __shared__ float red[256];
-  const long long b0 = static_cast<long long>(blockIdx.x) * 1024;
-  const long long b1 = (b0 + 1024 < B) ? b0 + 1024 : B;
+  const long long b0 = static_cast<long long>(blockIdx.x) * kNumSamples;
+  const long long b1 = (b0 + kNumSamples < B) ? b0 + kNumSamples : B;
   for (int dbase = 0; dbase < dim; dbase += 16) {
     const int d = dbase + (threadIdx.x & 15);
     float acc = 0.f;
@@ -585,50 +409,17 @@ __global__ __launch_bounds__(256) void numeric_partial_kernel(const NumPack P, c
   }
 }
 
-__global__ void numeric_final_kernel(const NumPack P, const float* __restrict__ partial, const int max_dim,
-                                     const unsigned num_blocks) {
+// one wavefront per (feature, d): lanes stride over the block partials, fixed shuffle tree
+__global__ __launch_bounds__(64) void numeric_final_kernel(const NumPack P, const float* __restrict__ partial,
+                                                           const int max_dim, const unsigned num_blocks) {
   const NumField fd = P.f[blockIdx.x];
-  for (int d = threadIdx.x; d < fd.dim; d += blockDim.x) {
-    float t = 0.f;
-    for (unsigned k = 0; k < num_blocks; ++k) t += partial[(static_cast<size_t>(blockIdx.x) * num_blocks + k) * max_dim + d];
-    fd.grad[d] += t;
-  }
-}
-
-template <int G, int NV, bool VEC>
-static int launch_reduce(const BwdPlan& p, int64_t B, const unsigned* keys, const unsigned* vals, const float* dout,
-                         int64_t stride_b, const float* row_scale, char* ws, hipStream_t s) {
-  const int groups_per_block = 256 / G;
-  const unsigned blocks = (p.n_chunks + groups_per_block - 1) / groups_per_block;
-  float* head = reinterpret_cast<float*>(ws + p.off_head);
-  float* tail = reinterpret_cast<float*>(ws + p.off_tail);
-  int* flags = reinterpret_cast<int*>(ws + p.off_flags);
-  hipLaunchKernelGGL((segment_reduce_kernel<G, NV, VEC>), dim3(blocks), dim3(256), 0, s, p.red, p.n_cat,
-                     static_cast<long long>(B), keys, vals, p.n_lookups, p.total_rows, dout,
-                     static_cast<long long>(stride_b), row_scale, head, tail, flags, p.max_dim, p.n_chunks);
-  int rc = check_launch("segment_reduce_kernel");
-  if (rc != RBX_OK) return rc;
-  hipLaunchKernelGGL((segment_fixup_kernel<G, NV, VEC>), dim3(blocks), dim3(256), 0, s, p.red, p.n_cat, keys, vals, head,
-                     tail, flags, p.max_dim, p.n_chunks);
-  return check_launch("segment_fixup_kernel");
-}
-
-template <bool VEC>
-static int dispatch_reduce(const BwdPlan& p, int64_t B, const unsigned* keys, const unsigned* vals, const float* dout,
-                           int64_t stride_b, const float* row_scale, char* ws, hipStream_t s) {
-  const int units = VEC ? p.max_dim / 4 : p.max_dim;
-  switch (pow2_ceil(units)) {
-    case 1: return launch_reduce<1, 1, VEC>(p, B, keys, vals, dout, stride_b, row_scale, ws, s);
-    case 2: return launch_reduce<2, 1, VEC>(p, B, keys, vals, dout, stride_b, row_scale, ws, s);
-    case 4: return launch_reduce<4, 1, VEC>(p, B, keys, vals, dout, stride_b, row_scale, ws, s);
-    case 8: return launch_reduce<8, 1, VEC>(p, B, keys, vals, dout, stride_b, row_scale, ws, s);
-    case 16: return launch_reduce<16, 1, VEC>(p, B, keys, vals, dout, stride_b, row_scale, ws, s);
-    case 32: return launch_reduce<32, 1, VEC>(p, B, keys, vals, dout, stride_b, row_scale, ws, s);
-    case 64: return launch_reduce<64, 1, VEC>(p, B, keys, vals, dout, stride_b, row_scale, ws, s);
-    case 128: return launch_reduce<64, 2, VEC>(p, B, keys, vals, dout, stride_b, row_scale, ws, s);
-    case 256: return launch_reduce<64, 4, VEC>(p, B, keys, vals, dout, stride_b, row_scale, ws, s);
-    default: return fail(RBX_ERR_UNSUPPORTED, "embedding dim too large for one lane group");
-  }
+  const int d = blockIdx.y;
+  if (d >= fd.dim) return;
+  float t = 0.f;
+  for (unsigned k = threadIdx.x; k < num_blocks; k += 64)
+    t += partial[(static_cast<size_t>(blockIdx.x) * num_blocks + k) * max_dim + d];
+  t = group_sum<64>(t);
+  if (threadIdx.x == 0) fd.grad[d] += t;
 }
 
 }  // namespace rbx
@@ -639,20 +430,14 @@ extern "C" size_t rbx_embed_bwd_workspace_size(const rbx_field_t* fields, int32_
   return p.bytes;
 }
 
-extern "C" int rbx_embed_sort(const rbx_field_t* fields, int32_t n_fields, int64_t batch, void* d_workspace,
-                              size_t workspace_bytes, int32_t* d_status, void* stream) {
-  using namespace rbx;
-  BwdPlan p;
-  int rc = make_plan(fields, n_fields, batch, nullptr, 0, &p);
-  if (rc != RBX_OK) return rc;
+namespace rbx {
+int run_sort(const BwdPlan& p, char* ws, int* d_status, hipStream_t s) {
   if (p.n_lookups == 0) return RBX_OK;
-  if (d_workspace == nullptr || workspace_bytes < p.bytes)
-    return fail(RBX_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, p.bytes);
-  char* ws = static_cast<char*>(d_workspace);
-  hipStream_t s = as_stream(stream);
   unsigned* keys[2] = {reinterpret_cast<unsigned*>(ws + p.off_keys[0]), reinterpret_cast<unsigned*>(ws + p.off_keys[1])};
   unsigned* vals[2] = {reinterpret_cast<unsigned*>(ws + p.off_vals[0]), reinterpret_cast<unsigned*>(ws + p.off_vals[1])};
   unsigned* hist = reinterpret_cast<unsigned*>(ws + p.off_hist);
+  unsigned* ssum = reinterpret_cast<unsigned*>(ws + p.off_ssum);
+  int rc;
   {
     unsigned blocks = (p.n_lookups + 255) / 256;
     if (blocks > static_cast<unsigned>(kCUs * 8)) blocks = kCUs * 8;
@@ -666,14 +451,30 @@ extern "C" int rbx_embed_sort(const rbx_field_t* fields, int32_t n_fields, int64
     const int shift = pass * 8;
     hipLaunchKernelGGL(radix_hist_kernel, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], p.n_lookups, shift, hist,
                        p.n_tiles);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, s, hist, p.n_tiles * kRadix);
+    const unsigned hist_len = p.n_tiles * kRadix;
+    const unsigned n_slices = (hist_len + kScanSlice - 1) / kScanSlice;
+    hipLaunchKernelGGL(radix_scan_local_kernel, dim3(n_slices), dim3(1024), 0, s, hist, hist_len, ssum);
+    hipLaunchKernelGGL(radix_scan_sums_kernel, dim3(1), dim3(1024), 0, s, ssum, n_slices);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], vals[cur],
-                       keys[cur ^ 1], vals[cur ^ 1], p.n_lookups, shift, hist, p.n_tiles);
+                       keys[cur ^ 1], vals[cur ^ 1], p.n_lookups, shift, hist, ssum, p.n_tiles);
     rc = check_launch("radix pass");
     if (rc != RBX_OK) return rc;
     cur ^= 1;
   }
-  return RBX_OK;   // sorted pairs live in buffer (passes & 1)
+  return RBX_OK;
+}
+}  // namespace rbx
+
+extern "C" int rbx_embed_sort(const rbx_field_t* fields, int32_t n_fields, int64_t batch, void* d_workspace,
+                              size_t workspace_bytes, int32_t* d_status, void* stream) {
+  using namespace rbx;
+  BwdPlan p;
+  int rc = make_plan(fields, n_fields, batch, nullptr, 0, &p);
+  if (rc != RBX_OK) return rc;
+  if (p.n_lookups == 0) return RBX_OK;
+  if (d_workspace == nullptr || workspace_bytes < p.bytes)
+    return fail(RBX_ERR_WORKSPACE, "workspace %zu B < required %zu B", workspace_bytes, p.bytes);
+  return run_sort(p, static_cast<char*>(d_workspace), d_status, as_stream(stream));
 }
 
 extern "C" int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch, const float* d_dout,
@@ -698,8 +499,10 @@ extern "C" int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_
     const int cur = p.passes & 1;
     const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);
     const unsigned* vals = reinterpret_cast<const unsigned*>(ws + p.off_vals[cur]);
-    rc = p.vec ? dispatch_reduce<true>(p, batch, keys, vals, d_dout, out_stride_b, d_row_scale, ws, s)
-               : dispatch_reduce<false>(p, batch, keys, vals, d_dout, out_stride_b, d_row_scale, ws, s);
+    const GenericPolicy::Args args = {d_dout, static_cast<long long>(out_stride_b), d_row_scale,
+                                      static_cast<long long>(batch)};
+    rc = p.vec ? dispatch_reduce<GenericPolicy, true>(p, args, keys, vals, ws, s)
+               : dispatch_reduce<GenericPolicy, false>(p, args, keys, vals, ws, s);
     if (rc != RBX_OK) return rc;
   }
   if (p.n_num > 0) {
@@ -707,7 +510,8 @@ extern "C" int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_
     hipLaunchKernelGGL(numeric_partial_kernel, dim3(p.num_blocks, p.n_num), dim3(256), 0, s, p.num,
                        static_cast<long long>(batch), d_dout, static_cast<long long>(out_stride_b), partial, p.max_dim,
                        p.num_blocks);
-    hipLaunchKernelGGL(numeric_final_kernel, dim3(p.n_num), dim3(64), 0, s, p.num, partial, p.max_dim, p.num_blocks);
+    hipLaunchKernelGGL(numeric_final_kernel, dim3(p.n_num, p.max_dim), dim3(64), 0, s, p.num, partial, p.max_dim,
+                       p.num_blocks);
     rc = check_launch("numeric grad kernels");
     if (rc != RBX_OK) return rc;
   }

@@ -270,8 +270,9 @@ extern "C" int rbx_embed_fwd(const rbx_field_t* fields, int32_t n_fields, int64_
                              int64_t out_stride_b, float* d_row_scale, int32_t* d_status, void* stream) {
   using namespace rbx;
   if (n_fields <= 0 || n_fields > RBX_MAX_FIELDS) return fail(RBX_ERR_INVALID, "n_fields=%d out of range", n_fields);
-  if (batch < 0 || d_out == nullptr) return fail(RBX_ERR_INVALID, "bad batch/out");
+  if (batch < 0) return fail(RBX_ERR_INVALID, "negative batch");
   if (batch == 0) return RBX_OK;
+  if (d_out == nullptr) return fail(RBX_ERR_INVALID, "d_out is NULL");
   // split into a float4 launch and a scalar launch (slot = position in the caller's array)
   rbx_field_t part[2][RBX_MAX_FIELDS];
   int slot[2][RBX_MAX_FIELDS];

@@ -1,0 +1,477 @@
+// rbx_fm_fused.hip -- K1+K4 fused: the whole FM model body (embedding gather,
+// first-order LR term, second-order interaction) in one forward kernel that never
+// materialises [B, F, D], and its backward fused into the sorted segmented
+// scatter-add (gfx950).
+//
+// Reference op sequence replaced (paths relative to /root/reference/recbox):
+//   feature_emb = FeatureEmbedding(X)            ranking/pytorch/layers/embeddings/feature_embedding.py:188-214
+//   lr_out = sum_f LR_f(X) + bias                ranking/pytorch/layers/blocks/logistic_regression.py:30-35
+//   fm_out = 0.5 sum_d[(sum_f e)^2 - sum_f e^2]  ranking/pytorch/layers/interactions/inner_product.py:41-48
+//   y = fm_out + lr_out                          ranking/pytorch/layers/blocks/factorization_machine.py:30-34
+// and the autograd backward of all of it.
+//
+// Forward.  A lane group of D/4 lanes owns one sample and walks the F features; each
+// lane keeps its float4 slice of S = sum_f e_f and Q = sum_f e_f^2 in registers, so
+// the only cross-lane traffic is the final sum over d.  Feature descriptors are
+// wave-uniform (scalar loads from the kernarg segment); features are processed 8 at a
+// time: 8 id loads, then 8 independent row loads in flight per lane.  HBM traffic is
+// the table rows + ids + 4 B/sample of logit + D*4 B/sample of S (kept for backward).
+//
+// Backward.  dL/de_f[b] = g_b (S_b - e_f[b]) and e_f[b] is the ROW w_r itself, so for a
+// table row r hit by samples b_1..b_k:
+//     dW[r]  = sum_j g_bj S_bj  -  w_r * sum_j g_bj          dW_lr[r] = sum_j g_bj
+// The sorted (row, sample) pairs drive a segmented reduction whose per-lookup inputs are
+// g[b] (4 B) and S[b] (D*4 B) -- 4.3 MB at B=65 536, D=16, L2-resident -- instead of a
+// 163 MB dE tensor.  Numeric features x_f * w_f reduce over the batch:
+//     dw_f = sum_b g x S_b - w_f sum_b g x^2,   dw_lr_f = sum_b g x,   dbias = sum_b g.
+#include "rbx_segreduce.h"
+
+namespace rbx {
+
+struct FmField {            // 40 B
+  const void* ids;
+  const float* emb;         // [V, D] table or numeric weight [D]; NULL when there is no second-order part
+  const float* lr;          // [V] (dim-1 table) or numeric weight [1]; NULL when there is no first-order part
+  long long stride_b;
+  int vocab;
+  unsigned char dtype, kind, r0, r1;
+};
+struct FmPack { FmField f[RBX_MAX_FIELDS]; };
+
+template <int G, int NV, bool VEC>
+__global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const int F, const long long B, const int D,
+                                                           const bool has_emb, const bool has_lr,
+                                                           const float* __restrict__ bias,
+                                                           float* __restrict__ logit, float* __restrict__ ssum,
+                                                           int* __restrict__ status) {
+  constexpr int W = VEC ? 4 : 1;
+  constexpr int NA = NV * W;
+  constexpr int U = 8;
+  const int lane_g = threadIdx.x % G;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
+  for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
+    float s[NA], q[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) s[i] = q[i] = 0.f;
+    float lr = 0.f;
+    for (int f0 = 0; f0 < F; f0 += U) {
+      long long id[U];
+      float x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        id[u] = 0;
+        x[u] = 1.f;
+        if (f0 + u < F) {
+          const FmField& fd = P.f[f0 + u];
+          if (fd.kind == RBX_FIELD_CATEGORICAL) {
+            id[u] = load_id(fd.ids, b * fd.stride_b, fd.dtype);
+            if (id[u] < 0 || id[u] >= fd.vocab) {
+              if (status != nullptr) atomicOr(status, 1);
+              id[u] = 0;
+              x[u] = 0.f;                       // out-of-range lookups read as zero rows
+            }
+          } else {
+            x[u] = load_value(fd.ids, b * fd.stride_b, fd.dtype);
+          }
+        }
+      }
+      float e[U][NA];
+      float l1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) e[u][i] = 0.f;
+        l1[u] = 0.f;
+        if (f0 + u < F) {
+          const FmField& fd = P.f[f0 + u];
+          if (has_emb) {
+            const float* row = fd.emb + id[u] * D;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+              const int d = (lane_g + v * G) * W;
+              if (d < D) {
+                if constexpr (VEC) {
+                  const float4 t = *reinterpret_cast<const float4*>(row + d);
+                  e[u][v * 4] = t.x; e[u][v * 4 + 1] = t.y; e[u][v * 4 + 2] = t.z; e[u][v * 4 + 3] = t.w;
+                } else {
+                  e[u][v] = row[d];
+                }
+              }
+            }
+          }
+          if (has_lr && lane_g == ((f0 + u) % G)) l1[u] = fd.lr[id[u]];   // one lane per feature fetches the LR weight
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const float t = e[u][i] * x[u];
+          s[i] += t;
+          q[i] += t * t;
+        }
+        lr += l1[u] * x[u];
+      }
+    }
+    float fm = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) fm += (s[i] * s[i] - q[i]) * 0.5f;
+    float total = group_sum<G>(fm + lr);
+    if (lane_g == 0) logit[b] = total + (bias != nullptr ? bias[0] : 0.f);
+    if (has_emb && ssum != nullptr) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int d = (lane_g + v * G) * W;
+        if (d < D) {
+          if constexpr (VEC) {
+            *reinterpret_cast<float4*>(ssum + b * D + d) = make_float4(s[v * 4], s[v * 4 + 1], s[v * 4 + 2], s[v * 4 + 3]);
+          } else {
+            ssum[b * D + d] = s[v];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- backward policy: contribution g_b * S_b, cnt += g_b; flush dW = A - cnt*w ------------
+struct FmPolicy {
+  struct Args {
+    const float* g;        // [B] upstream grad of the logit
+    const float* ssum;     // [B, D]
+    int D;
+  };
+  template <class F>
+  static __device__ __forceinline__ void contribute(const Args& a, const RedField& fd, unsigned local, int lane_g,
+                                                    F& frag, float& cnt) {
+    const float g = a.g[local];
+    cnt = g;
+    if (a.ssum != nullptr) frag.fma_from(a.ssum + static_cast<size_t>(local) * a.D, fd.dim, lane_g, g);
+  }
+  template <class F>
+  static __device__ __forceinline__ void flush(const Args&, const RedField& fd, unsigned row, const F& acc, float cnt,
+                                               int lane_g) {
+    if (fd.grad != nullptr) {
+      F out = acc;
+      out.fma_from(fd.table + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g, -cnt);   // A - cnt * w_r
+      out.accumulate_into(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);
+    }
+    if (fd.grad2 != nullptr && lane_g == 0) fd.grad2[row] += cnt;
+  }
+};
+
+// ---- numeric features + bias: batch reductions ------------------------------------------------
+struct FmNumField {          // 48 B
+  const void* ids;
+  const float* w;            // emb weight [D] (or NULL)
+  float* gw;                 // grad of emb weight [D] (or NULL)
+  float* glr;                // grad of LR weight [1] (or NULL)
+  long long stride_b;
+  int dtype;
+  int reserved;
+};
+struct FmNumPack { FmNumField f[RBX_MAX_FIELDS]; };
+
+static int fm_num_samples(int D) { return D <= 64 ? 256 : 64; }   // samples staged per workgroup (LDS budget)
+
+// partial layout per (block, feature): [D] sum g x S_d | [1] sum g x^2 | [1] sum g x   -> D+2 floats;
+// feature index n_num holds sum g in slot 0 (bias).
+// A workgroup stages `ns` samples (S rows, g*x and x per numeric feature, g) in LDS, then
+// every thread owns one output and sums over the samples in a fixed order: this is a
+// [n_num, ns] x [ns, D] product per workgroup, deterministic and sync-free after staging.
+__global__ __launch_bounds__(256) void fm_numeric_partial_kernel(const FmNumPack P, const int n_num, const long long B,
+                                                                 const int D, const int ns,
+                                                                 const float* __restrict__ g,
+                                                                 const float* __restrict__ ssum,
+                                                                 float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  float* sS = lds;                          // [ns][D]
+  float* sgx = sS + ns * D;                 // [n_num][ns]
+  float* sx = sgx + n_num * ns;             // [n_num][ns]
+  float* sg = sx + n_num * ns;              // [ns]
+  const long long b0 = static_cast<long long>(blockIdx.x) * ns;
+  const int live = static_cast<int>((B - b0 < ns) ? (B - b0) : ns);
+  if (ssum != nullptr) {
+    for (int i = threadIdx.x; i < ns * D; i += blockDim.x) sS[i] = (i < live * D) ? ssum[b0 * D + i] : 0.f;
+  }
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) {
+    const float gb = (i < live) ? g[b0 + i] : 0.f;
+    sg[i] = gb;
+    for (int f = 0; f < n_num; ++f) {
+      const FmNumField& fd = P.f[f];
+      const float x = (i < live) ? load_value(fd.ids, (b0 + i) * fd.stride_b, fd.dtype) : 0.f;
+      sx[f * ns + i] = x;
+      sgx[f * ns + i] = gb * x;
+    }
+  }
+  __syncthreads();
+  const int stride = D + 2;
+  const int n_out = n_num * stride + 1;
+  float* out = partial + static_cast<size_t>(blockIdx.x) * (n_num + 1) * stride;
+  for (int o = threadIdx.x; o < n_out; o += blockDim.x) {
+    const int f = o / stride, slot = o - f * stride;
+    float t = 0.f;
+    if (f == n_num) {
+      for (int i = 0; i < ns; ++i) t += sg[i];
+    } else if (slot < D) {
+      if (ssum != nullptr)
+        for (int i = 0; i < ns; ++i) t += sgx[f * ns + i] * sS[i * D + slot];
+    } else if (slot == D) {
+      for (int i = 0; i < ns; ++i) t += sgx[f * ns + i] * sx[f * ns + i];
+    } else {
+      for (int i = 0; i < ns; ++i) t += sgx[f * ns + i];
+    }
+    out[o] = t;
+  }
+}
+
+__global__ __launch_bounds__(64) void fm_numeric_final_kernel(const FmNumPack P, const int n_num, const int D,
+                                                              const unsigned num_blocks,
+                                                              const float* __restrict__ partial,
+                                                              float* __restrict__ dbias) {
+  const int f = blockIdx.x;            // n_num + 1 features (last = bias)
+  const int stride = D + 2;
+  auto total = [&](int slot) -> float {
+    float t = 0.f;
+    for (unsigned k = threadIdx.x; k < num_blocks; k += 64)
+      t += partial[(static_cast<size_t>(k) * (n_num + 1) + f) * stride + slot];
+    return group_sum<64>(t);
+  };
+  if (f == n_num) {
+    const float tg = total(0);
+    if (dbias != nullptr && threadIdx.x == 0) dbias[0] += tg;
+    return;
+  }
+  const FmNumField& fd = P.f[f];
+  const float t2 = total(D), t1 = total(D + 1);
+  if (fd.glr != nullptr && threadIdx.x == 0) fd.glr[0] += t1;
+  if (fd.gw != nullptr) {
+    for (int d = 0; d < D; ++d) {
+      const float a = total(d);
+      if (threadIdx.x == 0) fd.gw[d] += a - fd.w[d] * t2;
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+struct FmHost {
+  int F = 0, D = 0;
+  bool has_emb = false, has_lr = false, vec = false;
+  FmPack pack;
+};
+
+static int fm_validate(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t B, FmHost* h) {
+  if (emb == nullptr && lr == nullptr) return fail(RBX_ERR_INVALID, "fm: both field arrays are NULL");
+  if (n <= 0 || n > RBX_MAX_FIELDS) return fail(RBX_ERR_INVALID, "fm: n_fields=%d not in [1,%d]", n, RBX_MAX_FIELDS);
+  h->F = n;
+  h->has_emb = emb != nullptr;
+  h->has_lr = lr != nullptr;
+  h->D = h->has_emb ? emb[0].dim : 1;
+  h->vec = h->has_emb && (h->D % 4 == 0);
+  const rbx_field_t* lead = h->has_emb ? emb : lr;
+  for (int i = 0; i < n; ++i) {
+    const rbx_field_t& a = lead[i];
+    if (a.kind != RBX_FIELD_CATEGORICAL && a.kind != RBX_FIELD_NUMERIC)
+      return fail(RBX_ERR_UNSUPPORTED, "fm: feature %d: only categorical / numeric features can be fused", i);
+    if (a.seq_len != 1 || a.pool != RBX_POOL_NONE)
+      return fail(RBX_ERR_UNSUPPORTED, "fm: feature %d: sequence features are not fused (use the layer path)", i);
+    if (a.ids == nullptr) return fail(RBX_ERR_INVALID, "fm: feature %d: ids is NULL", i);
+    if (a.ids_dtype < RBX_I32 || a.ids_dtype > RBX_F64) return fail(RBX_ERR_INVALID, "fm: feature %d: bad ids_dtype", i);
+    if (a.kind == RBX_FIELD_CATEGORICAL && (a.vocab <= 0 || a.vocab > INT_MAX))
+      return fail(RBX_ERR_INVALID, "fm: feature %d: bad vocab", i);
+    FmField& k = h->pack.f[i];
+    k.ids = a.ids;
+    k.stride_b = a.ids_stride_b;
+    k.vocab = static_cast<int>(a.vocab);
+    k.dtype = static_cast<unsigned char>(a.ids_dtype);
+    k.kind = static_cast<unsigned char>(a.kind);
+    k.r0 = k.r1 = 0;
+    k.emb = nullptr;
+    k.lr = nullptr;
+    if (h->has_emb) {
+      if (emb[i].dim != h->D) return fail(RBX_ERR_UNSUPPORTED, "fm: all embedding dims must be equal to fuse");
+      if (emb[i].table == nullptr) return fail(RBX_ERR_INVALID, "fm: feature %d: table is NULL", i);
+      if ((reinterpret_cast<uintptr_t>(emb[i].table) & 15) != 0) h->vec = false;
+      k.emb = emb[i].table;
+    }
+    if (h->has_lr) {
+      const rbx_field_t& l = lr[i];
+      if (l.dim != 1 || l.table == nullptr) return fail(RBX_ERR_INVALID, "fm: feature %d: LR tables must have dim 1", i);
+      if (h->has_emb && (l.ids != a.ids || l.kind != a.kind || l.vocab != a.vocab || l.ids_stride_b != a.ids_stride_b))
+        return fail(RBX_ERR_INVALID, "fm: feature %d: LR and embedding descriptors must describe the same ids", i);
+      k.lr = l.table;
+    }
+  }
+  (void)B;
+  return RBX_OK;
+}
+
+template <int G, int NV, bool VEC>
+static int launch_fm_fwd(const FmHost& h, int64_t B, const float* bias, float* logit, float* ssum, int* status,
+                         hipStream_t s) {
+  const int gpb = 256 / G;
+  long long blocks = (B + gpb - 1) / gpb;
+  if (blocks > kCUs * 16) blocks = kCUs * 16;
+  hipLaunchKernelGGL((fm_fused_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, h.pack,
+                     h.F, static_cast<long long>(B), h.D, h.has_emb, h.has_lr, bias, logit, ssum, status);
+  return check_launch("fm_fused_fwd_kernel");
+}
+
+template <bool VEC>
+static int dispatch_fm_fwd(const FmHost& h, int64_t B, const float* bias, float* logit, float* ssum, int* status,
+                           hipStream_t s) {
+  const int units = VEC ? h.D / 4 : h.D;
+  switch (pow2_ceil(units)) {
+    case 1: return launch_fm_fwd<1, 1, VEC>(h, B, bias, logit, ssum, status, s);
+    case 2: return launch_fm_fwd<2, 1, VEC>(h, B, bias, logit, ssum, status, s);
+    case 4: return launch_fm_fwd<4, 1, VEC>(h, B, bias, logit, ssum, status, s);
+    case 8: return launch_fm_fwd<8, 1, VEC>(h, B, bias, logit, ssum, status, s);
+    case 16: return launch_fm_fwd<16, 1, VEC>(h, B, bias, logit, ssum, status, s);
+    case 32: return launch_fm_fwd<32, 1, VEC>(h, B, bias, logit, ssum, status, s);
+    case 64: return launch_fm_fwd<64, 1, VEC>(h, B, bias, logit, ssum, status, s);
+    default: return fail(RBX_ERR_UNSUPPORTED, "fm: embedding dim %d too large to fuse", h.D);
+  }
+}
+
+// plan over the categorical features (keys from `lead`, grads from emb and lr)
+static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t B, BwdPlan* p, FmNumPack* np,
+                   int* n_num) {
+  rbx_field_t tmp[RBX_MAX_FIELDS];
+  const rbx_field_t* lead = (emb != nullptr) ? emb : lr;
+  *n_num = 0;
+  int n_cat = 0;
+  int cat_src[RBX_MAX_FIELDS];
+  for (int i = 0; i < n; ++i) {
+    if (lead[i].kind == RBX_FIELD_NUMERIC) {
+      FmNumField& f = np->f[(*n_num)++];
+      f.ids = lead[i].ids;
+      f.stride_b = lead[i].ids_stride_b;
+      f.dtype = lead[i].ids_dtype;
+      f.w = emb ? emb[i].table : nullptr;
+      f.gw = emb ? emb[i].grad : nullptr;
+      f.glr = lr ? lr[i].grad : nullptr;
+      f.reserved = 0;
+      continue;
+    }
+    tmp[n_cat] = lead[i];
+    // a feature whose tables are all frozen still needs no sort entry
+    float* g1 = emb ? emb[i].grad : nullptr;
+    float* g2 = lr ? lr[i].grad : nullptr;
+    if (g1 == nullptr && g2 == nullptr) continue;
+    tmp[n_cat].grad = g1 ? g1 : g2;          // make_plan skips fields without a grad
+    tmp[n_cat].out_off = 0;
+    cat_src[n_cat] = i;
+    ++n_cat;
+  }
+  if (n_cat == 0) {
+    p->n_lookups = 0;
+    p->bytes = 256;
+    const int D0 = emb ? emb[0].dim : 1;
+    p->num_blocks = static_cast<unsigned>((B + fm_num_samples(D0) - 1) / fm_num_samples(D0));
+    return RBX_OK;
+  }
+  const int D = emb ? emb[0].dim : 1;
+  int rc = make_plan(tmp, n_cat, B, nullptr, 0, p, /*extra_dim=*/4);
+  if (rc != RBX_OK) return rc;
+  if (p->n_cat != n_cat) return fail(RBX_ERR_INVALID, "fm: internal plan mismatch");
+  p->vec = emb != nullptr && (D % 4 == 0);
+  for (int c = 0; c < n_cat; ++c) {
+    const int i = cat_src[c];
+    RedField& rf = p->red.f[c];
+    rf.grad = emb ? emb[i].grad : nullptr;
+    rf.grad2 = lr ? lr[i].grad : nullptr;
+    rf.table = emb ? emb[i].table : nullptr;
+    rf.dim = static_cast<short>(D);
+    if (rf.grad != nullptr && (reinterpret_cast<uintptr_t>(rf.grad) & 15) != 0) p->vec = false;
+    if (rf.table != nullptr && (reinterpret_cast<uintptr_t>(rf.table) & 15) != 0) p->vec = false;
+  }
+  p->max_dim = D;
+  p->num_blocks = static_cast<unsigned>((B + fm_num_samples(D) - 1) / fm_num_samples(D));
+  return RBX_OK;
+}
+
+static size_t fm_num_bytes(const BwdPlan& p, int n_num, int D) {
+  return static_cast<size_t>(p.num_blocks) * (n_num + 1) * (D + 2) * sizeof(float) + 256;
+}
+
+}  // namespace rbx
+
+extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+                          const float* d_lr_bias, float* d_logit, float* d_sum, int32_t* d_status, void* stream) {
+  using namespace rbx;
+  FmHost h;
+  int rc = fm_validate(emb, lr, n_fields, batch, &h);
+  if (rc != RBX_OK) return rc;
+  if (batch < 0) return fail(RBX_ERR_INVALID, "negative batch");
+  if (batch == 0) return RBX_OK;
+  if (d_logit == nullptr) return fail(RBX_ERR_INVALID, "d_logit is NULL");
+  if (h.vec && d_sum != nullptr && (reinterpret_cast<uintptr_t>(d_sum) & 15) != 0) h.vec = false;
+  return h.vec ? dispatch_fm_fwd<true>(h, batch, d_lr_bias, d_logit, d_sum, d_status, as_stream(stream))
+               : dispatch_fm_fwd<false>(h, batch, d_lr_bias, d_logit, d_sum, d_status, as_stream(stream));
+}
+
+extern "C" size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields,
+                                            int64_t batch) {
+  using namespace rbx;
+  BwdPlan p;
+  FmNumPack np;
+  int n_num = 0;
+  if (fm_plan(emb, lr, n_fields, batch, &p, &np, &n_num) != RBX_OK) return 0;
+  const int D = emb ? emb[0].dim : 1;
+  return p.bytes + fm_num_bytes(p, n_num, D);
+}
+
+extern "C" int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+                           void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream) {
+  using namespace rbx;
+  BwdPlan p;
+  FmNumPack np;
+  int n_num = 0;
+  int rc = fm_plan(emb, lr, n_fields, batch, &p, &np, &n_num);
+  if (rc != RBX_OK) return rc;
+  if (p.n_lookups == 0) return RBX_OK;
+  if (d_workspace == nullptr || workspace_bytes < p.bytes) return fail(RBX_ERR_WORKSPACE, "fm: workspace too small");
+  return run_sort(p, static_cast<char*>(d_workspace), d_status, as_stream(stream));
+}
+
+extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+                          const float* d_dlogit, const float* d_sum, float* d_dbias, void* d_workspace,
+                          size_t workspace_bytes, void* stream) {
+  using namespace rbx;
+  if (d_dlogit == nullptr) return fail(RBX_ERR_INVALID, "fm: d_dlogit is NULL");
+  if (emb != nullptr && d_sum == nullptr) return fail(RBX_ERR_INVALID, "fm: d_sum from the forward is required");
+  if (batch == 0) return RBX_OK;
+  BwdPlan p;
+  FmNumPack np;
+  int n_num = 0;
+  int rc = fm_plan(emb, lr, n_fields, batch, &p, &np, &n_num);
+  if (rc != RBX_OK) return rc;
+  const int D = emb ? emb[0].dim : 1;
+  const size_t need = p.bytes + fm_num_bytes(p, n_num, D);
+  if (d_workspace == nullptr || workspace_bytes < need)
+    return fail(RBX_ERR_WORKSPACE, "fm: workspace %zu B < required %zu B", workspace_bytes, need);
+  char* ws = static_cast<char*>(d_workspace);
+  hipStream_t s = as_stream(stream);
+  if (p.n_lookups > 0) {
+    const int cur = p.passes & 1;
+    const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);
+    const unsigned* vals = reinterpret_cast<const unsigned*>(ws + p.off_vals[cur]);
+    const FmPolicy::Args args = {d_dlogit, emb ? d_sum : nullptr, D};
+    const bool vec = p.vec && ((reinterpret_cast<uintptr_t>(d_sum) & 15) == 0);
+    rc = vec ? dispatch_reduce<FmPolicy, true>(p, args, keys, vals, ws, s)
+             : dispatch_reduce<FmPolicy, false>(p, args, keys, vals, ws, s);
+    if (rc != RBX_OK) return rc;
+  }
+  if (n_num > 0 || d_dbias != nullptr) {
+    float* partial = reinterpret_cast<float*>(ws + p.bytes);
+    const int ns = fm_num_samples(D);
+    const size_t lds = static_cast<size_t>(ns) * (D + 2 * n_num + 1) * sizeof(float);
+    hipLaunchKernelGGL(fm_numeric_partial_kernel, dim3(p.num_blocks), dim3(256), lds, s, np, n_num,
+                       static_cast<long long>(batch), D, ns, d_dlogit, emb ? d_sum : nullptr, partial);
+    hipLaunchKernelGGL(fm_numeric_final_kernel, dim3(n_num + 1), dim3(64), 0, s, np, n_num, D, p.num_blocks, partial,
+                       d_dbias);
+    rc = check_launch("fm numeric kernels");
+    if (rc != RBX_OK) return rc;
+  }
+  return RBX_OK;
+}

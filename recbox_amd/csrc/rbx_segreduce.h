@@ -1,0 +1,237 @@
+// rbx_segreduce.h -- policy-templated segmented reduction over sorted (row, lookup)
+// pairs: the second half of the deterministic embedding backward.
+//
+// A Policy says what one lookup contributes and how a finished run is written:
+//   struct Policy {
+//     struct Args {...};                                   // by-value kernel argument
+//     template <class F> static __device__ void contribute(const Args&, const RedField&, unsigned local,
+//                                                          int lane_g, F& frag, float& cnt);
+//     template <class F> static __device__ void flush(const Args&, const RedField&, unsigned row,
+//                                                     const F& acc, float cnt, int lane_g);
+//   };
+// `frag` is the lane's slice of a D-vector, `cnt` one extra scalar per run (unused by the
+// generic policy, sum of upstream grads for the fused FM policy).  Chunk summaries are
+// `sum_stride = max_dim + extra` floats; cnt lives at offset max_dim.
+#pragma once
+#include "rbx_bwd_common.h"
+
+namespace rbx {
+
+template <class F>
+__device__ __forceinline__ void frag_add(F& a, const F& b) {
+#pragma unroll
+  for (int q = 0; q < static_cast<int>(sizeof(a.a) / sizeof(float)); ++q) a.a[q] += b.a[q];
+}
+
+// Interior runs are written directly; a run that crosses the chunk border leaves a head /
+// tail summary and a flag, and the chunk where such a run ENDS is queued for the fix-up.
+template <class Policy, int G, int NV, bool VEC>
+__global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, const int n_cat,
+                                                             const typename Policy::Args args,
+                                                             const unsigned* __restrict__ keys,
+                                                             const unsigned* __restrict__ vals, const unsigned n,
+                                                             const unsigned sentinel, float* __restrict__ head,
+                                                             float* __restrict__ tail, int* __restrict__ flags,
+                                                             unsigned* __restrict__ fin, const int max_dim,
+                                                             const int sum_stride, const unsigned n_chunks) {
+  __shared__ RedField sf[RBX_MAX_FIELDS];
+  {
+    const int words = n_cat * static_cast<int>(sizeof(RedField) / 4);
+    const int* src = reinterpret_cast<const int*>(&P);
+    int* dst = reinterpret_cast<int*>(sf);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  using F = Frag<G, NV, VEC>;
+  const int lane_g = threadIdx.x % G;
+  const unsigned c = blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
+  if (c >= n_chunks) return;
+  const unsigned s = c * kChunk;
+  const unsigned e = (s + kChunk < n) ? s + kChunk : n;
+  const unsigned key_before = (s > 0) ? keys[s - 1] : sentinel;
+  const unsigned key_after = (e < n) ? keys[e] : sentinel;
+  unsigned cur = keys[s];
+  const bool open_in = (s > 0) && (cur == key_before) && (cur != sentinel);
+  bool seen_boundary = false;
+  unsigned cur_val = vals[s];
+  F acc;
+  acc.zero();
+  float cnt = 0.f;
+  constexpr int U = 4;
+  for (unsigned i0 = s; i0 < e; i0 += U) {
+    unsigned kk[U], vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned i = i0 + u;
+      const bool ok = i < e;
+      kk[u] = ok ? keys[i] : sentinel;
+      vv[u] = ok ? vals[i] : 0u;
+    }
+    F rows[U];
+    float rc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rows[u].zero();
+      rc[u] = 0.f;
+      if (kk[u] != sentinel)
+        Policy::contribute(args, sf[vv[u] >> kLocalBits], vv[u] & kLocalMask, lane_g, rows[u], rc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u >= e) break;
+      if (kk[u] != cur) {                               // run boundary
+        if (cur != sentinel) {
+          const RedField& fd = sf[cur_val >> kLocalBits];
+          if (!seen_boundary && open_in) {
+            float* dst = head + static_cast<size_t>(c) * sum_stride;
+            acc.store(dst, fd.dim, lane_g);
+            if (lane_g == 0) dst[max_dim] = cnt;
+          } else {
+            Policy::flush(args, fd, cur - fd.row_base, acc, cnt, lane_g);
+          }
+        }
+        seen_boundary = true;
+        acc.zero();
+        cnt = 0.f;
+        cur = kk[u];
+        cur_val = vv[u];
+      }
+      frag_add(acc, rows[u]);
+      cnt += rc[u];
+    }
+  }
+  int flag = 0;
+  if (cur != sentinel) {
+    const RedField& fd = sf[cur_val >> kLocalBits];
+    const bool open_out = (e < n) && (key_after == cur);
+    const bool is_head = !seen_boundary && open_in;
+    if (open_out) {
+      float* dst = tail + static_cast<size_t>(c) * sum_stride;
+      acc.store(dst, fd.dim, lane_g);
+      if (lane_g == 0) dst[max_dim] = cnt;
+      if (is_head) flag |= kFlagPass;
+    } else if (is_head) {
+      float* dst = head + static_cast<size_t>(c) * sum_stride;
+      acc.store(dst, fd.dim, lane_g);
+      if (lane_g == 0) dst[max_dim] = cnt;
+      flag |= kFlagFin;
+    } else {
+      Policy::flush(args, fd, cur - fd.row_base, acc, cnt, lane_g);
+    }
+  }
+  if (seen_boundary && open_in) flag |= kFlagFin;
+  if (lane_g == 0) {
+    flags[c] = flag;
+    if (flag & kFlagFin) fin[1 + atomicAdd(fin, 1u)] = c;     // fix-up work list (order is irrelevant)
+  }
+}
+
+// Runs that cross chunk borders.  One WAVEFRONT per finalising chunk: its 64/G lane groups
+// walk the chain of pass-through chunks backwards 64/G tails at a time (flags first, a
+// ballot finds where the run started); partial sums are combined by a fixed xor butterfly,
+// so the result is order-deterministic.  A 21 845-lookup run (V=3 at B=65 536) is 683
+// chunks = 43 window steps at D=16 instead of 683 dependent loads.
+template <class Policy, int G, int NV, bool VEC>
+__global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, const typename Policy::Args args,
+                                                            const unsigned* __restrict__ keys,
+                                                            const unsigned* __restrict__ vals,
+                                                            const float* __restrict__ head,
+                                                            const float* __restrict__ tail,
+                                                            const int* __restrict__ flags,
+                                                            const unsigned* __restrict__ fin, const int max_dim,
+                                                            const int sum_stride) {
+  using F = Frag<G, NV, VEC>;
+  constexpr int NG = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int gi = lane / G, lane_g = lane % G;
+  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned count = fin[0];
+  for (unsigned idx = wave; idx < count; idx += nwaves) {
+    const unsigned c = fin[1 + idx];
+    const unsigned s = c * kChunk;
+    const unsigned key = keys[s];
+    const RedField fd = P.f[vals[s] >> kLocalBits];
+    F acc;
+    acc.zero();
+    float cnt = 0.f;
+    if (gi == 0) {
+      const float* src = head + static_cast<size_t>(c) * sum_stride;
+      acc.add_from(src, fd.dim, lane_g);
+      cnt = src[max_dim];
+    }
+    long long jbase = static_cast<long long>(c) - 1;
+    while (true) {
+      const long long j = jbase - gi;
+      const bool valid = j >= 0;
+      const int fl = valid ? flags[j] : 0;
+      const bool stop = !valid || !(fl & kFlagPass);
+      const unsigned long long m = __ballot(stop);
+      const int t = m ? (__ffsll(static_cast<long long>(m)) - 1) / G : NG;   // group holding the run's first chunk
+      F part;
+      part.zero();
+      float pc = 0.f;
+      if (valid && gi <= t) {
+        const float* src = tail + static_cast<size_t>(j) * sum_stride;
+        part.add_from(src, fd.dim, lane_g);
+        pc = src[max_dim];
+      }
+#pragma unroll
+      for (int o = G; o < 64; o <<= 1) {
+#pragma unroll
+        for (int q = 0; q < NV * F::W; ++q) part.a[q] += __shfl_xor(part.a[q], o, 64);
+        pc += __shfl_xor(pc, o, 64);
+      }
+      if (gi == 0) {
+        frag_add(acc, part);
+        cnt += pc;
+      }
+      if (m) break;
+      jbase -= NG;
+    }
+    if (gi == 0) Policy::flush(args, fd, key - fd.row_base, acc, cnt, lane_g);
+  }
+}
+
+template <class Policy, int G, int NV, bool VEC>
+static int launch_reduce(const BwdPlan& p, const typename Policy::Args& args, const unsigned* keys,
+                         const unsigned* vals, char* ws, hipStream_t s) {
+  const int groups_per_block = 256 / G;
+  const unsigned blocks = (p.n_chunks + groups_per_block - 1) / groups_per_block;
+  float* head = reinterpret_cast<float*>(ws + p.off_head);
+  float* tail = reinterpret_cast<float*>(ws + p.off_tail);
+  int* flags = reinterpret_cast<int*>(ws + p.off_flags);
+  unsigned* fin = reinterpret_cast<unsigned*>(ws + p.off_fin);
+  if (hipMemsetAsync(fin, 0, sizeof(unsigned), s) != hipSuccess)
+    return fail(RBX_ERR_LAUNCH, "memset of the fix-up counter failed");
+  hipLaunchKernelGGL((segment_reduce_kernel<Policy, G, NV, VEC>), dim3(blocks), dim3(256), 0, s, p.red, p.n_cat, args,
+                     keys, vals, p.n_lookups, p.total_rows, head, tail, flags, fin, p.max_dim, p.sum_stride,
+                     p.n_chunks);
+  int rc = check_launch("segment_reduce_kernel");
+  if (rc != RBX_OK) return rc;
+  unsigned fix_blocks = (p.n_chunks + 3) / 4;               // one wave per finalising chunk, grid-stride
+  if (fix_blocks > static_cast<unsigned>(kCUs * 4)) fix_blocks = kCUs * 4;
+  hipLaunchKernelGGL((segment_fixup_kernel<Policy, G, NV, VEC>), dim3(fix_blocks), dim3(256), 0, s, p.red, args, keys,
+                     vals, head, tail, flags, fin, p.max_dim, p.sum_stride);
+  return check_launch("segment_fixup_kernel");
+}
+
+template <class Policy, bool VEC>
+static int dispatch_reduce(const BwdPlan& p, const typename Policy::Args& args, const unsigned* keys,
+                           const unsigned* vals, char* ws, hipStream_t s) {
+  const int units = VEC ? p.max_dim / 4 : p.max_dim;
+  switch (pow2_ceil(units)) {
+    case 1: return launch_reduce<Policy, 1, 1, VEC>(p, args, keys, vals, ws, s);
+    case 2: return launch_reduce<Policy, 2, 1, VEC>(p, args, keys, vals, ws, s);
+    case 4: return launch_reduce<Policy, 4, 1, VEC>(p, args, keys, vals, ws, s);
+    case 8: return launch_reduce<Policy, 8, 1, VEC>(p, args, keys, vals, ws, s);
+    case 16: return launch_reduce<Policy, 16, 1, VEC>(p, args, keys, vals, ws, s);
+    case 32: return launch_reduce<Policy, 32, 1, VEC>(p, args, keys, vals, ws, s);
+    case 64: return launch_reduce<Policy, 64, 1, VEC>(p, args, keys, vals, ws, s);
+    case 128: return launch_reduce<Policy, 64, 2, VEC>(p, args, keys, vals, ws, s);
+    case 256: return launch_reduce<Policy, 64, 4, VEC>(p, args, keys, vals, ws, s);
+    default: return fail(RBX_ERR_UNSUPPORTED, "embedding dim too large for one lane group");
+  }
+}
+
+}  // namespace rbx

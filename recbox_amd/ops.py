@@ -151,6 +151,37 @@ def _timed(meta, fn):
     return fn() if kernel_timer is None else kernel_timer.bracket(meta, fn)
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One auxiliary HIP stream per device: the id sort of the backward depends only on the
+    ids, so it is enqueued there during the forward and overlaps the forward kernels."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
+class _EarlySort(object):
+    """Workspace + completion event of a sort launched from the forward."""
+
+    def __init__(self, device, ws_bytes, launch):
+        cur = torch.cuda.current_stream(device)
+        self.ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=device)
+        self.ws_bytes = int(ws_bytes)
+        side = _side_stream(device)
+        side.wait_stream(cur)                       # ids (and the fresh workspace) are ready
+        check(launch(self.ws, ctypes.c_void_p(side.cuda_stream)))
+        self.event = side.record_event()
+        self.ws.record_stream(side)
+
+    def join(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 def _check_status(status):
     if status is not None and int(status.item()) != 0:
         raise IndexError("index out of range in self")
@@ -178,6 +209,14 @@ class _EmbedLookup(torch.autograd.Function):
         _check_status(status)
         ctx.plan, ctx.inputs, ctx.row_scale, ctx.B = plan, keep, row_scale, B
         ctx.params = params
+        ctx.sort = None
+        if B > 0 and torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            # same descriptor set as the backward (placeholder grad pointers), sorted on the side stream
+            plan.bind_params(params, [p if p.requires_grad else None for p in params])
+            ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, plan.n, B)
+            if ws_bytes > 0:
+                ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_embed_sort(
+                    plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, st))
         return out
 
     @staticmethod
@@ -187,21 +226,19 @@ class _EmbedLookup(torch.autograd.Function):
             dout = dout.contiguous().float()
         need = [i + 2 + len(ctx.inputs) for i in range(len(params))]
         want = [ctx.needs_input_grad[j] for j in need]
-        # one zero-filled flat buffer for every dense gradient (single memset), views per parameter
-        sizes = [p.numel() if w else 0 for p, w in zip(params, want)]
-        padded = [(s + 3) // 4 * 4 for s in sizes]           # keep every view 16-byte aligned
-        flat = torch.zeros(sum(padded), dtype=torch.float32, device=dout.device)
-        grads, o = [], 0
-        for p, w, s, ps in zip(params, want, sizes, padded):
-            grads.append(flat[o:o + s].view_as(p) if w else None)
-            o += ps
+        grads = _flat_zero_grads(params, want, dout.device)
+        if B == 0:
+            return (None, None) + (None,) * len(ctx.inputs) + tuple(grads)
         plan.bind_inputs(ctx.inputs)
         plan.bind_params(params, grads)
-        ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, plan.n, B)
-        if ws_bytes == 0:
-            check(_lib.RBX_ERR_INVALID if _lib.last_error() else _lib.RBX_OK)
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dout.device)
-        check(lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, _stream()))
+        want_now = [p.requires_grad for p in params]
+        if ctx.sort is not None and want_now == list(want):
+            ctx.sort.join()
+            ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes
+        else:                                          # e.g. torch.autograd.grad on a subset: sort now
+            ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, plan.n, B)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dout.device)
+            check(lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, _stream()))
         check(lib.rbx_embed_bwd(plan.arr, plan.n, B, _ptr(dout), dout.stride(0), _ptr(ctx.row_scale),
                                 _ptr(ws), ws_bytes, _stream()))
         return (None, None) + (None,) * len(ctx.inputs) + tuple(grads)
@@ -281,3 +318,112 @@ DENOM_NONE, DENOM_VALUE, DENOM_MASK, DENOM_LEN = 0, 1, 2, 3
 
 def pool(emb, mask=None, numer_masked=False, denom=DENOM_NONE, eps=0.0):
     return _Pool.apply(emb, mask, numer_masked, denom, eps)
+
+
+def _flat_zero_grads(params, want, device):
+    """One zero-filled buffer (single memset) carved into per-parameter dense grads."""
+    sizes = [p.numel() if w else 0 for p, w in zip(params, want)]
+    padded = [(n + 3) // 4 * 4 for n in sizes]               # keep every view 16-byte aligned
+    flat = torch.zeros(sum(padded), dtype=torch.float32, device=device)
+    grads, o = [], 0
+    for p, w, n, pn in zip(params, want, sizes, padded):
+        grads.append(flat[o:o + n].view_as(p) if w else None)
+        o += pn
+    return grads
+
+
+class _FmFused(torch.autograd.Function):
+    """logit[B,1] of the FM model body in one kernel; backward fused into the segmented scatter-add."""
+
+    @staticmethod
+    def forward(ctx, emb_plan, lr_plan, n_inputs, n_emb, n_lr, *tensors):
+        inputs = tensors[:n_inputs]
+        emb_params = tensors[n_inputs:n_inputs + n_emb]
+        lr_params = tensors[n_inputs + n_emb:n_inputs + n_emb + n_lr]
+        rest = tensors[n_inputs + n_emb + n_lr:]
+        bias = rest[0] if rest else None
+        for p in emb_params + lr_params:
+            _require_cuda(p, "embedding parameter")
+        lead = emb_plan if emb_plan is not None else lr_plan
+        B, keep = lead.bind_inputs(inputs)
+        dev = keep[0].device
+        if emb_plan is not None:
+            emb_plan.bind_params(emb_params)
+        if lr_plan is not None:
+            if emb_plan is not None:
+                lr_plan.bind_inputs(keep)
+            lr_plan.bind_params(lr_params)
+        train = torch.is_grad_enabled() and any(t.requires_grad for t in tensors[n_inputs:])
+        D = emb_plan.specs[0].dim if emb_plan is not None else 1
+        logit = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if (train and emb_plan is not None) else None
+        status = torch.zeros(1, dtype=torch.int32, device=dev) if config.check_ids else None
+        ea = emb_plan.arr if emb_plan is not None else None
+        la = lr_plan.arr if lr_plan is not None else None
+        check(_timed(("fm_fwd", lead.n, D, B),
+                     lambda: lib.rbx_fm_fwd(ea, la, lead.n, B, _ptr(bias), _ptr(logit), _ptr(ssum), _ptr(status),
+                                            _stream())))
+        _check_status(status)
+        ctx.state = (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs)
+        ctx.sort = None
+        if train and B > 0:
+            if emb_plan is not None:
+                emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
+            if lr_plan is not None:
+                lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
+            ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
+            if ws_bytes > 0:
+                ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_fm_sort(
+                    ea, la, lead.n, B, _ptr(ws), ws_bytes, None, st))
+        return logit
+
+    @staticmethod
+    def backward(ctx, dlogit):
+        emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs = ctx.state
+        n_emb, n_lr = len(emb_params), len(lr_params)
+        base = 5 + n_inputs
+        want_e = [ctx.needs_input_grad[base + i] for i in range(n_emb)]
+        want_l = [ctx.needs_input_grad[base + n_emb + i] for i in range(n_lr)]
+        want_b = bias is not None and ctx.needs_input_grad[base + n_emb + n_lr]
+        dev = dlogit.device
+        grads = _flat_zero_grads(list(emb_params) + list(lr_params), want_e + want_l, dev)
+        ge, gl = grads[:n_emb], grads[n_emb:]
+        gb = torch.zeros(1, dtype=torch.float32, device=dev) if want_b else None
+        head = (None,) * base
+        if B == 0:
+            return head + tuple(ge) + tuple(gl) + ((gb,) if bias is not None else ())
+        dlogit = dlogit.contiguous().float().view(-1)
+        lead = emb_plan if emb_plan is not None else lr_plan
+        lead.bind_inputs(keep)
+        if emb_plan is not None:
+            emb_plan.bind_params(emb_params, ge)
+        if lr_plan is not None:
+            if emb_plan is not None:
+                lr_plan.bind_inputs(keep)
+            lr_plan.bind_params(lr_params, gl)
+        ea = emb_plan.arr if emb_plan is not None else None
+        la = lr_plan.arr if lr_plan is not None else None
+        same = [p.requires_grad for p in emb_params] == want_e and [p.requires_grad for p in lr_params] == want_l
+        if ctx.sort is not None and same:
+            ctx.sort.join()
+            ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes
+        else:
+            ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, _stream()))
+        check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), _ptr(ws), ws_bytes, _stream()))
+        return head + tuple(ge) + tuple(gl) + ((gb,) if bias is not None else ())
+
+
+def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None):
+    """FM model body: LR(X) + bias + product_sum(FeatureEmbedding(X)); either part may be absent."""
+    extra = (bias,) if bias is not None else ()
+    return _FmFused.apply(emb_plan, lr_plan, len(inputs), len(emb_params), len(lr_params),
+                          *inputs, *emb_params, *lr_params, *extra)
+
+
+def interaction_rowsum(emb):
+    """sum over the field axis of [B, F, 1] (the LR reduction when sequence features are present):
+    bi_interaction's sibling -- implemented as product_sum's linear part would be overkill, so this
+    reuses the pooling kernel: [B, L=F, D=1] summed over L."""
+    return pool(emb, None, False, DENOM_NONE, 0.0)

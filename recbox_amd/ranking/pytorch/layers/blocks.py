@@ -4,6 +4,7 @@ logistic_regression.py:23-35 and factorization_machine.py:24-34)."""
 import torch
 from torch import nn
 
+from .... import ops
 from .embeddings import FeatureEmbedding
 from .interactions import InnerProductInteraction
 
@@ -18,8 +19,13 @@ class LogisticRegression(nn.Module):
         self.embedding_layer = FeatureEmbedding(feature_map, 1, use_pretrain=False, use_sharing=False)
 
     def forward(self, X):
-        embed_weights = self.embedding_layer(X)        # [B, F, 1] from one gather launch
-        output = embed_weights.sum(dim=1)
+        table = self.embedding_layer.embedding_layer
+        names, values, plan, posts = table.plan_for(X)
+        if table.fusable(plan, posts):
+            # one kernel: sum_f w_f[id] (+ x * w for numeric features) + bias, no [B, F, 1] tensor
+            return ops.fm_fused(None, plan.plan, values, [], [m.weight for m in plan.modules], self.bias)
+        embed_weights = self.embedding_layer(X)        # sequence features: gather+sum-pool, then reduce over F
+        output = ops.interaction_rowsum(embed_weights)
         if self.bias is not None:
             output = output + self.bias
         return output

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from .... import _embed_host as host
-from ...._lib import FIELD_CATEGORICAL, FIELD_NUMERIC, POOL_CONCAT
+from ...._lib import FIELD_CATEGORICAL, FIELD_NUMERIC, POOL_CONCAT, POOL_NONE
 from . import pooling as layers  # noqa: F401  ("layers.MaskedAveragePooling()" in feature maps)
 from .pooling import MaskedAveragePooling, MaskedSumPooling  # noqa: F401
 
@@ -187,7 +187,8 @@ class FeatureEmbeddingDict(nn.Module):
                                eps=encoder.fused_eps), None
         return host.Lookup(feature, FIELD_CATEGORICAL, module, dim, pool=POOL_CONCAT, seq_len=seq_len), encoder
 
-    def forward(self, inputs, feature_source=[], feature_type=[]):
+    def plan_for(self, inputs, feature_source=[], feature_type=[]):
+        """(names, values, plan, posts) of one call signature; plans are cached."""
         sources, types = _as_list(feature_source), _as_list(feature_type)
         names, values = [], []
         for feature, spec in self._feature_map.features.items():
@@ -200,9 +201,8 @@ class FeatureEmbeddingDict(nn.Module):
                     raise NotImplementedError
                 names.append(feature)
                 values.append(inputs[feature])
-        out = _FusedDict()
         if not names:
-            return out
+            return names, values, None, None
         key = (tuple(names), tuple(v.shape[1] if v.dim() > 1 else 0 for v in values))
         cached = self._plans.get(key)
         if cached is None:
@@ -213,7 +213,18 @@ class FeatureEmbeddingDict(nn.Module):
                 posts.append(post)
             cached = (host.Plan(lookups), posts)
             self._plans[key] = cached
-        plan, posts = cached
+        return names, values, cached[0], cached[1]
+
+    def fusable(self, plan, posts):
+        """True when the FM / LR body can be fused: one id per sample, no encoders, one dim."""
+        return (plan is not None and plan.uniform_dim is not None and all(p is None for p in posts)
+                and all(s.seq_len == 1 and s.pool == POOL_NONE for s in plan.specs))
+
+    def forward(self, inputs, feature_source=[], feature_type=[]):
+        names, values, plan, posts = self.plan_for(inputs, feature_source, feature_type)
+        out = _FusedDict()
+        if not names:
+            return out
         fused = plan.run(values)
         clean = True
         for i, feature in enumerate(names):

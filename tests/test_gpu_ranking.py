@@ -182,6 +182,82 @@ def test_fm_matches_oracle_seeded(B, zipf):
         assert_close(p1.grad * B, p0.grad * B, TOL * max(1.0, B / 64), "grad " + n0)
 
 
+def test_fused_fm_model_golden():
+    """FM model body fused into rbx_fm_fwd / rbx_fm_bwd against the live-reference fixture."""
+    from recbox_amd.ranking.pytorch.models import FM
+    fx = Fixture("ranking_fm")
+    fm = _FM(criteo_small_features())
+    model = load_params(FM(fm, 16), fx["p"]).cuda()
+    X = _cuda(fx.tensors("in"))
+    logit = model.logits(X)
+    assert_close(logit, fx["out"]["logit"], TOL)
+    prob = model(X)["y_pred"]
+    assert_close(prob, fx["out"]["prob"], TOL)
+    loss = torch.nn.functional.binary_cross_entropy(prob, X["label"], reduction="mean")
+    assert_close(loss, fx["out"]["loss"], TOL)
+    loss.backward()
+    assert_grads_close(model, fx["g"], TOL)
+
+
+@pytest.mark.parametrize("B,zipf", [(1, False), (33, True), (4096, False), (5000, True)])
+def test_fused_fm_matches_layer_path_and_oracle(B, zipf):
+    from oracle import torch_ref as R
+    from recbox_amd.ranking.pytorch.models import FM
+    fm, X, y = _criteo_like(B, CRITEO_SMALL_VOCABS + [], 16, seed=100 + B, zipf=zipf)
+    ref = R.RefFMModel(fm, 16)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        for m in ref.modules():
+            if isinstance(m, torch.nn.Embedding) and m.padding_idx is not None:
+                m.weight[m.padding_idx].zero_()
+    fused, plain = FM(fm, 16, fused=True), FM(fm, 16, fused=False)
+    fused.load_state_dict(ref.state_dict())
+    plain.load_state_dict(ref.state_dict())
+    fused.cuda(), plain.cuda()
+    Xc, yc = _cuda(X), y.cuda()
+    outs = []
+    for model, inp, lab in ((ref, X, y), (fused, Xc, yc), (plain, Xc, yc)):
+        logit = model.logits(inp) if hasattr(model, "logits") else model(inp)
+        loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(logit), lab, reduction="sum")
+        loss.backward()
+        outs.append(logit)
+    assert_close(outs[1], outs[0], TOL, "fused logit vs oracle")
+    assert_close(outs[2], outs[0], TOL, "layer-path logit vs oracle")
+    scale = max(1.0, B / 64.0)          # summed loss: gradients of hot rows grow with B
+    for (n0, p0), (_, p1), (_, p2) in zip(ref.named_parameters(), fused.named_parameters(),
+                                          plain.named_parameters()):
+        assert_close(p1.grad, p0.grad, TOL * scale, "fused grad " + n0)
+        assert_close(p2.grad, p0.grad, TOL * scale, "layer grad " + n0)
+
+
+def test_logistic_regression_fused_and_frozen_tables():
+    L = _layers()
+    from oracle import torch_ref as R
+    fm, X, y = _criteo_like(300, CRITEO_SMALL_VOCABS[:6], 8, seed=5)
+    ref = R.RefLogisticRegression(fm)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.normal_(0, 0.1)
+    dut = L.LogisticRegression(fm)
+    dut.load_state_dict(ref.state_dict())
+    dut.cuda()
+    frozen = "embedding_layer.embedding_layer.embedding_layers.C2.weight"
+    for m in (ref, dut):
+        dict(m.named_parameters())[frozen].requires_grad_(False)
+    o0 = ref(X)
+    o1 = dut(_cuda(X))
+    assert_close(o1, o0, TOL)
+    (o0 * y).sum().backward()
+    (o1 * y.cuda()).sum().backward()
+    for (n, p0), (_, p1) in zip(ref.named_parameters(), dut.named_parameters()):
+        if n == frozen:
+            assert p1.grad is None
+        else:
+            assert_close(p1.grad, p0.grad, TOL, n)
+
+
 def test_backward_is_deterministic_and_linear():
     """Full-size property checks (B = 65 536, 26 fields): two backward passes are
     bit-identical (no float atomics) and column sums of dW equal column sums of dY."""
