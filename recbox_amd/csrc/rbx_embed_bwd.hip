@@ -349,6 +349,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
 
 // ---- generic policy: a lookup contributes w * dY[b, slot] (the kernels are in rbx_segreduce.h) ----
 struct GenericPolicy {
+  static constexpr bool kHasCount = false;
   struct Args {
     const float* dout;
     long long stride_b;

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
 
 // ---- backward policy: contribution g_b * S_b, cnt += g_b; flush dW = A - cnt*w ------------
 struct FmPolicy {
+  static constexpr bool kHasCount = true;
   struct Args {
     const float* g;        // [B] upstream grad of the logit
     const float* ssum;     // [B, D]

@@ -4,6 +4,7 @@
 // A Policy says what one lookup contributes and how a finished run is written:
 //   struct Policy {
 //     struct Args {...};                                   // by-value kernel argument
+//     static constexpr bool kHasCount;                     // summaries carry the extra scalar
 //     template <class F> static __device__ void contribute(const Args&, const RedField&, unsigned local,
 //                                                          int lane_g, F& frag, float& cnt);
 //     template <class F> static __device__ void flush(const Args&, const RedField&, unsigned row,
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, co
           if (!seen_boundary && open_in) {
             float* dst = head + static_cast<size_t>(c) * sum_stride;
             acc.store(dst, fd.dim, lane_g);
-            if (lane_g == 0) dst[max_dim] = cnt;
+            if (Policy::kHasCount && lane_g == 0) dst[max_dim] = cnt;
           } else {
             Policy::flush(args, fd, cur - fd.row_base, acc, cnt, lane_g);
           }
@@ -108,12 +109,12 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, co
     if (open_out) {
       float* dst = tail + static_cast<size_t>(c) * sum_stride;
       acc.store(dst, fd.dim, lane_g);
-      if (lane_g == 0) dst[max_dim] = cnt;
+      if (Policy::kHasCount && lane_g == 0) dst[max_dim] = cnt;
       if (is_head) flag |= kFlagPass;
     } else if (is_head) {
       float* dst = head + static_cast<size_t>(c) * sum_stride;
       acc.store(dst, fd.dim, lane_g);
-      if (lane_g == 0) dst[max_dim] = cnt;
+      if (Policy::kHasCount && lane_g == 0) dst[max_dim] = cnt;
       flag |= kFlagFin;
     } else {
       Policy::flush(args, fd, cur - fd.row_base, acc, cnt, lane_g);
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, con
     if (gi == 0) {
       const float* src = head + static_cast<size_t>(c) * sum_stride;
       acc.add_from(src, fd.dim, lane_g);
-      cnt = src[max_dim];
+      if (Policy::kHasCount) cnt = src[max_dim];
     }
     long long jbase = static_cast<long long>(c) - 1;
     while (true) {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, con
       if (valid && gi <= t) {
         const float* src = tail + static_cast<size_t>(j) * sum_stride;
         part.add_from(src, fd.dim, lane_g);
-        pc = src[max_dim];
+        if (Policy::kHasCount) pc = src[max_dim];
       }
 #pragma unroll
       for (int o = G; o < 64; o <<= 1) {

@@ -191,7 +191,7 @@ class _EmbedLookup(torch.autograd.Function):
     """out[B, width] = multi-table gather (+pooling); backward = sorted segmented scatter-add."""
 
     @staticmethod
-    def forward(ctx, plan, n_inputs, *tensors):
+    def forward(ctx, plan, n_inputs, train, *tensors):
         inputs, params = tensors[:n_inputs], tensors[n_inputs:]
         for p in params:
             _require_cuda(p, "embedding parameter")
@@ -210,7 +210,7 @@ class _EmbedLookup(torch.autograd.Function):
         ctx.plan, ctx.inputs, ctx.row_scale, ctx.B = plan, keep, row_scale, B
         ctx.params = params
         ctx.sort = None
-        if B > 0 and torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if B > 0 and train:
             # same descriptor set as the backward (placeholder grad pointers), sorted on the side stream
             plan.bind_params(params, [p if p.requires_grad else None for p in params])
             ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, plan.n, B)
@@ -224,11 +224,11 @@ class _EmbedLookup(torch.autograd.Function):
         plan, params, B = ctx.plan, ctx.params, ctx.B
         if dout.stride(1) != 1 or dout.dtype != torch.float32:
             dout = dout.contiguous().float()
-        need = [i + 2 + len(ctx.inputs) for i in range(len(params))]
+        need = [i + 3 + len(ctx.inputs) for i in range(len(params))]
         want = [ctx.needs_input_grad[j] for j in need]
         grads = _flat_zero_grads(params, want, dout.device)
         if B == 0:
-            return (None, None) + (None,) * len(ctx.inputs) + tuple(grads)
+            return (None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
         plan.bind_inputs(ctx.inputs)
         plan.bind_params(params, grads)
         want_now = [p.requires_grad for p in params]
@@ -241,12 +241,13 @@ class _EmbedLookup(torch.autograd.Function):
             check(lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, _stream()))
         check(lib.rbx_embed_bwd(plan.arr, plan.n, B, _ptr(dout), dout.stride(0), _ptr(ctx.row_scale),
                                 _ptr(ws), ws_bytes, _stream()))
-        return (None, None) + (None,) * len(ctx.inputs) + tuple(grads)
+        return (None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
 
 
 def embed_lookup(plan, inputs, params):
     """Run plan over ``inputs`` (one tensor per feature) and ``params`` (distinct tables/weights)."""
-    return _EmbedLookup.apply(plan, len(inputs), *inputs, *params)
+    train = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # grad mode is off inside forward()
+    return _EmbedLookup.apply(plan, len(inputs), train, *inputs, *params)
 
 
 class _Interaction(torch.autograd.Function):
@@ -336,7 +337,7 @@ class _FmFused(torch.autograd.Function):
     """logit[B,1] of the FM model body in one kernel; backward fused into the segmented scatter-add."""
 
     @staticmethod
-    def forward(ctx, emb_plan, lr_plan, n_inputs, n_emb, n_lr, *tensors):
+    def forward(ctx, emb_plan, lr_plan, n_inputs, n_emb, n_lr, train, *tensors):
         inputs = tensors[:n_inputs]
         emb_params = tensors[n_inputs:n_inputs + n_emb]
         lr_params = tensors[n_inputs + n_emb:n_inputs + n_emb + n_lr]
@@ -353,7 +354,6 @@ class _FmFused(torch.autograd.Function):
             if emb_plan is not None:
                 lr_plan.bind_inputs(keep)
             lr_plan.bind_params(lr_params)
-        train = torch.is_grad_enabled() and any(t.requires_grad for t in tensors[n_inputs:])
         D = emb_plan.specs[0].dim if emb_plan is not None else 1
         logit = torch.empty((B, 1), dtype=torch.float32, device=dev)
         ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if (train and emb_plan is not None) else None
@@ -381,7 +381,7 @@ class _FmFused(torch.autograd.Function):
     def backward(ctx, dlogit):
         emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs = ctx.state
         n_emb, n_lr = len(emb_params), len(lr_params)
-        base = 5 + n_inputs
+        base = 6 + n_inputs
         want_e = [ctx.needs_input_grad[base + i] for i in range(n_emb)]
         want_l = [ctx.needs_input_grad[base + n_emb + i] for i in range(n_lr)]
         want_b = bias is not None and ctx.needs_input_grad[base + n_emb + n_lr]
@@ -418,7 +418,8 @@ class _FmFused(torch.autograd.Function):
 def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None):
     """FM model body: LR(X) + bias + product_sum(FeatureEmbedding(X)); either part may be absent."""
     extra = (bias,) if bias is not None else ()
-    return _FmFused.apply(emb_plan, lr_plan, len(inputs), len(emb_params), len(lr_params),
+    train = torch.is_grad_enabled() and any(p.requires_grad for p in list(emb_params) + list(lr_params) + list(extra))
+    return _FmFused.apply(emb_plan, lr_plan, len(inputs), len(emb_params), len(lr_params), train,
                           *inputs, *emb_params, *lr_params, *extra)
 
 
