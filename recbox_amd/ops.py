@@ -172,6 +172,11 @@ class _EarlySort(object):
         cur = torch.cuda.current_stream(device)
         self.ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=device)
         self.ws_bytes = int(ws_bytes)
+        self.event = None
+        if torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture keep everything on the capturing stream
+            check(launch(self.ws, ctypes.c_void_p(cur.cuda_stream)))
+            return
         side = _side_stream(device)
         side.wait_stream(cur)                       # ids (and the fresh workspace) are ready
         check(launch(self.ws, ctypes.c_void_p(side.cuda_stream)))
@@ -179,7 +184,8 @@ class _EarlySort(object):
         self.ws.record_stream(side)
 
     def join(self):
-        torch.cuda.current_stream().wait_event(self.event)
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
 
 
 def _check_status(status):
