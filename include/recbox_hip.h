@@ -107,8 +107,10 @@ int rbx_embed_fwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
  *   rbx_embed_sort   : builds (global row, lookup) pairs for every categorical
  *                      lookup, drops padding_idx / masked ids, radix-sorts them.
  *   rbx_embed_bwd    : segment-reduces d_out rows in sorted order and adds each
- *                      touched row ONCE into fields[f].grad (dense [vocab,dim],
- *                      caller pre-zeroes or accumulates); numeric fields get
+ *                      touched row ONCE into fields[f].grad (dense [vocab,dim]).
+ *                      accumulate == 0: the caller pre-zeroed the grads, touched rows
+ *                      are stored (no read); accumulate != 0: read-modify-write into
+ *                      existing grads.  Numeric fields get
  *                      grad[d] += sum_b x_b * d_out[b, off+d].  Features that
  *                      share a table (same `table` pointer) are merged.
  * Results are run-to-run deterministic (no float atomics). */
@@ -117,7 +119,7 @@ int rbx_embed_sort(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
                    void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream);
 int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
                   const float* d_dout, int64_t out_stride_b, const float* d_row_scale,
-                  void* d_workspace, size_t workspace_bytes, void* stream);
+                  int32_t accumulate, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K4: InnerProductInteraction / rechub FM on a materialised [B,F,D] tensor ---
  * ranking/pytorch/layers/interactions/inner_product.py:40-56,
@@ -147,8 +149,8 @@ size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, 
 int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                 void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream);
 int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
-               const float* d_dlogit, const float* d_sum, float* d_dbias, void* d_workspace,
-               size_t workspace_bytes, void* stream);
+               const float* d_dlogit, const float* d_sum, float* d_dbias, int32_t accumulate,
+               void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- pooling of a materialised [B,L,D] tensor (standalone pooling modules) ------
  * core/pytorch/layers/sequence.py:4-20, ranking/pytorch/layers/pooling.py:22-40,

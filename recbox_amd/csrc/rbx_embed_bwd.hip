@@ -355,6 +355,7 @@ struct GenericPolicy {
     long long stride_b;
     const float* row_scale;
     long long B;
+    int accumulate;        // 0: grads were pre-zeroed by the caller -> store; 1: read-modify-write
   };
   template <class F>
   static __device__ __forceinline__ void contribute(const Args& a, const RedField& fd, unsigned local, int lane_g,
@@ -371,9 +372,11 @@ struct GenericPolicy {
     (void)cnt;
   }
   template <class F>
-  static __device__ __forceinline__ void flush(const Args&, const RedField& fd, unsigned row, const F& acc, float,
+  static __device__ __forceinline__ void flush(const Args& a, const RedField& fd, unsigned row, const F& acc, float,
                                                int lane_g) {
-    acc.accumulate_into(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);
+    // every touched row is written by exactly one lane group per call
+    float* dst = fd.grad + static_cast<size_t>(row) * fd.dim;
+    if (a.accumulate) acc.accumulate_into(dst, fd.dim, lane_g); else acc.store(dst, fd.dim, lane_g);
   }
 };
 
@@ -479,8 +482,8 @@ extern "C" int rbx_embed_sort(const rbx_field_t* fields, int32_t n_fields, int64
 }
 
 extern "C" int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch, const float* d_dout,
-                             int64_t out_stride_b, const float* d_row_scale, void* d_workspace, size_t workspace_bytes,
-                             void* stream) {
+                             int64_t out_stride_b, const float* d_row_scale, int32_t accumulate, void* d_workspace,
+                             size_t workspace_bytes, void* stream) {
   using namespace rbx;
   if (d_dout == nullptr) return fail(RBX_ERR_INVALID, "d_dout is NULL");
   if (batch == 0) return RBX_OK;
@@ -501,7 +504,7 @@ extern "C" int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_
     const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);
     const unsigned* vals = reinterpret_cast<const unsigned*>(ws + p.off_vals[cur]);
     const GenericPolicy::Args args = {d_dout, static_cast<long long>(out_stride_b), d_row_scale,
-                                      static_cast<long long>(batch)};
+                                      static_cast<long long>(batch), accumulate};
     rc = p.vec ? dispatch_reduce<GenericPolicy, true>(p, args, keys, vals, ws, s)
                : dispatch_reduce<GenericPolicy, false>(p, args, keys, vals, ws, s);
     if (rc != RBX_OK) return rc;

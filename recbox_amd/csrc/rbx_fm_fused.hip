@@ -141,6 +141,7 @@ struct FmPolicy {
     const float* g;        // [B] upstream grad of the logit
     const float* ssum;     // [B, D]
     int D;
+    int accumulate;        // 0: grads pre-zeroed -> store; 1: read-modify-write
   };
   template <class F>
   static __device__ __forceinline__ void contribute(const Args& a, const RedField& fd, unsigned local, int lane_g,
@@ -150,14 +151,17 @@ struct FmPolicy {
     if (a.ssum != nullptr) frag.fma_from(a.ssum + static_cast<size_t>(local) * a.D, fd.dim, lane_g, g);
   }
   template <class F>
-  static __device__ __forceinline__ void flush(const Args&, const RedField& fd, unsigned row, const F& acc, float cnt,
+  static __device__ __forceinline__ void flush(const Args& a, const RedField& fd, unsigned row, const F& acc, float cnt,
                                                int lane_g) {
     if (fd.grad != nullptr) {
       F out = acc;
       out.fma_from(fd.table + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g, -cnt);   // A - cnt * w_r
-      out.accumulate_into(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);
+      float* dst = fd.grad + static_cast<size_t>(row) * fd.dim;
+      if (a.accumulate) out.accumulate_into(dst, fd.dim, lane_g); else out.store(dst, fd.dim, lane_g);
     }
-    if (fd.grad2 != nullptr && lane_g == 0) fd.grad2[row] += cnt;
+    if (fd.grad2 != nullptr && lane_g == 0) {
+      if (a.accumulate) fd.grad2[row] += cnt; else fd.grad2[row] = cnt;
+    }
   }
 };
 
@@ -173,7 +177,7 @@ struct FmNumField {          // 48 B
 };
 struct FmNumPack { FmNumField f[RBX_MAX_FIELDS]; };
 
-static int fm_num_samples(int D) { return D <= 64 ? 256 : 64; }   // samples staged per workgroup (LDS budget)
+static int fm_num_samples(int D) { return D <= 128 ? 64 : 32; }   // samples staged per workgroup
 
 // partial layout per (block, feature): [D] sum g x S_d | [1] sum g x^2 | [1] sum g x   -> D+2 floats;
 // feature index n_num holds sum g in slot 0 (bias).
@@ -226,32 +230,37 @@ __global__ __launch_bounds__(256) void fm_numeric_partial_kernel(const FmNumPack
   }
 }
 
+// one wavefront per (feature, slot): lanes stride over the workgroup partials, fixed shuffle tree.
+// grid (n_num + 1, D + 2); scratch[f] keeps sum g x^2 for the w-correction applied by slot < D blocks,
+// so the correction term is recomputed per block (cheap) instead of synchronising blocks.
 __global__ __launch_bounds__(64) void fm_numeric_final_kernel(const FmNumPack P, const int n_num, const int D,
                                                               const unsigned num_blocks,
                                                               const float* __restrict__ partial,
                                                               float* __restrict__ dbias) {
-  const int f = blockIdx.x;            // n_num + 1 features (last = bias)
+  const int f = blockIdx.x, slot = blockIdx.y;
   const int stride = D + 2;
-  auto total = [&](int slot) -> float {
+  auto total = [&](int sl) -> float {
     float t = 0.f;
     for (unsigned k = threadIdx.x; k < num_blocks; k += 64)
-      t += partial[(static_cast<size_t>(k) * (n_num + 1) + f) * stride + slot];
+      t += partial[(static_cast<size_t>(k) * (n_num + 1) + f) * stride + sl];
     return group_sum<64>(t);
   };
   if (f == n_num) {
+    if (slot != 0) return;
     const float tg = total(0);
     if (dbias != nullptr && threadIdx.x == 0) dbias[0] += tg;
     return;
   }
   const FmNumField& fd = P.f[f];
-  const float t2 = total(D), t1 = total(D + 1);
-  if (fd.glr != nullptr && threadIdx.x == 0) fd.glr[0] += t1;
-  if (fd.gw != nullptr) {
-    for (int d = 0; d < D; ++d) {
-      const float a = total(d);
-      if (threadIdx.x == 0) fd.gw[d] += a - fd.w[d] * t2;
-    }
+  if (slot == D) return;                          // sum g x^2 is only a correction term (read below)
+  if (slot == D + 1) {
+    const float t1 = total(D + 1);
+    if (fd.glr != nullptr && threadIdx.x == 0) fd.glr[0] += t1;
+    return;
   }
+  if (fd.gw == nullptr) return;
+  const float a = total(slot), t2 = total(D);
+  if (threadIdx.x == 0) fd.gw[slot] += a - fd.w[slot] * t2;
 }
 
 // ---- host side -------------------------------------------------------------------------------
@@ -436,8 +445,8 @@ extern "C" int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_
 }
 
 extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
-                          const float* d_dlogit, const float* d_sum, float* d_dbias, void* d_workspace,
-                          size_t workspace_bytes, void* stream) {
+                          const float* d_dlogit, const float* d_sum, float* d_dbias, int32_t accumulate,
+                          void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace rbx;
   if (d_dlogit == nullptr) return fail(RBX_ERR_INVALID, "fm: d_dlogit is NULL");
   if (emb != nullptr && d_sum == nullptr) return fail(RBX_ERR_INVALID, "fm: d_sum from the forward is required");
@@ -457,7 +466,7 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
     const int cur = p.passes & 1;
     const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);
     const unsigned* vals = reinterpret_cast<const unsigned*>(ws + p.off_vals[cur]);
-    const FmPolicy::Args args = {d_dlogit, emb ? d_sum : nullptr, D};
+    const FmPolicy::Args args = {d_dlogit, emb ? d_sum : nullptr, D, accumulate};
     const bool vec = p.vec && ((reinterpret_cast<uintptr_t>(d_sum) & 15) == 0);
     rc = vec ? dispatch_reduce<FmPolicy, true>(p, args, keys, vals, ws, s)
              : dispatch_reduce<FmPolicy, false>(p, args, keys, vals, ws, s);
@@ -469,8 +478,8 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
     const size_t lds = static_cast<size_t>(ns) * (D + 2 * n_num + 1) * sizeof(float);
     hipLaunchKernelGGL(fm_numeric_partial_kernel, dim3(p.num_blocks), dim3(256), lds, s, np, n_num,
                        static_cast<long long>(batch), D, ns, d_dlogit, emb ? d_sum : nullptr, partial);
-    hipLaunchKernelGGL(fm_numeric_final_kernel, dim3(n_num + 1), dim3(64), 0, s, np, n_num, D, p.num_blocks, partial,
-                       d_dbias);
+    hipLaunchKernelGGL(fm_numeric_final_kernel, dim3(n_num + 1, D + 2), dim3(64), 0, s, np, n_num, D, p.num_blocks,
+                       partial, d_dbias);
     rc = check_launch("fm numeric kernels");
     if (rc != RBX_OK) return rc;
   }

@@ -127,11 +127,12 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, co
   }
 }
 
-// Runs that cross chunk borders.  One WAVEFRONT per finalising chunk: its 64/G lane groups
-// walk the chain of pass-through chunks backwards 64/G tails at a time (flags first, a
-// ballot finds where the run started); partial sums are combined by a fixed xor butterfly,
-// so the result is order-deterministic.  A 21 845-lookup run (V=3 at B=65 536) is 683
-// chunks = 43 window steps at D=16 instead of 683 dependent loads.
+// Runs that cross chunk borders.  One WORKGROUP per finalising chunk: its 256/G lane groups
+// walk the chain of pass-through chunks backwards 256/G tails per step (flags first, a
+// ballot + LDS min finds where the run started); partial sums are combined by a fixed
+// xor butterfly inside each wave and a fixed wave order across waves, so the result is
+// order-deterministic.  A 21 845-lookup run (V=3 at B=65 536) is 683 chunks = 11 window
+// steps at D=16 instead of 683 dependent loads.
 template <class Policy, int G, int NV, bool VEC>
 __global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, const typename Policy::Args args,
                                                             const unsigned* __restrict__ keys,
@@ -142,13 +143,16 @@ __global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, con
                                                             const unsigned* __restrict__ fin, const int max_dim,
                                                             const int sum_stride) {
   using F = Frag<G, NV, VEC>;
-  constexpr int NG = 64 / G;
-  const int lane = threadIdx.x & 63;
-  const int gi = lane / G, lane_g = lane % G;
-  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+  constexpr int NG = 64 / G;            // lane groups per wave
+  constexpr int NGB = 256 / G;          // lane groups per workgroup
+  constexpr int NA = NV * F::W;
+  constexpr int kNone = 1 << 30;
+  __shared__ int s_stop[4];
+  __shared__ float s_part[4][G * NA + 1];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int gi = threadIdx.x / G, lane_g = threadIdx.x % G;
   const unsigned count = fin[0];
-  for (unsigned idx = wave; idx < count; idx += nwaves) {
+  for (unsigned idx = blockIdx.x; idx < count; idx += gridDim.x) {
     const unsigned c = fin[1 + idx];
     const unsigned s = c * kChunk;
     const unsigned key = keys[s];
@@ -168,7 +172,11 @@ __global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, con
       const int fl = valid ? flags[j] : 0;
       const bool stop = !valid || !(fl & kFlagPass);
       const unsigned long long m = __ballot(stop);
-      const int t = m ? (__ffsll(static_cast<long long>(m)) - 1) / G : NG;   // group holding the run's first chunk
+      if (lane == 0) s_stop[wid] = m ? (__ffsll(static_cast<long long>(m)) - 1) / G + wid * NG : kNone;
+      __syncthreads();
+      int t = s_stop[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) t = (s_stop[w] < t) ? s_stop[w] : t;   // group holding the run's first chunk
       F part;
       part.zero();
       float pc = 0.f;
@@ -180,15 +188,26 @@ __global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, con
 #pragma unroll
       for (int o = G; o < 64; o <<= 1) {
 #pragma unroll
-        for (int q = 0; q < NV * F::W; ++q) part.a[q] += __shfl_xor(part.a[q], o, 64);
+        for (int q = 0; q < NA; ++q) part.a[q] += __shfl_xor(part.a[q], o, 64);
         pc += __shfl_xor(pc, o, 64);
       }
-      if (gi == 0) {
-        frag_add(acc, part);
-        cnt += pc;
+      if (lane < G) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) s_part[wid][lane * NA + q] = part.a[q];
+        if (lane == 0) s_part[wid][G * NA] = pc;
       }
-      if (m) break;
-      jbase -= NG;
+      __syncthreads();
+      if (gi == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+          for (int q = 0; q < NA; ++q) acc.a[q] += s_part[w][lane_g * NA + q];
+          cnt += s_part[w][G * NA];
+        }
+      }
+      __syncthreads();
+      if (t != kNone) break;
+      jbase -= NGB;
     }
     if (gi == 0) Policy::flush(args, fd, key - fd.row_base, acc, cnt, lane_g);
   }
@@ -210,7 +229,7 @@ static int launch_reduce(const BwdPlan& p, const typename Policy::Args& args, co
                      p.n_chunks);
   int rc = check_launch("segment_reduce_kernel");
   if (rc != RBX_OK) return rc;
-  unsigned fix_blocks = (p.n_chunks + 3) / 4;               // one wave per finalising chunk, grid-stride
+  unsigned fix_blocks = p.n_chunks;                         // one workgroup per finalising chunk, grid-stride
   if (fix_blocks > static_cast<unsigned>(kCUs * 4)) fix_blocks = kCUs * 4;
   hipLaunchKernelGGL((segment_fixup_kernel<Policy, G, NV, VEC>), dim3(fix_blocks), dim3(256), 0, s, p.red, args, keys,
                      vals, head, tail, flags, fin, p.max_dim, p.sum_stride);

@@ -23,6 +23,9 @@ class config(object):
     # The reference raises IndexError for an out-of-range id (nn.Embedding on CPU).
     # The kernels flag it on device; checking the flag costs one sync per call.
     check_ids = os.environ.get("RECBOX_AMD_CHECK_IDS", "1") != "0"
+    # fork the id sort onto the side stream even while a hipGraph is being captured (the
+    # fork/join becomes graph edges, so the sort overlaps the forward on replay too)
+    fork_in_capture = os.environ.get("RECBOX_AMD_FORK_IN_CAPTURE", "1") != "0"
 
 
 def _require_cuda(t, what):
@@ -173,8 +176,7 @@ class _EarlySort(object):
         self.ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=device)
         self.ws_bytes = int(ws_bytes)
         self.event = None
-        if torch.cuda.is_current_stream_capturing():
-            # inside a hipGraph capture keep everything on the capturing stream
+        if torch.cuda.is_current_stream_capturing() and not config.fork_in_capture:
             check(launch(self.ws, ctypes.c_void_p(cur.cuda_stream)))
             return
         side = _side_stream(device)
@@ -245,7 +247,8 @@ class _EmbedLookup(torch.autograd.Function):
             ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, plan.n, B)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dout.device)
             check(lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, _stream()))
-        check(lib.rbx_embed_bwd(plan.arr, plan.n, B, _ptr(dout), dout.stride(0), _ptr(ctx.row_scale),
+        # grads are views of a freshly zeroed buffer: accumulate=0 lets the kernel store instead of RMW
+        check(lib.rbx_embed_bwd(plan.arr, plan.n, B, _ptr(dout), dout.stride(0), _ptr(ctx.row_scale), 0,
                                 _ptr(ws), ws_bytes, _stream()))
         return (None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
 
@@ -417,7 +420,7 @@ class _FmFused(torch.autograd.Function):
             ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
             check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, _stream()))
-        check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), _ptr(ws), ws_bytes, _stream()))
+        check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, _ptr(ws), ws_bytes, _stream()))
         return head + tuple(ge) + tuple(gl) + ((gb,) if bias is not None else ())
 
 
