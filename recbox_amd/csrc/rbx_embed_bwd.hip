@@ -117,7 +117,7 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
   p->off_head = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
   p->off_tail = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
   p->off_flags = o; o += align_up(static_cast<size_t>(p->n_chunks) * 4, 256);
-  p->off_fin = o; o += align_up((static_cast<size_t>(p->n_chunks) + 1) * 4, 256);   // count, then chunk ids
+  p->off_fin = o; o += align_up((2 * static_cast<size_t>(p->n_chunks) + 2) * 4, 256);   // 2 counters, short list, long list
   p->off_num = o; o += align_up(static_cast<size_t>(p->n_num) * p->num_blocks * p->max_dim * 4, 256);
   p->bytes = o + 256;
   return RBX_OK;
@@ -372,11 +372,16 @@ struct GenericPolicy {
     (void)cnt;
   }
   template <class F>
-  static __device__ __forceinline__ void flush(const Args& a, const RedField& fd, unsigned row, const F& acc, float,
-                                               int lane_g) {
-    // every touched row is written by exactly one lane group per call
-    float* dst = fd.grad + static_cast<size_t>(row) * fd.dim;
-    if (a.accumulate) acc.accumulate_into(dst, fd.dim, lane_g); else acc.store(dst, fd.dim, lane_g);
+  static __device__ __forceinline__ void prefetch(const Args& a, const RedField& fd, unsigned row, int lane_g, F& pre) {
+    if (a.accumulate) pre.add_from(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);   // old grad (RMW)
+  }
+  template <class F>
+  static __device__ __forceinline__ void flush(const Args&, const RedField& fd, unsigned row, const F& acc, float,
+                                               const F& pre, int lane_g) {
+    // every touched row is written by exactly one lane group per call; pre = old grad or zeros
+    F out = acc;
+    frag_add(out, pre);
+    out.store(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);
   }
 };
 

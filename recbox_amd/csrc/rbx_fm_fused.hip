@@ -151,11 +151,16 @@ struct FmPolicy {
     if (a.ssum != nullptr) frag.fma_from(a.ssum + static_cast<size_t>(local) * a.D, fd.dim, lane_g, g);
   }
   template <class F>
+  static __device__ __forceinline__ void prefetch(const Args&, const RedField& fd, unsigned row, int lane_g, F& pre) {
+    if (fd.grad != nullptr) pre.add_from(fd.table + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);   // w_r
+  }
+  template <class F>
   static __device__ __forceinline__ void flush(const Args& a, const RedField& fd, unsigned row, const F& acc, float cnt,
-                                               int lane_g) {
+                                               const F& pre, int lane_g) {
     if (fd.grad != nullptr) {
-      F out = acc;
-      out.fma_from(fd.table + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g, -cnt);   // A - cnt * w_r
+      F out = acc;                                               // A - cnt * w_r
+#pragma unroll
+      for (int q = 0; q < static_cast<int>(sizeof(out.a) / sizeof(float)); ++q) out.a[q] -= cnt * pre.a[q];
       float* dst = fd.grad + static_cast<size_t>(row) * fd.dim;
       if (a.accumulate) out.accumulate_into(dst, fd.dim, lane_g); else out.store(dst, fd.dim, lane_g);
     }

@@ -7,8 +7,10 @@
 //     static constexpr bool kHasCount;                     // summaries carry the extra scalar
 //     template <class F> static __device__ void contribute(const Args&, const RedField&, unsigned local,
 //                                                          int lane_g, F& frag, float& cnt);
+//     template <class F> static __device__ void prefetch(const Args&, const RedField&, unsigned row,
+//                                                        int lane_g, F& pre);   // loads flush() needs
 //     template <class F> static __device__ void flush(const Args&, const RedField&, unsigned row,
-//                                                     const F& acc, float cnt, int lane_g);
+//                                                     const F& acc, float cnt, const F& pre, int lane_g);
 //   };
 // `frag` is the lane's slice of a D-vector, `cnt` one extra scalar per run (unused by the
 // generic policy, sum of upstream grads for the fused FM policy).  Chunk summaries are
@@ -55,12 +57,14 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, co
   const bool open_in = (s > 0) && (cur == key_before) && (cur != sentinel);
   bool seen_boundary = false;
   unsigned cur_val = vals[s];
-  F acc;
+  F acc, pre_last;
   acc.zero();
+  pre_last.zero();
   float cnt = 0.f;
-  constexpr int U = 4;
+  bool head_done = false;
+  constexpr int U = (NV * F::W <= 4) ? 8 : 4;      // lookups in flight per lane group
   for (unsigned i0 = s; i0 < e; i0 += U) {
-    unsigned kk[U], vv[U];
+    unsigned kk[U + 1], vv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const unsigned i = i0 + u;
@@ -68,29 +72,27 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, co
       kk[u] = ok ? keys[i] : sentinel;
       vv[u] = ok ? vals[i] : 0u;
     }
-    F rows[U];
+    kk[U] = (i0 + U < e) ? keys[i0 + U] : key_after;          // key that follows the batch
+    F rows[U], pre[U];
     float rc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       rows[u].zero();
+      pre[u].zero();
       rc[u] = 0.f;
-      if (kk[u] != sentinel)
-        Policy::contribute(args, sf[vv[u] >> kLocalBits], vv[u] & kLocalMask, lane_g, rows[u], rc[u]);
+      if (kk[u] != sentinel && i0 + u < e) {
+        const RedField& fd = sf[vv[u] >> kLocalBits];
+        Policy::contribute(args, fd, vv[u] & kLocalMask, lane_g, rows[u], rc[u]);
+        // a run ends after this lookup: fetch what flush() will need NOW, so that the random
+        // row read overlaps the other loads of the batch instead of serialising the walk
+        const unsigned nxt = (i0 + u + 1 < e) ? kk[u + 1] : key_after;
+        if (nxt != kk[u]) Policy::prefetch(args, fd, kk[u] - fd.row_base, lane_g, pre[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (i0 + u >= e) break;
-      if (kk[u] != cur) {                               // run boundary
-        if (cur != sentinel) {
-          const RedField& fd = sf[cur_val >> kLocalBits];
-          if (!seen_boundary && open_in) {
-            float* dst = head + static_cast<size_t>(c) * sum_stride;
-            acc.store(dst, fd.dim, lane_g);
-            if (Policy::kHasCount && lane_g == 0) dst[max_dim] = cnt;
-          } else {
-            Policy::flush(args, fd, cur - fd.row_base, acc, cnt, lane_g);
-          }
-        }
+      if (kk[u] != cur) {                               // first lookup of a new run
         seen_boundary = true;
         acc.zero();
         cnt = 0.f;
@@ -99,8 +101,23 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, co
       }
       frag_add(acc, rows[u]);
       cnt += rc[u];
+      const unsigned nxt = (i0 + u + 1 < e) ? kk[u + 1] : key_after;
+      const bool last_in_chunk = (i0 + u + 1 >= e);
+      if (cur != sentinel && nxt != cur && !last_in_chunk) {   // the run ends here, inside the chunk
+        const RedField& fd = sf[cur_val >> kLocalBits];
+        if (!seen_boundary && open_in) {
+          float* dst = head + static_cast<size_t>(c) * sum_stride;
+          acc.store(dst, fd.dim, lane_g);
+          if (Policy::kHasCount && lane_g == 0) dst[max_dim] = cnt;
+          head_done = true;
+        } else {
+          Policy::flush(args, fd, cur - fd.row_base, acc, cnt, pre[u], lane_g);
+        }
+      }
+      if (last_in_chunk) pre_last = pre[u];
     }
   }
+  // the run that is open at the end of the chunk
   int flag = 0;
   if (cur != sentinel) {
     const RedField& fd = sf[cur_val >> kLocalBits];
@@ -117,31 +134,80 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, co
       if (Policy::kHasCount && lane_g == 0) dst[max_dim] = cnt;
       flag |= kFlagFin;
     } else {
-      Policy::flush(args, fd, cur - fd.row_base, acc, cnt, lane_g);
+      Policy::flush(args, fd, cur - fd.row_base, acc, cnt, pre_last, lane_g);
     }
   }
-  if (seen_boundary && open_in) flag |= kFlagFin;
+  if (head_done) flag |= kFlagFin;
   if (lane_g == 0) {
     flags[c] = flag;
-    if (flag & kFlagFin) fin[1 + atomicAdd(fin, 1u)] = c;     // fix-up work list (order is irrelevant)
+    if (flag & kFlagFin) fin[2 + atomicAdd(fin, 1u)] = c;     // fix-up work list (order is irrelevant)
   }
 }
 
-// Runs that cross chunk borders.  One WORKGROUP per finalising chunk: its 256/G lane groups
-// walk the chain of pass-through chunks backwards 256/G tails per step (flags first, a
-// ballot + LDS min finds where the run started); partial sums are combined by a fixed
-// xor butterfly inside each wave and a fixed wave order across waves, so the result is
-// order-deterministic.  A 21 845-lookup run (V=3 at B=65 536) is 683 chunks = 11 window
-// steps at D=16 instead of 683 dependent loads.
+// Runs that cross chunk borders, pass 1: one lane group per finalising chunk walks back at
+// most kShortHops chunks (the common case: a run of 33..300 lookups); longer chains are
+// queued for the cooperative pass below.
+constexpr int kShortHops = 8;
+
 template <class Policy, int G, int NV, bool VEC>
-__global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, const typename Policy::Args args,
-                                                            const unsigned* __restrict__ keys,
-                                                            const unsigned* __restrict__ vals,
-                                                            const float* __restrict__ head,
-                                                            const float* __restrict__ tail,
-                                                            const int* __restrict__ flags,
-                                                            const unsigned* __restrict__ fin, const int max_dim,
-                                                            const int sum_stride) {
+__global__ __launch_bounds__(256) void segment_fixup_short_kernel(const RedPack P, const typename Policy::Args args,
+                                                                  const unsigned* __restrict__ keys,
+                                                                  const unsigned* __restrict__ vals,
+                                                                  const float* __restrict__ head,
+                                                                  const float* __restrict__ tail,
+                                                                  const int* __restrict__ flags,
+                                                                  unsigned* __restrict__ fin, const int max_dim,
+                                                                  const int sum_stride, const unsigned n_chunks) {
+  using F = Frag<G, NV, VEC>;
+  const int lane_g = threadIdx.x % G;
+  const unsigned ngroups = gridDim.x * (blockDim.x / G);
+  const unsigned count = fin[0];
+  for (unsigned idx = blockIdx.x * (blockDim.x / G) + threadIdx.x / G; idx < count; idx += ngroups) {
+    const unsigned c = fin[2 + idx];
+    // how long is the chain?  (flags only: cheap, L2-resident)
+    int hops = 0;
+    bool closed = false;
+    for (long long j = static_cast<long long>(c) - 1; j >= 0 && hops < kShortHops; --j) {
+      ++hops;
+      if (!(flags[j] & kFlagPass)) { closed = true; break; }
+    }
+    if (!closed && c > 0) {
+      if (lane_g == 0) fin[2 + n_chunks + atomicAdd(fin + 1, 1u)] = c;
+      continue;
+    }
+    const unsigned s = c * kChunk;
+    const unsigned key = keys[s];
+    const RedField fd = P.f[vals[s] >> kLocalBits];
+    F acc, pre;
+    acc.zero();
+    pre.zero();
+    Policy::prefetch(args, fd, key - fd.row_base, lane_g, pre);
+    const float* src = head + static_cast<size_t>(c) * sum_stride;
+    acc.add_from(src, fd.dim, lane_g);
+    float cnt = Policy::kHasCount ? src[max_dim] : 0.f;
+    for (int h = 1; h <= hops; ++h) {                       // independent loads, fixed summation order
+      const float* t = tail + static_cast<size_t>(c - h) * sum_stride;
+      acc.add_from(t, fd.dim, lane_g);
+      if (Policy::kHasCount) cnt += t[max_dim];
+    }
+    Policy::flush(args, fd, key - fd.row_base, acc, cnt, pre, lane_g);
+  }
+}
+
+// pass 2: one WORKGROUP per long chain: its 256/G lane groups walk the pass-through chunks
+// backwards 256/G tails per step (flags first, a ballot + LDS min finds where the run
+// started); partial sums are combined by a fixed xor butterfly inside each wave and a fixed
+// wave order across waves, so the result is order-deterministic.  A 21 845-lookup run
+// (V=3 at B=65 536) is 683 chunks = 11 window steps at D=16 instead of 683 dependent loads.
+template <class Policy, int G, int NV, bool VEC>
+__global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P, const typename Policy::Args args,
+                                                                 const unsigned* __restrict__ keys,
+                                                                 const unsigned* __restrict__ vals,
+                                                                 const float* __restrict__ head,
+                                                                 const float* __restrict__ tail,
+                                                                 const int* __restrict__ flags,
+                                                                 const unsigned* __restrict__ fin, const int max_dim,
+                                                                 const int sum_stride, const unsigned n_chunks) {
   using F = Frag<G, NV, VEC>;
   constexpr int NG = 64 / G;            // lane groups per wave
   constexpr int NGB = 256 / G;          // lane groups per workgroup
@@ -151,16 +217,18 @@ __global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, con
   __shared__ float s_part[4][G * NA + 1];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int gi = threadIdx.x / G, lane_g = threadIdx.x % G;
-  const unsigned count = fin[0];
+  const unsigned count = fin[1];
   for (unsigned idx = blockIdx.x; idx < count; idx += gridDim.x) {
-    const unsigned c = fin[1 + idx];
+    const unsigned c = fin[2 + n_chunks + idx];
     const unsigned s = c * kChunk;
     const unsigned key = keys[s];
     const RedField fd = P.f[vals[s] >> kLocalBits];
-    F acc;
+    F acc, pre;
     acc.zero();
+    pre.zero();
     float cnt = 0.f;
     if (gi == 0) {
+      Policy::prefetch(args, fd, key - fd.row_base, lane_g, pre);
       const float* src = head + static_cast<size_t>(c) * sum_stride;
       acc.add_from(src, fd.dim, lane_g);
       if (Policy::kHasCount) cnt = src[max_dim];
@@ -209,7 +277,7 @@ __global__ __launch_bounds__(256) void segment_fixup_kernel(const RedPack P, con
       if (t != kNone) break;
       jbase -= NGB;
     }
-    if (gi == 0) Policy::flush(args, fd, key - fd.row_base, acc, cnt, lane_g);
+    if (gi == 0) Policy::flush(args, fd, key - fd.row_base, acc, cnt, pre, lane_g);
   }
 }
 
@@ -222,18 +290,22 @@ static int launch_reduce(const BwdPlan& p, const typename Policy::Args& args, co
   float* tail = reinterpret_cast<float*>(ws + p.off_tail);
   int* flags = reinterpret_cast<int*>(ws + p.off_flags);
   unsigned* fin = reinterpret_cast<unsigned*>(ws + p.off_fin);
-  if (hipMemsetAsync(fin, 0, sizeof(unsigned), s) != hipSuccess)
-    return fail(RBX_ERR_LAUNCH, "memset of the fix-up counter failed");
+  if (hipMemsetAsync(fin, 0, 2 * sizeof(unsigned), s) != hipSuccess)
+    return fail(RBX_ERR_LAUNCH, "memset of the fix-up counters failed");
   hipLaunchKernelGGL((segment_reduce_kernel<Policy, G, NV, VEC>), dim3(blocks), dim3(256), 0, s, p.red, p.n_cat, args,
                      keys, vals, p.n_lookups, p.total_rows, head, tail, flags, fin, p.max_dim, p.sum_stride,
                      p.n_chunks);
   int rc = check_launch("segment_reduce_kernel");
   if (rc != RBX_OK) return rc;
-  unsigned fix_blocks = p.n_chunks;                         // one workgroup per finalising chunk, grid-stride
-  if (fix_blocks > static_cast<unsigned>(kCUs * 4)) fix_blocks = kCUs * 4;
-  hipLaunchKernelGGL((segment_fixup_kernel<Policy, G, NV, VEC>), dim3(fix_blocks), dim3(256), 0, s, p.red, args, keys,
-                     vals, head, tail, flags, fin, p.max_dim, p.sum_stride);
-  return check_launch("segment_fixup_kernel");
+  unsigned short_blocks = blocks;                           // one lane group per finalising chunk, grid-stride
+  if (short_blocks > static_cast<unsigned>(kCUs * 8)) short_blocks = kCUs * 8;
+  hipLaunchKernelGGL((segment_fixup_short_kernel<Policy, G, NV, VEC>), dim3(short_blocks), dim3(256), 0, s, p.red, args,
+                     keys, vals, head, tail, flags, fin, p.max_dim, p.sum_stride, p.n_chunks);
+  unsigned long_blocks = p.n_chunks;                        // one workgroup per long chain, grid-stride
+  if (long_blocks > static_cast<unsigned>(kCUs * 2)) long_blocks = kCUs * 2;
+  hipLaunchKernelGGL((segment_fixup_long_kernel<Policy, G, NV, VEC>), dim3(long_blocks), dim3(256), 0, s, p.red, args,
+                     keys, vals, head, tail, flags, fin, p.max_dim, p.sum_stride, p.n_chunks);
+  return check_launch("segment_fixup kernels");
 }
 
 template <class Policy, bool VEC>
