@@ -102,6 +102,39 @@ struct Frag {
     }
   }
   __device__ __forceinline__ void add_from(const float* row, int dim, int lane_g) { fma_from(row, dim, lane_g, 1.0f); }
+  // streaming variants: rows that are touched once per call should not evict the L2-resident
+  // gather operands (S, g), so they use the non-temporal cache policy
+  __device__ __forceinline__ void add_from_nt(const float* row, int dim, int lane_g) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = (lane_g + u * G) * W;
+      if (e < dim) {
+        if constexpr (VEC) {
+          const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(row + e));
+          a[u * 4 + 0] += t.x; a[u * 4 + 1] += t.y; a[u * 4 + 2] += t.z; a[u * 4 + 3] += t.w;
+        } else {
+          a[u] += __builtin_nontemporal_load(row + e);
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store_nt(float* row, int dim, int lane_g) const {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = (lane_g + u * G) * W;
+      if (e < dim) {
+        if constexpr (VEC) {
+          v4f t;
+          t.x = a[u * 4]; t.y = a[u * 4 + 1]; t.z = a[u * 4 + 2]; t.w = a[u * 4 + 3];
+          __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(row + e));
+        } else {
+          __builtin_nontemporal_store(a[u], row + e);
+        }
+      }
+    }
+  }
   __device__ __forceinline__ void store(float* row, int dim, int lane_g) const {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {

@@ -381,7 +381,7 @@ struct GenericPolicy {
     // every touched row is written by exactly one lane group per call; pre = old grad or zeros
     F out = acc;
     frag_add(out, pre);
-    out.store(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);
+    out.store_nt(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);
   }
 };
 

@@ -152,7 +152,7 @@ struct FmPolicy {
   }
   template <class F>
   static __device__ __forceinline__ void prefetch(const Args&, const RedField& fd, unsigned row, int lane_g, F& pre) {
-    if (fd.grad != nullptr) pre.add_from(fd.table + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);   // w_r
+    if (fd.grad != nullptr) pre.add_from_nt(fd.table + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);   // w_r
   }
   template <class F>
   static __device__ __forceinline__ void flush(const Args& a, const RedField& fd, unsigned row, const F& acc, float cnt,
@@ -162,7 +162,7 @@ struct FmPolicy {
 #pragma unroll
       for (int q = 0; q < static_cast<int>(sizeof(out.a) / sizeof(float)); ++q) out.a[q] -= cnt * pre.a[q];
       float* dst = fd.grad + static_cast<size_t>(row) * fd.dim;
-      if (a.accumulate) out.accumulate_into(dst, fd.dim, lane_g); else out.store(dst, fd.dim, lane_g);
+      if (a.accumulate) out.accumulate_into(dst, fd.dim, lane_g); else out.store_nt(dst, fd.dim, lane_g);
     }
     if (fd.grad2 != nullptr && lane_g == 0) {
       if (a.accumulate) fd.grad2[row] += cnt; else fd.grad2[row] = cnt;

@@ -65,12 +65,23 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, co
   constexpr int U = (NV * F::W <= 4) ? 8 : 4;      // lookups in flight per lane group
   for (unsigned i0 = s; i0 < e; i0 += U) {
     unsigned kk[U + 1], vv[U];
+    {
+      // the G lanes of a group split the batch's key/value loads and exchange them by shuffle
+      constexpr int PER = (U + G - 1) / G;
+      unsigned mk[PER], mv[PER];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned i = i0 + u;
-      const bool ok = i < e;
-      kk[u] = ok ? keys[i] : sentinel;
-      vv[u] = ok ? vals[i] : 0u;
+      for (int k = 0; k < PER; ++k) {
+        const unsigned i = i0 + k * G + lane_g;
+        const bool ok = (k * G + lane_g < U) && (i < e);
+        mk[k] = ok ? __builtin_nontemporal_load(keys + i) : sentinel;
+        mv[k] = ok ? __builtin_nontemporal_load(vals + i) : 0u;
+      }
+      const int gbase = (threadIdx.x & 63) & ~(G - 1);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        kk[u] = __shfl(mk[u / G], gbase + (u % G), 64);
+        vv[u] = __shfl(mv[u / G], gbase + (u % G), 64);
+      }
     }
     kk[U] = (i0 + U < e) ? keys[i0 + U] : key_after;          // key that follows the batch
     F rows[U], pre[U];
