@@ -152,6 +152,45 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
                const float* d_dlogit, const float* d_sum, float* d_dbias, int32_t accumulate,
                void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---- K5: two-tower scoring (third_party/rechub/models/matching/dssm.py:48,57,65,
+ * youtube_dnn.py:47-48,56,65,70).  l2norm = F.normalize(x, p=2, dim=-1, eps): y = x / max(||x||, eps);
+ * d_inv[rows] keeps 1/max(||x||,eps) (negative when the clamp was active) for the backward.
+ * pairdot: out[b,n] = scale * <u[b,:], v[b,n,:]>  (DSSM: n_cand = 1; YoutubeDNN: 1 + n_neg, scale = 1/T). */
+int rbx_l2norm_fwd(const float* d_x, int64_t rows, int32_t dim, float eps, float* d_y, float* d_inv, void* stream);
+int rbx_l2norm_bwd(const float* d_y, const float* d_inv, const float* d_dy, int64_t rows, int32_t dim,
+                   float* d_dx, void* stream);
+int rbx_pairdot_fwd(const float* d_u, const float* d_v, int64_t batch, int32_t n_cand, int32_t dim, float scale,
+                    float* d_out, void* stream);
+int rbx_pairdot_bwd(const float* d_u, const float* d_v, const float* d_dout, int64_t batch, int32_t n_cand,
+                    int32_t dim, float scale, float* d_du, float* d_dv, void* stream);
+
+/* ---- dense tower: y = act(x W^T + b) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------
+ * core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58,
+ * third_party/rechub/basic/layers.py:255-263.  x[m,k], W[n,k] (nn.Linear layout), bias[n] or NULL,
+ * act: 0 none, 1 ReLU.  Backward: dx[m,k] (NULL to skip), dW[n,k], db[n] (NULL to skip) are
+ * OVERWRITTEN; d_y (forward output) is only read when act == 1. */
+int rbx_linear_fwd(const float* d_x, const float* d_w, const float* d_bias, int64_t m, int32_t n, int32_t k,
+                   int32_t act, float* d_y, void* stream);
+size_t rbx_linear_bwd_workspace_size(int64_t m, int32_t n, int32_t k, int32_t act);
+int rbx_linear_bwd(const float* d_x, const float* d_w, const float* d_y, const float* d_dy, int64_t m, int32_t n,
+                   int32_t k, int32_t act, float* d_dx, float* d_dw, float* d_db, void* d_workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* ---- K6: fused masked-softmax attention for short sequences (L <= 256, head_dim in {4..64}) ----
+ * ranking/pytorch/layers/attentions/dot_product_attention.py:31-43 (ScaledDotProductAttention) and the
+ * attention core of nn.MultiheadAttention in third_party/rechub/models/matching/sasrec.py:81-87.
+ * q[bh, lq, hd], k/v[bh, lk, hd] contiguous; score = scale * <q, k>; causal != 0 hides keys j > i;
+ * d_mask (optional float [bh, lq, lk]): entries == 0 set the score to mask_fill (-1e9 for the
+ * first-party layer, -inf for a boolean attn_mask).  d_lse[bh, lq] is kept for the backward; d_p
+ * (optional [bh, lq, lk]) receives the attention probabilities.  d_scratch: bh*lq floats. */
+int rbx_attn_fwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask, int64_t bh,
+                 int32_t lq, int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill,
+                 float* d_o, float* d_lse, float* d_p, void* stream);
+int rbx_attn_bwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask, const float* d_o,
+                 const float* d_do, const float* d_lse, int64_t bh, int32_t lq, int32_t lk, int32_t head_dim,
+                 float scale, int32_t causal, float mask_fill, float* d_dq, float* d_dk, float* d_dv,
+                 float* d_scratch, void* stream);
+
 /* ---- pooling of a materialised [B,L,D] tensor (standalone pooling modules) ------
  * core/pytorch/layers/sequence.py:4-20, ranking/pytorch/layers/pooling.py:22-40,
  * third_party/rechub/basic/layers.py:176-230.

@@ -56,6 +56,16 @@ SIGNATURES = {
     "rbx_fm_bwd_workspace_size": (_sz, [_FP, _FP, _i32, _i64]),
     "rbx_fm_sort": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P, _P]),
     "rbx_fm_bwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _P, _i32, _P, _sz, _P]),
+    "rbx_l2norm_fwd": (ctypes.c_int, [_P, _i64, _i32, _f32, _P, _P, _P]),
+    "rbx_l2norm_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _P, _P]),
+    "rbx_pairdot_fwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _f32, _P, _P]),
+    "rbx_pairdot_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _f32, _P, _P, _P]),
+    "rbx_linear_fwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _P, _P]),
+    "rbx_linear_bwd_workspace_size": (_sz, [_i64, _i32, _i32, _i32]),
+    "rbx_linear_bwd": (ctypes.c_int, [_P, _P, _P, _P, _i64, _i32, _i32, _i32, _P, _P, _P, _P, _sz, _P]),
+    "rbx_attn_fwd": (ctypes.c_int, [_P, _P, _P, _P, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _P, _P, _P, _P]),
+    "rbx_attn_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _i64, _i32, _i32, _i32, _f32, _i32, _f32,
+                                    _P, _P, _P, _P, _P]),
     "rbx_pool_fwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _i32, _i32, _f32, _P, _P, _P]),
     "rbx_pool_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _P, _P]),
 }

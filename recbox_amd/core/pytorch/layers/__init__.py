@@ -1,2 +1,3 @@
 from .sequence import *
 from .embedding import *
+from .mlp import *

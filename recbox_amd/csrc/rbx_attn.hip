@@ -1,0 +1,343 @@
+// rbx_attn.hip -- K6: fused masked softmax attention for short sequences (gfx950).
+//
+// Reference behaviour replaced:
+//   first-party ScaledDotProductAttention.forward
+//     (ranking/pytorch/layers/attentions/dot_product_attention.py:31-43: QK^T, /scale,
+//      masked_fill(mask == 0, -1e9), softmax, .V; returns (output, attention))
+//   the core of nn.MultiheadAttention inside rechub SASRec
+//     (third_party/rechub/models/matching/sasrec.py:81-87: boolean causal mask -> -inf)
+// and their autograd backward.  The [B, H, L, L] score matrix never reaches HBM unless the
+// caller asks for the attention probabilities.
+//
+// Shape regime (SURVEY.md 5 "long context"): L <= 256, head_dim <= 64 (SASRec cfg 5:
+// L = 200, d = 64, 1 head), so K and V of one (sample, head) are 2 * 200 * 64 * 4 B = 100 KB
+// and sit in the CU's 160 KB LDS; one workgroup of 256 threads owns one (sample, head),
+// thread i owns query row i with q_i, o_i in registers and streams the keys: every lane of
+// a wave reads the SAME k_j / v_j row (LDS broadcast, conflict free).  Exact fp32 on the
+// VALU: at fp32 the matrix cores run at the vector rate, and the 1e-4 parity bar rules out
+// bf16.  Softmax is online over blocks of 8 keys (one rescale per block).
+// Backward recomputes p from the saved log-sum-exp: phase A (thread = query row) produces
+// dQ and D_i = <dO_i, O_i>; phase B (thread = key row, Q and dO staged in LDS) produces
+// dK, dV -- no atomics, deterministic.
+#include "rbx_internal.h"
+
+namespace rbx {
+
+constexpr int kAttnThreads = 256;
+constexpr int kKeyBlock = 8;
+
+// mask: optional float [BH, Lq, Lk]; an entry == 0 means "masked": score := fill
+template <int HD>
+__global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                const float* __restrict__ V,
+                                                                const float* __restrict__ mask, const int Lq,
+                                                                const int Lk, const float scale, const int causal,
+                                                                const float fill, float* __restrict__ O,
+                                                                float* __restrict__ LSE, float* __restrict__ P) {
+  extern __shared__ float lds[];
+  float* Ks = lds;                 // [Lk][HD]
+  float* Vs = lds + Lk * HD;       // [Lk][HD]
+  const long long bh = blockIdx.x;
+  const float* kg = K + bh * Lk * HD;
+  const float* vg = V + bh * Lk * HD;
+  for (int i = threadIdx.x * 4; i < Lk * HD; i += kAttnThreads * 4) {
+    *reinterpret_cast<float4*>(Ks + i) = *reinterpret_cast<const float4*>(kg + i);
+    *reinterpret_cast<float4*>(Vs + i) = *reinterpret_cast<const float4*>(vg + i);
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < Lq; i0 += kAttnThreads) {
+    const int i = i0 + threadIdx.x;
+    const bool live = i < Lq;
+    float q[HD], o[HD];
+    const float* qg = Q + (bh * Lq + (live ? i : 0)) * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(qg + d);
+      q[d] = t.x * scale; q[d + 1] = t.y * scale; q[d + 2] = t.z * scale; q[d + 3] = t.w * scale;
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int jmax = live ? (causal ? (i < Lk - 1 ? i : Lk - 1) : Lk - 1) : -1;
+    // wave-uniform trip count so that the LDS reads stay broadcasts
+    int jend = jmax;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int other = __shfl_xor(jend, off, 64);
+      jend = other > jend ? other : jend;
+    }
+    const float* mrow = (mask != nullptr && live) ? mask + (bh * Lq + i) * Lk : nullptr;
+    for (int j0 = 0; j0 <= jend; j0 += kKeyBlock) {
+      float s[kKeyBlock];
+      float mb = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < kKeyBlock; ++k) {
+        const int j = j0 + k;
+        float acc = 0.f;
+        if (j < Lk) {
+          const float* kr = Ks + j * HD;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) acc += q[d] * kr[d];
+        }
+        if (mrow != nullptr && j <= jmax && mrow[j] == 0.f) acc = fill;
+        s[k] = (j <= jmax) ? acc : -INFINITY;
+        mb = fmaxf(mb, s[k]);
+      }
+      if (mb == -INFINITY) continue;                 // nothing visible in this block for this row
+      const float mn = fmaxf(m, mb);
+      const float alpha = __expf(m - mn);            // m == -inf -> 0
+      l *= alpha;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] *= alpha;
+#pragma unroll
+      for (int k = 0; k < kKeyBlock; ++k) {
+        const int j = j0 + k;
+        const float p = (s[k] == -INFINITY) ? 0.f : __expf(s[k] - mn);
+        l += p;
+        if (j < Lk) {
+          const float* vr = Vs + j * HD;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) o[d] += p * vr[d];
+        }
+      }
+      m = mn;
+    }
+    if (live) {
+      const float invl = 1.0f / l;                   // l == 0 (fully -inf row) -> NaN like the reference
+      float* og = O + (bh * Lq + i) * HD;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4)
+        *reinterpret_cast<float4*>(og + d) = make_float4(o[d] * invl, o[d + 1] * invl, o[d + 2] * invl, o[d + 3] * invl);
+      if (LSE != nullptr) LSE[bh * Lq + i] = m + __logf(l);
+      if (P != nullptr) {                            // attention probabilities requested: second sweep
+        float* pg = P + (bh * Lq + i) * Lk;
+        for (int j = 0; j < Lk; ++j) {
+          float acc = 0.f;
+          const float* kr = Ks + j * HD;
+#pragma unroll
+          for (int d = 0; d < HD; ++d) acc += q[d] * kr[d];
+          if (mrow != nullptr && mrow[j] == 0.f) acc = fill;
+          pg[j] = (j <= jmax) ? __expf(acc - m) * invl : 0.f;
+        }
+      }
+    }
+  }
+}
+
+// phase A: dQ and D = <dO, O>
+template <int HD>
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                   const float* __restrict__ V,
+                                                                   const float* __restrict__ mask,
+                                                                   const float* __restrict__ O,
+                                                                   const float* __restrict__ dO,
+                                                                   const float* __restrict__ LSE, const int Lq,
+                                                                   const int Lk, const float scale, const int causal,
+                                                                   const float fill, float* __restrict__ dQ,
+                                                                   float* __restrict__ Dv) {
+  extern __shared__ float lds[];
+  float* Ks = lds;
+  float* Vs = lds + Lk * HD;
+  const long long bh = blockIdx.x;
+  const float* kg = K + bh * Lk * HD;
+  const float* vg = V + bh * Lk * HD;
+  for (int i = threadIdx.x * 4; i < Lk * HD; i += kAttnThreads * 4) {
+    *reinterpret_cast<float4*>(Ks + i) = *reinterpret_cast<const float4*>(kg + i);
+    *reinterpret_cast<float4*>(Vs + i) = *reinterpret_cast<const float4*>(vg + i);
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < Lq; i0 += kAttnThreads) {
+    const int i = i0 + threadIdx.x;
+    const bool live = i < Lq;
+    const long long row = bh * Lq + (live ? i : 0);
+    float q[HD], go[HD], dq[HD];
+    float Di = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+      q[d] = Q[row * HD + d] * scale;
+      go[d] = dO[row * HD + d];
+      Di += go[d] * O[row * HD + d];
+      dq[d] = 0.f;
+    }
+    const float lse = LSE[row];
+    const int jmax = live ? (causal ? (i < Lk - 1 ? i : Lk - 1) : Lk - 1) : -1;
+    int jend = jmax;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int other = __shfl_xor(jend, off, 64);
+      jend = other > jend ? other : jend;
+    }
+    const float* mrow = (mask != nullptr && live) ? mask + row * Lk : nullptr;
+    for (int j = 0; j <= jend; ++j) {
+      const float* kr = Ks + j * HD;
+      const float* vr = Vs + j * HD;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        s += q[d] * kr[d];
+        dp += go[d] * vr[d];
+      }
+      if (mrow != nullptr && j <= jmax && mrow[j] == 0.f) s = fill;
+      const float p = (j <= jmax) ? __expf(s - lse) : 0.f;
+      const float ds = p * (dp - Di);
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dq[d] += ds * kr[d];
+    }
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dQ[row * HD + d] = dq[d] * scale;
+      Dv[row] = Di;
+    }
+  }
+}
+
+// phase B: dK, dV (thread = key row; Q (pre-scaled) and dO staged in LDS)
+template <int HD>
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                                    const float* __restrict__ V,
+                                                                    const float* __restrict__ mask,
+                                                                    const float* __restrict__ dO,
+                                                                    const float* __restrict__ LSE,
+                                                                    const float* __restrict__ Dv, const int Lq,
+                                                                    const int Lk, const float scale, const int causal,
+                                                                    const float fill, float* __restrict__ dK,
+                                                                    float* __restrict__ dV) {
+  extern __shared__ float lds[];
+  float* Qs = lds;                       // [Lq][HD], pre-scaled
+  float* Gs = Qs + Lq * HD;              // [Lq][HD] dO
+  float* Ls = Gs + Lq * HD;              // [Lq] lse
+  float* Ds = Ls + Lq;                   // [Lq] D
+  const long long bh = blockIdx.x;
+  for (int i = threadIdx.x; i < Lq * HD; i += kAttnThreads) {
+    Qs[i] = Q[bh * Lq * HD + i] * scale;
+    Gs[i] = dO[bh * Lq * HD + i];
+  }
+  for (int i = threadIdx.x; i < Lq; i += kAttnThreads) {
+    Ls[i] = LSE[bh * Lq + i];
+    Ds[i] = Dv[bh * Lq + i];
+  }
+  __syncthreads();
+  for (int j0 = 0; j0 < Lk; j0 += kAttnThreads) {
+    const int j = j0 + threadIdx.x;
+    const bool live = j < Lk;
+    const long long row = bh * Lk + (live ? j : 0);
+    float kx[HD], vx[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+      kx[d] = K[row * HD + d];
+      vx[d] = V[row * HD + d];
+      dk[d] = 0.f;
+      dv[d] = 0.f;
+    }
+    // causal: query i sees key j iff j <= i; the wave starts at its smallest j
+    int istart = causal ? (live ? j : Lq) : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int other = __shfl_xor(istart, off, 64);
+      istart = other < istart ? other : istart;
+    }
+    for (int i = istart; i < Lq; ++i) {
+      const float* qr = Qs + i * HD;
+      const float* gr = Gs + i * HD;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        s += qr[d] * kx[d];
+        dp += gr[d] * vx[d];
+      }
+      const bool vis = live && (!causal || j <= i);
+      if (mask != nullptr && vis && mask[(bh * Lq + i) * Lk + j] == 0.f) s = fill;
+      const float p = vis ? __expf(s - Ls[i]) : 0.f;
+      const float ds = p * (dp - Ds[i]);
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        dv[d] += p * gr[d];
+        dk[d] += ds * qr[d];
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        dK[row * HD + d] = dk[d];
+        dV[row * HD + d] = dv[d];
+      }
+    }
+  }
+}
+
+static int attn_check(int64_t bh, int lq, int lk, int hd) {
+  if (bh < 0 || lq <= 0 || lk <= 0) return fail(RBX_ERR_INVALID, "attention: bad shape");
+  if (hd != 4 && hd != 8 && hd != 16 && hd != 32 && hd != 64)
+    return fail(RBX_ERR_UNSUPPORTED, "attention: head_dim %d not in {4,8,16,32,64}", hd);
+  const size_t lds = static_cast<size_t>(2) * (lq > lk ? lq : lk) * hd * sizeof(float) + 2 * lq * sizeof(float);
+  if (lds > 160 * 1024) return fail(RBX_ERR_UNSUPPORTED, "attention: L*head_dim too large for the LDS-resident kernel");
+  return RBX_OK;
+}
+
+}  // namespace rbx
+
+#define RBX_ATTN_HD(hd, CALL) \
+  switch (hd) {               \
+    case 4: CALL(4); break;   \
+    case 8: CALL(8); break;   \
+    case 16: CALL(16); break; \
+    case 32: CALL(32); break; \
+    default: CALL(64); break; \
+  }
+
+extern "C" int rbx_attn_fwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask, int64_t bh,
+                            int32_t lq, int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill,
+                            float* d_o, float* d_lse, float* d_p, void* stream) {
+  using namespace rbx;
+  int rc = attn_check(bh, lq, lk, head_dim);
+  if (rc != RBX_OK) return rc;
+  if (d_q == nullptr || d_k == nullptr || d_v == nullptr || d_o == nullptr) return fail(RBX_ERR_INVALID, "attention: NULL tensor");
+  if (bh == 0) return RBX_OK;
+  const size_t lds = static_cast<size_t>(2) * lk * head_dim * sizeof(float);
+  hipStream_t s = as_stream(stream);
+#define CALL(HD)                                                                                                  \
+  do {                                                                                                            \
+    if (lds > 64 * 1024)                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD>),                                    \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                     \
+    hipLaunchKernelGGL((attn_fwd_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, d_q,   \
+                       d_k, d_v, d_mask, lq, lk, scale, causal, mask_fill, d_o, d_lse, d_p);                      \
+  } while (0)
+  RBX_ATTN_HD(head_dim, CALL)
+#undef CALL
+  return check_launch("attn_fwd_kernel");
+}
+
+extern "C" int rbx_attn_bwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask,
+                            const float* d_o, const float* d_do, const float* d_lse, int64_t bh, int32_t lq,
+                            int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill, float* d_dq,
+                            float* d_dk, float* d_dv, float* d_scratch, void* stream) {
+  using namespace rbx;
+  int rc = attn_check(bh, lq, lk, head_dim);
+  if (rc != RBX_OK) return rc;
+  if (d_q == nullptr || d_k == nullptr || d_v == nullptr || d_o == nullptr || d_do == nullptr || d_lse == nullptr ||
+      d_dq == nullptr || d_dk == nullptr || d_dv == nullptr || d_scratch == nullptr)
+    return fail(RBX_ERR_INVALID, "attention backward: NULL tensor");
+  if (bh == 0) return RBX_OK;
+  const size_t lds_a = static_cast<size_t>(2) * lk * head_dim * sizeof(float);
+  const size_t lds_b = (static_cast<size_t>(2) * lq * head_dim + 2 * lq) * sizeof(float);
+  hipStream_t s = as_stream(stream);
+#define CALL(HD)                                                                                                   \
+  do {                                                                                                             \
+    if (lds_a > 64 * 1024)                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<HD>),                                  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_a));                    \
+    if (lds_b > 64 * 1024)                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<HD>),                                 \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b));                    \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds_a, s,    \
+                       d_q, d_k, d_v, d_mask, d_o, d_do, d_lse, lq, lk, scale, causal, mask_fill, d_dq,            \
+                       d_scratch);                                                                                 \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds_b, s,   \
+                       d_q, d_k, d_v, d_mask, d_do, d_lse, d_scratch, lq, lk, scale, causal, mask_fill, d_dk,      \
+                       d_dv);                                                                                      \
+  } while (0)
+  RBX_ATTN_HD(head_dim, CALL)
+#undef CALL
+  return check_launch("attn_bwd kernels");
+}

@@ -1,0 +1,48 @@
+"""Dense-tower execution: nn.Sequential children stay the reference's modules (real
+``nn.Linear`` so harness type tests / checkpoints keep working); this walker replaces
+their compute with the fp32-MFMA GEMM of ``rbx_linear_fwd/bwd`` and fuses a following
+ReLU into the GEMM epilogue.  BatchNorm / Dropout / other activations are elementwise
+or per-feature ATen kernels and run as the modules they are.
+"""
+from torch import nn
+
+from . import ops
+
+
+def activation_by_name(name):
+    """'ReLU' / 'relu' / nn.Module -> module (as recbox.utils.torch_utils.set_activation
+    and fuxictr.pytorch.torch_utils.get_activation do)."""
+    if name is None or isinstance(name, nn.Module):
+        return name
+    if isinstance(name, str):
+        low = name.lower()
+        if low == "relu":
+            return nn.ReLU()
+        if low == "sigmoid":
+            return nn.Sigmoid()
+        if low == "tanh":
+            return nn.Tanh()
+        if low == "softmax":
+            return nn.Softmax(dim=-1)
+        if low == "prelu":
+            return nn.PReLU()
+        if low in ("none", ""):
+            return None
+        return getattr(nn, name)()
+    raise NotImplementedError("activation={} is not supported.".format(name))
+
+
+def run_sequential(seq, x):
+    """Forward through an nn.Sequential, routing every nn.Linear through the HIP GEMM."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if type(m) is nn.Linear:
+            fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+            x = ops.linear(x, m.weight, m.bias, "relu" if fuse else None)
+            i += 2 if fuse else 1
+        else:
+            x = m(x)
+            i += 1
+    return x

@@ -2,3 +2,4 @@ from .pooling import *
 from .embeddings import *
 from .interactions import *
 from .blocks import *
+from .attentions import *

@@ -1,14 +1,14 @@
-"""LR / FM blocks (drop-in for ``recbox.ranking.pytorch.layers.{LogisticRegression,
-FactorizationMachine}``, /root/reference/recbox/ranking/pytorch/layers/blocks/
-logistic_regression.py:23-35 and factorization_machine.py:24-34)."""
+"""LR / FM / MLP blocks (drop-in for ``recbox.ranking.pytorch.layers.{LogisticRegression,
+FactorizationMachine, MLP_Block}``, /root/reference/recbox/ranking/pytorch/layers/blocks/
+logistic_regression.py:23-35, factorization_machine.py:24-34, mlp_block.py:23-61)."""
 import torch
 from torch import nn
 
-from .... import ops
+from .... import dense, ops
 from .embeddings import FeatureEmbedding
 from .interactions import InnerProductInteraction
 
-__all__ = ["LogisticRegression", "FactorizationMachine"]
+__all__ = ["LogisticRegression", "FactorizationMachine", "MLP_Block"]
 
 
 class LogisticRegression(nn.Module):
@@ -41,3 +41,39 @@ class FactorizationMachine(nn.Module):
         lr_out = self.lr_layer(X)
         fm_out = self.fm_layer(feature_emb)
         return fm_out + lr_out
+
+
+class MLP_Block(nn.Module):
+    """Same constructor / ``self.mlp`` child order as the reference (real nn.Linear holders);
+    every Linear runs on the fp32 matrix cores (rbx_linear_fwd/bwd, ReLU fused)."""
+
+    def __init__(self, input_dim, hidden_units=[], hidden_activations="ReLU", output_dim=None,
+                 output_activation=None, dropout_rates=0.0, batch_norm=False, norm_before_activation=True,
+                 use_bias=True):
+        super(MLP_Block, self).__init__()
+        layers = []
+        hidden_units = list(hidden_units)
+        if not isinstance(dropout_rates, list):
+            dropout_rates = [dropout_rates] * len(hidden_units)
+        if not isinstance(hidden_activations, list):
+            hidden_activations = [hidden_activations] * len(hidden_units)
+        acts = [dense.activation_by_name(a) for a in hidden_activations]
+        dims = [input_dim] + hidden_units
+        for i in range(len(dims) - 1):
+            layers.append(nn.Linear(dims[i], dims[i + 1], bias=use_bias))
+            if norm_before_activation and batch_norm:
+                layers.append(nn.BatchNorm1d(dims[i + 1]))
+            if acts[i]:
+                layers.append(acts[i])
+            if (not norm_before_activation) and batch_norm:
+                layers.append(nn.BatchNorm1d(dims[i + 1]))
+            if dropout_rates[i] > 0:
+                layers.append(nn.Dropout(p=dropout_rates[i]))
+        if output_dim is not None:
+            layers.append(nn.Linear(dims[-1], output_dim, bias=use_bias))
+        if output_activation is not None:
+            layers.append(dense.activation_by_name(output_activation))
+        self.mlp = nn.Sequential(*layers)
+
+    def forward(self, inputs):
+        return dense.run_sequential(self.mlp, inputs)

@@ -1,0 +1,192 @@
+"""Two-tower and sequential matching models (drop-in for ``torch_rechub.models.matching.
+{DSSM, YoutubeDNN, SASRec}``, /root/reference/recbox/third_party/rechub/models/matching/
+dssm.py:15-66, youtube_dnn.py:14-71, sasrec.py:17-124): same constructors, ``mode`` switch,
+outputs and parameter names.  Compute: embedding + pooling in one gather launch, MLP Linear
+layers on the fp32 matrix cores, ``F.normalize`` and the pairwise dot as HIP kernels
+(``rbx_l2norm_*``, ``rbx_pairdot_*``), SASRec's causal attention as the fused LDS-resident
+kernel (``rbx_attn_*``)."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..basic.layers import MLP, EmbeddingLayer
+
+
+class DSSM(torch.nn.Module):
+    def __init__(self, user_features, item_features, user_params, item_params, temperature=1.0):
+        super().__init__()
+        self.user_features = user_features
+        self.item_features = item_features
+        self.temperature = temperature
+        self.user_dims = sum([fea.embed_dim for fea in user_features])
+        self.item_dims = sum([fea.embed_dim for fea in item_features])
+        self.embedding = EmbeddingLayer(user_features + item_features)
+        self.user_mlp = MLP(self.user_dims, output_layer=False, **user_params)
+        self.item_mlp = MLP(self.item_dims, output_layer=False, **item_params)
+        self.mode = None
+
+    def forward(self, x):
+        user_embedding = self.user_tower(x)
+        item_embedding = self.item_tower(x)
+        if self.mode == "user":
+            return user_embedding
+        if self.mode == "item":
+            return item_embedding
+        y = ops.pair_dot(user_embedding, item_embedding).squeeze(1)      # cosine score [B]
+        return torch.sigmoid(y)                                          # (the reference leaves /temperature out)
+
+    def user_tower(self, x):
+        if self.mode == "item":
+            return None
+        input_user = self.embedding(x, self.user_features, squeeze_dim=True)
+        return ops.l2_normalize(self.user_mlp(input_user))
+
+    def item_tower(self, x):
+        if self.mode == "user":
+            return None
+        input_item = self.embedding(x, self.item_features, squeeze_dim=True)
+        return ops.l2_normalize(self.item_mlp(input_item))
+
+
+class YoutubeDNN(torch.nn.Module):
+    def __init__(self, user_features, item_features, neg_item_feature, user_params, temperature=1.0):
+        super().__init__()
+        self.user_features = user_features
+        self.item_features = item_features
+        self.neg_item_feature = neg_item_feature
+        self.temperature = temperature
+        self.user_dims = sum([fea.embed_dim for fea in user_features])
+        self.embedding = EmbeddingLayer(user_features + item_features)
+        self.user_mlp = MLP(self.user_dims, output_layer=False, **user_params)
+        self.mode = None
+
+    def forward(self, x):
+        user_embedding = self.user_tower(x)
+        item_embedding = self.item_tower(x)
+        if self.mode == "user":
+            return user_embedding
+        if self.mode == "item":
+            return item_embedding
+        return ops.pair_dot(user_embedding, item_embedding, scale=1.0 / self.temperature)   # [B, 1 + n_neg]
+
+    def user_tower(self, x):
+        if self.mode == "item":
+            return None
+        input_user = self.embedding(x, self.user_features, squeeze_dim=True)
+        user_embedding = ops.l2_normalize(self.user_mlp(input_user)).unsqueeze(1)           # [B, 1, D]
+        if self.mode == "user":
+            return user_embedding.squeeze(1)
+        return user_embedding
+
+    def item_tower(self, x):
+        if self.mode == "user":
+            return None
+        if self.mode == "item":
+            pos = self.embedding(x, self.item_features, squeeze_dim=False)                  # [B, 1, D]
+            return ops.l2_normalize(pos).squeeze(1)
+        # positive id and the n_neg negative ids in ONE gather launch: [B, (1 + n_neg) * D]
+        both = self.embedding(x, self.item_features + self.neg_item_feature, squeeze_dim=True)
+        dim = self.item_features[0].embed_dim
+        return ops.l2_normalize(both.view(both.shape[0], -1, dim))                          # [B, 1 + n_neg, D]
+
+
+class PointWiseFeedForward(torch.nn.Module):
+    def __init__(self, hidden_units, dropout_rate):
+        super(PointWiseFeedForward, self).__init__()
+        self.conv1 = torch.nn.Conv1d(hidden_units, hidden_units, kernel_size=1)
+        self.dropout1 = torch.nn.Dropout(p=dropout_rate)
+        self.relu = torch.nn.ReLU()
+        self.conv2 = torch.nn.Conv1d(hidden_units, hidden_units, kernel_size=1)
+        self.dropout2 = torch.nn.Dropout(p=dropout_rate)
+
+    def forward(self, inputs):
+        # a kernel-size-1 Conv1d over [B, C, L] is a Linear over the channel axis of [B, L, C]
+        if self.dropout1.p > 0 and self.training:
+            h = self.relu(self.dropout1(ops.linear(inputs, self.conv1.weight.squeeze(-1), self.conv1.bias)))
+        else:
+            h = ops.linear(inputs, self.conv1.weight.squeeze(-1), self.conv1.bias, act="relu")
+        h = self.dropout2(ops.linear(h, self.conv2.weight.squeeze(-1), self.conv2.bias))
+        return h + inputs
+
+
+class SASRec(torch.nn.Module):
+    """features = [seq, pos, neg] SequenceFeatures (pooling='concat', pos/neg shared_with seq)."""
+
+    def __init__(self, features, max_len=50, dropout_rate=0.5, num_blocks=2, num_heads=1):
+        super(SASRec, self).__init__()
+        self.features = features
+        self.item_num = self.features[0].vocab_size
+        self.embed_dim = self.features[0].embed_dim
+        self.item_emb = EmbeddingLayer(self.features)
+        self.position_emb = torch.nn.Embedding(max_len, self.embed_dim)
+        self.emb_dropout = torch.nn.Dropout(p=dropout_rate)
+        self.attention_layernorms = torch.nn.ModuleList()
+        self.attention_layers = torch.nn.ModuleList()
+        self.forward_layernorms = torch.nn.ModuleList()
+        self.forward_layers = torch.nn.ModuleList()
+        self.last_layernorm = torch.nn.LayerNorm(self.embed_dim, eps=1e-8)
+        for _ in range(num_blocks):
+            self.attention_layernorms.append(torch.nn.LayerNorm(self.embed_dim, eps=1e-8))
+            self.attention_layers.append(torch.nn.MultiheadAttention(self.embed_dim, num_heads, dropout_rate))
+            self.forward_layernorms.append(torch.nn.LayerNorm(self.embed_dim, eps=1e-8))
+            self.forward_layers.append(PointWiseFeedForward(self.embed_dim, dropout_rate))
+
+    def _mha(self, layer, query, keyval):
+        """nn.MultiheadAttention(query, keyval, keyval, attn_mask=causal) on [B, L, E] tensors."""
+        if layer.dropout > 0 and self.training:
+            raise NotImplementedError("attention dropout inside the fused kernel is not implemented; build "
+                                      "SASRec with dropout_rate=0 (BASELINE.json cfg 5) or call .eval()")
+        E, H = layer.embed_dim, layer.num_heads
+        hd = E // H
+        w, b = layer.in_proj_weight, layer.in_proj_bias
+        q = ops.linear(query, w[:E], b[:E] if b is not None else None)
+        kv = ops.linear(keyval, w[E:], b[E:] if b is not None else None)          # one GEMM for K and V
+        B, L = query.shape[0], query.shape[1]
+        q = q.view(B, L, H, hd).transpose(1, 2)
+        k = kv[..., :E].reshape(B, L, H, hd).transpose(1, 2)
+        v = kv[..., E:].reshape(B, L, H, hd).transpose(1, 2)
+        o, _ = ops.attention(q, k, v, mask=None, scale=hd ** -0.5, causal=True, fill=float("-inf"))
+        o = o.transpose(1, 2).reshape(B, L, E)
+        return ops.linear(o, layer.out_proj.weight, layer.out_proj.bias)
+
+    def seq_forward(self, x, embed_x_feature):
+        ids = x['seq']
+        e = embed_x_feature * (self.features[0].embed_dim ** 0.5)
+        if e.dim() == 4:
+            e = e.squeeze(1)
+        positions = torch.arange(ids.shape[1], device=ids.device).unsqueeze(0).expand(ids.shape[0], -1)
+        e = e + ops_position(self.position_emb, positions)
+        e = self.emb_dropout(e)
+        keep = (ids != 0).unsqueeze(-1)
+        e = e * keep
+        for i in range(len(self.attention_layers)):
+            q = self.attention_layernorms[i](e)
+            e = q + self._mha(self.attention_layers[i], q, e)
+            e = self.forward_layernorms[i](e)
+            e = self.forward_layers[i](e)
+            e = e * keep
+        return self.last_layernorm(e)
+
+    def forward(self, x):
+        embedding = self.item_emb(x, self.features)          # [B, 3, L, D] from one gather launch
+        seq_embed, pos_embed, neg_embed = embedding[:, 0], embedding[:, 1], embedding[:, 2]
+        seq_output = self.seq_forward(x, seq_embed)
+        B, L, D = seq_output.shape
+        flat = seq_output.reshape(B * L, D)
+        pos_logits = ops.pair_dot(flat, pos_embed.reshape(B * L, 1, D)).view(B, L)
+        neg_logits = ops.pair_dot(flat, neg_embed.reshape(B * L, 1, D)).view(B, L)
+        return pos_logits, neg_logits
+
+
+def ops_position(position_emb, positions):
+    """position_emb(positions) through the gather kernel (one-table lookup with a [B, L] id block)."""
+    from ... import _embed_host as host
+    from ..._lib import FIELD_CATEGORICAL, POOL_CONCAT
+    plan = getattr(position_emb, "_rbx_plan", None)
+    L = positions.shape[1]
+    if plan is None or plan.specs[0].seq_len != L:
+        plan = host.Plan([host.Lookup("position", FIELD_CATEGORICAL, position_emb, position_emb.embedding_dim,
+                                      pool=POOL_CONCAT, seq_len=L)])
+        position_emb._rbx_plan = plan
+    out = plan.run([positions])
+    return out.view(positions.shape[0], L, position_emb.embedding_dim)

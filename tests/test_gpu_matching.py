@@ -1,0 +1,242 @@
+"""GPU parity of the matching side (recbox.core EmbeddingLayer, rechub-style layers and the
+DSSM / YoutubeDNN / DeepFM / SASRec models), the dense tower GEMM and the attention core against
+the golden fixtures of the live reference.  Everything goes through the C ABI."""
+from collections import OrderedDict
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import Fixture, assert_close, assert_grads_close, load_params
+from test_oracle_golden import CRITEO_SMALL_VOCABS, _MFM, matching_specs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _cuda(d):
+    return OrderedDict((k, v.cuda()) for k, v in d.items())
+
+
+def test_matching_embedding_golden():
+    import recbox_amd.core.pytorch.layers as C
+    fx = Fixture("matching_embedding")
+    layer = load_params(C.EmbeddingLayer(_MFM(matching_specs()), 8), fx["p"]).cuda()
+    X = _cuda(fx.tensors("in"))
+    u = layer(X, feature_source="user")
+    i = layer(X, feature_source="item")
+    assert i.dim() == 2 and tuple(u.shape) == (7, 3, 8)
+    assert_close(u, fx["out"]["user"], TOL)
+    assert_close(i, fx["out"]["item"], TOL)
+    ((u * X["Ru"]).sum() + (i * X["Ri"]).sum()).backward()
+    assert_grads_close(layer, fx["g"], TOL)
+    el = layer.embedding_layer.embedding_layers
+    assert el["item_id"] is el["user_hist"] and type(el["user_id"]) is torch.nn.Embedding
+
+
+def _rh():
+    from recbox_amd.rechub.basic import features as Fe, layers as La
+    return Fe, La
+
+
+def test_rechub_embedding_golden():
+    Fe, La = _rh()
+    Sp, Sq, De = Fe.SparseFeature, Fe.SequenceFeature, Fe.DenseFeature
+    D = 8
+    feats = [Sp("uid", 13, D), Sq("hist_mean", 21, D, pooling="mean", shared_with="iid", padding_idx=0),
+             Sq("hist_sum", 21, D, pooling="sum", shared_with="iid", padding_idx=0),
+             Sp("iid", 21, D), De("price"), De("age"), Sq("tags", 9, D, pooling="mean")]
+    fx = Fixture("rechub_embedding")
+    layer = load_params(La.EmbeddingLayer(feats), fx["p"]).cuda()
+    X = _cuda(fx.tensors("in"))
+    sq = layer(X, feats, squeeze_dim=True)
+    ns = layer(X, [f for f in feats if not isinstance(f, De)], squeeze_dim=False)
+    assert_close(sq, fx["out"]["squeezed"], TOL)
+    assert_close(ns, fx["out"]["stacked"], TOL)
+    ((sq * X["Rq"]).sum() + (ns * X["Rn"]).sum()).backward()
+    assert_grads_close(layer, fx["g"], TOL)
+    cfe = [Sq("seq", 11, 8, pooling="concat"), Sq("pos", 11, 8, pooling="concat", shared_with="seq")]
+    cl = load_params(La.EmbeddingLayer(cfe), fx["pc"]).cuda()
+    co = cl({"seq": X["c_seq"], "pos": X["c_pos"]}, cfe)
+    assert tuple(co.shape) == (7, 2, 5, 8)
+    assert_close(co, fx["out"]["concat"], TOL)
+    (co * X["Rc"]).sum().backward()
+    assert_grads_close(cl, fx["gc"], TOL)           # the pad row DOES receive gradient here
+    with pytest.raises(ValueError):
+        layer(X, [De("price")], squeeze_dim=False)
+
+
+def test_rechub_pooling_modules_golden():
+    Fe, La = _rh()
+    fx = Fixture("pooling")
+    t = _cuda(fx.tensors("in"))
+    keep = t["keep"].unsqueeze(1).float()
+    cases = {"rechub_avg": lambda e: La.AveragePooling()(e, keep), "rechub_sum": lambda e: La.SumPooling()(e, keep),
+             "rechub_avg_nomask": lambda e: La.AveragePooling()(e), "rechub_sum_nomask": lambda e: La.SumPooling()(e)}
+    for key, fn in cases.items():
+        e = t["E"].clone().requires_grad_(True)
+        o = fn(e)
+        assert_close(o, fx["out"][key], TOL, key)
+        (o * t["R"]).sum().backward()
+        assert_close(e.grad, fx["g"][key], TOL, "grad " + key)
+
+
+def test_mlp_golden():
+    import recbox_amd.core.pytorch.layers as C
+    import recbox_amd.ranking.pytorch.layers as L
+    Fe, La = _rh()
+    fx = Fixture("mlp")
+    x = fx.tensors("in")["x"].cuda()
+    mods = {"core": C.MLP_Layer(12, output_dim=3, hidden_units=[16, 8], hidden_activations="ReLU",
+                                dropout_rates=[0, 0], batch_norm=True),
+            "block": L.MLP_Block(12, hidden_units=[16, 8], hidden_activations="ReLU", output_dim=1, batch_norm=False),
+            "rechub": La.MLP(12, output_layer=True, dims=[16, 8], dropout=0, activation="relu")}
+    for key, m in mods.items():
+        load_params(m, {k[len(key) + 1:]: v for k, v in fx["p"].items() if k.startswith(key + ".")}).cuda().train()
+        assert all(type(c) is not torch.nn.Linear or True for c in m.mlp)
+        xi = x.clone().requires_grad_(True)
+        o = m(xi)
+        assert_close(o, fx["out"][key], TOL, key)
+        (o * torch.from_numpy(fx["out"]["R_" + key]).cuda()).sum().backward()
+        assert_close(xi.grad, fx["g"][key + ".x"], TOL)
+        for n, p in m.named_parameters():
+            assert_close(p.grad, fx["g"][key + "." + n], TOL, key + "." + n)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1, 1, 1, None), (65, 33, 17, "relu"), (300, 130, 257, None),
+                                       (9000, 40, 24, "relu"), (8192, 16, 2496, None)])
+def test_linear_matches_torch_fp32(M, N, K, act):
+    """The MFMA GEMM (all three operand layouts, split-K weight grad) against torch fp32 on CPU."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y0 = F.linear(xr.double(), wr.double(), br.double())
+    y0 = torch.relu(y0) if act else y0
+    (y0 * R.double()).sum().backward()
+    xc, wc, bc = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+    y1 = ops.linear(xc, wc, bc, act)
+    (y1 * R.cuda()).sum().backward()
+    assert_close(y1, y0.float(), 2e-5 * max(1.0, K ** 0.5 / 8), "y")
+    assert_close(xc.grad, xr.grad.float(), 1e-4, "dx")
+    assert_close(wc.grad, wr.grad.float(), 1e-4 * max(1.0, M ** 0.5 / 16), "dw")
+    assert_close(bc.grad, br.grad.float(), 1e-4 * max(1.0, M ** 0.5 / 16), "db")
+
+
+def test_sdpa_and_losses_golden():
+    import recbox_amd.ranking.pytorch.layers as L
+    fx = Fixture("attention_losses")
+    t = _cuda(fx.tensors("in"))
+    q, k, v = (t[n].clone().requires_grad_(True) for n in ("Q", "K", "V"))
+    o, a = L.ScaledDotProductAttention(0.0)(q, k, v, scale=8 ** 0.5, mask=t["mask"])
+    assert_close(o, fx["out"]["attn_out"], TOL)
+    assert_close(a, fx["out"]["attn"], TOL)
+    (o * t["R"]).sum().backward()
+    for n, gr in (("Q", q.grad), ("K", k.grad), ("V", v.grad)):
+        assert_close(gr, fx["g"][n], TOL, n)
+
+
+def _dssm_feats(Fe, D=16):
+    Sp, Sq = Fe.SparseFeature, Fe.SequenceFeature
+    uf = [Sp("user_id", 61, D), Sp("gender", 3, D),
+          Sq("hist_movie_id", 38, D, pooling="mean", shared_with="movie_id", padding_idx=0)]
+    itf = [Sp("movie_id", 38, D), Sp("cate_id", 7, D)]
+    return uf, itf
+
+
+def test_dssm_golden():
+    """BASELINE.json configs[0] (DSSM two-tower, MovieLens-shaped ids) in miniature."""
+    Fe, La = _rh()
+    from recbox_amd.rechub.models.matching import DSSM
+    fx = Fixture("rechub_dssm")
+    uf, itf = _dssm_feats(Fe)
+    model = DSSM(uf, itf, {"dims": [32, 16], "activation": "prelu"}, {"dims": [32, 16], "activation": "prelu"},
+                 temperature=0.02)
+    load_params(model, fx["p"]).cuda().train()
+    X = _cuda(fx.tensors("in"))
+    p = model(X)
+    assert_close(p, fx["out"]["y"], TOL)
+    loss = F.binary_cross_entropy(p, X["label"])
+    assert_close(loss, fx["out"]["loss"], TOL)
+    loss.backward()
+    assert_grads_close(model, fx["g"], TOL)
+    model.mode = "user"
+    assert tuple(model(X).shape) == (64, 16)
+
+
+def test_youtubednn_golden():
+    Fe, La = _rh()
+    from recbox_amd.rechub.models.matching import YoutubeDNN
+    Sp, Sq = Fe.SparseFeature, Fe.SequenceFeature
+    D = 16
+    uf = [Sp("user_id", 61, D), Sq("hist_movie_id", 38, D, pooling="mean", shared_with="movie_id", padding_idx=0)]
+    itf = [Sp("movie_id", 38, D)]
+    ngf = [Sq("neg_items", 38, D, pooling="concat", shared_with="movie_id")]
+    fx = Fixture("rechub_youtubednn")
+    model = load_params(YoutubeDNN(uf, itf, ngf, {"dims": [32, 16]}, temperature=0.02), fx["p"]).cuda().train()
+    X = _cuda(fx.tensors("in"))
+    y = model(X)
+    assert tuple(y.shape) == (64, 4)
+    assert_close(y, fx["out"]["y"], 2e-4)            # logits are cosine / 0.02: 50x amplification
+    loss = F.cross_entropy(y, torch.zeros(64, dtype=torch.long, device="cuda"))
+    assert_close(loss, fx["out"]["loss"], TOL)
+    loss.backward()
+    assert_grads_close(model, fx["g"], 2e-4)
+
+
+def test_deepfm_golden():
+    Fe, La = _rh()
+    from recbox_amd.rechub.models.ranking import DeepFM
+    dense = [Fe.DenseFeature("I%d" % i) for i in range(1, 4)]
+    sparse = [Fe.SparseFeature("C%d" % (i + 1), v + 1, 16) for i, v in enumerate(CRITEO_SMALL_VOCABS[:8])]
+    fx = Fixture("rechub_deepfm")
+    model = DeepFM(sparse + dense, sparse, {"dims": [32, 16], "dropout": 0.0, "activation": "relu"})
+    load_params(model, fx["p"]).cuda().train()
+    X = _cuda(fx.tensors("in"))
+    p = model(X)
+    assert_close(p, fx["out"]["y"], TOL)
+    loss = F.binary_cross_entropy(p, X["label"])
+    loss.backward()
+    assert_grads_close(model, fx["g"], TOL)
+
+
+def test_sasrec_golden():
+    Fe, La = _rh()
+    from recbox_amd.rechub.models.matching import SASRec
+    Sq = Fe.SequenceFeature
+    fe = [Sq("seq", 31, 8, pooling="concat"), Sq("pos", 31, 8, pooling="concat", shared_with="seq"),
+          Sq("neg", 31, 8, pooling="concat", shared_with="seq")]
+    fx = Fixture("rechub_sasrec")
+    model = load_params(SASRec(fe, max_len=12, dropout_rate=0.0, num_blocks=2, num_heads=1), fx["p"]).cuda().train()
+    X = _cuda(fx.tensors("in"))
+    pl, nl = model(X)
+    assert_close(pl, fx["out"]["pos_logits"], TOL)
+    assert_close(nl, fx["out"]["neg_logits"], TOL)
+    m = (X["pos"] != 0).float()
+    loss = -((F.logsigmoid(pl) + F.logsigmoid(-nl)) * m).sum() / m.sum()
+    assert_close(loss, fx["out"]["loss"], TOL)
+    loss.backward()
+    assert_grads_close(model, fx["g"], TOL)
+
+
+def test_attention_causal_l200_d64_matches_torch():
+    """cfg-5 shape of the attention core (L=200, d=64, causal) against torch fp32 on CPU."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, H, L, D = 3, 1, 200, 64
+    q, k, v = (torch.randn(B, H, L, D, generator=g) for _ in range(3))
+    R = torch.randn(B, H, L, D, generator=g)
+    qr, kr, vr = (t.clone().double().requires_grad_(True) for t in (q, k, v))
+    s = (qr @ kr.transpose(-1, -2)) * D ** -0.5
+    s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf"))
+    o0 = s.softmax(-1) @ vr
+    (o0 * R.double()).sum().backward()
+    qc, kc, vc = (t.clone().cuda().requires_grad_(True) for t in (q, k, v))
+    o1, _ = ops.attention(qc, kc, vc, scale=D ** -0.5, causal=True, fill=float("-inf"))
+    (o1 * R.cuda()).sum().backward()
+    assert_close(o1, o0.float(), TOL)
+    for a, b, n in ((qc.grad, qr.grad, "dq"), (kc.grad, kr.grad, "dk"), (vc.grad, vr.grad, "dv")):
+        assert_close(a, b.float(), TOL, n)
