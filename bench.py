@@ -84,33 +84,60 @@ def init_weights(model, seed=0, std=0.1):
 
 def cpu_baseline(dim, B, dist, budget_s):
     """The oracle (a restatement of the reference's op sequence in plain PyTorch CPU ops)
-    timed on this box's host cores, same shapes, fwd+bwd, no optimiser step."""
+    timed on this box's host cores, same shapes, fwd+bwd, no optimiser step.  ATen's CPU
+    embedding/backward kernels do not scale to hundreds of threads, so the thread count is
+    picked by a short calibration (one step each at 1/8 batch) and reported as `cores`."""
     from oracle import torch_ref as R
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     fmw = CriteoFeatureMap(dim)
     model = R.RefFMModel(fmw.fm, dim)
     init_weights(model)
     batch = synthetic_batch(B, 1, dist, "cpu")
     X, y = slice_inputs(fmw.fm, batch)
 
-    def step():
+    def step(Xs, ys):
         for p in model.parameters():
             p.grad = None
-        loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(model(X)), y, reduction="mean")
+        loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(model(Xs)), ys, reduction="mean")
         loss.backward()
 
-    step()                                   # warm-up
+    small = max(B // 8, 1)
+    Xs = OrderedDict((k, v[:small]) for k, v in X.items())
+    ys = y[:small]
+    best, best_t = ncpu, None
+    for threads in sorted(set(t for t in (ncpu, 64, 32, 16, 8) if t <= ncpu), reverse=True):
+        torch.set_num_threads(threads)
+        step(Xs, ys)
+        t0 = time.perf_counter()
+        step(Xs, ys)
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best, best_t = threads, dt
+    torch.set_num_threads(best)
+    step(X, y)                                   # warm-up at full size
     t0, n = time.perf_counter(), 0
     while True:
-        step()
+        step(X, y)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 20:
             break
-    return {"value": B * n / el, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d full steps of the same workload (B=%d, dim=%d, %s ids) on torch CPU ops, %d threads"
-                      % (n, B, dim, dist, cores)}
+    return {"value": B * n / el, "unit": "samples/s", "cores": best, "kind": "port",
+            "sample": "%d full steps of the same workload (B=%d, dim=%d, %s ids) on torch CPU ops, %d of %d "
+                      "hardware threads (fastest of a 1/8-batch calibration)" % (n, B, dim, dist, best, ncpu)}
+
+
+def measured_traffic(path, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/traffic_r01.json; FETCH_SIZE / WRITE_SIZE are collected in separate runs and
+    corrected as MI355X_MICROARCH.md prescribes).  None when no measurement is on file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as fh:
+            rec = json.load(fh)
+        ent = rec.get(path, {})
+        return ent.get("hbm_bytes_per_launch") if ent.get("kernel") == kernel else None
+    except Exception:
+        return None
 
 
 def main():
@@ -214,7 +241,9 @@ def main():
         if kms:
             achieved = per_sample * B / (kms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": None, "kernel": kname,
+                    "frac": achieved / 8000.0,
+                    "traffic": measured_traffic(args.path, kname) if (B == 65536 and args.dim == 16) else None,
+                    "kernel": kname,
                     "kernel_ms": kms, "algorithmic_bytes_per_launch": per_sample * B}
         out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
                "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,

@@ -14,8 +14,8 @@ def main():
         short = name.split("(")[0].replace("void ", "")
         if len(short) > 72:
             short = short[:69] + "..."
-        extra = "  %8.1f" % (total / 1000.0 / steps) if steps else ""
-        print("%-72s %7d %12.1f %10.2f %6.2f%s" % (short, calls, total / 1000.0, avg / 1000.0, pct, extra))
+        extra = "  %8.1f" % (total / steps) if steps else ""          # the view reports microseconds
+        print("%-72s %7d %12.1f %10.2f %6.2f%s" % (short, calls, total, avg, pct, extra))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,70 @@
+"""Collectives used by the sharded embedding path, on top of ``torch.distributed``.
+
+On the GPU box the backend is "nccl", which on ROCm builds IS RCCL over xGMI: variable-size
+all-to-all maps to ``all_to_all_single`` (grouped send/recv on the current HIP stream, one
+direct xGMI link per peer on a fully connected 8-GPU node).  gloo (CPU tests) has no
+all-to-all, so the same exchange is expressed with batched point-to-point there.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world(group=None):
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def exchange_counts(send_counts, group=None):
+    """send_counts: int64 tensor [W] (rows this rank sends to each peer) -> recv_counts list[W]."""
+    rank, W = world(group)
+    if W == 1:
+        return [int(send_counts[0])]
+    if dist.get_backend(group) == "nccl":
+        recv = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv, send_counts, group=group)
+        return recv.tolist()
+    table = [torch.empty_like(send_counts) for _ in range(W)]
+    dist.all_gather(table, send_counts, group=group)
+    return [int(t[rank]) for t in table]
+
+
+def all_to_all_rows(x, send_counts, recv_counts, group=None):
+    """x: [sum(send_counts), ...] rows grouped by destination rank -> [sum(recv_counts), ...]
+    rows grouped by source rank."""
+    rank, W = world(group)
+    out = x.new_empty((sum(recv_counts),) + tuple(x.shape[1:]))
+    if W == 1:
+        out.copy_(x)
+        return out
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(out, x.contiguous(), list(recv_counts), list(send_counts), group=group)
+        return out
+    # gloo: batched point-to-point with the same semantics
+    ops, so, ro = [], 0, 0
+    x = x.contiguous()
+    for peer in range(W):
+        s, r = send_counts[peer], recv_counts[peer]
+        if peer == rank:
+            out[ro:ro + r].copy_(x[so:so + s])
+        else:
+            if s > 0:
+                ops.append(dist.P2POp(dist.isend, x[so:so + s].contiguous(), peer, group=group))
+            if r > 0:
+                ops.append(dist.P2POp(dist.irecv, out[ro:ro + r], peer, group=group))
+        so += s
+        ro += r
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
+
+
+def all_reduce_grads(params, group=None):
+    """Data-parallel towers: one all-reduce (sum) per dense gradient."""
+    _, W = world(group)
+    if W == 1:
+        return
+    for p in params:
+        if p.grad is not None:
+            dist.all_reduce(p.grad, group=group)
