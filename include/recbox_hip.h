@@ -141,8 +141,10 @@ int rbx_interaction_bwd(const float* d_emb, const float* d_dout, int64_t batch, 
  *   d_sum[B,D] = sum_f e_f   (kept for the backward; may be NULL for inference)
  * Backward: row r of table f gets  dW[r] += sum_b g_b S_b - w_r * sum_b g_b  and
  * dW_lr[r] += sum_b g_b  over the samples b that looked r up (sorted, segmented,
- * deterministic); numeric weights and the bias are batch reductions.  Grads accumulate
- * into emb[i].grad / lr[i].grad (dense) and d_dbias[1]. */
+ * deterministic); numeric weights and the bias are batch reductions.  Grads go into
+ * emb[i].grad / lr[i].grad (dense; stored when accumulate == 0, added otherwise) and d_dbias[1].
+ * phases: bit 0 = categorical tables (needs the sort), bit 1 = numeric weights + bias (does
+ * not): a caller that sorts on another stream runs phase 2 first and phase 1 after the join. */
 int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                const float* d_lr_bias, float* d_logit, float* d_sum, int32_t* d_status, void* stream);
 size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch);
@@ -150,7 +152,7 @@ int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields,
                 void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream);
 int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                const float* d_dlogit, const float* d_sum, float* d_dbias, int32_t accumulate,
-               void* d_workspace, size_t workspace_bytes, void* stream);
+               int32_t phases, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K5: two-tower scoring (third_party/rechub/models/matching/dssm.py:48,57,65,
  * youtube_dnn.py:47-48,56,65,70).  l2norm = F.normalize(x, p=2, dim=-1, eps): y = x / max(||x||, eps);

@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
                                                            int* __restrict__ status) {
   constexpr int W = VEC ? 4 : 1;
   constexpr int NA = NV * W;
-  constexpr int U = 8;
+  // features in flight per lane.  8 is the measured optimum at D=16 on MI355X: 16 in flight ran 1.6x
+  // SLOWER (94 vs 58 us at B=65 536) -- the gather is bound by the random-row request rate, not latency
+  constexpr int U = (NA <= 4) ? 8 : 4;
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
   for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
@@ -451,7 +453,7 @@ extern "C" int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_
 
 extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                           const float* d_dlogit, const float* d_sum, float* d_dbias, int32_t accumulate,
-                          void* d_workspace, size_t workspace_bytes, void* stream) {
+                          int32_t phases, void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace rbx;
   if (d_dlogit == nullptr) return fail(RBX_ERR_INVALID, "fm: d_dlogit is NULL");
   if (emb != nullptr && d_sum == nullptr) return fail(RBX_ERR_INVALID, "fm: d_sum from the forward is required");
@@ -467,7 +469,7 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
     return fail(RBX_ERR_WORKSPACE, "fm: workspace %zu B < required %zu B", workspace_bytes, need);
   char* ws = static_cast<char*>(d_workspace);
   hipStream_t s = as_stream(stream);
-  if (p.n_lookups > 0) {
+  if (p.n_lookups > 0 && (phases & 1)) {
     const int cur = p.passes & 1;
     const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);
     const unsigned* vals = reinterpret_cast<const unsigned*>(ws + p.off_vals[cur]);
@@ -477,7 +479,7 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
              : dispatch_reduce<FmPolicy, false>(p, args, keys, vals, ws, s);
     if (rc != RBX_OK) return rc;
   }
-  if (n_num > 0 || d_dbias != nullptr) {
+  if ((phases & 2) && (n_num > 0 || d_dbias != nullptr)) {
     float* partial = reinterpret_cast<float*>(ws + p.bytes);
     const int ns = fm_num_samples(D);
     const size_t lds = static_cast<size_t>(ns) * (D + 2 * n_num + 1) * sizeof(float);

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, co
   pre_last.zero();
   float cnt = 0.f;
   bool head_done = false;
-  constexpr int U = (NV * F::W <= 4) ? 8 : 4;      // lookups in flight per lane group
+  constexpr int U = (NV * F::W <= 4) ? 8 : 4;      // lookups in flight per lane group (16 measured slower)
   for (unsigned i0 = s; i0 < e; i0 += U) {
     unsigned kk[U + 1], vv[U];
     {
