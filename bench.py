@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python instead of replaying a hipGraph")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the row-sharded model even at world size 1 (exercises the RCCL exchange path)")
+    ap.add_argument("--shard-min-vocab", type=int, default=100000)
     ap.add_argument("--path", choices=["fused", "layers"], default="fused",
                     help="fused: FM model body in rbx_fm_fwd/bwd; layers: drop-in layers composed as the reference does")
     args = ap.parse_args()
@@ -160,17 +163,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from recbox_amd import ops
-    from recbox_amd.ranking.pytorch.models import FM
+    from recbox_amd.ranking.pytorch.models import FM, ShardedFM
     ops.config.check_ids = False              # no per-call host sync inside the timed region
     fmw = CriteoFeatureMap(args.dim)
-    model = FM(fmw.fm, args.dim, fused=(args.path == "fused")).to(dev)
-    init_weights(model)
+    sharded = world > 1 or args.force_sharded
+    if sharded:
+        # big tables row-sharded over the ranks (all-to-all-v over RCCL/xGMI), small ones replicated
+        model = ShardedFM(fmw.fm, args.dim, shard_min_vocab=args.shard_min_vocab).to(dev)
+    else:
+        model = FM(fmw.fm, args.dim, fused=(args.path == "fused")).to(dev)
+    init_weights(model)                       # same seed on every rank: replicated parameters start identical
     B = args.batch
     batch = synthetic_batch(B, 1 + rank, args.dist, dev)
     X, y = slice_inputs(fmw.fm, batch)
@@ -180,14 +189,15 @@ def main():
         model.zero_grad(set_to_none=True)
         prob = model(X)["y_pred"]
         loss = torch.nn.functional.binary_cross_entropy(prob, y, reduction="mean")
-        loss.backward()
-        if world > 1:
-            for p in model.parameters():      # data-parallel replicas: dense grads all-reduced
-                torch.distributed.all_reduce(p.grad)
+        if sharded:
+            (loss / world).backward()         # global-mean loss: shard owners sum contributions of every rank
+            model.sync_grads()                # replicated small tables / numeric weights / bias: one all-reduce
+        else:
+            loss.backward()
         return loss
 
     step = eager_step
-    if not args.eager and world == 1:
+    if not args.eager and not sharded:
         # one hipGraph holds the whole step (same kernels, same C ABI); the batch lives in static buffers
         from recbox_amd.graph import GraphedStep
         step = GraphedStep(eager_step, warmup=3)
@@ -195,7 +205,7 @@ def main():
     for _ in range(args.warmup):
         step()
     # dominant kernel = the embedding gather: fm_fused_fwd (fused path) or the [B, 39, 16] embed_fwd (layer path)
-    if args.path == "fused":
+    if args.path == "fused" or sharded:
         timer = ops.KernelTimer(lambda m: m[0] == "fm_fwd")
     else:
         timer = ops.KernelTimer(lambda m: m[0] == "embed_fwd" and m[2] == n_fields * args.dim)
@@ -229,7 +239,7 @@ def main():
         # algorithmic bytes of the gather per sample: 26 rows x 64 B
         # + 26 ids x 8 B (float64 columns) + 13 dense values x 8 B + the [39,16] fp32 slot written
         n_sparse = len(CRITEO_VOCABS)
-        if args.path == "fused":
+        if args.path == "fused" or sharded:
             # rows + float64 ids + float64 dense values + LR rows + logit + S kept for backward
             per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 8 + n_sparse * 4 + 4 + args.dim * 4
             kname = "fm_fused_fwd_kernel<%d,1,true>" % (args.dim // 4)
@@ -252,12 +262,13 @@ def main():
                "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
                                       "%s ids, %s path, %s, dense-grad autograd contract, no optimiser step"
                                       % (args.dim, B, args.dist, args.path, "eager launches" if step is eager_step else "hipGraph replay"),
-                          "global_batch": B * world, "parallelism": "dp%d" % world},
+                          "global_batch": B * world,
+                          "parallelism": ("dp%d + row-sharded tables (all-to-all-v)" % world) if sharded else "dp1"},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.dim, B, args.dist, args.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_sharded:
         torch.distributed.destroy_process_group()
 
 

@@ -146,7 +146,17 @@ int rbx_interaction_bwd(const float* d_emb, const float* d_dout, int64_t batch, 
  * phases: bit 0 = categorical tables (needs the sort), bit 1 = numeric weights + bias (does
  * not): a caller that sorts on another stream runs phase 2 first and phase 1 after the join. */
 int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
-               const float* d_lr_bias, float* d_logit, float* d_sum, int32_t* d_status, void* stream);
+               const float* d_lr_bias, const float* d_extra, int32_t n_extra, int32_t extra_stride,
+               int32_t extra_lr_off, float* d_logit, float* d_sum, int32_t* d_status, void* stream);
+/* Rows of row-sharded tables arrive from their owners instead of being gathered locally:
+ * d_extra[B, n_extra, extra_stride] holds, per (sample, table), the embedding row in floats [0, D)
+ * and the dim-1 LR weight at float extra_lr_off (-1: none); they take part in S, Q and the LR sum
+ * exactly like local features.  rbx_fm_extra_bwd writes their gradient block in the same packed
+ * layout ([g (S - e) | g at the LR slot | 0]); it travels back to the owners (recbox_amd/sharded.py).
+ * dim == 0 there means "LR weights only". */
+int rbx_fm_extra_bwd(const float* d_dlogit, const float* d_sum, const float* d_extra, int64_t batch,
+                     int32_t n_extra, int32_t dim, int32_t extra_stride, int32_t extra_lr_off,
+                     float* d_dextra, void* stream);
 size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch);
 int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                 void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream);

@@ -18,7 +18,7 @@ def world(group=None):
 def exchange_counts(send_counts, group=None):
     """send_counts: int64 tensor [W] (rows this rank sends to each peer) -> recv_counts list[W]."""
     rank, W = world(group)
-    if W == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [int(send_counts[0])]
     if dist.get_backend(group) == "nccl":
         recv = torch.empty_like(send_counts)
@@ -34,7 +34,7 @@ def all_to_all_rows(x, send_counts, recv_counts, group=None):
     rows grouped by source rank."""
     rank, W = world(group)
     out = x.new_empty((sum(recv_counts),) + tuple(x.shape[1:]))
-    if W == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         out.copy_(x)
         return out
     if dist.get_backend(group) == "nccl":
@@ -58,6 +58,21 @@ def all_to_all_rows(x, send_counts, recv_counts, group=None):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return out
+
+
+def all_to_all_equal(x, group=None):
+    """x: [W * c, ...] (block p goes to rank p) -> [W * c, ...] (block p came from rank p).  Equal
+    splits need no size exchange, so on RCCL this is a single capturable collective."""
+    rank, W = world(group)
+    if not (dist.is_available() and dist.is_initialized()):
+        return x.clone()
+    x = x.contiguous()
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty_like(x)
+        dist.all_to_all_single(out, x, group=group)
+        return out
+    c = x.shape[0] // W
+    return all_to_all_rows(x, [c] * W, [c] * W, group)
 
 
 def all_reduce_grads(params, group=None):

@@ -42,6 +42,8 @@ template <int G, int NV, bool VEC>
 __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const int F, const long long B, const int D,
                                                            const bool has_emb, const bool has_lr,
                                                            const float* __restrict__ bias,
+                                                           const float* __restrict__ xe, const int n_extra,
+                                                           const int x_stride, const int x_lr_off,
                                                            float* __restrict__ logit, float* __restrict__ ssum,
                                                            int* __restrict__ status) {
   constexpr int W = VEC ? 4 : 1;
@@ -114,6 +116,26 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
         }
         lr += l1[u] * x[u];
       }
+    }
+    // rows that were fetched elsewhere (row-sharded tables: the owners sent them back): the
+    // sample's [n_extra, D] block is contiguous, so these reads are coalesced
+    for (int t = 0; t < n_extra; ++t) {
+      const float* row = xe + (b * n_extra + t) * static_cast<long long>(x_stride);
+      if (has_emb) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int d = (lane_g + v * G) * W;
+          if (d < D) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+              const float e = row[d + k];
+              s[v * W + k] += e;
+              q[v * W + k] += e * e;
+            }
+          }
+        }
+      }
+      if (x_lr_off >= 0 && lane_g == (t % G)) lr += row[x_lr_off];
     }
     float fm = 0.f;
 #pragma unroll
@@ -270,6 +292,26 @@ __global__ __launch_bounds__(64) void fm_numeric_final_kernel(const FmNumPack P,
   if (threadIdx.x == 0) fd.gw[slot] += a - fd.w[slot] * t2;
 }
 
+// d row(b,t) = [ g_b (S_b - e[b,t,:]) | ... g_b at the LR slot ... | 0 ]  in the rows' own packed layout
+// (these rows belong to another rank: the gradient block is sent back to it as is)
+__global__ __launch_bounds__(256) void fm_extra_bwd_kernel(const float* __restrict__ g, const float* __restrict__ ssum,
+                                                           const float* __restrict__ x, const long long B,
+                                                           const int n_extra, const int D, const int stride,
+                                                           const int lr_off, const bool has_emb,
+                                                           float* __restrict__ dx) {
+  const long long total = B * n_extra * stride;
+  const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += step) {
+    const long long bt = i / stride;
+    const int c = static_cast<int>(i - bt * stride);
+    const long long b = bt / n_extra;
+    float v = 0.f;
+    if (has_emb && c < D) v = g[b] * (ssum[b * D + c] - x[i]);
+    else if (c == lr_off) v = g[b];
+    dx[i] = v;
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------
 struct FmHost {
   int F = 0, D = 0;
@@ -324,28 +366,29 @@ static int fm_validate(const rbx_field_t* emb, const rbx_field_t* lr, int n, int
 }
 
 template <int G, int NV, bool VEC>
-static int launch_fm_fwd(const FmHost& h, int64_t B, const float* bias, float* logit, float* ssum, int* status,
-                         hipStream_t s) {
+static int launch_fm_fwd(const FmHost& h, int64_t B, const float* bias, const float* xe, int n_extra, int x_stride,
+                         int x_lr_off, float* logit, float* ssum, int* status, hipStream_t s) {
   const int gpb = 256 / G;
   long long blocks = (B + gpb - 1) / gpb;
   if (blocks > kCUs * 16) blocks = kCUs * 16;
   hipLaunchKernelGGL((fm_fused_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, h.pack,
-                     h.F, static_cast<long long>(B), h.D, h.has_emb, h.has_lr, bias, logit, ssum, status);
+                     h.F, static_cast<long long>(B), h.D, h.has_emb, h.has_lr, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum,
+                     status);
   return check_launch("fm_fused_fwd_kernel");
 }
 
 template <bool VEC>
-static int dispatch_fm_fwd(const FmHost& h, int64_t B, const float* bias, float* logit, float* ssum, int* status,
-                           hipStream_t s) {
+static int dispatch_fm_fwd(const FmHost& h, int64_t B, const float* bias, const float* xe, int n_extra, int x_stride,
+                           int x_lr_off, float* logit, float* ssum, int* status, hipStream_t s) {
   const int units = VEC ? h.D / 4 : h.D;
   switch (pow2_ceil(units)) {
-    case 1: return launch_fm_fwd<1, 1, VEC>(h, B, bias, logit, ssum, status, s);
-    case 2: return launch_fm_fwd<2, 1, VEC>(h, B, bias, logit, ssum, status, s);
-    case 4: return launch_fm_fwd<4, 1, VEC>(h, B, bias, logit, ssum, status, s);
-    case 8: return launch_fm_fwd<8, 1, VEC>(h, B, bias, logit, ssum, status, s);
-    case 16: return launch_fm_fwd<16, 1, VEC>(h, B, bias, logit, ssum, status, s);
-    case 32: return launch_fm_fwd<32, 1, VEC>(h, B, bias, logit, ssum, status, s);
-    case 64: return launch_fm_fwd<64, 1, VEC>(h, B, bias, logit, ssum, status, s);
+    case 1: return launch_fm_fwd<1, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
+    case 2: return launch_fm_fwd<2, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
+    case 4: return launch_fm_fwd<4, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
+    case 8: return launch_fm_fwd<8, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
+    case 16: return launch_fm_fwd<16, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
+    case 32: return launch_fm_fwd<32, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
+    case 64: return launch_fm_fwd<64, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
     default: return fail(RBX_ERR_UNSUPPORTED, "fm: embedding dim %d too large to fuse", h.D);
   }
 }
@@ -414,7 +457,8 @@ static size_t fm_num_bytes(const BwdPlan& p, int n_num, int D) {
 }  // namespace rbx
 
 extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
-                          const float* d_lr_bias, float* d_logit, float* d_sum, int32_t* d_status, void* stream) {
+                          const float* d_lr_bias, const float* d_extra, int32_t n_extra, int32_t extra_stride,
+                          int32_t extra_lr_off, float* d_logit, float* d_sum, int32_t* d_status, void* stream) {
   using namespace rbx;
   FmHost h;
   int rc = fm_validate(emb, lr, n_fields, batch, &h);
@@ -423,8 +467,17 @@ extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
   if (batch == 0) return RBX_OK;
   if (d_logit == nullptr) return fail(RBX_ERR_INVALID, "d_logit is NULL");
   if (h.vec && d_sum != nullptr && (reinterpret_cast<uintptr_t>(d_sum) & 15) != 0) h.vec = false;
-  return h.vec ? dispatch_fm_fwd<true>(h, batch, d_lr_bias, d_logit, d_sum, d_status, as_stream(stream))
-               : dispatch_fm_fwd<false>(h, batch, d_lr_bias, d_logit, d_sum, d_status, as_stream(stream));
+  if (n_extra < 0 || (n_extra > 0 && d_extra == nullptr)) return fail(RBX_ERR_INVALID, "fm: n_extra=%d without rows", n_extra);
+  if (n_extra > 0) {
+    const int need = (h.has_emb ? h.D : 0);
+    if (extra_stride < need || extra_lr_off >= extra_stride || (extra_lr_off >= 0 && extra_lr_off < need))
+      return fail(RBX_ERR_INVALID, "fm: extra rows: stride %d / lr offset %d do not fit dim %d", extra_stride,
+                  extra_lr_off, need);
+  }
+  return h.vec ? dispatch_fm_fwd<true>(h, batch, d_lr_bias, d_extra, n_extra, extra_stride, extra_lr_off, d_logit, d_sum,
+                                       d_status, as_stream(stream))
+               : dispatch_fm_fwd<false>(h, batch, d_lr_bias, d_extra, n_extra, extra_stride, extra_lr_off, d_logit,
+                                        d_sum, d_status, as_stream(stream));
 }
 
 extern "C" size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields,
@@ -491,4 +544,22 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
     if (rc != RBX_OK) return rc;
   }
   return RBX_OK;
+}
+
+extern "C" int rbx_fm_extra_bwd(const float* d_dlogit, const float* d_sum, const float* d_extra, int64_t batch,
+                                int32_t n_extra, int32_t dim, int32_t extra_stride, int32_t extra_lr_off,
+                                float* d_dextra, void* stream) {
+  using namespace rbx;
+  if (d_dlogit == nullptr || d_dextra == nullptr) return fail(RBX_ERR_INVALID, "fm_extra_bwd: NULL tensor");
+  const bool has_emb = dim > 0;
+  if (has_emb && (d_sum == nullptr || d_extra == nullptr))
+    return fail(RBX_ERR_INVALID, "fm_extra_bwd: S and the extra rows are needed for dE");
+  if (batch <= 0 || n_extra <= 0) return RBX_OK;
+  const long long total = static_cast<long long>(batch) * n_extra * extra_stride;
+  long long blocks = (total + 255) / 256;
+  if (blocks > kCUs * 8) blocks = kCUs * 8;
+  hipLaunchKernelGGL(fm_extra_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_dlogit,
+                     d_sum, d_extra, static_cast<long long>(batch), n_extra, dim, extra_stride, extra_lr_off, has_emb,
+                     d_dextra);
+  return check_launch("fm_extra_bwd_kernel");
 }

@@ -10,7 +10,7 @@ from torch import nn
 from ... import ops
 from .layers import FactorizationMachine, FeatureEmbedding
 
-__all__ = ["FM"]
+__all__ = ["FM", "ShardedFM"]
 
 
 class FM(nn.Module):
@@ -36,3 +36,84 @@ class FM(nn.Module):
 
     def forward(self, X):
         return {"y_pred": torch.sigmoid(self.logits(X))}
+
+
+class ShardedFM(nn.Module):
+    """FM over the GPUs of one node: one process per GPU, every process trains on its own
+    slice of the global batch.
+
+    * categorical tables with ``vocab_size >= shard_min_vocab`` are ROW-SHARDED (``ShardedTables``: embedding rows
+      and LR weights of all such tables behind one all-to-all-v exchange each way over RCCL/xGMI);
+    * the remaining (small) tables, numeric weights and the bias are replicated; ``sync_grads()`` all-reduces
+      their dense gradients in one flat buffer.
+
+    The fetched remote rows enter the fused FM kernel as ``extra`` rows, so the local compute stays the same
+    single forward kernel + fused segmented backward as on one GPU."""
+
+    def __init__(self, feature_map, embedding_dim=10, shard_min_vocab=100000, capacity_factor=None,
+                 process_group=None, local_ops=None):
+        super(ShardedFM, self).__init__()
+        from collections import OrderedDict
+        from ...sharded import ShardedTables
+        from ... import comm
+        self.group = process_group
+        self.world_size = comm.world(process_group)[1]
+        self.sharded_names = [n for n, s in feature_map.features.items()
+                              if s["type"] == "categorical" and s.get("vocab_size", 0) >= shard_min_vocab]
+        local_map = _SubFeatureMap(feature_map, OrderedDict((n, s) for n, s in feature_map.features.items()
+                                                            if n not in self.sharded_names))
+        self.embedding_layer = FeatureEmbedding(local_map, embedding_dim)
+        self.fm = FactorizationMachine(local_map)
+        self.tables = None
+        if self.sharded_names:
+            self.tables = ShardedTables([feature_map.features[n]["vocab_size"] for n in self.sharded_names],
+                                        embedding_dim, with_lr=True, capacity_factor=capacity_factor,
+                                        process_group=process_group, local_ops=local_ops)
+
+    def replicated_parameters(self):
+        return list(self.embedding_layer.parameters()) + list(self.fm.parameters())
+
+    def logits(self, X):
+        emb = self.embedding_layer.embedding_layer
+        lr = self.fm.lr_layer.embedding_layer.embedding_layer
+        names, values, plan, posts = emb.plan_for(X)
+        lnames, _, lplan, lposts = lr.plan_for(X)
+        if not (emb.fusable(plan, posts) and lr.fusable(lplan, lposts) and names == lnames):
+            raise NotImplementedError("ShardedFM fuses one-id-per-sample categorical and numeric features only")
+        packed, lr_off = None, -1
+        if self.tables is not None:
+            ids = torch.stack([X[n].long() for n in self.sharded_names], dim=1)        # [B, T]
+            packed, lr_off = self.tables(ids), self.tables.lr_off                      # [B, T, D + 4] from the owners
+        return ops.fm_fused(plan.plan, lplan.plan, values, [m.weight for m in plan.modules],
+                            [m.weight for m in lplan.modules], self.fm.lr_layer.bias, extra=packed,
+                            extra_lr_off=lr_off)
+
+    def forward(self, X):
+        return {"y_pred": torch.sigmoid(self.logits(X))}
+
+    def sync_grads(self):
+        """All-reduce (sum) the dense gradients of the replicated parameters as ONE flat buffer."""
+        if self.world_size == 1:
+            return
+        import torch.distributed as dist
+        grads = [p.grad for p in self.replicated_parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, group=self.group)
+        o = 0
+        for g in grads:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+
+
+class _SubFeatureMap(object):
+    """A view of a ranking FeatureMap restricted to some features (same attribute surface)."""
+
+    def __init__(self, parent, features):
+        self.features = features
+        self.num_fields = sum(1 for s in features.values() if s["type"] != "meta")
+        self.data_dir = getattr(parent, "data_dir", None)
+        self.dataset_id = getattr(parent, "dataset_id", None)
+        self.default_emb_dim = getattr(parent, "default_emb_dim", None)
+        self.labels = getattr(parent, "labels", [])

@@ -1,18 +1,27 @@
-"""Row-sharded embedding table over the GPUs of one node.
+"""Row-sharded embedding tables over the GPUs of one node.
 
 The reference has no model-parallel embedding (single ``torch.device``; DataParallel / DDP only in
 vendored trainers); this is the MI355X-native scaling path for tables that should not
 be replicated: ``owner(id) = id % W``, local row ``id // W``.  One exchange each way:
 
-  forward   bucket ids by owner -> all-to-all-v(ids) -> owner gathers rows (rbx_embed_fwd) ->
-            all-to-all-v(rows) back -> un-permute
-  backward  permute dY -> all-to-all-v(dY) -> owner scatter-adds into its shard's dense grad
+  forward   bucket lookups by owner -> all-to-all(row numbers) -> owner gathers rows (rbx_embed_fwd)
+            -> all-to-all(rows) back -> un-permute
+  backward  permute dY -> all-to-all(dY) -> owner scatter-adds into its shard's dense grad
             (rbx_embed_sort + rbx_embed_bwd: sorted, segmented, deterministic)
 
 xGMI is point-to-point (7 links per GPU): an all-to-all keeps every link busy at once, so the
 exchange time is max_peer_bytes / link_bw rather than a ring's 2(N-1)/N * S / link_bw.
-Small tables stay replicated (``comm.all_reduce_grads``): cheaper than exchanging.
+Small tables stay replicated (their dense grads are all-reduced): cheaper than exchanging.
+
+Two exchange modes:
+  exact   variable-size all-to-all-v; needs the per-peer counts on the host (one sync per call).
+  padded  every rank sends exactly ``capacity`` slots to every peer (empty slots carry row -1):
+          no host sync, fixed shapes, so the WHOLE training step -- routing, RCCL exchanges, fused
+          kernels -- can be captured in one hipGraph.  A lookup that does not fit sets the
+          ``overflow`` flag (checked by the caller after the step) instead of being dropped silently.
 """
+import math
+
 import torch
 from torch import nn
 
@@ -20,28 +29,48 @@ from . import comm
 
 
 class HipLocalOps(object):
-    """Local gather / scatter-add of one shard through the C ABI."""
+    """Local gather / scatter-add of one shard through the C ABI (plans are cached per shard shape)."""
+
+    def __init__(self):
+        self._plans = {}
+
+    def _plan(self, weight):
+        from . import ops
+        from ._lib import FIELD_CATEGORICAL, POOL_NONE
+        key = tuple(weight.shape)
+        plan = self._plans.get(key)
+        if plan is None:
+            spec = ops.FieldSpec("shard", FIELD_CATEGORICAL, weight.shape[1], 0, param=0, pool=POOL_NONE,
+                                 vocab=weight.shape[0])
+            plan = ops.EmbedPlan([spec], weight.shape[1])
+            self._plans[key] = plan
+        return plan
 
     def gather(self, weight, rows):
-        from . import _embed_host as host
-        from ._lib import FIELD_CATEGORICAL
-        holder = _Holder(weight)
-        plan = host.Plan([host.Lookup("shard", FIELD_CATEGORICAL, holder, weight.shape[1])])
-        return plan.run([rows]).detach()
+        """rows [n] (row -1 = empty slot -> zero vector) -> [n, width]."""
+        from . import ops
+        from ._lib import check, lib
+        n = rows.numel()
+        out = torch.empty((n, weight.shape[1]), dtype=torch.float32, device=weight.device)
+        if n == 0:
+            return out
+        plan = self._plan(weight)
+        plan.bind_inputs([rows])
+        plan.bind_params([weight.detach()])
+        check(lib.rbx_embed_fwd(plan.arr, 1, n, ops._ptr(out), weight.shape[1], None, None, ops._stream()))
+        return out
 
     def scatter_add(self, weight, rows, dy):
-        """dense [n_local, D] gradient of ``gather`` w.r.t. weight."""
+        """dense [n_local, width] gradient of ``gather`` w.r.t. weight (rows < 0 are skipped)."""
         from . import ops
-        from ._lib import FIELD_CATEGORICAL, POOL_NONE, check, lib
+        from ._lib import check, lib
         n = rows.numel()
         grad = torch.zeros_like(weight)
         if n == 0:
             return grad
-        spec = ops.FieldSpec("shard", FIELD_CATEGORICAL, weight.shape[1], 0, param=0, pool=POOL_NONE,
-                             vocab=weight.shape[0])
-        plan = ops.EmbedPlan([spec], weight.shape[1])
+        plan = self._plan(weight)
         plan.bind_inputs([rows])
-        plan.bind_params([weight], [grad])
+        plan.bind_params([weight.detach()], [grad])
         ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
         st = ops._stream()
@@ -51,44 +80,79 @@ class HipLocalOps(object):
         return grad
 
 
-class _Holder(nn.Embedding):
-    """nn.Embedding view over an existing weight tensor (no copy), for the planner."""
+class _ExactLookup(torch.autograd.Function):
+    """(owner, row) lookups, variable-size exchange (one host sync for the counts)."""
 
-    def __init__(self, weight):
-        nn.Module.__init__(self)
-        self.num_embeddings, self.embedding_dim = weight.shape
-        self.padding_idx = None
-        self.weight = weight
-
-
-class _ShardedLookup(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, weight, group, local_ops):
+    def forward(ctx, owner, row, group, local_ops, out_shape, weight):
         rank, W = comm.world(group)
-        flat = ids.reshape(-1).long()
-        owner = flat % W
-        perm = torch.argsort(owner, stable=True)                 # rows grouped by destination rank
-        send_rows = (flat // W)[perm]
+        owner = owner.reshape(-1)
+        row = row.reshape(-1)
+        perm = torch.argsort(owner, stable=True)                 # lookups grouped by destination rank
+        send_rows = row[perm]
         send_counts_t = torch.bincount(owner, minlength=W)
         send_counts = send_counts_t.tolist()                     # sizes of the variable all-to-all (host sync)
         recv_counts = comm.exchange_counts(send_counts_t, group)
-        recv_rows = comm.all_to_all_rows(send_rows, send_counts, recv_counts, group)      # ids out
+        recv_rows = comm.all_to_all_rows(send_rows, send_counts, recv_counts, group)      # row numbers out
         vecs = local_ops.gather(weight, recv_rows)                                        # owner-side gather
         back = comm.all_to_all_rows(vecs, recv_counts, send_counts, group)                # rows back
         out = torch.empty_like(back)
         out[perm] = back
         ctx.save_for_backward(perm, recv_rows, weight)
-        ctx.meta = (send_counts, recv_counts, group, local_ops, ids.shape)
-        return out.view(*ids.shape, weight.shape[1])
+        ctx.meta = (send_counts, recv_counts, group, local_ops)
+        return out.view(*out_shape, weight.shape[1])
 
     @staticmethod
     def backward(ctx, dout):
         perm, recv_rows, weight = ctx.saved_tensors
-        send_counts, recv_counts, group, local_ops, shape = ctx.meta
+        send_counts, recv_counts, group, local_ops = ctx.meta
         d_sorted = dout.reshape(-1, weight.shape[1])[perm].contiguous()
         d_recv = comm.all_to_all_rows(d_sorted, send_counts, recv_counts, group)          # dY to the owners
-        grad = local_ops.scatter_add(weight, recv_rows, d_recv)
-        return None, grad, None, None
+        return None, None, None, None, None, local_ops.scatter_add(weight, recv_rows, d_recv)
+
+
+class _PaddedLookup(torch.autograd.Function):
+    """(owner, row) lookups, fixed-capacity exchange: static shapes, no host sync, graph-capturable."""
+
+    @staticmethod
+    def forward(ctx, owner, row, capacity, overflow, group, local_ops, out_shape, weight):
+        rank, W = comm.world(group)
+        owner = owner.reshape(-1)
+        row = row.reshape(-1)
+        n = owner.numel()
+        dev = owner.device
+        order = torch.argsort(owner, stable=True)
+        owner_s = owner[order]
+        counts = torch.zeros(W, dtype=torch.long, device=dev).scatter_add_(0, owner, torch.ones_like(owner))
+        starts = torch.cumsum(counts, 0) - counts
+        rank_in = torch.arange(n, device=dev) - starts[owner_s]
+        fits = rank_in < capacity
+        overflow.logical_or_((~fits).any())                       # reported, never silently dropped
+        dump = W * capacity                                       # one spare slot swallows what does not fit
+        slot = torch.where(fits, owner_s * capacity + rank_in, torch.full_like(rank_in, dump))
+        send = torch.full((dump + 1,), -1, dtype=torch.long, device=dev)
+        send[slot] = row[order]
+        recv = comm.all_to_all_equal(send[:dump], group)                                   # [W * capacity] rows, -1 = empty
+        vecs = local_ops.gather(weight, recv)
+        back = comm.all_to_all_equal(vecs, group)                                          # same slot numbering
+        width = weight.shape[1]
+        picked = torch.cat([back, back.new_zeros((1, width))], dim=0)[slot]                # dump slot reads zeros
+        out = torch.empty_like(picked)
+        out[order] = picked
+        ctx.save_for_backward(order, slot, recv, weight)
+        ctx.meta = (capacity, group, local_ops, W)
+        return out.view(*out_shape, width)
+
+    @staticmethod
+    def backward(ctx, dout):
+        order, slot, recv, weight = ctx.saved_tensors
+        capacity, group, local_ops, W = ctx.meta
+        width = weight.shape[1]
+        d_sorted = dout.reshape(-1, width)[order]
+        dsend = d_sorted.new_zeros((W * capacity + 1, width))
+        dsend[slot] = d_sorted
+        d_recv = comm.all_to_all_equal(dsend[:W * capacity].contiguous(), group)           # aligned with `recv`
+        return None, None, None, None, None, None, None, local_ops.scatter_add(weight, recv, d_recv)
 
 
 class ShardedEmbedding(nn.Module):
@@ -115,10 +179,81 @@ class ShardedEmbedding(nn.Module):
         self.local.weight[:rows.numel()].copy_(full[rows].to(self.local.weight.device))
 
     def forward(self, ids):
-        out = _ShardedLookup.apply(ids, self.local.weight, self.group, self.local_ops)
-        return out
+        flat = ids.long()
+        return _ExactLookup.apply(flat % self.world_size, flat // self.world_size, self.group, self.local_ops,
+                                  tuple(ids.shape), self.local.weight)
 
     def zero_pad_grad(self):
         """nn.Embedding(padding_idx) semantics for the shard that owns the pad row."""
         if self.local.padding_idx is not None and self.local.weight.grad is not None:
             self.local.weight.grad[self.local.padding_idx].zero_()
+
+
+class ShardedTables(nn.Module):
+    """T tables row-sharded together: one routing and one exchange per call for all of them.
+
+    Rank r stores, back to back, its rows of every table (``base[r][t]`` = first local row of table t
+    on rank r) in ONE packed weight ``self.weight`` of shape [rows_r, row_width]: floats [0, D) are
+    the embedding row, float D is the table's dim-1 LR weight (``with_lr``), the rest pads the row to
+    a multiple of 4 floats so that gathers, the wire format and the fused FM kernel stay float4-aligned.
+    A lookup (t, id) goes to rank ``id % W``, local row ``base[id % W][t] + id // W`` -- computed by
+    the requester, so only row numbers travel.
+
+    ``capacity_factor``: None -> exact all-to-all-v (host sync); a float >= 1 -> padded, sync-free
+    exchange with ``capacity = ceil(lookups / W * factor)`` slots per peer (see module docstring)."""
+
+    def __init__(self, vocabs, embedding_dim, with_lr=True, capacity_factor=None, process_group=None, local_ops=None):
+        super().__init__()
+        rank, W = comm.world(process_group)
+        self.vocabs, self.embedding_dim, self.with_lr = list(vocabs), embedding_dim, with_lr
+        self.group, self.rank, self.world_size = process_group, rank, W
+        self.lr_off = embedding_dim if with_lr else -1
+        self.row_width = (embedding_dim + (1 if with_lr else 0) + 3) // 4 * 4
+        counts = torch.tensor([[(v - r + W - 1) // W for v in self.vocabs] for r in range(W)], dtype=torch.long)
+        base = torch.zeros_like(counts)
+        base[:, 1:] = counts.cumsum(dim=1)[:, :-1]
+        self.register_buffer("base", base, persistent=False)                       # [W, T]
+        self.register_buffer("overflow", torch.zeros((), dtype=torch.bool), persistent=False)
+        self.rows_local = int(counts[rank].sum())
+        self.weight = nn.Parameter(torch.zeros(max(self.rows_local, 1), self.row_width))
+        nn.init.normal_(self.weight[:, :embedding_dim + (1 if with_lr else 0)], std=1e-4)
+        self.capacity_factor = capacity_factor
+        self.local_ops = local_ops if local_ops is not None else HipLocalOps()
+
+    @torch.no_grad()
+    def load_full_tables(self, emb_tables, lr_tables=None):
+        D = self.embedding_dim
+        for t, v in enumerate(self.vocabs):
+            rows = torch.arange(self.rank, v, self.world_size)
+            lo = int(self.base[self.rank, t])
+            self.weight[lo:lo + rows.numel(), :D].copy_(emb_tables[t][rows].to(self.weight.device))
+            if self.with_lr and lr_tables is not None:
+                self.weight[lo:lo + rows.numel(), D].copy_(lr_tables[t][rows].reshape(-1).to(self.weight.device))
+
+    def local_rows_of(self, t):
+        """(slice of local rows, global ids they hold) for table t on this rank."""
+        lo = int(self.base[self.rank, t])
+        ids = torch.arange(self.rank, self.vocabs[t], self.world_size)
+        return slice(lo, lo + ids.numel()), ids
+
+    def capacity_for(self, n_lookups):
+        c = int(math.ceil(n_lookups / self.world_size * self.capacity_factor))
+        return (c + 63) // 64 * 64
+
+    def forward(self, ids):
+        """ids [B, T] (one id per table per sample) -> packed rows [B, T, row_width]."""
+        ids = ids.long()
+        W = self.world_size
+        owner = ids % W
+        t_index = torch.arange(ids.shape[1], device=ids.device).unsqueeze(0).expand_as(ids)
+        row = self.base[owner, t_index] + ids // W
+        if self.capacity_factor is None:
+            return _ExactLookup.apply(owner, row, self.group, self.local_ops, tuple(ids.shape), self.weight)
+        return _PaddedLookup.apply(owner, row, self.capacity_for(ids.numel()), self.overflow, self.group,
+                                   self.local_ops, tuple(ids.shape), self.weight)
+
+    def split(self, packed):
+        """packed [B, T, row_width] -> (E [B, T, D], L [B, T] or None) views."""
+        E = packed[..., :self.embedding_dim]
+        L = packed[..., self.embedding_dim] if self.with_lr else None
+        return E, L

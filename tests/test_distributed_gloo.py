@@ -12,14 +12,17 @@ import torch.multiprocessing as mp
 
 
 class OracleLocalOps(object):
-    """CPU stand-in for HipLocalOps (test infrastructure): plain index_select / index_add_."""
+    """CPU stand-in for HipLocalOps (test infrastructure): plain index_select / index_add_;
+    row -1 is an empty slot of the padded exchange (zero vector, no gradient)."""
 
     def gather(self, weight, rows):
-        return weight.detach().index_select(0, rows)
+        out = weight.detach().index_select(0, rows.clamp(min=0))
+        return out * (rows >= 0).unsqueeze(1)
 
     def scatter_add(self, weight, rows, dy):
         g = torch.zeros_like(weight)
-        g.index_add_(0, rows, dy)
+        keep = rows >= 0
+        g.index_add_(0, rows[keep], dy[keep])
         return g
 
 
@@ -68,6 +71,44 @@ def _worker(rank, world, port, result):
         assert tuple(e2.shape) == (0, D)
         one_sided = torch.full((5,), 2 * 3 + (1 if world > 1 else 0))   # all ids owned by rank 1 (or 0 if W=1)
         assert torch.equal(emb(one_sided), full[one_sided])
+        # several tables behind ONE exchange, embedding + LR weight packed in one row; both exchange modes
+        from recbox_amd.sharded import ShardedTables
+        vocabs = [13, 29, 7]
+        gt = torch.Generator().manual_seed(5)
+        full_e = [torch.randn(v, D, generator=gt) for v in vocabs]
+        full_l = [torch.randn(v, 1, generator=gt) for v in vocabs]
+        tid = torch.stack([torch.randint(0, v, (B,), generator=gi) for v in vocabs], dim=1)      # [B, T]
+        RE, RL = torch.randn(B, 3, D, generator=gi), torch.randn(B, 3, generator=gi)
+        g_ids = [torch.empty_like(tid) for _ in range(world)]
+        g_RE = [torch.empty_like(RE) for _ in range(world)]
+        g_RL = [torch.empty_like(RL) for _ in range(world)]
+        dist.all_gather(g_ids, tid)
+        dist.all_gather(g_RE, RE)
+        dist.all_gather(g_RL, RL)
+        for factor in (None, 3.0):
+            tabs = ShardedTables(vocabs, D, with_lr=True, capacity_factor=factor, local_ops=OracleLocalOps())
+            assert tabs.row_width == 8 and tabs.lr_off == D
+            tabs.load_full_tables(full_e, full_l)
+            E, Lw = tabs.split(tabs(tid))
+            for t in range(3):
+                assert torch.equal(E[:, t], full_e[t][tid[:, t]]) and torch.equal(Lw[:, t], full_l[t][tid[:, t], 0])
+            ((E * RE).sum() + (Lw * RL).sum()).backward()
+            assert not bool(tabs.overflow)
+            for t, v in enumerate(vocabs):
+                we, wl = torch.zeros(v, D), torch.zeros(v)
+                for i, re, rl in zip(g_ids, g_RE, g_RL):
+                    we.index_add_(0, i[:, t], re[:, t])
+                    wl.index_add_(0, i[:, t], rl[:, t])
+                sl, owned = tabs.local_rows_of(t)
+                assert torch.allclose(tabs.weight.grad[sl, :D], we[owned], atol=1e-6)
+                assert torch.allclose(tabs.weight.grad[sl, D], wl[owned], atol=1e-6)
+                assert float(tabs.weight.grad[sl, D + 1:].abs().max()) == 0.0
+        # a capacity that cannot hold a one-sided batch raises the overflow flag instead of dropping silently
+        tight = ShardedTables([64], D, with_lr=False, capacity_factor=1.0, local_ops=OracleLocalOps())
+        tight(torch.zeros(256, 1, dtype=torch.long))         # every lookup goes to rank 0: 256 > capacity 128
+        flag = torch.tensor([float(bool(tight.overflow))])
+        dist.all_reduce(flag)
+        assert (flag.item() > 0) == (world > 1)
         # dense tower grads: all-reduce
         lin = torch.nn.Linear(3, 2)
         with torch.no_grad():

@@ -258,6 +258,44 @@ def test_logistic_regression_fused_and_frozen_tables():
             assert_close(p1.grad, p0.grad, TOL, n)
 
 
+@pytest.mark.parametrize("factor", [None, 1.5])
+def test_sharded_fm_equals_fm_on_one_gpu(factor):
+    """ShardedFM (remote rows through the exchange path, here a world of one; exact and padded exchange)
+    == FM: logits and every gradient."""
+    from recbox_amd.ranking.pytorch.models import FM, ShardedFM
+    vocabs = [50, 7, 400, 31, 300, 9]
+    fm, X, y = _criteo_like(513, vocabs, 16, seed=21, zipf=True)
+    ref = FM(fm, 16).cuda()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.normal_(0, 0.1)
+    dut = ShardedFM(fm, 16, shard_min_vocab=300, capacity_factor=factor).cuda()   # C3 and C5 become row-sharded
+    assert dut.sharded_names == ["C3", "C5"]
+    sd = ref.state_dict()
+    e_pre = "embedding_layer.embedding_layer.embedding_layers.%s.weight"
+    l_pre = "fm.lr_layer.embedding_layer.embedding_layer.embedding_layers.%s.weight"
+    dut.load_state_dict({k: v for k, v in sd.items() if not any(("." + n + ".") in k for n in dut.sharded_names)},
+                        strict=False)
+    dut.tables.load_full_tables([sd[e_pre % n] for n in dut.sharded_names], [sd[l_pre % n] for n in dut.sharded_names])
+    Xc, yc = _cuda(X), y.cuda()
+    outs = []
+    for m in (ref, dut):
+        logit = m.logits(Xc)
+        torch.nn.functional.binary_cross_entropy(torch.sigmoid(logit), yc, reduction="sum").backward()
+        outs.append(logit)
+    assert_close(outs[1], outs[0], 1e-5, "logit")
+    ref_g = dict((n, p.grad) for n, p in ref.named_parameters())
+    for n, p in dut.named_parameters():
+        if n.startswith("tables."):
+            continue
+        assert_close(p.grad, ref_g[n], 1e-4 * 8, n)
+    for t, name in enumerate(dut.sharded_names):
+        sl, owned = dut.tables.local_rows_of(t)
+        got = dut.tables.weight.grad[sl]
+        assert_close(got[1:, :16], ref_g[e_pre % name][owned.cuda()][1:], 1e-4 * 8, "shard emb " + name)
+        assert_close(got[1:, 16], ref_g[l_pre % name][owned.cuda()][1:, 0], 1e-4 * 8, "shard lr " + name)
+
+
 def test_backward_is_deterministic_and_linear():
     """Full-size property checks (B = 65 536, 26 fields): two backward passes are
     bit-identical (no float atomics) and column sums of dW equal column sums of dY."""
