@@ -154,6 +154,12 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded model even at world size 1 (exercises the RCCL exchange path)")
     ap.add_argument("--shard-min-vocab", type=int, default=100000)
+    ap.add_argument("--graph-sharded", action="store_true",
+                    help="try to capture the sharded step (padded exchange + RCCL) in a hipGraph; OFF by default: "
+                         "on ROCm 7.2 / torch 2.10 capturing RCCL collectives hung the process in round 1")
+    ap.add_argument("--capacity-factor", type=float, default=0.0,
+                    help="slots per peer of the sync-free padded exchange, relative to a perfectly balanced batch; "
+                         "0 = exact all-to-all-v (host sync per call, no graph capture)")
     ap.add_argument("--path", choices=["fused", "layers"], default="fused",
                     help="fused: FM model body in rbx_fm_fwd/bwd; layers: drop-in layers composed as the reference does")
     args = ap.parse_args()
@@ -176,7 +182,8 @@ def main():
     sharded = world > 1 or args.force_sharded
     if sharded:
         # big tables row-sharded over the ranks (all-to-all-v over RCCL/xGMI), small ones replicated
-        model = ShardedFM(fmw.fm, args.dim, shard_min_vocab=args.shard_min_vocab).to(dev)
+        model = ShardedFM(fmw.fm, args.dim, shard_min_vocab=args.shard_min_vocab,
+                          capacity_factor=(args.capacity_factor or None)).to(dev)
     else:
         model = FM(fmw.fm, args.dim, fused=(args.path == "fused")).to(dev)
     init_weights(model)                       # same seed on every rank: replicated parameters start identical
@@ -197,10 +204,19 @@ def main():
         return loss
 
     step = eager_step
-    if not args.eager and not sharded:
-        # one hipGraph holds the whole step (same kernels, same C ABI); the batch lives in static buffers
+    graph_note = "eager launches"
+    if not args.eager and (not sharded or (args.graph_sharded and args.capacity_factor)):
+        # one hipGraph holds the whole step (same kernels, same C ABI, and -- when sharded -- the RCCL
+        # exchanges of the padded sync-free routing); the batch lives in static buffers
         from recbox_amd.graph import GraphedStep
-        step = GraphedStep(eager_step, warmup=3)
+        try:
+            step = GraphedStep(eager_step, warmup=3)
+            graph_note = "hipGraph replay"
+        except Exception as exc:                       # e.g. a collective that refuses capture: stay eager
+            if rank == 0:
+                print("[bench] graph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc), file=sys.stderr)
+            torch.cuda.synchronize()
+            step = eager_step
 
     for _ in range(args.warmup):
         step()
@@ -234,6 +250,12 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
 
+    overflow = False
+    if sharded and model.tables is not None:
+        flag = model.tables.overflow.float().reshape(1)
+        if world > 1:
+            torch.distributed.all_reduce(flag)
+        overflow = bool(flag.item() > 0)
     if rank == 0:
         ms = el / args.steps * 1e3
         # algorithmic bytes of the gather per sample: 26 rows x 64 B
@@ -261,10 +283,15 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
                                       "%s ids, %s path, %s, dense-grad autograd contract, no optimiser step"
-                                      % (args.dim, B, args.dist, args.path, "eager launches" if step is eager_step else "hipGraph replay"),
+                                      % (args.dim, B, args.dist, args.path, graph_note),
                           "global_batch": B * world,
                           "parallelism": ("dp%d + row-sharded tables (all-to-all-v)" % world) if sharded else "dp1"},
                "roofline": roof}
+        if sharded:
+            out["config"]["exchange"] = ("padded capacity_factor=%g, overflow=%s" % (args.capacity_factor, overflow)
+                                         if args.capacity_factor else "exact all-to-all-v")
+            if overflow:
+                out["config"]["warning"] = "exchange capacity overflowed: rerun with a larger --capacity-factor"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.dim, B, args.dist, args.cpu_seconds)
         print(json.dumps(out))

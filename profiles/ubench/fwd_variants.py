@@ -53,3 +53,41 @@ for kind in ("f64_strided", "i64_contig", "i32_contig"):
     time_it(fields(kind, emb, D), fields(kind, lr, 1), "emb+lr, ids " + kind)
     time_it(fields(kind, emb, D), None, "emb only, ids " + kind)
 time_it(None, fields("i64_contig", lr, 1), "lr only, ids i64_contig")
+
+# ---- bench-like conditions: 13 numeric fields, [B, 40] float64 batch, cache flushed between launches ----
+N_DENSE = 13
+batch = torch.cat([torch.rand(B, N_DENSE, dtype=torch.float64, device="cuda"), block,
+                   torch.zeros(B, 1, dtype=torch.float64, device="cuda")], dim=1).contiguous()      # [B, 40]
+wn = [torch.randn(D, device="cuda") for _ in range(N_DENSE)]
+wl = [torch.randn(1, device="cuda") for _ in range(N_DENSE)]
+
+
+def bench_fields(tables_num, tables_cat, dim):
+    arr = (L.rbx_field_t * (N_DENSE + n))()
+    for i in range(N_DENSE + n):
+        f = arr[i]
+        f.ids, f.ids_stride_b, f.ids_dtype = batch[:, i].data_ptr(), batch.stride(0), L.RBX_F64
+        f.dim, f.seq_len, f.pool, f.mask_id = dim, 1, L.POOL_NONE, L.RBX_NO_ID
+        if i < N_DENSE:
+            f.table, f.kind, f.vocab, f.padding_idx = tables_num[i].data_ptr(), L.FIELD_NUMERIC, 0, L.RBX_NO_ID
+        else:
+            f.table, f.kind, f.vocab, f.padding_idx = tables_cat[i - N_DENSE].data_ptr(), L.FIELD_CATEGORICAL, \
+                CRITEO_VOCABS[i - N_DENSE] + 1, 0
+    return arr
+
+
+ea, la = bench_fields(wn, emb, D), bench_fields(wl, lr, 1)
+scratch = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+for flush in (False, True):
+    ts = []
+    for _ in range(12):
+        if flush:
+            scratch.zero_()                       # 512 MB of writes: evicts L2 and the 256 MB Infinity Cache
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.lib.rbx_fm_fwd(ea, la, N_DENSE + n, B, None, None, 0, 0, -1, logit.data_ptr(), ssum.data_ptr(), None, None))
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1000)
+    print("bench layout (39 fields, f64 [B,40]), cache %-7s median %6.1f us  min %6.1f us"
+          % ("flushed" if flush else "warm", sorted(ts)[len(ts) // 2], min(ts)))

@@ -61,22 +61,27 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
     for (int f0 = 0; f0 < F; f0 += U) {
       long long id[U];
       float x[U];
+      // phase 1: issue the batch's id / value loads, nothing consumes them yet
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        id[u] = 0;
+        const FmField& fd = P.f[(f0 + u < F) ? f0 + u : F - 1];
+        id[u] = load_raw(fd.ids, b * fd.stride_b, fd.dtype);
+      }
+      // phase 2: decode and range-check
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const FmField& fd = P.f[(f0 + u < F) ? f0 + u : F - 1];
         x[u] = 1.f;
-        if (f0 + u < F) {
-          const FmField& fd = P.f[f0 + u];
-          if (fd.kind == RBX_FIELD_CATEGORICAL) {
-            id[u] = load_id(fd.ids, b * fd.stride_b, fd.dtype);
-            if (id[u] < 0 || id[u] >= fd.vocab) {
-              if (status != nullptr) atomicOr(status, 1);
-              id[u] = 0;
-              x[u] = 0.f;                       // out-of-range lookups read as zero rows
-            }
-          } else {
-            x[u] = load_value(fd.ids, b * fd.stride_b, fd.dtype);
+        if (fd.kind == RBX_FIELD_CATEGORICAL) {
+          id[u] = decode_id(id[u], fd.dtype);
+          if (id[u] < 0 || id[u] >= fd.vocab) {
+            if (status != nullptr && f0 + u < F) atomicOr(status, 1);
+            id[u] = 0;
+            x[u] = 0.f;                         // out-of-range lookups read as zero rows
           }
+        } else {
+          x[u] = decode_value(id[u], fd.dtype);
+          id[u] = 0;
         }
       }
       float e[U][NA];

@@ -61,6 +61,33 @@ __device__ __forceinline__ float load_value(const void* p, long long idx, int dt
   }
 }
 
+// Two-phase id access for kernels that keep several lookups in flight: load_raw only issues the load
+// (no use of the value, so the loads of a batch stay outstanding together); decode_* do the dtype
+// conversion afterwards.  Calling load_id per lookup instead serialises the batch: every range
+// check waits for its own load (measured: 64 -> 4x us on the fused FM forward).
+__device__ __forceinline__ long long load_raw(const void* p, long long idx, int dt) {
+  if (dt & 1) return static_cast<const long long*>(p)[idx];                 // I64 / F64: 8-byte elements
+  return static_cast<long long>(static_cast<const int*>(p)[idx]);             // I32 / F32: 4-byte elements
+}
+
+__device__ __forceinline__ long long decode_id(long long raw, int dt) {
+  switch (dt) {
+    case RBX_I32:
+    case RBX_I64: return raw;
+    case RBX_F32: return static_cast<long long>(__int_as_float(static_cast<int>(raw)));
+    default:      return static_cast<long long>(__longlong_as_double(raw));
+  }
+}
+
+__device__ __forceinline__ float decode_value(long long raw, int dt) {
+  switch (dt) {
+    case RBX_I32:
+    case RBX_I64: return static_cast<float>(raw);
+    case RBX_F32: return __int_as_float(static_cast<int>(raw));
+    default:      return static_cast<float>(__longlong_as_double(raw));
+  }
+}
+
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
