@@ -210,7 +210,7 @@ def main():
         # exchanges of the padded sync-free routing); the batch lives in static buffers
         from recbox_amd.graph import GraphedStep
         try:
-            step = GraphedStep(eager_step, warmup=3)
+            step = GraphedStep(eager_step, warmup=3, capture_error_mode="thread_local" if sharded else "global")
             graph_note = "hipGraph replay"
         except Exception as exc:                       # e.g. a collective that refuses capture: stay eager
             if rank == 0:

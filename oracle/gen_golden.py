@@ -409,6 +409,36 @@ def gen_attention_and_losses(recbox, fuxictr, B=3, H=2, L=9, D=8):
                                       "sigmoid_ce": yp2.grad}})
 
 
+def gen_target_attention_and_listwise_losses(recbox, fuxictr, B=5, L=7, E=16):
+    g = torch.Generator().manual_seed(1)
+    att = fuxictr.pytorch.layers.MultiHeadTargetAttention(input_dim=E, attention_dim=16, num_heads=2, dropout_rate=0,
+                                                           use_scale=True, use_qkvo=True)
+    reinit(att, seed=4)
+    tgt = torch.randn(B, E, generator=g).requires_grad_(True)
+    hist = torch.randn(B, L, E, generator=g).requires_grad_(True)
+    lens = torch.tensor([7, 3, 1, 5, 2])
+    mask = (torch.arange(L)[None, :] < lens[:, None]).float()
+    out = att(tgt, hist, mask)
+    R = torch.randn(out.shape, generator=g)
+    (out * R).sum().backward()
+    from recbox.core.pytorch import losses
+    yp = torch.randn(6, 5, generator=g)
+    yt = torch.zeros(6, 5)
+    yt[:, 0] = 1
+    louts, lgrads = {}, {}
+    for name, fn in (("pairwise_logistic", losses.PairwiseLogisticLoss()), ("pairwise_margin", losses.PairwiseMarginLoss(0.5)),
+                     ("mse", losses.MSELoss()), ("ccl", losses.CosineContrastiveLoss(0.1)),
+                     ("ccl_weighted", losses.CosineContrastiveLoss(0.1, negative_weight=2.0))):
+        y = yp.clone().requires_grad_(True)
+        v = fn(y, yt)
+        v.backward()
+        louts[name], lgrads[name] = v, y.grad
+    save("target_attention_losses", **{"in": {"target": tgt, "history": hist, "mask": mask, "R": R, "y_pred": yp, "y_true": yt},
+                                       "p": att.state_dict(), "out": dict(louts, attn=out),
+                                       "g": dict(lgrads, target=tgt.grad, history=hist.grad,
+                                                 **{"p." + n: p.grad for n, p in att.named_parameters()})})
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -428,6 +458,7 @@ def main():
     gen_rechub_models()
     gen_mlp(recbox, fuxictr)
     gen_attention_and_losses(recbox, fuxictr)
+    gen_target_attention_and_listwise_losses(recbox, fuxictr)
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ class GraphedStep(object):
             loss = step()           # replays fwd+bwd; parameter .grad tensors are static
     """
 
-    def __init__(self, fn, warmup=3):
+    def __init__(self, fn, warmup=3, capture_error_mode="global"):
         if ops.config.check_ids:
             raise RuntimeError("GraphedStep: set recbox_amd.ops.config.check_ids = False first "
                                "(the id range check syncs the host, which cannot be captured)")
@@ -37,7 +37,7 @@ class GraphedStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             self.out = fn()
 
     def __call__(self):

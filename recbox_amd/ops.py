@@ -142,9 +142,21 @@ class KernelTimer(object):
         return rc
 
     def mean_ms(self):
+        """Mean bracketed time minus the cost of an empty bracket (two back-to-back event records on
+        the same stream measure a few microseconds of their own)."""
         if not self.samples:
             return None
-        return sum(a.elapsed_time(b) for a, b in self.samples) / len(self.samples)
+        raw = sum(a.elapsed_time(b) for a, b in self.samples) / len(self.samples)
+        empties = []
+        for _ in range(20):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            empties.append((e0, e1))
+        torch.cuda.synchronize()
+        floor = sorted(a.elapsed_time(b) for a, b in empties)[len(empties) // 2]
+        return max(raw - floor, 1e-6)
 
 
 kernel_timer = None   # set by bench.py

@@ -10,7 +10,27 @@ from torch import nn
 from ... import ops
 from .layers import FactorizationMachine, FeatureEmbedding
 
-__all__ = ["FM", "ShardedFM"]
+__all__ = ["FM", "ShardedFM", "inputs_from_batch"]
+
+
+def inputs_from_batch(feature_map, batch, feature_source=None):
+    """``RankingModel.get_inputs`` for a batch that is ALREADY on the GPU (ranking_model.py:106-116): the
+    flat ``[B, cols]`` tensor the reference's loaders deliver (float64 as soon as one column is float,
+    h5_dataloader.py:36-47) is cut into per-feature COLUMN VIEWS -- no slice copies, no ``.long()`` casts: the
+    kernels read strided float64/float32/int columns in place and cast in registers.  A narrower wire format
+    (int32 ids, fp32 dense values) is therefore just a different dtype of ``batch``."""
+    from collections import OrderedDict
+    if feature_source and isinstance(feature_source, str):
+        feature_source = [feature_source]
+    X = OrderedDict()
+    for name, spec in feature_map.features.items():
+        if feature_source is not None and spec["source"] not in feature_source:
+            continue
+        if spec["type"] == "meta":
+            continue
+        col = feature_map.get_column_index(name)
+        X[name] = batch[:, col[0]:col[-1] + 1] if isinstance(col, list) else batch[:, col]
+    return X
 
 
 class FM(nn.Module):
@@ -35,6 +55,8 @@ class FM(nn.Module):
         return self.fm(X, self.embedding_layer(X))
 
     def forward(self, X):
+        if torch.is_tensor(X):                      # the reference's harness hands over the flat batch tensor
+            X = inputs_from_batch(self.feature_map, X)
         return {"y_pred": torch.sigmoid(self.logits(X))}
 
 

@@ -150,3 +150,24 @@ def test_embed_plan_layout_is_pure_host_logic():
     assert plan.plan.arr[2].vocab == 10 and plan.plan.arr[2].seq_len == 5 and plan.plan.needs_row_scale
     with pytest.raises(NotImplementedError):
         host.Plan([host.Lookup("x%d" % i, FIELD_DENSE, None, 1) for i in range(65)])
+
+
+def test_listwise_losses_match_reference_fixture():
+    """The six y_pred[B, 1+negs] losses are plain ATen expressions (SURVEY a-13): checked on CPU."""
+    from conftest import Fixture, assert_close
+    from recbox_amd.core.pytorch import losses
+    fx = Fixture("target_attention_losses")
+    t = fx.tensors("in")
+    cases = {"pairwise_logistic": losses.PairwiseLogisticLoss(), "pairwise_margin": losses.PairwiseMarginLoss(0.5),
+             "mse": losses.MSELoss(), "ccl": losses.CosineContrastiveLoss(0.1),
+             "ccl_weighted": losses.CosineContrastiveLoss(0.1, negative_weight=2.0)}
+    for name, fn in cases.items():
+        y = t["y_pred"].clone().requires_grad_(True)
+        v = fn(y, t["y_true"])
+        assert_close(v, fx["out"][name], 1e-6, name)
+        v.backward()
+        assert_close(y.grad, fx["g"][name], 1e-6, "grad " + name)
+    fx2 = Fixture("attention_losses")
+    t2 = fx2.tensors("in")
+    assert_close(losses.SoftmaxCrossEntropyLoss()(t2["y_pred"], t2["y_true"]), fx2["out"]["softmax_ce"], 1e-6)
+    assert_close(losses.SigmoidCrossEntropyLoss()(t2["y_pred"], t2["y_true"]), fx2["out"]["sigmoid_ce"], 1e-5)

@@ -240,3 +240,19 @@ def test_attention_causal_l200_d64_matches_torch():
     assert_close(o1, o0.float(), TOL)
     for a, b, n in ((qc.grad, qr.grad, "dq"), (kc.grad, kr.grad, "dk"), (vc.grad, vr.grad, "dv")):
         assert_close(a, b.float(), TOL, n)
+
+
+def test_multi_head_target_attention_golden():
+    import recbox_amd.ranking.pytorch.layers as L
+    fx = Fixture("target_attention_losses")
+    att = load_params(L.MultiHeadTargetAttention(input_dim=16, attention_dim=16, num_heads=2), fx["p"]).cuda()
+    t = _cuda(fx.tensors("in"))
+    tgt = t["target"].clone().requires_grad_(True)
+    hist = t["history"].clone().requires_grad_(True)
+    out = att(tgt, hist, t["mask"])
+    assert_close(out, fx["out"]["attn"], TOL)
+    (out * t["R"]).sum().backward()
+    assert_close(tgt.grad, fx["g"]["target"], TOL)
+    assert_close(hist.grad, fx["g"]["history"], TOL)
+    for n, p in att.named_parameters():
+        assert_close(p.grad, fx["g"]["p." + n], TOL, n)
