@@ -245,11 +245,19 @@ extern "C" int rbx_linear_fwd(const float* d_x, const float* d_w, const float* d
                               as_stream(stream));
 }
 
+// split-K scratch of the weight gradient: room for 2 x CUs slices of [n, k], at most 64 MiB
+static size_t dw_ws_floats(int32_t n, int32_t k) {
+  const size_t want = static_cast<size_t>(n) * k * 2 * rbx::kCUs;
+  const size_t cap = size_t(1) << 24;
+  const size_t one = static_cast<size_t>(n) * k;
+  return want < cap ? want : (cap > one ? cap : one);
+}
+
 extern "C" size_t rbx_linear_bwd_workspace_size(int64_t m, int32_t n, int32_t k, int32_t act) {
   // relu-masked dy copy + split-K slices of dW (at most 2*CUs tiles worth) + bias partials
   const size_t masked = (act == 1) ? static_cast<size_t>(m) * n : 0;
   const size_t splits = 2 * rbx::kCUs;
-  const size_t dw = static_cast<size_t>(n) * k * 16 < (size_t(1) << 26) ? static_cast<size_t>(n) * k * 16 : (size_t(1) << 26);
+  const size_t dw = dw_ws_floats(n, k);
   const size_t db = static_cast<size_t>((m + 1023) / 1024) * n;
   (void)splits;
   return (masked + dw + db + 1024) * sizeof(float);
@@ -276,7 +284,7 @@ extern "C" int rbx_linear_bwd(const float* d_x, const float* d_w, const float* d
     g = ws;
     ws += cnt;
   }
-  const size_t dw_floats = static_cast<size_t>(n) * k * 16 < (size_t(1) << 26) ? static_cast<size_t>(n) * k * 16 : (size_t(1) << 26);
+  const size_t dw_floats = dw_ws_floats(n, k);
   int rc = RBX_OK;
   if (d_dx != nullptr) {
     // dx[m,k] = g[m,n] * W[n,k]: A = g (n contiguous = its K), B(kk=n, col=k) = W[n*k + k] (col contiguous)

@@ -165,93 +165,118 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const FieldPack P, const
         w.store(dst, dim, lane_g);
         continue;
       }
-      // sequence feature: L lookups, pooled or kept
-      const int L = fd.seq_len;
-      const int pool = fd.pool;
-      const long long base = bb[u] * fd.ids_stride_b;
-      Frag acc;
-      acc.zero();
-      float count = 0.f;
-      for (int l0 = 0; l0 < L; l0 += U) {
-        long long ids[U];
-        bool ok[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const int l = l0 + j;
-          ok[j] = l < L;
-          ids[j] = ok[j] ? load_id(fd.ids, base + static_cast<long long>(l) * fd.ids_stride_l, fd.ids_dtype) : 0;
-        }
-        Frag r[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          r[j].zero();
-          if (!ok[j]) continue;
-          const bool masked = (pool == RBX_POOL_MEAN_ID || pool == RBX_POOL_SUM_ID) && ids[j] == fd.mask_id;
-          if (ids[j] >= 0 && ids[j] < fd.vocab) {
-            // masked rows are still read by the reference (bmm with a 0 weight); skip the traffic
-            if (!masked) r[j].load(fd.table + ids[j] * dim, dim, lane_g);
-          } else if (status != nullptr) {
-            atomicOr(status, 1);
-          }
-          if (masked) ok[j] = false;
-        }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-          const int l = l0 + j;
-          if (l >= L) continue;
-          if (pool == RBX_POOL_CONCAT) {
-            r[j].store(dst + static_cast<long long>(l) * dim, dim, lane_g);
-          } else {
-            acc.add(r[j]);
-            if (pool == RBX_POOL_MEAN_VALUE) {
-              const float s = group_sum<G>(r[j].hsum());   // value mask: row sum != 0
-              count += (s != 0.f) ? 1.f : 0.f;
-            } else if (pool == RBX_POOL_MEAN_ID) {
-              count += ok[j] ? 1.f : 0.f;
-            }
-          }
-        }
-      }
-      if (pool == RBX_POOL_CONCAT) continue;
-      if (pool == RBX_POOL_MEAN_VALUE || pool == RBX_POOL_MEAN_ID) {
-        const float inv = 1.0f / (count + fd.eps);
-        // the reference divides; x * (1/(c+eps)) differs from x / (c+eps) by <= 1 ulp
-        acc.scale(inv);
-        if (row_scale != nullptr && lane_g == 0) row_scale[static_cast<long long>(fd.slot) * B + bb[u]] = inv;
-      }
-      acc.store(dst, dim, lane_g);
+      // sequence features never reach this kernel (embed_seq_kernel serves them)
     }
   }
 }
 
+// Sequence features (multi-hot): one lane group walks the L lookups of ONE (sample, feature) pair
+// with 8 row reads in flight and pools in registers, so [B, L, D] never reaches HBM.  Kept apart from
+// the one-hot kernel so that neither pays the other's registers (one kernel for both ran at 110 VGPRs
+// = 4 waves/SIMD and left the history gather of cfg 3 at 1.7 TB/s).
 template <int G, int NV, bool VEC>
-static int launch_fwd(const FieldPack& pack, int F, int64_t B, float* out, int64_t stride_b, float* row_scale,
-                      int* status, hipStream_t s) {
+__global__ __launch_bounds__(256) void embed_seq_kernel(const FieldPack P, const int F, const long long B,
+                                                        float* __restrict__ out, const long long stride_b,
+                                                        float* __restrict__ row_scale,
+                                                        int* __restrict__ status) {
+  using Frag = RowFrag<G, NV, VEC>;
+  constexpr int U = (NV * (VEC ? 4 : 1) <= 4) ? 8 : 4;
+  const int lane_g = threadIdx.x % G;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
+  const long long npairs = B * F;
+  for (long long p = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; p < npairs;
+       p += ngroups) {
+    // sample fastest: the groups of a wave work on the SAME feature (uniform loop bounds, one table)
+    const int f = (npairs < (1ll << 32)) ? static_cast<int>(static_cast<unsigned>(p) / static_cast<unsigned>(B))
+                                         : static_cast<int>(p / B);
+    const long long b = p - static_cast<long long>(f) * B;
+    const FieldK fd = P.f[f];                             // private copy: no re-reads inside the loops
+    const int L = fd.seq_len, pool = fd.pool, dim = fd.dim, dt = fd.ids_dtype;
+    const bool id_pool = (pool == RBX_POOL_MEAN_ID || pool == RBX_POOL_SUM_ID);
+    float* dst = out + b * stride_b + fd.out_off;
+    const long long base = b * fd.ids_stride_b;
+    Frag acc;
+    acc.zero();
+    float count = 0.f;
+    for (int l0 = 0; l0 < L; l0 += U) {
+      long long ids[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {                       // phase 1: id loads only
+        const int l = (l0 + j < L) ? l0 + j : L - 1;
+        ids[j] = load_raw(fd.ids, base + static_cast<long long>(l) * fd.ids_stride_l, dt);
+      }
+      Frag r[U];
+      bool use[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {                       // phase 2: row loads
+        r[j].zero();
+        const long long id = decode_id(ids[j], dt);
+        const bool live = l0 + j < L;
+        const bool in_range = id >= 0 && id < fd.vocab;
+        if (live && !in_range && status != nullptr) atomicOr(status, 1);
+        // id-masked rows get weight 0 in the reference's bmm: skip their traffic
+        use[j] = live && in_range && !(id_pool && id == fd.mask_id);
+        if (use[j]) r[j].load(fd.table + id * dim, dim, lane_g);
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {                       // phase 3: pool / keep
+        if (l0 + j >= L) continue;
+        if (pool == RBX_POOL_CONCAT) {
+          r[j].store(dst + static_cast<long long>(l0 + j) * dim, dim, lane_g);
+        } else {
+          acc.add(r[j]);
+          if (pool == RBX_POOL_MEAN_VALUE) {
+            const float sm = group_sum<G>(r[j].hsum());   // value mask: row sum != 0
+            count += (sm != 0.f) ? 1.f : 0.f;
+          } else if (pool == RBX_POOL_MEAN_ID) {
+            count += use[j] ? 1.f : 0.f;
+          }
+        }
+      }
+    }
+    if (pool == RBX_POOL_CONCAT) continue;
+    if (pool == RBX_POOL_MEAN_VALUE || pool == RBX_POOL_MEAN_ID) {
+      const float inv = 1.0f / (count + fd.eps);
+      // the reference divides; x * (1/(c+eps)) differs from x / (c+eps) by <= 1 ulp
+      acc.scale(inv);
+      if (row_scale != nullptr && lane_g == 0) row_scale[static_cast<long long>(fd.slot) * B + b] = inv;
+    }
+    acc.store(dst, dim, lane_g);
+  }
+}
+
+template <int G, int NV, bool VEC>
+static int launch_fwd(bool seq, const FieldPack& pack, int F, int64_t B, float* out, int64_t stride_b,
+                      float* row_scale, int* status, hipStream_t s) {
   const long long npairs = B * F;
   const int groups_per_block = 256 / G;
   long long blocks = (npairs + groups_per_block - 1) / groups_per_block;
-  const long long cap = static_cast<long long>(kCUs) * 8;
+  const long long cap = static_cast<long long>(kCUs) * (seq ? 64 : 8);   // sequences: one pair per group, many waves
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((embed_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, pack, F,
-                     static_cast<long long>(B), out, static_cast<long long>(stride_b), row_scale, status);
+  if (seq)
+    hipLaunchKernelGGL((embed_seq_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, pack, F,
+                       static_cast<long long>(B), out, static_cast<long long>(stride_b), row_scale, status);
+  else
+    hipLaunchKernelGGL((embed_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, pack, F,
+                       static_cast<long long>(B), out, static_cast<long long>(stride_b), row_scale, status);
   return check_launch("embed_fwd_kernel");
 }
 
 template <bool VEC>
-static int dispatch_fwd(int units, const FieldPack& pack, int F, int64_t B, float* out, int64_t stride_b,
+static int dispatch_fwd(bool seq, int units, const FieldPack& pack, int F, int64_t B, float* out, int64_t stride_b,
                         float* row_scale, int* status, hipStream_t s) {
   const int g = pow2_ceil(units);
   switch (g) {
-    case 1: return launch_fwd<1, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
-    case 2: return launch_fwd<2, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
-    case 4: return launch_fwd<4, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
-    case 8: return launch_fwd<8, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
-    case 16: return launch_fwd<16, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
-    case 32: return launch_fwd<32, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
-    case 64: return launch_fwd<64, 1, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
-    case 128: return launch_fwd<64, 2, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
-    case 256: return launch_fwd<64, 4, VEC>(pack, F, B, out, stride_b, row_scale, status, s);
+    case 1: return launch_fwd<1, 1, VEC>(seq, pack, F, B, out, stride_b, row_scale, status, s);
+    case 2: return launch_fwd<2, 1, VEC>(seq, pack, F, B, out, stride_b, row_scale, status, s);
+    case 4: return launch_fwd<4, 1, VEC>(seq, pack, F, B, out, stride_b, row_scale, status, s);
+    case 8: return launch_fwd<8, 1, VEC>(seq, pack, F, B, out, stride_b, row_scale, status, s);
+    case 16: return launch_fwd<16, 1, VEC>(seq, pack, F, B, out, stride_b, row_scale, status, s);
+    case 32: return launch_fwd<32, 1, VEC>(seq, pack, F, B, out, stride_b, row_scale, status, s);
+    case 64: return launch_fwd<64, 1, VEC>(seq, pack, F, B, out, stride_b, row_scale, status, s);
+    case 128: return launch_fwd<64, 2, VEC>(seq, pack, F, B, out, stride_b, row_scale, status, s);
+    case 256: return launch_fwd<64, 4, VEC>(seq, pack, F, B, out, stride_b, row_scale, status, s);
     default: return fail(RBX_ERR_UNSUPPORTED, "embedding dim too large for one lane group (units=%d)", units);
   }
 }
@@ -273,29 +298,32 @@ extern "C" int rbx_embed_fwd(const rbx_field_t* fields, int32_t n_fields, int64_
   if (batch < 0) return fail(RBX_ERR_INVALID, "negative batch");
   if (batch == 0) return RBX_OK;
   if (d_out == nullptr) return fail(RBX_ERR_INVALID, "d_out is NULL");
-  // split into a float4 launch and a scalar launch (slot = position in the caller's array)
-  rbx_field_t part[2][RBX_MAX_FIELDS];
-  int slot[2][RBX_MAX_FIELDS];
-  int cnt[2] = {0, 0};
-  int units[2] = {1, 1};
+  // split into (float4 | scalar) x (one id per sample | sequence) launches; slot = position in the caller's array
+  static thread_local rbx_field_t part[4][RBX_MAX_FIELDS];
+  int slot[4][RBX_MAX_FIELDS];
+  int cnt[4] = {0, 0, 0, 0};
+  int units[4] = {1, 1, 1, 1};
   for (int i = 0; i < n_fields; ++i) {
-    const int k = field_vec_ok(fields[i], d_out, out_stride_b) ? 0 : 1;
+    const bool vec = field_vec_ok(fields[i], d_out, out_stride_b);
+    const bool seq = fields[i].kind == RBX_FIELD_CATEGORICAL && (fields[i].seq_len > 1 || fields[i].pool != RBX_POOL_NONE);
+    const int k = (vec ? 0 : 1) + (seq ? 2 : 0);
     part[k][cnt[k]] = fields[i];
     slot[k][cnt[k]] = i;
-    const int u = (k == 0) ? fields[i].dim / 4 : fields[i].dim;
+    const int u = vec ? fields[i].dim / 4 : fields[i].dim;
     if (u > units[k]) units[k] = u;
     ++cnt[k];
   }
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 4; ++k) {
     if (cnt[k] == 0) continue;
     FieldPack pack;
     int rc = pack_fields(part[k], cnt[k], batch, false, &pack);
     if (rc != RBX_OK) return rc;
     for (int i = 0; i < cnt[k]; ++i) pack.f[i].slot = static_cast<unsigned char>(slot[k][i]);
-    rc = (k == 0) ? dispatch_fwd<true>(units[k], pack, cnt[k], batch, d_out, out_stride_b, d_row_scale, d_status,
-                                       as_stream(stream))
-                  : dispatch_fwd<false>(units[k], pack, cnt[k], batch, d_out, out_stride_b, d_row_scale, d_status,
-                                        as_stream(stream));
+    const bool seq = k >= 2;
+    rc = (k % 2 == 0) ? dispatch_fwd<true>(seq, units[k], pack, cnt[k], batch, d_out, out_stride_b, d_row_scale, d_status,
+                                           as_stream(stream))
+                      : dispatch_fwd<false>(seq, units[k], pack, cnt[k], batch, d_out, out_stride_b, d_row_scale,
+                                            d_status, as_stream(stream));
     if (rc != RBX_OK) return rc;
   }
   return RBX_OK;
