@@ -265,6 +265,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float*
   }
 }
 
+// fast path on the fp32 matrix cores (rbx_attn_mfma.hip)
+bool attn_mfma_supported(int lq, int lk, int hd, const float* mask, const float* probs);
+int attn_mfma_fwd(const float* q, const float* k, const float* v, long long bh, int L, int hd, float scale, int causal,
+                  float* o, float* lse, hipStream_t s);
+int attn_mfma_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
+                  long long bh, int L, int hd, float scale, int causal, float* dq, float* dk, float* dv, float* scratch,
+                  hipStream_t s);
+
 static int attn_check(int64_t bh, int lq, int lk, int hd) {
   if (bh < 0 || lq <= 0 || lk <= 0) return fail(RBX_ERR_INVALID, "attention: bad shape");
   if (hd != 4 && hd != 8 && hd != 16 && hd != 32 && hd != 64)
@@ -293,6 +301,8 @@ extern "C" int rbx_attn_fwd(const float* d_q, const float* d_k, const float* d_v
   if (rc != RBX_OK) return rc;
   if (d_q == nullptr || d_k == nullptr || d_v == nullptr || d_o == nullptr) return fail(RBX_ERR_INVALID, "attention: NULL tensor");
   if (bh == 0) return RBX_OK;
+  if (d_lse != nullptr && attn_mfma_supported(lq, lk, head_dim, d_mask, d_p))
+    return attn_mfma_fwd(d_q, d_k, d_v, bh, lq, head_dim, scale, causal, d_o, d_lse, as_stream(stream));
   const size_t lds = static_cast<size_t>(2) * lk * head_dim * sizeof(float);
   hipStream_t s = as_stream(stream);
 #define CALL(HD)                                                                                                  \
@@ -319,6 +329,9 @@ extern "C" int rbx_attn_bwd(const float* d_q, const float* d_k, const float* d_v
       d_dq == nullptr || d_dk == nullptr || d_dv == nullptr || d_scratch == nullptr)
     return fail(RBX_ERR_INVALID, "attention backward: NULL tensor");
   if (bh == 0) return RBX_OK;
+  if (attn_mfma_supported(lq, lk, head_dim, d_mask, nullptr))
+    return attn_mfma_bwd(d_q, d_k, d_v, d_o, d_do, d_lse, bh, lq, head_dim, scale, causal, d_dq, d_dk, d_dv, d_scratch,
+                         as_stream(stream));
   const size_t lds_a = static_cast<size_t>(2) * lk * head_dim * sizeof(float);
   const size_t lds_b = (static_cast<size_t>(2) * lq * head_dim + 2 * lq) * sizeof(float);
   hipStream_t s = as_stream(stream);

@@ -1,0 +1,343 @@
+// rbx_attn_mfma.hip -- K6 on the fp32 matrix cores: fused (causal) softmax attention for the
+// SASRec shape regime (L <= 256, head_dim 32 or 64, no explicit mask), forward and backward.
+//
+// Same reference behaviour as rbx_attn.hip (nn.MultiheadAttention core of
+// third_party/rechub/models/matching/sasrec.py:81-87); this file is the fast path, the VALU
+// kernels there keep serving explicit masks, returned probabilities and small head dims.
+//
+// One workgroup (4 waves) per (sample, head); all products run on v_mfma_f32_32x32x2_f32 (exact
+// fp32, so the 1e-4 parity bar holds).  The trick that removes every register shuffle: tiles are
+// computed TRANSPOSED.  S^T = K Q^T has C-layout "lane & 31 = query, 16 registers x 2 half-waves
+// = 32 keys", so softmax statistics are per LANE (one xor-32 shuffle joins the halves) and the
+// probabilities p[r] are ALREADY the B operand of the next product O^T = V^T P^T (B[k][col]: k
+// selected by the half-wave, col = lane & 31) -- register r of S^T feeds MFMA step r of O^T.
+// The per-row operands (K, V, or Q, dO in the second backward phase) sit in LDS as row-major
+// [L][HD + 1] (odd stride: both "lanes = rows" and "lanes = columns" reads are conflict free);
+// the per-lane operands (the Q / dO / K / V tile of the wave) live in registers.
+//   forward : lane = query.  S^T -> online softmax -> O^T accumulators (rescaled per lane).
+//   backward A (lane = query): S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - D) -> dQ^T += K^T dS^T.
+//   backward B (lane = key)  : S = Q K^T, dP = dO V^T -> dV^T += dO^T P, dK^T += Q^T dS.
+// No atomics, deterministic.  Query/key tiles are dealt to the 4 waves in a zig-zag (heavy tile
+// + light tile) so the causal triangle is balanced.
+#include "rbx_internal.h"
+
+namespace rbx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kT = 32;                      // tile edge (queries or keys)
+
+__device__ __forceinline__ int tile_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// [rows][HD] global -> LDS [rows_pad][HD + 1], scaled, zero beyond `rows`.  float4 global reads, four
+// in flight per thread (one workgroup per CU: nothing else hides this latency); the odd LDS row stride
+// forces scalar LDS writes.
+template <int HD>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* __restrict__ lds, int rows, int rows_pad,
+                                           float scale) {
+  constexpr int Q4 = HD / 4;                               // float4 per row
+  const int total = rows_pad * Q4;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * 256) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      const int r = i / Q4;
+      v[u] = (i < total && r < rows) ? reinterpret_cast<const float4*>(g)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      if (i < total) {
+        const int r = i / Q4, d = (i - r * Q4) * 4;
+        float* dst = lds + r * (HD + 1) + d;
+        dst[0] = v[u].x * scale; dst[1] = v[u].y * scale; dst[2] = v[u].z * scale; dst[3] = v[u].w * scale;
+      }
+    }
+  }
+}
+
+// the wave's own tile as B operands: reg[s] = g[row0 + (lane & 31)][2 s + (lane >> 5)] * scale
+// (both half-waves read the row with float4 loads and keep their parity)
+template <int HD>
+__device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, int row0, int rows, float scale,
+                                               float (&reg)[HD / 2]) {
+  const int lane = threadIdx.x & 63;
+  const int row = row0 + (lane & 31), half = lane >> 5;
+  const bool ok = row < rows;
+  const float4* src = reinterpret_cast<const float4*>(g + static_cast<long long>(ok ? row : 0) * HD);
+#pragma unroll
+  for (int q = 0; q < HD / 4; ++q) {
+    const float4 v = ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    reg[2 * q] = (half ? v.y : v.x) * scale;
+    reg[2 * q + 1] = (half ? v.w : v.z) * scale;
+  }
+}
+
+// acc[row = li of `rows_lds`][col = lane] = sum_d rows_lds[row0 + li][d] * reg[d]
+template <int HD>
+__device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, int row0, const float (&reg)[HD / 2]) {
+  const int lane = threadIdx.x & 63;
+  const float* a = rows_lds + (row0 + (lane & 31)) * (HD + 1) + (lane >> 5);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < HD / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], reg[s], acc, 0, 0, 0);
+  return acc;
+}
+
+// out[dt][row = d][col = lane] += sum_r rows_lds[row0 + tile_row(r)][dt*32 + li] * w[r]
+template <int HD>
+__device__ __forceinline__ void tile_accumulate(const float* __restrict__ rows_lds, int row0, const f32x16& w,
+                                                f32x16 (&out)[HD / 32]) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float* a = rows_lds + (row0 + tile_row(r, half)) * (HD + 1) + li;
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt) out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt * 32], w[r], out[dt], 0, 0, 0);
+  }
+}
+
+// transposed accumulators (row = d, col = lane's row) -> g[row][d] * scale
+template <int HD>
+__device__ __forceinline__ void store_transposed(float* __restrict__ g, int row0, int rows, float scale,
+                                                 const f32x16 (&acc)[HD / 32]) {
+  const int lane = threadIdx.x & 63;
+  const int row = row0 + (lane & 31), half = lane >> 5;
+  if (row >= rows) return;
+#pragma unroll
+  for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(g + static_cast<long long>(row) * HD + dt * 32 + 8 * q + 4 * half) =
+          make_float4(acc[dt][4 * q] * scale, acc[dt][4 * q + 1] * scale, acc[dt][4 * q + 2] * scale,
+                      acc[dt][4 * q + 3] * scale);
+}
+
+// Tile schedule: with L <= 256 there are at most 8 tiles; wave w takes the heavy tile nT-1-w and the
+// light tile w (causal cost of tile t is t+1, so every wave gets ~nT+1 tile steps).
+#define RBX_FOR_WAVE_TILES(nT, wid, t)                                                             \
+  for (int zz_pass = 0, t = (nT) - 1 - (wid); zz_pass < 2 && (wid) <= (nT) - 1 - (wid) &&        \
+                                              !(zz_pass == 1 && (wid) == (nT) - 1 - (wid));        \
+       ++zz_pass, t = (wid))
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                            const float* __restrict__ V, const int L,
+                                                            const float scale, const int causal,
+                                                            float* __restrict__ O, float* __restrict__ LSE) {
+  extern __shared__ float lds[];
+  const int nT = (L + kT - 1) / kT, Lp = nT * kT;
+  float* Ks = lds;
+  float* Vs = lds + Lp * (HD + 1);
+  const long long bh = blockIdx.x;
+  stage_rows<HD>(K + bh * L * HD, Ks, L, Lp, 1.0f);
+  stage_rows<HD>(V + bh * L * HD, Vs, L, Lp, 1.0f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+  RBX_FOR_WAVE_TILES(nT, wid, qt) {
+    const int i0 = qt * kT, qi = i0 + li;
+    float qreg[HD / 2];
+    load_tile_regs<HD>(Q + bh * L * HD, i0, L, scale, qreg);
+    f32x16 oacc[HD / 32];
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+    const int kt_end = causal ? qt : nT - 1;
+    for (int kt = 0; kt <= kt_end; ++kt) {
+      const int j0 = kt * kT;
+      f32x16 s = tile_dot<HD>(Ks, j0, qreg);                 // S^T[key][query]
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kj = j0 + tile_row(r, half);
+        if (kj >= L || (causal && kj > qi)) s[r] = -INFINITY;
+        mx = fmaxf(mx, s[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = (mn == -INFINITY) ? 1.f : __expf(m - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - mn);
+        ps += s[r];
+      }
+      ps += __shfl_xor(ps, 32, 64);
+      lsum = lsum * alpha + ps;
+#pragma unroll
+      for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      m = mn;
+      tile_accumulate<HD>(Vs, j0, s, oacc);                  // O^T[d][query] += V^T P^T
+    }
+    store_transposed<HD>(O + bh * L * HD, i0, L, 1.0f / lsum, oacc);
+    if (half == 0 && qi < L) LSE[bh * L + qi] = m + __logf(lsum);
+  }
+}
+
+// backward phase A: lane = query.  dQ and D = <dO, O>.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                              const float* __restrict__ V,
+                                                              const float* __restrict__ O,
+                                                              const float* __restrict__ dO,
+                                                              const float* __restrict__ LSE, const int L,
+                                                              const float scale, const int causal,
+                                                              float* __restrict__ dQ, float* __restrict__ Dv) {
+  extern __shared__ float lds[];
+  const int nT = (L + kT - 1) / kT, Lp = nT * kT;
+  float* Ks = lds;
+  float* Vs = lds + Lp * (HD + 1);
+  const long long bh = blockIdx.x;
+  stage_rows<HD>(K + bh * L * HD, Ks, L, Lp, 1.0f);
+  stage_rows<HD>(V + bh * L * HD, Vs, L, Lp, 1.0f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+  RBX_FOR_WAVE_TILES(nT, wid, qt) {
+    const int i0 = qt * kT, qi = i0 + li;
+    float qreg[HD / 2], greg[HD / 2], oreg[HD / 2];
+    load_tile_regs<HD>(Q + bh * L * HD, i0, L, scale, qreg);
+    load_tile_regs<HD>(dO + bh * L * HD, i0, L, 1.0f, greg);
+    load_tile_regs<HD>(O + bh * L * HD, i0, L, 1.0f, oreg);
+    float Di = 0.f;
+#pragma unroll
+    for (int s = 0; s < HD / 2; ++s) Di += greg[s] * oreg[s];
+    Di += __shfl_xor(Di, 32, 64);
+    const float lse = (qi < L) ? LSE[bh * L + qi] : 0.f;
+    if (half == 0 && qi < L) Dv[bh * L + qi] = Di;
+    f32x16 dq[HD / 32];
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    const int kt_end = causal ? qt : nT - 1;
+    for (int kt = 0; kt <= kt_end; ++kt) {
+      const int j0 = kt * kT;
+      f32x16 s = tile_dot<HD>(Ks, j0, qreg);                 // S^T
+      const f32x16 dp = tile_dot<HD>(Vs, j0, greg);          // dP^T[key][query] = <V_key, dO_query>
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kj = j0 + tile_row(r, half);
+        const bool vis = kj < L && qi < L && !(causal && kj > qi);
+        const float p = vis ? __expf(s[r] - lse) : 0.f;
+        s[r] = p * (dp[r] - Di);                             // dS^T
+      }
+      tile_accumulate<HD>(Ks, j0, s, dq);                    // dQ^T[d][query] += K^T dS^T
+    }
+    store_transposed<HD>(dQ + bh * L * HD, i0, L, scale, dq);
+  }
+}
+
+// backward phase B: lane = key.  dK, dV.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                               const float* __restrict__ V,
+                                                               const float* __restrict__ dO,
+                                                               const float* __restrict__ LSE,
+                                                               const float* __restrict__ Dv, const int L,
+                                                               const float scale, const int causal,
+                                                               float* __restrict__ dK, float* __restrict__ dV) {
+  extern __shared__ float lds[];
+  const int nT = (L + kT - 1) / kT, Lp = nT * kT;
+  float* Qs = lds;                          // scale * Q
+  float* Gs = Qs + Lp * (HD + 1);           // dO
+  float* Ls = Gs + Lp * (HD + 1);           // lse[Lp]
+  float* Ds = Ls + Lp;                      // D[Lp]
+  const long long bh = blockIdx.x;
+  stage_rows<HD>(Q + bh * L * HD, Qs, L, Lp, scale);
+  stage_rows<HD>(dO + bh * L * HD, Gs, L, Lp, 1.0f);
+  for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
+    Ls[i] = (i < L) ? LSE[bh * L + i] : 0.f;
+    Ds[i] = (i < L) ? Dv[bh * L + i] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+  RBX_FOR_WAVE_TILES(nT, wid, jt) {
+    const int j0 = jt * kT, kj = j0 + li;
+    float kreg[HD / 2], vreg[HD / 2];
+    load_tile_regs<HD>(K + bh * L * HD, j0, L, 1.0f, kreg);
+    load_tile_regs<HD>(V + bh * L * HD, j0, L, 1.0f, vreg);
+    f32x16 dk[HD / 32], dv[HD / 32];
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
+    const int it_beg = causal ? jt : 0;
+    for (int it = it_beg; it < nT; ++it) {
+      const int i0 = it * kT;
+      f32x16 s = tile_dot<HD>(Qs, i0, kreg);                 // S[query][key] (already scaled)
+      const f32x16 dp = tile_dot<HD>(Gs, i0, vreg);          // dP[query][key]
+      f32x16 p;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = i0 + tile_row(r, half);
+        const bool vis = kj < L && qi < L && !(causal && kj > qi);
+        p[r] = vis ? __expf(s[r] - Ls[qi]) : 0.f;
+        s[r] = p[r] * (dp[r] - Ds[qi]);                      // dS
+      }
+      tile_accumulate<HD>(Gs, i0, p, dv);                    // dV^T[d][key] += dO^T P
+      tile_accumulate<HD>(Qs, i0, s, dk);                    // dK^T[d][key] += (scale Q)^T dS
+    }
+    store_transposed<HD>(dK + bh * L * HD, j0, L, 1.0f, dk);
+    store_transposed<HD>(dV + bh * L * HD, j0, L, 1.0f, dv);
+  }
+}
+
+bool attn_mfma_supported(int lq, int lk, int hd, const float* mask, const float* probs) {
+  return mask == nullptr && probs == nullptr && lq == lk && lq <= 256 && (hd == 32 || hd == 64);
+}
+
+template <int HD>
+static size_t lds_bytes(int L, bool phase_b) {
+  const int Lp = (L + kT - 1) / kT * kT;
+  return (static_cast<size_t>(2) * Lp * (HD + 1) + (phase_b ? 2 * Lp : 0)) * sizeof(float);
+}
+
+template <int HD>
+static int run_fwd(const float* q, const float* k, const float* v, long long bh, int L, float scale, int causal, float* o,
+                   float* lse, hipStream_t s) {
+  const size_t lds = lds_bytes<HD>(L, false);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(256), lds, s, q, k, v, L, scale,
+                     causal, o, lse);
+  return check_launch("attn_mfma_fwd_kernel");
+}
+
+template <int HD>
+static int run_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
+                   long long bh, int L, float scale, int causal, float* dq, float* dk, float* dv, float* scratch,
+                   hipStream_t s) {
+  const size_t la = lds_bytes<HD>(L, false), lb = lds_bytes<HD>(L, true);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_q_kernel<HD>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(la));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kv_kernel<HD>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb));
+  hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(256), la, s, q, k, v, o, go, lse,
+                     L, scale, causal, dq, scratch);
+  hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(256), lb, s, q, k, v, go, lse,
+                     scratch, L, scale, causal, dk, dv);
+  return check_launch("attn_mfma_bwd kernels");
+}
+
+int attn_mfma_fwd(const float* q, const float* k, const float* v, long long bh, int L, int hd, float scale, int causal,
+                  float* o, float* lse, hipStream_t s) {
+  return hd == 64 ? run_fwd<64>(q, k, v, bh, L, scale, causal, o, lse, s)
+                  : run_fwd<32>(q, k, v, bh, L, scale, causal, o, lse, s);
+}
+
+int attn_mfma_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
+                  long long bh, int L, int hd, float scale, int causal, float* dq, float* dk, float* dv, float* scratch,
+                  hipStream_t s) {
+  return hd == 64 ? run_bwd<64>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, s)
+                  : run_bwd<32>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, s);
+}
+
+}  // namespace rbx

@@ -222,20 +222,24 @@ def test_sasrec_golden():
     assert_grads_close(model, fx["g"], TOL)
 
 
-def test_attention_causal_l200_d64_matches_torch():
-    """cfg-5 shape of the attention core (L=200, d=64, causal) against torch fp32 on CPU."""
+@pytest.mark.parametrize("L,D,causal", [(200, 64, True), (37, 32, True), (256, 64, False), (64, 32, False),
+                                        (1, 64, True), (200, 16, True)])
+def test_attention_matches_torch(L, D, causal):
+    """The attention core (MFMA path for d in {32, 64}, VALU path otherwise) against torch fp64 on CPU;
+    (200, 64, causal) is the cfg-5 shape."""
     from recbox_amd import ops
     g = torch.Generator().manual_seed(3)
-    B, H, L, D = 3, 1, 200, 64
+    B, H = 3, 2
     q, k, v = (torch.randn(B, H, L, D, generator=g) for _ in range(3))
     R = torch.randn(B, H, L, D, generator=g)
     qr, kr, vr = (t.clone().double().requires_grad_(True) for t in (q, k, v))
     s = (qr @ kr.transpose(-1, -2)) * D ** -0.5
-    s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf"))
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf"))
     o0 = s.softmax(-1) @ vr
     (o0 * R.double()).sum().backward()
     qc, kc, vc = (t.clone().cuda().requires_grad_(True) for t in (q, k, v))
-    o1, _ = ops.attention(qc, kc, vc, scale=D ** -0.5, causal=True, fill=float("-inf"))
+    o1, _ = ops.attention(qc, kc, vc, scale=D ** -0.5, causal=causal, fill=float("-inf"))
     (o1 * R.cuda()).sum().backward()
     assert_close(o1, o0.float(), TOL)
     for a, b, n in ((qc.grad, qr.grad, "dq"), (kc.grad, kr.grad, "dk"), (vc.grad, vr.grad, "dv")):
