@@ -8,7 +8,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "librecbox_hip.so")
+# RECBOX_HIP_LIB points at another build of the same C ABI (kernel A/B runs, system-wide installs)
+LIB_PATH = os.environ.get("RECBOX_HIP_LIB") or os.path.join(HERE, "lib", "librecbox_hip.so")
 
 RBX_MAX_FIELDS = 64
 RBX_NO_ID = -(1 << 63)

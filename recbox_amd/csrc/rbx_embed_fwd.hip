@@ -32,6 +32,10 @@ struct Acc<true> {
   __device__ __forceinline__ float hsum() const { return (v.x + v.y) + (v.z + v.w); }
   __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
   __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+  __device__ __forceinline__ void xor_add(int o) {
+    v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
+    v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+  }
 };
 template <>
 struct Acc<false> {
@@ -42,6 +46,7 @@ struct Acc<false> {
   __device__ __forceinline__ float hsum() const { return v; }
   __device__ __forceinline__ void load(const float* p) { v = *p; }
   __device__ __forceinline__ void store(float* p) const { *p = v; }
+  __device__ __forceinline__ void xor_add(int o) { v += __shfl_xor(v, o, 64); }
 };
 
 // One lane's share of a row: NV units, unit u covers elements [(lane_g + u*G)*W, +W).
@@ -80,6 +85,10 @@ struct RowFrag {
 #pragma unroll
     for (int u = 0; u < NV; ++u) s += a[u].hsum();
     return s;
+  }
+  __device__ __forceinline__ void xor_add(int o) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) a[u].xor_add(o);
   }
 };
 
@@ -170,78 +179,157 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const FieldPack P, const
   }
 }
 
-// Sequence features (multi-hot): one lane group walks the L lookups of ONE (sample, feature) pair
-// with 8 row reads in flight and pools in registers, so [B, L, D] never reaches HBM.  Kept apart from
-// the one-hot kernel so that neither pays the other's registers (one kernel for both ran at 110 VGPRs
-// = 4 waves/SIMD and left the history gather of cfg 3 at 1.7 TB/s).
-template <int G, int NV, bool VEC>
-__global__ __launch_bounds__(256) void embed_seq_kernel(const FieldPack P, const int F, const long long B,
+// Sequence features (multi-hot): one lane group serves ONE (sample, feature) pair and pools in
+// registers, so [B, L, D] never reaches HBM.  Kept apart from the one-hot kernel so that neither pays
+// the other's registers.  Padded histories are half padding on average, so a chunk of the sequence is
+// handled in two steps: (1) the G lanes load their ids in one coalesced sweep, classify them (pad /
+// masked / out of range) and COMPACT the surviving (id, position) pairs into a per-group LDS list with a
+// ballot + popcount prefix; (2) the list is walked U rows at a time, every load slot doing useful work
+// and no id latency between row batches.
+// Narrow rows (dim/4 < 16 lanes): the group is still 16 lanes wide and splits into R sub-groups of
+// W = G/R lanes, sub-group r pooling list entries r, r+R, ...; the partial pools meet in a shuffle
+// butterfly at the end.  This shortens the serial chain per sample R-fold, makes the id sweep read 64+
+// contiguous bytes per sample and evens out ragged lengths inside a wave.  Summation order is fixed by
+// (R, list order) -> deterministic, and equal to sequence order when R == 1.
+template <int G, int R, int NV, bool VEC>
+#ifndef RBX_SEQ_WAVES
+#define RBX_SEQ_WAVES 4
+#endif
+#ifndef RBX_SEQ_SG16
+#define RBX_SEQ_SG16 32
+#endif
+#ifndef RBX_SEQ_U
+#define RBX_SEQ_U 4
+#endif
+__global__ __launch_bounds__(256, RBX_SEQ_WAVES) void embed_seq_kernel(const FieldPack P, const int F, const long long B,
                                                         float* __restrict__ out, const long long stride_b,
                                                         float* __restrict__ row_scale,
                                                         int* __restrict__ status) {
-  using Frag = RowFrag<G, NV, VEC>;
-  constexpr int U = (NV * (VEC ? 4 : 1) <= 4) ? 8 : 4;
+  constexpr int W = G / R;                                // lanes that hold one row
+  using Frag = RowFrag<W, NV, VEC>;
+  constexpr int U = (NV * (VEC ? 4 : 1) <= 4) ? RBX_SEQ_U : 4;   // rows in flight per lane
+#ifndef RBX_SEQ_IPL16
+#define RBX_SEQ_IPL16 4
+#endif
+  constexpr int IPL = (G >= 32) ? 4 : RBX_SEQ_IPL16;                  // ids per lane per chunk (chunk = 128..256 lookups)
+  constexpr int C = G * IPL;                              // lookups per chunk
+  constexpr int GPB = 256 / G;
+  __shared__ int s_id[GPB][C];
+  __shared__ int s_pos[GPB][C];
+  const int lane_w = threadIdx.x % W;
+  const int sub = (threadIdx.x % G) / W;
   const int lane_g = threadIdx.x % G;
-  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
-  const long long npairs = B * F;
-  for (long long p = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; p < npairs;
-       p += ngroups) {
-    // sample fastest: the groups of a wave work on the SAME feature (uniform loop bounds, one table)
-    const int f = (npairs < (1ll << 32)) ? static_cast<int>(static_cast<unsigned>(p) / static_cast<unsigned>(B))
-                                         : static_cast<int>(p / B);
-    const long long b = p - static_cast<long long>(f) * B;
-    const FieldK fd = P.f[f];                             // private copy: no re-reads inside the loops
-    const int L = fd.seq_len, pool = fd.pool, dim = fd.dim, dt = fd.ids_dtype;
+  const int gidx = threadIdx.x / G;
+  const int gshift = (threadIdx.x & 63) & ~(G - 1);       // first lane of the group inside its wave
+  const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+  const unsigned long long below = (1ull << lane_g) - 1ull;
+  volatile int* my_id = s_id[gidx];
+  volatile int* my_pos = s_pos[gidx];
+  // A wavefront works on ONE feature: wave task t = (feature, block of 64/G samples).  The descriptor is
+  // then wave-uniform -- it lives in SGPRs, straight from the kernarg segment, instead of 14 VGPRs.
+  constexpr int GPW = 64 / G;
+  const long long tasks_per_field = (B + GPW - 1) / GPW;
+  const long long ntasks = tasks_per_field * F;
+  const long long nwaves = static_cast<long long>(gridDim.x) * 4;
+  for (long long t = static_cast<long long>(blockIdx.x) * 4 + threadIdx.x / 64; t < ntasks; t += nwaves) {
+    const int f = __builtin_amdgcn_readfirstlane(static_cast<int>(t / tasks_per_field));
+    const long long b = (t - f * tasks_per_field) * GPW + (threadIdx.x & 63) / G;
+    const bool alive = b < B;
+    const FieldK& fd = P.f[f];
+    const int L = alive ? fd.seq_len : 0, pool = fd.pool, dim = fd.dim, dt = fd.ids_dtype;
     const bool id_pool = (pool == RBX_POOL_MEAN_ID || pool == RBX_POOL_SUM_ID);
     float* dst = out + b * stride_b + fd.out_off;
     const long long base = b * fd.ids_stride_b;
     Frag acc;
     acc.zero();
     float count = 0.f;
-    for (int l0 = 0; l0 < L; l0 += U) {
-      long long ids[U];
+    // wave-uniform number of chunks
+    int Lmax = L;
 #pragma unroll
-      for (int j = 0; j < U; ++j) {                       // phase 1: id loads only
-        const int l = (l0 + j < L) ? l0 + j : L - 1;
-        ids[j] = load_raw(fd.ids, base + static_cast<long long>(l) * fd.ids_stride_l, dt);
+    for (int o = 32; o >= G && o > 0; o >>= 1) {
+      const int other = __shfl_xor(Lmax, o, 64);
+      Lmax = other > Lmax ? other : Lmax;
+    }
+    for (int c0 = 0; c0 < Lmax; c0 += C) {
+      long long raw[IPL];
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) {                     // (1a) one coalesced sweep of id loads
+        const int l = c0 + i * G + lane_g;
+        raw[i] = (l < L) ? load_raw(fd.ids, base + static_cast<long long>(l) * fd.ids_stride_l, dt) : 0;
       }
-      Frag r[U];
-      bool use[U];
+      int nvalid = 0;
 #pragma unroll
-      for (int j = 0; j < U; ++j) {                       // phase 2: row loads
-        r[j].zero();
-        const long long id = decode_id(ids[j], dt);
-        const bool live = l0 + j < L;
+      for (int i = 0; i < IPL; ++i) {                     // (1b) classify + compact
+        const int l = c0 + i * G + lane_g;
+        const long long id = decode_id(raw[i], dt);
+        const bool live = l < L;
         const bool in_range = id >= 0 && id < fd.vocab;
         if (live && !in_range && status != nullptr) atomicOr(status, 1);
-        // id-masked rows get weight 0 in the reference's bmm: skip their traffic
-        use[j] = live && in_range && !(id_pool && id == fd.mask_id);
-        if (use[j]) r[j].load(fd.table + id * dim, dim, lane_g);
+        // id-masked rows get weight 0 in the reference's bmm: skip their traffic.  concat keeps every slot.
+        const bool use = live && (pool == RBX_POOL_CONCAT || (in_range && !(id_pool && id == fd.mask_id)));
+        const unsigned long long m = (__ballot(use) >> gshift) & gmask;
+        if (use) {
+          const int k = nvalid + __popcll(m & below);
+          my_id[k] = in_range ? static_cast<int>(id) : -1;
+          my_pos[k] = l;
+        }
+        nvalid += __popcll(m);
       }
+      __builtin_amdgcn_wave_barrier();
+      int nmax = nvalid;                                   // wave-uniform batch count
 #pragma unroll
-      for (int j = 0; j < U; ++j) {                       // phase 3: pool / keep
-        if (l0 + j >= L) continue;
-        if (pool == RBX_POOL_CONCAT) {
-          r[j].store(dst + static_cast<long long>(l0 + j) * dim, dim, lane_g);
-        } else {
-          acc.add(r[j]);
-          if (pool == RBX_POOL_MEAN_VALUE) {
-            const float sm = group_sum<G>(r[j].hsum());   // value mask: row sum != 0
-            count += (sm != 0.f) ? 1.f : 0.f;
-          } else if (pool == RBX_POOL_MEAN_ID) {
-            count += use[j] ? 1.f : 0.f;
+      for (int o = 32; o >= G && o > 0; o >>= 1) {
+        const int other = __shfl_xor(nmax, o, 64);
+        nmax = other > nmax ? other : nmax;
+      }
+      // (2) dense row batches.  U = 4 rows per lane in flight: deeper batches (8) or software pipelining
+      // cost registers, i.e. resident waves, and measured slower at every row width (profiles/r01_kernels_bench.txt)
+      for (int k0 = 0; k0 < nmax; k0 += U * R) {
+        int idu[U], lu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = k0 + u * R + sub;
+          idu[u] = (k < nvalid) ? my_id[k] : -1;
+          lu[u] = (k < nvalid) ? my_pos[k] : -1;
+        }
+        Frag r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          r[u].zero();
+          if (idu[u] >= 0) r[u].load(fd.table + static_cast<long long>(idu[u]) * dim, dim, lane_w);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (pool == RBX_POOL_CONCAT) {
+            if (lu[u] >= 0) r[u].store(dst + static_cast<long long>(lu[u]) * dim, dim, lane_w);
+          } else {
+            acc.add(r[u]);
+            if (pool == RBX_POOL_MEAN_VALUE) {
+              const float sm = group_sum<W>(r[u].hsum());   // value mask: row sum != 0
+              count += (sm != 0.f) ? 1.f : 0.f;
+            } else if (pool == RBX_POOL_MEAN_ID) {
+              count += (lu[u] >= 0) ? 1.f : 0.f;
+            }
           }
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    if (pool == RBX_POOL_CONCAT) continue;
+    if (pool != RBX_POOL_CONCAT) {                         // wave-uniform: every lane joins the butterfly
+#pragma unroll
+      for (int o = W; o < G; o <<= 1) {
+        acc.xor_add(o);
+        count += __shfl_xor(count, o, 64);
+      }
+    }
+    if (!alive || pool == RBX_POOL_CONCAT || sub != 0) continue;
     if (pool == RBX_POOL_MEAN_VALUE || pool == RBX_POOL_MEAN_ID) {
       const float inv = 1.0f / (count + fd.eps);
       // the reference divides; x * (1/(c+eps)) differs from x / (c+eps) by <= 1 ulp
       acc.scale(inv);
-      if (row_scale != nullptr && lane_g == 0) row_scale[static_cast<long long>(fd.slot) * B + b] = inv;
+      if (row_scale != nullptr && lane_w == 0) row_scale[static_cast<long long>(fd.slot) * B + b] = inv;
     }
-    acc.store(dst, dim, lane_g);
+    acc.store(dst, dim, lane_w);
   }
 }
 
@@ -249,13 +337,15 @@ template <int G, int NV, bool VEC>
 static int launch_fwd(bool seq, const FieldPack& pack, int F, int64_t B, float* out, int64_t stride_b,
                       float* row_scale, int* status, hipStream_t s) {
   const long long npairs = B * F;
-  const int groups_per_block = 256 / G;
+  constexpr int SG = (G <= 8) ? 16 : ((G == 16) ? RBX_SEQ_SG16 : 64);   // lanes per (sample, sequence feature)
+  const int groups_per_block = 256 / (seq ? SG : G);
   long long blocks = (npairs + groups_per_block - 1) / groups_per_block;
+  if (seq) blocks = ((B + 64 / SG - 1) / (64 / SG) * F + 3) / 4;          // 4 wave tasks per workgroup
   const long long cap = static_cast<long long>(kCUs) * (seq ? 64 : 8);   // sequences: one pair per group, many waves
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   if (seq)
-    hipLaunchKernelGGL((embed_seq_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, pack, F,
+    hipLaunchKernelGGL((embed_seq_kernel<SG, SG / G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, pack, F,
                        static_cast<long long>(B), out, static_cast<long long>(stride_b), row_scale, status);
   else
     hipLaunchKernelGGL((embed_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, pack, F,
