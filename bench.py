@@ -154,12 +154,10 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded model even at world size 1 (exercises the RCCL exchange path)")
     ap.add_argument("--shard-min-vocab", type=int, default=100000)
-    ap.add_argument("--graph-sharded", action="store_true",
-                    help="try to capture the sharded step (padded exchange + RCCL) in a hipGraph; OFF by default: "
-                         "on ROCm 7.2 / torch 2.10 capturing RCCL collectives hung the process in round 1")
-    ap.add_argument("--capacity-factor", type=float, default=0.0,
-                    help="slots per peer of the sync-free padded exchange, relative to a perfectly balanced batch; "
-                         "0 = exact all-to-all-v (host sync per call, no graph capture)")
+    ap.add_argument("--capacity-factor", type=float, default=1.5,
+                    help="slots per peer of the sync-free padded exchange, relative to a perfectly balanced batch "
+                         "(doubled automatically if the warm-up overflows); 0 = exact all-to-all-v (host sync per "
+                         "call, eager launches only)")
     ap.add_argument("--path", choices=["fused", "layers"], default="fused",
                     help="fused: FM model body in rbx_fm_fwd/bwd; layers: drop-in layers composed as the reference does")
     args = ap.parse_args()
@@ -180,17 +178,23 @@ def main():
     ops.config.check_ids = False              # no per-call host sync inside the timed region
     fmw = CriteoFeatureMap(args.dim)
     sharded = world > 1 or args.force_sharded
-    if sharded:
-        # big tables row-sharded over the ranks (all-to-all-v over RCCL/xGMI), small ones replicated
-        model = ShardedFM(fmw.fm, args.dim, shard_min_vocab=args.shard_min_vocab,
-                          capacity_factor=(args.capacity_factor or None)).to(dev)
-    else:
-        model = FM(fmw.fm, args.dim, fused=(args.path == "fused")).to(dev)
-    init_weights(model)                       # same seed on every rank: replicated parameters start identical
     B = args.batch
     batch = synthetic_batch(B, 1 + rank, args.dist, dev)
     X, y = slice_inputs(fmw.fm, batch)
     n_fields = len(fmw.fm.features)
+    cap_factor = args.capacity_factor
+
+    def build_model():
+        if sharded:
+            # big tables row-sharded over the ranks (all-to-all over RCCL/xGMI), small ones replicated
+            m = ShardedFM(fmw.fm, args.dim, shard_min_vocab=args.shard_min_vocab,
+                          capacity_factor=(cap_factor or None)).to(dev)
+        else:
+            m = FM(fmw.fm, args.dim, fused=(args.path == "fused")).to(dev)
+        init_weights(m)                       # same seed on every rank: replicated parameters start identical
+        return m
+
+    model = build_model()
 
     def eager_step():
         model.zero_grad(set_to_none=True)
@@ -203,20 +207,31 @@ def main():
             loss.backward()
         return loss
 
+    def overflowed():
+        flag = model.tables.overflow.float().reshape(1).clone()
+        if world > 1:
+            torch.distributed.all_reduce(flag)
+        return bool(flag.item() > 0)
+
     step = eager_step
     graph_note = "eager launches"
-    if not args.eager and (not sharded or (args.graph_sharded and args.capacity_factor)):
-        # one hipGraph holds the whole step (same kernels, same C ABI, and -- when sharded -- the RCCL
-        # exchanges of the padded sync-free routing); the batch lives in static buffers
+    if not args.eager and not sharded:
+        # one hipGraph holds the whole step (same kernels, same C ABI); the batch lives in static buffers
         from recbox_amd.graph import GraphedStep
-        try:
-            step = GraphedStep(eager_step, warmup=3, capture_error_mode="thread_local" if sharded else "global")
-            graph_note = "hipGraph replay"
-        except Exception as exc:                       # e.g. a collective that refuses capture: stay eager
-            if rank == 0:
-                print("[bench] graph capture failed (%s: %s); running eagerly" % (type(exc).__name__, exc), file=sys.stderr)
-            torch.cuda.synchronize()
-            step = eager_step
+        step = GraphedStep(eager_step, warmup=3)
+        graph_note = "hipGraph replay"
+    elif sharded and cap_factor and model.tables is not None:
+        # padded sync-free exchange: the step is four hipGraph pieces with the RCCL collectives between them
+        from recbox_amd.graph import ShardedFMStep
+        for _ in range(4):
+            step = ShardedFMStep(model, X, y, graphs=not args.eager)
+            step()
+            if not overflowed():
+                break
+            cap_factor *= 2                   # skewed ids: some owner received more than its slots; start over
+            del step
+            model = build_model()
+        graph_note = "4 hipGraph pieces + eager RCCL collectives" if not args.eager else "eager launches"
 
     for _ in range(args.warmup):
         step()
@@ -225,7 +240,8 @@ def main():
         timer = ops.KernelTimer(lambda m: m[0] == "fm_fwd")
     else:
         timer = ops.KernelTimer(lambda m: m[0] == "embed_fwd" and m[2] == n_fields * args.dim)
-    if step is eager_step:
+    plain_eager = step is eager_step or (sharded and args.eager)
+    if plain_eager:
         ops.kernel_timer = timer
     if world > 1:
         torch.distributed.barrier()
@@ -237,7 +253,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     el = time.perf_counter() - t0
-    if step is not eager_step:
+    if not plain_eager:
         # a graph replay cannot be bracketed from Python: time the dominant kernel with HIP events
         # on the launch stream over the same steps launched eagerly right after the timed region
         ops.kernel_timer = timer
@@ -250,12 +266,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
 
-    overflow = False
-    if sharded and model.tables is not None:
-        flag = model.tables.overflow.float().reshape(1)
-        if world > 1:
-            torch.distributed.all_reduce(flag)
-        overflow = bool(flag.item() > 0)
+    overflow = overflowed() if (sharded and model.tables is not None) else False
     if rank == 0:
         ms = el / args.steps * 1e3
         # algorithmic bytes of the gather per sample: 26 rows x 64 B
@@ -288,8 +299,8 @@ def main():
                           "parallelism": ("dp%d + row-sharded tables (all-to-all-v)" % world) if sharded else "dp1"},
                "roofline": roof}
         if sharded:
-            out["config"]["exchange"] = ("padded capacity_factor=%g, overflow=%s" % (args.capacity_factor, overflow)
-                                         if args.capacity_factor else "exact all-to-all-v")
+            out["config"]["exchange"] = ("padded capacity_factor=%g, overflow=%s" % (cap_factor, overflow)
+                                         if cap_factor else "exact all-to-all-v")
             if overflow:
                 out["config"]["warning"] = "exchange capacity overflowed: rerun with a larger --capacity-factor"
         if world == 1 and not args.no_cpu_baseline:

@@ -147,16 +147,33 @@ int rbx_interaction_bwd(const float* d_emb, const float* d_dout, int64_t batch, 
  * not): a caller that sorts on another stream runs phase 2 first and phase 1 after the join. */
 int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                const float* d_lr_bias, const float* d_extra, int32_t n_extra, int32_t extra_stride,
-               int32_t extra_lr_off, float* d_logit, float* d_sum, int32_t* d_status, void* stream);
+               int32_t extra_lr_off, const int32_t* d_extra_index, int64_t extra_rows, float* d_logit,
+               float* d_sum, int32_t* d_status, void* stream);
 /* Rows of row-sharded tables arrive from their owners instead of being gathered locally:
  * d_extra[B, n_extra, extra_stride] holds, per (sample, table), the embedding row in floats [0, D)
  * and the dim-1 LR weight at float extra_lr_off (-1: none); they take part in S, Q and the LR sum
  * exactly like local features.  rbx_fm_extra_bwd writes their gradient block in the same packed
  * layout ([g (S - e) | g at the LR slot | 0]); it travels back to the owners (recbox_amd/sharded.py).
- * dim == 0 there means "LR weights only". */
+ * dim == 0 there means "LR weights only".
+ * d_extra_index (optional, [B, n_extra] int32): d_extra is then the exchange buffer itself,
+ * [extra_rows, extra_stride], and row (b, t) sits at wire slot d_extra_index[b, t] (rbx_route); a slot
+ * outside [0, extra_rows) is a lookup that found no room on the wire: zero row, no gradient.  The
+ * indexed rbx_fm_extra_bwd writes only the slots that are referenced: the caller zero-fills d_dextra. */
 int rbx_fm_extra_bwd(const float* d_dlogit, const float* d_sum, const float* d_extra, int64_t batch,
                      int32_t n_extra, int32_t dim, int32_t extra_stride, int32_t extra_lr_off,
-                     float* d_dextra, void* stream);
+                     const int32_t* d_extra_index, int64_t extra_rows, float* d_dextra, void* stream);
+
+/* ---- C1: routing of the padded, sync-free exchange of row-sharded tables (no reference precedent:
+ * SURVEY.md 2.1 / 8e; layout in recbox_amd/sharded.py).  d_ids [batch, n_tables] int64, lookup
+ * i = b * n_tables + t.  owner = id mod world; d_base[world, n_tables] = first row of table t inside
+ * the owner's packed weight; the row number base[owner][t] + id div world is written to wire slot
+ * d_slot[i] = owner * capacity + (count of earlier lookups with that owner) of d_send[world * capacity]
+ * (empty slots = -1).  Lookups that do not fit get slot world * capacity and set *d_overflow = 1
+ * (never cleared here).  Stable and deterministic; no host sync. */
+size_t rbx_route_workspace_size(int64_t n_lookups, int32_t world);
+int rbx_route(const int64_t* d_ids, int64_t n_lookups, int32_t n_tables, int32_t world, int64_t capacity,
+              const int64_t* d_base, int64_t* d_send, int32_t* d_slot, uint8_t* d_overflow, void* d_workspace,
+              size_t workspace_bytes, void* stream);
 size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch);
 int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                 void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream);

@@ -39,11 +39,11 @@ def fields(kind, tables, dim):
 
 def time_it(ea, la, tag):
     for _ in range(5):
-        L.check(L.lib.rbx_fm_fwd(ea, la, n, B, None, None, 0, 0, -1, logit.data_ptr(), ssum.data_ptr() if ea else None, None, None))
+        L.check(L.lib.rbx_fm_fwd(ea, la, n, B, None, None, 0, 0, -1, None, 0, logit.data_ptr(), ssum.data_ptr() if ea else None, None, None))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(50):
-        L.check(L.lib.rbx_fm_fwd(ea, la, n, B, None, None, 0, 0, -1, logit.data_ptr(), ssum.data_ptr() if ea else None, None, None))
+        L.check(L.lib.rbx_fm_fwd(ea, la, n, B, None, None, 0, 0, -1, None, 0, logit.data_ptr(), ssum.data_ptr() if ea else None, None, None))
     e1.record()
     torch.cuda.synchronize()
     print("%-44s %7.1f us" % (tag, e0.elapsed_time(e1) * 1000 / 50))
@@ -85,7 +85,7 @@ for flush in (False, True):
             scratch.zero_()                       # 512 MB of writes: evicts L2 and the 256 MB Infinity Cache
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(L.lib.rbx_fm_fwd(ea, la, N_DENSE + n, B, None, None, 0, 0, -1, logit.data_ptr(), ssum.data_ptr(), None, None))
+        L.check(L.lib.rbx_fm_fwd(ea, la, N_DENSE + n, B, None, None, 0, 0, -1, None, 0, logit.data_ptr(), ssum.data_ptr(), None, None))
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1000)

@@ -75,6 +75,23 @@ def all_to_all_equal(x, group=None):
     return all_to_all_rows(x, [c] * W, [c] * W, group)
 
 
+def all_to_all_equal_into(out, x, group=None):
+    """all_to_all_equal into a caller-owned buffer (static buffers between hipGraph pieces)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        out.copy_(x)
+    elif dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(out, x, group=group)
+    else:
+        out.copy_(all_to_all_equal(x, group))
+    return out
+
+
+def all_reduce_sum_(x, group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(x, group=group)
+    return x
+
+
 def all_reduce_grads(params, group=None):
     """Data-parallel towers: one all-reduce (sum) per dense gradient."""
     _, W = world(group)

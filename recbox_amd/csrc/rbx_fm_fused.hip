@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
                                                            const float* __restrict__ bias,
                                                            const float* __restrict__ xe, const int n_extra,
                                                            const int x_stride, const int x_lr_off,
+                                                           const int* __restrict__ xidx, const long long x_rows,
                                                            float* __restrict__ logit, float* __restrict__ ssum,
                                                            int* __restrict__ status) {
   constexpr int W = VEC ? 4 : 1;
@@ -122,25 +123,54 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
         lr += l1[u] * x[u];
       }
     }
-    // rows that were fetched elsewhere (row-sharded tables: the owners sent them back): the
-    // sample's [n_extra, D] block is contiguous, so these reads are coalesced
-    for (int t = 0; t < n_extra; ++t) {
-      const float* row = xe + (b * n_extra + t) * static_cast<long long>(x_stride);
-      if (has_emb) {
+    // rows that were fetched elsewhere (row-sharded tables: the owners sent them back).  Without an index the
+    // sample's [n_extra, stride] block is contiguous (coalesced reads); with one, row (b, t) sits at wire
+    // slot xidx[b, t] of the exchange buffer (slots outside [0, x_rows) = lookups that did not fit: zero rows),
+    // which saves the un-permute pass over the buffer.  4 rows in flight per lane.
+    for (int t0 = 0; t0 < n_extra; t0 += 4) {
+      long long ridx[4];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const int d = (lane_g + v * G) * W;
-          if (d < D) {
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u;
+        ridx[u] = -1;
+        if (t < n_extra) ridx[u] = (xidx != nullptr) ? static_cast<long long>(xidx[b * n_extra + t]) : b * n_extra + t;
+        if (xidx != nullptr && ridx[u] >= x_rows) ridx[u] = -1;
+      }
+      float e[4][NA];
+      float l1[4];
 #pragma unroll
-            for (int k = 0; k < W; ++k) {
-              const float e = row[d + k];
-              s[v * W + k] += e;
-              q[v * W + k] += e * e;
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) e[u][i] = 0.f;
+        l1[u] = 0.f;
+        if (ridx[u] >= 0) {
+          const float* row = xe + ridx[u] * static_cast<long long>(x_stride);
+          if (has_emb) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+              const int d = (lane_g + v * G) * W;
+              if (d < D) {
+                if constexpr (VEC) {
+                  const float4 tt = *reinterpret_cast<const float4*>(row + d);     // stride % 4 == 0 is validated
+                  e[u][v * 4] = tt.x; e[u][v * 4 + 1] = tt.y; e[u][v * 4 + 2] = tt.z; e[u][v * 4 + 3] = tt.w;
+                } else {
+                  e[u][v] = row[d];
+                }
+              }
             }
           }
+          if (x_lr_off >= 0 && lane_g == ((t0 + u) % G)) l1[u] = row[x_lr_off];
         }
       }
-      if (x_lr_off >= 0 && lane_g == (t % G)) lr += row[x_lr_off];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          s[i] += e[u][i];
+          q[i] += e[u][i] * e[u][i];
+        }
+        lr += l1[u];
+      }
     }
     float fm = 0.f;
 #pragma unroll
@@ -303,6 +333,7 @@ __global__ __launch_bounds__(256) void fm_extra_bwd_kernel(const float* __restri
                                                            const float* __restrict__ x, const long long B,
                                                            const int n_extra, const int D, const int stride,
                                                            const int lr_off, const bool has_emb,
+                                                           const int* __restrict__ xidx, const long long x_rows,
                                                            float* __restrict__ dx) {
   const long long total = B * n_extra * stride;
   const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
@@ -310,10 +341,16 @@ __global__ __launch_bounds__(256) void fm_extra_bwd_kernel(const float* __restri
     const long long bt = i / stride;
     const int c = static_cast<int>(i - bt * stride);
     const long long b = bt / n_extra;
+    long long at = i;                              // position of this float in x / dx
+    if (xidx != nullptr) {
+      const long long r = xidx[bt];
+      if (r < 0 || r >= x_rows) continue;          // lookup without a wire slot: no gradient
+      at = r * stride + c;
+    }
     float v = 0.f;
-    if (has_emb && c < D) v = g[b] * (ssum[b * D + c] - x[i]);
+    if (has_emb && c < D) v = g[b] * (ssum[b * D + c] - x[at]);
     else if (c == lr_off) v = g[b];
-    dx[i] = v;
+    dx[at] = v;
   }
 }
 
@@ -372,28 +409,30 @@ static int fm_validate(const rbx_field_t* emb, const rbx_field_t* lr, int n, int
 
 template <int G, int NV, bool VEC>
 static int launch_fm_fwd(const FmHost& h, int64_t B, const float* bias, const float* xe, int n_extra, int x_stride,
-                         int x_lr_off, float* logit, float* ssum, int* status, hipStream_t s) {
+                         int x_lr_off, const int* xidx, long long x_rows, float* logit, float* ssum, int* status,
+                         hipStream_t s) {
   const int gpb = 256 / G;
   long long blocks = (B + gpb - 1) / gpb;
   if (blocks > kCUs * 16) blocks = kCUs * 16;
   hipLaunchKernelGGL((fm_fused_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, h.pack,
-                     h.F, static_cast<long long>(B), h.D, h.has_emb, h.has_lr, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum,
-                     status);
+                     h.F, static_cast<long long>(B), h.D, h.has_emb, h.has_lr, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows,
+                     logit, ssum, status);
   return check_launch("fm_fused_fwd_kernel");
 }
 
 template <bool VEC>
 static int dispatch_fm_fwd(const FmHost& h, int64_t B, const float* bias, const float* xe, int n_extra, int x_stride,
-                           int x_lr_off, float* logit, float* ssum, int* status, hipStream_t s) {
+                           int x_lr_off, const int* xidx, long long x_rows, float* logit, float* ssum, int* status,
+                         hipStream_t s) {
   const int units = VEC ? h.D / 4 : h.D;
   switch (pow2_ceil(units)) {
-    case 1: return launch_fm_fwd<1, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
-    case 2: return launch_fm_fwd<2, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
-    case 4: return launch_fm_fwd<4, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
-    case 8: return launch_fm_fwd<8, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
-    case 16: return launch_fm_fwd<16, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
-    case 32: return launch_fm_fwd<32, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
-    case 64: return launch_fm_fwd<64, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, logit, ssum, status, s);
+    case 1: return launch_fm_fwd<1, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
+    case 2: return launch_fm_fwd<2, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
+    case 4: return launch_fm_fwd<4, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
+    case 8: return launch_fm_fwd<8, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
+    case 16: return launch_fm_fwd<16, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
+    case 32: return launch_fm_fwd<32, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
+    case 64: return launch_fm_fwd<64, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
     default: return fail(RBX_ERR_UNSUPPORTED, "fm: embedding dim %d too large to fuse", h.D);
   }
 }
@@ -463,7 +502,8 @@ static size_t fm_num_bytes(const BwdPlan& p, int n_num, int D) {
 
 extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                           const float* d_lr_bias, const float* d_extra, int32_t n_extra, int32_t extra_stride,
-                          int32_t extra_lr_off, float* d_logit, float* d_sum, int32_t* d_status, void* stream) {
+                          int32_t extra_lr_off, const int32_t* d_extra_index, int64_t extra_rows, float* d_logit,
+                          float* d_sum, int32_t* d_status, void* stream) {
   using namespace rbx;
   FmHost h;
   int rc = fm_validate(emb, lr, n_fields, batch, &h);
@@ -478,11 +518,13 @@ extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
     if (extra_stride < need || extra_lr_off >= extra_stride || (extra_lr_off >= 0 && extra_lr_off < need))
       return fail(RBX_ERR_INVALID, "fm: extra rows: stride %d / lr offset %d do not fit dim %d", extra_stride,
                   extra_lr_off, need);
+    if (d_extra_index != nullptr && extra_rows <= 0) return fail(RBX_ERR_INVALID, "fm: indexed extra rows need extra_rows > 0");
+    if (h.vec && (extra_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(d_extra) & 15) != 0)) h.vec = false;
   }
-  return h.vec ? dispatch_fm_fwd<true>(h, batch, d_lr_bias, d_extra, n_extra, extra_stride, extra_lr_off, d_logit, d_sum,
-                                       d_status, as_stream(stream))
-               : dispatch_fm_fwd<false>(h, batch, d_lr_bias, d_extra, n_extra, extra_stride, extra_lr_off, d_logit,
-                                        d_sum, d_status, as_stream(stream));
+  return h.vec ? dispatch_fm_fwd<true>(h, batch, d_lr_bias, d_extra, n_extra, extra_stride, extra_lr_off, d_extra_index,
+                                       extra_rows, d_logit, d_sum, d_status, as_stream(stream))
+               : dispatch_fm_fwd<false>(h, batch, d_lr_bias, d_extra, n_extra, extra_stride, extra_lr_off, d_extra_index,
+                                        extra_rows, d_logit, d_sum, d_status, as_stream(stream));
 }
 
 extern "C" size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields,
@@ -553,7 +595,7 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
 
 extern "C" int rbx_fm_extra_bwd(const float* d_dlogit, const float* d_sum, const float* d_extra, int64_t batch,
                                 int32_t n_extra, int32_t dim, int32_t extra_stride, int32_t extra_lr_off,
-                                float* d_dextra, void* stream) {
+                                const int32_t* d_extra_index, int64_t extra_rows, float* d_dextra, void* stream) {
   using namespace rbx;
   if (d_dlogit == nullptr || d_dextra == nullptr) return fail(RBX_ERR_INVALID, "fm_extra_bwd: NULL tensor");
   const bool has_emb = dim > 0;
@@ -565,6 +607,6 @@ extern "C" int rbx_fm_extra_bwd(const float* d_dlogit, const float* d_sum, const
   if (blocks > kCUs * 8) blocks = kCUs * 8;
   hipLaunchKernelGGL(fm_extra_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_dlogit,
                      d_sum, d_extra, static_cast<long long>(batch), n_extra, dim, extra_stride, extra_lr_off, has_emb,
-                     d_dextra);
+                     d_extra_index, static_cast<long long>(extra_rows), d_dextra);
   return check_launch("fm_extra_bwd_kernel");
 }

@@ -43,3 +43,117 @@ class GraphedStep(object):
     def __call__(self):
         self.graph.replay()
         return self.out
+
+
+class ShardedFMStep(object):
+    """One training step of ``ShardedFM`` (row-sharded tables, padded sync-free exchange) as FOUR hipGraph
+    pieces with the RCCL collectives launched between them:
+
+        route      ids -> (owner, row) -> wire slots                      [graph]
+        all-to-all row numbers to the owners                              RCCL
+        serve      owners gather the packed rows (rbx_embed_fwd)          [graph]
+        all-to-all rows back                                              RCCL
+        local      fused FM forward (remote rows read at their wire slots),
+                   loss, fused backward of the replicated tables,
+                   dL/d(remote rows) written to the wire slots, flat grads [graph]
+        all-to-all dL/d(rows) to the owners; all-reduce of the flat
+                   gradient of the replicated parameters                  RCCL
+        settle     owners scatter-add into their shard's dense grad
+                   (rbx_embed_sort + rbx_embed_bwd), grads un-flattened   [graph]
+
+    Capturing a collective inside a hipGraph is not dependable on this stack (round 1: the capture of a
+    torch.distributed all_to_all_single hung), so the graphs stop at the collectives; the host cost per step is
+    4 graph launches + 4 collectives instead of ~150 eager kernel launches.  ``graphs=False`` runs the same
+    pieces eagerly (tests, debugging).  Inputs ``X`` (dict of static tensors) and ``y`` are read in place:
+    refill them before every call.  After a call, ``.grad`` of every parameter is what
+    ``(bce(model(X), y) / world).backward(); model.sync_grads()`` leaves."""
+
+    def __init__(self, model, X, y, graphs=True, warmup=2, loss_fn=None):
+        from . import comm
+        if model.tables is None or model.tables.capacity_factor is None:
+            raise ValueError("ShardedFMStep needs row-sharded tables with the padded exchange (capacity_factor)")
+        if graphs and ops.config.check_ids:
+            raise RuntimeError("ShardedFMStep: set recbox_amd.ops.config.check_ids = False first")
+        self.model, self.X, self.y = model, X, y
+        self.tables = tables = model.tables
+        self.group = tables.group
+        self.W = W = tables.world_size
+        self.loss_fn = loss_fn or (lambda prob, target: torch.nn.functional.binary_cross_entropy(
+            prob, target, reduction="mean"))
+        ids = model.sharded_ids(X)
+        self.B, self.T = ids.shape
+        self.cap = cap = tables.capacity_for(ids.numel())
+        dev, width = ids.device, tables.row_width
+        # wire buffers: written by one piece / collective, read by the next
+        self.recv = torch.full((W * cap,), -1, dtype=torch.long, device=dev)
+        self.back = torch.zeros((W * cap, width), dtype=torch.float32, device=dev)
+        self.d_recv = torch.zeros((W * cap, width), dtype=torch.float32, device=dev)
+        self.replicated = [p for p in model.replicated_parameters() if p.requires_grad]
+        self.sizes = [p.numel() for p in self.replicated]
+        self.comm = comm
+        self.pieces = [self._route, self._serve, self._local, self._settle]
+        self.graphs = None
+        if graphs:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):           # allocator, plans, RCCL communicator: warm before capturing
+                for _ in range(warmup):
+                    self._run(self.pieces)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graphs = []
+            for piece in self.pieces:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    piece()
+                self.graphs.append(g.replay)
+
+    # ---- pieces (each one a fixed kernel sequence over static buffers) ----------------------------------
+    def _route(self):
+        slot, self.send = self.tables.route(self.model.sharded_ids(self.X), self.cap)      # rbx_route
+        self.slot = slot.contiguous()
+
+    def _serve(self):
+        self.vecs = self.tables.local_ops.gather(self.tables.weight, self.recv)
+
+    def _local(self):
+        for p in self.replicated:
+            p.grad = None
+        # the fused FM kernels read row (b, t) at wire slot slot[b, t] of the exchange buffer and write
+        # dL/d(row) to the same slot: no un-permute pass in either direction
+        back = self.back.detach().requires_grad_()
+        prob = torch.sigmoid(self.model.logits(self.X, packed=back, packed_index=self.slot))
+        self.loss = self.loss_fn(prob, self.y)
+        (self.loss / self.W).backward()           # global-mean loss: owners sum the contributions of every rank
+        self.loss = self.loss.detach()            # do not keep the autograd graph alive between steps
+        self.dsend = back.grad
+        self.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                               for p in self.replicated]) if self.replicated else None
+
+    def _settle(self):
+        self.tables.weight.grad = self.tables.local_ops.scatter_add(self.tables.weight, self.recv, self.d_recv)
+        if self.flat is not None and self.W > 1:
+            o = 0
+            for p, n in zip(self.replicated, self.sizes):
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(self.flat[o:o + n].view_as(p))
+                o += n
+
+    # ---- the step ------------------------------------------------------------------------------------------
+    def _run(self, pieces):
+        route, serve, local, settle = pieces
+        comm, group = self.comm, self.group
+        route()
+        comm.all_to_all_equal_into(self.recv, self.send, group)
+        serve()
+        comm.all_to_all_equal_into(self.back, self.vecs, group)
+        local()
+        comm.all_to_all_equal_into(self.d_recv, self.dsend, group)
+        if self.flat is not None:
+            comm.all_reduce_sum_(self.flat, group)
+        settle()
+        return self.loss
+
+    def __call__(self):
+        return self._run(self.graphs if self.graphs is not None else self.pieces)

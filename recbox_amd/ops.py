@@ -361,7 +361,7 @@ class _FmFused(torch.autograd.Function):
     part like local features; their gradients come back as ordinary autograd outputs."""
 
     @staticmethod
-    def forward(ctx, emb_plan, lr_plan, n_inputs, n_emb, n_lr, train, has_bias, has_extra, *tensors):
+    def forward(ctx, emb_plan, lr_plan, n_inputs, n_emb, n_lr, train, has_bias, has_extra, extra_index, *tensors):
         inputs = tensors[:n_inputs]
         emb_params = tensors[n_inputs:n_inputs + n_emb]
         lr_params = tensors[n_inputs + n_emb:n_inputs + n_emb + n_lr]
@@ -380,10 +380,15 @@ class _FmFused(torch.autograd.Function):
                 lr_plan.bind_inputs(keep)
             lr_plan.bind_params(lr_params)
         D = emb_plan.specs[0].dim if emb_plan is not None else 1
-        n_extra, x_stride, x_lr = 0, 0, -1
+        n_extra, x_stride, x_lr, x_rows = 0, 0, -1, 0
         if has_extra:
             extra = extra.contiguous().float()
-            n_extra, x_stride, x_lr = extra.shape[1], extra.shape[2], has_extra - 1
+            if extra_index is None:                       # [B, T, stride]: row (b, t) in place
+                n_extra, x_stride, x_lr = extra.shape[1], extra.shape[2], has_extra - 1
+            else:                                         # [rows, stride] exchange buffer + wire slots [B, T] int32
+                if extra_index.dtype != torch.int32 or not extra_index.is_contiguous() or extra.dim() != 2:
+                    raise ValueError("fm_fused: extra_index must be a contiguous int32 [B, T] over extra [rows, stride]")
+                n_extra, x_stride, x_lr, x_rows = extra_index.shape[1], extra.shape[1], has_extra - 1, extra.shape[0]
         logit = torch.empty((B, 1), dtype=torch.float32, device=dev)
         ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if (train and emb_plan is not None) else None
         status = torch.zeros(1, dtype=torch.int32, device=dev) if config.check_ids else None
@@ -391,9 +396,11 @@ class _FmFused(torch.autograd.Function):
         la = lr_plan.arr if lr_plan is not None else None
         check(_timed(("fm_fwd", lead.n, D, B),
                      lambda: lib.rbx_fm_fwd(ea, la, lead.n, B, _ptr(bias), _ptr(extra), n_extra, x_stride, x_lr,
-                                            _ptr(logit), _ptr(ssum), _ptr(status), _stream())))
+                                            _ptr(extra_index), x_rows, _ptr(logit), _ptr(ssum), _ptr(status),
+                                            _stream())))
         _check_status(status)
-        ctx.state = (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias, has_extra)
+        ctx.state = (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias, has_extra,
+                     extra_index)
         ctx.sort = None
         if train and B > 0:
             if emb_plan is not None:
@@ -409,9 +416,9 @@ class _FmFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogit):
         (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias,
-         has_extra) = ctx.state
+         has_extra, extra_index) = ctx.state
         n_emb, n_lr = len(emb_params), len(lr_params)
-        base = 8 + n_inputs
+        base = 9 + n_inputs
         want_e = [ctx.needs_input_grad[base + i] for i in range(n_emb)]
         want_l = [ctx.needs_input_grad[base + n_emb + i] for i in range(n_lr)]
         pos = base + n_emb + n_lr
@@ -424,7 +431,8 @@ class _FmFused(torch.autograd.Function):
         grads = _flat_zero_grads(list(emb_params) + list(lr_params), want_e + want_l, dev)
         ge, gl = grads[:n_emb], grads[n_emb:]
         gb = torch.zeros(1, dtype=torch.float32, device=dev) if want_b else None
-        dx = torch.empty_like(extra) if want_x else None
+        # indexed: only the referenced wire slots are written, the empty ones must read as zero
+        dx = (torch.empty_like(extra) if extra_index is None else torch.zeros_like(extra)) if want_x else None
         head = (None,) * base
 
         def result():
@@ -450,8 +458,13 @@ class _FmFused(torch.autograd.Function):
         la = lr_plan.arr if lr_plan is not None else None
         if want_x:
             D = emb_plan.specs[0].dim if emb_plan is not None else 0
-            check(lib.rbx_fm_extra_bwd(_ptr(dlogit), _ptr(ssum), _ptr(extra), B, extra.shape[1], D, extra.shape[2],
-                                       has_extra - 1, _ptr(dx), _stream()))
+            if extra_index is None:
+                check(lib.rbx_fm_extra_bwd(_ptr(dlogit), _ptr(ssum), _ptr(extra), B, extra.shape[1], D, extra.shape[2],
+                                           has_extra - 1, None, 0, _ptr(dx), _stream()))
+            else:
+                check(lib.rbx_fm_extra_bwd(_ptr(dlogit), _ptr(ssum), _ptr(extra), B, extra_index.shape[1], D,
+                                           extra.shape[1], has_extra - 1, _ptr(extra_index), extra.shape[0], _ptr(dx),
+                                           _stream()))
         same = [p.requires_grad for p in emb_params] == want_e and [p.requires_grad for p in lr_params] == want_l
         ws_early = ctx.sort.ws if (ctx.sort is not None and same) else None
         if ws_early is not None:
@@ -470,10 +483,13 @@ class _FmFused(torch.autograd.Function):
         return result()
 
 
-def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=None, extra_lr_off=-1):
+def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=None, extra_lr_off=-1,
+             extra_index=None):
     """FM model body: LR(X) + bias + product_sum(FeatureEmbedding(X)); either part may be absent.
     extra [B, T, stride]: packed rows of row-sharded tables already fetched from their owners (embedding in
-    floats [0, D), the LR weight at float ``extra_lr_off``; -1 = no LR weight in the row)."""
+    floats [0, D), the LR weight at float ``extra_lr_off``; -1 = no LR weight in the row).
+    extra_index [B, T] int32: ``extra`` is then the exchange buffer [rows, stride] itself and row (b, t) sits at
+    wire slot extra_index[b, t] (``route``); slots >= rows are lookups that found no room: zero row, no grad."""
     tail = ((bias,) if bias is not None else ())
     has_extra = 0
     if extra is not None:
@@ -484,7 +500,24 @@ def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=
     needs = list(emb_params) + list(lr_params) + list(tail)
     train = torch.is_grad_enabled() and any(p.requires_grad for p in needs)
     return _FmFused.apply(emb_plan, lr_plan, len(inputs), len(emb_params), len(lr_params), train,
-                          bias is not None, has_extra, *inputs, *emb_params, *lr_params, *tail)
+                          bias is not None, has_extra, extra_index, *inputs, *emb_params, *lr_params, *tail)
+
+
+def route(ids, world, capacity, base, overflow):
+    """Wire slots of the padded exchange (rbx_route).  ids [B, T] int64 (contiguous), base [world, T] int64,
+    overflow: uint8/bool scalar tensor (set to 1 when a lookup did not fit, never cleared).
+    Returns (send [world * capacity] int64 row numbers, -1 = empty; slot [B, T] int32)."""
+    _require_cuda(ids, "ids")
+    if ids.dtype != torch.int64 or not ids.is_contiguous() or ids.dim() != 2:
+        raise ValueError("route: ids must be a contiguous int64 [B, T] tensor")
+    dev, n = ids.device, ids.numel()
+    send = torch.empty(world * capacity, dtype=torch.int64, device=dev)
+    slot = torch.empty(ids.shape, dtype=torch.int32, device=dev)
+    ws_bytes = lib.rbx_route_workspace_size(n, world)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    check(lib.rbx_route(_ptr(ids), n, ids.shape[1], world, capacity, _ptr(base), _ptr(send), _ptr(slot),
+                        _ptr(overflow), _ptr(ws), ws_bytes, _stream()))
+    return send, slot
 
 
 def interaction_rowsum(emb):

@@ -95,20 +95,28 @@ class ShardedFM(nn.Module):
     def replicated_parameters(self):
         return list(self.embedding_layer.parameters()) + list(self.fm.parameters())
 
-    def logits(self, X):
+    def sharded_ids(self, X):
+        return torch.stack([X[n].long() for n in self.sharded_names], dim=1)           # [B, T]
+
+    def logits(self, X, packed=None, packed_index=None):
+        """``packed`` [B, T, row_width]: rows of the sharded tables already fetched from their owners (the
+        piecewise-graphed step of recbox_amd.graph does the exchange itself); None = fetch them here.
+        With ``packed_index`` [B, T] int32, ``packed`` is the exchange buffer [slots, row_width] and row (b, t)
+        sits at wire slot packed_index[b, t]."""
         emb = self.embedding_layer.embedding_layer
         lr = self.fm.lr_layer.embedding_layer.embedding_layer
         names, values, plan, posts = emb.plan_for(X)
         lnames, _, lplan, lposts = lr.plan_for(X)
         if not (emb.fusable(plan, posts) and lr.fusable(lplan, lposts) and names == lnames):
             raise NotImplementedError("ShardedFM fuses one-id-per-sample categorical and numeric features only")
-        packed, lr_off = None, -1
+        lr_off = -1
         if self.tables is not None:
-            ids = torch.stack([X[n].long() for n in self.sharded_names], dim=1)        # [B, T]
-            packed, lr_off = self.tables(ids), self.tables.lr_off                      # [B, T, D + 4] from the owners
+            if packed is None:
+                packed = self.tables(self.sharded_ids(X))                              # [B, T, D + 4] from the owners
+            lr_off = self.tables.lr_off
         return ops.fm_fused(plan.plan, lplan.plan, values, [m.weight for m in plan.modules],
                             [m.weight for m in lplan.modules], self.fm.lr_layer.bias, extra=packed,
-                            extra_lr_off=lr_off)
+                            extra_lr_off=lr_off, extra_index=packed_index)
 
     def forward(self, X):
         return {"y_pred": torch.sigmoid(self.logits(X))}

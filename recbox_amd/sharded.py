@@ -111,48 +111,55 @@ class _ExactLookup(torch.autograd.Function):
         return None, None, None, None, None, local_ops.scatter_add(weight, recv_rows, d_recv)
 
 
+def padded_route(owner, row, capacity, W, overflow):
+    """Slot assignment of the padded exchange, torch restatement of ``rbx_route`` (CPU / gloo tests and the
+    check of the HIP kernel).  owner/row: flat [n].  Returns (slot, send): ``slot[i]`` is the wire slot of
+    lookup i = owner * capacity + (number of EARLIER lookups with the same owner); ``W * capacity`` = the dump
+    slot of lookups that do not fit (sets ``overflow``); ``send`` [W * capacity] holds the row numbers, -1 = empty."""
+    n = owner.numel()
+    dev = owner.device
+    order = torch.argsort(owner, stable=True)
+    owner_s = owner[order]
+    counts = torch.zeros(W, dtype=torch.long, device=dev).scatter_add_(0, owner, torch.ones_like(owner))
+    starts = torch.cumsum(counts, 0) - counts
+    rank_in = torch.arange(n, device=dev) - starts[owner_s]
+    fits = rank_in < capacity
+    overflow.logical_or_((~fits).any())                       # reported, never silently dropped
+    dump = W * capacity                                       # one spare slot swallows what does not fit
+    slot_s = torch.where(fits, owner_s * capacity + rank_in, torch.full_like(rank_in, dump))
+    send = torch.full((dump + 1,), -1, dtype=torch.long, device=dev)
+    send[slot_s] = row[order]
+    slot = torch.empty_like(slot_s)
+    slot[order] = slot_s
+    return slot, send[:dump]
+
+
 class _PaddedLookup(torch.autograd.Function):
-    """(owner, row) lookups, fixed-capacity exchange: static shapes, no host sync, graph-capturable."""
+    """Lookups ids[B, T], fixed-capacity exchange: static shapes, no host sync, graph-capturable."""
 
     @staticmethod
-    def forward(ctx, owner, row, capacity, overflow, group, local_ops, out_shape, weight):
-        rank, W = comm.world(group)
-        owner = owner.reshape(-1)
-        row = row.reshape(-1)
-        n = owner.numel()
-        dev = owner.device
-        order = torch.argsort(owner, stable=True)
-        owner_s = owner[order]
-        counts = torch.zeros(W, dtype=torch.long, device=dev).scatter_add_(0, owner, torch.ones_like(owner))
-        starts = torch.cumsum(counts, 0) - counts
-        rank_in = torch.arange(n, device=dev) - starts[owner_s]
-        fits = rank_in < capacity
-        overflow.logical_or_((~fits).any())                       # reported, never silently dropped
-        dump = W * capacity                                       # one spare slot swallows what does not fit
-        slot = torch.where(fits, owner_s * capacity + rank_in, torch.full_like(rank_in, dump))
-        send = torch.full((dump + 1,), -1, dtype=torch.long, device=dev)
-        send[slot] = row[order]
-        recv = comm.all_to_all_equal(send[:dump], group)                                   # [W * capacity] rows, -1 = empty
+    def forward(ctx, ids, tables, capacity, weight):
+        W, group, local_ops = tables.world_size, tables.group, tables.local_ops
+        slot, send = tables.route(ids, capacity)
+        slot = slot.reshape(-1).long()
+        recv = comm.all_to_all_equal(send, group)                                          # [W * capacity] rows, -1 = empty
         vecs = local_ops.gather(weight, recv)
         back = comm.all_to_all_equal(vecs, group)                                          # same slot numbering
         width = weight.shape[1]
-        picked = torch.cat([back, back.new_zeros((1, width))], dim=0)[slot]                # dump slot reads zeros
-        out = torch.empty_like(picked)
-        out[order] = picked
-        ctx.save_for_backward(order, slot, recv, weight)
+        out = torch.cat([back, back.new_zeros((1, width))], dim=0)[slot]                   # dump slot reads zeros
+        ctx.save_for_backward(slot, recv, weight)
         ctx.meta = (capacity, group, local_ops, W)
-        return out.view(*out_shape, width)
+        return out.view(*ids.shape, width)
 
     @staticmethod
     def backward(ctx, dout):
-        order, slot, recv, weight = ctx.saved_tensors
+        slot, recv, weight = ctx.saved_tensors
         capacity, group, local_ops, W = ctx.meta
         width = weight.shape[1]
-        d_sorted = dout.reshape(-1, width)[order]
-        dsend = d_sorted.new_zeros((W * capacity + 1, width))
-        dsend[slot] = d_sorted
+        dsend = dout.new_zeros((W * capacity + 1, width))
+        dsend[slot] = dout.reshape(-1, width)                     # slots are unique except the dump slot (discarded)
         d_recv = comm.all_to_all_equal(dsend[:W * capacity].contiguous(), group)           # aligned with `recv`
-        return None, None, None, None, None, None, None, local_ops.scatter_add(weight, recv, d_recv)
+        return None, None, None, local_ops.scatter_add(weight, recv, d_recv)
 
 
 class ShardedEmbedding(nn.Module):
@@ -240,17 +247,32 @@ class ShardedTables(nn.Module):
         c = int(math.ceil(n_lookups / self.world_size * self.capacity_factor))
         return (c + 63) // 64 * 64
 
-    def forward(self, ids):
-        """ids [B, T] (one id per table per sample) -> packed rows [B, T, row_width]."""
+    def locate(self, ids):
+        """ids [B, T] -> (owner rank, row number inside the owner's packed weight), both [B, T]."""
         ids = ids.long()
         W = self.world_size
         owner = ids % W
         t_index = torch.arange(ids.shape[1], device=ids.device).unsqueeze(0).expand_as(ids)
-        row = self.base[owner, t_index] + ids // W
+        return owner, self.base[owner, t_index] + ids // W
+
+    def route(self, ids, capacity):
+        """Wire slots of the padded exchange for ids [B, T]: (slot [B, T], send [W * capacity] row numbers).
+        On the GPU this is rbx_route (three launches); elsewhere the torch restatement ``padded_route``."""
+        ids = ids.long().contiguous()
+        if ids.is_cuda:
+            from . import ops
+            send, slot = ops.route(ids, self.world_size, capacity, self.base, self.overflow)
+            return slot, send
+        owner, row = self.locate(ids)
+        slot, send = padded_route(owner.reshape(-1), row.reshape(-1), capacity, self.world_size, self.overflow)
+        return slot.view_as(ids), send
+
+    def forward(self, ids):
+        """ids [B, T] (one id per table per sample) -> packed rows [B, T, row_width]."""
         if self.capacity_factor is None:
+            owner, row = self.locate(ids)
             return _ExactLookup.apply(owner, row, self.group, self.local_ops, tuple(ids.shape), self.weight)
-        return _PaddedLookup.apply(owner, row, self.capacity_for(ids.numel()), self.overflow, self.group,
-                                   self.local_ops, tuple(ids.shape), self.weight)
+        return _PaddedLookup.apply(ids, self, self.capacity_for(ids.numel()), self.weight)
 
     def split(self, packed):
         """packed [B, T, row_width] -> (E [B, T, D], L [B, T] or None) views."""

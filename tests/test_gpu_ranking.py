@@ -296,6 +296,70 @@ def test_sharded_fm_equals_fm_on_one_gpu(factor):
         assert_close(got[1:, 16], ref_g[l_pre % name][owned.cuda()][1:, 0], 1e-4 * 8, "shard lr " + name)
 
 
+@pytest.mark.parametrize("world,cap", [(1, 4096), (3, 1024), (8, 320), (8, 64)])
+def test_route_kernel_equals_torch_restatement(world, cap):
+    """rbx_route (stable counting sort by owner, wire slots, dump slot + overflow byte) == the torch restatement
+    recbox_amd.sharded.padded_route, bit for bit, including a capacity that overflows."""
+    from recbox_amd import ops
+    from recbox_amd.sharded import padded_route
+    g = torch.Generator().manual_seed(5)
+    B, T = 1000, 3
+    vocabs = [5000, 77, 123456]
+    ids = torch.stack([torch.randint(0, v, (B,), generator=g) for v in vocabs], dim=1)
+    ids[::7, 0] = 8                                              # a hot id: one owner gets far more than its share
+    counts = torch.tensor([[(v - r + world - 1) // world for v in vocabs] for r in range(world)])
+    base = torch.zeros_like(counts)
+    base[:, 1:] = counts.cumsum(1)[:, :-1]
+    owner = ids % world
+    row = base[owner, torch.arange(T)[None, :].expand_as(ids)] + ids // world
+    of_ref = torch.zeros((), dtype=torch.bool)
+    slot_ref, send_ref = padded_route(owner.reshape(-1), row.reshape(-1), cap, world, of_ref)
+    of = torch.zeros((), dtype=torch.bool, device="cuda")
+    send, slot = ops.route(ids.cuda(), world, cap, base.cuda(), of)
+    torch.cuda.synchronize()
+    assert torch.equal(slot.cpu().reshape(-1).long(), slot_ref)
+    assert torch.equal(send.cpu(), send_ref)
+    assert bool(of.cpu()) == bool(of_ref)
+    if cap == 64:
+        assert bool(of_ref)                                      # this case is meant to overflow
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_sharded_fm_step_pieces(graphs):
+    """ShardedFMStep (route / serve / local / settle pieces with the collectives between them, eager and as
+    hipGraph replays) leaves the same loss and gradients as the autograd step of ShardedFM."""
+    from recbox_amd import ops
+    from recbox_amd.graph import ShardedFMStep
+    from recbox_amd.ranking.pytorch.models import ShardedFM
+    vocabs = [50, 7, 400, 31, 300, 9]
+    fm, X, y = _criteo_like(513, vocabs, 16, seed=23, zipf=True)
+    ref = ShardedFM(fm, 16, shard_min_vocab=300, capacity_factor=1.5).cuda()
+    dut = ShardedFM(fm, 16, shard_min_vocab=300, capacity_factor=1.5).cuda()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.normal_(0, 0.1)
+    dut.load_state_dict(ref.state_dict())
+    Xc, yc = _cuda(X), y.cuda()
+    prob = ref(Xc)["y_pred"]
+    loss_ref = torch.nn.functional.binary_cross_entropy(prob, yc, reduction="mean")
+    loss_ref.backward()
+    old = ops.config.check_ids
+    ops.config.check_ids = False
+    try:
+        step = ShardedFMStep(dut, Xc, yc, graphs=graphs)
+        for _ in range(2):                       # replays are idempotent: grads are rebuilt, not accumulated
+            loss = step()
+    finally:
+        ops.config.check_ids = old
+    torch.cuda.synchronize()
+    assert not bool(dut.tables.overflow)
+    assert_close(loss.reshape(1), loss_ref.reshape(1), 1e-6, "loss")
+    ref_g = dict((n, p.grad) for n, p in ref.named_parameters())
+    for n, p in dut.named_parameters():
+        assert p.grad is not None, n
+        assert_close(p.grad, ref_g[n], 1e-6, n)
+
+
 def test_backward_is_deterministic_and_linear():
     """Full-size property checks (B = 65 536, 26 fields): two backward passes are
     bit-identical (no float atomics) and column sums of dW equal column sums of dY."""
