@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded model even at world size 1 (exercises the RCCL exchange path)")
     ap.add_argument("--shard-min-vocab", type=int, default=100000)
-    ap.add_argument("--capacity-factor", type=float, default=1.5,
+    ap.add_argument("--capacity-factor", type=float, default=1.25,
                     help="slots per peer of the sync-free padded exchange, relative to a perfectly balanced batch "
                          "(doubled automatically if the warm-up overflows); 0 = exact all-to-all-v (host sync per "
                          "call, eager launches only)")

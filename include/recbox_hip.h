@@ -164,14 +164,15 @@ int rbx_fm_extra_bwd(const float* d_dlogit, const float* d_sum, const float* d_e
                      const int32_t* d_extra_index, int64_t extra_rows, float* d_dextra, void* stream);
 
 /* ---- C1: routing of the padded, sync-free exchange of row-sharded tables (no reference precedent:
- * SURVEY.md 2.1 / 8e; layout in recbox_amd/sharded.py).  d_ids [batch, n_tables] int64, lookup
- * i = b * n_tables + t.  owner = id mod world; d_base[world, n_tables] = first row of table t inside
+ * SURVEY.md 2.1 / 8e; layout in recbox_amd/sharded.py).  tables[t] describes the id column of sharded
+ * table t (only ids / ids_stride_b / ids_dtype are read: the same strided, typed columns rbx_fm_fwd
+ * takes); lookup i = b * n_tables + t.  owner = id mod world; d_base[world, n_tables] = first row of table t inside
  * the owner's packed weight; the row number base[owner][t] + id div world is written to wire slot
  * d_slot[i] = owner * capacity + (count of earlier lookups with that owner) of d_send[world * capacity]
  * (empty slots = -1).  Lookups that do not fit get slot world * capacity and set *d_overflow = 1
  * (never cleared here).  Stable and deterministic; no host sync. */
 size_t rbx_route_workspace_size(int64_t n_lookups, int32_t world);
-int rbx_route(const int64_t* d_ids, int64_t n_lookups, int32_t n_tables, int32_t world, int64_t capacity,
+int rbx_route(const rbx_field_t* tables, int32_t n_tables, int64_t batch, int32_t world, int64_t capacity,
               const int64_t* d_base, int64_t* d_send, int32_t* d_slot, uint8_t* d_overflow, void* d_workspace,
               size_t workspace_bytes, void* stream);
 size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch);

@@ -19,12 +19,27 @@ namespace rbx {
 constexpr int kRouteTile = 2048;      // lookups per workgroup: 8 rounds of 256
 constexpr int kRouteMaxW = 64;
 
+struct RouteField {          // ids of one table: a strided, typed column read in place
+  const void* ids;
+  long long stride_b;
+  int dtype;
+  int pad;
+};
+struct RoutePack { RouteField f[RBX_MAX_FIELDS]; };
+
+// lookup i = (sample i / T, table i % T)
+__device__ __forceinline__ long long route_id(const RoutePack& P, long long i, int T) {
+  const long long b = i / T;
+  const RouteField& fd = P.f[static_cast<int>(i - b * T)];
+  return load_id(fd.ids, b * fd.stride_b, fd.dtype);
+}
+
 __device__ __forceinline__ int owner_of(long long id, int W) {
   int o = static_cast<int>(id % W);
   return o < 0 ? o + W : o;
 }
 
-__global__ __launch_bounds__(256) void route_count_kernel(const long long* __restrict__ ids, const long long n,
+__global__ __launch_bounds__(256) void route_count_kernel(const RoutePack P, const int T, const long long n,
                                                           const int W, int* __restrict__ hist /*[W][tiles]*/,
                                                           const int tiles) {
   __shared__ int s_cnt[kRouteMaxW];
@@ -34,7 +49,7 @@ __global__ __launch_bounds__(256) void route_count_kernel(const long long* __res
 #pragma unroll
   for (int j = 0; j < kRouteTile / 256; ++j) {
     const long long i = first + j * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&s_cnt[owner_of(ids[i], W)], 1);     // integer LDS atomics: order-independent
+    if (i < n) atomicAdd(&s_cnt[owner_of(route_id(P, i, T), W)], 1);     // integer LDS atomics: order-independent
   }
   __syncthreads();
   if (threadIdx.x < W) hist[static_cast<long long>(threadIdx.x) * tiles + blockIdx.x] = s_cnt[threadIdx.x];
@@ -70,7 +85,7 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int* __restrict__ hist,
   if (threadIdx.x == 0 && s_carry > capacity && overflow != nullptr) *overflow = 1;
 }
 
-__global__ __launch_bounds__(256) void route_assign_kernel(const long long* __restrict__ ids, const long long n,
+__global__ __launch_bounds__(256) void route_assign_kernel(const RoutePack P, const long long n,
                                                            const int T, const int W, const long long capacity,
                                                            const long long* __restrict__ base /*[W][T]*/,
                                                            const int* __restrict__ hist, const int tiles,
@@ -86,7 +101,7 @@ __global__ __launch_bounds__(256) void route_assign_kernel(const long long* __re
   for (int j = 0; j < kRouteTile / 256; ++j) {
     const long long i = first + j * 256 + threadIdx.x;
     const bool valid = i < n;
-    const long long id = valid ? ids[i] : 0;
+    const long long id = valid ? route_id(P, i, T) : 0;
     const int own = valid ? owner_of(id, W) : -1;
     int in_wave = 0;
     for (int w = 0; w < W; ++w) {              // W is small (GPUs of one node)
@@ -124,34 +139,41 @@ extern "C" size_t rbx_route_workspace_size(int64_t n_lookups, int32_t world) {
   return static_cast<size_t>(rbx::route_tiles(n_lookups)) * static_cast<size_t>(world) * sizeof(int);
 }
 
-extern "C" int rbx_route(const int64_t* d_ids, int64_t n_lookups, int32_t n_tables, int32_t world, int64_t capacity,
+extern "C" int rbx_route(const rbx_field_t* tables, int32_t n_tables, int64_t batch, int32_t world, int64_t capacity,
                          const int64_t* d_base, int64_t* d_send, int32_t* d_slot, uint8_t* d_overflow,
                          void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace rbx;
-  if (n_lookups < 0 || n_tables <= 0) return fail(RBX_ERR_INVALID, "route: bad sizes");
+  if (batch < 0 || n_tables <= 0 || n_tables > RBX_MAX_FIELDS || tables == nullptr)
+    return fail(RBX_ERR_INVALID, "route: bad sizes (batch %lld, %d tables)", static_cast<long long>(batch), n_tables);
   if (world <= 0 || world > kRouteMaxW) return fail(RBX_ERR_UNSUPPORTED, "route: world=%d not in [1,%d]", world, kRouteMaxW);
   if (capacity <= 0 || capacity * world >= INT_MAX) return fail(RBX_ERR_INVALID, "route: bad capacity");
-  if (n_lookups % n_tables != 0) return fail(RBX_ERR_INVALID, "route: n_lookups must be batch * n_tables");
   hipStream_t s = as_stream(stream);
   if (d_send == nullptr || d_slot == nullptr || d_base == nullptr) return fail(RBX_ERR_INVALID, "route: NULL output/base");
+  RoutePack pack;
+  for (int t = 0; t < n_tables; ++t) {
+    if (batch > 0 && tables[t].ids == nullptr) return fail(RBX_ERR_INVALID, "route: table %d: ids is NULL", t);
+    if (tables[t].ids_dtype < RBX_I32 || tables[t].ids_dtype > RBX_F64) return fail(RBX_ERR_INVALID, "route: table %d: bad ids_dtype", t);
+    pack.f[t].ids = tables[t].ids;
+    pack.f[t].stride_b = tables[t].ids_stride_b;
+    pack.f[t].dtype = tables[t].ids_dtype;
+    pack.f[t].pad = 0;
+  }
   // empty wire slots carry row -1 (the owner's gather returns a zero row for them)
   if (hipMemsetAsync(d_send, 0xFF, static_cast<size_t>(capacity) * world * sizeof(int64_t), s) != hipSuccess)
     return fail(RBX_ERR_LAUNCH, "route: memset failed");
+  const long long n_lookups = static_cast<long long>(batch) * n_tables;
   if (n_lookups == 0) return RBX_OK;
-  if (d_ids == nullptr) return fail(RBX_ERR_INVALID, "route: d_ids is NULL");
   const long long tiles = route_tiles(n_lookups);
   if (tiles >= INT_MAX) return fail(RBX_ERR_UNSUPPORTED, "route: too many lookups");
   if (d_workspace == nullptr || workspace_bytes < rbx_route_workspace_size(n_lookups, world))
     return fail(RBX_ERR_WORKSPACE, "route: workspace too small");
   int* hist = static_cast<int*>(d_workspace);
-  const long long* ids = reinterpret_cast<const long long*>(d_ids);
-  hipLaunchKernelGGL(route_count_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, ids,
-                     static_cast<long long>(n_lookups), world, hist, static_cast<int>(tiles));
+  hipLaunchKernelGGL(route_count_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, pack, n_tables, n_lookups,
+                     world, hist, static_cast<int>(tiles));
   hipLaunchKernelGGL(route_scan_kernel, dim3(world), dim3(256), 0, s, hist, static_cast<int>(tiles),
                      static_cast<long long>(capacity), d_overflow);
-  hipLaunchKernelGGL(route_assign_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, ids,
-                     static_cast<long long>(n_lookups), n_tables, world, static_cast<long long>(capacity),
-                     reinterpret_cast<const long long*>(d_base), hist, static_cast<int>(tiles),
-                     reinterpret_cast<long long*>(d_send), d_slot);
+  hipLaunchKernelGGL(route_assign_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, pack, n_lookups, n_tables,
+                     world, static_cast<long long>(capacity), reinterpret_cast<const long long*>(d_base), hist,
+                     static_cast<int>(tiles), reinterpret_cast<long long*>(d_send), d_slot);
   return check_launch("route kernels");
 }

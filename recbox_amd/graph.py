@@ -110,7 +110,8 @@ class ShardedFMStep(object):
 
     # ---- pieces (each one a fixed kernel sequence over static buffers) ----------------------------------
     def _route(self):
-        slot, self.send = self.tables.route(self.model.sharded_ids(self.X), self.cap)      # rbx_route
+        # rbx_route reads the id columns of the batch in place (float64 / int columns, strided views)
+        slot, self.send = self.tables.route([self.X[n] for n in self.model.sharded_names], self.cap)
         self.slot = slot.contiguous()
 
     def _serve(self):

@@ -503,173 +503,26 @@ def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=
                           bias is not None, has_extra, extra_index, *inputs, *emb_params, *lr_params, *tail)
 
 
+_route_plans = {}
+
+
 def route(ids, world, capacity, base, overflow):
-    """Wire slots of the padded exchange (rbx_route).  ids [B, T] int64 (contiguous), base [world, T] int64,
-    overflow: uint8/bool scalar tensor (set to 1 when a lookup did not fit, never cleared).
+    """Wire slots of the padded exchange (rbx_route).  ids: [B, T] tensor or a list of T id columns [B] (any of
+    int32/int64/float32/float64, strided views are read in place); base [world, T] int64; overflow: uint8/bool
+    scalar tensor (set to 1 when a lookup did not fit, never cleared).
     Returns (send [world * capacity] int64 row numbers, -1 = empty; slot [B, T] int32)."""
-    _require_cuda(ids, "ids")
-    if ids.dtype != torch.int64 or not ids.is_contiguous() or ids.dim() != 2:
-        raise ValueError("route: ids must be a contiguous int64 [B, T] tensor")
-    dev, n = ids.device, ids.numel()
+    cols = [ids[:, t] for t in range(ids.shape[1])] if torch.is_tensor(ids) else list(ids)
+    T = len(cols)
+    plan = _route_plans.get(T)
+    if plan is None:
+        plan = EmbedPlan([FieldSpec("t%d" % t, FIELD_CATEGORICAL, 1, t) for t in range(T)], T)
+        _route_plans[T] = plan
+    B, keep = plan.bind_inputs(cols)
+    dev = keep[0].device
     send = torch.empty(world * capacity, dtype=torch.int64, device=dev)
-    slot = torch.empty(ids.shape, dtype=torch.int32, device=dev)
-    ws_bytes = lib.rbx_route_workspace_size(n, world)
+    slot = torch.empty((B, T), dtype=torch.int32, device=dev)
+    ws_bytes = lib.rbx_route_workspace_size(B * T, world)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-    check(lib.rbx_route(_ptr(ids), n, ids.shape[1], world, capacity, _ptr(base), _ptr(send), _ptr(slot),
+    check(lib.rbx_route(plan.arr, T, B, world, capacity, _ptr(base), _ptr(send), _ptr(slot),
                         _ptr(overflow), _ptr(ws), ws_bytes, _stream()))
     return send, slot
-
-
-def interaction_rowsum(emb):
-    """sum over the field axis of [B, F, 1] (the LR reduction when sequence features are present):
-    bi_interaction's sibling -- implemented as product_sum's linear part would be overkill, so this
-    reuses the pooling kernel: [B, L=F, D=1] summed over L."""
-    return pool(emb, None, False, DENOM_NONE, 0.0)
-
-
-# --------------------------------------------------------------------------------------------
-# dense tower (fp32 MFMA GEMM) and two-tower scoring
-# --------------------------------------------------------------------------------------------
-class _Linear(torch.autograd.Function):
-    """y = act(x W^T + b) via rbx_linear_fwd; act in {None, "relu"} is fused into the epilogue."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, act):
-        _require_cuda(x, "linear input")
-        _require_cuda(weight, "linear weight")
-        shape = x.shape
-        x2 = x.reshape(-1, shape[-1]).contiguous().float()
-        w = weight.contiguous()
-        M, K = x2.shape
-        N = w.shape[0]
-        if w.shape[1] != K:
-            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, w.shape[1], N))
-        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        check(lib.rbx_linear_fwd(_ptr(x2), _ptr(w), _ptr(bias), M, N, K, act, _ptr(y), _stream()))
-        ctx.save_for_backward(x2, w, y if act == 1 else None)
-        ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, shape
-        return y.view(*shape[:-1], N)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x2, w, y = ctx.saved_tensors
-        M, K = x2.shape
-        N = w.shape[0]
-        dy2 = dy.reshape(M, N).contiguous().float()
-        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        db = torch.empty(N, dtype=torch.float32, device=dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, ctx.act)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
-        check(lib.rbx_linear_bwd(_ptr(x2), _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx), _ptr(dw), _ptr(db),
-                                 _ptr(ws), ws_bytes, _stream()))
-        return (dx.view(ctx.shape) if dx is not None else None), dw, db, None
-
-
-def linear(x, weight, bias=None, act=None):
-    return _Linear.apply(x, weight, bias, 1 if act == "relu" else 0)
-
-
-class _L2Norm(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, eps):
-        _require_cuda(x, "normalize input")
-        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
-        rows, D = x2.shape
-        y = torch.empty_like(x2)
-        inv = torch.empty(rows, dtype=torch.float32, device=x.device)
-        check(lib.rbx_l2norm_fwd(_ptr(x2), rows, D, float(eps), _ptr(y), _ptr(inv), _stream()))
-        ctx.save_for_backward(y, inv)
-        ctx.shape = x.shape
-        return y.view(x.shape)
-
-    @staticmethod
-    def backward(ctx, dy):
-        y, inv = ctx.saved_tensors
-        rows, D = y.shape
-        dy2 = dy.reshape(rows, D).contiguous().float()
-        dx = torch.empty_like(y)
-        check(lib.rbx_l2norm_bwd(_ptr(y), _ptr(inv), _ptr(dy2), rows, D, _ptr(dx), _stream()))
-        return dx.view(ctx.shape), None
-
-
-def l2_normalize(x, eps=1e-12):
-    """F.normalize(x, p=2, dim=-1, eps)."""
-    return _L2Norm.apply(x, eps)
-
-
-class _PairDot(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, u, v, scale):
-        _require_cuda(u, "user embedding")
-        B, D = u.shape[0], u.shape[-1]
-        u2 = u.reshape(B, D).contiguous().float()
-        v3 = v.reshape(B, -1, D).contiguous().float()
-        N = v3.shape[1]
-        out = torch.empty((B, N), dtype=torch.float32, device=u.device)
-        check(lib.rbx_pairdot_fwd(_ptr(u2), _ptr(v3), B, N, D, float(scale), _ptr(out), _stream()))
-        ctx.save_for_backward(u2, v3)
-        ctx.scale, ctx.ushape, ctx.vshape = float(scale), u.shape, v.shape
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        u2, v3 = ctx.saved_tensors
-        B, N, D = v3.shape
-        dout = dout.reshape(B, N).contiguous().float()
-        du = torch.empty_like(u2) if ctx.needs_input_grad[0] else None
-        dv = torch.empty_like(v3) if ctx.needs_input_grad[1] else None
-        check(lib.rbx_pairdot_bwd(_ptr(u2), _ptr(v3), _ptr(dout), B, N, D, ctx.scale, _ptr(du), _ptr(dv), _stream()))
-        return (du.view(ctx.ushape) if du is not None else None), (dv.view(ctx.vshape) if dv is not None else None), None
-
-
-def pair_dot(u, v, scale=1.0):
-    """out[b, n] = scale * <u[b], v[b, n]>; u [B,D] or [B,1,D], v [B,D] or [B,N,D]."""
-    return _PairDot.apply(u, v, scale)
-
-
-class _Attention(torch.autograd.Function):
-    """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
-
-    @staticmethod
-    def forward(ctx, q, k, v, mask, scale, causal, fill, need_probs):
-        _require_cuda(q, "attention query")
-        lead = q.shape[:-2]
-        Lq, hd = q.shape[-2], q.shape[-1]
-        Lk = k.shape[-2]
-        q3 = q.reshape(-1, Lq, hd).contiguous().float()
-        k3 = k.reshape(-1, Lk, hd).contiguous().float()
-        v3 = v.reshape(-1, Lk, hd).contiguous().float()
-        BH = q3.shape[0]
-        m3 = None
-        if mask is not None:
-            m3 = mask.float().expand(*lead, Lq, Lk).reshape(BH, Lq, Lk).contiguous()
-        o = torch.empty_like(q3)
-        lse = torch.empty((BH, Lq), dtype=torch.float32, device=q.device)
-        p = torch.empty((BH, Lq, Lk), dtype=torch.float32, device=q.device) if need_probs else None
-        check(lib.rbx_attn_fwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), BH, Lq, Lk, hd, float(scale), int(causal),
-                               float(fill), _ptr(o), _ptr(lse), _ptr(p), _stream()))
-        ctx.save_for_backward(q3, k3, v3, m3, o, lse)
-        ctx.meta = (lead, Lq, Lk, hd, float(scale), int(causal), float(fill))
-        out = o.view(*lead, Lq, hd)
-        if need_probs:
-            probs = p.view(*lead, Lq, Lk)
-            ctx.mark_non_differentiable(probs)
-            return out, probs
-        return out, None
-
-    @staticmethod
-    def backward(ctx, do, _dp):
-        q3, k3, v3, m3, o, lse = ctx.saved_tensors
-        lead, Lq, Lk, hd, scale, causal, fill = ctx.meta
-        BH = q3.shape[0]
-        do3 = do.reshape(BH, Lq, hd).contiguous().float()
-        dq, dk, dv = torch.empty_like(q3), torch.empty_like(k3), torch.empty_like(v3)
-        scratch = torch.empty((BH, Lq), dtype=torch.float32, device=do.device)
-        check(lib.rbx_attn_bwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), _ptr(o), _ptr(do3), _ptr(lse), BH, Lq, Lk, hd,
-                               scale, causal, fill, _ptr(dq), _ptr(dk), _ptr(dv), _ptr(scratch), _stream()))
-        return (dq.view(*lead, Lq, hd), dk.view(*lead, Lk, hd), dv.view(*lead, Lk, hd), None, None, None, None, None)
-
-
-def attention(q, k, v, mask=None, scale=1.0, causal=False, fill=-1.0e9, need_probs=False):
-    return _Attention.apply(q, k, v, mask, scale, causal, fill, need_probs)

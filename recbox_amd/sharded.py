@@ -258,11 +258,15 @@ class ShardedTables(nn.Module):
     def route(self, ids, capacity):
         """Wire slots of the padded exchange for ids [B, T]: (slot [B, T], send [W * capacity] row numbers).
         On the GPU this is rbx_route (three launches); elsewhere the torch restatement ``padded_route``."""
-        ids = ids.long().contiguous()
-        if ids.is_cuda:
+        cols = ids if not torch.is_tensor(ids) else None       # list of T id columns [B], read in place on the GPU
+        first = cols[0] if cols is not None else ids
+        if first.is_cuda:
             from . import ops
             send, slot = ops.route(ids, self.world_size, capacity, self.base, self.overflow)
             return slot, send
+        if cols is not None:
+            ids = torch.stack([c.long() for c in cols], dim=1)
+        ids = ids.long()
         owner, row = self.locate(ids)
         slot, send = padded_route(owner.reshape(-1), row.reshape(-1), capacity, self.world_size, self.overflow)
         return slot.view_as(ids), send
