@@ -194,6 +194,26 @@ int rbx_pairdot_fwd(const float* d_u, const float* d_v, int64_t batch, int32_t n
 int rbx_pairdot_bwd(const float* d_u, const float* d_v, const float* d_dout, int64_t batch, int32_t n_cand,
                     int32_t dim, float scale, float* d_du, float* d_dv, void* stream);
 
+/* ---- K7: candidate scoring without materialising the candidate embeddings
+ * (third_party/rechub/models/matching/sasrec.py:98-105: pos/neg logits = (seq_output * item_emb(ids)).sum(-1);
+ * the [rows, 1 + n] sampled-softmax logits consumed by core/pytorch/losses/softmax_crossentropy_loss.py:14-22).
+ *   d_out[r, c] = scale * < d_x[r, :], table_c[ids_c[r], :] >
+ * cands[i] is one candidate set: ids ([rows] or [rows, seq_len] through ids_stride_b / ids_stride_l, any id
+ * dtype), table/vocab/dim (all sets share dim), seq_len = candidates per row, out_off = first output column;
+ * the sets together must cover columns [0, n_out) exactly once (n_out <= 256).  Out-of-range ids score 0 and
+ * raise d_status.  Backward: dense dW into cands[i].grad through the sorted segmented scatter-add
+ * (contribution scale * g[r,c] * x[r,:]; rows equal to padding_idx receive no gradient; grad == NULL =
+ * frozen), and d_dx[r, :] = scale * sum_c g[r,c] * row (skipped when d_dx is NULL).  rbx_gatherdot_sort
+ * depends on the ids only and may run on another stream during the forward. */
+int rbx_gatherdot_fwd(const rbx_field_t* cands, int32_t n_cands, int64_t rows, const float* d_x, int64_t x_stride,
+                      float scale, float* d_out, int32_t* d_status, void* stream);
+size_t rbx_gatherdot_bwd_workspace_size(const rbx_field_t* cands, int32_t n_cands, int64_t rows);
+int rbx_gatherdot_sort(const rbx_field_t* cands, int32_t n_cands, int64_t rows, void* d_workspace,
+                       size_t workspace_bytes, int32_t* d_status, void* stream);
+int rbx_gatherdot_bwd(const rbx_field_t* cands, int32_t n_cands, int64_t rows, const float* d_x, int64_t x_stride,
+                      const float* d_dout, float scale, float* d_dx, int64_t dx_stride, int32_t accumulate,
+                      void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* ---- dense tower: y = act(x W^T + b) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------
  * core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58,
  * third_party/rechub/basic/layers.py:255-263.  x[m,k], W[n,k] (nn.Linear layout), bias[n] or NULL,

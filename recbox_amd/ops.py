@@ -526,3 +526,258 @@ def route(ids, world, capacity, base, overflow):
     check(lib.rbx_route(plan.arr, T, B, world, capacity, _ptr(base), _ptr(send), _ptr(slot),
                         _ptr(overflow), _ptr(ws), ws_bytes, _stream()))
     return send, slot
+
+
+def interaction_rowsum(emb):
+    """sum over the field axis of [B, F, 1] (the LR reduction when sequence features are present):
+    bi_interaction's sibling -- implemented as product_sum's linear part would be overkill, so this
+    reuses the pooling kernel: [B, L=F, D=1] summed over L."""
+    return pool(emb, None, False, DENOM_NONE, 0.0)
+
+
+# --------------------------------------------------------------------------------------------
+# dense tower (fp32 MFMA GEMM) and two-tower scoring
+# --------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) via rbx_linear_fwd; act in {None, "relu"} is fused into the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        _require_cuda(x, "linear input")
+        _require_cuda(weight, "linear weight")
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        w = weight.contiguous()
+        M, K = x2.shape
+        N = w.shape[0]
+        if w.shape[1] != K:
+            raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, w.shape[1], N))
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        check(lib.rbx_linear_fwd(_ptr(x2), _ptr(w), _ptr(bias), M, N, K, act, _ptr(y), _stream()))
+        ctx.save_for_backward(x2, w, y if act == 1 else None)
+        ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, shape
+        return y.view(*shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = dy.reshape(M, N).contiguous().float()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(N, dtype=torch.float32, device=dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, ctx.act)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+        check(lib.rbx_linear_bwd(_ptr(x2), _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx), _ptr(dw), _ptr(db),
+                                 _ptr(ws), ws_bytes, _stream()))
+        return (dx.view(ctx.shape) if dx is not None else None), dw, db, None
+
+
+def linear(x, weight, bias=None, act=None):
+    return _Linear.apply(x, weight, bias, 1 if act == "relu" else 0)
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        _require_cuda(x, "normalize input")
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        rows, D = x2.shape
+        y = torch.empty_like(x2)
+        inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib.rbx_l2norm_fwd(_ptr(x2), rows, D, float(eps), _ptr(y), _ptr(inv), _stream()))
+        ctx.save_for_backward(y, inv)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        rows, D = y.shape
+        dy2 = dy.reshape(rows, D).contiguous().float()
+        dx = torch.empty_like(y)
+        check(lib.rbx_l2norm_bwd(_ptr(y), _ptr(inv), _ptr(dy2), rows, D, _ptr(dx), _stream()))
+        return dx.view(ctx.shape), None
+
+
+def l2_normalize(x, eps=1e-12):
+    """F.normalize(x, p=2, dim=-1, eps)."""
+    return _L2Norm.apply(x, eps)
+
+
+class _PairDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, v, scale):
+        _require_cuda(u, "user embedding")
+        B, D = u.shape[0], u.shape[-1]
+        u2 = u.reshape(B, D).contiguous().float()
+        v3 = v.reshape(B, -1, D).contiguous().float()
+        N = v3.shape[1]
+        out = torch.empty((B, N), dtype=torch.float32, device=u.device)
+        check(lib.rbx_pairdot_fwd(_ptr(u2), _ptr(v3), B, N, D, float(scale), _ptr(out), _stream()))
+        ctx.save_for_backward(u2, v3)
+        ctx.scale, ctx.ushape, ctx.vshape = float(scale), u.shape, v.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u2, v3 = ctx.saved_tensors
+        B, N, D = v3.shape
+        dout = dout.reshape(B, N).contiguous().float()
+        du = torch.empty_like(u2) if ctx.needs_input_grad[0] else None
+        dv = torch.empty_like(v3) if ctx.needs_input_grad[1] else None
+        check(lib.rbx_pairdot_bwd(_ptr(u2), _ptr(v3), _ptr(dout), B, N, D, ctx.scale, _ptr(du), _ptr(dv), _stream()))
+        return (du.view(ctx.ushape) if du is not None else None), (dv.view(ctx.vshape) if dv is not None else None), None
+
+
+def pair_dot(u, v, scale=1.0):
+    """out[b, n] = scale * <u[b], v[b, n]>; u [B,D] or [B,1,D], v [B,D] or [B,N,D]."""
+    return _PairDot.apply(u, v, scale)
+
+
+_dot_plans = {}
+
+
+class _GatherDot(torch.autograd.Function):
+    """out[R, n_out] = scale * <x[r], W_c[ids_c[r]]> (rbx_gatherdot_*): the candidate vectors never reach HBM."""
+
+    @staticmethod
+    def forward(ctx, plan, n_sets, train, scale, x, *tensors):
+        inputs, params = tensors[:n_sets], tensors[n_sets:]
+        _require_cuda(x, "x")
+        for p in params:
+            _require_cuda(p, "embedding parameter")
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("recbox_amd: embedding parameters must be contiguous fp32")
+        if x.dtype != torch.float32 or x.stride(1) != 1:
+            x = x.contiguous().float()
+        R, keep = plan.bind_inputs(inputs)
+        if R != x.shape[0]:
+            raise ValueError("gather_dot: ids have %d rows, x has %d" % (R, x.shape[0]))
+        plan.bind_params(params)
+        out = torch.empty((R, plan.width), dtype=torch.float32, device=x.device)
+        status = torch.zeros(1, dtype=torch.int32, device=x.device) if config.check_ids else None
+        check(_timed(("gatherdot_fwd", plan.n, plan.width, R),
+                     lambda: lib.rbx_gatherdot_fwd(plan.arr, plan.n, R, _ptr(x), x.stride(0), scale, _ptr(out),
+                                                   _ptr(status), _stream())))
+        _check_status(status)
+        ctx.plan, ctx.inputs, ctx.params, ctx.R, ctx.scale, ctx.x = plan, keep, params, R, scale, x
+        ctx.sort = None
+        if R > 0 and train and any(p.requires_grad for p in params):
+            plan.bind_params(params, [p if p.requires_grad else None for p in params])
+            ws_bytes = lib.rbx_gatherdot_bwd_workspace_size(plan.arr, plan.n, R)
+            if ws_bytes > 0:
+                ctx.sort = _EarlySort(x.device, ws_bytes, lambda ws, st: lib.rbx_gatherdot_sort(
+                    plan.arr, plan.n, R, _ptr(ws), ws_bytes, None, st))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan, params, R, x = ctx.plan, ctx.params, ctx.R, ctx.x
+        dout = dout.contiguous().float()
+        n_sets = len(ctx.inputs)
+        want_x = ctx.needs_input_grad[4]
+        want = [ctx.needs_input_grad[5 + n_sets + i] for i in range(len(params))]
+        grads = _flat_zero_grads(params, want, dout.device)
+        dx = torch.empty_like(x) if want_x else None
+        head = (None, None, None, None, dx) + (None,) * n_sets
+        if R == 0:
+            return head + tuple(grads)
+        plan.bind_inputs(ctx.inputs)
+        plan.bind_params(params, grads)
+        ws, ws_bytes = None, 0
+        if any(want):
+            if ctx.sort is not None and [p.requires_grad for p in params] == list(want):
+                ctx.sort.join()
+                ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes
+            else:
+                ws_bytes = lib.rbx_gatherdot_bwd_workspace_size(plan.arr, plan.n, R)
+                ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dout.device)
+                check(lib.rbx_gatherdot_sort(plan.arr, plan.n, R, _ptr(ws), ws_bytes, None, _stream()))
+        check(lib.rbx_gatherdot_bwd(plan.arr, plan.n, R, _ptr(x), x.stride(0), _ptr(dout), ctx.scale, _ptr(dx),
+                                    x.stride(0) if dx is None else dx.stride(0), 0, _ptr(ws), ws_bytes, _stream()))
+        return head + tuple(grads)
+
+
+def gather_dot(x, id_sets, weights, scale=1.0, padding_idx=None):
+    """Candidate scoring: ``out[r, c] = scale * <x[r, :], W_c[ids_c[r], :]>`` == ``(x.unsqueeze(1) *
+    embedding(ids)).sum(-1)`` without the [R, n_out, D] candidate tensor (SASRec pos/neg logits, sampled softmax).
+
+    x [R, D]; id_sets: list of id tensors, each [R] or [R, n_i] (columns are laid out set after set);
+    weights: one table shared by every set, or one table per set; padding_idx: rows that receive no gradient."""
+    if torch.is_tensor(weights):
+        weights = [weights] * len(id_sets)
+    if len(weights) != len(id_sets):
+        raise ValueError("gather_dot: one table per id set (or a single shared table) expected")
+    params, index = [], []
+    for w in weights:
+        for i, p in enumerate(params):
+            if p is w:
+                index.append(i)
+                break
+        else:
+            index.append(len(params))
+            params.append(w)
+    widths = [1 if t.dim() == 1 else t.shape[1] for t in id_sets]
+    D = params[0].shape[1]
+    key = (tuple(widths), tuple(index), tuple(p.shape[0] for p in params), D, padding_idx)
+    plan = _dot_plans.get(key)
+    if plan is None:
+        specs, col = [], 0
+        for s, (n, pi) in enumerate(zip(widths, index)):
+            specs.append(FieldSpec("set%d" % s, FIELD_CATEGORICAL, D, col, param=pi,
+                                   pool=POOL_CONCAT if id_sets[s].dim() == 2 else POOL_NONE, seq_len=n,
+                                   vocab=params[pi].shape[0], padding_idx=padding_idx))
+            col += n
+        plan = EmbedPlan(specs, col)
+        _dot_plans[key] = plan
+    train = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    return _GatherDot.apply(plan, len(id_sets), train, float(scale), x, *id_sets, *params)
+
+
+class _Attention(torch.autograd.Function):
+    """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale, causal, fill, need_probs):
+        _require_cuda(q, "attention query")
+        lead = q.shape[:-2]
+        Lq, hd = q.shape[-2], q.shape[-1]
+        Lk = k.shape[-2]
+        q3 = q.reshape(-1, Lq, hd).contiguous().float()
+        k3 = k.reshape(-1, Lk, hd).contiguous().float()
+        v3 = v.reshape(-1, Lk, hd).contiguous().float()
+        BH = q3.shape[0]
+        m3 = None
+        if mask is not None:
+            m3 = mask.float().expand(*lead, Lq, Lk).reshape(BH, Lq, Lk).contiguous()
+        o = torch.empty_like(q3)
+        lse = torch.empty((BH, Lq), dtype=torch.float32, device=q.device)
+        p = torch.empty((BH, Lq, Lk), dtype=torch.float32, device=q.device) if need_probs else None
+        check(lib.rbx_attn_fwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), BH, Lq, Lk, hd, float(scale), int(causal),
+                               float(fill), _ptr(o), _ptr(lse), _ptr(p), _stream()))
+        ctx.save_for_backward(q3, k3, v3, m3, o, lse)
+        ctx.meta = (lead, Lq, Lk, hd, float(scale), int(causal), float(fill))
+        out = o.view(*lead, Lq, hd)
+        if need_probs:
+            probs = p.view(*lead, Lq, Lk)
+            ctx.mark_non_differentiable(probs)
+            return out, probs
+        return out, None
+
+    @staticmethod
+    def backward(ctx, do, _dp):
+        q3, k3, v3, m3, o, lse = ctx.saved_tensors
+        lead, Lq, Lk, hd, scale, causal, fill = ctx.meta
+        BH = q3.shape[0]
+        do3 = do.reshape(BH, Lq, hd).contiguous().float()
+        dq, dk, dv = torch.empty_like(q3), torch.empty_like(k3), torch.empty_like(v3)
+        scratch = torch.empty((BH, Lq), dtype=torch.float32, device=do.device)
+        check(lib.rbx_attn_bwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), _ptr(o), _ptr(do3), _ptr(lse), BH, Lq, Lk, hd,
+                               scale, causal, fill, _ptr(dq), _ptr(dk), _ptr(dv), _ptr(scratch), _stream()))
+        return (dq.view(*lead, Lq, hd), dk.view(*lead, Lk, hd), dv.view(*lead, Lk, hd), None, None, None, None, None)
+
+
+def attention(q, k, v, mask=None, scale=1.0, causal=False, fill=-1.0e9, need_probs=False):
+    return _Attention.apply(q, k, v, mask, scale, causal, fill, need_probs)

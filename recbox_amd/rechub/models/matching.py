@@ -168,14 +168,16 @@ class SASRec(torch.nn.Module):
         return self.last_layernorm(e)
 
     def forward(self, x):
-        embedding = self.item_emb(x, self.features)          # [B, 3, L, D] from one gather launch
-        seq_embed, pos_embed, neg_embed = embedding[:, 0], embedding[:, 1], embedding[:, 2]
-        seq_output = self.seq_forward(x, seq_embed)
+        """sasrec.py:96-107.  The reference embeds seq, pos and neg ([B, 3, L, D]) and multiplies; here only the
+        input sequence is materialised: the pos / neg logits come from rbx_gatherdot (K7), which reads each
+        candidate row once and never writes the two [B, L, D] candidate tensors (nor their gradients)."""
+        seq_f, cand_f = self.features[0], self.features[1:]
+        seq_embed = self.item_emb(x, [seq_f])                 # [B, 1, L, D]
+        seq_output = self.seq_forward(x, seq_embed[:, 0])
         B, L, D = seq_output.shape
-        flat = seq_output.reshape(B * L, D)
-        pos_logits = ops.pair_dot(flat, pos_embed.reshape(B * L, 1, D)).view(B, L)
-        neg_logits = ops.pair_dot(flat, neg_embed.reshape(B * L, 1, D)).view(B, L)
-        return pos_logits, neg_logits
+        tables = [self.item_emb.embed_dict[f.name if f.shared_with is None else f.shared_with].weight for f in cand_f]
+        logits = ops.gather_dot(seq_output.reshape(B * L, D), [x[f.name].reshape(-1) for f in cand_f], tables)
+        return tuple(logits[:, c].reshape(B, L) for c in range(len(cand_f)))
 
 
 def ops_position(position_emb, positions):

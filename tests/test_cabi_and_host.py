@@ -32,6 +32,24 @@ def test_header_symbols_are_exported_and_bound():
     assert ctypes.sizeof(_lib.rbx_field_t) == 96     # matches the C layout (8-byte aligned)
 
 
+def test_every_c_symbol_has_a_python_caller():
+    """The host layer (recbox_amd/*.py) calls every compute entry point of the C ABI, and the op surface the
+    mirrors are built on is complete (guards against a half-written ops.py reaching the GPU box)."""
+    from recbox_amd import _lib, ops
+    src = ""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "recbox_amd")):
+        for f in files:
+            if f.endswith(".py") and f != "_lib.py":
+                src += open(os.path.join(dirpath, f)).read()
+    for n in _lib.SIGNATURES:
+        if n in ("rbx_last_error", "rbx_version"):
+            continue
+        assert ("lib.%s(" % n) in src, "no Python caller of %s" % n
+    for name in ("embed_lookup", "interaction", "pool", "fm_fused", "route", "linear", "l2_normalize", "pair_dot",
+                 "gather_dot", "attention", "interaction_rowsum", "KernelTimer", "EmbedPlan", "FieldSpec"):
+        assert hasattr(ops, name), "recbox_amd.ops.%s is missing" % name
+
+
 def test_product_path_refuses_cpu_tensors():
     """No silent CPU/PyTorch fallback: a CPU call raises."""
     import recbox_amd.ranking.pytorch.layers as L

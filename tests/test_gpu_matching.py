@@ -139,6 +139,38 @@ def test_sdpa_and_losses_golden():
         assert_close(gr, fx["g"][n], TOL, n)
 
 
+@pytest.mark.parametrize("D,n_sets,width", [(64, 2, 1), (16, 1, 5), (128, 2, 3), (20, 2, 1), (6, 1, 2)])
+def test_gather_dot_vs_torch(D, n_sets, width):
+    """K7 rbx_gatherdot fwd/bwd == (x.unsqueeze(1) * embedding(ids)).sum(-1) in fp32 torch (the reference's
+    sasrec.py:98-105 op sequence): logits, dx and the dense table gradient, shared and separate tables,
+    duplicate ids (small vocab), a padding row that must get no gradient."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(D * 10 + n_sets)
+    R, V = 777, 50
+    x = torch.randn(R, D, generator=g)
+    tabs = [torch.randn(V, D, generator=g) * 0.5 for _ in range(n_sets if D != 64 else 1)]
+    sets = [torch.randint(0, V, (R,) if width == 1 else (R, width), generator=g) for _ in range(n_sets)]
+    gout = torch.randn(R, n_sets * width, generator=g)
+    pad = 0 if D == 16 else None
+    # fp32 torch reference on the CPU
+    xr = x.clone().requires_grad_(True)
+    tr = [t.clone().requires_grad_(True) for t in tabs]
+    cols = []
+    for s, ids in enumerate(sets):
+        e = torch.nn.functional.embedding(ids.reshape(R, -1), tr[s % len(tr)], padding_idx=pad)      # [R, w, D]
+        cols.append((xr.unsqueeze(1) * e).sum(-1) * 0.25)
+    ref = torch.cat(cols, dim=1)
+    (ref * gout).sum().backward()
+    xc = x.cuda().requires_grad_(True)
+    tc = [t.cuda().requires_grad_(True) for t in tabs]
+    out = ops.gather_dot(xc, [i.cuda() for i in sets], tc[0] if len(tc) == 1 else tc, scale=0.25, padding_idx=pad)
+    assert_close(out, ref.detach(), 1e-5, "logits")
+    (out * gout.cuda()).sum().backward()
+    assert_close(xc.grad, xr.grad, 1e-4, "dx")
+    for a, b in zip(tc, tr):
+        assert_close(a.grad, b.grad, 1e-4, "dW")
+
+
 def _dssm_feats(Fe, D=16):
     Sp, Sq = Fe.SparseFeature, Fe.SequenceFeature
     uf = [Sp("user_id", 61, D), Sp("gender", 3, D),
