@@ -79,7 +79,24 @@ def gather_pool(V, D, B, L):
     print("  its backward (sort + segmented scatter-add + %d MB dense-grad zero fill)  %8.1f us" % (V * D * 4 >> 20, tb * 1e6))
 
 
+def gather_dot(V, D, R, n_sets):
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(V, D, generator=g) * 0.1).cuda().requires_grad_(True)
+    x = torch.randn(R, D, generator=g).cuda().requires_grad_(True)
+    sets = [torch.randint(0, V, (R,), generator=g).cuda() for _ in range(n_sets)]
+    t = timeit(lambda: ops.gather_dot(x, sets, w))
+    out = ops.gather_dot(x, sets, w)
+    gr = torch.randn_like(out)
+    tb = timeit(lambda: torch.autograd.grad(out, (x, w), gr, retain_graph=True), iters=4)
+    byt = R * n_sets * (D * 4 + 8 + 4) + R * D * 4
+    print("gather-dot fwd V=%d D=%d rows=%d sets=%d  %8.1f us  %7.1f GB/s of rows+ids+logits+x" % (V, D, R, n_sets, t * 1e6, byt / t / 1e9))
+    print("  its backward (dx gather + sort + segmented scatter-add + %d MB dense-grad zero fill)  %8.1f us" % (V * D * 4 >> 20, tb * 1e6))
+
+
 if __name__ == "__main__":
+    if "dot" in sys.argv[1:]:
+        gather_dot(1_000_000, 64, 4096 * 200, 2)
+        sys.exit(0)
     if "gather" in sys.argv[1:]:
         gather_pool(10_000_000, 128, 65536, 50)
         gather_pool(10_000_000, 64, 65536, 50)
@@ -93,6 +110,7 @@ if __name__ == "__main__":
     print("# cfg 5 SASRec attention core")
     attention(4096, 1, 200, 64)
     gemm(4096 * 200, 64, 64, None)
+    gather_dot(1_000_000, 64, 4096 * 200, 2)
     print("# cfg 3 YoutubeDNN history pooling, one GPU holding the whole 10M x 128 table (5.1 GB)")
     gather_pool(10_000_000, 128, 65536, 50)
     print("# cfg 2 layer path pieces")

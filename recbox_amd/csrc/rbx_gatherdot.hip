@@ -80,11 +80,11 @@ struct DotCols {             // output column -> (candidate set, position inside
   unsigned char pos[kDotMaxOut];
 };
 
-// lookups q = r * n_out + c, c fastest: the groups of a wavefront share x rows and write adjacent logits
+// one lane group per row r: the x row is read once, the candidate rows of the row 4 at a time
 template <int G, int NV, bool VEC>
 __global__ __launch_bounds__(256) void gatherdot_fwd_kernel(const FieldPack P, const int F, const DotCols C, const long long R,
                                                             const int n_out, const float* __restrict__ x,
-                                                            const long long xs, const float scale,
+                                                            const long long xs, const float scale, const int D,
                                                             float* __restrict__ out, int* __restrict__ status) {
   __shared__ FieldK sf[RBX_MAX_FIELDS];
   {
@@ -95,57 +95,41 @@ __global__ __launch_bounds__(256) void gatherdot_fwd_kernel(const FieldPack P, c
   }
   __syncthreads();
   using Frag = DotFrag<G, NV, VEC>;
-  constexpr int U = (NV * (VEC ? 4 : 1) <= 4) ? 4 : 2;        // lookups in flight per lane group
+  constexpr int U = (NV * (VEC ? 4 : 1) <= 4) ? 4 : 2;        // candidate rows in flight per lane group
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
-  const long long total = R * n_out;
-  const bool small = total < (1ll << 32);
-  for (long long q0 = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; q0 < total;
-       q0 += ngroups * U) {
-    long long rr[U], id[U];
-    int dim[U];
-    const float* tab[U];
-    bool live[U];
+  for (long long r = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; r < R; r += ngroups) {
+    Frag v;
+    v.load(x + r * xs, D, lane_g);
+    for (int c0 = 0; c0 < n_out; c0 += U) {
+      long long id[U];
+      const float* tab[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const long long q = q0 + u * ngroups;
-      live[u] = q < total;
-      const long long qc = live[u] ? q : 0;
-      int c;
-      if (small) {
-        const unsigned d = static_cast<unsigned>(qc) / static_cast<unsigned>(n_out);
-        rr[u] = d;
-        c = static_cast<int>(static_cast<unsigned>(qc) - d * static_cast<unsigned>(n_out));
-      } else {
-        rr[u] = qc / n_out;
-        c = static_cast<int>(qc - rr[u] * n_out);
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + u;
+        id[u] = -1;
+        tab[u] = nullptr;
+        if (c < n_out) {
+          const FieldK& fd = sf[C.set[c]];
+          id[u] = load_id(fd.ids, r * fd.ids_stride_b + static_cast<long long>(C.pos[c]) * fd.ids_stride_l, fd.ids_dtype);
+          if (id[u] < 0 || id[u] >= fd.vocab) {
+            if (status != nullptr) atomicOr(status, 1);
+            id[u] = -1;                                          // out-of-range lookups score 0
+          }
+          tab[u] = fd.table;
+        }
       }
-      const FieldK& fd = sf[C.set[c]];
-      id[u] = live[u] ? load_id(fd.ids, rr[u] * fd.ids_stride_b + static_cast<long long>(C.pos[c]) * fd.ids_stride_l,
-                                fd.ids_dtype)
-                      : 0;
-      if (live[u] && (id[u] < 0 || id[u] >= fd.vocab)) {
-        if (status != nullptr) atomicOr(status, 1);
-        live[u] = false;                                         // out-of-range lookups score 0
-      }
-      dim[u] = fd.dim;
-      tab[u] = fd.table;
-    }
-    Frag w[U], v[U];
+      Frag w[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      w[u].zero();
-      v[u].zero();
-      if (live[u]) {
-        w[u].load(tab[u] + id[u] * dim[u], dim[u], lane_g);
-        v[u].load(x + rr[u] * xs, dim[u], lane_g);
+      for (int u = 0; u < U; ++u) {
+        w[u].zero();
+        if (id[u] >= 0) w[u].load(tab[u] + id[u] * D, D, lane_g);
       }
-    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float s = group_sum<G>(w[u].dot(v[u]));
-      const long long q = q0 + u * ngroups;
-      if (lane_g == 0 && q < total) out[q] = s * scale;
+      for (int u = 0; u < U; ++u) {
+        const float s = group_sum<G>(w[u].dot(v));
+        if (lane_g == 0 && c0 + u < n_out) out[r * n_out + c0 + u] = s * scale;
+      }
     }
   }
 }
@@ -283,12 +267,11 @@ static int dot_validate(const rbx_field_t* cands, int n, int64_t R, DotHost* h) 
 template <int G, int NV, bool VEC>
 static int launch_dot_fwd(const DotHost& h, int n, int64_t R, const float* x, int64_t xs, float scale, float* out,
                           int* status, hipStream_t s) {
-  const long long total = static_cast<long long>(R) * h.n_out;
   const int gpb = 256 / G;
-  long long blocks = (total + gpb - 1) / gpb;
-  if (blocks > kCUs * 8) blocks = kCUs * 8;
+  long long blocks = (R + gpb - 1) / gpb;
+  if (blocks > kCUs * 16) blocks = kCUs * 16;
   hipLaunchKernelGGL((gatherdot_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, h.pack, n,
-                     h.cols, static_cast<long long>(R), h.n_out, x, static_cast<long long>(xs), scale, out, status);
+                     h.cols, static_cast<long long>(R), h.n_out, x, static_cast<long long>(xs), scale, h.D, out, status);
   return check_launch("gatherdot_fwd_kernel");
 }
 
