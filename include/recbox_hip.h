@@ -214,6 +214,30 @@ int rbx_gatherdot_bwd(const rbx_field_t* cands, int32_t n_cands, int64_t rows, c
                       const float* d_dout, float scale, float* d_dx, int64_t dx_stride, int32_t accumulate,
                       void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the two-tower loader's per-epoch negative sampling and per-batch item-corpus gather
+ * (matching/pytorch/dataloaders/h5_generator.py:61-84 sampling_block, :144-181 negative_sampling,
+ * :23-28 TrainDataset.__getitem__, :49-58 collate_fn).
+ * rbx_negsample: d_out[rows, (d_pos ? 1 : 0) + num_negs]; column 0 = d_pos[r] when given (hstack([pos, negs]));
+ * every other entry is uniform over [0, num_items) with replacement (np.random.choice(..., replace=True)).
+ * With d_excl_offsets/d_excl_items (CSR over queries, items sorted ascending inside a query) and d_query[rows]
+ * (query of each row), items the query interacted with are never drawn (ignore_pos_items=True: uniform over
+ * the complement; up to 64 redraws).  Generator: Philox4x32-10, key = seed, counter = (offset + r * num_negs + j,
+ * attempt); item = high 64 bits of (low 64 random bits) x num_items.  Same (seed, offset) -> same draws. */
+int rbx_negsample(int64_t num_items, int64_t rows, int32_t num_negs, uint64_t seed, uint64_t offset,
+                  const int64_t* d_pos, const int64_t* d_query, const int64_t* d_excl_offsets,
+                  const int64_t* d_excl_items, int64_t* d_out, void* stream);
+/* rbx_gather_rows: for every column c and index q: dst_c[q, :] = src_c[d_index[q], :] (row_bytes bytes, any
+ * element type: ids, sequences [n_items, L], float features) -- the byte-exact equivalent of
+ * dict((k, v[item_indexes]) for k, v in item_corpus.items()) followed by flatten(end_dim=1).  An index outside
+ * [0, n_src_rows) raises d_status (numpy raises IndexError) and reads row 0. */
+typedef struct rbx_rowcopy {
+  const void* src;     /* [n_src_rows, row_bytes] */
+  void* dst;           /* [n_index, row_bytes] */
+  int64_t row_bytes;
+} rbx_rowcopy_t;
+int rbx_gather_rows(const rbx_rowcopy_t* cols, int32_t n_cols, const int64_t* d_index, int64_t n_index,
+                    int64_t n_src_rows, int32_t* d_status, void* stream);
+
 /* ---- dense tower: y = act(x W^T + b) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------
  * core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58,
  * third_party/rechub/basic/layers.py:255-263.  x[m,k], W[n,k] (nn.Linear layout), bias[n] or NULL,

@@ -38,6 +38,13 @@ def load():
     lib.orc_interaction_fwd.argtypes = [P, i64, i32, i32, i32, P]
     lib.orc_l2norm_fwd.argtypes = [P, i64, i32, f32, P]
     lib.orc_pairdot_fwd.argtypes = [P, P, i64, i32, i32, f32, P]
+    u64 = ctypes.c_uint64
+    lib.orc_philox4x32_10.argtypes = [P, P, P]
+    lib.orc_negsample.argtypes = [i64, i64, i32, u64, u64, P, P, P, P, P]
+    lib.orc_gather_rows.argtypes = [P, P, i64, P, i64, i64]
+    lib.orc_gather_rows.restype = ctypes.c_int
+    lib.orc_philox4x32_10.restype = None
+    lib.orc_negsample.restype = None
     for fn in (lib.orc_embed_bwd, lib.orc_fm_fwd, lib.orc_fm_bwd, lib.orc_interaction_fwd, lib.orc_l2norm_fwd,
                lib.orc_pairdot_fwd):
         fn.restype = None
@@ -72,3 +79,30 @@ def array_of(fields):
     for i, f in enumerate(fields):
         arr[i] = f
     return arr
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 block: ctr 4 x uint32, key 2 x uint32 -> 4 x uint32."""
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    load().orc_philox4x32_10(ptr(c), ptr(k), ptr(out))
+    return out
+
+
+def negsample(num_items, rows, num_negs, seed, offset=0, pos=None, query=None, excl_offsets=None, excl_items=None):
+    width = num_negs + (1 if pos is not None else 0)
+    out = np.zeros((rows, width), dtype=np.int64)
+    arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.int64) for a in (pos, query, excl_offsets, excl_items)]
+    load().orc_negsample(num_items, rows, num_negs, seed, offset, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]),
+                         ptr(out))
+    return out
+
+
+def gather_rows(column, index):
+    column = np.ascontiguousarray(column)
+    index = np.ascontiguousarray(index, dtype=np.int64).reshape(-1)
+    out = np.zeros((index.size,) + column.shape[1:], dtype=column.dtype)
+    row_bytes = column.dtype.itemsize * int(np.prod(column.shape[1:], dtype=np.int64))
+    bad = load().orc_gather_rows(ptr(column), ptr(out), row_bytes, ptr(index), index.size, column.shape[0])
+    return out, bool(bad)

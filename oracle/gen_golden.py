@@ -439,6 +439,38 @@ def gen_target_attention_and_listwise_losses(recbox, fuxictr, B=5, L=7, E=16):
                                                  **{"p." + n: p.grad for n, p in att.named_parameters()})})
 
 
+def gen_matching_loader(recbox, N=23, I=17, B=8, num_negs=3):
+    """TrainDataset.__getitem__ + collate_fn / collate_fn_unique of the live reference on a fixed
+    all_item_indexes block (the sampling itself is numpy's MT19937 stream and is not a fixture)."""
+    from torch.utils.data.dataloader import default_collate  # noqa: F401  (what the reference's collate uses)
+    import importlib
+    ref = importlib.import_module("recbox.matching.pytorch.dataloaders.h5_generator")   # (the package re-exports a
+    # function of the same name, so `import ... as` would bind that instead of the module)
+    rng = np.random.RandomState(3)
+    data = OrderedDict([("user_id", rng.randint(1, 40, size=N).astype(np.int64)),
+                        ("user_history", rng.randint(0, I, size=(N, 5)).astype(np.int32)),
+                        ("user_age", rng.rand(N).astype(np.float32))])
+    corpus = OrderedDict([("item_id", np.arange(I, dtype=np.int64) + 100),
+                          ("cate_id", rng.randint(1, 6, size=I).astype(np.int64)),
+                          ("item_tags", rng.randint(0, 9, size=(I, 3)).astype(np.int32)),
+                          ("item_price", rng.rand(I).astype(np.float64))])
+    labels = np.ones(N, dtype=np.float64)
+    all_idx = rng.randint(0, I, size=(N, 1 + num_negs)).astype(np.int64)
+    all_idx[::4, 2] = all_idx[::4, 1]                       # duplicates inside a row and across rows
+    ds = object.__new__(ref.TrainDataset)                   # bypass load_h5 (h5py is not in this image)
+    ds.data_dict, ds.num_samples = dict(data), N
+    ds.item_corpus_dict, ds.num_items = dict(corpus), I
+    ds.labels, ds.all_item_indexes = labels, all_idx
+    batch_index = rng.permutation(N)[:B]
+    samples = [ds[int(i)] for i in batch_index]
+    u, it, lab, inv = ref.collate_fn(samples)
+    u2, it2, lab2, inv2 = ref.collate_fn_unique([ds[int(i)] for i in batch_index])
+    save("matching_loader",
+         **{"data": data, "corpus": corpus, "in": {"labels": labels, "all_item_indexes": all_idx, "batch_index": batch_index},
+            "user": u, "item": it, "out": {"labels": lab},
+            "user_u": u2, "item_u": it2, "out_u": {"labels": lab2, "inverse_indexes": inv2}})
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -459,6 +491,7 @@ def main():
     gen_mlp(recbox, fuxictr)
     gen_attention_and_losses(recbox, fuxictr)
     gen_target_attention_and_listwise_losses(recbox, fuxictr)
+    gen_matching_loader(recbox)
 
 
 if __name__ == "__main__":

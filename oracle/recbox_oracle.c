@@ -227,3 +227,64 @@ void orc_pairdot_fwd(const float* u, const float* v, int64_t B, int32_t N, int32
       out[b * N + n] = acc * scale;
     }
 }
+
+/* ---- negative sampling + item-corpus gather --------------------------------------------------
+ * Distribution and layout follow matching/pytorch/dataloaders/h5_generator.py:61-84 (np.random.choice(num_items,
+ * size=(n, num_negs), replace=True); ignore_pos_items: uniform over the complement of the query's items),
+ * :144-181 (hstack([pos, negs])), :23-28 + :49-58 (item_corpus[k][item_indexes], flattened).
+ * The random STREAM is the build's own (numpy's MT19937 cannot be drawn in parallel): Philox4x32-10 as published
+ * (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 v1.14 known-answer
+ * vectors are checked in tests/test_c_oracle.py), key = seed, counter = (element, attempt, 0). */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static int64_t orc_draw(uint64_t element, uint32_t attempt, uint64_t seed, uint64_t num_items) {
+  const uint32_t ctr[4] = {(uint32_t)element, (uint32_t)(element >> 32), attempt, 0u};
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t o[4];
+  orc_philox4x32_10(ctr, key, o);
+  const uint64_t r = ((uint64_t)o[1] << 32) | o[0];
+  return (int64_t)(((unsigned __int128)r * num_items) >> 64);
+}
+
+void orc_negsample(int64_t num_items, int64_t rows, int32_t num_negs, uint64_t seed, uint64_t offset, const int64_t* pos,
+                   const int64_t* query, const int64_t* excl_off, const int64_t* excl_items, int64_t* out) {
+  const int width = num_negs + (pos ? 1 : 0);
+  for (int64_t r = 0; r < rows; ++r) {
+    if (pos) out[r * width] = pos[r];
+    for (int j = 0; j < num_negs; ++j) {
+      const uint64_t element = offset + (uint64_t)r * num_negs + j;
+      int64_t lo = 0, hi = 0, item = 0;
+      if (excl_off) { lo = excl_off[query[r]]; hi = excl_off[query[r] + 1]; }
+      for (uint32_t a = 0; a < 64; ++a) {
+        item = orc_draw(element, a, seed, (uint64_t)num_items);
+        int hit = 0;
+        for (int64_t k = lo; k < hi && !hit; ++k) hit = excl_items[k] == item;     /* membership, linear on purpose */
+        if (!hit) break;
+      }
+      out[r * width + (pos ? 1 : 0) + j] = item;
+    }
+  }
+}
+
+/* dst[q, :] = src[index[q], :] for one column (v[item_indexes]); returns 1 when an index was out of range */
+int orc_gather_rows(const void* src, void* dst, int64_t row_bytes, const int64_t* index, int64_t n_index, int64_t n_rows) {
+  int bad = 0;
+  for (int64_t q = 0; q < n_index; ++q) {
+    int64_t row = index[q];
+    if (row < 0 || row >= n_rows) { bad = 1; row = 0; }
+    memcpy((char*)dst + q * row_bytes, (const char*)src + row * row_bytes, (size_t)row_bytes);
+  }
+  return bad;
+}

@@ -39,8 +39,14 @@ class rbx_field_t(ctypes.Structure):
                 ("eps", ctypes.c_float)]
 
 
+class rbx_rowcopy_t(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("row_bytes", ctypes.c_int64)]
+
+
 _P = ctypes.c_void_p
 _FP = ctypes.POINTER(rbx_field_t)
+_RP = ctypes.POINTER(rbx_rowcopy_t)
+_u64 = ctypes.c_uint64
 _i32, _i64, _sz, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
 # name -> (restype, argtypes); must list every symbol of include/recbox_hip.h
@@ -64,6 +70,8 @@ SIGNATURES = {
     "rbx_gatherdot_bwd_workspace_size": (_sz, [_FP, _i32, _i64]),
     "rbx_gatherdot_sort": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P, _P]),
     "rbx_gatherdot_bwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _P, _f32, _P, _i64, _i32, _P, _sz, _P]),
+    "rbx_negsample": (ctypes.c_int, [_i64, _i64, _i32, _u64, _u64, _P, _P, _P, _P, _P, _P]),
+    "rbx_gather_rows": (ctypes.c_int, [_RP, _i32, _P, _i64, _i64, _P, _P]),
     "rbx_l2norm_fwd": (ctypes.c_int, [_P, _i64, _i32, _f32, _P, _P, _P]),
     "rbx_l2norm_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _P, _P]),
     "rbx_pairdot_fwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _f32, _P, _P]),

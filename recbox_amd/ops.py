@@ -736,6 +736,56 @@ def gather_dot(x, id_sets, weights, scale=1.0, padding_idx=None):
     return _GatherDot.apply(plan, len(id_sets), train, float(scale), x, *id_sets, *params)
 
 
+def negsample(num_items, rows, num_negs, seed, offset=0, pos=None, query=None, excl_offsets=None, excl_items=None,
+              device=None):
+    """[rows, (1 if pos is given) + num_negs] int64 item indexes: column 0 = pos, the rest uniform over
+    [0, num_items) with replacement (rbx_negsample; Philox4x32-10 keyed by ``seed``, element counter starting at
+    ``offset``).  query / excl_offsets / excl_items: CSR of the items each query interacted with (sorted inside
+    a query) -- they are never drawn (the reference's ``ignore_pos_items``)."""
+    tensors = [t for t in (pos, query, excl_offsets, excl_items) if t is not None]
+    for t in tensors:
+        _require_cuda(t, "negsample input")
+        if t.dtype != torch.int64 or not t.is_contiguous():
+            raise ValueError("negsample: index tensors must be contiguous int64")
+    dev = tensors[0].device if tensors else torch.device(device if device is not None else "cuda")
+    width = num_negs + (1 if pos is not None else 0)
+    out = torch.empty((rows, width), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.rbx_negsample(num_items, rows, num_negs, int(seed) & (2 ** 64 - 1), int(offset), _ptr(pos), _ptr(query),
+                                _ptr(excl_offsets), _ptr(excl_items), _ptr(out), _stream()))
+    return out
+
+
+def gather_rows(columns, index):
+    """[v[index] for v in columns] in one launch (rbx_gather_rows): every column is a contiguous device tensor
+    [n, ...] of any dtype; index int64 [m].  Byte-exact row copies (ids, sequences, float features alike)."""
+    _require_cuda(index, "index")
+    if index.dtype != torch.int64:
+        index = index.long()
+    index = index.contiguous().reshape(-1)
+    cols = list(columns)
+    if not cols:
+        return []
+    n = cols[0].shape[0]
+    arr = (_lib.rbx_rowcopy_t * len(cols))()
+    outs = []
+    for a, v in zip(arr, cols):
+        _require_cuda(v, "column")
+        if not v.is_contiguous() or v.shape[0] != n:
+            raise ValueError("gather_rows: columns must be contiguous and share the leading dimension")
+        out = torch.empty((index.numel(),) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        a.src, a.dst = v.data_ptr(), out.data_ptr()
+        width = 1
+        for d in v.shape[1:]:
+            width *= d
+        a.row_bytes = v.element_size() * width
+        outs.append(out)
+    status = torch.zeros(1, dtype=torch.int32, device=index.device) if config.check_ids else None
+    check(lib.rbx_gather_rows(arr, len(cols), _ptr(index), index.numel(), n, _ptr(status), _stream()))
+    _check_status(status)
+    return outs
+
+
 class _Attention(torch.autograd.Function):
     """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
 

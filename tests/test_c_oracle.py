@@ -112,3 +112,56 @@ def test_rechub_id_mask_pools_match_fixture():
     assert lib.orc_embed_fwd(C.array_of(fields), 7, ctypes.c_int64(B), C.ptr(out), ctypes.c_int64(5 * D + 2),
                              C.ptr(scale)) == 0
     assert_close(out, fx["out"]["squeezed"], TOL)
+
+
+# ---- sampler + corpus gather ---------------------------------------------------------------
+def test_philox_known_answers():
+    """Random123 v1.14 kat_vectors for philox4x32-10: the generator the sampler is defined on."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in C.philox4x32_10(ctr, key)) == want
+
+
+def test_negsample_oracle_distribution_and_exclusion():
+    """The reference's contract (h5_generator.py:61-84): column 0 = positives, negatives uniform over
+    [0, num_items) with replacement; ignore_pos_items never returns an item of the query."""
+    n_items, rows, negs = 50, 4000, 5
+    pos = np.arange(rows, dtype=np.int64) % n_items
+    s = C.negsample(n_items, rows, negs, seed=11, pos=pos)
+    assert s.shape == (rows, 1 + negs) and (s[:, 0] == pos).all()
+    neg = s[:, 1:]
+    assert neg.min() >= 0 and neg.max() < n_items
+    counts = np.bincount(neg.reshape(-1), minlength=n_items)
+    expected = rows * negs / n_items
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert chi2 < 100.0                                     # 49 dof: P(chi2 > 100) < 3e-5
+    assert (C.negsample(n_items, rows, negs, seed=11, pos=pos) == s).all()          # reproducible
+    assert (C.negsample(n_items, rows, negs, seed=12, pos=pos) != s)[:, 1:].mean() > 0.9
+    # exclusion: query q interacted with items {q, q+1, ..., q+9} mod 50
+    query = np.arange(rows, dtype=np.int64) % 7
+    off = np.arange(8, dtype=np.int64) * 10
+    items = np.concatenate([np.sort((q + np.arange(10)) % n_items) for q in range(7)]).astype(np.int64)
+    e = C.negsample(n_items, rows, negs, seed=11, pos=pos, query=query, excl_offsets=off, excl_items=items)
+    for q in range(7):
+        bad = set(items[off[q]:off[q + 1]].tolist())
+        assert not (set(e[query == q][:, 1:].reshape(-1).tolist()) & bad)
+    keep = ~np.isin(neg, items[:10]) | (query != 0)[:, None]
+    assert (e[:, 1:][keep & (query == 0)[:, None]] == neg[keep & (query == 0)[:, None]]).all()   # attempt 0 kept when legal
+
+
+def test_gather_rows_oracle_matches_reference_loader_fixture():
+    """orc_gather_rows == TrainDataset.__getitem__ + collate_fn of the live reference (fixture)."""
+    fx = Fixture("matching_loader")
+    idx = fx["in"]["all_item_indexes"][fx["in"]["batch_index"]]
+    for k, v in fx["corpus"].items():
+        got, bad = C.gather_rows(v, idx.reshape(-1))
+        assert not bad and got.dtype == fx["item"][k].dtype
+        assert (got == fx["item"][k]).all(), k
+    for k, v in fx["data"].items():
+        got, _ = C.gather_rows(v, fx["in"]["batch_index"])
+        assert (got == fx["user"][k]).all(), k
+    _, bad = C.gather_rows(fx["corpus"]["item_id"], np.array([0, 99], dtype=np.int64))
+    assert bad
