@@ -238,6 +238,24 @@ typedef struct rbx_rowcopy {
 int rbx_gather_rows(const rbx_rowcopy_t* cols, int32_t n_cols, const int64_t* d_index, int64_t n_index,
                     int64_t n_src_rows, int32_t* d_status, void* stream);
 
+/* ---- exact top-k retrieval for evaluation (core/metrics.py:54-68 evaluate_block,
+ * utils/ann/faiss.py:3-15 IndexFlatIP.search).  The score matrix U I^T comes from rbx_linear_fwd (fp32 MFMA).
+ * rbx_topk: for every row the k (<= 1024) largest of d_scores[r, 0..n) sorted by (score descending, index
+ * ascending -- ties are deterministic, the reference leaves them to faiss/numpy); d_index (optional, same
+ * layout as d_scores) supplies the index reported for each element, otherwise its column.  Rows shorter than
+ * k are padded with (-FLT_MAX, -1) like faiss.  Long rows are selected in two levels (workspace).
+ * rbx_penalize_members: scores[r, j] = (float)((double)scores[r, j] + penalty) where candidates[r, j] is in the
+ * sorted CSR list offsets/items of query d_query[r]  (mask train items: "scores += -1e9 * mask").
+ * rbx_membership: flags[r, j] = candidates[r, j] in the list of d_query[r]  (hits against valid_user2items). */
+size_t rbx_topk_workspace_size(int64_t rows, int64_t n, int32_t k);
+int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t rows, int64_t n, int64_t row_stride, int32_t k,
+             float* d_out_scores, int64_t* d_out_index, void* d_workspace, size_t workspace_bytes, void* stream);
+int rbx_penalize_members(const int64_t* d_candidates, int64_t rows, int32_t k, const int64_t* d_query,
+                         const int64_t* d_offsets, const int64_t* d_items, double penalty, float* d_scores,
+                         void* stream);
+int rbx_membership(const int64_t* d_candidates, int64_t rows, int32_t k, const int64_t* d_query,
+                   const int64_t* d_offsets, const int64_t* d_items, uint8_t* d_flags, void* stream);
+
 /* ---- dense tower: y = act(x W^T + b) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------
  * core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58,
  * third_party/rechub/basic/layers.py:255-263.  x[m,k], W[n,k] (nn.Linear layout), bias[n] or NULL,

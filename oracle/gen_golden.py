@@ -471,6 +471,66 @@ def gen_matching_loader(recbox, N=23, I=17, B=8, num_negs=3):
             "user_u": u2, "item_u": it2, "out_u": {"labels": lab2, "inverse_indexes": inv2}})
 
 
+class _ExactIPIndex(object):
+    """What faiss.IndexFlatIP is (exact inner-product search on fp32 copies, faiss.py:3-15), in numpy: faiss itself
+    is not installed in this image.  Only the SEARCH is replaced; masking, sorting and every metric below run in the
+    reference's own evaluate_block / metric classes."""
+
+    class _Idx(object):
+        pass
+
+    def __init__(self, corpus_vecs, dim, l2_normalize=False, index_name="IndexFlatIP"):
+        self.vecs = corpus_vecs.astype("float32")
+        self.index = self._Idx()
+        self.index.ntotal = self.vecs.shape[0]
+
+    def search(self, query_vecs, topk=50):
+        scores = query_vecs.astype("float32") @ self.vecs.T
+        order = np.argsort(-scores, axis=1, kind="stable")[:, :topk]
+        return np.take_along_axis(scores, order, axis=1), order
+
+
+def gen_retrieval_metrics(recbox, U=37, I=640, D=16):
+    """evaluate_metrics / evaluate_block of the live reference (core/metrics.py) on seeded embeddings."""
+    import importlib
+    ref = importlib.import_module("recbox.core.metrics")
+    ref.FaissIndex = _ExactIPIndex
+    rng = np.random.RandomState(5)
+    user = rng.randn(U, D).astype(np.float64)
+    item = rng.randn(I, D).astype(np.float64)
+    n_q = 41
+    query = rng.permutation(n_q)[:U].astype(np.int64)
+    train, valid = {}, {}
+    for q in range(n_q):
+        n_tr = int(rng.randint(0, 60)) if q % 5 else int(rng.randint(300, 520))     # some users mask most of the top 500
+        train[q] = rng.choice(I, n_tr, replace=False).tolist()
+        v = rng.choice(I, int(rng.randint(1, 30)), replace=False).tolist()
+        valid[q] = v + v[:2] if q % 3 == 0 else v                                    # duplicates in the label list
+    metrics = ["Recall(k=5)", "Recall(k=50)", "nRecall(k=20)", "Precision(k=10)", "F1(k=10)", "DCG(k=10)", "NDCG(k=20)",
+               "NDCG(k=50)", "MRR(k=50)", "HitRate(k=10)", "MAP(k=50)"]
+    funcs = [eval(m, vars(ref)) for m in metrics]
+    per_user = np.array(ref.evaluate_block(user, _ExactIPIndex(item, D), query, train, valid, funcs, 50))
+    avg = ref.evaluate_metrics(user, item, train, valid, query, metrics)
+    # top-50 item lists the reference scored (recomputed the same way, for the index-level check)
+    sc, ind = _ExactIPIndex(item, D).search(user, topk=500)
+    mask = np.zeros((U, I))
+    for i, q in enumerate(query):
+        mask[i, train[q]] = 1
+    sc += -1e9 * np.take_along_axis(mask, ind, axis=1)
+    top = np.take_along_axis(ind, np.argsort(-sc, axis=1), axis=1)[:, :50]
+    def csr(d):
+        off = np.zeros(n_q + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(d[q]) for q in range(n_q)])
+        return off, np.array([x for q in range(n_q) for x in d[q]], dtype=np.int64)
+    tr_off, tr_items = csr(train)
+    va_off, va_items = csr(valid)
+    save("retrieval_metrics",
+         **{"in": {"user": user, "item": item, "query": query, "train_off": tr_off, "train_items": tr_items,
+                   "valid_off": va_off, "valid_items": va_items},
+            "out": {"per_user": per_user, "average": np.array([avg[m] for m in metrics]), "top50": top,
+                    "metrics": np.array(metrics)}})
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -492,6 +552,7 @@ def main():
     gen_attention_and_losses(recbox, fuxictr)
     gen_target_attention_and_listwise_losses(recbox, fuxictr)
     gen_matching_loader(recbox)
+    gen_retrieval_metrics(recbox)
 
 
 if __name__ == "__main__":

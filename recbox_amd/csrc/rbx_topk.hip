@@ -1,0 +1,256 @@
+// rbx_topk.hip -- SURVEY 8f-2: exact top-k retrieval for the evaluation of two-tower models
+// (gfx950): per-row top-k selection over a score matrix, the "seen items" penalty and the
+// hit flags the ranking metrics are computed from.
+//
+// Reference behaviour replaced (paths relative to /root/reference/recbox):
+//   FaissIndex(IndexFlatIP).search(user_embs, topk=500)      utils/ann/faiss.py:3-15, core/metrics.py:56
+//       exact inner-product search: scores = U I^T in fp32 (the fp32-MFMA GEMM rbx_linear_fwd), then the
+//       500 largest per row, sorted descending  -> rbx_topk
+//   mask[i, train_user2items[q_i]] = 1; scores += -1e9 * mask      core/metrics.py:57-62   -> rbx_penalize_members
+//   np.argsort(-scores)[:, :max_topk]                              core/metrics.py:63-64   -> rbx_topk again
+//   item in set(true_items)                                        core/metrics.py:78-190  -> rbx_membership
+//
+// Selection = MSB-first radix select on order-preserving keys (4 passes of 8 bits over the row find the
+// exact k-th largest key), one ordered pass collects the winners (ties at the threshold go to the LOWEST
+// index -- deterministic; faiss/numpy leave ties unspecified), a bitonic sort in LDS orders the k winners
+// by (score descending, index ascending).  Long rows are cut into segments of 32 768 scores so that a
+// single query still fills the chip: every segment keeps its k best, a second launch selects among the
+// survivors.  HBM/L2-bound streaming reads (5 sweeps of the row), integer compares: no MFMA.
+#include "rbx_internal.h"
+
+namespace rbx {
+
+constexpr int kTopkMaxK = 1024;
+constexpr int kTopkSeg = 32768;
+
+__device__ __forceinline__ unsigned key_of(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // larger float <=> larger key
+}
+__device__ __forceinline__ float value_of(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// One workgroup per (query, segment).  vals: query u at vals + u * row_stride; the segment covers elements
+// [s * seg, min(n, (s+1) * seg)).  idx_in == nullptr: the index of an element is its position in the row.
+// Output slot (u * nseg + s) * K .. + K: the segment's top K (padded with -FLT_MAX / -1 when it is shorter).
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ vals, const long long* __restrict__ idx_in,
+                                                   const long long row_stride, const long long n, const int seg,
+                                                   const int nseg, const int K, float* __restrict__ out_vals,
+                                                   long long* __restrict__ out_idx) {
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_key[kTopkMaxK];
+  __shared__ long long s_idx[kTopkMaxK];
+  __shared__ unsigned s_prefix, s_remaining, s_count, s_eq_base;
+  __shared__ unsigned s_wave[4];
+  const long long u = blockIdx.x / nseg;
+  const int s = static_cast<int>(blockIdx.x - u * nseg);
+  const long long first = static_cast<long long>(s) * seg;
+  const int len = static_cast<int>((n - first < seg) ? (n - first) : seg);
+  const float* row = vals + u * row_stride + first;
+  const long long* irow = idx_in != nullptr ? idx_in + u * row_stride + first : nullptr;
+  const int want = (K < len) ? K : len;
+  const int tid = threadIdx.x;
+
+  // ---- radix select: key of the want-th largest element ----------------------------------------------
+  if (tid == 0) { s_prefix = 0u; s_remaining = static_cast<unsigned>(want); }
+  unsigned mask = 0u;
+  for (int shift = 24; shift >= 0 && want > 0; shift -= 8) {
+    s_hist[tid] = 0u;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    for (int i = tid; i < len; i += 256) {
+      const unsigned k = key_of(row[i]);
+      if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned rem = s_remaining, cum = 0u;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (cum + s_hist[b] >= rem) break;
+        cum += s_hist[b];
+      }
+      s_remaining = rem - cum;                               // still needed from bin b
+      s_prefix = prefix | (static_cast<unsigned>(b) << shift);
+    }
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  const unsigned T = s_prefix;                               // exact key of the want-th largest
+  const unsigned need_eq = s_remaining;                      // how many elements equal to T are taken (lowest indices)
+
+  // ---- collect: everything above T, then the first need_eq elements equal to T in index order ---------
+  if (tid == 0) { s_count = 0u; s_eq_base = 0u; }
+  for (int i = tid; i < kTopkMaxK; i += 256) { s_key[i] = 0u; s_idx[i] = -1; }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int i0 = 0; i0 < len && want > 0; i0 += 256) {
+    const int i = i0 + tid;
+    const bool live = i < len;
+    const unsigned k = live ? key_of(row[i]) : 0u;
+    const bool gt = live && k > T;
+    const bool eq = live && k == T;
+    if (gt) {
+      const unsigned slot = atomicAdd(&s_count, 1u);        // order is irrelevant: the sort fixes it
+      s_key[slot] = k;
+      s_idx[slot] = irow != nullptr ? irow[i] : first + i;
+    }
+    const unsigned long long m = __ballot(eq);
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    if (eq) {
+      unsigned rank = s_eq_base + __popcll(m & below);
+      for (int w = 0; w < wave; ++w) rank += s_wave[w];
+      if (rank < need_eq) {
+        const unsigned slot = atomicAdd(&s_count, 1u);
+        s_key[slot] = k;
+        s_idx[slot] = irow != nullptr ? irow[i] : first + i;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) s_eq_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+
+  // ---- bitonic sort of the winners: (key descending, index ascending); empty slots (key 0, idx -1) sink ----
+  int P = 1;
+  while (P < K) P <<= 1;
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < P / 2; t += 256) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;                   // "up" blocks end with the better element first
+        const unsigned ka = s_key[lo], kb = s_key[hi];
+        const long long ia = s_idx[lo], ib = s_idx[hi];
+        // a is better than b: real before empty, larger key first, then the smaller index
+        const bool a_empty = ia < 0, b_empty = ib < 0;
+        const bool a_first = a_empty != b_empty ? b_empty : (ka != kb ? ka > kb : ia <= ib);
+        if (a_first != up) {
+          s_key[lo] = kb; s_key[hi] = ka;
+          s_idx[lo] = ib; s_idx[hi] = ia;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* ov = out_vals + static_cast<long long>(blockIdx.x) * K;
+  long long* oi = out_idx + static_cast<long long>(blockIdx.x) * K;
+  for (int t = tid; t < K; t += 256) {
+    const bool empty = s_idx[t] < 0;
+    ov[t] = empty ? -3.402823466e+38f : value_of(s_key[t]);
+    oi[t] = s_idx[t];
+  }
+}
+
+// is `item` in the sorted CSR list of query q?
+__device__ __forceinline__ bool csr_member(const long long* __restrict__ off, const long long* __restrict__ items,
+                                           long long q, long long item) {
+  long long lo = off[q], hi = off[q + 1];
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    const long long v = items[mid];
+    if (v == item) return true;
+    if (v < item) lo = mid + 1; else hi = mid;
+  }
+  return false;
+}
+
+// mode 0: flags[r, j] = member;  mode 1: scores[r, j] = (float)((double)scores[r, j] + penalty * member)
+__global__ __launch_bounds__(256) void membership_kernel(const long long* __restrict__ cand, const long long rows, const int k,
+                                                         const long long* __restrict__ query,
+                                                         const long long* __restrict__ off,
+                                                         const long long* __restrict__ items, const int mode,
+                                                         const double penalty, float* __restrict__ scores,
+                                                         unsigned char* __restrict__ flags) {
+  const long long total = rows * k;
+  const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += step) {
+    const long long r = i / k;
+    const long long c = cand[i];
+    const bool hit = c >= 0 && csr_member(off, items, query[r], c);
+    if (mode == 0) flags[i] = hit ? 1 : 0;
+    else if (hit) scores[i] = static_cast<float>(static_cast<double>(scores[i]) + penalty);
+  }
+}
+
+static int topk_nseg(long long n) { return static_cast<int>((n + kTopkSeg - 1) / kTopkSeg); }
+
+}  // namespace rbx
+
+extern "C" size_t rbx_topk_workspace_size(int64_t rows, int64_t n, int32_t k) {
+  if (rows <= 0 || n <= 0 || k <= 0) return 0;
+  const int nseg = rbx::topk_nseg(n);
+  if (nseg <= 1) return 0;
+  return static_cast<size_t>(rows) * nseg * k * (sizeof(float) + sizeof(int64_t)) + 256;
+}
+
+extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t rows, int64_t n, int64_t row_stride,
+                        int32_t k, float* d_out_scores, int64_t* d_out_index, void* d_workspace, size_t workspace_bytes,
+                        void* stream) {
+  using namespace rbx;
+  if (rows < 0 || n < 0) return fail(RBX_ERR_INVALID, "topk: negative sizes");
+  if (k <= 0 || k > kTopkMaxK) return fail(RBX_ERR_UNSUPPORTED, "topk: k=%d not in [1,%d]", k, kTopkMaxK);
+  if (rows == 0) return RBX_OK;
+  if (d_out_scores == nullptr || d_out_index == nullptr) return fail(RBX_ERR_INVALID, "topk: NULL output");
+  if (n > 0 && d_scores == nullptr) return fail(RBX_ERR_INVALID, "topk: d_scores is NULL");
+  if (row_stride < n) return fail(RBX_ERR_INVALID, "topk: row_stride < n");
+  if (rows * static_cast<long long>(topk_nseg(n > 0 ? n : 1)) >= INT_MAX) return fail(RBX_ERR_UNSUPPORTED, "topk: too many rows");
+  hipStream_t s = as_stream(stream);
+  const int nseg = n > 0 ? topk_nseg(n) : 1;
+  const long long* idx = reinterpret_cast<const long long*>(d_index);
+  long long* oidx = reinterpret_cast<long long*>(d_out_index);
+  if (nseg == 1) {
+    hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, d_scores, idx,
+                       static_cast<long long>(row_stride), static_cast<long long>(n), kTopkSeg, 1, k, d_out_scores, oidx);
+    return check_launch("topk_kernel");
+  }
+  if (d_workspace == nullptr || workspace_bytes < rbx_topk_workspace_size(rows, n, k))
+    return fail(RBX_ERR_WORKSPACE, "topk: workspace too small");
+  const long long cand = static_cast<long long>(nseg) * k;                       // survivors per query
+  long long* cidx = static_cast<long long*>(d_workspace);
+  float* cval = reinterpret_cast<float*>(cidx + rows * cand);
+  hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows * nseg)), dim3(256), 0, s, d_scores, idx,
+                     static_cast<long long>(row_stride), static_cast<long long>(n), kTopkSeg, nseg, k, cval, cidx);
+  const int nseg2 = topk_nseg(cand);
+  if (nseg2 != 1) return fail(RBX_ERR_UNSUPPORTED, "topk: n=%lld with k=%d needs a third level", static_cast<long long>(n), k);
+  hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, cval, cidx, cand, cand, kTopkSeg, 1, k,
+                     d_out_scores, oidx);
+  return check_launch("topk_kernel (2 levels)");
+}
+
+extern "C" int rbx_membership(const int64_t* d_candidates, int64_t rows, int32_t k, const int64_t* d_query,
+                              const int64_t* d_offsets, const int64_t* d_items, uint8_t* d_flags, void* stream) {
+  using namespace rbx;
+  if (rows < 0 || k <= 0) return fail(RBX_ERR_INVALID, "membership: bad sizes");
+  if (rows == 0) return RBX_OK;
+  if (!d_candidates || !d_query || !d_offsets || !d_items || !d_flags) return fail(RBX_ERR_INVALID, "membership: NULL tensor");
+  long long blocks = (static_cast<long long>(rows) * k + 255) / 256;
+  if (blocks > kCUs * 16) blocks = kCUs * 16;
+  hipLaunchKernelGGL(membership_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const long long*>(d_candidates), static_cast<long long>(rows), k,
+                     reinterpret_cast<const long long*>(d_query), reinterpret_cast<const long long*>(d_offsets),
+                     reinterpret_cast<const long long*>(d_items), 0, 0.0, static_cast<float*>(nullptr), d_flags);
+  return check_launch("membership_kernel");
+}
+
+extern "C" int rbx_penalize_members(const int64_t* d_candidates, int64_t rows, int32_t k, const int64_t* d_query,
+                                    const int64_t* d_offsets, const int64_t* d_items, double penalty, float* d_scores,
+                                    void* stream) {
+  using namespace rbx;
+  if (rows < 0 || k <= 0) return fail(RBX_ERR_INVALID, "penalize_members: bad sizes");
+  if (rows == 0) return RBX_OK;
+  if (!d_candidates || !d_query || !d_offsets || !d_items || !d_scores)
+    return fail(RBX_ERR_INVALID, "penalize_members: NULL tensor");
+  long long blocks = (static_cast<long long>(rows) * k + 255) / 256;
+  if (blocks > kCUs * 16) blocks = kCUs * 16;
+  hipLaunchKernelGGL(membership_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const long long*>(d_candidates), static_cast<long long>(rows), k,
+                     reinterpret_cast<const long long*>(d_query), reinterpret_cast<const long long*>(d_offsets),
+                     reinterpret_cast<const long long*>(d_items), 1, penalty, d_scores,
+                     static_cast<unsigned char*>(nullptr));
+  return check_launch("membership_kernel");
+}

@@ -786,6 +786,55 @@ def gather_rows(columns, index):
     return outs
 
 
+def topk(scores, k, index=None):
+    """Per row the k largest entries of scores [rows, n] (fp32), sorted by (score descending, index ascending):
+    (values [rows, k] fp32, indexes [rows, k] int64).  ``index`` [rows, n] int64 replaces the column number as the
+    reported index.  Rows shorter than k are padded with (-FLT_MAX, -1).  (rbx_topk: radix select + LDS bitonic sort)"""
+    _require_cuda(scores, "scores")
+    if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
+        scores = scores.float().contiguous()
+    rows, n = scores.shape
+    if index is not None:
+        index = index.long().contiguous()
+        if index.shape != scores.shape or scores.stride(0) != n:
+            raise ValueError("topk: index must have the shape of (contiguous) scores")
+    vals = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    idx = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    ws_bytes = lib.rbx_topk_workspace_size(rows, n, k)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=scores.device)
+    check(lib.rbx_topk(_ptr(scores), _ptr(index), rows, n, scores.stride(0), k, _ptr(vals), _ptr(idx), _ptr(ws), ws_bytes,
+                       _stream()))
+    return vals, idx
+
+
+def _csr_args(candidates, query, offsets, items):
+    for t in (candidates, query, offsets, items):
+        _require_cuda(t, "membership input")
+        if t.dtype != torch.int64 or not t.is_contiguous():
+            raise ValueError("membership: index tensors must be contiguous int64")
+    if candidates.dim() != 2 or query.numel() != candidates.shape[0]:
+        raise ValueError("membership: candidates [rows, k], query [rows]")
+
+
+def membership(candidates, query, offsets, items):
+    """flags[r, j] = candidates[r, j] in items[offsets[query[r]] : offsets[query[r] + 1]] (sorted lists) -> bool."""
+    _csr_args(candidates, query, offsets, items)
+    flags = torch.empty(candidates.shape, dtype=torch.uint8, device=candidates.device)
+    check(lib.rbx_membership(_ptr(candidates), candidates.shape[0], candidates.shape[1], _ptr(query), _ptr(offsets),
+                             _ptr(items), _ptr(flags), _stream()))
+    return flags.bool()
+
+
+def penalize_members_(scores, candidates, query, offsets, items, penalty):
+    """In place: scores[r, j] += penalty where candidates[r, j] is in the list of query[r] (fp64 add, fp32 store)."""
+    _csr_args(candidates, query, offsets, items)
+    if scores.dtype != torch.float32 or not scores.is_contiguous() or scores.shape != candidates.shape:
+        raise ValueError("penalize_members_: scores must be contiguous fp32 with the shape of candidates")
+    check(lib.rbx_penalize_members(_ptr(candidates), candidates.shape[0], candidates.shape[1], _ptr(query),
+                                   _ptr(offsets), _ptr(items), float(penalty), _ptr(scores), _stream()))
+    return scores
+
+
 class _Attention(torch.autograd.Function):
     """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
 
