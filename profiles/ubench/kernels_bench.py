@@ -93,7 +93,33 @@ def gather_dot(V, D, R, n_sets):
     print("  its backward (dx gather + sort + segmented scatter-add + %d MB dense-grad zero fill)  %8.1f us" % (V * D * 4 >> 20, tb * 1e6))
 
 
+def retrieval(U, I, D, k=500):
+    g = torch.Generator().manual_seed(0)
+    u = torch.randn(U, D, generator=g).cuda()
+    v = torch.randn(I, D, generator=g).cuda()
+    scores = ops.linear(u, v)
+    tg = timeit(lambda: ops.linear(u, v), iters=5)
+    tk = timeit(lambda: ops.topk(scores, k), iters=5)
+    print("retrieval  users=%d items=%d D=%d: scores GEMM %8.1f us (%5.1f TFLOP/s)   top-%d select %8.1f us (%6.1f GB/s of one "
+          "sweep over the scores)" % (U, I, D, tg * 1e6, 2.0 * U * I * D / tg / 1e12, k, tk * 1e6, U * I * 4 / tk / 1e9))
+
+
+def sampler(I, rows, negs):
+    t = timeit(lambda: ops.negsample(I, rows, negs, seed=1, device="cuda"))
+    corpus = [torch.randint(0, 1000, (I,)).cuda(), torch.randint(0, 1000, (I, 8), dtype=torch.int32).cuda()]
+    idx = ops.negsample(I, rows, negs, seed=1, device="cuda").reshape(-1)
+    tg = timeit(lambda: ops.gather_rows(corpus, idx))
+    print("negative sampling items=%d rows=%d negs=%d  %8.1f us (%6.1f G draws/s)   corpus gather (8 B + 32 B rows) %8.1f us "
+          "(%6.1f GB/s of rows+ids+out)" % (I, rows, negs, t * 1e6, rows * negs / t / 1e9, tg * 1e6,
+                                          idx.numel() * (8 + 40 * 2) / tg / 1e9))
+
+
 if __name__ == "__main__":
+    if "eval" in sys.argv[1:]:
+        retrieval(6040, 3706, 64)
+        retrieval(1024, 1_000_000, 128)
+        sampler(10_000_000, 65536, 4)
+        sys.exit(0)
     if "dot" in sys.argv[1:]:
         gather_dot(1_000_000, 64, 4096 * 200, 2)
         sys.exit(0)
@@ -111,6 +137,10 @@ if __name__ == "__main__":
     attention(4096, 1, 200, 64)
     gemm(4096 * 200, 64, 64, None)
     gather_dot(1_000_000, 64, 4096 * 200, 2)
+    print("# SURVEY 8f: loader and evaluation")
+    retrieval(6040, 3706, 64)
+    retrieval(1024, 1_000_000, 128)
+    sampler(10_000_000, 65536, 4)
     print("# cfg 3 YoutubeDNN history pooling, one GPU holding the whole 10M x 128 table (5.1 GB)")
     gather_pool(10_000_000, 128, 65536, 50)
     print("# cfg 2 layer path pieces")

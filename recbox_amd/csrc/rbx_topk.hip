@@ -13,15 +13,16 @@
 // Selection = MSB-first radix select on order-preserving keys (4 passes of 8 bits over the row find the
 // exact k-th largest key), one ordered pass collects the winners (ties at the threshold go to the LOWEST
 // index -- deterministic; faiss/numpy leave ties unspecified), a bitonic sort in LDS orders the k winners
-// by (score descending, index ascending).  Long rows are cut into segments of 32 768 scores so that a
-// single query still fills the chip: every segment keeps its k best, a second launch selects among the
-// survivors.  HBM/L2-bound streaming reads (5 sweeps of the row), integer compares: no MFMA.
+// by (score descending, index ascending).  A workgroup stages the keys of its 8 192-score segment in LDS, so
+// HBM is read once and the five sweeps run out of LDS.  Longer rows are cut into segments (a single query
+// still fills the chip): every segment keeps its k best and further launches select among the survivors
+// until one segment per row is left.  HBM-bound streaming read + LDS integer work: no MFMA.
 #include "rbx_internal.h"
 
 namespace rbx {
 
 constexpr int kTopkMaxK = 1024;
-constexpr int kTopkSeg = 32768;
+constexpr int kTopkSeg = 8192;        // scores per workgroup: their keys are staged in LDS once (32 KB)
 
 __device__ __forceinline__ unsigned key_of(float v) {
   const unsigned u = __float_as_uint(v);
@@ -51,6 +52,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
   const long long* irow = idx_in != nullptr ? idx_in + u * row_stride + first : nullptr;
   const int want = (K < len) ? K : len;
   const int tid = threadIdx.x;
+  __shared__ unsigned s_row[kTopkSeg];
+  for (int i = tid; i < len; i += 256) s_row[i] = key_of(row[i]);     // the only pass over HBM
 
   // ---- radix select: key of the want-th largest element ----------------------------------------------
   if (tid == 0) { s_prefix = 0u; s_remaining = static_cast<unsigned>(want); }
@@ -60,19 +63,29 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
     __syncthreads();
     const unsigned prefix = s_prefix;
     for (int i = tid; i < len; i += 256) {
-      const unsigned k = key_of(row[i]);
+      const unsigned k = s_row[i];
       if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned rem = s_remaining, cum = 0u;
-      int b = 255;
-      for (; b > 0; --b) {
-        if (cum + s_hist[b] >= rem) break;
-        cum += s_hist[b];
+    {
+      // parallel suffix sum over the 256 bins (thread t owns bin t): above = elements in bins > t
+      const unsigned v = s_hist[tid];
+      const int ln = tid & 63, wv = tid >> 6;
+      unsigned incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned dn = __shfl_down(incl, o, 64);
+        if (ln + o < 64) incl += dn;
       }
-      s_remaining = rem - cum;                               // still needed from bin b
-      s_prefix = prefix | (static_cast<unsigned>(b) << shift);
+      if (ln == 0) s_wave[wv] = incl;
+      const unsigned rem = s_remaining;
+      __syncthreads();
+      unsigned above = incl - v;
+      for (int w = wv + 1; w < 4; ++w) above += s_wave[w];
+      if (above < rem && above + v >= rem) {                  // exactly one bin holds the rem-th largest
+        s_remaining = rem - above;
+        s_prefix = prefix | (static_cast<unsigned>(tid) << shift);
+      }
     }
     mask |= 255u << shift;
     __syncthreads();
@@ -80,38 +93,56 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
   const unsigned T = s_prefix;                               // exact key of the want-th largest
   const unsigned need_eq = s_remaining;                      // how many elements equal to T are taken (lowest indices)
 
-  // ---- collect: everything above T, then the first need_eq elements equal to T in index order ---------
-  if (tid == 0) { s_count = 0u; s_eq_base = 0u; }
+  // ---- collect: everything above T, then need_eq elements equal to T --------------------------------------
+  __shared__ unsigned s_eq_total;
+  if (tid == 0) { s_count = 0u; s_eq_base = 0u; s_eq_total = 0u; }
   for (int i = tid; i < kTopkMaxK; i += 256) { s_key[i] = 0u; s_idx[i] = -1; }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  const unsigned long long below = (1ull << lane) - 1ull;
-  for (int i0 = 0; i0 < len && want > 0; i0 += 256) {
-    const int i = i0 + tid;
-    const bool live = i < len;
-    const unsigned k = live ? key_of(row[i]) : 0u;
-    const bool gt = live && k > T;
-    const bool eq = live && k == T;
-    if (gt) {
-      const unsigned slot = atomicAdd(&s_count, 1u);        // order is irrelevant: the sort fixes it
-      s_key[slot] = k;
-      s_idx[slot] = irow != nullptr ? irow[i] : first + i;
-    }
-    const unsigned long long m = __ballot(eq);
-    if (lane == 0) s_wave[wave] = __popcll(m);
-    __syncthreads();
-    if (eq) {
-      unsigned rank = s_eq_base + __popcll(m & below);
-      for (int w = 0; w < wave; ++w) rank += s_wave[w];
-      if (rank < need_eq) {
-        const unsigned slot = atomicAdd(&s_count, 1u);
+  if (want > 0) {
+    unsigned eq_mine = 0u;
+    for (int i = tid; i < len; i += 256) {
+      const unsigned k = s_row[i];
+      if (k > T) {
+        const unsigned slot = atomicAdd(&s_count, 1u);        // order is irrelevant: the sort fixes it
         s_key[slot] = k;
         s_idx[slot] = irow != nullptr ? irow[i] : first + i;
       }
+      eq_mine += (k == T) ? 1u : 0u;
     }
-    __syncthreads();
-    if (tid == 0) s_eq_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    __syncthreads();
+    if (eq_mine) atomicAdd(&s_eq_total, eq_mine);
+  }
+  __syncthreads();
+  const bool tie = s_eq_total > need_eq;                     // more candidates at the threshold than places left
+  if (want > 0 && !tie) {
+    for (int i = tid; i < len; i += 256) {
+      if (s_row[i] == T) {
+        const unsigned slot = atomicAdd(&s_count, 1u);
+        s_key[slot] = T;
+        s_idx[slot] = irow != nullptr ? irow[i] : first + i;
+      }
+    }
+  } else if (want > 0) {                                     // ties: the lowest indices win, so walk in index order
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int i0 = 0; i0 < len; i0 += 256) {
+      const int i = i0 + tid;
+      const bool eq = i < len && s_row[i] == T;
+      const unsigned long long m = __ballot(eq);
+      if (lane == 0) s_wave[wave] = __popcll(m);
+      __syncthreads();
+      if (eq) {
+        unsigned rank = s_eq_base + __popcll(m & below);
+        for (int w = 0; w < wave; ++w) rank += s_wave[w];
+        if (rank < need_eq) {
+          const unsigned slot = atomicAdd(&s_count, 1u);
+          s_key[slot] = T;
+          s_idx[slot] = irow != nullptr ? irow[i] : first + i;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) s_eq_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+      __syncthreads();
+    }
   }
 
   // ---- bitonic sort of the winners: (key descending, index ascending); empty slots (key 0, idx -1) sink ----
@@ -185,7 +216,9 @@ extern "C" size_t rbx_topk_workspace_size(int64_t rows, int64_t n, int32_t k) {
   if (rows <= 0 || n <= 0 || k <= 0) return 0;
   const int nseg = rbx::topk_nseg(n);
   if (nseg <= 1) return 0;
-  return static_cast<size_t>(rows) * nseg * k * (sizeof(float) + sizeof(int64_t)) + 256;
+  // two survivor buffers (levels ping-pong between them); the first level is the largest
+  const size_t level = static_cast<size_t>(rows) * nseg * k * (sizeof(float) + sizeof(int64_t)) + 256;
+  return 2 * level;
 }
 
 extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t rows, int64_t n, int64_t row_stride,
@@ -198,28 +231,34 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
   if (d_out_scores == nullptr || d_out_index == nullptr) return fail(RBX_ERR_INVALID, "topk: NULL output");
   if (n > 0 && d_scores == nullptr) return fail(RBX_ERR_INVALID, "topk: d_scores is NULL");
   if (row_stride < n) return fail(RBX_ERR_INVALID, "topk: row_stride < n");
-  if (rows * static_cast<long long>(topk_nseg(n > 0 ? n : 1)) >= INT_MAX) return fail(RBX_ERR_UNSUPPORTED, "topk: too many rows");
+  int nseg = n > 0 ? topk_nseg(n) : 1;
+  if (rows * static_cast<long long>(nseg) >= INT_MAX) return fail(RBX_ERR_UNSUPPORTED, "topk: too many rows");
   hipStream_t s = as_stream(stream);
-  const int nseg = n > 0 ? topk_nseg(n) : 1;
-  const long long* idx = reinterpret_cast<const long long*>(d_index);
   long long* oidx = reinterpret_cast<long long*>(d_out_index);
-  if (nseg == 1) {
-    hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, d_scores, idx,
-                       static_cast<long long>(row_stride), static_cast<long long>(n), kTopkSeg, 1, k, d_out_scores, oidx);
-    return check_launch("topk_kernel");
-  }
-  if (d_workspace == nullptr || workspace_bytes < rbx_topk_workspace_size(rows, n, k))
+  if (nseg > 1 && (d_workspace == nullptr || workspace_bytes < rbx_topk_workspace_size(rows, n, k)))
     return fail(RBX_ERR_WORKSPACE, "topk: workspace too small");
-  const long long cand = static_cast<long long>(nseg) * k;                       // survivors per query
-  long long* cidx = static_cast<long long*>(d_workspace);
-  float* cval = reinterpret_cast<float*>(cidx + rows * cand);
-  hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows * nseg)), dim3(256), 0, s, d_scores, idx,
-                     static_cast<long long>(row_stride), static_cast<long long>(n), kTopkSeg, nseg, k, cval, cidx);
-  const int nseg2 = topk_nseg(cand);
-  if (nseg2 != 1) return fail(RBX_ERR_UNSUPPORTED, "topk: n=%lld with k=%d needs a third level", static_cast<long long>(n), k);
-  hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, cval, cidx, cand, cand, kTopkSeg, 1, k,
+  const size_t half = nseg > 1 ? rbx_topk_workspace_size(rows, n, k) / 2 : 0;
+  const float* vals = d_scores;
+  const long long* idx = reinterpret_cast<const long long*>(d_index);
+  long long stride = row_stride, len = n;
+  int level = 0;
+  while (nseg > 1) {                                          // every level keeps k survivors per segment
+    char* buf = static_cast<char*>(d_workspace) + (level & 1) * half;
+    const long long cand = static_cast<long long>(nseg) * k;
+    long long* cidx = reinterpret_cast<long long*>(buf);
+    float* cval = reinterpret_cast<float*>(cidx + rows * cand);
+    hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows * nseg)), dim3(256), 0, s, vals, idx, stride, len,
+                       kTopkSeg, nseg, k, cval, cidx);
+    vals = cval;
+    idx = cidx;
+    stride = len = cand;
+    nseg = topk_nseg(cand);
+    ++level;
+    if (k >= kTopkSeg) return fail(RBX_ERR_UNSUPPORTED, "topk: k too large for the segment size");
+  }
+  hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, vals, idx, stride, len, kTopkSeg, 1, k,
                      d_out_scores, oidx);
-  return check_launch("topk_kernel (2 levels)");
+  return check_launch("topk_kernel");
 }
 
 extern "C" int rbx_membership(const int64_t* d_candidates, int64_t rows, int32_t k, const int64_t* d_query,
