@@ -231,7 +231,7 @@ def main():
             cap_factor *= 2                   # skewed ids: some owner received more than its slots; start over
             del step
             model = build_model()
-        graph_note = "4 hipGraph pieces + eager RCCL collectives" if not args.eager else "eager launches"
+        graph_note = "6 hipGraph pieces + RCCL collectives between them" if not args.eager else "eager launches"
 
     for _ in range(args.warmup):
         step()

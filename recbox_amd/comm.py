@@ -75,21 +75,34 @@ def all_to_all_equal(x, group=None):
     return all_to_all_rows(x, [c] * W, [c] * W, group)
 
 
-def all_to_all_equal_into(out, x, group=None):
-    """all_to_all_equal into a caller-owned buffer (static buffers between hipGraph pieces)."""
+class _Done(object):
+    """Handle of a collective that has already been enqueued in stream order."""
+
+    def wait(self):
+        return True
+
+
+def all_to_all_equal_into(out, x, group=None, async_op=False):
+    """all_to_all_equal into a caller-owned buffer (static buffers between hipGraph pieces).  Returns a handle
+    whose ``wait()`` orders the current stream after the exchange; with ``async_op`` the exchange runs on RCCL's
+    own stream and work enqueued before ``wait()`` overlaps with it."""
     if not (dist.is_available() and dist.is_initialized()):
         out.copy_(x)
     elif dist.get_backend(group) == "nccl":
-        dist.all_to_all_single(out, x, group=group)
+        work = dist.all_to_all_single(out, x, group=group, async_op=async_op)
+        if async_op:
+            return work
     else:
         out.copy_(all_to_all_equal(x, group))
-    return out
+    return _Done()
 
 
-def all_reduce_sum_(x, group=None):
+def all_reduce_sum_(x, group=None, async_op=False):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(x, group=group)
-    return x
+        work = dist.all_reduce(x, group=group, async_op=async_op)
+        if async_op:
+            return work
+    return _Done()
 
 
 def all_reduce_grads(params, group=None):

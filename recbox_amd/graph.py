@@ -46,24 +46,25 @@ class GraphedStep(object):
 
 
 class ShardedFMStep(object):
-    """One training step of ``ShardedFM`` (row-sharded tables, padded sync-free exchange) as FOUR hipGraph
+    """One training step of ``ShardedFM`` (row-sharded tables, padded sync-free exchange) as SIX hipGraph
     pieces with the RCCL collectives launched between them:
 
-        route      ids -> (owner, row) -> wire slots                      [graph]
+        route      ids -> (owner, row) -> wire slots (rbx_route)          [graph]
         all-to-all row numbers to the owners                              RCCL
         serve      owners gather the packed rows (rbx_embed_fwd)          [graph]
         all-to-all rows back                                              RCCL
-        local      fused FM forward (remote rows read at their wire slots),
-                   loss, fused backward of the replicated tables,
-                   dL/d(remote rows) written to the wire slots, flat grads [graph]
-        all-to-all dL/d(rows) to the owners; all-reduce of the flat
-                   gradient of the replicated parameters                  RCCL
+        head       fused FM forward (remote rows read at their wire slots),
+                   loss, dL/dlogit, dL/d(remote rows) written to the slots [graph]
+        all-to-all dL/d(rows) to the owners                               RCCL, asynchronous ...
+        tail       fused backward of the replicated tables, flat grads    [graph]  ... overlapped with this
+        all-reduce of the flat gradient of the replicated parameters      RCCL, asynchronous ...
         settle     owners scatter-add into their shard's dense grad
-                   (rbx_embed_sort + rbx_embed_bwd), grads un-flattened   [graph]
+                   (rbx_embed_sort + rbx_embed_bwd)                       [graph]  ... overlapped with this
+        finish     replicated grads un-flattened                          [graph]
 
     Capturing a collective inside a hipGraph is not dependable on this stack (round 1: the capture of a
     torch.distributed all_to_all_single hung), so the graphs stop at the collectives; the host cost per step is
-    4 graph launches + 4 collectives instead of ~150 eager kernel launches.  ``graphs=False`` runs the same
+    6 graph launches + 4 collectives instead of ~150 eager kernel launches.  ``graphs=False`` runs the same
     pieces eagerly (tests, debugging).  Inputs ``X`` (dict of static tensors) and ``y`` are read in place:
     refill them before every call.  After a call, ``.grad`` of every parameter is what
     ``(bce(model(X), y) / world).backward(); model.sync_grads()`` leaves."""
@@ -91,7 +92,7 @@ class ShardedFMStep(object):
         self.replicated = [p for p in model.replicated_parameters() if p.requires_grad]
         self.sizes = [p.numel() for p in self.replicated]
         self.comm = comm
-        self.pieces = [self._route, self._serve, self._local, self._settle]
+        self.pieces = [self._route, self._serve, self._head, self._tail, self._settle, self._finish]
         self.graphs = None
         if graphs:
             side = torch.cuda.Stream()
@@ -117,22 +118,28 @@ class ShardedFMStep(object):
     def _serve(self):
         self.vecs = self.tables.local_ops.gather(self.tables.weight, self.recv)
 
-    def _local(self):
+    def _head(self):
         for p in self.replicated:
             p.grad = None
-        # the fused FM kernels read row (b, t) at wire slot slot[b, t] of the exchange buffer and write
-        # dL/d(row) to the same slot: no un-permute pass in either direction
-        back = self.back.detach().requires_grad_()
-        prob = torch.sigmoid(self.model.logits(self.X, packed=back, packed_index=self.slot))
-        self.loss = self.loss_fn(prob, self.y)
-        (self.loss / self.W).backward()           # global-mean loss: owners sum the contributions of every rank
-        self.loss = self.loss.detach()            # do not keep the autograd graph alive between steps
-        self.dsend = back.grad
+        # the fused FM kernel reads row (b, t) at wire slot slot[b, t] of the exchange buffer (no un-permute pass)
+        self.logit = self.model.logits(self.X, packed=self.back, packed_index=self.slot)
+        leaf = self.logit.detach().requires_grad_()
+        loss = self.loss_fn(torch.sigmoid(leaf), self.y)
+        (loss / self.W).backward()                # global-mean loss: owners sum the contributions of every rank
+        self.loss, self.dlogit = loss.detach(), leaf.grad
+        # dL/d(remote rows) goes to the same wire slots and leaves for the owners while the local backward runs
+        self.dsend = ops.fm_extra_grad(self.logit, self.dlogit, self.back, self.slot, self.tables.lr_off)
+        ops.join_early_sort(self.logit)           # the side-stream sort must end inside this graph piece
+
+    def _tail(self):
+        self.logit.backward(self.dlogit)          # fused backward of the replicated tables / numeric weights / bias
         self.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                                for p in self.replicated]) if self.replicated else None
 
     def _settle(self):
         self.tables.weight.grad = self.tables.local_ops.scatter_add(self.tables.weight, self.recv, self.d_recv)
+
+    def _finish(self):
         if self.flat is not None and self.W > 1:
             o = 0
             for p, n in zip(self.replicated, self.sizes):
@@ -143,17 +150,21 @@ class ShardedFMStep(object):
 
     # ---- the step ------------------------------------------------------------------------------------------
     def _run(self, pieces):
-        route, serve, local, settle = pieces
+        route, serve, head, tail, settle, finish = pieces
         comm, group = self.comm, self.group
         route()
         comm.all_to_all_equal_into(self.recv, self.send, group)
         serve()
         comm.all_to_all_equal_into(self.back, self.vecs, group)
-        local()
-        comm.all_to_all_equal_into(self.d_recv, self.dsend, group)
-        if self.flat is not None:
-            comm.all_reduce_sum_(self.flat, group)
-        settle()
+        head()
+        grads_out = comm.all_to_all_equal_into(self.d_recv, self.dsend, group, async_op=True)
+        tail()                                    # overlaps with the gradient exchange
+        reduced = comm.all_reduce_sum_(self.flat, group, async_op=True) if self.flat is not None else None
+        grads_out.wait()
+        settle()                                  # overlaps with the all-reduce of the replicated gradients
+        if reduced is not None:
+            reduced.wait()
+        finish()
         return self.loss
 
     def __call__(self):

@@ -503,6 +503,33 @@ def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=
                           bias is not None, has_extra, extra_index, *inputs, *emb_params, *lr_params, *tail)
 
 
+def fm_extra_grad(logit, dlogit, extra, extra_index, extra_lr_off):
+    """dL/d(extra rows) of ``logit = fm_fused(..., extra=extra, extra_index=...)`` for a given dL/dlogit, written to the
+    wire slots (zeros elsewhere): [g (S - e) | g at the LR slot | 0] per row (rbx_fm_extra_bwd).  Lets a caller send
+    the remote rows' gradient on its way BEFORE running the rest of the backward (``logit.backward(dlogit)``)."""
+    ctx = logit.grad_fn
+    emb_plan, ssum, B = ctx.state[0], ctx.state[6], ctx.state[7]
+    D = emb_plan.specs[0].dim if emb_plan is not None else 0
+    dlogit = dlogit.contiguous().float().view(-1)
+    dx = torch.zeros_like(extra) if extra_index is not None else torch.empty_like(extra)
+    if extra_index is None:
+        check(lib.rbx_fm_extra_bwd(_ptr(dlogit), _ptr(ssum), _ptr(extra), B, extra.shape[1], D, extra.shape[2],
+                                   extra_lr_off, None, 0, _ptr(dx), _stream()))
+    else:
+        check(lib.rbx_fm_extra_bwd(_ptr(dlogit), _ptr(ssum), _ptr(extra), B, extra_index.shape[1], D, extra.shape[1],
+                                   extra_lr_off, _ptr(extra_index), extra.shape[0], _ptr(dx), _stream()))
+    return dx
+
+
+def join_early_sort(logit):
+    """Order the current stream after the id sort that ``fm_fused`` / ``embed_lookup`` / ``gather_dot`` started on the
+    side stream (needed when forward and backward are captured in different hipGraphs)."""
+    srt = getattr(logit.grad_fn, "sort", None)
+    if srt is not None:
+        srt.join()
+        srt.event = None
+
+
 _route_plans = {}
 
 
