@@ -194,6 +194,24 @@ int rbx_pairdot_fwd(const float* d_u, const float* d_v, int64_t batch, int32_t n
 int rbx_pairdot_bwd(const float* d_u, const float* d_v, const float* d_dout, int64_t batch, int32_t n_cand,
                     int32_t dim, float scale, float* d_du, float* d_dv, void* stream);
 
+/* ---- BatchNorm1d of the dense towers (third_party/rechub/basic/layers.py:255-263: Linear -> BatchNorm1d ->
+ * activation -> Dropout after every layer; optional in core/pytorch/layers/mlp.py:25-37 and
+ * ranking/pytorch/layers/blocks/mlp_block.py:42-58).  x [rows, cols] row-major, statistics per column.
+ * training != 0: batch statistics (biased variance normalises, the running statistics receive
+ * (1 - momentum) * old + momentum * {mean, unbiased variance} when the pointers are given); training == 0:
+ * running statistics.  d_mean / d_rstd [cols] are outputs kept for the backward.  relu != 0 applies ReLU to y;
+ * the backward then takes that y as d_y_relu (mask y > 0) -- NULL when no activation was fused.
+ * Backward: d_dgamma = sum dy * xhat, d_dbeta = sum dy (always written, also used as scratch),
+ * d_dx = gamma * rstd * (dy - dbeta/M - xhat * dgamma/M) (training) or gamma * rstd * dy (eval); NULL skips it.
+ * Reductions are two-stage in a fixed order (Welford partials merged with Chan's formula): deterministic. */
+size_t rbx_batchnorm_workspace_size(int64_t rows, int32_t cols);
+int rbx_batchnorm_fwd(const float* d_x, int64_t rows, int32_t cols, const float* d_gamma, const float* d_beta, float eps,
+                      int32_t training, float momentum, float* d_running_mean, float* d_running_var, int32_t relu,
+                      float* d_mean, float* d_rstd, float* d_y, void* d_workspace, size_t workspace_bytes, void* stream);
+int rbx_batchnorm_bwd(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
+                      const float* d_gamma, const float* d_mean, const float* d_rstd, int32_t training, float* d_dx,
+                      float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K7: candidate scoring without materialising the candidate embeddings
  * (third_party/rechub/models/matching/sasrec.py:98-105: pos/neg logits = (seq_output * item_emb(ids)).sum(-1);
  * the [rows, 1 + n] sampled-softmax logits consumed by core/pytorch/losses/softmax_crossentropy_loss.py:14-22).

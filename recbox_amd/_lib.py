@@ -76,6 +76,9 @@ SIGNATURES = {
     "rbx_topk": (ctypes.c_int, [_P, _P, _i64, _i64, _i64, _i32, _P, _P, _P, _sz, _P]),
     "rbx_penalize_members": (ctypes.c_int, [_P, _i64, _i32, _P, _P, _P, ctypes.c_double, _P, _P]),
     "rbx_membership": (ctypes.c_int, [_P, _i64, _i32, _P, _P, _P, _P, _P]),
+    "rbx_batchnorm_workspace_size": (_sz, [_i64, _i32]),
+    "rbx_batchnorm_fwd": (ctypes.c_int, [_P, _i64, _i32, _P, _P, _f32, _i32, _f32, _P, _P, _i32, _P, _P, _P, _P, _sz, _P]),
+    "rbx_batchnorm_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _P, _P, _P, _i32, _P, _P, _P, _P, _sz, _P]),
     "rbx_l2norm_fwd": (ctypes.c_int, [_P, _i64, _i32, _f32, _P, _P, _P]),
     "rbx_l2norm_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _P, _P]),
     "rbx_pairdot_fwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _f32, _P, _P]),

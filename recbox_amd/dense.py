@@ -1,8 +1,9 @@
 """Dense-tower execution: nn.Sequential children stay the reference's modules (real
 ``nn.Linear`` so harness type tests / checkpoints keep working); this walker replaces
 their compute with the fp32-MFMA GEMM of ``rbx_linear_fwd/bwd`` and fuses a following
-ReLU into the GEMM epilogue.  BatchNorm / Dropout / other activations are elementwise
-or per-feature ATen kernels and run as the modules they are.
+ReLU into the GEMM epilogue; nn.BatchNorm1d on 2-D activations runs through
+``rbx_batchnorm_fwd/bwd`` (a following ReLU fused in).  Dropout / other activations
+are elementwise ATen kernels and run as the modules they are.
 """
 from torch import nn
 
@@ -41,6 +42,10 @@ def run_sequential(seq, x):
         if type(m) is nn.Linear:
             fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
             x = ops.linear(x, m.weight, m.bias, "relu" if fuse else None)
+            i += 2 if fuse else 1
+        elif type(m) is nn.BatchNorm1d and x.dim() == 2 and x.is_cuda:
+            fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+            x = ops.batch_norm(x, m, relu=fuse)
             i += 2 if fuse else 1
         else:
             x = m(x)

@@ -862,6 +862,68 @@ def penalize_members_(scores, candidates, query, offsets, items, penalty):
     return scores
 
 
+class _BatchNorm(torch.autograd.Function):
+    """F.batch_norm on [rows, cols] (+ optional fused ReLU) through rbx_batchnorm_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stats, training, momentum, eps, relu):
+        running_mean, running_var = stats.running_mean, stats.running_var      # buffers updated in place by the kernel
+        _require_cuda(x, "x")
+        x = x.contiguous().float()
+        rows, cols = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(cols, dtype=torch.float32, device=dev)
+        rstd = torch.empty(cols, dtype=torch.float32, device=dev)
+        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        check(lib.rbx_batchnorm_fwd(_ptr(x), rows, cols, _ptr(weight), _ptr(bias), eps, 1 if training else 0, momentum,
+                                    _ptr(running_mean), _ptr(running_var), 1 if relu else 0, _ptr(mean), _ptr(rstd),
+                                    _ptr(y), _ptr(ws), ws_bytes, _stream()))
+        ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
+        ctx.training, ctx.has_bias = training, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd, y_relu = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        rows, cols = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
+        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        check(lib.rbx_batchnorm_bwd(_ptr(x), _ptr(dy), _ptr(y_relu), rows, cols, _ptr(weight), _ptr(mean), _ptr(rstd),
+                                    1 if ctx.training else 0, _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws_bytes,
+                                    _stream()))
+        return (dx, dgamma if (weight is not None and ctx.needs_input_grad[1]) else None,
+                dbeta if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None, None, None)
+
+
+def batch_norm(x, module, relu=False):
+    """``module(x)`` for an nn.BatchNorm1d on [rows, cols] input (optionally followed by ReLU), with torch's
+    bookkeeping: running statistics, num_batches_tracked, momentum=None = cumulative average, eval mode."""
+    training = module.training or module.running_mean is None
+    momentum = 0.0 if module.momentum is None else module.momentum
+    if module.training and module.track_running_stats and module.num_batches_tracked is not None:
+        module.num_batches_tracked.add_(1)
+        if module.momentum is None:
+            momentum = 1.0 / float(module.num_batches_tracked)
+    return _BatchNorm.apply(x, module.weight, module.bias, _BnStats(module), training, float(momentum), float(module.eps),
+                            relu)
+
+
+class _BnStats(object):
+    """The running-statistics buffers of a BatchNorm module, handed to the autograd Function as a plain object
+    (they are updated in place and take no part in differentiation)."""
+
+    def __init__(self, module):
+        track = module.track_running_stats and module.running_mean is not None
+        self.running_mean = module.running_mean if track else None
+        self.running_var = module.running_var if track else None
+
+
 class _Attention(torch.autograd.Function):
     """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
 

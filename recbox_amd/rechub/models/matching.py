@@ -61,13 +61,21 @@ class YoutubeDNN(torch.nn.Module):
         self.mode = None
 
     def forward(self, x):
+        if self.mode is None:
+            # training: ONE gather launch (and one backward scatter-add) for the user side, the positive item and
+            # the negatives.  The history, the positive and the negatives share one table; looking them up in two
+            # calls, as youtube_dnn.py:52-70 does, would build two dense [V, D] gradients of that table and add them.
+            dim = self.item_features[0].embed_dim
+            both = self.embedding(x, self.user_features + self.item_features + self.neg_item_feature, squeeze_dim=True)
+            user_embedding = ops.l2_normalize(self.user_mlp(both[:, :self.user_dims].contiguous())).unsqueeze(1)
+            items = both[:, self.user_dims:].contiguous()
+            item_embedding = ops.l2_normalize(items.view(items.shape[0], -1, dim))
+            return ops.pair_dot(user_embedding, item_embedding, scale=1.0 / self.temperature)   # [B, 1 + n_neg]
         user_embedding = self.user_tower(x)
         item_embedding = self.item_tower(x)
         if self.mode == "user":
             return user_embedding
-        if self.mode == "item":
-            return item_embedding
-        return ops.pair_dot(user_embedding, item_embedding, scale=1.0 / self.temperature)   # [B, 1 + n_neg]
+        return item_embedding
 
     def user_tower(self, x):
         if self.mode == "item":

@@ -171,6 +171,52 @@ def test_gather_dot_vs_torch(D, n_sets, width):
         assert_close(a.grad, b.grad, 1e-4, "dW")
 
 
+@pytest.mark.parametrize("rows,cols,relu", [(64, 32, False), (1000, 400, True), (513, 37, True), (2, 8, False)])
+def test_batch_norm_vs_torch(rows, cols, relu):
+    """rbx_batchnorm_fwd/bwd == nn.BatchNorm1d (+ReLU) of torch CPU fp32: outputs, input / affine gradients, running
+    statistics and num_batches_tracked in training mode over two steps, then eval mode."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    ref = torch.nn.BatchNorm1d(cols)
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(cols, generator=g) + 0.5)
+        ref.bias.copy_(torch.randn(cols, generator=g) * 0.1)
+    dut = torch.nn.BatchNorm1d(cols)
+    dut.load_state_dict(ref.state_dict())
+    dut.cuda()
+    for step in range(2):
+        x = torch.randn(rows, cols, generator=g) * 2.0 + 3.0          # mean far from 0: E[x^2]-E[x]^2 would lose digits
+        r = torch.randn(rows, cols, generator=g)
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        yr = torch.relu(yr) if relu else yr
+        (yr * r).sum().backward()
+        xc = x.cuda().requires_grad_(True)
+        yc = ops.batch_norm(xc, dut, relu=relu)
+        (yc * r.cuda()).sum().backward()
+        assert_close(yc, yr.detach(), 1e-5, "y")
+        assert_close(xc.grad, xr.grad, 2e-4, "dx")
+        assert_close(dut.weight.grad, ref.weight.grad, 1e-4 * max(1.0, rows ** 0.5 / 4), "dgamma")
+        assert_close(dut.bias.grad, ref.bias.grad, 1e-4 * max(1.0, rows ** 0.5 / 4), "dbeta")
+        assert_close(dut.running_mean, ref.running_mean, 1e-6, "running_mean")
+        assert_close(dut.running_var, ref.running_var, 1e-5, "running_var")
+        assert int(dut.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+        ref.zero_grad()
+        dut.zero_grad()
+    ref.eval()
+    dut.eval()
+    x = torch.randn(rows, cols, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.sum().backward()
+    xc = x.cuda().requires_grad_(True)
+    yc = ops.batch_norm(xc, dut)
+    yc.sum().backward()
+    assert_close(yc, yr.detach(), 1e-5, "eval y")
+    assert_close(xc.grad, xr.grad, 1e-5, "eval dx")
+    assert int(dut.num_batches_tracked) == 2
+
+
 def _dssm_feats(Fe, D=16):
     Sp, Sq = Fe.SparseFeature, Fe.SequenceFeature
     uf = [Sp("user_id", 61, D), Sp("gender", 3, D),
