@@ -276,15 +276,17 @@ int rbx_membership(const int64_t* d_candidates, int64_t rows, int32_t k, const i
 
 /* ---- dense tower: y = act(x W^T + b) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------
  * core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58,
- * third_party/rechub/basic/layers.py:255-263.  x[m,k], W[n,k] (nn.Linear layout), bias[n] or NULL,
- * act: 0 none, 1 ReLU.  Backward: dx[m,k] (NULL to skip), dW[n,k], db[n] (NULL to skip) are
- * OVERWRITTEN; d_y (forward output) is only read when act == 1. */
-int rbx_linear_fwd(const float* d_x, const float* d_w, const float* d_bias, int64_t m, int32_t n, int32_t k,
-                   int32_t act, float* d_y, void* stream);
+ * third_party/rechub/basic/layers.py:255-263.  x[m,k] with row stride x_stride >= k floats (a column block of
+ * a wider activation, e.g. the embedding part of a padded [B, width] gather output, is read in place),
+ * W[n,k] (nn.Linear layout), bias[n] or NULL, act: 0 none, 1 ReLU.  Backward: dx[m,k] (row stride dx_stride;
+ * NULL to skip), dW[n,k], db[n] (NULL to skip) are OVERWRITTEN; d_y (forward output) is only read when
+ * act == 1.  Rows that are 16-byte aligned (pointer and stride) are loaded as float4. */
+int rbx_linear_fwd(const float* d_x, int64_t x_stride, const float* d_w, const float* d_bias, int64_t m, int32_t n,
+                   int32_t k, int32_t act, float* d_y, void* stream);
 size_t rbx_linear_bwd_workspace_size(int64_t m, int32_t n, int32_t k, int32_t act);
-int rbx_linear_bwd(const float* d_x, const float* d_w, const float* d_y, const float* d_dy, int64_t m, int32_t n,
-                   int32_t k, int32_t act, float* d_dx, float* d_dw, float* d_db, void* d_workspace,
-                   size_t workspace_bytes, void* stream);
+int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d_w, const float* d_y, const float* d_dy, int64_t m,
+                   int32_t n, int32_t k, int32_t act, float* d_dx, int64_t dx_stride, float* d_dw, float* d_db,
+                   void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K6: fused masked-softmax attention for short sequences (L <= 256, head_dim in {4..64}) ----
  * ranking/pytorch/layers/attentions/dot_product_attention.py:31-43 (ScaledDotProductAttention) and the

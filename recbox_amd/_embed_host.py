@@ -51,9 +51,9 @@ class Plan(object):
         dims = set(s.dim for s in specs)
         self.uniform_dim = dims.pop() if len(dims) == 1 else None
 
-    def run(self, inputs):
+    def run(self, inputs, pad_rows=False):
         params = [m.weight for m in self.modules]
-        return ops.embed_lookup(self.plan, inputs, params)
+        return ops.embed_lookup(self.plan, inputs, params, pad_rows=pad_rows)
 
     def slot(self, out, i):
         """View of output slot i: [B, dim] or [B, L, dim] for concat pooling."""

@@ -201,11 +201,12 @@ static bool vec_ok(const float* p, long long ld) { return (reinterpret_cast<uint
 // generic driver: C[M,N] = op(A) op(B)
 template <bool AK, bool BK_>
 static int run_gemm(const float* A, long long lda, const float* B, long long ldb, float* C, int M, int N, int K,
-                    const float* bias, int act, float* ws, size_t ws_floats, hipStream_t s) {
+                    const float* bias, int act, float* ws, size_t ws_floats, hipStream_t s, long long ldc = 0) {
+  if (ldc == 0) ldc = N;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   int splits = 1;
   const long long tiles = static_cast<long long>(tm) * tn;
-  if (tiles < kCUs && K >= 4096 && ws != nullptr) {            // tiny output, long reduction: split K
+  if (tiles < kCUs && K >= 4096 && ws != nullptr && ldc == N) {   // tiny output, long reduction: split K
     splits = static_cast<int>((2 * kCUs + tiles - 1) / tiles);
     const int max_splits = K / 512;
     if (splits > max_splits) splits = max_splits;
@@ -218,7 +219,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   splits = (K + kps - 1) / kps;
   float* dst = (splits > 1) ? ws : C;
   hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn, tm, splits), dim3(256), 0, s, A, lda, B, ldb, dst,
-                     static_cast<long long>(N), M, N, K, kps, bias, act, vec_ok(A, lda), vec_ok(B, ldb));
+                     (splits > 1) ? static_cast<long long>(N) : ldc, M, N, K, kps, bias, act, vec_ok(A, lda), vec_ok(B, ldb));
   int rc = check_launch("gemm_f32_kernel");
   if (rc != RBX_OK) return rc;
   if (splits > 1) {
@@ -233,15 +234,16 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
 
 }  // namespace rbx
 
-extern "C" int rbx_linear_fwd(const float* d_x, const float* d_w, const float* d_bias, int64_t m, int32_t n,
-                              int32_t k, int32_t act, float* d_y, void* stream) {
+extern "C" int rbx_linear_fwd(const float* d_x, int64_t x_stride, const float* d_w, const float* d_bias, int64_t m,
+                              int32_t n, int32_t k, int32_t act, float* d_y, void* stream) {
   using namespace rbx;
   if (d_x == nullptr || d_w == nullptr || d_y == nullptr) return fail(RBX_ERR_INVALID, "linear: NULL tensor");
   if (m < 0 || n <= 0 || k <= 0 || m > INT_MAX) return fail(RBX_ERR_INVALID, "linear: bad shape");
+  if (x_stride < k) return fail(RBX_ERR_INVALID, "linear: x_stride %lld < k %d", static_cast<long long>(x_stride), k);
   if (act != 0 && act != 1) return fail(RBX_ERR_UNSUPPORTED, "linear: activation code %d", act);
   if (m == 0) return RBX_OK;
   // y[m,n] = x[m,k] * W[n,k]^T : A = x (k contiguous), B(k,n) = W[n*k + k] (k contiguous)
-  return run_gemm<true, true>(d_x, k, d_w, k, d_y, static_cast<int>(m), n, k, d_bias, act, nullptr, 0,
+  return run_gemm<true, true>(d_x, x_stride, d_w, k, d_y, static_cast<int>(m), n, k, d_bias, act, nullptr, 0,
                               as_stream(stream));
 }
 
@@ -263,11 +265,12 @@ extern "C" size_t rbx_linear_bwd_workspace_size(int64_t m, int32_t n, int32_t k,
   return (masked + dw + db + 1024) * sizeof(float);
 }
 
-extern "C" int rbx_linear_bwd(const float* d_x, const float* d_w, const float* d_y, const float* d_dy, int64_t m,
-                              int32_t n, int32_t k, int32_t act, float* d_dx, float* d_dw, float* d_db,
-                              void* d_workspace, size_t workspace_bytes, void* stream) {
+extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d_w, const float* d_y, const float* d_dy,
+                              int64_t m, int32_t n, int32_t k, int32_t act, float* d_dx, int64_t dx_stride, float* d_dw,
+                              float* d_db, void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace rbx;
   if (d_x == nullptr || d_w == nullptr || d_dy == nullptr) return fail(RBX_ERR_INVALID, "linear_bwd: NULL tensor");
+  if (x_stride < k || (d_dx != nullptr && dx_stride < k)) return fail(RBX_ERR_INVALID, "linear_bwd: row stride < k");
   if (act == 1 && d_y == nullptr) return fail(RBX_ERR_INVALID, "linear_bwd: y is needed for the ReLU mask");
   if (m <= 0 || m > INT_MAX) return (m == 0) ? RBX_OK : fail(RBX_ERR_INVALID, "linear_bwd: bad m");
   const size_t need = rbx_linear_bwd_workspace_size(m, n, k, act);
@@ -288,12 +291,12 @@ extern "C" int rbx_linear_bwd(const float* d_x, const float* d_w, const float* d
   int rc = RBX_OK;
   if (d_dx != nullptr) {
     // dx[m,k] = g[m,n] * W[n,k]: A = g (n contiguous = its K), B(kk=n, col=k) = W[n*k + k] (col contiguous)
-    rc = run_gemm<true, false>(g, n, d_w, k, d_dx, M, k, n, nullptr, 0, nullptr, 0, s);
+    rc = run_gemm<true, false>(g, n, d_w, k, d_dx, M, k, n, nullptr, 0, nullptr, 0, s, dx_stride);
     if (rc != RBX_OK) return rc;
   }
   if (d_dw != nullptr) {
     // dW[n,k] = g^T[n,m] * x[m,k]: A(i=n, kk=m) = g[m*n + n] (row contiguous), B(kk=m, col=k) = x[m*k + k]
-    rc = run_gemm<false, false>(g, n, d_x, k, d_dw, n, k, M, nullptr, 0, ws, dw_floats, s);
+    rc = run_gemm<false, false>(g, n, d_x, x_stride, d_dw, n, k, M, nullptr, 0, ws, dw_floats, s);
     if (rc != RBX_OK) return rc;
   }
   if (d_db != nullptr) {

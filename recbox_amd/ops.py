@@ -211,7 +211,7 @@ class _EmbedLookup(torch.autograd.Function):
     """out[B, width] = multi-table gather (+pooling); backward = sorted segmented scatter-add."""
 
     @staticmethod
-    def forward(ctx, plan, n_inputs, train, *tensors):
+    def forward(ctx, plan, n_inputs, train, pad_rows, *tensors):
         inputs, params = tensors[:n_inputs], tensors[n_inputs:]
         for p in params:
             _require_cuda(p, "embedding parameter")
@@ -220,12 +220,12 @@ class _EmbedLookup(torch.autograd.Function):
         B, keep = plan.bind_inputs(inputs)
         plan.bind_params(params)
         dev = params[0].device if params else keep[0].device
-        out = torch.empty((B, plan.width), dtype=torch.float32, device=dev)
+        out = _padded_rows(B, plan.width, dev) if pad_rows else torch.empty((B, plan.width), dtype=torch.float32, device=dev)
         row_scale = torch.empty((plan.n, B), dtype=torch.float32, device=dev) if plan.needs_row_scale else None
         status = torch.zeros(1, dtype=torch.int32, device=dev) if config.check_ids else None
         check(_timed(("embed_fwd", plan.n, plan.width, B),
-                     lambda: lib.rbx_embed_fwd(plan.arr, plan.n, B, _ptr(out), plan.width, _ptr(row_scale),
-                                               _ptr(status), _stream())))
+                     lambda: lib.rbx_embed_fwd(plan.arr, plan.n, B, _ptr(out), out.stride(0) if B > 1 else plan.width,
+                                               _ptr(row_scale), _ptr(status), _stream())))
         _check_status(status)
         ctx.plan, ctx.inputs, ctx.row_scale, ctx.B = plan, keep, row_scale, B
         ctx.params = params
@@ -244,11 +244,11 @@ class _EmbedLookup(torch.autograd.Function):
         plan, params, B = ctx.plan, ctx.params, ctx.B
         if dout.stride(1) != 1 or dout.dtype != torch.float32:
             dout = dout.contiguous().float()
-        need = [i + 3 + len(ctx.inputs) for i in range(len(params))]
+        need = [i + 4 + len(ctx.inputs) for i in range(len(params))]
         want = [ctx.needs_input_grad[j] for j in need]
         grads = _flat_zero_grads(params, want, dout.device)
         if B == 0:
-            return (None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
+            return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
         plan.bind_inputs(ctx.inputs)
         plan.bind_params(params, grads)
         want_now = [p.requires_grad for p in params]
@@ -260,15 +260,17 @@ class _EmbedLookup(torch.autograd.Function):
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dout.device)
             check(lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, _stream()))
         # grads are views of a freshly zeroed buffer: accumulate=0 lets the kernel store instead of RMW
-        check(lib.rbx_embed_bwd(plan.arr, plan.n, B, _ptr(dout), dout.stride(0), _ptr(ctx.row_scale), 0,
-                                _ptr(ws), ws_bytes, _stream()))
-        return (None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
+        check(lib.rbx_embed_bwd(plan.arr, plan.n, B, _ptr(dout), dout.stride(0) if B > 1 else plan.width,
+                                _ptr(ctx.row_scale), 0, _ptr(ws), ws_bytes, _stream()))
+        return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
 
 
-def embed_lookup(plan, inputs, params):
-    """Run plan over ``inputs`` (one tensor per feature) and ``params`` (distinct tables/weights)."""
+def embed_lookup(plan, inputs, params, pad_rows=False):
+    """Run plan over ``inputs`` (one tensor per feature) and ``params`` (distinct tables/weights).
+    pad_rows: give the [B, width] result a row stride that is a multiple of 4 floats (16-byte aligned rows for the
+    float4 kernels and the GEMM that consumes it); the result is then a column view of a wider buffer."""
     train = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # grad mode is off inside forward()
-    return _EmbedLookup.apply(plan, len(inputs), train, *inputs, *params)
+    return _EmbedLookup.apply(plan, len(inputs), train, pad_rows, *inputs, *params)
 
 
 class _Interaction(torch.autograd.Function):
@@ -565,22 +567,39 @@ def interaction_rowsum(emb):
 # --------------------------------------------------------------------------------------------
 # dense tower (fp32 MFMA GEMM) and two-tower scoring
 # --------------------------------------------------------------------------------------------
+def _rows_view(x):
+    """x [..., K] as a 2-D fp32 view with unit inner stride (row stride may exceed K); copies only when it must."""
+    if x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1]:
+        return x
+    return x.reshape(-1, x.shape[-1]).contiguous().float()
+
+
+def _padded_rows(rows, cols, device):
+    """[rows, cols] fp32 whose row stride is a multiple of 4 floats (16-byte aligned rows -> float4 loads)."""
+    stride = (cols + 3) // 4 * 4
+    if stride == cols:
+        return torch.empty((rows, cols), dtype=torch.float32, device=device)
+    return torch.empty((rows, stride), dtype=torch.float32, device=device)[:, :cols]
+
+
 class _Linear(torch.autograd.Function):
-    """y = act(x W^T + b) via rbx_linear_fwd; act in {None, "relu"} is fused into the epilogue."""
+    """y = act(x W^T + b) via rbx_linear_fwd; act in {None, "relu"} is fused into the epilogue.  x may be a column
+    block of a wider row-major activation (row stride > K): it is read, and its gradient written, in place."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act):
         _require_cuda(x, "linear input")
         _require_cuda(weight, "linear weight")
         shape = x.shape
-        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        x2 = _rows_view(x)
         w = weight.contiguous()
         M, K = x2.shape
         N = w.shape[0]
         if w.shape[1] != K:
             raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, w.shape[1], N))
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        check(lib.rbx_linear_fwd(_ptr(x2), _ptr(w), _ptr(bias), M, N, K, act, _ptr(y), _stream()))
+        check(lib.rbx_linear_fwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(bias), M, N, K, act, _ptr(y),
+                                 _stream()))
         ctx.save_for_backward(x2, w, y if act == 1 else None)
         ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, shape
         return y.view(*shape[:-1], N)
@@ -591,12 +610,16 @@ class _Linear(torch.autograd.Function):
         M, K = x2.shape
         N = w.shape[0]
         dy2 = dy.reshape(M, N).contiguous().float()
-        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:       # 2-D inputs get 16-byte aligned gradient rows (float4 stores, aligned re-reads)
+            dx = _padded_rows(M, K, dy.device) if len(ctx.shape) == 2 else torch.empty((M, K), dtype=torch.float32,
+                                                                                      device=dy.device)
         dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
         db = torch.empty(N, dtype=torch.float32, device=dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, ctx.act)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
-        check(lib.rbx_linear_bwd(_ptr(x2), _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx), _ptr(dw), _ptr(db),
+        check(lib.rbx_linear_bwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act,
+                                 _ptr(dx), (dx.stride(0) if M > 1 else K) if dx is not None else K, _ptr(dw), _ptr(db),
                                  _ptr(ws), ws_bytes, _stream()))
         return (dx.view(ctx.shape) if dx is not None else None), dw, db, None
 

@@ -84,7 +84,9 @@ class EmbeddingLayer(nn.Module):
             cached = (host.Plan(lookups), len(sparse))
             self._plans[key] = cached
         plan, n_sparse = cached
-        out = plan.run([x[lk.name] for lk in plan.lookups])
+        # the flattened [B, sum(dims) + n_dense] layout rarely has 16-byte aligned rows (26 * 64 + 13 = 1677 floats):
+        # it is produced with a padded row stride and consumed in place by the tower's first GEMM
+        out = plan.run([x[lk.name] for lk in plan.lookups], pad_rows=squeeze_dim)
         if squeeze_dim:
             return out
         B = out.shape[0]

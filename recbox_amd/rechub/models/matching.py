@@ -95,7 +95,7 @@ class YoutubeDNN(torch.nn.Module):
         # positive id and the n_neg negative ids in ONE gather launch: [B, (1 + n_neg) * D]
         both = self.embedding(x, self.item_features + self.neg_item_feature, squeeze_dim=True)
         dim = self.item_features[0].embed_dim
-        return ops.l2_normalize(both.view(both.shape[0], -1, dim))                          # [B, 1 + n_neg, D]
+        return ops.l2_normalize(both.reshape(both.shape[0], -1, dim))                          # [B, 1 + n_neg, D]
 
 
 class PointWiseFeedForward(torch.nn.Module):
