@@ -212,6 +212,18 @@ int rbx_batchnorm_bwd(const float* d_x, const float* d_dy, const float* d_y_relu
                       const float* d_gamma, const float* d_mean, const float* d_rstd, int32_t training, float* d_dx,
                       float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---- LayerNorm over the last dimension (the five nn.LayerNorm(D, eps=1e-8) of a SASRec block stack,
+ * third_party/rechub/models/matching/sasrec.py:52-63,81-94).  x [rows, dim] contiguous; biased variance, eps inside
+ * the square root (torch semantics); d_mean / d_rstd [rows] are kept for the backward.  Backward:
+ * dx = rstd * (g - mean_d(g) - xhat * mean_d(g * xhat)) with g = dy * gamma (NULL skips it);
+ * d_dgamma = sum_rows dy * xhat, d_dbeta = sum_rows dy (both or neither; two-stage fixed-order reduction). */
+int rbx_layernorm_fwd(const float* d_x, int64_t rows, int32_t dim, const float* d_gamma, const float* d_beta, float eps,
+                      float* d_mean, float* d_rstd, float* d_y, void* stream);
+size_t rbx_layernorm_bwd_workspace_size(int64_t rows, int32_t dim);
+int rbx_layernorm_bwd(const float* d_x, const float* d_dy, int64_t rows, int32_t dim, const float* d_gamma,
+                      const float* d_mean, const float* d_rstd, float* d_dx, float* d_dgamma, float* d_dbeta,
+                      void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K7: candidate scoring without materialising the candidate embeddings
  * (third_party/rechub/models/matching/sasrec.py:98-105: pos/neg logits = (seq_output * item_emb(ids)).sum(-1);
  * the [rows, 1 + n] sampled-softmax logits consumed by core/pytorch/losses/softmax_crossentropy_loss.py:14-22).

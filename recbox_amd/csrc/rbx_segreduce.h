@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void segment_fixup_short_kernel(const RedPack 
 // backwards 256/G tails per step (flags first, a ballot + LDS min finds where the run
 // started); partial sums are combined by a fixed xor butterfly inside each wave and a fixed
 // wave order across waves, so the result is order-deterministic.  A 21 845-lookup run
-// (V=3 at B=65 536) is 683 chunks = 11 window steps at D=16 instead of 683 dependent loads.
+// (V=3 at B=65 536) is 683 chunks = 2 window steps of 512 chunks at D=16 instead of 683 dependent loads;
+// a 370 000-lookup run (the pad id of SASRec's [4096, 200] id blocks) is 90 steps.
 template <class Policy, int G, int NV, bool VEC>
 __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P, const typename Policy::Args args,
                                                                  const unsigned* __restrict__ keys,
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
                                                                  const unsigned* __restrict__ fin, const int max_dim,
                                                                  const int sum_stride, const unsigned n_chunks) {
   using F = Frag<G, NV, VEC>;
-  constexpr int NG = 64 / G;            // lane groups per wave
   constexpr int NGB = 256 / G;          // lane groups per workgroup
+  constexpr int R = 8;                  // chunks per lane group and step (independent loads, fewer barriers)
   constexpr int NA = NV * F::W;
   constexpr int kNone = 1 << 30;
   __shared__ int s_stop[4];
@@ -246,23 +247,42 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
     }
     long long jbase = static_cast<long long>(c) - 1;
     while (true) {
-      const long long j = jbase - gi;
-      const bool valid = j >= 0;
-      const int fl = valid ? flags[j] : 0;
-      const bool stop = !valid || !(fl & kFlagPass);
-      const unsigned long long m = __ballot(stop);
-      if (lane == 0) s_stop[wid] = m ? (__ffsll(static_cast<long long>(m)) - 1) / G + wid * NG : kNone;
+      // lane group gi looks at the R chunks jbase - gi*R - r (r = 0..R-1): a window of NGB * R chunks per step
+      int fl[R];
+      int first_stop = kNone;                              // window distance of the first chunk that ends the walk
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const long long j = jbase - (static_cast<long long>(gi) * R + r);
+        fl[r] = (j >= 0) ? flags[j] : 0;
+      }
+#pragma unroll
+      for (int r = R - 1; r >= 0; --r) {
+        const long long j = jbase - (static_cast<long long>(gi) * R + r);
+        if (j < 0 || !(fl[r] & kFlagPass)) first_stop = gi * R + r;
+      }
+      int wmin = first_stop;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int other = __shfl_xor(wmin, o, 64);
+        wmin = other < wmin ? other : wmin;
+      }
+      if (lane == 0) s_stop[wid] = wmin;
       __syncthreads();
       int t = s_stop[0];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) t = (s_stop[w] < t) ? s_stop[w] : t;   // group holding the run's first chunk
+      for (int w = 1; w < 4; ++w) t = (s_stop[w] < t) ? s_stop[w] : t;   // distance of the chunk where the run started
       F part;
       part.zero();
       float pc = 0.f;
-      if (valid && gi <= t) {
-        const float* src = tail + static_cast<size_t>(j) * sum_stride;
-        part.add_from(src, fd.dim, lane_g);
-        if (Policy::kHasCount) pc = src[max_dim];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int d = gi * R + r;
+        const long long j = jbase - d;
+        if (j >= 0 && d <= t) {
+          const float* src = tail + static_cast<size_t>(j) * sum_stride;
+          part.add_from(src, fd.dim, lane_g);
+          if (Policy::kHasCount) pc += src[max_dim];
+        }
       }
 #pragma unroll
       for (int o = G; o < 64; o <<= 1) {
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
       }
       __syncthreads();
       if (t != kNone) break;
-      jbase -= NGB;
+      jbase -= NGB * R;
     }
     if (gi == 0) Policy::flush(args, fd, key - fd.row_base, acc, cnt, pre, lane_g);
   }

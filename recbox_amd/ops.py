@@ -947,6 +947,48 @@ class _BnStats(object):
         self.running_var = module.running_var if track else None
 
 
+class _LayerNorm(torch.autograd.Function):
+    """F.layer_norm over the last dimension through rbx_layernorm_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _require_cuda(x, "x")
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        rows, dim = x2.shape
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib.rbx_layernorm_fwd(_ptr(x2), rows, dim, _ptr(weight), _ptr(bias), eps, _ptr(mean), _ptr(rstd), _ptr(y),
+                                    _stream()))
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        ctx.shape, ctx.has_bias = shape, bias is not None
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        rows, dim = x2.shape
+        dy2 = dy.reshape(rows, dim).contiguous().float()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        want_p = weight is not None and (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]))
+        dgamma = torch.empty(dim, dtype=torch.float32, device=x2.device) if want_p else None
+        dbeta = torch.empty(dim, dtype=torch.float32, device=x2.device) if want_p else None
+        ws_bytes = lib.rbx_layernorm_bwd_workspace_size(rows, dim) if want_p else 0
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x2.device)
+        check(lib.rbx_layernorm_bwd(_ptr(x2), _ptr(dy2), rows, dim, _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                    _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws_bytes, _stream()))
+        return (dx.view(ctx.shape) if dx is not None else None, dgamma if ctx.needs_input_grad[1] else None,
+                dbeta if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None)
+
+
+def layer_norm(x, module):
+    """``module(x)`` for an nn.LayerNorm over the last dimension."""
+    if len(module.normalized_shape) != 1 or module.normalized_shape[0] != x.shape[-1]:
+        raise NotImplementedError("layer_norm: only normalisation over the last dimension is implemented")
+    return _LayerNorm.apply(x, module.weight, module.bias, float(module.eps))
+
+
 class _Attention(torch.autograd.Function):
     """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
 

@@ -168,12 +168,12 @@ class SASRec(torch.nn.Module):
         keep = (ids != 0).unsqueeze(-1)
         e = e * keep
         for i in range(len(self.attention_layers)):
-            q = self.attention_layernorms[i](e)
+            q = ops.layer_norm(e, self.attention_layernorms[i])
             e = q + self._mha(self.attention_layers[i], q, e)
-            e = self.forward_layernorms[i](e)
+            e = ops.layer_norm(e, self.forward_layernorms[i])
             e = self.forward_layers[i](e)
             e = e * keep
-        return self.last_layernorm(e)
+        return ops.layer_norm(e, self.last_layernorm)
 
     def forward(self, x):
         """sasrec.py:96-107.  The reference embeds seq, pos and neg ([B, 3, L, D]) and multiplies; here only the

@@ -217,6 +217,33 @@ def test_batch_norm_vs_torch(rows, cols, relu):
     assert int(dut.num_batches_tracked) == 2
 
 
+@pytest.mark.parametrize("shape", [(7, 9, 64), (300, 16), (5, 3, 200), (33, 7), (2, 1024)])
+def test_layer_norm_vs_torch(shape):
+    """rbx_layernorm_fwd/bwd == nn.LayerNorm(D, eps=1e-8) of torch CPU fp32 (output, dx, dgamma, dbeta)."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    D = shape[-1]
+    ref = torch.nn.LayerNorm(D, eps=1e-8)
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(D, generator=g) + 0.5)
+        ref.bias.copy_(torch.randn(D, generator=g) * 0.1)
+    dut = torch.nn.LayerNorm(D, eps=1e-8)
+    dut.load_state_dict(ref.state_dict())
+    dut.cuda()
+    x = torch.randn(*shape, generator=g) * 1.5 + 2.0
+    r = torch.randn(*shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    (ref(xr) * r).sum().backward()
+    xc = x.cuda().requires_grad_(True)
+    yc = ops.layer_norm(xc, dut)
+    (yc * r.cuda()).sum().backward()
+    assert_close(yc, ref(x).detach(), 2e-5, "y")
+    assert_close(xc.grad, xr.grad, 1e-4, "dx")
+    rows = x.numel() // D
+    assert_close(dut.weight.grad, ref.weight.grad, 1e-4 * max(1.0, rows ** 0.5 / 4), "dgamma")
+    assert_close(dut.bias.grad, ref.bias.grad, 1e-4 * max(1.0, rows ** 0.5 / 4), "dbeta")
+
+
 def _dssm_feats(Fe, D=16):
     Sp, Sq = Fe.SparseFeature, Fe.SequenceFeature
     uf = [Sp("user_id", 61, D), Sp("gender", 3, D),
