@@ -160,14 +160,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
-// C[i] = sum_z part[z][i] (+ optional accumulate), fixed order
+// C[i] = sum_z part[z][i] in a fixed order.  A workgroup owns 64 outputs; its 4 wavefronts take every 4th slice
+// (4 independent partial sums each, so the loads overlap) and meet in LDS.  The earlier one-thread-per-output
+// loop ran 148 us for 512 slices of a [64, 64] weight gradient: 16 workgroups of dependent loads.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const long long n,
                                                             const int splits, float* __restrict__ out) {
-  const long long stride = static_cast<long long>(gridDim.x) * blockDim.x;
-  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float t = 0.f;
-    for (int z = 0; z < splits; ++z) t += part[z * n + i];
-    out[i] = t;
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  for (long long i0 = static_cast<long long>(blockIdx.x) * 64; i0 < n; i0 += static_cast<long long>(gridDim.x) * 64) {
+    const long long i = i0 + col;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (i < n) {
+      int z = zl;
+      for (; z + 12 < splits; z += 16) {
+        t0 += part[static_cast<long long>(z) * n + i];
+        t1 += part[static_cast<long long>(z + 4) * n + i];
+        t2 += part[static_cast<long long>(z + 8) * n + i];
+        t3 += part[static_cast<long long>(z + 12) * n + i];
+      }
+      for (; z < splits; z += 4) t0 += part[static_cast<long long>(z) * n + i];
+    }
+    red[zl][col] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (zl == 0 && i < n) out[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    __syncthreads();
   }
 }
 
@@ -224,7 +240,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   if (rc != RBX_OK) return rc;
   if (splits > 1) {
     const long long n = static_cast<long long>(M) * N;
-    long long blocks = (n + 255) / 256;
+    long long blocks = (n + 63) / 64;
     if (blocks > kCUs * 8) blocks = kCUs * 8;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, ws, n, splits, C);
     rc = check_launch("splitk_reduce_kernel");
@@ -303,7 +319,7 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     float* part = ws + dw_floats;
     const int rb = static_cast<int>((m + 1023) / 1024);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 63) / 64, rb), dim3(256), 0, s, g, M, n, 1024, part);
-    long long blocks = (n + 255) / 256;
+    long long blocks = (n + 63) / 64;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, part,
                        static_cast<long long>(n), rb, d_db);
     rc = check_launch("bias grad kernels");

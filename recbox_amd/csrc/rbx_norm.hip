@@ -156,18 +156,26 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
 }
 
+// a workgroup owns 64 columns; its 4 wavefronts take every 4th row block and meet in LDS (fixed order)
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, const int nblocks, const int cols,
                                                            float* __restrict__ dbeta, float* __restrict__ dgamma) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f;
-  for (int b = 0; b < nblocks; ++b) {
-    const float* src = partial + (static_cast<long long>(b) * cols + c) * 2;
-    s0 += src[0];
-    s1 += src[1];
+  if (c < cols)
+    for (int b = zl; b < nblocks; b += 4) {
+      const float* src = partial + (static_cast<long long>(b) * cols + c) * 2;
+      s0 += src[0];
+      s1 += src[1];
+    }
+  red[0][zl][threadIdx.x & 63] = s0;
+  red[1][zl][threadIdx.x & 63] = s1;
+  __syncthreads();
+  if (zl == 0 && c < cols) {
+    const int t = threadIdx.x;
+    dbeta[c] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+    dgamma[c] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
   }
-  dbeta[c] = s0;
-  dgamma[c] = s1;
 }
 
 template <bool VEC>
@@ -282,7 +290,7 @@ extern "C" int rbx_batchnorm_bwd(const float* d_x, const float* d_dy, const floa
   const int nb = bn_blocks(rows);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, d_dy, d_y_relu,
                      static_cast<long long>(rows), cols, d_mean, d_rstd, partial);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, partial, nb, cols, d_dbeta, d_dgamma);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, nb, cols, d_dbeta, d_dgamma);
   if (d_dx != nullptr) {
     const bool vec = bn_vec(cols, d_x, d_dy, d_dx);
     const long long total = static_cast<long long>(rows) * cols / (vec ? 4 : 1);
@@ -531,7 +539,7 @@ extern "C" int rbx_layernorm_bwd(const float* d_x, const float* d_dy, int64_t ro
     const int nb = ln_blocks(rows);
     hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3((dim + 63) / 64, nb), dim3(256), 0, s, d_x, d_dy, static_cast<long long>(rows),
                        dim, d_mean, d_rstd, kLnRows, partial);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((dim + 255) / 256), dim3(256), 0, s, partial, nb, dim, d_dbeta, d_dgamma);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, partial, nb, dim, d_dbeta, d_dgamma);
     rc = check_launch("layernorm parameter-gradient kernels");
   }
   return rc;

@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
                                                                  const int sum_stride, const unsigned n_chunks) {
   using F = Frag<G, NV, VEC>;
   constexpr int NGB = 256 / G;          // lane groups per workgroup
-  constexpr int R = 8;                  // chunks per lane group and step (independent loads, fewer barriers)
+  // chunks per lane group and step: a window of ~512 chunks whatever G is (independent loads, few barriers)
+  constexpr int R = (2 * G < 8) ? 8 : ((2 * G > 32) ? 32 : 2 * G);
   constexpr int NA = NV * F::W;
   constexpr int kNone = 1 << 30;
   __shared__ int s_stop[4];
