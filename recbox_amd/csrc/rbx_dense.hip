@@ -23,21 +23,27 @@ namespace rbx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
+#ifndef RBX_GEMM_BK
+#define RBX_GEMM_BK 16
+#endif
+constexpr int BM = 128, BN = 128, BK = RBX_GEMM_BK;
+constexpr int kXcds = 8;         // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 constexpr int LDT = BM + 4;     // LDS row stride (floats): keeps b128 stores aligned, spreads k rows over banks
 
-// Load one 128 x 16 operand tile into registers (8 floats per thread).
+// Load one 128 x BK operand tile into registers (BK/2 floats per thread).
 //   KCONTIG: element (r, k) at base[r * ld + k]   -> thread reads float4 along k
 //   else   : element (r, k) at base[k * ld + r]   -> thread reads float4 along r
+constexpr int KT = BK / 4;            // threads along k of a k-contiguous tile
+constexpr int NP = BK / 8;            // float4 loads per thread and operand
 template <bool KCONTIG>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, long long ld, int r0, int k0, int R, int K,
-                                          bool vec_ok, float (&reg)[8]) {
+                                          bool vec_ok, float (&reg)[4 * NP]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < NP; ++p) {
     if constexpr (KCONTIG) {
-      const int r = r0 + (t >> 2) + 64 * p;
-      const int k = k0 + (t & 3) * 4;
+      const int r = r0 + t / KT + (256 / KT) * p;
+      const int k = k0 + (t % KT) * 4;
       const float* src = base + static_cast<long long>(r) * ld + k;
       if (vec_ok && r < R && k + 3 < K) {
         const float4 v = *reinterpret_cast<const float4*>(src);
@@ -62,13 +68,13 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long l
 }
 
 template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(float* __restrict__ tile, const float (&reg)[8]) {
+__device__ __forceinline__ void store_tile(float* __restrict__ tile, const float (&reg)[4 * NP]) {
   const int t = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < NP; ++p) {
     if constexpr (KCONTIG) {
-      const int r = (t >> 2) + 64 * p;
-      const int k = (t & 3) * 4;
+      const int r = t / KT + (256 / KT) * p;
+      const int k = (t % KT) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) tile[(k + j) * LDT + r] = reg[p * 4 + j];
     } else {
@@ -87,10 +93,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        float* __restrict__ C, const long long ldc, const int M,
                                                        const int N, const int K, const int k_per_split,
                                                        const float* __restrict__ bias, const int act,
-                                                       const bool vec_a, const bool vec_b) {
+                                                       const bool vec_a, const bool vec_b, const int tiles_m,
+                                                       const int tiles_n) {
   __shared__ float As[2][BK * LDT];
   __shared__ float Bs[2][BK * LDT];
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so launch
+  // index L runs on XCD L % 8.  Tiles are numbered n-fastest and XCD x works through ONE contiguous range of them:
+  // the workgroups that share an L2 then share the A row block (all n tiles of an m tile back to back) and walk B in
+  // the same order, instead of every XCD fetching every A tile.
+  int tile;
+  {
+    const int total = tiles_m * tiles_n, L = blockIdx.x;
+    const int xcd = L % kXcds, slot = L / kXcds;
+    const int q = total / kXcds, rem = total % kXcds;
+    tile = xcd * q + (xcd < rem ? xcd : rem) + slot;
+  }
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int kbeg = blockIdx.z * k_per_split;
   const int kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
   if (gridDim.z > 1) C += static_cast<long long>(blockIdx.z) * M * ldc;
@@ -106,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float ra[8], rb[8];
+  float ra[4 * NP], rb[4 * NP];
   load_tile<A_KCONTIG>(A, lda, m0, kbeg, M, kend, vec_a, ra);
   load_tile<B_KCONTIG>(B, ldb, n0, kbeg, N, kend, vec_b, rb);
   store_tile<A_KCONTIG>(As[0], ra);
@@ -155,6 +173,74 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
           if (act == 1 && gridDim.z == 1) v = v > 0.f ? v : 0.f;
           C[static_cast<long long>(row) * ldc + col] = v;
         }
+      }
+    }
+  }
+}
+
+// Narrow companion of gemm_f32_kernel for the last 32 * NT (<= 64) output columns: N = 400 is 3 full 128-column
+// tiles plus 16 columns, and a fourth full tile would spend 22% of the MFMA time on padding.  The four wavefronts
+// stack along M (32 rows each) and every wavefront computes NT 32x32 MFMA tiles; same operand staging.
+template <bool A_KCONTIG, bool B_KCONTIG, int NT>
+__global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __restrict__ A, const long long lda,
+                                                              const float* __restrict__ B, const long long ldb,
+                                                              float* __restrict__ C, const long long ldc, const int M,
+                                                              const int N, const int K, const int n0,
+                                                              const float* __restrict__ bias, const int act,
+                                                              const bool vec_a, const bool vec_b) {
+  __shared__ float As[2][BK * LDT];
+  __shared__ float Bs[2][BK * LDT];
+  const int m0 = blockIdx.x * BM;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid * 32;
+  const int li = lane & 31, lk = lane >> 5;
+  const int nlim = (n0 + 32 * NT < N) ? n0 + 32 * NT : N;      // B rows beyond the narrow tile are not fetched
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float ra[4 * NP], rb[4 * NP];
+  load_tile<A_KCONTIG>(A, lda, m0, 0, M, K, vec_a, ra);
+  load_tile<B_KCONTIG>(B, ldb, n0, 0, nlim, K, vec_b, rb);
+  store_tile<A_KCONTIG>(As[0], ra);
+  store_tile<B_KCONTIG>(Bs[0], rb);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool more = k0 + BK < K;
+    if (more) {
+      load_tile<A_KCONTIG>(A, lda, m0, k0 + BK, M, K, vec_a, ra);
+      load_tile<B_KCONTIG>(B, ldb, n0, k0 + BK, nlim, K, vec_b, rb);
+    }
+    const float* as = As[cur];
+    const float* bs = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = as[(kk + lk) * LDT + wm + li];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[(kk + lk) * LDT + j * 32 + li], acc[j], 0, 0, 0);
+    }
+    if (more) {
+      store_tile<A_KCONTIG>(As[cur ^ 1], ra);
+      store_tile<B_KCONTIG>(Bs[cur ^ 1], rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + j * 32 + li;
+    if (col >= N) continue;
+    const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (row < M) {
+        float v = acc[j][r] + bv;
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        C[static_cast<long long>(row) * ldc + col] = v;
       }
     }
   }
@@ -234,8 +320,22 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   kps = (kps + BK - 1) / BK * BK;
   splits = (K + kps - 1) / kps;
   float* dst = (splits > 1) ? ws : C;
-  hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn, tm, splits), dim3(256), 0, s, A, lda, B, ldb, dst,
-                     (splits > 1) ? static_cast<long long>(N) : ldc, M, N, K, kps, bias, act, vec_ok(A, lda), vec_ok(B, ldb));
+  // the last partial column tile: when it is at most 64 columns wide (and K is not split) it goes to the narrow kernel
+  const int tail = N % BN;
+  const int tn_full = (splits == 1 && tail > 0 && tail <= 64) ? N / BN : tn;
+  if (tn_full > 0)
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm, 1, splits), dim3(256), 0, s, A, lda, B, ldb, dst,
+                       (splits > 1) ? static_cast<long long>(N) : ldc, M, N, K, kps, bias, act, vec_ok(A, lda),
+                       vec_ok(B, ldb), tm, tn_full);
+  if (tn_full < tn) {
+    const int n0 = tn_full * BN;
+    if (tail <= 32)
+      hipLaunchKernelGGL((gemm_f32_narrow_kernel<AK, BK_, 1>), dim3(tm), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, n0,
+                         bias, act, vec_ok(A, lda), vec_ok(B, ldb));
+    else
+      hipLaunchKernelGGL((gemm_f32_narrow_kernel<AK, BK_, 2>), dim3(tm), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, n0,
+                         bias, act, vec_ok(A, lda), vec_ok(B, ldb));
+  }
   int rc = check_launch("gemm_f32_kernel");
   if (rc != RBX_OK) return rc;
   if (splits > 1) {
