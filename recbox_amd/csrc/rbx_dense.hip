@@ -48,6 +48,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long l
       if (vec_ok && r < R && k + 3 < K) {
         const float4 v = *reinterpret_cast<const float4*>(src);
         reg[p * 4 + 0] = v.x; reg[p * 4 + 1] = v.y; reg[p * 4 + 2] = v.z; reg[p * 4 + 3] = v.w;
+      } else if (r < R && k + 3 < K) {              // unaligned rows (K = 1677): four plain loads, no per-element tests
+        reg[p * 4 + 0] = src[0]; reg[p * 4 + 1] = src[1]; reg[p * 4 + 2] = src[2]; reg[p * 4 + 3] = src[3];
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) reg[p * 4 + j] = (r < R && k + j < K) ? src[j] : 0.f;
@@ -59,6 +61,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, long l
       if (vec_ok && k < K && r + 3 < R) {
         const float4 v = *reinterpret_cast<const float4*>(src);
         reg[p * 4 + 0] = v.x; reg[p * 4 + 1] = v.y; reg[p * 4 + 2] = v.z; reg[p * 4 + 3] = v.w;
+      } else if (k < K && r + 3 < R) {
+        reg[p * 4 + 0] = src[0]; reg[p * 4 + 1] = src[1]; reg[p * 4 + 2] = src[2]; reg[p * 4 + 3] = src[3];
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) reg[p * 4 + j] = (k < K && r + j < R) ? src[j] : 0.f;
