@@ -125,11 +125,13 @@ int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
  * ranking/pytorch/layers/interactions/inner_product.py:40-56,
  * third_party/rechub/basic/layers.py:286-292.
  * mode 0: product_sum -> [B,1]; 1: bi_interaction -> [B,D];
- * mode 2: inner_product -> [B,F(F-1)/2]; 3: elementwise_product -> [B,F(F-1)/2,D]. */
-int rbx_interaction_fwd(const float* d_emb, int64_t batch, int32_t n_fields, int32_t dim,
+ * mode 2: inner_product -> [B,F(F-1)/2]; 3: elementwise_product -> [B,F(F-1)/2,D].
+ * emb_stride_b / demb_stride_b: floats between consecutive samples (>= F*D): the [F, D] block of a sample may
+ * be the leading columns of a wider activation row (the flattened embedding layout of rechub's DeepFM). */
+int rbx_interaction_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch, int32_t n_fields, int32_t dim,
                         int32_t mode, float* d_out, void* stream);
-int rbx_interaction_bwd(const float* d_emb, const float* d_dout, int64_t batch, int32_t n_fields,
-                        int32_t dim, int32_t mode, float* d_demb, void* stream);
+int rbx_interaction_bwd(const float* d_emb, int64_t emb_stride_b, const float* d_dout, int64_t batch, int32_t n_fields,
+                        int32_t dim, int32_t mode, float* d_demb, int64_t demb_stride_b, void* stream);
 
 /* ---- fused FM model body: gather + LR + second-order interaction, [B,F,D] never stored ----
  * Replaces the op sequence feature_embedding.py:188-214 -> logistic_regression.py:30-35 ->

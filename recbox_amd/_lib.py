@@ -57,8 +57,8 @@ SIGNATURES = {
     "rbx_embed_bwd_workspace_size": (_sz, [_FP, _i32, _i64]),
     "rbx_embed_sort": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P, _P]),
     "rbx_embed_bwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _P, _i32, _P, _sz, _P]),
-    "rbx_interaction_fwd": (ctypes.c_int, [_P, _i64, _i32, _i32, _i32, _P, _P]),
-    "rbx_interaction_bwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _i32, _P, _P]),
+    "rbx_interaction_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _i32, _i32, _P, _P]),
+    "rbx_interaction_bwd": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _i32, _P, _i64, _P]),
     "rbx_fm_fwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _i32, _i32, _i32, _P, _i64, _P, _P, _P, _P]),
     "rbx_fm_extra_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _i32, _P, _i64, _P, _P]),
     "rbx_route_workspace_size": (_sz, [_i64, _i32]),

@@ -19,13 +19,13 @@
 namespace rbx {
 
 template <int G, int NV, bool VEC>
-__global__ __launch_bounds__(256) void fm_fwd_kernel(const float* __restrict__ emb, const long long B, const int F,
-                                                     const int D, const int mode, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void fm_fwd_kernel(const float* __restrict__ emb, const long long sb, const long long B,
+                                                     const int F, const int D, const int mode, float* __restrict__ out) {
   constexpr int W = VEC ? 4 : 1;
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
   for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
-    const float* base = emb + b * F * D;
+    const float* base = emb + b * sb;
     float s[NV * W], q[NV * W];
 #pragma unroll
     for (int i = 0; i < NV * W; ++i) s[i] = q[i] = 0.f;
@@ -66,15 +66,16 @@ __global__ __launch_bounds__(256) void fm_fwd_kernel(const float* __restrict__ e
 }
 
 template <int G, int NV, bool VEC>
-__global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
-                                                     const long long B, const int F, const int D, const int mode,
-                                                     float* __restrict__ demb) {
+__global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ emb, const long long sb,
+                                                     const float* __restrict__ dout, const long long B, const int F,
+                                                     const int D, const int mode, float* __restrict__ demb,
+                                                     const long long dsb) {
   constexpr int W = VEC ? 4 : 1;
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
   for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
-    const float* base = emb + b * F * D;
-    float* dbase = demb + b * F * D;
+    const float* base = emb + b * sb;
+    float* dbase = demb + b * dsb;
     float s[NV * W], g[NV * W];
 #pragma unroll
     for (int i = 0; i < NV * W; ++i) s[i] = 0.f;
@@ -119,12 +120,12 @@ __global__ __launch_bounds__(256) void fm_bwd_kernel(const float* __restrict__ e
 __device__ __forceinline__ int pair_index(int i, int j, int F) { return i * F - (i * (i + 1)) / 2 + (j - i - 1); }
 
 // one wavefront per sample; the sample's [F, D] block sits in LDS
-__global__ __launch_bounds__(64) void pair_fwd_kernel(const float* __restrict__ emb, const int F, const int D,
-                                                      const int mode, float* __restrict__ out) {
+__global__ __launch_bounds__(64) void pair_fwd_kernel(const float* __restrict__ emb, const long long sb, const int F,
+                                                      const int D, const int mode, float* __restrict__ out) {
   extern __shared__ float se[];
   const long long b = blockIdx.x;
   const int FD = F * D, P = F * (F - 1) / 2;
-  for (int i = threadIdx.x; i < FD; i += 64) se[i] = emb[b * FD + i];
+  for (int i = threadIdx.x; i < FD; i += 64) se[i] = emb[b * sb + i];
   __syncthreads();
   if (mode == 2) {
     for (int i = 0; i < F - 1; ++i) {
@@ -146,13 +147,13 @@ __global__ __launch_bounds__(64) void pair_fwd_kernel(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(64) void pair_bwd_kernel(const float* __restrict__ emb, const float* __restrict__ dout,
-                                                      const int F, const int D, const int mode,
-                                                      float* __restrict__ demb) {
+__global__ __launch_bounds__(64) void pair_bwd_kernel(const float* __restrict__ emb, const long long sb,
+                                                      const float* __restrict__ dout, const int F, const int D,
+                                                      const int mode, float* __restrict__ demb, const long long dsb) {
   extern __shared__ float se[];
   const long long b = blockIdx.x;
   const int FD = F * D, P = F * (F - 1) / 2;
-  for (int i = threadIdx.x; i < FD; i += 64) se[i] = emb[b * FD + i];
+  for (int i = threadIdx.x; i < FD; i += 64) se[i] = emb[b * sb + i];
   __syncthreads();
   for (int t = threadIdx.x; t < FD; t += 64) {
     const int i = t / D, d = t % D;
@@ -163,74 +164,77 @@ __global__ __launch_bounds__(64) void pair_bwd_kernel(const float* __restrict__ 
       const float g = (mode == 2) ? dout[b * P + p] : dout[(b * P + p) * D + d];
       acc += g * se[j * D + d];
     }
-    demb[b * FD + t] = acc;
+    demb[b * dsb + t] = acc;
   }
 }
 
 template <int G, int NV, bool VEC>
 static int launch_fm(bool bwd, const float* emb, const float* dout, int64_t B, int F, int D, int mode, float* out,
-                     hipStream_t s) {
+                     long long sb, long long dsb, hipStream_t s) {
   const int gpb = 256 / G;
   long long blocks = (B + gpb - 1) / gpb;
   if (blocks > kCUs * 8) blocks = kCUs * 8;
   if (bwd)
-    hipLaunchKernelGGL((fm_bwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, emb, dout,
-                       static_cast<long long>(B), F, D, mode, out);
+    hipLaunchKernelGGL((fm_bwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, emb, sb, dout,
+                       static_cast<long long>(B), F, D, mode, out, dsb);
   else
-    hipLaunchKernelGGL((fm_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, emb,
+    hipLaunchKernelGGL((fm_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, emb, sb,
                        static_cast<long long>(B), F, D, mode, out);
   return check_launch("fm kernel");
 }
 
 template <bool VEC>
 static int dispatch_fm(bool bwd, const float* emb, const float* dout, int64_t B, int F, int D, int mode, float* out,
-                       hipStream_t s) {
+                       long long sb, long long dsb, hipStream_t s) {
   const int units = VEC ? D / 4 : D;
   switch (pow2_ceil(units)) {
-    case 1: return launch_fm<1, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
-    case 2: return launch_fm<2, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
-    case 4: return launch_fm<4, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
-    case 8: return launch_fm<8, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
-    case 16: return launch_fm<16, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
-    case 32: return launch_fm<32, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
-    case 64: return launch_fm<64, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
-    case 128: return launch_fm<64, 2, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
-    case 256: return launch_fm<64, 4, VEC>(bwd, emb, dout, B, F, D, mode, out, s);
+    case 1: return launch_fm<1, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
+    case 2: return launch_fm<2, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
+    case 4: return launch_fm<4, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
+    case 8: return launch_fm<8, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
+    case 16: return launch_fm<16, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
+    case 32: return launch_fm<32, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
+    case 64: return launch_fm<64, 1, VEC>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
+    case 128: return launch_fm<64, 2, VEC>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
+    case 256: return launch_fm<64, 4, VEC>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
     default: return fail(RBX_ERR_UNSUPPORTED, "interaction dim too large");
   }
 }
 
-static int run_interaction(bool bwd, const float* emb, const float* dout, int64_t B, int F, int D, int mode, float* out,
-                           void* stream) {
+static int run_interaction(bool bwd, const float* emb, long long sb, const float* dout, int64_t B, int F, int D, int mode,
+                           float* out, long long dsb, void* stream) {
   if (emb == nullptr || out == nullptr || (bwd && dout == nullptr)) return fail(RBX_ERR_INVALID, "NULL tensor");
   if (B < 0 || F <= 0 || D <= 0) return fail(RBX_ERR_INVALID, "bad shape B=%lld F=%d D=%d", (long long)B, F, D);
   if (mode < 0 || mode > 3) return fail(RBX_ERR_INVALID, "InnerProductInteraction output mode %d is not supported", mode);
   if (B == 0) return RBX_OK;
+  if (sb < static_cast<long long>(F) * D || (bwd && dsb < static_cast<long long>(F) * D))
+    return fail(RBX_ERR_INVALID, "interaction: batch stride smaller than n_fields * dim");
   hipStream_t s = as_stream(stream);
   if (mode <= 1) {
     const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(emb) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    return vec ? dispatch_fm<true>(bwd, emb, dout, B, F, D, mode, out, s)
-               : dispatch_fm<false>(bwd, emb, dout, B, F, D, mode, out, s);
+                     ((reinterpret_cast<uintptr_t>(out) & 15) == 0) && sb % 4 == 0 && (!bwd || dsb % 4 == 0);
+    return vec ? dispatch_fm<true>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s)
+               : dispatch_fm<false>(bwd, emb, dout, B, F, D, mode, out, sb, dsb, s);
   }
   const size_t lds = static_cast<size_t>(F) * D * sizeof(float);
   if (lds > 64 * 1024) return fail(RBX_ERR_UNSUPPORTED, "F*D=%d too large for the pairwise modes", F * D);
   if (F < 2) return RBX_OK;
   if (bwd)
-    hipLaunchKernelGGL(pair_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), lds, s, emb, dout, F, D, mode, out);
+    hipLaunchKernelGGL(pair_bwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), lds, s, emb, sb, dout, F, D, mode, out, dsb);
   else
-    hipLaunchKernelGGL(pair_fwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), lds, s, emb, F, D, mode, out);
+    hipLaunchKernelGGL(pair_fwd_kernel, dim3(static_cast<unsigned>(B)), dim3(64), lds, s, emb, sb, F, D, mode, out);
   return check_launch("pair kernel");
 }
 
 }  // namespace rbx
 
-extern "C" int rbx_interaction_fwd(const float* d_emb, int64_t batch, int32_t n_fields, int32_t dim, int32_t mode,
-                                   float* d_out, void* stream) {
-  return rbx::run_interaction(false, d_emb, nullptr, batch, n_fields, dim, mode, d_out, stream);
+extern "C" int rbx_interaction_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch, int32_t n_fields, int32_t dim,
+                                   int32_t mode, float* d_out, void* stream) {
+  return rbx::run_interaction(false, d_emb, emb_stride_b, nullptr, batch, n_fields, dim, mode, d_out, 0, stream);
 }
 
-extern "C" int rbx_interaction_bwd(const float* d_emb, const float* d_dout, int64_t batch, int32_t n_fields,
-                                   int32_t dim, int32_t mode, float* d_demb, void* stream) {
-  return rbx::run_interaction(true, d_emb, d_dout, batch, n_fields, dim, mode, d_demb, stream);
+extern "C" int rbx_interaction_bwd(const float* d_emb, int64_t emb_stride_b, const float* d_dout, int64_t batch,
+                                   int32_t n_fields, int32_t dim, int32_t mode, float* d_demb, int64_t demb_stride_b,
+                                   void* stream) {
+  return rbx::run_interaction(true, d_emb, emb_stride_b, d_dout, batch, n_fields, dim, mode, d_demb, demb_stride_b, stream);
 }

@@ -274,19 +274,25 @@ def embed_lookup(plan, inputs, params, pad_rows=False):
 
 
 class _Interaction(torch.autograd.Function):
+    """InnerProductInteraction on [B, F, D]; the [F, D] block of a sample may be the leading columns of a wider row
+    (batch stride > F * D): it is read, and its gradient written, in place."""
+
     @staticmethod
     def forward(ctx, emb, mode):
         _require_cuda(emb, "feature_emb")
         if emb.dim() != 3:
             raise ValueError("feature_emb must be [B, F, D], got %s" % (tuple(emb.shape),))
-        emb = emb.contiguous().float()
         B, F, D = emb.shape
+        if not (emb.dtype == torch.float32 and emb.stride(2) == 1 and emb.stride(1) == D and
+                (B <= 1 or emb.stride(0) >= F * D)):
+            emb = emb.contiguous().float()
+        sb = emb.stride(0) if B > 1 else F * D
         P = F * (F - 1) // 2
         shape = {0: (B, 1), 1: (B, D), 2: (B, P), 3: (B, P, D)}[mode]
         out = torch.empty(shape, dtype=torch.float32, device=emb.device)
-        check(lib.rbx_interaction_fwd(_ptr(emb), B, F, D, mode, _ptr(out), _stream()))
+        check(lib.rbx_interaction_fwd(_ptr(emb), sb, B, F, D, mode, _ptr(out), _stream()))
         ctx.save_for_backward(emb)
-        ctx.mode = mode
+        ctx.mode, ctx.sb = mode, sb
         return out
 
     @staticmethod
@@ -294,10 +300,10 @@ class _Interaction(torch.autograd.Function):
         (emb,) = ctx.saved_tensors
         B, F, D = emb.shape
         dout = dout.contiguous().float()
-        demb = torch.empty_like(emb)
+        demb = torch.empty((B, F, D), dtype=torch.float32, device=emb.device)
         if F < 2 and ctx.mode >= 2:
             demb.zero_()
-        check(lib.rbx_interaction_bwd(_ptr(emb), _ptr(dout), B, F, D, ctx.mode, _ptr(demb), _stream()))
+        check(lib.rbx_interaction_bwd(_ptr(emb), ctx.sb, _ptr(dout), B, F, D, ctx.mode, _ptr(demb), F * D, _stream()))
         return demb, None
 
 

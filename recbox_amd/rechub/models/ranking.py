@@ -2,6 +2,7 @@
 /root/reference/recbox/third_party/rechub/models/ranking/deepfm.py:14-42)."""
 import torch
 
+from ..basic.features import DenseFeature, SparseFeature
 from ..basic.layers import FM, LR, MLP, EmbeddingLayer
 
 
@@ -17,10 +18,27 @@ class DeepFM(torch.nn.Module):
         self.embedding = EmbeddingLayer(deep_features + fm_features)
         self.mlp = MLP(self.deep_dims, **mlp_params)
 
+    def _shared_gather(self):
+        """True when the deep input is [the FM embeddings flattened | dense values]: the sparse features of
+        ``deep_features`` are exactly ``fm_features`` in the same order (how deepfm.py is used with Criteo)."""
+        sparse = [f for f in self.deep_features if not isinstance(f, DenseFeature)]
+        return (len(sparse) == len(self.fm_features) and all(a is b for a, b in zip(sparse, self.fm_features))
+                and len(set(f.embed_dim for f in self.fm_features)) == 1
+                and all(isinstance(f, SparseFeature) for f in self.fm_features))
+
     def forward(self, x):
-        input_deep = self.embedding(x, self.deep_features, squeeze_dim=True)     # [B, deep_dims]
-        input_fm = self.embedding(x, self.fm_features, squeeze_dim=False)        # [B, F, D]
-        y_linear = self.linear(input_fm.flatten(start_dim=1))
+        if self._shared_gather():
+            # deepfm.py:34-35 looks every table up twice (deep input, FM input) and autograd then adds two dense
+            # [V, D] gradients per table.  Here ONE gather produces [B, F*D | dense] (rows padded to 16 bytes); the
+            # FM part and the LR part read its leading F*D columns in place, the tower reads the whole row.
+            input_deep = self.embedding(x, self.deep_features, squeeze_dim=True)
+            flat_fm = input_deep[:, :self.fm_dims]
+            input_fm = flat_fm.view(flat_fm.shape[0], len(self.fm_features), self.fm_features[0].embed_dim)
+            y_linear = self.linear(flat_fm)
+        else:
+            input_deep = self.embedding(x, self.deep_features, squeeze_dim=True)     # [B, deep_dims]
+            input_fm = self.embedding(x, self.fm_features, squeeze_dim=False)        # [B, F, D]
+            y_linear = self.linear(input_fm.flatten(start_dim=1))
         y_fm = self.fm(input_fm)
         y_deep = self.mlp(input_deep)
         y = y_linear + y_fm + y_deep

@@ -125,7 +125,7 @@ def test_bad_descriptors_return_error_codes():
     assert L.lib.rbx_embed_fwd(arr, 1, 4, out.data_ptr(), 4, None, None, None) == L.RBX_ERR_UNSUPPORTED
     with pytest.raises(NotImplementedError):
         L.check(L.RBX_ERR_UNSUPPORTED)
-    assert L.lib.rbx_interaction_fwd(out.data_ptr(), 4, 2, 2, 9, out.data_ptr(), None) == L.RBX_ERR_INVALID
+    assert L.lib.rbx_interaction_fwd(out.data_ptr(), 4, 4, 2, 2, 9, out.data_ptr(), None) == L.RBX_ERR_INVALID
     assert L.lib.rbx_attn_fwd(out.data_ptr(), out.data_ptr(), out.data_ptr(), None, 1, 2, 2, 48, 1.0, 0, 0.0,
                               out.data_ptr(), None, None, None) == L.RBX_ERR_UNSUPPORTED
 
