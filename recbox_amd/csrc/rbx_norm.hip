@@ -61,20 +61,29 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// one thread per column: merge the row blocks in order, finish mean / rstd, update the running statistics
+// a workgroup owns 64 columns: its 4 wavefronts merge every 4th row block (in order), the four results are merged
+// in a fixed order; then mean / rstd and the running statistics
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ partial, const int nblocks, const int cols,
                                                              const float eps, const float momentum,
                                                              float* __restrict__ running_mean,
                                                              float* __restrict__ running_var, float* __restrict__ mean,
                                                              float* __restrict__ rstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ Welford red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
   Welford t = {0.f, 0.f, 0.f};
-  for (int b = 0; b < nblocks; ++b) {
-    const float* src = partial + (static_cast<long long>(b) * cols + c) * 3;
-    const Welford o = {src[0], src[1], src[2]};
-    t.merge(o);
-  }
+  if (c < cols)
+    for (int b = zl; b < nblocks; b += 4) {
+      const float* src = partial + (static_cast<long long>(b) * cols + c) * 3;
+      const Welford o = {src[0], src[1], src[2]};
+      t.merge(o);
+    }
+  red[zl][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (zl != 0 || c >= cols) return;
+  t = red[0][threadIdx.x];
+  t.merge(red[1][threadIdx.x]);
+  t.merge(red[2][threadIdx.x]);
+  t.merge(red[3][threadIdx.x]);
   const float var = t.m2 / t.n;                                  // biased: what normalises the batch
   mean[c] = t.mean;
   rstd[c] = 1.0f / sqrtf(var + eps);
@@ -254,7 +263,7 @@ extern "C" int rbx_batchnorm_fwd(const float* d_x, int64_t rows, int32_t cols, c
     const int nb = bn_blocks(rows);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, static_cast<long long>(rows),
                        cols, partial);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cb), dim3(256), 0, s, partial, nb, cols, eps, momentum, d_running_mean,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, nb, cols, eps, momentum, d_running_mean,
                        d_running_var, d_mean, d_rstd);
   } else {
     if (!d_running_mean || !d_running_var) return fail(RBX_ERR_INVALID, "batchnorm: eval mode needs the running statistics");
