@@ -18,5 +18,7 @@ python profiles/topk.py $(find $out/prof_sharded -name "*.db" | head -1) 64 > $o
 timeout 500 python profiles/ubench/kernels_bench.py > $out/kernels_bench.txt 2>/dev/null
 (cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $out/prof_kb -o b -- python /root/repo/profiles/ubench/kernels_bench.py > $out/prof_kb.log 2>&1)
 python profiles/topk.py $(find $out/prof_kb -name "*.db" | head -1) > $out/kernels_bench_kernel_stats.txt
+timeout 600 python profiles/ubench/models_bench.py > $out/models_bench.txt 2>/dev/null
+timeout 300 python profiles/ubench/rocblas_compare.py > $out/rocblas_compare.txt 2>/dev/null
 rm -rf $out/prof_fused $out/prof_sharded $out/prof_kb
 ls -la $out
