@@ -20,6 +20,8 @@ _DTYPE_CODE = {torch.int32: _lib.RBX_I32, torch.int64: _lib.RBX_I64,
 
 class config(object):
     """Run-time switches of the host layer."""
+    # fused FM: enqueue the id sort of the backward (side stream) ahead of the forward kernel so that they overlap
+    sort_before_forward = os.environ.get("RECBOX_AMD_SORT_FIRST", "1") != "0"
     # The reference raises IndexError for an out-of-range id (nn.Embedding on CPU).
     # The kernels flag it on device; checking the flag costs one sync per call.
     check_ids = os.environ.get("RECBOX_AMD_CHECK_IDS", "1") != "0"
@@ -402,6 +404,22 @@ class _FmFused(torch.autograd.Function):
         status = torch.zeros(1, dtype=torch.int32, device=dev) if config.check_ids else None
         ea = emb_plan.arr if emb_plan is not None else None
         la = lr_plan.arr if lr_plan is not None else None
+        # The sort of the backward depends on the ids only: it is put on the side stream BEFORE the forward kernel is
+        # enqueued, so the two run side by side (enqueued after it, the side stream would first wait for the forward).
+        sort = None
+        if train and B > 0 and config.sort_before_forward:
+            if emb_plan is not None:
+                emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
+            if lr_plan is not None:
+                lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
+            ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
+            if ws_bytes > 0:
+                sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_fm_sort(
+                    ea, la, lead.n, B, _ptr(ws), ws_bytes, None, st))
+            if emb_plan is not None:
+                emb_plan.bind_params(emb_params)
+            if lr_plan is not None:
+                lr_plan.bind_params(lr_params)
         check(_timed(("fm_fwd", lead.n, D, B),
                      lambda: lib.rbx_fm_fwd(ea, la, lead.n, B, _ptr(bias), _ptr(extra), n_extra, x_stride, x_lr,
                                             _ptr(extra_index), x_rows, _ptr(logit), _ptr(ssum), _ptr(status),
@@ -409,8 +427,8 @@ class _FmFused(torch.autograd.Function):
         _check_status(status)
         ctx.state = (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias, has_extra,
                      extra_index)
-        ctx.sort = None
-        if train and B > 0:
+        ctx.sort = sort
+        if train and B > 0 and not config.sort_before_forward:
             if emb_plan is not None:
                 emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
             if lr_plan is not None:
