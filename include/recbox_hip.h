@@ -288,6 +288,16 @@ int rbx_penalize_members(const int64_t* d_candidates, int64_t rows, int32_t k, c
 int rbx_membership(const int64_t* d_candidates, int64_t rows, int32_t k, const int64_t* d_query,
                    const int64_t* d_offsets, const int64_t* d_items, uint8_t* d_flags, void* stream);
 
+/* ---- cross layers (ranking/pytorch/layers/interactions/cross_net.py:22-59).
+ * out = xi + x0 * h + bias:  CrossNetV2: h = Linear_i(xi) [rows, dim] (h_cols == dim, bias NULL);
+ * CrossNet: h = xi w_i [rows, 1] (h_cols == 1) and bias[dim].  The Linear itself is rbx_linear_fwd.
+ * Backward of the element-wise tail: d_dx0 = dout * h (NULL skips it), d_dh = dout * x0 (summed over the row when
+ * h_cols == 1); d(xi) is dout itself and d(bias) its column sum. */
+int rbx_cross_fwd(const float* d_x0, const float* d_xi, const float* d_h, const float* d_bias, int64_t rows, int32_t dim,
+                  int32_t h_cols, float* d_out, void* stream);
+int rbx_cross_bwd(const float* d_x0, const float* d_h, const float* d_dout, int64_t rows, int32_t dim, int32_t h_cols,
+                  float* d_dx0, float* d_dh, void* stream);
+
 /* ---- dense tower: y = act(x W^T + b) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------
  * core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58,
  * third_party/rechub/basic/layers.py:255-263.  x[m,k] with row stride x_stride >= k floats (a column block of

@@ -531,6 +531,25 @@ def gen_retrieval_metrics(recbox, U=37, I=640, D=16):
                     "metrics": np.array(metrics)}})
 
 
+def gen_cross_net(fuxictr, B=7, dim=24, layers=3):
+    """CrossNet / CrossNetV2 / CrossInteraction of the live reference (cross_net.py:22-59)."""
+    import fuxictr.pytorch.layers as FL
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, dim, generator=g)
+    R = torch.randn(B, dim, generator=g)
+    groups = {"in": {"x": x, "R": R}}
+    for name, cls in (("v1", FL.CrossNet), ("v2", FL.CrossNetV2)):
+        net = cls(dim, layers)
+        reinit(net, std=0.2, seed=3)
+        xi = x.clone().requires_grad_(True)
+        out = net(xi)
+        (out * R).sum().backward()
+        groups["p_" + name] = net.state_dict()
+        groups["out_" + name] = {"y": out, "dx": xi.grad}
+        groups["g_" + name] = grads_of(net)
+    save("cross_net", **groups)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -553,6 +572,7 @@ def main():
     gen_target_attention_and_listwise_losses(recbox, fuxictr)
     gen_matching_loader(recbox)
     gen_retrieval_metrics(recbox)
+    gen_cross_net(fuxictr)
 
 
 if __name__ == "__main__":

@@ -172,3 +172,108 @@ extern "C" int rbx_pairdot_bwd(const float* d_u, const float* d_v, const float* 
 #undef CALL
   return check_launch("pairdot_bwd_kernel");
 }
+
+// ---- cross layers: X_{i+1} = X_i + X_0 * h (+ bias) ------------------------------------------
+// ranking/pytorch/layers/interactions/cross_net.py:48-59 (CrossNetV2: h = Linear_i(X_i), [B, dim]) and
+// :22-46 (CrossNet: h = X_i w_i, [B, 1], plus a bias vector).  The Linear is the fp32 MFMA GEMM; this is the
+// element-wise tail fused into one pass each way (the reference runs mul, add (, add) and their three backward
+// kernels).  h_cols == 1 broadcasts h over the row.  HBM-bound streaming: 3 reads + 1 write forward.
+namespace rbx {
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void cross_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ xi,
+                                                        const float* __restrict__ h, const float* __restrict__ bias,
+                                                        const long long rows, const int dim, const int h_cols,
+                                                        float* __restrict__ out) {
+  constexpr int W = VEC ? 4 : 1;
+  const long long total = rows * dim / W;
+  const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += step) {
+    const long long e = i * W;
+    const long long r = e / dim;
+    const int c = static_cast<int>(e - r * dim);
+    float a[W], b[W], hv[W], o[W];
+    if constexpr (VEC) {
+      const float4 t0 = *reinterpret_cast<const float4*>(x0 + e);
+      const float4 t1 = *reinterpret_cast<const float4*>(xi + e);
+      a[0] = t0.x; a[1] = t0.y; a[2] = t0.z; a[3] = t0.w;
+      b[0] = t1.x; b[1] = t1.y; b[2] = t1.z; b[3] = t1.w;
+      if (h_cols == 1) {
+        hv[0] = hv[1] = hv[2] = hv[3] = h[r];
+      } else {
+        const float4 t2 = *reinterpret_cast<const float4*>(h + e);
+        hv[0] = t2.x; hv[1] = t2.y; hv[2] = t2.z; hv[3] = t2.w;
+      }
+    } else {
+      a[0] = x0[e];
+      b[0] = xi[e];
+      hv[0] = (h_cols == 1) ? h[r] : h[e];
+    }
+#pragma unroll
+    for (int k = 0; k < W; ++k) o[k] = b[k] + (a[k] * hv[k] + (bias != nullptr ? bias[c + k] : 0.f));
+    if constexpr (VEC) *reinterpret_cast<float4*>(out + e) = make_float4(o[0], o[1], o[2], o[3]);
+    else out[e] = o[0];
+  }
+}
+
+// dx0 = g * h, dh = g * x0 (row-summed when h is [rows, 1]); dxi = g and dbias = colsum(g) need no kernel here
+template <int G>
+__global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ h,
+                                                        const float* __restrict__ g, const long long rows, const int dim,
+                                                        const int h_cols, float* __restrict__ dx0,
+                                                        float* __restrict__ dh) {
+  // a lane group of G lanes walks one row (needed for the row sum of the broadcast case; coalesced either way)
+  const int lane_g = threadIdx.x % G;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
+  for (long long r = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; r < rows; r += ngroups) {
+    const float hb = (h_cols == 1) ? h[r] : 0.f;
+    float acc = 0.f;
+    for (int c = lane_g; c < dim; c += G) {
+      const long long e = r * dim + c;
+      const float gv = g[e], xv = x0[e];
+      const float hv = (h_cols == 1) ? hb : h[e];
+      if (dx0 != nullptr) dx0[e] = gv * hv;
+      if (h_cols == 1) acc += gv * xv;
+      else dh[e] = gv * xv;
+    }
+    if (h_cols == 1) {
+      acc = group_sum<G>(acc);
+      if (lane_g == 0) dh[r] = acc;
+    }
+  }
+}
+
+}  // namespace rbx
+
+extern "C" int rbx_cross_fwd(const float* d_x0, const float* d_xi, const float* d_h, const float* d_bias, int64_t rows,
+                             int32_t dim, int32_t h_cols, float* d_out, void* stream) {
+  using namespace rbx;
+  if (rows < 0 || dim <= 0 || (h_cols != 1 && h_cols != dim)) return fail(RBX_ERR_INVALID, "cross: bad shape");
+  if (rows == 0) return RBX_OK;
+  if (!d_x0 || !d_xi || !d_h || !d_out) return fail(RBX_ERR_INVALID, "cross: NULL tensor");
+  const bool vec = dim % 4 == 0 && ((reinterpret_cast<uintptr_t>(d_x0) | reinterpret_cast<uintptr_t>(d_xi) |
+                                     reinterpret_cast<uintptr_t>(d_h) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
+  const long long total = static_cast<long long>(rows) * dim / (vec ? 4 : 1);
+  long long blocks = (total + 255) / 256;
+  if (blocks > kCUs * 16) blocks = kCUs * 16;
+  if (vec)
+    hipLaunchKernelGGL(cross_fwd_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_x0, d_xi,
+                       d_h, d_bias, static_cast<long long>(rows), dim, h_cols, d_out);
+  else
+    hipLaunchKernelGGL(cross_fwd_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_x0, d_xi,
+                       d_h, d_bias, static_cast<long long>(rows), dim, h_cols, d_out);
+  return check_launch("cross_fwd_kernel");
+}
+
+extern "C" int rbx_cross_bwd(const float* d_x0, const float* d_h, const float* d_dout, int64_t rows, int32_t dim,
+                             int32_t h_cols, float* d_dx0, float* d_dh, void* stream) {
+  using namespace rbx;
+  if (rows < 0 || dim <= 0 || (h_cols != 1 && h_cols != dim)) return fail(RBX_ERR_INVALID, "cross_bwd: bad shape");
+  if (rows == 0) return RBX_OK;
+  if (!d_x0 || !d_h || !d_dout || !d_dh) return fail(RBX_ERR_INVALID, "cross_bwd: NULL tensor");
+  long long blocks = (rows + 3) / 4;                       // 4 lane groups of 64 per workgroup
+  if (blocks > kCUs * 16) blocks = kCUs * 16;
+  hipLaunchKernelGGL(cross_bwd_kernel<64>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_x0, d_h,
+                     d_dout, static_cast<long long>(rows), dim, h_cols, d_dx0, d_dh);
+  return check_launch("cross_bwd_kernel");
+}

@@ -1013,6 +1013,38 @@ def layer_norm(x, module):
     return _LayerNorm.apply(x, module.weight, module.bias, float(module.eps))
 
 
+class _Cross(torch.autograd.Function):
+    """out = xi + x0 * h (+ bias); h is [B, dim] (CrossNetV2) or [B, 1] (CrossNet)."""
+
+    @staticmethod
+    def forward(ctx, x0, xi, h, bias):
+        for t in (x0, xi, h):
+            _require_cuda(t, "cross input")
+        x0, xi, h = x0.contiguous().float(), xi.contiguous().float(), h.contiguous().float()
+        rows, dim = x0.shape
+        out = torch.empty_like(x0)
+        check(lib.rbx_cross_fwd(_ptr(x0), _ptr(xi), _ptr(h), _ptr(bias), rows, dim, h.shape[1], _ptr(out), _stream()))
+        ctx.save_for_backward(x0, h)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, h = ctx.saved_tensors
+        g = g.contiguous().float()
+        rows, dim = x0.shape
+        dx0 = torch.empty_like(x0) if ctx.needs_input_grad[0] else None
+        dh = torch.empty_like(h)
+        check(lib.rbx_cross_bwd(_ptr(x0), _ptr(h), _ptr(g), rows, dim, h.shape[1], _ptr(dx0), _ptr(dh), _stream()))
+        dbias = g.sum(dim=0) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        return dx0, (g if ctx.needs_input_grad[1] else None), dh, dbias
+
+
+def cross(x0, xi, h, bias=None):
+    """``xi + x0 * h + bias`` in one pass (rbx_cross_fwd/bwd): the element-wise tail of a cross layer."""
+    return _Cross.apply(x0, xi, h, bias)
+
+
 class _Attention(torch.autograd.Function):
     """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
 

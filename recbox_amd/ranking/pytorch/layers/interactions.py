@@ -7,7 +7,7 @@ from torch import nn
 
 from .... import ops
 
-__all__ = ["InnerProductInteraction"]
+__all__ = ["InnerProductInteraction", "CrossInteraction", "CrossNet", "CrossNetV2"]
 
 
 class InnerProductInteraction(nn.Module):
@@ -30,3 +30,50 @@ class InnerProductInteraction(nn.Module):
 
     def forward(self, feature_emb):
         return ops.interaction(feature_emb, self._output_type)
+
+
+class CrossInteraction(nn.Module):
+    """``weight(X_i) * X_0 + bias`` (cross_net.py:22-31): parameters as in the reference (``weight`` =
+    nn.Linear(input_dim, 1, bias=False), ``bias`` [input_dim])."""
+
+    def __init__(self, input_dim):
+        super(CrossInteraction, self).__init__()
+        self.weight = nn.Linear(input_dim, 1, bias=False)
+        self.bias = nn.Parameter(torch.zeros(input_dim))
+
+    def forward(self, X_0, X_i):
+        return ops.cross(X_0, torch.zeros_like(X_i), ops.linear(X_i, self.weight.weight), self.bias)
+
+
+class CrossNet(nn.Module):
+    """X_{i+1} = X_i + (X_i w_i) * X_0 + b_i (cross_net.py:34-46).  The [B, 1] projection runs on the narrow fp32-MFMA
+    tile, the rest is one fused pass (rbx_cross_fwd) per layer."""
+
+    def __init__(self, input_dim, num_layers):
+        super(CrossNet, self).__init__()
+        self.num_layers = num_layers
+        self.cross_net = nn.ModuleList(CrossInteraction(input_dim) for _ in range(self.num_layers))
+
+    def forward(self, X_0):
+        X_i = X_0
+        for i in range(self.num_layers):
+            layer = self.cross_net[i]
+            X_i = ops.cross(X_0, X_i, ops.linear(X_i, layer.weight.weight), layer.bias)
+        return X_i
+
+
+class CrossNetV2(nn.Module):
+    """X_{i+1} = X_i + X_0 * Linear_i(X_i) (cross_net.py:48-59): the Linear is rbx_linear_fwd (fp32 MFMA), the
+    element-wise tail rbx_cross_fwd."""
+
+    def __init__(self, input_dim, num_layers):
+        super(CrossNetV2, self).__init__()
+        self.num_layers = num_layers
+        self.cross_layers = nn.ModuleList(nn.Linear(input_dim, input_dim) for _ in range(self.num_layers))
+
+    def forward(self, X_0):
+        X_i = X_0
+        for i in range(self.num_layers):
+            layer = self.cross_layers[i]
+            X_i = ops.cross(X_0, X_i, ops.linear(X_i, layer.weight, layer.bias))
+        return X_i

@@ -360,6 +360,27 @@ def test_sharded_fm_step_pieces(graphs):
         assert_close(p.grad, ref_g[n], 1e-6, n)
 
 
+@pytest.mark.parametrize("version", ["v1", "v2"])
+def test_cross_net_golden(version):
+    """CrossNet / CrossNetV2 against the live-reference fixture: output, dx and every parameter grad."""
+    L = _layers()
+    fx = Fixture("cross_net")
+    x = fx.tensors("in")["x"]
+    R = fx.tensors("in")["R"]
+    cls = L.CrossNet if version == "v1" else L.CrossNetV2
+    net = load_params(cls(x.shape[1], 3), fx["p_" + version]).cuda()
+    xc = x.cuda().requires_grad_(True)
+    out = net(xc)
+    assert_close(out, fx["out_" + version]["y"], TOL, "y")
+    (out * R.cuda()).sum().backward()
+    assert_close(xc.grad, fx["out_" + version]["dx"], TOL, "dx")
+    assert_grads_close(net, fx["g_" + version], TOL)
+    if version == "v1":                                       # the per-layer module is usable on its own, like the reference's
+        one = net.cross_net[0]
+        want = one.weight(xc.detach()) * xc.detach() + one.bias
+        assert_close(one(xc.detach(), xc.detach()), want.detach(), TOL, "CrossInteraction")
+
+
 def test_backward_is_deterministic_and_linear():
     """Full-size property checks (B = 65 536, 26 fields): two backward passes are
     bit-identical (no float atomics) and column sums of dW equal column sums of dY."""
