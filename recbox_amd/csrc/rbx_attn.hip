@@ -296,6 +296,7 @@ static int attn_check(int64_t bh, int lq, int lk, int hd) {
 extern "C" int rbx_attn_fwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask, int64_t bh,
                             int32_t lq, int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill,
                             float* d_o, float* d_lse, float* d_p, void* stream) {
+  if (bh == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   int rc = attn_check(bh, lq, lk, head_dim);
   if (rc != RBX_OK) return rc;
@@ -322,6 +323,7 @@ extern "C" int rbx_attn_bwd(const float* d_q, const float* d_k, const float* d_v
                             const float* d_o, const float* d_do, const float* d_lse, int64_t bh, int32_t lq,
                             int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill, float* d_dq,
                             float* d_dk, float* d_dv, float* d_scratch, void* stream) {
+  if (bh == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   int rc = attn_check(bh, lq, lk, head_dim);
   if (rc != RBX_OK) return rc;

@@ -356,6 +356,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
 
 extern "C" int rbx_linear_fwd(const float* d_x, int64_t x_stride, const float* d_w, const float* d_bias, int64_t m,
                               int32_t n, int32_t k, int32_t act, float* d_y, void* stream) {
+  if (m == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (d_x == nullptr || d_w == nullptr || d_y == nullptr) return fail(RBX_ERR_INVALID, "linear: NULL tensor");
   if (m < 0 || n <= 0 || k <= 0 || m > INT_MAX) return fail(RBX_ERR_INVALID, "linear: bad shape");
@@ -388,6 +389,7 @@ extern "C" size_t rbx_linear_bwd_workspace_size(int64_t m, int32_t n, int32_t k,
 extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d_w, const float* d_y, const float* d_dy,
                               int64_t m, int32_t n, int32_t k, int32_t act, float* d_dx, int64_t dx_stride, float* d_dw,
                               float* d_db, void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (m == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (d_x == nullptr || d_w == nullptr || d_dy == nullptr) return fail(RBX_ERR_INVALID, "linear_bwd: NULL tensor");
   if (x_stride < k || (d_dx != nullptr && dx_stride < k)) return fail(RBX_ERR_INVALID, "linear_bwd: row stride < k");

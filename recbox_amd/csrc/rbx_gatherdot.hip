@@ -317,11 +317,11 @@ static int dispatch_dot_dx(const DotHost& h, int n, int64_t R, const float* g, f
 extern "C" int rbx_gatherdot_fwd(const rbx_field_t* cands, int32_t n_cands, int64_t rows, const float* d_x,
                                  int64_t x_stride, float scale, float* d_out, int32_t* d_status, void* stream) {
   using namespace rbx;
+  if (rows == 0) return RBX_OK;                            // empty batch: nothing to read, pointers may be NULL
   static thread_local DotHost h;
   h = DotHost();
   int rc = dot_validate(cands, n_cands, rows, &h);
   if (rc != RBX_OK) return rc;
-  if (rows == 0) return RBX_OK;
   if (d_x == nullptr || d_out == nullptr) return fail(RBX_ERR_INVALID, "gatherdot: NULL tensor");
   if (x_stride < h.D) return fail(RBX_ERR_INVALID, "gatherdot: x_stride %lld < dim %d", static_cast<long long>(x_stride), h.D);
   if (x_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(d_x) & 15) != 0) h.vec = false;
@@ -330,6 +330,7 @@ extern "C" int rbx_gatherdot_fwd(const rbx_field_t* cands, int32_t n_cands, int6
 
 extern "C" size_t rbx_gatherdot_bwd_workspace_size(const rbx_field_t* cands, int32_t n_cands, int64_t rows) {
   using namespace rbx;
+  if (rows <= 0) return 0;
   static thread_local DotHost h;
   h = DotHost();
   if (dot_validate(cands, n_cands, rows, &h) != RBX_OK) return 0;
@@ -341,6 +342,7 @@ extern "C" size_t rbx_gatherdot_bwd_workspace_size(const rbx_field_t* cands, int
 extern "C" int rbx_gatherdot_sort(const rbx_field_t* cands, int32_t n_cands, int64_t rows, void* d_workspace,
                                   size_t workspace_bytes, int32_t* d_status, void* stream) {
   using namespace rbx;
+  if (rows == 0) return RBX_OK;
   static thread_local DotHost h;
   h = DotHost();
   int rc = dot_validate(cands, n_cands, rows, &h);
@@ -358,11 +360,11 @@ extern "C" int rbx_gatherdot_bwd(const rbx_field_t* cands, int32_t n_cands, int6
                                  int64_t x_stride, const float* d_dout, float scale, float* d_dx, int64_t dx_stride,
                                  int32_t accumulate, void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace rbx;
+  if (rows == 0) return RBX_OK;
   static thread_local DotHost h;
   h = DotHost();
   int rc = dot_validate(cands, n_cands, rows, &h);
   if (rc != RBX_OK) return rc;
-  if (rows == 0) return RBX_OK;
   if (d_x == nullptr || d_dout == nullptr) return fail(RBX_ERR_INVALID, "gatherdot_bwd: NULL tensor");
   hipStream_t s = as_stream(stream);
   if (d_dx != nullptr) {

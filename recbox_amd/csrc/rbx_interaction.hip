@@ -203,6 +203,7 @@ static int dispatch_fm(bool bwd, const float* emb, const float* dout, int64_t B,
 
 static int run_interaction(bool bwd, const float* emb, long long sb, const float* dout, int64_t B, int F, int D, int mode,
                            float* out, long long dsb, void* stream) {
+  if (B == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   if (emb == nullptr || out == nullptr || (bwd && dout == nullptr)) return fail(RBX_ERR_INVALID, "NULL tensor");
   if (B < 0 || F <= 0 || D <= 0) return fail(RBX_ERR_INVALID, "bad shape B=%lld F=%d D=%d", (long long)B, F, D);
   if (mode < 0 || mode > 3) return fail(RBX_ERR_INVALID, "InnerProductInteraction output mode %d is not supported", mode);

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 
 extern "C" int rbx_pool_fwd(const float* d_emb, const float* d_mask, int64_t batch, int32_t seq_len, int32_t dim,
                             int32_t numer_masked, int32_t denom, float eps, float* d_out, float* d_inv, void* stream) {
+  if (batch == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (d_emb == nullptr || d_out == nullptr || d_inv == nullptr) return fail(RBX_ERR_INVALID, "NULL tensor");
   if (batch < 0 || seq_len <= 0 || dim <= 0) return fail(RBX_ERR_INVALID, "bad shape");
@@ -101,6 +102,7 @@ extern "C" int rbx_pool_fwd(const float* d_emb, const float* d_mask, int64_t bat
 
 extern "C" int rbx_pool_bwd(const float* d_dout, const float* d_mask, const float* d_inv, int64_t batch,
                             int32_t seq_len, int32_t dim, int32_t numer_masked, float* d_demb, void* stream) {
+  if (batch == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (d_dout == nullptr || d_inv == nullptr || d_demb == nullptr) return fail(RBX_ERR_INVALID, "NULL tensor");
   if (numer_masked && d_mask == nullptr) return fail(RBX_ERR_INVALID, "mask required");

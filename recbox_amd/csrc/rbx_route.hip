@@ -148,7 +148,8 @@ extern "C" int rbx_route(const rbx_field_t* tables, int32_t n_tables, int64_t ba
   if (world <= 0 || world > kRouteMaxW) return fail(RBX_ERR_UNSUPPORTED, "route: world=%d not in [1,%d]", world, kRouteMaxW);
   if (capacity <= 0 || capacity * world >= INT_MAX) return fail(RBX_ERR_INVALID, "route: bad capacity");
   hipStream_t s = as_stream(stream);
-  if (d_send == nullptr || d_slot == nullptr || d_base == nullptr) return fail(RBX_ERR_INVALID, "route: NULL output/base");
+  if (d_send == nullptr || d_base == nullptr || (batch > 0 && d_slot == nullptr))
+    return fail(RBX_ERR_INVALID, "route: NULL output/base");
   RoutePack pack;
   for (int t = 0; t < n_tables; ++t) {
     if (batch > 0 && tables[t].ids == nullptr) return fail(RBX_ERR_INVALID, "route: table %d: ids is NULL", t);

@@ -115,6 +115,7 @@ static unsigned grid_for(long long groups, int g) {
 
 extern "C" int rbx_l2norm_fwd(const float* d_x, int64_t rows, int32_t dim, float eps, float* d_y, float* d_inv,
                               void* stream) {
+  if (rows == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (d_x == nullptr || d_y == nullptr || d_inv == nullptr) return fail(RBX_ERR_INVALID, "l2norm: NULL tensor");
   if (rows < 0 || dim <= 0) return fail(RBX_ERR_INVALID, "l2norm: bad shape");
@@ -130,6 +131,7 @@ extern "C" int rbx_l2norm_fwd(const float* d_x, int64_t rows, int32_t dim, float
 
 extern "C" int rbx_l2norm_bwd(const float* d_y, const float* d_inv, const float* d_dy, int64_t rows, int32_t dim,
                               float* d_dx, void* stream) {
+  if (rows == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (d_y == nullptr || d_inv == nullptr || d_dy == nullptr || d_dx == nullptr)
     return fail(RBX_ERR_INVALID, "l2norm_bwd: NULL tensor");
@@ -145,6 +147,7 @@ extern "C" int rbx_l2norm_bwd(const float* d_y, const float* d_inv, const float*
 
 extern "C" int rbx_pairdot_fwd(const float* d_u, const float* d_v, int64_t batch, int32_t n_cand, int32_t dim,
                                float scale, float* d_out, void* stream) {
+  if (batch == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (d_u == nullptr || d_v == nullptr || d_out == nullptr) return fail(RBX_ERR_INVALID, "pairdot: NULL tensor");
   if (batch < 0 || n_cand <= 0 || dim <= 0) return fail(RBX_ERR_INVALID, "pairdot: bad shape");
@@ -161,6 +164,7 @@ extern "C" int rbx_pairdot_fwd(const float* d_u, const float* d_v, int64_t batch
 
 extern "C" int rbx_pairdot_bwd(const float* d_u, const float* d_v, const float* d_dout, int64_t batch,
                                int32_t n_cand, int32_t dim, float scale, float* d_du, float* d_dv, void* stream) {
+  if (batch == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (d_u == nullptr || d_v == nullptr || d_dout == nullptr) return fail(RBX_ERR_INVALID, "pairdot_bwd: NULL tensor");
   if (batch == 0) return RBX_OK;
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict_
 
 extern "C" int rbx_cross_fwd(const float* d_x0, const float* d_xi, const float* d_h, const float* d_bias, int64_t rows,
                              int32_t dim, int32_t h_cols, float* d_out, void* stream) {
+  if (rows == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (rows < 0 || dim <= 0 || (h_cols != 1 && h_cols != dim)) return fail(RBX_ERR_INVALID, "cross: bad shape");
   if (rows == 0) return RBX_OK;
@@ -267,6 +272,7 @@ extern "C" int rbx_cross_fwd(const float* d_x0, const float* d_xi, const float* 
 
 extern "C" int rbx_cross_bwd(const float* d_x0, const float* d_h, const float* d_dout, int64_t rows, int32_t dim,
                              int32_t h_cols, float* d_dx0, float* d_dh, void* stream) {
+  if (rows == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   if (rows < 0 || dim <= 0 || (h_cols != 1 && h_cols != dim)) return fail(RBX_ERR_INVALID, "cross_bwd: bad shape");
   if (rows == 0) return RBX_OK;

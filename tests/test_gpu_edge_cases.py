@@ -1,0 +1,60 @@
+"""Empty / degenerate inputs through the ops added for K7, the norms, the loader and the retrieval path: a zero-size
+batch must come back as correctly shaped empty tensors (and zero gradients), never a crash or a launch error."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_batches_everywhere():
+    from recbox_amd import ops
+    dev = "cuda"
+    w = torch.randn(10, 8, device=dev, requires_grad=True)
+    x = torch.zeros(0, 8, device=dev, requires_grad=True)
+    out = ops.gather_dot(x, [torch.zeros(0, dtype=torch.long, device=dev)], w)
+    assert out.shape == (0, 1)
+    out.sum().backward()
+    assert w.grad is not None and float(w.grad.abs().sum()) == 0.0 and x.grad.shape == (0, 8)
+    ln = torch.nn.LayerNorm(8).to(dev)
+    assert ops.layer_norm(torch.zeros(0, 3, 8, device=dev), ln).shape == (0, 3, 8)
+    v, i = ops.topk(torch.zeros(0, 5, device=dev), 3)
+    assert v.shape == (0, 3) and i.shape == (0, 3)
+    v, i = ops.topk(torch.randn(2, 0, device=dev), 3)                       # rows without candidates: all padding
+    assert bool((i == -1).all())
+    assert ops.negsample(10, 0, 4, seed=1, device=dev).shape == (0, 4)
+    assert ops.negsample(10, 5, 0, seed=1, pos=torch.arange(5, device=dev)).tolist() == [[0], [1], [2], [3], [4]]
+    assert ops.gather_rows([torch.arange(6, device=dev).view(3, 2)], torch.zeros(0, dtype=torch.long, device=dev))[0].shape == (0, 2)
+    of = torch.zeros((), dtype=torch.bool, device=dev)
+    send, slot = ops.route(torch.zeros(0, 2, dtype=torch.long, device=dev), 2, 64, torch.zeros(2, 2, dtype=torch.long, device=dev), of)
+    assert slot.shape == (0, 2) and bool((send == -1).all()) and not bool(of)
+    y = ops.cross(torch.zeros(0, 4, device=dev), torch.zeros(0, 4, device=dev), torch.zeros(0, 4, device=dev))
+    assert y.shape == (0, 4)
+    assert ops.linear(torch.zeros(0, 8, device=dev), torch.randn(3, 8, device=dev)).shape == (0, 3)
+    torch.cuda.synchronize()
+
+
+def test_batch_norm_single_row_raises_like_torch():
+    from recbox_amd import ops
+    bn = torch.nn.BatchNorm1d(4).cuda()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        ops.batch_norm(torch.randn(1, 4, device="cuda"), bn)
+    bn.eval()
+    assert ops.batch_norm(torch.randn(1, 4, device="cuda"), bn).shape == (1, 4)          # eval mode accepts it
+
+
+def test_linear_strided_rows_match_contiguous():
+    """A column block of a wider activation is read in place (row stride > K) and gives the same result and grads."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(0)
+    wide = torch.randn(300, 52, generator=g).cuda()
+    w = torch.randn(7, 37, generator=g).cuda().requires_grad_(True)
+    b = torch.randn(7, generator=g).cuda().requires_grad_(True)
+    xs = wide[:, :37].detach().requires_grad_(True)                                     # stride 52, 37 columns
+    xc = wide[:, :37].contiguous().detach().requires_grad_(True)
+    ys, yc = ops.linear(xs, w, b, "relu"), ops.linear(xc, w, b, "relu")
+    assert torch.equal(ys, yc)
+    r = torch.randn_like(ys)
+    gs = torch.autograd.grad((ys * r).sum(), (xs, w, b))
+    gc = torch.autograd.grad((yc * r).sum(), (xc, w, b))
+    for a, c in zip(gs, gc):
+        assert torch.equal(a.contiguous(), c.contiguous())
