@@ -52,6 +52,7 @@ class ShardedFMStep(object):
         route      ids -> (owner, row) -> wire slots (rbx_route)          [graph]
         all-to-all row numbers to the owners                              RCCL
         serve      owners gather the packed rows (rbx_embed_fwd)          [graph]
+        presort    owners sort the received row numbers (rbx_embed_sort)  [graph, side stream, joined before settle]
         all-to-all rows back                                              RCCL
         head       fused FM forward (remote rows read at their wire slots),
                    loss, dL/dlogit, dL/d(remote rows) written to the slots [graph]
@@ -93,6 +94,8 @@ class ShardedFMStep(object):
         self.sizes = [p.numel() for p in self.replicated]
         self.comm = comm
         self.pieces = [self._route, self._serve, self._head, self._tail, self._settle, self._finish]
+        self.side = torch.cuda.Stream(device=dev)        # owner-side id sort runs here, beside the local forward
+        self.sorted_ws = None
         self.graphs = None
         if graphs:
             side = torch.cuda.Stream()
@@ -104,6 +107,11 @@ class ShardedFMStep(object):
             torch.cuda.synchronize()
             self.graphs = []
             for piece in self.pieces:
+                if piece == self._head:                 # the owner-side sort is captured on its own stream first
+                    gs = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gs, stream=self.side, capture_error_mode="thread_local"):
+                        self._presort()
+                    self.presort_replay = gs.replay
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     piece()
@@ -136,8 +144,12 @@ class ShardedFMStep(object):
         self.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                                for p in self.replicated]) if self.replicated else None
 
+    def _presort(self):
+        self.sorted_ws = self.tables.local_ops.presort(self.tables.weight, self.recv)
+
     def _settle(self):
-        self.tables.weight.grad = self.tables.local_ops.scatter_add(self.tables.weight, self.recv, self.d_recv)
+        self.tables.weight.grad = self.tables.local_ops.scatter_add(self.tables.weight, self.recv, self.d_recv,
+                                                                    sorted_ws=self.sorted_ws)
 
     def _finish(self):
         if self.flat is not None and self.W > 1:
@@ -155,12 +167,19 @@ class ShardedFMStep(object):
         route()
         comm.all_to_all_equal_into(self.recv, self.send, group)
         serve()
+        # the owners' id sort needs only the row numbers: it runs on a side stream beside the rows' way back and
+        # the local forward, and is joined right before the owner-side scatter-add
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            (self.presort_replay if pieces is self.graphs else self._presort)()
         comm.all_to_all_equal_into(self.back, self.vecs, group)
         head()
         grads_out = comm.all_to_all_equal_into(self.d_recv, self.dsend, group, async_op=True)
         tail()                                    # overlaps with the gradient exchange
         reduced = comm.all_reduce_sum_(self.flat, group, async_op=True) if self.flat is not None else None
         grads_out.wait()
+        cur.wait_stream(self.side)
         settle()                                  # overlaps with the all-reduce of the replicated gradients
         if reduced is not None:
             reduced.wait()

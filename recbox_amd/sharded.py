@@ -60,7 +60,23 @@ class HipLocalOps(object):
         check(lib.rbx_embed_fwd(plan.arr, 1, n, ops._ptr(out), weight.shape[1], None, None, ops._stream()))
         return out
 
-    def scatter_add(self, weight, rows, dy):
+    def presort(self, weight, rows):
+        """The id sort of ``scatter_add`` depends on the row numbers only: run it as soon as they are known (the
+        result is passed to ``scatter_add`` as ``sorted_ws``)."""
+        from . import ops
+        from ._lib import check, lib
+        n = rows.numel()
+        if n == 0:
+            return None
+        plan = self._plan(weight)
+        plan.bind_inputs([rows])
+        plan.bind_params([weight.detach()], [weight.detach()])          # placeholder grad pointer: "trainable"
+        ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
+        check(lib.rbx_embed_sort(plan.arr, 1, n, ops._ptr(ws), ws_bytes, None, ops._stream()))
+        return ws
+
+    def scatter_add(self, weight, rows, dy, sorted_ws=None):
         """dense [n_local, width] gradient of ``gather`` w.r.t. weight (rows < 0 are skipped)."""
         from . import ops
         from ._lib import check, lib
@@ -72,9 +88,11 @@ class HipLocalOps(object):
         plan.bind_inputs([rows])
         plan.bind_params([weight.detach()], [grad])
         ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
         st = ops._stream()
-        check(lib.rbx_embed_sort(plan.arr, 1, n, ops._ptr(ws), ws_bytes, None, st))
+        ws = sorted_ws
+        if ws is None:
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
+            check(lib.rbx_embed_sort(plan.arr, 1, n, ops._ptr(ws), ws_bytes, None, st))
         dy = dy.contiguous()
         check(lib.rbx_embed_bwd(plan.arr, 1, n, ops._ptr(dy), dy.stride(0), None, 0, ops._ptr(ws), ws_bytes, st))
         return grad
