@@ -16,8 +16,8 @@ Small tables stay replicated (their dense grads are all-reduced): cheaper than e
 Two exchange modes:
   exact   variable-size all-to-all-v; needs the per-peer counts on the host (one sync per call).
   padded  every rank sends exactly ``capacity`` slots to every peer (empty slots carry row -1):
-          no host sync, fixed shapes, so the WHOLE training step -- routing, RCCL exchanges, fused
-          kernels -- can be captured in one hipGraph.  A lookup that does not fit sets the
+          no host sync, fixed shapes: the routing is one HIP call (rbx_route) and the step can be
+          captured as hipGraph pieces between the RCCL exchanges (recbox_amd.graph.ShardedFMStep).  A lookup that does not fit sets the
           ``overflow`` flag (checked by the caller after the step) instead of being dropped silently.
 """
 import math
@@ -59,6 +59,12 @@ class HipLocalOps(object):
         plan.bind_params([weight.detach()])
         check(lib.rbx_embed_fwd(plan.arr, 1, n, ops._ptr(out), weight.shape[1], None, None, ops._stream()))
         return out
+
+    def route(self, ids, world, capacity, base, overflow):
+        """Wire slots of the padded exchange: (slot [B, T] int32, send [world * capacity] int64) -- rbx_route."""
+        from . import ops
+        send, slot = ops.route(ids, world, capacity, base, overflow)
+        return slot, send
 
     def presort(self, weight, rows):
         """The id sort of ``scatter_add`` depends on the row numbers only: run it as soon as they are known (the
@@ -127,29 +133,6 @@ class _ExactLookup(torch.autograd.Function):
         d_sorted = dout.reshape(-1, weight.shape[1])[perm].contiguous()
         d_recv = comm.all_to_all_rows(d_sorted, send_counts, recv_counts, group)          # dY to the owners
         return None, None, None, None, None, local_ops.scatter_add(weight, recv_rows, d_recv)
-
-
-def padded_route(owner, row, capacity, W, overflow):
-    """Slot assignment of the padded exchange, torch restatement of ``rbx_route`` (CPU / gloo tests and the
-    check of the HIP kernel).  owner/row: flat [n].  Returns (slot, send): ``slot[i]`` is the wire slot of
-    lookup i = owner * capacity + (number of EARLIER lookups with the same owner); ``W * capacity`` = the dump
-    slot of lookups that do not fit (sets ``overflow``); ``send`` [W * capacity] holds the row numbers, -1 = empty."""
-    n = owner.numel()
-    dev = owner.device
-    order = torch.argsort(owner, stable=True)
-    owner_s = owner[order]
-    counts = torch.zeros(W, dtype=torch.long, device=dev).scatter_add_(0, owner, torch.ones_like(owner))
-    starts = torch.cumsum(counts, 0) - counts
-    rank_in = torch.arange(n, device=dev) - starts[owner_s]
-    fits = rank_in < capacity
-    overflow.logical_or_((~fits).any())                       # reported, never silently dropped
-    dump = W * capacity                                       # one spare slot swallows what does not fit
-    slot_s = torch.where(fits, owner_s * capacity + rank_in, torch.full_like(rank_in, dump))
-    send = torch.full((dump + 1,), -1, dtype=torch.long, device=dev)
-    send[slot_s] = row[order]
-    slot = torch.empty_like(slot_s)
-    slot[order] = slot_s
-    return slot, send[:dump]
 
 
 class _PaddedLookup(torch.autograd.Function):
@@ -274,20 +257,10 @@ class ShardedTables(nn.Module):
         return owner, self.base[owner, t_index] + ids // W
 
     def route(self, ids, capacity):
-        """Wire slots of the padded exchange for ids [B, T]: (slot [B, T], send [W * capacity] row numbers).
-        On the GPU this is rbx_route (three launches); elsewhere the torch restatement ``padded_route``."""
-        cols = ids if not torch.is_tensor(ids) else None       # list of T id columns [B], read in place on the GPU
-        first = cols[0] if cols is not None else ids
-        if first.is_cuda:
-            from . import ops
-            send, slot = ops.route(ids, self.world_size, capacity, self.base, self.overflow)
-            return slot, send
-        if cols is not None:
-            ids = torch.stack([c.long() for c in cols], dim=1)
-        ids = ids.long()
-        owner, row = self.locate(ids)
-        slot, send = padded_route(owner.reshape(-1), row.reshape(-1), capacity, self.world_size, self.overflow)
-        return slot.view_as(ids), send
+        """Wire slots of the padded exchange for ids ([B, T] tensor or a list of T id columns read in place):
+        (slot [B, T], send [W * capacity] row numbers).  The work is the local backend's: rbx_route for
+        ``HipLocalOps`` (three launches, no host sync)."""
+        return self.local_ops.route(ids, self.world_size, capacity, self.base, self.overflow)
 
     def forward(self, ids):
         """ids [B, T] (one id per table per sample) -> packed rows [B, T, row_width]."""

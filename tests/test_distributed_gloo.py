@@ -11,6 +11,29 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def padded_route(owner, row, capacity, W, overflow):
+    """TEST INFRASTRUCTURE: torch restatement of ``rbx_route`` (slot assignment of the padded exchange), used by the
+    gloo tests below and as the checker of the HIP kernel in test_gpu_ranking.py.  owner/row: flat [n].  Returns (slot, send): ``slot[i]`` is the wire slot of
+    lookup i = owner * capacity + (number of EARLIER lookups with the same owner); ``W * capacity`` = the dump
+    slot of lookups that do not fit (sets ``overflow``); ``send`` [W * capacity] holds the row numbers, -1 = empty."""
+    n = owner.numel()
+    dev = owner.device
+    order = torch.argsort(owner, stable=True)
+    owner_s = owner[order]
+    counts = torch.zeros(W, dtype=torch.long, device=dev).scatter_add_(0, owner, torch.ones_like(owner))
+    starts = torch.cumsum(counts, 0) - counts
+    rank_in = torch.arange(n, device=dev) - starts[owner_s]
+    fits = rank_in < capacity
+    overflow.logical_or_((~fits).any())                       # reported, never silently dropped
+    dump = W * capacity                                       # one spare slot swallows what does not fit
+    slot_s = torch.where(fits, owner_s * capacity + rank_in, torch.full_like(rank_in, dump))
+    send = torch.full((dump + 1,), -1, dtype=torch.long, device=dev)
+    send[slot_s] = row[order]
+    slot = torch.empty_like(slot_s)
+    slot[order] = slot_s
+    return slot, send[:dump]
+
+
 class OracleLocalOps(object):
     """CPU stand-in for HipLocalOps (test infrastructure): plain index_select / index_add_;
     row -1 is an empty slot of the padded exchange (zero vector, no gradient)."""
@@ -19,11 +42,21 @@ class OracleLocalOps(object):
         out = weight.detach().index_select(0, rows.clamp(min=0))
         return out * (rows >= 0).unsqueeze(1)
 
-    def scatter_add(self, weight, rows, dy):
+    def scatter_add(self, weight, rows, dy, sorted_ws=None):
         g = torch.zeros_like(weight)
         keep = rows >= 0
         g.index_add_(0, rows[keep], dy[keep])
         return g
+
+    def route(self, ids, world, capacity, base, overflow):
+        if not torch.is_tensor(ids):
+            ids = torch.stack([c.long() for c in ids], dim=1)
+        ids = ids.long()
+        owner = ids % world
+        t_index = torch.arange(ids.shape[1]).unsqueeze(0).expand_as(ids)
+        row = base[owner, t_index] + ids // world
+        slot, send = padded_route(owner.reshape(-1), row.reshape(-1), capacity, world, overflow)
+        return slot.view_as(ids), send
 
 
 def _free_port():

@@ -299,9 +299,9 @@ def test_sharded_fm_equals_fm_on_one_gpu(factor):
 @pytest.mark.parametrize("world,cap", [(1, 4096), (3, 1024), (8, 320), (8, 64)])
 def test_route_kernel_equals_torch_restatement(world, cap):
     """rbx_route (stable counting sort by owner, wire slots, dump slot + overflow byte) == the torch restatement
-    recbox_amd.sharded.padded_route, bit for bit, including a capacity that overflows."""
+    padded_route (tests/test_distributed_gloo.py), bit for bit, including a capacity that overflows."""
     from recbox_amd import ops
-    from recbox_amd.sharded import padded_route
+    from test_distributed_gloo import padded_route
     g = torch.Generator().manual_seed(5)
     B, T = 1000, 3
     vocabs = [5000, 77, 123456]
