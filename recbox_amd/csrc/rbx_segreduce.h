@@ -29,7 +29,7 @@ __device__ __forceinline__ void frag_add(F& a, const F& b) {
 // Interior runs are written directly; a run that crosses the chunk border leaves a head /
 // tail summary and a flag, and the chunk where such a run ENDS is queued for the fix-up.
 template <class Policy, int G, int NV, bool VEC>
-__global__ __launch_bounds__(256) void segment_reduce_kernel(const RedPack P, const int n_cat,
+__global__ __launch_bounds__(256, 4) void segment_reduce_kernel(const RedPack P, const int n_cat,
                                                              const typename Policy::Args args,
                                                              const unsigned* __restrict__ keys,
                                                              const unsigned* __restrict__ vals, const unsigned n,
