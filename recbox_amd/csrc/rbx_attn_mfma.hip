@@ -26,6 +26,7 @@ namespace rbx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kT = 32;                      // tile edge (queries or keys)
+constexpr int kAttnThreads = 512;           // 8 wavefronts: two per SIMD, so one hides the other's MFMA / LDS latency
 
 __device__ __forceinline__ int tile_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -37,17 +38,17 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* _
                                            float scale) {
   constexpr int Q4 = HD / 4;                               // float4 per row
   const int total = rows_pad * Q4;
-  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * 256) {
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * kAttnThreads) {
     float4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 256;
+      const int i = i0 + u * kAttnThreads;
       const int r = i / Q4;
       v[u] = (i < total && r < rows) ? reinterpret_cast<const float4*>(g)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 256;
+      const int i = i0 + u * kAttnThreads;
       if (i < total) {
         const int r = i / Q4, d = (i - r * Q4) * 4;
         float* dst = lds + r * (HD + 1) + d;
@@ -79,11 +80,17 @@ template <int HD>
 __device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, int row0, const float (&reg)[HD / 2]) {
   const int lane = threadIdx.x & 63;
   const float* a = rows_lds + (row0 + (lane & 31)) * (HD + 1) + (lane >> 5);
-  f32x16 acc;
+  // two accumulator chains (even / odd k steps): a single chain makes every MFMA wait for the previous one
+  f32x16 acc, acc1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
 #pragma unroll
-  for (int s = 0; s < HD / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], reg[s], acc, 0, 0, 0);
+  for (int s = 0; s < HD / 2; s += 2) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], reg[s], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s + 2], reg[s + 1], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
   return acc;
 }
 
@@ -117,15 +124,16 @@ __device__ __forceinline__ void store_transposed(float* __restrict__ g, int row0
                       acc[dt][4 * q + 3] * scale);
 }
 
-// Tile schedule: with L <= 256 there are at most 8 tiles; wave w takes the heavy tile nT-1-w and the
-// light tile w (causal cost of tile t is t+1, so every wave gets ~nT+1 tile steps).
-#define RBX_FOR_WAVE_TILES(nT, wid, t)                                                             \
-  for (int zz_pass = 0, t = (nT) - 1 - (wid); zz_pass < 2 && (wid) <= (nT) - 1 - (wid) &&        \
-                                              !(zz_pass == 1 && (wid) == (nT) - 1 - (wid));        \
-       ++zz_pass, t = (wid))
+// Tile schedule: with L <= 256 there are at most 8 tiles and the workgroup has 8 wavefronts.  The causal cost of tile t
+// is t+1 tile steps, so SIMD s (wavefronts s and s+4) gets the heavy tile nT-1-s and the light tile s: ~nT+1 steps
+// of MFMA work per SIMD, run as two wavefronts that fill each other's latency gaps.
+#define RBX_FOR_WAVE_TILES(nT, wid, t)                                                                      \
+  for (int zz_once = 1, t = ((wid) < 4) ? (nT) - 1 - (wid) : (wid) - 4;                                     \
+       zz_once && (((wid) < 4) ? ((wid) <= (nT) - 1 - (wid)) : ((wid) - 4 < (nT) - 1 - ((wid) - 4)));       \
+       zz_once = 0)
 
 template <int HD>
-__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ V, const int L,
                                                             const float scale, const int causal,
                                                             float* __restrict__ O, float* __restrict__ LSE) {
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const float* __restr
 
 // backward phase A: lane = query.  dQ and D = <dO, O>.
 template <int HD>
-__global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                               const float* __restrict__ V,
                                                               const float* __restrict__ O,
                                                               const float* __restrict__ dO,
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_q_kernel(const float* __res
 
 // backward phase B: lane = key.  dK, dV.
 template <int HD>
-__global__ __launch_bounds__(256) void attn_mfma_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                                const float* __restrict__ V,
                                                                const float* __restrict__ dO,
                                                                const float* __restrict__ LSE,
@@ -306,7 +314,7 @@ static int run_fwd(const float* q, const float* k, const float* v, long long bh,
   const size_t lds = lds_bytes<HD>(L, false);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(256), lds, s, q, k, v, L, scale,
+  hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, q, k, v, L, scale,
                      causal, o, lse);
   return check_launch("attn_mfma_fwd_kernel");
 }
@@ -320,9 +328,9 @@ static int run_bwd(const float* q, const float* k, const float* v, const float* 
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(la));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kv_kernel<HD>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb));
-  hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(256), la, s, q, k, v, o, go, lse,
+  hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), la, s, q, k, v, o, go, lse,
                      L, scale, causal, dq, scratch);
-  hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(256), lb, s, q, k, v, go, lse,
+  hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lb, s, q, k, v, go, lse,
                      scratch, L, scale, causal, dk, dv);
   return check_launch("attn_mfma_bwd kernels");
 }
