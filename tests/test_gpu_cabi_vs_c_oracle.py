@@ -29,10 +29,10 @@ def _dev_field(L, host_field, ids_t, table_t, grad_t):
     return f
 
 
-def _mixed_case(B, D, seed, id_dtype):
+def _mixed_case(B, D, seed, id_dtype, Lh=6):
     """numeric + one-hot + shared table + all pool modes + dense, ids read from a strided block."""
     g = np.random.default_rng(seed)
-    V1, V2, Lh = 50, 9, 6
+    V1, V2 = 50, 9
     block = np.zeros((B, 4 + 3 * Lh), dtype=id_dtype)             # one [B, cols] batch tensor, column views
     block[:, 0] = g.random(B).astype(id_dtype) if np.issubdtype(id_dtype, np.floating) else g.integers(0, 3, B)
     block[:, 1] = g.integers(0, V1, B)
@@ -59,12 +59,16 @@ def _mixed_case(B, D, seed, id_dtype):
     return block, {"W1": W1, "W2": W2, "wn": wn}, specs, Lh
 
 
-@pytest.mark.parametrize("B,D,id_dtype", [(1, 16, np.int64), (77, 16, np.float64), (300, 7, np.int32),
-                                          (129, 1, np.float32), (64, 128, np.int64), (33, 252, np.int64)])
-def test_embed_fwd_bwd_raw_cabi(B, D, id_dtype):
+@pytest.mark.parametrize("B,D,id_dtype,Lh", [(1, 16, np.int64, 6), (77, 16, np.float64, 6), (300, 7, np.int32, 6),
+                                             (129, 1, np.float32, 6), (64, 128, np.int64, 6), (33, 252, np.int64, 6),
+                                             # long histories: several LDS compaction chunks per (sample, feature) in
+                                             # every lane-group shape of the sequence kernel (cfg 5 has L = 200)
+                                             (40, 64, np.int64, 200), (9, 16, np.int32, 300), (20, 128, np.int64, 70),
+                                             (12, 4, np.float64, 130), (7, 32, np.int64, 257), (5, 256, np.int64, 65)])
+def test_embed_fwd_bwd_raw_cabi(B, D, id_dtype, Lh):
     L = _lib()
     orc = C.load()
-    block, W, specs, Lh = _mixed_case(B, D, seed=B + D, id_dtype=id_dtype)
+    block, W, specs, Lh = _mixed_case(B, D, seed=B + D, id_dtype=id_dtype, Lh=Lh)
     dW = {k: np.zeros_like(v) for k, v in W.items()}
     dblock = torch.from_numpy(block).cuda()
     dWt = {k: torch.from_numpy(v).cuda() for k, v in W.items()}
@@ -106,13 +110,16 @@ def test_embed_fwd_bwd_raw_cabi(B, D, id_dtype):
     L.check(L.lib.rbx_embed_sort(darr, n, B, ws.data_ptr(), ws_bytes, status.data_ptr(), None))
     L.check(L.lib.rbx_embed_bwd(darr, n, B, Rd.data_ptr(), width, sc1.data_ptr(), 1, ws.data_ptr(), ws_bytes, None))
     torch.cuda.synchronize()
+    # a 9-row table receives B * Lh * 3 contributions: the fp32 sums (oracle: left to right, kernel: chunked, fixed
+    # order) differ by rounding that grows with sqrt(#terms); 1e-4 holds for the short histories
+    gtol = 1e-4 * max(1.0, (B * Lh) ** 0.5 / 8.0)
     for k in W:
-        assert_close(dG[k], dW[k], 1e-4, "grad " + k)
+        assert_close(dG[k], dW[k], gtol, "grad " + k)
     # accumulate = 1 really accumulates: a second pass doubles the gradients
     L.check(L.lib.rbx_embed_bwd(darr, n, B, Rd.data_ptr(), width, sc1.data_ptr(), 1, ws.data_ptr(), ws_bytes, None))
     torch.cuda.synchronize()
     for k in W:
-        assert_close(dG[k], 2 * dW[k], 2e-4, "accumulated grad " + k)
+        assert_close(dG[k], 2 * dW[k], 2 * gtol, "accumulated grad " + k)
 
 
 def test_bad_descriptors_return_error_codes():
