@@ -52,52 +52,53 @@ class EmbeddingDictLayer(nn.Module):
         self.embedding_layers = nn.ModuleDict()
         self.embedding_callbacks = nn.ModuleDict()
         self._plans = {}
+        plain = not disable_sharing_pretrain          # the LR flavour (width 1) ignores sharing / callbacks / pretrained tables
+        if not plain and embedding_dim != 1:
+            raise AssertionError("disable_sharing_pretrain is the width-1 (LR) flavour")
         for feature, spec in self._feature_map.feature_specs.items():
             if not self.is_required(feature):
                 continue
-            if disable_sharing_pretrain:  # LR flavour
-                assert embedding_dim == 1
-                dim = embedding_dim
-            else:
-                dim = spec.get("embedding_dim", embedding_dim)
-            if (not disable_sharing_pretrain) and "embedding_callback" in spec:
+            if plain and "embedding_callback" in spec:
                 self.embedding_callbacks[feature] = eval(spec["embedding_callback"])
-            if (not disable_sharing_pretrain) and "share_embedding" in spec:
-                # same module object; KeyError if the target is not registered yet (as the reference)
+            if plain and "share_embedding" in spec:
+                # the SAME module object is registered twice; a target that is not registered yet is a KeyError, as in
+                # the reference
                 self.embedding_layers[feature] = self.embedding_layers[spec["share_embedding"]]
                 continue
-            if spec["type"] == "numeric":
-                self.embedding_layers[feature] = nn.Linear(1, dim, bias=False)
-            elif spec["type"] in ("categorical", "sequence"):
-                table = nn.Embedding(spec["vocab_size"], dim, padding_idx=spec.get("padding_idx", None))
-                if (not disable_sharing_pretrain) and "pretrained_emb" in spec:
-                    table = self.load_pretrained_embedding(table, feature_map, feature,
-                                                           freeze=spec["freeze_emb"],
-                                                           padding_idx=spec.get("padding_idx", None))
-                self.embedding_layers[feature] = table
+            holder = self._new_holder(feature, spec, spec.get("embedding_dim", embedding_dim) if plain else 1, plain)
+            if holder is not None:
+                self.embedding_layers[feature] = holder
+
+    def _new_holder(self, feature, spec, width, plain):
+        """The parameter holder of one feature: Linear(1, D) for numeric values, Embedding(V, D) for ids."""
+        kind = spec["type"]
+        if kind == "numeric":
+            return nn.Linear(1, width, bias=False)
+        if kind not in ("categorical", "sequence"):
+            return None
+        pad = spec.get("padding_idx", None)
+        table = nn.Embedding(spec["vocab_size"], width, padding_idx=pad)
+        if plain and "pretrained_emb" in spec:
+            table = self.load_pretrained_embedding(table, self._feature_map, feature, freeze=spec["freeze_emb"],
+                                                   padding_idx=pad)
+        return table
 
     def is_required(self, feature):
-        if self.required_feature_columns and (feature not in self.required_feature_columns):
-            return False
-        if self.not_required_feature_columns and (feature in self.not_required_feature_columns):
-            return False
-        return True
+        wanted, unwanted = self.required_feature_columns, self.not_required_feature_columns
+        return not ((wanted and feature not in wanted) or (unwanted and feature in unwanted))
 
     def get_pretrained_embedding(self, pretrained_path, feature_name):
-        import h5py  # only needed for pretrained tables
-        with h5py.File(pretrained_path, 'r') as hf:
-            return hf[feature_name][:]
+        import h5py  # only needed for pretrained tables (not installed in every image: imported on use)
+        with h5py.File(pretrained_path, 'r') as store:
+            return store[feature_name][:]
 
     def load_pretrained_embedding(self, embedding_matrix, feature_map, feature_name, freeze=False, padding_idx=None):
         import os
-        import numpy as np
-        path = os.path.join(feature_map.data_dir, feature_map.feature_specs[feature_name]["pretrained_emb"])
-        embeddings = self.get_pretrained_embedding(path, feature_name)
+        rel = feature_map.feature_specs[feature_name]["pretrained_emb"]
+        rows = torch.as_tensor(self.get_pretrained_embedding(os.path.join(feature_map.data_dir, rel), feature_name)).float()
         if padding_idx is not None:
-            embeddings[padding_idx] = np.zeros(embeddings.shape[-1])
-        embedding_matrix.weight = torch.nn.Parameter(torch.from_numpy(embeddings).float())
-        if freeze:
-            embedding_matrix.weight.requires_grad = False
+            rows[padding_idx].zero_()
+        embedding_matrix.weight = torch.nn.Parameter(rows, requires_grad=not freeze)
         return embedding_matrix
 
     def dict2tensor(self, embedding_dict):

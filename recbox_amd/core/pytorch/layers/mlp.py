@@ -14,26 +14,9 @@ class MLP_Layer(nn.Module):
     def __init__(self, input_dim, output_dim=None, hidden_units=[], hidden_activations="ReLU",
                  final_activation=None, dropout_rates=[], batch_norm=False, use_bias=True):
         super(MLP_Layer, self).__init__()
-        layers = []
-        if not isinstance(dropout_rates, list):
-            dropout_rates = [dropout_rates] * len(hidden_units)
-        if not isinstance(hidden_activations, list):
-            hidden_activations = [hidden_activations] * len(hidden_units)
-        acts = [dense.activation_by_name(a) for a in hidden_activations]
-        dims = [input_dim] + list(hidden_units)
-        for i in range(len(dims) - 1):
-            layers.append(nn.Linear(dims[i], dims[i + 1], bias=use_bias))
-            if batch_norm:
-                layers.append(nn.BatchNorm1d(dims[i + 1]))
-            if acts[i]:
-                layers.append(acts[i])
-            if dropout_rates[i] > 0:
-                layers.append(nn.Dropout(p=dropout_rates[i]))
-        if output_dim is not None:
-            layers.append(nn.Linear(dims[-1], output_dim, bias=use_bias))
-        if final_activation is not None:
-            layers.append(dense.activation_by_name(final_activation))
-        self.mlp = nn.Sequential(*layers)
+        self.mlp = nn.Sequential(*dense.tower_modules(input_dim, hidden_units, hidden_activations, dropout_rates,
+                                                      batch_norm, use_bias, out_dim=output_dim,
+                                                      out_activation=final_activation))
 
     def forward(self, inputs):
         return dense.run_sequential(self.mlp, inputs)

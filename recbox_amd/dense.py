@@ -33,6 +33,38 @@ def activation_by_name(name):
     raise NotImplementedError("activation={} is not supported.".format(name))
 
 
+def _broadcast(value, n):
+    """A per-layer setting given once (scalar / name / None) or as a list of n entries."""
+    return list(value) if isinstance(value, (list, tuple)) else [value] * n
+
+
+def tower_modules(in_dim, widths, activations, dropouts, batch_norm, bias, out_dim=None, out_activation=None,
+                  norm_after_activation=False):
+    """The children of a tower's ``nn.Sequential`` in the order the reference registers them (so ``mlp.<i>.weight``
+    checkpoint keys line up): per hidden layer Linear, [BatchNorm1d], [activation], [BatchNorm1d when it comes after
+    the activation], [Dropout]; then the optional output Linear and output activation."""
+    widths = list(widths)
+    per_act = _broadcast(activations, len(widths))
+    per_drop = _broadcast(dropouts, len(widths))
+    fan_in = in_dim
+    for width, act, drop in zip(widths, per_act, per_drop):
+        yield nn.Linear(fan_in, width, bias=bias)
+        fan_in = width
+        if batch_norm and not norm_after_activation:
+            yield nn.BatchNorm1d(width)
+        module = activation_by_name(act)
+        if module:
+            yield module
+        if batch_norm and norm_after_activation:
+            yield nn.BatchNorm1d(width)
+        if drop and drop > 0:
+            yield nn.Dropout(p=drop)
+    if out_dim is not None:
+        yield nn.Linear(fan_in, out_dim, bias=bias)
+    if out_activation is not None:
+        yield activation_by_name(out_activation)
+
+
 def run_sequential(seq, x):
     """Forward through an nn.Sequential, routing every nn.Linear through the HIP GEMM."""
     mods = list(seq)

@@ -19,60 +19,57 @@ def _as_list(x):
     return x if isinstance(x, list) else [x]
 
 
+# scalar header fields of feature_map.json, in file order, with the value a fresh map starts from
+_HEADER = (("num_fields", 0), ("total_features", 0), ("input_length", 0), ("labels", None), ("group_id", None))
+
+
 class FeatureMap(object):
     def __init__(self, dataset_id, data_dir):
-        self.data_dir = data_dir
-        self.dataset_id = dataset_id
-        self.num_fields = 0
-        self.total_features = 0
-        self.input_length = 0
+        self.dataset_id, self.data_dir = dataset_id, data_dir       # data_dir: where pretrained tables are looked up
+        for key, start in _HEADER:
+            setattr(self, key, [] if key == "labels" else start)
         self.features = OrderedDict()
-        self.labels = []
         self.column_index = dict()
-        self.group_id = None
         self.default_emb_dim = None
 
-    # ---- persistence (same JSON layout as the reference) ----
+    # ---- persistence (the reference's feature_map.json layout: header scalars + a list of one-entry dicts) ----
     def load(self, json_file, params):
         logging.info("Load feature_map from json: " + json_file)
         with io.open(json_file, "r", encoding="utf-8") as fd:
-            blob = json.load(fd)
-        if blob["dataset_id"] != self.dataset_id:
+            doc = json.load(fd)
+        if doc["dataset_id"] != self.dataset_id:
             raise RuntimeError("dataset_id={} does not match feature_map!".format(self.dataset_id))
-        self.num_fields = blob["num_fields"]
-        self.labels = blob.get("labels", [])
-        self.total_features = blob.get("total_features", 0)
-        self.input_length = blob.get("input_length", 0)
-        self.group_id = blob.get("group_id", None)
+        self.num_fields = doc["num_fields"]                          # the only header field that must be present
+        for key, start in _HEADER[1:]:
+            setattr(self, key, doc.get(key, [] if key == "labels" else start))
         self.default_emb_dim = params.get("embedding_dim", None)
-        self.features = OrderedDict((k, v) for entry in blob["features"] for k, v in entry.items())
-        if params.get("use_features", None):
-            self.features = OrderedDict((name, self.features[name]) for name in params["use_features"])
-        if params.get("feature_specs", None):
-            self.update_feature_specs(params["feature_specs"])
+        specs = OrderedDict()
+        for entry in doc["features"]:
+            specs.update(entry)
+        keep = params.get("use_features", None)
+        self.features = OrderedDict((name, specs[name]) for name in keep) if keep else specs
+        overrides = params.get("feature_specs", None)
+        if overrides:
+            self.update_feature_specs(overrides)
         self.set_column_index()
 
     def update_feature_specs(self, feature_specs):
-        for col in feature_specs:
-            for name in _as_list(col["name"]):
-                for key, value in col.items():
-                    if key != "name":
-                        self.features[name][key] = value
+        for patch in feature_specs:
+            settings = dict((k, v) for k, v in patch.items() if k != "name")
+            for name in _as_list(patch["name"]):
+                self.features[name].update(settings)
 
     def save(self, json_file):
         logging.info("Save feature_map to json: " + json_file)
         os.makedirs(os.path.dirname(json_file), exist_ok=True)
-        blob = OrderedDict()
-        blob["dataset_id"] = self.dataset_id
-        blob["num_fields"] = self.num_fields
-        blob["total_features"] = self.total_features
-        blob["input_length"] = self.input_length
-        blob["labels"] = self.labels
-        if self.group_id is not None:
-            blob["group_id"] = self.group_id
-        blob["features"] = [{k: v} for k, v in self.features.items()]
+        doc = OrderedDict(dataset_id=self.dataset_id)
+        for key, _ in _HEADER:
+            if key == "group_id" and self.group_id is None:
+                continue
+            doc[key] = getattr(self, key)
+        doc["features"] = [{name: spec} for name, spec in self.features.items()]
         with open(json_file, "w") as fd:
-            json.dump(blob, fd, indent=4)
+            json.dump(doc, fd, indent=4)
 
     # ---- queries ----
     def _selected(self, feature_source):
@@ -93,19 +90,15 @@ class FeatureMap(object):
         return total
 
     def set_column_index(self):
+        """feature -> column (or list of ``max_len`` columns) of the flat [B, cols] batch; labels follow the inputs."""
         logging.info("Set column index...")
-        col = 0
+        cursor = 0
         for name, spec in self.features.items():
-            if "max_len" in spec:
-                self.column_index[name] = list(range(col, col + spec["max_len"]))
-                col += spec["max_len"]
-            else:
-                self.column_index[name] = col
-                col += 1
-        self.input_length = col
-        for label in self.labels:
-            self.column_index[label] = col
-            col += 1
+            width = spec.get("max_len")
+            self.column_index[name] = cursor if width is None else list(range(cursor, cursor + width))
+            cursor += 1 if width is None else width
+        self.input_length = cursor
+        self.column_index.update((label, cursor + k) for k, label in enumerate(self.labels))
 
     def get_column_index(self, feature):
         if feature not in self.column_index:

@@ -51,29 +51,10 @@ class MLP_Block(nn.Module):
                  output_activation=None, dropout_rates=0.0, batch_norm=False, norm_before_activation=True,
                  use_bias=True):
         super(MLP_Block, self).__init__()
-        layers = []
-        hidden_units = list(hidden_units)
-        if not isinstance(dropout_rates, list):
-            dropout_rates = [dropout_rates] * len(hidden_units)
-        if not isinstance(hidden_activations, list):
-            hidden_activations = [hidden_activations] * len(hidden_units)
-        acts = [dense.activation_by_name(a) for a in hidden_activations]
-        dims = [input_dim] + hidden_units
-        for i in range(len(dims) - 1):
-            layers.append(nn.Linear(dims[i], dims[i + 1], bias=use_bias))
-            if norm_before_activation and batch_norm:
-                layers.append(nn.BatchNorm1d(dims[i + 1]))
-            if acts[i]:
-                layers.append(acts[i])
-            if (not norm_before_activation) and batch_norm:
-                layers.append(nn.BatchNorm1d(dims[i + 1]))
-            if dropout_rates[i] > 0:
-                layers.append(nn.Dropout(p=dropout_rates[i]))
-        if output_dim is not None:
-            layers.append(nn.Linear(dims[-1], output_dim, bias=use_bias))
-        if output_activation is not None:
-            layers.append(dense.activation_by_name(output_activation))
-        self.mlp = nn.Sequential(*layers)
+        self.mlp = nn.Sequential(*dense.tower_modules(input_dim, hidden_units, hidden_activations, dropout_rates,
+                                                      batch_norm, use_bias, out_dim=output_dim,
+                                                      out_activation=output_activation,
+                                                      norm_after_activation=not norm_before_activation))
 
     def forward(self, inputs):
         return dense.run_sequential(self.mlp, inputs)

@@ -75,81 +75,83 @@ class FeatureEmbeddingDict(nn.Module):
         self.embedding_layers = nn.ModuleDict()
         self.feature_encoders = nn.ModuleDict()
         self._plans = {}
-        lr_mode = (not (use_pretrain and use_sharing)) and embedding_dim == 1
+        # "LR mode": a width-1 layer that neither loads pretrained tables nor shares them is the first-order term of
+        # LogisticRegression -- every table is [V, 1] and sequences are summed
+        first_order = embedding_dim == 1 and not (use_pretrain and use_sharing)
         for feature, spec in self._feature_map.features.items():
             if not self.is_required(feature):
                 continue
-            if lr_mode:
-                dim = 1
-                if spec["type"] == "sequence":
-                    self.feature_encoders[feature] = layers.MaskedSumPooling()
-            else:
-                dim = spec.get("embedding_dim", embedding_dim)
-                if spec.get("feature_encoder", None):
-                    self.feature_encoders[feature] = self.get_feature_encoder(spec["feature_encoder"])
-            # sharing only applies when the target is already registered (else a separate table, as the reference)
-            if use_sharing and spec.get("share_embedding") in self.embedding_layers:
-                self.embedding_layers[feature] = self.embedding_layers[spec["share_embedding"]]
+            encoder = self._encoder_for(spec, first_order)
+            if encoder is not None:
+                self.feature_encoders[feature] = encoder
+            target = spec.get("share_embedding") if use_sharing else None
+            if target in self.embedding_layers:          # an alias; a target that is not registered (yet) gets its own table
+                self.embedding_layers[feature] = self.embedding_layers[target]
                 continue
-            if spec["type"] == "numeric":
-                self.embedding_layers[feature] = nn.Linear(1, dim, bias=False)
-            elif spec["type"] in ("categorical", "sequence"):
-                table = nn.Embedding(spec["vocab_size"], dim, padding_idx=spec.get("padding_idx", None))
-                if use_pretrain and "pretrained_emb" in spec:
-                    table = self.load_pretrained_embedding(table, feature_map, feature, freeze=spec["freeze_emb"],
-                                                           padding_idx=spec.get("padding_idx", None))
-                self.embedding_layers[feature] = table
+            holder = self._new_holder(feature, spec, 1 if first_order else spec.get("embedding_dim", embedding_dim))
+            if holder is not None:
+                self.embedding_layers[feature] = holder
         self.reset_parameters()
 
+    def _encoder_for(self, spec, first_order):
+        if first_order:
+            return layers.MaskedSumPooling() if spec["type"] == "sequence" else None
+        text = spec.get("feature_encoder", None)
+        return self.get_feature_encoder(text) if text else None
+
+    def _new_holder(self, feature, spec, width):
+        kind = spec["type"]
+        if kind == "numeric":
+            return nn.Linear(1, width, bias=False)
+        if kind not in ("categorical", "sequence"):
+            return None
+        pad = spec.get("padding_idx", None)
+        table = nn.Embedding(spec["vocab_size"], width, padding_idx=pad)
+        if self.use_pretrain and "pretrained_emb" in spec:
+            table = self.load_pretrained_embedding(table, self._feature_map, feature, freeze=spec["freeze_emb"],
+                                                   padding_idx=pad)
+        return table
+
     def get_feature_encoder(self, encoder):
+        texts = encoder if isinstance(encoder, list) else None
         try:
-            if type(encoder) == list:
-                return nn.Sequential(*[eval(enc) for enc in encoder])
-            return eval(encoder)
+            return nn.Sequential(*[eval(t) for t in texts]) if texts is not None else eval(encoder)
         except Exception:
             raise ValueError("feature_encoder={} is not supported.".format(encoder))
 
     def reset_parameters(self):
+        """Initialiser on every trainable table of this layer (rows 1: when the table has a padding row, which stays
+        zero); pretrained tables and frozen shared tables are left alone."""
         self.embedding_initializer = get_initializer(self.embedding_initializer)
         for name, module in self.embedding_layers.items():
             spec = self._feature_map.features[name]
-            if self.use_pretrain and "pretrained_emb" in spec:
+            loaded = self.use_pretrain and "pretrained_emb" in spec
+            frozen_alias = "share_embedding" in spec and module.weight.requires_grad is False
+            if loaded or frozen_alias or type(module) != nn.Embedding:
                 continue
-            if "share_embedding" in spec and module.weight.requires_grad is False:
-                continue
-            if type(module) == nn.Embedding:
-                if module.padding_idx is not None:
-                    self.embedding_initializer(module.weight[1:, :])
-                else:
-                    self.embedding_initializer(module.weight)
+            self.embedding_initializer(module.weight if module.padding_idx is None else module.weight[1:, :])
 
     def is_required(self, feature):
-        spec = self._feature_map.features[feature]
-        if spec["type"] == "meta":
+        if self._feature_map.features[feature]["type"] == "meta":
             return False
-        if self.required_feature_columns and (feature not in self.required_feature_columns):
-            return False
-        if self.not_required_feature_columns and (feature in self.not_required_feature_columns):
-            return False
-        return True
+        wanted, unwanted = self.required_feature_columns, self.not_required_feature_columns
+        return not ((wanted and feature not in wanted) or (unwanted and feature in unwanted))
 
     def get_pretrained_embedding(self, pretrained_path, feature_name):
-        import h5py  # only needed for pretrained tables
-        with h5py.File(pretrained_path, 'r') as hf:
-            return hf[feature_name][:]
+        import h5py  # only needed for pretrained tables (imported on use)
+        with h5py.File(pretrained_path, 'r') as store:
+            return store[feature_name][:]
 
     def load_pretrained_embedding(self, embedding_matrix, feature_map, feature_name, freeze=False, padding_idx=None):
         import os
-        import numpy as np
-        path = os.path.join(feature_map.data_dir, feature_map.features[feature_name]["pretrained_emb"])
-        embeddings = self.get_pretrained_embedding(path, feature_name)
+        rel = feature_map.features[feature_name]["pretrained_emb"]
+        rows = torch.as_tensor(self.get_pretrained_embedding(os.path.join(feature_map.data_dir, rel), feature_name)).float()
+        if rows.shape[-1] != embedding_matrix.embedding_dim:
+            raise AssertionError("{}'s embedding_dim is not correctly set to match its pretrained_emb shape"
+                                 .format(feature_name))
         if padding_idx is not None:
-            embeddings[padding_idx] = np.zeros(embeddings.shape[-1])
-        assert embeddings.shape[-1] == embedding_matrix.embedding_dim, \
-            "{}'s embedding_dim is not correctly set to match its pretrained_emb shape".format(feature_name)
-        embedding_matrix.weight = torch.nn.Parameter(torch.from_numpy(embeddings).float())
-        if freeze:
-            embedding_matrix.weight.requires_grad = False
+            rows[padding_idx].zero_()
+        embedding_matrix.weight = torch.nn.Parameter(rows, requires_grad=not freeze)
         return embedding_matrix
 
     def dict2tensor(self, embedding_dict, feature_source=[], feature_type=[], dynamic_emb_dim=False):
