@@ -195,11 +195,13 @@ def main():
         return m
 
     model = build_model()
+    from recbox_amd.ranking.pytorch.torch_utils import get_loss
+    loss_fn = get_loss("binary_crossentropy")
 
     def eager_step():
         model.zero_grad(set_to_none=True)
         prob = model(X)["y_pred"]
-        loss = torch.nn.functional.binary_cross_entropy(prob, y, reduction="mean")
+        loss = loss_fn(prob, y, reduction="mean")     # the harness's get_loss("binary_crossentropy")
         if sharded:
             (loss / world).backward()         # global-mean loss: shard owners sum contributions of every rank
             model.sync_grads()                # replicated small tables / numeric weights / bias: one all-reduce

@@ -298,6 +298,16 @@ int rbx_cross_fwd(const float* d_x0, const float* d_xi, const float* d_h, const 
 int rbx_cross_bwd(const float* d_x0, const float* d_h, const float* d_dout, int64_t rows, int32_t dim, int32_t h_cols,
                   float* d_dx0, float* d_dh, void* stream);
 
+/* ---- the ranking harness's loss: F.binary_cross_entropy(y_pred, y_true, reduction='mean') on sigmoid outputs
+ * (ranking/pytorch/models/ranking_model.py:69, ranking/pytorch/torch_utils.py:54-65).  torch semantics: both log terms
+ * clamped at -100; d_loss[1] = mean; backward d_dprob = d_dloss[0] / n * (p - y) / max(p (1 - p), 1e-12).
+ * Block partials + fixed-order final sum: deterministic. */
+size_t rbx_bce_workspace_size(int64_t n);
+int rbx_bce_mean_fwd(const float* d_prob, const float* d_target, int64_t n, float* d_loss, void* d_workspace,
+                     size_t workspace_bytes, void* stream);
+int rbx_bce_mean_bwd(const float* d_prob, const float* d_target, const float* d_dloss, int64_t n, float* d_dprob,
+                     void* stream);
+
 /* ---- dense tower: y = act(x W^T + b) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------
  * core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58,
  * third_party/rechub/basic/layers.py:255-263.  x[m,k] with row stride x_stride >= k floats (a column block of

@@ -283,3 +283,92 @@ extern "C" int rbx_cross_bwd(const float* d_x0, const float* d_h, const float* d
                      d_dout, static_cast<long long>(rows), dim, h_cols, d_dx0, d_dh);
   return check_launch("cross_bwd_kernel");
 }
+
+// ---- binary cross entropy on probabilities, mean-reduced (the ranking harness's loss) -------------------------
+// ranking/pytorch/models/ranking_model.py:69 + ranking/pytorch/torch_utils.py:54-65: F.binary_cross_entropy(y_pred,
+// y_true, reduction='mean') on SIGMOID OUTPUTS.  torch semantics: log terms clamped at -100; backward
+// (p - y) / max(p (1 - p), 1e-12) * g / N.  ATen runs the element-wise loss, a 16 us generic reduction of 65 536
+// values, a division and two backward kernels; here: one pass with block partials, a fixed-order final sum, one
+// backward pass.  Deterministic (no atomics).
+namespace rbx {
+
+constexpr int kBceBlock = 1024;       // elements per workgroup of the forward pass
+
+__global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                          const long long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const long long base = static_cast<long long>(blockIdx.x) * kBceBlock;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < kBceBlock / 256; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    if (i < n) {
+      const float pi = p[i], yi = y[i];
+      const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(log1pf(-pi), -100.f);
+      acc -= yi * lp + (1.f - yi) * lq;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one workgroup: fixed-order sum of the block partials, times 1/n
+__global__ __launch_bounds__(256) void bce_final_kernel(const float* __restrict__ partial, const int nblocks, const float inv_n,
+                                                        float* __restrict__ loss) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) acc += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y,
+                                                      const float* __restrict__ gloss, const long long n, const float inv_n,
+                                                      float* __restrict__ dp) {
+  const float g = gloss[0] * inv_n;
+  const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += step) {
+    const float pi = p[i];
+    dp[i] = g * (pi - y[i]) / fmaxf((1.f - pi) * pi, 1e-12f);
+  }
+}
+
+}  // namespace rbx
+
+extern "C" size_t rbx_bce_workspace_size(int64_t n) {
+  return n > 0 ? static_cast<size_t>((n + rbx::kBceBlock - 1) / rbx::kBceBlock) * sizeof(float) + 256 : 0;
+}
+
+extern "C" int rbx_bce_mean_fwd(const float* d_prob, const float* d_target, int64_t n, float* d_loss, void* d_workspace,
+                                size_t workspace_bytes, void* stream) {
+  using namespace rbx;
+  if (n <= 0) return fail(RBX_ERR_INVALID, "bce: empty input (the mean of no elements is undefined)");
+  if (!d_prob || !d_target || !d_loss) return fail(RBX_ERR_INVALID, "bce: NULL tensor");
+  if (d_workspace == nullptr || workspace_bytes < rbx_bce_workspace_size(n)) return fail(RBX_ERR_WORKSPACE, "bce: workspace too small");
+  const long long nb = (n + kBceBlock - 1) / kBceBlock;
+  if (nb >= INT_MAX) return fail(RBX_ERR_UNSUPPORTED, "bce: too many elements");
+  float* partial = static_cast<float*>(d_workspace);
+  hipLaunchKernelGGL(bce_partial_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, as_stream(stream), d_prob, d_target,
+                     static_cast<long long>(n), partial);
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, static_cast<int>(nb),
+                     1.0f / static_cast<float>(n), d_loss);
+  return check_launch("bce forward kernels");
+}
+
+extern "C" int rbx_bce_mean_bwd(const float* d_prob, const float* d_target, const float* d_dloss, int64_t n, float* d_dprob,
+                                void* stream) {
+  using namespace rbx;
+  if (n <= 0) return RBX_OK;
+  if (!d_prob || !d_target || !d_dloss || !d_dprob) return fail(RBX_ERR_INVALID, "bce_bwd: NULL tensor");
+  long long blocks = (n + 255) / 256;
+  if (blocks > kCUs * 8) blocks = kCUs * 8;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_prob, d_target,
+                     d_dloss, static_cast<long long>(n), 1.0f / static_cast<float>(n), d_dprob);
+  return check_launch("bce_bwd_kernel");
+}

@@ -80,8 +80,7 @@ class ShardedFMStep(object):
         self.tables = tables = model.tables
         self.group = tables.group
         self.W = W = tables.world_size
-        self.loss_fn = loss_fn or (lambda prob, target: torch.nn.functional.binary_cross_entropy(
-            prob, target, reduction="mean"))
+        self.loss_fn = loss_fn or ops.binary_cross_entropy      # the ranking harness's mean BCE on sigmoid outputs
         ids = model.sharded_ids(X)
         self.B, self.T = ids.shape
         self.cap = cap = tables.capacity_for(ids.numel())

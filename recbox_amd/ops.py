@@ -1047,6 +1047,41 @@ def cross(x0, xi, h, bias=None):
     return _Cross.apply(x0, xi, h, bias)
 
 
+class _BceMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob, target):
+        _require_cuda(prob, "y_pred")
+        p = prob.contiguous().float().view(-1)
+        y = target.contiguous().float().view(-1)
+        if p.numel() != y.numel():
+            raise ValueError("Using a target size ({}) that is different to the input size ({}) is deprecated. "
+                             "Please ensure they have the same size.".format(tuple(target.shape), tuple(prob.shape)))
+        n = p.numel()
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        ws_bytes = lib.rbx_bce_workspace_size(n)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=p.device)
+        check(lib.rbx_bce_mean_fwd(_ptr(p), _ptr(y), n, _ptr(loss), _ptr(ws), ws_bytes, _stream()))
+        ctx.save_for_backward(p, y)
+        ctx.shape = prob.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, y = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        g = g.contiguous().float().view(1)
+        check(lib.rbx_bce_mean_bwd(_ptr(p), _ptr(y), _ptr(g), p.numel(), _ptr(dp), _stream()))
+        return dp.view(ctx.shape), None
+
+
+def binary_cross_entropy(y_pred, y_true, reduction="mean"):
+    """``F.binary_cross_entropy(y_pred, y_true, reduction='mean')`` (the ranking harness's loss on sigmoid outputs)
+    as one forward pass + a fixed-order final sum and one backward pass (rbx_bce_mean_fwd/bwd)."""
+    if reduction != "mean":
+        raise NotImplementedError("binary_cross_entropy: only reduction='mean' runs on the fused kernel")
+    return _BceMean.apply(y_pred, y_true)
+
+
 class _Attention(torch.autograd.Function):
     """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
 

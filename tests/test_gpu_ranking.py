@@ -381,6 +381,34 @@ def test_cross_net_golden(version):
         assert_close(one(xc.detach(), xc.detach()), want.detach(), TOL, "CrossInteraction")
 
 
+@pytest.mark.parametrize("n", [1, 513, 65536])
+def test_bce_mean_vs_torch(n):
+    """rbx_bce_mean_fwd/bwd == F.binary_cross_entropy(reduction='mean') of torch CPU, including the -100 log clamp at
+    p = 0 / 1 and the 1e-12 clamp of the backward."""
+    from recbox_amd.ranking.pytorch.torch_utils import get_loss
+    g = torch.Generator().manual_seed(n)
+    p = torch.rand(n, 1, generator=g)
+    y = (torch.rand(n, 1, generator=g) < 0.3).float()
+    if n > 4:
+        p[0], p[1], y[0], y[1] = 0.0, 1.0, 1.0, 0.0           # saturated wrong predictions: clamped, not inf
+        p[2], p[3] = 1e-9, 1.0 - 1e-7
+    pr = p.clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy(pr, y, reduction="mean")
+    (ref * 3.0).backward()
+    pc = p.cuda().requires_grad_(True)
+    out = get_loss("binary_crossentropy")(pc, y.cuda(), reduction="mean")
+    (out * 3.0).backward()
+    assert_close(out.reshape(1), ref.detach().reshape(1), 1e-5 * max(1.0, float(ref)), "loss")
+    scale = float(pr.grad.abs().max())
+    assert float((pc.grad.cpu() - pr.grad).abs().max()) <= 1e-5 * max(1.0, scale)
+    a = get_loss("bce")(pc.detach(), y.cuda())
+    b = get_loss("bce")(pc.detach(), y.cuda())
+    assert torch.equal(a, b)                                   # fixed-order reduction: bit-identical
+    with pytest.raises(NotImplementedError):
+        get_loss("no_such_loss")
+    assert get_loss("mse_loss") is torch.nn.functional.mse_loss
+
+
 def test_backward_is_deterministic_and_linear():
     """Full-size property checks (B = 65 536, 26 fields): two backward passes are
     bit-identical (no float atomics) and column sums of dW equal column sums of dY."""
