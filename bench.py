@@ -258,10 +258,18 @@ def main():
     if not plain_eager:
         # a graph replay cannot be bracketed from Python: time the dominant kernel with HIP events
         # on the launch stream over the same steps launched eagerly right after the timed region
+        # Launched eagerly the step is host-bound (the GPU idles between kernels and the kernel would be timed on a
+        # drained, down-clocked device), so the stream is first loaded with ~15 ms of fills: the eager launches then
+        # queue up behind them and run back to back, as in the replay.  Events are in-stream: they bracket the kernel only.
+        n_timed = min(args.steps, 10)
+        ballast = torch.empty(1 << 28, dtype=torch.float32, device=dev)          # 1 GiB
+        for _ in range(80):
+            ballast.zero_()
         ops.kernel_timer = timer
-        for _ in range(min(args.steps, 20)):
+        for _ in range(n_timed):
             eager_step()
         torch.cuda.synchronize()
+        del ballast
     ops.kernel_timer = None
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
