@@ -225,15 +225,26 @@ def main():
     elif sharded and cap_factor and model.tables is not None:
         # padded sync-free exchange: the step is four hipGraph pieces with the RCCL collectives between them
         from recbox_amd.graph import ShardedFMStep
+        use_graphs = not args.eager
         for _ in range(4):
-            step = ShardedFMStep(model, X, y, graphs=not args.eager)
+            try:
+                step = ShardedFMStep(model, X, y, graphs=use_graphs)
+            except Exception as exc:           # a capture that this stack refuses: same pieces, launched eagerly
+                if not use_graphs:
+                    raise
+                if rank == 0:
+                    print("[bench] piecewise graph capture failed (%s: %s); running the pieces eagerly"
+                          % (type(exc).__name__, exc), file=sys.stderr)
+                torch.cuda.synchronize()
+                use_graphs = False
+                step = ShardedFMStep(model, X, y, graphs=False)
             step()
             if not overflowed():
                 break
             cap_factor *= 2                   # skewed ids: some owner received more than its slots; start over
             del step
             model = build_model()
-        graph_note = "6 hipGraph pieces + RCCL collectives between them" if not args.eager else "eager launches"
+        graph_note = "7 hipGraph pieces + RCCL collectives between them" if use_graphs else "eager launches"
 
     for _ in range(args.warmup):
         step()
@@ -242,7 +253,7 @@ def main():
         timer = ops.KernelTimer(lambda m: m[0] == "fm_fwd")
     else:
         timer = ops.KernelTimer(lambda m: m[0] == "embed_fwd" and m[2] == n_fields * args.dim)
-    plain_eager = step is eager_step or (sharded and args.eager)
+    plain_eager = step is eager_step or (sharded and graph_note == "eager launches")
     if plain_eager:
         ops.kernel_timer = timer
     if world > 1:
