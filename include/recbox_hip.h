@@ -133,6 +133,16 @@ int rbx_interaction_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch,
 int rbx_interaction_bwd(const float* d_emb, int64_t emb_stride_b, const float* d_dout, int64_t batch, int32_t n_fields,
                         int32_t dim, int32_t mode, float* d_demb, int64_t demb_stride_b, void* stream);
 
+/* ---- the pairing step of BilinearInteraction / BilinearInteractionV2
+ * (ranking/pytorch/layers/interactions/bilinear_interaction.py:24-90).  out[b, p(i,j), :] = left * right[b, j, :] over
+ * the F(F-1)/2 pairs i < j in triu order; per_pair == 0: left[B, F, D] = hidden (e_i W or e_i W_i: field_all /
+ * field_each), indexed by i; per_pair == 1: left[B, P, D] = e_i W_p (field_interaction), indexed by the pair.  The
+ * products with W run on rbx_linear_fwd.  Backward writes d_dleft (same shape as left) and d_dright[B, F, D]. */
+int rbx_pairmul_fwd(const float* d_left, const float* d_right, int64_t batch, int32_t n_fields, int32_t dim,
+                    int32_t per_pair, float* d_out, void* stream);
+int rbx_pairmul_bwd(const float* d_left, const float* d_right, const float* d_dout, int64_t batch, int32_t n_fields,
+                    int32_t dim, int32_t per_pair, float* d_dleft, float* d_dright, void* stream);
+
 /* ---- fused FM model body: gather + LR + second-order interaction, [B,F,D] never stored ----
  * Replaces the op sequence feature_embedding.py:188-214 -> logistic_regression.py:30-35 ->
  * inner_product.py:41-48 -> factorization_machine.py:30-34 (forward and autograd backward).

@@ -550,6 +550,26 @@ def gen_cross_net(fuxictr, B=7, dim=24, layers=3):
     save("cross_net", **groups)
 
 
+def gen_bilinear(fuxictr, B=7, F=5, D=4):
+    """BilinearInteraction (pair loop) and BilinearInteractionV2 (index_select) of the live reference, three W layouts."""
+    import fuxictr.pytorch.layers as FL
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, F, D, generator=g)
+    R = torch.randn(B, F * (F - 1) // 2, D, generator=g)
+    groups = {"in": {"x": x, "R": R}}
+    for kind in ("field_all", "field_each", "field_interaction"):
+        for ver, cls in (("v1", FL.BilinearInteraction), ("v2", FL.BilinearInteractionV2)):
+            layer = cls(F, D, bilinear_type=kind)
+            with torch.no_grad():
+                layer.bilinear_W.copy_(torch.randn(layer.bilinear_W.shape, generator=torch.Generator().manual_seed(5)) * 0.3)
+            xi = x.clone().requires_grad_(True)
+            out = layer(xi)
+            (out * R).sum().backward()
+            groups["out_%s_%s" % (kind, ver)] = {"y": out, "dx": xi.grad, "W": layer.bilinear_W.detach(),
+                                                 "dW": layer.bilinear_W.grad}
+    save("bilinear", **groups)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -573,6 +593,7 @@ def main():
     gen_matching_loader(recbox)
     gen_retrieval_metrics(recbox)
     gen_cross_net(fuxictr)
+    gen_bilinear(fuxictr)
 
 
 if __name__ == "__main__":

@@ -168,6 +168,76 @@ __global__ __launch_bounds__(64) void pair_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// ---- bilinear pair products (BilinearInteraction / BilinearInteractionV2,
+// ranking/pytorch/layers/interactions/bilinear_interaction.py:24-90) -------------------------------------------------
+// out[b, p(i,j), :] = left(b, p, :) * right[b, j, :] for the F(F-1)/2 pairs i < j in triu order, where left is the
+// field-wise transformed embedding hidden[b, i, :] = e_i W (per_pair == 0: field_all / field_each, left is [B, F, D])
+// or the pair-wise one e_i W_p (per_pair == 1: field_interaction, left is [B, P, D]).  The matrix products are
+// rbx_linear_fwd; this is the pairing.  One wavefront per sample, its [F, D] blocks in LDS.
+__global__ __launch_bounds__(64) void pairmul_fwd_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                         const int F, const int D, const int per_pair,
+                                                         float* __restrict__ out) {
+  extern __shared__ float se[];                       // right [F, D], then left [F, D] when it is per field
+  const long long b = blockIdx.x;
+  const int FD = F * D, P = F * (F - 1) / 2;
+  float* sl = se + FD;
+  for (int i = threadIdx.x; i < FD; i += 64) {
+    se[i] = right[b * FD + i];
+    if (!per_pair) sl[i] = left[b * FD + i];
+  }
+  __syncthreads();
+  for (int i = 0; i < F - 1; ++i) {
+    const int n = (F - 1 - i) * D;                    // contiguous run of outputs for row i
+    const long long o0 = (b * P + pair_index(i, i + 1, F)) * static_cast<long long>(D);
+    for (int t = threadIdx.x; t < n; t += 64) {
+      const int j = i + 1 + t / D, d = t % D;
+      const float l = per_pair ? left[o0 + t] : sl[i * D + d];
+      out[o0 + t] = l * se[j * D + d];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void pairmul_bwd_kernel(const float* __restrict__ left, const float* __restrict__ right,
+                                                         const float* __restrict__ g, const int F, const int D,
+                                                         const int per_pair, float* __restrict__ dleft,
+                                                         float* __restrict__ dright) {
+  extern __shared__ float se[];
+  const long long b = blockIdx.x;
+  const int FD = F * D, P = F * (F - 1) / 2;
+  float* sl = se + FD;
+  for (int i = threadIdx.x; i < FD; i += 64) {
+    se[i] = right[b * FD + i];
+    if (!per_pair) sl[i] = left[b * FD + i];
+  }
+  __syncthreads();
+  const float* gb = g + b * P * static_cast<long long>(D);
+  const float* lb = left + b * P * static_cast<long long>(D);   // only read when per_pair
+  if (per_pair) {                                      // d left[b, p, :] = g * right[j_p]
+    for (int i = 0; i < F - 1; ++i) {
+      const int n = (F - 1 - i) * D;
+      const long long o0 = pair_index(i, i + 1, F) * static_cast<long long>(D);
+      for (int t = threadIdx.x; t < n; t += 64) {
+        const int j = i + 1 + t / D, d = t % D;
+        dleft[b * P * static_cast<long long>(D) + o0 + t] = gb[o0 + t] * se[j * D + d];
+      }
+    }
+  }
+  for (int t = threadIdx.x; t < FD; t += 64) {
+    const int x = t / D, d = t % D;
+    float as_left = 0.f, as_right = 0.f;
+    for (int j = x + 1; j < F; ++j) {                  // x is the left field of pair (x, j)
+      const int p = pair_index(x, j, F);
+      as_left += gb[p * D + d] * se[j * D + d];
+    }
+    for (int i = 0; i < x; ++i) {                      // x is the right field of pair (i, x)
+      const int p = pair_index(i, x, F);
+      as_right += gb[p * D + d] * (per_pair ? lb[p * D + d] : sl[i * D + d]);
+    }
+    if (!per_pair) dleft[b * FD + t] = as_left;
+    dright[b * FD + t] = as_right;
+  }
+}
+
 template <int G, int NV, bool VEC>
 static int launch_fm(bool bwd, const float* emb, const float* dout, int64_t B, int F, int D, int mode, float* out,
                      long long sb, long long dsb, hipStream_t s) {
@@ -238,4 +308,31 @@ extern "C" int rbx_interaction_bwd(const float* d_emb, int64_t emb_stride_b, con
                                    int32_t n_fields, int32_t dim, int32_t mode, float* d_demb, int64_t demb_stride_b,
                                    void* stream) {
   return rbx::run_interaction(true, d_emb, emb_stride_b, d_dout, batch, n_fields, dim, mode, d_demb, demb_stride_b, stream);
+}
+
+extern "C" int rbx_pairmul_fwd(const float* d_left, const float* d_right, int64_t batch, int32_t n_fields, int32_t dim,
+                               int32_t per_pair, float* d_out, void* stream) {
+  using namespace rbx;
+  if (batch == 0) return RBX_OK;
+  if (batch < 0 || n_fields <= 0 || dim <= 0) return fail(RBX_ERR_INVALID, "pairmul: bad shape");
+  if (!d_left || !d_right || !d_out) return fail(RBX_ERR_INVALID, "pairmul: NULL tensor");
+  if (n_fields < 2) return RBX_OK;
+  const size_t lds = static_cast<size_t>(2) * n_fields * dim * sizeof(float);
+  if (lds > 64 * 1024) return fail(RBX_ERR_UNSUPPORTED, "pairmul: F*D=%d too large", n_fields * dim);
+  hipLaunchKernelGGL(pairmul_fwd_kernel, dim3(static_cast<unsigned>(batch)), dim3(64), lds, as_stream(stream), d_left, d_right,
+                     n_fields, dim, per_pair, d_out);
+  return check_launch("pairmul_fwd_kernel");
+}
+
+extern "C" int rbx_pairmul_bwd(const float* d_left, const float* d_right, const float* d_dout, int64_t batch, int32_t n_fields,
+                               int32_t dim, int32_t per_pair, float* d_dleft, float* d_dright, void* stream) {
+  using namespace rbx;
+  if (batch == 0) return RBX_OK;
+  if (batch < 0 || n_fields <= 0 || dim <= 0) return fail(RBX_ERR_INVALID, "pairmul_bwd: bad shape");
+  if (!d_left || !d_right || !d_dout || !d_dleft || !d_dright) return fail(RBX_ERR_INVALID, "pairmul_bwd: NULL tensor");
+  const size_t lds = static_cast<size_t>(2) * n_fields * dim * sizeof(float);
+  if (lds > 64 * 1024) return fail(RBX_ERR_UNSUPPORTED, "pairmul_bwd: F*D=%d too large", n_fields * dim);
+  hipLaunchKernelGGL(pairmul_bwd_kernel, dim3(static_cast<unsigned>(batch)), dim3(64), lds, as_stream(stream), d_left, d_right,
+                     d_dout, n_fields, dim, per_pair, d_dleft, d_dright);
+  return check_launch("pairmul_bwd_kernel");
 }

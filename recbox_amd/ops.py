@@ -1082,6 +1082,40 @@ def binary_cross_entropy(y_pred, y_true, reduction="mean"):
     return _BceMean.apply(y_pred, y_true)
 
 
+class _PairMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, left, right, per_pair):
+        _require_cuda(left, "left")
+        left, right = left.contiguous().float(), right.contiguous().float()
+        B, F, D = right.shape
+        P = F * (F - 1) // 2
+        if left.shape[0] != B or left.shape[2] != D or left.shape[1] != (P if per_pair else F):
+            raise ValueError("pair_mul: left must be [B, F, D] (per field) or [B, F(F-1)/2, D] (per pair) matching "
+                             "right [B, F, D]")
+        per_pair = 1 if per_pair else 0
+        out = torch.empty((B, P, D), dtype=torch.float32, device=right.device)
+        check(lib.rbx_pairmul_fwd(_ptr(left), _ptr(right), B, F, D, per_pair, _ptr(out), _stream()))
+        ctx.save_for_backward(left, right)
+        ctx.per_pair = per_pair
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        left, right = ctx.saved_tensors
+        B, F, D = right.shape
+        g = g.contiguous().float()
+        dleft, dright = torch.zeros_like(left), torch.zeros_like(right)
+        check(lib.rbx_pairmul_bwd(_ptr(left), _ptr(right), _ptr(g), B, F, D, ctx.per_pair, _ptr(dleft), _ptr(dright),
+                                  _stream()))
+        return dleft, dright, None
+
+
+def pair_mul(left, right, per_pair=False):
+    """out[b, p(i,j), :] = left(b, p, :) * right[b, j, :] over the pairs i < j (triu order): the pairing step of the
+    bilinear interaction.  left is [B, F, D] (indexed by i) or [B, F(F-1)/2, D] (indexed by the pair)."""
+    return _PairMul.apply(left, right, bool(per_pair))
+
+
 class _Attention(torch.autograd.Function):
     """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
 

@@ -7,7 +7,8 @@ from torch import nn
 
 from .... import ops
 
-__all__ = ["InnerProductInteraction", "CrossInteraction", "CrossNet", "CrossNetV2"]
+__all__ = ["InnerProductInteraction", "CrossInteraction", "CrossNet", "CrossNetV2", "BilinearInteraction",
+           "BilinearInteractionV2"]
 
 
 class InnerProductInteraction(nn.Module):
@@ -77,3 +78,52 @@ class CrossNetV2(nn.Module):
             layer = self.cross_layers[i]
             X_i = ops.cross(X_0, X_i, ops.linear(X_i, layer.weight, layer.bias))
         return X_i
+
+
+class BilinearInteractionV2(nn.Module):
+    """FiBiNET's bilinear interaction (bilinear_interaction.py:24-90; V1 and V2 of the reference compute the same
+    [B, F(F-1)/2, D] tensor, V1 pair by pair in Python): p_ij = (e_i W) * e_j over the pairs i < j with
+    ``bilinear_type`` choosing W: one matrix ("field_all"), one per left field ("field_each") or one per pair
+    ("field_interaction", the default).  ``bilinear_W`` has the reference's shape and xavier-normal init.
+
+    The products with W are fp32-MFMA GEMMs (rbx_linear_fwd): one [B*F, D] x [D, D] for field_all, one
+    [B, F*D] x block_diag(W_0..W_{F-1}) for field_each, and for field_interaction one [B, D] x [D, (F-1-i) D] per left
+    field i (its pairs' matrices side by side; the field's [B, D] slice is read in place).  The pairing is
+    rbx_pairmul_fwd/bwd."""
+
+    def __init__(self, num_fields, embedding_dim, bilinear_type="field_interaction"):
+        super(BilinearInteractionV2, self).__init__()
+        self.bilinear_type = bilinear_type
+        self.num_fields, self.embedding_dim = num_fields, embedding_dim
+        self.interact_dim = int(num_fields * (num_fields - 1) / 2)
+        lead = {"field_all": (), "field_each": (num_fields,), "field_interaction": (self.interact_dim,)}
+        if bilinear_type not in lead:
+            raise NotImplementedError
+        self.bilinear_W = nn.Parameter(torch.Tensor(*lead[bilinear_type], embedding_dim, embedding_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_normal_(self.bilinear_W)
+
+    def forward(self, feature_emb):
+        B, F, D = feature_emb.shape
+        W = self.bilinear_W
+        if self.bilinear_type == "field_all":
+            hidden = ops.linear(feature_emb.reshape(B * F, D), W.t()).view(B, F, D)
+            return ops.pair_mul(hidden, feature_emb)
+        if self.bilinear_type == "field_each":
+            hidden = ops.linear(feature_emb.reshape(B, F * D), torch.block_diag(*W.unbind(0)).t()).view(B, F, D)
+            return ops.pair_mul(hidden, feature_emb)
+        lefts, p0 = [], 0
+        for i in range(F - 1):
+            n = F - 1 - i                                       # pairs (i, i+1) .. (i, F-1) are consecutive in triu order
+            # [e_i W_p for the n pairs] = e_i [W_p0 | W_p0+1 | ...]: as an nn.Linear weight that is [(n D), D]
+            weight = W[p0:p0 + n].transpose(1, 2).reshape(n * D, D)
+            lefts.append(ops.linear(feature_emb[:, i, :], weight))
+            p0 += n
+        left = torch.cat(lefts, dim=1).view(B, self.interact_dim, D)
+        return ops.pair_mul(left, feature_emb, per_pair=True)
+
+
+class BilinearInteraction(BilinearInteractionV2):
+    """Same layer (the reference keeps both spellings; this one loops over pairs in Python there)."""

@@ -398,7 +398,7 @@ def test_bce_mean_vs_torch(n):
     pc = p.cuda().requires_grad_(True)
     out = get_loss("binary_crossentropy")(pc, y.cuda(), reduction="mean")
     (out * 3.0).backward()
-    assert_close(out.reshape(1), ref.detach().reshape(1), 1e-5 * max(1.0, float(ref)), "loss")
+    assert_close(out.reshape(1), ref.detach().reshape(1), 1e-5 * max(1.0, float(ref.detach())), "loss")
     scale = float(pr.grad.abs().max())
     assert float((pc.grad.cpu() - pr.grad).abs().max()) <= 1e-5 * max(1.0, scale)
     a = get_loss("bce")(pc.detach(), y.cuda())
@@ -407,6 +407,30 @@ def test_bce_mean_vs_torch(n):
     with pytest.raises(NotImplementedError):
         get_loss("no_such_loss")
     assert get_loss("mse_loss") is torch.nn.functional.mse_loss
+
+
+@pytest.mark.parametrize("kind", ["field_all", "field_each", "field_interaction"])
+def test_bilinear_golden(kind):
+    """BilinearInteraction / BilinearInteractionV2 against the live-reference fixture (the reference's
+    two spellings agree to 1e-6 with each other): output, dx and dW."""
+    L = _layers()
+    fx = Fixture("bilinear")
+    x, R = fx.tensors("in")["x"], fx.tensors("in")["R"]
+    B, F, D = x.shape
+    for ver, cls in (("v1", L.BilinearInteraction), ("v2", L.BilinearInteractionV2)):
+        ref = fx["out_%s_%s" % (kind, ver)]
+        layer = cls(F, D, bilinear_type=kind).cuda()
+        assert tuple(layer.bilinear_W.shape) == ref["W"].shape
+        with torch.no_grad():
+            layer.bilinear_W.copy_(torch.from_numpy(ref["W"]))
+        xc = x.cuda().requires_grad_(True)
+        out = layer(xc)
+        assert_close(out, ref["y"], TOL, "y")
+        (out * R.cuda()).sum().backward()
+        assert_close(xc.grad, ref["dx"], TOL, "dx")
+        assert_close(layer.bilinear_W.grad, ref["dW"], TOL, "dW")
+    with pytest.raises(NotImplementedError):
+        L.BilinearInteractionV2(F, D, bilinear_type="nope")
 
 
 def test_backward_is_deterministic_and_linear():
