@@ -570,6 +570,20 @@ def gen_bilinear(fuxictr, B=7, F=5, D=4):
     save("bilinear", **groups)
 
 
+def gen_cin(fuxictr, B=7, F=5, D=4):
+    """CompressedInteractionNet of the live reference (compressed_interaction_net.py:21-48), two layers."""
+    import fuxictr.pytorch.layers as FL
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, F, D, generator=g)
+    net = FL.CompressedInteractionNet(F, [6, 3], output_dim=2)
+    reinit(net, std=0.3, seed=6)
+    xi = x.clone().requires_grad_(True)
+    out = net(xi)
+    R = torch.randn(out.shape, generator=g)
+    (out * R).sum().backward()
+    save("cin", **{"in": {"x": x, "R": R}, "p": net.state_dict(), "out": {"y": out, "dx": xi.grad}, "g": grads_of(net)})
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -594,6 +608,7 @@ def main():
     gen_retrieval_metrics(recbox)
     gen_cross_net(fuxictr)
     gen_bilinear(fuxictr)
+    gen_cin(fuxictr)
 
 
 if __name__ == "__main__":

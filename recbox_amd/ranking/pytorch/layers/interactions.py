@@ -8,7 +8,7 @@ from torch import nn
 from .... import ops
 
 __all__ = ["InnerProductInteraction", "CrossInteraction", "CrossNet", "CrossNetV2", "BilinearInteraction",
-           "BilinearInteractionV2"]
+           "BilinearInteractionV2", "CompressedInteractionNet"]
 
 
 class InnerProductInteraction(nn.Module):
@@ -127,3 +127,36 @@ class BilinearInteractionV2(nn.Module):
 
 class BilinearInteraction(BilinearInteractionV2):
     """Same layer (the reference keeps both spellings; this one loops over pairs in Python there)."""
+
+
+class CompressedInteractionNet(nn.Module):
+    """xDeepFM's CIN (compressed_interaction_net.py:21-48) with the reference's parameter holders (``cin_layer.layer_<k>``
+    = nn.Conv1d(kernel_size=1), ``fc`` = nn.Linear) so checkpoints load unchanged.
+
+    Layer k: Z[b, (h, m), d] = X_0[b, h, d] * X_k[b, m, d], X_{k+1}[b, o, d] = sum_c W[o, c] Z[b, c, d] + bias[o].  The 1x1
+    convolution is a GEMM over the channel axis for every (b, d): it runs as ONE fp32-MFMA product
+    [B*D, F*H_k] x [F*H_k, H_{k+1}] (rbx_linear_fwd) on the outer-product tensor laid out with d next to b.  The outer
+    product itself is still materialised (an element-wise ATen kernel), as in the reference -- generating its tiles in LDS
+    inside the GEMM is the next step for this layer."""
+
+    def __init__(self, num_fields, cin_hidden_units, output_dim=1):
+        super(CompressedInteractionNet, self).__init__()
+        self.cin_hidden_units = cin_hidden_units
+        self.fc = nn.Linear(sum(cin_hidden_units), output_dim)
+        self.cin_layer = nn.ModuleDict()
+        width = num_fields
+        for k, unit in enumerate(cin_hidden_units):
+            self.cin_layer["layer_" + str(k + 1)] = nn.Conv1d(num_fields * width, unit, kernel_size=1)
+            width = unit
+
+    def forward(self, feature_emb):
+        B, F, D = feature_emb.shape
+        x0 = feature_emb.transpose(1, 2)                        # [B, D, F]: the GEMM wants channels last
+        xk = x0
+        pooled = []
+        for k in range(len(self.cin_hidden_units)):
+            conv = self.cin_layer["layer_" + str(k + 1)]
+            z = (x0.unsqueeze(3) * xk.unsqueeze(2)).reshape(B * D, F * xk.shape[2])      # [(b, d), (h, m)]
+            xk = ops.linear(z, conv.weight.squeeze(-1), conv.bias).view(B, D, -1)        # [B, D, H_{k+1}]
+            pooled.append(xk.sum(dim=1))                                                  # sum over d -> [B, H_{k+1}]
+        return ops.linear(torch.cat(pooled, dim=-1), self.fc.weight, self.fc.bias)

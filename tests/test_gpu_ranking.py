@@ -433,6 +433,20 @@ def test_bilinear_golden(kind):
         L.BilinearInteractionV2(F, D, bilinear_type="nope")
 
 
+def test_cin_golden():
+    """CompressedInteractionNet against the live-reference fixture: same state_dict keys, output, dx, grads."""
+    L = _layers()
+    fx = Fixture("cin")
+    x, R = fx.tensors("in")["x"], fx.tensors("in")["R"]
+    net = load_params(L.CompressedInteractionNet(x.shape[1], [6, 3], output_dim=2), fx["p"]).cuda()
+    xc = x.cuda().requires_grad_(True)
+    out = net(xc)
+    assert_close(out, fx["out"]["y"], TOL, "y")
+    (out * R.cuda()).sum().backward()
+    assert_close(xc.grad, fx["out"]["dx"], TOL, "dx")
+    assert_grads_close(net, fx["g"], TOL)
+
+
 def test_backward_is_deterministic_and_linear():
     """Full-size property checks (B = 65 536, 26 fields): two backward passes are
     bit-identical (no float atomics) and column sums of dW equal column sums of dY."""
