@@ -24,6 +24,7 @@ def exchange_counts(send_counts, group=None):
         recv = torch.empty_like(send_counts)
         dist.all_to_all_single(recv, send_counts, group=group)
         return recv.tolist()
+    send_counts = send_counts.cpu()                       # gloo moves host memory only
     table = [torch.empty_like(send_counts) for _ in range(W)]
     dist.all_gather(table, send_counts, group=group)
     return [int(t[rank]) for t in table]
@@ -40,7 +41,10 @@ def all_to_all_rows(x, send_counts, recv_counts, group=None):
     if dist.get_backend(group) == "nccl":
         dist.all_to_all_single(out, x.contiguous(), list(recv_counts), list(send_counts), group=group)
         return out
-    # gloo: batched point-to-point with the same semantics
+    # gloo: batched point-to-point with the same semantics.  gloo has no device transport: device rows are
+    # staged through the host (2-rank-on-one-GPU tests; the production backend is RCCL above)
+    if x.is_cuda:
+        return all_to_all_rows(x.cpu(), send_counts, recv_counts, group).to(x.device)
     ops, so, ro = [], 0, 0
     x = x.contiguous()
     for peer in range(W):

@@ -1,0 +1,87 @@
+"""Two / three ranks of the row-sharded FM step on ONE GPU (processes sharing cuda:0, rendezvous over gloo with the rows
+staged through the host): the HIP pieces of the N>1 path -- rbx_route wire slots for world > 1, owner-side gather,
+the fused FM over exchanged rows, dY to the owners, owner-side sorted scatter-add, flat all-reduce of the replicated
+gradients -- against the single-GPU FM trained on the GLOBAL batch.  RCCL itself needs one GPU per rank and is
+covered by the driver's multi-GPU bench; everything around the collective is exercised here."""
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+VOCABS = [50, 7, 400, 31, 301, 9]
+D, B = 16, 257                                    # per-rank batch (odd: ragged last blocks everywhere)
+E_PRE = "embedding_layer.embedding_layer.embedding_layers.%s.weight"
+L_PRE = "fm.lr_layer.embedding_layer.embedding_layer.embedding_layers.%s.weight"
+
+
+def _worker(rank, world, port, mode, result):
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from conftest import assert_close
+        from recbox_amd import ops
+        from recbox_amd.graph import ShardedFMStep
+        from recbox_amd.ranking.pytorch.models import FM, ShardedFM
+        from test_gpu_ranking import _criteo_like, _cuda
+        torch.cuda.set_device(0)
+        fm, X, y = _criteo_like(world * B, VOCABS, D, seed=31, zipf=True)       # the GLOBAL batch, same on every rank
+        torch.manual_seed(3)
+        ref = FM(fm, D).cuda()
+        with torch.no_grad():
+            for p in ref.parameters():
+                p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.1)
+        factor = None if mode == "exact" else 2.0
+        dut = ShardedFM(fm, D, shard_min_vocab=300, capacity_factor=factor).cuda()
+        assert dut.sharded_names == ["C3", "C5"] and dut.world_size == world
+        sd = ref.state_dict()
+        dut.load_state_dict({k: v for k, v in sd.items() if not any(("." + n + ".") in k for n in dut.sharded_names)},
+                            strict=False)
+        dut.tables.load_full_tables([sd[E_PRE % n] for n in dut.sharded_names], [sd[L_PRE % n] for n in dut.sharded_names])
+        Xg, yg = _cuda(X), y.cuda()
+        loss_ref = torch.nn.functional.binary_cross_entropy(torch.sigmoid(ref.logits(Xg)), yg, reduction="mean")
+        loss_ref.backward()
+        mine = slice(rank * B, (rank + 1) * B)
+        Xr = type(Xg)((k, v[mine].contiguous()) for k, v in Xg.items())
+        yr = yg[mine].contiguous()
+        if mode == "exact":                      # autograd path, all-to-all-v with exchanged counts
+            loss = torch.nn.functional.binary_cross_entropy(dut(Xr)["y_pred"], yr, reduction="mean")
+            (loss / world).backward()
+            dut.sync_grads()
+        else:                                    # the bench's step: padded sync-free exchange, eager pieces
+            old = ops.config.check_ids
+            ops.config.check_ids = False
+            try:
+                step = ShardedFMStep(dut, Xr, yr, graphs=False)
+                for _ in range(2):
+                    loss = step()
+            finally:
+                ops.config.check_ids = old
+            assert not bool(dut.tables.overflow)
+        torch.cuda.synchronize()
+        mean_loss = loss.detach().reshape(1).clone()
+        dist.all_reduce(mean_loss)
+        assert_close(mean_loss / world, loss_ref.reshape(1), 1e-6, "loss")
+        ref_g = dict((n, p.grad) for n, p in ref.named_parameters())
+        for n, p in dut.named_parameters():
+            if n.startswith("tables."):
+                continue
+            assert p.grad is not None, n
+            assert_close(p.grad, ref_g[n], 1e-6, n)
+        for t, name in enumerate(dut.sharded_names):
+            sl, owned = dut.tables.local_rows_of(t)
+            got = dut.tables.weight.grad[sl]
+            keep = (owned != 0).cuda()           # row 0 is padding_idx in FM, an ordinary row in the shards
+            assert_close(got[keep][:, :D], ref_g[E_PRE % name][owned.cuda()][keep], 1e-6, "shard emb " + name)
+            assert_close(got[keep][:, D], ref_g[L_PRE % name][owned.cuda()][keep][:, 0], 1e-6, "shard lr " + name)
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,world", [("exact", 2), ("padded", 2), ("padded", 3)])
+def test_ranks_on_one_gpu_equal_single_gpu_fm(mode, world):
+    from test_distributed_gloo import _free_port
+    result = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), mode, result), nprocs=world, join=True)
+    assert dict(result) == {r: "ok" for r in range(world)}
