@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python instead of replaying a hipGraph")
+    ap.add_argument("--fresh-grads", action="store_true",
+                    help="allocate and zero-fill new dense gradients every step (autograd's default) instead of re-zeroing "
+                         "the rows the previous step wrote in a persistent buffer")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-sharded model even at world size 1 (exercises the RCCL exchange path)")
     ap.add_argument("--shard-min-vocab", type=int, default=100000)
@@ -176,6 +179,10 @@ def main():
     from recbox_amd import ops
     from recbox_amd.ranking.pytorch.models import FM, ShardedFM
     ops.config.check_ids = False              # no per-call host sync inside the timed region
+    # every step starts from zero_grad(set_to_none=True): the dense gradients may live in ONE persistent buffer of which
+    # only the rows the previous step wrote are cleared (rbx_fm_rezero) instead of a 379 MB zero fill per step; p.grad
+    # after a step is the same dense [V, D] tensor either way (tests/test_gpu_ranking.py: bit-identical)
+    ops.config.reuse_grad_buffers = not args.fresh_grads
     fmw = CriteoFeatureMap(args.dim)
     sharded = world > 1 or args.force_sharded
     B = args.batch
@@ -220,7 +227,7 @@ def main():
     if not args.eager and not sharded:
         # one hipGraph holds the whole step (same kernels, same C ABI); the batch lives in static buffers
         from recbox_amd.graph import GraphedStep
-        step = GraphedStep(eager_step, warmup=3)
+        step = GraphedStep(eager_step, warmup=3, reuse_grads=not args.fresh_grads)
         graph_note = "hipGraph replay"
     elif sharded and cap_factor and model.tables is not None:
         # padded sync-free exchange: the step is four hipGraph pieces with the RCCL collectives between them
@@ -314,8 +321,10 @@ def main():
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
-                                      "%s ids, %s path, %s, dense-grad autograd contract, no optimiser step"
-                                      % (args.dim, B, args.dist, args.path, graph_note),
+                                      "%s ids, %s path, %s, dense-grad autograd contract (%s), no optimiser step"
+                                      % (args.dim, B, args.dist, args.path, graph_note,
+                                         "fresh zero-filled grads every step" if args.fresh_grads or args.path != "fused"
+                                         or sharded else "persistent grad buffer, rows of the previous step re-zeroed"),
                           "global_batch": B * world,
                           "parallelism": ("dp%d + row-sharded tables (all-to-all-v)" % world) if sharded else "dp1"},
                "roofline": roof}

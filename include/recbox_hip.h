@@ -193,6 +193,13 @@ int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields,
 int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                const float* d_dlogit, const float* d_sum, float* d_dbias, int32_t accumulate,
                int32_t phases, void* d_workspace, size_t workspace_bytes, void* stream);
+/* For a caller that keeps PERSISTENT dense gradient buffers (the reference's autograd allocates and zero-fills a new
+ * [V, D] gradient per table and step: torch/nn/functional.py embedding backward; 379 MB per step at the Criteo
+ * shape, of which a batch touches 36 MB): with the workspace of the PREVIOUS rbx_fm_sort (same fields, same batch)
+ * and emb[i].grad / lr[i].grad = the buffers that step's rbx_fm_bwd stored into, write zeros to exactly the rows it
+ * touched.  Call it before the next rbx_fm_sort reuses the workspace. */
+int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+                  void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K5: two-tower scoring (third_party/rechub/models/matching/dssm.py:48,57,65,
  * youtube_dnn.py:47-48,56,65,70).  l2norm = F.normalize(x, p=2, dim=-1, eps): y = x / max(||x||, eps);

@@ -498,6 +498,81 @@ static size_t fm_num_bytes(const BwdPlan& p, int n_num, int D) {
   return static_cast<size_t>(p.num_blocks) * (n_num + 1) * (D + 2) * sizeof(float) + 256;
 }
 
+
+// ---- re-zero of the gradient rows a previous step wrote ----------------------------------------------
+// The sorted (key, val) pairs of the PREVIOUS rbx_fm_sort on this workspace name every gradient row that step's
+// rbx_fm_bwd stored to: one lane group per pair, the head of each run of equal keys clears its row (dim floats of
+// dW, one float of the LR gradient).  36 MB of stores at the Criteo shape instead of a 379 MB fill of the dense grads.
+template <bool VEC>
+__global__ __launch_bounds__(256) void fm_rezero_kernel(const RedPack P, const int n_cat, const unsigned* __restrict__ keys,
+                                                        const unsigned* __restrict__ vals, const unsigned n,
+                                                        const unsigned sentinel, const int lanes) {
+  __shared__ RedField sf[RBX_MAX_FIELDS];
+  {
+    const int words = n_cat * static_cast<int>(sizeof(RedField) / 4);
+    const int* src = reinterpret_cast<const int*>(&P);
+    int* dst = reinterpret_cast<int*>(sf);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  constexpr int W = VEC ? 4 : 1;
+  // one lane group per sorted pair, so that a row is cleared by ONE coalesced store of the group (a thread per pair
+  // with four 16-byte stores each was measured 2.8x slower: 83 vs 30 us); only the ~30 % that start a run write
+  const int lane_g = threadIdx.x % lanes;
+  const unsigned i = blockIdx.x * (blockDim.x / lanes) + threadIdx.x / lanes;
+  if (i >= n) return;
+  const unsigned key = keys[i];
+  if (key >= sentinel || (i > 0 && keys[i - 1] == key)) return;
+  const RedField& fd = sf[vals[i] >> kLocalBits];
+  const size_t row = key - fd.row_base;
+  if (fd.grad != nullptr) {
+    float* dst = fd.grad + row * fd.dim;
+    for (int e = lane_g * W; e < fd.dim; e += lanes * W) {
+      if constexpr (VEC) {
+        const v4f z = {0.f, 0.f, 0.f, 0.f};
+        __builtin_nontemporal_store(z, reinterpret_cast<v4f*>(dst + e));
+      } else {
+        dst[e] = 0.f;
+      }
+    }
+  }
+  if (fd.grad2 != nullptr && lane_g == 0) fd.grad2[row] = 0.f;
+}
+
+}  // namespace rbx
+
+extern "C" int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+                             void* d_workspace, size_t workspace_bytes, void* stream) {
+  using namespace rbx;
+  if (batch == 0) return RBX_OK;
+  BwdPlan p;
+  FmNumPack np;
+  int n_num = 0;
+  int rc = fm_plan(emb, lr, n_fields, batch, &p, &np, &n_num);
+  if (rc != RBX_OK) return rc;
+  if (p.n_lookups == 0) return RBX_OK;
+  if (d_workspace == nullptr || workspace_bytes < p.bytes) return fail(RBX_ERR_WORKSPACE, "fm_rezero: workspace too small");
+  const char* ws = static_cast<const char*>(d_workspace);
+  const int cur = p.passes & 1;
+  const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);
+  const unsigned* vals = reinterpret_cast<const unsigned*>(ws + p.off_vals[cur]);
+  const int D = emb ? emb[0].dim : 1;
+  const int width = p.vec ? (D + 3) / 4 : D;
+  int lanes = 1;
+  while (lanes < width && lanes < 64) lanes *= 2;
+  const unsigned per_block = 256 / lanes;
+  const unsigned blocks = (p.n_lookups + per_block - 1) / per_block;
+  if (p.vec)
+    hipLaunchKernelGGL(fm_rezero_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), p.red, p.n_cat, keys, vals,
+                       p.n_lookups, p.total_rows, lanes);
+  else
+    hipLaunchKernelGGL(fm_rezero_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), p.red, p.n_cat, keys, vals,
+                       p.n_lookups, p.total_rows, lanes);
+  return check_launch("fm_rezero_kernel");
+}
+
+namespace rbx {
 }  // namespace rbx
 
 extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,

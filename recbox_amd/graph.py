@@ -21,24 +21,34 @@ class GraphedStep(object):
         step = GraphedStep(lambda: train_step(static_batch), warmup=3)
         for batch in loader:
             static_batch.copy_(batch, non_blocking=True)
-            loss = step()           # replays fwd+bwd; parameter .grad tensors are static
+            loss = step()           # replays fwd+bwd; parameter .grad tensors are static: consume them
+                                    # (optimizer step) before the next replay
     """
 
-    def __init__(self, fn, warmup=3, capture_error_mode="global"):
+    def __init__(self, fn, warmup=3, capture_error_mode="global", reuse_grads=True):
         if ops.config.check_ids:
             raise RuntimeError("GraphedStep: set recbox_amd.ops.config.check_ids = False first "
                                "(the id range check syncs the host, which cannot be captured)")
         self.fn = fn
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):               # warm up allocator + autograd on a side stream
-            for _ in range(warmup):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
-            self.out = fn()
+        # Parameter gradients of a replayed step are static tensors that the next replay overwrites.  Under exactly
+        # that contract the fused FM backward may keep ONE dense gradient buffer and clear only the rows the previous
+        # replay wrote instead of re-filling 379 MB of zeros per step (ops.config.reuse_grad_buffers): ``fn`` must
+        # start from ``p.grad = None`` for the embedding parameters, as a captured step does anyway.
+        old = ops.config.reuse_grad_buffers
+        ops.config.reuse_grad_buffers = bool(reuse_grads) or old
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):           # warm up allocator + autograd on a side stream
+                for _ in range(max(warmup, 2)):     # (two steps: the second one records the re-zero path)
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
+                self.out = fn()
+        finally:
+            ops.config.reuse_grad_buffers = old
 
     def __call__(self):
         self.graph.replay()

@@ -30,6 +30,12 @@ class config(object):
     # fork the id sort onto the side stream even while a hipGraph is being captured (the
     # fork/join becomes graph edges, so the sort overlaps the forward on replay too)
     fork_in_capture = os.environ.get("RECBOX_AMD_FORK_IN_CAPTURE", "1") != "0"
+    # fused FM: keep ONE persistent dense gradient buffer per table set and, instead of zero-filling a new one every
+    # step (379 MB at the Criteo shape), clear only the rows the previous step wrote (rbx_fm_rezero, 36 MB).  The
+    # gradients handed to autograd then ALIAS that buffer: they are valid until the next training forward of the same
+    # op (the contract hipGraph replays have anyway -- recbox_amd.graph.GraphedStep turns this on), and every step
+    # must start from ``p.grad is None`` (optimizer.zero_grad(set_to_none=True)).  Off by default.
+    reuse_grad_buffers = os.environ.get("RECBOX_AMD_REUSE_GRADS", "0") != "0"
 
 
 def _require_cuda(t, what):
@@ -187,9 +193,9 @@ def _side_stream(device):
 class _EarlySort(object):
     """Workspace + completion event of a sort launched from the forward."""
 
-    def __init__(self, device, ws_bytes, launch):
+    def __init__(self, device, ws_bytes, launch, ws=None):
         cur = torch.cuda.current_stream(device)
-        self.ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=device)
+        self.ws = ws if ws is not None else torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=device)
         self.ws_bytes = int(ws_bytes)
         self.event = None
         if torch.cuda.is_current_stream_capturing() and not config.fork_in_capture:
@@ -366,6 +372,56 @@ def _flat_zero_grads(params, want, device):
     return grads
 
 
+class _GradPool(object):
+    """Persistent dense gradients + sort workspace of one fused FM op (``config.reuse_grad_buffers``).
+
+    ``ws`` always holds the sorted ids of the LAST sort launched on it; ``dirty_batch`` is the batch size of the
+    backward whose stores are still in ``flat`` (0 = all zero) -- always the one whose sort is in ``ws``."""
+
+    def __init__(self, params, pooled, device):
+        self.key = self._key(params)
+        self.bound = None                     # views kept for binding descriptors (autograd gets fresh ones)
+        # only tables addressed by ids are cleared by row; numeric-feature weights get a fresh (tiny) zero buffer
+        self.sizes = [p.numel() if (p.requires_grad and keep) else 0 for p, keep in zip(params, pooled)]
+        self.padded = [(n + 3) // 4 * 4 for n in self.sizes]
+        self.flat = None
+        self.ws = None
+        self.ws_bytes = 0
+        self.dirty_batch = 0
+        self.ticket = 0                       # bumped by every sort: a backward whose ticket is stale re-sorts
+        self.device = device
+
+    @staticmethod
+    def _key(params):
+        return tuple((id(p), p.data_ptr(), p.requires_grad) for p in params)
+
+    def matches(self, params):
+        return self.key == self._key(params)
+
+    def bind_views(self, params):
+        if self.bound is None:
+            self.bound = self.views(params)
+        return self.bound
+
+    def views(self, params):
+        if self.flat is None:
+            self.flat = torch.zeros(sum(self.padded), dtype=torch.float32, device=self.device)     # the only full fill
+        loose = [p for p, n in zip(params, self.sizes) if n == 0]
+        small = iter(_flat_zero_grads(loose, [p.requires_grad for p in loose], self.device))    # one fill for all of them
+        out, o = [], 0
+        for p, n, pn in zip(params, self.sizes, self.padded):
+            out.append(self.flat[o:o + n].view_as(p) if n else next(small))
+            o += pn
+        return out
+
+    def workspace(self, ws_bytes):
+        if self.ws is None or self.ws_bytes < ws_bytes:
+            assert self.dirty_batch == 0
+            self.ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=self.device)
+            self.ws_bytes = int(ws_bytes)
+        return self.ws
+
+
 class _FmFused(torch.autograd.Function):
     """logit[B,1] of the FM model body in one kernel; backward fused into the segmented scatter-add.
 
@@ -436,10 +492,62 @@ class _FmFused(torch.autograd.Function):
             if lr_plan is not None:
                 lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
             ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
-            if ws_bytes > 0:
+            pool = (_FmFused._pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev)
+                    if config.reuse_grad_buffers else None)
+            if ws_bytes > 0 and pool is None:
                 ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_fm_sort(
                     ea, la, lead.n, B, _ptr(ws), ws_bytes, None, st))
+            elif ws_bytes > 0:
+                # ahead of the sort, on the same stream: clear what the previous backward stored (its sorted ids are
+                # still in the pool's workspace), then sort this batch's ids over them.  (Clearing on a third stream
+                # beside the sort was measured slower -- 0.344 vs 0.331 ms per step: the step is bound by the memory
+                # request rate, concurrent kernels only slow each other down.)
+                dirty = pool.dirty_batch
+                if dirty and pool.ws_bytes < ws_bytes:          # a larger batch than ever before: clear, then regrow
+                    check(_FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, _stream()))
+                    dirty = 0
+                ws = pool.workspace(ws_bytes)
+
+                def launch(ws, st):
+                    if dirty:
+                        rc = _FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st)
+                        if rc != _lib.RBX_OK:
+                            return rc
+                        if emb_plan is not None:
+                            emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
+                        if lr_plan is not None:
+                            lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
+                    return lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), pool.ws_bytes, None, st)
+
+                ctx.sort = _EarlySort(dev, pool.ws_bytes, launch, ws=ws)
+                pool.ticket += 1
+                ctx.pool, ctx.ticket = pool, pool.ticket
         return logit
+
+    @staticmethod
+    def _pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev):
+        params = list(emb_params) + list(lr_params)
+        pool = getattr(lead, "_grad_pool", None)
+        if pool is None or not pool.matches(params):
+            pooled = []
+            for plan, ps in ((emb_plan, emb_params), (lr_plan, lr_params)):
+                by_id = set(sp.param for sp in plan.specs if sp.kind == FIELD_CATEGORICAL) if plan is not None else ()
+                pooled += [i in by_id for i in range(len(ps))]
+            pool = lead._grad_pool = _GradPool(params, pooled, dev)
+        return pool
+
+    @staticmethod
+    def _rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st):
+        grads = pool.bind_views(list(emb_params) + list(lr_params))
+        if emb_plan is not None:
+            emb_plan.bind_params(emb_params, grads[:len(emb_params)])
+        if lr_plan is not None:
+            lr_plan.bind_params(lr_params, grads[len(emb_params):])
+        ea = emb_plan.arr if emb_plan is not None else None
+        la = lr_plan.arr if lr_plan is not None else None
+        rc = lib.rbx_fm_rezero(ea, la, lead.n, pool.dirty_batch, _ptr(pool.ws), pool.ws_bytes, st)
+        pool.dirty_batch = 0
+        return rc
 
     @staticmethod
     def backward(ctx, dlogit):
@@ -456,7 +564,18 @@ class _FmFused(torch.autograd.Function):
         dev = dlogit.device
         # (zero-filling these buffers on a third stream during the forward was measured: it only adds HBM
         #  contention -- 0.388 vs 0.366 ms per step -- and defeats the caching allocator in eager mode)
-        grads = _flat_zero_grads(list(emb_params) + list(lr_params), want_e + want_l, dev)
+        same = [p.requires_grad for p in emb_params] == want_e and [p.requires_grad for p in lr_params] == want_l
+        pool = getattr(ctx, "pool", None)
+        if pool is not None and not (same and ctx.ticket == pool.ticket and B > 0):
+            pool, ctx.sort = None, None          # another forward has sorted over this workspace since: start over
+        if pool is not None:
+            for p, w in zip(list(emb_params) + list(lr_params), want_e + want_l):
+                if w and p.grad is not None:
+                    raise RuntimeError("recbox_amd: config.reuse_grad_buffers needs p.grad to be None at every backward "
+                                       "(zero_grad(set_to_none=True)); the gradients alias one persistent buffer")
+            grads = pool.views(list(emb_params) + list(lr_params))
+        else:
+            grads = _flat_zero_grads(list(emb_params) + list(lr_params), want_e + want_l, dev)
         ge, gl = grads[:n_emb], grads[n_emb:]
         gb = torch.zeros(1, dtype=torch.float32, device=dev) if want_b else None
         # indexed: only the referenced wire slots are written, the empty ones must read as zero
@@ -493,7 +612,6 @@ class _FmFused(torch.autograd.Function):
                 check(lib.rbx_fm_extra_bwd(_ptr(dlogit), _ptr(ssum), _ptr(extra), B, extra_index.shape[1], D,
                                            extra.shape[1], has_extra - 1, _ptr(extra_index), extra.shape[0], _ptr(dx),
                                            _stream()))
-        same = [p.requires_grad for p in emb_params] == want_e and [p.requires_grad for p in lr_params] == want_l
         ws_early = ctx.sort.ws if (ctx.sort is not None and same) else None
         if ws_early is not None:
             # numeric weights + bias do not need the sorted ids: run them while the sort may still be in flight
@@ -508,6 +626,8 @@ class _FmFused(torch.autograd.Function):
             check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, _stream()))
         check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 if ws_early is not None else 3,
                              _ptr(ws), ws_bytes, _stream()))
+        if pool is not None:
+            pool.dirty_batch = B                 # the rows named by the sorted ids in pool.ws now hold this step's sums
         return result()
 
 

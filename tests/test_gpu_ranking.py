@@ -232,6 +232,98 @@ def test_fused_fm_matches_layer_path_and_oracle(B, zipf):
         assert_close(p2.grad, p0.grad, TOL * scale, "layer grad " + n0)
 
 
+def _fm_pair(seed, vocabs=None):
+    from recbox_amd.ranking.pytorch.models import FM
+    fm, _, _ = _criteo_like(4, vocabs or (CRITEO_SMALL_VOCABS + [70000]), 16, seed=seed)
+    a, b = FM(fm, 16, fused=True).cuda(), FM(fm, 16, fused=True).cuda()
+    with torch.no_grad():
+        for p in a.parameters():
+            p.normal_(0, 0.1)
+    b.load_state_dict(a.state_dict())
+    return fm, a, b
+
+
+def _bce_step(model, X, y):
+    model.zero_grad(set_to_none=True)
+    loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(model.logits(X)), y, reduction="mean")
+    loss.backward()
+    return loss
+
+
+def test_reuse_grad_buffers_equals_fresh_grads():
+    """ops.config.reuse_grad_buffers (persistent dense grads, rbx_fm_rezero clears only the rows the previous step wrote)
+    leaves bit-identical gradients to the zero-filled path over steps with different ids and batch sizes (smaller,
+    larger than ever before, back), after a training forward without backward, and when two forwards precede the
+    backwards; a step that does not start from p.grad None is refused."""
+    from recbox_amd import ops
+    vocabs = CRITEO_SMALL_VOCABS + [70000]
+    fm, fresh, reuse = _fm_pair(41, vocabs)
+    old = ops.config.reuse_grad_buffers
+    try:
+        for k, B in enumerate([513, 513, 100, 2000, 1, 513]):
+            _, X, y = _criteo_like(B, vocabs, 16, seed=50 + k, zipf=bool(k % 2))
+            Xc, yc = _cuda(X), y.cuda()
+            ops.config.reuse_grad_buffers = False
+            _bce_step(fresh, Xc, yc)
+            ops.config.reuse_grad_buffers = True
+            if k == 3:
+                reuse.logits(Xc)                             # a training forward whose backward never runs
+            _bce_step(reuse, Xc, yc)
+            for (n, p0), (_, p1) in zip(fresh.named_parameters(), reuse.named_parameters()):
+                assert torch.equal(p1.grad, p0.grad), "step %d: %s" % (k, n)
+        # two forwards, then both backwards: the first one's sorted ids were overwritten -> it re-sorts, fresh grads
+        _, X1, y1 = _criteo_like(300, vocabs, 16, seed=71)
+        _, X2, y2 = _criteo_like(300, vocabs, 16, seed=72)
+        want = []
+        ops.config.reuse_grad_buffers = False
+        for X, y in ((X1, y1), (X2, y2)):
+            _bce_step(fresh, _cuda(X), y.cuda())
+            want.append([p.grad.clone() for p in fresh.parameters()])
+        ops.config.reuse_grad_buffers = True
+        reuse.zero_grad(set_to_none=True)
+        l1 = reuse.logits(_cuda(X1))
+        l2 = reuse.logits(_cuda(X2))
+        for logit, y, w in ((l2, y2, want[1]), (l1, y1, want[0])):
+            reuse.zero_grad(set_to_none=True)
+            torch.nn.functional.binary_cross_entropy(torch.sigmoid(logit), y.cuda(), reduction="mean").backward()
+            for p, g in zip(reuse.parameters(), w):
+                assert torch.equal(p.grad, g)
+        with pytest.raises(RuntimeError, match="reuse_grad_buffers"):
+            logit = reuse.logits(_cuda(X1))                  # p.grad still set from the step above
+            logit.sum().backward()
+    finally:
+        ops.config.reuse_grad_buffers = old
+
+
+def test_graphed_step_replays_equal_eager_steps():
+    """GraphedStep (whole step in one hipGraph, persistent gradients re-zeroed by row): after refilling the static batch,
+    a replay leaves the loss and gradients of the eager step on that batch -- three different batches in a row."""
+    from recbox_amd import ops
+    from recbox_amd.graph import GraphedStep
+    vocabs = CRITEO_SMALL_VOCABS + [70000]
+    fm, eager, graphed = _fm_pair(43, vocabs)
+    B = 777
+    _, X0, y0 = _criteo_like(B, vocabs, 16, seed=60)
+    Xs, ys = _cuda(X0), y0.cuda()
+    old = ops.config.check_ids
+    ops.config.check_ids = False
+    try:
+        step = GraphedStep(lambda: _bce_step(graphed, Xs, ys), warmup=3)
+        for k in range(3):
+            _, X, y = _criteo_like(B, vocabs, 16, seed=61 + k, zipf=(k == 1))
+            for n in Xs:
+                Xs[n].copy_(X[n])
+            ys.copy_(y)
+            loss = step()
+            want = _bce_step(eager, _cuda(X), y.cuda())
+            torch.cuda.synchronize()
+            assert_close(loss.reshape(1), want.reshape(1), 1e-6, "loss")
+            for (n, p0), (_, p1) in zip(eager.named_parameters(), graphed.named_parameters()):
+                assert torch.equal(p1.grad, p0.grad), "replay %d: %s" % (k, n)
+    finally:
+        ops.config.check_ids = old
+
+
 def test_logistic_regression_fused_and_frozen_tables():
     L = _layers()
     from oracle import torch_ref as R
