@@ -1,0 +1,29 @@
+"""Timeline of ONE hipGraph replay out of a rocprofv3 --kernel-trace rocpd database: start offset, duration and queue of
+every kernel between two consecutive launches of an anchor kernel (default: the first kernel of the step).
+    python profiles/timeline.py <results.db> [anchor-substring] [which-occurrence]
+"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    anchor = sys.argv[2] if len(sys.argv) > 2 else "fm_rezero"
+    which = int(sys.argv[3]) if len(sys.argv) > 3 else -5
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    rows = db.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")).fetchall()
+    marks = [i for i, r in enumerate(rows) if anchor in r[0]]
+    a, b = marks[which], marks[which + 1]
+    t0 = rows[a][1]
+    print("# one step: %d kernels, %.1f us from the first start to the next step's first start" %
+          (b - a, (rows[b][1] - t0) / 1e3))
+    print("%-60s %9s %9s %9s  %s" % ("kernel", "start_us", "dur_us", "end_us", "queue"))
+    for r in rows[a:b]:
+        name = r[0].split("(")[0].replace("void ", "")[:60]
+        print("%-60s %9.1f %9.1f %9.1f  %s" % (name, (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, (r[2] - t0) / 1e3,
+                                               r[3] if qcol else ""))
+
+
+if __name__ == "__main__":
+    main()

@@ -117,7 +117,7 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
   p->off_head = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
   p->off_tail = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
   p->off_flags = o; o += align_up(static_cast<size_t>(p->n_chunks) * 4, 256);
-  p->off_fin = o; o += align_up((2 * static_cast<size_t>(p->n_chunks) + 2) * 4, 256);   // 2 counters, short list, long list
+  p->off_fin = o; o += align_up((2 * static_cast<size_t>(p->n_chunks) + 3) * 4, 256);   // 3 counters, short list, long list
   p->off_num = o; o += align_up(static_cast<size_t>(p->n_num) * p->num_blocks * p->max_dim * 4, 256);
   p->bytes = o + 256;
   return RBX_OK;
@@ -126,7 +126,13 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
 // ---- build_keys ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void build_keys_kernel(const KeyPack P, const int n_cat, const unsigned n_lookups,
                                                          const unsigned sentinel, unsigned* __restrict__ keys,
-                                                         unsigned* __restrict__ vals, int* __restrict__ status) {
+                                                         unsigned* __restrict__ vals, int* __restrict__ status,
+                                                         unsigned* __restrict__ fin) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {          // fix-up work-list length and arrival counter (rbx_segreduce.h)
+    fin[0] = 0;
+    fin[1] = 0;
+    fin[2] = 0;
+  }
   __shared__ KeyField sf[RBX_MAX_FIELDS];
   {
     const int words = n_cat * static_cast<int>(sizeof(KeyField) / 4);
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const unsigned
 // total; level 2: one workgroup scans the slice totals; the scatter kernel adds the
 // slice prefix when it picks up its 256 (digit, tile) offsets.
 constexpr int kScanSlice = 4096;
+constexpr int kMaxFusedSlices = 4 * kSortThreads;      // slice totals one scatter workgroup can scan by itself
 
 __device__ __forceinline__ unsigned block_scan_1024x4(unsigned (&v)[4], unsigned* wave_tot, unsigned* total) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -252,7 +259,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
                                                                      unsigned* __restrict__ vals_out, const unsigned n,
                                                                      const int shift, const unsigned* __restrict__ hist,
                                                                      const unsigned* __restrict__ slice_sum,
-                                                                     const unsigned n_tiles) {
+                                                                     const unsigned n_tiles, const unsigned n_slices,
+                                                                     const bool raw_sums) {
   constexpr int kWaves = kSortThreads / 64;
   constexpr int kPerWave = kSortTile / kWaves;       // 512
   constexpr int kSteps = kPerWave / 64;              // 8
@@ -264,7 +272,36 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned tile0 = blockIdx.x * kSortTile;
   for (int i = threadIdx.x; i < kWaves * kRadix; i += kSortThreads) (&wcnt[0][0])[i] = 0;
-  {
+  if (raw_sums) {
+    // slice_sum holds the slice TOTALS as radix_scan_local_kernel left them (at most kMaxFusedSlices of them): every
+    // workgroup scans them itself (a few dozen values at the bench shape) instead of waiting for a separate
+    // one-workgroup kernel per pass
+    __shared__ unsigned spre[kMaxFusedSlices];
+    __shared__ unsigned stot[kWaves];
+    const unsigned i0 = threadIdx.x * 4;
+    unsigned t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = (i0 + q < n_slices) ? slice_sum[i0 + q] : 0u;
+    const unsigned mine = t[0] + t[1] + t[2] + t[3];
+    unsigned inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) stot[wid] = inc;
+    __syncthreads();
+    unsigned run = inc - mine;
+    for (int w = 0; w < wid; ++w) run += stot[w];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      spre[i0 + q] = run;
+      run += t[q];
+    }
+    __syncthreads();
+    const unsigned hi = threadIdx.x * n_tiles + blockIdx.x;
+    gbase[threadIdx.x] = hist[hi] + spre[hi / kScanSlice];
+  } else {
     const unsigned hi = threadIdx.x * n_tiles + blockIdx.x;
     gbase[threadIdx.x] = hist[hi] + slice_sum[hi / kScanSlice];
   }
@@ -451,7 +488,7 @@ int run_sort(const BwdPlan& p, char* ws, int* d_status, hipStream_t s) {
     unsigned blocks = (p.n_lookups + 255) / 256;
     if (blocks > static_cast<unsigned>(kCUs * 8)) blocks = kCUs * 8;
     hipLaunchKernelGGL(build_keys_kernel, dim3(blocks), dim3(256), 0, s, p.keys, p.n_cat, p.n_lookups, p.total_rows,
-                       keys[0], vals[0], d_status);
+                       keys[0], vals[0], d_status, reinterpret_cast<unsigned*>(ws + p.off_fin));
     rc = check_launch("build_keys_kernel");
     if (rc != RBX_OK) return rc;
   }
@@ -463,9 +500,10 @@ int run_sort(const BwdPlan& p, char* ws, int* d_status, hipStream_t s) {
     const unsigned hist_len = p.n_tiles * kRadix;
     const unsigned n_slices = (hist_len + kScanSlice - 1) / kScanSlice;
     hipLaunchKernelGGL(radix_scan_local_kernel, dim3(n_slices), dim3(1024), 0, s, hist, hist_len, ssum);
-    hipLaunchKernelGGL(radix_scan_sums_kernel, dim3(1), dim3(1024), 0, s, ssum, n_slices);
+    const bool raw_sums = n_slices <= static_cast<unsigned>(kMaxFusedSlices);
+    if (!raw_sums) hipLaunchKernelGGL(radix_scan_sums_kernel, dim3(1), dim3(1024), 0, s, ssum, n_slices);
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], vals[cur],
-                       keys[cur ^ 1], vals[cur ^ 1], p.n_lookups, shift, hist, ssum, p.n_tiles);
+                       keys[cur ^ 1], vals[cur ^ 1], p.n_lookups, shift, hist, ssum, p.n_tiles, n_slices, raw_sums);
     rc = check_launch("radix pass");
     if (rc != RBX_OK) return rc;
     cur ^= 1;

@@ -517,18 +517,34 @@ __global__ __launch_bounds__(256) void fm_rezero_kernel(const RedPack P, const i
   __syncthreads();
   typedef float v4f __attribute__((ext_vector_type(4)));
   constexpr int W = VEC ? 4 : 1;
-  // one lane group per sorted pair, so that a row is cleared by ONE coalesced store of the group (a thread per pair
-  // with four 16-byte stores each was measured 2.8x slower: 83 vs 30 us); only the ~30 % that start a run write
-  const int lane_g = threadIdx.x % lanes;
-  const unsigned i = blockIdx.x * (blockDim.x / lanes) + threadIdx.x / lanes;
-  if (i >= n) return;
-  const unsigned key = keys[i];
-  if (key >= sentinel || (i > 0 && keys[i - 1] == key)) return;
-  const RedField& fd = sf[vals[i] >> kLocalBits];
-  const size_t row = key - fd.row_base;
-  if (fd.grad != nullptr) {
-    float* dst = fd.grad + row * fd.dim;
-    for (int e = lane_g * W; e < fd.dim; e += lanes * W) {
+  // Phase 1, a thread per sorted pair: three independent coalesced loads decide whether the pair starts a run and
+  // where its row lives.  Phase 2, a lane group per pair: the wave walks its 64 pairs `64 / lanes` at a time and a
+  // row is cleared by ONE coalesced store of its group.  (One lane group per pair from the start, with the loads
+  // chained behind each other, was latency-bound at 41 us; a thread per pair storing 4 x 16 B took 83 us.)
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  float* row_ptr = nullptr;
+  int dim = 0;
+  if (i < n) {
+    const unsigned key = keys[i];
+    const unsigned prev = (i > 0) ? keys[i - 1] : sentinel;
+    const unsigned val = vals[i];
+    if (key < sentinel && key != prev) {
+      const RedField& fd = sf[val >> kLocalBits];
+      const size_t row = key - fd.row_base;
+      if (fd.grad != nullptr) {
+        row_ptr = fd.grad + row * fd.dim;
+        dim = fd.dim;
+      }
+      if (fd.grad2 != nullptr) fd.grad2[row] = 0.f;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int lane_g = lane % lanes, group = lane / lanes, per_step = 64 / lanes;
+  for (int base = 0; base < 64; base += per_step) {
+    const int src = base + group;
+    float* dst = reinterpret_cast<float*>(__shfl(reinterpret_cast<unsigned long long>(row_ptr), src, 64));
+    const int d = __shfl(dim, src, 64);
+    for (int e = lane_g * W; e < d; e += lanes * W) {
       if constexpr (VEC) {
         const v4f z = {0.f, 0.f, 0.f, 0.f};
         __builtin_nontemporal_store(z, reinterpret_cast<v4f*>(dst + e));
@@ -537,7 +553,6 @@ __global__ __launch_bounds__(256) void fm_rezero_kernel(const RedPack P, const i
       }
     }
   }
-  if (fd.grad2 != nullptr && lane_g == 0) fd.grad2[row] = 0.f;
 }
 
 }  // namespace rbx
@@ -561,8 +576,7 @@ extern "C" int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int3
   const int width = p.vec ? (D + 3) / 4 : D;
   int lanes = 1;
   while (lanes < width && lanes < 64) lanes *= 2;
-  const unsigned per_block = 256 / lanes;
-  const unsigned blocks = (p.n_lookups + per_block - 1) / per_block;
+  const unsigned blocks = (p.n_lookups + 255) / 256;
   if (p.vec)
     hipLaunchKernelGGL(fm_rezero_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), p.red, p.n_cat, keys, vals,
                        p.n_lookups, p.total_rows, lanes);

@@ -26,6 +26,7 @@ __device__ __forceinline__ void frag_add(F& a, const F& b) {
   for (int q = 0; q < static_cast<int>(sizeof(a.a) / sizeof(float)); ++q) a.a[q] += b.a[q];
 }
 
+constexpr int kFinList = 3;      // fin[0] work-list length, fin[1] long-list length, fin[2] arrival counter, then the lists
 // Interior runs are written directly; a run that crosses the chunk border leaves a head /
 // tail summary and a flag, and the chunk where such a run ENDS is queued for the fix-up.
 template <class Policy, int G, int NV, bool VEC>
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256, 4) void segment_reduce_kernel(const RedPack P,
   if (head_done) flag |= kFlagFin;
   if (lane_g == 0) {
     flags[c] = flag;
-    if (flag & kFlagFin) fin[2 + atomicAdd(fin, 1u)] = c;     // fix-up work list (order is irrelevant)
+    if (flag & kFlagFin) fin[kFinList + atomicAdd(fin, 1u)] = c;     // fix-up work list (order is irrelevant)
   }
 }
 
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void segment_fixup_short_kernel(const RedPack 
   const unsigned ngroups = gridDim.x * (blockDim.x / G);
   const unsigned count = fin[0];
   for (unsigned idx = blockIdx.x * (blockDim.x / G) + threadIdx.x / G; idx < count; idx += ngroups) {
-    const unsigned c = fin[2 + idx];
+    const unsigned c = fin[kFinList + idx];
     // how long is the chain?  (flags only: cheap, L2-resident)
     int hops = 0;
     bool closed = false;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void segment_fixup_short_kernel(const RedPack 
       if (!(flags[j] & kFlagPass)) { closed = true; break; }
     }
     if (!closed && c > 0) {
-      if (lane_g == 0) fin[2 + n_chunks + atomicAdd(fin + 1, 1u)] = c;
+      if (lane_g == 0) fin[kFinList + n_chunks + atomicAdd(fin + 1, 1u)] = c;
       continue;
     }
     const unsigned s = c * kChunk;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
                                                                  const float* __restrict__ head,
                                                                  const float* __restrict__ tail,
                                                                  const int* __restrict__ flags,
-                                                                 const unsigned* __restrict__ fin, const int max_dim,
+                                                                 unsigned* __restrict__ fin, const int max_dim,
                                                                  const int sum_stride, const unsigned n_chunks) {
   using F = Frag<G, NV, VEC>;
   constexpr int NGB = 256 / G;          // lane groups per workgroup
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
   const int gi = threadIdx.x / G, lane_g = threadIdx.x % G;
   const unsigned count = fin[1];
   for (unsigned idx = blockIdx.x; idx < count; idx += gridDim.x) {
-    const unsigned c = fin[2 + n_chunks + idx];
+    const unsigned c = fin[kFinList + n_chunks + idx];
     const unsigned s = c * kChunk;
     const unsigned key = keys[s];
     const RedField fd = P.f[vals[s] >> kLocalBits];
@@ -311,6 +312,17 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
     }
     if (gi == 0) Policy::flush(args, fd, key - fd.row_base, acc, cnt, pre, lane_g);
   }
+  // the last workgroup to get here clears the counters: the workspace is ready for another backward on the same
+  // sorted ids (build_keys clears them for a new sort), and no memset node sits between the sort and the reduce
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(fin + 2, 1u) == gridDim.x - 1) {
+      fin[0] = 0;
+      fin[1] = 0;
+      fin[2] = 0;
+    }
+  }
 }
 
 template <class Policy, int G, int NV, bool VEC>
@@ -322,8 +334,7 @@ static int launch_reduce(const BwdPlan& p, const typename Policy::Args& args, co
   float* tail = reinterpret_cast<float*>(ws + p.off_tail);
   int* flags = reinterpret_cast<int*>(ws + p.off_flags);
   unsigned* fin = reinterpret_cast<unsigned*>(ws + p.off_fin);
-  if (hipMemsetAsync(fin, 0, 2 * sizeof(unsigned), s) != hipSuccess)
-    return fail(RBX_ERR_LAUNCH, "memset of the fix-up counters failed");
+  // fin[0..2] are zero here: build_keys clears them for a new sort, the long fix-up kernel when it is done
   hipLaunchKernelGGL((segment_reduce_kernel<Policy, G, NV, VEC>), dim3(blocks), dim3(256), 0, s, p.red, p.n_cat, args,
                      keys, vals, p.n_lookups, p.total_rows, head, tail, flags, fin, p.max_dim, p.sum_stride,
                      p.n_chunks);
