@@ -182,7 +182,8 @@ def main():
     # every step starts from zero_grad(set_to_none=True): the dense gradients may live in ONE persistent buffer of which
     # only the rows the previous step wrote are cleared (rbx_fm_rezero) instead of a 379 MB zero fill per step; p.grad
     # after a step is the same dense [V, D] tensor either way (tests/test_gpu_ranking.py: bit-identical)
-    ops.config.reuse_grad_buffers = not args.fresh_grads
+    # (the N>1 path keeps fresh gradients: its replicated tables are the small ones, there is nothing to save)
+    ops.config.reuse_grad_buffers = not (args.fresh_grads or world > 1 or args.force_sharded)
     fmw = CriteoFeatureMap(args.dim)
     sharded = world > 1 or args.force_sharded
     B = args.batch
