@@ -138,8 +138,16 @@ class ShardedFMStep(object):
     def _head(self):
         for p in self.replicated:
             p.grad = None
-        # the fused FM kernel reads row (b, t) at wire slot slot[b, t] of the exchange buffer (no un-permute pass)
-        self.logit = self.model.logits(self.X, packed=self.back, packed_index=self.slot)
+        # the fused FM kernel reads row (b, t) at wire slot slot[b, t] of the exchange buffer (no un-permute pass).
+        # Fresh gradients here: _finish writes the ALL-REDUCED gradients into p.grad, i.e. rows this rank's batch never
+        # touched -- a persistent buffer that is re-zeroed by this rank's sorted ids (ops.config.reuse_grad_buffers)
+        # would keep them.
+        reuse = ops.config.reuse_grad_buffers
+        ops.config.reuse_grad_buffers = reuse and self.W == 1
+        try:
+            self.logit = self.model.logits(self.X, packed=self.back, packed_index=self.slot)
+        finally:
+            ops.config.reuse_grad_buffers = reuse
         leaf = self.logit.detach().requires_grad_()
         loss = self.loss_fn(torch.sigmoid(leaf), self.y)
         (loss / self.W).backward()                # global-mean loss: owners sum the contributions of every rank

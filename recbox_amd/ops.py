@@ -34,7 +34,9 @@ class config(object):
     # step (379 MB at the Criteo shape), clear only the rows the previous step wrote (rbx_fm_rezero, 36 MB).  The
     # gradients handed to autograd then ALIAS that buffer: they are valid until the next training forward of the same
     # op (the contract hipGraph replays have anyway -- recbox_amd.graph.GraphedStep turns this on), and every step
-    # must start from ``p.grad is None`` (optimizer.zero_grad(set_to_none=True)).  Off by default.
+    # must start from ``p.grad is None`` (optimizer.zero_grad(set_to_none=True)), and nothing may write OTHER rows into
+    # those gradients in place (an in-place all-reduce of table gradients would: rows of other ranks' batches are not
+    # in this rank's sorted ids and would never be cleared).  Off by default.
     reuse_grad_buffers = os.environ.get("RECBOX_AMD_REUSE_GRADS", "0") != "0"
 
 

@@ -114,9 +114,16 @@ class ShardedFM(nn.Module):
             if packed is None:
                 packed = self.tables(self.sharded_ids(X))                              # [B, T, D + 4] from the owners
             lr_off = self.tables.lr_off
-        return ops.fm_fused(plan.plan, lplan.plan, values, [m.weight for m in plan.modules],
-                            [m.weight for m in lplan.modules], self.fm.lr_layer.bias, extra=packed,
-                            extra_lr_off=lr_off, extra_index=packed_index)
+        # sync_grads() writes all-reduced rows (other ranks' batches) into the replicated tables' gradients in place:
+        # they must be fresh tensors, not the row-re-zeroed persistent buffer of ops.config.reuse_grad_buffers
+        reuse = ops.config.reuse_grad_buffers
+        ops.config.reuse_grad_buffers = reuse and self.world_size == 1
+        try:
+            return ops.fm_fused(plan.plan, lplan.plan, values, [m.weight for m in plan.modules],
+                                [m.weight for m in lplan.modules], self.fm.lr_layer.bias, extra=packed,
+                                extra_lr_off=lr_off, extra_index=packed_index)
+        finally:
+            ops.config.reuse_grad_buffers = reuse
 
     def forward(self, X):
         return {"y_pred": torch.sigmoid(self.logits(X))}
