@@ -63,6 +63,9 @@ class ShardedFMStep(object):
         all-to-all row numbers to the owners                              RCCL
         serve      owners gather the packed rows (rbx_embed_fwd)          [graph]
         presort    owners sort the received row numbers (rbx_embed_sort)  [graph, side stream, joined before settle]
+        localsort  id sort of the replicated tables' backward (rbx_fm_sort; needs X only)
+                                                                          [graph, own stream from the start of the step,
+                                                                           beside route / exchange / serve; joined before tail]
         all-to-all rows back                                              RCCL
         head       fused FM forward (remote rows read at their wire slots),
                    loss, dL/dlogit, dL/d(remote rows) written to the slots [graph]
@@ -104,7 +107,9 @@ class ShardedFMStep(object):
         self.comm = comm
         self.pieces = [self._route, self._serve, self._head, self._tail, self._settle, self._finish]
         self.side = torch.cuda.Stream(device=dev)        # owner-side id sort runs here, beside the local forward
+        self.early = torch.cuda.Stream(device=dev)       # id sort of the replicated tables: beside route / exchange / serve
         self.sorted_ws = None
+        self.local_sorted = None
         self.graphs = None
         if graphs:
             side = torch.cuda.Stream()
@@ -116,11 +121,15 @@ class ShardedFMStep(object):
             torch.cuda.synchronize()
             self.graphs = []
             for piece in self.pieces:
-                if piece == self._head:                 # the owner-side sort is captured on its own stream first
+                if piece == self._head:                 # the two id sorts are captured on their own streams first
                     gs = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gs, stream=self.side, capture_error_mode="thread_local"):
                         self._presort()
                     self.presort_replay = gs.replay
+                    gl = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gl, stream=self.early, capture_error_mode="thread_local"):
+                        self._localsort()
+                    self.localsort_replay = gl.replay
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     piece()
@@ -145,7 +154,8 @@ class ShardedFMStep(object):
         reuse = ops.config.reuse_grad_buffers
         ops.config.reuse_grad_buffers = reuse and self.W == 1
         try:
-            self.logit = self.model.logits(self.X, packed=self.back, packed_index=self.slot)
+            self.logit = self.model.logits(self.X, packed=self.back, packed_index=self.slot,
+                                           presorted=self.local_sorted)
         finally:
             ops.config.reuse_grad_buffers = reuse
         leaf = self.logit.detach().requires_grad_()
@@ -154,12 +164,16 @@ class ShardedFMStep(object):
         self.loss, self.dlogit = loss.detach(), leaf.grad
         # dL/d(remote rows) goes to the same wire slots and leaves for the owners while the local backward runs
         self.dsend = ops.fm_extra_grad(self.logit, self.dlogit, self.back, self.slot, self.tables.lr_off)
-        ops.join_early_sort(self.logit)           # the side-stream sort must end inside this graph piece
+        ops.join_early_sort(self.logit)           # (a sort started by the forward itself must end inside this piece)
 
     def _tail(self):
         self.logit.backward(self.dlogit)          # fused backward of the replicated tables / numeric weights / bias
         self.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                                for p in self.replicated]) if self.replicated else None
+
+    def _localsort(self):
+        # ids of the replicated tables -> sorted (row, sample) pairs for the fused backward; needs X only
+        self.local_sorted = self.model.presort_local(self.X)
 
     def _presort(self):
         self.sorted_ws = self.tables.local_ops.presort(self.tables.weight, self.recv)
@@ -181,18 +195,24 @@ class ShardedFMStep(object):
     def _run(self, pieces):
         route, serve, head, tail, settle, finish = pieces
         comm, group = self.comm, self.group
+        cur = torch.cuda.current_stream()
+        # the id sort of the replicated tables' backward depends on X only: it fills the GPU while route -> exchange ->
+        # serve -> exchange (short, dependent, partly on the wire) are under way, and is joined before the tail
+        self.early.wait_stream(cur)
+        with torch.cuda.stream(self.early):
+            (self.localsort_replay if pieces is self.graphs else self._localsort)()
         route()
         comm.all_to_all_equal_into(self.recv, self.send, group)
         serve()
         # the owners' id sort needs only the row numbers: it runs on a side stream beside the rows' way back and
         # the local forward, and is joined right before the owner-side scatter-add
-        cur = torch.cuda.current_stream()
         self.side.wait_stream(cur)
         with torch.cuda.stream(self.side):
             (self.presort_replay if pieces is self.graphs else self._presort)()
         comm.all_to_all_equal_into(self.back, self.vecs, group)
         head()
         grads_out = comm.all_to_all_equal_into(self.d_recv, self.dsend, group, async_op=True)
+        cur.wait_stream(self.early)
         tail()                                    # overlaps with the gradient exchange
         reduced = comm.all_reduce_sum_(self.flat, group, async_op=True) if self.flat is not None else None
         grads_out.wait()

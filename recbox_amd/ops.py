@@ -431,7 +431,8 @@ class _FmFused(torch.autograd.Function):
     part like local features; their gradients come back as ordinary autograd outputs."""
 
     @staticmethod
-    def forward(ctx, emb_plan, lr_plan, n_inputs, n_emb, n_lr, train, has_bias, has_extra, extra_index, *tensors):
+    def forward(ctx, emb_plan, lr_plan, n_inputs, n_emb, n_lr, train, has_bias, has_extra, extra_index, presorted,
+                *tensors):
         inputs = tensors[:n_inputs]
         emb_params = tensors[n_inputs:n_inputs + n_emb]
         lr_params = tensors[n_inputs + n_emb:n_inputs + n_emb + n_lr]
@@ -488,7 +489,11 @@ class _FmFused(torch.autograd.Function):
         ctx.state = (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias, has_extra,
                      extra_index)
         ctx.sort = sort
-        if train and B > 0 and not config.sort_before_forward:
+        if presorted is not None:
+            if presorted.B != B or presorted.n != lead.n:
+                raise ValueError("fm_fused: the presorted ids belong to another batch")
+            ctx.sort = presorted                  # fm_presort ran ahead of this forward; the caller orders the streams
+        elif train and B > 0 and not config.sort_before_forward:
             if emb_plan is not None:
                 emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
             if lr_plan is not None:
@@ -556,7 +561,7 @@ class _FmFused(torch.autograd.Function):
         (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias,
          has_extra, extra_index) = ctx.state
         n_emb, n_lr = len(emb_params), len(lr_params)
-        base = 9 + n_inputs
+        base = 10 + n_inputs
         want_e = [ctx.needs_input_grad[base + i] for i in range(n_emb)]
         want_l = [ctx.needs_input_grad[base + n_emb + i] for i in range(n_lr)]
         pos = base + n_emb + n_lr
@@ -633,8 +638,40 @@ class _FmFused(torch.autograd.Function):
         return result()
 
 
+class _Presorted(object):
+    """Sorted ids of a fused FM backward, produced ahead of the forward by ``fm_presort``."""
+
+    def __init__(self, ws, ws_bytes, B, n):
+        self.ws, self.ws_bytes, self.B, self.n, self.event = ws, ws_bytes, B, n, None
+
+    def join(self):
+        pass                                      # the caller of fm_presort orders its streams itself
+
+
+def fm_presort(emb_plan, lr_plan, inputs, emb_params, lr_params):
+    """The id sort of ``fm_fused``'s backward (rbx_fm_sort) on the CURRENT stream, before the forward exists: it needs
+    the ids only.  A step that spends its first part waiting for remote rows (recbox_amd.graph.ShardedFMStep) runs it
+    there, on a stream of its own, and hands the result to ``fm_fused(..., presorted=...)``; the backward must be
+    ordered after it by the caller (stream wait)."""
+    lead = emb_plan if emb_plan is not None else lr_plan
+    B, keep = lead.bind_inputs(inputs)
+    if emb_plan is not None:
+        emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
+        if lr_plan is not None:
+            lr_plan.bind_inputs(keep)
+    if lr_plan is not None:
+        lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
+    ea = emb_plan.arr if emb_plan is not None else None
+    la = lr_plan.arr if lr_plan is not None else None
+    ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B) if B > 0 else 0
+    ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=keep[0].device)
+    if ws_bytes > 0:
+        check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, _stream()))
+    return _Presorted(ws, int(ws_bytes), B, lead.n)
+
+
 def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=None, extra_lr_off=-1,
-             extra_index=None):
+             extra_index=None, presorted=None):
     """FM model body: LR(X) + bias + product_sum(FeatureEmbedding(X)); either part may be absent.
     extra [B, T, stride]: packed rows of row-sharded tables already fetched from their owners (embedding in
     floats [0, D), the LR weight at float ``extra_lr_off``; -1 = no LR weight in the row).
@@ -650,7 +687,8 @@ def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=
     needs = list(emb_params) + list(lr_params) + list(tail)
     train = torch.is_grad_enabled() and any(p.requires_grad for p in needs)
     return _FmFused.apply(emb_plan, lr_plan, len(inputs), len(emb_params), len(lr_params), train,
-                          bias is not None, has_extra, extra_index, *inputs, *emb_params, *lr_params, *tail)
+                          bias is not None, has_extra, extra_index, presorted if train else None, *inputs,
+                          *emb_params, *lr_params, *tail)
 
 
 def fm_extra_grad(logit, dlogit, extra, extra_index, extra_lr_off):

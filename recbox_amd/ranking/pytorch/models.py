@@ -98,17 +98,28 @@ class ShardedFM(nn.Module):
     def sharded_ids(self, X):
         return torch.stack([X[n].long() for n in self.sharded_names], dim=1)           # [B, T]
 
-    def logits(self, X, packed=None, packed_index=None):
-        """``packed`` [B, T, row_width]: rows of the sharded tables already fetched from their owners (the
-        piecewise-graphed step of recbox_amd.graph does the exchange itself); None = fetch them here.
-        With ``packed_index`` [B, T] int32, ``packed`` is the exchange buffer [slots, row_width] and row (b, t)
-        sits at wire slot packed_index[b, t]."""
+    def _fused_plans(self, X):
         emb = self.embedding_layer.embedding_layer
         lr = self.fm.lr_layer.embedding_layer.embedding_layer
         names, values, plan, posts = emb.plan_for(X)
         lnames, _, lplan, lposts = lr.plan_for(X)
         if not (emb.fusable(plan, posts) and lr.fusable(lplan, lposts) and names == lnames):
             raise NotImplementedError("ShardedFM fuses one-id-per-sample categorical and numeric features only")
+        return values, plan, lplan
+
+    def presort_local(self, X):
+        """The id sort of the replicated tables' backward, on the current stream (ops.fm_presort): it needs ``X`` only,
+        so a step can run it while the remote rows are still on their way; pass the result to ``logits``."""
+        values, plan, lplan = self._fused_plans(X)
+        return ops.fm_presort(plan.plan, lplan.plan, values, [m.weight for m in plan.modules],
+                              [m.weight for m in lplan.modules])
+
+    def logits(self, X, packed=None, packed_index=None, presorted=None):
+        """``packed`` [B, T, row_width]: rows of the sharded tables already fetched from their owners (the
+        piecewise-graphed step of recbox_amd.graph does the exchange itself); None = fetch them here.
+        With ``packed_index`` [B, T] int32, ``packed`` is the exchange buffer [slots, row_width] and row (b, t)
+        sits at wire slot packed_index[b, t].  ``presorted``: result of ``presort_local(X)``."""
+        values, plan, lplan = self._fused_plans(X)
         lr_off = -1
         if self.tables is not None:
             if packed is None:
@@ -121,7 +132,7 @@ class ShardedFM(nn.Module):
         try:
             return ops.fm_fused(plan.plan, lplan.plan, values, [m.weight for m in plan.modules],
                                 [m.weight for m in lplan.modules], self.fm.lr_layer.bias, extra=packed,
-                                extra_lr_off=lr_off, extra_index=packed_index)
+                                extra_lr_off=lr_off, extra_index=packed_index, presorted=presorted)
         finally:
             ops.config.reuse_grad_buffers = reuse
 

@@ -74,7 +74,7 @@ def _worker(rank, world, port, mode, result):
             keep = (owned != 0).cuda()           # row 0 is padding_idx in FM, an ordinary row in the shards
             assert_close(got[keep][:, :D], ref_g[E_PRE % name][owned.cuda()][keep], 1e-6, "shard emb " + name)
             assert_close(got[keep][:, D], ref_g[L_PRE % name][owned.cuda()][keep][:, 0], 1e-6, "shard lr " + name)
-        result[rank] = "ok"
+        result.put((rank, "ok"))
     finally:
         dist.destroy_process_group()
 
@@ -82,6 +82,12 @@ def _worker(rank, world, port, mode, result):
 @pytest.mark.parametrize("mode,world", [("exact", 2), ("padded", 2), ("padded", 3)])
 def test_ranks_on_one_gpu_equal_single_gpu_fm(mode, world):
     from test_distributed_gloo import _free_port
-    result = mp.Manager().dict()
+    # (no mp.Manager here: it forks a server out of a parent whose HIP runtime is already initialised, and the proxy
+    #  connection then drops now and again; a spawn-context queue has no such child)
+    result = mp.get_context("spawn").SimpleQueue()
     mp.spawn(_worker, args=(world, _free_port(), mode, result), nprocs=world, join=True)
-    assert dict(result) == {r: "ok" for r in range(world)}
+    got = {}
+    while not result.empty():
+        rank, status = result.get()
+        got[rank] = status
+    assert got == {r: "ok" for r in range(world)}
