@@ -231,7 +231,7 @@ def main():
         step = GraphedStep(eager_step, warmup=3, reuse_grads=not args.fresh_grads)
         graph_note = "hipGraph replay"
     elif sharded and cap_factor and model.tables is not None:
-        # padded sync-free exchange: the step is four hipGraph pieces with the RCCL collectives between them
+        # padded sync-free exchange: the step is eight hipGraph pieces with the RCCL collectives between them
         from recbox_amd.graph import ShardedFMStep
         use_graphs = not args.eager
         for _ in range(4):
@@ -252,7 +252,7 @@ def main():
             cap_factor *= 2                   # skewed ids: some owner received more than its slots; start over
             del step
             model = build_model()
-        graph_note = "7 hipGraph pieces + RCCL collectives between them" if use_graphs else "eager launches"
+        graph_note = "8 hipGraph pieces + RCCL collectives between them" if use_graphs else "eager launches"
 
     for _ in range(args.warmup):
         step()

@@ -324,6 +324,11 @@ int rbx_bce_mean_fwd(const float* d_prob, const float* d_target, int64_t n, floa
                      size_t workspace_bytes, void* stream);
 int rbx_bce_mean_bwd(const float* d_prob, const float* d_target, const float* d_dloss, int64_t n, float* d_dprob,
                      void* stream);
+/* The same loss on LOGITS with both backward steps folded in (a step that owns its loss, recbox_amd.graph.ShardedFMStep):
+ * p = sigmoid(x) (optional output d_prob = the model's y_pred, ranking_model.py forward), d_loss[0] = the mean BCE as above,
+ * d_dlogit = grad_scale * dL/dx = grad_scale / n * (p - y) / max(p (1 - p), 1e-12) * (1 - p) p (optional). */
+int rbx_sigmoid_bce_mean(const float* d_logit, const float* d_target, int64_t n, float grad_scale, float* d_prob,
+                         float* d_loss, float* d_dlogit, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- dense tower: y = act(x W^T + b) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------
  * core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58,

@@ -88,6 +88,7 @@ SIGNATURES = {
     "rbx_bce_workspace_size": (_sz, [_i64]),
     "rbx_bce_mean_fwd": (ctypes.c_int, [_P, _P, _i64, _P, _P, _sz, _P]),
     "rbx_bce_mean_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _P, _P]),
+    "rbx_sigmoid_bce_mean": (ctypes.c_int, [_P, _P, _i64, _f32, _P, _P, _P, _P, _sz, _P]),
     "rbx_pairmul_fwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _i32, _P, _P]),
     "rbx_pairmul_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _P, _P, _P]),
     "rbx_l2norm_fwd": (ctypes.c_int, [_P, _i64, _i32, _f32, _P, _P, _P]),

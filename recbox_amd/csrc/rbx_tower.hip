@@ -339,7 +339,55 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
   }
 }
 
+// sigmoid + BCE + both backward steps in ONE pass (the step of recbox_amd.graph.ShardedFMStep owns its loss, so the
+// nine small kernels of sigmoid -> BCE -> backward -> sigmoid backward collapse into this one and bce_final_kernel):
+// p = 1 / (1 + exp(-x)); the loss term and dL/dp exactly as above; dL/dx = dL/dp * (1 - p) * p (torch's sigmoid backward).
+__global__ __launch_bounds__(256) void sigmoid_bce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const long long n, const float gscale, float* __restrict__ prob,
+                                                          float* __restrict__ dx, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const long long base = static_cast<long long>(blockIdx.x) * kBceBlock;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < kBceBlock / 256; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    if (i < n) {
+      const float pi = 1.f / (1.f + expf(-x[i])), yi = y[i];
+      const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(log1pf(-pi), -100.f);
+      acc -= yi * lp + (1.f - yi) * lq;
+      if (prob != nullptr) prob[i] = pi;
+      if (dx != nullptr) {
+        const float dp = gscale * (pi - yi) / fmaxf((1.f - pi) * pi, 1e-12f);
+        dx[i] = dp * (1.f - pi) * pi;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace rbx
+
+extern "C" int rbx_sigmoid_bce_mean(const float* d_logit, const float* d_target, int64_t n, float grad_scale, float* d_prob,
+                                    float* d_loss, float* d_dlogit, void* d_workspace, size_t workspace_bytes,
+                                    void* stream) {
+  using namespace rbx;
+  if (n <= 0) return fail(RBX_ERR_INVALID, "sigmoid_bce: empty input (the mean of no elements is undefined)");
+  if (!d_logit || !d_target || !d_loss) return fail(RBX_ERR_INVALID, "sigmoid_bce: NULL tensor");
+  if (d_workspace == nullptr || workspace_bytes < rbx_bce_workspace_size(n))
+    return fail(RBX_ERR_WORKSPACE, "sigmoid_bce: workspace too small");
+  const long long nb = (n + kBceBlock - 1) / kBceBlock;
+  if (nb >= INT_MAX) return fail(RBX_ERR_UNSUPPORTED, "sigmoid_bce: too many elements");
+  float* partial = static_cast<float*>(d_workspace);
+  const float inv_n = 1.0f / static_cast<float>(n);
+  hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, as_stream(stream), d_logit, d_target,
+                     static_cast<long long>(n), grad_scale * inv_n, d_prob, d_dlogit, partial);
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, static_cast<int>(nb), inv_n, d_loss);
+  return check_launch("sigmoid_bce kernels");
+}
 
 extern "C" size_t rbx_bce_workspace_size(int64_t n) {
   return n > 0 ? static_cast<size_t>((n + rbx::kBceBlock - 1) / rbx::kBceBlock) * sizeof(float) + 256 : 0;

@@ -56,7 +56,7 @@ class GraphedStep(object):
 
 
 class ShardedFMStep(object):
-    """One training step of ``ShardedFM`` (row-sharded tables, padded sync-free exchange) as SIX hipGraph
+    """One training step of ``ShardedFM`` (row-sharded tables, padded sync-free exchange) as hipGraph
     pieces with the RCCL collectives launched between them:
 
         route      ids -> (owner, row) -> wire slots (rbx_route)          [graph]
@@ -94,6 +94,7 @@ class ShardedFMStep(object):
         self.group = tables.group
         self.W = W = tables.world_size
         self.loss_fn = loss_fn or ops.binary_cross_entropy      # the ranking harness's mean BCE on sigmoid outputs
+        self.fused_loss = loss_fn is None                       # ... which this step then evaluates on the logits in one pass
         ids = model.sharded_ids(X)
         self.B, self.T = ids.shape
         self.cap = cap = tables.capacity_for(ids.numel())
@@ -158,10 +159,13 @@ class ShardedFMStep(object):
                                            presorted=self.local_sorted)
         finally:
             ops.config.reuse_grad_buffers = reuse
-        leaf = self.logit.detach().requires_grad_()
-        loss = self.loss_fn(torch.sigmoid(leaf), self.y)
-        (loss / self.W).backward()                # global-mean loss: owners sum the contributions of every rank
-        self.loss, self.dlogit = loss.detach(), leaf.grad
+        if self.fused_loss:                       # sigmoid + mean BCE + both backward steps: two kernels instead of nine
+            self.loss, self.dlogit = ops.sigmoid_bce(self.logit, self.y, grad_scale=1.0 / self.W)
+        else:
+            leaf = self.logit.detach().requires_grad_()
+            loss = self.loss_fn(torch.sigmoid(leaf), self.y)
+            (loss / self.W).backward()            # global-mean loss: owners sum the contributions of every rank
+            self.loss, self.dlogit = loss.detach(), leaf.grad
         # dL/d(remote rows) goes to the same wire slots and leaves for the owners while the local backward runs
         self.dsend = ops.fm_extra_grad(self.logit, self.dlogit, self.back, self.slot, self.tables.lr_off)
         ops.join_early_sort(self.logit)           # (a sort started by the forward itself must end inside this piece)

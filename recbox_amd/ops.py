@@ -1242,6 +1242,26 @@ def binary_cross_entropy(y_pred, y_true, reduction="mean"):
     return _BceMean.apply(y_pred, y_true)
 
 
+def sigmoid_bce(logit, y_true, grad_scale=1.0, want_prob=False):
+    """(loss, dL/dlogit * grad_scale[, y_pred]) of ``F.binary_cross_entropy(torch.sigmoid(logit), y_true)`` in one pass
+    plus the fixed-order final sum (rbx_sigmoid_bce_mean): for a step that owns its loss and drives the backward itself
+    (recbox_amd.graph.ShardedFMStep); no autograd node is recorded."""
+    _require_cuda(logit, "logit")
+    x = logit.detach().contiguous().float()
+    y = y_true.detach().contiguous().float()
+    if x.numel() != y.numel():
+        raise ValueError("sigmoid_bce: %s logits vs %s targets" % (tuple(x.shape), tuple(y.shape)))
+    n = x.numel()
+    loss = torch.empty((), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    prob = torch.empty_like(x) if want_prob else None
+    ws_bytes = lib.rbx_bce_workspace_size(n)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+    check(lib.rbx_sigmoid_bce_mean(_ptr(x), _ptr(y), n, float(grad_scale), _ptr(prob), _ptr(loss), _ptr(dx), _ptr(ws),
+                                   ws_bytes, _stream()))
+    return (loss, dx, prob) if want_prob else (loss, dx)
+
+
 class _PairMul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, left, right, per_pair):

@@ -501,6 +501,29 @@ def test_bce_mean_vs_torch(n):
     assert get_loss("mse_loss") is torch.nn.functional.mse_loss
 
 
+@pytest.mark.parametrize("n", [1, 777, 65536])
+def test_sigmoid_bce_vs_torch_chain(n):
+    """rbx_sigmoid_bce_mean == sigmoid -> F.binary_cross_entropy(mean) -> backward of torch CPU: loss, y_pred and
+    dL/dlogit (with a gradient scale), including saturated logits (log clamp at -100, 1e-12 clamp of the backward)."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 1, generator=g) * 3
+    y = (torch.rand(n, 1, generator=g) < 0.3).float()
+    if n > 6:
+        x[0], x[1], y[0], y[1] = -120.0, 120.0, 1.0, 0.0          # saturated and wrong
+        x[2], x[3], y[2], y[3] = -30.0, 30.0, 0.0, 1.0            # saturated and right
+        x[4], x[5] = 17.0, -17.0
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy(torch.sigmoid(xr), y, reduction="mean")
+    (ref / 4.0).backward()
+    loss, dx, prob = ops.sigmoid_bce(x.cuda(), y.cuda(), grad_scale=0.25, want_prob=True)
+    assert_close(loss.reshape(1), ref.detach().reshape(1), 1e-6 * max(1.0, float(ref.detach())), "loss")
+    assert_close(prob, torch.sigmoid(x), 1e-6, "y_pred")
+    assert float((dx.cpu() - xr.grad).abs().max()) <= 1e-6 * max(1.0, float(xr.grad.abs().max())) / max(1, n) * n
+    again = ops.sigmoid_bce(x.cuda(), y.cuda(), grad_scale=0.25)
+    assert torch.equal(again[0], loss) and torch.equal(again[1], dx)
+
+
 @pytest.mark.parametrize("kind", ["field_all", "field_each", "field_interaction"])
 def test_bilinear_golden(kind):
     """BilinearInteraction / BilinearInteractionV2 against the live-reference fixture (the reference's
