@@ -201,6 +201,15 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
 int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                   void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---- C2: the exchange itself on the caller's stream.  The reference has no sharded exchange (nn.DataParallel / DDP
+ * only); recbox_amd/comm.py uses torch.distributed's all_to_all_single by default, which runs on RCCL's
+ * own stream behind two event joins.  rbx_all_to_all is the same grouped ncclSend / ncclRecv sequence enqueued on
+ * `stream`: block p of d_send (bytes_per_peer bytes) goes to rank p, block p of d_recv comes from rank p.  `comm` is
+ * the ncclComm_t of the process group (ProcessGroupNCCL._comm_ptr()); rbx_comm_bind hands over the RCCL entry points
+ * of the library the process has already loaded (ncclGroupStart, ncclGroupEnd, ncclSend, ncclRecv, ncclGetErrorString). */
+int rbx_comm_bind(void* fn_group_start, void* fn_group_end, void* fn_send, void* fn_recv, void* fn_error_string);
+int rbx_all_to_all(void* comm, const void* d_send, void* d_recv, size_t bytes_per_peer, int32_t world, void* stream);
+
 /* ---- K5: two-tower scoring (third_party/rechub/models/matching/dssm.py:48,57,65,
  * youtube_dnn.py:47-48,56,65,70).  l2norm = F.normalize(x, p=2, dim=-1, eps): y = x / max(||x||, eps);
  * d_inv[rows] keeps 1/max(||x||,eps) (negative when the clamp was active) for the backward.

@@ -5,6 +5,8 @@ all-to-all maps to ``all_to_all_single`` (grouped send/recv on the current HIP s
 direct xGMI link per peer on a fully connected 8-GPU node).  gloo (CPU tests) has no
 all-to-all, so the same exchange is expressed with batched point-to-point there.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -86,6 +88,112 @@ class _Done(object):
         return True
 
 
+class _Joined(object):
+    def __init__(self, cur, side):
+        self.cur, self.side = cur, side
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self.side)
+        return True
+
+
+class _Direct(object):
+    """RCCL's grouped send/recv issued on the caller's stream through the C ABI (rbx_all_to_all), with the
+    communicator torch.distributed built.  Off unless ``RECBOX_AMD_DIRECT_RCCL=1`` / ``comm.direct.enable()``:
+    torch.distributed's own call stays the default and the fallback."""
+
+    def __init__(self):
+        self.on = os.environ.get("RECBOX_AMD_DIRECT_RCCL", "0") != "0"
+        self.bound = False
+        self.comms = {}
+        self.stream = None              # for exchanges that overlap with compute (async_op)
+        self.keep = None
+
+    def enable(self, on=True):
+        self.on = bool(on)
+
+    def _bind(self):
+        import ctypes
+        import glob
+        from . import _lib
+        cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so.1", "librccl.so"]
+        err = None
+        for path in cands:
+            try:
+                rccl = ctypes.CDLL(path)          # already loaded by torch: this only takes a handle
+                fns = [ctypes.cast(getattr(rccl, n), ctypes.c_void_p)
+                       for n in ("ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString")]
+                _lib.check(_lib.lib.rbx_comm_bind(*fns))
+                self.keep, self.bound = rccl, True
+                return
+            except (OSError, AttributeError) as exc:
+                err = exc
+        raise RuntimeError("recbox_amd.comm: cannot bind RCCL (%s)" % (err,))
+
+    def comm_ptr(self, group, device):
+        key = (id(group), device.index)
+        ptr = self.comms.get(key)
+        if ptr is None:
+            pg = group if group is not None else dist.distributed_c10d._get_default_group()
+            ptr = int(pg._get_backend(torch.device("cuda", device.index))._comm_ptr())
+            if ptr == 0:
+                raise RuntimeError("recbox_amd.comm: the process group has no RCCL communicator yet")
+            self.comms[key] = ptr
+        return ptr
+
+    def all_to_all(self, out, x, group, async_op):
+        import ctypes
+        from . import _lib
+        if not self.bound:
+            self._bind()
+        W = dist.get_world_size(group)
+        if not (x.is_contiguous() and out.is_contiguous()) or x.numel() * x.element_size() != out.numel() * out.element_size():
+            raise ValueError("all_to_all_equal_into: contiguous buffers of equal size")
+        nbytes = x.numel() * x.element_size()
+        if nbytes % W:
+            raise ValueError("all_to_all_equal_into: %d bytes do not split over %d ranks" % (nbytes, W))
+        comm = self.comm_ptr(group, x.device)
+        cur = torch.cuda.current_stream(x.device)
+        st = cur
+        if async_op:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=x.device)
+            st = self.stream
+            st.wait_stream(cur)
+        _lib.check(_lib.lib.rbx_all_to_all(ctypes.c_void_p(comm), ctypes.c_void_p(x.data_ptr()),
+                                           ctypes.c_void_p(out.data_ptr()), nbytes // W, W,
+                                           ctypes.c_void_p(st.cuda_stream)))
+        return _Joined(cur, st) if async_op else _Done()
+
+
+    def self_check(self, group=None, device=None):
+        """One small exchange both ways (this path and torch.distributed's) on a known pattern; switches the direct
+        path off, with a warning, if it raises or differs.  Every rank must call it."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"):
+            return self.on
+        rank, W = dist.get_rank(group), dist.get_world_size(group)
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        x = (torch.arange(W * 6, dtype=torch.float32, device=device) + 1000.0 * rank).reshape(W * 3, 2)
+        want = torch.empty_like(x)
+        dist.all_to_all_single(want, x, group=group)
+        ok = torch.zeros(1, device=device)
+        try:
+            got = torch.empty_like(x)
+            self.all_to_all(got, x, group, False)
+            again = torch.empty_like(x)
+            self.all_to_all(again, x, group, True).wait()
+            ok.fill_(1.0 if (torch.equal(got, want) and torch.equal(again, want)) else 0.0)
+        except Exception as exc:                      # noqa: BLE001 -- any failure means "use torch.distributed"
+            import warnings
+            warnings.warn("recbox_amd.comm: direct RCCL exchange unavailable (%s: %s)" % (type(exc).__name__, exc))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks take the same path
+        self.on = bool(ok.item() > 0)
+        return self.on
+
+
+direct = _Direct()
+
+
 def all_to_all_equal_into(out, x, group=None, async_op=False):
     """all_to_all_equal into a caller-owned buffer (static buffers between hipGraph pieces).  Returns a handle
     whose ``wait()`` orders the current stream after the exchange; with ``async_op`` the exchange runs on RCCL's
@@ -93,6 +201,8 @@ def all_to_all_equal_into(out, x, group=None, async_op=False):
     if not (dist.is_available() and dist.is_initialized()):
         out.copy_(x)
     elif dist.get_backend(group) == "nccl":
+        if direct.on:
+            return direct.all_to_all(out, x, group, async_op)
         work = dist.all_to_all_single(out, x, group=group, async_op=async_op)
         if async_op:
             return work

@@ -1,0 +1,52 @@
+// rbx_comm.hip -- the exchange step of the row-sharded tables issued straight on the caller's HIP stream.
+//
+// torch.distributed runs every collective on RCCL's own stream and joins it to the caller's stream with two events;
+// between short dependent pieces (route -> ids out -> gather -> rows back -> forward ...) each of those joins costs
+// 15-50 us of idle GPU.  Here the all-to-all is the grouped ncclSend / ncclRecv sequence itself, enqueued on the
+// stream the neighbouring kernels run on, through the communicator torch.distributed already built (its handle is
+// passed in; the RCCL entry points come from the library the process has loaded -- rbx_comm_bind -- so this file
+// links against nothing).
+#include "rbx_internal.h"
+
+namespace rbx {
+typedef int (*nccl_group_fn)();
+typedef int (*nccl_p2p_fn)(void* buf, size_t count, int datatype, int peer, void* comm, hipStream_t stream);
+typedef const char* (*nccl_err_fn)(int);
+static nccl_group_fn g_group_start = nullptr, g_group_end = nullptr;
+static nccl_p2p_fn g_send = nullptr, g_recv = nullptr;
+static nccl_err_fn g_errstr = nullptr;
+constexpr int kNcclInt8 = 0;      // ncclInt8 / ncclChar
+}  // namespace rbx
+
+extern "C" int rbx_comm_bind(void* fn_group_start, void* fn_group_end, void* fn_send, void* fn_recv, void* fn_error_string) {
+  using namespace rbx;
+  if (!fn_group_start || !fn_group_end || !fn_send || !fn_recv)
+    return fail(RBX_ERR_INVALID, "comm_bind: ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv are required");
+  g_group_start = reinterpret_cast<nccl_group_fn>(fn_group_start);
+  g_group_end = reinterpret_cast<nccl_group_fn>(fn_group_end);
+  g_send = reinterpret_cast<nccl_p2p_fn>(fn_send);
+  g_recv = reinterpret_cast<nccl_p2p_fn>(fn_recv);
+  g_errstr = reinterpret_cast<nccl_err_fn>(fn_error_string);
+  return RBX_OK;
+}
+
+extern "C" int rbx_all_to_all(void* comm, const void* d_send, void* d_recv, size_t bytes_per_peer, int32_t world,
+                              void* stream) {
+  using namespace rbx;
+  if (g_send == nullptr) return fail(RBX_ERR_INVALID, "all_to_all: rbx_comm_bind has not been called");
+  if (comm == nullptr || world <= 0) return fail(RBX_ERR_INVALID, "all_to_all: no communicator / world %d", world);
+  if (bytes_per_peer == 0) return RBX_OK;
+  if (d_send == nullptr || d_recv == nullptr) return fail(RBX_ERR_INVALID, "all_to_all: NULL buffer");
+  hipStream_t s = as_stream(stream);
+  int rc = g_group_start();
+  const char* sp = static_cast<const char*>(d_send);
+  char* rp = static_cast<char*>(d_recv);
+  for (int peer = 0; peer < world && rc == 0; ++peer) {
+    rc = g_send(const_cast<char*>(sp) + static_cast<size_t>(peer) * bytes_per_peer, bytes_per_peer, kNcclInt8, peer, comm, s);
+    if (rc == 0) rc = g_recv(rp + static_cast<size_t>(peer) * bytes_per_peer, bytes_per_peer, kNcclInt8, peer, comm, s);
+  }
+  const int rc_end = g_group_end();
+  if (rc == 0) rc = rc_end;
+  if (rc != 0) return fail(RBX_ERR_LAUNCH, "all_to_all: RCCL error %d (%s)", rc, g_errstr ? g_errstr(rc) : "?");
+  return RBX_OK;
+}

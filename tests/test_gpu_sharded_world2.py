@@ -91,3 +91,52 @@ def test_ranks_on_one_gpu_equal_single_gpu_fm(mode, world):
         rank, status = result.get()
         got[rank] = status
     assert got == {r: "ok" for r in range(world)}
+
+
+def _rccl_worker(rank, world, port, result):
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                            device_id=torch.device("cuda", 0))
+    try:
+        from conftest import assert_close
+        from recbox_amd import comm, ops
+        from recbox_amd.graph import ShardedFMStep
+        from recbox_amd.ranking.pytorch.models import ShardedFM
+        from test_gpu_ranking import _criteo_like, _cuda
+        torch.cuda.set_device(0)
+        comm.direct.enable(True)
+        assert comm.direct.self_check() is True            # == torch.distributed's all_to_all_single, sync and async
+        x = torch.randn(4096, 20, device="cuda")
+        out = torch.empty_like(x)
+        comm.all_to_all_equal_into(out, x)
+        assert torch.equal(out, x)                         # a world of one: block 0 comes back
+        fm, X, y = _criteo_like(513, VOCABS, D, seed=23, zipf=True)
+        Xc, yc = _cuda(X), y.cuda()
+        grads = []
+        ops.config.check_ids = False
+        for use_direct in (False, True):
+            comm.direct.enable(use_direct)
+            torch.manual_seed(1)
+            model = ShardedFM(fm, D, shard_min_vocab=300, capacity_factor=1.5).cuda()
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.1)
+            step = ShardedFMStep(model, Xc, yc, graphs=True)
+            for _ in range(2):
+                loss = step()
+            torch.cuda.synchronize()
+            grads.append([loss.clone()] + [p.grad.clone() for p in model.parameters()])
+        for a, b in zip(*grads):
+            assert torch.equal(a, b)
+        result.put((rank, "ok"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_rccl_exchange_equals_torch_distributed():
+    """rbx_all_to_all (grouped ncclSend/ncclRecv on the step's own stream through the communicator of the process
+    group) in a world of one THROUGH RCCL: the same bytes as torch.distributed's all_to_all_single, and a graphed
+    ShardedFMStep leaves bit-identical loss and gradients on either path.  More than one rank needs one GPU each."""
+    from test_distributed_gloo import _free_port
+    result = mp.get_context("spawn").SimpleQueue()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), result), nprocs=1, join=True)
+    assert result.get() == (0, "ok")
