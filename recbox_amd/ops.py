@@ -94,16 +94,21 @@ class EmbedPlan(object):
             f.out_off = s.out_off
             f.eps = s.eps
             f.ids_stride_l = 0
+            f.table = None
+            f.grad = None
+        self._param_fields = [(f, s.param) for f, s in zip(self.arr, specs) if s.param >= 0]
+        self._bound_params = None
+        self._want_dims = [2 if s.seq_len > 1 or (s.kind == FIELD_CATEGORICAL and s.pool != POOL_NONE) else 1 for s in specs]
 
     def bind_inputs(self, inputs):
         """Point the descriptors at this batch; returns (B, kept tensors)."""
         keep = []
         B = None
-        for f, s, t in zip(self.arr, self.specs, inputs):
-            _require_cuda(t, "input '%s'" % s.name)
+        for f, s, t, want_dims in zip(self.arr, self.specs, inputs, self._want_dims):
+            if not t.is_cuda:
+                _require_cuda(t, "input '%s'" % s.name)
             if t.dtype not in _DTYPE_CODE:
                 t = t.float() if (t.is_floating_point() or s.kind != FIELD_CATEGORICAL) else t.long()
-            want_dims = 2 if s.seq_len > 1 or (s.kind == FIELD_CATEGORICAL and s.pool != POOL_NONE) else 1
             if want_dims == 1:
                 if t.dim() != 1:
                     t = t.reshape(-1)
@@ -123,15 +128,17 @@ class EmbedPlan(object):
         return B, keep
 
     def bind_params(self, params, grads=None):
-        for f, s in zip(self.arr, self.specs):
-            if s.param < 0:
-                f.table = None
-                f.grad = None
-                continue
-            p = params[s.param]
-            f.table = p.data_ptr()
-            g = None if grads is None else grads[s.param]
-            f.grad = g.data_ptr() if g is not None else None
+        # a step binds the same tables several times (forward, sort placeholders, backward): the ctypes stores are
+        # skipped when the pointers are the ones already in the descriptors
+        key = (tuple(p.data_ptr() for p in params),
+               None if grads is None else tuple(0 if g is None else g.data_ptr() for g in grads))
+        if key == self._bound_params:
+            return
+        self._bound_params = key
+        tables, gptrs = key
+        for f, i in self._param_fields:
+            f.table = tables[i]
+            f.grad = (gptrs[i] or None) if gptrs is not None else None
 
 
 class KernelTimer(object):
