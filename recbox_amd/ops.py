@@ -369,16 +369,36 @@ def pool(emb, mask=None, numer_masked=False, denom=DENOM_NONE, eps=0.0):
     return _Pool.apply(emb, mask, numer_masked, denom, eps)
 
 
+def _layout(params, sizes):
+    """Offsets of the parameters' gradients inside one flat buffer: a view whose rows are a multiple of 4 floats wide
+    starts on a 16-byte boundary (the kernels' float4 path); dim-1 tables (LR weights) need none."""
+    offs, o = [], 0
+    for p, n in zip(params, sizes):
+        if n and p.shape[-1] % 4 == 0:
+            o = (o + 3) // 4 * 4
+        offs.append(o)
+        o += n
+    return offs, o
+
+
 def _flat_zero_grads(params, want, device):
     """One zero-filled buffer (single memset) carved into per-parameter dense grads."""
     sizes = [p.numel() if w else 0 for p, w in zip(params, want)]
-    padded = [(n + 3) // 4 * 4 for n in sizes]               # keep every view 16-byte aligned
-    flat = torch.zeros(sum(padded), dtype=torch.float32, device=device)
-    grads, o = [], 0
-    for p, w, n, pn in zip(params, want, sizes, padded):
-        grads.append(flat[o:o + n].view_as(p) if w else None)
-        o += pn
-    return grads
+    offs, total = _layout(params, sizes)
+    flat = torch.zeros(total, dtype=torch.float32, device=device)
+    return _carve(flat, params, sizes, offs)
+
+
+def _carve(flat, params, sizes, offs):
+    """Views of ``flat`` shaped like ``params`` (None where the size is 0).  Without gaps between them the views come
+    from one C++ call (what DDP's buckets use) instead of two tensor ops per parameter -- 52 parameters per FM step."""
+    live = [(p, n, o) for p, n, o in zip(params, sizes, offs) if n]
+    packed = all(a[2] + a[1] == b[2] for a, b in zip(live, live[1:])) and (not live or live[0][2] == 0)
+    if packed and live:
+        end = live[-1][2] + live[-1][1]
+        views = iter(torch._utils._unflatten_dense_tensors(flat[:end] if end != flat.numel() else flat, [p for p, _, _ in live]))
+        return [next(views) if n else None for n in sizes]
+    return [flat[o:o + n].view_as(p) if n else None for p, n, o in zip(params, sizes, offs)]
 
 
 class _GradPool(object):
@@ -392,7 +412,7 @@ class _GradPool(object):
         self.bound = None                     # views kept for binding descriptors (autograd gets fresh ones)
         # only tables addressed by ids are cleared by row; numeric-feature weights get a fresh (tiny) zero buffer
         self.sizes = [p.numel() if (p.requires_grad and keep) else 0 for p, keep in zip(params, pooled)]
-        self.padded = [(n + 3) // 4 * 4 for n in self.sizes]
+        self.offs, self.total = _layout(params, self.sizes)
         self.flat = None
         self.ws = None
         self.ws_bytes = 0
@@ -414,14 +434,10 @@ class _GradPool(object):
 
     def views(self, params):
         if self.flat is None:
-            self.flat = torch.zeros(sum(self.padded), dtype=torch.float32, device=self.device)     # the only full fill
+            self.flat = torch.zeros(self.total, dtype=torch.float32, device=self.device)     # the only full fill
         loose = [p for p, n in zip(params, self.sizes) if n == 0]
         small = iter(_flat_zero_grads(loose, [p.requires_grad for p in loose], self.device))    # one fill for all of them
-        out, o = [], 0
-        for p, n, pn in zip(params, self.sizes, self.padded):
-            out.append(self.flat[o:o + n].view_as(p) if n else next(small))
-            o += pn
-        return out
+        return [v if v is not None else next(small) for v in _carve(self.flat, params, self.sizes, self.offs)]
 
     def workspace(self, ws_bytes):
         if self.ws is None or self.ws_bytes < ws_bytes:
