@@ -7,7 +7,10 @@
 namespace rbx {
 
 constexpr int kSortThreads = 256;
-constexpr int kSortItems = 8;                              // per thread
+#ifndef RBX_SORT_ITEMS
+#define RBX_SORT_ITEMS 8
+#endif
+constexpr int kSortItems = RBX_SORT_ITEMS;                 // per thread
 constexpr int kSortTile = kSortThreads * kSortItems;       // 2048 pairs per workgroup
 constexpr int kRadix = 256;
 constexpr int kChunk = 32;                                 // sorted pairs per lane group in the reduce (16 measured slower)

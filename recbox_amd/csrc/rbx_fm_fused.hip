@@ -499,62 +499,6 @@ static size_t fm_num_bytes(const BwdPlan& p, int n_num, int D) {
 }
 
 
-// ---- re-zero of the gradient rows a previous step wrote ----------------------------------------------
-// The sorted (key, val) pairs of the PREVIOUS rbx_fm_sort on this workspace name every gradient row that step's
-// rbx_fm_bwd stored to: one lane group per pair, the head of each run of equal keys clears its row (dim floats of
-// dW, one float of the LR gradient).  36 MB of stores at the Criteo shape instead of a 379 MB fill of the dense grads.
-template <bool VEC>
-__global__ __launch_bounds__(256) void fm_rezero_kernel(const RedPack P, const int n_cat, const unsigned* __restrict__ keys,
-                                                        const unsigned* __restrict__ vals, const unsigned n,
-                                                        const unsigned sentinel, const int lanes) {
-  __shared__ RedField sf[RBX_MAX_FIELDS];
-  {
-    const int words = n_cat * static_cast<int>(sizeof(RedField) / 4);
-    const int* src = reinterpret_cast<const int*>(&P);
-    int* dst = reinterpret_cast<int*>(sf);
-    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
-  }
-  __syncthreads();
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  constexpr int W = VEC ? 4 : 1;
-  // Phase 1, a thread per sorted pair: three independent coalesced loads decide whether the pair starts a run and
-  // where its row lives.  Phase 2, a lane group per pair: the wave walks its 64 pairs `64 / lanes` at a time and a
-  // row is cleared by ONE coalesced store of its group.  (One lane group per pair from the start, with the loads
-  // chained behind each other, was latency-bound at 41 us; a thread per pair storing 4 x 16 B took 83 us.)
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  float* row_ptr = nullptr;
-  int dim = 0;
-  if (i < n) {
-    const unsigned key = keys[i];
-    const unsigned prev = (i > 0) ? keys[i - 1] : sentinel;
-    const unsigned val = vals[i];
-    if (key < sentinel && key != prev) {
-      const RedField& fd = sf[val >> kLocalBits];
-      const size_t row = key - fd.row_base;
-      if (fd.grad != nullptr) {
-        row_ptr = fd.grad + row * fd.dim;
-        dim = fd.dim;
-      }
-      if (fd.grad2 != nullptr) fd.grad2[row] = 0.f;
-    }
-  }
-  const int lane = threadIdx.x & 63;
-  const int lane_g = lane % lanes, group = lane / lanes, per_step = 64 / lanes;
-  for (int base = 0; base < 64; base += per_step) {
-    const int src = base + group;
-    float* dst = reinterpret_cast<float*>(__shfl(reinterpret_cast<unsigned long long>(row_ptr), src, 64));
-    const int d = __shfl(dim, src, 64);
-    for (int e = lane_g * W; e < d; e += lanes * W) {
-      if constexpr (VEC) {
-        const v4f z = {0.f, 0.f, 0.f, 0.f};
-        __builtin_nontemporal_store(z, reinterpret_cast<v4f*>(dst + e));
-      } else {
-        dst[e] = 0.f;
-      }
-    }
-  }
-}
-
 }  // namespace rbx
 
 extern "C" int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
@@ -568,22 +512,7 @@ extern "C" int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int3
   if (rc != RBX_OK) return rc;
   if (p.n_lookups == 0) return RBX_OK;
   if (d_workspace == nullptr || workspace_bytes < p.bytes) return fail(RBX_ERR_WORKSPACE, "fm_rezero: workspace too small");
-  const char* ws = static_cast<const char*>(d_workspace);
-  const int cur = p.passes & 1;
-  const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);
-  const unsigned* vals = reinterpret_cast<const unsigned*>(ws + p.off_vals[cur]);
-  const int D = emb ? emb[0].dim : 1;
-  const int width = p.vec ? (D + 3) / 4 : D;
-  int lanes = 1;
-  while (lanes < width && lanes < 64) lanes *= 2;
-  const unsigned blocks = (p.n_lookups + 255) / 256;
-  if (p.vec)
-    hipLaunchKernelGGL(fm_rezero_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), p.red, p.n_cat, keys, vals,
-                       p.n_lookups, p.total_rows, lanes);
-  else
-    hipLaunchKernelGGL(fm_rezero_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), p.red, p.n_cat, keys, vals,
-                       p.n_lookups, p.total_rows, lanes);
-  return check_launch("fm_rezero_kernel");
+  return launch_rezero(p, static_cast<const char*>(d_workspace), as_stream(stream));
 }
 
 namespace rbx {

@@ -36,7 +36,9 @@ class config(object):
     # op (the contract hipGraph replays have anyway -- recbox_amd.graph.GraphedStep turns this on), and every step
     # must start from ``p.grad is None`` (optimizer.zero_grad(set_to_none=True)), and nothing may write OTHER rows into
     # those gradients in place (an in-place all-reduce of table gradients would: rows of other ranks' batches are not
-    # in this rank's sorted ids and would never be cleared).  Off by default.
+    # in this rank's sorted ids and would never be cleared).  For the same reason a table must receive its gradient from
+    # this op ALONE: autograd sums the contributions of several ops in place, into the first one that arrives -- which
+    # is why only the fused FM body (whose tables are its own) offers this, not the generic lookup.  Off by default.
     reuse_grad_buffers = os.environ.get("RECBOX_AMD_REUSE_GRADS", "0") != "0"
 
 
@@ -418,6 +420,7 @@ class _GradPool(object):
         self.ws_bytes = 0
         self.dirty_batch = 0
         self.ticket = 0                       # bumped by every sort: a backward whose ticket is stale re-sorts
+        self.pending = False                  # a forward holds the ticket and its backward has not run yet
         self.device = device
 
     @staticmethod
@@ -524,6 +527,13 @@ class _FmFused(torch.autograd.Function):
             ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
             pool = (_FmFused._pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev)
                     if config.reuse_grad_buffers else None)
+            if pool is not None and pool.pending:
+                # a second training forward before the first one's backward: if both end up in one backward pass, autograd
+                # sums their gradients IN PLACE into whichever arrives first -- rows of the other batch would land in
+                # the persistent buffer and never be cleared.  Both forwards get fresh gradients instead.
+                pool.ticket += 1
+                pool.pending = False
+                pool = None
             if ws_bytes > 0 and pool is None:
                 ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_fm_sort(
                     ea, la, lead.n, B, _ptr(ws), ws_bytes, None, st))
@@ -551,6 +561,7 @@ class _FmFused(torch.autograd.Function):
 
                 ctx.sort = _EarlySort(dev, pool.ws_bytes, launch, ws=ws)
                 pool.ticket += 1
+                pool.pending = True
                 ctx.pool, ctx.ticket = pool, pool.ticket
         return logit
 
@@ -658,6 +669,7 @@ class _FmFused(torch.autograd.Function):
                              _ptr(ws), ws_bytes, _stream()))
         if pool is not None:
             pool.dirty_batch = B                 # the rows named by the sorted ids in pool.ws now hold this step's sums
+            pool.pending = False
         return result()
 
 

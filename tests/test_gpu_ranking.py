@@ -288,6 +288,24 @@ def test_reuse_grad_buffers_equals_fresh_grads():
             torch.nn.functional.binary_cross_entropy(torch.sigmoid(logit), y.cuda(), reduction="mean").backward()
             for p, g in zip(reuse.parameters(), w):
                 assert torch.equal(p.grad, g)
+        # two forwards feeding ONE backward pass (autograd sums their gradients in place): neither may use the persistent
+        # buffer; the step after it, with a fresh batch, is still exact
+        reuse.zero_grad(set_to_none=True)
+        fresh.zero_grad(set_to_none=True)
+        for model in (fresh, reuse):
+            ops.config.reuse_grad_buffers = model is reuse
+            la, lb = model.logits(_cuda(X1)), model.logits(_cuda(X2))
+            (torch.nn.functional.binary_cross_entropy(torch.sigmoid(la), y1.cuda()) +
+             torch.nn.functional.binary_cross_entropy(torch.sigmoid(lb), y2.cuda())).backward()
+        for (n, p0), (_, p1) in zip(fresh.named_parameters(), reuse.named_parameters()):
+            assert_close(p1.grad, p0.grad, 1e-6, "two forwards, one backward: " + n)
+        _, X3, y3 = _criteo_like(400, vocabs, 16, seed=73)
+        for model in (fresh, reuse):
+            ops.config.reuse_grad_buffers = model is reuse
+            for _ in range(2):
+                _bce_step(model, _cuda(X3), y3.cuda())
+        for (n, p0), (_, p1) in zip(fresh.named_parameters(), reuse.named_parameters()):
+            assert torch.equal(p1.grad, p0.grad), "after the combined backward: " + n
         with pytest.raises(RuntimeError, match="reuse_grad_buffers"):
             logit = reuse.logits(_cuda(X1))                  # p.grad still set from the step above
             logit.sum().backward()
