@@ -540,8 +540,9 @@ class _FmFused(torch.autograd.Function):
             elif ws_bytes > 0:
                 # ahead of the sort, on the same stream: clear what the previous backward stored (its sorted ids are
                 # still in the pool's workspace), then sort this batch's ids over them.  (Clearing on a third stream
-                # beside the sort was measured slower -- 0.344 vs 0.331 ms per step: the step is bound by the memory
-                # request rate, concurrent kernels only slow each other down.)
+                # beside the sort was measured slower -- 0.344 vs 0.331 ms per step --, and so was clearing beside the
+                # forward kernel -- 0.309 vs 0.299 ms, the forward going from 46 to 61 us: the step is bound by the
+                # memory request rate, concurrent kernels only slow each other down.)
                 dirty = pool.dirty_batch
                 if dirty and pool.ws_bytes < ws_bytes:          # a larger batch than ever before: clear, then regrow
                     check(_FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, _stream()))
