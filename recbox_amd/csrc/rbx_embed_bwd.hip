@@ -124,10 +124,11 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
 }
 
 // ---- build_keys ----------------------------------------------------------------
-__global__ __launch_bounds__(256) void build_keys_kernel(const KeyPack P, const int n_cat, const unsigned n_lookups,
+__global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack P, const int n_cat, const unsigned n_lookups,
                                                          const unsigned sentinel, unsigned* __restrict__ keys,
                                                          unsigned* __restrict__ vals, int* __restrict__ status,
-                                                         unsigned* __restrict__ fin) {
+                                                         unsigned* __restrict__ fin, unsigned* __restrict__ hist,
+                                                         const unsigned n_tiles) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {          // fix-up work-list length and arrival counter (rbx_segreduce.h)
     fin[0] = 0;
     fin[1] = 0;
@@ -140,9 +141,16 @@ __global__ __launch_bounds__(256) void build_keys_kernel(const KeyPack P, const 
     int* dst = reinterpret_cast<int*>(sf);
     for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
   }
+  // one workgroup per sort tile, so that the tile's histogram of the FIRST radix digit falls out of the same pass
+  // (the keys are in registers anyway): the first radix_hist_kernel launch of the sort is not needed
+  __shared__ unsigned cnt[kRadix];
+  cnt[threadIdx.x] = 0;
   __syncthreads();
-  const unsigned stride = gridDim.x * blockDim.x;
-  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < n_lookups; j += stride) {
+  const unsigned tile0 = blockIdx.x * kSortTile;
+#pragma unroll
+  for (int it = 0; it < kSortItems; ++it) {
+    const unsigned j = tile0 + it * kSortThreads + threadIdx.x;
+    if (j >= n_lookups) break;
     int lo = 0, hi = n_cat - 1;                      // last field with lk_off <= j
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
@@ -164,7 +172,10 @@ __global__ __launch_bounds__(256) void build_keys_kernel(const KeyPack P, const 
     }
     keys[j] = key;
     vals[j] = (static_cast<unsigned>(lo) << kLocalBits) | local;
+    atomicAdd(&cnt[key & 0xFFu], 1u);
   }
+  __syncthreads();
+  hist[threadIdx.x * n_tiles + blockIdx.x] = cnt[threadIdx.x];   // digit-major, as radix_hist_kernel writes it
 }
 
 // ---- radix sort: per-tile digit histogram ----------------------------------------
@@ -485,18 +496,18 @@ int run_sort(const BwdPlan& p, char* ws, int* d_status, hipStream_t s) {
   unsigned* ssum = reinterpret_cast<unsigned*>(ws + p.off_ssum);
   int rc;
   {
-    unsigned blocks = (p.n_lookups + 255) / 256;
-    if (blocks > static_cast<unsigned>(kCUs * 8)) blocks = kCUs * 8;
-    hipLaunchKernelGGL(build_keys_kernel, dim3(blocks), dim3(256), 0, s, p.keys, p.n_cat, p.n_lookups, p.total_rows,
-                       keys[0], vals[0], d_status, reinterpret_cast<unsigned*>(ws + p.off_fin));
+    hipLaunchKernelGGL(build_keys_kernel, dim3(p.n_tiles), dim3(kSortThreads), 0, s, p.keys, p.n_cat, p.n_lookups,
+                       p.total_rows, keys[0], vals[0], d_status, reinterpret_cast<unsigned*>(ws + p.off_fin), hist,
+                       p.n_tiles);
     rc = check_launch("build_keys_kernel");
     if (rc != RBX_OK) return rc;
   }
   int cur = 0;
   for (int pass = 0; pass < p.passes; ++pass) {
     const int shift = pass * 8;
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], p.n_lookups, shift, hist,
-                       p.n_tiles);
+    if (pass > 0)        // (the first digit's histograms come out of build_keys_kernel)
+      hipLaunchKernelGGL(radix_hist_kernel, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], p.n_lookups, shift, hist,
+                         p.n_tiles);
     const unsigned hist_len = p.n_tiles * kRadix;
     const unsigned n_slices = (hist_len + kScanSlice - 1) / kScanSlice;
     hipLaunchKernelGGL(radix_scan_local_kernel, dim3(n_slices), dim3(1024), 0, s, hist, hist_len, ssum);
