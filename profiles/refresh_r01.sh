@@ -17,7 +17,7 @@ python profiles/topk.py $(find $out/prof_fused -name "*.db" | head -1) 58 > $out
 python profiles/topk.py $(find $out/prof_sharded -name "*.db" | head -1) 64 > $out/sharded_kernel_stats.txt
 # one hipGraph replay as a timeline (which kernels overlap, where the chain waits)
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $out/prof_tl -o b -- python /root/repo/bench.py --no-cpu-baseline > /dev/null 2>&1)
-python profiles/timeline.py $(find $out/prof_tl -name "*.db" | head -1) fm_rezero 30 > $out/fused_replay_timeline.txt
+python profiles/timeline.py $(find $out/prof_tl -name "*.db" | head -1) rezero_rows 30 > $out/fused_replay_timeline.txt
 # HBM traffic of the dominant kernels: one counter per pass, kernel trace only (MI355X_MICROARCH.md, HBM section)
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c -o b -- python /root/repo/bench.py --no-cpu-baseline --eager --steps 5 --warmup 3 > /dev/null 2>&1)

@@ -8,7 +8,7 @@ import sys
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    anchor = sys.argv[2] if len(sys.argv) > 2 else "fm_rezero"
+    anchor = sys.argv[2] if len(sys.argv) > 2 else "rezero_rows"
     which = int(sys.argv[3]) if len(sys.argv) > 3 else -5
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)

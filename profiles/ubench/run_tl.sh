@@ -6,5 +6,5 @@ rm -rf /tmp/prof
 rocprofv3 --kernel-trace --stats -d /tmp/prof -o tl -- python $R/bench.py --no-cpu-baseline "$@" > /dev/null 2>&1
 cd $R
 DB=$(find /tmp/prof -name "tl_results.db" | head -1)
-python profiles/timeline.py $DB ${ANCHOR:-fm_rezero} ${WHICH:-30} > gpurun_out/rz/timeline${TAG}.txt 2>&1
+python profiles/timeline.py $DB ${ANCHOR:-rezero_rows} ${WHICH:-30} > gpurun_out/rz/timeline${TAG}.txt 2>&1
 python profiles/topk.py $DB > gpurun_out/rz/stats${TAG}.txt
