@@ -21,7 +21,24 @@ res = {}
 for mode in (True, "whole"):
     model = ShardedFM(fmw.fm, 16, shard_min_vocab=100000, capacity_factor=1.25).to(dev)
     bench.init_weights(model)
-    step = ShardedFMStep(model, X, y, graphs=mode)
+    if mode == "whole":
+        eager = ShardedFMStep(model, X, y, graphs=False)          # the same pieces, captured together below
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                             # warm up off the legacy stream, as GraphedStep does
+            for _ in range(2):
+                eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            eager._run(eager.pieces)
+
+        def step():
+            g.replay()
+            return eager.loss
+    else:
+        step = ShardedFMStep(model, X, y, graphs=mode)
     for _ in range(10): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50): loss = step()

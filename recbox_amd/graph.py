@@ -112,24 +112,7 @@ class ShardedFMStep(object):
         self.sorted_ws = None
         self.local_sorted = None
         self.graphs = None
-        self.whole = None
-        if graphs == "whole":
-            # EXPERIMENT: the whole step, collectives included, in ONE hipGraph.  Needs the exchanges on the step's own
-            # stream (comm.direct: grouped ncclSend/ncclRecv -- RCCL itself supports capture; torch.distributed's
-            # wrapper did not) and, for more than one rank, no torch.distributed collective inside the step.
-            if not comm.direct.on or W > 1:
-                raise NotImplementedError("ShardedFMStep(graphs='whole'): needs comm.direct and, so far, a world of one")
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(warmup):
-                    self._run(self.pieces)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            self.whole = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.whole, capture_error_mode="thread_local"):
-                self._run(self.pieces)
-        elif graphs:
+        if graphs:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):           # allocator, plans, RCCL communicator: warm before capturing
@@ -245,7 +228,4 @@ class ShardedFMStep(object):
         return self.loss
 
     def __call__(self):
-        if self.whole is not None:
-            self.whole.replay()
-            return self.loss
         return self._run(self.graphs if self.graphs is not None else self.pieces)
