@@ -342,6 +342,78 @@ def test_graphed_step_replays_equal_eager_steps():
         ops.config.check_ids = old
 
 
+def test_bench_configuration_graph_replays_equal_fresh_eager_steps():
+    """BASELINE.json configs[1] exactly as bench.py runs it (26 Criteo-sized tables + 13 numeric features, D = 16,
+    B = 65 536, ids as float64 columns, hipGraph replay with persistent gradients): two replays on two different batches
+    leave bit-identical loss and gradients to eager steps that zero-fill fresh gradients."""
+    import bench
+    from recbox_amd import ops
+    from recbox_amd.graph import GraphedStep
+    from recbox_amd.ranking.pytorch.models import FM
+    from recbox_amd.ranking.pytorch.torch_utils import get_loss
+    dev = torch.device("cuda", 0)
+    fmw = bench.CriteoFeatureMap(16)
+    eager, graphed = FM(fmw.fm, 16, fused=True).to(dev), FM(fmw.fm, 16, fused=True).to(dev)
+    bench.init_weights(eager)
+    graphed.load_state_dict(eager.state_dict())
+    loss_fn = get_loss("binary_crossentropy")
+    static = bench.synthetic_batch(65536, 1, "uniform", dev)
+    Xs, ys = bench.slice_inputs(fmw.fm, static)
+    ys = ys.clone()
+
+    def step(model, X, y):
+        for p in model.parameters():
+            p.grad = None
+        loss = loss_fn(model(X)["y_pred"], y, reduction="mean")
+        loss.backward()
+        return loss
+
+    old = ops.config.check_ids
+    ops.config.check_ids = False
+    try:
+        replay = GraphedStep(lambda: step(graphed, Xs, ys), warmup=3)
+        for seed, dist in ((2, "uniform"), (3, "zipf")):
+            batch = bench.synthetic_batch(65536, seed, dist, dev)
+            static.copy_(batch)
+            ys.copy_(bench.slice_inputs(fmw.fm, batch)[1])
+            loss = replay()
+            X, y = bench.slice_inputs(fmw.fm, batch)
+            want = step(eager, X, y)
+            torch.cuda.synchronize()
+            assert torch.equal(loss, want), (float(loss), float(want))
+            for (n, p0), (_, p1) in zip(eager.named_parameters(), graphed.named_parameters()):
+                assert torch.equal(p1.grad, p0.grad), "%s ids: %s" % (dist, n)
+    finally:
+        ops.config.check_ids = old
+
+
+def test_bench_configuration_matches_cpu_oracle_at_full_size():
+    """The bench step itself (B = 65 536, Criteo-sized tables, summed BCE so that gradients are O(1)) against the CPU
+    oracle (the reference's op sequence on ATen CPU kernels): logits within 1e-4, every gradient within 1e-4 of the
+    largest magnitude of its tensor (rows of the 3-row table sum 21 845 terms)."""
+    import bench
+    from oracle import torch_ref as R
+    from recbox_amd.ranking.pytorch.models import FM
+    fmw = bench.CriteoFeatureMap(16)
+    ref = R.RefFMModel(fmw.fm, 16)
+    bench.init_weights(ref)
+    dut = FM(fmw.fm, 16, fused=True)
+    dut.load_state_dict(ref.state_dict())
+    dut.cuda()
+    batch = bench.synthetic_batch(65536, 5, "uniform", "cpu")
+    X, y = bench.slice_inputs(fmw.fm, batch)
+    Xc, yc = bench.slice_inputs(fmw.fm, batch.cuda())
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    lr = ref(X)
+    torch.nn.functional.binary_cross_entropy(torch.sigmoid(lr), y, reduction="sum").backward()
+    ld = dut.logits(Xc)
+    torch.nn.functional.binary_cross_entropy(torch.sigmoid(ld), yc, reduction="sum").backward()
+    assert_close(ld, lr, TOL, "logit")
+    for (n, p0), (_, p1) in zip(ref.named_parameters(), dut.named_parameters()):
+        scale = max(1.0, float(p0.grad.abs().max()))
+        assert_close(p1.grad / scale, p0.grad / scale, TOL, "grad " + n)
+
+
 def test_logistic_regression_fused_and_frozen_tables():
     L = _layers()
     from oracle import torch_ref as R
