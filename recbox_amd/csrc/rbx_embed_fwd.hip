@@ -341,7 +341,10 @@ static int launch_fwd(bool seq, const FieldPack& pack, int F, int64_t B, float* 
   const int groups_per_block = 256 / (seq ? SG : G);
   long long blocks = (npairs + groups_per_block - 1) / groups_per_block;
   if (seq) blocks = ((B + 64 / SG - 1) / (64 / SG) * F + 3) / 4;          // 4 wave tasks per workgroup
-  const long long cap = static_cast<long long>(kCUs) * (seq ? 64 : 8);   // sequences: one pair per group, many waves
+#ifndef RBX_FWD_BLOCKS_PER_CU
+#define RBX_FWD_BLOCKS_PER_CU 32   // 8 left the one-id gather latency-bound: [B,39,16] at B=65536 took 130 us, 100 us with 32 (64: 105)
+#endif
+  const long long cap = static_cast<long long>(kCUs) * (seq ? 64 : RBX_FWD_BLOCKS_PER_CU);   // sequences: one pair per group, many waves
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   if (seq)
