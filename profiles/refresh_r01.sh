@@ -15,6 +15,8 @@ timeout 200 python bench.py --no-cpu-baseline --force-sharded --eager 2>/dev/nul
 python profiles/topk.py $(find $out/prof_fused -name "*.db" | head -1) 58 > $out/fused_kernel_stats.txt
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $out/prof_sharded -o b -- python /root/repo/bench.py --no-cpu-baseline --force-sharded > $out/prof_sharded.log 2>&1)
 python profiles/topk.py $(find $out/prof_sharded -name "*.db" | head -1) 64 > $out/sharded_kernel_stats.txt
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $out/prof_layers -o b -- python /root/repo/bench.py --no-cpu-baseline --path layers > $out/prof_layers.log 2>&1)
+python profiles/topk.py $(find $out/prof_layers -name "*.db" | head -1) 73 > $out/layers_kernel_stats.txt
 # one hipGraph replay as a timeline (which kernels overlap, where the chain waits)
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $out/prof_tl -o b -- python /root/repo/bench.py --no-cpu-baseline > /dev/null 2>&1)
 python profiles/timeline.py $(find $out/prof_tl -name "*.db" | head -1) rezero_rows 30 > $out/fused_replay_timeline.txt
@@ -28,5 +30,5 @@ timeout 500 python profiles/ubench/kernels_bench.py > $out/kernels_bench.txt 2>/
 python profiles/topk.py $(find $out/prof_kb -name "*.db" | head -1) > $out/kernels_bench_kernel_stats.txt
 timeout 600 python profiles/ubench/models_bench.py > $out/models_bench.txt 2>/dev/null
 timeout 300 python profiles/ubench/rocblas_compare.py > $out/rocblas_compare.txt 2>/dev/null
-rm -rf $out/prof_fused $out/prof_sharded $out/prof_kb $out/prof_tl $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+rm -rf $out/prof_fused $out/prof_layers $out/prof_sharded $out/prof_kb $out/prof_tl $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 ls -la $out
