@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
   constexpr int W = VEC ? 4 : 1;
   constexpr int NA = NV * W;
   // features in flight per lane.  8 is the measured optimum at D=16 on MI355X: 16 in flight ran 1.6x
-  // SLOWER (94 vs 58 us at B=65 536) -- the gather is bound by the random-row request rate, not latency
+  // SLOWER (94 vs 58 us at B=65 536) -- the gather is bound by the random-row request rate, not latency.
+  // More wavefronts do not help either: a sample's feature batches dealt to 2 / 4 neighbouring lane groups (2x / 4x
+  // the wavefronts, partial sums joined by a shuffle) took 102 / 149 us instead of 46.
   constexpr int U = (NA <= 4) ? 8 : 4;
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
