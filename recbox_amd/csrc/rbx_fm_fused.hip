@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
   // SLOWER (94 vs 58 us at B=65 536) -- the gather is bound by the random-row request rate, not latency.
   // More wavefronts do not help either: a sample's feature batches dealt to 2 / 4 neighbouring lane groups (2x / 4x
   // the wavefronts, partial sums joined by a shuffle) took 102 / 149 us instead of 46.
-  constexpr int U = (NA <= 4) ? 8 : 4;
+#ifndef RBX_FM_U
+#define RBX_FM_U 8
+#endif
+  constexpr int U = (NA <= 4) ? RBX_FM_U : 4;
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
   for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
