@@ -232,10 +232,10 @@ def test_fused_fm_matches_layer_path_and_oracle(B, zipf):
         assert_close(p2.grad, p0.grad, TOL * scale, "layer grad " + n0)
 
 
-def _fm_pair(seed, vocabs=None):
+def _fm_pair(seed, vocabs=None, dim=16):
     from recbox_amd.ranking.pytorch.models import FM
-    fm, _, _ = _criteo_like(4, vocabs or (CRITEO_SMALL_VOCABS + [70000]), 16, seed=seed)
-    a, b = FM(fm, 16, fused=True).cuda(), FM(fm, 16, fused=True).cuda()
+    fm, _, _ = _criteo_like(4, vocabs or (CRITEO_SMALL_VOCABS + [70000]), dim, seed=seed)
+    a, b = FM(fm, dim, fused=True).cuda(), FM(fm, dim, fused=True).cuda()
     with torch.no_grad():
         for p in a.parameters():
             p.normal_(0, 0.1)
@@ -309,6 +309,47 @@ def test_reuse_grad_buffers_equals_fresh_grads():
         with pytest.raises(RuntimeError, match="reuse_grad_buffers"):
             logit = reuse.logits(_cuda(X1))                  # p.grad still set from the step above
             logit.sum().backward()
+    finally:
+        ops.config.reuse_grad_buffers = old
+
+
+@pytest.mark.parametrize("kind", ["fm_dim7", "fm_dim4", "lr_only", "frozen_table"])
+def test_reuse_grad_buffers_other_shapes(kind):
+    """The persistent-gradient path where the kernels take other branches: scalar (D = 7) and one-float4 (D = 4) rows,
+    the LR-only body (LogisticRegression: dim-1 tables, no embedding part), and a model with a frozen table -- several
+    steps each (the row re-zero only runs from the second step on), bit-identical to fresh gradients."""
+    from recbox_amd import ops
+    vocabs = [37, 5, 3001, 211, 70000]
+    if kind == "lr_only":
+        L = _layers()
+        fm, _, _ = _criteo_like(4, vocabs, 16, seed=5)
+        fresh, reuse = L.LogisticRegression(fm, use_bias=True).cuda(), L.LogisticRegression(fm, use_bias=True).cuda()
+        with torch.no_grad():
+            for p in fresh.parameters():
+                p.normal_(0, 0.1)
+        reuse.load_state_dict(fresh.state_dict())
+        run = lambda m, X: m(X)
+    else:
+        dim = {"fm_dim7": 7, "fm_dim4": 4}.get(kind, 16)
+        fm, fresh, reuse = _fm_pair(77, vocabs, dim=dim)
+        if kind == "frozen_table":
+            for m in (fresh, reuse):
+                m.embedding_layer.embedding_layer.embedding_layers["C3"].weight.requires_grad_(False)
+        run = lambda m, X: m.logits(X)
+    old = ops.config.reuse_grad_buffers
+    try:
+        for k, B in enumerate([300, 300, 1000, 77]):
+            _, X, y = _criteo_like(B, vocabs, 16, seed=90 + k, zipf=bool(k % 2))
+            Xc, yc = _cuda(X), y.cuda()
+            for model, flag in ((fresh, False), (reuse, True)):
+                ops.config.reuse_grad_buffers = flag
+                model.zero_grad(set_to_none=True)
+                torch.nn.functional.binary_cross_entropy(torch.sigmoid(run(model, Xc)), yc, reduction="mean").backward()
+            for (n, p0), (_, p1) in zip(fresh.named_parameters(), reuse.named_parameters()):
+                if p0.grad is None:
+                    assert p1.grad is None, n
+                else:
+                    assert torch.equal(p1.grad, p0.grad), "%s step %d: %s" % (kind, k, n)
     finally:
         ops.config.reuse_grad_buffers = old
 
