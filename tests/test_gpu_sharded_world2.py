@@ -48,11 +48,12 @@ def _worker(rank, world, port, mode, result):
             loss = torch.nn.functional.binary_cross_entropy(dut(Xr)["y_pred"], yr, reduction="mean")
             (loss / world).backward()
             dut.sync_grads()
-        else:                                    # the bench's step: padded sync-free exchange, eager pieces
+        else:                                    # the bench's step: padded sync-free exchange; eager pieces, or hipGraph
+                                                 # pieces with the collectives between them ("padded_graphs")
             old = ops.config.check_ids
             ops.config.check_ids = False
             try:
-                step = ShardedFMStep(dut, Xr, yr, graphs=False)
+                step = ShardedFMStep(dut, Xr, yr, graphs=(mode == "padded_graphs"))
                 for _ in range(2):
                     loss = step()
             finally:
@@ -101,7 +102,7 @@ def _spawn(worker, world, *extra):
         return got
 
 
-@pytest.mark.parametrize("mode,world", [("exact", 2), ("padded", 2), ("padded", 3)])
+@pytest.mark.parametrize("mode,world", [("exact", 2), ("padded", 2), ("padded", 3), ("padded_graphs", 2)])
 def test_ranks_on_one_gpu_equal_single_gpu_fm(mode, world):
     assert _spawn(_worker, world, mode) == {r: "ok" for r in range(world)}
 
