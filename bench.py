@@ -171,13 +171,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # RECBOX_BENCH_ONE_GPU=1 (tests only): every rank on cuda:0 over gloo, to run the N>1 control flow of this script
+    # on a single-GPU box (RCCL needs one GPU per rank); the numbers of such a run mean nothing
+    one_gpu = os.environ.get("RECBOX_BENCH_ONE_GPU", "0") != "0"
+    local_rank = 0 if one_gpu else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from recbox_amd import comm, ops
     from recbox_amd.ranking.pytorch.models import FM, ShardedFM

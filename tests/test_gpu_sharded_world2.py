@@ -151,3 +151,27 @@ def test_direct_rccl_exchange_equals_torch_distributed():
     group) in a world of one THROUGH RCCL: the same bytes as torch.distributed's all_to_all_single, and a graphed
     ShardedFMStep leaves bit-identical loss and gradients on either path.  More than one rank needs one GPU each."""
     assert _spawn(_rccl_worker, 1) == {0: "ok"}
+
+
+def test_bench_script_runs_its_two_rank_path():
+    """bench.py launched as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with both
+    ranks on this box's single GPU over gloo (RECBOX_BENCH_ONE_GPU=1): the N>1 control flow of the script -- sharded
+    model, piecewise-graphed step, overflow check, barrier + max-over-ranks timing, one JSON line from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from test_distributed_gloo import _free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RECBOX_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--batch", "8192"]
+    out = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and rec["config"]["global_batch"] == 2 * 8192
+    assert "row-sharded" in rec["config"]["parallelism"] and "overflow=False" in rec["config"]["exchange"]
