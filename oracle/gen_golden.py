@@ -550,6 +550,21 @@ def gen_cross_net(fuxictr, B=7, dim=24, layers=3):
     save("cross_net", **groups)
 
 
+def gen_cross_net_mix(fuxictr, B=9, dim=20, layers=2, rank=6, experts=3):
+    """CrossNetMix of the live reference (cross_net.py:60-117): mixture of low-rank cross experts."""
+    import fuxictr.pytorch.layers as FL
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, dim, generator=g)
+    R = torch.randn(B, dim, generator=g)
+    net = FL.CrossNetMix(dim, layer_num=layers, low_rank=rank, num_experts=experts)
+    reinit(net, std=0.3, seed=13)
+    xi = x.clone().requires_grad_(True)
+    out = net(xi)
+    (out * R).sum().backward()
+    save("cross_net_mix", **{"in": {"x": x, "R": R}, "p": net.state_dict(), "out": {"y": out, "dx": xi.grad},
+                             "g": grads_of(net)})
+
+
 def gen_bilinear(fuxictr, B=7, F=5, D=4):
     """BilinearInteraction (pair loop) and BilinearInteractionV2 (index_select) of the live reference, three W layouts."""
     import fuxictr.pytorch.layers as FL
@@ -609,6 +624,7 @@ def main():
     gen_cross_net(fuxictr)
     gen_bilinear(fuxictr)
     gen_cin(fuxictr)
+    gen_cross_net_mix(fuxictr)
 
 
 if __name__ == "__main__":

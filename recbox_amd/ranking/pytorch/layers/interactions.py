@@ -8,7 +8,7 @@ from torch import nn
 from .... import ops
 
 __all__ = ["InnerProductInteraction", "CrossInteraction", "CrossNet", "CrossNetV2", "BilinearInteraction",
-           "BilinearInteractionV2", "CompressedInteractionNet"]
+           "BilinearInteractionV2", "CompressedInteractionNet", "CrossNetMix"]
 
 
 class InnerProductInteraction(nn.Module):
@@ -78,6 +78,49 @@ class CrossNetV2(nn.Module):
             layer = self.cross_layers[i]
             X_i = ops.cross(X_0, X_i, ops.linear(X_i, layer.weight, layer.bias))
         return X_i
+
+
+class CrossNetMix(nn.Module):
+    """DCN-M's mixture of low-rank cross experts (cross_net.py:60-117), parameter holders as in the reference
+    (``U_list`` / ``V_list`` / ``C_list``: per layer [experts, in, r] / [experts, in, r] / [experts, r, r], ``gating``:
+    one bias-free Linear(in, 1) per expert, ``bias``: per layer [in, 1]).
+
+    Per layer and expert e the reference computes x_0 * (U_e tanh(C_e tanh(V_e^T x_l)) + b), and mixes the experts with
+    softmax(gates).  Because the softmax weights sum to one, the mixture is x_0 * (sum_e p_e U_e h_e + b): the experts
+    are batched into THREE fp32-MFMA GEMMs per layer -- [B, in] x [in, E r] for all V_e, [B, E r] x [E r, in] for all U_e
+    applied to the gate-scaled h_e, [B, in] x [in, E] for the gates -- plus one small [B, r] x [r, r] per expert, and the
+    layer ends in rbx_cross_fwd (x_l + x_0 * h, the bias riding in the last GEMM's epilogue), instead of 4 matmuls and a Hadamard product per expert."""
+
+    def __init__(self, in_features, layer_num=2, low_rank=32, num_experts=4):
+        super(CrossNetMix, self).__init__()
+        self.layer_num, self.num_experts = layer_num, num_experts
+
+        def stack(*shape):
+            return nn.ParameterList(nn.Parameter(nn.init.xavier_normal_(torch.empty(num_experts, *shape)))
+                                    for _ in range(layer_num))
+
+        self.U_list = stack(in_features, low_rank)
+        self.V_list = stack(in_features, low_rank)
+        self.C_list = stack(low_rank, low_rank)
+        self.gating = nn.ModuleList(nn.Linear(in_features, 1, bias=False) for _ in range(num_experts))
+        self.bias = nn.ParameterList(nn.Parameter(torch.zeros(in_features, 1)) for _ in range(layer_num))
+
+    def forward(self, inputs):
+        E = self.num_experts
+        x_0 = inputs
+        x_l = x_0
+        gate_w = torch.cat([g.weight for g in self.gating], dim=0)                       # [E, in]
+        for i in range(self.layer_num):
+            U, V, C = self.U_list[i], self.V_list[i], self.C_list[i]
+            n_in, r = V.shape[1], V.shape[2]
+            p = torch.softmax(ops.linear(x_l, gate_w), dim=1)                            # [B, E]
+            h = torch.tanh(ops.linear(x_l, V.permute(0, 2, 1).reshape(E * r, n_in)))     # every V_e^T x_l: [B, E r]
+            h = torch.stack([ops.linear(h[:, e * r:(e + 1) * r], C[e]) for e in range(E)], dim=1)
+            h = torch.tanh(h) * p.unsqueeze(2)                                           # p_e tanh(C_e .): [B, E, r]
+            mix = ops.linear(h.reshape(-1, E * r), U.permute(1, 0, 2).reshape(n_in, E * r),
+                             self.bias[i].reshape(-1))                                   # sum_e p_e U_e h_e + b
+            x_l = ops.cross(x_0, x_l, mix)
+        return x_l.unsqueeze(2).squeeze()
 
 
 class BilinearInteractionV2(nn.Module):

@@ -679,6 +679,21 @@ def test_bilinear_golden(kind):
         L.BilinearInteractionV2(F, D, bilinear_type="nope")
 
 
+def test_cross_net_mix_golden():
+    """CrossNetMix (experts batched into three GEMMs per layer + rbx_cross) against the live-reference fixture: same
+    state_dict keys, output, dx and every parameter gradient."""
+    L = _layers()
+    fx = Fixture("cross_net_mix")
+    x, R = fx.tensors("in")["x"], fx.tensors("in")["R"]
+    net = load_params(L.CrossNetMix(x.shape[1], layer_num=2, low_rank=6, num_experts=3), fx["p"]).cuda()
+    xc = x.cuda().requires_grad_(True)
+    out = net(xc)
+    assert_close(out, fx["out"]["y"], TOL, "y")
+    (out * R.cuda()).sum().backward()
+    assert_close(xc.grad, fx["out"]["dx"], TOL, "dx")
+    assert_grads_close(net, fx["g"], TOL)
+
+
 def test_cin_golden():
     """CompressedInteractionNet against the live-reference fixture: same state_dict keys, output, dx, grads."""
     L = _layers()
