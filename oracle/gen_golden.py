@@ -565,6 +565,34 @@ def gen_cross_net_mix(fuxictr, B=9, dim=20, layers=2, rank=6, experts=3):
                              "g": grads_of(net)})
 
 
+def gen_im_hfm(fuxictr, B=6, F=5, D=8):
+    """InteractionMachine (orders 2 and 5, with and without BatchNorm) and HolographicInteraction (three types) of the
+    live reference (interaction_machine.py:21-71, holographic_interaction.py:22-52)."""
+    import fuxictr.pytorch.layers as FL
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, F, D, generator=g) * 0.7
+    groups = {"in": {"x": x}}
+    for tag, order, bn in (("o2", 2, False), ("o5bn", 5, True)):
+        net = FL.InteractionMachine(D, order=order, batch_norm=bn)
+        reinit(net, std=0.3, seed=order)
+        net.train()
+        xi = x.clone().requires_grad_(True)
+        out = net(xi)
+        Rm = torch.randn(out.shape, generator=g)
+        (out * Rm).sum().backward()
+        groups["p_" + tag] = {k: v for k, v in net.state_dict().items() if "running" not in k and "num_batches" not in k}
+        groups["out_" + tag] = {"y": out, "dx": xi.grad, "R": Rm}
+        groups["g_" + tag] = grads_of(net)
+    for kind in ("hadamard_product", "circular_convolution", "circular_correlation"):
+        layer = FL.HolographicInteraction(F, interaction_type=kind)
+        xi = x.clone().requires_grad_(True)
+        out = layer(xi)
+        Rh = torch.randn(out.shape, generator=g)
+        (out * Rh).sum().backward()
+        groups["hfm_" + kind] = {"y": out, "dx": xi.grad, "R": Rh}
+    save("im_hfm", **groups)
+
+
 def gen_bilinear(fuxictr, B=7, F=5, D=4):
     """BilinearInteraction (pair loop) and BilinearInteractionV2 (index_select) of the live reference, three W layouts."""
     import fuxictr.pytorch.layers as FL
@@ -625,6 +653,7 @@ def main():
     gen_bilinear(fuxictr)
     gen_cin(fuxictr)
     gen_cross_net_mix(fuxictr)
+    gen_im_hfm(fuxictr)
 
 
 if __name__ == "__main__":

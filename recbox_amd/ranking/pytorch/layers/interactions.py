@@ -8,7 +8,8 @@ from torch import nn
 from .... import ops
 
 __all__ = ["InnerProductInteraction", "CrossInteraction", "CrossNet", "CrossNetV2", "BilinearInteraction",
-           "BilinearInteractionV2", "CompressedInteractionNet", "CrossNetMix"]
+           "BilinearInteractionV2", "CompressedInteractionNet", "CrossNetMix", "InteractionMachine",
+           "HolographicInteraction"]
 
 
 class InnerProductInteraction(nn.Module):
@@ -203,3 +204,67 @@ class CompressedInteractionNet(nn.Module):
             xk = ops.linear(z, conv.weight.squeeze(-1), conv.bias).view(B, D, -1)        # [B, D, H_{k+1}]
             pooled.append(xk.sum(dim=1))                                                  # sum over d -> [B, H_{k+1}]
         return ops.linear(torch.cat(pooled, dim=-1), self.fc.weight, self.fc.bias)
+
+
+class InteractionMachine(nn.Module):
+    """Interaction Machine (interaction_machine.py:21-71): the order-k elementary symmetric polynomials of the field
+    embeddings, from the power sums p_k = sum_f e_f^k (Newton's identities), concatenated, optionally batch-normalised,
+    then ``fc``.  Holders ``bn`` / ``fc`` as in the reference; the BatchNorm runs on rbx_batchnorm_fwd/bwd, ``fc`` on the
+    fp32-MFMA GEMM; the power sums are element-wise ATen passes over [B, F, D] (memory-bound, nothing to fuse them into)."""
+
+    def __init__(self, embedding_dim, order=2, batch_norm=False):
+        super(InteractionMachine, self).__init__()
+        assert order < 6, "order={} is not supported.".format(order)
+        self.order = order
+        self.bn = nn.BatchNorm1d(embedding_dim * order) if batch_norm else None
+        self.fc = nn.Linear(order * embedding_dim, 1)
+
+    @staticmethod
+    def _elementary(k, p):
+        p1, p2, p3, p4, p5 = (p + [None] * 5)[:5]
+        if k == 1:
+            return p1
+        if k == 2:
+            return (p1.pow(2) - p2) / 2
+        if k == 3:
+            return (p1.pow(3) - 3 * p1 * p2 + 2 * p3) / 6
+        if k == 4:
+            return (p1.pow(4) - 6 * p1.pow(2) * p2 + 3 * p2.pow(2) + 8 * p1 * p3 - 6 * p4) / 24
+        return (p1.pow(5) - 10 * p1.pow(3) * p2 + 20 * p1.pow(2) * p3 - 30 * p1 * p4 - 20 * p2 * p3
+                + 15 * p1 * p2.pow(2) + 24 * p5) / 120
+
+    def forward(self, X):
+        sums, Q = [], X
+        for k in range(1, self.order + 1):
+            if k > 1:
+                Q = Q * X
+            sums.append(Q.sum(dim=1))
+        out = torch.cat([self._elementary(k, sums) for k in range(1, self.order + 1)], dim=-1)
+        if self.bn is not None:
+            out = ops.batch_norm(out, self.bn)
+        return ops.linear(out, self.fc.weight, self.fc.bias)
+
+
+class HolographicInteraction(nn.Module):
+    """HFM's pairwise compression (holographic_interaction.py:22-52) over the pairs i < j: Hadamard product
+    (rbx_pairmul_fwd/bwd), circular convolution or circular correlation of the two embeddings.  The circular forms are
+    evaluated through the FFT exactly as the reference writes them (torch.fft, i.e. rocFFT: D = 16..64 points per row);
+    ``triu_index`` / ``conj_sign`` stay frozen parameters so that state_dicts match."""
+
+    def __init__(self, num_fields, interaction_type="circular_convolution"):
+        super(HolographicInteraction, self).__init__()
+        self.interaction_type = interaction_type
+        if self.interaction_type == "circular_correlation":
+            self.conj_sign = nn.Parameter(torch.tensor([1., -1.]), requires_grad=False)
+        self.triu_index = nn.Parameter(torch.triu_indices(num_fields, num_fields, offset=1), requires_grad=False)
+
+    def forward(self, feature_emb):
+        if self.interaction_type == "hadamard_product":
+            return ops.pair_mul(feature_emb, feature_emb)
+        if self.interaction_type not in ("circular_convolution", "circular_correlation"):
+            raise ValueError("interaction_type={} not supported.".format(self.interaction_type))
+        left = torch.fft.fft(torch.index_select(feature_emb, 1, self.triu_index[0]))
+        right = torch.fft.fft(torch.index_select(feature_emb, 1, self.triu_index[1]))
+        if self.interaction_type == "circular_correlation":
+            left = torch.conj(left)                       # the reference flips the sign of the imaginary part
+        return torch.fft.ifft(left * right).real

@@ -694,6 +694,37 @@ def test_cross_net_mix_golden():
     assert_grads_close(net, fx["g"], TOL)
 
 
+@pytest.mark.parametrize("tag,order,bn", [("o2", 2, False), ("o5bn", 5, True)])
+def test_interaction_machine_golden(tag, order, bn):
+    L = _layers()
+    fx = Fixture("im_hfm")
+    x = fx.tensors("in")["x"]
+    net = L.InteractionMachine(x.shape[2], order=order, batch_norm=bn)
+    net.load_state_dict(fx.tensors("p_" + tag), strict=False)          # (running statistics are not part of the fixture)
+    net.cuda().train()
+    xc = x.cuda().requires_grad_(True)
+    out = net(xc)
+    assert_close(out, fx["out_" + tag]["y"], TOL, "y")
+    (out * fx.tensors("out_" + tag)["R"].cuda()).sum().backward()
+    assert_close(xc.grad, fx["out_" + tag]["dx"], TOL, "dx")
+    assert_grads_close(net, fx["g_" + tag], TOL)
+
+
+@pytest.mark.parametrize("kind", ["hadamard_product", "circular_convolution", "circular_correlation"])
+def test_holographic_interaction_golden(kind):
+    L = _layers()
+    fx = Fixture("im_hfm")
+    x = fx.tensors("in")["x"]
+    layer = L.HolographicInteraction(x.shape[1], interaction_type=kind).cuda()
+    xc = x.cuda().requires_grad_(True)
+    out = layer(xc)
+    assert_close(out, fx["hfm_" + kind]["y"], TOL, "y")
+    (out * fx.tensors("hfm_" + kind)["R"].cuda()).sum().backward()
+    assert_close(xc.grad, fx["hfm_" + kind]["dx"], TOL, "dx")
+    with pytest.raises(ValueError):
+        L.HolographicInteraction(3, interaction_type="nope")(xc)
+
+
 def test_cin_golden():
     """CompressedInteractionNet against the live-reference fixture: same state_dict keys, output, dx, grads."""
     L = _layers()
