@@ -593,6 +593,41 @@ def gen_im_hfm(fuxictr, B=6, F=5, D=8):
     save("im_hfm", **groups)
 
 
+def gen_senet_din(fuxictr, B=6, F=7, D=8, L=5):
+    """SqueezeExcitation (both activations) and DIN_Attention (ReLU / Dice units, with and without softmax) of the live
+    reference (squeeze_excitation.py:21-41, target_attention.py:25-66, activations.py:23-32)."""
+    import fuxictr.pytorch.layers as FL
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, F, D, generator=g)
+    target = torch.randn(B, D, generator=g)
+    hist = torch.randn(B, L, D, generator=g)
+    mask = (torch.rand(B, L, generator=g) < 0.7).float()
+    mask[:, 0] = 1.0
+    groups = {"in": {"x": x, "target": target, "hist": hist, "mask": mask}}
+    for act in ("ReLU", "Sigmoid"):
+        net = FL.SqueezeExcitation(F, reduction_ratio=3, excitation_activation=act)
+        reinit(net, std=0.4, seed=3)
+        xi = x.clone().requires_grad_(True)
+        out = net(xi)
+        R = torch.randn(out.shape, generator=g)
+        (out * R).sum().backward()
+        groups["p_se_" + act] = net.state_dict()
+        groups["out_se_" + act] = {"y": out, "dx": xi.grad, "R": R}
+        groups["g_se_" + act] = grads_of(net)
+    for tag, acts, soft in (("relu", "ReLU", False), ("dice_soft", "Dice", True)):
+        net = FL.DIN_Attention(embedding_dim=D, attention_units=[12, 6], hidden_activations=acts, use_softmax=soft)
+        reinit(net, std=0.3, seed=7)
+        net.train()
+        t, h = target.clone().requires_grad_(True), hist.clone().requires_grad_(True)
+        out = net(t, h, mask)
+        R = torch.randn(out.shape, generator=g)
+        (out * R).sum().backward()
+        groups["p_din_" + tag] = {k: v for k, v in net.state_dict().items() if "running" not in k and "num_batches" not in k}
+        groups["out_din_" + tag] = {"y": out, "dt": t.grad, "dh": h.grad, "R": R}
+        groups["g_din_" + tag] = grads_of(net)
+    save("senet_din", **groups)
+
+
 def gen_bilinear(fuxictr, B=7, F=5, D=4):
     """BilinearInteraction (pair loop) and BilinearInteractionV2 (index_select) of the live reference, three W layouts."""
     import fuxictr.pytorch.layers as FL
@@ -654,6 +689,7 @@ def main():
     gen_cin(fuxictr)
     gen_cross_net_mix(fuxictr)
     gen_im_hfm(fuxictr)
+    gen_senet_din(fuxictr)
 
 
 if __name__ == "__main__":

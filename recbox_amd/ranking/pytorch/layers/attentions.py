@@ -3,11 +3,14 @@
 call signature ``forward(Q, K, V, scale=None, mask=None) -> (output, attention)``; the QK^T ->
 mask(-1e9) -> softmax -> .V chain is one fused HIP kernel (``rbx_attn_fwd``) and the score
 matrix only reaches HBM because this API returns the attention probabilities."""
+import math
+
+import torch
 from torch import nn
 
-from .... import ops
+from .... import dense, ops
 
-__all__ = ["ScaledDotProductAttention", "MultiHeadTargetAttention"]
+__all__ = ["ScaledDotProductAttention", "MultiHeadTargetAttention", "SqueezeExcitation", "DIN_Attention", "Dice", "GELU"]
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -69,3 +72,75 @@ class MultiHeadTargetAttention(nn.Module):
         if self.use_qkvo:
             output = ops.linear(output, self.W_o.weight)
         return output
+
+
+class Dice(nn.Module):
+    """DIN's data-adaptive activation (activations.py:23-32): p = sigmoid(BN(x)) with a non-affine BatchNorm
+    (eps 1e-9, momentum 0.01), y = p x + alpha (1 - p) x.  The BatchNorm runs on rbx_batchnorm_fwd/bwd."""
+
+    def __init__(self, input_dim, eps=1e-9):
+        super(Dice, self).__init__()
+        self.bn = nn.BatchNorm1d(input_dim, affine=False, eps=eps, momentum=0.01)
+        self.alpha = nn.Parameter(torch.zeros(input_dim))
+
+    def forward(self, X):
+        p = torch.sigmoid(ops.batch_norm(X, self.bn) if X.dim() == 2 else self.bn(X))
+        return p * X + self.alpha * (1 - p) * X
+
+
+class GELU(nn.Module):
+    """The tanh form the reference spells out (activations.py:35-40)."""
+
+    def forward(self, x):
+        return 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * torch.pow(x, 3))))
+
+
+class SqueezeExcitation(nn.Module):
+    """FiBiNET's SENET re-weighting of the fields (squeeze_excitation.py:21-41): per-field mean over the embedding
+    dimension -> two bias-free Linears (``excitation``, the reference's nn.Sequential: both on the fp32-MFMA GEMM, ReLU
+    fused) -> field weights."""
+
+    def __init__(self, num_fields, reduction_ratio=3, excitation_activation="ReLU"):
+        super(SqueezeExcitation, self).__init__()
+        reduced = max(1, int(num_fields / reduction_ratio))
+        kind = excitation_activation.lower()
+        if kind not in ("relu", "sigmoid"):
+            raise NotImplementedError
+        self.excitation = nn.Sequential(nn.Linear(num_fields, reduced, bias=False), nn.ReLU(),
+                                        nn.Linear(reduced, num_fields, bias=False),
+                                        nn.ReLU() if kind == "relu" else nn.Sigmoid())
+
+    def forward(self, feature_emb):
+        A = dense.run_sequential(self.excitation, feature_emb.mean(dim=-1))
+        return feature_emb * A.unsqueeze(-1)
+
+
+class DIN_Attention(nn.Module):
+    """DIN's local activation unit (target_attention.py:25-66): an MLP over [target, history, target - history,
+    target * history] scores every position of the behaviour sequence (``attention_layer`` = MLP_Block, i.e. the
+    [B L, 4E] x [4E, units] products on the fp32 matrix cores); masked, optionally soft-maxed, weighted sum."""
+
+    def __init__(self, embedding_dim=64, attention_units=[32], hidden_activations="ReLU", output_activation=None,
+                 dropout_rate=0, batch_norm=False, use_softmax=False):
+        super(DIN_Attention, self).__init__()
+        from .blocks import MLP_Block
+        self.embedding_dim = embedding_dim
+        self.use_softmax = use_softmax
+        if isinstance(hidden_activations, str) and hidden_activations.lower() == "dice":
+            hidden_activations = [Dice(units) for units in attention_units]
+        self.attention_layer = MLP_Block(input_dim=4 * embedding_dim, output_dim=1, hidden_units=attention_units,
+                                         hidden_activations=hidden_activations, output_activation=output_activation,
+                                         dropout_rates=dropout_rate, batch_norm=batch_norm)
+
+    def forward(self, target_item, history_sequence, mask=None):
+        seq_len = history_sequence.size(1)
+        target = target_item.unsqueeze(1).expand(-1, seq_len, -1)
+        pairs = torch.cat([target, history_sequence, target - history_sequence, target * history_sequence], dim=-1)
+        weight = self.attention_layer(pairs.view(-1, 4 * self.embedding_dim)).view(-1, seq_len)
+        if mask is not None:
+            weight = weight * mask.float()
+        if self.use_softmax:
+            if mask is not None:
+                weight = weight + -1.e9 * (1 - mask.float())
+            weight = weight.softmax(dim=-1)
+        return (weight.unsqueeze(-1) * history_sequence).sum(dim=1)

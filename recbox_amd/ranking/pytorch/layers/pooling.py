@@ -8,7 +8,7 @@ from torch import nn
 from .... import ops
 from ...._lib import POOL_MEAN_VALUE, POOL_SUM
 
-__all__ = ["MaskedAveragePooling", "MaskedSumPooling"]
+__all__ = ["MaskedAveragePooling", "MaskedSumPooling", "KMaxPooling"]
 
 
 class MaskedAveragePooling(nn.Module):
@@ -29,3 +29,17 @@ class MaskedSumPooling(nn.Module):
 
     def forward(self, embedding_matrix):
         return ops.pool(embedding_matrix, None, False, ops.DENOM_NONE, 0.0)
+
+
+class KMaxPooling(nn.Module):
+    """The k largest entries along ``dim`` in their original order (pooling.py:43-53).  Selection with a gradient
+    through the selected positions: ATen's topk / sort / gather (the rbx_topk kernel of the retrieval metrics returns
+    values for ranking, it carries no backward)."""
+
+    def __init__(self, k, dim):
+        super(KMaxPooling, self).__init__()
+        self.k, self.dim = k, dim
+
+    def forward(self, X):
+        keep = X.topk(self.k, dim=self.dim).indices.sort(dim=self.dim).values
+        return X.gather(self.dim, keep)

@@ -725,6 +725,49 @@ def test_holographic_interaction_golden(kind):
         L.HolographicInteraction(3, interaction_type="nope")(xc)
 
 
+@pytest.mark.parametrize("act", ["ReLU", "Sigmoid"])
+def test_squeeze_excitation_golden(act):
+    L = _layers()
+    fx = Fixture("senet_din")
+    x = fx.tensors("in")["x"]
+    net = load_params(L.SqueezeExcitation(x.shape[1], reduction_ratio=3, excitation_activation=act), fx["p_se_" + act]).cuda()
+    xc = x.cuda().requires_grad_(True)
+    out = net(xc)
+    assert_close(out, fx["out_se_" + act]["y"], TOL, "y")
+    (out * fx.tensors("out_se_" + act)["R"].cuda()).sum().backward()
+    assert_close(xc.grad, fx["out_se_" + act]["dx"], TOL, "dx")
+    assert_grads_close(net, fx["g_se_" + act], TOL)
+
+
+@pytest.mark.parametrize("tag,acts,soft", [("relu", "ReLU", False), ("dice_soft", "Dice", True)])
+def test_din_attention_golden(tag, acts, soft):
+    L = _layers()
+    fx = Fixture("senet_din")
+    t = fx.tensors("in")
+    net = L.DIN_Attention(embedding_dim=t["target"].shape[1], attention_units=[12, 6], hidden_activations=acts,
+                          use_softmax=soft)
+    net.load_state_dict(fx.tensors("p_din_" + tag), strict=False)      # (running statistics are not in the fixture)
+    net.cuda().train()
+    tc, hc = t["target"].cuda().requires_grad_(True), t["hist"].cuda().requires_grad_(True)
+    out = net(tc, hc, t["mask"].cuda())
+    assert_close(out, fx["out_din_" + tag]["y"], TOL, "y")
+    (out * fx.tensors("out_din_" + tag)["R"].cuda()).sum().backward()
+    assert_close(tc.grad, fx["out_din_" + tag]["dt"], TOL, "d target")
+    assert_close(hc.grad, fx["out_din_" + tag]["dh"], TOL, "d history")
+    assert_grads_close(net, fx["g_din_" + tag], TOL)
+
+
+def test_kmax_pooling_matches_its_definition():
+    L = _layers()
+    x = torch.randn(5, 9, 4, generator=torch.Generator().manual_seed(3)).cuda().requires_grad_(True)
+    out = L.KMaxPooling(3, dim=1)(x)
+    want = torch.stack([torch.stack([x[b, :, d][torch.sort(torch.topk(x[b, :, d], 3).indices).values] for d in range(4)], 1)
+                        for b in range(5)])
+    assert torch.equal(out, want)
+    out.sum().backward()
+    assert float(x.grad.sum()) == 5 * 3 * 4
+
+
 def test_cin_golden():
     """CompressedInteractionNet against the live-reference fixture: same state_dict keys, output, dx, grads."""
     L = _layers()
