@@ -200,6 +200,10 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
  * touched.  Call it before the next rbx_fm_sort reuses the workspace. */
 int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                   void* d_workspace, size_t workspace_bytes, void* stream);
+/* The same for the generic lookup: the rows named by the previous rbx_embed_sort on this workspace (fields[i].grad =
+ * the persistent buffers its rbx_embed_bwd stored into).  Only for tables that get their gradient from that lookup alone. */
+int rbx_embed_rezero(const rbx_field_t* fields, int32_t n_fields, int64_t batch, void* d_workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* ---- C2: the exchange itself on the caller's stream.  The reference has no sharded exchange (nn.DataParallel / DDP
  * only); recbox_amd/comm.py uses torch.distributed's all_to_all_single by default, which runs on RCCL's

@@ -535,6 +535,18 @@ extern "C" int rbx_embed_sort(const rbx_field_t* fields, int32_t n_fields, int64
   return run_sort(p, static_cast<char*>(d_workspace), d_status, as_stream(stream));
 }
 
+extern "C" int rbx_embed_rezero(const rbx_field_t* fields, int32_t n_fields, int64_t batch, void* d_workspace,
+                                size_t workspace_bytes, void* stream) {
+  using namespace rbx;
+  if (batch == 0) return RBX_OK;
+  BwdPlan p;
+  int rc = make_plan(fields, n_fields, batch, nullptr, 0, &p);
+  if (rc != RBX_OK) return rc;
+  if (p.n_lookups == 0) return RBX_OK;
+  if (d_workspace == nullptr || workspace_bytes < p.bytes) return fail(RBX_ERR_WORKSPACE, "embed_rezero: workspace too small");
+  return launch_rezero(p, static_cast<const char*>(d_workspace), as_stream(stream));
+}
+
 extern "C" int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch, const float* d_dout,
                              int64_t out_stride_b, const float* d_row_scale, int32_t accumulate, void* d_workspace,
                              size_t workspace_bytes, void* stream) {

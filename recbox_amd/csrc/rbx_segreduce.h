@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void rezero_rows_kernel(const RedPack P, const
 }
 
 
-// launch helper of rbx_fm_rezero (any plan built by make_plan / fm_plan works: the kernel reads the RedPack only)
+// launch helper of rbx_fm_rezero / rbx_embed_rezero (any plan built by make_plan / fm_plan: the kernel reads the RedPack only)
 static inline int launch_rezero(const BwdPlan& p, const char* ws, hipStream_t s) {
   const int cur = p.passes & 1;
   const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);

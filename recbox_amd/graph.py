@@ -26,6 +26,7 @@ class GraphedStep(object):
     """
 
     def __init__(self, fn, warmup=3, capture_error_mode="global", reuse_grads=True):
+        # reuse_grads: False / True (the fused FM body) / "all" (also the generic lookup: ops.config.reuse_grad_buffers)
         if ops.config.check_ids:
             raise RuntimeError("GraphedStep: set recbox_amd.ops.config.check_ids = False first "
                                "(the id range check syncs the host, which cannot be captured)")
@@ -35,7 +36,7 @@ class GraphedStep(object):
         # replay wrote instead of re-filling 379 MB of zeros per step (ops.config.reuse_grad_buffers): ``fn`` must
         # start from ``p.grad = None`` for the embedding parameters, as a captured step does anyway.
         old = ops.config.reuse_grad_buffers
-        ops.config.reuse_grad_buffers = bool(reuse_grads) or old
+        ops.config.reuse_grad_buffers = "all" if "all" in (reuse_grads, old) else (bool(reuse_grads) or old)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

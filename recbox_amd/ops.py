@@ -38,8 +38,11 @@ class config(object):
     # those gradients in place (an in-place all-reduce of table gradients would: rows of other ranks' batches are not
     # in this rank's sorted ids and would never be cleared).  For the same reason a table must receive its gradient from
     # this op ALONE: autograd sums the contributions of several ops in place, into the first one that arrives -- which
-    # is why only the fused FM body (whose tables are its own) offers this, not the generic lookup.  Off by default.
-    reuse_grad_buffers = os.environ.get("RECBOX_AMD_REUSE_GRADS", "0") != "0"
+    # is why "1" / True covers only the fused FM body (whose tables are its own).  "all" extends it to the generic lookup
+    # (embed_lookup: FeatureEmbedding, EmbeddingLayer, rechub's layers): ONLY for models whose tables each feed exactly
+    # one lookup per step (YoutubeDNN / DeepFM mirrors here do; SASRec's item table also feeds gather_dot and must not).
+    # Off by default.
+    reuse_grad_buffers = {"0": False, "": False, "all": "all"}.get(os.environ.get("RECBOX_AMD_REUSE_GRADS", "0"), True)
 
 
 def _require_cuda(t, what):
@@ -255,10 +258,51 @@ class _EmbedLookup(torch.autograd.Function):
             # same descriptor set as the backward (placeholder grad pointers), sorted on the side stream
             plan.bind_params(params, [p if p.requires_grad else None for p in params])
             ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, plan.n, B)
-            if ws_bytes > 0:
+            pool = _EmbedLookup._pool_for(plan, params, dev) if config.reuse_grad_buffers == "all" else None
+            if pool is not None and pool.pending:       # overlapping training forwards: fresh gradients for both (see
+                pool.ticket += 1                        # _FmFused.forward)
+                pool.pending = False
+                pool = None
+            if ws_bytes > 0 and pool is None:
                 ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_embed_sort(
                     plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, st))
+            elif ws_bytes > 0:
+                placeholders = [p if p.requires_grad else None for p in params]
+
+                def rezero(st):                         # clear the rows the previous backward stored (ids still in pool.ws)
+                    plan.bind_params(params, pool.bind_views(list(params)))
+                    rc = lib.rbx_embed_rezero(plan.arr, plan.n, pool.dirty_batch, _ptr(pool.ws), pool.ws_bytes, st)
+                    pool.dirty_batch = 0
+                    plan.bind_params(params, placeholders)
+                    return rc
+
+                dirty = pool.dirty_batch
+                if dirty and pool.ws_bytes < ws_bytes:  # a larger batch than ever before: clear, then regrow
+                    check(rezero(_stream()))
+                    dirty = 0
+                ws = pool.workspace(ws_bytes)
+
+                def launch(ws, st):
+                    if dirty:
+                        rc = rezero(st)
+                        if rc != _lib.RBX_OK:
+                            return rc
+                    return lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), pool.ws_bytes, None, st)
+
+                ctx.sort = _EarlySort(dev, pool.ws_bytes, launch, ws=ws)
+                pool.ticket += 1
+                pool.pending = True
+                ctx.pool, ctx.ticket = pool, pool.ticket
         return out
+
+    @staticmethod
+    def _pool_for(plan, params, dev):
+        params = list(params)
+        pool = getattr(plan, "_grad_pool", None)
+        if pool is None or not pool.matches(params):
+            by_id = set(sp.param for sp in plan.specs if sp.kind == FIELD_CATEGORICAL)
+            pool = plan._grad_pool = _GradPool(params, [i in by_id for i in range(len(params))], dev)
+        return pool
 
     @staticmethod
     def backward(ctx, dout):
@@ -267,12 +311,22 @@ class _EmbedLookup(torch.autograd.Function):
             dout = dout.contiguous().float()
         need = [i + 4 + len(ctx.inputs) for i in range(len(params))]
         want = [ctx.needs_input_grad[j] for j in need]
-        grads = _flat_zero_grads(params, want, dout.device)
+        want_now = [p.requires_grad for p in params]
+        pool = getattr(ctx, "pool", None)
+        if pool is not None and not (want_now == list(want) and ctx.ticket == pool.ticket and B > 0):
+            pool, ctx.sort = None, None          # another forward has sorted over this workspace since: start over
+        if pool is not None:
+            for p, w in zip(params, want):
+                if w and p.grad is not None:
+                    raise RuntimeError("recbox_amd: config.reuse_grad_buffers needs p.grad to be None at every backward "
+                                       "(zero_grad(set_to_none=True)); the gradients alias one persistent buffer")
+            grads = pool.views(list(params))
+        else:
+            grads = _flat_zero_grads(params, want, dout.device)
         if B == 0:
             return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
         plan.bind_inputs(ctx.inputs)
         plan.bind_params(params, grads)
-        want_now = [p.requires_grad for p in params]
         if ctx.sort is not None and want_now == list(want):
             ctx.sort.join()
             ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes
@@ -283,6 +337,9 @@ class _EmbedLookup(torch.autograd.Function):
         # grads are views of a freshly zeroed buffer: accumulate=0 lets the kernel store instead of RMW
         check(lib.rbx_embed_bwd(plan.arr, plan.n, B, _ptr(dout), dout.stride(0) if B > 1 else plan.width,
                                 _ptr(ctx.row_scale), 0, _ptr(ws), ws_bytes, _stream()))
+        if pool is not None:
+            pool.dirty_batch = B                 # the rows named by the sorted ids in pool.ws now hold this step's sums
+            pool.pending = False
         return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
 
 

@@ -365,3 +365,88 @@ def test_multi_head_target_attention_golden():
     assert_close(hist.grad, fx["g"]["history"], TOL)
     for n, p in att.named_parameters():
         assert_close(p.grad, fx["g"]["p." + n], TOL, n)
+
+
+def _matching_model_and_batches():
+    """Two matching EmbeddingLayers (user side only: one lookup per step, so every table feeds exactly one op) and a few
+    batches of different sizes: id + padded mean-pooled history + numeric feature."""
+    import recbox_amd.core.pytorch.layers as C
+
+    class UserTower(torch.nn.Module):
+        def __init__(self):
+            super(UserTower, self).__init__()
+            self.emb = C.EmbeddingLayer(_MFM(matching_specs()), 8)
+            self.head = torch.nn.Linear(3 * 8, 1)
+
+        def forward(self, X):
+            u = self.emb(X, feature_source="user")
+            return self.head(u.flatten(start_dim=1))
+
+    batches = []
+    for k, B in enumerate([40, 40, 200, 9]):
+        g = torch.Generator().manual_seed(300 + k)
+        hist = torch.randint(0, 19, (B, 6), generator=g)
+        hist[torch.arange(6)[None, :] >= torch.randint(0, 7, (B, 1), generator=g)] = 19        # pad tail (some rows empty)
+        X = OrderedDict(user_id=torch.randint(0, 13, (B,), generator=g), user_hist=hist,
+                        age=torch.rand(B, generator=g), item_id=torch.randint(0, 19, (B,), generator=g))
+        batches.append((X, (torch.rand(B, 1, generator=g) < 0.4).float()))
+    return UserTower().cuda(), UserTower().cuda(), batches, (lambda m, X: m(X))
+
+
+@pytest.mark.parametrize("which", ["youtubednn", "deepfm"])
+def test_model_mirrors_with_persistent_gradients(which):
+    """ops.config.reuse_grad_buffers = "all" on the model mirrors whose tables each feed ONE lookup per training step
+    (YoutubeDNN: user id + history + item + negatives in a single gather with a shared item table; DeepFM: one gather
+    for the FM, LR and deep parts): three steps on different batches, bit-identical to fresh gradients."""
+    from recbox_amd import ops
+    from recbox_amd.rechub.basic.features import DenseFeature, SequenceFeature, SparseFeature
+    from recbox_amd.rechub.models.matching import YoutubeDNN
+    from recbox_amd.rechub.models.ranking import DeepFM
+    V, D = 5000, 16
+
+    def build():
+        if which == "youtubednn":
+            uf = [SparseFeature("user_id", 300, 8),
+                  SequenceFeature("hist", V, D, pooling="mean", shared_with="item", padding_idx=0)]
+            return YoutubeDNN(uf, [SparseFeature("item", V, D)],
+                              [SequenceFeature("neg_items", V, D, pooling="concat", shared_with="item")],
+                              {"dims": [32, D], "activation": "relu"}, temperature=0.05).cuda()
+        dense = [DenseFeature("I%d" % i) for i in range(3)]
+        sparse = [SparseFeature("C%d" % i, v, D) for i, v in enumerate([7, 400, V])]
+        return DeepFM(dense + sparse, sparse, {"dims": [24, 24], "dropout": 0.0, "activation": "relu"}).cuda()
+
+    def batch(B, seed):
+        g = torch.Generator().manual_seed(seed)
+        if which == "youtubednn":
+            L = 9
+            lens = torch.randint(0, L + 1, (B,), generator=g)
+            hist = torch.randint(1, V, (B, L), generator=g) * (torch.arange(L)[None, :] < lens[:, None])
+            x = {"user_id": torch.randint(0, 300, (B,), generator=g), "hist": hist,
+                 "item": torch.randint(1, V, (B,), generator=g), "neg_items": torch.randint(1, V, (B, 3), generator=g)}
+            return {k: v.cuda() for k, v in x.items()}, torch.zeros(B, dtype=torch.long, device="cuda")
+        x = {"I%d" % i: torch.rand(B, generator=g) for i in range(3)}
+        for i, v in enumerate([7, 400, V]):
+            x["C%d" % i] = torch.randint(0, v, (B,), generator=g)
+        return {k: v.cuda() for k, v in x.items()}, (torch.rand(B, generator=g) < 0.3).float().cuda()
+
+    fresh, reuse = build(), build()
+    with torch.no_grad():
+        for p in fresh.parameters():
+            p.normal_(0, 0.1)
+    reuse.load_state_dict(fresh.state_dict())
+    loss_fn = F.cross_entropy if which == "youtubednn" else F.binary_cross_entropy
+    old = ops.config.reuse_grad_buffers
+    try:
+        for k, B in enumerate([64, 64, 257]):
+            x, y = batch(B, 500 + k)
+            for model, flag in ((fresh, False), (reuse, "all")):
+                ops.config.reuse_grad_buffers = flag
+                model.train()
+                model.zero_grad(set_to_none=True)
+                loss_fn(model(x), y).backward()
+            for (n, p0), (_, p1) in zip(fresh.named_parameters(), reuse.named_parameters()):
+                assert (p0.grad is None) == (p1.grad is None), n
+                if p0.grad is not None:
+                    assert torch.equal(p1.grad, p0.grad), "%s step %d: %s" % (which, k, n)
+    finally:
+        ops.config.reuse_grad_buffers = old

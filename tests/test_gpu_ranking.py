@@ -354,6 +354,41 @@ def test_reuse_grad_buffers_other_shapes(kind):
         ops.config.reuse_grad_buffers = old
 
 
+@pytest.mark.parametrize("model_kind", ["fm_layers", "sequence_pooling"])
+def test_reuse_grad_buffers_all_covers_the_generic_lookup(model_kind):
+    """ops.config.reuse_grad_buffers = "all": the generic lookup (FeatureEmbedding of the layer-composed FM; a matching
+    EmbeddingLayer with a shared table, a pad row and mean-pooled histories) keeps persistent gradients too -- several
+    steps with different ids and batch sizes, bit-identical to fresh zero-filled gradients."""
+    from recbox_amd import ops
+    if model_kind == "fm_layers":
+        from recbox_amd.ranking.pytorch.models import FM
+        vocabs = [37, 5, 3001, 211, 70000]
+        fm, _, _ = _criteo_like(4, vocabs, 16, seed=7)
+        fresh, reuse = FM(fm, 16, fused=False).cuda(), FM(fm, 16, fused=False).cuda()
+        batches = [_criteo_like(B, vocabs, 16, seed=120 + k, zipf=bool(k % 2))[1:] for k, B in enumerate([300, 300, 900, 50])]
+        run = lambda m, X: m.logits(X)
+    else:
+        from test_gpu_matching import _matching_model_and_batches
+        fresh, reuse, batches, run = _matching_model_and_batches()
+    with torch.no_grad():
+        for p in fresh.parameters():
+            p.normal_(0, 0.1)
+    reuse.load_state_dict(fresh.state_dict())
+    old = ops.config.reuse_grad_buffers
+    try:
+        for k, (X, y) in enumerate(batches):
+            Xc, yc = _cuda(X), y.cuda()
+            for model, flag in ((fresh, False), (reuse, "all")):
+                ops.config.reuse_grad_buffers = flag
+                model.zero_grad(set_to_none=True)
+                out = run(model, Xc)
+                torch.nn.functional.binary_cross_entropy(torch.sigmoid(out.reshape(yc.shape)), yc, reduction="mean").backward()
+            for (n, p0), (_, p1) in zip(fresh.named_parameters(), reuse.named_parameters()):
+                assert torch.equal(p1.grad, p0.grad), "%s step %d: %s" % (model_kind, k, n)
+    finally:
+        ops.config.reuse_grad_buffers = old
+
+
 def test_graphed_step_replays_equal_eager_steps():
     """GraphedStep (whole step in one hipGraph, persistent gradients re-zeroed by row): after refilling the static batch,
     a replay leaves the loss and gradients of the eager step on that batch -- three different batches in a row."""
