@@ -201,6 +201,8 @@ def main():
     # after a step is the same dense [V, D] tensor either way (tests/test_gpu_ranking.py: bit-identical)
     # (the N>1 path keeps fresh gradients: its replicated tables are the small ones, there is nothing to save)
     ops.config.reuse_grad_buffers = not (args.fresh_grads or world > 1 or args.force_sharded)
+    if ops.config.reuse_grad_buffers and args.path == "layers":
+        ops.config.reuse_grad_buffers = "all"       # layer-composed FM: every table feeds exactly one lookup per step
     fmw = CriteoFeatureMap(args.dim)
     sharded = world > 1 or args.force_sharded
     B = args.batch
@@ -249,7 +251,7 @@ def main():
         # one hipGraph holds the whole step (same kernels, same C ABI); the batch lives in static buffers
         from recbox_amd.graph import GraphedStep
         try:
-            step = GraphedStep(eager_step, warmup=3, reuse_grads=not args.fresh_grads)
+            step = GraphedStep(eager_step, warmup=3, reuse_grads=ops.config.reuse_grad_buffers)
             graph_note = "hipGraph replay"
         except Exception as exc:               # a capture this stack refuses: the same step, launched from Python
             print("[bench] hipGraph capture failed (%s: %s); launching the step eagerly" % (type(exc).__name__, exc),
@@ -351,8 +353,8 @@ def main():
                "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
                                       "%s ids, %s path, %s, dense-grad autograd contract (%s), no optimiser step"
                                       % (args.dim, B, args.dist, args.path, graph_note,
-                                         "fresh zero-filled grads every step" if args.fresh_grads or args.path != "fused"
-                                         or sharded else "persistent grad buffer, rows of the previous step re-zeroed"),
+                                         "persistent grad buffer, rows of the previous step re-zeroed"
+                                         if ops.config.reuse_grad_buffers else "fresh zero-filled grads every step"),
                           "global_batch": B * world,
                           "parallelism": ("dp%d + row-sharded tables (all-to-all-v)" % world) if sharded else "dp1"},
                "roofline": roof}
