@@ -258,41 +258,23 @@ class _EmbedLookup(torch.autograd.Function):
             # same descriptor set as the backward (placeholder grad pointers), sorted on the side stream
             plan.bind_params(params, [p if p.requires_grad else None for p in params])
             ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, plan.n, B)
-            pool = _EmbedLookup._pool_for(plan, params, dev) if config.reuse_grad_buffers == "all" else None
-            if pool is not None and pool.pending:       # overlapping training forwards: fresh gradients for both (see
-                pool.ticket += 1                        # _FmFused.forward)
-                pool.pending = False
-                pool = None
+            pool = _GradPool.claim(_EmbedLookup._pool_for(plan, params, dev)
+                                   if config.reuse_grad_buffers == "all" else None)
             if ws_bytes > 0 and pool is None:
                 ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_embed_sort(
                     plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, st))
             elif ws_bytes > 0:
                 placeholders = [p if p.requires_grad else None for p in params]
 
-                def rezero(st):                         # clear the rows the previous backward stored (ids still in pool.ws)
+                def rezero(st):
                     plan.bind_params(params, pool.bind_views(list(params)))
                     rc = lib.rbx_embed_rezero(plan.arr, plan.n, pool.dirty_batch, _ptr(pool.ws), pool.ws_bytes, st)
                     pool.dirty_batch = 0
                     plan.bind_params(params, placeholders)
                     return rc
 
-                dirty = pool.dirty_batch
-                if dirty and pool.ws_bytes < ws_bytes:  # a larger batch than ever before: clear, then regrow
-                    check(rezero(_stream()))
-                    dirty = 0
-                ws = pool.workspace(ws_bytes)
-
-                def launch(ws, st):
-                    if dirty:
-                        rc = rezero(st)
-                        if rc != _lib.RBX_OK:
-                            return rc
-                    return lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), pool.ws_bytes, None, st)
-
-                ctx.sort = _EarlySort(dev, pool.ws_bytes, launch, ws=ws)
-                pool.ticket += 1
-                pool.pending = True
-                ctx.pool, ctx.ticket = pool, pool.ticket
+                pool.early_sort(ctx, dev, ws_bytes, rezero, lambda ws, nbytes, st: lib.rbx_embed_sort(
+                    plan.arr, plan.n, B, _ptr(ws), nbytes, None, st))
         return out
 
     @staticmethod
@@ -312,16 +294,10 @@ class _EmbedLookup(torch.autograd.Function):
         need = [i + 4 + len(ctx.inputs) for i in range(len(params))]
         want = [ctx.needs_input_grad[j] for j in need]
         want_now = [p.requires_grad for p in params]
-        pool = getattr(ctx, "pool", None)
-        if pool is not None and not (want_now == list(want) and ctx.ticket == pool.ticket and B > 0):
-            pool, ctx.sort = None, None          # another forward has sorted over this workspace since: start over
-        if pool is not None:
-            for p, w in zip(params, want):
-                if w and p.grad is not None:
-                    raise RuntimeError("recbox_amd: config.reuse_grad_buffers needs p.grad to be None at every backward "
-                                       "(zero_grad(set_to_none=True)); the gradients alias one persistent buffer")
-            grads = pool.views(list(params))
-        else:
+        pool, grads = None, None
+        if getattr(ctx, "pool", None) is not None:
+            pool, grads = ctx.pool.backward_grads(ctx, params, want, want_now == list(want) and B > 0)
+        if pool is None:
             grads = _flat_zero_grads(params, want, dout.device)
         if B == 0:
             return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
@@ -338,8 +314,7 @@ class _EmbedLookup(torch.autograd.Function):
         check(lib.rbx_embed_bwd(plan.arr, plan.n, B, _ptr(dout), dout.stride(0) if B > 1 else plan.width,
                                 _ptr(ctx.row_scale), 0, _ptr(ws), ws_bytes, _stream()))
         if pool is not None:
-            pool.dirty_batch = B                 # the rows named by the sorted ids in pool.ws now hold this step's sums
-            pool.pending = False
+            pool.done(B)
         return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
 
 
@@ -499,6 +474,58 @@ class _GradPool(object):
         small = iter(_flat_zero_grads(loose, [p.requires_grad for p in loose], self.device))    # one fill for all of them
         return [v if v is not None else next(small) for v in _carve(self.flat, params, self.sizes, self.offs)]
 
+    @staticmethod
+    def claim(pool):
+        """The pool a training forward may use, or None.  A second training forward before the first one's backward: if
+        both end up in one backward pass, autograd sums their gradients IN PLACE into whichever arrives first -- rows of
+        the other batch would land in the persistent buffer and never be cleared.  Both forwards then get fresh
+        gradients (the first one's ticket goes stale)."""
+        if pool is not None and pool.pending:
+            pool.ticket += 1
+            pool.pending = False
+            return None
+        return pool
+
+    def early_sort(self, ctx, device, ws_bytes, rezero, sort):
+        """Launch, on the side stream: ``rezero(stream)`` -- clear the rows the previous backward stored, its sorted ids
+        are still in ``self.ws`` -- when there are any, then ``sort(ws, ws_bytes, stream)`` of this batch's ids over
+        them.  Both return a C-ABI code.  (Clearing on a third stream beside the sort was measured slower -- 0.344 vs
+        0.331 ms per FM step --, and so was clearing beside the forward kernel -- 0.309 vs 0.299 ms, the forward going
+        from 46 to 61 us: the step is bound by the memory request rate, concurrent kernels only slow each other down.)"""
+        dirty = self.dirty_batch
+        if dirty and self.ws_bytes < ws_bytes:          # a larger batch than ever before: clear, then regrow
+            check(rezero(_stream()))
+            dirty = 0
+        ws = self.workspace(ws_bytes)
+
+        def launch(ws, st):
+            if dirty:
+                rc = rezero(st)
+                if rc != _lib.RBX_OK:
+                    return rc
+            return sort(ws, self.ws_bytes, st)
+
+        ctx.sort = _EarlySort(device, self.ws_bytes, launch, ws=ws)
+        self.ticket += 1
+        self.pending = True
+        ctx.pool, ctx.ticket = self, self.ticket
+
+    def backward_grads(self, ctx, params, want, usable):
+        """(pool or None, gradient tensors) for a backward: the persistent views when this backward still owns the
+        sorted ids in ``self.ws`` and every parameter starts from ``grad is None``."""
+        if not (usable and ctx.ticket == self.ticket):
+            ctx.sort = None                      # another forward has sorted over this workspace since: start over
+            return None, None
+        for p, w in zip(params, want):
+            if w and p.grad is not None:
+                raise RuntimeError("recbox_amd: config.reuse_grad_buffers needs p.grad to be None at every backward "
+                                   "(zero_grad(set_to_none=True)); the gradients alias one persistent buffer")
+        return self, self.views(list(params))
+
+    def done(self, B):
+        self.dirty_batch = B                     # the rows named by the sorted ids in self.ws now hold this step's sums
+        self.pending = False
+
     def workspace(self, ws_bytes):
         if self.ws is None or self.ws_bytes < ws_bytes:
             assert self.dirty_batch == 0
@@ -582,45 +609,22 @@ class _FmFused(torch.autograd.Function):
             if lr_plan is not None:
                 lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
             ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
-            pool = (_FmFused._pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev)
-                    if config.reuse_grad_buffers else None)
-            if pool is not None and pool.pending:
-                # a second training forward before the first one's backward: if both end up in one backward pass, autograd
-                # sums their gradients IN PLACE into whichever arrives first -- rows of the other batch would land in
-                # the persistent buffer and never be cleared.  Both forwards get fresh gradients instead.
-                pool.ticket += 1
-                pool.pending = False
-                pool = None
+            pool = _GradPool.claim(_FmFused._pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev)
+                                   if config.reuse_grad_buffers else None)
             if ws_bytes > 0 and pool is None:
                 ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_fm_sort(
                     ea, la, lead.n, B, _ptr(ws), ws_bytes, None, st))
             elif ws_bytes > 0:
-                # ahead of the sort, on the same stream: clear what the previous backward stored (its sorted ids are
-                # still in the pool's workspace), then sort this batch's ids over them.  (Clearing on a third stream
-                # beside the sort was measured slower -- 0.344 vs 0.331 ms per step --, and so was clearing beside the
-                # forward kernel -- 0.309 vs 0.299 ms, the forward going from 46 to 61 us: the step is bound by the
-                # memory request rate, concurrent kernels only slow each other down.)
-                dirty = pool.dirty_batch
-                if dirty and pool.ws_bytes < ws_bytes:          # a larger batch than ever before: clear, then regrow
-                    check(_FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, _stream()))
-                    dirty = 0
-                ws = pool.workspace(ws_bytes)
+                def rezero(st):
+                    rc = _FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st)
+                    if emb_plan is not None:
+                        emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
+                    if lr_plan is not None:
+                        lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
+                    return rc
 
-                def launch(ws, st):
-                    if dirty:
-                        rc = _FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st)
-                        if rc != _lib.RBX_OK:
-                            return rc
-                        if emb_plan is not None:
-                            emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
-                        if lr_plan is not None:
-                            lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
-                    return lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), pool.ws_bytes, None, st)
-
-                ctx.sort = _EarlySort(dev, pool.ws_bytes, launch, ws=ws)
-                pool.ticket += 1
-                pool.pending = True
-                ctx.pool, ctx.ticket = pool, pool.ticket
+                pool.early_sort(ctx, dev, ws_bytes, rezero, lambda ws, nbytes, st: lib.rbx_fm_sort(
+                    ea, la, lead.n, B, _ptr(ws), nbytes, None, st))
         return logit
 
     @staticmethod
@@ -664,16 +668,10 @@ class _FmFused(torch.autograd.Function):
         # (zero-filling these buffers on a third stream during the forward was measured: it only adds HBM
         #  contention -- 0.388 vs 0.366 ms per step -- and defeats the caching allocator in eager mode)
         same = [p.requires_grad for p in emb_params] == want_e and [p.requires_grad for p in lr_params] == want_l
-        pool = getattr(ctx, "pool", None)
-        if pool is not None and not (same and ctx.ticket == pool.ticket and B > 0):
-            pool, ctx.sort = None, None          # another forward has sorted over this workspace since: start over
-        if pool is not None:
-            for p, w in zip(list(emb_params) + list(lr_params), want_e + want_l):
-                if w and p.grad is not None:
-                    raise RuntimeError("recbox_amd: config.reuse_grad_buffers needs p.grad to be None at every backward "
-                                       "(zero_grad(set_to_none=True)); the gradients alias one persistent buffer")
-            grads = pool.views(list(emb_params) + list(lr_params))
-        else:
+        pool, grads = None, None
+        if getattr(ctx, "pool", None) is not None:
+            pool, grads = ctx.pool.backward_grads(ctx, list(emb_params) + list(lr_params), want_e + want_l, same and B > 0)
+        if pool is None:
             grads = _flat_zero_grads(list(emb_params) + list(lr_params), want_e + want_l, dev)
         ge, gl = grads[:n_emb], grads[n_emb:]
         gb = torch.zeros(1, dtype=torch.float32, device=dev) if want_b else None
@@ -726,8 +724,7 @@ class _FmFused(torch.autograd.Function):
         check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 if ws_early is not None else 3,
                              _ptr(ws), ws_bytes, _stream()))
         if pool is not None:
-            pool.dirty_batch = B                 # the rows named by the sorted ids in pool.ws now hold this step's sums
-            pool.pending = False
+            pool.done(B)
         return result()
 
 
