@@ -200,6 +200,15 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
  * touched.  Call it before the next rbx_fm_sort reuses the workspace. */
 int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                   void* d_workspace, size_t workspace_bytes, void* stream);
+/* Two lookups over the SAME id tensors with the same table layout (the embedding tables of FeatureEmbedding and the dim-1
+ * tables of LogisticRegression over one batch: feature_embedding.py + logistic_regression.py:30-35) sort identical
+ * (row, sample) pairs.  Given the descriptors of a sort that is already in d_src_workspace (src_is_fm = 0: src_a is an
+ * rbx_embed_sort field array, src_b unused; 1: src_a / src_b are rbx_fm_sort's emb / lr arrays) and those of the lookup
+ * that needs one (dst_*), copy the sorted pairs instead of sorting again.  Returns RBX_ERR_UNSUPPORTED -- nothing was
+ * launched, sort as usual -- when the two do not sort the same pairs. */
+int rbx_sort_share(const rbx_field_t* src_a, const rbx_field_t* src_b, int32_t src_n, int32_t src_is_fm,
+                   const void* d_src_workspace, const rbx_field_t* dst_a, const rbx_field_t* dst_b, int32_t dst_n,
+                   int32_t dst_is_fm, void* d_dst_workspace, size_t dst_workspace_bytes, int64_t batch, void* stream);
 /* The same for the generic lookup: the rows named by the previous rbx_embed_sort on this workspace (fields[i].grad =
  * the persistent buffers its rbx_embed_bwd stored into).  Only for tables that get their gradient from that lookup alone. */
 int rbx_embed_rezero(const rbx_field_t* fields, int32_t n_fields, int64_t batch, void* d_workspace,

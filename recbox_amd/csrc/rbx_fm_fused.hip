@@ -574,6 +574,74 @@ extern "C" int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_
   return run_sort(p, static_cast<char*>(d_workspace), d_status, as_stream(stream));
 }
 
+namespace rbx {
+
+// Two plans sort the same (key, val) pairs when they look up the same id tensors with the same key construction
+// (table order and sizes, padding / mask ids, sequence lengths): e.g. the embedding tables and the dim-1 LR tables of
+// one batch.  Member-wise: the packs are not zero-initialised.
+static bool same_pairs(const BwdPlan& a, const BwdPlan& b) {
+  if (a.n_cat != b.n_cat || a.n_lookups != b.n_lookups || a.total_rows != b.total_rows || a.passes != b.passes) return false;
+  for (int i = 0; i < a.n_cat; ++i) {
+    const KeyField& x = a.keys.f[i];
+    const KeyField& y = b.keys.f[i];
+    if (x.ids != y.ids || x.stride_b != y.stride_b || x.stride_l != y.stride_l || x.vocab != y.vocab ||
+        x.mask_id != y.mask_id || x.pad_id != y.pad_id || x.row_base != y.row_base || x.lk_off != y.lk_off ||
+        x.seq_len != y.seq_len || x.dtype != y.dtype || x.pool != y.pool)
+      return false;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void copy_pairs_kernel(const unsigned* __restrict__ sk, const unsigned* __restrict__ sv,
+                                                         unsigned* __restrict__ dk, unsigned* __restrict__ dv,
+                                                         const unsigned n, unsigned* __restrict__ fin) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {          // what build_keys_kernel does for a sort of its own
+    fin[0] = 0;
+    fin[1] = 0;
+    fin[2] = 0;
+  }
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    dk[i] = sk[i];
+    dv[i] = sv[i];
+  }
+}
+
+static int plan_of(const rbx_field_t* a, const rbx_field_t* b, int n, int is_fm, int64_t B, BwdPlan* p) {
+  if (is_fm) {
+    FmNumPack np;
+    int n_num = 0;
+    return fm_plan(a, b, n, B, p, &np, &n_num);
+  }
+  return make_plan(a, n, B, nullptr, 0, p);
+}
+
+}  // namespace rbx
+
+extern "C" int rbx_sort_share(const rbx_field_t* src_a, const rbx_field_t* src_b, int32_t src_n, int32_t src_is_fm,
+                              const void* d_src_workspace, const rbx_field_t* dst_a, const rbx_field_t* dst_b,
+                              int32_t dst_n, int32_t dst_is_fm, void* d_dst_workspace, size_t dst_workspace_bytes,
+                              int64_t batch, void* stream) {
+  using namespace rbx;
+  if (batch <= 0 || d_src_workspace == nullptr || d_dst_workspace == nullptr) return RBX_ERR_UNSUPPORTED;
+  BwdPlan src, dst;
+  if (plan_of(src_a, src_b, src_n, src_is_fm, batch, &src) != RBX_OK) return RBX_ERR_UNSUPPORTED;
+  int rc = plan_of(dst_a, dst_b, dst_n, dst_is_fm, batch, &dst);
+  if (rc != RBX_OK) return rc;
+  if (dst.n_lookups == 0 || !same_pairs(src, dst)) return RBX_ERR_UNSUPPORTED;
+  if (dst_workspace_bytes < dst.bytes) return fail(RBX_ERR_WORKSPACE, "sort_share: workspace too small");
+  const char* sws = static_cast<const char*>(d_src_workspace);
+  char* dws = static_cast<char*>(d_dst_workspace);
+  const int cur = dst.passes & 1;
+  unsigned blocks = (dst.n_lookups + 1023) / 1024;
+  if (blocks > static_cast<unsigned>(kCUs) * 8) blocks = kCUs * 8;
+  hipLaunchKernelGGL(copy_pairs_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const unsigned*>(sws + src.off_keys[cur]),
+                     reinterpret_cast<const unsigned*>(sws + src.off_vals[cur]),
+                     reinterpret_cast<unsigned*>(dws + dst.off_keys[cur]), reinterpret_cast<unsigned*>(dws + dst.off_vals[cur]),
+                     dst.n_lookups, reinterpret_cast<unsigned*>(dws + dst.off_fin));
+  return check_launch("copy_pairs_kernel");
+}
+
 extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                           const float* d_dlogit, const float* d_sum, float* d_dbias, int32_t accumulate,
                           int32_t phases, void* d_workspace, size_t workspace_bytes, void* stream) {

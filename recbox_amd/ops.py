@@ -42,6 +42,10 @@ class config(object):
     # (embed_lookup: FeatureEmbedding, EmbeddingLayer, rechub's layers): ONLY for models whose tables each feed exactly
     # one lookup per step (YoutubeDNN / DeepFM mirrors here do; SASRec's item table also feeds gather_dot and must not).
     # Off by default.
+    # Two lookups of one step over the same id tensors and table layout (FeatureEmbedding and LogisticRegression of a
+    # CTR model) sort identical (row, sample) pairs for their backward: the second one copies the first one's result
+    # (rbx_sort_share checks the descriptors) instead of sorting again.
+    share_sorts = os.environ.get("RECBOX_AMD_SHARE_SORTS", "1") != "0"
     reuse_grad_buffers = {"0": False, "": False, "all": "all"}.get(os.environ.get("RECBOX_AMD_REUSE_GRADS", "0"), True)
 
 
@@ -204,6 +208,43 @@ def _side_stream(device):
     return st
 
 
+class _SortMemo(object):
+    """The last id sort enqueued on a device: a snapshot of its descriptors, where its result lives, and the id tensors
+    with their version counters (an in-place write to one of them invalidates the memo)."""
+    __slots__ = ("a", "b", "n", "fm", "ws", "B", "ids", "stream")
+
+
+_sort_memo = {}
+sort_counts = {"sorted": 0, "shared": 0}        # observability: id sorts run / replaced by a copy (tests read it)
+
+
+def _enqueue_sort(desc, keep, B, ws, nbytes, st, sort_call):
+    """Put the id sort described by ``desc`` = (array a, array b or None, n, is_fm) into ``ws`` on stream ``st``:
+    a copy of the last sort's pairs when that one sorted the same lookups on the same stream (rbx_sort_share decides),
+    else ``sort_call()``."""
+    if not config.share_sorts:
+        return sort_call()
+    dev = keep[0].device.index
+    memo = _sort_memo.get(dev)
+    if (memo is not None and memo.B == B and memo.ws is not ws and memo.stream == st.value
+            and all(t._version == v for t, v in memo.ids)):
+        rc = lib.rbx_sort_share(memo.a, memo.b, memo.n, memo.fm, _ptr(memo.ws), desc[0], desc[1], desc[2], desc[3],
+                                _ptr(ws), nbytes, B, st)
+        if rc != _lib.RBX_ERR_UNSUPPORTED:
+            sort_counts["shared"] += 1
+            return rc                          # copied (or a real error); the memo keeps pointing at the original sort
+    sort_counts["sorted"] += 1
+    rc = sort_call()
+    if rc == _lib.RBX_OK:
+        memo = _SortMemo()
+        memo.a = type(desc[0]).from_buffer_copy(desc[0]) if desc[0] is not None else None
+        memo.b = type(desc[1]).from_buffer_copy(desc[1]) if desc[1] is not None else None
+        memo.n, memo.fm, memo.ws, memo.B, memo.stream = desc[2], desc[3], ws, B, st.value
+        memo.ids = [(t, t._version) for t in keep]
+        _sort_memo[dev] = memo
+    return rc
+
+
 class _EarlySort(object):
     """Workspace + completion event of a sort launched from the forward."""
 
@@ -261,8 +302,9 @@ class _EmbedLookup(torch.autograd.Function):
             pool = _GradPool.claim(_EmbedLookup._pool_for(plan, params, dev)
                                    if config.reuse_grad_buffers == "all" else None)
             if ws_bytes > 0 and pool is None:
-                ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_embed_sort(
-                    plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, st))
+                ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: _enqueue_sort(
+                    (plan.arr, None, plan.n, 0), keep, B, ws, ws_bytes, st,
+                    lambda: lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, st)))
             elif ws_bytes > 0:
                 placeholders = [p if p.requires_grad else None for p in params]
 
@@ -273,8 +315,9 @@ class _EmbedLookup(torch.autograd.Function):
                     plan.bind_params(params, placeholders)
                     return rc
 
-                pool.early_sort(ctx, dev, ws_bytes, rezero, lambda ws, nbytes, st: lib.rbx_embed_sort(
-                    plan.arr, plan.n, B, _ptr(ws), nbytes, None, st))
+                pool.early_sort(ctx, dev, ws_bytes, rezero, lambda ws, nbytes, st: _enqueue_sort(
+                    (plan.arr, None, plan.n, 0), keep, B, ws, nbytes, st,
+                    lambda: lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), nbytes, None, st)))
         return out
 
     @staticmethod
@@ -612,8 +655,9 @@ class _FmFused(torch.autograd.Function):
             pool = _GradPool.claim(_FmFused._pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev)
                                    if config.reuse_grad_buffers else None)
             if ws_bytes > 0 and pool is None:
-                ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_fm_sort(
-                    ea, la, lead.n, B, _ptr(ws), ws_bytes, None, st))
+                ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: _enqueue_sort(
+                    (ea, la, lead.n, 1), keep, B, ws, ws_bytes, st,
+                    lambda: lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, st)))
             elif ws_bytes > 0:
                 def rezero(st):
                     rc = _FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st)
@@ -623,8 +667,9 @@ class _FmFused(torch.autograd.Function):
                         lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
                     return rc
 
-                pool.early_sort(ctx, dev, ws_bytes, rezero, lambda ws, nbytes, st: lib.rbx_fm_sort(
-                    ea, la, lead.n, B, _ptr(ws), nbytes, None, st))
+                pool.early_sort(ctx, dev, ws_bytes, rezero, lambda ws, nbytes, st: _enqueue_sort(
+                    (ea, la, lead.n, 1), keep, B, ws, nbytes, st,
+                    lambda: lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), nbytes, None, st)))
         return logit
 
     @staticmethod

@@ -389,6 +389,53 @@ def test_reuse_grad_buffers_all_covers_the_generic_lookup(model_kind):
         ops.config.reuse_grad_buffers = old
 
 
+def test_lookups_over_the_same_ids_share_one_sort():
+    """FeatureEmbedding and LogisticRegression of the layer-composed FM look up the same id columns with the same table
+    layout: the second lookup copies the first one's sorted (row, sample) pairs (rbx_sort_share) -- gradients bit-identical
+    to sorting twice; a lookup over other ids, or after an in-place write to an id tensor, sorts for itself."""
+    from recbox_amd import ops
+    from recbox_amd.ranking.pytorch.models import FM
+    vocabs = [37, 5, 3001, 211, 70000]
+    fm, X, y = _criteo_like(700, vocabs, 16, seed=9, zipf=True)
+    a, b = FM(fm, 16, fused=False).cuda(), FM(fm, 16, fused=False).cuda()
+    with torch.no_grad():
+        for p in a.parameters():
+            p.normal_(0, 0.1)
+    b.load_state_dict(a.state_dict())
+    Xc, yc = _cuda(X), y.cuda()
+    old = ops.config.share_sorts
+    try:
+        ops.config.share_sorts = False
+        _bce_step(a, Xc, yc)
+        ops.config.share_sorts = True
+        before = dict(ops.sort_counts)
+        _bce_step(b, Xc, yc)
+        assert ops.sort_counts["sorted"] - before["sorted"] == 1 and ops.sort_counts["shared"] - before["shared"] == 1
+        for (n, p0), (_, p1) in zip(a.named_parameters(), b.named_parameters()):
+            assert torch.equal(p1.grad, p0.grad), n
+        # other ids in one of the columns between the two lookups' tensors: no sharing, still right
+        # (the memo would also serve a NEW step over the unchanged batch -- same ids, same pairs --, so start clean)
+        ops._sort_memo.clear()
+        before = dict(ops.sort_counts)
+        b.zero_grad(set_to_none=True)
+        emb = b.embedding_layer(Xc)
+        X2 = type(Xc)((k, v.clone()) for k, v in Xc.items())
+        X2["C3"] = X2["C3"].flip(0).contiguous()
+        lr_out = b.fm.lr_layer(X2)
+        (emb.sum() + lr_out.sum()).backward()
+        assert ops.sort_counts["shared"] == before["shared"] and ops.sort_counts["sorted"] - before["sorted"] == 2
+        # an in-place write to an id tensor after the first lookup invalidates the memo
+        ops._sort_memo.clear()
+        before = dict(ops.sort_counts)
+        b.zero_grad(set_to_none=True)
+        emb = b.embedding_layer(Xc)
+        Xc["C1"].copy_(Xc["C1"].flip(0))
+        lr_out = b.fm.lr_layer(Xc)
+        assert ops.sort_counts["shared"] == before["shared"]
+    finally:
+        ops.config.share_sorts = old
+
+
 def test_graphed_step_replays_equal_eager_steps():
     """GraphedStep (whole step in one hipGraph, persistent gradients re-zeroed by row): after refilling the static batch,
     a replay leaves the loss and gradients of the eager step on that batch -- three different batches in a row."""
