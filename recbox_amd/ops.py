@@ -211,10 +211,11 @@ def _side_stream(device):
 class _SortMemo(object):
     """The last id sort enqueued on a device: a snapshot of its descriptors, where its result lives, and the id tensors
     with their version counters (an in-place write to one of them invalidates the memo)."""
-    __slots__ = ("a", "b", "n", "fm", "ws", "B", "ids", "stream")
+    __slots__ = ("a", "b", "n", "fm", "ws", "B", "ids", "stream", "serial", "captured")
 
 
 _sort_memo = {}
+_sort_serial = [0]                                         # counts _enqueue_sort calls
 sort_counts = {"sorted": 0, "shared": 0}        # observability: id sorts run / replaced by a copy (tests read it)
 
 
@@ -226,7 +227,13 @@ def _enqueue_sort(desc, keep, B, ws, nbytes, st, sort_call):
         return sort_call()
     dev = keep[0].device.index
     memo = _sort_memo.get(dev)
-    if (memo is not None and memo.B == B and memo.ws is not ws and memo.stream == st.value
+    _sort_serial[0] += 1
+    capturing = torch.cuda.is_current_stream_capturing()
+    # Inside a stream capture the copy is baked into the graph: it may only come from the sort enqueued JUST before it in
+    # the same capture (FeatureEmbedding, then LogisticRegression).  A memo of an earlier step would be read again on
+    # every replay, whatever the batch then holds.
+    fresh = (memo is not None and memo.captured and memo.serial == _sort_serial[0] - 1) if capturing else True
+    if (memo is not None and fresh and memo.B == B and memo.ws is not ws and memo.stream == st.value
             and all(t._version == v for t, v in memo.ids)):
         rc = lib.rbx_sort_share(memo.a, memo.b, memo.n, memo.fm, _ptr(memo.ws), desc[0], desc[1], desc[2], desc[3],
                                 _ptr(ws), nbytes, B, st)
@@ -241,8 +248,18 @@ def _enqueue_sort(desc, keep, B, ws, nbytes, st, sort_call):
         memo.b = type(desc[1]).from_buffer_copy(desc[1]) if desc[1] is not None else None
         memo.n, memo.fm, memo.ws, memo.B, memo.stream = desc[2], desc[3], ws, B, st.value
         memo.ids = [(t, t._version) for t in keep]
+        memo.serial, memo.captured = _sort_serial[0], capturing
         _sort_memo[dev] = memo
     return rc
+
+
+def _forget_sort(ws):
+    """A backward has consumed the sort in ``ws``: the step is over, the next one sorts afresh (its ids may live in the
+    same tensors with the same version counters only if nothing was written -- but a workspace handed back to the
+    allocator, or replayed by a graph, must not be read through a stale memo)."""
+    for dev, memo in list(_sort_memo.items()):
+        if memo.ws is ws:
+            del _sort_memo[dev]
 
 
 class _EarlySort(object):
@@ -358,6 +375,7 @@ class _EmbedLookup(torch.autograd.Function):
                                 _ptr(ctx.row_scale), 0, _ptr(ws), ws_bytes, _stream()))
         if pool is not None:
             pool.done(B)
+        _forget_sort(ws)
         return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
 
 
@@ -770,6 +788,7 @@ class _FmFused(torch.autograd.Function):
                              _ptr(ws), ws_bytes, _stream()))
         if pool is not None:
             pool.done(B)
+        _forget_sort(ws)
         return result()
 
 

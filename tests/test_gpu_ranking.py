@@ -436,6 +436,42 @@ def test_lookups_over_the_same_ids_share_one_sort():
         ops.config.share_sorts = old
 
 
+@pytest.mark.parametrize("reuse", [False, "all"])
+def test_graphed_layer_path_replays_follow_the_batch(reuse):
+    """The layer-composed FM (two lookups, the second one sharing the first one's id sort) inside a hipGraph: after the
+    static batch is refilled, a replay must sort the NEW ids (a shared copy baked into the graph may only come from the
+    sort captured just before it) -- loss and gradients of the eager step on that batch, three batches in a row."""
+    from recbox_amd import ops
+    from recbox_amd.graph import GraphedStep
+    from recbox_amd.ranking.pytorch.models import FM
+    vocabs = [37, 5, 3001, 211, 70000]
+    fm, X0, y0 = _criteo_like(600, vocabs, 16, seed=70)
+    eager, graphed = FM(fm, 16, fused=False).cuda(), FM(fm, 16, fused=False).cuda()
+    with torch.no_grad():
+        for p in eager.parameters():
+            p.normal_(0, 0.1)
+    graphed.load_state_dict(eager.state_dict())
+    Xs, ys = _cuda(X0), y0.cuda()
+    old = (ops.config.check_ids, ops.config.reuse_grad_buffers)
+    ops.config.check_ids = False
+    try:
+        step = GraphedStep(lambda: _bce_step(graphed, Xs, ys), warmup=3, reuse_grads=reuse)
+        for k in range(3):
+            _, X, y = _criteo_like(600, vocabs, 16, seed=71 + k, zipf=(k == 1))
+            for n in Xs:
+                Xs[n].copy_(X[n])
+            ys.copy_(y)
+            loss = step()
+            ops.config.reuse_grad_buffers = False
+            want = _bce_step(eager, _cuda(X), y.cuda())
+            torch.cuda.synchronize()
+            assert_close(loss.reshape(1), want.reshape(1), 1e-6, "loss")
+            for (n, p0), (_, p1) in zip(eager.named_parameters(), graphed.named_parameters()):
+                assert torch.equal(p1.grad, p0.grad), "replay %d: %s" % (k, n)
+    finally:
+        ops.config.check_ids, ops.config.reuse_grad_buffers = old
+
+
 def test_graphed_step_replays_equal_eager_steps():
     """GraphedStep (whole step in one hipGraph, persistent gradients re-zeroed by row): after refilling the static batch,
     a replay leaves the loss and gradients of the eager step on that batch -- three different batches in a row."""
