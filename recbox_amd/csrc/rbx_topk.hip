@@ -28,6 +28,9 @@ __device__ __forceinline__ unsigned key_of(float v) {
   const unsigned u = __float_as_uint(v);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // larger float <=> larger key
 }
+__device__ __forceinline__ unsigned long long pack_winner(unsigned key, long long index) {
+  return (static_cast<unsigned long long>(key) << 32) | static_cast<unsigned>(~static_cast<unsigned>(index));
+}
 __device__ __forceinline__ float value_of(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
@@ -40,8 +43,9 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
                                                    const int nseg, const int K, float* __restrict__ out_vals,
                                                    long long* __restrict__ out_idx) {
   __shared__ unsigned s_hist[256];
-  __shared__ unsigned s_key[kTopkMaxK];
-  __shared__ long long s_idx[kTopkMaxK];
+  // a winner = (key << 32) | ~index: ONE 64-bit word per element, so that the sort compares and swaps single words
+  // (larger key first, then the smaller index; 0 = empty slot, sinks to the end).  Indices are < 2^32 - 1 (checked).
+  __shared__ unsigned long long s_win[kTopkMaxK];
   __shared__ unsigned s_prefix, s_remaining, s_count, s_eq_base;
   __shared__ unsigned s_wave[4];
   const long long u = blockIdx.x / nseg;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
   // ---- collect: everything above T, then need_eq elements equal to T --------------------------------------
   __shared__ unsigned s_eq_total;
   if (tid == 0) { s_count = 0u; s_eq_base = 0u; s_eq_total = 0u; }
-  for (int i = tid; i < kTopkMaxK; i += 256) { s_key[i] = 0u; s_idx[i] = -1; }
+  for (int i = tid; i < kTopkMaxK; i += 256) s_win[i] = 0ull;
   __syncthreads();
   if (want > 0) {
     unsigned eq_mine = 0u;
@@ -104,8 +108,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
       const unsigned k = s_row[i];
       if (k > T) {
         const unsigned slot = atomicAdd(&s_count, 1u);        // order is irrelevant: the sort fixes it
-        s_key[slot] = k;
-        s_idx[slot] = irow != nullptr ? irow[i] : first + i;
+        s_win[slot] = pack_winner(k, irow != nullptr ? irow[i] : first + i);
       }
       eq_mine += (k == T) ? 1u : 0u;
     }
@@ -117,8 +120,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
     for (int i = tid; i < len; i += 256) {
       if (s_row[i] == T) {
         const unsigned slot = atomicAdd(&s_count, 1u);
-        s_key[slot] = T;
-        s_idx[slot] = irow != nullptr ? irow[i] : first + i;
+        s_win[slot] = pack_winner(T, irow != nullptr ? irow[i] : first + i);
       }
     }
   } else if (want > 0) {                                     // ties: the lowest indices win, so walk in index order
@@ -135,8 +137,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
         for (int w = 0; w < wave; ++w) rank += s_wave[w];
         if (rank < need_eq) {
           const unsigned slot = atomicAdd(&s_count, 1u);
-          s_key[slot] = T;
-          s_idx[slot] = irow != nullptr ? irow[i] : first + i;
+          s_win[slot] = pack_winner(T, irow != nullptr ? irow[i] : first + i);
         }
       }
       __syncthreads();
@@ -155,14 +156,10 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
         const int lo = 2 * t - (t & (stride - 1));
         const int hi = lo + stride;
         const bool up = (lo & size) == 0;                   // "up" blocks end with the better element first
-        const unsigned ka = s_key[lo], kb = s_key[hi];
-        const long long ia = s_idx[lo], ib = s_idx[hi];
-        // a is better than b: real before empty, larger key first, then the smaller index
-        const bool a_empty = ia < 0, b_empty = ib < 0;
-        const bool a_first = a_empty != b_empty ? b_empty : (ka != kb ? ka > kb : ia <= ib);
-        if (a_first != up) {
-          s_key[lo] = kb; s_key[hi] = ka;
-          s_idx[lo] = ib; s_idx[hi] = ia;
+        const unsigned long long a = s_win[lo], b = s_win[hi];
+        if ((a >= b) != up) {                               // a is better than b when its word is larger
+          s_win[lo] = b;
+          s_win[hi] = a;
         }
       }
     }
@@ -171,9 +168,9 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
   float* ov = out_vals + static_cast<long long>(blockIdx.x) * K;
   long long* oi = out_idx + static_cast<long long>(blockIdx.x) * K;
   for (int t = tid; t < K; t += 256) {
-    const bool empty = s_idx[t] < 0;
-    ov[t] = empty ? -3.402823466e+38f : value_of(s_key[t]);
-    oi[t] = s_idx[t];
+    const unsigned long long w = s_win[t];
+    ov[t] = w == 0ull ? -3.402823466e+38f : value_of(static_cast<unsigned>(w >> 32));
+    oi[t] = w == 0ull ? -1ll : static_cast<long long>(~static_cast<unsigned>(w) );
   }
 }
 
@@ -231,6 +228,7 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
   if (d_out_scores == nullptr || d_out_index == nullptr) return fail(RBX_ERR_INVALID, "topk: NULL output");
   if (n > 0 && d_scores == nullptr) return fail(RBX_ERR_INVALID, "topk: d_scores is NULL");
   if (row_stride < n) return fail(RBX_ERR_INVALID, "topk: row_stride < n");
+  if (n >= 0xFFFFFFFFll) return fail(RBX_ERR_UNSUPPORTED, "topk: rows of 2^32 - 1 scores or more are not supported");
   int nseg = n > 0 ? topk_nseg(n) : 1;
   if (rows * static_cast<long long>(nseg) >= INT_MAX) return fail(RBX_ERR_UNSUPPORTED, "topk: too many rows");
   hipStream_t s = as_stream(stream);
