@@ -36,12 +36,14 @@ __device__ __forceinline__ float value_of(unsigned k) {
 }
 
 // One workgroup per (query, segment).  vals: query u at vals + u * row_stride; the segment covers elements
-// [s * seg, min(n, (s+1) * seg)).  idx_in == nullptr: the index of an element is its position in the row.
+// [s * seg, min(n, (s+1) * seg)).  idx_in == nullptr: the index of an element is its position in the row; otherwise
+// idx_in holds the row positions of a previous level's survivors.
 // Output slot (u * nseg + s) * K .. + K: the segment's top K (padded with -FLT_MAX / -1 when it is shorter).
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ vals, const long long* __restrict__ idx_in,
                                                    const long long row_stride, const long long n, const int seg,
                                                    const int nseg, const int K, float* __restrict__ out_vals,
-                                                   long long* __restrict__ out_idx) {
+                                                   long long* __restrict__ out_idx,
+                                                   const long long* __restrict__ remap, const long long remap_stride) {
   __shared__ unsigned s_hist[256];
   // a winner = (key << 32) | ~index: ONE 64-bit word per element, so that the sort compares and swaps single words
   // (larger key first, then the smaller index; 0 = empty slot, sinks to the end).  Indices are < 2^32 - 1 (checked).
@@ -170,7 +172,10 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
   for (int t = tid; t < K; t += 256) {
     const unsigned long long w = s_win[t];
     ov[t] = w == 0ull ? -3.402823466e+38f : value_of(static_cast<unsigned>(w >> 32));
-    oi[t] = w == 0ull ? -1ll : static_cast<long long>(~static_cast<unsigned>(w) );
+    // inside the kernel an element is named by its POSITION in the row (< 2^32 - 1); caller-supplied 64-bit ids are
+    // looked up only here, by the launch that writes the final result
+    const long long pos = static_cast<long long>(~static_cast<unsigned>(w));
+    oi[t] = w == 0ull ? -1ll : (remap != nullptr ? remap[u * remap_stride + pos] : pos);
   }
 }
 
@@ -237,7 +242,7 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
     return fail(RBX_ERR_WORKSPACE, "topk: workspace too small");
   const size_t half = nseg > 1 ? rbx_topk_workspace_size(rows, n, k) / 2 : 0;
   const float* vals = d_scores;
-  const long long* idx = reinterpret_cast<const long long*>(d_index);
+  const long long* idx = nullptr;                             // level 1 names elements by their position in the row
   long long stride = row_stride, len = n;
   int level = 0;
   while (nseg > 1) {                                          // every level keeps k survivors per segment
@@ -246,7 +251,7 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
     long long* cidx = reinterpret_cast<long long*>(buf);
     float* cval = reinterpret_cast<float*>(cidx + rows * cand);
     hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows * nseg)), dim3(256), 0, s, vals, idx, stride, len,
-                       kTopkSeg, nseg, k, cval, cidx);
+                       kTopkSeg, nseg, k, cval, cidx, static_cast<const long long*>(nullptr), 0ll);
     vals = cval;
     idx = cidx;
     stride = len = cand;
@@ -255,7 +260,7 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
     if (k >= kTopkSeg) return fail(RBX_ERR_UNSUPPORTED, "topk: k too large for the segment size");
   }
   hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, vals, idx, stride, len, kTopkSeg, 1, k,
-                     d_out_scores, oidx);
+                     d_out_scores, oidx, reinterpret_cast<const long long*>(d_index), static_cast<long long>(row_stride));
   return check_launch("topk_kernel");
 }
 

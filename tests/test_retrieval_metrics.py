@@ -56,7 +56,7 @@ def test_topk_equals_full_sort(rows, n, k):
     assert torch.equal(vals[:, :kk].cpu(), order.values[:, :kk])
     if kk < k:
         assert bool((idx[:, kk:] == -1).all()) and bool((vals[:, kk:] < -3e38).all())
-    remap = torch.randint(0, 10 ** 9, (rows, n), generator=g)
+    remap = torch.randint(0, 2 ** 40, (rows, n), generator=g)          # caller-side ids are full 64-bit values
     _, idx2 = ops.topk(s.cuda(), min(k, 64), index=remap.cuda())
     if len(torch.unique(s)) == s.numel():                            # without ties the remapped ids follow the same order
         assert torch.equal(idx2.cpu()[:, :min(kk, 64)], torch.gather(remap, 1, order.indices[:, :min(kk, 64)]))
