@@ -43,12 +43,13 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
                                                    const long long row_stride, const long long n, const int seg,
                                                    const int nseg, const int K, float* __restrict__ out_vals,
                                                    long long* __restrict__ out_idx,
-                                                   const long long* __restrict__ remap, const long long remap_stride) {
+                                                   const long long* __restrict__ remap, const long long remap_stride,
+                                                   const bool do_sort) {
   __shared__ unsigned s_hist[256];
   // a winner = (key << 32) | ~index: ONE 64-bit word per element, so that the sort compares and swaps single words
   // (larger key first, then the smaller index; 0 = empty slot, sinks to the end).  Indices are < 2^32 - 1 (checked).
   __shared__ unsigned long long s_win[kTopkMaxK];
-  __shared__ unsigned s_prefix, s_remaining, s_count, s_eq_base;
+  __shared__ unsigned s_prefix, s_remaining, s_count, s_bin_count;
   __shared__ unsigned s_wave[4];
   const long long u = blockIdx.x / nseg;
   const int s = static_cast<int>(blockIdx.x - u * nseg);
@@ -61,97 +62,82 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
   __shared__ unsigned s_row[kTopkSeg];
   for (int i = tid; i < len; i += 256) s_row[i] = key_of(row[i]);     // the only pass over HBM
 
-  // ---- radix select: key of the want-th largest element ----------------------------------------------
-  if (tid == 0) { s_prefix = 0u; s_remaining = static_cast<unsigned>(want); }
-  unsigned mask = 0u;
-  for (int shift = 24; shift >= 0 && want > 0; shift -= 8) {
+  // ---- radix select on the 64-bit word (key << 32 | ~position): 4 passes over the keys find the key T of the want-th
+  // largest element; if more elements equal T than places are left, 4 more passes over THOSE elements' ~position find
+  // which of them win (the lowest positions).  All words are distinct, so the winners are a set that does not depend
+  // on the order the elements are visited in: the levels need no common order between them.
+  auto position_of = [&](int i) -> long long { return irow != nullptr ? irow[i] : first + i; };
+  auto radix_pass = [&](const int shift, const bool on_pos, const unsigned key_T) {
+    // histogram of one digit over the elements still in play; thread t then owns bin t
     s_hist[tid] = 0u;
     __syncthreads();
     const unsigned prefix = s_prefix;
+    const unsigned mask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
     for (int i = tid; i < len; i += 256) {
       const unsigned k = s_row[i];
-      if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+      if (!on_pos) {
+        if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+      } else if (k == key_T) {
+        const unsigned q = ~static_cast<unsigned>(position_of(i));
+        if ((q & mask) == prefix) atomicAdd(&s_hist[(q >> shift) & 255u], 1u);
+      }
     }
     __syncthreads();
-    {
-      // parallel suffix sum over the 256 bins (thread t owns bin t): above = elements in bins > t
-      const unsigned v = s_hist[tid];
-      const int ln = tid & 63, wv = tid >> 6;
-      unsigned incl = v;
+    const unsigned v = s_hist[tid];
+    const int ln = tid & 63, wv = tid >> 6;
+    unsigned incl = v;                                       // suffix sum inside the wave: elements in bins >= t
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned dn = __shfl_down(incl, o, 64);
-        if (ln + o < 64) incl += dn;
-      }
-      if (ln == 0) s_wave[wv] = incl;
-      const unsigned rem = s_remaining;
-      __syncthreads();
-      unsigned above = incl - v;
-      for (int w = wv + 1; w < 4; ++w) above += s_wave[w];
-      if (above < rem && above + v >= rem) {                  // exactly one bin holds the rem-th largest
-        s_remaining = rem - above;
-        s_prefix = prefix | (static_cast<unsigned>(tid) << shift);
-      }
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned dn = __shfl_down(incl, o, 64);
+      if (ln + o < 64) incl += dn;
     }
-    mask |= 255u << shift;
+    if (ln == 0) s_wave[wv] = incl;
+    const unsigned rem = s_remaining;
     __syncthreads();
+    unsigned above = incl - v;
+    for (int w = wv + 1; w < 4; ++w) above += s_wave[w];
+    if (above < rem && above + v >= rem) {                   // exactly one bin holds the rem-th largest
+      s_remaining = rem - above;
+      s_prefix = prefix | (static_cast<unsigned>(tid) << shift);
+      s_bin_count = v;
+    }
+    __syncthreads();
+  };
+  if (tid == 0) { s_prefix = 0u; s_remaining = static_cast<unsigned>(want); s_bin_count = 0u; }
+  __syncthreads();
+  unsigned T = 0u, T2 = 0u;
+  bool tie = false;
+  if (want > 0) {
+    for (int shift = 24; shift >= 0; shift -= 8) radix_pass(shift, false, 0u);
+    T = s_prefix;                                            // exact key of the want-th largest
+    tie = s_bin_count > s_remaining;                         // more elements equal to T than places left
+    __syncthreads();
+    if (tie) {
+      if (tid == 0) s_prefix = 0u;                           // s_remaining = places left among the elements equal to T
+      __syncthreads();
+      for (int shift = 24; shift >= 0; shift -= 8) radix_pass(shift, true, T);
+      T2 = s_prefix;                                         // ~position of the last winner among them
+    }
   }
-  const unsigned T = s_prefix;                               // exact key of the want-th largest
-  const unsigned need_eq = s_remaining;                      // how many elements equal to T are taken (lowest indices)
 
-  // ---- collect: everything above T, then need_eq elements equal to T --------------------------------------
-  __shared__ unsigned s_eq_total;
-  if (tid == 0) { s_count = 0u; s_eq_base = 0u; s_eq_total = 0u; }
+  // ---- collect the winners (any order) ---------------------------------------------------------------------
+  if (tid == 0) s_count = 0u;
   for (int i = tid; i < kTopkMaxK; i += 256) s_win[i] = 0ull;
   __syncthreads();
   if (want > 0) {
-    unsigned eq_mine = 0u;
     for (int i = tid; i < len; i += 256) {
       const unsigned k = s_row[i];
-      if (k > T) {
-        const unsigned slot = atomicAdd(&s_count, 1u);        // order is irrelevant: the sort fixes it
-        s_win[slot] = pack_winner(k, irow != nullptr ? irow[i] : first + i);
-      }
-      eq_mine += (k == T) ? 1u : 0u;
-    }
-    if (eq_mine) atomicAdd(&s_eq_total, eq_mine);
-  }
-  __syncthreads();
-  const bool tie = s_eq_total > need_eq;                     // more candidates at the threshold than places left
-  if (want > 0 && !tie) {
-    for (int i = tid; i < len; i += 256) {
-      if (s_row[i] == T) {
-        const unsigned slot = atomicAdd(&s_count, 1u);
-        s_win[slot] = pack_winner(T, irow != nullptr ? irow[i] : first + i);
-      }
-    }
-  } else if (want > 0) {                                     // ties: the lowest indices win, so walk in index order
-    const int lane = tid & 63, wave = tid >> 6;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int i0 = 0; i0 < len; i0 += 256) {
-      const int i = i0 + tid;
-      const bool eq = i < len && s_row[i] == T;
-      const unsigned long long m = __ballot(eq);
-      if (lane == 0) s_wave[wave] = __popcll(m);
-      __syncthreads();
-      if (eq) {
-        unsigned rank = s_eq_base + __popcll(m & below);
-        for (int w = 0; w < wave; ++w) rank += s_wave[w];
-        if (rank < need_eq) {
-          const unsigned slot = atomicAdd(&s_count, 1u);
-          s_win[slot] = pack_winner(T, irow != nullptr ? irow[i] : first + i);
-        }
-      }
-      __syncthreads();
-      if (tid == 0) s_eq_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-      __syncthreads();
+      if (k < T) continue;
+      const long long pos = position_of(i);
+      if (k > T || !tie || ~static_cast<unsigned>(pos) >= T2) s_win[atomicAdd(&s_count, 1u)] = pack_winner(k, pos);
     }
   }
 
-  // ---- bitonic sort of the winners: (key descending, index ascending); empty slots (key 0, idx -1) sink ----
+  // ---- bitonic sort of the winners, final level only: larger word first = (key descending, position ascending);
+  // empty slots (0) sink.  The levels before it hand their winners on unsorted.
   int P = 1;
   while (P < K) P <<= 1;
-  for (int size = 2; size <= P; size <<= 1) {
+  for (int size = 2; do_sort && size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       __syncthreads();
       for (int t = tid; t < P / 2; t += 256) {
@@ -251,7 +237,7 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
     long long* cidx = reinterpret_cast<long long*>(buf);
     float* cval = reinterpret_cast<float*>(cidx + rows * cand);
     hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows * nseg)), dim3(256), 0, s, vals, idx, stride, len,
-                       kTopkSeg, nseg, k, cval, cidx, static_cast<const long long*>(nullptr), 0ll);
+                       kTopkSeg, nseg, k, cval, cidx, static_cast<const long long*>(nullptr), 0ll, false);
     vals = cval;
     idx = cidx;
     stride = len = cand;
@@ -260,7 +246,7 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
     if (k >= kTopkSeg) return fail(RBX_ERR_UNSUPPORTED, "topk: k too large for the segment size");
   }
   hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, vals, idx, stride, len, kTopkSeg, 1, k,
-                     d_out_scores, oidx, reinterpret_cast<const long long*>(d_index), static_cast<long long>(row_stride));
+                     d_out_scores, oidx, reinterpret_cast<const long long*>(d_index), static_cast<long long>(row_stride), true);
   return check_launch("topk_kernel");
 }
 

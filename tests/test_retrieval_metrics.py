@@ -63,6 +63,22 @@ def test_topk_equals_full_sort(rows, n, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(70000, 500), (8192, 1024), (100, 7), (20000, 1)])
+def test_topk_with_massive_ties(n, k):
+    """Degenerate score rows -- all equal, three distinct values, one value with a few larger ones -- over one and
+    several selection levels: the winners are the lowest columns among the equal scores, as a stable sort gives them."""
+    from recbox_amd import ops
+    rows = torch.stack([torch.zeros(n), (torch.arange(n) % 3).float(), torch.ones(n)])
+    rows[2, n // 2] = 5.0
+    rows[2, n - 1] = 4.0
+    vals, idx = ops.topk(rows.cuda(), k)
+    order = torch.sort(rows, dim=1, descending=True, stable=True)
+    kk = min(k, n)
+    assert torch.equal(idx[:, :kk].cpu(), order.indices[:, :kk])
+    assert torch.equal(vals[:, :kk].cpu(), order.values[:, :kk])
+
+
+@pytest.mark.gpu
 def test_membership_and_penalty():
     from recbox_amd import ops
     g = np.random.RandomState(2)
