@@ -314,8 +314,9 @@ int rbx_gather_rows(const rbx_rowcopy_t* cols, int32_t n_cols, const int64_t* d_
  * rbx_topk: for every row the k (<= 1024) largest of d_scores[r, 0..n) sorted by (score descending, column
  * ascending -- ties are deterministic, the reference leaves them to faiss/numpy); d_index (optional, same
  * layout as d_scores, any int64 values) supplies the id reported for each column, otherwise the column itself.
- * n < 2^32 - 1.  Rows shorter than k are padded with (-FLT_MAX, -1) like faiss.  Long rows are selected in
- * several levels (workspace).
+ * n < 2^32 - 1.  Rows shorter than k are padded with (-FLT_MAX, -1) like faiss.  Rows longer than 16 384 scores
+ * (workspace): a threshold estimated from 8 192 samples of the row, one filtering sweep, exact selection among the
+ * candidates; rows the estimate cannot serve fall back, on the device, to an exact selection in several levels.
  * rbx_penalize_members: scores[r, j] = (float)((double)scores[r, j] + penalty) where candidates[r, j] is in the
  * sorted CSR list offsets/items of query d_query[r]  (mask train items: "scores += -1e9 * mask").
  * rbx_membership: flags[r, j] = candidates[r, j] in the list of d_query[r]  (hits against valid_user2items). */

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
                                                    const int nseg, const int K, float* __restrict__ out_vals,
                                                    long long* __restrict__ out_idx,
                                                    const long long* __restrict__ remap, const long long remap_stride,
-                                                   const bool do_sort) {
+                                                   const bool do_sort, const unsigned* __restrict__ row_len,
+                                                   const int* __restrict__ row_state, const int run_state,
+                                                   const long long sample_stride, unsigned* __restrict__ thr_out) {
   __shared__ unsigned s_hist[256];
   // a winner = (key << 32) | ~index: ONE 64-bit word per element, so that the sort compares and swaps single words
   // (larger key first, then the smaller index; 0 = empty slot, sinks to the end).  Indices are < 2^32 - 1 (checked).
@@ -52,15 +54,17 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
   __shared__ unsigned s_prefix, s_remaining, s_count, s_bin_count;
   __shared__ unsigned s_wave[4];
   const long long u = blockIdx.x / nseg;
+  if (row_state != nullptr && row_state[u] != run_state) return;   // this row is served by the other path
   const int s = static_cast<int>(blockIdx.x - u * nseg);
   const long long first = static_cast<long long>(s) * seg;
-  const int len = static_cast<int>((n - first < seg) ? (n - first) : seg);
+  const long long n_row = row_len != nullptr ? (static_cast<long long>(row_len[u]) < n ? row_len[u] : n) : n;
+  const int len = static_cast<int>((n_row - first < seg) ? (n_row - first > 0 ? n_row - first : 0) : seg);
   const float* row = vals + u * row_stride + first;
   const long long* irow = idx_in != nullptr ? idx_in + u * row_stride + first : nullptr;
   const int want = (K < len) ? K : len;
   const int tid = threadIdx.x;
   __shared__ unsigned s_row[kTopkSeg];
-  for (int i = tid; i < len; i += 256) s_row[i] = key_of(row[i]);     // the only pass over HBM
+  for (int i = tid; i < len; i += 256) s_row[i] = key_of(row[i * sample_stride]);     // the only pass over HBM
 
   // ---- radix select on the 64-bit word (key << 32 | ~position): 4 passes over the keys find the key T of the want-th
   // largest element; if more elements equal T than places are left, 4 more passes over THOSE elements' ~position find
@@ -110,6 +114,10 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ val
   if (want > 0) {
     for (int shift = 24; shift >= 0; shift -= 8) radix_pass(shift, false, 0u);
     T = s_prefix;                                            // exact key of the want-th largest
+    if (thr_out != nullptr) {                                // threshold estimation on a sample: that is all
+      if (tid == 0) thr_out[u] = T;
+      return;
+    }
     tie = s_bin_count > s_remaining;                         // more elements equal to T than places left
     __syncthreads();
     if (tie) {
@@ -196,7 +204,86 @@ __global__ __launch_bounds__(256) void membership_kernel(const long long* __rest
   }
 }
 
+// ---- fast path for long rows -------------------------------------------------------------------------------
+// A threshold estimated from a strided sample of the row (topk_kernel in its thr_out mode: the key of the r-th largest
+// of 8 192 samples, r chosen so that ~4k + a margin elements of the row are expected above it) turns the first,
+// dominant level into ONE streaming sweep that keeps the elements >= threshold: kTopkCand slots per row.  The exact
+// selection then runs on those candidates.  A row whose candidates are fewer than k, or do not fit (ties, a skewed
+// sample), is flagged and served by the exact multi-level path instead -- both paths check the flag on the device.
+constexpr int kTopkCand = kTopkSeg;          // candidate slots per row (one segment of the final selection)
+constexpr int kTopkStage = 512;              // candidates one workgroup can hand over from its 8 192 scores
+
+__global__ __launch_bounds__(256) void topk_filter_kernel(const float* __restrict__ vals, const long long row_stride,
+                                                          const long long n, const int seg, const int nseg,
+                                                          const unsigned* __restrict__ thr, unsigned* __restrict__ cnt,
+                                                          unsigned* __restrict__ fail, float* __restrict__ cand_vals,
+                                                          long long* __restrict__ cand_pos) {
+  __shared__ float s_val[kTopkStage];
+  __shared__ unsigned s_pos[kTopkStage];
+  __shared__ unsigned s_n, s_base;
+  const long long u = blockIdx.x / nseg;
+  const int s = static_cast<int>(blockIdx.x - u * nseg);
+  const long long first = static_cast<long long>(s) * seg;
+  const int len = static_cast<int>((n - first < seg) ? (n - first) : seg);
+  const float* row = vals + u * row_stride + first;
+  const unsigned T = thr[u];
+  if (threadIdx.x == 0) s_n = 0u;
+  __syncthreads();
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const float v = row[i];
+    if (key_of(v) >= T) {
+      const unsigned slot = atomicAdd(&s_n, 1u);
+      if (slot < static_cast<unsigned>(kTopkStage)) {
+        s_val[slot] = v;
+        s_pos[slot] = static_cast<unsigned>(first + i);
+      }
+    }
+  }
+  __syncthreads();
+  const unsigned mine = s_n;
+  if (mine == 0u) return;
+  if (threadIdx.x == 0) {
+    unsigned base = 0xFFFFFFFFu;
+    if (mine > static_cast<unsigned>(kTopkStage)) atomicOr(&fail[u], 1u);
+    else base = atomicAdd(&cnt[u], mine);
+    if (base != 0xFFFFFFFFu && base + mine > static_cast<unsigned>(kTopkCand)) {
+      atomicOr(&fail[u], 1u);
+      base = 0xFFFFFFFFu;
+    }
+    s_base = base;
+  }
+  __syncthreads();
+  const unsigned base = s_base;
+  if (base == 0xFFFFFFFFu) return;
+  for (unsigned j = threadIdx.x; j < mine; j += 256) {
+    cand_vals[u * kTopkCand + base + j] = s_val[j];
+    cand_pos[u * kTopkCand + base + j] = static_cast<long long>(s_pos[j]);
+  }
+}
+
+// state[u] = 1 when the fast path has everything it needs for row u, else 0 (the exact path takes the row)
+__global__ __launch_bounds__(256) void topk_state_kernel(const unsigned* __restrict__ cnt, const unsigned* __restrict__ fail,
+                                                         const long long rows, const unsigned need, int* __restrict__ state) {
+  const long long u = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u < rows) state[u] = (fail[u] == 0u && cnt[u] >= need && cnt[u] <= static_cast<unsigned>(kTopkCand)) ? 1 : 0;
+}
+
 static int topk_nseg(long long n) { return static_cast<int>((n + kTopkSeg - 1) / kTopkSeg); }
+
+// sample rank for the threshold estimate, or 0 when the fast path does not apply (short rows, k not selective)
+static int topk_sample_rank(long long n, int k, long long* m_out, long long* stride_out) {
+  if (n <= 2ll * kTopkSeg) return 0;
+  const long long m = kTopkSeg, stride = n / m;
+  const long long r = (4ll * k * m + n - 1) / n + 8;
+  *m_out = m;
+  *stride_out = stride;
+  return (r < m / 4) ? static_cast<int>(r) : 0;
+}
+
+static size_t topk_fast_bytes(long long rows) {
+  return static_cast<size_t>(rows) * (3 * sizeof(unsigned) + sizeof(int)) + 256 +
+         static_cast<size_t>(rows) * kTopkCand * (sizeof(float) + sizeof(long long)) + 256;
+}
 
 }  // namespace rbx
 
@@ -206,7 +293,8 @@ extern "C" size_t rbx_topk_workspace_size(int64_t rows, int64_t n, int32_t k) {
   if (nseg <= 1) return 0;
   // two survivor buffers (levels ping-pong between them); the first level is the largest
   const size_t level = static_cast<size_t>(rows) * nseg * k * (sizeof(float) + sizeof(int64_t)) + 256;
-  return 2 * level;
+  long long m, stride;
+  return 2 * level + (rbx::topk_sample_rank(n, k, &m, &stride) > 0 ? rbx::topk_fast_bytes(rows) : 0);
 }
 
 extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t rows, int64_t n, int64_t row_stride,
@@ -226,7 +314,48 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
   long long* oidx = reinterpret_cast<long long*>(d_out_index);
   if (nseg > 1 && (d_workspace == nullptr || workspace_bytes < rbx_topk_workspace_size(rows, n, k)))
     return fail(RBX_ERR_WORKSPACE, "topk: workspace too small");
-  const size_t half = nseg > 1 ? rbx_topk_workspace_size(rows, n, k) / 2 : 0;
+  const size_t level_bytes = nseg > 1 ? static_cast<size_t>(rows) * nseg * k * (sizeof(float) + sizeof(int64_t)) + 256 : 0;
+  const size_t half = level_bytes;
+  const unsigned* no_len = nullptr;
+  unsigned* no_thr = nullptr;
+
+  // ---- fast path: sample threshold -> one filtering sweep -> exact selection among the candidates ------------
+  long long m = 0, sstride = 1;
+  const int rank = (nseg > 1) ? topk_sample_rank(n, k, &m, &sstride) : 0;
+  int* state = nullptr;
+  if (rank > 0) {
+    char* fast = static_cast<char*>(d_workspace) + 2 * level_bytes;
+    unsigned* thr = reinterpret_cast<unsigned*>(fast);
+    unsigned* cnt = thr + rows;
+    unsigned* failed = cnt + rows;
+    state = reinterpret_cast<int*>(failed + rows);
+    char* cbase = fast + ((static_cast<size_t>(rows) * (3 * sizeof(unsigned) + sizeof(int)) + 255) / 256) * 256;
+    long long* cpos = reinterpret_cast<long long*>(cbase);
+    float* cval = reinterpret_cast<float*>(cpos + rows * kTopkCand);
+    if (hipMemsetAsync(cnt, 0, static_cast<size_t>(rows) * 2 * sizeof(unsigned), s) != hipSuccess)
+      return fail(RBX_ERR_LAUNCH, "topk: memset of the candidate counters failed");
+    // (1) threshold = key of the rank-th largest of m strided samples of the row
+    hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, d_scores,
+                       static_cast<const long long*>(nullptr), static_cast<long long>(row_stride), m, kTopkSeg, 1, rank,
+                       static_cast<float*>(nullptr), static_cast<long long*>(nullptr), static_cast<const long long*>(nullptr),
+                       0ll, false, no_len, static_cast<const int*>(nullptr), 0, sstride, thr);
+    // (2) one sweep over the scores keeps what is >= threshold
+    hipLaunchKernelGGL(topk_filter_kernel, dim3(static_cast<unsigned>(rows * nseg)), dim3(256), 0, s, d_scores,
+                       static_cast<long long>(row_stride), static_cast<long long>(n), kTopkSeg, nseg, thr, cnt, failed, cval,
+                       cpos);
+    // (3) which rows have what they need
+    hipLaunchKernelGGL(topk_state_kernel, dim3(static_cast<unsigned>((rows + 255) / 256)), dim3(256), 0, s, cnt, failed,
+                       static_cast<long long>(rows), static_cast<unsigned>(k), state);
+    // (4) exact selection + sort among the candidates of those rows
+    hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, cval, cpos,
+                       static_cast<long long>(kTopkCand), static_cast<long long>(kTopkCand), kTopkSeg, 1, k, d_out_scores, oidx,
+                       reinterpret_cast<const long long*>(d_index), static_cast<long long>(row_stride), true, cnt, state, 1, 1ll,
+                       no_thr);
+    int rc = check_launch("topk fast path");
+    if (rc != RBX_OK) return rc;
+  }
+
+  // ---- exact multi-level path: every row without the fast path, or the rows it had to give up ------------------
   const float* vals = d_scores;
   const long long* idx = nullptr;                             // level 1 names elements by their position in the row
   long long stride = row_stride, len = n;
@@ -237,7 +366,8 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
     long long* cidx = reinterpret_cast<long long*>(buf);
     float* cval = reinterpret_cast<float*>(cidx + rows * cand);
     hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows * nseg)), dim3(256), 0, s, vals, idx, stride, len,
-                       kTopkSeg, nseg, k, cval, cidx, static_cast<const long long*>(nullptr), 0ll, false);
+                       kTopkSeg, nseg, k, cval, cidx, static_cast<const long long*>(nullptr), 0ll, false, no_len, state, 0, 1ll,
+                       no_thr);
     vals = cval;
     idx = cidx;
     stride = len = cand;
@@ -246,7 +376,8 @@ extern "C" int rbx_topk(const float* d_scores, const int64_t* d_index, int64_t r
     if (k >= kTopkSeg) return fail(RBX_ERR_UNSUPPORTED, "topk: k too large for the segment size");
   }
   hipLaunchKernelGGL(topk_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, s, vals, idx, stride, len, kTopkSeg, 1, k,
-                     d_out_scores, oidx, reinterpret_cast<const long long*>(d_index), static_cast<long long>(row_stride), true);
+                     d_out_scores, oidx, reinterpret_cast<const long long*>(d_index), static_cast<long long>(row_stride), true,
+                     no_len, state, 0, 1ll, no_thr);
   return check_launch("topk_kernel");
 }
 

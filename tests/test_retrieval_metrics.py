@@ -63,6 +63,30 @@ def test_topk_equals_full_sort(rows, n, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(70000, 500), (300000, 64), (20000, 1000)])
+def test_topk_long_rows_fast_and_exact_paths_side_by_side(n, k):
+    """Long rows take the sampled-threshold path (one filtering sweep, exact selection among the candidates); rows it
+    cannot serve -- constant rows, rows whose top values all sit in one 8 192-score segment, rows with fewer distinct
+    large values than the sample suggests -- fall back to the exact multi-level path on the device.  Both kinds in one
+    call, each row equal to a stable full sort."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(n)
+    rows = [torch.randn(n, generator=g), torch.zeros(n), torch.randn(n, generator=g) * 1e-3]
+    spike = torch.zeros(n)
+    spike[5000:5000 + 2 * k] = torch.rand(2 * k, generator=g) + 1.0          # every winner inside one segment
+    rows.append(spike)
+    heavy = torch.randn(n, generator=g)
+    heavy[::2] = heavy[0]                                                    # half the row is one value
+    rows.append(heavy)
+    rows.append(-torch.rand(n, generator=g))
+    s = torch.stack(rows)
+    vals, idx = ops.topk(s.cuda(), k)
+    order = torch.sort(s, dim=1, descending=True, stable=True)
+    assert torch.equal(idx.cpu(), order.indices[:, :k])
+    assert torch.equal(vals.cpu(), order.values[:, :k])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,k", [(70000, 500), (8192, 1024), (100, 7), (20000, 1)])
 def test_topk_with_massive_ties(n, k):
     """Degenerate score rows -- all equal, three distinct values, one value with a few larger ones -- over one and
