@@ -302,6 +302,76 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                                                           (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// dW[n,k] = g^T x (and db = column sums of g) for a TALL, NARROW layer -- n <= 256, k <= 64 with hundreds of thousands of rows
+// (SASRec's [B*L, 64] x [64, 64] and fused [64 -> 192] projections): a streaming reduction over the rows, bound by reading g and x once.
+// The four wavefronts of a workgroup own the four 32 x 32 quadrants of dW; a lane feeds v_mfma_f32_32x32x2_f32 straight
+// from global memory -- A[i][kk] = g[r + kk][c0 + i], B[kk][j] = x[r + kk][d0 + j]: lanes 0..31 read 128 contiguous bytes
+// of row r, lanes 32..63 of row r + 1 -- with 8 row pairs in flight, no LDS staging.  Every workgroup leaves a partial
+// [n, k] (and [n]) that splitk_reduce_kernel sums in a fixed order.  (The general split-K tile kernel spent 285 us on
+// [819200, 64]^T x [819200, 64]: a quarter-filled 128 x 128 tile per workgroup; its column-sum companion 107 us.)
+template <int NQ>
+__global__ __launch_bounds__(256) void tall_dw_kernel(const float* __restrict__ g, const long long ldg,
+                                                      const float* __restrict__ x, const long long ldx, const int M,
+                                                      const int n, const int k, const int rows_per_wg,
+                                                      float* __restrict__ dw_part, float* __restrict__ db_part) {
+  // wavefront w: x columns d0 = (w & 1) * 32 .. + 32 against the g column blocks (w >> 1) + 2 q, q < NQ (n <= 64 NQ)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int li = lane & 31, lk = lane >> 5;
+  const int d0 = (wid & 1) * 32;
+  const bool d_ok = d0 + li < k;
+  const int r_beg = blockIdx.x * rows_per_wg;
+  const int r_end = (r_beg + rows_per_wg < M) ? r_beg + rows_per_wg : M;
+  f32x16 acc[NQ];
+  float colsum[NQ];
+  bool c_ok[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    colsum[q] = 0.f;
+    c_ok[q] = ((wid >> 1) + 2 * q) * 32 + li < n;
+  }
+  constexpr int U = (NQ == 1) ? 8 : 4;     // row pairs in flight (a wavefront feeding both x halves from one g load was slower)
+  const float* gp = g + (wid >> 1) * 32 + li;
+  const float* xp = x + d0 + li;
+  for (int r0 = r_beg; r0 < r_end; r0 += 2 * U) {
+    float a[NQ][U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + 2 * u + lk;
+      const bool in = r < r_end;
+      b[u] = (in && d_ok) ? xp[static_cast<long long>(r) * ldx] : 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) a[q][u] = (in && c_ok[q]) ? gp[static_cast<long long>(r) * ldg + q * 64] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][u], b[u], acc[q], 0, 0, 0);
+        colsum[q] += a[q][u];
+      }
+    }
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float* out = dw_part + static_cast<long long>(blockIdx.x) * n * k;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c0 = ((wid >> 1) + 2 * q) * 32;
+    if (d_ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = c0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row < n) out[row * k + d0 + li] = acc[q][r];
+      }
+    }
+    if (db_part != nullptr && (wid & 1) == 0) {            // the wavefronts of x-quadrant 0 also own the column sums
+      const float t = colsum[q] + __shfl_xor(colsum[q], 32, 64);
+      if (lk == 0 && c_ok[q]) db_part[static_cast<long long>(blockIdx.x) * n + c0 + li] = t;
+    }
+  }
+}
+
 static bool vec_ok(const float* p, long long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0; }
 
 // generic driver: C[M,N] = op(A) op(B)
@@ -415,6 +485,34 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     // dx[m,k] = g[m,n] * W[n,k]: A = g (n contiguous = its K), B(kk=n, col=k) = W[n*k + k] (col contiguous)
     rc = run_gemm<true, false>(g, n, d_w, k, d_dx, M, k, n, nullptr, 0, nullptr, 0, s, dx_stride);
     if (rc != RBX_OK) return rc;
+  }
+  if (d_dw != nullptr && n <= 256 && k <= 64 && m >= 8192) {
+    // tall and narrow: one streaming pass over g and x leaves dW and db partials per workgroup (tall_dw_kernel)
+    const int rb = static_cast<int>((m + 1023) / 1024);                       // db partial rows the workspace holds
+    long long n_wg = static_cast<long long>(dw_floats / (static_cast<size_t>(n) * k));
+    if (n_wg > 4 * kCUs) n_wg = 4 * kCUs;
+    if (n_wg > rb) n_wg = rb;
+    int rows_per_wg = static_cast<int>((m + n_wg - 1) / n_wg);
+    rows_per_wg = (rows_per_wg + 15) / 16 * 16;
+    n_wg = (m + rows_per_wg - 1) / rows_per_wg;
+    float* part = ws + dw_floats;
+    float* dbp = d_db != nullptr ? part : nullptr;
+    const dim3 grid(static_cast<unsigned>(n_wg));
+    const long long ldg = n, ldx = x_stride;
+    switch ((n + 63) / 64) {
+      case 1: hipLaunchKernelGGL(tall_dw_kernel<1>, grid, dim3(256), 0, s, g, ldg, d_x, ldx, M, n, k, rows_per_wg, ws, dbp); break;
+      case 2: hipLaunchKernelGGL(tall_dw_kernel<2>, grid, dim3(256), 0, s, g, ldg, d_x, ldx, M, n, k, rows_per_wg, ws, dbp); break;
+      case 3: hipLaunchKernelGGL(tall_dw_kernel<3>, grid, dim3(256), 0, s, g, ldg, d_x, ldx, M, n, k, rows_per_wg, ws, dbp); break;
+      default: hipLaunchKernelGGL(tall_dw_kernel<4>, grid, dim3(256), 0, s, g, ldg, d_x, ldx, M, n, k, rows_per_wg, ws, dbp); break;
+    }
+    const long long nk = static_cast<long long>(n) * k;
+    long long blocks = (nk + 63) / 64;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, ws, nk,
+                       static_cast<int>(n_wg), d_dw);
+    if (d_db != nullptr)
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1), dim3(256), 0, s, part, static_cast<long long>(n),
+                         static_cast<int>(n_wg), d_db);
+    return check_launch("tall dW / db kernels");
   }
   if (d_dw != nullptr) {
     // dW[n,k] = g^T[n,m] * x[m,k]: A(i=n, kk=m) = g[m*n + n] (row contiguous), B(kk=m, col=k) = x[m*k + k]

@@ -104,7 +104,11 @@ def test_mlp_golden():
 
 
 @pytest.mark.parametrize("M,N,K,act", [(1, 1, 1, None), (65, 33, 17, "relu"), (300, 130, 257, None),
-                                       (9000, 40, 24, "relu"), (8192, 16, 2496, None)])
+                                       (9000, 40, 24, "relu"), (8192, 16, 2496, None),
+                                       # tall and narrow (SASRec's [B*L, 64] x [64, 64]): the streaming dW / db kernel,
+                                       # full and ragged quadrants, a row count that is no multiple of anything
+                                       (20001, 64, 64, None), (8192, 33, 64, "relu"), (12345, 64, 20, None),
+                                       (9999, 7, 5, None), (10000, 192, 64, None), (8200, 130, 33, "relu"), (8192, 256, 64, None)])
 def test_linear_matches_torch_fp32(M, N, K, act):
     """The MFMA GEMM (all three operand layouts, split-K weight grad) against torch fp32 on CPU."""
     from recbox_amd import ops
