@@ -338,6 +338,11 @@ int rbx_cross_fwd(const float* d_x0, const float* d_xi, const float* d_h, const 
                   int32_t h_cols, float* d_out, void* stream);
 int rbx_cross_bwd(const float* d_x0, const float* d_h, const float* d_dout, int64_t rows, int32_t dim, int32_t h_cols,
                   float* d_dx0, float* d_dh, void* stream);
+/* out[r, :] = (alpha * x[r, :] + add[r, :]) * scale[r]   (add optional): SASRec's embedding prologue `e *= sqrt(D);
+ * e += position_emb(...); e *= ~timeline_mask.unsqueeze(-1)` and its per-block mask (third_party/rechub/models/matching/
+ * sasrec.py:68-77, 92) in one pass; its backward is the same call on the incoming gradient. */
+int rbx_rowscale(const float* d_x, const float* d_add, const float* d_scale, int64_t rows, int32_t dim, float alpha,
+                 float* d_out, void* stream);
 
 /* ---- the ranking harness's loss: F.binary_cross_entropy(y_pred, y_true, reduction='mean') on sigmoid outputs
  * (ranking/pytorch/models/ranking_model.py:69, ranking/pytorch/torch_utils.py:54-65).  torch semantics: both log terms

@@ -69,6 +69,7 @@ SIGNATURES = {
     "rbx_all_to_all": (ctypes.c_int, [_P, _P, _P, _sz, _i32, _P]),
     "rbx_embed_rezero": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P]),
     "rbx_sort_share": (ctypes.c_int, [_FP, _FP, _i32, _i32, _P, _FP, _FP, _i32, _i32, _P, _sz, _i64, _P]),
+    "rbx_rowscale": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _f32, _P, _P]),
     "rbx_fm_rezero": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P]),
     "rbx_fm_bwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _P, _i32, _i32, _P, _sz, _P]),
     "rbx_gatherdot_fwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _f32, _P, _P, _P]),

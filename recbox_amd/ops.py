@@ -1361,6 +1361,45 @@ def cross(x0, xi, h, bias=None):
     return _Cross.apply(x0, xi, h, bias)
 
 
+class _RowScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, add, scale, alpha):
+        _require_cuda(x, "row_scale input")
+        shape = x.shape
+        x2 = x.contiguous().float().view(-1, shape[-1])
+        a2 = add.contiguous().float().view(-1, shape[-1]) if add is not None else None
+        s1 = scale.contiguous().float().view(-1)
+        if s1.numel() != x2.shape[0] or (a2 is not None and a2.shape != x2.shape):
+            raise ValueError("row_scale: x [..., D], add like x, scale with one value per row")
+        out = torch.empty_like(x2)
+        check(lib.rbx_rowscale(_ptr(x2), _ptr(a2), _ptr(s1), x2.shape[0], x2.shape[1], float(alpha), _ptr(out), _stream()))
+        ctx.save_for_backward(s1)
+        ctx.alpha, ctx.shape, ctx.has_add = float(alpha), shape, add is not None
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (s1,) = ctx.saved_tensors
+        g2 = g.contiguous().float().view(-1, ctx.shape[-1])
+
+        def scaled(alpha):
+            out = torch.empty_like(g2)
+            check(lib.rbx_rowscale(_ptr(g2), None, _ptr(s1), g2.shape[0], g2.shape[1], alpha, _ptr(out), _stream()))
+            return out.view(ctx.shape)
+
+        dx = scaled(ctx.alpha) if ctx.needs_input_grad[0] else None
+        dadd = None
+        if ctx.has_add and ctx.needs_input_grad[1]:
+            dadd = dx if (dx is not None and ctx.alpha == 1.0) else scaled(1.0)
+        return dx, dadd, None, None
+
+
+def row_scale(x, scale, add=None, alpha=1.0):
+    """``(alpha * x + add) * scale.unsqueeze(-1)`` in one pass (rbx_rowscale): ``scale`` holds one value per row of
+    ``x`` [..., D] (a 0/1 timeline mask, say) and carries no gradient."""
+    return _RowScale.apply(x, add, scale, alpha)
+
+
 class _BceMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prob, target):

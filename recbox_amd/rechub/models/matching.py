@@ -159,20 +159,23 @@ class SASRec(torch.nn.Module):
 
     def seq_forward(self, x, embed_x_feature):
         ids = x['seq']
-        e = embed_x_feature * (self.features[0].embed_dim ** 0.5)
+        e = embed_x_feature
         if e.dim() == 4:
             e = e.squeeze(1)
         positions = torch.arange(ids.shape[1], device=ids.device).unsqueeze(0).expand(ids.shape[0], -1)
-        e = e + ops_position(self.position_emb, positions)
-        e = self.emb_dropout(e)
-        keep = (ids != 0).unsqueeze(-1)
-        e = e * keep
+        keep = (ids != 0).to(e.dtype)                         # ~timeline_mask, one value per (sample, position)
+        scale = self.features[0].embed_dim ** 0.5
+        if isinstance(self.emb_dropout, torch.nn.Dropout) and self.emb_dropout.p > 0 and self.training:
+            e = self.emb_dropout(e * scale + ops_position(self.position_emb, positions))
+            e = ops.row_scale(e, keep)
+        else:      # (e * sqrt(D) + position) * ~mask in one pass (rbx_rowscale) instead of three element-wise kernels
+            e = ops.row_scale(e, keep, add=ops_position(self.position_emb, positions), alpha=scale)
         for i in range(len(self.attention_layers)):
             q = ops.layer_norm(e, self.attention_layernorms[i])
             e = q + self._mha(self.attention_layers[i], q, e)
             e = ops.layer_norm(e, self.forward_layernorms[i])
             e = self.forward_layers[i](e)
-            e = e * keep
+            e = ops.row_scale(e, keep)
         return ops.layer_norm(e, self.last_layernorm)
 
     def forward(self, x):

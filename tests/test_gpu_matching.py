@@ -454,3 +454,31 @@ def test_model_mirrors_with_persistent_gradients(which):
                     assert torch.equal(p1.grad, p0.grad), "%s step %d: %s" % (which, k, n)
     finally:
         ops.config.reuse_grad_buffers = old
+
+
+@pytest.mark.parametrize("shape,with_add,alpha", [((5, 9, 64), True, 8.0), ((4096, 7), False, 1.0), ((3, 1, 4), True, 1.0),
+                                                  ((0, 16), False, 1.0)])
+def test_row_scale_vs_torch(shape, with_add, alpha):
+    """rbx_rowscale: (alpha x + add) * scale per row -- SASRec's embedding prologue and timeline mask in one pass --
+    forward and both gradients against the three ATen expressions the reference writes."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    add = torch.randn(shape, generator=g) if with_add else None
+    s = (torch.rand(shape[:-1], generator=g) < 0.6).float()
+    R = torch.randn(shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ar = add.clone().requires_grad_(True) if with_add else None
+    ref = xr * alpha
+    if with_add:
+        ref = ref + ar
+    ref = ref * s.unsqueeze(-1)
+    (ref * R).sum().backward()
+    xc = x.cuda().requires_grad_(True)
+    ac = add.cuda().requires_grad_(True) if with_add else None
+    out = ops.row_scale(xc, s.cuda(), add=ac, alpha=alpha)
+    (out * R.cuda()).sum().backward()
+    assert_close(out, ref, 1e-6, "out")
+    assert_close(xc.grad, xr.grad, 1e-6, "dx")
+    if with_add:
+        assert_close(ac.grad, ar.grad, 1e-6, "dadd")
