@@ -107,14 +107,17 @@ class PointWiseFeedForward(torch.nn.Module):
         self.conv2 = torch.nn.Conv1d(hidden_units, hidden_units, kernel_size=1)
         self.dropout2 = torch.nn.Dropout(p=dropout_rate)
 
-    def forward(self, inputs):
+    def branch(self, inputs):
+        """The two 1x1 convolutions without the residual connection."""
         # a kernel-size-1 Conv1d over [B, C, L] is a Linear over the channel axis of [B, L, C]
         if self.dropout1.p > 0 and self.training:
             h = self.relu(self.dropout1(ops.linear(inputs, self.conv1.weight.squeeze(-1), self.conv1.bias)))
         else:
             h = ops.linear(inputs, self.conv1.weight.squeeze(-1), self.conv1.bias, act="relu")
-        h = self.dropout2(ops.linear(h, self.conv2.weight.squeeze(-1), self.conv2.bias))
-        return h + inputs
+        return self.dropout2(ops.linear(h, self.conv2.weight.squeeze(-1), self.conv2.bias))
+
+    def forward(self, inputs):
+        return self.branch(inputs) + inputs
 
 
 class SASRec(torch.nn.Module):
@@ -174,8 +177,8 @@ class SASRec(torch.nn.Module):
             q = ops.layer_norm(e, self.attention_layernorms[i])
             e = q + self._mha(self.attention_layers[i], q, e)
             e = ops.layer_norm(e, self.forward_layernorms[i])
-            e = self.forward_layers[i](e)
-            e = ops.row_scale(e, keep)
+            # (ffn(e) + e) * ~mask: the residual add and the timeline mask in one pass
+            e = ops.row_scale(self.forward_layers[i].branch(e), keep, add=e)
         return ops.layer_norm(e, self.last_layernorm)
 
     def forward(self, x):
