@@ -171,6 +171,7 @@ struct Frag {
 
 constexpr int kFlagFin = 1;    // chunk finalises a run that started in an earlier chunk
 constexpr int kFlagPass = 2;   // whole chunk is the middle of one run
+constexpr int kFlagZero = 4;   // the chunk's tail summary is exactly zero (the fix-ups need not read it)
 
 
 }  // namespace rbx

@@ -140,6 +140,15 @@ __global__ __launch_bounds__(256, 4) void segment_reduce_kernel(const RedPack P,
       acc.store(dst, fd.dim, lane_g);
       if (Policy::kHasCount && lane_g == 0) dst[max_dim] = cnt;
       if (is_head) flag |= kFlagPass;
+      // A tail that is exactly zero (every contribution had a zero upstream gradient: masked positions) is marked, so
+      // that the fix-up of a run of hundreds of thousands of such lookups -- SASRec's pad id -- walks flags instead of
+      // summing zeros.  Exact: NaN / inf products are not zero and are still read.
+      bool zero = (cnt == 0.f);
+#pragma unroll
+      for (int q = 0; q < static_cast<int>(sizeof(acc.a) / sizeof(float)); ++q) zero = zero && (acc.a[q] == 0.f);
+#pragma unroll
+      for (int o = 1; o < G; o <<= 1) zero = zero && (__shfl_xor(static_cast<int>(zero), o, 64) != 0);
+      if (zero) flag |= kFlagZero;
     } else if (is_head) {
       float* dst = head + static_cast<size_t>(c) * sum_stride;
       acc.store(dst, fd.dim, lane_g);
@@ -198,6 +207,7 @@ __global__ __launch_bounds__(256) void segment_fixup_short_kernel(const RedPack 
     acc.add_from(src, fd.dim, lane_g);
     float cnt = Policy::kHasCount ? src[max_dim] : 0.f;
     for (int h = 1; h <= hops; ++h) {                       // independent loads, fixed summation order
+      if (flags[c - h] & kFlagZero) continue;               // (adds exact zeros)
       const float* t = tail + static_cast<size_t>(c - h) * sum_stride;
       acc.add_from(t, fd.dim, lane_g);
       if (Policy::kHasCount) cnt += t[max_dim];
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
       for (int r = 0; r < R; ++r) {
         const int d = gi * R + r;
         const long long j = jbase - d;
-        if (j >= 0 && d <= t) {
+        if (j >= 0 && d <= t && !(fl[r] & kFlagZero)) {
           const float* src = tail + static_cast<size_t>(j) * sum_stride;
           part.add_from(src, fd.dim, lane_g);
           if (Policy::kHasCount) pc += src[max_dim];
