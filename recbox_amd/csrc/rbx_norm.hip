@@ -171,12 +171,25 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
   __shared__ float red[2][4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f;
-  if (c < cols)
-    for (int b = zl; b < nblocks; b += 4) {
+  if (c < cols) {
+    int b = zl;
+    for (; b + 28 < nblocks; b += 32) {                     // 8 partials in flight, added in the same (ascending) order
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const float2*>(partial + (static_cast<long long>(b + 4 * u) * cols + c) * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s0 += v[u].x;
+        s1 += v[u].y;
+      }
+    }
+    for (; b < nblocks; b += 4) {
       const float* src = partial + (static_cast<long long>(b) * cols + c) * 2;
       s0 += src[0];
       s1 += src[1];
     }
+  }
   red[0][zl][threadIdx.x & 63] = s0;
   red[1][zl][threadIdx.x & 63] = s1;
   __syncthreads();
