@@ -293,8 +293,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
   float t = 0.f;
-  if (n < N)
-    for (int r = r0 + (threadIdx.x >> 6); r < r1; r += 4) t += dy[static_cast<long long>(r) * N + n];
+  if (n < N) {
+    int r = r0 + (threadIdx.x >> 6);
+    for (; r + 28 < r1; r += 32) {                           // 8 rows in flight, added in the same (ascending) order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = dy[static_cast<long long>(r + 4 * u) * N + n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; r < r1; r += 4) t += dy[static_cast<long long>(r) * N + n];
+  }
   red[threadIdx.x >> 6][threadIdx.x & 63] = t;
   __syncthreads();
   if (threadIdx.x < 64 && n < N)
