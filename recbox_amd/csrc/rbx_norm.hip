@@ -148,7 +148,24 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   float s0 = 0.f, s1 = 0.f;
   if (c < cols) {
     const float m = mean[c], rs = rstd[c];
-    for (long long r = r0 + (threadIdx.x >> 6); r < r1; r += 4) {
+    long long r = r0 + (threadIdx.x >> 6);
+    for (; r + 12 < r1; r += 16) {                           // 4 rows in flight, added in ascending order
+      float gg[4], xx[4], yy[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long q = (r + 4 * u) * cols + c;
+        gg[u] = dy[q];
+        xx[u] = x[q];
+        yy[u] = y_relu != nullptr ? y_relu[q] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float g = (yy[u] > 0.f) ? gg[u] : 0.f;         // fused ReLU: its mask is y > 0
+        s0 += g;
+        s1 += g * ((xx[u] - m) * rs);
+      }
+    }
+    for (; r < r1; r += 4) {
       float g = dy[r * cols + c];
       if (y_relu != nullptr && !(y_relu[r * cols + c] > 0.f)) g = 0.f;     // fused ReLU: its mask is y > 0
       s0 += g;
@@ -463,7 +480,24 @@ __global__ __launch_bounds__(256) void ln_bwd_partial_kernel(const float* __rest
   const long long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
   float s0 = 0.f, s1 = 0.f;
   if (c < dim) {
-    for (long long r = r0 + (threadIdx.x >> 6); r < r1; r += 4) {
+    long long r = r0 + (threadIdx.x >> 6);
+    for (; r + 12 < r1; r += 16) {                           // 4 rows in flight (16 loads), added in ascending order
+      float gg[4], xx[4], mm[4], rr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long q = r + 4 * u;
+        gg[u] = dy[q * dim + c];
+        xx[u] = x[q * dim + c];
+        mm[u] = mean[q];
+        rr[u] = rstd[q];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s0 += gg[u];
+        s1 += gg[u] * ((xx[u] - mm[u]) * rr[u]);
+      }
+    }
+    for (; r < r1; r += 4) {
       const float g = dy[r * dim + c];
       s0 += g;
       s1 += g * ((x[r * dim + c] - mean[r]) * rstd[r]);
