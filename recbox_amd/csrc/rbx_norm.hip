@@ -47,8 +47,17 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   const long long r0 = static_cast<long long>(blockIdx.y) * kBnRows;
   const long long r1 = (r0 + kBnRows < rows) ? r0 + kBnRows : rows;
   Welford w = {0.f, 0.f, 0.f};
-  if (c < cols)
-    for (long long r = r0 + (threadIdx.x >> 6); r < r1; r += 4) w.add(x[r * cols + c]);
+  if (c < cols) {
+    long long r = r0 + (threadIdx.x >> 6);
+    for (; r + 28 < r1; r += 32) {                           // 8 rows in flight, folded in ascending order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(r + 4 * u) * cols + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w.add(v[u]);
+    }
+    for (; r < r1; r += 4) w.add(x[r * cols + c]);
+  }
   red[threadIdx.x >> 6][threadIdx.x & 63] = w;
   __syncthreads();
   if (threadIdx.x < 64 && c < cols) {
@@ -72,11 +81,24 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
   Welford t = {0.f, 0.f, 0.f};
   if (c < cols)
-    for (int b = zl; b < nblocks; b += 4) {
+  {
+    int b = zl;
+    for (; b + 28 < nblocks; b += 32) {                      // 8 partials in flight, merged in ascending order
+      Welford o[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float* src = partial + (static_cast<long long>(b + 4 * u) * cols + c) * 3;
+        o[u] = {src[0], src[1], src[2]};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t.merge(o[u]);
+    }
+    for (; b < nblocks; b += 4) {
       const float* src = partial + (static_cast<long long>(b) * cols + c) * 3;
       const Welford o = {src[0], src[1], src[2]};
       t.merge(o);
     }
+  }
   red[zl][threadIdx.x & 63] = t;
   __syncthreads();
   if (zl != 0 || c >= cols) return;
