@@ -449,7 +449,18 @@ __global__ __launch_bounds__(256) void numeric_partial_kernel(const NumPack P, c
     const int d = dbase + (threadIdx.x & 15);
     float acc = 0.f;
     if (d < dim) {
-      for (long long b = b0 + (threadIdx.x >> 4); b < b1; b += 16) {
+      long long b = b0 + (threadIdx.x >> 4);
+      for (; b + 48 < b1; b += 64) {                         // 4 samples in flight, added in ascending order
+        float xv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xv[u] = load_value(fd.ids, (b + 16 * u) * fd.stride_b, fd.dtype);
+          gv[u] = dout[(b + 16 * u) * stride_b + fd.out_off + d];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += xv[u] * gv[u];
+      }
+      for (; b < b1; b += 16) {
         const float x = load_value(fd.ids, b * fd.stride_b, fd.dtype);
         acc += x * dout[b * stride_b + fd.out_off + d];
       }
