@@ -126,16 +126,70 @@ __global__ __launch_bounds__(256) void bn_eval_stats_kernel(const float* __restr
   rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
-// y = (x - mean) * rstd * gamma + beta, optional ReLU; 4 columns per lane when cols % 4 == 0
+// y = (x - mean) * rstd * gamma + beta, optional ReLU; 4 columns per lane when cols % 4 == 0.
+// The host picks a grid whose stride is a multiple of `cols` whenever it can (bn_grid): a lane then stays on the same
+// columns for the whole sweep, keeps their statistics in registers and has 4 independent loads in flight; other grids
+// take the generic loop (a 64-bit modulo and 4 parameter loads per element).
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const long long rows, const int cols,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const int relu, float* __restrict__ y) {
   constexpr int W = VEC ? 4 : 1;
+  constexpr int U = 4;
   const long long total = rows * cols / W;
   const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
-  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += step) {
+  long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if ((step * W) % cols == 0) {
+    if (i >= total) return;
+    const int c = static_cast<int>((i * W) % cols);
+    float m[W], rs[W], g[W], b[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      m[k] = mean[c + k];
+      rs[k] = rstd[c + k];
+      g[k] = gamma != nullptr ? gamma[c + k] : 1.f;
+      b[k] = beta != nullptr ? beta[c + k] : 0.f;
+    }
+    auto one = [&](const float (&v)[W], const long long e) {
+      float o[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        o[k] = (v[k] - m[k]) * rs[k] * g[k] + b[k];
+        if (relu && o[k] < 0.f) o[k] = 0.f;
+      }
+      if constexpr (VEC) *reinterpret_cast<float4*>(y + e) = make_float4(o[0], o[1], o[2], o[3]);
+      else y[e] = o[0];
+    };
+    for (; i + (U - 1) * step < total; i += U * step) {
+      float v[U][W];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long e = (i + u * step) * W;
+        if constexpr (VEC) {
+          const float4 t = *reinterpret_cast<const float4*>(x + e);
+          v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+        } else {
+          v[u][0] = x[e];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) one(v[u], (i + u * step) * W);
+    }
+    for (; i < total; i += step) {
+      float v[W];
+      const long long e = i * W;
+      if constexpr (VEC) {
+        const float4 t = *reinterpret_cast<const float4*>(x + e);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+        v[0] = x[e];
+      }
+      one(v, e);
+    }
+    return;
+  }
+  for (; i < total; i += step) {
     const long long e = i * W;
     const int c = static_cast<int>(e % cols);
     float v[W], o[W];
@@ -248,10 +302,75 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ dgamma, const int training,
                                                         float* __restrict__ dx) {
   constexpr int W = VEC ? 4 : 1;
+  constexpr int U = 2;
   const long long total = rows * cols / W;
   const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
   const float inv_m = 1.0f / static_cast<float>(rows);
-  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += step) {
+  long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if ((step * W) % cols == 0) {                             // fixed columns per lane (bn_grid): statistics in registers
+    if (i >= total) return;
+    const int c = static_cast<int>((i * W) % cols);
+    float m[W], rs[W], g[W], db[W], dg[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      m[k] = mean[c + k];
+      rs[k] = rstd[c + k];
+      g[k] = gamma != nullptr ? gamma[c + k] : 1.f;
+      db[k] = dbeta[c + k];
+      dg[k] = dgamma[c + k];
+    }
+    auto load = [&](const float* __restrict__ src, const long long e, float (&v)[W]) {
+      if constexpr (VEC) {
+        const float4 t = *reinterpret_cast<const float4*>(src + e);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+        v[0] = src[e];
+      }
+    };
+    auto one = [&](const float (&xv)[W], float (&gv)[W], const float (&yv)[W], const long long e) {
+      float o[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        if (y_relu != nullptr && !(yv[k] > 0.f)) gv[k] = 0.f;
+        if (training) {
+          const float xhat = (xv[k] - m[k]) * rs[k];
+          o[k] = g[k] * rs[k] * (gv[k] - db[k] * inv_m - xhat * dg[k] * inv_m);
+        } else {
+          o[k] = g[k] * rs[k] * gv[k];
+        }
+      }
+      if constexpr (VEC) *reinterpret_cast<float4*>(dx + e) = make_float4(o[0], o[1], o[2], o[3]);
+      else dx[e] = o[0];
+    };
+    for (; i + (U - 1) * step < total; i += U * step) {
+      float xv[U][W], gv[U][W], yv[U][W];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long e = (i + u * step) * W;
+        load(x, e, xv[u]);
+        load(dy, e, gv[u]);
+        if (y_relu != nullptr) load(y_relu, e, yv[u]);
+        else
+#pragma unroll
+          for (int k = 0; k < W; ++k) yv[u][k] = 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) one(xv[u], gv[u], yv[u], (i + u * step) * W);
+    }
+    for (; i < total; i += step) {
+      float xv[W], gv[W], yv[W];
+      const long long e = i * W;
+      load(x, e, xv);
+      load(dy, e, gv);
+      if (y_relu != nullptr) load(y_relu, e, yv);
+      else
+#pragma unroll
+        for (int k = 0; k < W; ++k) yv[k] = 1.f;
+      one(xv, gv, yv, e);
+    }
+    return;
+  }
+  for (; i < total; i += step) {
     const long long e = i * W;
     const int c = static_cast<int>(e % cols);
     float xv[W], gv[W], o[W];
@@ -283,6 +402,19 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
     if constexpr (VEC) *reinterpret_cast<float4*>(dx + e) = make_float4(o[0], o[1], o[2], o[3]);
     else dx[e] = o[0];
   }
+}
+
+// grid of the element-wise sweeps: as many workgroups as the cap allows, rounded down to a count whose stride
+// (blocks * 256 lanes * W columns) is a multiple of `cols`, so that every lane keeps its columns (see bn_apply_kernel)
+static unsigned bn_grid(long long total_vecs, int cols, int w) {
+  long long blocks = (total_vecs + 255) / 256;
+  const long long cap = kCUs * 16;
+  if (blocks > cap) blocks = cap;
+  long long a = cols, b = 256LL * w;
+  while (b != 0) { const long long t = a % b; a = b; b = t; }
+  const long long unit = cols / a;                          // blocks must be a multiple of cols / gcd(cols, 256 * W)
+  if (unit <= blocks) blocks = blocks / unit * unit;
+  return static_cast<unsigned>(blocks);
 }
 
 static int bn_blocks(int64_t rows) { return static_cast<int>((rows + kBnRows - 1) / kBnRows); }
@@ -324,13 +456,12 @@ extern "C" int rbx_batchnorm_fwd(const float* d_x, int64_t rows, int32_t cols, c
   }
   const bool vec = bn_vec(cols, d_x, d_y, d_y);
   const long long total = static_cast<long long>(rows) * cols / (vec ? 4 : 1);
-  long long blocks = (total + 255) / 256;
-  if (blocks > kCUs * 16) blocks = kCUs * 16;
+  const unsigned blocks = bn_grid(total, cols, vec ? 4 : 1);
   if (vec)
-    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, d_x,
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, s, d_x,
                        static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_beta, relu, d_y);
   else
-    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, d_x,
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, s, d_x,
                        static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_beta, relu, d_y);
   return check_launch("batchnorm forward kernels");
 }
@@ -355,13 +486,12 @@ extern "C" int rbx_batchnorm_bwd(const float* d_x, const float* d_dy, const floa
   if (d_dx != nullptr) {
     const bool vec = bn_vec(cols, d_x, d_dy, d_dx);
     const long long total = static_cast<long long>(rows) * cols / (vec ? 4 : 1);
-    long long blocks = (total + 255) / 256;
-    if (blocks > kCUs * 16) blocks = kCUs * 16;
+    const unsigned blocks = bn_grid(total, cols, vec ? 4 : 1);
     if (vec)
-      hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, d_x, d_dy, d_y_relu,
+      hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(blocks), dim3(256), 0, s, d_x, d_dy, d_y_relu,
                          static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx);
     else
-      hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, d_x, d_dy, d_y_relu,
+      hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(blocks), dim3(256), 0, s, d_x, d_dy, d_y_relu,
                          static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx);
   }
   return check_launch("batchnorm backward kernels");

@@ -175,10 +175,14 @@ def test_gather_dot_vs_torch(D, n_sets, width):
         assert_close(a.grad, b.grad, 1e-4, "dW")
 
 
-@pytest.mark.parametrize("rows,cols,relu", [(64, 32, False), (1000, 400, True), (513, 37, True), (2, 8, False)])
+@pytest.mark.parametrize("rows,cols,relu", [(64, 32, False), (1000, 400, True), (513, 37, True), (2, 8, False),
+                                            (70001, 400, False), (300011, 37, False), (40000, 1030, False),
+                                            (9000, 400, True)])
 def test_batch_norm_vs_torch(rows, cols, relu):
     """rbx_batchnorm_fwd/bwd == nn.BatchNorm1d (+ReLU) of torch CPU fp32: outputs, input / affine gradients, running
-    statistics and num_batches_tracked in training mode over two steps, then eval mode."""
+    statistics and num_batches_tracked in training mode over two steps, then eval mode.  (The large shapes sweep the
+    element-wise kernels several times per lane; they run without ReLU because among 10^7 pre-activations one lands within
+    an ulp of zero and its mask legitimately differs between two fp32 implementations.)"""
     from recbox_amd import ops
     g = torch.Generator().manual_seed(rows + cols)
     ref = torch.nn.BatchNorm1d(cols)
