@@ -343,6 +343,14 @@ int rbx_cross_bwd(const float* d_x0, const float* d_h, const float* d_dout, int6
  * sasrec.py:68-77, 92) in one pass; its backward is the same call on the incoming gradient. */
 int rbx_rowscale(const float* d_x, const float* d_add, const float* d_scale, int64_t rows, int32_t dim, float alpha,
                  float* d_out, void* stream);
+/* out[r, c] = base[r, c] + (c < prefix_cols ? a[r, c] + b[r, c] : 0) for c < cols; base, a, b optional (NULL = zeros),
+ * strides in floats.  The input gradient of a row block that one consumer reads whole and two more read through its
+ * leading columns: DeepFM feeds the same embeddings to the tower (embeddings | dense values), to FM and to the
+ * first-order Linear (third_party/rechub/models/ranking/deepfm.py:34-39; autograd's glue for it is a fill, a strided
+ * copy and two adds). */
+int rbx_sum_prefix(const float* d_base, int64_t base_stride, const float* d_a, int64_t a_stride, const float* d_b,
+                   int64_t b_stride, int64_t rows, int32_t cols, int32_t prefix_cols, float* d_out, int64_t out_stride,
+                   void* stream);
 
 /* ---- the ranking harness's loss: F.binary_cross_entropy(y_pred, y_true, reduction='mean') on sigmoid outputs
  * (ranking/pytorch/models/ranking_model.py:69, ranking/pytorch/torch_utils.py:54-65).  torch semantics: both log terms

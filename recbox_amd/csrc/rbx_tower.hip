@@ -327,6 +327,96 @@ extern "C" int rbx_rowscale(const float* d_x, const float* d_add, const float* d
   return check_launch("rowscale_kernel");
 }
 
+// ---- gradient of a row block that is read whole AND through its leading columns ---------------------------------
+// third_party/rechub/models/ranking/deepfm.py:34-39 feeds the SAME embeddings to the tower (whole row: embeddings | dense
+// values), to FM and to the first-order Linear (leading F*D columns).  Autograd's glue for that fan-out is a zero fill, a
+// strided copy and two adds over [B, F*D] (669 us at B = 65 536, F*D = 1664); here one pass:
+//   out[r, c] = base[r, c] + (c < prefix_cols ? a[r, c] + b[r, c] : 0),   c < cols      (base / a / b optional)
+namespace rbx {
+template <bool VEC>
+__global__ __launch_bounds__(256) void sum_prefix_kernel(const float* __restrict__ base, const long long base_stride,
+                                                         const float* __restrict__ a, const long long a_stride,
+                                                         const float* __restrict__ b, const long long b_stride,
+                                                         const long long rows, const int cols, const int prefix_cols,
+                                                         float* __restrict__ out, const long long out_stride) {
+  constexpr int W = VEC ? 4 : 1;
+  const unsigned per_row = static_cast<unsigned>((cols + W - 1) / W);
+  const long long total = rows * per_row;
+  const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += step) {
+    long long r;
+    if (total < (1LL << 32)) r = static_cast<unsigned>(i) / per_row;       // 32-bit division whenever it fits
+    else r = i / per_row;
+    const int c = static_cast<int>(i - r * per_row) * W;
+    float v[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] = 0.f;
+    if (base != nullptr) {
+      if constexpr (VEC) {
+        const float4 t = *reinterpret_cast<const float4*>(base + r * base_stride + c);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+        v[0] = base[r * base_stride + c];
+      }
+    }
+    if (c < prefix_cols) {
+      if (a != nullptr) {
+        if constexpr (VEC) {
+          const float4 t = *reinterpret_cast<const float4*>(a + r * a_stride + c);
+          v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        } else {
+          v[0] += a[r * a_stride + c];
+        }
+      }
+      if (b != nullptr) {
+        if constexpr (VEC) {
+          const float4 t = *reinterpret_cast<const float4*>(b + r * b_stride + c);
+          v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        } else {
+          v[0] += b[r * b_stride + c];
+        }
+      }
+    }
+    if constexpr (VEC) *reinterpret_cast<float4*>(out + r * out_stride + c) = make_float4(v[0], v[1], v[2], v[3]);
+    else out[r * out_stride + c] = v[0];
+  }
+}
+}  // namespace rbx
+
+extern "C" int rbx_sum_prefix(const float* d_base, int64_t base_stride, const float* d_a, int64_t a_stride, const float* d_b,
+                              int64_t b_stride, int64_t rows, int32_t cols, int32_t prefix_cols, float* d_out,
+                              int64_t out_stride, void* stream) {
+  using namespace rbx;
+  if (rows < 0 || cols < 0 || prefix_cols < 0 || prefix_cols > cols)
+    return fail(RBX_ERR_INVALID, "sum_prefix: need rows >= 0 and 0 <= prefix_cols <= cols");
+  if (rows == 0 || cols == 0) return RBX_OK;
+  if (!d_out) return fail(RBX_ERR_INVALID, "sum_prefix: NULL output");
+  if (out_stride < cols || (d_base && base_stride < cols) || (d_a && a_stride < prefix_cols) || (d_b && b_stride < prefix_cols))
+    return fail(RBX_ERR_INVALID, "sum_prefix: a row stride is shorter than its row");
+  // float4 sweep when every row starts 16-byte aligned, the prefix ends on a float4 and the padded tail of the last
+  // float4 of a row lies inside the row stride of the tensors that hold whole rows
+  const int padded = (cols + 3) / 4 * 4;
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(d_base) | reinterpret_cast<uintptr_t>(d_a) |
+                         reinterpret_cast<uintptr_t>(d_b) | reinterpret_cast<uintptr_t>(d_out);
+  const bool vec = (bits & 15) == 0 && (prefix_cols & 3) == 0 && (out_stride & 3) == 0 && out_stride >= padded &&
+                   (!d_base || ((base_stride & 3) == 0 && base_stride >= padded)) && (!d_a || (a_stride & 3) == 0) &&
+                   (!d_b || (b_stride & 3) == 0);
+  const long long total = static_cast<long long>(rows) * (vec ? padded / 4 : cols);
+  long long blocks = (total + 255) / 256;
+  if (blocks > kCUs * 16) blocks = kCUs * 16;
+  if (vec)
+    hipLaunchKernelGGL(sum_prefix_kernel<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_base,
+                       static_cast<long long>(base_stride), d_a, static_cast<long long>(a_stride), d_b,
+                       static_cast<long long>(b_stride), static_cast<long long>(rows), cols, prefix_cols, d_out,
+                       static_cast<long long>(out_stride));
+  else
+    hipLaunchKernelGGL(sum_prefix_kernel<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_base,
+                       static_cast<long long>(base_stride), d_a, static_cast<long long>(a_stride), d_b,
+                       static_cast<long long>(b_stride), static_cast<long long>(rows), cols, prefix_cols, d_out,
+                       static_cast<long long>(out_stride));
+  return check_launch("sum_prefix_kernel");
+}
+
 // ---- binary cross entropy on probabilities, mean-reduced (the ranking harness's loss) -------------------------
 // ranking/pytorch/models/ranking_model.py:69 + ranking/pytorch/torch_utils.py:54-65: F.binary_cross_entropy(y_pred,
 // y_true, reduction='mean') on SIGMOID OUTPUTS.  torch semantics: log terms clamped at -100; backward

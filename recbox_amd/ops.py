@@ -1400,6 +1400,43 @@ def row_scale(x, scale, add=None, alpha=1.0):
     return _RowScale.apply(x, add, scale, alpha)
 
 
+class _SharedPrefix(torch.autograd.Function):
+    """x -> (x, x[:, :n], ..., x[:, :n]): identity in forward; backward sums the gradient of the whole rows and of the
+    prefix views in one pass (rbx_sum_prefix)."""
+
+    @staticmethod
+    def forward(ctx, x, n, copies):
+        _require_cuda(x, "shared_prefix input")
+        if x.dim() != 2 or not 0 < n <= x.shape[1] or not 1 <= copies <= 2:
+            raise ValueError("shared_prefix: x [rows, cols], 0 < n <= cols, 1 or 2 prefix views")
+        ctx.n, ctx.shape = int(n), tuple(x.shape)
+        return (x.view_as(x),) + tuple(x[:, :n] for _ in range(copies))
+
+    @staticmethod
+    def backward(ctx, g_whole, *g_prefix):
+        rows, cols = ctx.shape
+        gs = [_rows_view(g) for g in g_prefix if g is not None]
+        base = _rows_view(g_whole) if g_whole is not None else None
+        if base is None and not gs:
+            return None, None, None
+        dev = (base if base is not None else gs[0]).device
+        out = _padded_rows(rows, cols, dev)
+        a = gs[0] if gs else None
+        b = gs[1] if len(gs) > 1 else None
+        check(lib.rbx_sum_prefix(_ptr(base), base.stride(0) if base is not None else 0, _ptr(a),
+                                 a.stride(0) if a is not None else 0, _ptr(b), b.stride(0) if b is not None else 0,
+                                 rows, cols, ctx.n, _ptr(out), out.stride(0), _stream()))
+        return out, None, None
+
+
+def shared_prefix(x, n, copies=2):
+    """``(x, x[:, :n], x[:, :n])`` for a [rows, cols] block whose leading ``n`` columns have consumers of their own
+    (DeepFM: the tower reads embeddings | dense values, FM and the first-order Linear the embeddings; deepfm.py:34-39).
+    Same values as plain slicing; the input gradient is assembled by one kernel instead of autograd's zero fill +
+    strided copy + two adds."""
+    return _SharedPrefix.apply(x, int(n), int(copies))
+
+
 class _BceMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prob, target):

@@ -2,6 +2,7 @@
 /root/reference/recbox/third_party/rechub/models/ranking/deepfm.py:14-42)."""
 import torch
 
+from ... import ops
 from ..basic.features import DenseFeature, SparseFeature
 from ..basic.layers import FM, LR, MLP, EmbeddingLayer
 
@@ -32,9 +33,13 @@ class DeepFM(torch.nn.Module):
             # [V, D] gradients per table.  Here ONE gather produces [B, F*D | dense] (rows padded to 16 bytes); the
             # FM part and the LR part read its leading F*D columns in place, the tower reads the whole row.
             input_deep = self.embedding(x, self.deep_features, squeeze_dim=True)
-            flat_fm = input_deep[:, :self.fm_dims]
+            if input_deep.is_cuda and input_deep.dim() == 2:
+                # three readers of one block: its gradient is assembled by one kernel (ops.shared_prefix)
+                input_deep, flat_fm, flat_lr = ops.shared_prefix(input_deep, self.fm_dims, copies=2)
+            else:
+                flat_fm = flat_lr = input_deep[:, :self.fm_dims]
             input_fm = flat_fm.view(flat_fm.shape[0], len(self.fm_features), self.fm_features[0].embed_dim)
-            y_linear = self.linear(flat_fm)
+            y_linear = self.linear(flat_lr)
         else:
             input_deep = self.embedding(x, self.deep_features, squeeze_dim=True)     # [B, deep_dims]
             input_fm = self.embedding(x, self.fm_features, squeeze_dim=False)        # [B, F, D]

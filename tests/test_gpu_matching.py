@@ -486,3 +486,38 @@ def test_row_scale_vs_torch(shape, with_add, alpha):
     assert_close(xc.grad, xr.grad, 1e-6, "dx")
     if with_add:
         assert_close(ac.grad, ar.grad, 1e-6, "dadd")
+
+
+@pytest.mark.parametrize("rows,cols,n,copies", [(300, 1677, 1664, 2), (257, 40, 24, 2), (64, 37, 5, 2), (1, 8, 8, 1),
+                                                (5000, 1680, 1664, 2)])
+def test_shared_prefix_vs_plain_slicing(rows, cols, n, copies):
+    """ops.shared_prefix (rbx_sum_prefix) == x, x[:, :n], x[:, :n] with autograd's own fan-out: same forward values,
+    same input gradient, also when a reader is absent or hands back a broadcast gradient (DeepFM's shared block,
+    deepfm.py:34-39)."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g)
+    w = [torch.randn(rows, cols, generator=g), torch.randn(rows, n, generator=g), torch.randn(rows, n, generator=g)]
+    padded = ops._padded_rows(rows, cols, "cuda")
+    padded.copy_(x)                                           # row stride a multiple of 4 floats, like the lookup's output
+    for xin in (padded, x.cuda()):
+        for used in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0), (0, 0, 1)):
+            if copies == 1 and used[2]:
+                continue
+            xr = x.clone().requires_grad_(True)
+            parts_r = (xr, xr[:, :n], xr[:, :n])
+            xc = xin.detach().requires_grad_(True)
+            parts_c = ops.shared_prefix(xc, n, copies=copies)
+            for a, b in zip(parts_c, parts_r):
+                assert torch.equal(a.detach().cpu(), b.detach())
+            lr = sum((p * wt).sum() for p, wt, u in zip(parts_r, w, used) if u)
+            lc = sum((p * wt.cuda()).sum() for p, wt, u in zip(parts_c, w, used) if u)
+            lr.backward()
+            lc.backward()
+            assert_close(xc.grad, xr.grad, 1e-6, "dx %s" % (used,))
+    xr = x.clone().requires_grad_(True)
+    xc = x.cuda().requires_grad_(True)
+    parts_c = ops.shared_prefix(xc, n, copies=copies)
+    (xr.sum() * 2.0 + xr[:, :n].sum()).backward()             # broadcast (stride-0) gradients
+    (parts_c[0].sum() * 2.0 + parts_c[1].sum()).backward()
+    assert_close(xc.grad, xr.grad, 1e-6, "dx broadcast")
