@@ -311,6 +311,127 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                                                           (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// ---- n == 1: the logit heads (Linear(400, 1) of every tower, rechub LR's Linear(F*D, 1)) -----------------------------
+// A [M, K] x [K] product is a streaming read of x; on the 128 x 32 narrow GEMM tile it ran at 2.6 TB/s ([65 536, 1664]:
+// 168 us forward, 480 us backward).  Here: a wavefront per row with a fixed xor butterfly (forward), an outer product
+// whose lanes keep their columns of w in registers (dx), and g-weighted column sums with fixed-order partials (dW, db).
+__global__ __launch_bounds__(256) void gemv_fwd_kernel(const float* __restrict__ x, const long long ldx,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       const int M, const int K, const int act, const int vec,
+                                                       float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  const int k4 = vec ? (K & ~3) : 0;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += nwaves) {
+    const float* __restrict__ xr = x + static_cast<long long>(r) * ldx;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int c = lane * 4; c < k4; c += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(xr + c);
+      const float4 b = *reinterpret_cast<const float4*>(w + c);
+      acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+    }
+#pragma unroll 4
+    for (int c = k4 + lane; c < K; c += 64) acc += xr[c] * w[c];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      float v = acc + (bias != nullptr ? bias[0] : 0.f);
+      if (act == 1 && v < 0.f) v = 0.f;
+      y[r] = v;
+    }
+  }
+}
+
+// dx[r, c] = g[r] * w[c].  VEC: K % 4 == 0, 16-byte aligned rows.  When the grid stride is a multiple of the row length
+// (outer_grid) a lane keeps its columns; otherwise it recomputes (row, column) per element.
+template <bool VEC>
+__global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ g, const float* __restrict__ w, const int M,
+                                                    const int K, float* __restrict__ dx, const long long lddx) {
+  constexpr int W = VEC ? 4 : 1;
+  const unsigned per_row = static_cast<unsigned>(K / W);
+  const long long total = static_cast<long long>(M) * per_row;
+  const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
+  long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  if (step % per_row == 0) {
+    long long r = i / per_row;
+    const int c = static_cast<int>(i - r * per_row) * W;
+    const long long dr = step / per_row;
+    float wv[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) wv[q] = w[c + q];
+#pragma unroll 4
+    for (; r < M; r += dr) {
+      const float gr = g[r];
+      float* dst = dx + r * lddx + c;
+      if constexpr (VEC) *reinterpret_cast<float4*>(dst) = make_float4(gr * wv[0], gr * wv[1], gr * wv[2], gr * wv[3]);
+      else dst[0] = gr * wv[0];
+    }
+    return;
+  }
+  for (; i < total; i += step) {
+    const long long r = i / per_row;
+    const int c = static_cast<int>(i - r * per_row) * W;
+    const float gr = g[r];
+    float* dst = dx + r * lddx + c;
+    if constexpr (VEC) *reinterpret_cast<float4*>(dst) = make_float4(gr * w[c], gr * w[c + 1], gr * w[c + 2], gr * w[c + 3]);
+    else dst[0] = gr * w[c];
+  }
+}
+
+static unsigned outer_grid(long long total_vecs, long long per_row) {
+  long long blocks = (total_vecs + 255) / 256;
+  const long long cap = kCUs * 16;
+  if (blocks > cap) blocks = cap;
+  long long a = per_row, b = 256;
+  while (b != 0) { const long long t = a % b; a = b; b = t; }
+  const long long unit = per_row / a;
+  if (unit <= blocks) blocks = blocks / unit * unit;
+  return static_cast<unsigned>(blocks < 1 ? 1 : blocks);
+}
+
+// dw_part[rb][k] = sum over the row block of g[r] * x[r, k]; db_part[rb] = sum of g[r]: grid (ceil(K/64), row_blocks)
+__global__ __launch_bounds__(256) void wcolsum_partial_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                              const long long ldx, const int M, const int K,
+                                                              const int rows_per_block, float* __restrict__ dw_part,
+                                                              float* __restrict__ db_part) {
+  __shared__ float red[4][64];
+  __shared__ float redg[4];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  const bool ok = n < K;
+  float t = 0.f, gs = 0.f;
+  int r = r0 + (threadIdx.x >> 6);
+  for (; r + 28 < r1; r += 32) {                             // 8 rows in flight, added in ascending order
+    float v[8], gg[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      gg[u] = g[r + 4 * u];
+      v[u] = ok ? x[static_cast<long long>(r + 4 * u) * ldx + n] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      t += gg[u] * v[u];
+      gs += gg[u];
+    }
+  }
+  for (; r < r1; r += 4) {
+    const float gr = g[r];
+    t += gr * (ok ? x[static_cast<long long>(r) * ldx + n] : 0.f);
+    gs += gr;
+  }
+  red[threadIdx.x >> 6][threadIdx.x & 63] = t;
+  if ((threadIdx.x & 63) == 0) redg[threadIdx.x >> 6] = gs;
+  __syncthreads();
+  if (threadIdx.x < 64 && ok)
+    dw_part[static_cast<long long>(blockIdx.y) * K + n] = (red[0][threadIdx.x] + red[1][threadIdx.x]) +
+                                                          (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (threadIdx.x == 0 && blockIdx.x == 0 && db_part != nullptr)
+    db_part[blockIdx.y] = (redg[0] + redg[1]) + (redg[2] + redg[3]);
+}
+
 // dW[n,k] = g^T x (and db = column sums of g) for a TALL, NARROW layer -- n <= 256, k <= 64 with hundreds of thousands of rows
 // (SASRec's [B*L, 64] x [64, 64] and fused [64 -> 192] projections): a streaming reduction over the rows, bound by reading g and x once.
 // The four wavefronts of a workgroup own the four 32 x 32 quadrants of dW; a lane feeds v_mfma_f32_32x32x2_f32 straight
@@ -442,6 +563,14 @@ extern "C" int rbx_linear_fwd(const float* d_x, int64_t x_stride, const float* d
   if (x_stride < k) return fail(RBX_ERR_INVALID, "linear: x_stride %lld < k %d", static_cast<long long>(x_stride), k);
   if (act != 0 && act != 1) return fail(RBX_ERR_UNSUPPORTED, "linear: activation code %d", act);
   if (m == 0) return RBX_OK;
+  if (n == 1) {                                             // a logit head: one streaming pass, a wavefront per row
+    long long blocks = (m + 3) / 4;
+    if (blocks > kCUs * 16) blocks = kCUs * 16;
+    const int vec = (x_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_w)) & 15) == 0;
+    hipLaunchKernelGGL(gemv_fwd_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_x,
+                       static_cast<long long>(x_stride), d_w, d_bias, static_cast<int>(m), k, act, vec, d_y);
+    return check_launch("gemv_fwd_kernel");
+  }
   // y[m,n] = x[m,k] * W[n,k]^T : A = x (k contiguous), B(k,n) = W[n*k + k] (k contiguous)
   return run_gemm<true, true>(d_x, x_stride, d_w, k, d_y, static_cast<int>(m), n, k, d_bias, act, nullptr, 0,
                               as_stream(stream));
@@ -490,6 +619,34 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
   }
   const size_t dw_floats = dw_ws_floats(n, k);
   int rc = RBX_OK;
+  if (n == 1) {
+    // logit head: dx = g (x) w as a streaming store, dW / db as g-weighted column sums of x (fixed-order partials)
+    if (d_dx != nullptr) {
+      const bool vec = (k % 4 == 0) && (dx_stride % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(d_dx) | reinterpret_cast<uintptr_t>(d_w)) & 15) == 0;
+      const long long per_row = vec ? k / 4 : k;
+      const unsigned blocks = outer_grid(static_cast<long long>(m) * per_row, per_row);
+      if (vec)
+        hipLaunchKernelGGL(outer_kernel<true>, dim3(blocks), dim3(256), 0, s, g, d_w, M, k, d_dx, static_cast<long long>(dx_stride));
+      else
+        hipLaunchKernelGGL(outer_kernel<false>, dim3(blocks), dim3(256), 0, s, g, d_w, M, k, d_dx, static_cast<long long>(dx_stride));
+    }
+    if (d_dw != nullptr || d_db != nullptr) {
+      // row blocks: 1024 rows (the db partial area is sized for that), more when the dW partials would not fit
+      long long rpb = 1024;
+      while (((m + rpb - 1) / rpb) * static_cast<long long>(k) > static_cast<long long>(dw_floats)) rpb *= 2;
+      const int rb = static_cast<int>((m + rpb - 1) / rpb);
+      float* part = ws + dw_floats;
+      hipLaunchKernelGGL(wcolsum_partial_kernel, dim3((k + 63) / 64, rb), dim3(256), 0, s, g, d_x,
+                         static_cast<long long>(x_stride), M, k, static_cast<int>(rpb), ws, d_db != nullptr ? part : nullptr);
+      if (d_dw != nullptr)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((k + 63) / 64)), dim3(256), 0, s, ws,
+                           static_cast<long long>(k), rb, d_dw);
+      if (d_db != nullptr)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1), dim3(256), 0, s, part, 1LL, rb, d_db);
+    }
+    return check_launch("logit head backward kernels");
+  }
   if (d_dx != nullptr) {
     // dx[m,k] = g[m,n] * W[n,k]: A = g (n contiguous = its K), B(kk=n, col=k) = W[n*k + k] (col contiguous)
     rc = run_gemm<true, false>(g, n, d_w, k, d_dx, M, k, n, nullptr, 0, nullptr, 0, s, dx_stride);

@@ -108,7 +108,10 @@ def test_mlp_golden():
                                        # tall and narrow (SASRec's [B*L, 64] x [64, 64]): the streaming dW / db kernel,
                                        # full and ragged quadrants, a row count that is no multiple of anything
                                        (20001, 64, 64, None), (8192, 33, 64, "relu"), (12345, 64, 20, None),
-                                       (9999, 7, 5, None), (10000, 192, 64, None), (8200, 130, 33, "relu"), (8192, 256, 64, None)])
+                                       (9999, 7, 5, None), (10000, 192, 64, None), (8200, 130, 33, "relu"), (8192, 256, 64, None),
+                                       # logit heads (n == 1): the streaming GEMV / outer-product / weighted column-sum kernels
+                                       (70001, 1, 400, None), (5000, 1, 1664, None), (3001, 1, 37, "relu"), (2, 1, 7, None),
+                                       (66000, 1, 30, None)])
 def test_linear_matches_torch_fp32(M, N, K, act):
     """The MFMA GEMM (all three operand layouts, split-K weight grad) against torch fp32 on CPU."""
     from recbox_amd import ops
