@@ -1437,6 +1437,35 @@ def shared_prefix(x, n, copies=2):
     return _SharedPrefix.apply(x, int(n), int(copies))
 
 
+class _SplitLast(torch.autograd.Function):
+    """x[..., :n], x[..., n:] as two CONTIGUOUS tensors; backward is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        if not 0 < n < x.shape[-1]:
+            raise ValueError("split_last: 0 < n < x.shape[-1]")
+        ctx.n, ctx.shape = int(n), tuple(x.shape)
+        return x[..., :n].contiguous(), x[..., n:].contiguous()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        ref = ga if ga is not None else gb
+        if ga is None:
+            ga = ref.new_zeros(ctx.shape[:-1] + (ctx.n,))
+        if gb is None:
+            gb = ref.new_zeros(ctx.shape[:-1] + (ctx.shape[-1] - ctx.n,))
+        return torch.cat([ga, gb], dim=-1), None
+
+
+def split_last(x, n):
+    """``x[..., :n].contiguous(), x[..., n:].contiguous()`` whose backward is ONE concatenation.  Plain slicing of a fused
+    projection (K | V out of one GEMM, SASRec's nn.MultiheadAttention in_proj) costs autograd two zero fills, two strided
+    copies and an add per backward: 477 us per block at [4096, 200, 128], against 170 us for the concatenation."""
+    return _SplitLast.apply(x, int(n))
+
+
 class _BceMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prob, target):

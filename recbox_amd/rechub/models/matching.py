@@ -154,8 +154,9 @@ class SASRec(torch.nn.Module):
         kv = ops.linear(keyval, w[E:], b[E:] if b is not None else None)          # one GEMM for K and V
         B, L = query.shape[0], query.shape[1]
         q = q.view(B, L, H, hd).transpose(1, 2)
-        k = kv[..., :E].reshape(B, L, H, hd).transpose(1, 2)
-        v = kv[..., E:].reshape(B, L, H, hd).transpose(1, 2)
+        k, v = ops.split_last(kv, E)                            # contiguous halves; backward = one concatenation
+        k = k.view(B, L, H, hd).transpose(1, 2)
+        v = v.view(B, L, H, hd).transpose(1, 2)
         o, _ = ops.attention(q, k, v, mask=None, scale=hd ** -0.5, causal=True, fill=float("-inf"))
         o = o.transpose(1, 2).reshape(B, L, E)
         return ops.linear(o, layer.out_proj.weight, layer.out_proj.bias)
