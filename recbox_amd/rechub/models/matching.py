@@ -67,8 +67,8 @@ class YoutubeDNN(torch.nn.Module):
             # calls, as youtube_dnn.py:52-70 does, would build two dense [V, D] gradients of that table and add them.
             dim = self.item_features[0].embed_dim
             both = self.embedding(x, self.user_features + self.item_features + self.neg_item_feature, squeeze_dim=True)
-            user_embedding = ops.l2_normalize(self.user_mlp(both[:, :self.user_dims].contiguous())).unsqueeze(1)
-            items = both[:, self.user_dims:].contiguous()
+            user_in, items = ops.split_last(both, self.user_dims)       # contiguous parts; backward = one concatenation
+            user_embedding = ops.l2_normalize(self.user_mlp(user_in)).unsqueeze(1)
             item_embedding = ops.l2_normalize(items.view(items.shape[0], -1, dim))
             return ops.pair_dot(user_embedding, item_embedding, scale=1.0 / self.temperature)   # [B, 1 + n_neg]
         user_embedding = self.user_tower(x)
