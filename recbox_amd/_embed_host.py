@@ -6,6 +6,8 @@ dedupes parameter holders (``share_embedding`` / ``shared_with`` alias the same
 module object) and returns an ``ops.EmbedPlan`` plus the holder modules in
 parameter order.  Plans are cached by the caller per call signature.
 """
+from collections import OrderedDict
+
 from torch import nn
 
 from . import ops
@@ -62,3 +64,56 @@ class Plan(object):
         if s.pool == POOL_CONCAT:
             v = v.reshape(out.shape[0], s.seq_len, s.dim)
         return v
+
+
+class FusedDict(OrderedDict):
+    """feature -> embedding views of one layer call that also remembers the fused ``[B, width]`` block they are cut
+    from, so that ``dict2tensor`` can hand the block out instead of stacking the views again.  The shortcut is only
+    valid while the dict still holds exactly what the layer put there: ANY mutation after ``seal`` (the FuxiCTR idiom
+    ``feature_emb_dict[f] = pooled_or_gated_emb``, ``pop``, ``del``, ``update`` ...) drops the block, and
+    ``dict2tensor`` then stacks the CURRENT values as the reference does (feature_embedding.py:169-186,
+    core/pytorch/layers/embedding.py:109-114)."""
+    fused = None
+    plan = None
+    names = ()
+    _sealed = False
+
+    def seal(self, fused, plan, names=()):
+        self.fused, self.plan, self.names, self._sealed = fused, plan, tuple(names), True
+
+    def _touch(self):
+        if self._sealed:
+            self.fused, self.plan, self.names, self._sealed = None, None, (), False
+
+    def __setitem__(self, key, value):
+        self._touch()
+        OrderedDict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        self._touch()
+        OrderedDict.__delitem__(self, key)
+
+    def pop(self, *args):
+        self._touch()
+        return OrderedDict.pop(self, *args)
+
+    def popitem(self, last=True):
+        self._touch()
+        return OrderedDict.popitem(self, last)
+
+    def clear(self):
+        self._touch()
+        OrderedDict.clear(self)
+
+    def update(self, *args, **kwargs):
+        self._touch()
+        OrderedDict.update(self, *args, **kwargs)
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            self._touch()
+        return OrderedDict.setdefault(self, key, default)
+
+    def move_to_end(self, key, last=True):
+        self._touch()
+        OrderedDict.move_to_end(self, key, last)

@@ -22,10 +22,7 @@ from .sequence import *  # noqa: F401,F403
 __all__ = ["EmbeddingLayer", "EmbeddingDictLayer"]
 
 
-class _FusedDict(OrderedDict):
-    """feature -> embedding views that also remembers the fused [B, width] tensor."""
-    fused = None
-    plan = None
+_FusedDict = host.FusedDict      # feature -> views; drops its fused block as soon as the caller edits the dict
 
 
 class EmbeddingLayer(nn.Module):
@@ -105,7 +102,8 @@ class EmbeddingDictLayer(nn.Module):
         if len(embedding_dict) == 1:
             return list(embedding_dict.values())[0]
         fused = getattr(embedding_dict, "fused", None)
-        if fused is not None and embedding_dict.plan.uniform_dim is not None \
+        if fused is not None and tuple(embedding_dict.keys()) == tuple(embedding_dict.names) \
+                and embedding_dict.plan.uniform_dim is not None \
                 and all(s.pool != POOL_CONCAT for s in embedding_dict.plan.specs):
             return fused.view(fused.shape[0], len(embedding_dict), embedding_dict.plan.uniform_dim)
         return torch.stack(list(embedding_dict.values()), dim=1)
@@ -164,5 +162,5 @@ class EmbeddingDictLayer(nn.Module):
                 clean = False
             out[feature] = emb
         if clean:
-            out.fused, out.plan = fused, plan
+            out.seal(fused, plan, names)
         return out

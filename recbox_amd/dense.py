@@ -46,6 +46,11 @@ def tower_modules(in_dim, widths, activations, dropouts, batch_norm, bias, out_d
     widths = list(widths)
     per_act = _broadcast(activations, len(widths))
     per_drop = _broadcast(dropouts, len(widths))
+    if len(per_act) < len(widths) or len(per_drop) < len(widths):
+        # the reference indexes ``hidden_activations[idx]`` / ``dropout_rates[idx]`` (mlp.py:25-37, mlp_block.py:42-58):
+        # a list shorter than hidden_units is an IndexError there, never a silently shorter tower
+        raise IndexError("list index out of range (%d hidden layers, %d activations, %d dropout rates)"
+                         % (len(widths), len(per_act), len(per_drop)))
     fan_in = in_dim
     for width, act, drop in zip(widths, per_act, per_drop):
         yield nn.Linear(fan_in, width, bias=bias)

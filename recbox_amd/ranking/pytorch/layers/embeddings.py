@@ -40,10 +40,7 @@ def get_initializer(initializer):
     return initializer
 
 
-class _FusedDict(OrderedDict):
-    fused = None
-    plan = None
-    names = ()
+_FusedDict = host.FusedDict      # feature -> views; drops its fused block as soon as the caller edits the dict
 
 
 class FeatureEmbedding(nn.Module):
@@ -236,5 +233,5 @@ class FeatureEmbeddingDict(nn.Module):
                 clean = False
             out[feature] = emb
         if clean:
-            out.fused, out.plan, out.names = fused, plan, tuple(names)
+            out.seal(fused, plan, names)
         return out

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
+from ..basic.features import DenseFeature
 from ..basic.layers import MLP, EmbeddingLayer
 
 
@@ -61,7 +62,7 @@ class YoutubeDNN(torch.nn.Module):
         self.mode = None
 
     def forward(self, x):
-        if self.mode is None:
+        if self.mode is None and not any(isinstance(f, DenseFeature) for f in self.user_features):
             # training: ONE gather launch (and one backward scatter-add) for the user side, the positive item and
             # the negatives.  The history, the positive and the negatives share one table; looking them up in two
             # calls, as youtube_dnn.py:52-70 does, would build two dense [V, D] gradients of that table and add them.
@@ -71,11 +72,16 @@ class YoutubeDNN(torch.nn.Module):
             user_embedding = ops.l2_normalize(self.user_mlp(user_in)).unsqueeze(1)
             item_embedding = ops.l2_normalize(items.view(items.shape[0], -1, dim))
             return ops.pair_dot(user_embedding, item_embedding, scale=1.0 / self.temperature)   # [B, 1 + n_neg]
+        # (a squeezed gather lays DenseFeature values out AFTER every embedding of the call -- layers.py:109-114 --, so
+        #  with dense user features the single gather above would put them behind the item / negative rows: the towers
+        #  are then looked up separately, as youtube_dnn.py:46-70 does)
         user_embedding = self.user_tower(x)
         item_embedding = self.item_tower(x)
         if self.mode == "user":
             return user_embedding
-        return item_embedding
+        if self.mode == "item":
+            return item_embedding
+        return ops.pair_dot(user_embedding, item_embedding, scale=1.0 / self.temperature)       # [B, 1 + n_neg]
 
     def user_tower(self, x):
         if self.mode == "item":

@@ -189,3 +189,79 @@ def test_listwise_losses_match_reference_fixture():
     t2 = fx2.tensors("in")
     assert_close(losses.SoftmaxCrossEntropyLoss()(t2["y_pred"], t2["y_true"]), fx2["out"]["softmax_ce"], 1e-6)
     assert_close(losses.SigmoidCrossEntropyLoss()(t2["y_pred"], t2["y_true"]), fx2["out"]["sigmoid_ce"], 1e-5)
+
+
+def test_fused_dict_drops_its_block_when_the_caller_edits_it():
+    """``dict2tensor`` may hand out the fused [B, width] block only while the dict still holds what the
+    layer put there; the FuxiCTR idiom ``feature_emb_dict[f] = new_emb`` (and pop / del / update) must make it stack the
+    CURRENT values, as feature_embedding.py:169-186 and core/pytorch/layers/embedding.py:109-114 do."""
+    from collections import OrderedDict
+    from recbox_amd._embed_host import FusedDict
+    import recbox_amd.ranking.pytorch.layers as RL
+    import recbox_amd.core.pytorch.layers as CL
+
+    class Spec(object):
+        pool = 0
+
+    class Plan(object):
+        specs = [Spec(), Spec()]
+        uniform_dim = 4
+
+    def fresh():
+        block = torch.arange(24.0).reshape(3, 8)
+        d = FusedDict()
+        d["a"], d["b"] = block[:, :4], block[:, 4:]
+        d.seal(block, Plan(), ["a", "b"])
+        return d, block
+
+    for edit in ("set", "pop", "del", "update", "popitem", "clear", "move"):
+        d, block = fresh()
+        assert d.fused is block
+        if edit == "set":
+            d["b"] = torch.ones(3, 4)
+        elif edit == "pop":
+            d.pop("a")
+        elif edit == "del":
+            del d["a"]
+        elif edit == "update":
+            d.update({"b": torch.ones(3, 4)})
+        elif edit == "popitem":
+            d.popitem()
+        elif edit == "clear":
+            d.clear()
+        else:
+            d.move_to_end("a")
+        assert d.fused is None and d.plan is None and d.names == (), edit
+
+    class FMap(object):
+        features = OrderedDict((n, {"source": "", "type": "categorical", "vocab_size": 5}) for n in ("a", "b"))
+        feature_specs = features
+        num_fields = 2
+
+    rl = RL.FeatureEmbeddingDict(FMap(), 4)
+    cl = CL.EmbeddingDictLayer(FMap(), 4)
+    for layer in (rl, cl):
+        d, block = fresh()
+        assert layer.dict2tensor(d).data_ptr() == block.data_ptr()            # untouched: the block itself, viewed
+        new_b = torch.full((3, 4), -1.0)
+        d["b"] = new_b
+        got = layer.dict2tensor(d)
+        assert torch.equal(got, torch.stack([block[:, :4], new_b], dim=1))    # the replaced value is what gets stacked
+        d, block = fresh()
+        d.pop("a")
+        got = layer.dict2tensor(d)
+        want = block[:, 4:] if layer is cl else block[:, 4:].unsqueeze(1)     # core: a single entry is returned un-stacked
+        assert torch.equal(got, want)
+
+
+def test_tower_with_too_few_per_layer_settings_raises_like_the_reference():
+    """``MLP_Layer(hidden_units=[8, 4])`` with the default ``dropout_rates=[]`` is an IndexError in the
+    reference (mlp.py:25-37 indexes ``dropout_rates[idx]``); it must not build a shorter tower silently."""
+    import recbox_amd.core.pytorch.layers as CL
+    import recbox_amd.ranking.pytorch.layers as RL
+    with pytest.raises(IndexError):
+        CL.MLP_Layer(6, hidden_units=[8, 4])
+    with pytest.raises(IndexError):
+        RL.MLP_Block(6, hidden_units=[8, 4], hidden_activations=["relu"])
+    assert len(CL.MLP_Layer(6, hidden_units=[8, 4], dropout_rates=[0, 0]).mlp) == 4
+    assert len(RL.MLP_Block(6, hidden_units=[8, 4]).mlp) == 4                 # scalar default dropout broadcasts

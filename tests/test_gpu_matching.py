@@ -524,3 +524,42 @@ def test_shared_prefix_vs_plain_slicing(rows, cols, n, copies):
     (xr.sum() * 2.0 + xr[:, :n].sum()).backward()             # broadcast (stride-0) gradients
     (parts_c[0].sum() * 2.0 + parts_c[1].sum()).backward()
     assert_close(xc.grad, xr.grad, 1e-6, "dx broadcast")
+
+
+def test_youtubednn_with_dense_user_features_matches_oracle():
+    """a squeezed gather puts DenseFeature values BEHIND every embedding of the call, so YoutubeDNN's
+    single-gather training path may not be used when the user side has dense features (youtube_dnn.py:46-56 embeds
+    ``user_features`` on their own).  Against the CPU oracle of the reference's op sequence: logits and every gradient."""
+    from oracle import torch_ref as R
+    Fe, La = _rh()
+    from recbox_amd.rechub.models.matching import YoutubeDNN
+    V, D, B, L, n_neg = 53, 8, 37, 6, 3
+
+    def feats(Sp, Sq, De):
+        uf = [Sp("user_id", 19, D), De("age"), Sq("hist", V, D, pooling="mean", shared_with="item", padding_idx=0), De("act")]
+        return uf, [Sp("item", V, D)], [Sq("neg_items", V, D, pooling="concat", shared_with="item")]
+
+    ref = R.RefYoutubeDNN(*feats(R.RefSparseFeature, R.RefSequenceFeature, R.RefDenseFeature), {"dims": [16, D]},
+                          temperature=0.1)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+    dut = YoutubeDNN(*feats(Fe.SparseFeature, Fe.SequenceFeature, Fe.DenseFeature), {"dims": [16, D]}, temperature=0.1)
+    dut.load_state_dict(ref.state_dict())
+    dut.cuda().train()
+    ref.train()
+    lens = torch.randint(0, L + 1, (B,), generator=g)
+    x = {"user_id": torch.randint(0, 19, (B,), generator=g), "age": torch.rand(B, generator=g),
+         "act": torch.randn(B, generator=g),
+         "hist": torch.randint(1, V, (B, L), generator=g) * (torch.arange(L)[None, :] < lens[:, None]),
+         "item": torch.randint(1, V, (B,), generator=g), "neg_items": torch.randint(1, V, (B, n_neg), generator=g)}
+    y0 = ref(x)
+    F.cross_entropy(y0, torch.zeros(B, dtype=torch.long)).backward()
+    y1 = dut(_cuda(x))
+    assert tuple(y1.shape) == (B, 1 + n_neg)
+    assert_close(y1, y0, TOL)
+    F.cross_entropy(y1, torch.zeros(B, dtype=torch.long, device="cuda")).backward()
+    want = dict(ref.named_parameters())
+    for n, p in dut.named_parameters():
+        assert_close(p.grad, want[n].grad, TOL, "grad " + n)

@@ -48,6 +48,32 @@ def test_feature_embedding_golden():
     assert el["c2"] is el["hist"] and type(el["c1"]) is torch.nn.Embedding and type(el["n1"]) is torch.nn.Linear
 
 
+def test_dict2tensor_stacks_the_current_values_after_an_edit():
+    """models post-process entries of the embedding dict (``feature_emb_dict[f] = gated``) and then call
+    ``dict2tensor``; the reference stacks the CURRENT values (feature_embedding.py:169-186).  The fused block of the
+    layer call must not be handed out once the dict was edited -- and gradients must flow through the edit."""
+    L = _layers()
+    fm = _FM(criteo_small_features())
+    layer = L.FeatureEmbedding(fm, 16).cuda()
+    X = _cuda(Fixture("ranking_fm").tensors("in"))
+    inner = layer.embedding_layer
+    d = inner(X)
+    whole = inner.dict2tensor(d)
+    assert whole.data_ptr() == d.fused.data_ptr()                       # untouched dict: the block itself
+    names = list(d.keys())
+    gate = torch.rand(whole.shape[0], 16, device="cuda", requires_grad=True)
+    d[names[20]] = d[names[20]] * gate
+    got = inner.dict2tensor(d)
+    want = whole.clone()
+    want[:, 20] = whole[:, 20] * gate.detach()
+    assert torch.equal(got, want)
+    got.sum().backward()
+    assert torch.equal(gate.grad, whole[:, 20].detach())
+    d2 = inner(X)
+    d2.pop(names[3])
+    assert torch.equal(inner.dict2tensor(d2), torch.cat([whole[:, :3], whole[:, 4:]], dim=1))
+
+
 def test_fm_golden():
     L = _layers()
     fx = Fixture("ranking_fm")
