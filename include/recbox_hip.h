@@ -120,6 +120,13 @@ int rbx_embed_sort(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
 int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
                   const float* d_dout, int64_t out_stride_b, const float* d_row_scale,
                   int32_t accumulate, void* d_workspace, size_t workspace_bytes, void* stream);
+/* Same, with one indirection: sample b reads its upstream gradient from row d_dout_index[b] of d_dout (int32, [batch])
+ * instead of row b.  The owner side of the sharded exchange (rbx_shard_serve below) uses it: many received lookups
+ * share one gradient row (the pooled history of a sample), which is then never expanded in memory. */
+int rbx_embed_bwd_indexed(const rbx_field_t* fields, int32_t n_fields, int64_t batch,
+                          const float* d_dout, int64_t out_stride_b, const int32_t* d_dout_index,
+                          const float* d_row_scale, int32_t accumulate, void* d_workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* ---- K4: InnerProductInteraction / rechub FM on a materialised [B,F,D] tensor ---
  * ranking/pytorch/layers/interactions/inner_product.py:40-56,
@@ -187,6 +194,56 @@ size_t rbx_route_workspace_size(int64_t n_lookups, int32_t world);
 int rbx_route(const rbx_field_t* tables, int32_t n_tables, int64_t batch, int32_t world, int64_t capacity,
               const int64_t* d_base, int64_t* d_send, int32_t* d_slot, uint8_t* d_overflow, void* d_workspace,
               size_t workspace_bytes, void* stream);
+
+/* ---- C1 (second generation): ONE exchange each way for row-sharded tables, pooled lookups reduced at the owner
+ * (csrc/rbx_shard.hip; no reference precedent -- the reference's only parallelism is nn.DataParallel / DDP, SURVEY.md
+ * 2.1 -- this is SURVEY.md 5.8 / 8e and BASELINE.json configs 3 and 4).  Per sample: n_rows single-row lookups
+ * (one-hot features and the columns of a pooling='concat' sequence: third_party/rechub/basic/layers.py:72,98-107) and
+ * n_pool <= 1 id-masked mean / sum pooled sequence (layers.py:135-148,187-210; YoutubeDNN's history,
+ * models/matching/youtube_dnn.py:46-56).  owner = id mod world, local row = d_base[owner][lookup] + id div world.
+ * Static wire format per (requester, owner) pair:
+ *   int32 chunk of rbx_shard_int_chunk() values: [cap_pool row numbers grouped by sample | n_pool * (batch + 1)
+ *     offsets | cap_rows row numbers (-1 = empty)],
+ *   fp32 chunk of rbx_shard_float_rows() rows x dim: [n_pool * batch partial sums (gradients) | cap_rows rows].
+ * The all-to-alls between the calls are the caller's (recbox_amd/comm.py over RCCL, or rbx_all_to_all).
+ *   rbx_shard_route        requester: ids -> d_send[world][int chunk]; d_slot[batch][n_rows] = wire slot of each
+ *                          single-row lookup (owner * cap_rows + rank; world * cap_rows = did not fit / out of range);
+ *                          d_inv[batch] = 1 / (valid ids + eps) (mean) or 1 (sum).  row_fields[t] / pool_field: ids,
+ *                          strides, ids_dtype, vocab (+ seq_len, mask_id, pool, eps of the pooled one) are read.
+ *                          Lookups beyond a capacity set *d_overflow; ids outside [0, vocab) set bit 0 of *d_status
+ *                          (the reference raises IndexError) and are treated as absent.
+ *   rbx_shard_serve        owner: d_recv[world][int chunk] -> d_back[world][float rows][dim] (one partial sum per
+ *                          (source, sample), one row per occupied single-row slot), plus for the backward
+ *                          d_keys[world * (cap_pool + cap_rows)] (local row of every received lookup, -1 = none) and
+ *                          d_src (row of the gradient buffer [world * float rows, dim] holding its upstream gradient):
+ *                          rbx_embed_sort over d_keys + rbx_embed_bwd_indexed(d_dout_index = d_src) is the owner's
+ *                          deterministic scatter-add.  A row number >= n_local_rows sets bit 1 of *d_status.
+ *   rbx_shard_combine_fwd  requester: places row (b, t) and the scaled sum of the world partial sums of sample b at
+ *                          d_out + b * out_stride_b + col_off[lookup] (HOST array, n_rows + n_pool entries; the
+ *                          pooled lookup is the last one): the slots of the layer's [batch, width] output block.
+ *   rbx_shard_combine_bwd  requester: the upstream gradient of those slots -> d_gsend[world][float rows][dim]. */
+typedef struct rbx_shard_geom {
+  int32_t world;
+  int32_t dim;               /* floats per row, multiple of 4 */
+  int32_t n_rows;            /* single-row lookups per sample */
+  int32_t n_pool;            /* pooled lookups per sample: 0 or 1 */
+  int64_t batch;             /* samples per rank (equal on every rank: static wire sizes) */
+  int64_t cap_rows;          /* wire slots per (requester, owner) pair for single-row lookups */
+  int64_t cap_pool;          /* ... for the ids of the pooled lookup */
+} rbx_shard_geom_t;
+size_t rbx_shard_int_chunk(const rbx_shard_geom_t* geom);
+size_t rbx_shard_float_rows(const rbx_shard_geom_t* geom);
+size_t rbx_shard_route_workspace_size(const rbx_shard_geom_t* geom, int32_t pool_seq_len);
+int rbx_shard_route(const rbx_shard_geom_t* geom, const rbx_field_t* row_fields, const rbx_field_t* pool_field,
+                    const int64_t* d_base, int32_t* d_send, int32_t* d_slot, float* d_inv, uint8_t* d_overflow,
+                    int32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream);
+int rbx_shard_serve(const rbx_shard_geom_t* geom, const int32_t* d_recv, const float* d_weight, int64_t n_local_rows,
+                    float* d_back, int32_t* d_keys, int32_t* d_src, int32_t* d_status, void* stream);
+int rbx_shard_combine_fwd(const rbx_shard_geom_t* geom, const float* d_back, const int32_t* d_slot, const float* d_inv,
+                          float* d_out, int64_t out_stride_b, const int64_t* col_off, void* stream);
+int rbx_shard_combine_bwd(const rbx_shard_geom_t* geom, const float* d_dout, int64_t dout_stride_b,
+                          const int64_t* col_off, const int32_t* d_slot, const float* d_inv, float* d_gsend,
+                          void* stream);
 size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch);
 int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                 void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream);

@@ -25,11 +25,15 @@ class Lookup(object):
 class Plan(object):
     """ops.EmbedPlan + the parameter holders + slot geometry."""
 
-    def __init__(self, lookups):
+    def __init__(self, lookups, offsets=None, width=None):
+        """offsets / width: explicit slot offsets inside a wider output row (the row-sharded layers leave holes that
+        the exchange fills: recbox_amd.sharded); default = the slots back to back."""
         self.lookups = lookups
         self.modules = []
         specs, off = [], 0
-        for lk in lookups:
+        for k, lk in enumerate(lookups):
+            if offsets is not None:
+                off = offsets[k]
             param = -1
             vocab, padding_idx = 0, None
             if lk.kind != FIELD_DENSE:
@@ -48,8 +52,8 @@ class Plan(object):
             specs.append(spec)
             off += spec.width
         self.specs = specs
-        self.width = off
-        self.plan = ops.EmbedPlan(specs, off)
+        self.width = off if width is None else width
+        self.plan = ops.EmbedPlan(specs, self.width)
         dims = set(s.dim for s in specs)
         self.uniform_dim = dims.pop() if len(dims) == 1 else None
 

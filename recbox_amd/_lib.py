@@ -39,6 +39,12 @@ class rbx_field_t(ctypes.Structure):
                 ("eps", ctypes.c_float)]
 
 
+class rbx_shard_geom_t(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_int32), ("dim", ctypes.c_int32), ("n_rows", ctypes.c_int32),
+                ("n_pool", ctypes.c_int32), ("batch", ctypes.c_int64), ("cap_rows", ctypes.c_int64),
+                ("cap_pool", ctypes.c_int64)]
+
+
 class rbx_rowcopy_t(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("row_bytes", ctypes.c_int64)]
 
@@ -46,6 +52,7 @@ class rbx_rowcopy_t(ctypes.Structure):
 _P = ctypes.c_void_p
 _FP = ctypes.POINTER(rbx_field_t)
 _RP = ctypes.POINTER(rbx_rowcopy_t)
+_GP = ctypes.POINTER(rbx_shard_geom_t)
 _u64 = ctypes.c_uint64
 _i32, _i64, _sz, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
@@ -57,6 +64,14 @@ SIGNATURES = {
     "rbx_embed_bwd_workspace_size": (_sz, [_FP, _i32, _i64]),
     "rbx_embed_sort": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P, _P]),
     "rbx_embed_bwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _P, _i32, _P, _sz, _P]),
+    "rbx_embed_bwd_indexed": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _P, _P, _i32, _P, _sz, _P]),
+    "rbx_shard_int_chunk": (_sz, [_GP]),
+    "rbx_shard_float_rows": (_sz, [_GP]),
+    "rbx_shard_route_workspace_size": (_sz, [_GP, _i32]),
+    "rbx_shard_route": (ctypes.c_int, [_GP, _FP, _FP, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "rbx_shard_serve": (ctypes.c_int, [_GP, _P, _P, _i64, _P, _P, _P, _P, _P]),
+    "rbx_shard_combine_fwd": (ctypes.c_int, [_GP, _P, _P, _P, _P, _i64, ctypes.POINTER(ctypes.c_int64), _P]),
+    "rbx_shard_combine_bwd": (ctypes.c_int, [_GP, _P, _i64, ctypes.POINTER(ctypes.c_int64), _P, _P, _P, _P]),
     "rbx_interaction_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _i32, _i32, _P, _P]),
     "rbx_interaction_bwd": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _i32, _P, _i64, _P]),
     "rbx_fm_fwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _i32, _i32, _i32, _P, _i64, _P, _P, _P, _P]),

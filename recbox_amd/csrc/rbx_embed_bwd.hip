@@ -404,6 +404,7 @@ struct GenericPolicy {
     const float* row_scale;
     long long B;
     int accumulate;        // 0: grads were pre-zeroed by the caller -> store; 1: read-modify-write
+    const int* index;      // optional: sample b reads row index[b] of dout (rbx_embed_bwd_indexed)
   };
   template <class F>
   static __device__ __forceinline__ void contribute(const Args& a, const RedField& fd, unsigned local, int lane_g,
@@ -411,7 +412,8 @@ struct GenericPolicy {
     const unsigned L = static_cast<unsigned>(fd.seq_len);
     const unsigned b = local / L;
     const unsigned l = local - b * L;
-    const float* src = a.dout + static_cast<long long>(b) * a.stride_b + fd.out_off +
+    const long long brow = (a.index != nullptr) ? static_cast<long long>(a.index[b]) : static_cast<long long>(b);
+    const float* src = a.dout + brow * a.stride_b + fd.out_off +
                        (fd.pool == RBX_POOL_CONCAT ? static_cast<long long>(l) * fd.dim : 0ll);
     float w = 1.0f;
     if (fd.pool == RBX_POOL_MEAN_VALUE || fd.pool == RBX_POOL_MEAN_ID)
@@ -561,6 +563,13 @@ extern "C" int rbx_embed_rezero(const rbx_field_t* fields, int32_t n_fields, int
 extern "C" int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_t batch, const float* d_dout,
                              int64_t out_stride_b, const float* d_row_scale, int32_t accumulate, void* d_workspace,
                              size_t workspace_bytes, void* stream) {
+  return rbx_embed_bwd_indexed(fields, n_fields, batch, d_dout, out_stride_b, nullptr, d_row_scale, accumulate, d_workspace,
+                               workspace_bytes, stream);
+}
+
+extern "C" int rbx_embed_bwd_indexed(const rbx_field_t* fields, int32_t n_fields, int64_t batch, const float* d_dout,
+                                     int64_t out_stride_b, const int32_t* d_dout_index, const float* d_row_scale,
+                                     int32_t accumulate, void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace rbx;
   if (d_dout == nullptr) return fail(RBX_ERR_INVALID, "d_dout is NULL");
   if (batch == 0) return RBX_OK;
@@ -581,11 +590,12 @@ extern "C" int rbx_embed_bwd(const rbx_field_t* fields, int32_t n_fields, int64_
     const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);
     const unsigned* vals = reinterpret_cast<const unsigned*>(ws + p.off_vals[cur]);
     const GenericPolicy::Args args = {d_dout, static_cast<long long>(out_stride_b), d_row_scale,
-                                      static_cast<long long>(batch), accumulate};
+                                      static_cast<long long>(batch), accumulate, d_dout_index};
     rc = p.vec ? dispatch_reduce<GenericPolicy, true>(p, args, keys, vals, ws, s)
                : dispatch_reduce<GenericPolicy, false>(p, args, keys, vals, ws, s);
     if (rc != RBX_OK) return rc;
   }
+  if (p.n_num > 0 && d_dout_index != nullptr) return fail(RBX_ERR_UNSUPPORTED, "embed_bwd_indexed: numeric features are not indexed");
   if (p.n_num > 0) {
     float* partial = reinterpret_cast<float*>(ws + p.off_num);
     hipLaunchKernelGGL(numeric_partial_kernel, dim3(p.num_blocks, p.n_num), dim3(256), 0, s, p.num,

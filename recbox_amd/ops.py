@@ -63,6 +63,38 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _id_column(t):
+    """An id tensor as the kernels read it: on the GPU, one of int32 / int64 / float32 / float64 (strides are free)."""
+    _require_cuda(t, "ids")
+    if t.dtype not in _DTYPE_CODE:
+        t = t.float() if t.is_floating_point() else t.long()
+    return t
+
+
+class SideWork(object):
+    """``fn()`` enqueued on the device's auxiliary stream (ordered after what the current stream holds now); ``join()``
+    orders the current stream after it.  ``result`` is whatever ``fn`` returned (tensors in it were allocated on the
+    side stream and are registered with the current one)."""
+
+    def __init__(self, device, fn, uses=()):
+        cur = torch.cuda.current_stream(device)
+        side = _side_stream(device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self.result = fn()
+        self.event = side.record_event()
+        for t in uses:
+            t.record_stream(side)
+        for t in (self.result if isinstance(self.result, (list, tuple)) else [self.result]):
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+
+    def join(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+            self.event = None
+
+
 class FieldSpec(object):
     """Static description of one feature inside an EmbedPlan."""
     __slots__ = ("name", "kind", "pool", "dim", "seq_len", "vocab", "padding_idx", "mask_id", "eps",
@@ -919,7 +951,11 @@ def _padded_rows(rows, cols, device):
     stride = (cols + 3) // 4 * 4
     if stride == cols:
         return torch.empty((rows, cols), dtype=torch.float32, device=device)
-    return torch.empty((rows, stride), dtype=torch.float32, device=device)[:, :cols]
+    # NOT a view of the wider buffer (set_ on a fresh tensor shares the storage without autograd's view tracking): a
+    # later autograd Function may fill further columns of it in place (recbox_amd.sharded._ShardLookup, mark_dirty),
+    # which autograd forbids on a view that a custom Function returned
+    buf = torch.empty(rows * stride, dtype=torch.float32, device=device)
+    return torch.empty(0, dtype=torch.float32, device=device).set_(buf.untyped_storage(), 0, (rows, cols), (stride, 1))
 
 
 class _Linear(torch.autograd.Function):

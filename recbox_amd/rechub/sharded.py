@@ -1,0 +1,285 @@
+"""Multi-GPU forms of the rechub model mirrors (BASELINE.json configs 3 and 4): one process per GPU,
+``torch.distributed`` backend "nccl" (= RCCL over xGMI), every process trains on its own slice of the global batch.
+
+The reference offers ``nn.DataParallel`` only for these models (third_party/rechub/trainers/ctr_trainer.py:41-43,
+match_trainer.py:46): every table replicated, full dense gradients gathered on GPU 0 -- a 10 M x 128 table does not
+scale that way.  Here
+
+* tables with ``vocab_size >= shard_min_vocab`` live in a ``ShardedStore`` (recbox_amd/sharded.py): ``owner = id % W``,
+  ONE all-to-all each way per step, mean/sum-pooled sequences reduced at the owner;
+* everything else -- small tables, MLP towers, BatchNorm, the FM / LR heads -- is replicated and data-parallel: the
+  dense gradients are all-reduced as ONE flat buffer, issued the moment the embedding backward starts (the towers'
+  backward is complete by then) so that it overlaps the gradient exchange and the scatter-adds;
+* BatchNorm statistics are PER REPLICA, as under the reference's ``nn.DataParallel`` (each replica normalises its own
+  slice; ctr_trainer.py:43) -- not synchronised as RecBole's DDP path does (recbole/trainer/trainer.py:61).  Running
+  statistics therefore differ slightly between ranks; checkpoint rank 0's, as DataParallel does.
+
+``ShardedEmbeddingLayer`` keeps the interface of ``EmbeddingLayer`` (``forward(x, features, squeeze_dim)``), so the
+model classes are the single-GPU ones with that layer swapped in.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _embed_host as host
+from .. import comm
+from ..sharded import ShardCall, ShardedStore
+from .basic.features import DenseFeature, SequenceFeature, SparseFeature
+from .basic.layers import FM, LR, MLP, EmbeddingLayer
+from .models.matching import YoutubeDNN
+from .models.ranking import DeepFM
+
+
+class ShardedEmbeddingLayer(EmbeddingLayer):
+    """``EmbeddingLayer`` whose large tables are row-sharded over the process group.
+
+    ``embed_dict`` holds the replicated tables (real ``nn.Embedding``, same names as on one GPU); ``store`` holds this
+    rank's rows of the sharded ones.  A layer call is one local gather launch for the replicated features plus one
+    exchange for the sharded ones, both writing into the same ``[B, width]`` block the single-GPU layer produces."""
+
+    def __init__(self, features, shard_min_vocab=100000, capacity_factor=1.25, process_group=None, local_ops=None):
+        nn.Module.__init__(self)
+        self.features = features
+        self.embed_dict = nn.ModuleDict()
+        self.n_dense = 0
+        self._plans = {}
+        self.group = process_group
+        by_name = dict((f.name, f) for f in features if not isinstance(f, DenseFeature))
+        self.sharded_tables = []                      # names of the sharded tables, in store order
+        for fea in features:
+            if isinstance(fea, DenseFeature):
+                self.n_dense += 1
+                continue
+            if fea.shared_with is not None or fea.name in self.embed_dict or fea.name in self.sharded_tables:
+                continue
+            if fea.vocab_size >= shard_min_vocab:
+                self.sharded_tables.append(fea.name)                 # (never materialised as a full table)
+            else:
+                self.embed_dict[fea.name] = fea.get_embedding_layer()
+        self.store = None
+        if self.sharded_tables:
+            dims = set(by_name[n].embed_dim for n in self.sharded_tables)
+            if len(dims) != 1:
+                raise NotImplementedError("ShardedEmbeddingLayer: the sharded tables must share one embed_dim, got %s"
+                                          % sorted(dims))
+            self.store = ShardedStore([by_name[n].vocab_size for n in self.sharded_tables], dims.pop(),
+                                      capacity_factor=capacity_factor, process_group=process_group, local_ops=local_ops)
+
+    def table_of(self, fea):
+        return fea.name if fea.shared_with is None else fea.shared_with
+
+    def forward(self, x, features, squeeze_dim=False):
+        key = (tuple(id(f) for f in features), squeeze_dim,
+               tuple(x[f.name].shape[1] if isinstance(f, SequenceFeature) else 0 for f in features))
+        cached = self._plans.get(key)
+        if cached is None:
+            cached = self._plans[key] = self._build(x, features, squeeze_dim)
+        local, call, order, n_sparse, width, seq_len, dim = cached
+        B = x[features[0].name].shape[0]
+        block = None
+        if local is not None:
+            block = local.run([x[lk.name] for lk in local.lookups], pad_rows=squeeze_dim)
+        if call is not None:
+            rows = []
+            for name, col in order["rows"]:
+                rows.append(x[name] if col is None else x[name][:, col])
+            pool = x[order["pool"]] if order["pool"] is not None else None
+            block = self.store.lookup(call, width, rows, pool, block)
+        if squeeze_dim:
+            return block
+        if seq_len is not None:
+            return block.view(B, n_sparse, seq_len, dim)
+        return block.view(B, n_sparse, dim)
+
+    def _build(self, x, features, squeeze_dim):
+        """Lay the call out exactly as EmbeddingLayer does (layers.py:66-116: sparse / sequence slots in feature order,
+        dense values behind them when squeezed), then split the slots into the local plan and the exchange."""
+        from .._lib import FIELD_CATEGORICAL, FIELD_DENSE, POOL_CONCAT, POOL_MEAN_ID, POOL_SUM_ID
+        sparse, dense_l = [], []
+        for fea in features:
+            if isinstance(fea, DenseFeature):
+                dense_l.append(fea)
+            elif isinstance(fea, (SparseFeature, SequenceFeature)):
+                sparse.append(fea)
+            else:
+                raise ValueError("unknown feature class %s" % type(fea).__name__)
+        if squeeze_dim:
+            if not sparse and not dense_l:
+                raise ValueError("The input features can note be empty")
+        elif not sparse:
+            raise ValueError("If keep the original shape:[batch_size, num_features, embed_dim], expected %s in feature "
+                             "list, got %s" % ("SparseFeatures", features))
+        lookups, offsets, off = [], [], 0
+        rows, row_src, pool, pool_src = [], [], None, None
+        dims, seq_lens, concat = set(), set(), []
+        for fea in sparse:
+            tname = self.table_of(fea)
+            dim = fea.embed_dim
+            dims.add(dim)
+            is_seq = isinstance(fea, SequenceFeature)
+            if is_seq and fea.pooling not in ("sum", "mean", "concat"):
+                raise ValueError("Sequence pooling method supports only pooling in %s, got %s." % (["sum", "mean"], fea.pooling))
+            L = x[fea.name].shape[1] if is_seq else 1
+            is_concat = is_seq and fea.pooling == "concat"
+            concat.append(is_concat)
+            if is_concat:
+                seq_lens.add(L)
+            if tname in self.sharded_tables:
+                t = self.sharded_tables.index(tname)
+                if not is_seq:
+                    rows.append((t, off))
+                    row_src.append((fea.name, None))
+                elif is_concat:
+                    for c in range(L):                       # every column is a single-row lookup
+                        rows.append((t, off + c * dim))
+                        row_src.append((fea.name, c))
+                else:
+                    if pool is not None:
+                        raise NotImplementedError("one pooled sequence over sharded tables per layer call")
+                    mask_id = fea.padding_idx if fea.padding_idx is not None else -1      # InputMask: id != -1
+                    pool = (t, off, L, fea.pooling, mask_id, 1e-16 if fea.pooling == "mean" else 0.0)
+                    pool_src = fea.name
+            else:
+                table = self.embed_dict[tname]
+                if not is_seq:
+                    lookups.append(host.Lookup(fea.name, FIELD_CATEGORICAL, table, dim))
+                else:
+                    kind = {"sum": POOL_SUM_ID, "mean": POOL_MEAN_ID, "concat": POOL_CONCAT}[fea.pooling]
+                    mask_id = fea.padding_idx if fea.padding_idx is not None else -1
+                    lookups.append(host.Lookup(fea.name, FIELD_CATEGORICAL, table, dim, pool=kind, seq_len=L,
+                                               mask_id=mask_id, eps=1e-16))
+                offsets.append(off)
+            off += dim * (L if is_concat else 1)
+        if squeeze_dim:
+            for fea in dense_l:
+                lookups.append(host.Lookup(fea.name, FIELD_DENSE, None, 1))
+                offsets.append(off)
+                off += 1
+        width = off
+        seq_len, dim = None, None
+        if not squeeze_dim:
+            if len(dims) != 1:
+                raise RuntimeError("Sizes of tensors must match except in dimension 1 (embed_dim differs across features)")
+            dim = dims.pop()
+            if any(concat):
+                if not all(concat) or len(seq_lens) != 1:
+                    raise RuntimeError("Tensors must have same number of dimensions (mixing pooling='concat' "
+                                       "with pooled/sparse features)")
+                seq_len = seq_lens.pop()
+        local = host.Plan(lookups, offsets=offsets, width=width) if lookups else None
+        call = ShardCall(rows, pool) if (rows or pool is not None) else None
+        return local, call, {"rows": row_src, "pool": pool_src}, len(sparse), width, seq_len, dim
+
+
+class DenseGradSync(object):
+    """Data-parallel gradients of the replicated parameters.
+
+    ``early``: parameters whose gradients are complete when the embedding backward STARTS (towers, heads): packed into
+    one flat buffer and all-reduced asynchronously from the store's ``on_backward_start`` hook, overlapping the
+    gradient exchange and the scatter-adds.  ``late``: the replicated tables, whose gradients come out of the embedding
+    backward itself: one more flat all-reduce in ``finish()``.  ``finish()`` also un-flattens; call it after
+    ``loss.backward()``."""
+
+    def __init__(self, early, late, group=None):
+        self.early = [p for p in early if p.requires_grad]
+        self.late = [p for p in late if p.requires_grad]
+        self.group = group
+        self.world = comm.world(group)[1]
+        self._pending = None
+
+    def start(self):
+        if self.world == 1 or not self.early:
+            return
+        grads = [p.grad for p in self.early]
+        if any(g is None for g in grads):             # e.g. a head that took no part in this loss: all-reduce later
+            return
+        flat = torch._utils._flatten_dense_tensors(grads)
+        self._pending = (flat, grads, comm.all_reduce_sum_(flat, self.group, async_op=True))
+
+    def finish(self):
+        if self.world == 1:
+            return
+        params = list(self.late)
+        if self._pending is not None:
+            flat, grads, work = self._pending
+            work.wait()
+            for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                g.copy_(r)
+            self._pending = None
+        else:
+            params = self.early + params
+        # every rank reduces the same layout: a parameter without a gradient on this rank contributes zeros
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        if grads:
+            flat = torch._utils._flatten_dense_tensors(grads)
+            comm.all_reduce_sum_(flat, self.group)
+            for p, g, r in zip(params, grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                if p.grad is None:
+                    p.grad = r.clone()
+                else:
+                    g.copy_(r)
+
+
+class _ShardedModelMixin(object):
+    def _install_sync(self):
+        emb = self.embedding
+        tables = list(emb.embed_dict.parameters())
+        skip = set(id(p) for p in tables)
+        if emb.store is not None:
+            skip.add(id(emb.store.weight))
+        towers = [p for p in self.parameters() if id(p) not in skip]
+        self.grad_sync = DenseGradSync(towers, tables, emb.group)
+        if emb.store is not None:
+            emb.store.on_backward_start = self.grad_sync.start
+
+    @property
+    def world_size(self):
+        return comm.world(self.embedding.group)[1]
+
+    def sync_grads(self):
+        """After ``(loss / world_size).backward()``: finish the all-reduces of the replicated gradients."""
+        self.grad_sync.finish()
+
+    def replicated_parameters(self):
+        skip = id(self.embedding.store.weight) if self.embedding.store is not None else None
+        return [p for p in self.parameters() if id(p) != skip]
+
+
+class ShardedYoutubeDNN(_ShardedModelMixin, YoutubeDNN):
+    """``YoutubeDNN`` (third_party/rechub/models/matching/youtube_dnn.py:14-71) with the item table row-sharded:
+    the history is mean-pooled AT THE OWNERS (one partial sum per (sample, shard) comes back), the positive and the
+    negative items travel as rows; user tower replicated, gradients all-reduced.  BASELINE.json cfg 3."""
+
+    def __init__(self, user_features, item_features, neg_item_feature, user_params, temperature=1.0,
+                 shard_min_vocab=100000, capacity_factor=1.25, process_group=None, local_ops=None):
+        torch.nn.Module.__init__(self)
+        self.user_features = user_features
+        self.item_features = item_features
+        self.neg_item_feature = neg_item_feature
+        self.temperature = temperature
+        self.user_dims = sum([fea.embed_dim for fea in user_features])
+        self.embedding = ShardedEmbeddingLayer(user_features + item_features, shard_min_vocab=shard_min_vocab,
+                                               capacity_factor=capacity_factor, process_group=process_group,
+                                               local_ops=local_ops)
+        self.user_mlp = MLP(self.user_dims, output_layer=False, **user_params)
+        self.mode = None
+        self._install_sync()
+
+
+class ShardedDeepFM(_ShardedModelMixin, DeepFM):
+    """``DeepFM`` (third_party/rechub/models/ranking/deepfm.py:14-42) data-parallel over the ranks, its large tables
+    row-sharded.  BASELINE.json cfg 4 ("1 vs 8 GPU data-parallel all-reduce")."""
+
+    def __init__(self, deep_features, fm_features, mlp_params, shard_min_vocab=100000, capacity_factor=1.25,
+                 process_group=None, local_ops=None):
+        torch.nn.Module.__init__(self)
+        self.deep_features = deep_features
+        self.fm_features = fm_features
+        self.deep_dims = sum([fea.embed_dim for fea in deep_features])
+        self.fm_dims = sum([fea.embed_dim for fea in fm_features])
+        self.linear = LR(self.fm_dims)
+        self.fm = FM(reduce_sum=True)
+        self.embedding = ShardedEmbeddingLayer(deep_features + fm_features, shard_min_vocab=shard_min_vocab,
+                                               capacity_factor=capacity_factor, process_group=process_group,
+                                               local_ops=local_ops)
+        self.mlp = MLP(self.deep_dims, **mlp_params)
+        self._install_sync()

@@ -274,3 +274,300 @@ class ShardedTables(nn.Module):
         E = packed[..., :self.embedding_dim]
         L = packed[..., self.embedding_dim] if self.with_lr else None
         return E, L
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Second generation: ONE exchange each way, pooled lookups reduced at the owner (csrc/rbx_shard.hip).
+# BASELINE.json cfg 3 (YoutubeDNN over a row-sharded 10 M x 128 item table) and cfg 4 (DeepFM, large tables
+# sharded, the rest data-parallel) run on this.
+# ------------------------------------------------------------------------------------------------------------
+class ShardCall(object):
+    """Static description of what one layer call asks of a ``ShardedStore`` per sample:
+    ``rows``  list of (table index, column offset in the output row) -- one id per sample each;
+    ``pool``  None or (table index, column offset, seq_len, "mean" | "sum", mask_id, eps) -- a padded id sequence
+              pooled with an id mask (rechub InputMask + AveragePooling / SumPooling, layers.py:135-148,187-210)."""
+
+    def __init__(self, rows, pool=None):
+        self.rows = [(int(t), int(o)) for t, o in rows]
+        self.pool = pool
+        self.T, self.P = len(self.rows), (1 if pool is not None else 0)
+        self.key = (tuple(self.rows), None if pool is None else tuple(pool))
+
+    def geometry(self, W, D, B, factor):
+        L = self.pool[2] if self.pool is not None else 0
+        cap_rows = -(-int(math.ceil(B * self.T / W * factor)) // 64) * 64 if self.T else 0
+        cap_pool = -(-int(math.ceil(B * L / W * factor)) // 64) * 64 if self.P else 0
+        return ShardGeom(W, D, self.T, self.P, B, max(cap_rows, 64) if self.T else 0, max(cap_pool, 64) if self.P else 0)
+
+
+class ShardGeom(object):
+    """Sizes of the wire format (the C side derives the same numbers: rbx_shard_int_chunk / rbx_shard_float_rows)."""
+
+    def __init__(self, W, D, T, P, B, cap_rows, cap_pool):
+        self.W, self.D, self.T, self.P, self.B, self.cap_rows, self.cap_pool = W, D, T, P, B, cap_rows, cap_pool
+        self.off_offs = cap_pool
+        self.off_rows = cap_pool + P * (B + 1)
+        self.ichunk = (self.off_rows + cap_rows + 3) // 4 * 4
+        self.frows = P * B + cap_rows
+        self.n_keys = W * (cap_pool + cap_rows)
+
+    def c_struct(self):
+        from ._lib import rbx_shard_geom_t
+        return rbx_shard_geom_t(self.W, self.D, self.T, self.P, self.B, self.cap_rows, self.cap_pool)
+
+
+class HipShardOps(object):
+    """The local work of the exchange through the C ABI (rbx_shard_* + the sorted scatter-add)."""
+
+    def __init__(self):
+        self._plans = {}
+
+    def route(self, geom, call, row_ids, pool_ids, vocabs, base, overflow, status):
+        """-> (send int32 [W * ichunk], slot int32 [B, T], inv fp32 [B])."""
+        from . import ops
+        from ._lib import POOL_MEAN_ID, POOL_SUM_ID, RBX_NO_ID, check, lib, rbx_field_t
+        dev = base.device
+        g = geom.c_struct()
+        # the wire sizes are derived twice (here and in C): they must agree before a buffer is sized by them
+        if lib.rbx_shard_int_chunk(g) != geom.ichunk or lib.rbx_shard_float_rows(g) != geom.frows:
+            raise RuntimeError("recbox_amd.sharded: wire geometry disagrees with librecbox_hip (%d/%d vs %d/%d)"
+                               % (geom.ichunk, geom.frows, lib.rbx_shard_int_chunk(g), lib.rbx_shard_float_rows(g)))
+        send = torch.empty(geom.W * geom.ichunk, dtype=torch.int32, device=dev)
+        slot = torch.empty((geom.B, geom.T), dtype=torch.int32, device=dev) if geom.T else None
+        inv = torch.empty(geom.B, dtype=torch.float32, device=dev) if geom.P else None
+        rows = (rbx_field_t * max(geom.T, 1))()
+        keep = []
+        for f, t, (tbl, _) in zip(rows, row_ids, call.rows):
+            t = ops._id_column(t)
+            keep.append(t)
+            f.ids, f.ids_stride_b, f.ids_stride_l = t.data_ptr(), t.stride(0), 0
+            f.ids_dtype, f.vocab, f.seq_len = ops._DTYPE_CODE[t.dtype], vocabs[tbl], 1
+        pool = None
+        L = 0
+        if geom.P:
+            tbl, _, L, mode, mask_id, eps = call.pool
+            t = ops._id_column(pool_ids)
+            keep.append(t)
+            pool = rbx_field_t()
+            pool.ids, pool.ids_stride_b, pool.ids_stride_l = t.data_ptr(), t.stride(0), t.stride(1)
+            pool.ids_dtype, pool.vocab, pool.seq_len = ops._DTYPE_CODE[t.dtype], vocabs[tbl], L
+            pool.pool = POOL_MEAN_ID if mode == "mean" else POOL_SUM_ID
+            pool.mask_id = RBX_NO_ID if mask_id is None else int(mask_id)
+            pool.eps = eps
+        ws_bytes = lib.rbx_shard_route_workspace_size(g, L)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        check(lib.rbx_shard_route(g, rows if geom.T else None, pool, ops._ptr(base), ops._ptr(send), ops._ptr(slot),
+                                  ops._ptr(inv), ops._ptr(overflow), ops._ptr(status), ops._ptr(ws), ws_bytes,
+                                  ops._stream()))
+        return send, slot, inv
+
+    def serve(self, geom, recv, weight, status):
+        """-> (back fp32 [W * frows, D], keys int32 [n_keys], src int32 [n_keys])."""
+        from . import ops
+        from ._lib import check, lib
+        dev = weight.device
+        back = torch.empty((geom.W * geom.frows, geom.D), dtype=torch.float32, device=dev)
+        keys = torch.empty(geom.n_keys, dtype=torch.int32, device=dev)
+        src = torch.empty(geom.n_keys, dtype=torch.int32, device=dev)
+        check(lib.rbx_shard_serve(geom.c_struct(), ops._ptr(recv), ops._ptr(weight), weight.shape[0], ops._ptr(back),
+                                  ops._ptr(keys), ops._ptr(src), ops._ptr(status), ops._stream()))
+        return back, keys, src
+
+    @staticmethod
+    def _offs(geom, call):
+        import ctypes
+        offs = [o for _, o in call.rows] + ([call.pool[1]] if call.pool is not None else [])
+        return (ctypes.c_int64 * len(offs))(*offs)
+
+    def combine_fwd(self, geom, call, back, slot, inv, out):
+        from . import ops
+        from ._lib import check, lib
+        check(lib.rbx_shard_combine_fwd(geom.c_struct(), ops._ptr(back), ops._ptr(slot), ops._ptr(inv), ops._ptr(out),
+                                        out.stride(0) if geom.B > 1 else out.shape[1], self._offs(geom, call),
+                                        ops._stream()))
+
+    def combine_bwd(self, geom, call, dout, slot, inv):
+        from . import ops
+        from ._lib import check, lib
+        gsend = torch.empty((geom.W * geom.frows, geom.D), dtype=torch.float32, device=dout.device)
+        check(lib.rbx_shard_combine_bwd(geom.c_struct(), ops._ptr(dout), dout.stride(0) if geom.B > 1 else dout.shape[1],
+                                        self._offs(geom, call), ops._ptr(slot), ops._ptr(inv), ops._ptr(gsend),
+                                        ops._stream()))
+        return gsend
+
+    def _plan(self, weight):
+        from . import ops
+        from ._lib import FIELD_CATEGORICAL, POOL_NONE
+        key = tuple(weight.shape)
+        plan = self._plans.get(key)
+        if plan is None:
+            spec = ops.FieldSpec("shard", FIELD_CATEGORICAL, weight.shape[1], 0, param=0, pool=POOL_NONE,
+                                 vocab=weight.shape[0])
+            plan = self._plans[key] = ops.EmbedPlan([spec], weight.shape[1])
+        return plan
+
+    def presort(self, weight, keys):
+        """The id sort of ``scatter`` needs the received row numbers only: it may run right after ``serve``."""
+        from . import ops
+        from ._lib import check, lib
+        n = keys.numel()
+        if n == 0:
+            return None
+        plan = self._plan(weight)
+        plan.bind_inputs([keys])
+        plan.bind_params([weight.detach()], [weight.detach()])            # placeholder grad pointer: "trainable"
+        ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
+        check(lib.rbx_embed_sort(plan.arr, 1, n, ops._ptr(ws), ws_bytes, None, ops._stream()))
+        return ws
+
+    def scatter(self, weight, keys, src, grecv, sorted_ws=None):
+        """Dense gradient of the shard: grad[keys[i]] += grecv[src[i]] (keys < 0 skipped), sorted + segmented."""
+        from . import ops
+        from ._lib import check, lib
+        n = keys.numel()
+        grad = torch.zeros_like(weight)
+        if n == 0:
+            return grad
+        plan = self._plan(weight)
+        plan.bind_inputs([keys])
+        plan.bind_params([weight.detach()], [grad])
+        ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
+        ws = sorted_ws
+        if ws is None:
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
+            check(lib.rbx_embed_sort(plan.arr, 1, n, ops._ptr(ws), ws_bytes, None, ops._stream()))
+        check(lib.rbx_embed_bwd_indexed(plan.arr, 1, n, ops._ptr(grecv), grecv.stride(0), ops._ptr(src), None, 0,
+                                        ops._ptr(ws), ws_bytes, ops._stream()))
+        return grad
+
+
+class _ShardLookup(torch.autograd.Function):
+    """The exchange as ONE autograd node: fills the sharded lookups' slots of ``block`` (the [B, width] output rows of
+    a layer call; allocated here when the call has no replicated features), backward returns the shard's dense
+    gradient and hands ``dblock`` on to the replicated lookups untouched."""
+
+    @staticmethod
+    def forward(ctx, store, call, width, block, weight, *ids):
+        W, group, lo = store.world_size, store.group, store.local_ops
+        row_ids = ids[:call.T]
+        pool_ids = ids[call.T] if call.P else None
+        B = (row_ids[0] if call.T else pool_ids).shape[0]
+        geom = call.geometry(W, store.embedding_dim, B, store.capacity_factor)
+        dev = weight.device
+        had_block = block is not None
+        if block is None:
+            if dev.type == "cuda":               # 16-byte aligned rows for the GEMM / float4 kernels that consume it
+                from . import ops
+                block = ops._padded_rows(B, width, dev)
+            else:
+                block = torch.empty((B, width), dtype=torch.float32, device=dev)
+        else:
+            ctx.mark_dirty(block)
+        status = None
+        if store.check_ids():
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+        base = store.base_for(call)
+        send, slot, inv = lo.route(geom, call, row_ids, pool_ids, store.vocabs, base, store.overflow, status)
+        recv = torch.empty_like(send)
+        comm.all_to_all_equal_into(recv, send, group).wait()                          # requests to the owners
+        back, keys, src = lo.serve(geom, recv, weight.detach(), status)
+        # the owner's id sort needs only the received row numbers: it runs beside the rows' way back
+        sort = None
+        if ctx.needs_input_grad[4]:
+            sort = store.early_sort(lo, weight, keys)
+        got = torch.empty_like(back)
+        comm.all_to_all_equal_into(got, back, group).wait()                           # rows / partial sums back
+        lo.combine_fwd(geom, call, got, slot, inv, block)
+        if status is not None and int(status.item()) != 0:
+            raise IndexError("index out of range in self")
+        ctx.store, ctx.call, ctx.geom = store, call, geom
+        ctx.had_block = had_block
+        ctx.sort = sort
+        ctx.save_for_backward(slot, inv, keys, src, weight)
+        return block
+
+    @staticmethod
+    def backward(ctx, dblock):
+        store, call, geom = ctx.store, ctx.call, ctx.geom
+        slot, inv, keys, src, weight = ctx.saved_tensors
+        lo = store.local_ops
+        if store.on_backward_start is not None:
+            store.on_backward_start()           # every consumer of this block has finished its backward by now
+        if dblock.stride(1) != 1 or dblock.dtype != torch.float32:
+            dblock = dblock.contiguous().float()
+        gsend = lo.combine_bwd(geom, call, dblock, slot, inv)
+        grecv = torch.empty_like(gsend)
+        comm.all_to_all_equal_into(grecv, gsend, store.group).wait()                  # gradients to the owners
+        ws = None
+        if ctx.sort is not None:
+            ctx.sort.join()
+            ws = ctx.sort.ws
+        grad = lo.scatter(weight, keys, src, grecv, sorted_ws=ws)
+        return (None, None, None, dblock if ctx.had_block else None, grad) + (None,) * (call.T + call.P)
+
+
+class ShardedStore(nn.Module):
+    """Tables of one embedding dimension, row-sharded together over the ranks of ``process_group``:
+    ``owner(id) = id % W``; rank r keeps, back to back in ONE weight ``[rows_r, D]``, its rows ``id // W`` of every
+    table (``base[r][t]`` = first of them).  Checkpoints hold one shard per rank.  A table has no ``padding_idx``
+    here (rechub's tables have none, initializers.py:17; the id mask of a pooled lookup is the feature's)."""
+
+    def __init__(self, vocabs, embedding_dim, capacity_factor=1.25, process_group=None, local_ops=None):
+        super().__init__()
+        rank, W = comm.world(process_group)
+        if embedding_dim % 4:
+            raise NotImplementedError("ShardedStore: embedding_dim must be a multiple of 4 (got %d)" % embedding_dim)
+        self.vocabs, self.embedding_dim = [int(v) for v in vocabs], int(embedding_dim)
+        self.group, self.rank, self.world_size = process_group, rank, W
+        counts = torch.tensor([[(v - r + W - 1) // W for v in self.vocabs] for r in range(W)], dtype=torch.long)
+        base = torch.zeros_like(counts)
+        base[:, 1:] = counts.cumsum(dim=1)[:, :-1]
+        self.register_buffer("base", base, persistent=False)                         # [W, n_tables]
+        self.register_buffer("overflow", torch.zeros((), dtype=torch.uint8), persistent=False)
+        self.rows_local = int(counts[rank].sum())
+        self.weight = nn.Parameter(torch.empty(max(self.rows_local, 1), self.embedding_dim))
+        nn.init.normal_(self.weight, std=1e-4)
+        self.capacity_factor = float(capacity_factor)
+        self.local_ops = local_ops if local_ops is not None else HipShardOps()
+        self.on_backward_start = None          # hook: the dense tower's gradients are complete (data-parallel all-reduce)
+        self._bases = {}
+
+    def check_ids(self):
+        from . import ops
+        return ops.config.check_ids
+
+    def early_sort(self, lo, weight, keys):
+        """The owner's id sort needs the received row numbers only: side stream, joined before the scatter-add."""
+        from . import ops
+        if not weight.is_cuda or not hasattr(lo, "presort"):
+            return None
+        work = ops.SideWork(weight.device, lambda: lo.presort(weight, keys), uses=(keys,))
+        work.ws = work.result
+        return work if work.ws is not None else None
+
+    def base_for(self, call):
+        """[W, T + P] int64: first local row, on every owner, of the table each lookup of ``call`` addresses."""
+        b = self._bases.get(call.key)
+        if b is None or b.device != self.base.device:
+            tbl = [t for t, _ in call.rows] + ([call.pool[0]] if call.pool is not None else [])
+            b = self._bases[call.key] = self.base[:, tbl].contiguous()
+        return b
+
+    @torch.no_grad()
+    def load_full_tables(self, tables):
+        for t, v in enumerate(self.vocabs):
+            rows = torch.arange(self.rank, v, self.world_size)
+            lo = int(self.base[self.rank, t])
+            self.weight[lo:lo + rows.numel()].copy_(tables[t][rows].to(self.weight.device))
+
+    def local_rows_of(self, t):
+        """(slice of local rows, global ids they hold) for table t on this rank."""
+        lo = int(self.base[self.rank, t])
+        ids = torch.arange(self.rank, self.vocabs[t], self.world_size)
+        return slice(lo, lo + ids.numel()), ids
+
+    def lookup(self, call, width, row_ids, pool_ids=None, block=None):
+        """Fill the slots of ``call`` in ``block`` [B, width] (None: a new block) and return it."""
+        ids = list(row_ids) + ([pool_ids] if call.P else [])
+        return _ShardLookup.apply(self, call, width, block, self.weight, *ids)

@@ -171,3 +171,107 @@ def test_single_process_is_identity_exchange():
     emb.load_full_table(full)
     ids = torch.tensor([[1, 9], [0, 4]])
     assert torch.equal(emb(ids), full[ids])
+
+
+# ---- second generation exchange: ShardedStore (one exchange each way, pooled lookups reduced at the owner) -------------
+def _store_case(rank, world):
+    """A layer call over two sharded tables: three single-row lookups (two of table 0, one of table 1) and a mean-pooled
+    history over table 0 -- the shape of YoutubeDNN's item side (youtube_dnn.py:46-70) plus a second table."""
+    from recbox_amd.sharded import ShardCall
+    vocabs, D, B, L = [37, 13], 8, 11, 5
+    call = ShardCall([(0, 8), (0, 16), (1, 24)], pool=(0, 0, L, "mean", 0, 1e-16))
+    g = torch.Generator().manual_seed(7)
+    full = [torch.randn(v, D, generator=g) for v in vocabs]
+    gi = torch.Generator().manual_seed(200 + rank)
+    lens = torch.randint(0, L + 1, (B,), generator=gi)
+    hist = torch.randint(1, vocabs[0], (B, L), generator=gi) * (torch.arange(L)[None, :] < lens[:, None])
+    rows = [torch.randint(0, vocabs[0], (B,), generator=gi), torch.randint(0, vocabs[0], (B,), generator=gi),
+            torch.randint(0, vocabs[1], (B,), generator=gi)]
+    R = torch.randn(B, 32, generator=gi)
+    return vocabs, D, B, L, call, full, hist, rows, R
+
+
+def _store_reference(full, hist, rows, D):
+    """What the single-GPU layer computes on full tables (rechub EmbeddingLayer: id-masked mean, eps 1e-16)."""
+    mask = (hist != 0).float()
+    pooled = (full[0][hist] * mask.unsqueeze(-1)).sum(dim=1) / (mask.sum(dim=1, keepdim=True) + 1e-16)
+    return torch.cat([pooled, full[0][rows[0]], full[0][rows[1]], full[1][rows[2]]], dim=1)
+
+
+def _store_worker(rank, world, port, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from shard_oracle import OracleShardOps
+        from recbox_amd import ops
+        from recbox_amd.sharded import ShardedStore
+        vocabs, D, B, L, call, full, hist, rows, R = _store_case(rank, world)
+        store = ShardedStore(vocabs, D, capacity_factor=3.0, local_ops=OracleShardOps())
+        store.load_full_tables(full)
+        old = ops.config.check_ids
+        ops.config.check_ids = True
+        try:
+            out = store.lookup(call, 32, rows, hist)
+            want = _store_reference(full, hist, rows, D)
+            assert torch.allclose(out, want, atol=1e-6), "block differs: %g" % (out - want).abs().max()
+            assert torch.equal(out[:, 8:], want[:, 8:]), "single rows must be exact"
+            (out * R).sum().backward()
+            assert not bool(store.overflow)
+            # reference: dense grads of the FULL tables from ALL ranks' batches, then this rank's rows
+            leaves = [f.clone().requires_grad_() for f in full]
+            for r in range(world):
+                _, _, _, _, _, _, h_r, rows_r, R_r = _store_case(r, world)
+                (_store_reference(leaves, h_r, rows_r, D) * R_r).sum().backward()
+            for t in range(len(vocabs)):
+                sl, owned = store.local_rows_of(t)
+                assert torch.allclose(store.weight.grad[sl], leaves[t].grad[owned], atol=1e-5), "shard grad, table %d" % t
+            # an id outside [0, vocab) is an IndexError (the reference's nn.Embedding raises), on every rank or none
+            bad = [r.clone() for r in rows]
+            bad[2][0] = vocabs[1]
+            try:
+                store.lookup(call, 32, bad, hist)
+                raised = False
+            except IndexError:
+                raised = True
+            assert raised
+            # a history with more ids for one owner than its capacity raises the overflow flag (never silently dropped)
+            tight = ShardedStore(vocabs, D, capacity_factor=1.0, local_ops=OracleShardOps())
+            one_owner = torch.full((64, L), world if world < vocabs[0] else 0)      # every id -> owner 0
+            tight.lookup(call, 32, [r.repeat(6)[:64] for r in rows], one_owner)
+            flag = torch.tensor([float(bool(tight.overflow))])
+            dist.all_reduce(flag)
+            assert (flag.item() > 0) == (world > 1)
+        finally:
+            ops.config.check_ids = old
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_store_exchange_gloo(world):
+    port = _free_port()
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_store_worker, args=(world, port, result), nprocs=world, join=True)
+    assert dict(result) == {r: "ok" for r in range(world)}
+
+
+def test_sharded_store_single_process():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from shard_oracle import OracleShardOps
+    from recbox_amd.sharded import ShardedStore
+    vocabs, D, B, L, call, full, hist, rows, R = _store_case(0, 1)
+    store = ShardedStore(vocabs, D, local_ops=OracleShardOps())
+    store.load_full_tables(full)
+    out = store.lookup(call, 32, rows, hist)
+    assert torch.allclose(out, _store_reference(full, hist, rows, D), atol=1e-6)
+    (out * R).sum().backward()
+    leaves = [f.clone().requires_grad_() for f in full]
+    (_store_reference(leaves, hist, rows, D) * R).sum().backward()
+    assert torch.allclose(store.weight.grad[:vocabs[0]], leaves[0].grad, atol=1e-5)
+    assert torch.allclose(store.weight.grad[vocabs[0]:], leaves[1].grad, atol=1e-5)

@@ -175,3 +175,115 @@ def test_bench_script_runs_its_two_rank_path():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert rec["value"] > 0 and rec["config"]["global_batch"] == 2 * 8192
     assert "row-sharded" in rec["config"]["parallelism"] and "overflow=False" in rec["config"]["exchange"]
+
+
+# ---- BASELINE.json configs 3 and 4 in their multi-GPU form: ranks sharing ONE GPU over gloo ------------------------------
+def _bn_eval(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.eval()
+
+
+def _model_worker(rank, world, port, which, bn_mode, result):
+    """``which`` in {"youtubednn", "deepfm"}: the sharded / data-parallel model on this rank's slice against the
+    single-GPU mirror on the GLOBAL batch.  bn_mode "eval": BatchNorm uses its running statistics, so the towers do not
+    depend on how the batch is split and the two must agree to 1e-5 (loss, every gradient, the shard's rows of the table
+    gradients).  bn_mode "replica": training-mode BatchNorm with PER-REPLICA statistics (the reference's nn.DataParallel
+    semantics, ctr_trainer.py:43): the reference is then the single-GPU model run on every slice in turn, gradients
+    averaged."""
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        import torch.nn.functional as F
+        from conftest import assert_close
+        from test_gpu_shard import _rh, _seed_params, _youtube_batch, _youtube_feats
+        torch.cuda.set_device(0)
+        Fe = _rh()
+        B = 96                                           # per rank
+        if which == "youtubednn":
+            from recbox_amd.rechub.models.matching import YoutubeDNN
+            from recbox_amd.rechub.sharded import ShardedYoutubeDNN
+            V, D, L, n_neg = 1501, 16, 7, 3
+            ref = YoutubeDNN(*_youtube_feats(Fe, V, D), {"dims": [32, D]}, temperature=0.1).cuda()
+            _seed_params(ref)
+            dut = ShardedYoutubeDNN(*_youtube_feats(Fe, V, D), {"dims": [32, D]}, temperature=0.1, shard_min_vocab=500,
+                                    capacity_factor=2.0).cuda()
+            sharded = ["item"]
+            xg = {k: v.cuda() for k, v in _youtube_batch(world * B, V, L, n_neg, 11).items()}
+            target = torch.zeros(world * B, dtype=torch.long, device="cuda")
+
+            def loss_of(model, x, sl):
+                return F.cross_entropy(model(x), target[sl])
+        else:
+            from recbox_amd.rechub.models.ranking import DeepFM
+            from recbox_amd.rechub.sharded import ShardedDeepFM
+            vocabs, D = [7, 900, 31, 1200, 5, 640], 16
+
+            def feats():
+                dense = [Fe.DenseFeature("I%d" % i) for i in range(3)]
+                sparse = [Fe.SparseFeature("C%d" % i, v, D) for i, v in enumerate(vocabs)]
+                return dense + sparse, sparse
+
+            mlp = {"dims": [24, 16], "dropout": 0.0, "activation": "relu"}
+            ref = DeepFM(*feats(), mlp).cuda()
+            _seed_params(ref)
+            dut = ShardedDeepFM(*feats(), mlp, shard_min_vocab=600, capacity_factor=2.0).cuda()
+            sharded = ["C1", "C3", "C5"]
+            g = torch.Generator().manual_seed(13)
+            xg = {"I%d" % i: torch.rand(world * B, generator=g).cuda() for i in range(3)}
+            for i, v in enumerate(vocabs):
+                xg["C%d" % i] = torch.randint(0, v, (world * B,), generator=g).cuda()
+            target = (torch.rand(world * B, generator=g) < 0.3).float().cuda()
+
+            def loss_of(model, x, sl):
+                return F.binary_cross_entropy(model(x), target[sl])
+        assert dut.embedding.sharded_tables == sharded and dut.world_size == world
+        sd = ref.state_dict()
+        full = [sd.pop("embedding.embed_dict.%s.weight" % n) for n in sharded]
+        missing, unexpected = dut.load_state_dict(sd, strict=False)
+        assert missing == ["embedding.store.weight"] and not unexpected
+        dut.embedding.store.load_full_tables(full)
+        if bn_mode == "eval":
+            _bn_eval(ref)
+            _bn_eval(dut)
+            loss_ref = loss_of(ref, xg, slice(None))
+            loss_ref.backward()
+        else:
+            loss_ref = 0.0
+            for r in range(world):
+                sl = slice(r * B, (r + 1) * B)
+                part = loss_of(ref, {k: v[sl] for k, v in xg.items()}, sl) / world
+                part.backward()
+                loss_ref = loss_ref + part.detach()
+        mine = slice(rank * B, (rank + 1) * B)
+        loss = loss_of(dut, {k: v[mine].contiguous() for k, v in xg.items()}, mine)
+        (loss / world).backward()
+        dut.sync_grads()
+        torch.cuda.synchronize()
+        assert not bool(dut.embedding.store.overflow)
+        mean_loss = (loss.detach() / world).reshape(1).clone()
+        dist.all_reduce(mean_loss)
+        assert_close(mean_loss, loss_ref.reshape(1), 1e-5, "loss")
+        want = dict(ref.named_parameters())
+        store = dut.embedding.store
+        for n, p in dut.named_parameters():
+            if n == "embedding.store.weight":
+                for t, name in enumerate(sharded):
+                    sl, owned = store.local_rows_of(t)
+                    assert_close(p.grad[sl], want["embedding.embed_dict.%s.weight" % name].grad[owned.cuda()], 1e-5,
+                                 "shard of " + name)
+            else:
+                assert p.grad is not None, n
+                assert_close(p.grad, want[n].grad, 1e-5, "grad " + n)
+        result.put((rank, "ok"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which,bn_mode,world", [("youtubednn", "eval", 2), ("youtubednn", "replica", 2),
+                                                 ("youtubednn", "eval", 3), ("deepfm", "eval", 2),
+                                                 ("deepfm", "replica", 2), ("deepfm", "eval", 3)])
+def test_sharded_models_on_one_gpu_equal_single_gpu_models(which, bn_mode, world):
+    """cfg 3 (YoutubeDNN, item table row-sharded, history pooled at the owners) and cfg 4 (DeepFM data-parallel, large
+    tables sharded) with 2 / 3 ranks: every HIP piece of the N>1 step with a real exchange (rows staged through the host
+    over gloo) == the single-GPU model on the global batch."""
+    assert _spawn(_model_worker, world, which, bn_mode) == {r: "ok" for r in range(world)}
