@@ -1,5 +1,14 @@
 #!/usr/bin/env python
-"""bench.py -- FM (recbox.ranking) forward+backward on a Criteo-shaped batch.
+"""bench.py -- the embedding + feature-interaction hot path, forward+backward, on synthetic Criteo-shaped batches.
+
+    python bench.py [--config fm|youtubednn|deepfm|sasrec] --gpus N --steps K --warmup W
+
+--config fm (the default: BASELINE.json configs[1], the configuration the headline metric is quoted on) is described
+below; youtubednn / deepfm / sasrec are configs[2..4] (see `MODEL_CONFIGS`): with --gpus N > 1 the first two run in
+their multi-GPU form (item table / large tables row-sharded over the ranks with one RCCL all-to-all each way, the rest
+data-parallel with one flat all-reduce), sasrec runs N independent replicas' worth of data-parallel steps.
+
+FM (recbox.ranking) forward+backward on a Criteo-shaped batch.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`
 prints ONE JSON line from rank 0.  A "step" is one pass of the hot path over one
@@ -140,12 +149,351 @@ def measured_traffic(path, kernel):
         return None
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2..4]: the rechub model mirrors (SURVEY.md 8d shapes)
+# ---------------------------------------------------------------------------------------------------------------
+MODEL_CONFIGS = {
+    "youtubednn": "YoutubeDNN two-tower (rechub), ONE shared item table 10 M x 128 (history <= 50 mean-pooled + 1 positive + 4 "
+                  "negatives per sample), user MLP 256-128 with BatchNorm, temperature 0.02, CE over [B, 5]",
+    "deepfm": "DeepFM (rechub) on Criteo-shaped 26 sparse + 13 dense fields, dim 64, MLP 3 x 400 with BatchNorm, dropout 0",
+    "sasrec": "SASRec (rechub), 1 M items, dim 64, seq_len 200, 2 blocks, 1 head, dropout 0, pos/neg log-sigmoid loss",
+}
+FP32_MFMA_PEAK = 157.3        # TFLOP/s dense, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md: no TF32 on gfx950; bf16 would break 1e-4)
+
+
+def init_weights_device(model, dev, seed, rank, std=0.1, big=1 << 22):
+    """Replicated parameters from a CPU generator (identical on every rank); tables / shards with more than `big`
+    elements from a device generator (seeded per rank: every rank holds different rows)."""
+    g = torch.Generator().manual_seed(seed)
+    gd = torch.Generator(device=dev).manual_seed(seed * 1000 + rank)
+    with torch.no_grad():
+        for _, p in sorted(model.named_parameters()):
+            if p.numel() > big:
+                p.copy_(torch.randn(p.shape, generator=gd, device=dev) * std)
+            else:
+                p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
+
+
+def _youtube_features(V, D):
+    from recbox_amd.rechub.basic.features import SequenceFeature, SparseFeature
+    return ([SequenceFeature("hist", V, D, pooling="mean", shared_with="item", padding_idx=0)],
+            [SparseFeature("item", V, D)],
+            [SequenceFeature("neg_items", V, D, pooling="concat", shared_with="item")])
+
+
+def _youtube_batch(B, V, L, n_neg, seed, dist, dev):
+    g = torch.Generator().manual_seed(seed)
+
+    def ids(shape):
+        if dist == "zipf":
+            return torch.floor(float(V - 1) ** torch.rand(shape, generator=g, dtype=torch.float64)).long().clamp(1, V - 1)
+        return torch.randint(1, V, shape, generator=g)
+
+    lens = torch.randint(1, L + 1, (B,), generator=g)                     # U{1..50}, padded with id 0 (SURVEY 8d)
+    hist = ids((B, L)) * (torch.arange(L)[None, :] < lens[:, None])
+    return {"hist": hist.to(dev), "item": ids((B,)).to(dev), "neg_items": ids((B, n_neg)).to(dev)}
+
+
+def _deepfm_features(D):
+    from recbox_amd.rechub.basic.features import DenseFeature, SparseFeature
+    dense = [DenseFeature("I%d" % i) for i in range(N_DENSE)]
+    sparse = [SparseFeature("C%d" % i, v + 1, D) for i, v in enumerate(CRITEO_VOCABS)]
+    return dense, sparse
+
+
+def _deepfm_batch(B, seed, dist, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = {}
+    for i in range(N_DENSE):
+        x["I%d" % i] = torch.rand(B, generator=g).to(dev)
+    for i, v in enumerate(CRITEO_VOCABS):
+        if dist == "zipf":
+            x["C%d" % i] = torch.floor(float(v) ** torch.rand(B, generator=g, dtype=torch.float64)).long().clamp(1, v).to(dev)
+        else:
+            x["C%d" % i] = torch.randint(1, v + 1, (B,), generator=g).to(dev)
+    x["label"] = (torch.rand(B, generator=g) < 0.25).float().to(dev)
+    return x
+
+
+def _sasrec_features(V, D):
+    from recbox_amd.rechub.basic.features import SequenceFeature
+    return [SequenceFeature("seq", V, D, pooling="concat"),
+            SequenceFeature("pos", V, D, pooling="concat", shared_with="seq"),
+            SequenceFeature("neg", V, D, pooling="concat", shared_with="seq")]
+
+
+def _sasrec_batch(B, V, L, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(20, L + 1, (B,), generator=g)                    # U{20..200}, left-aligned, 0 pad (SURVEY 8d)
+    keep = torch.arange(L)[None, :] < lens[:, None]
+    return {"seq": (torch.randint(1, V, (B, L), generator=g) * keep).to(dev),
+            "pos": (torch.randint(1, V, (B, L), generator=g) * keep).to(dev),
+            "neg": (torch.randint(1, V, (B, L), generator=g) * keep).to(dev),
+            "weight": (keep.float() / keep.sum().float()).to(dev)}          # masked mean without boolean indexing
+
+
+def _sasrec_loss(model, x):
+    """-mean over the real positions of log sigmoid(pos) + log(1 - sigmoid(neg)) (sasrec.py:100-107 + the BPR-style
+    pos/neg objective of the rechub trainer), as a weighted sum so that the step has static shapes (graph capture)."""
+    import torch.nn.functional as F
+    pos, neg = model(x)
+    w = x["weight"]
+    return -((F.logsigmoid(pos) + F.logsigmoid(-neg)) * w).sum()
+
+
+def model_cpu_baseline(cfg, args, budget_s):
+    """The oracle's restatement of the same model (ATen CPU ops, the reference's op sequence) on this box's host cores:
+    a bounded sample of the same workload."""
+    import torch.nn.functional as F
+    from oracle import torch_ref as R
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)
+    torch.set_num_threads(threads)
+    B = args.batch
+    if cfg == "youtubednn":
+        V = args.items or 10_000_000
+        uf, itf, negf = _youtube_features(V, 128)
+        model = R.RefYoutubeDNN(uf, itf, negf, {"dims": [256, 128], "activation": "relu"}, temperature=0.02)
+        x = _youtube_batch(B, V, 50, 4, 1, args.dist, "cpu")
+        tgt = torch.zeros(B, dtype=torch.long)
+        loss_of = lambda: F.cross_entropy(model(x), tgt)                                  # noqa: E731
+        what = "B=%d, table %d x 128" % (B, V)
+    elif cfg == "deepfm":
+        dense, sparse = _deepfm_features(64)
+        model = R.RefDeepFM(dense + sparse, sparse, {"dims": [400, 400, 400], "dropout": 0.0, "activation": "relu"})
+        x = _deepfm_batch(B, 1, args.dist, "cpu")
+        loss_of = lambda: F.binary_cross_entropy(model(x), x["label"])                    # noqa: E731
+        what = "B=%d, dim 64" % B
+    else:
+        B = min(B, 512)
+        V = args.items or 1_000_000
+        model = R.RefSASRec(_sasrec_features(V, 64), max_len=200, dropout_rate=0.0, num_blocks=2, num_heads=1)
+        x = _sasrec_batch(B, V, 200, 1, "cpu")
+        loss_of = lambda: _sasrec_loss(model, x)                                          # noqa: E731
+        what = "B=%d (of %d), 1 M items, L=200" % (B, args.batch)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.normal_(0.0, 0.1)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss_of().backward()
+
+    step()
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 10:
+            break
+    return {"value": B * n / el, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of the same model (%s) on torch CPU ops, %d of %d hardware threads" % (n, what, threads, ncpu)}
+
+
+def run_model_config(args, rank, world, dev):
+    """configs[2..4].  N = 1: the single-GPU mirror, whole step replayed as one hipGraph (persistent dense gradients).
+    N > 1 (or --force-sharded): youtubednn / deepfm in their sharded + data-parallel form (eager launches: the
+    collectives sit inside the autograd node), sasrec data-parallel with one flat all-reduce."""
+    import torch.nn.functional as F
+    from recbox_amd import comm, ops
+    cfg = args.config
+    ops.config.check_ids = False
+    sharded = world > 1 or args.force_sharded
+    B, K = args.batch, max(args.rotate, 1)
+    factor = args.capacity_factor or 1.25
+    note = {}
+    # (parameters are created on the GPU: a 5 GB table built on the host first is slow)
+    if cfg == "youtubednn":
+        V, D, L, n_neg = args.items or 10_000_000, 128, 50, 4
+        feats = _youtube_features(V, D)
+        params = {"dims": [256, 128], "activation": "relu"}
+        with torch.device(dev):
+            if sharded:
+                from recbox_amd.rechub.sharded import ShardedYoutubeDNN
+                model = ShardedYoutubeDNN(*feats, params, temperature=0.02, capacity_factor=factor)
+            else:
+                from recbox_amd.rechub.models.matching import YoutubeDNN
+                model = YoutubeDNN(*feats, params, temperature=0.02)
+        batches = [_youtube_batch(B, V, L, n_neg, 1 + rank + 1000 * k, args.dist, dev) for k in range(K)]
+        target = torch.zeros(B, dtype=torch.long, device=dev)
+        loss_of = lambda x: F.cross_entropy(model(x), target)                          # noqa: E731
+    elif cfg == "deepfm":
+        D = 64
+        dense, sparse = _deepfm_features(D)
+        mlp = {"dims": [400, 400, 400], "dropout": 0.0, "activation": "relu"}
+        with torch.device(dev):
+            if sharded:
+                from recbox_amd.rechub.sharded import ShardedDeepFM
+                model = ShardedDeepFM(dense + sparse, sparse, mlp, shard_min_vocab=args.shard_min_vocab,
+                                      capacity_factor=factor)
+            else:
+                from recbox_amd.rechub.models.ranking import DeepFM
+                model = DeepFM(dense + sparse, sparse, mlp)
+        batches = [_deepfm_batch(B, 1 + rank + 1000 * k, args.dist, dev) for k in range(K)]
+        loss_of = lambda x: F.binary_cross_entropy(model(x), x["label"])               # noqa: E731
+    else:
+        V, D, L = args.items or 1_000_000, 64, 200
+        from recbox_amd.rechub.models.matching import SASRec
+        with torch.device(dev):
+            model = SASRec(_sasrec_features(V, D), max_len=L, dropout_rate=0.0, num_blocks=2, num_heads=1)
+        batches = [_sasrec_batch(B, V, L, 1 + rank + 1000 * k, dev) for k in range(K)]
+        loss_of = lambda x: _sasrec_loss(model, x)                                     # noqa: E731
+    model.to(dev).train()
+    init_weights_device(model, dev, 0, rank)
+    params = list(model.parameters())
+    x = dict((k, v.clone()) for k, v in batches[0].items())
+
+    def refill(i):
+        if K > 1:
+            for k, v in batches[i % K].items():
+                x[k].copy_(v)
+
+    dp_flat = None
+    if sharded and not hasattr(model, "sync_grads") and world > 1:
+        dp_flat = [p for p in params if p.requires_grad]
+
+    def eager_step():
+        for p in params:
+            p.grad = None
+        loss = loss_of(x)
+        if sharded:
+            (loss / world).backward()                     # global-mean loss: shard owners sum every rank's contributions
+            if hasattr(model, "sync_grads"):
+                model.sync_grads()
+            elif dp_flat is not None:                     # plain data parallel: ONE flat all-reduce of every gradient
+                flat = torch._utils._flatten_dense_tensors([p.grad for p in dp_flat])
+                comm.all_reduce_sum_(flat)
+                for p, r in zip(dp_flat, torch._utils._unflatten_dense_tensors(flat, [p.grad for p in dp_flat])):
+                    p.grad.copy_(r)
+        else:
+            loss.backward()
+        return loss
+
+    step, graph_note = eager_step, "eager launches"
+    persistent = (not args.fresh_grads) and not sharded and cfg in ("youtubednn", "deepfm")
+    if not args.eager and not sharded:
+        from recbox_amd.graph import GraphedStep
+        try:
+            # every table of youtubednn / deepfm feeds exactly ONE lookup per step: the dense gradients may stay in a
+            # persistent buffer of which only the previous step's rows are cleared (ops.config.reuse_grad_buffers = "all")
+            step = GraphedStep(eager_step, warmup=3, reuse_grads="all" if persistent else False)
+            graph_note = "hipGraph replay"
+        except Exception as exc:
+            print("[bench] hipGraph capture failed (%s: %s); launching the step eagerly" % (type(exc).__name__, exc),
+                  file=sys.stderr)
+            torch.cuda.synchronize()
+            step = eager_step
+    for i in range(args.warmup):
+        refill(i)
+        step()
+    # ---- the dominant kernel of the config and its algorithmic work per launch (DESIGN.md section 5) ----
+    if cfg == "youtubednn":
+        nnz = sum(int((b["hist"] != 0).sum()) for b in batches) / float(K)
+        lookups = nnz + B * (1 + n_neg)
+        if sharded:
+            want = lambda m: m[0] == "shard_serve"                                        # noqa: E731
+            kname = "shard_serve_kernel<32,1> (owner-side gather + pooling of the received lookups)"
+            # rows read + int32 row numbers + offsets + partial sums and item rows written
+            work = lookups * (D * 4 + 4) + world * (B + 1) * 4 + (world * B + B * (1 + n_neg)) * D * 4
+        else:
+            want = lambda m: m[0] == "embed_fwd" and m[3] == B                            # noqa: E731
+            kname = "embed_seq_kernel<64,2,1,true> + embed_fwd_kernel (rbx_embed_fwd: history pooled in the gather)"
+            work = lookups * (D * 4 + 8) + B * (2 + n_neg) * D * 4
+        roof = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s"}
+    elif cfg == "deepfm":
+        K1 = len(CRITEO_VOCABS) * 64 + N_DENSE
+        want = lambda m: m[0] == "linear_fwd" and m[3] == K1                              # noqa: E731
+        kname = "gemm_f32_kernel (+ narrow tail): tower layer 1 forward, [B, %d] x [400, %d]^T on v_mfma_f32_32x32x2_f32" % (K1, K1)
+        work = 2.0 * B * 400 * K1
+        roof = {"bound": "mfma", "peak": FP32_MFMA_PEAK * 1e3, "unit": "GFLOP/s"}
+    else:
+        want = lambda m: m[0] == "attn_bwd"                                               # noqa: E731
+        kname = "attn_mfma_bwd_q/kv_kernel<64> (causal attention backward, L=200, d=64)"
+        work = 5.0 * B * 200 * 200 * 64                                                   # 5 causal-halved L x L x d GEMMs
+        roof = {"bound": "mfma", "peak": FP32_MFMA_PEAK * 1e3, "unit": "GFLOP/s"}
+    timer = ops.KernelTimer(want)
+    if step is eager_step:
+        ops.kernel_timer = timer
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        refill(args.warmup + i)
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    el = time.perf_counter() - t0
+    if step is not eager_step:
+        # the replay cannot be bracketed: time the dominant kernel with HIP events over eager steps queued behind fills
+        n_timed = min(args.steps, 10)
+        ballast = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        for _ in range(40):
+            ballast.zero_()
+        ops.kernel_timer = timer
+        for i in range(n_timed):
+            refill(args.warmup + args.steps + i)
+            eager_step()
+        torch.cuda.synchronize()
+        del ballast
+    ops.kernel_timer = None
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    overflow = False
+    store = getattr(getattr(model, "embedding", None), "store", None)
+    if store is not None:
+        flag = store.overflow.float().reshape(1).clone()
+        if world > 1:
+            torch.distributed.all_reduce(flag)
+        overflow = bool(flag.item() > 0)
+    if rank != 0:
+        return
+    kms = timer.mean_ms()
+    if kms:
+        roof.update({"achieved": work / (kms * 1e-3) / 1e9, "kernel": kname, "kernel_ms": kms, "traffic": None,
+                     ("algorithmic_bytes_per_launch" if roof["bound"] == "hbm" else "algorithmic_flop_per_launch"): work,
+                     "inputs": ("%d distinct batches rotated through the static buffers" % K) if K > 1 else "one batch replayed"})
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        if roof["unit"] == "GFLOP/s":                       # report TFLOP/s as the contract asks
+            roof.update({"unit": "TFLOP/s", "achieved": roof["achieved"] / 1e3, "peak": roof["peak"] / 1e3})
+    else:
+        roof = None
+    par = "dp1"
+    if sharded:
+        par = {"youtubednn": "item table row-sharded over %d ranks (all-to-all, history pooled at the owners) + dp%d tower",
+               "deepfm": "dp%d, tables >= %d rows row-sharded over the ranks (all-to-all), flat all-reduce of the rest" % (world, args.shard_min_vocab) + "%.0s",
+               "sasrec": "dp%d (replicated model, one flat all-reduce)%.0s"}[cfg] % ((world, world) if cfg == "youtubednn" else (world,))
+    out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
+           "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s; batch %d per GPU, %s ids (%s), %s, dense-grad autograd contract (%s), no optimiser step"
+                                  % (MODEL_CONFIGS[cfg], B, args.dist,
+                                     ("%d distinct batches rotated" % K) if K > 1 else "one batch replayed", graph_note,
+                                     "persistent grad buffers, rows of the previous step re-zeroed" if persistent
+                                     else "fresh zero-filled grads every step"),
+                      "global_batch": B * world, "parallelism": par},
+           "roofline": roof}
+    if store is not None:
+        out["config"]["exchange"] = "padded capacity_factor=%g, overflow=%s" % (factor, overflow)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = model_cpu_baseline(cfg, args, args.cpu_seconds)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=["fm"] + sorted(MODEL_CONFIGS), default="fm",
+                    help="fm = BASELINE.json configs[1] (the headline metric); the others are configs[2..4]")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=65536, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 65536; sasrec 4096)")
     ap.add_argument("--dim", type=int, default=16)
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -170,7 +518,10 @@ def main():
                          "batch keeps its rows in the 256 MB Infinity Cache); 0/1 = replay one batch")
     ap.add_argument("--path", choices=["fused", "layers"], default="fused",
                     help="fused: FM model body in rbx_fm_fwd/bwd; layers: drop-in layers composed as the reference does")
+    ap.add_argument("--items", type=int, default=None, help="youtubednn: rows of the item table (10 M); sasrec: items (1 M)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 4096 if args.config == "sasrec" else 65536
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -189,6 +540,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.config != "fm":
+        run_model_config(args, rank, world, dev)
+        if world > 1 or args.force_sharded:
+            torch.distributed.destroy_process_group()
+        return
 
     from recbox_amd import comm, ops
     from recbox_amd.ranking.pytorch.models import FM, ShardedFM

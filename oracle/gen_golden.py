@@ -354,6 +354,31 @@ def gen_rechub_models(B=64):
                              "g": grads_of(model)})
 
 
+def gen_rechub_sasrec_d64(B=2, L=200, D=64, V=97):
+    """BASELINE.json cfg 5's shape (D = 64 with ONE head => head_dim 64, L = 200): the build's MFMA attention kernel is
+    the one that runs here (the small rechub_sasrec fixture, head_dim 8, exercises the VALU kernel)."""
+    from recbox.third_party.rechub.basic.features import SequenceFeature as Sq
+    from recbox.third_party.rechub.models.matching import SASRec
+    g = torch.Generator().manual_seed(3)
+    fe = [Sq("seq", V, D, pooling="concat"), Sq("pos", V, D, pooling="concat", shared_with="seq"),
+          Sq("neg", V, D, pooling="concat", shared_with="seq")]
+    model = SASRec(fe, max_len=L, dropout_rate=0.0, num_blocks=2, num_heads=1)
+    reinit(model, seed=5)
+    lens = torch.tensor([L, 57])[:B]
+    seq = torch.randint(1, V, (B, L), generator=g) * (torch.arange(L)[None, :] < lens[:, None])
+    pos = torch.roll(seq, -1, dims=1) * (seq != 0)
+    neg = torch.randint(1, V, (B, L), generator=g) * (seq != 0)
+    Xs = {"seq": seq, "pos": pos, "neg": neg}
+    model.train()
+    pl, nl = model(Xs)
+    m = (pos != 0).float()
+    loss = -((torch.nn.functional.logsigmoid(pl) + torch.nn.functional.logsigmoid(-nl)) * m).sum() / m.sum()
+    loss.backward()
+    save("rechub_sasrec_d64", **{"in": Xs, "p": model.state_dict(),
+                                 "out": {"pos_logits": pl, "neg_logits": nl, "loss": loss},
+                                 "g": grads_of(model)})
+
+
 def gen_mlp(recbox, fuxictr, B=7):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 12, generator=g)
@@ -672,6 +697,11 @@ def main():
     import fuxictr.pytorch.layers
     import recbox.core.pytorch.layers
     import recbox.matching.features
+    if len(sys.argv) > 1:                     # regenerate only the named fixtures: python oracle/gen_golden.py rechub_sasrec_d64
+        for name in sys.argv[1:]:
+            {"rechub_sasrec_d64": gen_rechub_sasrec_d64}[name]()
+        return
+    gen_rechub_sasrec_d64()
     gen_ranking_embedding(fuxictr)
     gen_ranking_fm(fuxictr)
     gen_inner_product(fuxictr)

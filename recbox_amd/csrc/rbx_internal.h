@@ -95,6 +95,57 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so a parallel kernel and its replay in a backward pass draw the
+// same bits.  Used by the negative sampler (rbx_sampler.hip) and by attention dropout (rbx_attn*.hip).
+struct Philox {
+  static constexpr unsigned kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u, kW0 = 0x9E3779B9u, kW1 = 0xBB67AE85u;
+  // 10 rounds of Philox4x32; c = counter, k = key; result in c
+  static __host__ __device__ __forceinline__ void run(unsigned c[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const unsigned long long p0 = static_cast<unsigned long long>(kM0) * c[0];
+      const unsigned long long p1 = static_cast<unsigned long long>(kM1) * c[2];
+      const unsigned n0 = static_cast<unsigned>(p1 >> 32) ^ c[1] ^ k0;
+      const unsigned n1 = static_cast<unsigned>(p1);
+      const unsigned n2 = static_cast<unsigned>(p0 >> 32) ^ c[3] ^ k1;
+      const unsigned n3 = static_cast<unsigned>(p0);
+      c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+      k0 += kW0;
+      k1 += kW1;
+    }
+  }
+};
+
+// ---- attention dropout: keep(bh, query i, key j) ---------------------------------------------------------------
+// One Philox call covers a 2 x 4 block of the (query, key) plane with 16-bit decisions: counter = (i >> 2, j >> 2,
+// bh, 2 * (bh >> 32) + ((i & 3) >> 1)), word 2 * (i & 1) + ((j & 3) >> 1), half-word j & 1; keep iff it is >= thr16 =
+// round(p * 65536).  Forward (lane = query) and both backward phases (lane = query / lane = key) evaluate the same
+// function, so the mask is never stored.  The kept probabilities are scaled by 65536 / (65536 - thr16).
+struct DropArgs {
+  unsigned thr16;      // 0 = no dropout
+  float scale;
+  unsigned k0, k1;     // seed
+  const unsigned long long* seed_add;   // optional device word added to the seed (bumped between hipGraph replays)
+};
+
+__device__ __forceinline__ void drop_block(unsigned i4, unsigned j4, unsigned long long bh, int h, unsigned k0, unsigned k1,
+                                           unsigned (&c)[4]) {
+  c[0] = i4; c[1] = j4; c[2] = static_cast<unsigned>(bh); c[3] = (static_cast<unsigned>(bh >> 32) << 1) | static_cast<unsigned>(h);
+  Philox::run(c, k0, k1);
+}
+
+__device__ __forceinline__ bool drop_keep(const unsigned (&c)[4], int i_low /* i & 1 */, int j_low /* j & 3 */, unsigned thr16) {
+  const unsigned w = c[2 * i_low + (j_low >> 1)];
+  return ((w >> (16 * (j_low & 1))) & 0xFFFFu) >= thr16;
+}
+
+__device__ __forceinline__ void drop_seed(const DropArgs& d, unsigned* k0, unsigned* k1) {
+  unsigned long long s = (static_cast<unsigned long long>(d.k1) << 32) | d.k0;
+  if (d.seed_add != nullptr) s += *d.seed_add;
+  *k0 = static_cast<unsigned>(s);
+  *k1 = static_cast<unsigned>(s >> 32);
+}
+
 inline int pow2_ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;

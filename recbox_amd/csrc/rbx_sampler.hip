@@ -22,25 +22,6 @@
 
 namespace rbx {
 
-struct Philox {
-  static constexpr unsigned kM0 = 0xD2511F53u, kM1 = 0xCD9E8D57u, kW0 = 0x9E3779B9u, kW1 = 0xBB67AE85u;
-  // 10 rounds of Philox4x32; c = counter, k = key; result in c
-  static __host__ __device__ __forceinline__ void run(unsigned c[4], unsigned k0, unsigned k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      const unsigned long long p0 = static_cast<unsigned long long>(kM0) * c[0];
-      const unsigned long long p1 = static_cast<unsigned long long>(kM1) * c[2];
-      const unsigned n0 = static_cast<unsigned>(p1 >> 32) ^ c[1] ^ k0;
-      const unsigned n1 = static_cast<unsigned>(p1);
-      const unsigned n2 = static_cast<unsigned>(p0 >> 32) ^ c[3] ^ k1;
-      const unsigned n3 = static_cast<unsigned>(p0);
-      c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-      k0 += kW0;
-      k1 += kW1;
-    }
-  }
-};
-
 constexpr int kMaxAttempts = 64;     // rejection rounds before a draw is kept as is
 
 // uniform item in [0, num_items): high 64 bits of (64 random bits) x num_items

@@ -974,8 +974,9 @@ class _Linear(torch.autograd.Function):
         if w.shape[1] != K:
             raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, w.shape[1], N))
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        check(lib.rbx_linear_fwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(bias), M, N, K, act, _ptr(y),
-                                 _stream()))
+        check(_timed(("linear_fwd", M, N, K),
+                     lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(bias), M, N, K, act,
+                                                _ptr(y), _stream())))
         ctx.save_for_backward(x2, w, y if act == 1 else None)
         ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, shape
         return y.view(*shape[:-1], N)
@@ -1629,8 +1630,10 @@ class _Attention(torch.autograd.Function):
         do3 = do.reshape(BH, Lq, hd).contiguous().float()
         dq, dk, dv = torch.empty_like(q3), torch.empty_like(k3), torch.empty_like(v3)
         scratch = torch.empty((BH, Lq), dtype=torch.float32, device=do.device)
-        check(lib.rbx_attn_bwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), _ptr(o), _ptr(do3), _ptr(lse), BH, Lq, Lk, hd,
-                               scale, causal, fill, _ptr(dq), _ptr(dk), _ptr(dv), _ptr(scratch), _stream()))
+        check(_timed(("attn_bwd", BH, Lq, hd),
+                     lambda: lib.rbx_attn_bwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), _ptr(o), _ptr(do3), _ptr(lse), BH, Lq,
+                                              Lk, hd, scale, causal, fill, _ptr(dq), _ptr(dk), _ptr(dv), _ptr(scratch),
+                                              _stream())))
         return (dq.view(*lead, Lq, hd), dk.view(*lead, Lk, hd), dv.view(*lead, Lk, hd), None, None, None, None, None)
 
 

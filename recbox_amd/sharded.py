@@ -369,8 +369,10 @@ class HipShardOps(object):
         back = torch.empty((geom.W * geom.frows, geom.D), dtype=torch.float32, device=dev)
         keys = torch.empty(geom.n_keys, dtype=torch.int32, device=dev)
         src = torch.empty(geom.n_keys, dtype=torch.int32, device=dev)
-        check(lib.rbx_shard_serve(geom.c_struct(), ops._ptr(recv), ops._ptr(weight), weight.shape[0], ops._ptr(back),
-                                  ops._ptr(keys), ops._ptr(src), ops._ptr(status), ops._stream()))
+        check(ops._timed(("shard_serve", geom.W, geom.B, geom.D),
+                         lambda: lib.rbx_shard_serve(geom.c_struct(), ops._ptr(recv), ops._ptr(weight), weight.shape[0],
+                                                     ops._ptr(back), ops._ptr(keys), ops._ptr(src), ops._ptr(status),
+                                                     ops._stream())))
         return back, keys, src
 
     @staticmethod

@@ -338,6 +338,35 @@ def test_sasrec_golden():
     assert_grads_close(model, fx["g"], TOL)
 
 
+def test_sasrec_d64_golden_runs_the_mfma_attention():
+    """Live-reference fixture at cfg 5's shape (D = 64, one head => head_dim 64, L = 200): the attention of this model
+    is the MFMA kernel (rbx_attn_mfma.hip), the small fixture above (head_dim 8) only reaches the VALU one."""
+    Fe, La = _rh()
+    from recbox_amd import ops
+    from recbox_amd.rechub.models.matching import SASRec
+    Sq = Fe.SequenceFeature
+    fe = [Sq("seq", 97, 64, pooling="concat"), Sq("pos", 97, 64, pooling="concat", shared_with="seq"),
+          Sq("neg", 97, 64, pooling="concat", shared_with="seq")]
+    fx = Fixture("rechub_sasrec_d64")
+    model = load_params(SASRec(fe, max_len=200, dropout_rate=0.0, num_blocks=2, num_heads=1), fx["p"]).cuda().train()
+    X = _cuda(fx.tensors("in"))
+    seen = []
+    timer = ops.KernelTimer(lambda m: seen.append(m) or False)
+    ops.kernel_timer = timer
+    try:
+        pl, nl = model(X)
+        m = (X["pos"] != 0).float()
+        loss = -((F.logsigmoid(pl) + F.logsigmoid(-nl)) * m).sum() / m.sum()
+        loss.backward()
+    finally:
+        ops.kernel_timer = None
+    assert ("attn_bwd", 2, 200, 64) in seen                    # head_dim 64, L = 200: the MFMA path's shape
+    assert_close(pl, fx["out"]["pos_logits"], TOL)
+    assert_close(nl, fx["out"]["neg_logits"], TOL)
+    assert_close(loss, fx["out"]["loss"], TOL)
+    assert_grads_close(model, fx["g"], TOL)
+
+
 @pytest.mark.parametrize("L,D,causal", [(200, 64, True), (37, 32, True), (256, 64, False), (64, 32, False),
                                         (1, 64, True), (200, 16, True)])
 def test_attention_matches_torch(L, D, causal):

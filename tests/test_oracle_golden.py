@@ -321,6 +321,23 @@ def test_rechub_sasrec():
     assert_grads_close(model, fx["g"], TOL)
 
 
+def test_rechub_sasrec_d64():
+    """cfg-5 shape (D = 64, one head, L = 200) from the live reference: pins the oracle at the shape whose attention runs
+    on the MFMA kernel on the GPU."""
+    fx = Fixture("rechub_sasrec_d64")
+    model = load_params(R.RefSASRec(sasrec_features(97, 64), max_len=200, dropout_rate=0.0, num_blocks=2, num_heads=1),
+                        fx["p"]).train()
+    X = fx.tensors("in")
+    pl, nl = model(X)
+    assert_close(pl, fx["out"]["pos_logits"], TOL)
+    assert_close(nl, fx["out"]["neg_logits"], TOL)
+    m = (X["pos"] != 0).float()
+    loss = -((F.logsigmoid(pl) + F.logsigmoid(-nl)) * m).sum() / m.sum()
+    assert_close(loss, fx["out"]["loss"], TOL)
+    loss.backward()
+    assert_grads_close(model, fx["g"], TOL)
+
+
 def test_mlp():
     fx = Fixture("mlp")
     x = fx.tensors("in")["x"]
