@@ -453,6 +453,28 @@ int rbx_attn_bwd(const float* d_q, const float* d_k, const float* d_v, const flo
                  float scale, int32_t causal, float mask_fill, float* d_dq, float* d_dk, float* d_dv,
                  float* d_scratch, void* stream);
 
+/* The same with DROPOUT ON THE ATTENTION PROBABILITIES, as both reference attentions apply it in training
+ * (nn.MultiheadAttention(embed_dim, heads, dropout) inside rechub SASRec, sasrec.py:29,56,81-87 -- default rate 0.5;
+ * first-party ScaledDotProductAttention: `attention = self.dropout(attention)`, dot_product_attention.py:40-41):
+ * out = (keep o softmax(s) / (1 - p)) V, the normaliser being the undropped sum; d_p, when asked for, receives the
+ * dropped probabilities (what the reference returns).  keep(bh, i, j) is a counter-based function of (seed +
+ * *d_seed_add, bh, i, j) -- Philox4x32-10, one call per 2 x 4 block of the (query, key) plane, 16-bit decisions,
+ * p rounded to a multiple of 2^-16 -- evaluated again by the backward: no mask is stored.  d_seed_add (optional device
+ * word): added to `seed` in the kernel, so that a hipGraph replay can draw a new mask (bump it between replays).
+ * rbx_attn_dropout_mask writes keep as [bh, lq, lk] bytes (tests; callers that want to inspect the mask).
+ * p_drop == 0 is exactly rbx_attn_fwd / rbx_attn_bwd. */
+int rbx_attn_dropout_fwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask, int64_t bh,
+                         int32_t lq, int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill,
+                         float p_drop, uint64_t seed, const uint64_t* d_seed_add, float* d_o, float* d_lse, float* d_p,
+                         void* stream);
+int rbx_attn_dropout_bwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask, const float* d_o,
+                         const float* d_do, const float* d_lse, int64_t bh, int32_t lq, int32_t lk, int32_t head_dim,
+                         float scale, int32_t causal, float mask_fill, float p_drop, uint64_t seed,
+                         const uint64_t* d_seed_add, float* d_dq, float* d_dk, float* d_dv, float* d_scratch,
+                         void* stream);
+int rbx_attn_dropout_mask(int64_t bh, int32_t lq, int32_t lk, float p_drop, uint64_t seed, const uint64_t* d_seed_add,
+                          uint8_t* d_keep, void* stream);
+
 /* ---- pooling of a materialised [B,L,D] tensor (standalone pooling modules) ------
  * core/pytorch/layers/sequence.py:4-20, ranking/pytorch/layers/pooling.py:22-40,
  * third_party/rechub/basic/layers.py:176-230.

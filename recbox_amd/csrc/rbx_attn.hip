@@ -33,8 +33,11 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __r
                                                                 const float* __restrict__ mask, const int Lq,
                                                                 const int Lk, const float scale, const int causal,
                                                                 const float fill, float* __restrict__ O,
-                                                                float* __restrict__ LSE, float* __restrict__ P) {
+                                                                float* __restrict__ LSE, float* __restrict__ P,
+                                                                const DropArgs drop) {
   extern __shared__ float lds[];
+  unsigned dk0 = 0, dk1 = 0;
+  if (drop.thr16 != 0) drop_seed(drop, &dk0, &dk1);
   float* Ks = lds;                 // [Lk][HD]
   float* Vs = lds + Lk * HD;       // [Lk][HD]
   const long long bh = blockIdx.x;
@@ -89,11 +92,19 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __r
       l *= alpha;
 #pragma unroll
       for (int d = 0; d < HD; ++d) o[d] *= alpha;
+      unsigned dc[2][4];
+      if (drop.thr16 != 0) {                         // two 2 x 4 blocks of the dropout mask cover the 8 keys of this step
+        drop_block(static_cast<unsigned>(i) >> 2, static_cast<unsigned>(j0) >> 2, static_cast<unsigned long long>(bh),
+                   (i & 3) >> 1, dk0, dk1, dc[0]);
+        drop_block(static_cast<unsigned>(i) >> 2, (static_cast<unsigned>(j0) >> 2) + 1, static_cast<unsigned long long>(bh),
+                   (i & 3) >> 1, dk0, dk1, dc[1]);
+      }
 #pragma unroll
       for (int k = 0; k < kKeyBlock; ++k) {
         const int j = j0 + k;
-        const float p = (s[k] == -INFINITY) ? 0.f : __expf(s[k] - mn);
-        l += p;
+        float p = (s[k] == -INFINITY) ? 0.f : __expf(s[k] - mn);
+        l += p;                                      // the normaliser is the undropped sum
+        if (drop.thr16 != 0) p = drop_keep(dc[k >> 2], i & 1, k & 3, drop.thr16) ? p * drop.scale : 0.f;
         if (j < Lk) {
           const float* vr = Vs + j * HD;
 #pragma unroll
@@ -117,7 +128,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __r
 #pragma unroll
           for (int d = 0; d < HD; ++d) acc += q[d] * kr[d];
           if (mrow != nullptr && mrow[j] == 0.f) acc = fill;
-          pg[j] = (j <= jmax) ? __expf(acc - m) * invl : 0.f;
+          float pj = (j <= jmax) ? __expf(acc - m) * invl : 0.f;
+          if (drop.thr16 != 0) {                     // the reference returns the DROPPED probabilities (dot_product_attention.py:40-43)
+            unsigned c[4];
+            drop_block(static_cast<unsigned>(i) >> 2, static_cast<unsigned>(j) >> 2, static_cast<unsigned long long>(bh),
+                       (i & 3) >> 1, dk0, dk1, c);
+            pj = drop_keep(c, i & 1, j & 3, drop.thr16) ? pj * drop.scale : 0.f;
+          }
+          pg[j] = pj;
         }
       }
     }
@@ -134,8 +152,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
                                                                    const float* __restrict__ LSE, const int Lq,
                                                                    const int Lk, const float scale, const int causal,
                                                                    const float fill, float* __restrict__ dQ,
-                                                                   float* __restrict__ Dv) {
+                                                                   float* __restrict__ Dv, const DropArgs drop) {
   extern __shared__ float lds[];
+  unsigned dk0 = 0, dk1 = 0;
+  if (drop.thr16 != 0) drop_seed(drop, &dk0, &dk1);
   float* Ks = lds;
   float* Vs = lds + Lk * HD;
   const long long bh = blockIdx.x;
@@ -168,6 +188,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
       jend = other > jend ? other : jend;
     }
     const float* mrow = (mask != nullptr && live) ? mask + row * Lk : nullptr;
+    unsigned dc[4] = {0u, 0u, 0u, 0u};
     for (int j = 0; j <= jend; ++j) {
       const float* kr = Ks + j * HD;
       const float* vr = Vs + j * HD;
@@ -176,6 +197,12 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
       for (int d = 0; d < HD; ++d) {
         s += q[d] * kr[d];
         dp += go[d] * vr[d];
+      }
+      if (drop.thr16 != 0) {
+        if ((j & 3) == 0)
+          drop_block(static_cast<unsigned>(i) >> 2, static_cast<unsigned>(j) >> 2, static_cast<unsigned long long>(bh),
+                     (i & 3) >> 1, dk0, dk1, dc);
+        dp = drop_keep(dc, i & 1, j & 3, drop.thr16) ? dp * drop.scale : 0.f;
       }
       if (mrow != nullptr && j <= jmax && mrow[j] == 0.f) s = fill;
       const float p = (j <= jmax) ? __expf(s - lse) : 0.f;
@@ -201,8 +228,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float*
                                                                     const float* __restrict__ Dv, const int Lq,
                                                                     const int Lk, const float scale, const int causal,
                                                                     const float fill, float* __restrict__ dK,
-                                                                    float* __restrict__ dV) {
+                                                                    float* __restrict__ dV, const DropArgs drop) {
   extern __shared__ float lds[];
+  unsigned dk0 = 0, dk1 = 0;
+  if (drop.thr16 != 0) drop_seed(drop, &dk0, &dk1);
   float* Qs = lds;                       // [Lq][HD], pre-scaled
   float* Gs = Qs + Lq * HD;              // [Lq][HD] dO
   float* Ls = Gs + Lq * HD;              // [Lq] lse
@@ -236,6 +265,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float*
       const int other = __shfl_xor(istart, off, 64);
       istart = other < istart ? other : istart;
     }
+    unsigned dc[4] = {0u, 0u, 0u, 0u};
+    int dc_for = -1;                     // the (i >> 1) the cached Philox block belongs to
     for (int i = istart; i < Lq; ++i) {
       const float* qr = Qs + i * HD;
       const float* gr = Gs + i * HD;
@@ -248,10 +279,21 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float*
       const bool vis = live && (!causal || j <= i);
       if (mask != nullptr && vis && mask[(bh * Lq + i) * Lk + j] == 0.f) s = fill;
       const float p = vis ? __expf(s - Ls[i]) : 0.f;
+      float pd = p;
+      if (drop.thr16 != 0) {
+        if ((i >> 1) != dc_for) {                  // a block covers two consecutive queries
+          drop_block(static_cast<unsigned>(i) >> 2, static_cast<unsigned>(j) >> 2, static_cast<unsigned long long>(bh),
+                     (i & 3) >> 1, dk0, dk1, dc);
+          dc_for = i >> 1;
+        }
+        const bool keep = drop_keep(dc, i & 1, j & 3, drop.thr16);
+        pd = keep ? p * drop.scale : 0.f;
+        dp = keep ? dp * drop.scale : 0.f;
+      }
       const float ds = p * (dp - Ds[i]);
 #pragma unroll
       for (int d = 0; d < HD; ++d) {
-        dv[d] += p * gr[d];
+        dv[d] += pd * gr[d];
         dk[d] += ds * qr[d];
       }
     }
@@ -268,10 +310,38 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float*
 // fast path on the fp32 matrix cores (rbx_attn_mfma.hip)
 bool attn_mfma_supported(int lq, int lk, int hd, const float* mask, const float* probs);
 int attn_mfma_fwd(const float* q, const float* k, const float* v, long long bh, int L, int hd, float scale, int causal,
-                  float* o, float* lse, hipStream_t s);
+                  float* o, float* lse, const DropArgs& drop, hipStream_t s);
 int attn_mfma_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
                   long long bh, int L, int hd, float scale, int causal, float* dq, float* dk, float* dv, float* scratch,
-                  hipStream_t s);
+                  const DropArgs& drop, hipStream_t s);
+
+// p in [0, 1) -> 16-bit threshold and the scale of the kept entries (exactly 1 / (1 - thr16 / 65536))
+static int make_drop(float p, uint64_t seed, const uint64_t* d_seed_add, DropArgs* d) {
+  if (!(p >= 0.f) || p >= 1.f) return fail(RBX_ERR_INVALID, "attention: dropout probability %g not in [0, 1)", static_cast<double>(p));
+  unsigned thr = static_cast<unsigned>(p * 65536.0f + 0.5f);
+  if (thr > 65535u) thr = 65535u;
+  d->thr16 = thr;
+  d->scale = 65536.0f / static_cast<float>(65536u - thr);
+  d->k0 = static_cast<unsigned>(seed);
+  d->k1 = static_cast<unsigned>(seed >> 32);
+  d->seed_add = reinterpret_cast<const unsigned long long*>(d_seed_add);
+  return RBX_OK;
+}
+
+__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(const long long total, const int lq, const int lk,
+                                                                const DropArgs drop, unsigned char* __restrict__ out) {
+  unsigned k0, k1;
+  drop_seed(drop, &k0, &k1);
+  const long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = static_cast<int>(e % lk);
+  const long long t = e / lk;
+  const int i = static_cast<int>(t % lq);
+  const long long bh = t / lq;
+  unsigned c[4];
+  drop_block(static_cast<unsigned>(i) >> 2, static_cast<unsigned>(j) >> 2, static_cast<unsigned long long>(bh), (i & 3) >> 1, k0, k1, c);
+  out[e] = drop_keep(c, i & 1, j & 3, drop.thr16) ? 1 : 0;
+}
 
 static int attn_check(int64_t bh, int lq, int lk, int hd) {
   if (bh < 0 || lq <= 0 || lk <= 0) return fail(RBX_ERR_INVALID, "attention: bad shape");
@@ -296,14 +366,39 @@ static int attn_check(int64_t bh, int lq, int lk, int hd) {
 extern "C" int rbx_attn_fwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask, int64_t bh,
                             int32_t lq, int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill,
                             float* d_o, float* d_lse, float* d_p, void* stream) {
+  return rbx_attn_dropout_fwd(d_q, d_k, d_v, d_mask, bh, lq, lk, head_dim, scale, causal, mask_fill, 0.f, 0, nullptr, d_o,
+                              d_lse, d_p, stream);
+}
+
+extern "C" int rbx_attn_dropout_mask(int64_t bh, int32_t lq, int32_t lk, float p_drop, uint64_t seed,
+                                     const uint64_t* d_seed_add, uint8_t* d_keep, void* stream) {
+  using namespace rbx;
+  if (bh < 0 || lq <= 0 || lk <= 0 || d_keep == nullptr) return fail(RBX_ERR_INVALID, "attn_dropout_mask: bad arguments");
+  DropArgs drop;
+  int rc = make_drop(p_drop, seed, d_seed_add, &drop);
+  if (rc != RBX_OK) return rc;
+  const long long total = static_cast<long long>(bh) * lq * lk;
+  if (total == 0) return RBX_OK;
+  hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     total, lq, lk, drop, d_keep);
+  return check_launch("attn_dropout_mask_kernel");
+}
+
+extern "C" int rbx_attn_dropout_fwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask, int64_t bh,
+                                    int32_t lq, int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill,
+                                    float p_drop, uint64_t seed, const uint64_t* d_seed_add, float* d_o, float* d_lse,
+                                    float* d_p, void* stream) {
   if (bh == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   int rc = attn_check(bh, lq, lk, head_dim);
   if (rc != RBX_OK) return rc;
+  DropArgs drop;
+  rc = make_drop(p_drop, seed, d_seed_add, &drop);
+  if (rc != RBX_OK) return rc;
   if (d_q == nullptr || d_k == nullptr || d_v == nullptr || d_o == nullptr) return fail(RBX_ERR_INVALID, "attention: NULL tensor");
   if (bh == 0) return RBX_OK;
   if (d_lse != nullptr && attn_mfma_supported(lq, lk, head_dim, d_mask, d_p))
-    return attn_mfma_fwd(d_q, d_k, d_v, bh, lq, head_dim, scale, causal, d_o, d_lse, as_stream(stream));
+    return attn_mfma_fwd(d_q, d_k, d_v, bh, lq, head_dim, scale, causal, d_o, d_lse, drop, as_stream(stream));
   const size_t lds = static_cast<size_t>(2) * lk * head_dim * sizeof(float);
   hipStream_t s = as_stream(stream);
 #define CALL(HD)                                                                                                  \
@@ -312,7 +407,7 @@ extern "C" int rbx_attn_fwd(const float* d_q, const float* d_k, const float* d_v
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD>),                                    \
                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                     \
     hipLaunchKernelGGL((attn_fwd_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, d_q,   \
-                       d_k, d_v, d_mask, lq, lk, scale, causal, mask_fill, d_o, d_lse, d_p);                      \
+                       d_k, d_v, d_mask, lq, lk, scale, causal, mask_fill, d_o, d_lse, d_p, drop);                \
   } while (0)
   RBX_ATTN_HD(head_dim, CALL)
 #undef CALL
@@ -323,9 +418,21 @@ extern "C" int rbx_attn_bwd(const float* d_q, const float* d_k, const float* d_v
                             const float* d_o, const float* d_do, const float* d_lse, int64_t bh, int32_t lq,
                             int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill, float* d_dq,
                             float* d_dk, float* d_dv, float* d_scratch, void* stream) {
+  return rbx_attn_dropout_bwd(d_q, d_k, d_v, d_mask, d_o, d_do, d_lse, bh, lq, lk, head_dim, scale, causal, mask_fill, 0.f, 0,
+                              nullptr, d_dq, d_dk, d_dv, d_scratch, stream);
+}
+
+extern "C" int rbx_attn_dropout_bwd(const float* d_q, const float* d_k, const float* d_v, const float* d_mask,
+                                    const float* d_o, const float* d_do, const float* d_lse, int64_t bh, int32_t lq,
+                                    int32_t lk, int32_t head_dim, float scale, int32_t causal, float mask_fill,
+                                    float p_drop, uint64_t seed, const uint64_t* d_seed_add, float* d_dq, float* d_dk,
+                                    float* d_dv, float* d_scratch, void* stream) {
   if (bh == 0) return RBX_OK;   // empty batch: nothing to do, pointers may be NULL
   using namespace rbx;
   int rc = attn_check(bh, lq, lk, head_dim);
+  if (rc != RBX_OK) return rc;
+  DropArgs drop;
+  rc = make_drop(p_drop, seed, d_seed_add, &drop);
   if (rc != RBX_OK) return rc;
   if (d_q == nullptr || d_k == nullptr || d_v == nullptr || d_o == nullptr || d_do == nullptr || d_lse == nullptr ||
       d_dq == nullptr || d_dk == nullptr || d_dv == nullptr || d_scratch == nullptr)
@@ -333,7 +440,7 @@ extern "C" int rbx_attn_bwd(const float* d_q, const float* d_k, const float* d_v
   if (bh == 0) return RBX_OK;
   if (attn_mfma_supported(lq, lk, head_dim, d_mask, nullptr))
     return attn_mfma_bwd(d_q, d_k, d_v, d_o, d_do, d_lse, bh, lq, head_dim, scale, causal, d_dq, d_dk, d_dv, d_scratch,
-                         as_stream(stream));
+                         drop, as_stream(stream));
   const size_t lds_a = static_cast<size_t>(2) * lk * head_dim * sizeof(float);
   const size_t lds_b = (static_cast<size_t>(2) * lq * head_dim + 2 * lq) * sizeof(float);
   hipStream_t s = as_stream(stream);
@@ -347,10 +454,10 @@ extern "C" int rbx_attn_bwd(const float* d_q, const float* d_k, const float* d_v
                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b));                    \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds_a, s,    \
                        d_q, d_k, d_v, d_mask, d_o, d_do, d_lse, lq, lk, scale, causal, mask_fill, d_dq,            \
-                       d_scratch);                                                                                 \
+                       d_scratch, drop);                                                                           \
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds_b, s,   \
                        d_q, d_k, d_v, d_mask, d_do, d_lse, d_scratch, lq, lk, scale, causal, mask_fill, d_dk,      \
-                       d_dv);                                                                                      \
+                       d_dv, drop);                                                                                \
   } while (0)
   RBX_ATTN_HD(head_dim, CALL)
 #undef CALL

@@ -132,11 +132,12 @@ __device__ __forceinline__ void store_transposed(float* __restrict__ g, int row0
        zz_once && (((wid) < 4) ? ((wid) <= (nT) - 1 - (wid)) : ((wid) - 4 < (nT) - 1 - ((wid) - 4)));       \
        zz_once = 0)
 
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ V, const int L,
                                                             const float scale, const int causal,
-                                                            float* __restrict__ O, float* __restrict__ LSE) {
+                                                            float* __restrict__ O, float* __restrict__ LSE,
+                                                            const DropArgs drop) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Ks = lds;
@@ -146,6 +147,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
   stage_rows<HD>(V + bh * L * HD, Vs, L, Lp, 1.0f);
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+  unsigned dk0 = 0, dk1 = 0;
+  if (DROP) drop_seed(drop, &dk0, &dk1);
   RBX_FOR_WAVE_TILES(nT, wid, qt) {
     const int i0 = qt * kT, qi = i0 + li;
     float qreg[HD / 2];
@@ -183,6 +186,17 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
       m = mn;
+      if (DROP) {        // dropout on the probabilities (nn.MultiheadAttention / ScaledDotProductAttention): the
+                         // normaliser lsum stays the undropped sum, kept entries are scaled by 1 / (1 - p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          unsigned c[4];
+          drop_block(static_cast<unsigned>(qi) >> 2, static_cast<unsigned>(j0 + 8 * g + 4 * half) >> 2,
+                     static_cast<unsigned long long>(bh), (qi & 3) >> 1, dk0, dk1, c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s[4 * g + q] = drop_keep(c, qi & 1, q, drop.thr16) ? s[4 * g + q] * drop.scale : 0.f;
+        }
+      }
       tile_accumulate<HD>(Vs, j0, s, oacc);                  // O^T[d][query] += V^T P^T
     }
     store_transposed<HD>(O + bh * L * HD, i0, L, 1.0f / lsum, oacc);
@@ -191,14 +205,15 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
 }
 
 // backward phase A: lane = query.  dQ and D = <dO, O>.
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                               const float* __restrict__ V,
                                                               const float* __restrict__ O,
                                                               const float* __restrict__ dO,
                                                               const float* __restrict__ LSE, const int L,
                                                               const float scale, const int causal,
-                                                              float* __restrict__ dQ, float* __restrict__ Dv) {
+                                                              float* __restrict__ dQ, float* __restrict__ Dv,
+                                                              const DropArgs drop) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Ks = lds;
@@ -208,6 +223,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
   stage_rows<HD>(V + bh * L * HD, Vs, L, Lp, 1.0f);
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+  unsigned dk0 = 0, dk1 = 0;
+  if (DROP) drop_seed(drop, &dk0, &dk1);
   RBX_FOR_WAVE_TILES(nT, wid, qt) {
     const int i0 = qt * kT, qi = i0 + li;
     float qreg[HD / 2], greg[HD / 2], oreg[HD / 2];
@@ -229,7 +246,17 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
     for (int kt = 0; kt <= kt_end; ++kt) {
       const int j0 = kt * kT;
       f32x16 s = tile_dot<HD>(Ks, j0, qreg);                 // S^T
-      const f32x16 dp = tile_dot<HD>(Vs, j0, greg);          // dP^T[key][query] = <V_key, dO_query>
+      f32x16 dp = tile_dot<HD>(Vs, j0, greg);                // dP^T[key][query] = <V_key, dO_query>
+      if (DROP) {                                            // d(dropped P) -> dP: the same mask and scale
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          unsigned c[4];
+          drop_block(static_cast<unsigned>(qi) >> 2, static_cast<unsigned>(j0 + 8 * g + 4 * half) >> 2,
+                     static_cast<unsigned long long>(bh), (qi & 3) >> 1, dk0, dk1, c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dp[4 * g + q] = drop_keep(c, qi & 1, q, drop.thr16) ? dp[4 * g + q] * drop.scale : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kj = j0 + tile_row(r, half);
@@ -244,14 +271,15 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
 }
 
 // backward phase B: lane = key.  dK, dV.
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                                const float* __restrict__ V,
                                                                const float* __restrict__ dO,
                                                                const float* __restrict__ LSE,
                                                                const float* __restrict__ Dv, const int L,
                                                                const float scale, const int causal,
-                                                               float* __restrict__ dK, float* __restrict__ dV) {
+                                                               float* __restrict__ dK, float* __restrict__ dV,
+                                                               const DropArgs drop) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Qs = lds;                          // scale * Q
@@ -267,6 +295,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+  unsigned dk0 = 0, dk1 = 0;
+  if (DROP) drop_seed(drop, &dk0, &dk1);
   RBX_FOR_WAVE_TILES(nT, wid, jt) {
     const int j0 = jt * kT, kj = j0 + li;
     float kreg[HD / 2], vreg[HD / 2];
@@ -281,15 +311,41 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
     for (int it = it_beg; it < nT; ++it) {
       const int i0 = it * kT;
       f32x16 s = tile_dot<HD>(Qs, i0, kreg);                 // S[query][key] (already scaled)
-      const f32x16 dp = tile_dot<HD>(Gs, i0, vreg);          // dP[query][key]
+      f32x16 dp = tile_dot<HD>(Gs, i0, vreg);                // dP[query][key]
       f32x16 p;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = i0 + tile_row(r, half);
         const bool vis = kj < L && qi < L && !(causal && kj > qi);
         p[r] = vis ? __expf(s[r] - Ls[qi]) : 0.f;
-        s[r] = p[r] * (dp[r] - Ds[qi]);                      // dS
       }
+      if (DROP) {
+        // lane = key: registers 4g..4g+3 are four consecutive queries, i.e. both 2 x 4 blocks of one (i >> 2, j >> 2)
+        f32x16 pd;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            unsigned c[4];
+            drop_block(static_cast<unsigned>(i0 + 8 * g + 4 * half) >> 2, static_cast<unsigned>(kj) >> 2,
+                       static_cast<unsigned long long>(bh), h, dk0, dk1, c);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int r = 4 * g + 2 * h + q;
+              const bool keep = drop_keep(c, q, kj & 3, drop.thr16);
+              pd[r] = keep ? p[r] * drop.scale : 0.f;
+              dp[r] = keep ? dp[r] * drop.scale : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = p[r] * (dp[r] - Ds[i0 + tile_row(r, half)]);     // dS
+        tile_accumulate<HD>(Gs, i0, pd, dv);                 // dV^T[d][key] += dO^T (dropped P)
+        tile_accumulate<HD>(Qs, i0, s, dk);
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = p[r] * (dp[r] - Ds[i0 + tile_row(r, half)]);       // dS
       tile_accumulate<HD>(Gs, i0, p, dv);                    // dV^T[d][key] += dO^T P
       tile_accumulate<HD>(Qs, i0, s, dk);                    // dK^T[d][key] += (scale Q)^T dS
     }
@@ -308,44 +364,50 @@ static size_t lds_bytes(int L, bool phase_b) {
   return (static_cast<size_t>(2) * Lp * (HD + 1) + (phase_b ? 2 * Lp : 0)) * sizeof(float);
 }
 
-template <int HD>
+template <int HD, bool DROP>
 static int run_fwd(const float* q, const float* k, const float* v, long long bh, int L, float scale, int causal, float* o,
-                   float* lse, hipStream_t s) {
+                   float* lse, const DropArgs& drop, hipStream_t s) {
   const size_t lds = lds_bytes<HD>(L, false);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD, DROP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, q, k, v, L, scale,
-                     causal, o, lse);
+  hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD, DROP>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, q, k, v, L,
+                     scale, causal, o, lse, drop);
   return check_launch("attn_mfma_fwd_kernel");
 }
 
-template <int HD>
+template <int HD, bool DROP>
 static int run_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
                    long long bh, int L, float scale, int causal, float* dq, float* dk, float* dv, float* scratch,
-                   hipStream_t s) {
+                   const DropArgs& drop, hipStream_t s) {
   const size_t la = lds_bytes<HD>(L, false), lb = lds_bytes<HD>(L, true);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_q_kernel<HD>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_q_kernel<HD, DROP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(la));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kv_kernel<HD>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kv_kernel<HD, DROP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb));
-  hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), la, s, q, k, v, o, go, lse,
-                     L, scale, causal, dq, scratch);
-  hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lb, s, q, k, v, go, lse,
-                     scratch, L, scale, causal, dk, dv);
+  hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<HD, DROP>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), la, s, q, k, v, o,
+                     go, lse, L, scale, causal, dq, scratch, drop);
+  hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<HD, DROP>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lb, s, q, k, v, go,
+                     lse, scratch, L, scale, causal, dk, dv, drop);
   return check_launch("attn_mfma_bwd kernels");
 }
 
 int attn_mfma_fwd(const float* q, const float* k, const float* v, long long bh, int L, int hd, float scale, int causal,
-                  float* o, float* lse, hipStream_t s) {
-  return hd == 64 ? run_fwd<64>(q, k, v, bh, L, scale, causal, o, lse, s)
-                  : run_fwd<32>(q, k, v, bh, L, scale, causal, o, lse, s);
+                  float* o, float* lse, const DropArgs& drop, hipStream_t s) {
+  if (drop.thr16 != 0)
+    return hd == 64 ? run_fwd<64, true>(q, k, v, bh, L, scale, causal, o, lse, drop, s)
+                    : run_fwd<32, true>(q, k, v, bh, L, scale, causal, o, lse, drop, s);
+  return hd == 64 ? run_fwd<64, false>(q, k, v, bh, L, scale, causal, o, lse, drop, s)
+                  : run_fwd<32, false>(q, k, v, bh, L, scale, causal, o, lse, drop, s);
 }
 
 int attn_mfma_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
                   long long bh, int L, int hd, float scale, int causal, float* dq, float* dk, float* dv, float* scratch,
-                  hipStream_t s) {
-  return hd == 64 ? run_bwd<64>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, s)
-                  : run_bwd<32>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, s);
+                  const DropArgs& drop, hipStream_t s) {
+  if (drop.thr16 != 0)
+    return hd == 64 ? run_bwd<64, true>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, s)
+                    : run_bwd<32, true>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, s);
+  return hd == 64 ? run_bwd<64, false>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, s)
+                  : run_bwd<32, false>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, s);
 }
 
 }  // namespace rbx

@@ -52,6 +52,8 @@ class GraphedStep(object):
             ops.config.reuse_grad_buffers = old
 
     def __call__(self):
+        if ops._dropout_ticks:
+            ops.bump_dropout_tick()          # a replay re-runs the captured seeds: the device tick makes the masks new
         self.graph.replay()
         return self.out
 

@@ -1592,11 +1592,36 @@ def pair_mul(left, right, per_pair=False):
     return _PairMul.apply(left, right, bool(per_pair))
 
 
+_dropout_ticks = {}
+
+
+def dropout_tick(device):
+    """The device word every dropout kernel adds to its seed (``d_seed_add``).  A captured step bakes its host seed
+    into the graph: ``bump_dropout_tick`` before a replay makes the replay draw a new mask (GraphedStep does it)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _dropout_ticks.get(key)
+    if t is None:
+        t = _dropout_ticks[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    return t
+
+
+def bump_dropout_tick():
+    for t in _dropout_ticks.values():
+        t.add_(0x9E3779B97F4A7C15 - (1 << 64))            # odd 64-bit increment (wraps): distinct seeds for 2^64 replays
+
+
+def _draw_seed():
+    """64 random bits from torch's default CPU generator: ``torch.manual_seed`` makes the masks reproducible."""
+    return int(torch.empty((), dtype=torch.int64).random_()) & ((1 << 63) - 1)
+
+
 class _Attention(torch.autograd.Function):
-    """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities."""
+    """softmax(scale * Q K^T + mask) V on [..., L, hd] tensors; optionally returns the probabilities; optional dropout
+    on the probabilities (rbx_attn_dropout_*: the mask is a counter-based function of (seed, head, query, key) that the
+    backward evaluates again -- nothing is stored)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, scale, causal, fill, need_probs):
+    def forward(ctx, q, k, v, mask, scale, causal, fill, need_probs, p_drop, seed):
         _require_cuda(q, "attention query")
         lead = q.shape[:-2]
         Lq, hd = q.shape[-2], q.shape[-1]
@@ -1611,10 +1636,16 @@ class _Attention(torch.autograd.Function):
         o = torch.empty_like(q3)
         lse = torch.empty((BH, Lq), dtype=torch.float32, device=q.device)
         p = torch.empty((BH, Lq, Lk), dtype=torch.float32, device=q.device) if need_probs else None
-        check(lib.rbx_attn_fwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), BH, Lq, Lk, hd, float(scale), int(causal),
-                               float(fill), _ptr(o), _ptr(lse), _ptr(p), _stream()))
+        tick = dropout_tick(q.device) if p_drop > 0 else None
+        if p_drop > 0:
+            check(lib.rbx_attn_dropout_fwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), BH, Lq, Lk, hd, float(scale),
+                                           int(causal), float(fill), float(p_drop), int(seed), _ptr(tick), _ptr(o),
+                                           _ptr(lse), _ptr(p), _stream()))
+        else:
+            check(lib.rbx_attn_fwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), BH, Lq, Lk, hd, float(scale), int(causal),
+                                   float(fill), _ptr(o), _ptr(lse), _ptr(p), _stream()))
         ctx.save_for_backward(q3, k3, v3, m3, o, lse)
-        ctx.meta = (lead, Lq, Lk, hd, float(scale), int(causal), float(fill))
+        ctx.meta = (lead, Lq, Lk, hd, float(scale), int(causal), float(fill), float(p_drop), int(seed), tick)
         out = o.view(*lead, Lq, hd)
         if need_probs:
             probs = p.view(*lead, Lq, Lk)
@@ -1625,17 +1656,39 @@ class _Attention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do, _dp):
         q3, k3, v3, m3, o, lse = ctx.saved_tensors
-        lead, Lq, Lk, hd, scale, causal, fill = ctx.meta
+        lead, Lq, Lk, hd, scale, causal, fill, p_drop, seed, tick = ctx.meta
         BH = q3.shape[0]
         do3 = do.reshape(BH, Lq, hd).contiguous().float()
         dq, dk, dv = torch.empty_like(q3), torch.empty_like(k3), torch.empty_like(v3)
         scratch = torch.empty((BH, Lq), dtype=torch.float32, device=do.device)
-        check(_timed(("attn_bwd", BH, Lq, hd),
-                     lambda: lib.rbx_attn_bwd(_ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), _ptr(o), _ptr(do3), _ptr(lse), BH, Lq,
-                                              Lk, hd, scale, causal, fill, _ptr(dq), _ptr(dk), _ptr(dv), _ptr(scratch),
-                                              _stream())))
-        return (dq.view(*lead, Lq, hd), dk.view(*lead, Lk, hd), dv.view(*lead, Lk, hd), None, None, None, None, None)
+        if p_drop > 0:
+            call = lambda: lib.rbx_attn_dropout_bwd(                                                      # noqa: E731
+                _ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), _ptr(o), _ptr(do3), _ptr(lse), BH, Lq, Lk, hd, scale, causal, fill,
+                p_drop, seed, _ptr(tick), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(scratch), _stream())
+        else:
+            call = lambda: lib.rbx_attn_bwd(                                                              # noqa: E731
+                _ptr(q3), _ptr(k3), _ptr(v3), _ptr(m3), _ptr(o), _ptr(do3), _ptr(lse), BH, Lq, Lk, hd, scale, causal, fill,
+                _ptr(dq), _ptr(dk), _ptr(dv), _ptr(scratch), _stream())
+        check(_timed(("attn_bwd", BH, Lq, hd), call))
+        return (dq.view(*lead, Lq, hd), dk.view(*lead, Lk, hd), dv.view(*lead, Lk, hd), None, None, None, None, None,
+                None, None)
 
 
-def attention(q, k, v, mask=None, scale=1.0, causal=False, fill=-1.0e9, need_probs=False):
-    return _Attention.apply(q, k, v, mask, scale, causal, fill, need_probs)
+def attention(q, k, v, mask=None, scale=1.0, causal=False, fill=-1.0e9, need_probs=False, dropout_p=0.0, seed=None):
+    """``dropout_p`` > 0: dropout on the attention probabilities (training-time nn.MultiheadAttention /
+    ScaledDotProductAttention); ``seed`` defaults to 64 bits drawn from torch's default CPU generator."""
+    if dropout_p and not 0.0 <= dropout_p < 1.0:
+        raise ValueError("dropout probability has to be between 0 and 1, but got {}".format(dropout_p))
+    if dropout_p and seed is None:
+        seed = _draw_seed()
+    return _Attention.apply(q, k, v, mask, scale, causal, fill, need_probs, float(dropout_p or 0.0), int(seed or 0))
+
+
+def attention_dropout_mask(bh, lq, lk, dropout_p, seed, device="cuda"):
+    """keep[bh, lq, lk] (bool) exactly as the fused kernels evaluate it for (dropout_p, seed) (rbx_attn_dropout_mask)."""
+    device = torch.device(device)
+    keep = torch.empty((bh, lq, lk), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        check(lib.rbx_attn_dropout_mask(bh, lq, lk, float(dropout_p), int(seed), _ptr(dropout_tick(device)), _ptr(keep),
+                                        _stream()))
+    return keep.bool()

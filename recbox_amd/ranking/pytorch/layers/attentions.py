@@ -19,13 +19,14 @@ class ScaledDotProductAttention(nn.Module):
         self.dropout = nn.Dropout(dropout_rate) if dropout_rate > 0 else None
 
     def forward(self, Q, K, V, scale=None, mask=None):
-        if self.dropout is not None and self.training:
-            raise NotImplementedError("attention dropout inside the fused kernel is not implemented; "
-                                      "use dropout_rate=0 (BASELINE.json configs run with dropout 0)")
+        # `attention = self.dropout(attention)` (dot_product_attention.py:40-41): applied to the probabilities inside
+        # the fused kernel; the returned attention is the dropped one, as in the reference
+        p_drop = self.dropout.p if (self.dropout is not None and self.training) else 0.0
         s = 1.0 / scale if scale else 1.0           # the reference DIVIDES the scores by `scale`
         if mask is not None:
             mask = mask.view(*Q.shape[:-1], K.shape[-2])
-        output, attention = ops.attention(Q, K, V, mask=mask, scale=s, causal=False, fill=-1.0e9, need_probs=True)
+        output, attention = ops.attention(Q, K, V, mask=mask, scale=s, causal=False, fill=-1.0e9, need_probs=True,
+                                          dropout_p=p_drop)
         return output, attention
 
 

@@ -150,9 +150,7 @@ class SASRec(torch.nn.Module):
 
     def _mha(self, layer, query, keyval):
         """nn.MultiheadAttention(query, keyval, keyval, attn_mask=causal) on [B, L, E] tensors."""
-        if layer.dropout > 0 and self.training:
-            raise NotImplementedError("attention dropout inside the fused kernel is not implemented; build "
-                                      "SASRec with dropout_rate=0 (BASELINE.json cfg 5) or call .eval()")
+        p_drop = layer.dropout if self.training else 0.0      # dropout on the probabilities, inside the fused kernel
         E, H = layer.embed_dim, layer.num_heads
         hd = E // H
         w, b = layer.in_proj_weight, layer.in_proj_bias
@@ -163,7 +161,7 @@ class SASRec(torch.nn.Module):
         k, v = ops.split_last(kv, E)                            # contiguous halves; backward = one concatenation
         k = k.view(B, L, H, hd).transpose(1, 2)
         v = v.view(B, L, H, hd).transpose(1, 2)
-        o, _ = ops.attention(q, k, v, mask=None, scale=hd ** -0.5, causal=True, fill=float("-inf"))
+        o, _ = ops.attention(q, k, v, mask=None, scale=hd ** -0.5, causal=True, fill=float("-inf"), dropout_p=p_drop)
         o = o.transpose(1, 2).reshape(B, L, E)
         return ops.linear(o, layer.out_proj.weight, layer.out_proj.bias)
 

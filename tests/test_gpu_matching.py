@@ -592,3 +592,164 @@ def test_youtubednn_with_dense_user_features_matches_oracle():
     want = dict(ref.named_parameters())
     for n, p in dut.named_parameters():
         assert_close(p.grad, want[n].grad, TOL, "grad " + n)
+
+
+@pytest.mark.parametrize("L,D,causal,use_mask,p", [(200, 64, True, False, 0.5), (37, 32, True, False, 0.1),
+                                                   (64, 64, False, False, 0.3), (9, 8, False, True, 0.5),
+                                                   (23, 16, True, False, 0.25)])
+def test_attention_dropout_vs_restatement_with_the_kernels_mask(L, D, causal, use_mask, p):
+    """Dropout on the attention probabilities inside the fused kernels (nn.MultiheadAttention(dropout) of rechub SASRec,
+    sasrec.py:29,56; `attention = self.dropout(attention)` of dot_product_attention.py:40-41): out = (keep o P / (1 - p)) V.
+    The kernels' keep mask (a counter-based function, re-evaluated by the backward) is read back through
+    rbx_attn_dropout_mask and injected into a torch fp64 restatement: output, returned probabilities and dQ / dK / dV."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(L + D)
+    BH = 6
+    q, k, v = (torch.randn(BH, L, D, generator=g) for _ in range(3))
+    R = torch.randn(BH, L, D, generator=g)
+    mask = (torch.rand(BH, L, L, generator=g) > 0.2).float() if use_mask else None
+    if mask is not None:
+        mask[:, :, 0] = 1.0
+    seed = 1234567 + L
+    keep = ops.attention_dropout_mask(BH, L, L, p, seed)
+    p_eff = round(p * 65536) / 65536.0
+    sigma = (p_eff * (1 - p_eff) / keep.numel()) ** 0.5
+    assert abs(float(keep.float().mean()) - (1 - p_eff)) < 4 * sigma + 1e-3   # the rate is what was asked for
+    assert not torch.equal(keep, ops.attention_dropout_mask(BH, L, L, p, seed + 1))
+    assert torch.equal(keep, ops.attention_dropout_mask(BH, L, L, p, seed))
+    qd, kd, vd = (t.double().requires_grad_() for t in (q, k, v))
+    s = (qd @ kd.transpose(1, 2)) * (D ** -0.5)
+    if mask is not None:
+        s = s.masked_fill(mask.double() == 0, -1.0e9)
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf"))
+    P = torch.softmax(s, dim=-1)
+    Pd = P * keep.cpu().double() / (1 - p_eff)
+    want = Pd @ vd
+    (want * R.double()).sum().backward()
+    qc, kc, vc = (t.cuda().requires_grad_() for t in (q, k, v))
+    out, probs = ops.attention(qc, kc, vc, mask=mask.cuda() if mask is not None else None, scale=D ** -0.5, causal=causal,
+                               fill=-1.0e9, need_probs=use_mask, dropout_p=p, seed=seed)
+    assert_close(out, want, TOL, "output")
+    if use_mask:
+        assert_close(probs, Pd, TOL, "returned (dropped) probabilities")
+    (out * R.cuda()).sum().backward()
+    assert_close(qc.grad, qd.grad, TOL, "dQ")
+    assert_close(kc.grad, kd.grad, TOL, "dK")
+    assert_close(vc.grad, vd.grad, TOL, "dV")
+
+
+def test_sasrec_trains_with_the_reference_default_dropout():
+    """rechub's SASRec defaults to dropout_rate = 0.5 (sasrec.py:29): embedding dropout, attention dropout (inside the
+    fused kernel) and the feed-forward dropouts all active.  The step runs, is finite, differs from the dropout-free
+    output, reproduces under the same torch seed, and .eval() switches every dropout off."""
+    Fe, La = _rh()
+    from recbox_amd.rechub.models.matching import SASRec
+    Sq = Fe.SequenceFeature
+    fe = [Sq("seq", 97, 64, pooling="concat"), Sq("pos", 97, 64, pooling="concat", shared_with="seq"),
+          Sq("neg", 97, 64, pooling="concat", shared_with="seq")]
+    fx = Fixture("rechub_sasrec_d64")
+    model = load_params(SASRec(fe, max_len=200), fx["p"]).cuda()
+    assert model.attention_layers[0].dropout == 0.5
+    X = _cuda(fx.tensors("in"))
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        pl, nl = model(X)
+        m = (X["pos"] != 0).float()
+        loss = -((F.logsigmoid(pl) + F.logsigmoid(-nl)) * m).sum() / m.sum()
+        loss.backward()
+        return pl.detach().clone(), model.attention_layers[0].in_proj_weight.grad.clone()
+
+    model.train()
+    torch.manual_seed(5)
+    torch.cuda.manual_seed(5)
+    a, ga = run()
+    torch.manual_seed(5)
+    torch.cuda.manual_seed(5)
+    b, gb = run()
+    assert torch.isfinite(a).all() and torch.isfinite(ga).all()
+    assert torch.equal(a, b) and torch.equal(ga, gb)
+    c, _ = run()
+    assert not torch.equal(a, c)                                            # another draw
+    model.eval()
+    e, _ = run()
+    assert_close(e, fx["out"]["pos_logits"], TOL)                           # dropout off == the dropout-free fixture
+
+
+def test_deepfm_cfg4_full_size_sampled_rows_vs_fp64_oracle():
+    """BASELINE.json cfg 4 at full size (Criteo-sized tables, D = 64, MLP 3 x 400, B = 65 536): the predictions of 512
+    sampled rows against the oracle's restatement evaluated in float64 on those rows (BatchNorm in eval mode, so that a
+    row does not depend on the rest of the batch), and the first-order / tower gradients against the oracle on the
+    sampled sub-batch."""
+    import bench
+    from oracle import torch_ref as R
+    from recbox_amd.rechub.models.ranking import DeepFM
+    B, D = 65536, 64
+    dense, sparse = bench._deepfm_features(D)
+    mlp = {"dims": [400, 400, 400], "dropout": 0.0, "activation": "relu"}
+    with torch.device("cuda"):
+        model = DeepFM(dense + sparse, sparse, mlp)
+    bench.init_weights_device(model, torch.device("cuda"), 0, 0, std=0.05)
+    g = torch.Generator().manual_seed(3)
+    for m in model.modules():                      # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    model.eval()
+    x = bench._deepfm_batch(B, 77, "uniform", "cuda")
+    with torch.no_grad():
+        pred = model(x)
+    pick = torch.randint(0, B, (512,), generator=g)
+    ref = R.RefDeepFM(dense + sparse, sparse, mlp).double().eval()
+    sd = {k: v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu() for k, v in model.state_dict().items()}
+    ref.load_state_dict(sd)
+    xs = {k: (v[pick.cuda()].cpu().double() if v.is_floating_point() else v[pick.cuda()].cpu()) for k, v in x.items()}
+    with torch.no_grad():
+        want = ref(xs)
+    assert_close(pred[pick.cuda()], want, TOL, "predictions of the sampled rows")
+    # gradients on the sampled sub-batch (eval-mode BatchNorm): every dense parameter, and the rows of one large table
+    sub = {k: v[pick.cuda()].contiguous() for k, v in x.items()}
+    F.binary_cross_entropy(model(sub), sub["label"], reduction="sum").backward()
+    F.binary_cross_entropy(ref(xs), xs["label"].double(), reduction="sum").backward()
+    wantp = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        if "embed_dict" in n and p.shape[0] > 100000 and "C2" not in n:
+            continue                                # (one 1 M-row table is enough; the rest are 256 MB of zeros each)
+        assert_close(p.grad, wantp[n].grad, 2e-4, "grad " + n)
+
+
+def test_sasrec_cfg5_full_size_vs_oracle():
+    """BASELINE.json cfg 5's shape (1 M items, D = 64, L = 200, 2 blocks, one head) at B = 512 against the oracle's
+    restatement on the CPU: both logit blocks and the gradients of every block parameter; the item-table gradient through
+    its touched rows."""
+    import bench
+    from oracle import torch_ref as R
+    from recbox_amd.rechub.models.matching import SASRec
+    V, D, L, B = 1_000_000, 64, 200, 512
+    feats = bench._sasrec_features(V, D)
+    with torch.device("cuda"):
+        model = SASRec(feats, max_len=L, dropout_rate=0.0, num_blocks=2, num_heads=1)
+    bench.init_weights_device(model, torch.device("cuda"), 0, 0, std=0.1)
+    model.train()
+    x = bench._sasrec_batch(B, V, L, 5, "cuda")
+    ref = R.RefSASRec(feats, max_len=L, dropout_rate=0.0, num_blocks=2, num_heads=1).train()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    xc = {k: v.cpu() for k, v in x.items()}
+    pl, nl = model(x)
+    pl0, nl0 = ref(xc)
+    assert_close(pl, pl0, 2e-4, "pos logits")       # logits are O(10): sums of 64 products of O(1) values
+    assert_close(nl, nl0, 2e-4, "neg logits")
+    w = x["weight"] * float((x["seq"] != 0).sum())                           # 1 on real positions
+    (-((F.logsigmoid(pl) + F.logsigmoid(-nl)) * w).sum()).backward()
+    (-((F.logsigmoid(pl0) + F.logsigmoid(-nl0)) * w.cpu()).sum()).backward()
+    wantp = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        want = wantp[n].grad
+        tol = 1e-4 * max(1.0, float(want.abs().max()))                        # sums over up to 100 000 positions
+        if n.endswith("embed_dict.seq.weight"):
+            rows = torch.unique(torch.cat([xc["seq"].reshape(-1), xc["pos"].reshape(-1), xc["neg"].reshape(-1)]))[:20000]
+            assert_close(p.grad[rows.cuda()], want[rows], tol, "item rows")
+            continue
+        assert_close(p.grad, want, tol, "grad " + n)
