@@ -475,6 +475,27 @@ int rbx_attn_dropout_bwd(const float* d_q, const float* d_k, const float* d_v, c
 int rbx_attn_dropout_mask(int64_t bh, int32_t lq, int32_t lk, float p_drop, uint64_t seed, const uint64_t* d_seed_add,
                           uint8_t* d_keep, void* stream);
 
+/* ---- K7, second half: the loss epilogue over the sampled logits (one forward pass + fixed-order final sum, one
+ * backward pass; ATen runs log_softmax / nll_loss / log_sigmoid / mul / sum and their backward as 4-8 kernels each).
+ *   rbx_softmax_ce_*        mean_r [ logsumexp(x[r, :]) - x[r, t_r] ] over logits [rows, n_classes] (row stride in floats):
+ *                           core/pytorch/losses/softmax_crossentropy_loss.py:14-22 (t = 0: -log softmax(y_pred)[:, 0]) and
+ *                           the CrossEntropyLoss of third_party/rechub/trainers/match_trainer.py:59-60.  d_target NULL = 0;
+ *                           a target outside [0, n_classes) sets *d_status (torch raises).  d_lse[rows] is kept for the
+ *                           backward, which writes d_dlogits [rows, n_classes] contiguous.
+ *   rbx_pair_logsigmoid_*   scale * sum_i -w_i (log sigmoid(pos_i) + log sigmoid(-neg_i)): the pos/neg objective over
+ *                           the [B, L] logit blocks of third_party/rechub/models/matching/sasrec.py:100-107 (w = 1 on
+ *                           real positions, 0 on padding; NULL = all ones). */
+size_t rbx_loss_workspace_size(int64_t n);
+int rbx_softmax_ce_fwd(const float* d_logits, int64_t stride, int64_t rows, int32_t n_classes, const int64_t* d_target,
+                       float* d_loss, float* d_lse, int32_t* d_status, void* d_workspace, size_t workspace_bytes,
+                       void* stream);
+int rbx_softmax_ce_bwd(const float* d_logits, int64_t stride, int64_t rows, int32_t n_classes, const int64_t* d_target,
+                       const float* d_lse, const float* d_dloss, float* d_dlogits, void* stream);
+int rbx_pair_logsigmoid_fwd(const float* d_pos, const float* d_neg, const float* d_weight, int64_t n, float scale,
+                            float* d_loss, void* d_workspace, size_t workspace_bytes, void* stream);
+int rbx_pair_logsigmoid_bwd(const float* d_pos, const float* d_neg, const float* d_weight, const float* d_dloss, int64_t n,
+                            float scale, float* d_dpos, float* d_dneg, void* stream);
+
 /* ---- pooling of a materialised [B,L,D] tensor (standalone pooling modules) ------
  * core/pytorch/layers/sequence.py:4-20, ranking/pytorch/layers/pooling.py:22-40,
  * third_party/rechub/basic/layers.py:176-230.

@@ -1,8 +1,9 @@
 """List-wise / pair-wise losses over ``y_pred[B, 1 + num_negs]`` (column 0 = the positive item).
 Drop-in names for ``recbox.core.pytorch.losses`` (/root/reference/recbox/core/pytorch/losses/*.py).
 They close the forward->backward loop of the two-tower models; each is a scalar reduction over a
-tiny ``[B, N]`` tensor, so -- as SURVEY.md a-13 prescribes -- they stay ATen expressions rather than
-HIP kernels (the hot kernels upstream of them produce ``y_pred``)."""
+tiny ``[B, N]`` tensor.  ``SoftmaxCrossEntropyLoss`` -- the sampled-softmax loss, the second half of SURVEY.md's K7 --
+runs on the fused ``rbx_softmax_ce_*`` epilogue; the others stay ATen expressions as SURVEY.md a-13 prescribes (the hot
+kernels upstream of them produce ``y_pred``)."""
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -19,6 +20,9 @@ class SoftmaxCrossEntropyLoss(nn.Module):
     """Sampled softmax: -log softmax(y)[:, 0], mean over the batch (softmax_crossentropy_loss.py:19-22)."""
 
     def forward(self, y_pred, y_true):
+        if y_pred.is_cuda and y_pred.dim() == 2:         # K7's loss epilogue: one pass each way (rbx_softmax_ce_*)
+            from ... import ops
+            return ops.softmax_cross_entropy(y_pred)
         return -torch.log(F.softmax(y_pred, dim=1)[:, 0]).mean()
 
 

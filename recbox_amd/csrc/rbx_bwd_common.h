@@ -12,7 +12,15 @@ constexpr int kSortThreads = 256;
 #endif
 constexpr int kSortItems = RBX_SORT_ITEMS;                 // per thread
 constexpr int kSortTile = kSortThreads * kSortItems;       // 2048 pairs per workgroup
-constexpr int kRadix = 256;
+constexpr int kRadix = 256;                                // bins of an 8-bit digit (the sort also runs 10- and 11-bit digits)
+// Widest digit the plan may choose.  10- and 11-bit digits (2 passes instead of 3 for 1 M-row tables) were measured on
+// the Criteo shape and LOST: a 2048-pair tile then scatters into 1024 buckets of ~2 pairs (8-byte runs instead of
+// 32-byte ones) and its per-digit steps are 4x longer -- radix_scatter 32.5 us per pass instead of 17.8, the sort 114 us
+// instead of 105 (profiles/r02/sort_variants.txt).  The kernels stay templated on the digit width.
+#ifndef RBX_MAX_RADIX_BITS
+#define RBX_MAX_RADIX_BITS 8
+#endif
+constexpr int kMaxRadixBits = RBX_MAX_RADIX_BITS;
 constexpr int kChunk = 32;                                 // sorted pairs per lane group in the reduce (16 measured slower)
 constexpr unsigned kLocalBits = 26;                        // val = slot << 26 | (b*L + l)
 constexpr unsigned kLocalMask = (1u << kLocalBits) - 1u;
@@ -46,6 +54,31 @@ struct RedField {            // 40 B
 };
 struct RedPack { RedField f[RBX_MAX_FIELDS]; };
 
+// The sort is SEGMENTED: lookups are laid out field after field, and the fields of one table (or of tables that share
+// fields with it) form a contiguous segment with its own contiguous row range -- so only the row number INSIDE the
+// segment has to be sorted, in ceil(bits / digit) passes over digit bits each (Criteo: 1 M-row tables -> 2 passes of
+// 10 bits instead of 3 passes of 8 over the 23-bit global row).  A sort tile never straddles two segments.
+struct SegPack {
+  unsigned tile0[RBX_MAX_FIELDS + 1];   // first tile of every segment (+ total)
+  unsigned lk0[RBX_MAX_FIELDS + 1];     // first lookup of every segment (+ total)
+  unsigned row0[RBX_MAX_FIELDS];        // first global row of the segment
+  int n;
+};
+
+// (segment, first lookup, lookups) of the tile a workgroup owns
+__device__ __forceinline__ void seg_of_tile(const SegPack& S, unsigned tile, int* seg, unsigned* first, unsigned* count) {
+  int lo = 0, hi = S.n - 1;                         // last segment with tile0 <= tile
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (S.tile0[mid] <= tile) lo = mid; else hi = mid - 1;
+  }
+  *seg = lo;
+  const unsigned f = S.lk0[lo] + (tile - S.tile0[lo]) * static_cast<unsigned>(kSortTile);
+  const unsigned end = S.lk0[lo + 1];
+  *first = f;
+  *count = (end - f < static_cast<unsigned>(kSortTile)) ? end - f : static_cast<unsigned>(kSortTile);
+}
+
 struct NumField {            // numeric features: grad[d] += sum_b x_b * dY[b, off+d]
   const void* ids;
   float* grad;
@@ -65,6 +98,8 @@ struct BwdPlan {
   unsigned n_lookups = 0;      // pairs to sort
   unsigned total_rows = 0;     // sentinel key
   int passes = 0;
+  int radix_bits = 8;          // digit width of a pass: 8, 10 or 11
+  SegPack segs;
   int max_dim = 1;
   bool vec = true;
   // workspace layout (byte offsets)

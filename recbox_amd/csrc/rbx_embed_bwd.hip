@@ -37,6 +37,8 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
   int seen_dim[RBX_MAX_FIELDS];
   long long seen_vocab[RBX_MAX_FIELDS];
   int n_seen = 0;
+  int field_table[RBX_MAX_FIELDS];         // table index of every categorical field, in KeyPack order
+  unsigned field_lookups[RBX_MAX_FIELDS];
   p->vec = (stride_b % 4 == 0) && ((reinterpret_cast<uintptr_t>(dout) & 15) == 0);
   for (int i = 0; i < n; ++i) {
     const rbx_field_t& f = fields[i];
@@ -69,6 +71,8 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
       rows += static_cast<unsigned long long>(f.vocab);
     }
     const int c = p->n_cat++;
+    field_table[c] = hit;
+    field_lookups[c] = static_cast<unsigned>(n_lk);
     KeyField& kf = p->keys.f[c];
     kf.ids = f.ids;
     kf.stride_b = f.ids_stride_b;
@@ -99,10 +103,49 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
     return fail(RBX_ERR_UNSUPPORTED, "too many lookups/rows for one call (%llu / %llu)", lookups, rows);
   p->n_lookups = static_cast<unsigned>(lookups);
   p->total_rows = static_cast<unsigned>(rows);
-  int bits = 1;
-  while ((1ull << bits) <= rows) ++bits;           // the sentinel key == rows must be representable
-  p->passes = (bits + 7) / 8;
-  p->n_tiles = (p->n_lookups + kSortTile - 1) / kSortTile;
+  // segments: maximal runs of consecutive fields closed under table sharing.  Tables are numbered in first-seen order,
+  // so the tables first seen inside a segment own one contiguous row range.
+  {
+    int last_field_of_table[RBX_MAX_FIELDS];
+    for (int c = 0; c < p->n_cat; ++c) last_field_of_table[field_table[c]] = c;
+    SegPack& S = p->segs;
+    S.n = 0;
+    unsigned tiles = 0, lk = 0;
+    unsigned long long max_rows = 1;
+    int c = 0;
+    while (c < p->n_cat) {
+      int end = last_field_of_table[field_table[c]];
+      unsigned long long seg_rows = 0;
+      unsigned seg_lk = 0;
+      const unsigned row0 = p->keys.f[c].row_base;
+      int t_lo = field_table[c], t_hi = field_table[c];
+      for (int k = c; k <= end; ++k) {
+        if (last_field_of_table[field_table[k]] > end) end = last_field_of_table[field_table[k]];
+        if (field_table[k] > t_hi) t_hi = field_table[k];
+        if (field_table[k] < t_lo) t_lo = field_table[k];
+        seg_lk += field_lookups[k];
+      }
+      for (int t = t_lo; t <= t_hi; ++t) seg_rows += static_cast<unsigned long long>(seen_vocab[t]);
+      if (seg_lk > 0) {                                  // (an empty batch has no tiles)
+        S.tile0[S.n] = tiles;
+        S.lk0[S.n] = lk;
+        S.row0[S.n] = row0;
+        ++S.n;
+        tiles += (seg_lk + kSortTile - 1) / kSortTile;
+        lk += seg_lk;
+        if (seg_rows > max_rows) max_rows = seg_rows;
+      }
+      c = end + 1;
+    }
+    S.tile0[S.n] = tiles;
+    S.lk0[S.n] = lk;
+    p->n_tiles = tiles;
+    int bits = 1;
+    while ((1ull << bits) <= max_rows) ++bits;     // 2^bits > rows of the largest segment: the all-ones key is free for masked lookups
+    p->passes = (bits + kMaxRadixBits - 1) / kMaxRadixBits;
+    const int per = (bits + p->passes - 1) / p->passes;
+    p->radix_bits = per <= 8 ? 8 : (per <= 10 ? 10 : 11);
+  }
   p->n_chunks = (p->n_lookups + kChunk - 1) / kChunk;
   p->num_blocks = static_cast<unsigned>((B + kNumSamples - 1) / kNumSamples);
   size_t o = 0;
@@ -111,8 +154,9 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
   p->off_keys[1] = o; o += nl;
   p->off_vals[0] = o; o += nl;
   p->off_vals[1] = o; o += nl;
-  p->off_hist = o; o += align_up(static_cast<size_t>(p->n_tiles) * kRadix * 4 + 4, 256);
-  p->off_ssum = o; o += align_up((static_cast<size_t>(p->n_tiles) * kRadix / 4096 + 2) * 4, 256);
+  const size_t radix = static_cast<size_t>(1) << p->radix_bits;
+  p->off_hist = o; o += align_up(static_cast<size_t>(p->n_tiles) * radix * 4 + 4, 256);
+  p->off_ssum = o; o += align_up((static_cast<size_t>(p->n_tiles) * radix / 4096 + 2) * 4, 256);
   p->sum_stride = p->max_dim + extra_dim;
   p->off_head = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
   p->off_tail = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
@@ -124,11 +168,19 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
 }
 
 // ---- build_keys ----------------------------------------------------------------
-__global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack P, const int n_cat, const unsigned n_lookups,
+// digit `shift / RB` of a key inside its segment; masked lookups (key == sentinel) are all ones: last in every pass
+template <int RB>
+__device__ __forceinline__ unsigned seg_digit(unsigned key, unsigned sentinel, unsigned row0, int shift) {
+  const unsigned local = (key == sentinel) ? 0xFFFFFFFFu : key - row0;
+  return (local >> shift) & ((1u << RB) - 1u);
+}
+
+template <int RB>
+__global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack P, const int n_cat, const SegPack S,
                                                          const unsigned sentinel, unsigned* __restrict__ keys,
                                                          unsigned* __restrict__ vals, int* __restrict__ status,
-                                                         unsigned* __restrict__ fin, unsigned* __restrict__ hist,
-                                                         const unsigned n_tiles) {
+                                                         unsigned* __restrict__ fin, unsigned* __restrict__ hist) {
+  constexpr int R = 1 << RB;
   if (blockIdx.x == 0 && threadIdx.x == 0) {          // fix-up work-list length and arrival counter (rbx_segreduce.h)
     fin[0] = 0;
     fin[1] = 0;
@@ -143,14 +195,19 @@ __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack 
   }
   // one workgroup per sort tile, so that the tile's histogram of the FIRST radix digit falls out of the same pass
   // (the keys are in registers anyway): the first radix_hist_kernel launch of the sort is not needed
-  __shared__ unsigned cnt[kRadix];
-  cnt[threadIdx.x] = 0;
+  __shared__ unsigned cnt[R];
+  for (int d = threadIdx.x; d < R; d += kSortThreads) cnt[d] = 0;
   __syncthreads();
-  const unsigned tile0 = blockIdx.x * kSortTile;
+  int seg;
+  unsigned tile0, tile_n;
+  seg_of_tile(S, blockIdx.x, &seg, &tile0, &tile_n);
+  const unsigned row0 = S.row0[seg];
+  // (a two-sweep variant -- all raw id loads first, decoding afterwards -- was measured slower: 19.3 vs 16.3 us)
 #pragma unroll
   for (int it = 0; it < kSortItems; ++it) {
-    const unsigned j = tile0 + it * kSortThreads + threadIdx.x;
-    if (j >= n_lookups) break;
+    const unsigned off = it * kSortThreads + threadIdx.x;
+    if (off >= tile_n) break;
+    const unsigned j = tile0 + off;
     int lo = 0, hi = n_cat - 1;                      // last field with lk_off <= j
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
@@ -172,27 +229,39 @@ __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack 
     }
     keys[j] = key;
     vals[j] = (static_cast<unsigned>(lo) << kLocalBits) | local;
-    atomicAdd(&cnt[key & 0xFFu], 1u);
+    atomicAdd(&cnt[seg_digit<RB>(key, sentinel, row0, 0)], 1u);
   }
   __syncthreads();
-  hist[threadIdx.x * n_tiles + blockIdx.x] = cnt[threadIdx.x];   // digit-major, as radix_hist_kernel writes it
+  // histogram layout: segment, then digit, then tile of the segment -- one flat exclusive scan then yields, for every
+  // (digit, tile), the global position of its first pair
+  const unsigned t_in = blockIdx.x - S.tile0[seg], nt = S.tile0[seg + 1] - S.tile0[seg];
+  unsigned* h = hist + static_cast<size_t>(S.tile0[seg]) * R + t_in;
+  for (int d = threadIdx.x; d < R; d += kSortThreads) h[static_cast<size_t>(d) * nt] = cnt[d];
 }
 
 // ---- radix sort: per-tile digit histogram ----------------------------------------
-__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const unsigned* __restrict__ keys, const unsigned n,
-                                                                  const int shift, unsigned* __restrict__ hist,
-                                                                  const unsigned n_tiles) {
-  __shared__ unsigned cnt[kRadix];
-  cnt[threadIdx.x] = 0;
+template <int RB>
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const unsigned* __restrict__ keys, const SegPack S,
+                                                                  const unsigned sentinel, const int shift,
+                                                                  unsigned* __restrict__ hist) {
+  constexpr int R = 1 << RB;
+  __shared__ unsigned cnt[R];
+  for (int d = threadIdx.x; d < R; d += kSortThreads) cnt[d] = 0;
   __syncthreads();
-  const unsigned base = blockIdx.x * kSortTile;
+  int seg;
+  unsigned tile0, tile_n;
+  seg_of_tile(S, blockIdx.x, &seg, &tile0, &tile_n);
+  const unsigned row0 = S.row0[seg];
+  // (loading the 8 keys of a thread before the first LDS atomic was measured slower: 11.3 vs 9.1 us)
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
-    const unsigned j = base + i * kSortThreads + threadIdx.x;
-    if (j < n) atomicAdd(&cnt[(keys[j] >> shift) & 0xFFu], 1u);
+    const unsigned off = i * kSortThreads + threadIdx.x;
+    if (off < tile_n) atomicAdd(&cnt[seg_digit<RB>(keys[tile0 + off], sentinel, row0, shift)], 1u);
   }
   __syncthreads();
-  hist[threadIdx.x * n_tiles + blockIdx.x] = cnt[threadIdx.x];   // digit-major for the scan
+  const unsigned t_in = blockIdx.x - S.tile0[seg], nt = S.tile0[seg + 1] - S.tile0[seg];
+  unsigned* h = hist + static_cast<size_t>(S.tile0[seg]) * R + t_in;
+  for (int d = threadIdx.x; d < R; d += kSortThreads) h[static_cast<size_t>(d) * nt] = cnt[d];
 }
 
 // ---- exclusive scan of hist[256 * n_tiles], two levels -------------------------------
@@ -264,25 +333,33 @@ __global__ __launch_bounds__(1024) void radix_scan_sums_kernel(unsigned* __restr
 // ---- stable scatter of one tile -----------------------------------------------------
 // Wave w owns the contiguous quarter [w*512, (w+1)*512) of the tile and walks it in
 // 64-item steps, so tile order == (wave, step, lane) and ranks respect it.
+template <int RB>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsigned* __restrict__ keys_in,
                                                                      const unsigned* __restrict__ vals_in,
                                                                      unsigned* __restrict__ keys_out,
-                                                                     unsigned* __restrict__ vals_out, const unsigned n,
-                                                                     const int shift, const unsigned* __restrict__ hist,
+                                                                     unsigned* __restrict__ vals_out, const SegPack S,
+                                                                     const unsigned sentinel, const int shift,
+                                                                     const unsigned* __restrict__ hist,
                                                                      const unsigned* __restrict__ slice_sum,
-                                                                     const unsigned n_tiles, const unsigned n_slices,
-                                                                     const bool raw_sums) {
+                                                                     const unsigned n_slices, const bool raw_sums) {
+  constexpr int R = 1 << RB;
+  constexpr int DPT = R / kSortThreads;              // digits per thread in the per-digit steps
   constexpr int kWaves = kSortThreads / 64;
   constexpr int kPerWave = kSortTile / kWaves;       // 512
   constexpr int kSteps = kPerWave / 64;              // 8
-  __shared__ unsigned wcnt[kWaves][kRadix];          // per-wave digit counts, then running offsets
-  __shared__ unsigned dstart[kRadix];                // tile-local start of each digit
-  __shared__ unsigned gbase[kRadix];                 // global start of (digit, tile)
+  __shared__ unsigned wcnt[kWaves][R];               // per-wave digit counts, then running offsets
+  __shared__ unsigned dstart[R];                     // tile-local start of each digit
+  __shared__ unsigned gbase[R];                      // global start of (digit, tile)
   __shared__ unsigned skey[kSortTile];
   __shared__ unsigned sval[kSortTile];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const unsigned tile0 = blockIdx.x * kSortTile;
-  for (int i = threadIdx.x; i < kWaves * kRadix; i += kSortThreads) (&wcnt[0][0])[i] = 0;
+  int seg;
+  unsigned tile0, tile_n;
+  seg_of_tile(S, blockIdx.x, &seg, &tile0, &tile_n);
+  const unsigned row0 = S.row0[seg];
+  const unsigned t_in = blockIdx.x - S.tile0[seg], nt = S.tile0[seg + 1] - S.tile0[seg];
+  const size_t hbase = static_cast<size_t>(S.tile0[seg]) * R + t_in;
+  for (int i = threadIdx.x; i < kWaves * R; i += kSortThreads) (&wcnt[0][0])[i] = 0;
   if (raw_sums) {
     // slice_sum holds the slice TOTALS as radix_scan_local_kernel left them (at most kMaxFusedSlices of them): every
     // workgroup scans them itself (a few dozen values at the bench shape) instead of waiting for a separate
@@ -310,11 +387,15 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
       run += t[q];
     }
     __syncthreads();
-    const unsigned hi = threadIdx.x * n_tiles + blockIdx.x;
-    gbase[threadIdx.x] = hist[hi] + spre[hi / kScanSlice];
+    for (int d = threadIdx.x; d < R; d += kSortThreads) {
+      const size_t hi = hbase + static_cast<size_t>(d) * nt;
+      gbase[d] = hist[hi] + spre[hi / kScanSlice];
+    }
   } else {
-    const unsigned hi = threadIdx.x * n_tiles + blockIdx.x;
-    gbase[threadIdx.x] = hist[hi] + slice_sum[hi / kScanSlice];
+    for (int d = threadIdx.x; d < R; d += kSortThreads) {
+      const size_t hi = hbase + static_cast<size_t>(d) * nt;
+      gbase[d] = hist[hi] + slice_sum[hi / kScanSlice];
+    }
   }
   __syncthreads();
 
@@ -322,15 +403,20 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
   unsigned rank[kSteps];                             // rank inside (wave, digit)
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
+  for (int s = 0; s < kSteps; ++s) {                 // all 16 loads of the thread in flight before the first is used
+    const unsigned off = wid * kPerWave + s * 64 + lane;
+    const bool ok = off < tile_n;
+    k[s] = ok ? __builtin_nontemporal_load(keys_in + tile0 + off) : 0xFFFFFFFFu;
+    v[s] = ok ? __builtin_nontemporal_load(vals_in + tile0 + off) : 0u;
+  }
+#pragma unroll
   for (int s = 0; s < kSteps; ++s) {
-    const unsigned j = tile0 + wid * kPerWave + s * 64 + lane;
-    const bool ok = j < n;
-    k[s] = ok ? keys_in[j] : 0xFFFFFFFFu;
-    v[s] = ok ? vals_in[j] : 0u;
-    const unsigned d = ok ? ((k[s] >> shift) & 0xFFu) : 0x100u;   // out-of-range lanes match nobody real
+    const unsigned off = wid * kPerWave + s * 64 + lane;
+    const bool ok = off < tile_n;
+    const unsigned d = ok ? seg_digit<RB>(k[s], sentinel, row0, shift) : 0u;
     unsigned long long peers = __ballot(ok);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < RB; ++b) {
       const unsigned long long m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
@@ -345,18 +431,24 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
     if (ok && before == 0) wc[d] = prev + __popcll(peers);
   }
   __syncthreads();
-  // per digit: exclusive prefix over waves, then over digits (one thread per digit)
+  // per digit: exclusive prefix over waves, then over digits (a thread owns DPT consecutive digits)
   {
-    const int d = threadIdx.x;
-    unsigned run = 0;
+    unsigned runs[DPT];
+    unsigned mine = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      const unsigned c = wcnt[w][d];
-      wcnt[w][d] = run;
-      run += c;
+    for (int q = 0; q < DPT; ++q) {
+      const int d = threadIdx.x * DPT + q;
+      unsigned run = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const unsigned c = wcnt[w][d];
+        wcnt[w][d] = run;
+        run += c;
+      }
+      runs[q] = run;
+      mine += run;
     }
-    // exclusive scan of `run` over the 256 digits
-    unsigned inc = run;
+    unsigned inc = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const unsigned t = __shfl_up(inc, o, 64);
@@ -365,29 +457,32 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
     __shared__ unsigned wtot[kWaves];
     if (lane == 63) wtot[wid] = inc;
     __syncthreads();
-    unsigned wb = 0;
-    for (int w = 0; w < wid; ++w) wb += wtot[w];
-    dstart[d] = wb + inc - run;
+    unsigned base = inc - mine;
+    for (int w = 0; w < wid; ++w) base += wtot[w];
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+      dstart[threadIdx.x * DPT + q] = base;
+      base += runs[q];
+    }
   }
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < kSteps; ++s) {
-    const unsigned j = tile0 + wid * kPerWave + s * 64 + lane;
-    if (j < n) {
-      const unsigned d = (k[s] >> shift) & 0xFFu;
+    const unsigned off = wid * kPerWave + s * 64 + lane;
+    if (off < tile_n) {
+      const unsigned d = seg_digit<RB>(k[s], sentinel, row0, shift);
       const unsigned pos = dstart[d] + wcnt[wid][d] + rank[s];
       skey[pos] = k[s];
       sval[pos] = v[s];
     }
   }
   __syncthreads();
-  const unsigned tile_n = (n - tile0 < static_cast<unsigned>(kSortTile)) ? (n - tile0) : kSortTile;
 #pragma unroll
   for (int i = 0; i < kSortItems; ++i) {
     const unsigned pos = i * kSortThreads + threadIdx.x;
     if (pos < tile_n) {
       const unsigned key = skey[pos];
-      const unsigned d = (key >> shift) & 0xFFu;
+      const unsigned d = seg_digit<RB>(key, sentinel, row0, shift);
       const unsigned g = gbase[d] + (pos - dstart[d]);
       keys_out[g] = key;
       vals_out[g] = sval[pos];
@@ -501,38 +596,44 @@ extern "C" size_t rbx_embed_bwd_workspace_size(const rbx_field_t* fields, int32_
 }
 
 namespace rbx {
-int run_sort(const BwdPlan& p, char* ws, int* d_status, hipStream_t s) {
-  if (p.n_lookups == 0) return RBX_OK;
+template <int RB>
+static int run_sort_rb(const BwdPlan& p, char* ws, int* d_status, hipStream_t s) {
+  constexpr int R = 1 << RB;
   unsigned* keys[2] = {reinterpret_cast<unsigned*>(ws + p.off_keys[0]), reinterpret_cast<unsigned*>(ws + p.off_keys[1])};
   unsigned* vals[2] = {reinterpret_cast<unsigned*>(ws + p.off_vals[0]), reinterpret_cast<unsigned*>(ws + p.off_vals[1])};
   unsigned* hist = reinterpret_cast<unsigned*>(ws + p.off_hist);
   unsigned* ssum = reinterpret_cast<unsigned*>(ws + p.off_ssum);
-  int rc;
-  {
-    hipLaunchKernelGGL(build_keys_kernel, dim3(p.n_tiles), dim3(kSortThreads), 0, s, p.keys, p.n_cat, p.n_lookups,
-                       p.total_rows, keys[0], vals[0], d_status, reinterpret_cast<unsigned*>(ws + p.off_fin), hist,
-                       p.n_tiles);
-    rc = check_launch("build_keys_kernel");
-    if (rc != RBX_OK) return rc;
-  }
+  hipLaunchKernelGGL(build_keys_kernel<RB>, dim3(p.n_tiles), dim3(kSortThreads), 0, s, p.keys, p.n_cat, p.segs, p.total_rows,
+                     keys[0], vals[0], d_status, reinterpret_cast<unsigned*>(ws + p.off_fin), hist);
+  int rc = check_launch("build_keys_kernel");
+  if (rc != RBX_OK) return rc;
   int cur = 0;
   for (int pass = 0; pass < p.passes; ++pass) {
-    const int shift = pass * 8;
+    const int shift = pass * RB;
     if (pass > 0)        // (the first digit's histograms come out of build_keys_kernel)
-      hipLaunchKernelGGL(radix_hist_kernel, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], p.n_lookups, shift, hist,
-                         p.n_tiles);
-    const unsigned hist_len = p.n_tiles * kRadix;
+      hipLaunchKernelGGL(radix_hist_kernel<RB>, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], p.segs, p.total_rows,
+                         shift, hist);
+    const unsigned hist_len = p.n_tiles * R;
     const unsigned n_slices = (hist_len + kScanSlice - 1) / kScanSlice;
     hipLaunchKernelGGL(radix_scan_local_kernel, dim3(n_slices), dim3(1024), 0, s, hist, hist_len, ssum);
     const bool raw_sums = n_slices <= static_cast<unsigned>(kMaxFusedSlices);
     if (!raw_sums) hipLaunchKernelGGL(radix_scan_sums_kernel, dim3(1), dim3(1024), 0, s, ssum, n_slices);
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], vals[cur],
-                       keys[cur ^ 1], vals[cur ^ 1], p.n_lookups, shift, hist, ssum, p.n_tiles, n_slices, raw_sums);
+    hipLaunchKernelGGL(radix_scatter_kernel<RB>, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], vals[cur],
+                       keys[cur ^ 1], vals[cur ^ 1], p.segs, p.total_rows, shift, hist, ssum, n_slices, raw_sums);
     rc = check_launch("radix pass");
     if (rc != RBX_OK) return rc;
     cur ^= 1;
   }
   return RBX_OK;
+}
+
+int run_sort(const BwdPlan& p, char* ws, int* d_status, hipStream_t s) {
+  if (p.n_lookups == 0) return RBX_OK;
+  switch (p.radix_bits) {
+    case 8: return run_sort_rb<8>(p, ws, d_status, s);
+    case 10: return run_sort_rb<10>(p, ws, d_status, s);
+    default: return run_sort_rb<11>(p, ws, d_status, s);
+  }
 }
 }  // namespace rbx
 

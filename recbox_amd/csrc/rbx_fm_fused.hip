@@ -580,7 +580,8 @@ namespace rbx {
 // (table order and sizes, padding / mask ids, sequence lengths): e.g. the embedding tables and the dim-1 LR tables of
 // one batch.  Member-wise: the packs are not zero-initialised.
 static bool same_pairs(const BwdPlan& a, const BwdPlan& b) {
-  if (a.n_cat != b.n_cat || a.n_lookups != b.n_lookups || a.total_rows != b.total_rows || a.passes != b.passes) return false;
+  if (a.n_cat != b.n_cat || a.n_lookups != b.n_lookups || a.total_rows != b.total_rows || a.passes != b.passes ||
+      a.radix_bits != b.radix_bits || a.n_tiles != b.n_tiles) return false;
   for (int i = 0; i < a.n_cat; ++i) {
     const KeyField& x = a.keys.f[i];
     const KeyField& y = b.keys.f[i];

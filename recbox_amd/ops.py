@@ -1692,3 +1692,80 @@ def attention_dropout_mask(bh, lq, lk, dropout_p, seed, device="cuda"):
         check(lib.rbx_attn_dropout_mask(bh, lq, lk, float(dropout_p), int(seed), _ptr(dropout_tick(device)), _ptr(keep),
                                         _stream()))
     return keep.bool()
+
+
+class _SoftmaxCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        _require_cuda(logits, "logits")
+        x = _rows_view(logits)
+        rows, n = x.shape
+        t = None
+        if target is not None:
+            t = target.reshape(-1).long().contiguous()
+            if t.numel() != rows:
+                raise ValueError("Expected input batch_size ({}) to match target batch_size ({}).".format(rows, t.numel()))
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        lse = torch.empty(rows, dtype=torch.float32, device=x.device)
+        status = torch.zeros(1, dtype=torch.int32, device=x.device) if (config.check_ids and t is not None) else None
+        ws_bytes = lib.rbx_loss_workspace_size(rows)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        check(lib.rbx_softmax_ce_fwd(_ptr(x), x.stride(0) if rows > 1 else n, rows, n, _ptr(t), _ptr(loss), _ptr(lse),
+                                     _ptr(status), _ptr(ws), ws_bytes, _stream()))
+        if status is not None and int(status.item()) != 0:
+            raise IndexError("Target is out of bounds.")
+        ctx.save_for_backward(x, t, lse)
+        ctx.shape = logits.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, lse = ctx.saved_tensors
+        rows, n = x.shape
+        dx = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+        g = g.contiguous().float().view(1)
+        check(lib.rbx_softmax_ce_bwd(_ptr(x), x.stride(0) if rows > 1 else n, rows, n, _ptr(t), _ptr(lse), _ptr(g), _ptr(dx),
+                                     _stream()))
+        return dx.view(ctx.shape), None
+
+
+def softmax_cross_entropy(logits, target=None):
+    """``F.cross_entropy(logits, target)`` (mean over the rows) on [rows, n] logits; ``target=None`` = column 0 for every
+    row, i.e. ``-log softmax(y_pred)[:, 0].mean()`` -- the sampled-softmax loss over [B, 1 + num_negs] scores
+    (rbx_softmax_ce_fwd/bwd: one pass each way + a fixed-order final sum)."""
+    return _SoftmaxCE.apply(logits, target)
+
+
+class _PairLogSigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, neg, weight, scale):
+        _require_cuda(pos, "pos logits")
+        p = pos.contiguous().float().view(-1)
+        q = neg.contiguous().float().view(-1)
+        w = weight.contiguous().float().view(-1) if weight is not None else None
+        if q.numel() != p.numel() or (w is not None and w.numel() != p.numel()):
+            raise ValueError("pair_logsigmoid_loss: pos, neg and weight must have the same number of elements")
+        n = p.numel()
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        ws_bytes = lib.rbx_loss_workspace_size(n)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=p.device)
+        check(lib.rbx_pair_logsigmoid_fwd(_ptr(p), _ptr(q), _ptr(w), n, float(scale), _ptr(loss), _ptr(ws), ws_bytes,
+                                          _stream()))
+        ctx.save_for_backward(p, q, w)
+        ctx.scale, ctx.shapes = float(scale), (pos.shape, neg.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, q, w = ctx.saved_tensors
+        dp, dq = torch.empty_like(p), torch.empty_like(q)
+        g = g.contiguous().float().view(1)
+        check(lib.rbx_pair_logsigmoid_bwd(_ptr(p), _ptr(q), _ptr(w), _ptr(g), p.numel(), ctx.scale, _ptr(dp), _ptr(dq),
+                                          _stream()))
+        return dp.view(ctx.shapes[0]), dq.view(ctx.shapes[1]), None, None
+
+
+def pair_logsigmoid_loss(pos, neg, weight=None, scale=1.0):
+    """``scale * sum(-weight * (logsigmoid(pos) + logsigmoid(-neg)))``: the pos / neg objective over SASRec's [B, L] logit
+    blocks (weight = 1 on real positions, 0 on padding; scale = 1 / number of real positions for the mean)."""
+    return _PairLogSigmoid.apply(pos, neg, weight, scale)

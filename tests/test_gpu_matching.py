@@ -199,16 +199,26 @@ def test_batch_norm_vs_torch(rows, cols, relu):
         x = torch.randn(rows, cols, generator=g) * 2.0 + 3.0          # mean far from 0: E[x^2]-E[x]^2 would lose digits
         r = torch.randn(rows, cols, generator=g)
         xr = x.clone().requires_grad_(True)
-        yr = ref(xr)
-        yr = torch.relu(yr) if relu else yr
+        zr = ref(xr)
+        yr = torch.relu(zr) if relu else zr
         (yr * r).sum().backward()
         xc = x.cuda().requires_grad_(True)
         yc = ops.batch_norm(xc, dut, relu=relu)
         (yc * r.cuda()).sum().backward()
         assert_close(yc, yr.detach(), 1e-5, "y")
-        assert_close(xc.grad, xr.grad, 2e-4, "dx")
-        assert_close(dut.weight.grad, ref.weight.grad, 1e-4 * max(1.0, rows ** 0.5 / 4), "dgamma")
-        assert_close(dut.bias.grad, ref.bias.grad, 1e-4 * max(1.0, rows ** 0.5 / 4), "dbeta")
+        if relu:
+            # a pre-activation within a few ulp of zero may fall on either side of the ReLU in two fp32 implementations
+            # (the CPU reference's reduction order depends on its thread count): such an element's own gradient -- and,
+            # through the batch statistics, nothing else measurably -- legitimately differs; at most a handful exist
+            edge = zr.detach().abs() < 1e-5
+            assert int(edge.sum()) <= 8
+            keep_cols = ~edge.any(dim=0)             # (a flipped element moves its whole column's dx through the batch means)
+            assert_close(xc.grad.cpu()[:, keep_cols], xr.grad[:, keep_cols], 2e-4, "dx")
+        else:
+            assert_close(xc.grad, xr.grad, 2e-4, "dx")
+        cols_ok = ~(zr.detach().abs() < 1e-5).any(dim=0) if relu else torch.ones(cols, dtype=torch.bool)
+        assert_close(dut.weight.grad.cpu()[cols_ok], ref.weight.grad[cols_ok], 1e-4 * max(1.0, rows ** 0.5 / 4), "dgamma")
+        assert_close(dut.bias.grad.cpu()[cols_ok], ref.bias.grad[cols_ok], 1e-4 * max(1.0, rows ** 0.5 / 4), "dbeta")
         assert_close(dut.running_mean, ref.running_mean, 1e-6, "running_mean")
         assert_close(dut.running_var, ref.running_var, 1e-5, "running_var")
         assert int(dut.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
@@ -753,3 +763,53 @@ def test_sasrec_cfg5_full_size_vs_oracle():
             assert_close(p.grad[rows.cuda()], want[rows], tol, "item rows")
             continue
         assert_close(p.grad, want, tol, "grad " + n)
+
+
+@pytest.mark.parametrize("rows,n", [(1, 5), (257, 5), (65536, 5), (1000, 1), (300, 101)])
+def test_softmax_cross_entropy_epilogue_vs_torch(rows, n):
+    """K7's loss epilogue (rbx_softmax_ce_*): -log softmax(y)[:, 0] mean (softmax_crossentropy_loss.py:19-22) and the
+    general-target CrossEntropyLoss, forward and gradient, against torch in fp64; a column view of a wider block is read
+    in place; an out-of-range target raises; bit-identical on repeat."""
+    from recbox_amd import ops
+    import recbox_amd.core.pytorch.losses as Ls
+    g = torch.Generator().manual_seed(rows + n)
+    wide = (torch.randn(rows, n + 3, generator=g) * 4).cuda()
+    y = wide[:, :n]                                                       # row stride n + 3
+    for target in (None, torch.randint(0, n, (rows,), generator=g).cuda()):
+        x = y.detach().clone().requires_grad_() if False else y.detach().requires_grad_()
+        loss = ops.softmax_cross_entropy(x, target)
+        loss.backward()
+        xd = y.detach().double().cpu().requires_grad_()
+        t = torch.zeros(rows, dtype=torch.long) if target is None else target.cpu()
+        want = F.cross_entropy(xd, t)
+        want.backward()
+        assert_close(loss, want, 1e-5, "loss")
+        assert_close(x.grad, xd.grad, 1e-6, "dlogits")
+        again = ops.softmax_cross_entropy(y.detach(), target)
+        assert torch.equal(again, loss.detach())
+    crit = Ls.SoftmaxCrossEntropyLoss()
+    assert_close(crit(y.detach(), None), -torch.log(torch.softmax(y.detach().double().cpu(), 1)[:, 0]).mean(), 1e-5)
+    if n > 1:
+        with pytest.raises(IndexError):
+            ops.softmax_cross_entropy(y.detach(), torch.full((rows,), n, device="cuda"))
+
+
+@pytest.mark.parametrize("shape,weighted", [((7, 12), True), ((512, 200), True), ((1, 1), False), ((4096, 200), True)])
+def test_pair_logsigmoid_epilogue_vs_torch(shape, weighted):
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(shape[0])
+    pos, neg = (torch.randn(shape, generator=g) * 6 for _ in range(2))
+    w = None
+    if weighted:
+        keep = (torch.rand(shape, generator=g) > 0.3).float()
+        w = keep / keep.sum().clamp(min=1)
+    pc, nc = pos.cuda().requires_grad_(), neg.cuda().requires_grad_()
+    loss = ops.pair_logsigmoid_loss(pc, nc, w.cuda() if w is not None else None, scale=0.5)
+    loss.backward()
+    pd, nd = pos.double().requires_grad_(), neg.double().requires_grad_()
+    ww = w.double() if w is not None else 1.0
+    want = 0.5 * (-((F.logsigmoid(pd) + F.logsigmoid(-nd)) * ww).sum())
+    want.backward()
+    assert_close(loss, want, 1e-5, "loss", rtol=1e-5)
+    assert_close(pc.grad, pd.grad, 1e-6, "dpos")
+    assert_close(nc.grad, nd.grad, 1e-6, "dneg")
