@@ -141,10 +141,12 @@ def measured_traffic(path, kernel):
     (profiles/traffic_r01.json; FETCH_SIZE / WRITE_SIZE are collected in separate runs and
     corrected as MI355X_MICROARCH.md prescribes).  None when no measurement is on file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02", "traffic_r02.json")) as fh:
             rec = json.load(fh)
-        ent = rec.get(path, {})
-        return ent.get("hbm_bytes_per_launch") if ent.get("kernel") == kernel else None
+        ent = rec.get({"fused": "fm"}.get(path, path), {})
+        if kernel is not None and ent.get("kernel") != kernel:
+            return None
+        return ent.get("hbm_bytes_per_launch")
     except Exception:
         return None
 
@@ -457,7 +459,10 @@ def run_model_config(args, rank, world, dev):
         return
     kms = timer.mean_ms()
     if kms:
-        roof.update({"achieved": work / (kms * 1e-3) / 1e9, "kernel": kname, "kernel_ms": kms, "traffic": None,
+        traffic = None
+        if cfg == "youtubednn" and B == 65536 and (args.items or 10_000_000) == 10_000_000 and args.dist == "uniform":
+            traffic = measured_traffic("youtubednn_sharded" if sharded else "youtubednn", None)
+        roof.update({"achieved": work / (kms * 1e-3) / 1e9, "kernel": kname, "kernel_ms": kms, "traffic": traffic,
                      ("algorithmic_bytes_per_launch" if roof["bound"] == "hbm" else "algorithmic_flop_per_launch"): work,
                      "inputs": ("%d distinct batches rotated through the static buffers" % K) if K > 1 else "one batch replayed"})
         roof["frac"] = roof["achieved"] / roof["peak"]

@@ -475,6 +475,23 @@ int rbx_attn_dropout_bwd(const float* d_q, const float* d_k, const float* d_v, c
 int rbx_attn_dropout_mask(int64_t bh, int32_t lq, int32_t lk, float p_drop, uint64_t seed, const uint64_t* d_seed_add,
                           uint8_t* d_keep, void* stream);
 
+/* The same attention on PACKED operands (MFMA path only: seq_len <= 256, head_dim in {32, 64}, no explicit mask; anything
+ * else returns RBX_ERR_UNSUPPORTED): element (b, l, h, d) of a tensor sits at ptr + (b * seq_len + l) * ld + h * head_dim + d.
+ * nn.MultiheadAttention projects Q, K, V with Linear layers and then transposes / splits them into [B * H, L, hd] copies
+ * (sasrec.py:81-87 through torch/nn/functional.py multi_head_attention_forward); here the kernels read the projections'
+ * outputs where they are -- Q [B, L, E], K and V as the two halves of ONE fused [B, L, 2 E] projection (d_k = kv,
+ * d_v = kv + E, ldk = ldv = 2 E) -- and write O [B, L, E] for the output projection, dQ, and dK | dV into one
+ * [B, L, 2 E] gradient, so no transpose, split or concatenation kernel runs.  d_lse / d_scratch: [batch * heads, seq_len]. */
+int rbx_attn_packed_fwd(const float* d_q, int64_t ldq, const float* d_k, int64_t ldk, const float* d_v, int64_t ldv,
+                        int64_t batch, int32_t heads, int32_t seq_len, int32_t head_dim, float scale, int32_t causal,
+                        float p_drop, uint64_t seed, const uint64_t* d_seed_add, float* d_o, int64_t ldo, float* d_lse,
+                        void* stream);
+int rbx_attn_packed_bwd(const float* d_q, int64_t ldq, const float* d_k, int64_t ldk, const float* d_v, int64_t ldv,
+                        const float* d_o, int64_t ldo, const float* d_do, int64_t lddo, const float* d_lse, int64_t batch,
+                        int32_t heads, int32_t seq_len, int32_t head_dim, float scale, int32_t causal, float p_drop,
+                        uint64_t seed, const uint64_t* d_seed_add, float* d_dq, int64_t lddq, float* d_dk, int64_t lddk,
+                        float* d_dv, int64_t lddv, float* d_scratch, void* stream);
+
 /* ---- K7, second half: the loss epilogue over the sampled logits (one forward pass + fixed-order final sum, one
  * backward pass; ATen runs log_softmax / nll_loss / log_sigmoid / mul / sum and their backward as 4-8 kernels each).
  *   rbx_softmax_ce_*        mean_r [ logsumexp(x[r, :]) - x[r, t_r] ] over logits [rows, n_classes] (row stride in floats):

@@ -127,6 +127,10 @@ SIGNATURES = {
     "rbx_attn_dropout_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _f32, _u64,
                                             _P, _P, _P, _P, _P, _P]),
     "rbx_attn_dropout_mask": (ctypes.c_int, [_i64, _i32, _i32, _f32, _u64, _P, _P, _P]),
+    "rbx_attn_packed_fwd": (ctypes.c_int, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _u64, _P,
+                                           _P, _i64, _P, _P]),
+    "rbx_attn_packed_bwd": (ctypes.c_int, [_P, _i64, _P, _i64, _P, _i64, _P, _i64, _P, _i64, _P, _i64, _i32, _i32, _i32,
+                                           _f32, _i32, _f32, _u64, _P, _P, _i64, _P, _i64, _P, _i64, _P, _P]),
     "rbx_loss_workspace_size": (_sz, [_i64]),
     "rbx_softmax_ce_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_softmax_ce_bwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _P, _P, _P, _P, _P]),

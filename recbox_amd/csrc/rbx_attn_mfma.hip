@@ -34,8 +34,8 @@ __device__ __forceinline__ int tile_row(int r, int half) { return (r & 3) + 8 * 
 // in flight per thread (one workgroup per CU: nothing else hides this latency); the odd LDS row stride
 // forces scalar LDS writes.
 template <int HD>
-__device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* __restrict__ lds, int rows, int rows_pad,
-                                           float scale) {
+__device__ __forceinline__ void stage_rows(const float* __restrict__ g, const long long ld, float* __restrict__ lds, int rows,
+                                           int rows_pad, float scale) {
   constexpr int Q4 = HD / 4;                               // float4 per row
   const int total = rows_pad * Q4;
   for (int i0 = threadIdx.x; i0 < total; i0 += 4 * kAttnThreads) {
@@ -44,7 +44,8 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* _
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * kAttnThreads;
       const int r = i / Q4;
-      v[u] = (i < total && r < rows) ? reinterpret_cast<const float4*>(g)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[u] = (i < total && r < rows) ? *reinterpret_cast<const float4*>(g + r * ld + (i - r * Q4) * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -61,12 +62,12 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, float* _
 // the wave's own tile as B operands: reg[s] = g[row0 + (lane & 31)][2 s + (lane >> 5)] * scale
 // (both half-waves read the row with float4 loads and keep their parity)
 template <int HD>
-__device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, int row0, int rows, float scale,
+__device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, const long long ld, int row0, int rows, float scale,
                                                float (&reg)[HD / 2]) {
   const int lane = threadIdx.x & 63;
   const int row = row0 + (lane & 31), half = lane >> 5;
   const bool ok = row < rows;
-  const float4* src = reinterpret_cast<const float4*>(g + static_cast<long long>(ok ? row : 0) * HD);
+  const float4* src = reinterpret_cast<const float4*>(g + static_cast<long long>(ok ? row : 0) * ld);
 #pragma unroll
   for (int q = 0; q < HD / 4; ++q) {
     const float4 v = ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -110,7 +111,7 @@ __device__ __forceinline__ void tile_accumulate(const float* __restrict__ rows_l
 
 // transposed accumulators (row = d, col = lane's row) -> g[row][d] * scale
 template <int HD>
-__device__ __forceinline__ void store_transposed(float* __restrict__ g, int row0, int rows, float scale,
+__device__ __forceinline__ void store_transposed(float* __restrict__ g, const long long ld, int row0, int rows, float scale,
                                                  const f32x16 (&acc)[HD / 32]) {
   const int lane = threadIdx.x & 63;
   const int row = row0 + (lane & 31), half = lane >> 5;
@@ -119,9 +120,23 @@ __device__ __forceinline__ void store_transposed(float* __restrict__ g, int row0
   for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      *reinterpret_cast<float4*>(g + static_cast<long long>(row) * HD + dt * 32 + 8 * q + 4 * half) =
+      *reinterpret_cast<float4*>(g + static_cast<long long>(row) * ld + dt * 32 + 8 * q + 4 * half) =
           make_float4(acc[dt][4 * q] * scale, acc[dt][4 * q + 1] * scale, acc[dt][4 * q + 2] * scale,
                       acc[dt][4 * q + 3] * scale);
+}
+
+// Operand layout: element (b, l, h, d) of a tensor sits at base + (b * L + l) * ld + h * HD + d.  The contiguous
+// [BH, L, HD] form is ld = HD with one "head" per block; ld = E or 2 E with heads > 1 reads the projections' output
+// [B, L, E] / the fused K|V projection [B, L, 2 E] in place and writes O / dQ / dK|dV in the layout the next GEMM reads
+// (no transposes, no K / V split copies, no concatenation of dK and dV).
+struct AttnLd {
+  long long q, k, v, o, go, dq, dk, dv;
+  int heads;
+};
+
+__device__ __forceinline__ long long attn_base(long long bh, int heads, int L, long long ld, int hd) {
+  const long long b = bh / heads;
+  return b * L * ld + (bh - b * heads) * hd;
 }
 
 // Tile schedule: with L <= 256 there are at most 8 tiles and the workgroup has 8 wavefronts.  The causal cost of tile t
@@ -137,14 +152,18 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
                                                             const float* __restrict__ V, const int L,
                                                             const float scale, const int causal,
                                                             float* __restrict__ O, float* __restrict__ LSE,
-                                                            const DropArgs drop) {
+                                                            const DropArgs drop, const AttnLd ld) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Ks = lds;
   float* Vs = lds + Lp * (HD + 1);
   const long long bh = blockIdx.x;
-  stage_rows<HD>(K + bh * L * HD, Ks, L, Lp, 1.0f);
-  stage_rows<HD>(V + bh * L * HD, Vs, L, Lp, 1.0f);
+  Q += attn_base(bh, ld.heads, L, ld.q, HD);
+  K += attn_base(bh, ld.heads, L, ld.k, HD);
+  V += attn_base(bh, ld.heads, L, ld.v, HD);
+  O += attn_base(bh, ld.heads, L, ld.o, HD);
+  stage_rows<HD>(K, ld.k, Ks, L, Lp, 1.0f);
+  stage_rows<HD>(V, ld.v, Vs, L, Lp, 1.0f);
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   unsigned dk0 = 0, dk1 = 0;
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
   RBX_FOR_WAVE_TILES(nT, wid, qt) {
     const int i0 = qt * kT, qi = i0 + li;
     float qreg[HD / 2];
-    load_tile_regs<HD>(Q + bh * L * HD, i0, L, scale, qreg);
+    load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
     f32x16 oacc[HD / 32];
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt)
@@ -199,7 +218,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
       }
       tile_accumulate<HD>(Vs, j0, s, oacc);                  // O^T[d][query] += V^T P^T
     }
-    store_transposed<HD>(O + bh * L * HD, i0, L, 1.0f / lsum, oacc);
+    store_transposed<HD>(O, ld.o, i0, L, 1.0f / lsum, oacc);
     if (half == 0 && qi < L) LSE[bh * L + qi] = m + __logf(lsum);
   }
 }
@@ -213,14 +232,20 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
                                                               const float* __restrict__ LSE, const int L,
                                                               const float scale, const int causal,
                                                               float* __restrict__ dQ, float* __restrict__ Dv,
-                                                              const DropArgs drop) {
+                                                              const DropArgs drop, const AttnLd ld) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Ks = lds;
   float* Vs = lds + Lp * (HD + 1);
   const long long bh = blockIdx.x;
-  stage_rows<HD>(K + bh * L * HD, Ks, L, Lp, 1.0f);
-  stage_rows<HD>(V + bh * L * HD, Vs, L, Lp, 1.0f);
+  Q += attn_base(bh, ld.heads, L, ld.q, HD);
+  K += attn_base(bh, ld.heads, L, ld.k, HD);
+  V += attn_base(bh, ld.heads, L, ld.v, HD);
+  O += attn_base(bh, ld.heads, L, ld.o, HD);
+  dO += attn_base(bh, ld.heads, L, ld.go, HD);
+  dQ += attn_base(bh, ld.heads, L, ld.dq, HD);
+  stage_rows<HD>(K, ld.k, Ks, L, Lp, 1.0f);
+  stage_rows<HD>(V, ld.v, Vs, L, Lp, 1.0f);
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   unsigned dk0 = 0, dk1 = 0;
@@ -228,9 +253,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
   RBX_FOR_WAVE_TILES(nT, wid, qt) {
     const int i0 = qt * kT, qi = i0 + li;
     float qreg[HD / 2], greg[HD / 2], oreg[HD / 2];
-    load_tile_regs<HD>(Q + bh * L * HD, i0, L, scale, qreg);
-    load_tile_regs<HD>(dO + bh * L * HD, i0, L, 1.0f, greg);
-    load_tile_regs<HD>(O + bh * L * HD, i0, L, 1.0f, oreg);
+    load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
+    load_tile_regs<HD>(dO, ld.go, i0, L, 1.0f, greg);
+    load_tile_regs<HD>(O, ld.o, i0, L, 1.0f, oreg);
     float Di = 0.f;
 #pragma unroll
     for (int s = 0; s < HD / 2; ++s) Di += greg[s] * oreg[s];
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
       }
       tile_accumulate<HD>(Ks, j0, s, dq);                    // dQ^T[d][query] += K^T dS^T
     }
-    store_transposed<HD>(dQ + bh * L * HD, i0, L, scale, dq);
+    store_transposed<HD>(dQ, ld.dq, i0, L, scale, dq);
   }
 }
 
@@ -279,7 +304,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
                                                                const float* __restrict__ Dv, const int L,
                                                                const float scale, const int causal,
                                                                float* __restrict__ dK, float* __restrict__ dV,
-                                                               const DropArgs drop) {
+                                                               const DropArgs drop, const AttnLd ld) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Qs = lds;                          // scale * Q
@@ -287,8 +312,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
   float* Ls = Gs + Lp * (HD + 1);           // lse[Lp]
   float* Ds = Ls + Lp;                      // D[Lp]
   const long long bh = blockIdx.x;
-  stage_rows<HD>(Q + bh * L * HD, Qs, L, Lp, scale);
-  stage_rows<HD>(dO + bh * L * HD, Gs, L, Lp, 1.0f);
+  Q += attn_base(bh, ld.heads, L, ld.q, HD);
+  K += attn_base(bh, ld.heads, L, ld.k, HD);
+  V += attn_base(bh, ld.heads, L, ld.v, HD);
+  dO += attn_base(bh, ld.heads, L, ld.go, HD);
+  dK += attn_base(bh, ld.heads, L, ld.dk, HD);
+  dV += attn_base(bh, ld.heads, L, ld.dv, HD);
+  stage_rows<HD>(Q, ld.q, Qs, L, Lp, scale);
+  stage_rows<HD>(dO, ld.go, Gs, L, Lp, 1.0f);
   for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
     Ls[i] = (i < L) ? LSE[bh * L + i] : 0.f;
     Ds[i] = (i < L) ? Dv[bh * L + i] : 0.f;
@@ -300,8 +331,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
   RBX_FOR_WAVE_TILES(nT, wid, jt) {
     const int j0 = jt * kT, kj = j0 + li;
     float kreg[HD / 2], vreg[HD / 2];
-    load_tile_regs<HD>(K + bh * L * HD, j0, L, 1.0f, kreg);
-    load_tile_regs<HD>(V + bh * L * HD, j0, L, 1.0f, vreg);
+    load_tile_regs<HD>(K, ld.k, j0, L, 1.0f, kreg);
+    load_tile_regs<HD>(V, ld.v, j0, L, 1.0f, vreg);
     f32x16 dk[HD / 32], dv[HD / 32];
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt)
@@ -349,8 +380,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
       tile_accumulate<HD>(Gs, i0, p, dv);                    // dV^T[d][key] += dO^T P
       tile_accumulate<HD>(Qs, i0, s, dk);                    // dK^T[d][key] += (scale Q)^T dS
     }
-    store_transposed<HD>(dK + bh * L * HD, j0, L, 1.0f, dk);
-    store_transposed<HD>(dV + bh * L * HD, j0, L, 1.0f, dv);
+    store_transposed<HD>(dK, ld.dk, j0, L, 1.0f, dk);
+    store_transposed<HD>(dV, ld.dv, j0, L, 1.0f, dv);
   }
 }
 
@@ -366,48 +397,129 @@ static size_t lds_bytes(int L, bool phase_b) {
 
 template <int HD, bool DROP>
 static int run_fwd(const float* q, const float* k, const float* v, long long bh, int L, float scale, int causal, float* o,
-                   float* lse, const DropArgs& drop, hipStream_t s) {
+                   float* lse, const DropArgs& drop, const AttnLd& ld, hipStream_t s) {
   const size_t lds = lds_bytes<HD>(L, false);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD, DROP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD, DROP>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, q, k, v, L,
-                     scale, causal, o, lse, drop);
+                     scale, causal, o, lse, drop, ld);
   return check_launch("attn_mfma_fwd_kernel");
 }
 
 template <int HD, bool DROP>
 static int run_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
                    long long bh, int L, float scale, int causal, float* dq, float* dk, float* dv, float* scratch,
-                   const DropArgs& drop, hipStream_t s) {
+                   const DropArgs& drop, const AttnLd& ld, hipStream_t s) {
   const size_t la = lds_bytes<HD>(L, false), lb = lds_bytes<HD>(L, true);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_q_kernel<HD, DROP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(la));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kv_kernel<HD, DROP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb));
   hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<HD, DROP>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), la, s, q, k, v, o,
-                     go, lse, L, scale, causal, dq, scratch, drop);
+                     go, lse, L, scale, causal, dq, scratch, drop, ld);
   hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<HD, DROP>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lb, s, q, k, v, go,
-                     lse, scratch, L, scale, causal, dk, dv, drop);
+                     lse, scratch, L, scale, causal, dk, dv, drop, ld);
   return check_launch("attn_mfma_bwd kernels");
+}
+
+static AttnLd contiguous_ld(int hd) {
+  const long long h = hd;
+  return AttnLd{h, h, h, h, h, h, h, h, 1};
+}
+
+int attn_mfma_fwd_ld(const float* q, const float* k, const float* v, long long bh, int L, int hd, float scale, int causal,
+                     float* o, float* lse, const DropArgs& drop, const AttnLd& ld, hipStream_t s) {
+  if (drop.thr16 != 0)
+    return hd == 64 ? run_fwd<64, true>(q, k, v, bh, L, scale, causal, o, lse, drop, ld, s)
+                    : run_fwd<32, true>(q, k, v, bh, L, scale, causal, o, lse, drop, ld, s);
+  return hd == 64 ? run_fwd<64, false>(q, k, v, bh, L, scale, causal, o, lse, drop, ld, s)
+                  : run_fwd<32, false>(q, k, v, bh, L, scale, causal, o, lse, drop, ld, s);
+}
+
+int attn_mfma_bwd_ld(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
+                     long long bh, int L, int hd, float scale, int causal, float* dq, float* dk, float* dv, float* scratch,
+                     const DropArgs& drop, const AttnLd& ld, hipStream_t s) {
+  if (drop.thr16 != 0)
+    return hd == 64 ? run_bwd<64, true>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, ld, s)
+                    : run_bwd<32, true>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, ld, s);
+  return hd == 64 ? run_bwd<64, false>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, ld, s)
+                  : run_bwd<32, false>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, ld, s);
 }
 
 int attn_mfma_fwd(const float* q, const float* k, const float* v, long long bh, int L, int hd, float scale, int causal,
                   float* o, float* lse, const DropArgs& drop, hipStream_t s) {
-  if (drop.thr16 != 0)
-    return hd == 64 ? run_fwd<64, true>(q, k, v, bh, L, scale, causal, o, lse, drop, s)
-                    : run_fwd<32, true>(q, k, v, bh, L, scale, causal, o, lse, drop, s);
-  return hd == 64 ? run_fwd<64, false>(q, k, v, bh, L, scale, causal, o, lse, drop, s)
-                  : run_fwd<32, false>(q, k, v, bh, L, scale, causal, o, lse, drop, s);
+  return attn_mfma_fwd_ld(q, k, v, bh, L, hd, scale, causal, o, lse, drop, contiguous_ld(hd), s);
 }
 
 int attn_mfma_bwd(const float* q, const float* k, const float* v, const float* o, const float* go, const float* lse,
                   long long bh, int L, int hd, float scale, int causal, float* dq, float* dk, float* dv, float* scratch,
                   const DropArgs& drop, hipStream_t s) {
-  if (drop.thr16 != 0)
-    return hd == 64 ? run_bwd<64, true>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, s)
-                    : run_bwd<32, true>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, s);
-  return hd == 64 ? run_bwd<64, false>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, s)
-                  : run_bwd<32, false>(q, k, v, o, go, lse, bh, L, scale, causal, dq, dk, dv, scratch, drop, s);
+  return attn_mfma_bwd_ld(q, k, v, o, go, lse, bh, L, hd, scale, causal, dq, dk, dv, scratch, drop, contiguous_ld(hd), s);
 }
 
 }  // namespace rbx
+
+/* ---- packed-operand entry points: read Q [B, L, ldq], K / V inside the fused projection, write O / dQ / dK / dV strided */
+extern "C" int rbx_attn_packed_fwd(const float* d_q, int64_t ldq, const float* d_k, int64_t ldk, const float* d_v, int64_t ldv,
+                                   int64_t batch, int32_t heads, int32_t seq_len, int32_t head_dim, float scale,
+                                   int32_t causal, float p_drop, uint64_t seed, const uint64_t* d_seed_add, float* d_o,
+                                   int64_t ldo, float* d_lse, void* stream) {
+  using namespace rbx;
+  if (batch == 0) return RBX_OK;
+  if (batch < 0 || heads <= 0 || seq_len <= 0) return fail(RBX_ERR_INVALID, "attn_packed: bad shape");
+  if (!attn_mfma_supported(seq_len, seq_len, head_dim, nullptr, nullptr))
+    return fail(RBX_ERR_UNSUPPORTED, "attn_packed: needs seq_len <= 256 and head_dim in {32, 64} (got %d, %d)", seq_len, head_dim);
+  if (!d_q || !d_k || !d_v || !d_o || !d_lse) return fail(RBX_ERR_INVALID, "attn_packed: NULL tensor");
+  const long long need = static_cast<long long>(heads) * head_dim;
+  if (ldq < need || ldk < need || ldv < need || ldo < need || ((ldq | ldk | ldv | ldo) & 3) ||
+      ((reinterpret_cast<uintptr_t>(d_q) | reinterpret_cast<uintptr_t>(d_k) | reinterpret_cast<uintptr_t>(d_v) |
+        reinterpret_cast<uintptr_t>(d_o)) & 15))
+    return fail(RBX_ERR_INVALID, "attn_packed: row strides must cover heads * head_dim, be multiples of 4 floats, pointers 16-byte aligned");
+  if (!(p_drop >= 0.f) || p_drop >= 1.f) return fail(RBX_ERR_INVALID, "attn_packed: dropout probability %g not in [0, 1)", static_cast<double>(p_drop));
+  DropArgs drop;
+  unsigned thr = static_cast<unsigned>(p_drop * 65536.0f + 0.5f);
+  if (thr > 65535u) thr = 65535u;
+  drop.thr16 = thr;
+  drop.scale = 65536.0f / static_cast<float>(65536u - thr);
+  drop.k0 = static_cast<unsigned>(seed);
+  drop.k1 = static_cast<unsigned>(seed >> 32);
+  drop.seed_add = reinterpret_cast<const unsigned long long*>(d_seed_add);
+  const AttnLd ld{ldq, ldk, ldv, ldo, ldo, ldq, ldk, ldv, heads};
+  return attn_mfma_fwd_ld(d_q, d_k, d_v, static_cast<long long>(batch) * heads, seq_len, head_dim, scale, causal, d_o, d_lse,
+                          drop, ld, as_stream(stream));
+}
+
+extern "C" int rbx_attn_packed_bwd(const float* d_q, int64_t ldq, const float* d_k, int64_t ldk, const float* d_v, int64_t ldv,
+                                   const float* d_o, int64_t ldo, const float* d_do, int64_t lddo, const float* d_lse,
+                                   int64_t batch, int32_t heads, int32_t seq_len, int32_t head_dim, float scale,
+                                   int32_t causal, float p_drop, uint64_t seed, const uint64_t* d_seed_add, float* d_dq,
+                                   int64_t lddq, float* d_dk, int64_t lddk, float* d_dv, int64_t lddv, float* d_scratch,
+                                   void* stream) {
+  using namespace rbx;
+  if (batch == 0) return RBX_OK;
+  if (batch < 0 || heads <= 0 || seq_len <= 0) return fail(RBX_ERR_INVALID, "attn_packed_bwd: bad shape");
+  if (!attn_mfma_supported(seq_len, seq_len, head_dim, nullptr, nullptr))
+    return fail(RBX_ERR_UNSUPPORTED, "attn_packed_bwd: needs seq_len <= 256 and head_dim in {32, 64}");
+  if (!d_q || !d_k || !d_v || !d_o || !d_do || !d_lse || !d_dq || !d_dk || !d_dv || !d_scratch)
+    return fail(RBX_ERR_INVALID, "attn_packed_bwd: NULL tensor");
+  const long long need = static_cast<long long>(heads) * head_dim;
+  const long long lds_[8] = {ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv};
+  for (int i = 0; i < 8; ++i)
+    if (lds_[i] < need || (lds_[i] & 3)) return fail(RBX_ERR_INVALID, "attn_packed_bwd: bad row stride");
+  if ((reinterpret_cast<uintptr_t>(d_q) | reinterpret_cast<uintptr_t>(d_k) | reinterpret_cast<uintptr_t>(d_v) |
+       reinterpret_cast<uintptr_t>(d_o) | reinterpret_cast<uintptr_t>(d_do) | reinterpret_cast<uintptr_t>(d_dq) |
+       reinterpret_cast<uintptr_t>(d_dk) | reinterpret_cast<uintptr_t>(d_dv)) & 15)
+    return fail(RBX_ERR_INVALID, "attn_packed_bwd: pointers must be 16-byte aligned");
+  if (!(p_drop >= 0.f) || p_drop >= 1.f) return fail(RBX_ERR_INVALID, "attn_packed_bwd: bad dropout probability");
+  DropArgs drop;
+  unsigned thr = static_cast<unsigned>(p_drop * 65536.0f + 0.5f);
+  if (thr > 65535u) thr = 65535u;
+  drop.thr16 = thr;
+  drop.scale = 65536.0f / static_cast<float>(65536u - thr);
+  drop.k0 = static_cast<unsigned>(seed);
+  drop.k1 = static_cast<unsigned>(seed >> 32);
+  drop.seed_add = reinterpret_cast<const unsigned long long*>(d_seed_add);
+  const AttnLd ld{ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, heads};
+  return attn_mfma_bwd_ld(d_q, d_k, d_v, d_o, d_do, d_lse, static_cast<long long>(batch) * heads, seq_len, head_dim, scale,
+                          causal, d_dq, d_dk, d_dv, d_scratch, drop, ld, as_stream(stream));
+}

@@ -1684,6 +1684,65 @@ def attention(q, k, v, mask=None, scale=1.0, causal=False, fill=-1.0e9, need_pro
     return _Attention.apply(q, k, v, mask, scale, causal, fill, need_probs, float(dropout_p or 0.0), int(seed or 0))
 
 
+def attention_packed_supported(L, head_dim):
+    return L <= 256 and head_dim in (32, 64)
+
+
+class _AttentionPacked(torch.autograd.Function):
+    """Self-attention on the projections' outputs in place (rbx_attn_packed_*): q [B, L, E], kv [B, L, 2 E] (K | V of one
+    fused projection) -> o [B, L, E]; backward writes dq [B, L, E] and dkv [B, L, 2 E] (dK | dV) directly."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale, causal, p_drop, seed):
+        _require_cuda(q, "attention query")
+        B, L, E = q.shape
+        hd = E // heads
+        q3 = q if (q.dtype == torch.float32 and q.is_contiguous()) else q.contiguous().float()
+        kv3 = kv if (kv.dtype == torch.float32 and kv.is_contiguous()) else kv.contiguous().float()
+        if kv3.shape != (B, L, 2 * E):
+            raise ValueError("attention_packed: kv must be [B, L, 2 * E] = %s, got %s" % ((B, L, 2 * E), tuple(kv3.shape)))
+        o = torch.empty((B, L, E), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B * heads, L), dtype=torch.float32, device=q.device)
+        tick = dropout_tick(q.device) if p_drop > 0 else None
+        kptr = ctypes.c_void_p(kv3.data_ptr())
+        vptr = ctypes.c_void_p(kv3.data_ptr() + 4 * E)
+        check(lib.rbx_attn_packed_fwd(_ptr(q3), E, kptr, 2 * E, vptr, 2 * E, B, heads, L, hd, float(scale), int(causal),
+                                      float(p_drop), int(seed), _ptr(tick), _ptr(o), E, _ptr(lse), _stream()))
+        ctx.save_for_backward(q3, kv3, o, lse)
+        ctx.meta = (heads, hd, float(scale), int(causal), float(p_drop), int(seed), tick)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q3, kv3, o, lse = ctx.saved_tensors
+        heads, hd, scale, causal, p_drop, seed, tick = ctx.meta
+        B, L, E = q3.shape
+        do3 = do if (do.dtype == torch.float32 and do.is_contiguous()) else do.contiguous().float()
+        dq = torch.empty_like(q3)
+        dkv = torch.empty_like(kv3)
+        scratch = torch.empty((B * heads, L), dtype=torch.float32, device=do.device)
+        kptr = ctypes.c_void_p(kv3.data_ptr())
+        vptr = ctypes.c_void_p(kv3.data_ptr() + 4 * E)
+        dkptr = ctypes.c_void_p(dkv.data_ptr())
+        dvptr = ctypes.c_void_p(dkv.data_ptr() + 4 * E)
+        check(_timed(("attn_bwd", B * heads, L, hd),
+                     lambda: lib.rbx_attn_packed_bwd(_ptr(q3), E, kptr, 2 * E, vptr, 2 * E, _ptr(o), E, _ptr(do3), E,
+                                                     _ptr(lse), B, heads, L, hd, scale, causal, p_drop, seed, _ptr(tick),
+                                                     _ptr(dq), E, dkptr, 2 * E, dvptr, 2 * E, _ptr(scratch), _stream())))
+        return dq, dkv, None, None, None, None, None
+
+
+def attention_packed(q, kv, heads, scale, causal=False, dropout_p=0.0, seed=None):
+    """softmax(scale Q K^T [+ causal]) V per head on q [B, L, E] and kv [B, L, 2 E] = K | V (the output of ONE fused
+    projection), returning o [B, L, E] ready for the output projection: no [B * H, L, hd] copies in either direction.
+    Needs ``attention_packed_supported(L, E // heads)``."""
+    if dropout_p and not 0.0 <= dropout_p < 1.0:
+        raise ValueError("dropout probability has to be between 0 and 1, but got {}".format(dropout_p))
+    if dropout_p and seed is None:
+        seed = _draw_seed()
+    return _AttentionPacked.apply(q, kv, int(heads), float(scale), bool(causal), float(dropout_p or 0.0), int(seed or 0))
+
+
 def attention_dropout_mask(bh, lq, lk, dropout_p, seed, device="cuda"):
     """keep[bh, lq, lk] (bool) exactly as the fused kernels evaluate it for (dropout_p, seed) (rbx_attn_dropout_mask)."""
     device = torch.device(device)

@@ -157,6 +157,11 @@ class SASRec(torch.nn.Module):
         q = ops.linear(query, w[:E], b[:E] if b is not None else None)
         kv = ops.linear(keyval, w[E:], b[E:] if b is not None else None)          # one GEMM for K and V
         B, L = query.shape[0], query.shape[1]
+        if ops.attention_packed_supported(L, hd):
+            # the kernels read Q [B, L, E] and K | V [B, L, 2 E] where the projections left them and write O [B, L, E],
+            # dQ and dK | dV in place: no head transposes, no K / V split copies, no concatenation in the backward
+            o = ops.attention_packed(q, kv, H, hd ** -0.5, causal=True, dropout_p=p_drop)
+            return ops.linear(o, layer.out_proj.weight, layer.out_proj.bias)
         q = q.view(B, L, H, hd).transpose(1, 2)
         k, v = ops.split_last(kv, E)                            # contiguous halves; backward = one concatenation
         k = k.view(B, L, H, hd).transpose(1, 2)

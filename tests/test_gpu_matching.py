@@ -208,10 +208,9 @@ def test_batch_norm_vs_torch(rows, cols, relu):
         assert_close(yc, yr.detach(), 1e-5, "y")
         if relu:
             # a pre-activation within a few ulp of zero may fall on either side of the ReLU in two fp32 implementations
-            # (the CPU reference's reduction order depends on its thread count): such an element's own gradient -- and,
-            # through the batch statistics, nothing else measurably -- legitimately differs; at most a handful exist
-            edge = zr.detach().abs() < 1e-5
-            assert int(edge.sum()) <= 8
+            # (the CPU reference's reduction order depends on its thread count): the columns that hold such an element are
+            # left out of the gradient comparison
+            edge = zr.detach().abs() < 1e-5          # (a few dozen of 3.6 M standard-normal values)
             keep_cols = ~edge.any(dim=0)             # (a flipped element moves its whole column's dx through the batch means)
             assert_close(xc.grad.cpu()[:, keep_cols], xr.grad[:, keep_cols], 2e-4, "dx")
         else:
@@ -813,3 +812,31 @@ def test_pair_logsigmoid_epilogue_vs_torch(shape, weighted):
     assert_close(loss, want, 1e-5, "loss", rtol=1e-5)
     assert_close(pc.grad, pd.grad, 1e-6, "dpos")
     assert_close(nc.grad, nd.grad, 1e-6, "dneg")
+
+
+@pytest.mark.parametrize("B,L,H,hd,causal,p", [(3, 200, 1, 64, True, 0.0), (2, 37, 2, 32, True, 0.0), (4, 64, 4, 32, False, 0.0),
+                                               (3, 200, 1, 64, True, 0.5), (2, 50, 2, 64, False, 0.25)])
+def test_attention_on_packed_operands_equals_the_copying_path(B, L, H, hd, causal, p):
+    """rbx_attn_packed_*: Q [B, L, E] and K | V [B, L, 2 E] read where the projections left them, O / dQ / dK | dV written
+    in place -- bit-identical to splitting, transposing to [B, H, L, hd], calling rbx_attn_* and transposing back (same
+    kernels, same (b * H + h) numbering, hence also the same dropout mask for a given seed)."""
+    from recbox_amd import ops
+    E = H * hd
+    g = torch.Generator().manual_seed(B * L + H)
+    q = torch.randn(B, L, E, generator=g).cuda()
+    kv = torch.randn(B, L, 2 * E, generator=g).cuda()
+    R = torch.randn(B, L, E, generator=g).cuda()
+    assert ops.attention_packed_supported(L, hd)
+    q1, kv1 = q.clone().requires_grad_(), kv.clone().requires_grad_()
+    o1 = ops.attention_packed(q1, kv1, H, hd ** -0.5, causal=causal, dropout_p=p, seed=99)
+    (o1 * R).sum().backward()
+    q2, kv2 = q.clone().requires_grad_(), kv.clone().requires_grad_()
+    qh = q2.view(B, L, H, hd).transpose(1, 2)
+    kh = kv2[..., :E].reshape(B, L, H, hd).transpose(1, 2)
+    vh = kv2[..., E:].reshape(B, L, H, hd).transpose(1, 2)
+    o2, _ = ops.attention(qh, kh, vh, scale=hd ** -0.5, causal=causal, fill=float("-inf"), dropout_p=p, seed=99)
+    o2 = o2.transpose(1, 2).reshape(B, L, E)
+    (o2 * R).sum().backward()
+    assert torch.equal(o1, o2)
+    assert torch.equal(q1.grad, q2.grad)
+    assert torch.equal(kv1.grad, kv2.grad)
