@@ -523,6 +523,10 @@ def main():
                     help="number of DISTINCT device-resident batches cycled through the static input buffer, one copy_ "
                          "per step inside the timed region (a training loop sees new ids every step: replaying one "
                          "batch keeps its rows in the 256 MB Infinity Cache); 0/1 = replay one batch")
+    ap.add_argument("--pack-tables", action="store_true",
+                    help="fm: FM.pack_tables() -- every (embedding, LR) table pair in one packed [V, 32] storage, one "
+                         "128-byte request per lookup.  Measured: no gain (fm_fused_fwd 48.0 vs 47.5 us; the dim-1 LR "
+                         "tables are 22 MB and cache-resident anyway), so it is off by default")
     ap.add_argument("--path", choices=["fused", "layers"], default="fused",
                     help="fused: FM model body in rbx_fm_fwd/bwd; layers: drop-in layers composed as the reference does")
     ap.add_argument("--items", type=int, default=None, help="youtubednn: rows of the item table (10 M); sasrec: items (1 M)")
@@ -597,6 +601,10 @@ def main():
         else:
             m = FM(fmw.fm, args.dim, fused=(args.path == "fused")).to(dev)
         init_weights(m)                       # same seed on every rank: replicated parameters start identical
+        if not sharded and args.path == "fused" and args.pack_tables:
+            # each (embedding, LR) table pair behind ONE packed [V, 32] storage: one 128-byte request per lookup in the
+            # fused forward (FM.pack_tables; the parameters, their names and the dense gradients are unchanged)
+            m.pack_tables()
         return m
 
     model = build_model()
@@ -746,10 +754,12 @@ def main():
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
-                                      "%s ids (%s), %s path, %s, dense-grad autograd contract (%s), no optimiser step"
+                                      "%s ids (%s), %s path%s, %s, dense-grad autograd contract (%s), no optimiser step"
                                       % (args.dim, B, args.dist,
                                          ("%d distinct batches rotated, one copy_ per step in the timed region" % K)
-                                         if K > 1 else "one batch replayed", args.path, graph_note,
+                                         if K > 1 else "one batch replayed", args.path,
+                                         " (emb | LR rows packed in one [V, 32] storage per table pair)"
+                                         if (not sharded and args.path == "fused" and args.pack_tables) else "", graph_note,
                                          "persistent grad buffer, rows of the previous step re-zeroed"
                                          if ops.config.reuse_grad_buffers else "fresh zero-filled grads every step"),
                           "global_batch": B * world,

@@ -81,6 +81,12 @@ typedef struct rbx_field {
   int32_t      kind;             /* rbx_field_kind_t */
   int32_t      pool;             /* rbx_pool_t */
   float        eps;              /* MEAN pools: 1e-12 (recbox), 1e-16 (rechub), 1e-8 (RecBole) */
+  int64_t      table_stride;     /* floats between consecutive table rows; 0 = dim (a contiguous [vocab, dim] table).
+                                  * Only rbx_fm_fwd / rbx_fm_sort / rbx_fm_bwd / rbx_fm_rezero honour other values: the
+                                  * embedding row and the dim-1 LR weight of an id may then share ONE padded row of a
+                                  * packed [vocab, stride] storage (emb.table = base, lr.table = base + D, both with
+                                  * table_stride = stride: one 128-byte line per lookup instead of two); every other
+                                  * entry point rejects a stride != dim.  Gradients stay contiguous [vocab, dim]. */
 } rbx_field_t;
 
 const char* rbx_last_error(void);

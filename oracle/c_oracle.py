@@ -22,7 +22,8 @@ class Field(ctypes.Structure):
                 ("ids_stride_b", ctypes.c_int64), ("ids_stride_l", ctypes.c_int64), ("vocab", ctypes.c_int64),
                 ("padding_idx", ctypes.c_int64), ("mask_id", ctypes.c_int64), ("out_off", ctypes.c_int64),
                 ("dim", ctypes.c_int32), ("seq_len", ctypes.c_int32), ("ids_dtype", ctypes.c_int32),
-                ("kind", ctypes.c_int32), ("pool", ctypes.c_int32), ("eps", ctypes.c_float)]
+                ("kind", ctypes.c_int32), ("pool", ctypes.c_int32), ("eps", ctypes.c_float),
+                ("table_stride", ctypes.c_int64)]        # always 0 here: the oracle restates contiguous tables
 
 
 def load():

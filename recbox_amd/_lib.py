@@ -36,7 +36,8 @@ class rbx_field_t(ctypes.Structure):
                 ("ids_dtype", ctypes.c_int32),
                 ("kind", ctypes.c_int32),
                 ("pool", ctypes.c_int32),
-                ("eps", ctypes.c_float)]
+                ("eps", ctypes.c_float),
+                ("table_stride", ctypes.c_int64)]
 
 
 class rbx_shard_geom_t(ctypes.Structure):

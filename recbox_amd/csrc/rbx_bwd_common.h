@@ -41,7 +41,7 @@ struct KeyField {            // 48 B
 };
 struct KeyPack { KeyField f[RBX_MAX_FIELDS]; };
 
-struct RedField {            // 40 B
+struct RedField {            // 48 B
   float* grad;
   float* grad2;              // fused FM: the dim-1 LR table's grad (same ids)
   const float* table;        // fused FM: the embedding table (dW = A - cnt * w)
@@ -51,6 +51,8 @@ struct RedField {            // 40 B
   short seq_len;
   unsigned char pool, slot;
   short reserved;
+  int table_stride;          // fused FM: floats between rows of `table` (packed [vocab, stride] storage); grads are [vocab, dim]
+  int reserved2;
 };
 struct RedPack { RedField f[RBX_MAX_FIELDS]; };
 

@@ -52,6 +52,9 @@ int pack_fields(const rbx_field_t* fields, int n, int64_t batch, bool need_grad,
     } else if (f.seq_len != 1 || f.pool != RBX_POOL_NONE) {
       return fail(RBX_ERR_INVALID, "field %d: numeric/dense features are scalar per sample", i);
     }
+    if (f.table_stride != 0 && f.table_stride != f.dim && f.kind == RBX_FIELD_CATEGORICAL)
+      return fail(RBX_ERR_UNSUPPORTED, "field %d: a table row stride of %lld floats (dim %d) is only supported by the fused FM "
+                  "entry points", i, (long long)f.table_stride, f.dim);
     if (f.out_off < 0 || f.out_off > INT_MAX) return fail(RBX_ERR_INVALID, "field %d: out_off", i);
     if (f.ids_stride_l < INT_MIN || f.ids_stride_l > INT_MAX) return fail(RBX_ERR_INVALID, "field %d: stride_l", i);
     if (need_grad && f.kind != RBX_FIELD_DENSE && f.grad == nullptr) {

@@ -97,6 +97,8 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
     rf.pool = static_cast<unsigned char>(f.pool);
     rf.slot = static_cast<unsigned char>(i);
     rf.reserved = 0;
+    rf.table_stride = f.dim;
+    rf.reserved2 = 0;
     lookups += n_lk;
   }
   if (lookups >= (1ull << 31) || rows >= (1ull << 31))

@@ -28,13 +28,15 @@
 
 namespace rbx {
 
-struct FmField {            // 40 B
+struct FmField {            // 48 B
   const void* ids;
   const float* emb;         // [V, D] table or numeric weight [D]; NULL when there is no second-order part
   const float* lr;          // [V] (dim-1 table) or numeric weight [1]; NULL when there is no first-order part
   long long stride_b;
   int vocab;
   unsigned char dtype, kind, r0, r1;
+  int emb_stride;           // floats between rows of emb / lr: D and 1 for contiguous tables; equal (e.g. 32) when both
+  int lr_stride;            // live in one packed [V, stride] storage -- then a lookup touches ONE 128-byte line
 };
 struct FmPack { FmField f[RBX_MAX_FIELDS]; };
 
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
         if (f0 + u < F) {
           const FmField& fd = P.f[f0 + u];
           if (has_emb) {
-            const float* row = fd.emb + id[u] * D;
+            const float* row = fd.emb + id[u] * fd.emb_stride;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
               const int d = (lane_g + v * G) * W;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
               }
             }
           }
-          if (has_lr && lane_g == ((f0 + u) % G)) l1[u] = fd.lr[id[u]];   // one lane per feature fetches the LR weight
+          if (has_lr && lane_g == ((f0 + u) % G)) l1[u] = fd.lr[id[u] * fd.lr_stride];   // one lane per feature fetches the LR weight
         }
       }
 #pragma unroll
@@ -216,7 +218,7 @@ struct FmPolicy {
   }
   template <class F>
   static __device__ __forceinline__ void prefetch(const Args&, const RedField& fd, unsigned row, int lane_g, F& pre) {
-    if (fd.grad != nullptr) pre.add_from_nt(fd.table + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);   // w_r
+    if (fd.grad != nullptr) pre.add_from_nt(fd.table + static_cast<size_t>(row) * fd.table_stride, fd.dim, lane_g);   // w_r
   }
   template <class F>
   static __device__ __forceinline__ void flush(const Args& a, const RedField& fd, unsigned row, const F& acc, float cnt,
@@ -394,11 +396,19 @@ static int fm_validate(const rbx_field_t* emb, const rbx_field_t* lr, int n, int
     k.r0 = k.r1 = 0;
     k.emb = nullptr;
     k.lr = nullptr;
+    k.emb_stride = h->D;
+    k.lr_stride = 1;
     if (h->has_emb) {
       if (emb[i].dim != h->D) return fail(RBX_ERR_UNSUPPORTED, "fm: all embedding dims must be equal to fuse");
       if (emb[i].table == nullptr) return fail(RBX_ERR_INVALID, "fm: feature %d: table is NULL", i);
       if ((reinterpret_cast<uintptr_t>(emb[i].table) & 15) != 0) h->vec = false;
       k.emb = emb[i].table;
+      if (a.kind == RBX_FIELD_CATEGORICAL && emb[i].table_stride != 0) {
+        if (emb[i].table_stride < h->D || emb[i].table_stride > INT_MAX)
+          return fail(RBX_ERR_INVALID, "fm: feature %d: table_stride %lld < dim %d", i, (long long)emb[i].table_stride, h->D);
+        k.emb_stride = static_cast<int>(emb[i].table_stride);
+        if (k.emb_stride % 4 != 0) h->vec = false;
+      }
     }
     if (h->has_lr) {
       const rbx_field_t& l = lr[i];
@@ -406,6 +416,10 @@ static int fm_validate(const rbx_field_t* emb, const rbx_field_t* lr, int n, int
       if (h->has_emb && (l.ids != a.ids || l.kind != a.kind || l.vocab != a.vocab || l.ids_stride_b != a.ids_stride_b))
         return fail(RBX_ERR_INVALID, "fm: feature %d: LR and embedding descriptors must describe the same ids", i);
       k.lr = l.table;
+      if (l.kind == RBX_FIELD_CATEGORICAL && l.table_stride != 0) {
+        if (l.table_stride < 1 || l.table_stride > INT_MAX) return fail(RBX_ERR_INVALID, "fm: feature %d: bad LR table_stride", i);
+        k.lr_stride = static_cast<int>(l.table_stride);
+      }
     }
   }
   (void)B;
@@ -469,6 +483,7 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
     if (g1 == nullptr && g2 == nullptr) continue;
     tmp[n_cat].grad = g1 ? g1 : g2;          // make_plan skips fields without a grad
     tmp[n_cat].out_off = 0;
+    tmp[n_cat].table_stride = 0;             // (the plan's keys do not depend on the storage; the stride is set below)
     cat_src[n_cat] = i;
     ++n_cat;
   }
@@ -491,6 +506,8 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
     rf.grad2 = lr ? lr[i].grad : nullptr;
     rf.table = emb ? emb[i].table : nullptr;
     rf.dim = static_cast<short>(D);
+    rf.table_stride = (emb && emb[i].table_stride != 0) ? static_cast<int>(emb[i].table_stride) : D;
+    if (rf.table_stride % 4 != 0) p->vec = false;          // float4 row reads need 16-byte aligned rows
     if (rf.grad != nullptr && (reinterpret_cast<uintptr_t>(rf.grad) & 15) != 0) p->vec = false;
     if (rf.table != nullptr && (reinterpret_cast<uintptr_t>(rf.table) & 15) != 0) p->vec = false;
   }

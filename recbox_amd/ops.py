@@ -172,14 +172,18 @@ class EmbedPlan(object):
         # a step binds the same tables several times (forward, sort placeholders, backward): the ctypes stores are
         # skipped when the pointers are the ones already in the descriptors
         key = (tuple(p.data_ptr() for p in params),
-               None if grads is None else tuple(0 if g is None else g.data_ptr() for g in grads))
+               None if grads is None else tuple(0 if g is None else g.data_ptr() for g in grads),
+               tuple(p.stride(0) for p in params))
         if key == self._bound_params:
             return
         self._bound_params = key
-        tables, gptrs = key
+        tables, gptrs, strides = key
         for f, i in self._param_fields:
             f.table = tables[i]
             f.grad = (gptrs[i] or None) if gptrs is not None else None
+            # a categorical table may be a column block of a wider packed storage (recbox_amd ... FM.pack_tables): the
+            # row stride travels in the descriptor; only the fused FM entry points accept one != dim
+            f.table_stride = strides[i] if (f.kind == FIELD_CATEGORICAL and strides[i] != f.dim) else 0
 
 
 class KernelTimer(object):
@@ -644,6 +648,8 @@ class _FmFused(torch.autograd.Function):
         extra = rest[0] if has_extra else None            # packed remote rows [B, T, stride]; LR slot = has_extra - 1
         for p in emb_params + lr_params:
             _require_cuda(p, "embedding parameter")
+            if p.dtype != torch.float32 or p.stride(-1) != 1:
+                raise RuntimeError("recbox_amd: embedding parameters must be fp32 with unit inner stride")
         lead = emb_plan if emb_plan is not None else lr_plan
         B, keep = lead.bind_inputs(inputs)
         dev = keep[0].device

@@ -59,6 +59,43 @@ class FM(nn.Module):
             X = inputs_from_batch(self.feature_map, X)
         return {"y_pred": torch.sigmoid(self.logits(X))}
 
+    @torch.no_grad()
+    def pack_tables(self, row_floats=None):
+        """Re-home every (embedding table, LR table) pair of a categorical feature in ONE packed storage
+        ``[vocab, row_floats]`` -- floats ``[0, D)`` the embedding row, float ``D`` the dim-1 LR weight, the rest padding;
+        ``row_floats`` defaults to the next multiple of 32 floats (128-byte rows) -- so that the fused forward issues one
+        128-byte request per lookup instead of a 64-byte row plus a 4-byte weight from two different lines.
+
+        The holders stay the reference's modules and keys: ``embedding_layers.<f>`` is still an ``nn.Embedding`` whose
+        ``weight`` is now the column view ``packed[:, :D]`` (a Parameter with row stride ``row_floats``), the LR holder's
+        ``weight`` is ``packed[:, D:D+1]``; ``state_dict()`` / ``load_state_dict()`` / optimisers see the same names and
+        shapes.  Gradients stay dense contiguous ``[vocab, D]`` / ``[vocab, 1]`` tensors.  Call it AFTER moving the model
+        to its device (``.to()`` / ``.cuda()`` re-allocate every parameter on its own, which silently un-packs: the
+        kernels then simply run on the separate tables again).  Tables shared by several features, pretrained / frozen
+        tables and sequence features are left alone.  Returns the number of packed pairs."""
+        emb = self.embedding_layer.embedding_layer.embedding_layers
+        lr = self.fm.lr_layer.embedding_layer.embedding_layer.embedding_layers
+        seen, packed_pairs = {}, 0
+        for name in emb:
+            seen[id(emb[name])] = seen.get(id(emb[name]), 0) + 1
+        for name, table in emb.items():
+            if name not in lr or type(table) is not nn.Embedding or type(lr[name]) is not nn.Embedding:
+                continue
+            w, l = table.weight, lr[name].weight
+            if seen[id(table)] != 1 or l.shape != (w.shape[0], 1) or w.requires_grad != l.requires_grad:
+                continue
+            V, D = w.shape
+            stride = row_floats or (D + 1 + 31) // 32 * 32
+            if stride < D + 1 or stride % 4:
+                raise ValueError("pack_tables: row_floats must be a multiple of 4 and >= embedding_dim + 1")
+            packed = torch.zeros((V, stride), dtype=torch.float32, device=w.device)
+            packed[:, :D].copy_(w)
+            packed[:, D:D + 1].copy_(l)
+            table.weight = nn.Parameter(packed[:, :D], requires_grad=w.requires_grad)
+            lr[name].weight = nn.Parameter(packed[:, D:D + 1], requires_grad=l.requires_grad)
+            packed_pairs += 1
+        return packed_pairs
+
 
 class ShardedFM(nn.Module):
     """FM over the GPUs of one node: one process per GPU, every process trains on its own

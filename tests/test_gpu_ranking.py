@@ -1011,3 +1011,66 @@ def test_fm_accepts_the_flat_batch_tensor_in_any_id_dtype():
     fm.features["S"] = {"source": "", "type": "sequence", "vocab_size": 9, "max_len": 2}
     fm.set_column_index()
     assert tuple(inputs_from_batch(fm, torch.zeros(4, 5).cuda())["S"].shape) == (4, 2)
+
+
+@pytest.mark.parametrize("row_floats", [None, 20])
+def test_fm_with_packed_tables_is_bit_identical(row_floats):
+    """FM.pack_tables(): every (embedding, LR) table pair behind one packed [V, stride] storage (one 128-byte request per
+    lookup in the fused forward).  Same parameter names, shapes and types; logits, loss and every dense gradient bit for bit
+    equal to the unpacked model; strict state_dict round trip both ways; a hipGraph replay keeps working."""
+    from recbox_amd import ops
+    from recbox_amd.graph import GraphedStep
+    from recbox_amd.ranking.pytorch.models import FM
+    vocabs = CRITEO_SMALL_VOCABS + [70000]
+    fm, X0, y0 = _criteo_like(1500, vocabs, 16, seed=5, zipf=True)
+    plain, packed = FM(fm, 16).cuda(), FM(fm, 16).cuda()
+    with torch.no_grad():
+        for p in plain.parameters():
+            p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.1)
+    packed.load_state_dict(plain.state_dict())
+    n = packed.pack_tables(row_floats)
+    assert n == len(vocabs)
+    el = packed.embedding_layer.embedding_layer.embedding_layers
+    ll = packed.fm.lr_layer.embedding_layer.embedding_layer.embedding_layers
+    stride = row_floats or 32
+    assert type(el["C1"]) is torch.nn.Embedding and el["C1"].weight.stride() == (stride, 1)
+    assert ll["C1"].weight.data_ptr() == el["C1"].weight.data_ptr() + 16 * 4 and ll["C1"].weight.stride(0) == stride
+    assert [k for k in packed.state_dict()] == [k for k in plain.state_dict()]
+    for (k, a), (_, b) in zip(plain.state_dict().items(), packed.state_dict().items()):
+        assert torch.equal(a, b), k
+    X, y = _cuda(X0), y0.cuda()
+
+    def step(model):
+        for p in model.parameters():
+            p.grad = None
+        logit = model.logits(X)
+        loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(logit), y)
+        loss.backward()
+        return logit.detach().clone(), loss.detach().clone()
+
+    l0, loss0 = step(plain)
+    l1, loss1 = step(packed)
+    assert torch.equal(l0, l1) and torch.equal(loss0, loss1)
+    for (k, p0), (_, p1) in zip(plain.named_parameters(), packed.named_parameters()):
+        assert p1.grad.is_contiguous() and torch.equal(p0.grad, p1.grad), k
+    # an optimiser step through the strided parameters, then back into a fresh unpacked model
+    with torch.no_grad():
+        for p0, p1 in zip(plain.parameters(), packed.parameters()):
+            p0.add_(p0.grad, alpha=-0.5)
+            p1.add_(p1.grad, alpha=-0.5)
+    fresh = FM(fm, 16).cuda()
+    fresh.load_state_dict(packed.state_dict())
+    for (k, a), (_, b) in zip(plain.state_dict().items(), fresh.state_dict().items()):
+        assert torch.equal(a, b), k
+    old = ops.config.check_ids
+    ops.config.check_ids = False
+    try:
+        replay = GraphedStep(lambda: step(packed), warmup=3)
+        want = step(plain)
+        got = replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        for (k, p0), (_, p1) in zip(plain.named_parameters(), packed.named_parameters()):
+            assert torch.equal(p0.grad, p1.grad), k
+    finally:
+        ops.config.check_ids = old
