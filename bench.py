@@ -471,10 +471,14 @@ def run_model_config(args, rank, world, dev):
     else:
         roof = None
     par = "dp1"
-    if sharded:
-        par = {"youtubednn": "item table row-sharded over %d ranks (all-to-all, history pooled at the owners) + dp%d tower",
-               "deepfm": "dp%d, tables >= %d rows row-sharded over the ranks (all-to-all), flat all-reduce of the rest" % (world, args.shard_min_vocab) + "%.0s",
-               "sasrec": "dp%d (replicated model, one flat all-reduce)%.0s"}[cfg] % ((world, world) if cfg == "youtubednn" else (world,))
+    if sharded and cfg == "youtubednn":
+        par = ("item table row-sharded over %d ranks (one all-to-all each way, history pooled at the owners) + dp%d tower"
+               % (world, world))
+    elif sharded and cfg == "deepfm":
+        par = ("dp%d, tables >= %d rows row-sharded over the ranks (one all-to-all each way), flat all-reduce of the rest"
+               % (world, args.shard_min_vocab))
+    elif sharded:
+        par = "dp%d (replicated model, one flat all-reduce of every gradient)" % world
     out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
            "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -523,6 +527,9 @@ def main():
                     help="number of DISTINCT device-resident batches cycled through the static input buffer, one copy_ "
                          "per step inside the timed region (a training loop sees new ids every step: replaying one "
                          "batch keeps its rows in the 256 MB Infinity Cache); 0/1 = replay one batch")
+    ap.add_argument("--contiguous-ids", action="store_true",
+                    help="fm (experiment): hand every feature its own contiguous [B] column instead of a strided view of the "
+                         "[B, 40] float64 batch (what the reference's loader delivers)")
     ap.add_argument("--pack-tables", action="store_true",
                     help="fm: FM.pack_tables() -- every (embedding, LR) table pair in one packed [V, 32] storage, one "
                          "128-byte request per lookup.  Measured: no gain (fm_fused_fwd 48.0 vs 47.5 us; the dim-1 LR "
@@ -585,6 +592,10 @@ def main():
     batch = batches[0].clone()
     X, y = slice_inputs(fmw.fm, batch)
     labels = [slice_inputs(fmw.fm, b)[1] for b in batches]
+    if args.contiguous_ids:
+        batch = batch.t().contiguous()                    # [40, B]: every column of the batch is now a contiguous row
+        batches = [b.t().contiguous() for b in batches]
+        X = OrderedDict((name, batch[fmw.fm.get_column_index(name)]) for name in fmw.fm.features)
 
     def refill(i):
         if K > 1:
