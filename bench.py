@@ -527,6 +527,9 @@ def main():
                     help="number of DISTINCT device-resident batches cycled through the static input buffer, one copy_ "
                          "per step inside the timed region (a training loop sees new ids every step: replaying one "
                          "batch keeps its rows in the 256 MB Infinity Cache); 0/1 = replay one batch")
+    ap.add_argument("--sort-after-forward", action="store_true",
+                    help="fm: enqueue the backward's id sort / re-zero after the forward kernel instead of beside it "
+                         "(recbox_amd.ops.config.sort_before_forward = False)")
     ap.add_argument("--contiguous-ids", action="store_true",
                     help="fm (experiment): hand every feature its own contiguous [B] column instead of a strided view of the "
                          "[B, 40] float64 batch (what the reference's loader delivers)")
@@ -575,6 +578,8 @@ def main():
         comm.direct.enable(True)
         comm.direct.self_check(device=dev)
     ops.config.check_ids = False              # no per-call host sync inside the timed region
+    if args.sort_after_forward:
+        ops.config.sort_before_forward = False
     # every step starts from zero_grad(set_to_none=True): the dense gradients may live in ONE persistent buffer of which
     # only the rows the previous step wrote are cleared (rbx_fm_rezero) instead of a 379 MB zero fill per step; p.grad
     # after a step is the same dense [V, D] tensor either way (tests/test_gpu_ranking.py: bit-identical)
@@ -689,6 +694,7 @@ def main():
     else:
         timer = ops.KernelTimer(lambda m: m[0] == "embed_fwd" and m[2] == n_fields * args.dim)
     warm_timer = ops.KernelTimer(timer.want)
+    alone_timer = ops.KernelTimer(timer.want)
     plain_eager = step is eager_step or (sharded and graph_note == "eager launches")
     if plain_eager:
         ops.kernel_timer = timer
@@ -718,6 +724,18 @@ def main():
             refill(args.warmup + args.steps + i)
             eager_step()
         torch.cuda.synchronize()
+        if ops.config.sort_before_forward and not sharded:
+            # the same kernel WITHOUT the id sort / re-zero of the backward running beside it (they are enqueued after
+            # the forward instead): frac_alone, the kernel's own rate
+            for _ in range(80):
+                ballast.zero_()
+            ops.config.sort_before_forward = False
+            ops.kernel_timer = alone_timer
+            for i in range(n_timed):
+                refill(args.warmup + args.steps + n_timed + i)
+                eager_step()
+            torch.cuda.synchronize()
+            ops.config.sort_before_forward = True
         if K > 1:
             # the same kernel on ONE batch replayed (rows of the previous launch still in the Infinity Cache): frac_warm
             for _ in range(80):
@@ -760,6 +778,14 @@ def main():
             if wms:
                 roof["frac_warm"] = per_sample * B / (wms * 1e-3) / 1e9 / 8000.0
                 roof["kernel_ms_warm"] = wms
+            ams = alone_timer.mean_ms()
+            if ams:
+                roof["frac_alone"] = per_sample * B / (ams * 1e-3) / 1e9 / 8000.0
+                roof["kernel_ms_alone"] = ams
+                roof["note"] = ("frac / kernel_ms: the kernel as it runs in the step, BESIDE the id sort and re-zero of the "
+                                "backward on a second stream (recbox_amd.ops.config.sort_before_forward: the step is ~6 % "
+                                "faster that way, each kernel slower); frac_alone / kernel_ms_alone: the same launches with "
+                                "that side work enqueued after the forward")
         out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
                "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",

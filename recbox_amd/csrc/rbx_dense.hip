@@ -17,6 +17,7 @@
 // (register double buffering, one barrier per k-tile).  The weight-gradient GEMM has a
 // tiny output and K = batch, so it is split along K across workgroups into a workspace
 // and reduced in a fixed order (deterministic, no float atomics).
+#include <stdlib.h>
 #include "rbx_internal.h"
 
 namespace rbx {
@@ -248,6 +249,169 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
       }
     }
   }
+}
+
+static bool vec_ok(const float* p, long long ld);
+
+// Wide companion for ONE column tile of up to 448 columns (N = 400: the towers of cfg 4; 256 / 128: cfg 3): the
+// 128 x 128 kernel covers N = 400 as three full column tiles plus a 16-column narrow launch that costs 18 % of the
+// main kernel's time for 4 % of the columns (it re-reads all of A).  Here a 512-thread workgroup owns 128 rows x ALL
+// columns: wavefront w computes rows (w & 3) * 32 .. + 32 against column tiles (w >> 2) * NH .. + NH (NH = 7 at N <= 448:
+// 112 accumulator registers, two wavefronts per SIMD); A is read once, B (the weights, L2-resident) once per workgroup.
+// (First version: 256 threads, 13 tiles per wavefront in AGPRs, one wavefront per SIMD -- 1.09 ms for the layer-1 forward of
+//  cfg 4 against 0.93 ms on the 128 x 128 + narrow pair: nothing hides the barrier and the LDS latency of a lone wavefront.)
+constexpr int kWideThreads = 512;
+
+template <int NH>
+struct WideGeom {
+  static constexpr int BNW = 64 * NH;                   // columns of the tile (two column halves of NH MFMA tiles)
+  static constexpr int LDW = BNW + 4;                   // LDS row stride of the B tile
+  static constexpr int PB = (BNW * BK / 4 + kWideThreads - 1) / kWideThreads;   // float4 loads per thread, B tile
+  static constexpr int PA = (BM * BK / 4 + kWideThreads - 1) / kWideThreads;    // float4 loads per thread, A tile
+};
+
+// ROWS x BK operand tile, 512 threads.  KCONTIG: element (r, k) at base[r * ld + k]; else at base[k * ld + r].
+template <bool KCONTIG, int ROWS, int P>
+__device__ __forceinline__ void wide_load(const float* __restrict__ base, long long ld, int r0, int k0, int R, int K, bool vec_ok,
+                                          float (&reg)[4 * P]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int idx = t + kWideThreads * p;
+    if (idx >= ROWS * BK / 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) reg[p * 4 + j] = 0.f;
+      continue;
+    }
+    if constexpr (KCONTIG) {
+      const int r = r0 + idx / KT;
+      const int k = k0 + (idx % KT) * 4;
+      const float* src = base + static_cast<long long>(r) * ld + k;
+      if (vec_ok && r < R && k + 3 < K) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        reg[p * 4 + 0] = v.x; reg[p * 4 + 1] = v.y; reg[p * 4 + 2] = v.z; reg[p * 4 + 3] = v.w;
+      } else if (r < R && k + 3 < K) {
+        reg[p * 4 + 0] = src[0]; reg[p * 4 + 1] = src[1]; reg[p * 4 + 2] = src[2]; reg[p * 4 + 3] = src[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) reg[p * 4 + j] = (r < R && k + j < K) ? src[j] : 0.f;
+      }
+    } else {
+      const int k = k0 + idx / (ROWS / 4);
+      const int r = r0 + (idx % (ROWS / 4)) * 4;
+      const float* src = base + static_cast<long long>(k) * ld + r;
+      if (vec_ok && k < K && r + 3 < R) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        reg[p * 4 + 0] = v.x; reg[p * 4 + 1] = v.y; reg[p * 4 + 2] = v.z; reg[p * 4 + 3] = v.w;
+      } else if (k < K && r + 3 < R) {
+        reg[p * 4 + 0] = src[0]; reg[p * 4 + 1] = src[1]; reg[p * 4 + 2] = src[2]; reg[p * 4 + 3] = src[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) reg[p * 4 + j] = (k < K && r + j < R) ? src[j] : 0.f;
+      }
+    }
+  }
+}
+
+template <bool KCONTIG, int ROWS, int LD, int P>
+__device__ __forceinline__ void wide_store(float* __restrict__ tile, const float (&reg)[4 * P]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int idx = t + kWideThreads * p;
+    if (idx >= ROWS * BK / 4) continue;
+    if constexpr (KCONTIG) {
+      const int r = idx / KT;
+      const int k = (idx % KT) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[(k + j) * LD + r] = reg[p * 4 + j];
+    } else {
+      const int k = idx / (ROWS / 4);
+      const int r = (idx % (ROWS / 4)) * 4;
+      *reinterpret_cast<float4*>(&tile[k * LD + r]) = make_float4(reg[p * 4], reg[p * 4 + 1], reg[p * 4 + 2], reg[p * 4 + 3]);
+    }
+  }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, int NH>
+__global__ __launch_bounds__(kWideThreads) void gemm_f32_wide_kernel(const float* __restrict__ A, const long long lda,
+                                                            const float* __restrict__ B, const long long ldb,
+                                                            float* __restrict__ C, const long long ldc, const int M,
+                                                            const int N, const int K, const float* __restrict__ bias,
+                                                            const int act, const bool vec_a, const bool vec_b) {
+  using G = WideGeom<NH>;
+  constexpr int LDW = G::LDW, PA = G::PA, PB = G::PB, BNW = G::BNW;
+  extern __shared__ float wide_lds[];
+  float* As0 = wide_lds;                                  // [2][BK * LDT]
+  float* Bs0 = wide_lds + 2 * BK * LDT;                   // [2][BK * LDW]
+  const int m0 = blockIdx.x * BM;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = (wid & 3) * 32;
+  const int wn = (wid >> 2) * NH * 32;
+  const int li = lane & 31, lk = lane >> 5;
+  // column tiles of this wavefront that hold real columns (wave-uniform: the rest are skipped, not computed on padding)
+  int live = (N - wn + 31) / 32;
+  live = live < 0 ? 0 : (live > NH ? NH : live);
+  f32x16 acc[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float ra[4 * PA], rb[4 * PB];
+  wide_load<A_KCONTIG, BM, PA>(A, lda, m0, 0, M, K, vec_a, ra);
+  wide_load<B_KCONTIG, BNW, PB>(B, ldb, 0, 0, N, K, vec_b, rb);
+  wide_store<A_KCONTIG, BM, LDT, PA>(As0, ra);
+  wide_store<B_KCONTIG, BNW, LDW, PB>(Bs0, rb);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool more = k0 + BK < K;
+    if (more) {                                    // the next k-tile's loads fly under this tile's MFMAs
+      wide_load<A_KCONTIG, BM, PA>(A, lda, m0, k0 + BK, M, K, vec_a, ra);
+      wide_load<B_KCONTIG, BNW, PB>(B, ldb, 0, k0 + BK, N, K, vec_b, rb);
+    }
+    const float* as = As0 + cur * BK * LDT;
+    const float* bs = Bs0 + cur * BK * LDW + wn;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = as[(kk + lk) * LDT + wm + li];
+#pragma unroll
+      for (int j = 0; j < NH; ++j)
+        if (j < live) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[(kk + lk) * LDW + j * 32 + li], acc[j], 0, 0, 0);
+    }
+    if (more) {
+      wide_store<A_KCONTIG, BM, LDT, PA>(As0 + (cur ^ 1) * BK * LDT, ra);
+      wide_store<B_KCONTIG, BNW, LDW, PB>(Bs0 + (cur ^ 1) * BK * LDW, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int col = wn + j * 32 + li;
+    if (j >= live || col >= N) continue;
+    const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (row < M) {
+        float v = acc[j][r] + bv;
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        C[static_cast<long long>(row) * ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <bool AK, bool BK_, int NH>
+static void launch_wide(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
+                        int K, const float* bias, int act, hipStream_t s) {
+  const size_t lds = static_cast<size_t>(2) * BK * (LDT + WideGeom<NH>::LDW) * sizeof(float);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_wide_kernel<AK, BK_, NH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  hipLaunchKernelGGL((gemm_f32_wide_kernel<AK, BK_, NH>), dim3((M + BM - 1) / BM), dim3(kWideThreads), lds, s, A, lda, B, ldb, C,
+                     ldc, M, N, K, bias, act, vec_ok(A, lda), vec_ok(B, ldb));
 }
 
 // C[i] = sum_z part[z][i] in a fixed order.  A workgroup owns 64 outputs; its 4 wavefronts take every 4th slice
@@ -504,6 +668,18 @@ __global__ __launch_bounds__(256) void tall_dw_kernel(const float* __restrict__ 
 
 static bool vec_ok(const float* p, long long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0; }
 
+// RBX_GEMM_WIDE=1 routes 64 < N <= 448 with N % 128 != 0 to the wide kernel, 2 also N = 128 / 256 / 384.  Off by default:
+// measured at cfg 4 (profiles/r02/gemm_variants.txt) the layer-1 forward takes 0.957 ms wide against 0.930 ms on the
+// 128 x 128 + narrow pair, the whole step 7.07 against 7.02 ms -- parity at best: the k-loop, not the tiling, is the limit.
+static int wide_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("RBX_GEMM_WIDE");
+    mode = (e != nullptr) ? atoi(e) : 0;
+  }
+  return mode;
+}
+
 // generic driver: C[M,N] = op(A) op(B)
 template <bool AK, bool BK_>
 static int run_gemm(const float* A, long long lda, const float* B, long long ldb, float* C, int M, int N, int K,
@@ -513,12 +689,29 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   int splits = 1;
   const long long tiles = static_cast<long long>(tm) * tn;
   if (tiles < kCUs && K >= 4096 && ws != nullptr && ldc == N) {   // tiny output, long reduction: split K
-    splits = static_cast<int>((2 * kCUs + tiles - 1) / tiles);
+    // every workgroup of the launch is resident at once (33.8 KB of LDS each), so the kernel lasts as long as the CU
+    // with the most workgroups: pick the split count whose tiles x splits fills whole rounds of the 256 CUs best
+    // (k = 1677: 56 tiles x 10 splits = 560 workgroups left a third of the chip idle during the last round; x 9 = 504 fits)
     const int max_splits = K / 512;
-    if (splits > max_splits) splits = max_splits;
     const long long fit = static_cast<long long>(ws_floats / (static_cast<size_t>(M) * N));
-    if (splits > fit) splits = static_cast<int>(fit);
-    if (splits < 1) splits = 1;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int sp = 1; sp <= max_splits && sp <= fit && tiles * sp <= 4 * kCUs; ++sp) {
+      const long long wgs = tiles * sp;
+      const long long rounds = (wgs + kCUs - 1) / kCUs;
+      double eff = static_cast<double>(wgs) / static_cast<double>(rounds * kCUs);
+      if (rounds < 2) eff *= 0.9;                      // one workgroup per CU hides less latency than two
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+    }
+    splits = best;
+  }
+  // one column tile of at most 416 columns and many rows: the wide kernel (no narrow companion, A read once)
+  const int wmode = wide_mode();
+  if (splits == 1 && M >= 2048 && N > 64 && N <= 448 && wmode > 0 && (N % BN != 0 || wmode > 1)) {
+    if (N <= 128) launch_wide<AK, BK_, 2>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, s);
+    else if (N <= 256) launch_wide<AK, BK_, 4>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, s);
+    else launch_wide<AK, BK_, 7>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, s);
+    return check_launch("gemm_f32_wide_kernel");
   }
   int kps = (K + splits - 1) / splits;
   kps = (kps + BK - 1) / BK * BK;

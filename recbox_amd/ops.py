@@ -20,10 +20,12 @@ _DTYPE_CODE = {torch.int32: _lib.RBX_I32, torch.int64: _lib.RBX_I64,
 
 class config(object):
     """Run-time switches of the host layer."""
-    # fused FM: enqueue the id sort of the backward (side stream) AHEAD of the forward kernel so that the two overlap.
-    # Measured: the step does not get faster (0.353-0.356 vs 0.357-0.359 ms) because the forward slows down under the
-    # sort's traffic (61 -> 65 us); off by default, the sort then overlaps the loss and the numeric reductions.
-    sort_before_forward = os.environ.get("RECBOX_AMD_SORT_FIRST", "0") != "0"
+    # fused FM: enqueue the id sort of the backward (and the re-zeroing of the persistent gradients) on the side stream
+    # AHEAD of the forward kernel so that they run beside it.  Round 1 measured no gain (0.353-0.356 vs 0.357-0.359 ms) on
+    # a path that zero-filled 379 MB per step; with the persistent gradients (round 2) the step goes from 0.317 to 0.297 ms:
+    # the forward kernel itself slows from 47 to 63-73 us beside the re-zero / key-build kernels (all of them load the
+    # memory system), but the chain is 20 us shorter.  On by default.
+    sort_before_forward = os.environ.get("RECBOX_AMD_SORT_FIRST", "1") != "0"
     # The reference raises IndexError for an out-of-range id (nn.Embedding on CPU).
     # The kernels flag it on device; checking the flag costs one sync per call.
     check_ids = os.environ.get("RECBOX_AMD_CHECK_IDS", "1") != "0"
@@ -674,35 +676,14 @@ class _FmFused(torch.autograd.Function):
         status = torch.zeros(1, dtype=torch.int32, device=dev) if config.check_ids else None
         ea = emb_plan.arr if emb_plan is not None else None
         la = lr_plan.arr if lr_plan is not None else None
-        # The sort of the backward depends on the ids only: it is put on the side stream BEFORE the forward kernel is
-        # enqueued, so the two run side by side (enqueued after it, the side stream would first wait for the forward).
-        sort = None
-        if train and B > 0 and config.sort_before_forward:
-            if emb_plan is not None:
-                emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
-            if lr_plan is not None:
-                lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
-            ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
-            if ws_bytes > 0:
-                sort = _EarlySort(dev, ws_bytes, lambda ws, st: lib.rbx_fm_sort(
-                    ea, la, lead.n, B, _ptr(ws), ws_bytes, None, st))
-            if emb_plan is not None:
-                emb_plan.bind_params(emb_params)
-            if lr_plan is not None:
-                lr_plan.bind_params(lr_params)
-        check(_timed(("fm_fwd", lead.n, D, B),
-                     lambda: lib.rbx_fm_fwd(ea, la, lead.n, B, _ptr(bias), _ptr(extra), n_extra, x_stride, x_lr,
-                                            _ptr(extra_index), x_rows, _ptr(logit), _ptr(ssum), _ptr(status),
-                                            _stream())))
-        _check_status(status)
-        ctx.state = (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias, has_extra,
-                     extra_index)
-        ctx.sort = sort
-        if presorted is not None:
-            if presorted.B != B or presorted.n != lead.n:
-                raise ValueError("fm_fused: the presorted ids belong to another batch")
-            ctx.sort = presorted                  # fm_presort ran ahead of this forward; the caller orders the streams
-        elif train and B > 0 and not config.sort_before_forward:
+        # The id sort of the backward (and, with persistent gradients, the re-zeroing of the rows the previous step wrote)
+        # depends on the ids only: ``start_sort`` puts it on the side stream.  With ``config.sort_before_forward`` that
+        # happens BEFORE the forward kernel is enqueued, so that the two run side by side (enqueued after it, the side
+        # stream first waits for the forward: the sort then overlaps only the loss and the numeric reductions).
+        ctx.sort = None
+        ctx.pool = None
+
+        def start_sort():
             if emb_plan is not None:
                 emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
             if lr_plan is not None:
@@ -726,6 +707,28 @@ class _FmFused(torch.autograd.Function):
                 pool.early_sort(ctx, dev, ws_bytes, rezero, lambda ws, nbytes, st: _enqueue_sort(
                     (ea, la, lead.n, 1), keep, B, ws, nbytes, st,
                     lambda: lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), nbytes, None, st)))
+            # the forward reads the tables only: back to descriptors without gradient pointers
+            if emb_plan is not None:
+                emb_plan.bind_params(emb_params)
+            if lr_plan is not None:
+                lr_plan.bind_params(lr_params)
+
+        own_sort = train and B > 0 and presorted is None
+        if own_sort and config.sort_before_forward:
+            start_sort()
+        check(_timed(("fm_fwd", lead.n, D, B),
+                     lambda: lib.rbx_fm_fwd(ea, la, lead.n, B, _ptr(bias), _ptr(extra), n_extra, x_stride, x_lr,
+                                            _ptr(extra_index), x_rows, _ptr(logit), _ptr(ssum), _ptr(status),
+                                            _stream())))
+        _check_status(status)
+        ctx.state = (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias, has_extra,
+                     extra_index)
+        if presorted is not None:
+            if presorted.B != B or presorted.n != lead.n:
+                raise ValueError("fm_fused: the presorted ids belong to another batch")
+            ctx.sort = presorted                  # fm_presort ran ahead of this forward; the caller orders the streams
+        elif own_sort and not config.sort_before_forward:
+            start_sort()
         return logit
 
     @staticmethod
