@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 100          /* 0.1.0 */
+#define RBX_VERSION 110          /* 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
 
@@ -355,11 +355,17 @@ int rbx_gatherdot_bwd(const rbx_field_t* cands, int32_t n_cands, int64_t rows, c
  * every other entry is uniform over [0, num_items) with replacement (np.random.choice(..., replace=True)).
  * With d_excl_offsets/d_excl_items (CSR over queries, items sorted ascending inside a query) and d_query[rows]
  * (query of each row), items the query interacted with are never drawn (ignore_pos_items=True: uniform over
- * the complement; up to 64 redraws).  Generator: Philox4x32-10, key = seed, counter = (offset + r * num_negs + j,
- * attempt); item = high 64 bits of (low 64 random bits) x num_items.  Same (seed, offset) -> same draws. */
+ * the complement: up to 64 redraws, then ONE exact draw of the k-th non-excluded item, so a query that interacted with
+ * almost the whole corpus never receives one of its own items).  Generator: Philox4x32-10, key = seed, counter =
+ * (offset + r * num_negs + j, attempt); item = high 64 bits of (low 64 random bits) x num_items.  Same (seed, offset) ->
+ * same draws.  rbx_negsample_checked also bounds-checks d_query[r] against n_queries (rows of the CSR): an index outside
+ * [0, n_queries) sets *d_status (numpy raises IndexError) and draws without exclusion. */
 int rbx_negsample(int64_t num_items, int64_t rows, int32_t num_negs, uint64_t seed, uint64_t offset,
                   const int64_t* d_pos, const int64_t* d_query, const int64_t* d_excl_offsets,
                   const int64_t* d_excl_items, int64_t* d_out, void* stream);
+int rbx_negsample_checked(int64_t num_items, int64_t rows, int32_t num_negs, uint64_t seed, uint64_t offset,
+                          const int64_t* d_pos, const int64_t* d_query, const int64_t* d_excl_offsets,
+                          const int64_t* d_excl_items, int64_t n_queries, int32_t* d_status, int64_t* d_out, void* stream);
 /* rbx_gather_rows: for every column c and index q: dst_c[q, :] = src_c[d_index[q], :] (row_bytes bytes, any
  * element type: ids, sequences [n_items, L], float features) -- the byte-exact equivalent of
  * dict((k, v[item_indexes]) for k, v in item_corpus.items()) followed by flatten(end_dim=1).  An index outside

@@ -267,11 +267,16 @@ void orc_negsample(int64_t num_items, int64_t rows, int32_t num_negs, uint64_t s
       const uint64_t element = offset + (uint64_t)r * num_negs + j;
       int64_t lo = 0, hi = 0, item = 0;
       if (excl_off) { lo = excl_off[query[r]]; hi = excl_off[query[r] + 1]; }
-      for (uint32_t a = 0; a < 64; ++a) {
+      int found = 0;
+      for (uint32_t a = 0; a < 64 && !found; ++a) {
         item = orc_draw(element, a, seed, (uint64_t)num_items);
         int hit = 0;
         for (int64_t k = lo; k < hi && !hit; ++k) hit = excl_items[k] == item;     /* membership, linear on purpose */
-        if (!hit) break;
+        found = !hit;
+      }
+      if (!found && hi - lo < num_items) {      /* 64 rejections: the k-th item of the complement, exactly */
+        item = orc_draw(element, 64, seed, (uint64_t)(num_items - (hi - lo)));
+        for (int64_t k = lo; k < hi && excl_items[k] <= item; ++k) ++item;
       }
       out[r * width + (pos ? 1 : 0) + j] = item;
     }

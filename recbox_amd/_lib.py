@@ -94,6 +94,7 @@ SIGNATURES = {
     "rbx_gatherdot_sort": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P, _P]),
     "rbx_gatherdot_bwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _P, _f32, _P, _i64, _i32, _P, _sz, _P]),
     "rbx_negsample": (ctypes.c_int, [_i64, _i64, _i32, _u64, _u64, _P, _P, _P, _P, _P, _P]),
+    "rbx_negsample_checked": (ctypes.c_int, [_i64, _i64, _i32, _u64, _u64, _P, _P, _P, _P, _i64, _P, _P, _P]),
     "rbx_gather_rows": (ctypes.c_int, [_RP, _i32, _P, _i64, _i64, _P, _P]),
     "rbx_topk_workspace_size": (_sz, [_i64, _i64, _i32]),
     "rbx_topk": (ctypes.c_int, [_P, _P, _i64, _i64, _i64, _i32, _P, _P, _P, _sz, _P]),

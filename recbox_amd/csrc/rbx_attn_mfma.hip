@@ -59,36 +59,41 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, const lo
   }
 }
 
-// the wave's own tile as B operands: reg[s] = g[row0 + (lane & 31)][2 s + (lane >> 5)] * scale
-// (both half-waves read the row with float4 loads and keep their parity)
+// the wave's own tile as B operands: reg[s] = g[row0 + (lane & 31)][(lane >> 5) * HD/2 + s] * scale.
+// MFMA step s contracts over TWO columns, one per half-wave; which two is free as long as both operands agree, so the
+// halves take the two contiguous halves of a row (columns [0, HD/2) and [HD/2, HD)): a lane reads HD/8 float4 that it
+// uses entirely, all in flight.  (The first version paired columns 2 s and 2 s + 1: every lane loaded the WHOLE row,
+// HD/4 float4, and kept every other element -- the compiler issued those loads two at a time, ~8 dependent round trips per
+// operand tile, which is where half of the wavefronts' cycles were parked: profiles/r02/sq_stalls.txt.)
 template <int HD>
 __device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, const long long ld, int row0, int rows, float scale,
                                                float (&reg)[HD / 2]) {
   const int lane = threadIdx.x & 63;
   const int row = row0 + (lane & 31), half = lane >> 5;
   const bool ok = row < rows;
-  const float4* src = reinterpret_cast<const float4*>(g + static_cast<long long>(ok ? row : 0) * ld);
+  const float4* src = reinterpret_cast<const float4*>(g + static_cast<long long>(ok ? row : 0) * ld + half * (HD / 2));
+  float4 v[HD / 8];
 #pragma unroll
-  for (int q = 0; q < HD / 4; ++q) {
-    const float4 v = ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    reg[2 * q] = (half ? v.y : v.x) * scale;
-    reg[2 * q + 1] = (half ? v.w : v.z) * scale;
+  for (int q = 0; q < HD / 8; ++q) v[q] = ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < HD / 8; ++q) {
+    reg[4 * q] = v[q].x * scale; reg[4 * q + 1] = v[q].y * scale; reg[4 * q + 2] = v[q].z * scale; reg[4 * q + 3] = v[q].w * scale;
   }
 }
 
-// acc[row = li of `rows_lds`][col = lane] = sum_d rows_lds[row0 + li][d] * reg[d]
+// acc[row = li of `rows_lds`][col = lane] = sum_d rows_lds[row0 + li][d] * reg[d]   (column pairing as in load_tile_regs)
 template <int HD>
 __device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, int row0, const float (&reg)[HD / 2]) {
   const int lane = threadIdx.x & 63;
-  const float* a = rows_lds + (row0 + (lane & 31)) * (HD + 1) + (lane >> 5);
+  const float* a = rows_lds + (row0 + (lane & 31)) * (HD + 1) + (lane >> 5) * (HD / 2);
   // two accumulator chains (even / odd k steps): a single chain makes every MFMA wait for the previous one
   f32x16 acc, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
 #pragma unroll
   for (int s = 0; s < HD / 2; s += 2) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], reg[s], acc, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s + 2], reg[s + 1], acc1, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], reg[s], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s + 1], reg[s + 1], acc1, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += acc1[r];

@@ -22,7 +22,7 @@
 
 namespace rbx {
 
-constexpr int kMaxAttempts = 64;     // rejection rounds before a draw is kept as is
+constexpr int kMaxAttempts = 64;     // rejection rounds; after them ONE exact draw over the complement of the exclusion list
 
 // uniform item in [0, num_items): high 64 bits of (64 random bits) x num_items
 __device__ __forceinline__ long long draw_item(unsigned long long element, unsigned attempt, unsigned long long seed,
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void negsample_kernel(const long long num_item
                                                         const long long* __restrict__ query,
                                                         const long long* __restrict__ excl_off,
                                                         const long long* __restrict__ excl_items,
+                                                        const long long n_queries, int* __restrict__ status,
                                                         long long* __restrict__ out) {
   const int width = num_negs + (pos != nullptr ? 1 : 0);
   const long long total = rows * width;
@@ -66,13 +67,25 @@ __global__ __launch_bounds__(256) void negsample_kernel(const long long num_item
     long long lo = 0, hi = 0;
     if (excl_off != nullptr) {
       const long long q = query[r];
-      lo = excl_off[q];
-      hi = excl_off[q + 1];
+      if (q < 0 || q >= n_queries) {                              // (numpy would raise IndexError: flagged, no exclusion)
+        if (status != nullptr) atomicOr(status, 1);
+      } else {
+        lo = excl_off[q];
+        hi = excl_off[q + 1];
+      }
     }
     long long item = 0;
-    for (unsigned a = 0; a < kMaxAttempts; ++a) {
+    bool found = false;
+    for (unsigned a = 0; a < kMaxAttempts && !found; ++a) {
       item = draw_item(element, a, seed, static_cast<unsigned long long>(num_items));
-      if (hi <= lo || !excluded(excl_items, lo, hi, item)) break;
+      found = hi <= lo || !excluded(excl_items, lo, hi, item);
+    }
+    if (!found && hi - lo < num_items) {
+      // the query interacted with (almost) the whole corpus: draw the k-th item of the complement exactly -- k uniform in
+      // [0, num_items - n_excl), then step over the sorted exclusion list (every excluded id <= the running item shifts
+      // it by one).  Still the reference's distribution (uniform over the items the query did not interact with).
+      item = draw_item(element, kMaxAttempts, seed, static_cast<unsigned long long>(num_items - (hi - lo)));
+      for (long long k = lo; k < hi && excl_items[k] <= item; ++k) ++item;
     }
     out[i] = item;
   }
@@ -126,6 +139,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const RowCopyPack P, c
 extern "C" int rbx_negsample(int64_t num_items, int64_t rows, int32_t num_negs, uint64_t seed, uint64_t offset,
                              const int64_t* d_pos, const int64_t* d_query, const int64_t* d_excl_offsets,
                              const int64_t* d_excl_items, int64_t* d_out, void* stream) {
+  return rbx_negsample_checked(num_items, rows, num_negs, seed, offset, d_pos, d_query, d_excl_offsets, d_excl_items, INT64_MAX,
+                               nullptr, d_out, stream);
+}
+
+extern "C" int rbx_negsample_checked(int64_t num_items, int64_t rows, int32_t num_negs, uint64_t seed, uint64_t offset,
+                                     const int64_t* d_pos, const int64_t* d_query, const int64_t* d_excl_offsets,
+                                     const int64_t* d_excl_items, int64_t n_queries, int32_t* d_status, int64_t* d_out,
+                                     void* stream) {
   using namespace rbx;
   if (num_items <= 0) return fail(RBX_ERR_INVALID, "negsample: num_items=%lld", static_cast<long long>(num_items));
   if (rows < 0 || num_negs < 0) return fail(RBX_ERR_INVALID, "negsample: negative sizes");
@@ -142,7 +163,7 @@ extern "C" int rbx_negsample(int64_t num_items, int64_t rows, int32_t num_negs, 
                      static_cast<unsigned long long>(seed), static_cast<unsigned long long>(offset),
                      reinterpret_cast<const long long*>(d_pos), reinterpret_cast<const long long*>(d_query),
                      reinterpret_cast<const long long*>(d_excl_offsets), reinterpret_cast<const long long*>(d_excl_items),
-                     reinterpret_cast<long long*>(d_out));
+                     static_cast<long long>(n_queries), d_status, reinterpret_cast<long long*>(d_out));
   return check_launch("negsample_kernel");
 }
 

@@ -1187,8 +1187,15 @@ def negsample(num_items, rows, num_negs, seed, offset=0, pos=None, query=None, e
     width = num_negs + (1 if pos is not None else 0)
     out = torch.empty((rows, width), dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        check(lib.rbx_negsample(num_items, rows, num_negs, int(seed) & (2 ** 64 - 1), int(offset), _ptr(pos), _ptr(query),
-                                _ptr(excl_offsets), _ptr(excl_items), _ptr(out), _stream()))
+        if excl_offsets is None:
+            check(lib.rbx_negsample(num_items, rows, num_negs, int(seed) & (2 ** 64 - 1), int(offset), _ptr(pos),
+                                    _ptr(query), None, None, _ptr(out), _stream()))
+        else:          # the query index of every row is checked against the CSR (numpy raises IndexError for a bad one)
+            status = torch.zeros(1, dtype=torch.int32, device=dev) if config.check_ids else None
+            check(lib.rbx_negsample_checked(num_items, rows, num_negs, int(seed) & (2 ** 64 - 1), int(offset), _ptr(pos),
+                                            _ptr(query), _ptr(excl_offsets), _ptr(excl_items), excl_offsets.numel() - 1,
+                                            _ptr(status), _ptr(out), _stream()))
+            _check_status(status)
     return out
 
 

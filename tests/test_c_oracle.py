@@ -165,3 +165,22 @@ def test_gather_rows_oracle_matches_reference_loader_fixture():
         assert (got == fx["user"][k]).all(), k
     _, bad = C.gather_rows(fx["corpus"]["item_id"], np.array([0, 99], dtype=np.int64))
     assert bad
+
+
+def test_negsample_oracle_never_returns_an_excluded_item_even_for_a_query_that_saw_almost_everything():
+    """after 64 rejected draws the sampler used to keep its last draw, i.e. could emit one of the query's own
+    items as a negative.  Now: one exact draw over the complement (uniform over the items the query did not interact with,
+    the reference's ignore_pos_items distribution)."""
+    n_items, rows, negs = 200, 64, 8
+    allowed = {0: [7, 123], 1: [199], 2: [0, 1, 2, 3]}
+    off, items = [0], []
+    for q in range(3):
+        ex = [i for i in range(n_items) if i not in allowed[q]]
+        items += ex
+        off.append(len(items))
+    query = np.arange(rows) % 3
+    out = C.negsample(n_items, rows, negs, seed=5, query=query, excl_offsets=np.array(off), excl_items=np.array(items))
+    for r in range(rows):
+        assert set(out[r].tolist()) <= set(allowed[int(query[r])])
+    assert {7, 123} == set(out[query == 0].reshape(-1).tolist())            # both survivors are drawn
+    assert {0, 1, 2, 3} == set(out[query == 2].reshape(-1).tolist())

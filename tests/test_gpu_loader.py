@@ -120,3 +120,28 @@ def test_train_generator_epoch():
     for user_q in range(5):
         own = set(c[q == user_q].tolist())
         assert not (set(negs[q == user_q].reshape(-1).tolist()) & own)
+
+
+def test_negsample_exact_fallback_and_query_bounds():
+    """a query that interacted with almost the whole corpus never gets one of its own items (exact draw over the
+    complement after 64 rejections; HIP == C oracle bit for bit), and a query index outside the CSR raises IndexError."""
+    import pytest
+    n_items, rows, negs = 200, 512, 6
+    allowed = {0: [7, 123], 1: [199], 2: [0, 1, 2, 3]}
+    off, items = [0], []
+    for q in range(3):
+        items += [i for i in range(n_items) if i not in allowed[q]]
+        off.append(len(items))
+    query = np.arange(rows) % 3
+    off, items = np.array(off), np.array(items)
+    got = ops.negsample(n_items, rows, negs, seed=5, query=torch.from_numpy(query).cuda(),
+                        excl_offsets=torch.from_numpy(off).cuda(), excl_items=torch.from_numpy(items).cuda()).cpu().numpy()
+    want = C.negsample(n_items, rows, negs, seed=5, query=query, excl_offsets=off, excl_items=items)
+    assert (got == want).all()
+    for r in range(rows):
+        assert set(got[r].tolist()) <= set(allowed[int(query[r])])
+    bad = torch.from_numpy(query).cuda()
+    bad[3] = 3                                                            # the CSR has 3 queries: 0, 1, 2
+    with pytest.raises(IndexError):
+        ops.negsample(n_items, rows, negs, seed=5, query=bad, excl_offsets=torch.from_numpy(off).cuda(),
+                      excl_items=torch.from_numpy(items).cuda())
