@@ -25,7 +25,10 @@ class GraphedStep(object):
                                     # (optimizer step) before the next replay
     """
 
-    def __init__(self, fn, warmup=3, capture_error_mode="global", reuse_grads=True):
+    def __init__(self, fn, warmup=3, capture_error_mode="global", reuse_grads=True, check_every=0):
+        # check_every: every that many replays, read the deferred id-range status word (one host sync) and raise
+        # IndexError if a replay met an id outside its table (0 = never: call ops.check_deferred_ids() yourself)
+        self.check_every, self.replays = int(check_every), 0
         # reuse_grads: False / True (the fused FM body) / "all" (also the generic lookup: ops.config.reuse_grad_buffers)
         if ops.config.check_ids:
             raise RuntimeError("GraphedStep: set recbox_amd.ops.config.check_ids = False first "
@@ -55,6 +58,9 @@ class GraphedStep(object):
         if ops._dropout_ticks:
             ops.bump_dropout_tick()          # a replay re-runs the captured seeds: the device tick makes the masks new
         self.graph.replay()
+        self.replays += 1
+        if self.check_every and self.replays % self.check_every == 0:
+            ops.check_deferred_ids()
         return self.out
 
 

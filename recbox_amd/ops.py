@@ -48,6 +48,13 @@ class config(object):
     # CTR model) sort identical (row, sample) pairs for their backward: the second one copies the first one's result
     # (rbx_sort_share checks the descriptors) instead of sorting again.
     share_sorts = os.environ.get("RECBOX_AMD_SHARE_SORTS", "1") != "0"
+    # with check_ids off: keep one persistent status word per device that the kernels OR into (check_deferred_ids() reads it)
+    defer_id_check = os.environ.get("RECBOX_AMD_DEFER_IDS", "1") != "0"
+    # fused FM backward: run the batch reductions of the numeric-feature weights and the bias (~35 us at the bench shape) on
+    # the side stream beside the segmented reduce instead of in front of it.  Measured SLOWER inside the captured step
+    # (0.336 vs 0.297 ms): with the extra fork / join the hipGraph runtime serialised the forward kernel behind the whole
+    # sort chain (profiles/r02/fm_replay_timeline_numeric_beside.txt).  Off.
+    numeric_beside_reduce = os.environ.get("RECBOX_AMD_NUMERIC_BESIDE", "0") != "0"
     reuse_grad_buffers = {"0": False, "": False, "all": "all"}.get(os.environ.get("RECBOX_AMD_REUSE_GRADS", "0"), True)
 
 
@@ -322,9 +329,41 @@ class _EarlySort(object):
             torch.cuda.current_stream().wait_event(self.event)
 
 
+_deferred_status = {}
+
+
+def _status_word(device):
+    """The int32 word the kernels raise for an out-of-range id.  ``config.check_ids``: a fresh word that ``_check_status``
+    reads right after the launch (one host sync per call, the reference's behaviour: nn.Embedding raises at once).  Off
+    (hipGraph capture, benchmarks): ONE persistent word per device that every launch ORs into and nothing reads inside the
+    step -- ``check_deferred_ids()`` reads and clears it whenever the caller can afford a sync (GraphedStep does every
+    ``check_every`` replays), so that a bad id is reported late rather than silently read as a zero row."""
+    if config.check_ids:
+        return torch.zeros(1, dtype=torch.int32, device=device)
+    if not config.defer_id_check:
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _deferred_status.get(key)
+    if t is None:
+        t = _deferred_status[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
 def _check_status(status):
-    if status is not None and int(status.item()) != 0:
+    if status is not None and config.check_ids and int(status.item()) != 0:
         raise IndexError("index out of range in self")
+
+
+def check_deferred_ids():
+    """Raise IndexError if any lookup since the last call met an id outside its table while ``config.check_ids`` was off
+    (one device-to-host read per device; the words are cleared)."""
+    bad = False
+    for t in _deferred_status.values():
+        if int(t.item()) != 0:
+            bad = True
+            t.zero_()
+    if bad:
+        raise IndexError("index out of range in self (reported late: recbox_amd.ops.config.check_ids was off)")
 
 
 class _EmbedLookup(torch.autograd.Function):
@@ -342,7 +381,7 @@ class _EmbedLookup(torch.autograd.Function):
         dev = params[0].device if params else keep[0].device
         out = _padded_rows(B, plan.width, dev) if pad_rows else torch.empty((B, plan.width), dtype=torch.float32, device=dev)
         row_scale = torch.empty((plan.n, B), dtype=torch.float32, device=dev) if plan.needs_row_scale else None
-        status = torch.zeros(1, dtype=torch.int32, device=dev) if config.check_ids else None
+        status = _status_word(dev)
         check(_timed(("embed_fwd", plan.n, plan.width, B),
                      lambda: lib.rbx_embed_fwd(plan.arr, plan.n, B, _ptr(out), out.stride(0) if B > 1 else plan.width,
                                                _ptr(row_scale), _ptr(status), _stream())))
@@ -673,7 +712,7 @@ class _FmFused(torch.autograd.Function):
                 n_extra, x_stride, x_lr, x_rows = extra_index.shape[1], extra.shape[1], has_extra - 1, extra.shape[0]
         logit = torch.empty((B, 1), dtype=torch.float32, device=dev)
         ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if (train and emb_plan is not None) else None
-        status = torch.zeros(1, dtype=torch.int32, device=dev) if config.check_ids else None
+        status = _status_word(dev)
         ea = emb_plan.arr if emb_plan is not None else None
         la = lr_plan.arr if lr_plan is not None else None
         # The id sort of the backward (and, with persistent gradients, the re-zeroing of the rows the previous step wrote)
@@ -814,7 +853,20 @@ class _FmFused(torch.autograd.Function):
                                            extra.shape[1], has_extra - 1, _ptr(extra_index), extra.shape[0], _ptr(dx),
                                            _stream()))
         ws_early = ctx.sort.ws if (ctx.sort is not None and same) else None
-        if ws_early is not None:
+        numeric_done = None
+        if ws_early is not None and config.numeric_beside_reduce and getattr(ctx.sort, "event", None) is not None:
+            # numeric weights + bias need dL/dlogit and S only: they go to the side stream -- behind the id sort that is
+            # (or was) running there -- and so run BESIDE the segmented reduce instead of in front of it
+            cur = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(cur)
+            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2, _ptr(ws_early),
+                                 ctx.sort.ws_bytes, ctypes.c_void_p(side.cuda_stream)))
+            numeric_done = side.record_event()
+            for t in [dlogit, ssum, gb] + [g for g in grads if g is not None]:
+                if t is not None:
+                    t.record_stream(side)
+        elif ws_early is not None:
             # numeric weights + bias do not need the sorted ids: run them while the sort may still be in flight
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2, _ptr(ws_early),
                                  ctx.sort.ws_bytes, _stream()))
@@ -827,6 +879,8 @@ class _FmFused(torch.autograd.Function):
             check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, _stream()))
         check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 if ws_early is not None else 3,
                              _ptr(ws), ws_bytes, _stream()))
+        if numeric_done is not None:
+            torch.cuda.current_stream(dev).wait_event(numeric_done)
         if pool is not None:
             pool.done(B)
         _forget_sort(ws)
@@ -1093,7 +1147,7 @@ class _GatherDot(torch.autograd.Function):
             raise ValueError("gather_dot: ids have %d rows, x has %d" % (R, x.shape[0]))
         plan.bind_params(params)
         out = torch.empty((R, plan.width), dtype=torch.float32, device=x.device)
-        status = torch.zeros(1, dtype=torch.int32, device=x.device) if config.check_ids else None
+        status = _status_word(x.device)
         check(_timed(("gatherdot_fwd", plan.n, plan.width, R),
                      lambda: lib.rbx_gatherdot_fwd(plan.arr, plan.n, R, _ptr(x), x.stride(0), scale, _ptr(out),
                                                    _ptr(status), _stream())))

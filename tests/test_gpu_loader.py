@@ -125,7 +125,7 @@ def test_train_generator_epoch():
 def test_negsample_exact_fallback_and_query_bounds():
     """a query that interacted with almost the whole corpus never gets one of its own items (exact draw over the
     complement after 64 rejections; HIP == C oracle bit for bit), and a query index outside the CSR raises IndexError."""
-    import pytest
+    from recbox_amd import ops
     n_items, rows, negs = 200, 512, 6
     allowed = {0: [7, 123], 1: [199], 2: [0, 1, 2, 3]}
     off, items = [0], []

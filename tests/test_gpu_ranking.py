@@ -1074,3 +1074,32 @@ def test_fm_with_packed_tables_is_bit_identical(row_floats):
             assert torch.equal(p0.grad, p1.grad), k
     finally:
         ops.config.check_ids = old
+
+
+def test_out_of_range_ids_are_reported_late_when_the_eager_check_is_off():
+    """With ops.config.check_ids = False (hipGraph capture, benchmarks) an id outside its table no longer raises at the
+    lookup -- the reference's nn.Embedding would (IndexError) -- but it is not silent either: every kernel ORs into one
+    persistent device word, ops.check_deferred_ids() reports it, and GraphedStep(check_every=N) calls that every N replays."""
+    from recbox_amd import ops
+    from recbox_amd.graph import GraphedStep
+    from recbox_amd.ranking.pytorch.models import FM
+    vocabs = CRITEO_SMALL_VOCABS[:6]
+    fm, X0, y0 = _criteo_like(300, vocabs, 16, seed=9)
+    model = FM(fm, 16).cuda()
+    Xs, ys = _cuda(X0), y0.cuda()
+    old = ops.config.check_ids
+    ops.config.check_ids = False
+    try:
+        ops.check_deferred_ids()                                   # clear whatever earlier tests left behind
+        step = GraphedStep(lambda: _bce_step(model, Xs, ys), warmup=3, check_every=2)
+        step()
+        step()                                                     # replay 2: checked, clean
+        Xs["C2"][17] = vocabs[1] + 5                               # beyond the table (vocab_size = vocabs[1] + 1)
+        step()                                                     # replay 3: flagged on the device, not read yet
+        with pytest.raises(IndexError):
+            step()                                                 # replay 4: the periodic check reports it
+        Xs["C2"][17] = 1
+        step()
+        ops.check_deferred_ids()                                   # the word was cleared: clean again
+    finally:
+        ops.config.check_ids = old
