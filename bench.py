@@ -336,7 +336,8 @@ def run_model_config(args, rank, world, dev):
                 from recbox_amd.rechub.models.ranking import DeepFM
                 model = DeepFM(dense + sparse, sparse, mlp)
         batches = [_deepfm_batch(B, 1 + rank + 1000 * k, args.dist, dev) for k in range(K)]
-        loss_of = lambda x: F.binary_cross_entropy(model(x), x["label"])               # noqa: E731
+        # the CTR trainer's torch.nn.BCELoss (rechub/trainers/ctr_trainer.py:33) on the model's sigmoid output
+        loss_of = lambda x: ops.binary_cross_entropy(model(x), x["label"])             # noqa: E731
     else:
         V, D, L = args.items or 1_000_000, 64, 200
         from recbox_amd.rechub.models.matching import SASRec
@@ -524,9 +525,13 @@ def main():
                          "(doubled automatically if the warm-up overflows); 0 = exact all-to-all-v (host sync per "
                          "call, eager launches only)")
     ap.add_argument("--rotate", type=int, default=8,
-                    help="number of DISTINCT device-resident batches cycled through the static input buffer, one copy_ "
-                         "per step inside the timed region (a training loop sees new ids every step: replaying one "
-                         "batch keeps its rows in the 256 MB Infinity Cache); 0/1 = replay one batch")
+                    help="number of DISTINCT device-resident batches the timed loop cycles through (a training loop sees "
+                         "new ids every step: replaying one batch keeps its rows in the 256 MB Infinity Cache); "
+                         "0/1 = replay one batch.  FM on one GPU: one captured step per resident batch; elsewhere (and "
+                         "with --rotate-by-copy) batch i %% K is copied into the static input buffer before each step, "
+                         "inside the timed region")
+    ap.add_argument("--rotate-by-copy", action="store_true",
+                    help="FM, one GPU: rotate by copy_ into one static buffer (one captured step) instead of one graph per batch")
     ap.add_argument("--sort-after-forward", action="store_true",
                     help="fm: enqueue the backward's id sort / re-zero after the forward kernel instead of beside it "
                          "(recbox_amd.ops.config.sort_before_forward = False)")
@@ -629,17 +634,21 @@ def main():
 
     params = list(model.parameters())
 
-    def eager_step():
-        for p in params:                      # == model.zero_grad(set_to_none=True) without walking the module tree
-            p.grad = None
-        prob = model(X)["y_pred"]
-        loss = loss_fn(prob, y, reduction="mean")     # the harness's get_loss("binary_crossentropy")
-        if sharded:
-            (loss / world).backward()         # global-mean loss: shard owners sum contributions of every rank
-            model.sync_grads()                # replicated small tables / numeric weights / bias: one all-reduce
-        else:
-            loss.backward()
-        return loss
+    def step_over(Xk, yk):
+        def one_step():
+            for p in params:                  # == model.zero_grad(set_to_none=True) without walking the module tree
+                p.grad = None
+            prob = model(Xk)["y_pred"]
+            loss = loss_fn(prob, yk, reduction="mean")    # the harness's get_loss("binary_crossentropy")
+            if sharded:
+                (loss / world).backward()     # global-mean loss: shard owners sum contributions of every rank
+                model.sync_grads()            # replicated small tables / numeric weights / bias: one all-reduce
+            else:
+                loss.backward()
+            return loss
+        return one_step
+
+    eager_step = step_over(X, y)              # reads the static buffer `batch` (refill(i) puts batch i % K there)
 
     def overflowed():
         flag = model.tables.overflow.float().reshape(1).clone()
@@ -649,13 +658,32 @@ def main():
 
     step = eager_step
     graph_note = "eager launches"
+    rotating_graphs = None
     if not args.eager and not sharded:
         # one hipGraph holds the whole step (same kernels, same C ABI); the batch lives in static buffers
         from recbox_amd.graph import GraphedStep
         try:
-            step = GraphedStep(eager_step, warmup=3, reuse_grads=ops.config.reuse_grad_buffers)
-            graph_note = "hipGraph replay"
+            if K > 1 and not args.rotate_by_copy:
+                # K distinct batches stay resident in HBM, each with a captured step of its own (the graphs share their
+                # intermediate memory and the model's persistent gradient buffer); the timed loop replays them in rotation:
+                # every step gathers rows of another batch and nothing is copied inside the timed region
+                rotating_graphs = []
+                for k in range(K):
+                    if args.contiguous_ids:               # batches[k] is [40, B]: a column of the batch is a row here
+                        Xk = OrderedDict((name, batches[k][fmw.fm.get_column_index(name)]) for name in fmw.fm.features)
+                        yk = labels[k]
+                    else:
+                        Xk, yk = slice_inputs(fmw.fm, batches[k])
+                    rotating_graphs.append(GraphedStep(step_over(Xk, yk), warmup=3 if k == 0 else 2,
+                                                       reuse_grads=ops.config.reuse_grad_buffers, params=params,
+                                                       pool=rotating_graphs[0].pool() if rotating_graphs else None))
+                step = rotating_graphs[0]
+                graph_note = "hipGraph replay (one captured step per resident batch)"
+            else:
+                step = GraphedStep(eager_step, warmup=3, reuse_grads=ops.config.reuse_grad_buffers)
+                graph_note = "hipGraph replay"
         except Exception as exc:               # a capture this stack refuses: the same step, launched from Python
+            rotating_graphs = None
             print("[bench] hipGraph capture failed (%s: %s); launching the step eagerly" % (type(exc).__name__, exc),
                   file=sys.stderr)
             torch.cuda.synchronize()
@@ -685,9 +713,15 @@ def main():
         graph_note = ("8 hipGraph pieces + RCCL collectives between them (%s)"
                       % ("rbx_all_to_all on the step's stream" if comm.direct.on else "torch.distributed")) if use_graphs else "eager launches"
 
+    def run_step(i):
+        if rotating_graphs is not None:
+            rotating_graphs[i % K]()
+        else:
+            refill(i)
+            step()
+
     for i in range(args.warmup):
-        refill(i)
-        step()
+        run_step(i)
     # dominant kernel = the embedding gather: fm_fused_fwd (fused path) or the [B, 39, 16] embed_fwd (layer path)
     if args.path == "fused" or sharded:
         timer = ops.KernelTimer(lambda m: m[0] == "fm_fwd")
@@ -703,8 +737,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        refill(args.warmup + i)
-        step()
+        run_step(args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -773,7 +806,7 @@ def main():
                     "traffic": measured_traffic(args.path, kname) if (B == 65536 and args.dim == 16) else None,
                     "kernel": kname,
                     "kernel_ms": kms, "algorithmic_bytes_per_launch": per_sample * B,
-                    "inputs": ("%d distinct batches rotated through the static buffer" % K) if K > 1 else "one batch replayed"}
+                    "inputs": ("%d distinct batches in rotation" % K) if K > 1 else "one batch replayed"}
             wms = warm_timer.mean_ms()
             if wms:
                 roof["frac_warm"] = per_sample * B / (wms * 1e-3) / 1e9 / 8000.0
@@ -793,7 +826,9 @@ def main():
                "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
                                       "%s ids (%s), %s path%s, %s, dense-grad autograd contract (%s), no optimiser step"
                                       % (args.dim, B, args.dist,
-                                         ("%d distinct batches rotated, one copy_ per step in the timed region" % K)
+                                         (("%d distinct batches resident in HBM, replayed in rotation" % K)
+                                          if rotating_graphs is not None else
+                                          ("%d distinct batches rotated, one copy_ per step in the timed region" % K))
                                          if K > 1 else "one batch replayed", args.path,
                                          " (emb | LR rows packed in one [V, 32] storage per table pair)"
                                          if (not sharded and args.path == "fused" and args.pack_tables) else "", graph_note,

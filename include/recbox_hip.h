@@ -163,17 +163,20 @@ int rbx_pairmul_bwd(const float* d_left, const float* d_right, const float* d_do
  * one-id-per-sample categorical and numeric features can be fused.  Either array may be NULL
  * (lr == NULL: interaction only; emb == NULL: LogisticRegression only).
  *   d_logit[B] = sum_f lr_f + bias + 0.5 * sum_d[(sum_f e_fd)^2 - sum_f e_fd^2]
+ *   d_prob[B]  = sigmoid(d_logit)  (optional, NULL to skip: the model's y_pred -- ranking_model.py output_activation --
+ *                out of the same pass)
  *   d_sum[B,D] = sum_f e_f   (kept for the backward; may be NULL for inference)
  * Backward: row r of table f gets  dW[r] += sum_b g_b S_b - w_r * sum_b g_b  and
  * dW_lr[r] += sum_b g_b  over the samples b that looked r up (sorted, segmented,
  * deterministic); numeric weights and the bias are batch reductions.  Grads go into
  * emb[i].grad / lr[i].grad (dense; stored when accumulate == 0, added otherwise) and d_dbias[1].
  * phases: bit 0 = categorical tables (needs the sort), bit 1 = numeric weights + bias (does
- * not): a caller that sorts on another stream runs phase 2 first and phase 1 after the join. */
+ * not): a caller that sorts on another stream runs phase 2 first and phase 1 after the join; bit 2 = the
+ * numeric-feature gradients and d_dbias are uninitialised memory: STORE them (no zero fill by the caller) instead of adding. */
 int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                const float* d_lr_bias, const float* d_extra, int32_t n_extra, int32_t extra_stride,
                int32_t extra_lr_off, const int32_t* d_extra_index, int64_t extra_rows, float* d_logit,
-               float* d_sum, int32_t* d_status, void* stream);
+               float* d_prob, float* d_sum, int32_t* d_status, void* stream);
 /* Rows of row-sharded tables arrive from their owners instead of being gathered locally:
  * d_extra[B, n_extra, extra_stride] holds, per (sample, table), the embedding row in floats [0, D)
  * and the dim-1 LR weight at float extra_lr_off (-1: none); they take part in S, Q and the LR sum
@@ -435,6 +438,16 @@ int rbx_bce_mean_bwd(const float* d_prob, const float* d_target, const float* d_
  * d_dlogit = grad_scale * dL/dx = grad_scale / n * (p - y) / max(p (1 - p), 1e-12) * (1 - p) p (optional). */
 int rbx_sigmoid_bce_mean(const float* d_logit, const float* d_target, int64_t n, float grad_scale, float* d_prob,
                          float* d_loss, float* d_dlogit, void* d_workspace, size_t workspace_bytes, void* stream);
+/* The same in ONE launch: the workgroup that finishes last adds the block partials (same fixed order, so the same bits as the
+ * two-launch form).  d_counter[1] is caller-owned state that must be 0 before the first call; every call leaves it at 0.
+ * Calls that share a counter must not overlap (one counter per stream). */
+int rbx_sigmoid_bce_mean_onepass(const float* d_logit, const float* d_target, int64_t n, float grad_scale, float* d_prob,
+                                 float* d_loss, float* d_dlogit, void* d_workspace, size_t workspace_bytes,
+                                 uint32_t* d_counter, void* stream);
+/* y[i] = scalar[0] * x[i], the scalar read on the device: the backward of a loss whose dL/dlogit (for an upstream gradient
+ * of 1) was already written by rbx_sigmoid_bce_mean in the forward -- autograd's upstream scalar is applied without a
+ * host read (ops.binary_cross_entropy on the output of ops.sigmoid_output). */
+int rbx_scale_by_scalar(const float* d_x, const float* d_scalar, int64_t n, float* d_y, void* stream);
 
 /* ---- dense tower: y = act(x W^T + b) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) -------
  * core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58,

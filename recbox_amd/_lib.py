@@ -75,7 +75,7 @@ SIGNATURES = {
     "rbx_shard_combine_bwd": (ctypes.c_int, [_GP, _P, _i64, ctypes.POINTER(ctypes.c_int64), _P, _P, _P, _P]),
     "rbx_interaction_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _i32, _i32, _P, _P]),
     "rbx_interaction_bwd": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _i32, _P, _i64, _P]),
-    "rbx_fm_fwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _i32, _i32, _i32, _P, _i64, _P, _P, _P, _P]),
+    "rbx_fm_fwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _i32, _i32, _i32, _P, _i64, _P, _P, _P, _P, _P]),
     "rbx_fm_extra_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _i32, _P, _i64, _P, _P]),
     "rbx_route_workspace_size": (_sz, [_i64, _i32]),
     "rbx_route": (ctypes.c_int, [_FP, _i32, _i64, _i32, _i64, _P, _P, _P, _P, _P, _sz, _P]),
@@ -112,6 +112,8 @@ SIGNATURES = {
     "rbx_bce_mean_fwd": (ctypes.c_int, [_P, _P, _i64, _P, _P, _sz, _P]),
     "rbx_bce_mean_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _P, _P]),
     "rbx_sigmoid_bce_mean": (ctypes.c_int, [_P, _P, _i64, _f32, _P, _P, _P, _P, _sz, _P]),
+    "rbx_scale_by_scalar": (ctypes.c_int, [_P, _P, _i64, _P, _P]),
+    "rbx_sigmoid_bce_mean_onepass": (ctypes.c_int, [_P, _P, _i64, _f32, _P, _P, _P, _P, _sz, _P, _P]),
     "rbx_pairmul_fwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _i32, _P, _P]),
     "rbx_pairmul_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _P, _P, _P]),
     "rbx_l2norm_fwd": (ctypes.c_int, [_P, _i64, _i32, _f32, _P, _P, _P]),

@@ -21,7 +21,13 @@ constexpr int kRadix = 256;                                // bins of an 8-bit d
 #define RBX_MAX_RADIX_BITS 8
 #endif
 constexpr int kMaxRadixBits = RBX_MAX_RADIX_BITS;
-constexpr int kChunk = 32;                                 // sorted pairs per lane group in the reduce (16 measured slower)
+// sorted pairs per lane group in the reduce.  Measured on the Criteo shape (profiles/r02/reduce_variants.txt): the kernel
+// sits at 77-86 us whatever the chunk, the lookups in flight and the occupancy are -- 40 pairs with 3 waves per SIMD
+// (no register spill, 666 workgroups: all resident at once) is the best of them at 80 us; 16, 48, 56 and 64 are slower.
+#ifndef RBX_CHUNK
+#define RBX_CHUNK 40
+#endif
+constexpr int kChunk = RBX_CHUNK;
 constexpr unsigned kLocalBits = 26;                        // val = slot << 26 | (b*L + l)
 constexpr unsigned kLocalMask = (1u << kLocalBits) - 1u;
 constexpr int kNumSamples = 256;                            // samples per workgroup in the numeric-feature reduction
@@ -64,8 +70,14 @@ struct SegPack {
   unsigned tile0[RBX_MAX_FIELDS + 1];   // first tile of every segment (+ total)
   unsigned lk0[RBX_MAX_FIELDS + 1];     // first lookup of every segment (+ total)
   unsigned row0[RBX_MAX_FIELDS];        // first global row of the segment
+  // A segment only takes part in the LAST ceil(bits of its row range / digit) passes of the sort: build_keys puts its
+  // pairs into the buffer pass `first_pass` reads, and the tiles of the segment leave the earlier passes at once.
+  // Criteo shape: 8 tables of <= 255 rows sort in 1 pass, 10 of <= 65 535 rows in 2, the 8 large ones in 3 -- 52
+  // (table, pass) units of work instead of 78.
+  unsigned char first_pass[RBX_MAX_FIELDS];
   int n;
 };
+static_assert(sizeof(KeyPack) + sizeof(SegPack) + 96 <= 4096, "build_keys_kernel's arguments must fit the 4 KiB kernarg segment");
 
 // (segment, first lookup, lookups) of the tile a workgroup owns
 __device__ __forceinline__ void seg_of_tile(const SegPack& S, unsigned tile, int* seg, unsigned* first, unsigned* count) {

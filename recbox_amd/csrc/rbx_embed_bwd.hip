@@ -114,6 +114,7 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
     S.n = 0;
     unsigned tiles = 0, lk = 0;
     unsigned long long max_rows = 1;
+    unsigned long long rows_of_seg[RBX_MAX_FIELDS];
     int c = 0;
     while (c < p->n_cat) {
       int end = last_field_of_table[field_table[c]];
@@ -132,6 +133,7 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
         S.tile0[S.n] = tiles;
         S.lk0[S.n] = lk;
         S.row0[S.n] = row0;
+        rows_of_seg[S.n] = seg_rows;
         ++S.n;
         tiles += (seg_lk + kSortTile - 1) / kSortTile;
         lk += seg_lk;
@@ -147,6 +149,12 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
     p->passes = (bits + kMaxRadixBits - 1) / kMaxRadixBits;
     const int per = (bits + p->passes - 1) / p->passes;
     p->radix_bits = per <= 8 ? 8 : (per <= 10 ? 10 : 11);
+    for (int g = 0; g < S.n; ++g) {
+      int sb = 1;
+      while ((1ull << sb) <= rows_of_seg[g]) ++sb;
+      const int need = (sb + p->radix_bits - 1) / p->radix_bits;
+      S.first_pass[g] = static_cast<unsigned char>(p->passes - need);
+    }
   }
   p->n_chunks = (p->n_lookups + kChunk - 1) / kChunk;
   p->num_blocks = static_cast<unsigned>((B + kNumSamples - 1) / kNumSamples);
@@ -179,8 +187,9 @@ __device__ __forceinline__ unsigned seg_digit(unsigned key, unsigned sentinel, u
 
 template <int RB>
 __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack P, const int n_cat, const SegPack S,
-                                                         const unsigned sentinel, unsigned* __restrict__ keys,
-                                                         unsigned* __restrict__ vals, int* __restrict__ status,
+                                                         const unsigned sentinel, unsigned* __restrict__ keys0,
+                                                         unsigned* __restrict__ vals0, unsigned* __restrict__ keys1,
+                                                         unsigned* __restrict__ vals1, int* __restrict__ status,
                                                          unsigned* __restrict__ fin, unsigned* __restrict__ hist) {
   constexpr int R = 1 << RB;
   if (blockIdx.x == 0 && threadIdx.x == 0) {          // fix-up work-list length and arrival counter (rbx_segreduce.h)
@@ -204,6 +213,11 @@ __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack 
   unsigned tile0, tile_n;
   seg_of_tile(S, blockIdx.x, &seg, &tile0, &tile_n);
   const unsigned row0 = S.row0[seg];
+  // the pairs go where the segment's first pass reads them; only a segment that starts in pass 0 needs its first
+  // digit's histogram from here (the others get it from radix_hist_kernel when their turn comes)
+  const int fp = S.first_pass[seg];
+  unsigned* __restrict__ keys = (fp & 1) ? keys1 : keys0;
+  unsigned* __restrict__ vals = (fp & 1) ? vals1 : vals0;
   // (a two-sweep variant -- all raw id loads first, decoding afterwards -- was measured slower: 19.3 vs 16.3 us)
 #pragma unroll
   for (int it = 0; it < kSortItems; ++it) {
@@ -231,8 +245,9 @@ __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack 
     }
     keys[j] = key;
     vals[j] = (static_cast<unsigned>(lo) << kLocalBits) | local;
-    atomicAdd(&cnt[seg_digit<RB>(key, sentinel, row0, 0)], 1u);
+    if (fp == 0) atomicAdd(&cnt[seg_digit<RB>(key, sentinel, row0, 0)], 1u);
   }
+  if (fp != 0) return;
   __syncthreads();
   // histogram layout: segment, then digit, then tile of the segment -- one flat exclusive scan then yields, for every
   // (digit, tile), the global position of its first pair
@@ -244,15 +259,17 @@ __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack 
 // ---- radix sort: per-tile digit histogram ----------------------------------------
 template <int RB>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const unsigned* __restrict__ keys, const SegPack S,
-                                                                  const unsigned sentinel, const int shift,
+                                                                  const unsigned sentinel, const int pass,
                                                                   unsigned* __restrict__ hist) {
   constexpr int R = 1 << RB;
   __shared__ unsigned cnt[R];
-  for (int d = threadIdx.x; d < R; d += kSortThreads) cnt[d] = 0;
-  __syncthreads();
   int seg;
   unsigned tile0, tile_n;
   seg_of_tile(S, blockIdx.x, &seg, &tile0, &tile_n);
+  if (pass < S.first_pass[seg]) return;               // the segment joins the sort in a later pass
+  const int shift = (pass - S.first_pass[seg]) * RB;
+  for (int d = threadIdx.x; d < R; d += kSortThreads) cnt[d] = 0;
+  __syncthreads();
   const unsigned row0 = S.row0[seg];
   // (loading the 8 keys of a thread before the first LDS atomic was measured slower: 11.3 vs 9.1 us)
 #pragma unroll
@@ -340,7 +357,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
                                                                      const unsigned* __restrict__ vals_in,
                                                                      unsigned* __restrict__ keys_out,
                                                                      unsigned* __restrict__ vals_out, const SegPack S,
-                                                                     const unsigned sentinel, const int shift,
+                                                                     const unsigned sentinel, const int pass,
                                                                      const unsigned* __restrict__ hist,
                                                                      const unsigned* __restrict__ slice_sum,
                                                                      const unsigned n_slices, const bool raw_sums) {
@@ -358,9 +375,16 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
   int seg;
   unsigned tile0, tile_n;
   seg_of_tile(S, blockIdx.x, &seg, &tile0, &tile_n);
+  if (pass < S.first_pass[seg]) return;               // the segment joins the sort in a later pass
+  const int shift = (pass - S.first_pass[seg]) * RB;
   const unsigned row0 = S.row0[seg];
   const unsigned t_in = blockIdx.x - S.tile0[seg], nt = S.tile0[seg + 1] - S.tile0[seg];
-  const size_t hbase = static_cast<size_t>(S.tile0[seg]) * R + t_in;
+  // Positions are taken RELATIVE to the segment's first histogram entry: the flat scan runs over every segment's
+  // entries, and those of a segment that is not in this pass are stale -- differences inside one segment do not see
+  // them (unsigned wrap-around included).
+  const size_t hfirst = static_cast<size_t>(S.tile0[seg]) * R;
+  const size_t hbase = hfirst + t_in;
+  const unsigned seg_lk0 = S.lk0[seg];
   for (int i = threadIdx.x; i < kWaves * R; i += kSortThreads) (&wcnt[0][0])[i] = 0;
   if (raw_sums) {
     // slice_sum holds the slice TOTALS as radix_scan_local_kernel left them (at most kMaxFusedSlices of them): every
@@ -389,14 +413,16 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
       run += t[q];
     }
     __syncthreads();
+    const unsigned first = hist[hfirst] + spre[hfirst / kScanSlice];
     for (int d = threadIdx.x; d < R; d += kSortThreads) {
       const size_t hi = hbase + static_cast<size_t>(d) * nt;
-      gbase[d] = hist[hi] + spre[hi / kScanSlice];
+      gbase[d] = seg_lk0 + (hist[hi] + spre[hi / kScanSlice] - first);
     }
   } else {
+    const unsigned first = hist[hfirst] + slice_sum[hfirst / kScanSlice];
     for (int d = threadIdx.x; d < R; d += kSortThreads) {
       const size_t hi = hbase + static_cast<size_t>(d) * nt;
-      gbase[d] = hist[hi] + slice_sum[hi / kScanSlice];
+      gbase[d] = seg_lk0 + (hist[hi] + slice_sum[hi / kScanSlice] - first);
     }
   }
   __syncthreads();
@@ -606,22 +632,21 @@ static int run_sort_rb(const BwdPlan& p, char* ws, int* d_status, hipStream_t s)
   unsigned* hist = reinterpret_cast<unsigned*>(ws + p.off_hist);
   unsigned* ssum = reinterpret_cast<unsigned*>(ws + p.off_ssum);
   hipLaunchKernelGGL(build_keys_kernel<RB>, dim3(p.n_tiles), dim3(kSortThreads), 0, s, p.keys, p.n_cat, p.segs, p.total_rows,
-                     keys[0], vals[0], d_status, reinterpret_cast<unsigned*>(ws + p.off_fin), hist);
+                     keys[0], vals[0], keys[1], vals[1], d_status, reinterpret_cast<unsigned*>(ws + p.off_fin), hist);
   int rc = check_launch("build_keys_kernel");
   if (rc != RBX_OK) return rc;
   int cur = 0;
   for (int pass = 0; pass < p.passes; ++pass) {
-    const int shift = pass * RB;
-    if (pass > 0)        // (the first digit's histograms come out of build_keys_kernel)
+    if (pass > 0)        // (pass 0's histograms come out of build_keys_kernel)
       hipLaunchKernelGGL(radix_hist_kernel<RB>, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], p.segs, p.total_rows,
-                         shift, hist);
+                         pass, hist);
     const unsigned hist_len = p.n_tiles * R;
     const unsigned n_slices = (hist_len + kScanSlice - 1) / kScanSlice;
     hipLaunchKernelGGL(radix_scan_local_kernel, dim3(n_slices), dim3(1024), 0, s, hist, hist_len, ssum);
     const bool raw_sums = n_slices <= static_cast<unsigned>(kMaxFusedSlices);
     if (!raw_sums) hipLaunchKernelGGL(radix_scan_sums_kernel, dim3(1), dim3(1024), 0, s, ssum, n_slices);
     hipLaunchKernelGGL(radix_scatter_kernel<RB>, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], vals[cur],
-                       keys[cur ^ 1], vals[cur ^ 1], p.segs, p.total_rows, shift, hist, ssum, n_slices, raw_sums);
+                       keys[cur ^ 1], vals[cur ^ 1], p.segs, p.total_rows, pass, hist, ssum, n_slices, raw_sums);
     rc = check_launch("radix pass");
     if (rc != RBX_OK) return rc;
     cur ^= 1;

@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
                                                            const float* __restrict__ xe, const int n_extra,
                                                            const int x_stride, const int x_lr_off,
                                                            const int* __restrict__ xidx, const long long x_rows,
-                                                           float* __restrict__ logit, float* __restrict__ ssum,
-                                                           int* __restrict__ status) {
+                                                           float* __restrict__ logit, float* __restrict__ prob,
+                                                           float* __restrict__ ssum, int* __restrict__ status) {
   constexpr int W = VEC ? 4 : 1;
   constexpr int NA = NV * W;
   // features in flight per lane.  8 is the measured optimum at D=16 on MI355X: 16 in flight ran 1.6x
@@ -183,7 +183,11 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
 #pragma unroll
     for (int i = 0; i < NA; ++i) fm += (s[i] * s[i] - q[i]) * 0.5f;
     float total = group_sum<G>(fm + lr);
-    if (lane_g == 0) logit[b] = total + (bias != nullptr ? bias[0] : 0.f);
+    if (lane_g == 0) {
+      const float z = total + (bias != nullptr ? bias[0] : 0.f);
+      logit[b] = z;
+      if (prob != nullptr) prob[b] = 1.f / (1.f + expf(-z));      // the model's y_pred = sigmoid(logit), same pass
+    }
     if (has_emb && ssum != nullptr) {
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
@@ -248,10 +252,16 @@ struct FmNumField {          // 48 B
 };
 struct FmNumPack { FmNumField f[RBX_MAX_FIELDS]; };
 
-static int fm_num_samples(int D) { return D <= 128 ? 64 : 32; }   // samples staged per workgroup
+// samples staged per workgroup: as many as fit 48 KB of LDS, at most 128 (D = 16 with 13 numeric features: 128 samples,
+// 22 KB, 512 workgroups at B = 65 536; the 256 threads split a sample's features between them), at least 32
+static int fm_num_samples(int D, int n_num) {
+  int ns = 128;
+  while (ns > 32 && static_cast<size_t>(ns) * (D + 2 * n_num + 1) * sizeof(float) > 48 * 1024) ns >>= 1;
+  return ns;
+}
 
-// partial layout per (block, feature): [D] sum g x S_d | [1] sum g x^2 | [1] sum g x   -> D+2 floats;
-// feature index n_num holds sum g in slot 0 (bias).
+// partial layout: output o = feature * (D+2) + slot, slots = [D] sum g x S_d | [1] sum g x^2 | [1] sum g x; feature index
+// n_num holds sum g in slot 0 (bias).  Stored [output][block], so that the final kernel's lanes read neighbouring floats.
 // A workgroup stages `ns` samples (S rows, g*x and x per numeric feature, g) in LDS, then
 // every thread owns one output and sums over the samples in a fixed order: this is a
 // [n_num, ns] x [ns, D] product per workgroup, deterministic and sync-free after staging.
@@ -261,43 +271,63 @@ __global__ __launch_bounds__(256) void fm_numeric_partial_kernel(const FmNumPack
                                                                  const float* __restrict__ ssum,
                                                                  float* __restrict__ partial) {
   extern __shared__ float lds[];
+  const int nsp = ns + 1;                   // row pitch of the per-feature arrays (staging writes walk the features)
   float* sS = lds;                          // [ns][D]
-  float* sgx = sS + ns * D;                 // [n_num][ns]
-  float* sx = sgx + n_num * ns;             // [n_num][ns]
-  float* sg = sx + n_num * ns;              // [ns]
+  float* sgx = sS + ns * D;                 // [n_num][ns + 1]
+  float* sx = sgx + n_num * nsp;            // [n_num][ns + 1]
+  float* sg = sx + n_num * nsp;             // [ns]
   const long long b0 = static_cast<long long>(blockIdx.x) * ns;
   const int live = static_cast<int>((B - b0 < ns) ? (B - b0) : ns);
   if (ssum != nullptr) {
     for (int i = threadIdx.x; i < ns * D; i += blockDim.x) sS[i] = (i < live * D) ? ssum[b0 * D + i] : 0.f;
   }
-  for (int i = threadIdx.x; i < ns; i += blockDim.x) {
-    const float gb = (i < live) ? g[b0 + i] : 0.f;
-    sg[i] = gb;
-    for (int f = 0; f < n_num; ++f) {
-      const FmNumField& fd = P.f[f];
-      const float x = (i < live) ? load_value(fd.ids, (b0 + i) * fd.stride_b, fd.dtype) : 0.f;
-      sx[f * ns + i] = x;
-      sgx[f * ns + i] = gb * x;
+  // (sample, feature) pairs dealt to the threads with the FEATURE fastest: the numeric columns of the reference's batch
+  // tensor sit next to each other in a sample's row, so a wavefront's 64 values come from ~5 rows (a dozen cache lines)
+  // instead of 64 rows
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) sg[i] = (i < live) ? g[b0 + i] : 0.f;
+  for (int idx = threadIdx.x; idx < ns * n_num; idx += blockDim.x) {
+    const int i = idx / n_num, f = idx - i * n_num;
+    const FmNumField& fd = P.f[f];
+    float x = 0.f, gb = 0.f;
+    if (i < live) {
+      x = load_value(fd.ids, (b0 + i) * fd.stride_b, fd.dtype);
+      gb = g[b0 + i];
     }
+    sx[f * nsp + i] = x;
+    sgx[f * nsp + i] = gb * x;
   }
   __syncthreads();
   const int stride = D + 2;
   const int n_out = n_num * stride + 1;
-  float* out = partial + static_cast<size_t>(blockIdx.x) * (n_num + 1) * stride;
+  float* out = partial + blockIdx.x;
+  const size_t nb = gridDim.x;
   for (int o = threadIdx.x; o < n_out; o += blockDim.x) {
     const int f = o / stride, slot = o - f * stride;
-    float t = 0.f;
+    // four interleaved partial sums (samples i, i+1, i+2, i+3 of every group of four), combined in a fixed order: the
+    // dependent add chain is a quarter as long and the LDS reads of four samples are in flight together
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     if (f == n_num) {
-      for (int i = 0; i < ns; ++i) t += sg[i];
+      for (int i = 0; i < ns; i += 4) { t0 += sg[i]; t1 += sg[i + 1]; t2 += sg[i + 2]; t3 += sg[i + 3]; }
     } else if (slot < D) {
-      if (ssum != nullptr)
-        for (int i = 0; i < ns; ++i) t += sgx[f * ns + i] * sS[i * D + slot];
+      if (ssum != nullptr) {
+        const float* a = sgx + f * nsp;
+        const float* c = sS + slot;
+        for (int i = 0; i < ns; i += 4) {
+          t0 += a[i] * c[i * D];
+          t1 += a[i + 1] * c[(i + 1) * D];
+          t2 += a[i + 2] * c[(i + 2) * D];
+          t3 += a[i + 3] * c[(i + 3) * D];
+        }
+      }
     } else if (slot == D) {
-      for (int i = 0; i < ns; ++i) t += sgx[f * ns + i] * sx[f * ns + i];
+      const float* a = sgx + f * nsp;
+      const float* c = sx + f * nsp;
+      for (int i = 0; i < ns; i += 4) { t0 += a[i] * c[i]; t1 += a[i + 1] * c[i + 1]; t2 += a[i + 2] * c[i + 2]; t3 += a[i + 3] * c[i + 3]; }
     } else {
-      for (int i = 0; i < ns; ++i) t += sgx[f * ns + i];
+      const float* a = sgx + f * nsp;
+      for (int i = 0; i < ns; i += 4) { t0 += a[i]; t1 += a[i + 1]; t2 += a[i + 2]; t3 += a[i + 3]; }
     }
-    out[o] = t;
+    out[static_cast<size_t>(o) * nb] = (t0 + t1) + (t2 + t3);
   }
 }
 
@@ -307,31 +337,34 @@ __global__ __launch_bounds__(256) void fm_numeric_partial_kernel(const FmNumPack
 __global__ __launch_bounds__(64) void fm_numeric_final_kernel(const FmNumPack P, const int n_num, const int D,
                                                               const unsigned num_blocks,
                                                               const float* __restrict__ partial,
-                                                              float* __restrict__ dbias) {
+                                                              float* __restrict__ dbias, const bool store) {
   const int f = blockIdx.x, slot = blockIdx.y;
   const int stride = D + 2;
   auto total = [&](int sl) -> float {
     float t = 0.f;
-    for (unsigned k = threadIdx.x; k < num_blocks; k += 64)
-      t += partial[(static_cast<size_t>(k) * (n_num + 1) + f) * stride + sl];
+    const float* src = partial + static_cast<size_t>(f * stride + sl) * num_blocks;
+    for (unsigned k = threadIdx.x; k < num_blocks; k += 64) t += src[k];
     return group_sum<64>(t);
   };
   if (f == n_num) {
     if (slot != 0) return;
     const float tg = total(0);
-    if (dbias != nullptr && threadIdx.x == 0) dbias[0] += tg;
+    if (dbias != nullptr && threadIdx.x == 0) dbias[0] = store ? tg : dbias[0] + tg;
     return;
   }
   const FmNumField& fd = P.f[f];
   if (slot == D) return;                          // sum g x^2 is only a correction term (read below)
   if (slot == D + 1) {
     const float t1 = total(D + 1);
-    if (fd.glr != nullptr && threadIdx.x == 0) fd.glr[0] += t1;
+    if (fd.glr != nullptr && threadIdx.x == 0) fd.glr[0] = store ? t1 : fd.glr[0] + t1;
     return;
   }
   if (fd.gw == nullptr) return;
   const float a = total(slot), t2 = total(D);
-  if (threadIdx.x == 0) fd.gw[slot] += a - fd.w[slot] * t2;
+  if (threadIdx.x == 0) {
+    const float v = a - fd.w[slot] * t2;
+    fd.gw[slot] = store ? v : fd.gw[slot] + v;
+  }
 }
 
 // d row(b,t) = [ g_b (S_b - e[b,t,:]) | ... g_b at the LR slot ... | 0 ]  in the rows' own packed layout
@@ -428,30 +461,30 @@ static int fm_validate(const rbx_field_t* emb, const rbx_field_t* lr, int n, int
 
 template <int G, int NV, bool VEC>
 static int launch_fm_fwd(const FmHost& h, int64_t B, const float* bias, const float* xe, int n_extra, int x_stride,
-                         int x_lr_off, const int* xidx, long long x_rows, float* logit, float* ssum, int* status,
-                         hipStream_t s) {
+                         int x_lr_off, const int* xidx, long long x_rows, float* logit, float* prob, float* ssum,
+                         int* status, hipStream_t s) {
   const int gpb = 256 / G;
   long long blocks = (B + gpb - 1) / gpb;
   if (blocks > kCUs * 16) blocks = kCUs * 16;
   hipLaunchKernelGGL((fm_fused_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, h.pack,
                      h.F, static_cast<long long>(B), h.D, h.has_emb, h.has_lr, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows,
-                     logit, ssum, status);
+                     logit, prob, ssum, status);
   return check_launch("fm_fused_fwd_kernel");
 }
 
 template <bool VEC>
 static int dispatch_fm_fwd(const FmHost& h, int64_t B, const float* bias, const float* xe, int n_extra, int x_stride,
-                           int x_lr_off, const int* xidx, long long x_rows, float* logit, float* ssum, int* status,
-                         hipStream_t s) {
+                           int x_lr_off, const int* xidx, long long x_rows, float* logit, float* prob, float* ssum,
+                           int* status, hipStream_t s) {
   const int units = VEC ? h.D / 4 : h.D;
   switch (pow2_ceil(units)) {
-    case 1: return launch_fm_fwd<1, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
-    case 2: return launch_fm_fwd<2, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
-    case 4: return launch_fm_fwd<4, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
-    case 8: return launch_fm_fwd<8, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
-    case 16: return launch_fm_fwd<16, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
-    case 32: return launch_fm_fwd<32, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
-    case 64: return launch_fm_fwd<64, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, ssum, status, s);
+    case 1: return launch_fm_fwd<1, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, prob, ssum, status, s);
+    case 2: return launch_fm_fwd<2, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, prob, ssum, status, s);
+    case 4: return launch_fm_fwd<4, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, prob, ssum, status, s);
+    case 8: return launch_fm_fwd<8, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, prob, ssum, status, s);
+    case 16: return launch_fm_fwd<16, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, prob, ssum, status, s);
+    case 32: return launch_fm_fwd<32, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, prob, ssum, status, s);
+    case 64: return launch_fm_fwd<64, 1, VEC>(h, B, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows, logit, prob, ssum, status, s);
     default: return fail(RBX_ERR_UNSUPPORTED, "fm: embedding dim %d too large to fuse", h.D);
   }
 }
@@ -491,7 +524,7 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
     p->n_lookups = 0;
     p->bytes = 256;
     const int D0 = emb ? emb[0].dim : 1;
-    p->num_blocks = static_cast<unsigned>((B + fm_num_samples(D0) - 1) / fm_num_samples(D0));
+    p->num_blocks = static_cast<unsigned>((B + fm_num_samples(D0, *n_num) - 1) / fm_num_samples(D0, *n_num));
     return RBX_OK;
   }
   const int D = emb ? emb[0].dim : 1;
@@ -512,7 +545,7 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
     if (rf.table != nullptr && (reinterpret_cast<uintptr_t>(rf.table) & 15) != 0) p->vec = false;
   }
   p->max_dim = D;
-  p->num_blocks = static_cast<unsigned>((B + fm_num_samples(D) - 1) / fm_num_samples(D));
+  p->num_blocks = static_cast<unsigned>((B + fm_num_samples(D, *n_num) - 1) / fm_num_samples(D, *n_num));
   return RBX_OK;
 }
 
@@ -543,7 +576,7 @@ namespace rbx {
 extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                           const float* d_lr_bias, const float* d_extra, int32_t n_extra, int32_t extra_stride,
                           int32_t extra_lr_off, const int32_t* d_extra_index, int64_t extra_rows, float* d_logit,
-                          float* d_sum, int32_t* d_status, void* stream) {
+                          float* d_prob, float* d_sum, int32_t* d_status, void* stream) {
   using namespace rbx;
   FmHost h;
   int rc = fm_validate(emb, lr, n_fields, batch, &h);
@@ -562,9 +595,9 @@ extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
     if (h.vec && (extra_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(d_extra) & 15) != 0)) h.vec = false;
   }
   return h.vec ? dispatch_fm_fwd<true>(h, batch, d_lr_bias, d_extra, n_extra, extra_stride, extra_lr_off, d_extra_index,
-                                       extra_rows, d_logit, d_sum, d_status, as_stream(stream))
+                                       extra_rows, d_logit, d_prob, d_sum, d_status, as_stream(stream))
                : dispatch_fm_fwd<false>(h, batch, d_lr_bias, d_extra, n_extra, extra_stride, extra_lr_off, d_extra_index,
-                                        extra_rows, d_logit, d_sum, d_status, as_stream(stream));
+                                        extra_rows, d_logit, d_prob, d_sum, d_status, as_stream(stream));
 }
 
 extern "C" size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields,
@@ -690,12 +723,12 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
   }
   if ((phases & 2) && (n_num > 0 || d_dbias != nullptr)) {
     float* partial = reinterpret_cast<float*>(ws + p.bytes);
-    const int ns = fm_num_samples(D);
-    const size_t lds = static_cast<size_t>(ns) * (D + 2 * n_num + 1) * sizeof(float);
+    const int ns = fm_num_samples(D, n_num);
+    const size_t lds = (static_cast<size_t>(ns) * (D + 1) + 2 * static_cast<size_t>(n_num) * (ns + 1)) * sizeof(float);
     hipLaunchKernelGGL(fm_numeric_partial_kernel, dim3(p.num_blocks), dim3(256), lds, s, np, n_num,
                        static_cast<long long>(batch), D, ns, d_dlogit, emb ? d_sum : nullptr, partial);
     hipLaunchKernelGGL(fm_numeric_final_kernel, dim3(n_num + 1, D + 2), dim3(64), 0, s, np, n_num, D, p.num_blocks,
-                       partial, d_dbias);
+                       partial, d_dbias, (phases & 4) != 0);
     rc = check_launch("fm numeric kernels");
     if (rc != RBX_OK) return rc;
   }

@@ -29,8 +29,12 @@ __device__ __forceinline__ void frag_add(F& a, const F& b) {
 constexpr int kFinList = 3;      // fin[0] work-list length, fin[1] long-list length, fin[2] arrival counter, then the lists
 // Interior runs are written directly; a run that crosses the chunk border leaves a head /
 // tail summary and a flag, and the chunk where such a run ENDS is queued for the fix-up.
+// waves per SIMD the register budget is sized for: at 4 (128 VGPRs) the FM policy spilled 28 bytes per lane to scratch
+#ifndef RBX_REDUCE_WAVES
+#define RBX_REDUCE_WAVES 3
+#endif
 template <class Policy, int G, int NV, bool VEC>
-__global__ __launch_bounds__(256, 4) void segment_reduce_kernel(const RedPack P, const int n_cat,
+__global__ __launch_bounds__(256, RBX_REDUCE_WAVES) void segment_reduce_kernel(const RedPack P, const int n_cat,
                                                              const typename Policy::Args args,
                                                              const unsigned* __restrict__ keys,
                                                              const unsigned* __restrict__ vals, const unsigned n,
@@ -63,7 +67,10 @@ __global__ __launch_bounds__(256, 4) void segment_reduce_kernel(const RedPack P,
   pre_last.zero();
   float cnt = 0.f;
   bool head_done = false;
-  constexpr int U = (NV * F::W <= 4) ? 8 : 4;      // lookups in flight per lane group (16 measured slower)
+#ifndef RBX_REDUCE_U
+#define RBX_REDUCE_U 8
+#endif
+  constexpr int U = (NV * F::W <= 4) ? RBX_REDUCE_U : 4;      // lookups in flight per lane group (16 measured slower)
   for (unsigned i0 = s; i0 < e; i0 += U) {
     unsigned kk[U + 1], vv[U];
     {

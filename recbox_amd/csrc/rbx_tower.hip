@@ -502,7 +502,76 @@ __global__ __launch_bounds__(256) void sigmoid_bce_kernel(const float* __restric
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+
+// The same pass with the final sum folded in: the workgroup that arrives LAST (device-scope counter) adds the block partials
+// in the fixed order bce_final_kernel uses -- the result does not depend on which workgroup that is -- and leaves the counter
+// at zero for the next call.  One launch instead of two in a chain of 5 us kernels.
+__global__ __launch_bounds__(256) void sigmoid_bce_onepass_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                  const long long n, const float gscale, const float inv_n,
+                                                                  float* __restrict__ prob, float* __restrict__ dx,
+                                                                  float* __restrict__ partial, unsigned* __restrict__ counter,
+                                                                  float* __restrict__ loss) {
+  __shared__ float red[4];
+  __shared__ bool last;
+  const long long base = static_cast<long long>(blockIdx.x) * kBceBlock;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < kBceBlock / 256; ++k) {
+    const long long i = base + k * 256 + threadIdx.x;
+    if (i < n) {
+      const float pi = 1.f / (1.f + expf(-x[i])), yi = y[i];
+      const float lp = fmaxf(logf(pi), -100.f), lq = fmaxf(log1pf(-pi), -100.f);
+      acc -= yi * lp + (1.f - yi) * lq;
+      if (prob != nullptr) prob[i] = pi;
+      if (dx != nullptr) {
+        const float dp = gscale * (pi - yi) / fmaxf((1.f - pi) * pi, 1e-12f);
+        dx[i] = dp * (1.f - pi) * pi;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(partial + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = (atomicAdd(counter, 1u) == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (int i = threadIdx.x; i < static_cast<int>(gridDim.x); i += 256)
+    t += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+    counter[0] = 0;
+  }
+}
+
 }  // namespace rbx
+
+extern "C" int rbx_sigmoid_bce_mean_onepass(const float* d_logit, const float* d_target, int64_t n, float grad_scale,
+                                            float* d_prob, float* d_loss, float* d_dlogit, void* d_workspace,
+                                            size_t workspace_bytes, uint32_t* d_counter, void* stream) {
+  using namespace rbx;
+  if (n <= 0) return fail(RBX_ERR_INVALID, "sigmoid_bce: empty input (the mean of no elements is undefined)");
+  if (!d_logit || !d_target || !d_loss || !d_counter) return fail(RBX_ERR_INVALID, "sigmoid_bce: NULL tensor");
+  if (d_workspace == nullptr || workspace_bytes < rbx_bce_workspace_size(n))
+    return fail(RBX_ERR_WORKSPACE, "sigmoid_bce: workspace too small");
+  const long long nb = (n + kBceBlock - 1) / kBceBlock;
+  if (nb >= INT_MAX) return fail(RBX_ERR_UNSUPPORTED, "sigmoid_bce: too many elements");
+  const float inv_n = 1.0f / static_cast<float>(n);
+  hipLaunchKernelGGL(sigmoid_bce_onepass_kernel, dim3(static_cast<unsigned>(nb)), dim3(256), 0, as_stream(stream), d_logit,
+                     d_target, static_cast<long long>(n), grad_scale * inv_n, inv_n, d_prob, d_dlogit,
+                     static_cast<float*>(d_workspace), d_counter, d_loss);
+  return check_launch("sigmoid_bce_onepass_kernel");
+}
 
 extern "C" int rbx_sigmoid_bce_mean(const float* d_logit, const float* d_target, int64_t n, float grad_scale, float* d_prob,
                                     float* d_loss, float* d_dlogit, void* d_workspace, size_t workspace_bytes,
@@ -520,6 +589,26 @@ extern "C" int rbx_sigmoid_bce_mean(const float* d_logit, const float* d_target,
                      static_cast<long long>(n), grad_scale * inv_n, d_prob, d_dlogit, partial);
   hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, static_cast<int>(nb), inv_n, d_loss);
   return check_launch("sigmoid_bce kernels");
+}
+
+namespace rbx {
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ scalar,
+                                                              const long long n, float* __restrict__ y) {
+  const float g = scalar[0];
+  const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += step) y[i] = g * x[i];
+}
+}  // namespace rbx
+
+extern "C" int rbx_scale_by_scalar(const float* d_x, const float* d_scalar, int64_t n, float* d_y, void* stream) {
+  using namespace rbx;
+  if (n <= 0) return RBX_OK;
+  if (!d_x || !d_scalar || !d_y) return fail(RBX_ERR_INVALID, "scale_by_scalar: NULL tensor");
+  long long blocks = (n + 255) / 256;
+  if (blocks > kCUs * 8) blocks = kCUs * 8;
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_x,
+                     d_scalar, static_cast<long long>(n), d_y);
+  return check_launch("scale_by_scalar_kernel");
 }
 
 extern "C" size_t rbx_bce_workspace_size(int64_t n) {

@@ -25,7 +25,14 @@ class GraphedStep(object):
                                     # (optimizer step) before the next replay
     """
 
-    def __init__(self, fn, warmup=3, capture_error_mode="global", reuse_grads=True, check_every=0):
+    def __init__(self, fn, warmup=3, capture_error_mode="global", reuse_grads=True, check_every=0, params=None,
+                 pool=None):
+        # params: parameters whose ``.grad`` this step produces.  Several GraphedSteps over ONE model (one graph per
+        # resident input buffer, replayed in rotation) each own the gradient tensors of their capture: with ``params``
+        # a call re-points every ``p.grad`` at the tensors THIS graph wrote (the table gradients of the persistent
+        # buffer are the same memory in every graph; the small dense ones are not).
+        # pool: a ``torch.cuda.graph_pool_handle()`` / another graph's ``.pool()`` to share intermediate memory with
+        # (graphs that are never replayed concurrently).
         # check_every: every that many replays, read the deferred id-range status word (one host sync) and raise
         # IndexError if a replay met an id outside its table (0 = never: call ops.check_deferred_ids() yourself)
         self.check_every, self.replays = int(check_every), 0
@@ -49,15 +56,22 @@ class GraphedStep(object):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
+            with torch.cuda.graph(self.graph, pool=pool, capture_error_mode=capture_error_mode):
                 self.out = fn()
         finally:
             ops.config.reuse_grad_buffers = old
+        self.grads = [(p, p.grad) for p in params] if params is not None else None
+
+    def pool(self):
+        return self.graph.pool()
 
     def __call__(self):
         if ops._dropout_ticks:
             ops.bump_dropout_tick()          # a replay re-runs the captured seeds: the device tick makes the masks new
         self.graph.replay()
+        if self.grads is not None:
+            for p, g in self.grads:
+                p.grad = g
         self.replays += 1
         if self.check_every and self.replays % self.check_every == 0:
             ops.check_deferred_ids()

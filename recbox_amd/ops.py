@@ -55,6 +55,9 @@ class config(object):
     # (0.336 vs 0.297 ms): with the extra fork / join the hipGraph runtime serialised the forward kernel behind the whole
     # sort chain (profiles/r02/fm_replay_timeline_numeric_beside.txt).  Off.
     numeric_beside_reduce = os.environ.get("RECBOX_AMD_NUMERIC_BESIDE", "0") != "0"
+    # binary_cross_entropy of a sigmoid_output(): one pass over the logits (+ final sum) and one scale kernel in the backward
+    # instead of sigmoid / BCE partial / final / BCE backward / sigmoid backward -- 8 launches of ~5 us in a row
+    fuse_sigmoid_bce = os.environ.get("RECBOX_AMD_FUSE_SIGMOID_BCE", "1") != "0"
     reuse_grad_buffers = {"0": False, "": False, "all": "all"}.get(os.environ.get("RECBOX_AMD_REUSE_GRADS", "0"), True)
 
 
@@ -553,11 +556,12 @@ def _layout(params, sizes):
     return offs, o
 
 
-def _flat_zero_grads(params, want, device):
-    """One zero-filled buffer (single memset) carved into per-parameter dense grads."""
+def _flat_zero_grads(params, want, device, zero=True):
+    """One zero-filled buffer (single memset) carved into per-parameter dense grads.  zero=False: uninitialised memory, for
+    gradients that the backward STORES in full (the numeric-feature weights of the fused FM body)."""
     sizes = [p.numel() if w else 0 for p, w in zip(params, want)]
     offs, total = _layout(params, sizes)
-    flat = torch.zeros(total, dtype=torch.float32, device=device)
+    flat = (torch.zeros if zero else torch.empty)(total, dtype=torch.float32, device=device)
     return _carve(flat, params, sizes, offs)
 
 
@@ -605,11 +609,12 @@ class _GradPool(object):
             self.bound = self.views(params)
         return self.bound
 
-    def views(self, params):
+    def views(self, params, zero_loose=True):
         if self.flat is None:
             self.flat = torch.zeros(self.total, dtype=torch.float32, device=self.device)     # the only full fill
         loose = [p for p, n in zip(params, self.sizes) if n == 0]
-        small = iter(_flat_zero_grads(loose, [p.requires_grad for p in loose], self.device))    # one fill for all of them
+        # one fill for all of them -- or none, when the backward stores them in full (rbx_fm_bwd phases bit 2)
+        small = iter(_flat_zero_grads(loose, [p.requires_grad for p in loose], self.device, zero=zero_loose))
         return [v if v is not None else next(small) for v in _carve(self.flat, params, self.sizes, self.offs)]
 
     @staticmethod
@@ -648,7 +653,7 @@ class _GradPool(object):
         self.pending = True
         ctx.pool, ctx.ticket = self, self.ticket
 
-    def backward_grads(self, ctx, params, want, usable):
+    def backward_grads(self, ctx, params, want, usable, zero_loose=True):
         """(pool or None, gradient tensors) for a backward: the persistent views when this backward still owns the
         sorted ids in ``self.ws`` and every parameter starts from ``grad is None``."""
         if not (usable and ctx.ticket == self.ticket):
@@ -658,7 +663,7 @@ class _GradPool(object):
             if w and p.grad is not None:
                 raise RuntimeError("recbox_amd: config.reuse_grad_buffers needs p.grad to be None at every backward "
                                    "(zero_grad(set_to_none=True)); the gradients alias one persistent buffer")
-        return self, self.views(list(params))
+        return self, self.views(list(params), zero_loose=zero_loose)
 
     def done(self, B):
         self.dirty_batch = B                     # the rows named by the sorted ids in self.ws now hold this step's sums
@@ -680,7 +685,7 @@ class _FmFused(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, emb_plan, lr_plan, n_inputs, n_emb, n_lr, train, has_bias, has_extra, extra_index, presorted,
-                *tensors):
+                with_prob, *tensors):
         inputs = tensors[:n_inputs]
         emb_params = tensors[n_inputs:n_inputs + n_emb]
         lr_params = tensors[n_inputs + n_emb:n_inputs + n_emb + n_lr]
@@ -711,6 +716,7 @@ class _FmFused(torch.autograd.Function):
                     raise ValueError("fm_fused: extra_index must be a contiguous int32 [B, T] over extra [rows, stride]")
                 n_extra, x_stride, x_lr, x_rows = extra_index.shape[1], extra.shape[1], has_extra - 1, extra.shape[0]
         logit = torch.empty((B, 1), dtype=torch.float32, device=dev)
+        prob = torch.empty((B, 1), dtype=torch.float32, device=dev) if with_prob else None    # sigmoid(logit), same pass
         ssum = torch.empty((B, D), dtype=torch.float32, device=dev) if (train and emb_plan is not None) else None
         status = _status_word(dev)
         ea = emb_plan.arr if emb_plan is not None else None
@@ -757,8 +763,8 @@ class _FmFused(torch.autograd.Function):
             start_sort()
         check(_timed(("fm_fwd", lead.n, D, B),
                      lambda: lib.rbx_fm_fwd(ea, la, lead.n, B, _ptr(bias), _ptr(extra), n_extra, x_stride, x_lr,
-                                            _ptr(extra_index), x_rows, _ptr(logit), _ptr(ssum), _ptr(status),
-                                            _stream())))
+                                            _ptr(extra_index), x_rows, _ptr(logit), _ptr(prob), _ptr(ssum),
+                                            _ptr(status), _stream())))
         _check_status(status)
         ctx.state = (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias, has_extra,
                      extra_index)
@@ -768,7 +774,10 @@ class _FmFused(torch.autograd.Function):
             ctx.sort = presorted                  # fm_presort ran ahead of this forward; the caller orders the streams
         elif own_sort and not config.sort_before_forward:
             start_sort()
-        return logit
+        if prob is not None:
+            ctx.mark_non_differentiable(prob)
+            ctx.set_materialize_grads(False)      # (or autograd zero-fills a [B, 1] "gradient" of prob at every backward)
+        return logit, prob
 
     @staticmethod
     def _pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev):
@@ -796,11 +805,13 @@ class _FmFused(torch.autograd.Function):
         return rc
 
     @staticmethod
-    def backward(ctx, dlogit):
+    def backward(ctx, dlogit, _dprob=None):
         (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias,
          has_extra, extra_index) = ctx.state
         n_emb, n_lr = len(emb_params), len(lr_params)
-        base = 10 + n_inputs
+        if dlogit is None:                        # only y_pred's own (cut) branch was used
+            dlogit = torch.zeros((B, 1), dtype=torch.float32, device=ssum.device if ssum is not None else keep[0].device)
+        base = 11 + n_inputs
         want_e = [ctx.needs_input_grad[base + i] for i in range(n_emb)]
         want_l = [ctx.needs_input_grad[base + n_emb + i] for i in range(n_lr)]
         pos = base + n_emb + n_lr
@@ -813,11 +824,15 @@ class _FmFused(torch.autograd.Function):
         same = [p.requires_grad for p in emb_params] == want_e and [p.requires_grad for p in lr_params] == want_l
         pool, grads = None, None
         if getattr(ctx, "pool", None) is not None:
-            pool, grads = ctx.pool.backward_grads(ctx, list(emb_params) + list(lr_params), want_e + want_l, same and B > 0)
+            pool, grads = ctx.pool.backward_grads(ctx, list(emb_params) + list(lr_params), want_e + want_l, same and B > 0,
+                                                  zero_loose=False)
         if pool is None:
             grads = _flat_zero_grads(list(emb_params) + list(lr_params), want_e + want_l, dev)
         ge, gl = grads[:n_emb], grads[n_emb:]
-        gb = torch.zeros(1, dtype=torch.float32, device=dev) if want_b else None
+        # persistent gradients: the numeric-feature weights and the bias are STORED by the numeric kernels (phases bit 2),
+        # their buffers need no fill (two 4 us fill kernels in a chain of small kernels)
+        store = 4 if pool is not None else 0
+        gb = (torch.empty if store else torch.zeros)(1, dtype=torch.float32, device=dev) if want_b else None
         # indexed: only the referenced wire slots are written, the empty ones must read as zero
         dx = (torch.empty_like(extra) if extra_index is None else torch.zeros_like(extra)) if want_x else None
         head = (None,) * base
@@ -860,7 +875,7 @@ class _FmFused(torch.autograd.Function):
             cur = torch.cuda.current_stream(dev)
             side = _side_stream(dev)
             side.wait_stream(cur)
-            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2, _ptr(ws_early),
+            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws_early),
                                  ctx.sort.ws_bytes, ctypes.c_void_p(side.cuda_stream)))
             numeric_done = side.record_event()
             for t in [dlogit, ssum, gb] + [g for g in grads if g is not None]:
@@ -868,7 +883,7 @@ class _FmFused(torch.autograd.Function):
                     t.record_stream(side)
         elif ws_early is not None:
             # numeric weights + bias do not need the sorted ids: run them while the sort may still be in flight
-            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2, _ptr(ws_early),
+            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws_early),
                                  ctx.sort.ws_bytes, _stream()))
         if ctx.sort is not None and same:
             ctx.sort.join()
@@ -877,8 +892,8 @@ class _FmFused(torch.autograd.Function):
             ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
             check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, _stream()))
-        check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 if ws_early is not None else 3,
-                             _ptr(ws), ws_bytes, _stream()))
+        check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0,
+                             (1 if ws_early is not None else 3) | store, _ptr(ws), ws_bytes, _stream()))
         if numeric_done is not None:
             torch.cuda.current_stream(dev).wait_event(numeric_done)
         if pool is not None:
@@ -920,12 +935,14 @@ def fm_presort(emb_plan, lr_plan, inputs, emb_params, lr_params):
 
 
 def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=None, extra_lr_off=-1,
-             extra_index=None, presorted=None):
+             extra_index=None, presorted=None, with_prob=False):
     """FM model body: LR(X) + bias + product_sum(FeatureEmbedding(X)); either part may be absent.
     extra [B, T, stride]: packed rows of row-sharded tables already fetched from their owners (embedding in
     floats [0, D), the LR weight at float ``extra_lr_off``; -1 = no LR weight in the row).
     extra_index [B, T] int32: ``extra`` is then the exchange buffer [rows, stride] itself and row (b, t) sits at
-    wire slot extra_index[b, t] (``route``); slots >= rows are lookups that found no room: zero row, no grad."""
+    wire slot extra_index[b, t] (``route``); slots >= rows are lookups that found no room: zero row, no grad.
+    with_prob: return (logit, sigmoid(logit)) -- the second written by the same kernel, not differentiable by itself
+    (``sigmoid_output(logit, prob)`` turns it into the model's y_pred)."""
     tail = ((bias,) if bias is not None else ())
     has_extra = 0
     if extra is not None:
@@ -935,9 +952,10 @@ def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=
             raise NotImplementedError("packed extra rows without an LR slot are not wired up")
     needs = list(emb_params) + list(lr_params) + list(tail)
     train = torch.is_grad_enabled() and any(p.requires_grad for p in needs)
-    return _FmFused.apply(emb_plan, lr_plan, len(inputs), len(emb_params), len(lr_params), train,
-                          bias is not None, has_extra, extra_index, presorted if train else None, *inputs,
-                          *emb_params, *lr_params, *tail)
+    logit, prob = _FmFused.apply(emb_plan, lr_plan, len(inputs), len(emb_params), len(lr_params), train,
+                                 bias is not None, has_extra, extra_index, presorted if train else None, bool(with_prob),
+                                 *inputs, *emb_params, *lr_params, *tail)
+    return (logit, prob) if with_prob else logit
 
 
 def fm_extra_grad(logit, dlogit, extra, extra_index, extra_lr_off):
@@ -1600,11 +1618,90 @@ class _BceMean(torch.autograd.Function):
         return dp.view(ctx.shape), None
 
 
+class _SigmoidBceMean(torch.autograd.Function):
+    """mean BCE of sigmoid(logit): the loss, and dL/dlogit for an upstream gradient of 1, in ONE pass with the fixed-order
+    final sum folded in (rbx_sigmoid_bce_mean_onepass); the backward multiplies by the upstream scalar on the device."""
+    _counters = {}
+
+    @staticmethod
+    def forward(ctx, logit, target):
+        x = logit.contiguous().float().view(-1)
+        y = target.contiguous().float().view(-1)
+        n = x.numel()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        ws_bytes = lib.rbx_bce_workspace_size(n)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        # the arrival counter of the one-launch form: one per device, zero between calls (losses of one process are not
+        # computed on two streams at once)
+        key = x.device
+        counter = _SigmoidBceMean._counters.get(key)
+        if counter is None:
+            if torch.cuda.is_current_stream_capturing():
+                counter = None                   # (cannot allocate-and-zero persistent state inside a capture)
+            else:
+                counter = _SigmoidBceMean._counters[key] = torch.zeros(64, dtype=torch.int32, device=x.device)
+        if counter is not None:
+            check(lib.rbx_sigmoid_bce_mean_onepass(_ptr(x), _ptr(y), n, 1.0, None, _ptr(loss), _ptr(dx), _ptr(ws), ws_bytes,
+                                                   _ptr(counter), _stream()))
+        else:
+            check(lib.rbx_sigmoid_bce_mean(_ptr(x), _ptr(y), n, 1.0, None, _ptr(loss), _ptr(dx), _ptr(ws), ws_bytes,
+                                           _stream()))
+        ctx.save_for_backward(dx)
+        ctx.shape = logit.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        g = g.contiguous().float().view(1)
+        out = torch.empty_like(dx)
+        check(lib.rbx_scale_by_scalar(_ptr(dx), _ptr(g), dx.numel(), _ptr(out), _stream()))
+        return out.view(ctx.shape), None
+
+
+class _SigmoidOf(torch.autograd.Function):
+    """y = sigmoid(logit) whose values were already written by the kernel that produced the logit: no forward kernel;
+    the backward is sigmoid's (dL/dlogit = g (1 - y) y)."""
+
+    @staticmethod
+    def forward(ctx, logit, prob):
+        ctx.save_for_backward(prob)
+        return prob.view_as(logit)
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        p = p.view_as(g)
+        return g * (1.0 - p) * p, None
+
+
+def sigmoid_output(logit, prob=None):
+    """``torch.sigmoid(logit)`` -- a ranking model's y_pred (ranking_model.py: output_activation) -- that remembers its logit:
+    ``binary_cross_entropy`` of exactly this tensor then runs on the logit (sigmoid, both log terms, the mean and dL/dlogit in
+    one pass + a final sum, one scale kernel in the backward) instead of the chain sigmoid -> BCE -> BCE backward ->
+    sigmoid backward.  Any other use of y_pred goes through autograd's sigmoid backward as before.
+    prob: sigmoid(logit) as ``fm_fused(..., with_prob=True)`` already wrote it (no kernel here)."""
+    y = torch.sigmoid(logit) if prob is None else _SigmoidOf.apply(logit, prob)
+    if logit.is_cuda and logit.dtype == torch.float32:
+        y._rbx_logit = logit
+    return y
+
+
 def binary_cross_entropy(y_pred, y_true, reduction="mean"):
     """``F.binary_cross_entropy(y_pred, y_true, reduction='mean')`` (the ranking harness's loss on sigmoid outputs)
-    as one forward pass + a fixed-order final sum and one backward pass (rbx_bce_mean_fwd/bwd)."""
+    as one forward pass + a fixed-order final sum and one backward pass (rbx_bce_mean_fwd/bwd); on a y_pred that came
+    out of ``sigmoid_output``, the same loss computed from its logit (rbx_sigmoid_bce_mean)."""
     if reduction != "mean":
         raise NotImplementedError("binary_cross_entropy: only reduction='mean' runs on the fused kernel")
+    logit = getattr(y_pred, "_rbx_logit", None)
+    if logit is not None and logit.shape == y_pred.shape and config.fuse_sigmoid_bce:
+        _require_cuda(logit, "logit")
+        if y_pred.numel() != y_true.numel():
+            raise ValueError("Using a target size ({}) that is different to the input size ({}) is deprecated. "
+                             "Please ensure they have the same size.".format(tuple(y_true.shape), tuple(y_pred.shape)))
+        if y_pred.numel() > 0:
+            return _SigmoidBceMean.apply(logit, y_true)
     return _BceMean.apply(y_pred, y_true)
 
 

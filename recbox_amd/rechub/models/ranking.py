@@ -47,4 +47,4 @@ class DeepFM(torch.nn.Module):
         y_fm = self.fm(input_fm)
         y_deep = self.mlp(input_deep)
         y = y_linear + y_fm + y_deep
-        return torch.sigmoid(y.squeeze(1))
+        return ops.sigmoid_output(y.squeeze(1))

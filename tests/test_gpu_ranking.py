@@ -527,6 +527,38 @@ def test_graphed_step_replays_equal_eager_steps():
         ops.config.check_ids = old
 
 
+def test_one_graph_per_resident_batch_replayed_in_rotation():
+    """bench.py's rotation: K batches stay on the device, each with a captured step of its own over ONE model (shared
+    intermediate memory, one persistent gradient buffer); replayed in any order, a call leaves the loss and EVERY p.grad
+    (the small dense ones live in per-graph memory: GraphedStep(params=...) re-points them) of the eager step on its batch."""
+    from recbox_amd import ops
+    from recbox_amd.graph import GraphedStep
+    vocabs = CRITEO_SMALL_VOCABS + [70000]
+    fm, eager, graphed = _fm_pair(47, vocabs)
+    B = 513
+    data = []
+    for k in range(3):
+        _, X, y = _criteo_like(B, vocabs, 16, seed=90 + k, zipf=(k == 1))
+        data.append((_cuda(X), y.cuda()))
+    params = list(graphed.parameters())
+    old = ops.config.check_ids
+    ops.config.check_ids = False
+    try:
+        steps = []
+        for Xk, yk in data:
+            steps.append(GraphedStep((lambda Xk=Xk, yk=yk: _bce_step(graphed, Xk, yk)), warmup=2, params=params,
+                                     pool=steps[0].pool() if steps else None))
+        for k in (0, 1, 2, 1, 1, 0, 2):
+            loss = steps[k]()
+            want = _bce_step(eager, data[k][0], data[k][1])
+            torch.cuda.synchronize()
+            assert_close(loss.reshape(1), want.reshape(1), 1e-6, "loss")
+            for (n, p0), (_, p1) in zip(eager.named_parameters(), graphed.named_parameters()):
+                assert torch.equal(p1.grad, p0.grad), "graph %d: %s" % (k, n)
+    finally:
+        ops.config.check_ids = old
+
+
 def test_bench_configuration_graph_replays_equal_fresh_eager_steps():
     """BASELINE.json configs[1] exactly as bench.py runs it (26 Criteo-sized tables + 13 numeric features, D = 16,
     B = 65 536, ids as float64 columns, hipGraph replay with persistent gradients): two replays on two different batches
@@ -1103,3 +1135,73 @@ def test_out_of_range_ids_are_reported_late_when_the_eager_check_is_off():
         ops.check_deferred_ids()                                   # the word was cleared: clean again
     finally:
         ops.config.check_ids = old
+
+
+@pytest.mark.gpu
+def test_sigmoid_output_bce_matches_the_unfused_chain():
+    """ops.binary_cross_entropy(ops.sigmoid_output(logit), y): loss and dL/dlogit from one pass over the logits
+    (rbx_sigmoid_bce_mean + rbx_scale_by_scalar) == torch's sigmoid -> binary_cross_entropy chain, clamps included; y_pred stays
+    an ordinary differentiable tensor for every other reader."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(4099, 1, generator=g) * 4
+    x0[:6, 0] = torch.tensor([60.0, -60.0, 110.0, -110.0, 0.0, 17.0])
+    y = (torch.rand(4099, 1, generator=g) < 0.3).float()
+    y[:4, 0] = torch.tensor([0.0, 1.0, 0.0, 1.0])                       # saturated AND wrong: the -100 clamp is hit
+    xr = x0.double().requires_grad_(True)
+    pr = torch.sigmoid(xr.float())
+    lr_ = torch.nn.functional.binary_cross_entropy(pr, y) * 3.0 + (pr * 0.25).sum()
+    lr_.backward()
+    x = x0.cuda().requires_grad_(True)
+    p = ops.sigmoid_output(x)
+    assert torch.equal(p.detach().cpu(), torch.sigmoid(x0.cuda()).cpu())
+    loss = ops.binary_cross_entropy(p, y.cuda()) * 3.0 + (p * 0.25).sum()
+    loss.backward()
+    assert abs(loss.item() - lr_.item()) <= 1e-4 * max(1.0, abs(lr_.item()))
+    assert (x.grad.cpu().double() - xr.grad).abs().max().item() <= 1e-6
+    # the same tensors with the fusion switched off: the two-step kernels
+    old = ops.config.fuse_sigmoid_bce
+    ops.config.fuse_sigmoid_bce = False
+    try:
+        x2 = x0.cuda().requires_grad_(True)
+        l2 = ops.binary_cross_entropy(ops.sigmoid_output(x2), y.cuda()) * 3.0
+        l2.backward()
+    finally:
+        ops.config.fuse_sigmoid_bce = old
+    x3 = x0.cuda().requires_grad_(True)
+    l3 = ops.binary_cross_entropy(ops.sigmoid_output(x3), y.cuda()) * 3.0
+    l3.backward()
+    assert abs(l2.item() - l3.item()) <= 1e-5 * max(1.0, abs(l2.item()))
+    assert (x2.grad - x3.grad).abs().max().item() <= 1e-7
+    with pytest.raises(ValueError):
+        ops.binary_cross_entropy(ops.sigmoid_output(x3.detach()), y.cuda()[:10])
+
+
+@pytest.mark.gpu
+def test_tables_of_mixed_sizes_sort_in_their_own_number_of_passes():
+    """Tables of 4, 200, 300, 70 000 and 1 200 000 rows in ONE lookup (1-, 2- and 3-pass segments of the backward's sort, two
+    shared tables among them, a padding row): gradients == the dense index_add restatement in float64."""
+    from recbox_amd import _embed_host as host
+    from recbox_amd._lib import FIELD_CATEGORICAL
+    torch.manual_seed(3)
+    B, D = 5000, 8
+    vocabs = [4, 200, 300, 70000, 1200000]
+    mods = [torch.nn.Embedding(v, D, padding_idx=(0 if k == 3 else None)).cuda() for k, v in enumerate(vocabs)]
+    uses = [0, 1, 2, 3, 4, 2, 0]                                            # field -> table (tables 2 and 0 feed two fields)
+    ids = [torch.randint(0, vocabs[t], (B,), device="cuda") for t in uses]
+    plan = host.Plan([host.Lookup("f%d" % k, FIELD_CATEGORICAL, mods[t], dim=D) for k, t in enumerate(uses)])
+    out = plan.run(ids)
+    assert out.shape == (B, len(uses) * D)
+    w = torch.randn(B, len(uses) * D, device="cuda")
+    (out * w).sum().backward()
+    for t, m in enumerate(mods):
+        want = torch.zeros(vocabs[t], D, dtype=torch.float64, device="cuda")
+        for k, u in enumerate(uses):
+            if u != t:
+                continue
+            g = w[:, k * D:(k + 1) * D].double()
+            if m.padding_idx is not None:
+                g = g * (ids[k] != m.padding_idx).unsqueeze(1)
+            want.index_add_(0, ids[k], g)
+            assert torch.equal(out[:, k * D:(k + 1) * D], m.weight.detach()[ids[k]])
+        assert (m.weight.grad.double() - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item()), t
