@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 110          /* 0.1.10: rbx_field_t grew table_stride (round 2) */
+#define RBX_VERSION 111          /* 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
 
@@ -462,6 +462,19 @@ size_t rbx_linear_bwd_workspace_size(int64_t m, int32_t n, int32_t k, int32_t ac
 int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d_w, const float* d_y, const float* d_dy, int64_t m,
                    int32_t n, int32_t k, int32_t act, float* d_dx, int64_t dx_stride, float* d_dw, float* d_db,
                    void* d_workspace, size_t workspace_bytes, void* stream);
+/* The same contraction with the element-wise neighbours of a transformer sub-layer folded into the epilogue, so that none
+ * of them is a pass of its own over an [m, n] activation (third_party/rechub/models/matching/sasrec.py:81-94: the residual
+ * `Q + mha_outputs`, `seqs *= ~timeline_mask`; in the backward, the sum autograd forms for a tensor with two readers and
+ * the ReLU backward of the FFN's hidden layer):
+ *   rbx_linear_fwd_fused:  y[m,n]  = (act(x W^T + b) + residual) * row_scale[row]       residual, row_scale optional (NULL)
+ *   rbx_linear_dx_fused:   dx[m,k] = ((dy W) o [mask > 0]) + residual                   mask [m,k], residual [m,k] optional
+ * Every operand has its own row stride (floats).  n > 1 (k > 1 for dx): the logit-head kernels have no such tail. */
+int rbx_linear_fwd_fused(const float* d_x, int64_t x_stride, const float* d_w, const float* d_bias, int64_t m, int32_t n,
+                         int32_t k, int32_t act, const float* d_residual, int64_t residual_stride,
+                         const float* d_row_scale, float* d_y, int64_t y_stride, void* stream);
+int rbx_linear_dx_fused(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
+                        const float* d_mask, int64_t mask_stride, const float* d_residual, int64_t residual_stride,
+                        float* d_dx, int64_t dx_stride, void* stream);
 
 /* ---- K6: fused masked-softmax attention for short sequences (L <= 256, head_dim in {4..64}) ----
  * ranking/pytorch/layers/attentions/dot_product_attention.py:31-43 (ScaledDotProductAttention) and the

@@ -31,6 +31,26 @@ constexpr int BM = 128, BN = 128, BK = RBX_GEMM_BK;
 constexpr int kXcds = 8;         // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 constexpr int LDT = BM + 4;     // LDS row stride (floats): keeps b128 stores aligned, spreads k rows over banks
 
+// Optional tail of the epilogue, applied after bias and activation (all pointers may be NULL):
+//   v = mask[row, col] > 0 ? v : 0      ReLU mask taken from ANOTHER tensor (dh = (g W2) o [h > 0]: the activation
+//                                       backward of the layer below, without a pass of its own)
+//   v += res[row, col]                  residual connection / the second gradient of a tensor with two readers
+//   v *= rowscale[row]                  SASRec's timeline mask
+// Each of them saves one read-modify-write pass over an [M, N] activation (210 MB at cfg 5).
+struct Epi {
+  const float* res;
+  long long ldres;
+  const float* mask;
+  long long ldmask;
+  const float* rowscale;
+};
+__device__ __forceinline__ float epi_apply(const Epi& e, float v, int row, int col) {
+  if (e.mask != nullptr) v = e.mask[static_cast<long long>(row) * e.ldmask + col] > 0.f ? v : 0.f;
+  if (e.res != nullptr) v += e.res[static_cast<long long>(row) * e.ldres + col];
+  if (e.rowscale != nullptr) v *= e.rowscale[row];
+  return v;
+}
+
 // Load one 128 x BK operand tile into registers (BK/2 floats per thread).
 //   KCONTIG: element (r, k) at base[r * ld + k]   -> thread reads float4 along k
 //   else   : element (r, k) at base[k * ld + r]   -> thread reads float4 along r
@@ -99,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const int N, const int K, const int k_per_split,
                                                        const float* __restrict__ bias, const int act,
                                                        const bool vec_a, const bool vec_b, const int tiles_m,
-                                                       const int tiles_n) {
+                                                       const int tiles_n, const Epi epi) {
   __shared__ float As[2][BK * LDT];
   __shared__ float Bs[2][BK * LDT];
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so launch
@@ -176,6 +196,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         if (row < M) {
           float v = acc[i][j][r] + bv;
           if (act == 1 && gridDim.z == 1) v = v > 0.f ? v : 0.f;
+          if (gridDim.z == 1) v = epi_apply(epi, v, row, col);
           C[static_cast<long long>(row) * ldc + col] = v;
         }
       }
@@ -192,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
                                                               float* __restrict__ C, const long long ldc, const int M,
                                                               const int N, const int K, const int n0,
                                                               const float* __restrict__ bias, const int act,
-                                                              const bool vec_a, const bool vec_b) {
+                                                              const bool vec_a, const bool vec_b, const Epi epi) {
   __shared__ float As[2][BK * LDT];
   __shared__ float Bs[2][BK * LDT];
   const int m0 = blockIdx.x * BM;
@@ -205,6 +226,32 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // The epilogue's extra operands are fetched NOW: this kernel runs a handful of k tiles (K = 64 for the SASRec
+  // projections), so a load issued after the last MFMA is a full memory round trip that nothing hides (measured: the
+  // fused launches took 270 us instead of 126).  They arrive while the operand tiles do.
+  f32x16 eres[NT], emask[NT];
+  float erow[16];
+  const bool has_res = epi.res != nullptr, has_mask = epi.mask != nullptr, has_rs = epi.rowscale != nullptr;
+  if (has_res || has_mask) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const bool ok = row < M && col < N;
+        eres[j][r] = (has_res && ok) ? epi.res[static_cast<long long>(row) * epi.ldres + col] : 0.f;
+        emask[j][r] = (has_mask && ok) ? epi.mask[static_cast<long long>(row) * epi.ldmask + col] : 1.f;
+      }
+    }
+  }
+  if (has_rs) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      erow[r] = row < M ? epi.rowscale[row] : 0.f;
+    }
+  }
   float ra[4 * NP], rb[4 * NP];
   load_tile<A_KCONTIG>(A, lda, m0, 0, M, K, vec_a, ra);
   load_tile<B_KCONTIG>(B, ldb, n0, 0, nlim, K, vec_b, rb);
@@ -245,6 +292,9 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
       if (row < M) {
         float v = acc[j][r] + bv;
         if (act == 1) v = v > 0.f ? v : 0.f;
+        if (has_mask) v = emask[j][r] > 0.f ? v : 0.f;
+        if (has_res) v += eres[j][r];
+        if (has_rs) v *= erow[r];
         C[static_cast<long long>(row) * ldc + col] = v;
       }
     }
@@ -683,12 +733,14 @@ static int wide_mode() {
 // generic driver: C[M,N] = op(A) op(B)
 template <bool AK, bool BK_>
 static int run_gemm(const float* A, long long lda, const float* B, long long ldb, float* C, int M, int N, int K,
-                    const float* bias, int act, float* ws, size_t ws_floats, hipStream_t s, long long ldc = 0) {
+                    const float* bias, int act, float* ws, size_t ws_floats, hipStream_t s, long long ldc = 0,
+                    const Epi epi = Epi{nullptr, 0, nullptr, 0, nullptr}) {
   if (ldc == 0) ldc = N;
+  const bool has_epi = epi.res != nullptr || epi.mask != nullptr || epi.rowscale != nullptr;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   int splits = 1;
   const long long tiles = static_cast<long long>(tm) * tn;
-  if (tiles < kCUs && K >= 4096 && ws != nullptr && ldc == N) {   // tiny output, long reduction: split K
+  if (tiles < kCUs && K >= 4096 && ws != nullptr && ldc == N && !has_epi) {   // tiny output, long reduction: split K
     // every workgroup of the launch is resident at once (33.8 KB of LDS each), so the kernel lasts as long as the CU
     // with the most workgroups: pick the split count whose tiles x splits fills whole rounds of the 256 CUs best
     // (k = 1677: 56 tiles x 10 splits = 560 workgroups left a third of the chip idle during the last round; x 9 = 504 fits)
@@ -707,7 +759,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   }
   // one column tile of at most 416 columns and many rows: the wide kernel (no narrow companion, A read once)
   const int wmode = wide_mode();
-  if (splits == 1 && M >= 2048 && N > 64 && N <= 448 && wmode > 0 && (N % BN != 0 || wmode > 1)) {
+  if (splits == 1 && !has_epi && M >= 2048 && N > 64 && N <= 448 && wmode > 0 && (N % BN != 0 || wmode > 1)) {
     if (N <= 128) launch_wide<AK, BK_, 2>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, s);
     else if (N <= 256) launch_wide<AK, BK_, 4>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, s);
     else launch_wide<AK, BK_, 7>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, s);
@@ -723,15 +775,15 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   if (tn_full > 0)
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm, 1, splits), dim3(256), 0, s, A, lda, B, ldb, dst,
                        (splits > 1) ? static_cast<long long>(N) : ldc, M, N, K, kps, bias, act, vec_ok(A, lda),
-                       vec_ok(B, ldb), tm, tn_full);
+                       vec_ok(B, ldb), tm, tn_full, epi);
   if (tn_full < tn) {
     const int n0 = tn_full * BN;
     if (tail <= 32)
       hipLaunchKernelGGL((gemm_f32_narrow_kernel<AK, BK_, 1>), dim3(tm), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, n0,
-                         bias, act, vec_ok(A, lda), vec_ok(B, ldb));
+                         bias, act, vec_ok(A, lda), vec_ok(B, ldb), epi);
     else
       hipLaunchKernelGGL((gemm_f32_narrow_kernel<AK, BK_, 2>), dim3(tm), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, n0,
-                         bias, act, vec_ok(A, lda), vec_ok(B, ldb));
+                         bias, act, vec_ok(A, lda), vec_ok(B, ldb), epi);
   }
   int rc = check_launch("gemm_f32_kernel");
   if (rc != RBX_OK) return rc;
@@ -767,6 +819,37 @@ extern "C" int rbx_linear_fwd(const float* d_x, int64_t x_stride, const float* d
   // y[m,n] = x[m,k] * W[n,k]^T : A = x (k contiguous), B(k,n) = W[n*k + k] (k contiguous)
   return run_gemm<true, true>(d_x, x_stride, d_w, k, d_y, static_cast<int>(m), n, k, d_bias, act, nullptr, 0,
                               as_stream(stream));
+}
+
+extern "C" int rbx_linear_fwd_fused(const float* d_x, int64_t x_stride, const float* d_w, const float* d_bias, int64_t m,
+                                    int32_t n, int32_t k, int32_t act, const float* d_residual, int64_t residual_stride,
+                                    const float* d_row_scale, float* d_y, int64_t y_stride, void* stream) {
+  if (m == 0) return RBX_OK;
+  using namespace rbx;
+  if (d_x == nullptr || d_w == nullptr || d_y == nullptr) return fail(RBX_ERR_INVALID, "linear_fused: NULL tensor");
+  if (m < 0 || n <= 1 || k <= 0 || m > INT_MAX) return fail(RBX_ERR_INVALID, "linear_fused: bad shape (n must be > 1)");
+  if (x_stride < k || y_stride < n || (d_residual != nullptr && residual_stride < n))
+    return fail(RBX_ERR_INVALID, "linear_fused: a row stride is shorter than its row");
+  if (act != 0 && act != 1) return fail(RBX_ERR_UNSUPPORTED, "linear_fused: activation code %d", act);
+  const Epi epi{d_residual, static_cast<long long>(residual_stride), nullptr, 0, d_row_scale};
+  return run_gemm<true, true>(d_x, x_stride, d_w, k, d_y, static_cast<int>(m), n, k, d_bias, act, nullptr, 0,
+                              as_stream(stream), y_stride, epi);
+}
+
+extern "C" int rbx_linear_dx_fused(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
+                                   const float* d_mask, int64_t mask_stride, const float* d_residual,
+                                   int64_t residual_stride, float* d_dx, int64_t dx_stride, void* stream) {
+  if (m == 0) return RBX_OK;
+  using namespace rbx;
+  if (d_dy == nullptr || d_w == nullptr || d_dx == nullptr) return fail(RBX_ERR_INVALID, "linear_dx_fused: NULL tensor");
+  if (m < 0 || n <= 0 || k <= 1 || m > INT_MAX) return fail(RBX_ERR_INVALID, "linear_dx_fused: bad shape (k must be > 1)");
+  if (dy_stride < n || dx_stride < k || (d_mask != nullptr && mask_stride < k) ||
+      (d_residual != nullptr && residual_stride < k))
+    return fail(RBX_ERR_INVALID, "linear_dx_fused: a row stride is shorter than its row");
+  const Epi epi{d_residual, static_cast<long long>(residual_stride), d_mask, static_cast<long long>(mask_stride), nullptr};
+  // dx[m,k] = dy[m,n] * W[n,k]: A = dy (n contiguous = its K), B(kk=n, col=k) = W[n*k + k] (col contiguous)
+  return run_gemm<true, false>(d_dy, dy_stride, d_w, k, d_dx, static_cast<int>(m), k, n, nullptr, 0, nullptr, 0,
+                               as_stream(stream), dx_stride, epi);
 }
 
 // split-K scratch of the weight gradient: room for 2 x CUs slices of [n, k], at most 64 MiB

@@ -58,6 +58,9 @@ class config(object):
     # binary_cross_entropy of a sigmoid_output(): one pass over the logits (+ final sum) and one scale kernel in the backward
     # instead of sigmoid / BCE partial / final / BCE backward / sigmoid backward -- 8 launches of ~5 us in a row
     fuse_sigmoid_bce = os.environ.get("RECBOX_AMD_FUSE_SIGMOID_BCE", "1") != "0"
+    # SASRec blocks as two autograd nodes (attention sub-layer, feed-forward sub-layer) whose residual adds, timeline mask, ReLU
+    # backward and gradient sums run in GEMM epilogues instead of passes of their own (ops.sasrec_attention_sublayer / _ffn_)
+    fuse_sublayers = os.environ.get("RECBOX_AMD_FUSE_SUBLAYERS", "1") != "0"
     reuse_grad_buffers = {"0": False, "": False, "all": "all"}.get(os.environ.get("RECBOX_AMD_REUSE_GRADS", "0"), True)
 
 
@@ -1918,6 +1921,197 @@ def attention_dropout_mask(bh, lq, lk, dropout_p, seed, device="cuda"):
         check(lib.rbx_attn_dropout_mask(bh, lq, lk, float(dropout_p), int(seed), _ptr(dropout_tick(device)), _ptr(keep),
                                         _stream()))
     return keep.bool()
+
+
+# ---- transformer sub-layers of SASRec as ONE autograd node each -------------------------------------------------------------
+# sasrec.py:81-94 composes a block from LayerNorm, nn.MultiheadAttention, a residual add, LayerNorm, two 1x1 convolutions,
+# another residual add and the timeline mask.  Composed from separate autograd nodes, every residual connection costs one
+# element-wise pass forward (the add) and one backward (autograd sums the two gradients of a tensor with two readers) over
+# a [B, L, E] activation -- 210 MB at cfg 5, ~90 us each, and there were 14 of them per step.  As one node per sub-layer
+# these sums happen in the epilogue of the GEMM that produces one of the two terms (rbx_linear_fwd_fused /
+# rbx_linear_dx_fused); the kernels in between are the ones the separate ops use.
+
+def _lin_fwd(x2, w, b, act=0, residual=None, row_scale=None):
+    M, K = x2.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    if residual is None and row_scale is None:
+        check(_timed(("linear_fwd", M, N, K),
+                     lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w), _ptr(b), M, N, K, act, _ptr(y), _stream())))
+    else:
+        check(lib.rbx_linear_fwd_fused(_ptr(x2), x2.stride(0), _ptr(w), _ptr(b), M, N, K, act, _ptr(residual),
+                                       residual.stride(0) if residual is not None else N, _ptr(row_scale), _ptr(y), N,
+                                       _stream()))
+    return y
+
+
+def _lin_dx(dy2, w, mask=None, residual=None):
+    """dx = ((dy W) o [mask > 0]) + residual"""
+    M, N = dy2.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
+    check(lib.rbx_linear_dx_fused(_ptr(dy2), dy2.stride(0), _ptr(w), M, N, K, _ptr(mask), mask.stride(0) if mask is not None else K,
+                                  _ptr(residual), residual.stride(0) if residual is not None else K, _ptr(dx), K, _stream()))
+    return dx
+
+
+def _lin_dwdb(x2, w, dy2, dw, db):
+    """dW = dy^T x into ``dw`` [N, K], db = colsum(dy) into ``db`` [N] (either may be None)."""
+    if dw is None and db is None:
+        return
+    M, K = x2.shape
+    N = dy2.shape[1]
+    if dw is None:                       # (the kernels produce db beside dW)
+        dw = torch.empty((N, K), dtype=torch.float32, device=x2.device)
+    ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, 0)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device)
+    check(lib.rbx_linear_bwd(_ptr(x2), x2.stride(0), _ptr(w), None, _ptr(dy2), M, N, K, 0, None, K, _ptr(dw), _ptr(db),
+                             _ptr(ws), ws_bytes, _stream()))
+
+
+def _ln_fwd(x2, weight, bias, eps):
+    rows, dim = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    check(lib.rbx_layernorm_fwd(_ptr(x2), rows, dim, _ptr(weight), _ptr(bias), eps, _ptr(mean), _ptr(rstd), _ptr(y), _stream()))
+    return y, mean, rstd
+
+
+def _ln_bwd(x2, dy2, weight, mean, rstd, want_p):
+    rows, dim = x2.shape
+    dx = torch.empty_like(x2)
+    dgamma = torch.empty(dim, dtype=torch.float32, device=x2.device) if want_p else None
+    dbeta = torch.empty(dim, dtype=torch.float32, device=x2.device) if want_p else None
+    ws_bytes = lib.rbx_layernorm_bwd_workspace_size(rows, dim) if want_p else 0
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x2.device)
+    check(lib.rbx_layernorm_bwd(_ptr(x2), _ptr(dy2), rows, dim, _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dgamma),
+                                _ptr(dbeta), _ptr(ws), ws_bytes, _stream()))
+    return dx, dgamma, dbeta
+
+
+class _AttnSublayer(torch.autograd.Function):
+    """e [B, L, E] -> q + out_proj(attention(in_proj_q(q), in_proj_kv(e))), q = LayerNorm(e): the first half of a SASRec block
+    (sasrec.py:81-88: ``Q = attention_layernorm(seqs); mha, _ = attention_layer(Q, seqs, seqs, attn_mask); seqs = Q + mha``)."""
+
+    @staticmethod
+    def forward(ctx, e, ln_w, ln_b, eps, in_w, in_b, out_w, out_b, heads, p_drop, seed):
+        _require_cuda(e, "sequence block")
+        B, L, E = e.shape
+        x2 = e.contiguous().float().view(B * L, E)
+        in_w = in_w.contiguous()
+        out_w = out_w.contiguous()
+        hd = E // heads
+        q, mean, rstd = _ln_fwd(x2, ln_w, ln_b, eps)
+        Q = _lin_fwd(q, in_w[:E], in_b[:E] if in_b is not None else None)
+        KV = _lin_fwd(x2, in_w[E:], in_b[E:] if in_b is not None else None)
+        O = torch.empty((B * L, E), dtype=torch.float32, device=e.device)
+        lse = torch.empty((B * heads, L), dtype=torch.float32, device=e.device)
+        tick = dropout_tick(e.device) if p_drop > 0 else None
+        scale = hd ** -0.5
+        kptr = ctypes.c_void_p(KV.data_ptr())
+        vptr = ctypes.c_void_p(KV.data_ptr() + 4 * E)
+        check(lib.rbx_attn_packed_fwd(_ptr(Q), E, kptr, 2 * E, vptr, 2 * E, B, heads, L, hd, float(scale), 1, float(p_drop),
+                                      int(seed), _ptr(tick), _ptr(O), E, _ptr(lse), _stream()))
+        out = _lin_fwd(O, out_w, out_b, residual=q)                       # Q + mha_outputs in the epilogue
+        ctx.save_for_backward(x2, ln_w, mean, rstd, q, in_w, Q, KV, O, lse, out_w)
+        ctx.meta = (B, L, E, heads, hd, float(scale), float(p_drop), int(seed), tick, in_b is not None, out_b is not None,
+                    ln_b is not None)
+        return out.view(B, L, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, ln_w, mean, rstd, q, in_w, Q, KV, O, lse, out_w = ctx.saved_tensors
+        B, L, E, heads, hd, scale, p_drop, seed, tick, has_in_b, has_out_b, has_ln_b = ctx.meta
+        dev = dout.device
+        g = dout.contiguous().float().view(B * L, E)
+        need = ctx.needs_input_grad
+        # output projection
+        d_out_w = torch.empty_like(out_w) if need[6] else None
+        d_out_b = torch.empty(E, dtype=torch.float32, device=dev) if (has_out_b and need[7]) else None
+        _lin_dwdb(O, out_w, g, d_out_w, d_out_b)
+        dO = _lin_dx(g, out_w)
+        # attention
+        dQ = torch.empty_like(Q)
+        dKV = torch.empty_like(KV)
+        scratch = torch.empty((B * heads, L), dtype=torch.float32, device=dev)
+        kptr = ctypes.c_void_p(KV.data_ptr())
+        vptr = ctypes.c_void_p(KV.data_ptr() + 4 * E)
+        dkptr = ctypes.c_void_p(dKV.data_ptr())
+        dvptr = ctypes.c_void_p(dKV.data_ptr() + 4 * E)
+        check(_timed(("attn_bwd", B * heads, L, hd),
+                     lambda: lib.rbx_attn_packed_bwd(_ptr(Q), E, kptr, 2 * E, vptr, 2 * E, _ptr(O), E, _ptr(dO), E, _ptr(lse),
+                                                     B, heads, L, hd, scale, 1, p_drop, seed, _ptr(tick), _ptr(dQ), E, dkptr,
+                                                     2 * E, dvptr, 2 * E, _ptr(scratch), _stream())))
+        # in_proj: one [3E, E] weight gradient, its two row blocks written in place
+        d_in_w = torch.empty_like(in_w) if need[4] else None
+        d_in_b = torch.empty(3 * E, dtype=torch.float32, device=dev) if (has_in_b and need[5]) else None
+        _lin_dwdb(q, in_w[:E], dQ, d_in_w[:E] if d_in_w is not None else None, d_in_b[:E] if d_in_b is not None else None)
+        _lin_dwdb(x2, in_w[E:], dKV, d_in_w[E:] if d_in_w is not None else None, d_in_b[E:] if d_in_b is not None else None)
+        # q = LayerNorm(e) has two readers (the query projection and the residual): their gradients meet in the epilogue
+        dq = _lin_dx(dQ, in_w[:E], residual=g)
+        want_p = need[1] or (has_ln_b and need[2])
+        de_ln, dgamma, dbeta = _ln_bwd(x2, dq, ln_w, mean, rstd, want_p)
+        # e has two readers too (the LayerNorm and the key / value projection)
+        de = _lin_dx(dKV, in_w[E:], residual=de_ln) if need[0] else None
+        return (de.view(B, L, E) if de is not None else None, dgamma if need[1] else None,
+                dbeta if (has_ln_b and need[2]) else None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None)
+
+
+def sasrec_attention_sublayer(e, norm, mha, dropout_p=0.0, seed=None):
+    """``q = norm(e); q + mha(q, e, e, causal)`` for [B, L, E] blocks (batch-first; nn.LayerNorm, nn.MultiheadAttention)."""
+    if dropout_p and seed is None:
+        seed = _draw_seed()
+    return _AttnSublayer.apply(e, norm.weight, norm.bias, float(norm.eps), mha.in_proj_weight, mha.in_proj_bias,
+                               mha.out_proj.weight, mha.out_proj.bias, int(mha.num_heads), float(dropout_p or 0.0),
+                               int(seed or 0))
+
+
+class _FfnSublayer(torch.autograd.Function):
+    """e [B, L, E] -> (n + W2 relu(W1 n + b1) + b2) * keep, n = LayerNorm(e): the second half of a SASRec block without
+    dropout (sasrec.py:89-92: ``seqs = forward_layernorm(seqs); seqs = forward_layer(seqs); seqs *= ~timeline_mask``)."""
+
+    @staticmethod
+    def forward(ctx, e, ln_w, ln_b, eps, w1, b1, w2, b2, keep):
+        _require_cuda(e, "sequence block")
+        B, L, E = e.shape
+        x2 = e.contiguous().float().view(B * L, E)
+        w1, w2 = w1.contiguous(), w2.contiguous()
+        k1 = keep.contiguous().float().view(-1)
+        n, mean, rstd = _ln_fwd(x2, ln_w, ln_b, eps)
+        h = _lin_fwd(n, w1, b1, act=1)
+        out = _lin_fwd(h, w2, b2, residual=n, row_scale=k1)               # (+ residual) * ~timeline_mask in the epilogue
+        ctx.save_for_backward(x2, ln_w, mean, rstd, n, w1, h, w2, k1)
+        ctx.meta = (B, L, E, b1 is not None, b2 is not None, ln_b is not None)
+        return out.view(B, L, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, ln_w, mean, rstd, n, w1, h, w2, k1 = ctx.saved_tensors
+        B, L, E, has_b1, has_b2, has_ln_b = ctx.meta
+        dev = dout.device
+        need = ctx.needs_input_grad
+        g0 = dout.contiguous().float().view(B * L, E)
+        g = torch.empty_like(g0)                                           # dL/d(pre-mask sum) = dout * keep
+        check(lib.rbx_rowscale(_ptr(g0), None, _ptr(k1), g0.shape[0], g0.shape[1], 1.0, _ptr(g), _stream()))
+        H = w1.shape[0]
+        dw2 = torch.empty_like(w2) if need[6] else None
+        db2 = torch.empty(E, dtype=torch.float32, device=dev) if (has_b2 and need[7]) else None
+        _lin_dwdb(h, w2, g, dw2, db2)
+        dh = _lin_dx(g, w2, mask=h)                                        # ReLU backward of the hidden layer in the epilogue
+        dw1 = torch.empty_like(w1) if need[4] else None
+        db1 = torch.empty(H, dtype=torch.float32, device=dev) if (has_b1 and need[5]) else None
+        _lin_dwdb(n, w1, dh, dw1, db1)
+        dn = _lin_dx(dh, w1, residual=g)                                   # n feeds the FFN and the residual
+        want_p = need[1] or (has_ln_b and need[2])
+        de, dgamma, dbeta = _ln_bwd(x2, dn, ln_w, mean, rstd, want_p)
+        return (de.view(B, L, E) if need[0] else None, dgamma if need[1] else None,
+                dbeta if (has_ln_b and need[2]) else None, None, dw1, db1, dw2, db2, None)
+
+
+def sasrec_ffn_sublayer(e, norm, w1, b1, w2, b2, keep):
+    """``n = norm(e); (n + relu(n w1^T + b1) w2^T + b2) * keep[..., None]`` for [B, L, E] blocks; keep [B, L] carries no gradient."""
+    return _FfnSublayer.apply(e, norm.weight, norm.bias, float(norm.eps), w1, b1, w2, b2, keep)
 
 
 class _SoftmaxCE(torch.autograd.Function):

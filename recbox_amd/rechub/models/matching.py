@@ -184,11 +184,24 @@ class SASRec(torch.nn.Module):
         else:      # (e * sqrt(D) + position) * ~mask in one pass (rbx_rowscale) instead of three element-wise kernels
             e = ops.row_scale(e, keep, add=ops_position(self.position_emb, positions), alpha=scale)
         for i in range(len(self.attention_layers)):
-            q = ops.layer_norm(e, self.attention_layernorms[i])
-            e = q + self._mha(self.attention_layers[i], q, e)
-            e = ops.layer_norm(e, self.forward_layernorms[i])
-            # (ffn(e) + e) * ~mask: the residual add and the timeline mask in one pass
-            e = ops.row_scale(self.forward_layers[i].branch(e), keep, add=e)
+            mha, ffn = self.attention_layers[i], self.forward_layers[i]
+            E, H = mha.embed_dim, mha.num_heads
+            if (ops.config.fuse_sublayers and e.dim() == 3 and mha.in_proj_weight is not None
+                    and ops.attention_packed_supported(e.shape[1], E // H)):
+                # LayerNorm, the three projections, the attention and the residual as ONE autograd node: the residual add
+                # and the two gradient sums of the backward live in GEMM epilogues
+                e = ops.sasrec_attention_sublayer(e, self.attention_layernorms[i], mha,
+                                                  dropout_p=mha.dropout if self.training else 0.0)
+            else:
+                q = ops.layer_norm(e, self.attention_layernorms[i])
+                e = q + self._mha(mha, q, e)
+            if ops.config.fuse_sublayers and e.dim() == 3 and not (self.training and (ffn.dropout1.p > 0 or ffn.dropout2.p > 0)):
+                e = ops.sasrec_ffn_sublayer(e, self.forward_layernorms[i], ffn.conv1.weight.squeeze(-1), ffn.conv1.bias,
+                                            ffn.conv2.weight.squeeze(-1), ffn.conv2.bias, keep)
+            else:
+                e = ops.layer_norm(e, self.forward_layernorms[i])
+                # (ffn(e) + e) * ~mask: the residual add and the timeline mask in one pass
+                e = ops.row_scale(ffn.branch(e), keep, add=e)
         return ops.layer_norm(e, self.last_layernorm)
 
     def forward(self, x):

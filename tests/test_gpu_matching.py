@@ -687,6 +687,53 @@ def test_sasrec_trains_with_the_reference_default_dropout():
     assert_close(e, fx["out"]["pos_logits"], TOL)                           # dropout off == the dropout-free fixture
 
 
+def test_sasrec_sublayers_as_one_node_equal_the_composed_ops():
+    """ops.sasrec_attention_sublayer / sasrec_ffn_sublayer (residual adds, timeline mask, ReLU backward and the gradient sums
+    of tensors with two readers folded into GEMM epilogues) against the same block composed from layer_norm / linear /
+    attention_packed / row_scale: logits and every parameter gradient, in eval mode and with attention dropout under one seed."""
+    from recbox_amd import ops
+    Fe, La = _rh()
+    from recbox_amd.rechub.models.matching import SASRec
+    Sq = Fe.SequenceFeature
+    fx = Fixture("rechub_sasrec_d64")
+    X = _cuda(fx.tensors("in"))
+
+    def run(fused, train):
+        # (new feature objects per model: a rechub feature caches its nn.Embedding, two models built from the same
+        #  features share the table -- and its .grad)
+        fe = [Sq("seq", 97, 64, pooling="concat"), Sq("pos", 97, 64, pooling="concat", shared_with="seq"),
+              Sq("neg", 97, 64, pooling="concat", shared_with="seq")]
+        model = load_params(SASRec(fe, max_len=200, dropout_rate=0.0), fx["p"]).cuda()
+        for m in model.attention_layers:
+            m.dropout = 0.25 if train else 0.0                               # dropout on the attention probabilities only
+        model.train(train)
+        old = ops.config.fuse_sublayers
+        ops.config.fuse_sublayers = fused
+        try:
+            torch.manual_seed(11)
+            torch.cuda.manual_seed(11)
+            pl, nl = model(X)
+            m = (X["pos"] != 0).float()
+            loss = -((F.logsigmoid(pl) + F.logsigmoid(-nl)) * m).sum() / m.sum()
+            loss.backward()
+        finally:
+            ops.config.fuse_sublayers = old
+        return pl.detach(), nl.detach(), dict((n, p.grad.clone()) for n, p in model.named_parameters())
+
+    for train in (False, True):
+        pa, na, ga = run(True, train)
+        pb, nb, gb = run(False, train)
+        assert_close(pa, pb, 1e-5, "pos logits (train=%s)" % train)
+        assert_close(na, nb, 1e-5, "neg logits (train=%s)" % train)
+        bad = ["%s %.2e (|ref| %.2e)" % (n, (ga[n] - gb[n]).abs().max().item(), gb[n].abs().max().item()) for n in gb
+               if (ga[n] - gb[n]).abs().max().item() > 1e-5 + 1e-5 * gb[n].abs().max().item()]
+        assert not bad, "train=%s: %s" % (train, "; ".join(bad))
+        if not train:
+            assert_close(pa, fx["out"]["pos_logits"], TOL)                  # and == the live-reference fixture
+            for n in ga:
+                assert_close(ga[n], fx["g"][n], TOL, "grad " + n)
+
+
 def test_deepfm_cfg4_full_size_sampled_rows_vs_fp64_oracle():
     """BASELINE.json cfg 4 at full size (Criteo-sized tables, D = 64, MLP 3 x 400, B = 65 536): the predictions of 512
     sampled rows against the oracle's restatement evaluated in float64 on those rows (BatchNorm in eval mode, so that a
