@@ -294,6 +294,11 @@ int rbx_all_to_all(void* comm, const void* d_send, void* d_recv, size_t bytes_pe
  * d_inv[rows] keeps 1/max(||x||,eps) (negative when the clamp was active) for the backward.
  * pairdot: out[b,n] = scale * <u[b,:], v[b,n,:]>  (DSSM: n_cand = 1; YoutubeDNN: 1 + n_neg, scale = 1/T). */
 int rbx_l2norm_fwd(const float* d_x, int64_t rows, int32_t dim, float eps, float* d_y, float* d_inv, void* stream);
+/* The same over rows that sit inside a wider block: row r = (r / inner, r % inner) at d_x + (r / inner) * outer_stride +
+ * (r % inner) * dim -- the [B, 1 + n_neg, D] item rows of YoutubeDNN read where the gather left them, behind the user
+ * columns of one [B, width] block (youtube_dnn.py:52-70), without a contiguous copy.  d_y [rows, dim] is contiguous. */
+int rbx_l2norm_fwd_strided(const float* d_x, int64_t inner, int64_t outer_stride, int64_t rows, int32_t dim, float eps,
+                           float* d_y, float* d_inv, void* stream);
 int rbx_l2norm_bwd(const float* d_y, const float* d_inv, const float* d_dy, int64_t rows, int32_t dim,
                    float* d_dx, void* stream);
 int rbx_pairdot_fwd(const float* d_u, const float* d_v, int64_t batch, int32_t n_cand, int32_t dim, float scale,

@@ -12,13 +12,15 @@ namespace rbx {
 
 // y = x / max(||x||, eps); inv[r] = 1/max(||x||, eps), stored NEGATIVE when the clamp was active
 template <int G>
-__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, const long long rows,
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, const long long inner,
+                                                         const long long outer, const long long rows,
                                                          const int D, const float eps, float* __restrict__ y,
                                                          float* __restrict__ inv) {
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
   for (long long r = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; r < rows; r += ngroups) {
-    const float* src = x + r * D;
+    // row r = (r / inner, r % inner) of a [., inner, D] block whose outer stride is `outer` floats (inner == rows: plain)
+    const float* src = (inner == 1) ? x + r * outer : x + (r / inner) * outer + (r % inner) * D;
     float ss = 0.f;
     for (int d = lane_g; d < D; d += G) ss += src[d] * src[d];
     ss = group_sum<G>(ss);
@@ -122,7 +124,25 @@ extern "C" int rbx_l2norm_fwd(const float* d_x, int64_t rows, int32_t dim, float
   if (rows == 0) return RBX_OK;
   const int g = pick_g(dim);
   hipStream_t s = as_stream(stream);
+#define CALL(GG) hipLaunchKernelGGL((l2norm_fwd_kernel<GG>), dim3(grid_for(rows, GG)), dim3(256), 0, s, d_x, 1LL, \
+                                    static_cast<long long>(dim), static_cast<long long>(rows), dim, eps, d_y, d_inv)
+  RBX_DISPATCH_G(g, CALL)
+#undef CALL
+  return check_launch("l2norm_fwd_kernel");
+}
+
+extern "C" int rbx_l2norm_fwd_strided(const float* d_x, int64_t inner, int64_t outer_stride, int64_t rows, int32_t dim,
+                                      float eps, float* d_y, float* d_inv, void* stream) {
+  if (rows == 0) return RBX_OK;
+  using namespace rbx;
+  if (d_x == nullptr || d_y == nullptr || d_inv == nullptr) return fail(RBX_ERR_INVALID, "l2norm: NULL tensor");
+  if (rows < 0 || dim <= 0 || inner <= 0 || rows % inner != 0 || outer_stride < inner * dim)
+    return fail(RBX_ERR_INVALID, "l2norm_strided: rows %lld must be whole groups of %lld rows, outer stride >= inner * dim",
+                static_cast<long long>(rows), static_cast<long long>(inner));
+  const int g = pick_g(dim);
+  hipStream_t s = as_stream(stream);
 #define CALL(GG) hipLaunchKernelGGL((l2norm_fwd_kernel<GG>), dim3(grid_for(rows, GG)), dim3(256), 0, s, d_x, \
+                                    static_cast<long long>(inner), static_cast<long long>(outer_stride), \
                                     static_cast<long long>(rows), dim, eps, d_y, d_inv)
   RBX_DISPATCH_G(g, CALL)
 #undef CALL

@@ -68,9 +68,11 @@ class YoutubeDNN(torch.nn.Module):
             # calls, as youtube_dnn.py:52-70 does, would build two dense [V, D] gradients of that table and add them.
             dim = self.item_features[0].embed_dim
             both = self.embedding(x, self.user_features + self.item_features + self.neg_item_feature, squeeze_dim=True)
-            user_in, items = ops.split_last(both, self.user_dims)       # contiguous parts; backward = one concatenation
+            # the two column blocks in place (the tower's first GEMM and the normalisation take a row stride); backward = one
+            # concatenation
+            user_in, items = ops.split_last(both, self.user_dims, views=True)
             user_embedding = ops.l2_normalize(self.user_mlp(user_in)).unsqueeze(1)
-            item_embedding = ops.l2_normalize(items.view(items.shape[0], -1, dim))
+            item_embedding = ops.l2_normalize(items.unflatten(1, (-1, dim)))
             return ops.pair_dot(user_embedding, item_embedding, scale=1.0 / self.temperature)   # [B, 1 + n_neg]
         # (a squeezed gather lays DenseFeature values out AFTER every embedding of the call -- layers.py:109-114 --, so
         #  with dense user features the single gather above would put them behind the item / negative rows: the towers

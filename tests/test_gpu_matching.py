@@ -887,3 +887,28 @@ def test_attention_on_packed_operands_equals_the_copying_path(B, L, H, hd, causa
     assert torch.equal(o1, o2)
     assert torch.equal(q1.grad, q2.grad)
     assert torch.equal(kv1.grad, kv2.grad)
+
+
+def test_l2_normalize_reads_rows_inside_a_wider_block():
+    """ops.l2_normalize of a [B, n, D] VIEW behind the first columns of a [B, width] block (rbx_l2norm_fwd_strided) and
+    ops.split_last(views=True): the values and gradients of the contiguous route, without the copies."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, n, D, lead = 301, 5, 32, 48
+    base = torch.randn(B, lead + n * D + 3, generator=g).cuda()            # (+3: the row stride is not the row length)
+    base[7, lead:lead + D] = 0.0                                            # a zero row: the eps clamp
+    block = base[:, :lead + n * D].clone().requires_grad_(True)
+    wide = base.clone().requires_grad_(True)
+    a0, b0 = ops.split_last(block, lead)
+    a1, b1 = ops.split_last(wide[:, :lead + n * D], lead, views=True)
+    assert b1.data_ptr() != b0.data_ptr() and not b1.is_contiguous()
+    y0 = ops.l2_normalize(b0.view(B, n, D))
+    y1 = ops.l2_normalize(b1.unflatten(1, (n, D)))
+    assert torch.equal(y0, y1) and torch.equal(a0, a1)
+    w = torch.randn(B, n, D, generator=g).cuda()
+    ((y0 * w).sum() + a0.sum()).backward()
+    ((y1 * w).sum() + a1.sum()).backward()
+    assert torch.equal(block.grad, wide.grad[:, :lead + n * D])
+    assert float(wide.grad[:, lead + n * D:].abs().max()) == 0.0
+    ref = F.normalize(b0.detach().view(B, n, D).double(), dim=-1).float()
+    assert_close(y1, ref, 1e-6)
