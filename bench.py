@@ -530,6 +530,10 @@ def main():
                          "0/1 = replay one batch.  FM on one GPU: one captured step per resident batch; elsewhere (and "
                          "with --rotate-by-copy) batch i %% K is copied into the static input buffer before each step, "
                          "inside the timed region")
+    ap.add_argument("--prefetch-sort", action="store_true",
+                    help="FM, one GPU: while step i runs, the ids of batch i + 1 are sorted on the side stream (FM.presort: a "
+                         "loop whose loader is one batch ahead), so that the sort no longer sits in front of the backward's "
+                         "reduce: 0.261 vs 0.267 ms.  Off by default: every step of the headline line sorts its own ids")
     ap.add_argument("--rotate-by-copy", action="store_true",
                     help="FM, one GPU: rotate by copy_ into one static buffer (one captured step) instead of one graph per batch")
     ap.add_argument("--sort-after-forward", action="store_true",
@@ -650,6 +654,28 @@ def main():
 
     eager_step = step_over(X, y)              # reads the static buffer `batch` (refill(i) puts batch i % K there)
 
+    def prefetching_step(Xk, yk, mine, X_next, nxt):
+        """The same step with its id sort made one step AHEAD: `mine` holds the sorted ids of this batch (made while the
+        previous step ran), and while this step runs the ids of the NEXT batch are sorted into `nxt` on the side stream --
+        what a training loop whose loader is one batch ahead does.  One sort per step, as before; it has left the chain
+        rezero -> sort -> reduce that the step otherwise waits for."""
+        side = ops.side_stream(dev)
+
+        def one_step():
+            for p in params:
+                p.grad = None
+            cur = torch.cuda.current_stream(dev)
+            start = cur.record_event()
+            prob = model(Xk, presorted=mine)["y_pred"]        # (the re-zero of the previous step's rows goes to `side` first)
+            side.wait_event(start)
+            with torch.cuda.stream(side):
+                model.presort(X_next, into=nxt)
+            loss = loss_fn(prob, yk, reduction="mean")
+            loss.backward()
+            cur.wait_stream(side)
+            return loss
+        return one_step
+
     def overflowed():
         flag = model.tables.overflow.float().reshape(1).clone()
         if world > 1:
@@ -668,17 +694,29 @@ def main():
                 # intermediate memory and the model's persistent gradient buffer); the timed loop replays them in rotation:
                 # every step gathers rows of another batch and nothing is copied inside the timed region
                 rotating_graphs = []
+                inputs_of = []
                 for k in range(K):
                     if args.contiguous_ids:               # batches[k] is [40, B]: a column of the batch is a row here
                         Xk = OrderedDict((name, batches[k][fmw.fm.get_column_index(name)]) for name in fmw.fm.features)
                         yk = labels[k]
                     else:
                         Xk, yk = slice_inputs(fmw.fm, batches[k])
-                    rotating_graphs.append(GraphedStep(step_over(Xk, yk), warmup=3 if k == 0 else 2,
+                    inputs_of.append((Xk, yk))
+                prefetch = args.path == "fused" and K >= 3 and args.prefetch_sort and ops.config.reuse_grad_buffers
+                if prefetch:
+                    sorted_ids = [model.presort(Xk) for Xk, _ in inputs_of]      # (also the primer of the first step)
+                    for k in range(K):                    # the captured re-zero of step k clears the rows step k - 1 wrote
+                        sorted_ids[k].previous = sorted_ids[k - 1]
+                for k in range(K):
+                    Xk, yk = inputs_of[k]
+                    fn = (prefetching_step(Xk, yk, sorted_ids[k], inputs_of[(k + 1) % K][0], sorted_ids[(k + 1) % K])
+                          if prefetch else step_over(Xk, yk))
+                    rotating_graphs.append(GraphedStep(fn, warmup=3 if k == 0 else 2,
                                                        reuse_grads=ops.config.reuse_grad_buffers, params=params,
                                                        pool=rotating_graphs[0].pool() if rotating_graphs else None))
                 step = rotating_graphs[0]
-                graph_note = "hipGraph replay (one captured step per resident batch)"
+                graph_note = "hipGraph replay (one captured step per resident batch%s)" % (
+                    "; the id sort of batch i + 1 runs beside step i, as with a loader one batch ahead" if prefetch else "")
             else:
                 step = GraphedStep(eager_step, warmup=3, reuse_grads=ops.config.reuse_grad_buffers)
                 graph_note = "hipGraph replay"

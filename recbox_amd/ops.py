@@ -51,10 +51,12 @@ class config(object):
     # with check_ids off: keep one persistent status word per device that the kernels OR into (check_deferred_ids() reads it)
     defer_id_check = os.environ.get("RECBOX_AMD_DEFER_IDS", "1") != "0"
     # fused FM backward: run the batch reductions of the numeric-feature weights and the bias (~35 us at the bench shape) on
-    # the side stream beside the segmented reduce instead of in front of it.  Measured SLOWER inside the captured step
-    # (0.336 vs 0.297 ms): with the extra fork / join the hipGraph runtime serialised the forward kernel behind the whole
-    # sort chain (profiles/r02/fm_replay_timeline_numeric_beside.txt).  Off.
-    numeric_beside_reduce = os.environ.get("RECBOX_AMD_NUMERIC_BESIDE", "0") != "0"
+    # the side stream beside the segmented reduce instead of in front of it ("presorted": only in steps whose sort was made
+    # ahead).  Measured SLOWER inside the captured step every time (0.336 vs 0.297 ms; with the prefetched sort 0.294 on a
+    # third stream and 0.314 behind the sort on the second, vs 0.261): a replayed graph runs on TWO hardware queues whatever
+    # the capture's streams were, and with a third branch the runtime put the reduce behind the sort chain
+    # (profiles/r02/fm_replay_timeline_numeric_beside.txt).  Off.
+    numeric_beside_reduce = {"0": False, "1": True, "presorted": "presorted"}[os.environ.get("RECBOX_AMD_NUMERIC_BESIDE", "0")]
     # binary_cross_entropy of a sigmoid_output(): one pass over the logits (+ final sum) and one scale kernel in the backward
     # instead of sigmoid / BCE partial / final / BCE backward / sigmoid backward -- 8 launches of ~5 us in a row
     fuse_sigmoid_bce = os.environ.get("RECBOX_AMD_FUSE_SIGMOID_BCE", "1") != "0"
@@ -248,10 +250,17 @@ def _timed(meta, fn):
 _side_streams = {}
 
 
-def _side_stream(device):
+def side_stream(device):
+    """The auxiliary HIP stream the backward's id sorts run on (one per device): a loop that sorts the NEXT batch's ids beside
+    the current step (``FM.presort``) enqueues that there."""
+    return _side_stream(torch.device(device))
+
+
+def _side_stream(device, which=0):
     """One auxiliary HIP stream per device: the id sort of the backward depends only on the
-    ids, so it is enqueued there during the forward and overlaps the forward kernels."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    ids, so it is enqueued there during the forward and overlaps the forward kernels.
+    which = 1: a second one, for work that must not queue up behind that sort."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     st = _side_streams.get(key)
     if st is None:
         st = torch.cuda.Stream(device=device)
@@ -596,6 +605,8 @@ class _GradPool(object):
         self.ws = None
         self.ws_bytes = 0
         self.dirty_batch = 0
+        self.dirty_ws = None                  # (workspace, bytes) whose sorted ids name the dirty rows: self.ws, or the
+        #                                       workspace of a sort made ahead of its step (fm_presort)
         self.ticket = 0                       # bumped by every sort: a backward whose ticket is stale re-sorts
         self.pending = False                  # a forward holds the ticket and its backward has not run yet
         self.device = device
@@ -668,9 +679,25 @@ class _GradPool(object):
                                    "(zero_grad(set_to_none=True)); the gradients alias one persistent buffer")
         return self, self.views(list(params), zero_loose=zero_loose)
 
-    def done(self, B):
-        self.dirty_batch = B                     # the rows named by the sorted ids in self.ws now hold this step's sums
+    def done(self, B, ws=None, ws_bytes=0):
+        self.dirty_batch = B                     # the rows named by the sorted ids in that workspace now hold this step's sums
+        self.dirty_ws = (ws, int(ws_bytes)) if ws is not None else (self.ws, self.ws_bytes)
         self.pending = False
+
+    def adopt_presorted(self, ctx, presorted, device, rezero, started):
+        """A forward whose id sort was made AHEAD of the step (fm_presort, into a workspace of the caller's): clear the rows
+        the previous backward stored -- its sorted ids are in ``dirty_ws``, another workspace -- on the side stream, beside the
+        forward kernel; the backward waits for that before it stores."""
+        ctx.rezero_event = None
+        if self.dirty_batch:
+            side = _side_stream(device)
+            side.wait_event(started)                # (recorded before the forward kernel: the re-zero does not wait for it)
+            check(rezero(ctypes.c_void_p(side.cuda_stream)))
+            ctx.rezero_event = side.record_event()
+        ctx.sort = presorted
+        self.ticket += 1
+        self.pending = True
+        ctx.pool, ctx.ticket = self, self.ticket
 
     def workspace(self, ws_bytes):
         if self.ws is None or self.ws_bytes < ws_bytes:
@@ -764,11 +791,32 @@ class _FmFused(torch.autograd.Function):
         own_sort = train and B > 0 and presorted is None
         if own_sort and config.sort_before_forward:
             start_sort()
+        adopt = None
+        if presorted is not None and train and B > 0 and config.reuse_grad_buffers and presorted.ws_bytes > 0:
+            # persistent gradients with a sort made ahead of the step: only the re-zero of the previous step's rows is left
+            # to do, on the side stream beside the forward kernel.  It is ENQUEUED after the forward kernel (it waits for an
+            # event recorded here, before it): in a captured step the forward is then the graph's first kernel node and stays
+            # on the queue the previous replay ended on -- with the re-zero first, the chain forward -> reduce moved to a
+            # second hardware queue and every replay began with a ~20 us cross-queue wait.
+            pool = _GradPool.claim(_FmFused._pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev))
+            if pool is not None:
+                adopt = (pool, torch.cuda.current_stream(dev).record_event())
         check(_timed(("fm_fwd", lead.n, D, B),
                      lambda: lib.rbx_fm_fwd(ea, la, lead.n, B, _ptr(bias), _ptr(extra), n_extra, x_stride, x_lr,
                                             _ptr(extra_index), x_rows, _ptr(logit), _ptr(prob), _ptr(ssum),
                                             _ptr(status), _stream())))
         _check_status(status)
+        if adopt is not None:
+            pool, started = adopt
+
+            def rezero(st):
+                rc = _FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st, previous=presorted.previous)
+                if emb_plan is not None:
+                    emb_plan.bind_params(emb_params)
+                if lr_plan is not None:
+                    lr_plan.bind_params(lr_params)
+                return rc
+            pool.adopt_presorted(ctx, presorted, dev, rezero, started)
         ctx.state = (emb_plan, lr_plan, keep, emb_params, lr_params, bias, ssum, B, n_inputs, extra, has_bias, has_extra,
                      extra_index)
         if presorted is not None:
@@ -795,7 +843,7 @@ class _FmFused(torch.autograd.Function):
         return pool
 
     @staticmethod
-    def _rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st):
+    def _rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st, previous=None):
         grads = pool.bind_views(list(emb_params) + list(lr_params))
         if emb_plan is not None:
             emb_plan.bind_params(emb_params, grads[:len(emb_params)])
@@ -803,7 +851,10 @@ class _FmFused(torch.autograd.Function):
             lr_plan.bind_params(lr_params, grads[len(emb_params):])
         ea = emb_plan.arr if emb_plan is not None else None
         la = lr_plan.arr if lr_plan is not None else None
-        rc = lib.rbx_fm_rezero(ea, la, lead.n, pool.dirty_batch, _ptr(pool.ws), pool.ws_bytes, st)
+        dws, dbytes = pool.dirty_ws if pool.dirty_ws is not None else (pool.ws, pool.ws_bytes)
+        if previous is not None:
+            dws, dbytes = previous.ws, previous.ws_bytes
+        rc = lib.rbx_fm_rezero(ea, la, lead.n, pool.dirty_batch, _ptr(dws), dbytes, st)
         pool.dirty_batch = 0
         return rc
 
@@ -872,11 +923,14 @@ class _FmFused(torch.autograd.Function):
                                            _stream()))
         ws_early = ctx.sort.ws if (ctx.sort is not None and same) else None
         numeric_done = None
-        if ws_early is not None and config.numeric_beside_reduce and getattr(ctx.sort, "event", None) is not None:
-            # numeric weights + bias need dL/dlogit and S only: they go to the side stream -- behind the id sort that is
-            # (or was) running there -- and so run BESIDE the segmented reduce instead of in front of it
+        beside = config.numeric_beside_reduce
+        if beside == "presorted":
+            beside = isinstance(ctx.sort, _Presorted)
+        if ws_early is not None and beside:
+            # numeric weights + bias need dL/dlogit and S only: they go to a stream of their own and so run BESIDE the
+            # segmented reduce instead of in front of it
             cur = torch.cuda.current_stream(dev)
-            side = _side_stream(dev)
+            side = _side_stream(dev, int(os.environ.get("RECBOX_AMD_NUMERIC_STREAM", "0")))
             side.wait_stream(cur)
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws_early),
                                  ctx.sort.ws_bytes, ctypes.c_void_p(side.cuda_stream)))
@@ -895,12 +949,17 @@ class _FmFused(torch.autograd.Function):
             ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
             check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, _stream()))
+        if getattr(ctx, "rezero_event", None) is not None:
+            torch.cuda.current_stream(dev).wait_event(ctx.rezero_event)     # (presorted step: the re-zero ran on the side stream)
         check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0,
                              (1 if ws_early is not None else 3) | store, _ptr(ws), ws_bytes, _stream()))
         if numeric_done is not None:
             torch.cuda.current_stream(dev).wait_event(numeric_done)
         if pool is not None:
-            pool.done(B)
+            if isinstance(ctx.sort, _Presorted):
+                pool.done(B, ws, ws_bytes)
+            else:
+                pool.done(B)
         _forget_sort(ws)
         return result()
 
@@ -910,16 +969,22 @@ class _Presorted(object):
 
     def __init__(self, ws, ws_bytes, B, n):
         self.ws, self.ws_bytes, self.B, self.n, self.event = ws, ws_bytes, B, n, None
+        # With persistent gradients the forward clears the rows the PREVIOUS step's backward stored; they are named by that
+        # step's sorted ids.  Eagerly the gradient pool remembers which workspace that was.  A captured step bakes the
+        # pointer in, so a loop of captured steps (one per resident batch, replayed in ring order) says it here: the
+        # result of fm_presort for the batch whose step runs immediately BEFORE this one.
+        self.previous = None
 
     def join(self):
         pass                                      # the caller of fm_presort orders its streams itself
 
 
-def fm_presort(emb_plan, lr_plan, inputs, emb_params, lr_params):
+def fm_presort(emb_plan, lr_plan, inputs, emb_params, lr_params, into=None):
     """The id sort of ``fm_fused``'s backward (rbx_fm_sort) on the CURRENT stream, before the forward exists: it needs
     the ids only.  A step that spends its first part waiting for remote rows (recbox_amd.graph.ShardedFMStep) runs it
     there, on a stream of its own, and hands the result to ``fm_fused(..., presorted=...)``; the backward must be
-    ordered after it by the caller (stream wait)."""
+    ordered after it by the caller (stream wait).  A training loop that knows the ids of batch i + 1 while batch i runs
+    sorts them then, beside step i (``into``: an earlier result of the same shape, whose workspace is sorted over again)."""
     lead = emb_plan if emb_plan is not None else lr_plan
     B, keep = lead.bind_inputs(inputs)
     if emb_plan is not None:
@@ -931,10 +996,16 @@ def fm_presort(emb_plan, lr_plan, inputs, emb_params, lr_params):
     ea = emb_plan.arr if emb_plan is not None else None
     la = lr_plan.arr if lr_plan is not None else None
     ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B) if B > 0 else 0
-    ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=keep[0].device)
+    if into is not None:
+        if into.B != B or into.n != lead.n or into.ws_bytes < ws_bytes:
+            raise ValueError("fm_presort: `into` was made for another batch shape")
+        ws = into.ws
+    else:
+        ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=keep[0].device)
     if ws_bytes > 0:
-        check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, _stream()))
-    return _Presorted(ws, int(ws_bytes), B, lead.n)
+        check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), max(int(ws_bytes), into.ws_bytes if into is not None else 0), None,
+                              _stream()))
+    return into if into is not None else _Presorted(ws, int(ws_bytes), B, lead.n)
 
 
 def fm_fused(emb_plan, lr_plan, inputs, emb_params, lr_params, bias=None, extra=None, extra_lr_off=-1,

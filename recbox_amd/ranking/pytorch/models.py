@@ -43,7 +43,7 @@ class FM(nn.Module):
         self.embedding_layer = FeatureEmbedding(feature_map, embedding_dim)
         self.fm = FactorizationMachine(feature_map)
 
-    def logits(self, X, with_prob=False):
+    def logits(self, X, with_prob=False, presorted=None):
         emb = self.embedding_layer.embedding_layer
         lr = self.fm.lr_layer.embedding_layer.embedding_layer
         names, values, plan, posts = emb.plan_for(X)
@@ -51,14 +51,32 @@ class FM(nn.Module):
         if self.fused and emb.fusable(plan, posts) and lr.fusable(lplan, lposts) and names == lnames:
             # gather + LR + interaction (+ the output sigmoid) in ONE kernel; [B, F, D] is never written (rbx_fm_fwd / rbx_fm_bwd)
             return ops.fm_fused(plan.plan, lplan.plan, values, [m.weight for m in plan.modules],
-                                [m.weight for m in lplan.modules], self.fm.lr_layer.bias, with_prob=with_prob)
+                                [m.weight for m in lplan.modules], self.fm.lr_layer.bias, with_prob=with_prob,
+                                presorted=presorted)
+        if presorted is not None:
+            raise ValueError("FM: presorted ids belong to the fused path")
         logit = self.fm(X, self.embedding_layer(X))
         return (logit, None) if with_prob else logit
 
-    def forward(self, X):
+    def presort(self, X, into=None):
+        """The id sort of this model's backward for batch ``X``, on the current stream (ops.fm_presort): it needs the ids only,
+        so a loop that has batch i + 1 at hand while step i runs sorts it then -- on a second stream, beside step i -- and
+        passes the result to ``forward(X, presorted=...)`` one step later.  ``into``: re-use the workspace of an earlier result."""
+        if torch.is_tensor(X):
+            X = inputs_from_batch(self.feature_map, X)
+        emb = self.embedding_layer.embedding_layer
+        lr = self.fm.lr_layer.embedding_layer.embedding_layer
+        names, values, plan, posts = emb.plan_for(X)
+        lnames, _, lplan, lposts = lr.plan_for(X)
+        if not (self.fused and emb.fusable(plan, posts) and lr.fusable(lplan, lposts) and names == lnames):
+            raise ValueError("FM.presort: only the fused path sorts ahead of its step")
+        return ops.fm_presort(plan.plan, lplan.plan, values, [m.weight for m in plan.modules],
+                              [m.weight for m in lplan.modules], into=into)
+
+    def forward(self, X, presorted=None):
         if torch.is_tensor(X):                      # the reference's harness hands over the flat batch tensor
             X = inputs_from_batch(self.feature_map, X)
-        logit, prob = self.logits(X, with_prob=True)
+        logit, prob = self.logits(X, with_prob=True, presorted=presorted)
         return {"y_pred": ops.sigmoid_output(logit, prob)}
 
     @torch.no_grad()

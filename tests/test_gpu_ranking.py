@@ -559,6 +559,70 @@ def test_one_graph_per_resident_batch_replayed_in_rotation():
         ops.config.check_ids = old
 
 
+def test_id_sort_made_one_step_ahead_eager_and_captured():
+    """FM.presort / forward(presorted=...): the id sort of batch i + 1 runs on the side stream while step i runs (what a loop
+    whose loader is one batch ahead does), with persistent gradients.  Eagerly the gradient pool remembers whose rows to
+    clear; captured steps (one per resident batch, replayed in ring order) are told through ``previous``.  Every step leaves
+    the loss and the gradients of the plain eager step on its batch."""
+    from recbox_amd import ops
+    from recbox_amd.graph import GraphedStep
+    vocabs = CRITEO_SMALL_VOCABS + [70000]
+    fm, eager, fast = _fm_pair(53, vocabs)
+    B, K = 640, 3
+    data = []
+    for k in range(K):
+        _, X, y = _criteo_like(B, vocabs, 16, seed=120 + k, zipf=(k == 2))
+        data.append((_cuda(X), y.cuda()))
+    params = list(fast.parameters())
+    side = ops.side_stream(torch.device("cuda"))
+
+    def make(k, handles):
+        Xk, yk = data[k]
+
+        def one_step():
+            for p in params:
+                p.grad = None
+            cur = torch.cuda.current_stream()
+            start = cur.record_event()
+            prob = fast(Xk, presorted=handles[k])["y_pred"]
+            side.wait_event(start)
+            with torch.cuda.stream(side):
+                fast.presort(data[(k + 1) % K][0], into=handles[(k + 1) % K])
+            loss = ops.binary_cross_entropy(prob, yk)
+            loss.backward()
+            cur.wait_stream(side)
+            return loss
+        return one_step
+
+    def check(k, loss):
+        eager.zero_grad(set_to_none=True)                      # the plain step: same model code, its own sort inside the step
+        want = ops.binary_cross_entropy(eager(data[k][0])["y_pred"], data[k][1])
+        want.backward()
+        torch.cuda.synchronize()
+        assert_close(loss.reshape(1), want.reshape(1), 1e-6, "loss of batch %d" % k)
+        for (n, p0), (_, p1) in zip(eager.named_parameters(), fast.named_parameters()):
+            assert torch.equal(p1.grad, p0.grad), "batch %d: %s" % (k, n)
+
+    old = (ops.config.check_ids, ops.config.reuse_grad_buffers)
+    ops.config.check_ids = False
+    try:
+        ops.config.reuse_grad_buffers = True
+        handles = [fast.presort(Xk) for Xk, _ in data]
+        steps = [make(k, handles) for k in range(K)]
+        for k in (0, 1, 2, 0, 1):                                  # eager: any order that follows the ring
+            check(k, steps[k]())
+        for k in range(K):
+            handles[k].previous = handles[k - 1]
+        graphs = []
+        for k in range(K):
+            graphs.append(GraphedStep(steps[k], warmup=2, params=params, pool=graphs[0].pool() if graphs else None))
+        ops.config.reuse_grad_buffers = False                      # (the eager reference steps use fresh gradients)
+        for k in (0, 1, 2, 0, 1, 2, 0):
+            check(k, graphs[k]())
+    finally:
+        ops.config.check_ids, ops.config.reuse_grad_buffers = old
+
+
 def test_bench_configuration_graph_replays_equal_fresh_eager_steps():
     """BASELINE.json configs[1] exactly as bench.py runs it (26 Criteo-sized tables + 13 numeric features, D = 16,
     B = 65 536, ids as float64 columns, hipGraph replay with persistent gradients): two replays on two different batches
