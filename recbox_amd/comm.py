@@ -224,6 +224,9 @@ def all_reduce_grads(params, group=None):
     _, W = world(group)
     if W == 1:
         return
-    for p in params:
-        if p.grad is not None:
-            dist.all_reduce(p.grad, group=group)
+    for p in params:                    # the same sequence of collectives on every rank: a missing gradient counts as zeros
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        dist.all_reduce(p.grad, group=group)

@@ -201,15 +201,22 @@ class ShardedFM(nn.Module):
         if self.world_size == 1:
             return
         import torch.distributed as dist
-        grads = [p.grad for p in self.replicated_parameters() if p.grad is not None]
-        if not grads:
+        # every rank reduces the SAME layout: a parameter that received no gradient on this rank (an empty local batch, a
+        # feature no sample of this rank used) contributes zeros -- ranks whose non-None sets differ would otherwise issue
+        # all-reduces of different sizes and hang
+        params = [p for p in self.replicated_parameters() if p.requires_grad]
+        if not params:
             return
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
         dist.all_reduce(flat, group=self.group)
         o = 0
-        for g in grads:
-            g.copy_(flat[o:o + g.numel()].view_as(g))
-            o += g.numel()
+        for p in params:
+            g = flat[o:o + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            o += p.numel()
 
 
 class _SubFeatureMap(object):

@@ -150,6 +150,14 @@ def _worker(rank, world, port, result):
         lin(torch.full((1, 3), float(rank + 1))).sum().backward()
         comm.all_reduce_grads(lin.parameters())
         assert torch.allclose(lin.weight.grad, torch.full((2, 3), float(sum(range(1, world + 1)))))
+        # a rank that produced NO gradient (an empty local batch) still takes part with zeros: same collectives on every rank
+        lin2 = torch.nn.Linear(3, 2)
+        with torch.no_grad():
+            lin2.weight.fill_(1.0)
+        if rank != 0:
+            lin2(torch.full((1, 3), float(rank + 1))).sum().backward()
+        comm.all_reduce_grads(lin2.parameters())
+        assert torch.allclose(lin2.weight.grad, torch.full((2, 3), float(sum(range(2, world + 1)))))
         result[rank] = "ok"
     finally:
         dist.destroy_process_group()
