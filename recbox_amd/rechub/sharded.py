@@ -243,6 +243,12 @@ class _ShardedModelMixin(object):
         skip = id(self.embedding.store.weight) if self.embedding.store is not None else None
         return [p for p in self.parameters() if id(p) != skip]
 
+    def raise_if_overflowed(self):
+        """Collective (call it from every rank, once per step or every N steps): RuntimeError on every rank when any
+        rank's exchange ran out of slots since the last call (recbox_amd.sharded.raise_if_overflowed)."""
+        if self.embedding.store is not None:
+            self.embedding.store.raise_if_overflowed()
+
 
 class ShardedYoutubeDNN(_ShardedModelMixin, YoutubeDNN):
     """``YoutubeDNN`` (third_party/rechub/models/matching/youtube_dnn.py:14-71) with the item table row-sharded:

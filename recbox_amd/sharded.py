@@ -197,6 +197,23 @@ class ShardedEmbedding(nn.Module):
             self.local.weight.grad[self.local.padding_idx].zero_()
 
 
+def raise_if_overflowed(module, group, what):
+    """Collective: has ANY rank's padded exchange run out of slots since the last call?  The flag is a device word the
+    routing kernels raise instead of dropping lookups silently (a dropped lookup reads a zero row and trains nothing); this
+    reads it (one host sync), agrees on it across the ranks, clears it and raises on EVERY rank -- so that no rank is left
+    waiting in the next collective.  Call it once per step, or every N steps, from every rank."""
+    flag = module.overflow.detach().float().reshape(1).clone()
+    if comm.world(group)[1] > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    module.overflow.zero_()
+    if float(flag.item()) > 0:
+        raise RuntimeError("%s: an owner received more lookups from one rank than the exchange has slots for "
+                           "(capacity_factor = %g); the affected lookups read zero rows.  Rebuild with a larger "
+                           "capacity_factor (skewed ids need more than the default 1.25), or capacity_factor=None for "
+                           "the exact all-to-all-v." % (what, module.capacity_factor))
+
+
 class ShardedTables(nn.Module):
     """T tables row-sharded together: one routing and one exchange per call for all of them.
 
@@ -227,6 +244,11 @@ class ShardedTables(nn.Module):
         nn.init.normal_(self.weight[:, :embedding_dim + (1 if with_lr else 0)], std=1e-4)
         self.capacity_factor = capacity_factor
         self.local_ops = local_ops if local_ops is not None else HipLocalOps()
+
+    def raise_if_overflowed(self):
+        """Collective; see ``raise_if_overflowed`` above."""
+        if self.capacity_factor is not None:
+            raise_if_overflowed(self, self.group, "ShardedTables")
 
     @torch.no_grad()
     def load_full_tables(self, emb_tables, lr_tables=None):
@@ -555,6 +577,10 @@ class ShardedStore(nn.Module):
             tbl = [t for t, _ in call.rows] + ([call.pool[0]] if call.pool is not None else [])
             b = self._bases[call.key] = self.base[:, tbl].contiguous()
         return b
+
+    def raise_if_overflowed(self):
+        """Collective; see ``raise_if_overflowed`` above."""
+        raise_if_overflowed(self, self.group, "ShardedStore")
 
     @torch.no_grad()
     def load_full_tables(self, tables):

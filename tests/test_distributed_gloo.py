@@ -142,6 +142,12 @@ def _worker(rank, world, port, result):
         flag = torch.tensor([float(bool(tight.overflow))])
         dist.all_reduce(flag)
         assert (flag.item() > 0) == (world > 1)
+        # ... and the library reports it on EVERY rank (collective), then starts from a clean flag
+        if world > 1:
+            with pytest.raises(RuntimeError, match="capacity_factor"):
+                tight.raise_if_overflowed()
+        tight.raise_if_overflowed()
+        tabs.raise_if_overflowed()
         # dense tower grads: all-reduce
         lin = torch.nn.Linear(3, 2)
         with torch.no_grad():
