@@ -592,12 +592,19 @@ template <int G, int NV, bool VEC>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const long long rows, const int dim,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                        const float* __restrict__ rstd, float* __restrict__ dx) {
+                                                        const float* __restrict__ rstd, float* __restrict__ dx,
+                                                        float* __restrict__ partial) {
   using Row = LnRow<G, NV, VEC>;
   constexpr int NA = NV * Row::W;
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
   const float inv_d = 1.0f / static_cast<float>(dim);
+  // partial != NULL: the parameter gradients' block sums (sum dy, sum dy * xhat per column) fall out of the same pass --
+  // dy and xhat are in registers anyway --, instead of a second kernel that reads x and dy again (210 + 210 MB at cfg 5).
+  // A lane adds its rows in ascending order, the lane groups of the workgroup are added in a fixed order: deterministic.
+  float pb[NA], pg[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) pb[i] = pg[i] = 0.f;
   for (long long r = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; r < rows; r += ngroups) {
     Row xv, gv;
     xv.load(x + r * dim, dim, lane_g);
@@ -609,6 +616,8 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict_
       const int e = Row::index(i, dim, lane_g);
       if (e >= 0) {
         xv.a[i] = (xv.a[i] - m) * rs;                      // xhat
+        pb[i] += gv.a[i];
+        pg[i] += gv.a[i] * xv.a[i];
         gv.a[i] *= gamma != nullptr ? gamma[e] : 1.f;      // g = dy * gamma
         s1 += gv.a[i];
         s2 += gv.a[i] * xv.a[i];
@@ -618,6 +627,28 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NA; ++i) gv.a[i] = rs * (gv.a[i] - m1 - xv.a[i] * m2);
     gv.store(dx + r * dim, dim, lane_g);
+  }
+  if (partial != nullptr) {
+    __shared__ float red[2][256 * NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      red[0][threadIdx.x * NA + i] = pb[i];
+      red[1][threadIdx.x * NA + i] = pg[i];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < G * NA; t += 256) {
+      const int lane = t / NA, i = t % NA;
+      const int e = Row::index(i, dim, lane);
+      if (e < 0) continue;
+      float s0 = 0.f, s1 = 0.f;
+      for (int gi = 0; gi < 256 / G; ++gi) {
+        s0 += red[0][(gi * G + lane) * NA + i];
+        s1 += red[1][(gi * G + lane) * NA + i];
+      }
+      float* dst = partial + (static_cast<long long>(blockIdx.x) * dim + e) * 2;
+      dst[0] = s0;
+      dst[1] = s1;
+    }
   }
 }
 
@@ -666,17 +697,21 @@ __global__ __launch_bounds__(256) void ln_bwd_partial_kernel(const float* __rest
 }
 
 constexpr int kLnRows = 1024;     // rows per workgroup of the dgamma / dbeta reduction
+constexpr int kLnFusedBlocks = 4 * kCUs;   // workgroups of the dx kernel when it also leaves the parameter-gradient partials
 static int ln_blocks(int64_t rows) { return static_cast<int>((rows + kLnRows - 1) / kLnRows); }
 
 template <int G, int NV, bool VEC>
 static int launch_ln(bool bwd, const float* x, const float* dy, int64_t rows, int dim, const float* gamma, const float* beta,
-                     float eps, float* mean, float* rstd, float* out, hipStream_t s) {
+                     float eps, float* mean, float* rstd, float* out, hipStream_t s, float* partial = nullptr,
+                     int* n_partial = nullptr) {
   const int gpb = 256 / G;
   long long blocks = (rows + gpb - 1) / gpb;
   if (blocks > kCUs * 16) blocks = kCUs * 16;
+  if (partial != nullptr && blocks > kLnFusedBlocks) blocks = kLnFusedBlocks;   // (the final kernel adds one partial per workgroup)
+  if (n_partial != nullptr) *n_partial = static_cast<int>(blocks);
   if (bwd)
     hipLaunchKernelGGL((ln_bwd_dx_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, x, dy,
-                       static_cast<long long>(rows), dim, gamma, mean, rstd, out);
+                       static_cast<long long>(rows), dim, gamma, mean, rstd, out, partial);
   else
     hipLaunchKernelGGL((ln_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, x,
                        static_cast<long long>(rows), dim, gamma, beta, eps, mean, rstd, out);
@@ -685,17 +720,18 @@ static int launch_ln(bool bwd, const float* x, const float* dy, int64_t rows, in
 
 template <bool VEC>
 static int dispatch_ln(bool bwd, const float* x, const float* dy, int64_t rows, int dim, const float* gamma, const float* beta,
-                       float eps, float* mean, float* rstd, float* out, hipStream_t s) {
+                       float eps, float* mean, float* rstd, float* out, hipStream_t s, float* partial = nullptr,
+                       int* n_partial = nullptr) {
   switch (pow2_ceil(VEC ? dim / 4 : dim)) {
-    case 1: return launch_ln<1, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s);
-    case 2: return launch_ln<2, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s);
-    case 4: return launch_ln<4, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s);
-    case 8: return launch_ln<8, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s);
-    case 16: return launch_ln<16, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s);
-    case 32: return launch_ln<32, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s);
-    case 64: return launch_ln<64, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s);
-    case 128: return launch_ln<64, 2, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s);
-    case 256: return launch_ln<64, 4, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s);
+    case 1: return launch_ln<1, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s, partial, n_partial);
+    case 2: return launch_ln<2, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s, partial, n_partial);
+    case 4: return launch_ln<4, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s, partial, n_partial);
+    case 8: return launch_ln<8, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s, partial, n_partial);
+    case 16: return launch_ln<16, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s, partial, n_partial);
+    case 32: return launch_ln<32, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s, partial, n_partial);
+    case 64: return launch_ln<64, 1, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s, partial, n_partial);
+    case 128: return launch_ln<64, 2, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s, partial, n_partial);
+    case 256: return launch_ln<64, 4, VEC>(bwd, x, dy, rows, dim, gamma, beta, eps, mean, rstd, out, s, partial, n_partial);
     default: return fail(RBX_ERR_UNSUPPORTED, "layernorm: dim %d too large for one lane group", dim);
   }
 }
@@ -719,7 +755,8 @@ extern "C" int rbx_layernorm_fwd(const float* d_x, int64_t rows, int32_t dim, co
 
 extern "C" size_t rbx_layernorm_bwd_workspace_size(int64_t rows, int32_t dim) {
   if (rows <= 0 || dim <= 0) return 0;
-  return static_cast<size_t>(rbx::ln_blocks(rows)) * dim * 2 * sizeof(float) + 256;
+  const size_t nb = static_cast<size_t>(rbx::ln_blocks(rows) > rbx::kLnFusedBlocks ? rbx::ln_blocks(rows) : rbx::kLnFusedBlocks);
+  return nb * dim * 2 * sizeof(float) + 256;
 }
 
 extern "C" int rbx_layernorm_bwd(const float* d_x, const float* d_dy, int64_t rows, int32_t dim, const float* d_gamma,
@@ -731,18 +768,29 @@ extern "C" int rbx_layernorm_bwd(const float* d_x, const float* d_dy, int64_t ro
   if (!d_x || !d_dy || !d_mean || !d_rstd) return fail(RBX_ERR_INVALID, "layernorm_bwd: NULL tensor");
   hipStream_t s = as_stream(stream);
   int rc = RBX_OK;
-  if (d_dx != nullptr) {
-    rc = ln_vec(dim, d_x, d_dy, d_dx)
-             ? dispatch_ln<true>(true, d_x, d_dy, rows, dim, d_gamma, nullptr, 0.f, const_cast<float*>(d_mean),
-                                 const_cast<float*>(d_rstd), d_dx, s)
-             : dispatch_ln<false>(true, d_x, d_dy, rows, dim, d_gamma, nullptr, 0.f, const_cast<float*>(d_mean),
-                                  const_cast<float*>(d_rstd), d_dx, s);
-    if (rc != RBX_OK) return rc;
-  }
-  if (d_dgamma != nullptr || d_dbeta != nullptr) {
+  const bool want_p = d_dgamma != nullptr || d_dbeta != nullptr;
+  if (want_p) {
     if (d_dgamma == nullptr || d_dbeta == nullptr) return fail(RBX_ERR_INVALID, "layernorm_bwd: d_dgamma and d_dbeta come together");
     if (d_workspace == nullptr || workspace_bytes < rbx_layernorm_bwd_workspace_size(rows, dim))
       return fail(RBX_ERR_WORKSPACE, "layernorm_bwd: workspace too small");
+  }
+  if (d_dx != nullptr) {
+    // with the parameter gradients wanted too, their block partials come out of the dx pass (one read of x and dy)
+    float* fused = want_p ? static_cast<float*>(d_workspace) : nullptr;
+    int nb = 0;
+    rc = ln_vec(dim, d_x, d_dy, d_dx)
+             ? dispatch_ln<true>(true, d_x, d_dy, rows, dim, d_gamma, nullptr, 0.f, const_cast<float*>(d_mean),
+                                 const_cast<float*>(d_rstd), d_dx, s, fused, &nb)
+             : dispatch_ln<false>(true, d_x, d_dy, rows, dim, d_gamma, nullptr, 0.f, const_cast<float*>(d_mean),
+                                  const_cast<float*>(d_rstd), d_dx, s, fused, &nb);
+    if (rc != RBX_OK) return rc;
+    if (want_p) {
+      hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, fused, nb, dim, d_dbeta, d_dgamma);
+      return check_launch("layernorm parameter-gradient kernel");
+    }
+    return rc;
+  }
+  if (want_p) {
     float* partial = static_cast<float*>(d_workspace);
     const int nb = ln_blocks(rows);
     hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3((dim + 63) / 64, nb), dim3(256), 0, s, d_x, d_dy, static_cast<long long>(rows),
