@@ -467,28 +467,51 @@ static void launch_wide(const float* A, long long lda, const float* B, long long
 // C[i] = sum_z part[z][i] in a fixed order.  A workgroup owns 64 outputs; its 4 wavefronts take every 4th slice
 // (4 independent partial sums each, so the loads overlap) and meet in LDS.  The earlier one-thread-per-output
 // loop ran 148 us for 512 slices of a [64, 64] weight gradient: 16 workgroups of dependent loads.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const long long n,
-                                                            const int splits, float* __restrict__ out) {
-  __shared__ float red[4][64];
+constexpr int kRedZ = 16;                  // slices summed side by side per output (wavefronts of the reduce workgroup)
+__global__ __launch_bounds__(64 * kRedZ) void splitk_reduce_kernel(const float* __restrict__ part, const long long n,
+                                                                    const int splits, float* __restrict__ out,
+                                                                    const float* __restrict__ part2, const long long n2,
+                                                                    float* __restrict__ out2, const int blocks1) {
+  // (part2, n2, out2): a second, smaller reduction over the same number of slices rides in the same launch -- the bias
+  // partials beside the weight partials -- in the workgroups from blocks1 on
+  __shared__ float red[kRedZ][64];
   const int col = threadIdx.x & 63, zl = threadIdx.x >> 6;
-  for (long long i0 = static_cast<long long>(blockIdx.x) * 64; i0 < n; i0 += static_cast<long long>(gridDim.x) * 64) {
+  const bool second = static_cast<int>(blockIdx.x) >= blocks1;
+  const float* src = second ? part2 : part;
+  float* dst = second ? out2 : out;
+  const long long nn = second ? n2 : n;
+  const long long b0 = second ? blockIdx.x - blocks1 : blockIdx.x;
+  const long long nb = second ? gridDim.x - blocks1 : blocks1;
+  for (long long i0 = b0 * 64; i0 < nn; i0 += nb * 64) {
     const long long i = i0 + col;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    if (i < n) {
+    if (i < nn) {
       int z = zl;
-      for (; z + 12 < splits; z += 16) {
-        t0 += part[static_cast<long long>(z) * n + i];
-        t1 += part[static_cast<long long>(z + 4) * n + i];
-        t2 += part[static_cast<long long>(z + 8) * n + i];
-        t3 += part[static_cast<long long>(z + 12) * n + i];
+      for (; z + 3 * kRedZ < splits; z += 4 * kRedZ) {
+        t0 += src[static_cast<long long>(z) * nn + i];
+        t1 += src[static_cast<long long>(z + kRedZ) * nn + i];
+        t2 += src[static_cast<long long>(z + 2 * kRedZ) * nn + i];
+        t3 += src[static_cast<long long>(z + 3 * kRedZ) * nn + i];
       }
-      for (; z < splits; z += 4) t0 += part[static_cast<long long>(z) * n + i];
+      for (; z < splits; z += kRedZ) t0 += src[static_cast<long long>(z) * nn + i];
     }
     red[zl][col] = (t0 + t1) + (t2 + t3);
     __syncthreads();
-    if (zl == 0 && i < n) out[i] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (zl == 0 && i < nn) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kRedZ; ++w) t += red[w][col];
+      dst[i] = t;
+    }
     __syncthreads();
   }
+}
+
+static void launch_splitk_reduce(hipStream_t s, unsigned blocks, const float* part, long long n, int splits, float* out,
+                                 const float* part2 = nullptr, long long n2 = 0, float* out2 = nullptr) {
+  const unsigned blocks2 = part2 != nullptr ? static_cast<unsigned>((n2 + 63) / 64) : 0u;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + blocks2), dim3(64 * kRedZ), 0, s, part, n, splits, out, part2, n2,
+                     out2, static_cast<int>(blocks));
 }
 
 // dy' = dy * (y > 0)   (ReLU backward, in a scratch buffer so dy stays intact)
@@ -791,7 +814,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     const long long n = static_cast<long long>(M) * N;
     long long blocks = (n + 63) / 64;
     if (blocks > kCUs * 8) blocks = kCUs * 8;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, ws, n, splits, C);
+    launch_splitk_reduce(s, static_cast<unsigned>(blocks), ws, n, splits, C);
     rc = check_launch("splitk_reduce_kernel");
   }
   return rc;
@@ -853,8 +876,17 @@ extern "C" int rbx_linear_dx_fused(const float* d_dy, int64_t dy_stride, const f
 }
 
 // split-K scratch of the weight gradient: room for 2 x CUs slices of [n, k], at most 64 MiB
+// workgroups of tall_dw_kernel at most (each leaves an [n, k] partial): RBX_TALL_WGS, default 4 per CU -- measured on
+// SASRec's [819 200, 64] x [819 200, 64] weight gradients: 158 us with 512 workgroups, 118 with 1024, 124 with 2048 (and the
+// reduce over the partials grows with them).
+static int tall_wgs_max() {
+  static const int v = [] { const char* e = getenv("RBX_TALL_WGS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 4 * rbx::kCUs; }();
+  return v;
+}
+
 static size_t dw_ws_floats(int32_t n, int32_t k) {
-  const size_t want = static_cast<size_t>(n) * k * 2 * rbx::kCUs;
+  const size_t slices = static_cast<size_t>(tall_wgs_max() > 2 * rbx::kCUs ? tall_wgs_max() : 2 * rbx::kCUs);
+  const size_t want = static_cast<size_t>(n) * k * slices;
   const size_t cap = size_t(1) << 24;
   const size_t one = static_cast<size_t>(n) * k;
   return want < cap ? want : (cap > one ? cap : one);
@@ -865,7 +897,10 @@ extern "C" size_t rbx_linear_bwd_workspace_size(int64_t m, int32_t n, int32_t k,
   const size_t masked = (act == 1) ? static_cast<size_t>(m) * n : 0;
   const size_t splits = 2 * rbx::kCUs;
   const size_t dw = dw_ws_floats(n, k);
-  const size_t db = static_cast<size_t>((m + 1023) / 1024) * n;
+  // bias partials: one row of n floats per 1024-row block -- or per workgroup of the tall-and-narrow kernel, whichever is more
+  const size_t db_rows = static_cast<size_t>((m + 1023) / 1024) > static_cast<size_t>(tall_wgs_max())
+                             ? static_cast<size_t>((m + 1023) / 1024) : static_cast<size_t>(tall_wgs_max());
+  const size_t db = db_rows * n;
   (void)splits;
   return (masked + dw + db + 1024) * sizeof(float);
 }
@@ -916,10 +951,10 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
       hipLaunchKernelGGL(wcolsum_partial_kernel, dim3((k + 63) / 64, rb), dim3(256), 0, s, g, d_x,
                          static_cast<long long>(x_stride), M, k, static_cast<int>(rpb), ws, d_db != nullptr ? part : nullptr);
       if (d_dw != nullptr)
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>((k + 63) / 64)), dim3(256), 0, s, ws,
-                           static_cast<long long>(k), rb, d_dw);
-      if (d_db != nullptr)
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1), dim3(256), 0, s, part, 1LL, rb, d_db);
+        launch_splitk_reduce(s, static_cast<unsigned>((k + 63) / 64), ws, static_cast<long long>(k), rb, d_dw,
+                             d_db != nullptr ? part : nullptr, 1LL, d_db);
+      else if (d_db != nullptr)
+        launch_splitk_reduce(s, 1u, part, 1LL, rb, d_db);
     }
     return check_launch("logit head backward kernels");
   }
@@ -930,10 +965,9 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
   }
   if (d_dw != nullptr && n <= 256 && k <= 64 && m >= 8192) {
     // tall and narrow: one streaming pass over g and x leaves dW and db partials per workgroup (tall_dw_kernel)
-    const int rb = static_cast<int>((m + 1023) / 1024);                       // db partial rows the workspace holds
     long long n_wg = static_cast<long long>(dw_floats / (static_cast<size_t>(n) * k));
-    if (n_wg > 4 * kCUs) n_wg = 4 * kCUs;
-    if (n_wg > rb) n_wg = rb;
+    if (n_wg > tall_wgs_max()) n_wg = tall_wgs_max();
+    if (n_wg > (m + 63) / 64) n_wg = (m + 63) / 64;
     int rows_per_wg = static_cast<int>((m + n_wg - 1) / n_wg);
     rows_per_wg = (rows_per_wg + 15) / 16 * 16;
     n_wg = (m + rows_per_wg - 1) / rows_per_wg;
@@ -949,11 +983,8 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     }
     const long long nk = static_cast<long long>(n) * k;
     long long blocks = (nk + 63) / 64;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, ws, nk,
-                       static_cast<int>(n_wg), d_dw);
-    if (d_db != nullptr)
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1), dim3(256), 0, s, part, static_cast<long long>(n),
-                         static_cast<int>(n_wg), d_db);
+    launch_splitk_reduce(s, static_cast<unsigned>(blocks), ws, nk, static_cast<int>(n_wg), d_dw,
+                         d_db != nullptr ? part : nullptr, static_cast<long long>(n), d_db);       // dW and db in one launch
     return check_launch("tall dW / db kernels");
   }
   if (d_dw != nullptr) {
@@ -966,8 +997,7 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     const int rb = static_cast<int>((m + 1023) / 1024);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((n + 63) / 64, rb), dim3(256), 0, s, g, M, n, 1024, part);
     long long blocks = (n + 63) / 64;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, part,
-                       static_cast<long long>(n), rb, d_db);
+    launch_splitk_reduce(s, static_cast<unsigned>(blocks), part, static_cast<long long>(n), rb, d_db);
     rc = check_launch("bias grad kernels");
   }
   return rc;
