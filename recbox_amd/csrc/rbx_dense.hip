@@ -744,6 +744,18 @@ static bool vec_ok(const float* p, long long ld) { return (reinterpret_cast<uint
 // RBX_GEMM_WIDE=1 routes 64 < N <= 448 with N % 128 != 0 to the wide kernel, 2 also N = 128 / 256 / 384.  Off by default:
 // measured at cfg 4 (profiles/r02/gemm_variants.txt) the layer-1 forward takes 0.957 ms wide against 0.930 ms on the
 // 128 x 128 + narrow pair, the whole step 7.07 against 7.02 ms -- parity at best: the k-loop, not the tiling, is the limit.
+// Unused dynamic LDS that limits the 128 x 128 kernel to THREE workgroups per CU (3 x (33.8 + 8) KB fit, a fourth does not)
+// when that makes the launch whole rounds of the resident set: 1536 tiles (cfg 4's [65536, 1677] x [1677, 400]) are 1.5 rounds
+// of 1024 resident workgroups but exactly 2 rounds of 768.  RBX_GEMM_ROUNDS=0 switches it off.
+static size_t gemm_lds_pad(long long wgs) {
+  static const int mode = [] { const char* e = getenv("RBX_GEMM_ROUNDS"); return e ? atoi(e) : 0; }();
+  if (mode == 0) return 0;
+  if (mode == 2) return 8192;                       // always three per CU
+  const long long r4 = (wgs + 4 * kCUs - 1) / (4 * kCUs), r3 = (wgs + 3 * kCUs - 1) / (3 * kCUs);
+  const double e4 = static_cast<double>(wgs) / (r4 * 4.0 * kCUs), e3 = static_cast<double>(wgs) / (r3 * 3.0 * kCUs);
+  return (e3 > e4 + 0.1) ? 8192 : 0;
+}
+
 static int wide_mode() {
   static int mode = -1;
   if (mode < 0) {
@@ -796,7 +808,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   const int tail = N % BN;
   const int tn_full = (splits == 1 && tail > 0 && tail <= 64) ? N / BN : tn;
   if (tn_full > 0)
-    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm, 1, splits), dim3(256), 0, s, A, lda, B, ldb, dst,
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm, 1, splits), dim3(256), gemm_lds_pad(tn_full * tm * splits), s, A, lda, B, ldb, dst,
                        (splits > 1) ? static_cast<long long>(N) : ldc, M, N, K, kps, bias, act, vec_ok(A, lda),
                        vec_ok(B, ldb), tm, tn_full, epi);
   if (tn_full < tn) {
