@@ -299,6 +299,16 @@ int rbx_l2norm_fwd(const float* d_x, int64_t rows, int32_t dim, float eps, float
  * columns of one [B, width] block (youtube_dnn.py:52-70), without a contiguous copy.  d_y [rows, dim] is contiguous. */
 int rbx_l2norm_fwd_strided(const float* d_x, int64_t inner, int64_t outer_stride, int64_t rows, int32_t dim, float eps,
                            float* d_y, float* d_inv, void* stream);
+/* F.normalize of the candidate rows and their inner product with the (already normalised) user vector in ONE pass
+ * (youtube_dnn.py:56,65,70): out[b, n] = scale * <u[b], v[b, n]> / max(|v[b, n]|, eps); d_inv[b, n] keeps 1 / max(|v|, eps)
+ * (negative when the clamp was active).  The normalised rows are never materialised.  v rows at d_v + b * v_outer_stride +
+ * n * dim (read where the gather left them); backward: d_du[b] = sum_n scale dout v_hat, d_dv rows (the projection of
+ * scale dout u / |v| orthogonal to v_hat; plain when clamped) at d_dv + b * dv_outer_stride + n * dim. */
+int rbx_cosdot_fwd(const float* d_u, const float* d_v, int64_t v_outer_stride, int64_t batch, int32_t n_cand, int32_t dim,
+                   float eps, float scale, float* d_out, float* d_inv, void* stream);
+int rbx_cosdot_bwd(const float* d_u, const float* d_v, int64_t v_outer_stride, const float* d_inv, const float* d_dout,
+                   int64_t batch, int32_t n_cand, int32_t dim, float scale, float* d_du, float* d_dv,
+                   int64_t dv_outer_stride, void* stream);
 int rbx_l2norm_bwd(const float* d_y, const float* d_inv, const float* d_dy, int64_t rows, int32_t dim,
                    float* d_dx, void* stream);
 int rbx_pairdot_fwd(const float* d_u, const float* d_v, int64_t batch, int32_t n_cand, int32_t dim, float scale,

@@ -118,6 +118,8 @@ SIGNATURES = {
     "rbx_pairmul_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _P, _P, _P]),
     "rbx_l2norm_fwd": (ctypes.c_int, [_P, _i64, _i32, _f32, _P, _P, _P]),
     "rbx_l2norm_fwd_strided": (ctypes.c_int, [_P, _i64, _i64, _i64, _i32, _f32, _P, _P, _P]),
+    "rbx_cosdot_fwd": (ctypes.c_int, [_P, _P, _i64, _i64, _i32, _i32, _f32, _f32, _P, _P, _P]),
+    "rbx_cosdot_bwd": (ctypes.c_int, [_P, _P, _i64, _P, _P, _i64, _i32, _i32, _f32, _P, _P, _i64, _P]),
     "rbx_l2norm_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _P, _P]),
     "rbx_pairdot_fwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _f32, _P, _P]),
     "rbx_pairdot_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _f32, _P, _P, _P]),

@@ -89,6 +89,79 @@ __global__ __launch_bounds__(256) void pairdot_bwd_kernel(const float* __restric
   }
 }
 
+// ---- normalise the candidates and score them in ONE pass (YoutubeDNN: youtube_dnn.py:56,65,70 -- F.normalize of the
+// [B, 1 + n_neg, D] item rows, then the inner product with the normalised user vector) -------------------------------
+// out[b, n] = scale * <u[b], v[b, n]> / max(|v[b, n]|, eps);  inv[b, n] = 1 / max(|v|, eps), NEGATIVE when the clamp was active.
+// The normalised rows are never written (168 MB at cfg 3) nor read back by a second kernel.  v rows sit at
+// v + b * v_outer + n * D: behind the user columns of the gathered block, read in place.
+template <int G>
+__global__ __launch_bounds__(256) void cosdot_fwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                         const long long v_outer, const long long pairs, const int N,
+                                                         const int D, const float eps, const float scale,
+                                                         float* __restrict__ out, float* __restrict__ inv) {
+  const int lane_g = threadIdx.x % G;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
+  for (long long p = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; p < pairs; p += ngroups) {
+    const long long b = p / N;
+    const float* vr = v + b * v_outer + (p - b * N) * D;
+    float ss = 0.f, t = 0.f;
+    for (int d = lane_g; d < D; d += G) {
+      const float x = vr[d];
+      ss += x * x;
+      t += u[b * D + d] * x;
+    }
+    ss = group_sum<G>(ss);
+    t = group_sum<G>(t);
+    const float nrm = sqrtf(ss);
+    const bool clamped = nrm < eps;
+    const float s = 1.0f / (clamped ? eps : nrm);
+    if (lane_g == 0) {
+      out[p] = t * s * scale;
+      inv[p] = clamped ? -s : s;
+    }
+  }
+}
+
+// Backward, one lane group per sample (du is summed over its candidates in order):
+//   vh = v * |inv|;  c = <u, vh>;  g = scale * dout[b, n]
+//   dv = |inv| * g * (u - vh * c)      (|inv| * g * u when the norm was clamped: the l2norm backward's rule)
+//   du[b] = sum_n g * vh
+// dv rows are written at dv + b * dv_outer + n * D (the gradient block mirrors the layout the rows were read from).
+template <int G>
+__global__ __launch_bounds__(256) void cosdot_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v,
+                                                         const long long v_outer, const float* __restrict__ inv,
+                                                         const float* __restrict__ dout, const long long B, const int N,
+                                                         const int D, const float scale, float* __restrict__ du,
+                                                         float* __restrict__ dv, const long long dv_outer) {
+  const int lane_g = threadIdx.x % G;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
+  for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
+    for (int n = 0; n < N; ++n) {
+      const float si = inv[b * N + n];
+      const float a = fabsf(si);
+      const float* vr = v + b * v_outer + static_cast<long long>(n) * D;
+      float c = 0.f;
+      if (si > 0.f) {
+        for (int d = lane_g; d < D; d += G) c += u[b * D + d] * (vr[d] * a);
+        c = group_sum<G>(c);
+      }
+      const float g = dout[b * N + n] * scale;
+      if (dv != nullptr) {
+        float* dr = dv + b * dv_outer + static_cast<long long>(n) * D;
+        for (int d = lane_g; d < D; d += G) dr[d] = a * g * (u[b * D + d] - (si > 0.f ? vr[d] * a * c : 0.f));
+      }
+    }
+    if (du != nullptr) {
+      for (int d = lane_g; d < D; d += G) {
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n)
+          acc += dout[b * N + n] * scale * (v[b * v_outer + static_cast<long long>(n) * D + d] * fabsf(inv[b * N + n]));
+        du[b * D + d] = acc;
+      }
+    }
+  }
+}
+
 static int pick_g(int D) {
   int g = pow2_ceil(D);
   return g > 64 ? 64 : g;
@@ -163,6 +236,42 @@ extern "C" int rbx_l2norm_bwd(const float* d_y, const float* d_inv, const float*
   RBX_DISPATCH_G(g, CALL)
 #undef CALL
   return check_launch("l2norm_bwd_kernel");
+}
+
+extern "C" int rbx_cosdot_fwd(const float* d_u, const float* d_v, int64_t v_outer_stride, int64_t batch, int32_t n_cand,
+                              int32_t dim, float eps, float scale, float* d_out, float* d_inv, void* stream) {
+  if (batch == 0) return RBX_OK;
+  using namespace rbx;
+  if (!d_u || !d_v || !d_out || !d_inv) return fail(RBX_ERR_INVALID, "cosdot: NULL tensor");
+  if (batch < 0 || n_cand <= 0 || dim <= 0 || v_outer_stride < static_cast<int64_t>(n_cand) * dim)
+    return fail(RBX_ERR_INVALID, "cosdot: bad shape / outer stride shorter than n_cand * dim");
+  const int g = pick_g(dim);
+  const long long pairs = static_cast<long long>(batch) * n_cand;
+  hipStream_t s = as_stream(stream);
+#define CALL(GG) hipLaunchKernelGGL((cosdot_fwd_kernel<GG>), dim3(grid_for(pairs, GG)), dim3(256), 0, s, d_u, d_v, \
+                                    static_cast<long long>(v_outer_stride), pairs, n_cand, dim, eps, scale, d_out, d_inv)
+  RBX_DISPATCH_G(g, CALL)
+#undef CALL
+  return check_launch("cosdot_fwd_kernel");
+}
+
+extern "C" int rbx_cosdot_bwd(const float* d_u, const float* d_v, int64_t v_outer_stride, const float* d_inv,
+                              const float* d_dout, int64_t batch, int32_t n_cand, int32_t dim, float scale, float* d_du,
+                              float* d_dv, int64_t dv_outer_stride, void* stream) {
+  if (batch == 0) return RBX_OK;
+  using namespace rbx;
+  if (!d_u || !d_v || !d_inv || !d_dout) return fail(RBX_ERR_INVALID, "cosdot_bwd: NULL tensor");
+  if (batch < 0 || n_cand <= 0 || dim <= 0 || v_outer_stride < static_cast<int64_t>(n_cand) * dim ||
+      (d_dv != nullptr && dv_outer_stride < static_cast<int64_t>(n_cand) * dim))
+    return fail(RBX_ERR_INVALID, "cosdot_bwd: bad shape / outer stride shorter than n_cand * dim");
+  const int g = pick_g(dim);
+  hipStream_t s = as_stream(stream);
+#define CALL(GG) hipLaunchKernelGGL((cosdot_bwd_kernel<GG>), dim3(grid_for(batch, GG)), dim3(256), 0, s, d_u, d_v, \
+                                    static_cast<long long>(v_outer_stride), d_inv, d_dout, static_cast<long long>(batch), \
+                                    n_cand, dim, scale, d_du, d_dv, static_cast<long long>(dv_outer_stride))
+  RBX_DISPATCH_G(g, CALL)
+#undef CALL
+  return check_launch("cosdot_bwd_kernel");
 }
 
 extern "C" int rbx_pairdot_fwd(const float* d_u, const float* d_v, int64_t batch, int32_t n_cand, int32_t dim,

@@ -1228,6 +1228,56 @@ def pair_dot(u, v, scale=1.0):
     return _PairDot.apply(u, v, scale)
 
 
+class _CosDot(torch.autograd.Function):
+    """out[b, n] = scale * <u[b], v[b, n]> / max(|v[b, n]|, eps): F.normalize of the candidate rows fused into their inner
+    product with the (already normalised) user vector (rbx_cosdot_*).  v [B, N, D] may be a view into a wider row block
+    (stride(0) >= N * D): it is read in place, and its gradient is written into a buffer of the SAME geometry -- row stride,
+    leading columns -- so that ``split_last(..., views=True)`` can hand the whole block back without a concatenation."""
+
+    @staticmethod
+    def forward(ctx, u, v, eps, scale):
+        _require_cuda(u, "user embedding")
+        B, N, D = v.shape
+        u2 = u.reshape(B, D).contiguous().float()
+        if not (v.dtype == torch.float32 and v.stride(2) == 1 and v.stride(1) == D and (B <= 1 or v.stride(0) >= N * D)):
+            v = v.contiguous().float()
+        outer = v.stride(0) if B > 1 else N * D
+        out = torch.empty((B, N), dtype=torch.float32, device=u.device)
+        inv = torch.empty((B, N), dtype=torch.float32, device=u.device)
+        check(lib.rbx_cosdot_fwd(_ptr(u2), _ptr(v), outer, B, N, D, float(eps), float(scale), _ptr(out), _ptr(inv), _stream()))
+        ctx.save_for_backward(u2, v, inv)
+        ctx.meta = (float(scale), u.shape, outer)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u2, v, inv = ctx.saved_tensors
+        scale, ushape, outer = ctx.meta
+        B, N, D = v.shape
+        dout = dout.reshape(B, N).contiguous().float()
+        du = torch.empty_like(u2) if ctx.needs_input_grad[0] else None
+        dv = None
+        if ctx.needs_input_grad[1]:
+            lead = v.storage_offset() % outer if outer > N * D else 0
+            if outer > N * D and lead + N * D <= outer:
+                # the rows were read behind `lead` columns of a [B, outer] block: their gradient goes to the same place of
+                # a block of that shape (the leading columns are left for whoever owns them: _SplitLast.backward)
+                base = torch.empty(B * outer, dtype=torch.float32, device=v.device)
+                dv = torch.empty(0, dtype=torch.float32, device=v.device).set_(base.untyped_storage(), lead, (B, N, D),
+                                                                               (outer, D, 1))
+            else:
+                dv = torch.empty((B, N, D), dtype=torch.float32, device=v.device)
+        check(lib.rbx_cosdot_bwd(_ptr(u2), _ptr(v), outer, _ptr(inv), _ptr(dout), B, N, D, scale, _ptr(du), _ptr(dv),
+                                 dv.stride(0) if (dv is not None and B > 1) else N * D, _stream()))
+        return (du.view(ushape) if du is not None else None), dv, None, None
+
+
+def cos_dot(u, v, eps=1e-12, scale=1.0):
+    """``scale * (u.unsqueeze(1) * F.normalize(v, p=2, dim=-1, eps=eps)).sum(-1)`` for u [B, D] (or [B, 1, D]) already normalised
+    and candidate rows v [B, N, D]: one pass over v, the normalised rows are never written."""
+    return _CosDot.apply(u, v, eps, scale)
+
+
 _dot_plans = {}
 
 
@@ -1646,6 +1696,24 @@ def shared_prefix(x, n, copies=2):
     return _SharedPrefix.apply(x, int(n), int(copies))
 
 
+def _block_behind(gb, shape, n):
+    """gb [rows, cols - n] that is the trailing-column view of a [rows, cols] fp32 buffer of its own (``_CosDot.backward``
+    allocates its gradient like that): the whole buffer as a tensor of ``shape``; else None."""
+    if len(shape) != 2 or gb.dim() < 2 or gb.dtype != torch.float32 or not gb.is_cuda:
+        return None
+    rows, cols = shape
+    g2 = gb if gb.dim() == 2 else None
+    if g2 is None:
+        if gb.dim() == 3 and gb.stride(2) == 1 and gb.stride(1) == gb.shape[2]:
+            g2 = gb.as_strided((gb.shape[0], gb.shape[1] * gb.shape[2]), (gb.stride(0), 1), gb.storage_offset())
+        else:
+            return None
+    if (g2.shape != (rows, cols - n) or g2.stride(1) != 1 or g2.stride(0) != cols or g2.storage_offset() != n
+            or g2.untyped_storage().nbytes() != rows * cols * 4 or rows < 2):
+        return None
+    return torch.empty(0, dtype=torch.float32, device=gb.device).set_(g2.untyped_storage(), 0, (rows, cols), (cols, 1))
+
+
 class _SplitLast(torch.autograd.Function):
     """x[..., :n], x[..., n:] as two CONTIGUOUS tensors (or, ``views``, as the two slices themselves); backward is one
     concatenation."""
@@ -1668,6 +1736,10 @@ class _SplitLast(torch.autograd.Function):
             ga = ref.new_zeros(ctx.shape[:-1] + (ctx.n,))
         if gb is None:
             gb = ref.new_zeros(ctx.shape[:-1] + (ctx.shape[-1] - ctx.n,))
+        whole = _block_behind(gb, ctx.shape, ctx.n)
+        if whole is not None:                     # gb already sits in a block of x's shape: only the leading columns move
+            whole[..., :ctx.n].copy_(ga)
+            return whole, None, None
         return torch.cat([ga, gb], dim=-1), None, None
 
 

@@ -71,9 +71,11 @@ class YoutubeDNN(torch.nn.Module):
             # the two column blocks in place (the tower's first GEMM and the normalisation take a row stride); backward = one
             # concatenation
             user_in, items = ops.split_last(both, self.user_dims, views=True)
-            user_embedding = ops.l2_normalize(self.user_mlp(user_in)).unsqueeze(1)
-            item_embedding = ops.l2_normalize(items.unflatten(1, (-1, dim)))
-            return ops.pair_dot(user_embedding, item_embedding, scale=1.0 / self.temperature)   # [B, 1 + n_neg]
+            user_embedding = ops.l2_normalize(self.user_mlp(user_in))
+            # F.normalize of the item rows + the inner product in one pass over them (rbx_cosdot_*): the normalised
+            # [B, 1 + n_neg, D] block is never written, and its gradient lands in a block of `both`'s shape
+            return ops.cos_dot(user_embedding, items.unflatten(1, (-1, dim)), eps=1e-12,
+                               scale=1.0 / self.temperature)                                    # [B, 1 + n_neg]
         # (a squeezed gather lays DenseFeature values out AFTER every embedding of the call -- layers.py:109-114 --, so
         #  with dense user features the single gather above would put them behind the item / negative rows: the towers
         #  are then looked up separately, as youtube_dnn.py:46-70 does)

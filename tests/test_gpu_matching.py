@@ -912,3 +912,42 @@ def test_l2_normalize_reads_rows_inside_a_wider_block():
     assert float(wide.grad[:, lead + n * D:].abs().max()) == 0.0
     ref = F.normalize(b0.detach().view(B, n, D).double(), dim=-1).float()
     assert_close(y1, ref, 1e-6)
+
+
+def test_cos_dot_fuses_the_normalisation_and_mirrors_the_gradient_layout():
+    """ops.cos_dot(u, v) == scale * <u, F.normalize(v)> (values, both gradients, the eps clamp on a zero row) for contiguous
+    rows and for rows read behind the leading columns of a wider block; in the second case the gradient comes back in a block
+    of the same shape and ops.split_last(views=True) returns it whole -- same numbers as the concatenating route."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, N, D, lead = 257, 5, 32, 64
+    u0 = F.normalize(torch.randn(B, D, generator=g), dim=-1)
+    blk0 = torch.randn(B, lead + N * D, generator=g)
+    blk0[3, lead + D:lead + 2 * D] = 0.0                                    # a zero candidate row
+    w = torch.randn(B, N, generator=g)
+    # float64 restatement
+    ur = u0.double().requires_grad_(True)
+    br = blk0.double().requires_grad_(True)
+    vr = br[:, lead:].unflatten(1, (N, D))
+    outr = 7.0 * (ur.unsqueeze(1) * F.normalize(vr, p=2, dim=-1, eps=1e-12)).sum(-1)
+    ((outr * w.double()).sum() + (br[:, :lead] * 0.5).sum()).backward()
+    for views in (True, False):
+        u = u0.cuda().requires_grad_(True)
+        blk = blk0.cuda().requires_grad_(True)
+        a, b = ops.split_last(blk, lead, views=views)
+        out = ops.cos_dot(u, b.unflatten(1, (N, D)), eps=1e-12, scale=7.0)
+        ((out * w.cuda()).sum() + (a * 0.5).sum()).backward()
+        assert_close(out, outr.float(), 1e-5, "values (views=%s)" % views)
+        assert_close(u.grad, ur.grad.float(), 1e-5, "du (views=%s)" % views)
+        assert_close(blk.grad, br.grad.float(), 1e-5, "d block (views=%s)" % views)
+    # the view route really skipped the concatenation: its gradient block is the buffer cos_dot wrote into
+    blk = blk0.cuda().requires_grad_(True)
+    a, b = ops.split_last(blk, lead, views=True)
+    seen = {}
+    def remember(gr):
+        seen["ptr"] = gr.untyped_storage().data_ptr()
+
+    hook = b.register_hook(remember)
+    ops.cos_dot(u0.cuda(), b.unflatten(1, (N, D)), scale=1.0).sum().backward()
+    hook.remove()
+    assert blk.grad.untyped_storage().data_ptr() == seen["ptr"]
