@@ -490,6 +490,18 @@ int rbx_linear_fwd_fused(const float* d_x, int64_t x_stride, const float* d_w, c
 int rbx_linear_dx_fused(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
                         const float* d_mask, int64_t mask_stride, const float* d_residual, int64_t residual_stride,
                         float* d_dx, int64_t dx_stride, void* stream);
+/* DeepFM (third_party/rechub/models/ranking/deepfm.py:34-42): one gathered block x [m, k] = [F * D embeddings | dense values] feeds
+ * the tower's first Linear, the FM term over its leading fm_cols = F * D columns and the first-order Linear over the same
+ * columns.  rbx_fm_sum_fwd: y_fm[b] = 0.5 sum_d (S_d^2 - sum_f e_fd^2) and S[b, d] = sum_f e[b, f, d] in one pass.
+ * rbx_linear_dx_deepfm: the block's WHOLE gradient out of the tower's dx GEMM --
+ *   dx[b, c] = sum_j dy[b, j] W[j, c]  +  [c < fm_cols] (g_fm[b] (S[b, c % fm_dim] - x[b, c]) + g_lr[b] lr_w[c])
+ * instead of three kernels writing three [m, fm_cols] gradients and a fourth adding them (d_lr_g / d_lr_w may be NULL). */
+int rbx_fm_sum_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch, int32_t n_fields, int32_t dim, float* d_out,
+                   float* d_sum, void* stream);
+int rbx_linear_dx_deepfm(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
+                         const float* d_x, int64_t x_stride, const float* d_fm_sum, int32_t fm_dim, int32_t fm_cols,
+                         const float* d_fm_g, const float* d_lr_g, const float* d_lr_w, float* d_dx, int64_t dx_stride,
+                         void* stream);
 
 /* ---- K6: fused masked-softmax attention for short sequences (L <= 256, head_dim in {4..64}) ----
  * ranking/pytorch/layers/attentions/dot_product_attention.py:31-43 (ScaledDotProductAttention) and the

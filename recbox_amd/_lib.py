@@ -127,6 +127,9 @@ SIGNATURES = {
     "rbx_linear_bwd_workspace_size": (_sz, [_i64, _i32, _i32, _i32]),
     "rbx_linear_fwd_fused": (ctypes.c_int, [_P, _i64, _P, _P, _i64, _i32, _i32, _i32, _P, _i64, _P, _P, _i64, _P]),
     "rbx_linear_dx_fused": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i64, _P, _i64, _P]),
+    "rbx_fm_sum_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _i32, _P, _P, _P]),
+    "rbx_linear_dx_deepfm": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i32, _i32, _P, _P, _P, _P, _i64,
+                                            _P]),
     "rbx_linear_bwd": (ctypes.c_int, [_P, _i64, _P, _P, _P, _i64, _i32, _i32, _i32, _P, _i64, _P, _P, _P, _sz, _P]),
     "rbx_attn_fwd": (ctypes.c_int, [_P, _P, _P, _P, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _P, _P, _P, _P]),
     "rbx_attn_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _i64, _i32, _i32, _i32, _f32, _i32, _f32,

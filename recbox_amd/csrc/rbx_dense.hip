@@ -43,10 +43,32 @@ struct Epi {
   const float* mask;
   long long ldmask;
   const float* rowscale;
+  // DeepFM's input block x [M, >= fm_cols] feeds the tower's first GEMM, the FM term and the first-order Linear.  With
+  // these set, the dx GEMM of the tower adds the other two readers' gradients to its output columns c < fm_cols:
+  //   + fm_g[row] * (fm_s[row, c % fm_dim] - fm_x[row, c])  +  lr_g[row] * lr_w[c]
+  // instead of three kernels writing three [M, fm_cols] gradients and a fourth one adding them.
+  const float* fm_x;
+  long long fm_ldx;
+  const float* fm_s;
+  const float* fm_g;
+  const float* lr_g;
+  const float* lr_w;
+  int fm_cols;
+  int fm_dim;
+  int fm_mask;            // fm_dim - 1 when fm_dim is a power of two (col & mask instead of col % dim), else -1
 };
+__device__ __forceinline__ float epi_fm_term(const Epi& e, int row, int col) {
+  if (e.fm_x == nullptr || col >= e.fm_cols) return 0.f;
+  const float x = e.fm_x[static_cast<long long>(row) * e.fm_ldx + col];
+  const int d = e.fm_mask >= 0 ? (col & e.fm_mask) : (col % e.fm_dim);
+  float t = e.fm_g[row] * (e.fm_s[static_cast<long long>(row) * e.fm_dim + d] - x);
+  if (e.lr_g != nullptr) t += e.lr_g[row] * e.lr_w[col];
+  return t;
+}
 __device__ __forceinline__ float epi_apply(const Epi& e, float v, int row, int col) {
   if (e.mask != nullptr) v = e.mask[static_cast<long long>(row) * e.ldmask + col] > 0.f ? v : 0.f;
   if (e.res != nullptr) v += e.res[static_cast<long long>(row) * e.ldres + col];
+  v += epi_fm_term(e, row, col);
   if (e.rowscale != nullptr) v *= e.rowscale[row];
   return v;
 }
@@ -294,6 +316,7 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
         if (act == 1) v = v > 0.f ? v : 0.f;
         if (has_mask) v = emask[j][r] > 0.f ? v : 0.f;
         if (has_res) v += eres[j][r];
+        v += epi_fm_term(epi, row, col);
         if (has_rs) v *= erow[r];
         C[static_cast<long long>(row) * ldc + col] = v;
       }
@@ -769,9 +792,9 @@ static int wide_mode() {
 template <bool AK, bool BK_>
 static int run_gemm(const float* A, long long lda, const float* B, long long ldb, float* C, int M, int N, int K,
                     const float* bias, int act, float* ws, size_t ws_floats, hipStream_t s, long long ldc = 0,
-                    const Epi epi = Epi{nullptr, 0, nullptr, 0, nullptr}) {
+                    const Epi epi = Epi{}) {
   if (ldc == 0) ldc = N;
-  const bool has_epi = epi.res != nullptr || epi.mask != nullptr || epi.rowscale != nullptr;
+  const bool has_epi = epi.res != nullptr || epi.mask != nullptr || epi.rowscale != nullptr || epi.fm_x != nullptr;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   int splits = 1;
   const long long tiles = static_cast<long long>(tm) * tn;
@@ -866,7 +889,10 @@ extern "C" int rbx_linear_fwd_fused(const float* d_x, int64_t x_stride, const fl
   if (x_stride < k || y_stride < n || (d_residual != nullptr && residual_stride < n))
     return fail(RBX_ERR_INVALID, "linear_fused: a row stride is shorter than its row");
   if (act != 0 && act != 1) return fail(RBX_ERR_UNSUPPORTED, "linear_fused: activation code %d", act);
-  const Epi epi{d_residual, static_cast<long long>(residual_stride), nullptr, 0, d_row_scale};
+  Epi epi{};
+  epi.res = d_residual;
+  epi.ldres = static_cast<long long>(residual_stride);
+  epi.rowscale = d_row_scale;
   return run_gemm<true, true>(d_x, x_stride, d_w, k, d_y, static_cast<int>(m), n, k, d_bias, act, nullptr, 0,
                               as_stream(stream), y_stride, epi);
 }
@@ -881,8 +907,37 @@ extern "C" int rbx_linear_dx_fused(const float* d_dy, int64_t dy_stride, const f
   if (dy_stride < n || dx_stride < k || (d_mask != nullptr && mask_stride < k) ||
       (d_residual != nullptr && residual_stride < k))
     return fail(RBX_ERR_INVALID, "linear_dx_fused: a row stride is shorter than its row");
-  const Epi epi{d_residual, static_cast<long long>(residual_stride), d_mask, static_cast<long long>(mask_stride), nullptr};
+  Epi epi{};
+  epi.res = d_residual;
+  epi.ldres = static_cast<long long>(residual_stride);
+  epi.mask = d_mask;
+  epi.ldmask = static_cast<long long>(mask_stride);
   // dx[m,k] = dy[m,n] * W[n,k]: A = dy (n contiguous = its K), B(kk=n, col=k) = W[n*k + k] (col contiguous)
+  return run_gemm<true, false>(d_dy, dy_stride, d_w, k, d_dx, static_cast<int>(m), k, n, nullptr, 0, nullptr, 0,
+                               as_stream(stream), dx_stride, epi);
+}
+
+extern "C" int rbx_linear_dx_deepfm(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
+                                    const float* d_x, int64_t x_stride, const float* d_fm_sum, int32_t fm_dim,
+                                    int32_t fm_cols, const float* d_fm_g, const float* d_lr_g, const float* d_lr_w,
+                                    float* d_dx, int64_t dx_stride, void* stream) {
+  if (m == 0) return RBX_OK;
+  using namespace rbx;
+  if (!d_dy || !d_w || !d_dx || !d_x || !d_fm_sum || !d_fm_g) return fail(RBX_ERR_INVALID, "linear_dx_deepfm: NULL tensor");
+  if ((d_lr_g == nullptr) != (d_lr_w == nullptr)) return fail(RBX_ERR_INVALID, "linear_dx_deepfm: lr_g and lr_w come together");
+  if (m < 0 || n <= 0 || k <= 1 || m > INT_MAX || fm_dim <= 0 || fm_cols <= 0 || fm_cols > k || fm_cols % fm_dim != 0)
+    return fail(RBX_ERR_INVALID, "linear_dx_deepfm: bad shape (fm_cols %d of k %d, fm_dim %d)", fm_cols, k, fm_dim);
+  if (dy_stride < n || dx_stride < k || x_stride < fm_cols) return fail(RBX_ERR_INVALID, "linear_dx_deepfm: row stride too short");
+  Epi epi{};
+  epi.fm_x = d_x;
+  epi.fm_ldx = static_cast<long long>(x_stride);
+  epi.fm_s = d_fm_sum;
+  epi.fm_g = d_fm_g;
+  epi.lr_g = d_lr_g;
+  epi.lr_w = d_lr_w;
+  epi.fm_cols = fm_cols;
+  epi.fm_dim = fm_dim;
+  epi.fm_mask = (fm_dim & (fm_dim - 1)) == 0 ? fm_dim - 1 : -1;
   return run_gemm<true, false>(d_dy, dy_stride, d_w, k, d_dx, static_cast<int>(m), k, n, nullptr, 0, nullptr, 0,
                                as_stream(stream), dx_stride, epi);
 }

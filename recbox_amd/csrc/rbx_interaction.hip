@@ -306,6 +306,66 @@ static int run_interaction(bool bwd, const float* emb, long long sb, const float
 
 }  // namespace rbx
 
+namespace rbx {
+// product_sum AND the field sum it is made of, one pass over the [B, F, D] block (D a multiple of 4, G = D / 4 lanes per
+// sample): y[b] = 0.5 sum_d (S_d^2 - Q_d), S[b, d] = sum_f e[b, f, d].  S is what the backward of the term needs
+// (d e[b, f, :] = g_b (S_b - e[b, f, :])): kept, the gradient can be formed wherever the block's gradient is assembled.
+template <int G>
+__global__ __launch_bounds__(256) void fm_sum_fwd_kernel(const float* __restrict__ emb, const long long sb, const long long B,
+                                                         const int F, const int D, float* __restrict__ out,
+                                                         float* __restrict__ sum) {
+  const int lane_g = threadIdx.x % G;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
+  const int e = lane_g * 4;
+  for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
+    const float* base = emb + b * sb;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < D) {
+#pragma unroll 8
+      for (int f = 0; f < F; ++f) {
+        const float4 t = *reinterpret_cast<const float4*>(base + f * D + e);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        q.x += t.x * t.x; q.y += t.y * t.y; q.z += t.z * t.z; q.w += t.w * t.w;
+      }
+      *reinterpret_cast<float4*>(sum + b * D + e) = s;
+    }
+    float t = 0.5f * ((s.x * s.x - q.x) + (s.y * s.y - q.y) + (s.z * s.z - q.z) + (s.w * s.w - q.w));
+    t = group_sum<G>(t);
+    if (lane_g == 0) out[b] = t;
+  }
+}
+}  // namespace rbx
+
+extern "C" int rbx_fm_sum_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch, int32_t n_fields, int32_t dim,
+                              float* d_out, float* d_sum, void* stream) {
+  using namespace rbx;
+  if (batch == 0) return RBX_OK;
+  if (!d_emb || !d_out || !d_sum) return fail(RBX_ERR_INVALID, "fm_sum: NULL tensor");
+  if (batch < 0 || n_fields <= 0 || dim <= 0 || emb_stride_b < static_cast<int64_t>(n_fields) * dim)
+    return fail(RBX_ERR_INVALID, "fm_sum: bad shape");
+  if (dim % 4 != 0 || dim > 256 || emb_stride_b % 4 != 0 ||
+      ((reinterpret_cast<uintptr_t>(d_emb) | reinterpret_cast<uintptr_t>(d_sum)) & 15) != 0)
+    return fail(RBX_ERR_UNSUPPORTED, "fm_sum: needs 16-byte aligned rows and dim %% 4 == 0, dim <= 256 (got dim %d)", dim);
+  const int g = pow2_ceil(dim / 4);
+  const int gpb = 256 / g;
+  long long blocks = (batch + gpb - 1) / gpb;
+  if (blocks > kCUs * 8) blocks = kCUs * 8;
+  hipStream_t s = as_stream(stream);
+#define CALL(GG) hipLaunchKernelGGL((fm_sum_fwd_kernel<GG>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, d_emb, \
+                                    static_cast<long long>(emb_stride_b), static_cast<long long>(batch), n_fields, dim, d_out, d_sum)
+  switch (g) {
+    case 1: CALL(1); break;
+    case 2: CALL(2); break;
+    case 4: CALL(4); break;
+    case 8: CALL(8); break;
+    case 16: CALL(16); break;
+    case 32: CALL(32); break;
+    default: CALL(64); break;
+  }
+#undef CALL
+  return check_launch("fm_sum_fwd_kernel");
+}
+
 extern "C" int rbx_interaction_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch, int32_t n_fields, int32_t dim,
                                    int32_t mode, float* d_out, void* stream) {
   return rbx::run_interaction(false, d_emb, emb_stride_b, nullptr, batch, n_fields, dim, mode, d_out, 0, stream);

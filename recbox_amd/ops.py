@@ -63,6 +63,9 @@ class config(object):
     # SASRec blocks as two autograd nodes (attention sub-layer, feed-forward sub-layer) whose residual adds, timeline mask, ReLU
     # backward and gradient sums run in GEMM epilogues instead of passes of their own (ops.sasrec_attention_sublayer / _ffn_)
     fuse_sublayers = os.environ.get("RECBOX_AMD_FUSE_SUBLAYERS", "1") != "0"
+    # DeepFM: the tower's first Linear, the FM term and the first-order Linear over one gathered block as one autograd node
+    # (ops.deepfm_input_stage): the block's gradient comes out of the tower's dx GEMM instead of four kernels
+    fuse_deepfm_input = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_INPUT", "1") != "0"
     reuse_grad_buffers = {"0": False, "": False, "all": "all"}.get(os.environ.get("RECBOX_AMD_REUSE_GRADS", "0"), True)
 
 
@@ -2269,6 +2272,89 @@ class _FfnSublayer(torch.autograd.Function):
 def sasrec_ffn_sublayer(e, norm, w1, b1, w2, b2, keep):
     """``n = norm(e); (n + relu(n w1^T + b1) w2^T + b2) * keep[..., None]`` for [B, L, E] blocks; keep [B, L] carries no gradient."""
     return _FfnSublayer.apply(e, norm.weight, norm.bias, float(norm.eps), w1, b1, w2, b2, keep)
+
+
+class _DeepFmInput(torch.autograd.Function):
+    """The three readers of DeepFM's gathered block x [B, K] = [F * D embeddings | dense values] (deepfm.py:34-42) as ONE
+    autograd node: h = x W1^T + b1 (the tower's first Linear), y_fm = FM(x[:, :F D]) and y_lr = x[:, :F D] w_lr^T + b_lr.
+    Separately they return three gradients of the block -- 440 MB each at cfg 4 -- that a fourth kernel adds; here the FM
+    and first-order terms are added in the epilogue of the tower's dx GEMM (rbx_linear_dx_deepfm), from the field sum S the
+    forward kept (rbx_fm_sum_fwd)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, lr_w, lr_b, fm_cols, dim):
+        _require_cuda(x, "DeepFM input block")
+        x2 = _rows_view(x)
+        w1 = w1.contiguous()
+        lr_w = lr_w.contiguous()
+        M, K = x2.shape
+        N = w1.shape[0]
+        F_ = fm_cols // dim
+        h = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        check(_timed(("linear_fwd", M, N, K),
+                     lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, 0, _ptr(h), _stream())))
+        y_fm = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+        ssum = torch.empty((M, dim), dtype=torch.float32, device=x.device)
+        check(lib.rbx_fm_sum_fwd(_ptr(x2), x2.stride(0), M, F_, dim, _ptr(y_fm), _ptr(ssum), _stream()))
+        y_lr = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+        check(lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(lr_w), _ptr(lr_b), M, 1, fm_cols, 0, _ptr(y_lr), _stream()))
+        ctx.save_for_backward(x2, w1, lr_w, ssum)
+        ctx.meta = (fm_cols, dim, b1 is not None, lr_b is not None, tuple(x.shape))
+        return h, y_fm, y_lr
+
+    @staticmethod
+    def backward(ctx, dh, g_fm, g_lr):
+        x2, w1, lr_w, ssum = ctx.saved_tensors
+        fm_cols, dim, has_b1, has_lr_b, xshape = ctx.meta
+        M, K = x2.shape
+        N = w1.shape[0]
+        dev = x2.device
+        need = ctx.needs_input_grad
+        zeros = None
+
+        def col(g, what):
+            nonlocal zeros
+            if g is None:
+                if zeros is None:
+                    zeros = torch.zeros(M, dtype=torch.float32, device=dev)
+                return zeros
+            return g.contiguous().float().view(-1)
+
+        dh2 = dh.contiguous().float() if dh is not None else torch.zeros((M, N), dtype=torch.float32, device=dev)
+        gf, gl = col(g_fm, "fm"), col(g_lr, "lr")
+        dw1 = torch.empty_like(w1) if need[1] else None
+        db1 = torch.empty(N, dtype=torch.float32, device=dev) if (has_b1 and need[2]) else None
+        _lin_dwdb(x2, w1, dh2, dw1, db1)
+        dlr_w = torch.empty_like(lr_w) if need[3] else None
+        dlr_b = torch.empty(1, dtype=torch.float32, device=dev) if (has_lr_b and need[4]) else None
+        if dlr_w is not None or dlr_b is not None:           # the logit head's streaming kernels (n = 1)
+            xl = x2[:, :fm_cols]
+            gl2 = gl.view(M, 1)
+            tmp_w = dlr_w if dlr_w is not None else torch.empty_like(lr_w)
+            ws_bytes = lib.rbx_linear_bwd_workspace_size(M, 1, fm_cols, 0)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            check(lib.rbx_linear_bwd(_ptr(xl), x2.stride(0), _ptr(lr_w), None, _ptr(gl2), M, 1, fm_cols, 0, None, fm_cols,
+                                     _ptr(tmp_w), _ptr(dlr_b), _ptr(ws), ws_bytes, _stream()))
+        dx = None
+        if need[0]:
+            dx = _padded_rows(M, K, dev)
+            check(lib.rbx_linear_dx_deepfm(_ptr(dh2), N, _ptr(w1), M, N, K, _ptr(x2), x2.stride(0), _ptr(ssum), dim, fm_cols,
+                                           _ptr(gf), _ptr(gl), _ptr(lr_w), _ptr(dx), dx.stride(0), _stream()))
+            dx = dx.view(xshape) if len(xshape) != 2 else dx
+        return dx, dw1, db1, dlr_w, dlr_b, None, None
+
+
+def deepfm_input_stage(x, first_linear, lr_linear, fm_cols, dim):
+    """(first_linear(x), FM(x[:, :fm_cols].view(B, -1, dim)), lr_linear(x[:, :fm_cols])) for DeepFM's gathered block
+    x [B, K]: one autograd node, the block's gradient comes out of ONE GEMM (see _DeepFmInput)."""
+    return _DeepFmInput.apply(x, first_linear.weight, first_linear.bias, lr_linear.weight, lr_linear.bias, int(fm_cols),
+                              int(dim))
+
+
+def deepfm_input_stage_supported(x, fm_cols, dim):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and dim % 4 == 0 and dim <= 256
+            and fm_cols % dim == 0 and 0 < fm_cols <= x.shape[1] and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and x.shape[1] > 1)
 
 
 class _SoftmaxCE(torch.autograd.Function):

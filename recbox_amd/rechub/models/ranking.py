@@ -2,7 +2,7 @@
 /root/reference/recbox/third_party/rechub/models/ranking/deepfm.py:14-42)."""
 import torch
 
-from ... import ops
+from ... import dense, ops
 from ..basic.features import DenseFeature, SparseFeature
 from ..basic.layers import FM, LR, MLP, EmbeddingLayer
 
@@ -33,6 +33,14 @@ class DeepFM(torch.nn.Module):
             # [V, D] gradients per table.  Here ONE gather produces [B, F*D | dense] (rows padded to 16 bytes); the
             # FM part and the LR part read its leading F*D columns in place, the tower reads the whole row.
             input_deep = self.embedding(x, self.deep_features, squeeze_dim=True)
+            dim = self.fm_features[0].embed_dim
+            mods = self.mlp.mlp
+            if (ops.config.fuse_deepfm_input and len(mods) > 0 and type(mods[0]) is torch.nn.Linear
+                    and not self.linear.sigmoid and ops.deepfm_input_stage_supported(input_deep, self.fm_dims, dim)):
+                # the three readers of the block as ONE autograd node: its gradient comes out of the tower's dx GEMM
+                h, y_fm, y_linear = ops.deepfm_input_stage(input_deep, mods[0], self.linear.fc, self.fm_dims, dim)
+                y_deep = dense.run_sequential(mods[1:], h)
+                return ops.sigmoid_output((y_linear + y_fm + y_deep).squeeze(1))
             if input_deep.is_cuda and input_deep.dim() == 2:
                 # three readers of one block: its gradient is assembled by one kernel (ops.shared_prefix)
                 input_deep, flat_fm, flat_lr = ops.shared_prefix(input_deep, self.fm_dims, copies=2)

@@ -951,3 +951,37 @@ def test_cos_dot_fuses_the_normalisation_and_mirrors_the_gradient_layout():
     ops.cos_dot(u0.cuda(), b.unflatten(1, (N, D)), scale=1.0).sum().backward()
     hook.remove()
     assert blk.grad.untyped_storage().data_ptr() == seen["ptr"]
+
+
+def test_deepfm_input_stage_as_one_node_equals_the_three_readers():
+    """ops.deepfm_input_stage (tower's first Linear + FM + first-order Linear over one gathered block; the block's gradient out
+    of ONE GEMM, rbx_linear_dx_deepfm) against the three separate readers: predictions and every gradient, and against the
+    live-reference fixture."""
+    from recbox_amd import ops
+    Fe, La = _rh()
+    from recbox_amd.rechub.models.ranking import DeepFM
+    fx = Fixture("rechub_deepfm")
+    X = _cuda(fx.tensors("in"))
+
+    def run(fused):
+        dense = [Fe.DenseFeature("I%d" % i) for i in range(1, 4)]
+        sparse = [Fe.SparseFeature("C%d" % (i + 1), v + 1, 16) for i, v in enumerate(CRITEO_SMALL_VOCABS[:8])]
+        model = DeepFM(sparse + dense, sparse, {"dims": [32, 16], "dropout": 0.0, "activation": "relu"})
+        load_params(model, fx["p"]).cuda().train()
+        old = ops.config.fuse_deepfm_input
+        ops.config.fuse_deepfm_input = fused
+        try:
+            p = model(X)
+            F.binary_cross_entropy(p, X["label"]).backward()
+        finally:
+            ops.config.fuse_deepfm_input = old
+        return p.detach(), dict((n, q.grad.clone()) for n, q in model.named_parameters())
+
+    pa, ga = run(True)
+    pb, gb = run(False)
+    assert_close(pa, pb, 1e-6, "predictions")
+    for n in gb:
+        assert_close(ga[n], gb[n], 1e-6, "grad " + n)
+    assert_close(pa, fx["out"]["y"], TOL)
+    for n in ga:
+        assert_close(ga[n], fx["g"][n], TOL, "grad " + n)
