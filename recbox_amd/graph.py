@@ -206,8 +206,8 @@ class ShardedFMStep(object):
         self.sorted_ws = self.tables.local_ops.presort(self.tables.weight, self.recv)
 
     def _settle(self):
-        self.tables.weight.grad = self.tables.local_ops.scatter_add(self.tables.weight, self.recv, self.d_recv,
-                                                                    sorted_ws=self.sorted_ws)
+        self.tables.weight.grad = self.tables.clear_pad_grad(
+            self.tables.local_ops.scatter_add(self.tables.weight, self.recv, self.d_recv, sorted_ws=self.sorted_ws))
 
     def _finish(self):
         if self.flat is not None and self.W > 1:

@@ -147,7 +147,8 @@ class ShardedFM(nn.Module):
         if self.sharded_names:
             self.tables = ShardedTables([feature_map.features[n]["vocab_size"] for n in self.sharded_names],
                                         embedding_dim, with_lr=True, capacity_factor=capacity_factor,
-                                        process_group=process_group, local_ops=local_ops)
+                                        process_group=process_group, local_ops=local_ops,
+                                        padding_idx=[feature_map.features[n].get("padding_idx") for n in self.sharded_names])
 
     def replicated_parameters(self):
         return list(self.embedding_layer.parameters()) + list(self.fm.parameters())

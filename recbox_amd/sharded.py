@@ -108,7 +108,8 @@ class _ExactLookup(torch.autograd.Function):
     """(owner, row) lookups, variable-size exchange (one host sync for the counts)."""
 
     @staticmethod
-    def forward(ctx, owner, row, group, local_ops, out_shape, weight):
+    def forward(ctx, owner, row, group, local_ops, out_shape, weight, tables=None):
+        ctx.tables = tables
         rank, W = comm.world(group)
         owner = owner.reshape(-1)
         row = row.reshape(-1)
@@ -132,7 +133,10 @@ class _ExactLookup(torch.autograd.Function):
         send_counts, recv_counts, group, local_ops = ctx.meta
         d_sorted = dout.reshape(-1, weight.shape[1])[perm].contiguous()
         d_recv = comm.all_to_all_rows(d_sorted, send_counts, recv_counts, group)          # dY to the owners
-        return None, None, None, None, None, local_ops.scatter_add(weight, recv_rows, d_recv)
+        grad = local_ops.scatter_add(weight, recv_rows, d_recv)
+        if ctx.tables is not None:
+            ctx.tables.clear_pad_grad(grad)
+        return None, None, None, None, None, grad, None
 
 
 class _PaddedLookup(torch.autograd.Function):
@@ -150,6 +154,7 @@ class _PaddedLookup(torch.autograd.Function):
         out = torch.cat([back, back.new_zeros((1, width))], dim=0)[slot]                   # dump slot reads zeros
         ctx.save_for_backward(slot, recv, weight)
         ctx.meta = (capacity, group, local_ops, W)
+        ctx.tables = tables
         return out.view(*ids.shape, width)
 
     @staticmethod
@@ -160,7 +165,7 @@ class _PaddedLookup(torch.autograd.Function):
         dsend = dout.new_zeros((W * capacity + 1, width))
         dsend[slot] = dout.reshape(-1, width)                     # slots are unique except the dump slot (discarded)
         d_recv = comm.all_to_all_equal(dsend[:W * capacity].contiguous(), group)           # aligned with `recv`
-        return None, None, None, local_ops.scatter_add(weight, recv, d_recv)
+        return None, None, None, ctx.tables.clear_pad_grad(local_ops.scatter_add(weight, recv, d_recv))
 
 
 class ShardedEmbedding(nn.Module):
@@ -227,10 +232,18 @@ class ShardedTables(nn.Module):
     ``capacity_factor``: None -> exact all-to-all-v (host sync); a float >= 1 -> padded, sync-free
     exchange with ``capacity = ceil(lookups / W * factor)`` slots per peer (see module docstring)."""
 
-    def __init__(self, vocabs, embedding_dim, with_lr=True, capacity_factor=None, process_group=None, local_ops=None):
+    def __init__(self, vocabs, embedding_dim, with_lr=True, capacity_factor=None, process_group=None, local_ops=None,
+                 padding_idx=None):
+        """padding_idx: None, or one entry per table (None / the row that is nn.Embedding's ``padding_idx`` in the reference's
+        table: it receives no gradient -- on the rank that owns it the row's gradient is cleared after the scatter-add -- and,
+        loaded as the zero row it is there, reads as zero)."""
         super().__init__()
         rank, W = comm.world(process_group)
         self.vocabs, self.embedding_dim, self.with_lr = list(vocabs), embedding_dim, with_lr
+        pads = list(padding_idx) if padding_idx is not None else [None] * len(self.vocabs)
+        if len(pads) != len(self.vocabs):
+            raise ValueError("ShardedTables: one padding_idx entry per table")
+        self.padding_idx = pads
         self.group, self.rank, self.world_size = process_group, rank, W
         self.lr_off = embedding_dim if with_lr else -1
         self.row_width = (embedding_dim + (1 if with_lr else 0) + 3) // 4 * 4
@@ -244,6 +257,17 @@ class ShardedTables(nn.Module):
         nn.init.normal_(self.weight[:, :embedding_dim + (1 if with_lr else 0)], std=1e-4)
         self.capacity_factor = capacity_factor
         self.local_ops = local_ops if local_ops is not None else HipLocalOps()
+        mine = [int(base[rank, t]) + p // W for t, p in enumerate(pads) if p is not None and 0 <= p < self.vocabs[t] and p % W == rank]
+        self.register_buffer("pad_rows", torch.tensor(mine, dtype=torch.long), persistent=False)
+        if mine:
+            with torch.no_grad():
+                self.weight[self.pad_rows] = 0.0
+
+    def clear_pad_grad(self, grad):
+        """nn.Embedding(padding_idx) on the rank that owns a padding row: that row's gradient is zero (in place)."""
+        if grad is not None and self.pad_rows.numel() > 0:
+            grad.index_fill_(0, self.pad_rows, 0.0)
+        return grad
 
     def raise_if_overflowed(self):
         """Collective; see ``raise_if_overflowed`` above."""
@@ -288,7 +312,7 @@ class ShardedTables(nn.Module):
         """ids [B, T] (one id per table per sample) -> packed rows [B, T, row_width]."""
         if self.capacity_factor is None:
             owner, row = self.locate(ids)
-            return _ExactLookup.apply(owner, row, self.group, self.local_ops, tuple(ids.shape), self.weight)
+            return _ExactLookup.apply(owner, row, self.group, self.local_ops, tuple(ids.shape), self.weight, self)
         return _PaddedLookup.apply(ids, self, self.capacity_for(ids.numel()), self.weight)
 
     def split(self, packed):

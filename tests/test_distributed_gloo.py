@@ -119,8 +119,13 @@ def _worker(rank, world, port, result):
         dist.all_gather(g_RE, RE)
         dist.all_gather(g_RL, RL)
         for factor in (None, 3.0):
-            tabs = ShardedTables(vocabs, D, with_lr=True, capacity_factor=factor, local_ops=OracleLocalOps())
+            # table 1 has a padding row (id 2, owned by rank 2 % world): a zero row that receives no gradient
+            tabs = ShardedTables(vocabs, D, with_lr=True, capacity_factor=factor, local_ops=OracleLocalOps(),
+                                 padding_idx=[None, 2, None])
             assert tabs.row_width == 8 and tabs.lr_off == D
+            assert tabs.pad_rows.numel() == (1 if rank == 2 % world else 0)
+            full_e[1][2].zero_()
+            full_l[1][2].zero_()
             tabs.load_full_tables(full_e, full_l)
             E, Lw = tabs.split(tabs(tid))
             for t in range(3):
@@ -132,6 +137,9 @@ def _worker(rank, world, port, result):
                 for i, re, rl in zip(g_ids, g_RE, g_RL):
                     we.index_add_(0, i[:, t], re[:, t])
                     wl.index_add_(0, i[:, t], rl[:, t])
+                if t == 1:
+                    we[2].zero_()
+                    wl[2].zero_()
                 sl, owned = tabs.local_rows_of(t)
                 assert torch.allclose(tabs.weight.grad[sl, :D], we[owned], atol=1e-6)
                 assert torch.allclose(tabs.weight.grad[sl, D], wl[owned], atol=1e-6)
