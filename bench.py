@@ -877,6 +877,11 @@ def main():
             if wms:
                 roof["frac_warm"] = per_sample * B / (wms * 1e-3) / 1e9 / 8000.0
                 roof["kernel_ms_warm"] = wms
+            if args.dim == 16 and (args.path == "fused" or sharded):
+                # what this GPU delivers on random 64-byte rows at all (a kernel that only gathers them): the ceiling the
+                # D = 16 forward can be held against; 128-byte rows and wider reach 5.8-6.0 TB/s
+                roof["row_gather_ceiling"] = {"GB/s": 3038.6, "frac_of_peak": 3038.6 / 8000.0,
+                                              "source": "profiles/r01_gather_yardstick.txt (profiles/ubench/gather_ubench.hip)"}
             ams = alone_timer.mean_ms()
             if ams:
                 roof["frac_alone"] = per_sample * B / (ams * 1e-3) / 1e9 / 8000.0
