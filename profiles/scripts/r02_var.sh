@@ -12,5 +12,5 @@ d=json.loads(sys.stdin.readline()); print('$v step_ms', round(d['ms_per_step'],4
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $out/prof -o b -- python /root/repo/bench.py --no-cpu-baseline > $out/prof_$v.log 2>&1)
   python profiles/topk.py $(find $out/prof -name "*.db" | head -1) 24 > $out/kernel_stats_$v.txt
   rm -rf $out/prof
-  grep "segment_\|build_keys\|rezero\|numeric_partial" $out/kernel_stats_$v.txt | cut -c1-130
+  grep "segment_" $out/kernel_stats_$v.txt | cut -c1-130
 done
