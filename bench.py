@@ -562,6 +562,8 @@ def main():
                     help="FM, one GPU: while step i runs, the ids of batch i + 1 are sorted on the side stream (FM.presort: a "
                          "loop whose loader is one batch ahead), so that the sort no longer sits in front of the backward's "
                          "reduce: 0.261 vs 0.267 ms.  Off by default: every step of the headline line sorts its own ids")
+    ap.add_argument("--pack-min-vocab", type=int, default=0,
+                    help="with --pack-tables: only tables with at least this many rows share one packed row with their LR weight")
     ap.add_argument("--rotate-by-copy", action="store_true",
                     help="FM, one GPU: rotate by copy_ into one static buffer (one captured step) instead of one graph per batch")
     ap.add_argument("--sort-after-forward", action="store_true",
@@ -657,7 +659,7 @@ def main():
         if not sharded and args.path == "fused" and args.pack_tables:
             # each (embedding, LR) table pair behind ONE packed [V, 32] storage: one 128-byte request per lookup in the
             # fused forward (FM.pack_tables; the parameters, their names and the dense gradients are unchanged)
-            m.pack_tables()
+            m.pack_tables(min_vocab=args.pack_min_vocab)
         return m
 
     model = build_model()

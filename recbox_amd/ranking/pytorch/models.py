@@ -80,7 +80,7 @@ class FM(nn.Module):
         return {"y_pred": ops.sigmoid_output(logit, prob)}
 
     @torch.no_grad()
-    def pack_tables(self, row_floats=None):
+    def pack_tables(self, row_floats=None, min_vocab=0):
         """Re-home every (embedding table, LR table) pair of a categorical feature in ONE packed storage
         ``[vocab, row_floats]`` -- floats ``[0, D)`` the embedding row, float ``D`` the dim-1 LR weight, the rest padding;
         ``row_floats`` defaults to the next multiple of 32 floats (128-byte rows) -- so that the fused forward issues one
@@ -92,7 +92,10 @@ class FM(nn.Module):
         shapes.  Gradients stay dense contiguous ``[vocab, D]`` / ``[vocab, 1]`` tensors.  Call it AFTER moving the model
         to its device (``.to()`` / ``.cuda()`` re-allocate every parameter on its own, which silently un-packs: the
         kernels then simply run on the separate tables again).  Tables shared by several features, pretrained / frozen
-        tables and sequence features are left alone.  Returns the number of packed pairs."""
+        tables and sequence features are left alone.  ``min_vocab``: only tables with at least that many rows -- a table
+        that does not fit the caches pays one 128-byte line for the embedding row and ANOTHER for its 4-byte LR weight on
+        every lookup, which packing halves; a small, cache-resident table only doubles its footprint.  Returns the number of
+        packed pairs."""
         emb = self.embedding_layer.embedding_layer.embedding_layers
         lr = self.fm.lr_layer.embedding_layer.embedding_layer.embedding_layers
         seen, packed_pairs = {}, 0
@@ -105,6 +108,8 @@ class FM(nn.Module):
             if seen[id(table)] != 1 or l.shape != (w.shape[0], 1) or w.requires_grad != l.requires_grad:
                 continue
             V, D = w.shape
+            if V < min_vocab:
+                continue
             stride = row_floats or (D + 1 + 31) // 32 * 32
             if stride < D + 1 or stride % 4:
                 raise ValueError("pack_tables: row_floats must be a multiple of 4 and >= embedding_dim + 1")
