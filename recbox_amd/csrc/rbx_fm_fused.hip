@@ -40,7 +40,43 @@ struct FmField {            // 48 B
 };
 struct FmPack { FmField f[RBX_MAX_FIELDS]; };
 
-template <int G, int NV, bool VEC>
+// Uniform-dtype fast path of the forward (DT = the one ids dtype every feature of the call has; -1 = mixed: the generic code).
+// The generic path converts a float64 id with static_cast<long long>(double) -- ~20 emulated instructions, there is no
+// 64-bit convert on gfx950 -- keeps ids in 64-bit registers and branches on the dtype of every feature; with 39 features per
+// sample the forward was bound by instruction issue, not by memory (every experiment on its memory side came out flat:
+// profiles/r02/sort_variants.txt).  Here: one v_cvt_i32_f64 (an id is < 2^31 once it passes the range check; NaN and
+// out-of-range values fail it exactly as in the generic path), 32-bit ids, no dtype switch.
+template <int DT>
+__device__ __forceinline__ long long fm_load_raw(const void* p, long long idx) {
+  if constexpr (DT == RBX_I64 || DT == RBX_F64) return static_cast<const long long*>(p)[idx];
+  else return static_cast<long long>(static_cast<const int*>(p)[idx]);
+}
+template <int DT>
+__device__ __forceinline__ bool fm_decode_id(long long raw, int vocab, int* id) {
+  if constexpr (DT == RBX_I32) {
+    *id = static_cast<int>(raw);
+    return static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
+  } else if constexpr (DT == RBX_I64) {
+    *id = static_cast<int>(raw);
+    return static_cast<unsigned long long>(raw) < static_cast<unsigned long long>(vocab);
+  } else if constexpr (DT == RBX_F32) {
+    const float f = __int_as_float(static_cast<int>(raw));
+    *id = __float2int_rz(f);                                // .long() truncates towards zero; saturates beyond int32
+    return (f == f) && static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
+  } else {
+    const double d = __longlong_as_double(raw);
+    *id = __double2int_rz(d);
+    return (d == d) && static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
+  }
+}
+template <int DT>
+__device__ __forceinline__ float fm_decode_value(long long raw) {
+  if constexpr (DT == RBX_I32 || DT == RBX_I64) return static_cast<float>(raw);
+  else if constexpr (DT == RBX_F32) return __int_as_float(static_cast<int>(raw));
+  else return static_cast<float>(__longlong_as_double(raw));
+}
+
+template <int G, int NV, bool VEC, int DT>
 __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const int F, const long long B, const int D,
                                                            const bool has_emb, const bool has_lr,
                                                            const float* __restrict__ bias,
@@ -73,14 +109,28 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const FmField& fd = P.f[(f0 + u < F) ? f0 + u : F - 1];
-        id[u] = load_raw(fd.ids, b * fd.stride_b, fd.dtype);
+        if constexpr (DT >= 0) id[u] = fm_load_raw<DT>(fd.ids, b * fd.stride_b);
+        else id[u] = load_raw(fd.ids, b * fd.stride_b, fd.dtype);
       }
       // phase 2: decode and range-check
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const FmField& fd = P.f[(f0 + u < F) ? f0 + u : F - 1];
         x[u] = 1.f;
-        if (fd.kind == RBX_FIELD_CATEGORICAL) {
+        if constexpr (DT >= 0) {
+          if (fd.kind == RBX_FIELD_CATEGORICAL) {
+            int v;
+            if (!fm_decode_id<DT>(id[u], fd.vocab, &v)) {
+              if (status != nullptr && f0 + u < F) atomicOr(status, 1);
+              v = 0;
+              x[u] = 0.f;                       // out-of-range lookups read as zero rows
+            }
+            id[u] = v;
+          } else {
+            x[u] = fm_decode_value<DT>(id[u]);
+            id[u] = 0;
+          }
+        } else if (fd.kind == RBX_FIELD_CATEGORICAL) {
           id[u] = decode_id(id[u], fd.dtype);
           if (id[u] < 0 || id[u] >= fd.vocab) {
             if (status != nullptr && f0 + u < F) atomicOr(status, 1);
@@ -102,7 +152,9 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
         if (f0 + u < F) {
           const FmField& fd = P.f[f0 + u];
           if (has_emb) {
-            const float* row = fd.emb + id[u] * fd.emb_stride;
+            const float* row = (DT >= 0) ? fd.emb + static_cast<unsigned long long>(static_cast<unsigned>(id[u])) *
+                                                        static_cast<unsigned>(fd.emb_stride)
+                                         : fd.emb + id[u] * fd.emb_stride;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
               const int d = (lane_g + v * G) * W;
@@ -116,7 +168,9 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
               }
             }
           }
-          if (has_lr && lane_g == ((f0 + u) % G)) l1[u] = fd.lr[id[u] * fd.lr_stride];   // one lane per feature fetches the LR weight
+          if (has_lr && lane_g == ((f0 + u) % G))                                       // one lane per feature fetches the LR weight
+            l1[u] = (DT >= 0) ? fd.lr[static_cast<unsigned long long>(static_cast<unsigned>(id[u])) * static_cast<unsigned>(fd.lr_stride)]
+                              : fd.lr[id[u] * fd.lr_stride];
         }
       }
 #pragma unroll
@@ -395,9 +449,15 @@ __global__ __launch_bounds__(256) void fm_extra_bwd_kernel(const float* __restri
 }
 
 // ---- host side -------------------------------------------------------------------------------
+static bool fm_fast_dtype() {                // RBX_FM_FAST_DTYPE=0: the generic forward for every call (A/B measurement)
+  static const bool on = [] { const char* e = getenv("RBX_FM_FAST_DTYPE"); return e == nullptr || e[0] != '0'; }();
+  return on;
+}
+
 struct FmHost {
   int F = 0, D = 0;
   bool has_emb = false, has_lr = false, vec = false;
+  int uniform_dt = -1;         // the ids dtype every feature shares, -1 when they differ
   FmPack pack;
 };
 
@@ -455,6 +515,9 @@ static int fm_validate(const rbx_field_t* emb, const rbx_field_t* lr, int n, int
       }
     }
   }
+  h->uniform_dt = lead[0].ids_dtype;
+  for (int i = 1; i < n; ++i)
+    if (lead[i].ids_dtype != h->uniform_dt) h->uniform_dt = -1;
   (void)B;
   return RBX_OK;
 }
@@ -466,9 +529,15 @@ static int launch_fm_fwd(const FmHost& h, int64_t B, const float* bias, const fl
   const int gpb = 256 / G;
   long long blocks = (B + gpb - 1) / gpb;
   if (blocks > kCUs * 16) blocks = kCUs * 16;
-  hipLaunchKernelGGL((fm_fused_fwd_kernel<G, NV, VEC>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, h.pack,
-                     h.F, static_cast<long long>(B), h.D, h.has_emb, h.has_lr, bias, xe, n_extra, x_stride, x_lr_off, xidx, x_rows,
-                     logit, prob, ssum, status);
+#define RBX_FM_LAUNCH(DT)                                                                                              \
+  hipLaunchKernelGGL((fm_fused_fwd_kernel<G, NV, VEC, DT>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, h.pack,   \
+                     h.F, static_cast<long long>(B), h.D, h.has_emb, h.has_lr, bias, xe, n_extra, x_stride, x_lr_off, xidx, \
+                     x_rows, logit, prob, ssum, status)
+  // the reference's loader hands over one float64 [B, cols] tensor; int64 ids are the other common case
+  if (h.uniform_dt == RBX_F64 && fm_fast_dtype()) RBX_FM_LAUNCH(RBX_F64);
+  else if (h.uniform_dt == RBX_I64 && fm_fast_dtype()) RBX_FM_LAUNCH(RBX_I64);
+  else RBX_FM_LAUNCH(-1);
+#undef RBX_FM_LAUNCH
   return check_launch("fm_fused_fwd_kernel");
 }
 
