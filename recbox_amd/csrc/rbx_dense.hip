@@ -132,10 +132,114 @@ __device__ __forceinline__ void store_tile(float* __restrict__ tile, const float
   }
 }
 
+// Steady-state loads of a k tile that lies inside [kbeg, kend): per-thread offsets that advance by one k tile per step --
+// no tests, no branches, no address arithmetic beyond one 64-bit add, so that the loads, the LDS traffic and the MFMAs of
+// one k step are ONE basic block.  Output tiles on the matrix edge run the same loop (workgroups that share a k slice
+// through the L2 then keep the same pace; with the edge tiles on the tested loads the dW GEMM of cfg 4 lost 40 %):
+// the rows of a k-contiguous operand beyond R are clamped to row R - 1, the columns of the other layout beyond R read on
+// into the next row (at most 127 floats; the loop stops two k tiles = 32 rows before kend, so that is allocated memory
+// whenever ld >= 8).  What those lanes fetch only reaches C rows / columns that are never stored.
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_offsets(long long ld, int r0, int k0, int R, long long (&off)[NP]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if constexpr (KCONTIG) {
+      int r = r0 + t / KT + (256 / KT) * p;
+      r = r < R ? r : R - 1;
+      off[p] = static_cast<long long>(r) * ld + k0 + (t % KT) * 4;
+    } else {
+      off[p] = static_cast<long long>(k0 + (t >> 5) + 8 * p) * ld + r0 + (t & 31) * 4;
+    }
+  }
+}
+// The loads are issued as inline assembly: written as C++ the compiler sinks them down to the LDS stores that consume
+// them (one basic block, single use), which exposes the whole memory latency; a fence does not hold them.  tile_arrived()
+// is the matching wait -- it names the registers as read-write so that no use can be scheduled above it.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tile_issue(const float* base, long long (&off)[NP], long long step, f32x4 (&v)[NP]) {
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    // four floats in one request whatever the row pitch: global memory takes dword-aligned dwordx4 loads (K = 1677)
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[p]) : "v"(base + off[p]));
+    off[p] += step;
+  }
+}
+__device__ __forceinline__ void tile_arrived(f32x4 (&a)[NP], f32x4 (&b)[NP]) {
+  static_assert(NP == 2, "operand list below is written for two float4 per thread and operand");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : : "memory");
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile_v(float* __restrict__ tile, const f32x4 (&v)[NP]) {
+  float reg[4 * NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) reg[p * 4 + j] = v[p][j];
+  store_tile<KCONTIG>(tile, reg);
+}
+
+#ifndef RBX_GEMM_PIPE
+#define RBX_GEMM_PIPE 1
+#endif
+#ifndef RBX_GEMM_PRIO
+#define RBX_GEMM_PRIO 0
+#endif
+
+// MFMA steps kk in [KLO, KHI) of one staged k tile for a wavefront's 2 x 2 tiles of 32 x 32
+template <int KLO, int KHI>
+__device__ __forceinline__ void mfma_steps(const float* __restrict__ as, const float* __restrict__ bs, int wm, int wn, int li,
+                                           int lk, f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int kk = KLO; kk < KHI; kk += 2) {
+    const float a0 = as[(kk + lk) * LDT + wm + li];
+    const float a1 = as[(kk + lk) * LDT + wm + 32 + li];
+    const float b0 = bs[(kk + lk) * LDT + wn + li];
+    const float b1 = bs[(kk + lk) * LDT + wn + 32 + li];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+}
+
+// All k tiles but the last two: the tile after the current one is loaded without tests and parked in LDS[cur ^ 1] HALFWAY
+// through the current tile's MFMAs (its stores issue in their shadow instead of after them), one barrier per tile.
+// Leaves k0 / cur at the first tile the tested loop below has to finish (its operands are staged).
+template <bool AK, bool BK_>
+__device__ __forceinline__ void gemm_steady(const float* __restrict__ A, long long lda, const float* __restrict__ B,
+                                            long long ldb, int m0, int n0, int M, int N, int kend, int& k0, int& cur,
+                                            float (&As)[2][BK * LDT], float (&Bs)[2][BK * LDT], int wm, int wn, int li, int lk,
+                                            f32x16 (&acc)[2][2]) {
+  f32x4 va[NP], vb[NP];
+  long long pa[NP], pb[NP];
+  tile_offsets<AK>(lda, m0, k0 + BK, M, pa);
+  tile_offsets<BK_>(ldb, n0, k0 + BK, N, pb);
+  const long long step_a = AK ? BK : BK * lda, step_b = BK_ ? BK : BK * ldb;
+  for (; k0 + 3 * BK <= kend; k0 += BK) {
+    tile_issue(A, pa, step_a, va);
+    tile_issue(B, pb, step_b, vb);
+#if RBX_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(RBX_GEMM_PRIO);
+#endif
+    mfma_steps<0, BK / 2>(As[cur], Bs[cur], wm, wn, li, lk, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    tile_arrived(va, vb);
+    store_tile_v<AK>(As[cur ^ 1], va);
+    store_tile_v<BK_>(Bs[cur ^ 1], vb);
+    mfma_steps<BK / 2, BK>(As[cur], Bs[cur], wm, wn, li, lk, acc);
+#if RBX_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // C[M,N] (+bias, act) = A(M,K) * B(K,N); blockIdx.z selects a K slice when gridDim.z > 1
 // (then C points at the slice's private [M,N] buffer: C + z * M * N, no epilogue math).
 template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const long long lda,
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restrict__ A, const long long lda,
                                                        const float* __restrict__ B, const long long ldb,
                                                        float* __restrict__ C, const long long ldc, const int M,
                                                        const int N, const int K, const int k_per_split,
@@ -178,25 +282,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   store_tile<B_KCONTIG>(Bs[0], rb);
   __syncthreads();
   int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+  int k0 = kbeg;
+#if RBX_GEMM_PIPE
+  if ((A_KCONTIG || lda >= 8) && (B_KCONTIG || ldb >= 8))       // (see tile_offsets: how far an edge tile reads on)
+    gemm_steady<A_KCONTIG, B_KCONTIG>(A, lda, B, ldb, m0, n0, M, N, kend, k0, cur, As, Bs, wm, wn, li, lk, acc);
+#endif
+  for (; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
     if (more) {                                    // next tile's HBM reads fly under this tile's MFMAs
       load_tile<A_KCONTIG>(A, lda, m0, k0 + BK, M, kend, vec_a, ra);
       load_tile<B_KCONTIG>(B, ldb, n0, k0 + BK, N, kend, vec_b, rb);
     }
-    const float* as = As[cur];
-    const float* bs = Bs[cur];
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = as[(kk + lk) * LDT + wm + li];
-      const float a1 = as[(kk + lk) * LDT + wm + 32 + li];
-      const float b0 = bs[(kk + lk) * LDT + wn + li];
-      const float b1 = bs[(kk + lk) * LDT + wn + 32 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
+    mfma_steps<0, BK>(As[cur], Bs[cur], wm, wn, li, lk, acc);
     if (more) {
       store_tile<A_KCONTIG>(As[cur ^ 1], ra);
       store_tile<B_KCONTIG>(Bs[cur ^ 1], rb);
