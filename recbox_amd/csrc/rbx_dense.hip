@@ -186,27 +186,32 @@ __device__ __forceinline__ void store_tile_v(float* __restrict__ tile, const f32
 #define RBX_GEMM_PRIO 0
 #endif
 
-// MFMA steps kk in [KLO, KHI) of one staged k tile for a wavefront's 2 x 2 tiles of 32 x 32
-template <int KLO, int KHI>
+// MFMA steps kk in [KLO, KHI) of one staged k tile for a wavefront's 2 x 2 tiles of 32 x 32: only the tiles named in
+// LIVE (bit 2 i + j) -- a wavefront whose 32-row / 32-column blocks lie beyond M / N skips
+// their products (N = 400 is 12.5 blocks: the weight-gradient GEMM [400, 65536] x [65536, 400] would otherwise run
+// 512 x 512 outputs' worth of MFMAs for 400 x 400).
+template <int KLO, int KHI, int LIVE>
 __device__ __forceinline__ void mfma_steps(const float* __restrict__ as, const float* __restrict__ bs, int wm, int wn, int li,
                                            int lk, f32x16 (&acc)[2][2]) {
+  // valid blocks are a prefix in both directions: LIVE is 15 (all four), 5 (one column of two), 3 (one row of two), 1, 0
 #pragma unroll
   for (int kk = KLO; kk < KHI; kk += 2) {
-    const float a0 = as[(kk + lk) * LDT + wm + li];
-    const float a1 = as[(kk + lk) * LDT + wm + 32 + li];
-    const float b0 = bs[(kk + lk) * LDT + wn + li];
-    const float b1 = bs[(kk + lk) * LDT + wn + 32 + li];
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    if constexpr ((LIVE & 3) != 0) a0 = as[(kk + lk) * LDT + wm + li];
+    if constexpr ((LIVE & 12) != 0) a1 = as[(kk + lk) * LDT + wm + 32 + li];
+    if constexpr ((LIVE & 5) != 0) b0 = bs[(kk + lk) * LDT + wn + li];
+    if constexpr ((LIVE & 10) != 0) b1 = bs[(kk + lk) * LDT + wn + 32 + li];
+    if constexpr ((LIVE & 1) != 0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    if constexpr ((LIVE & 2) != 0) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    if constexpr ((LIVE & 4) != 0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    if constexpr ((LIVE & 8) != 0) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
   }
 }
 
 // All k tiles but the last two: the tile after the current one is loaded without tests and parked in LDS[cur ^ 1] HALFWAY
 // through the current tile's MFMAs (its stores issue in their shadow instead of after them), one barrier per tile.
 // Leaves k0 / cur at the first tile the tested loop below has to finish (its operands are staged).
-template <bool AK, bool BK_>
+template <bool AK, bool BK_, int LIVE>
 __device__ __forceinline__ void gemm_steady(const float* __restrict__ A, long long lda, const float* __restrict__ B,
                                             long long ldb, int m0, int n0, int M, int N, int kend, int& k0, int& cur,
                                             float (&As)[2][BK * LDT], float (&Bs)[2][BK * LDT], int wm, int wn, int li, int lk,
@@ -222,12 +227,12 @@ __device__ __forceinline__ void gemm_steady(const float* __restrict__ A, long lo
 #if RBX_GEMM_PRIO
     __builtin_amdgcn_s_setprio(RBX_GEMM_PRIO);
 #endif
-    mfma_steps<0, BK / 2>(As[cur], Bs[cur], wm, wn, li, lk, acc);
+    mfma_steps<0, BK / 2, LIVE>(As[cur], Bs[cur], wm, wn, li, lk, acc);
     __builtin_amdgcn_sched_barrier(0);
     tile_arrived(va, vb);
     store_tile_v<AK>(As[cur ^ 1], va);
     store_tile_v<BK_>(Bs[cur ^ 1], vb);
-    mfma_steps<BK / 2, BK>(As[cur], Bs[cur], wm, wn, li, lk, acc);
+    mfma_steps<BK / 2, BK, LIVE>(As[cur], Bs[cur], wm, wn, li, lk, acc);
 #if RBX_GEMM_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -284,8 +289,18 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
   int cur = 0;
   int k0 = kbeg;
 #if RBX_GEMM_PIPE
-  if ((A_KCONTIG || lda >= 8) && (B_KCONTIG || ldb >= 8))       // (see tile_offsets: how far an edge tile reads on)
-    gemm_steady<A_KCONTIG, B_KCONTIG>(A, lda, B, ldb, m0, n0, M, N, kend, k0, cur, As, Bs, wm, wn, li, lk, acc);
+  if ((A_KCONTIG || lda >= 8) && (B_KCONTIG || ldb >= 8)) {     // (see tile_offsets: how far an edge tile reads on)
+    // which of the wavefront's four 32 x 32 tiles hold any output at all (bit 2 i + j)
+    const int rows = (m0 + wm + 32 < M) ? 2 : (m0 + wm < M ? 1 : 0), cols = (n0 + wn + 32 < N) ? 2 : (n0 + wn < N ? 1 : 0);
+    const int live = __builtin_amdgcn_readfirstlane((rows == 0 || cols == 0) ? 0 : (rows == 2 && cols == 2) ? 15 : (rows == 2) ? 5 : (cols == 2) ? 3 : 1);
+#define RBX_STEADY(L) gemm_steady<A_KCONTIG, B_KCONTIG, L>(A, lda, B, ldb, m0, n0, M, N, kend, k0, cur, As, Bs, wm, wn, li, lk, acc)
+    if (live == 15) RBX_STEADY(15);
+    else if (live == 5) RBX_STEADY(5);
+    else if (live == 3) RBX_STEADY(3);
+    else if (live == 1) RBX_STEADY(1);
+    else RBX_STEADY(0);
+#undef RBX_STEADY
+  }
 #endif
   for (; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
       load_tile<A_KCONTIG>(A, lda, m0, k0 + BK, M, kend, vec_a, ra);
       load_tile<B_KCONTIG>(B, ldb, n0, k0 + BK, N, kend, vec_b, rb);
     }
-    mfma_steps<0, BK>(As[cur], Bs[cur], wm, wn, li, lk, acc);
+    mfma_steps<0, BK, 15>(As[cur], Bs[cur], wm, wn, li, lk, acc);
     if (more) {
       store_tile<A_KCONTIG>(As[cur ^ 1], ra);
       store_tile<B_KCONTIG>(Bs[cur ^ 1], rb);
