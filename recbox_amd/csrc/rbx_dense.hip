@@ -192,15 +192,15 @@ __device__ __forceinline__ void store_tile_v(float* __restrict__ tile, const f32
 // 512 x 512 outputs' worth of MFMAs for 400 x 400).
 template <int KLO, int KHI, int LIVE>
 __device__ __forceinline__ void mfma_steps(const float* __restrict__ as, const float* __restrict__ bs, int wm, int wn, int li,
-                                           int lk, f32x16 (&acc)[2][2]) {
+                                           int lk, f32x16 (&acc)[2][2], int wm1, int wn1) {
   // valid blocks are a prefix in both directions: LIVE is 15 (all four), 5 (one column of two), 3 (one row of two), 1, 0
 #pragma unroll
   for (int kk = KLO; kk < KHI; kk += 2) {
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
     if constexpr ((LIVE & 3) != 0) a0 = as[(kk + lk) * LDT + wm + li];
-    if constexpr ((LIVE & 12) != 0) a1 = as[(kk + lk) * LDT + wm + 32 + li];
+    if constexpr ((LIVE & 12) != 0) a1 = as[(kk + lk) * LDT + wm1 + li];
     if constexpr ((LIVE & 5) != 0) b0 = bs[(kk + lk) * LDT + wn + li];
-    if constexpr ((LIVE & 10) != 0) b1 = bs[(kk + lk) * LDT + wn + 32 + li];
+    if constexpr ((LIVE & 10) != 0) b1 = bs[(kk + lk) * LDT + wn1 + li];
     if constexpr ((LIVE & 1) != 0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
     if constexpr ((LIVE & 2) != 0) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
     if constexpr ((LIVE & 4) != 0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -227,12 +227,12 @@ __device__ __forceinline__ void gemm_steady(const float* __restrict__ A, long lo
 #if RBX_GEMM_PRIO
     __builtin_amdgcn_s_setprio(RBX_GEMM_PRIO);
 #endif
-    mfma_steps<0, BK / 2, LIVE>(As[cur], Bs[cur], wm, wn, li, lk, acc);
+    mfma_steps<0, BK / 2, LIVE>(As[cur], Bs[cur], wm, wn, li, lk, acc, wm + 32, wn + 32);
     __builtin_amdgcn_sched_barrier(0);
     tile_arrived(va, vb);
     store_tile_v<AK>(As[cur ^ 1], va);
     store_tile_v<BK_>(Bs[cur ^ 1], vb);
-    mfma_steps<BK / 2, BK, LIVE>(As[cur], Bs[cur], wm, wn, li, lk, acc);
+    mfma_steps<BK / 2, BK, LIVE>(As[cur], Bs[cur], wm, wn, li, lk, acc, wm + 32, wn + 32);
 #if RBX_GEMM_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -241,7 +241,7 @@ __device__ __forceinline__ void gemm_steady(const float* __restrict__ A, long lo
   }
 }
 
-// C[M,N] (+bias, act) = A(M,K) * B(K,N); blockIdx.z selects a K slice when gridDim.z > 1
+// C[M,N] (+bias, act) = A(M,K) * B(K,N); with splits > 1 a workgroup computes one K slice of its tile
 // (then C points at the slice's private [M,N] buffer: C + z * M * N, no epilogue math).
 template <bool A_KCONTIG, bool B_KCONTIG>
 __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restrict__ A, const long long lda,
@@ -250,27 +250,65 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
                                                        const int N, const int K, const int k_per_split,
                                                        const float* __restrict__ bias, const int act,
                                                        const bool vec_a, const bool vec_b, const int tiles_m,
-                                                       const int tiles_n, const Epi epi) {
+                                                       const int tiles_n, const int splits, const Epi epi) {
   __shared__ float As[2][BK * LDT];
   __shared__ float Bs[2][BK * LDT];
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so launch
   // index L runs on XCD L % 8.  Tiles are numbered n-fastest and XCD x works through ONE contiguous range of them:
   // the workgroups that share an L2 then share the A row block (all n tiles of an m tile back to back) and walk B in
   // the same order, instead of every XCD fetching every A tile.
-  int tile;
-  {
+  int tm_i, tn_j, z = 0;
+  if (splits == 1) {
     const int total = tiles_m * tiles_n, L = blockIdx.x;
     const int xcd = L % kXcds, slot = L / kXcds;
     const int q = total / kXcds, rem = total % kXcds;
-    tile = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    const int tile = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    tm_i = tile / tiles_n;
+    tn_j = tile % tiles_n;
+  } else {
+    // K split over `splits` workgroups per tile, one flat launch: the tiles with 128 x 128 real outputs first (every K slice
+    // of them), the tiles on the matrix edge after them.  All workgroups are resident at once and the dispatcher deals
+    // them out in launch order, so the full tiles spread evenly (the host sizes `splits` for two of them per CU) and the
+    // edge tiles -- a fraction of the MFMA work -- land on top as third workgroups instead of displacing full ones.
+    const int tm_f = M / BM, tn_f = N / BN, n_full = tm_f * tn_f, n_edge = tiles_m * tiles_n - n_full;
+    const int L = blockIdx.x;
+    if (L < n_full * splits) {
+      z = L / n_full;
+      const int f = L % n_full;
+      tm_i = f / tn_f;
+      tn_j = f % tn_f;
+    } else {
+      const int e = L - n_full * splits;
+      z = e / n_edge;
+      const int q = e % n_edge, right = (tiles_n > tn_f) ? tm_f : 0;     // the right-hand column strip, then the bottom row
+      if (q < right) { tm_i = q; tn_j = tn_f; }
+      else { tm_i = tm_f; tn_j = q - right; }
+    }
   }
-  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int kbeg = blockIdx.z * k_per_split;
+  const int m0 = tm_i * BM, n0 = tn_j * BN;
+  const int kbeg = z * k_per_split;
   const int kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
-  if (gridDim.z > 1) C += static_cast<long long>(blockIdx.z) * M * ldc;
+  if (splits > 1) C += static_cast<long long>(z) * M * ldc;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;       // wave's 64x64 corner inside the tile
   const int li = lane & 31, lk = lane >> 5;
+  // The wavefront's corner inside the tile and which of its four 32 x 32 tiles hold any output (bit 2 i + j).  Interior
+  // tiles: 2 x 2 wavefronts of 64 x 64.  An edge tile with only one or two 32-row (32-column) blocks of real output deals
+  // those blocks out over all four wavefronts instead of leaving them to one or two of them (M = 400: the last row of
+  // tiles has 16 rows -- its wavefronts take one 32 x 32 tile each, a quarter of an interior tile's MFMA time, not a half).
+  int wm = (wid >> 1) * 64, wn = (wid & 1) * 64, live;
+  {
+    const int rb = (M - m0 + 31) / 32, cb = (N - n0 + 31) / 32;            // blocks with real rows / columns (>= 1)
+    int rows, cols;
+    if (rb == 1 && cb > 1) { wm = 0; wn = 32 * wid; rows = 1; cols = wid < cb ? 1 : 0; }
+    else if (cb == 1 && rb > 1) { wn = 0; wm = 32 * wid; cols = 1; rows = wid < rb ? 1 : 0; }
+    else if (rb == 2 && cb > 2) { wm = 32 * (wid & 1); wn = 64 * (wid >> 1); rows = 1; cols = cb - 2 * (wid >> 1); }
+    else if (cb == 2 && rb > 2) { wn = 32 * (wid & 1); wm = 64 * (wid >> 1); cols = 1; rows = rb - 2 * (wid >> 1); }
+    else { rows = rb - wm / 32; cols = cb - wn / 32; }
+    rows = rows > 2 ? 2 : rows;
+    cols = cols > 2 ? 2 : cols;
+    live = (rows <= 0 || cols <= 0) ? 0 : (rows == 2 && cols == 2) ? 15 : (rows == 2) ? 5 : (cols == 2) ? 3 : 1;
+    live = __builtin_amdgcn_readfirstlane(live);
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -290,9 +328,6 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
   int k0 = kbeg;
 #if RBX_GEMM_PIPE
   if ((A_KCONTIG || lda >= 8) && (B_KCONTIG || ldb >= 8)) {     // (see tile_offsets: how far an edge tile reads on)
-    // which of the wavefront's four 32 x 32 tiles hold any output at all (bit 2 i + j)
-    const int rows = (m0 + wm + 32 < M) ? 2 : (m0 + wm < M ? 1 : 0), cols = (n0 + wn + 32 < N) ? 2 : (n0 + wn < N ? 1 : 0);
-    const int live = __builtin_amdgcn_readfirstlane((rows == 0 || cols == 0) ? 0 : (rows == 2 && cols == 2) ? 15 : (rows == 2) ? 5 : (cols == 2) ? 3 : 1);
 #define RBX_STEADY(L) gemm_steady<A_KCONTIG, B_KCONTIG, L>(A, lda, B, ldb, m0, n0, M, N, kend, k0, cur, As, Bs, wm, wn, li, lk, acc)
     if (live == 15) RBX_STEADY(15);
     else if (live == 5) RBX_STEADY(5);
@@ -308,7 +343,8 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
       load_tile<A_KCONTIG>(A, lda, m0, k0 + BK, M, kend, vec_a, ra);
       load_tile<B_KCONTIG>(B, ldb, n0, k0 + BK, N, kend, vec_b, rb);
     }
-    mfma_steps<0, BK, 15>(As[cur], Bs[cur], wm, wn, li, lk, acc);
+    // (the last two k tiles run all four products: tiles that are not live read a clamped block and are never stored)
+    mfma_steps<0, BK, 15>(As[cur], Bs[cur], wm, wn, li, lk, acc, wm < 96 ? wm + 32 : 96, wn < 96 ? wn + 32 : 96);
     if (more) {
       store_tile<A_KCONTIG>(As[cur ^ 1], ra);
       store_tile<B_KCONTIG>(Bs[cur ^ 1], rb);
@@ -322,15 +358,15 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn + j * 32 + li;
-      if (col >= N) continue;
-      const float bv = (bias != nullptr && gridDim.z == 1) ? bias[col] : 0.f;
+      if (col >= N || ((live >> (2 * i + j)) & 1) == 0) continue;          // (a tile that is not live may lie over a neighbour's)
+      const float bv = (bias != nullptr && splits == 1) ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row < M) {
           float v = acc[i][j][r] + bv;
-          if (act == 1 && gridDim.z == 1) v = v > 0.f ? v : 0.f;
-          if (gridDim.z == 1) v = epi_apply(epi, v, row, col);
+          if (act == 1 && splits == 1) v = v > 0.f ? v : 0.f;
+          if (splits == 1) v = epi_apply(epi, v, row, col);
           C[static_cast<long long>(row) * ldc + col] = v;
         }
       }
@@ -914,12 +950,17 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     // every workgroup of the launch is resident at once (33.8 KB of LDS each), so the kernel lasts as long as the CU
     // with the most workgroups: pick the split count whose tiles x splits fills whole rounds of the 256 CUs best
     // (k = 1677: 56 tiles x 10 splits = 560 workgroups left a third of the chip idle during the last round; x 9 = 504 fits)
+    // Sized on the tiles with 128 x 128 real outputs: the edge tiles are launched after them and cost a fraction
+    // (M = 400 is three full rows of tiles and one with 16 rows -- counted as full, the 56 tiles of cfg 4's layer-1 dW
+    // got 9 slices (455 k steps each) where the 42 full ones fill the chip with 12 (341 steps)).
+    const long long n_full = static_cast<long long>(M / BM) * (N / BN);
+    const long long sized = n_full > 0 ? n_full : tiles;
     const int max_splits = K / 512;
     const long long fit = static_cast<long long>(ws_floats / (static_cast<size_t>(M) * N));
     int best = 1;
     double best_eff = 0.0;
     for (int sp = 1; sp <= max_splits && sp <= fit && tiles * sp <= 4 * kCUs; ++sp) {
-      const long long wgs = tiles * sp;
+      const long long wgs = sized * sp;
       const long long rounds = (wgs + kCUs - 1) / kCUs;
       double eff = static_cast<double>(wgs) / static_cast<double>(rounds * kCUs);
       if (rounds < 2) eff *= 0.9;                      // one workgroup per CU hides less latency than two
@@ -943,9 +984,9 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   const int tail = N % BN;
   const int tn_full = (splits == 1 && tail > 0 && tail <= 64) ? N / BN : tn;
   if (tn_full > 0)
-    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm, 1, splits), dim3(256), gemm_lds_pad(tn_full * tm * splits), s, A, lda, B, ldb, dst,
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm * splits), dim3(256), gemm_lds_pad(tn_full * tm * splits), s, A, lda, B, ldb, dst,
                        (splits > 1) ? static_cast<long long>(N) : ldc, M, N, K, kps, bias, act, vec_ok(A, lda),
-                       vec_ok(B, ldb), tm, tn_full, epi);
+                       vec_ok(B, ldb), tm, tn_full, splits, epi);
   if (tn_full < tn) {
     const int n0 = tn_full * BN;
     if (tail <= 32)
