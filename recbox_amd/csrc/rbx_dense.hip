@@ -353,6 +353,80 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
     cur ^= 1;
   }
   // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const bool has_mask = epi.mask != nullptr, has_res = epi.res != nullptr, has_fm = epi.fm_x != nullptr,
+             has_lr = epi.lr_g != nullptr, has_rs = epi.rowscale != nullptr;
+  if (m0 + BM <= M && n0 + BN <= N && splits == 1 && !(has_fm && (has_mask || has_res || has_rs))) {
+    // Interior tile: no row / column tests, and the optional operands of the epilogue are fetched for four outputs at a
+    // time in one straight run of loads.  (With a test per output every element was its own basic block -- load, wait,
+    // store, 64 times per lane: the DeepFM dx GEMM took 330 us longer than the same GEMM without its epilogue.)
+    constexpr int CH = 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn + j * 32 + li;
+        const int row0 = m0 + wm + i * 32 + 4 * lk;
+        const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+        for (int h = 0; h < 16; h += CH) {
+          float add[CH];
+#pragma unroll
+          for (int q = 0; q < CH; ++q) add[q] = 0.f;
+          if (has_fm) {
+            if (col < epi.fm_cols) {
+              const int d = epi.fm_mask >= 0 ? (col & epi.fm_mask) : (col % epi.fm_dim);
+              const float lw = has_lr ? epi.lr_w[col] : 0.f;
+              float x[CH], sm[CH], g[CH], gl[CH];
+#pragma unroll
+              for (int q = 0; q < CH; ++q) {
+                const long long row = row0 + ((h + q) & 3) + 8 * ((h + q) >> 2);
+                x[q] = epi.fm_x[row * epi.fm_ldx + col];
+                sm[q] = epi.fm_s[row * epi.fm_dim + d];
+                g[q] = epi.fm_g[row];
+                gl[q] = has_lr ? epi.lr_g[row] : 0.f;
+              }
+#pragma unroll
+              for (int q = 0; q < CH; ++q) add[q] = g[q] * (sm[q] - x[q]) + gl[q] * lw;
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+              float v = acc[i][j][h + q] + bv;
+              if (act == 1) v = v > 0.f ? v : 0.f;
+              C[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * ldc + col] = v + add[q];
+            }
+          } else {
+            float keep[CH], sc[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { keep[q] = 1.f; sc[q] = 1.f; }
+            if (has_mask) {
+#pragma unroll
+              for (int q = 0; q < CH; ++q)
+                keep[q] = epi.mask[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * epi.ldmask + col];
+            }
+            if (has_res) {
+#pragma unroll
+              for (int q = 0; q < CH; ++q)
+                add[q] = epi.res[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * epi.ldres + col];
+            }
+            if (has_rs) {
+#pragma unroll
+              for (int q = 0; q < CH; ++q) sc[q] = epi.rowscale[row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)];
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+              float v = acc[i][j][h + q] + bv;
+              if (act == 1) v = v > 0.f ? v : 0.f;
+              if (has_mask) v = keep[q] > 0.f ? v : 0.f;
+              v += add[q];
+              if (has_rs) v *= sc[q];
+              C[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * ldc + col] = v;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -982,7 +1056,14 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   float* dst = (splits > 1) ? ws : C;
   // the last partial column tile: when it is at most 64 columns wide (and K is not split) it goes to the narrow kernel
   const int tail = N % BN;
-  const int tn_full = (splits == 1 && tail > 0 && tail <= 64) ? N / BN : tn;
+#ifndef RBX_GEMM_NARROW_TAIL
+#define RBX_GEMM_NARROW_TAIL 1
+#endif
+  // RBX_GEMM_NARROW_TAIL=1: a tail of at most 64 columns behind full column tiles goes to the narrow kernel (a second
+  // launch that re-reads A); 0: the main kernel's edge-tile path takes it in the same launch (A comes from the L2).
+  // Measured at cfg 4 (N = 400 = 3 x 128 + 16, profiles/r02/gemm_variants.txt): layer-1 forward 820 us with the narrow
+  // launch, 856 in one launch (a fourth workgroup slot per row block for 4 % of the columns); 400 x 400: 214 vs 230.
+  const int tn_full = (splits == 1 && tail > 0 && tail <= 64 && (RBX_GEMM_NARROW_TAIL || N < BN)) ? N / BN : tn;
   if (tn_full > 0)
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm * splits), dim3(256), gemm_lds_pad(tn_full * tm * splits), s, A, lda, B, ldb, dst,
                        (splits > 1) ? static_cast<long long>(N) : ldc, M, N, K, kps, bias, act, vec_ok(A, lda),
