@@ -241,6 +241,113 @@ __device__ __forceinline__ void gemm_steady(const float* __restrict__ A, long lo
   }
 }
 
+// Narrow companion of gemm_f32_kernel for the last 32 * NT (<= 64) output columns: N = 400 is 3 full 128-column
+// tiles plus 16 columns, and a fourth full tile would spend 22% of the MFMA time on padding.  The four wavefronts
+// stack along M (32 rows each) and every wavefront computes NT 32x32 MFMA tiles; same operand staging.
+template <bool A_KCONTIG, bool B_KCONTIG, int NT>
+__device__ __forceinline__ void narrow_tile(const float* __restrict__ A, const long long lda, const float* __restrict__ B,
+                                            const long long ldb, float* __restrict__ C, const long long ldc, const int M,
+                                            const int N, const int K, const int n0, const float* __restrict__ bias,
+                                            const int act, const bool vec_a, const bool vec_b, const Epi& epi, const int m0,
+                                            float (&As)[2][BK * LDT], float (&Bs)[2][BK * LDT]) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wm = wid * 32;
+  const int li = lane & 31, lk = lane >> 5;
+  const int nlim = (n0 + 32 * NT < N) ? n0 + 32 * NT : N;      // B rows beyond the narrow tile are not fetched
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // The epilogue's extra operands are fetched NOW: this kernel runs a handful of k tiles (K = 64 for the SASRec
+  // projections), so a load issued after the last MFMA is a full memory round trip that nothing hides (measured: the
+  // fused launches took 270 us instead of 126).  They arrive while the operand tiles do.
+  f32x16 eres[NT], emask[NT];
+  float erow[16];
+  const bool has_res = epi.res != nullptr, has_mask = epi.mask != nullptr, has_rs = epi.rowscale != nullptr;
+  if (has_res || has_mask) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const bool ok = row < M && col < N;
+        eres[j][r] = (has_res && ok) ? epi.res[static_cast<long long>(row) * epi.ldres + col] : 0.f;
+        emask[j][r] = (has_mask && ok) ? epi.mask[static_cast<long long>(row) * epi.ldmask + col] : 1.f;
+      }
+    }
+  }
+  if (has_rs) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      erow[r] = row < M ? epi.rowscale[row] : 0.f;
+    }
+  }
+  float ra[4 * NP], rb[4 * NP];
+  load_tile<A_KCONTIG>(A, lda, m0, 0, M, K, vec_a, ra);
+  load_tile<B_KCONTIG>(B, ldb, n0, 0, nlim, K, vec_b, rb);
+  store_tile<A_KCONTIG>(As[0], ra);
+  store_tile<B_KCONTIG>(Bs[0], rb);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    const bool more = k0 + BK < K;
+    if (more) {
+      load_tile<A_KCONTIG>(A, lda, m0, k0 + BK, M, K, vec_a, ra);
+      load_tile<B_KCONTIG>(B, ldb, n0, k0 + BK, nlim, K, vec_b, rb);
+    }
+    const float* as = As[cur];
+    const float* bs = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = as[(kk + lk) * LDT + wm + li];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[(kk + lk) * LDT + j * 32 + li], acc[j], 0, 0, 0);
+    }
+    if (more) {
+      store_tile<A_KCONTIG>(As[cur ^ 1], ra);
+      store_tile<B_KCONTIG>(Bs[cur ^ 1], rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + j * 32 + li;
+    if (col >= N) continue;
+    const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (row < M) {
+        float v = acc[j][r] + bv;
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        if (has_mask) v = emask[j][r] > 0.f ? v : 0.f;
+        if (has_res) v += eres[j][r];
+        v += epi_fm_term(epi, row, col);
+        if (has_rs) v *= erow[r];
+        C[static_cast<long long>(row) * ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <bool A_KCONTIG, bool B_KCONTIG, int NT>
+__global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __restrict__ A, const long long lda,
+                                                              const float* __restrict__ B, const long long ldb,
+                                                              float* __restrict__ C, const long long ldc, const int M,
+                                                              const int N, const int K, const int n0,
+                                                              const float* __restrict__ bias, const int act,
+                                                              const bool vec_a, const bool vec_b, const Epi epi) {
+  __shared__ float As[2][BK * LDT];
+  __shared__ float Bs[2][BK * LDT];
+  narrow_tile<A_KCONTIG, B_KCONTIG, NT>(A, lda, B, ldb, C, ldc, M, N, K, n0, bias, act, vec_a, vec_b, epi,
+                                        static_cast<int>(blockIdx.x) * BM, As, Bs);
+}
+
 // C[M,N] (+bias, act) = A(M,K) * B(K,N); with splits > 1 a workgroup computes one K slice of its tile
 // (then C points at the slice's private [M,N] buffer: C + z * M * N, no epilogue math).
 template <bool A_KCONTIG, bool B_KCONTIG>
@@ -250,16 +357,27 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
                                                        const int N, const int K, const int k_per_split,
                                                        const float* __restrict__ bias, const int act,
                                                        const bool vec_a, const bool vec_b, const int tiles_m,
-                                                       const int tiles_n, const int splits, const Epi epi) {
+                                                       const int tiles_n, const int splits, const int narrow_from,
+                                                       const int narrow_nt, const Epi epi) {
   __shared__ float As[2][BK * LDT];
   __shared__ float Bs[2][BK * LDT];
+  // The first `narrow_from` workgroups compute the narrow tail (the last <= 64 columns behind tiles_n full column tiles) of
+  // row block blockIdx.x with the narrow kernel's body instead of a launch of their own: their k loop is bound by memory
+  // latency (one 32 x 32 tile per wavefront), so they start first and run BESIDE the full tiles, which keep the MFMA pipes
+  // busy meanwhile.  (Launched last they began in the final, half-empty round and outlived it: 766 vs 786 us only.)
+  if (static_cast<int>(blockIdx.x) < narrow_from) {
+    const int m0n = static_cast<int>(blockIdx.x) * BM;
+    if (narrow_nt == 1) narrow_tile<A_KCONTIG, B_KCONTIG, 1>(A, lda, B, ldb, C, ldc, M, N, K, tiles_n * BN, bias, act, vec_a, vec_b, epi, m0n, As, Bs);
+    else narrow_tile<A_KCONTIG, B_KCONTIG, 2>(A, lda, B, ldb, C, ldc, M, N, K, tiles_n * BN, bias, act, vec_a, vec_b, epi, m0n, As, Bs);
+    return;
+  }
   // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so launch
   // index L runs on XCD L % 8.  Tiles are numbered n-fastest and XCD x works through ONE contiguous range of them:
   // the workgroups that share an L2 then share the A row block (all n tiles of an m tile back to back) and walk B in
   // the same order, instead of every XCD fetching every A tile.
   int tm_i, tn_j, z = 0;
   if (splits == 1) {
-    const int total = tiles_m * tiles_n, L = blockIdx.x;
+    const int total = tiles_m * tiles_n, L = static_cast<int>(blockIdx.x) - narrow_from;
     const int xcd = L % kXcds, slot = L / kXcds;
     const int q = total / kXcds, rem = total % kXcds;
     const int tile = xcd * q + (xcd < rem ? xcd : rem) + slot;
@@ -271,7 +389,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
     // them out in launch order, so the full tiles spread evenly (the host sizes `splits` for two of them per CU) and the
     // edge tiles -- a fraction of the MFMA work -- land on top as third workgroups instead of displacing full ones.
     const int tm_f = M / BM, tn_f = N / BN, n_full = tm_f * tn_f, n_edge = tiles_m * tiles_n - n_full;
-    const int L = blockIdx.x;
+    const int L = static_cast<int>(blockIdx.x) - narrow_from;
     if (L < n_full * splits) {
       z = L / n_full;
       const int f = L % n_full;
@@ -443,104 +561,6 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restric
           if (splits == 1) v = epi_apply(epi, v, row, col);
           C[static_cast<long long>(row) * ldc + col] = v;
         }
-      }
-    }
-  }
-}
-
-// Narrow companion of gemm_f32_kernel for the last 32 * NT (<= 64) output columns: N = 400 is 3 full 128-column
-// tiles plus 16 columns, and a fourth full tile would spend 22% of the MFMA time on padding.  The four wavefronts
-// stack along M (32 rows each) and every wavefront computes NT 32x32 MFMA tiles; same operand staging.
-template <bool A_KCONTIG, bool B_KCONTIG, int NT>
-__global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __restrict__ A, const long long lda,
-                                                              const float* __restrict__ B, const long long ldb,
-                                                              float* __restrict__ C, const long long ldc, const int M,
-                                                              const int N, const int K, const int n0,
-                                                              const float* __restrict__ bias, const int act,
-                                                              const bool vec_a, const bool vec_b, const Epi epi) {
-  __shared__ float As[2][BK * LDT];
-  __shared__ float Bs[2][BK * LDT];
-  const int m0 = blockIdx.x * BM;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = wid * 32;
-  const int li = lane & 31, lk = lane >> 5;
-  const int nlim = (n0 + 32 * NT < N) ? n0 + 32 * NT : N;      // B rows beyond the narrow tile are not fetched
-  f32x16 acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  // The epilogue's extra operands are fetched NOW: this kernel runs a handful of k tiles (K = 64 for the SASRec
-  // projections), so a load issued after the last MFMA is a full memory round trip that nothing hides (measured: the
-  // fused launches took 270 us instead of 126).  They arrive while the operand tiles do.
-  f32x16 eres[NT], emask[NT];
-  float erow[16];
-  const bool has_res = epi.res != nullptr, has_mask = epi.mask != nullptr, has_rs = epi.rowscale != nullptr;
-  if (has_res || has_mask) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + j * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const bool ok = row < M && col < N;
-        eres[j][r] = (has_res && ok) ? epi.res[static_cast<long long>(row) * epi.ldres + col] : 0.f;
-        emask[j][r] = (has_mask && ok) ? epi.mask[static_cast<long long>(row) * epi.ldmask + col] : 1.f;
-      }
-    }
-  }
-  if (has_rs) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      erow[r] = row < M ? epi.rowscale[row] : 0.f;
-    }
-  }
-  float ra[4 * NP], rb[4 * NP];
-  load_tile<A_KCONTIG>(A, lda, m0, 0, M, K, vec_a, ra);
-  load_tile<B_KCONTIG>(B, ldb, n0, 0, nlim, K, vec_b, rb);
-  store_tile<A_KCONTIG>(As[0], ra);
-  store_tile<B_KCONTIG>(Bs[0], rb);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    const bool more = k0 + BK < K;
-    if (more) {
-      load_tile<A_KCONTIG>(A, lda, m0, k0 + BK, M, K, vec_a, ra);
-      load_tile<B_KCONTIG>(B, ldb, n0, k0 + BK, nlim, K, vec_b, rb);
-    }
-    const float* as = As[cur];
-    const float* bs = Bs[cur];
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = as[(kk + lk) * LDT + wm + li];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[(kk + lk) * LDT + j * 32 + li], acc[j], 0, 0, 0);
-    }
-    if (more) {
-      store_tile<A_KCONTIG>(As[cur ^ 1], ra);
-      store_tile<B_KCONTIG>(Bs[cur ^ 1], rb);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + j * 32 + li;
-    if (col >= N) continue;
-    const float bv = bias != nullptr ? bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (row < M) {
-        float v = acc[j][r] + bv;
-        if (act == 1) v = v > 0.f ? v : 0.f;
-        if (has_mask) v = emask[j][r] > 0.f ? v : 0.f;
-        if (has_res) v += eres[j][r];
-        v += epi_fm_term(epi, row, col);
-        if (has_rs) v *= erow[r];
-        C[static_cast<long long>(row) * ldc + col] = v;
       }
     }
   }
@@ -1064,11 +1084,16 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   // Measured at cfg 4 (N = 400 = 3 x 128 + 16, profiles/r02/gemm_variants.txt): layer-1 forward 820 us with the narrow
   // launch, 856 in one launch (a fourth workgroup slot per row block for 4 % of the columns); 400 x 400: 214 vs 230.
   const int tn_full = (splits == 1 && tail > 0 && tail <= 64 && (RBX_GEMM_NARROW_TAIL || N < BN)) ? N / BN : tn;
+#ifndef RBX_GEMM_NARROW_INSIDE
+#define RBX_GEMM_NARROW_INSIDE 1
+#endif
+  const bool inside = RBX_GEMM_NARROW_INSIDE && tn_full > 0 && tn_full < tn;       // the narrow tail rides in the main launch
   if (tn_full > 0)
-    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm * splits), dim3(256), gemm_lds_pad(tn_full * tm * splits), s, A, lda, B, ldb, dst,
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm * splits + (inside ? tm : 0)), dim3(256),
+                       gemm_lds_pad(tn_full * tm * splits), s, A, lda, B, ldb, dst,
                        (splits > 1) ? static_cast<long long>(N) : ldc, M, N, K, kps, bias, act, vec_ok(A, lda),
-                       vec_ok(B, ldb), tm, tn_full, splits, epi);
-  if (tn_full < tn) {
+                       vec_ok(B, ldb), tm, tn_full, splits, inside ? tm : 0, tail <= 32 ? 1 : 2, epi);
+  if (tn_full < tn && !inside) {
     const int n0 = tn_full * BN;
     if (tail <= 32)
       hipLaunchKernelGGL((gemm_f32_narrow_kernel<AK, BK_, 1>), dim3(tm), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, n0,
