@@ -144,12 +144,14 @@ __device__ __forceinline__ long long attn_base(long long bh, int heads, int L, l
   return b * L * ld + (bh - b * heads) * hd;
 }
 
-// Tile schedule: with L <= 256 there are at most 8 tiles and the workgroup has 8 wavefronts.  The causal cost of tile t
-// is t+1 tile steps, so SIMD s (wavefronts s and s+4) gets the heavy tile nT-1-s and the light tile s: ~nT+1 steps
-// of MFMA work per SIMD, run as two wavefronts that fill each other's latency gaps.
+// Tile schedule: with L <= 256 there are at most 8 tiles and the workgroup has 8 wavefronts.  Numbered by cost -- tile u
+// takes u+1 tile steps (query tile u in the forward / dQ kernels, key tile nT-1-u in the dK|dV kernel) -- SIMD s
+// (wavefronts s and s+4) gets the heavy tile nT-1-s and a light one: tile s when nT is even (nT+1 steps per SIMD), tile
+// s-1 when nT is odd (SIMD 0 keeps the heaviest tile alone: nT steps per SIMD.  L = 200 is 7 tiles: paired 6+0, 5+1, 4+2, 3
+// the SIMDs carried 8, 8, 8, 4 steps; 6, 5+0, 4+1, 3+2 is 7 each).  Two wavefronts per SIMD fill each other's latency gaps.
 #define RBX_FOR_WAVE_TILES(nT, wid, t)                                                                      \
-  for (int zz_once = 1, t = ((wid) < 4) ? (nT) - 1 - (wid) : (wid) - 4;                                     \
-       zz_once && (((wid) < 4) ? ((wid) <= (nT) - 1 - (wid)) : ((wid) - 4 < (nT) - 1 - ((wid) - 4)));       \
+  for (int zz_once = 1, t = ((wid) < 4) ? (nT) - 1 - (wid) : (wid) - 4 - ((nT) & 1);                        \
+       zz_once && (((wid) < 4) ? ((wid) <= (nT) - 1 - (wid)) : (t >= 0 && t < (nT) - 1 - t));               \
        zz_once = 0)
 
 template <int HD, bool DROP>
@@ -333,7 +335,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
-  RBX_FOR_WAVE_TILES(nT, wid, jt) {
+  RBX_FOR_WAVE_TILES(nT, wid, ju) {
+    const int jt = nT - 1 - ju;                     // (key tile jt meets nT - jt query tiles: cost index ju)
     const int j0 = jt * kT, kj = j0 + li;
     float kreg[HD / 2], vreg[HD / 2];
     load_tile_regs<HD>(K, ld.k, j0, L, 1.0f, kreg);
