@@ -104,9 +104,11 @@ class ShardedFMStep(object):
     6 graph launches + 4 collectives instead of ~150 eager kernel launches.  ``graphs=False`` runs the same
     pieces eagerly (tests, debugging).  Inputs ``X`` (dict of static tensors) and ``y`` are read in place:
     refill them before every call.  After a call, ``.grad`` of every parameter is what
-    ``(bce(model(X), y) / world).backward(); model.sync_grads()`` leaves."""
+    ``(bce(model(X), y) / world).backward(); model.sync_grads()`` leaves.  ``persistent_shard_grad``: the dense gradient of
+    this rank's table shard aliases ONE buffer from step to step, cleared by row (HipLocalOps.persistent) instead of
+    zero-filled in full -- consume it before the next call."""
 
-    def __init__(self, model, X, y, graphs=True, warmup=2, loss_fn=None):
+    def __init__(self, model, X, y, graphs=True, warmup=2, loss_fn=None, persistent_shard_grad=True):
         from . import comm
         if model.tables is None or model.tables.capacity_factor is None:
             raise ValueError("ShardedFMStep needs row-sharded tables with the padded exchange (capacity_factor)")
@@ -135,6 +137,9 @@ class ShardedFMStep(object):
         self.sorted_ws = None
         self.local_sorted = None
         self.graphs = None
+        if persistent_shard_grad and hasattr(tables.local_ops, "persistent"):
+            # the shard's dense gradient: one buffer cleared by row instead of a full zero fill per step
+            tables.local_ops.persistent(tables.weight)
         if graphs:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

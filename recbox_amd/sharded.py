@@ -33,6 +33,12 @@ class HipLocalOps(object):
 
     def __init__(self):
         self._plans = {}
+        # persistent(): the dense gradient of the shard lives in ONE buffer that is cleared by row -- exactly the rows the
+        # previous scatter_add stored, named by the sorted ids its presort left in the workspace -- instead of being
+        # zero-filled in full at every step (the local shard of the Criteo-shaped tables is 379 MB / world of zeros per
+        # step: 0.38 ms of the 0.66 ms step in a world of one).  Only for callers that sort and reduce a FIXED number of row
+        # slots per step, one presort and one scatter_add each, in that order (recbox_amd.graph.ShardedFMStep).
+        self._keep = None
 
     def _plan(self, weight):
         from . import ops
@@ -66,6 +72,10 @@ class HipLocalOps(object):
         send, slot = ops.route(ids, world, capacity, base, overflow)
         return slot, send
 
+    def persistent(self, weight):
+        """Switch to one persistent gradient buffer for this shard (see __init__)."""
+        self._keep = {"grad": torch.zeros_like(weight), "ws": None, "ws_bytes": 0, "dirty": 0}
+
     def presort(self, weight, rows):
         """The id sort of ``scatter_add`` depends on the row numbers only: run it as soon as they are known (the
         result is passed to ``scatter_add`` as ``sorted_ws``)."""
@@ -76,6 +86,20 @@ class HipLocalOps(object):
             return None
         plan = self._plan(weight)
         plan.bind_inputs([rows])
+        keep = self._keep
+        if keep is not None and keep["grad"].shape == weight.shape:
+            plan.bind_params([weight.detach()], [keep["grad"]])
+            ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
+            if keep["ws"] is None or keep["ws_bytes"] != ws_bytes:
+                if keep["dirty"]:
+                    raise RuntimeError("persistent shard gradient: the number of row slots changed between steps")
+                keep["ws"] = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
+                keep["ws_bytes"] = ws_bytes
+            if keep["dirty"]:                     # the rows the previous step stored: still named by the sorted ids in ws
+                check(lib.rbx_embed_rezero(plan.arr, 1, keep["dirty"], ops._ptr(keep["ws"]), ws_bytes, ops._stream()))
+                keep["dirty"] = 0
+            check(lib.rbx_embed_sort(plan.arr, 1, n, ops._ptr(keep["ws"]), ws_bytes, None, ops._stream()))
+            return keep["ws"]
         plan.bind_params([weight.detach()], [weight.detach()])          # placeholder grad pointer: "trainable"
         ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
@@ -87,7 +111,10 @@ class HipLocalOps(object):
         from . import ops
         from ._lib import check, lib
         n = rows.numel()
-        grad = torch.zeros_like(weight)
+        keep = self._keep
+        kept = (keep is not None and keep["grad"].shape == weight.shape and sorted_ws is not None
+                and sorted_ws is keep["ws"])
+        grad = keep["grad"] if kept else torch.zeros_like(weight)
         if n == 0:
             return grad
         plan = self._plan(weight)
@@ -95,6 +122,8 @@ class HipLocalOps(object):
         plan.bind_params([weight.detach()], [grad])
         ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
         st = ops._stream()
+        if kept:
+            keep["dirty"] = n                     # (the reduce below STORES the sums of the rows it touches)
         ws = sorted_ws
         if ws is None:
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)

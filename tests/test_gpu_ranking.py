@@ -823,6 +823,48 @@ def test_sharded_fm_step_pieces(graphs):
         assert_close(p.grad, ref_g[n], 1e-6, n)
 
 
+@pytest.mark.parametrize("graphs", [False, True])
+def test_sharded_fm_step_clears_the_rows_of_the_previous_batch(graphs):
+    """The shard's dense gradient is ONE buffer from step to step (HipLocalOps.persistent): after a step on batch A, a step on
+    batch B leaves exactly B's gradient -- the rows only A touched are zero again."""
+    from recbox_amd import ops
+    from recbox_amd.graph import ShardedFMStep
+    from recbox_amd.ranking.pytorch.models import ShardedFM
+    vocabs = [50, 7, 4000, 31, 3000, 9]
+    fm, XA, yA = _criteo_like(257, vocabs, 16, seed=31, zipf=False)
+    _, XB, yB = _criteo_like(257, vocabs, 16, seed=32, zipf=False)
+    ref = ShardedFM(fm, 16, shard_min_vocab=300, capacity_factor=1.5).cuda()
+    dut = ShardedFM(fm, 16, shard_min_vocab=300, capacity_factor=1.5).cuda()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.normal_(0, 0.1)
+    dut.load_state_dict(ref.state_dict())
+    Xc, yc = _cuda(XA), yA.cuda()
+    old = ops.config.check_ids
+    ops.config.check_ids = False
+    try:
+        step = ShardedFMStep(dut, Xc, yc, graphs=graphs)
+        step()
+        grad_a = dut.tables.weight.grad.clone()
+        for k, v in _cuda(XB).items():               # the step reads its inputs in place
+            Xc[k].copy_(v)
+        yc.copy_(yB.cuda())
+        loss = step()
+    finally:
+        ops.config.check_ids = old
+    torch.cuda.synchronize()
+    prob = ref(_cuda(XB))["y_pred"]
+    loss_ref = torch.nn.functional.binary_cross_entropy(prob, yB.cuda(), reduction="mean")
+    loss_ref.backward()
+    assert_close(loss.reshape(1), loss_ref.reshape(1), 1e-6, "loss")
+    ref_g = dict((n, p.grad) for n, p in ref.named_parameters())
+    for n, p in dut.named_parameters():
+        assert_close(p.grad, ref_g[n], 1e-6, n)
+    only_a = (grad_a.abs().sum(1) > 0) & (ref_g["tables.weight"].abs().sum(1) == 0)
+    assert int(only_a.sum()) > 100                   # (the case is meant to have rows that only batch A touched)
+    assert float(dut.tables.weight.grad[only_a].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("version", ["v1", "v2"])
 def test_cross_net_golden(version):
     """CrossNet / CrossNetV2 against the live-reference fixture: output, dx and every parameter grad."""
