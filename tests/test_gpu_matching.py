@@ -111,7 +111,12 @@ def test_mlp_golden():
                                        (9999, 7, 5, None), (10000, 192, 64, None), (8200, 130, 33, "relu"), (8192, 256, 64, None),
                                        # logit heads (n == 1): the streaming GEMV / outer-product / weighted column-sum kernels
                                        (70001, 1, 400, None), (5000, 1, 1664, None), (3001, 1, 37, "relu"), (2, 1, 7, None),
-                                       (66000, 1, 30, None)])
+                                       (66000, 1, 30, None),
+                                       # tiles on the matrix edge in every role (rows / columns of the forward, of dx and of the
+                                       # split-K dW): 1, 2, 3 and 4 live 32-row / 32-column blocks, narrow tails of one and two
+                                       # blocks riding in the main launch, cfg 4's [*, 1677] x [400, 1677] with K >= 4096 rows
+                                       (4200, 400, 1677, None), (4130, 168, 198, "relu"), (4100, 228, 168, None),
+                                       (4099, 198, 400, None), (4160, 130, 140, None)])
 def test_linear_matches_torch_fp32(M, N, K, act):
     """The MFMA GEMM (all three operand layouts, split-K weight grad) against torch fp32 on CPU."""
     from recbox_amd import ops
