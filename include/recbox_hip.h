@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 111          /* 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
+#define RBX_VERSION 112          /* 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
 
@@ -203,6 +203,11 @@ size_t rbx_route_workspace_size(int64_t n_lookups, int32_t world);
 int rbx_route(const rbx_field_t* tables, int32_t n_tables, int64_t batch, int32_t world, int64_t capacity,
               const int64_t* d_base, int64_t* d_send, int32_t* d_slot, uint8_t* d_overflow, void* d_workspace,
               size_t workspace_bytes, void* stream);
+/* The same with 32-bit row numbers on the wire (d_send [world * capacity] int32, empty slots = -1): the row numbers of one
+ * shard fit 31 bits whenever rbx_embed_fwd can address the shard at all, and the id exchange is half as long. */
+int rbx_route32(const rbx_field_t* tables, int32_t n_tables, int64_t batch, int32_t world, int64_t capacity,
+                const int64_t* d_base, int32_t* d_send, int32_t* d_slot, uint8_t* d_overflow, void* d_workspace,
+                size_t workspace_bytes, void* stream);
 
 /* ---- C1 (second generation): ONE exchange each way for row-sharded tables, pooled lookups reduced at the owner
  * (csrc/rbx_shard.hip; no reference precedent -- the reference's only parallelism is nn.DataParallel / DDP, SURVEY.md

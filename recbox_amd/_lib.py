@@ -79,6 +79,7 @@ SIGNATURES = {
     "rbx_fm_extra_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _i32, _P, _i64, _P, _P]),
     "rbx_route_workspace_size": (_sz, [_i64, _i32]),
     "rbx_route": (ctypes.c_int, [_FP, _i32, _i64, _i32, _i64, _P, _P, _P, _P, _P, _sz, _P]),
+    "rbx_route32": (ctypes.c_int, [_FP, _i32, _i64, _i32, _i64, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_fm_bwd_workspace_size": (_sz, [_FP, _FP, _i32, _i64]),
     "rbx_fm_sort": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P, _P]),
     "rbx_comm_bind": (ctypes.c_int, [_P, _P, _P, _P, _P]),

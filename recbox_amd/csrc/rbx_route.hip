@@ -85,11 +85,12 @@ __global__ __launch_bounds__(256) void route_scan_kernel(int* __restrict__ hist,
   if (threadIdx.x == 0 && s_carry > capacity && overflow != nullptr) *overflow = 1;
 }
 
+template <typename WireT>
 __global__ __launch_bounds__(256) void route_assign_kernel(const RoutePack P, const long long n,
                                                            const int T, const int W, const long long capacity,
                                                            const long long* __restrict__ base /*[W][T]*/,
                                                            const int* __restrict__ hist, const int tiles,
-                                                           long long* __restrict__ send, int* __restrict__ slot) {
+                                                           WireT* __restrict__ send, int* __restrict__ slot) {
   __shared__ int s_run[kRouteMaxW];            // owner's lookups before the current round
   __shared__ int s_wave[4][kRouteMaxW];        // per wavefront counts of the current round
   if (threadIdx.x < W) s_run[threadIdx.x] = hist[static_cast<long long>(threadIdx.x) * tiles + blockIdx.x];
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void route_assign_kernel(const RoutePack P, co
       if (rank < capacity) {
         const long long s = static_cast<long long>(own) * capacity + rank;
         slot[i] = static_cast<int>(s);
-        send[s] = row;
+        send[s] = static_cast<WireT>(row);
       } else {
         slot[i] = static_cast<int>(dump);
       }
@@ -139,10 +140,11 @@ extern "C" size_t rbx_route_workspace_size(int64_t n_lookups, int32_t world) {
   return static_cast<size_t>(rbx::route_tiles(n_lookups)) * static_cast<size_t>(world) * sizeof(int);
 }
 
-extern "C" int rbx_route(const rbx_field_t* tables, int32_t n_tables, int64_t batch, int32_t world, int64_t capacity,
-                         const int64_t* d_base, int64_t* d_send, int32_t* d_slot, uint8_t* d_overflow,
-                         void* d_workspace, size_t workspace_bytes, void* stream) {
-  using namespace rbx;
+namespace rbx {
+template <typename WireT>
+static int route_impl(const rbx_field_t* tables, int32_t n_tables, int64_t batch, int32_t world, int64_t capacity,
+                      const int64_t* d_base, WireT* d_send, int32_t* d_slot, uint8_t* d_overflow, void* d_workspace,
+                      size_t workspace_bytes, void* stream) {
   if (batch < 0 || n_tables <= 0 || n_tables > RBX_MAX_FIELDS || tables == nullptr)
     return fail(RBX_ERR_INVALID, "route: bad sizes (batch %lld, %d tables)", static_cast<long long>(batch), n_tables);
   if (world <= 0 || world > kRouteMaxW) return fail(RBX_ERR_UNSUPPORTED, "route: world=%d not in [1,%d]", world, kRouteMaxW);
@@ -160,7 +162,7 @@ extern "C" int rbx_route(const rbx_field_t* tables, int32_t n_tables, int64_t ba
     pack.f[t].pad = 0;
   }
   // empty wire slots carry row -1 (the owner's gather returns a zero row for them)
-  if (hipMemsetAsync(d_send, 0xFF, static_cast<size_t>(capacity) * world * sizeof(int64_t), s) != hipSuccess)
+  if (hipMemsetAsync(d_send, 0xFF, static_cast<size_t>(capacity) * world * sizeof(WireT), s) != hipSuccess)
     return fail(RBX_ERR_LAUNCH, "route: memset failed");
   const long long n_lookups = static_cast<long long>(batch) * n_tables;
   if (n_lookups == 0) return RBX_OK;
@@ -173,8 +175,23 @@ extern "C" int rbx_route(const rbx_field_t* tables, int32_t n_tables, int64_t ba
                      world, hist, static_cast<int>(tiles));
   hipLaunchKernelGGL(route_scan_kernel, dim3(world), dim3(256), 0, s, hist, static_cast<int>(tiles),
                      static_cast<long long>(capacity), d_overflow);
-  hipLaunchKernelGGL(route_assign_kernel, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, pack, n_lookups, n_tables,
-                     world, static_cast<long long>(capacity), reinterpret_cast<const long long*>(d_base), hist,
-                     static_cast<int>(tiles), reinterpret_cast<long long*>(d_send), d_slot);
+  hipLaunchKernelGGL(route_assign_kernel<WireT>, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, s, pack, n_lookups,
+                     n_tables, world, static_cast<long long>(capacity), reinterpret_cast<const long long*>(d_base), hist,
+                     static_cast<int>(tiles), d_send, d_slot);
   return check_launch("route kernels");
+}
+}  // namespace rbx
+
+extern "C" int rbx_route(const rbx_field_t* tables, int32_t n_tables, int64_t batch, int32_t world, int64_t capacity,
+                         const int64_t* d_base, int64_t* d_send, int32_t* d_slot, uint8_t* d_overflow,
+                         void* d_workspace, size_t workspace_bytes, void* stream) {
+  return rbx::route_impl<long long>(tables, n_tables, batch, world, capacity, d_base, reinterpret_cast<long long*>(d_send),
+                                    d_slot, d_overflow, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int rbx_route32(const rbx_field_t* tables, int32_t n_tables, int64_t batch, int32_t world, int64_t capacity,
+                           const int64_t* d_base, int32_t* d_send, int32_t* d_slot, uint8_t* d_overflow,
+                           void* d_workspace, size_t workspace_bytes, void* stream) {
+  return rbx::route_impl<int>(tables, n_tables, batch, world, capacity, d_base, d_send, d_slot, d_overflow, d_workspace,
+                              workspace_bytes, stream);
 }

@@ -125,7 +125,7 @@ class ShardedFMStep(object):
         self.cap = cap = tables.capacity_for(ids.numel())
         dev, width = ids.device, tables.row_width
         # wire buffers: written by one piece / collective, read by the next
-        self.recv = torch.full((W * cap,), -1, dtype=torch.long, device=dev)
+        self.recv = torch.full((W * cap,), -1, dtype=getattr(tables.local_ops, "wire_dtype", torch.long), device=dev)
         self.back = torch.zeros((W * cap, width), dtype=torch.float32, device=dev)
         self.d_recv = torch.zeros((W * cap, width), dtype=torch.float32, device=dev)
         self.replicated = [p for p in model.replicated_parameters() if p.requires_grad]

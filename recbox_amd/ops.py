@@ -1065,11 +1065,12 @@ def join_early_sort(logit):
 _route_plans = {}
 
 
-def route(ids, world, capacity, base, overflow):
+def route(ids, world, capacity, base, overflow, wire=torch.int64):
     """Wire slots of the padded exchange (rbx_route).  ids: [B, T] tensor or a list of T id columns [B] (any of
     int32/int64/float32/float64, strided views are read in place); base [world, T] int64; overflow: uint8/bool
     scalar tensor (set to 1 when a lookup did not fit, never cleared).
-    Returns (send [world * capacity] int64 row numbers, -1 = empty; slot [B, T] int32)."""
+    Returns (send [world * capacity] row numbers of dtype ``wire`` (int64, or int32: rbx_route32), -1 = empty;
+    slot [B, T] int32)."""
     cols = [ids[:, t] for t in range(ids.shape[1])] if torch.is_tensor(ids) else list(ids)
     T = len(cols)
     plan = _route_plans.get(T)
@@ -1078,12 +1079,18 @@ def route(ids, world, capacity, base, overflow):
         _route_plans[T] = plan
     B, keep = plan.bind_inputs(cols)
     dev = keep[0].device
-    send = torch.empty(world * capacity, dtype=torch.int64, device=dev)
+    if wire not in (torch.int64, torch.int32):
+        raise ValueError("route: wire dtype must be torch.int64 or torch.int32")
+    send = torch.empty(world * capacity, dtype=wire, device=dev)
     slot = torch.empty((B, T), dtype=torch.int32, device=dev)
     ws_bytes = lib.rbx_route_workspace_size(B * T, world)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-    check(lib.rbx_route(plan.arr, T, B, world, capacity, _ptr(base), _ptr(send), _ptr(slot),
-                        _ptr(overflow), _ptr(ws), ws_bytes, _stream()))
+    if wire == torch.int64:
+        check(lib.rbx_route(plan.arr, T, B, world, capacity, _ptr(base), _ptr(send), _ptr(slot), _ptr(overflow),
+                            _ptr(ws), ws_bytes, _stream()))
+    else:
+        check(lib.rbx_route32(plan.arr, T, B, world, capacity, _ptr(base), _ptr(send), _ptr(slot), _ptr(overflow),
+                              _ptr(ws), ws_bytes, _stream()))
     return send, slot
 
 

@@ -39,6 +39,8 @@ class HipLocalOps(object):
         # step: 0.38 ms of the 0.66 ms step in a world of one).  Only for callers that sort and reduce a FIXED number of row
         # slots per step, one presort and one scatter_add each, in that order (recbox_amd.graph.ShardedFMStep).
         self._keep = None
+        # row numbers travel as int32 (rbx_route32): a shard has fewer than 2^31 rows or rbx_embed_fwd could not address it
+        self.wire_dtype = torch.int32
 
     def _plan(self, weight):
         from . import ops
@@ -67,9 +69,9 @@ class HipLocalOps(object):
         return out
 
     def route(self, ids, world, capacity, base, overflow):
-        """Wire slots of the padded exchange: (slot [B, T] int32, send [world * capacity] int64) -- rbx_route."""
+        """Wire slots of the padded exchange: (slot [B, T] int32, send [world * capacity] int32 row numbers) -- rbx_route32."""
         from . import ops
-        send, slot = ops.route(ids, world, capacity, base, overflow)
+        send, slot = ops.route(ids, world, capacity, base, overflow, wire=self.wire_dtype)
         return slot, send
 
     def persistent(self, weight):

@@ -783,6 +783,11 @@ def test_route_kernel_equals_torch_restatement(world, cap):
     assert torch.equal(slot.cpu().reshape(-1).long(), slot_ref)
     assert torch.equal(send.cpu(), send_ref)
     assert bool(of.cpu()) == bool(of_ref)
+    of32 = torch.zeros((), dtype=torch.bool, device="cuda")              # the same with 32-bit row numbers on the wire
+    send32, slot32 = ops.route(ids.cuda(), world, cap, base.cuda(), of32, wire=torch.int32)
+    torch.cuda.synchronize()
+    assert send32.dtype == torch.int32 and torch.equal(send32.cpu().long(), send_ref)
+    assert torch.equal(slot32, slot) and bool(of32.cpu()) == bool(of_ref)
     if cap == 64:
         assert bool(of_ref)                                      # this case is meant to overflow
 
