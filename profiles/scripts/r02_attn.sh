@@ -2,4 +2,8 @@
 export TMPDIR=/tmp PYTHONPATH=/root/repo
 cd /root/repo
 timeout 900 python -m pytest tests/test_gpu_matching.py tests/test_gpu_cabi_vs_c_oracle.py tests/test_gpu_edge_cases.py -x -q -m gpu -k "attn or attention or sasrec or mha" 2>&1 | tail -3
-timeout 400 python bench.py --config sasrec --no-cpu-baseline 2>/dev/null | cut -c1-900
+for v in 1 0 1 0; do echo "RBX_ATTN_PREFETCH=$v"; RBX_ATTN_PREFETCH=$v timeout 400 python bench.py --config sasrec --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'; done
+out=/root/repo/gpurun_out/r2attn; rm -rf $out; mkdir -p $out
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof -o b -- python /root/repo/bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/prof.log 2>&1)
+python profiles/topk.py $(find $out/prof -name "*.db" | head -1) 8 > $out/kernel_stats.txt; rm -rf $out/prof
+head -10 $out/kernel_stats.txt | cut -c1-130

@@ -19,6 +19,7 @@
 //   backward B (lane = key)  : S = Q K^T, dP = dO V^T -> dV^T += dO^T P, dK^T += Q^T dS.
 // No atomics, deterministic.  Query/key tiles are dealt to the 4 waves in a zig-zag (heavy tile
 // + light tile) so the causal triangle is balanced.
+#include <stdlib.h>
 #include "rbx_internal.h"
 
 namespace rbx {
@@ -55,6 +56,41 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, const lo
         float* dst = lds + r * (HD + 1) + d;
         dst[0] = v[u].x * scale; dst[1] = v[u].y * scale; dst[2] = v[u].z * scale; dst[3] = v[u].w * scale;
       }
+    }
+  }
+}
+
+// The same block of the NEXT sequence, fetched into registers while the current one is being computed (a workgroup that
+// loops over sequences: one workgroup per CU means nothing else hides these loads -- the forward at L = 200 spent about as
+// long waiting for K and V as multiplying them).  Issued as inline assembly so that the compiler cannot sink the loads to
+// their use at the top of the next iteration; rows beyond `rows` are clamped here and zeroed when they are written to LDS.
+typedef float attn_f4 __attribute__((ext_vector_type(4)));
+template <int HD, int N>
+__device__ __forceinline__ void prefetch_rows(const float* g, const long long ld, int rows, attn_f4 (&v)[N]) {
+  constexpr int Q4 = HD / 4;
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int i = threadIdx.x + u * kAttnThreads;
+    int r = i / Q4;
+    const int c = i - r * Q4;
+    r = r < rows ? r : rows - 1;
+    const float* src = g + static_cast<long long>(r) * ld + c * 4;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[u]) : "v"(src));
+  }
+}
+template <int HD, int N>
+__device__ __forceinline__ void commit_rows(float* __restrict__ lds, int rows, int rows_pad, float scale,
+                                            const attn_f4 (&v)[N]) {
+  constexpr int Q4 = HD / 4;
+  const int total = rows_pad * Q4;
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int i = threadIdx.x + u * kAttnThreads;
+    if (i < total) {
+      const int r = i / Q4, d = (i - r * Q4) * 4;
+      const float k = r < rows ? scale : 0.f;
+      float* dst = lds + r * (HD + 1) + d;
+      dst[0] = v[u][0] * k; dst[1] = v[u][1] * k; dst[2] = v[u][2] * k; dst[3] = v[u][3] * k;
     }
   }
 }
@@ -154,79 +190,119 @@ __device__ __forceinline__ long long attn_base(long long bh, int heads, int L, l
        zz_once && (((wid) < 4) ? ((wid) <= (nT) - 1 - (wid)) : (t >= 0 && t < (nT) - 1 - t));               \
        zz_once = 0)
 
-template <int HD, bool DROP>
-__global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                            const float* __restrict__ V, const int L,
+// NPF > 0 (float4 per thread that hold one [Lp, HD] block: Lp * HD / 4 / 512): a workgroup per CU that loops over sequences (gridDim.x <= BH) and fetches the next sequence's K and V into registers
+// while it computes the current one; used where only one workgroup fits a CU anyway (K, V of a sequence > 80 KB of LDS).
+template <int HD, bool DROP, int NPF>
+__global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float* __restrict__ Q0, const float* __restrict__ K0,
+                                                            const float* __restrict__ V0, const int L,
                                                             const float scale, const int causal,
-                                                            float* __restrict__ O, float* __restrict__ LSE,
-                                                            const DropArgs drop, const AttnLd ld) {
+                                                            float* __restrict__ O0, float* __restrict__ LSE,
+                                                            const DropArgs drop, const AttnLd ld, const long long BH) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Ks = lds;
   float* Vs = lds + Lp * (HD + 1);
-  const long long bh = blockIdx.x;
-  Q += attn_base(bh, ld.heads, L, ld.q, HD);
-  K += attn_base(bh, ld.heads, L, ld.k, HD);
-  V += attn_base(bh, ld.heads, L, ld.v, HD);
-  O += attn_base(bh, ld.heads, L, ld.o, HD);
-  stage_rows<HD>(K, ld.k, Ks, L, Lp, 1.0f);
-  stage_rows<HD>(V, ld.v, Vs, L, Lp, 1.0f);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
-  RBX_FOR_WAVE_TILES(nT, wid, qt) {
-    const int i0 = qt * kT, qi = i0 + li;
-    float qreg[HD / 2];
-    load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
-    f32x16 oacc[HD / 32];
-#pragma unroll
-    for (int dt = 0; dt < HD / 32; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
-    const int kt_end = causal ? qt : nT - 1;
-    for (int kt = 0; kt <= kt_end; ++kt) {
-      const int j0 = kt * kT;
-      f32x16 s = tile_dot<HD>(Ks, j0, qreg);                 // S^T[key][query]
-      float mx = -INFINITY;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kj = j0 + tile_row(r, half);
-        if (kj >= L || (causal && kj > qi)) s[r] = -INFINITY;
-        mx = fmaxf(mx, s[r]);
+  constexpr bool PF = NPF > 0;
+  attn_f4 kpf[PF ? NPF : 1], vpf[PF ? NPF : 1];
+  for (long long bh = blockIdx.x; bh < BH; bh += gridDim.x) {
+    const float* Q = Q0 + attn_base(bh, ld.heads, L, ld.q, HD);
+    const float* K = K0 + attn_base(bh, ld.heads, L, ld.k, HD);
+    const float* V = V0 + attn_base(bh, ld.heads, L, ld.v, HD);
+    float* O = O0 + attn_base(bh, ld.heads, L, ld.o, HD);
+    if (!PF || bh == static_cast<long long>(blockIdx.x)) {
+      stage_rows<HD>(K, ld.k, Ks, L, Lp, 1.0f);
+      stage_rows<HD>(V, ld.v, Vs, L, Lp, 1.0f);
+    } else {
+      if constexpr (PF) {
+        // the matching wait: names the registers read-write so that nothing uses them above it
+        if constexpr (NPF == 8)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(kpf[0]), "+v"(kpf[1]), "+v"(kpf[2]), "+v"(kpf[3]), "+v"(kpf[4]), "+v"(kpf[5]),
+                       "+v"(kpf[6]), "+v"(kpf[NPF - 1]), "+v"(vpf[0]), "+v"(vpf[1]), "+v"(vpf[2]), "+v"(vpf[3]), "+v"(vpf[4]),
+                       "+v"(vpf[5]), "+v"(vpf[6]), "+v"(vpf[NPF - 1]) : : "memory");
+        else if constexpr (NPF == 7)
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(kpf[0]), "+v"(kpf[1]), "+v"(kpf[2]), "+v"(kpf[3]), "+v"(kpf[4]), "+v"(kpf[5]),
+                       "+v"(kpf[NPF - 1]), "+v"(vpf[0]), "+v"(vpf[1]), "+v"(vpf[2]), "+v"(vpf[3]), "+v"(vpf[4]), "+v"(vpf[5]),
+                       "+v"(vpf[NPF - 1]) : : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(kpf[0]), "+v"(kpf[1]), "+v"(kpf[2]), "+v"(kpf[3]), "+v"(kpf[4]),
+                       "+v"(kpf[NPF - 1]), "+v"(vpf[0]), "+v"(vpf[1]), "+v"(vpf[2]), "+v"(vpf[3]), "+v"(vpf[4]),
+                       "+v"(vpf[NPF - 1]) : : "memory");
+        static_assert(!PF || (NPF >= 6 && NPF <= 8), "operand lists above");
+        commit_rows<HD, PF ? NPF : 1>(Ks, L, Lp, 1.0f, kpf);
+        commit_rows<HD, PF ? NPF : 1>(Vs, L, Lp, 1.0f, vpf);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = (mn == -INFINITY) ? 1.f : __expf(m - mn);
-      float ps = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[r] = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - mn);
-        ps += s[r];
+    }
+    __syncthreads();
+    bool fetched = false;
+    auto fetch_next = [&]() {
+      if constexpr (PF) {
+        const long long nb = bh + gridDim.x;
+        if (nb < BH) {
+          prefetch_rows<HD, PF ? NPF : 1>(K0 + attn_base(nb, ld.heads, L, ld.k, HD), ld.k, L, kpf);
+          prefetch_rows<HD, PF ? NPF : 1>(V0 + attn_base(nb, ld.heads, L, ld.v, HD), ld.v, L, vpf);
+        }
+        fetched = true;
       }
-      ps += __shfl_xor(ps, 32, 64);
-      lsum = lsum * alpha + ps;
+    };
+    RBX_FOR_WAVE_TILES(nT, wid, qt) {
+      const int i0 = qt * kT, qi = i0 + li;
+      float qreg[HD / 2];
+      load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
+      fetch_next();                                            // (behind the wave's own operand loads: those return first)
+      f32x16 oacc[HD / 32];
 #pragma unroll
       for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-      m = mn;
-      if (DROP) {        // dropout on the probabilities (nn.MultiheadAttention / ScaledDotProductAttention): the
-                         // normaliser lsum stays the undropped sum, kept entries are scaled by 1 / (1 - p)
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+      float m = -INFINITY, lsum = 0.f;
+      const int kt_end = causal ? qt : nT - 1;
+      for (int kt = 0; kt <= kt_end; ++kt) {
+        const int j0 = kt * kT;
+        f32x16 s = tile_dot<HD>(Ks, j0, qreg);                 // S^T[key][query]
+        float mx = -INFINITY;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          unsigned c[4];
-          drop_block(static_cast<unsigned>(qi) >> 2, static_cast<unsigned>(j0 + 8 * g + 4 * half) >> 2,
-                     static_cast<unsigned long long>(bh), (qi & 3) >> 1, dk0, dk1, c);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) s[4 * g + q] = drop_keep(c, qi & 1, q, drop.thr16) ? s[4 * g + q] * drop.scale : 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int kj = j0 + tile_row(r, half);
+          if (kj >= L || (causal && kj > qi)) s[r] = -INFINITY;
+          mx = fmaxf(mx, s[r]);
         }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = (mn == -INFINITY) ? 1.f : __expf(m - mn);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - mn);
+          ps += s[r];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        m = mn;
+        if (DROP) {        // dropout on the probabilities (nn.MultiheadAttention / ScaledDotProductAttention): the
+                           // normaliser lsum stays the undropped sum, kept entries are scaled by 1 / (1 - p)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            unsigned c[4];
+            drop_block(static_cast<unsigned>(qi) >> 2, static_cast<unsigned>(j0 + 8 * g + 4 * half) >> 2,
+                       static_cast<unsigned long long>(bh), (qi & 3) >> 1, dk0, dk1, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[4 * g + q] = drop_keep(c, qi & 1, q, drop.thr16) ? s[4 * g + q] * drop.scale : 0.f;
+          }
+        }
+        tile_accumulate<HD>(Vs, j0, s, oacc);                  // O^T[d][query] += V^T P^T
       }
-      tile_accumulate<HD>(Vs, j0, s, oacc);                  // O^T[d][query] += V^T P^T
+      store_transposed<HD>(O, ld.o, i0, L, 1.0f / lsum, oacc);
+      if (half == 0 && qi < L) LSE[bh * L + qi] = m + __logf(lsum);
     }
-    store_transposed<HD>(O, ld.o, i0, L, 1.0f / lsum, oacc);
-    if (half == 0 && qi < L) LSE[bh * L + qi] = m + __logf(lsum);
+    if (PF && !fetched) fetch_next();                          // (a wavefront without a tile still fetches its share)
+    if constexpr (PF) __syncthreads();                         // every wavefront is done with this sequence's K, V rows
   }
 }
 
@@ -407,10 +483,24 @@ template <int HD, bool DROP>
 static int run_fwd(const float* q, const float* k, const float* v, long long bh, int L, float scale, int causal, float* o,
                    float* lse, const DropArgs& drop, const AttnLd& ld, hipStream_t s) {
   const size_t lds = lds_bytes<HD>(L, false);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD, DROP>),
+  static const bool pf_on = [] { const char* e = getenv("RBX_ATTN_PREFETCH"); return e == nullptr || e[0] != '0'; }();
+  if constexpr (HD == 64) {
+    if (pf_on && lds > 80 * 1024 && bh > kCUs) {             // one workgroup per CU either way: loop over sequences, prefetch
+      const int npf = ((L + kT - 1) / kT * kT) * (HD / 4) / kAttnThreads;      // 6, 7 or 8 at Lp = 192, 224, 256
+#define RBX_ATTN_PF(N)                                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD, DROP, N>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                      \
+      hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD, DROP, N>), dim3(kCUs), dim3(kAttnThreads), lds, s, q, k, v, L, scale,   \
+                         causal, o, lse, drop, ld, bh)
+      if (npf == 6) { RBX_ATTN_PF(6); } else if (npf == 7) { RBX_ATTN_PF(7); } else { RBX_ATTN_PF(8); }
+#undef RBX_ATTN_PF
+      return check_launch("attn_mfma_fwd_kernel");
+    }
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD, DROP, 0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD, DROP>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, q, k, v, L,
-                     scale, causal, o, lse, drop, ld);
+  hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD, DROP, 0>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, q, k, v,
+                     L, scale, causal, o, lse, drop, ld, bh);
   return check_launch("attn_mfma_fwd_kernel");
 }
 
