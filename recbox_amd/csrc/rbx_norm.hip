@@ -70,30 +70,33 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// a workgroup owns 64 columns: its 4 wavefronts merge every 4th row block (in order), the four results are merged
-// in a fixed order; then mean / rstd and the running statistics
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ partial, const int nblocks, const int cols,
+// a workgroup owns 64 columns: its 16 wavefronts merge every 16th row block (in order), the sixteen results are merged
+// in a fixed order; then mean / rstd and the running statistics.  (Four wavefronts walked 128 partials each at B = 65 536,
+// eight loads in flight at a time: sixteen dependent round trips, 13-24 us for a few KB.)
+constexpr int kBnFinalWaves = 16;
+__global__ __launch_bounds__(64 * kBnFinalWaves) void bn_stats_final_kernel(const float* __restrict__ partial, const int nblocks,
+                                                             const int cols,
                                                              const float eps, const float momentum,
                                                              float* __restrict__ running_mean,
                                                              float* __restrict__ running_var, float* __restrict__ mean,
                                                              float* __restrict__ rstd) {
-  __shared__ Welford red[4][64];
+  __shared__ Welford red[kBnFinalWaves][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
   Welford t = {0.f, 0.f, 0.f};
   if (c < cols)
   {
     int b = zl;
-    for (; b + 28 < nblocks; b += 32) {                      // 8 partials in flight, merged in ascending order
+    for (; b + 7 * kBnFinalWaves < nblocks; b += 8 * kBnFinalWaves) {      // 8 partials in flight, merged in ascending order
       Welford o[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const float* src = partial + (static_cast<long long>(b + 4 * u) * cols + c) * 3;
+        const float* src = partial + (static_cast<long long>(b + kBnFinalWaves * u) * cols + c) * 3;
         o[u] = {src[0], src[1], src[2]};
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) t.merge(o[u]);
     }
-    for (; b < nblocks; b += 4) {
+    for (; b < nblocks; b += kBnFinalWaves) {
       const float* src = partial + (static_cast<long long>(b) * cols + c) * 3;
       const Welford o = {src[0], src[1], src[2]};
       t.merge(o);
@@ -103,9 +106,8 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __rest
   __syncthreads();
   if (zl != 0 || c >= cols) return;
   t = red[0][threadIdx.x];
-  t.merge(red[1][threadIdx.x]);
-  t.merge(red[2][threadIdx.x]);
-  t.merge(red[3][threadIdx.x]);
+#pragma unroll
+  for (int z = 1; z < kBnFinalWaves; ++z) t.merge(red[z][threadIdx.x]);
   const float var = t.m2 / t.n;                                  // biased: what normalises the batch
   mean[c] = t.mean;
   rstd[c] = 1.0f / sqrtf(var + eps);
@@ -447,7 +449,7 @@ extern "C" int rbx_batchnorm_fwd(const float* d_x, int64_t rows, int32_t cols, c
     const int nb = bn_blocks(rows);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, static_cast<long long>(rows),
                        cols, partial);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, nb, cols, eps, momentum, d_running_mean,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((cols + 63) / 64), dim3(64 * kBnFinalWaves), 0, s, partial, nb, cols, eps, momentum, d_running_mean,
                        d_running_var, d_mean, d_rstd);
   } else {
     if (!d_running_mean || !d_running_var) return fail(RBX_ERR_INVALID, "batchnorm: eval mode needs the running statistics");
