@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256, RBX_REDUCE_WAVES) void segment_reduce_kernel(c
 #ifndef RBX_REDUCE_U
 #define RBX_REDUCE_U 8
 #endif
-  constexpr int U = (NV * F::W <= 4) ? RBX_REDUCE_U : 4;      // lookups in flight per lane group (16 measured slower)
+  // lookups in flight per lane group: 8 for rows of up to 32 floats (the FM tables; 16 measured slower), 4 for wider rows
+  // (D = 64 / 128: cfg 4 5.32 -> 5.29 ms, cfg 3 1.93 -> 1.82 ms with 4 instead of 8; with 16 cfg 3 took 2.87 ms)
+  constexpr int U = (G * NV * F::W <= 32) ? RBX_REDUCE_U : 4;
   for (unsigned i0 = s; i0 < e; i0 += U) {
     unsigned kk[U + 1], vv[U];
     {
