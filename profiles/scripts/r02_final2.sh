@@ -11,7 +11,7 @@ for cfg in deepfm sasrec; do
   head -12 $out/mfma_util_$cfg.txt
 done
 (timeout 300 python profiles/gemm_shapes.py; timeout 300 python profiles/gemm_shapes.py --edges) 2>&1 | grep -v amdgpu.ids > $out/gemm_shapes_new.txt
-if [ -f recbox_amd/lib/variants/pipe0.so ]; then
+if [ -f recbox_amd/lib/variants/pipe0.so ]; then  # (only when that variant library has been built: profiles/scripts/build_variant.sh pipe0 -DRBX_GEMM_PIPE=0)
   (RECBOX_HIP_LIB=recbox_amd/lib/variants/pipe0.so timeout 300 python profiles/gemm_shapes.py; RECBOX_HIP_LIB=recbox_amd/lib/variants/pipe0.so timeout 300 python profiles/gemm_shapes.py --edges) 2>&1 | grep -v amdgpu.ids > $out/gemm_shapes_tested_loop_only.txt
 fi
 cat $out/gemm_shapes_new.txt
