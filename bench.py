@@ -861,7 +861,7 @@ def main():
         if args.path == "fused" or sharded:
             # rows + float64 ids + float64 dense values + LR rows + logit + S kept for backward
             per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 8 + n_sparse * 4 + 4 + args.dim * 4
-            kname = "fm_fused_fwd_kernel<%d,1,true>" % (args.dim // 4)
+            kname = "fm_fused_fwd_kernel<%d,1,true,3>" % (args.dim // 4)       # (3 = RBX_F64: the id columns' dtype)
         else:
             per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 8 + n_fields * args.dim * 4
             kname = "embed_fwd_kernel<%d,1,true>" % (args.dim // 4)

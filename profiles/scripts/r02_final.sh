@@ -22,6 +22,7 @@ prof() { # name, bench args
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $out/prof -o b -- python /root/repo/bench.py --no-cpu-baseline $2 > $out/prof_$1.log 2>&1)
   python profiles/topk.py $(find $out/prof -name "*.db" | head -1) 48 > $out/$1_kernel_stats.txt
   if [ $1 = fm ]; then python profiles/timeline.py $(find $out/prof -name "*.db" | head -1) rezero_rows 30 > $out/fm_replay_timeline.txt 2>&1; fi
+  if [ $1 = fm ]; then python profiles/kernel_slice.py $(find $out/prof -name "*.db" | head -1) fm_fused_fwd 24 60 > $out/fm_fwd_kernel_by_phase.txt 2>&1; fi
   rm -rf $out/prof
 }
 prof fm ""

@@ -182,9 +182,6 @@ __device__ __forceinline__ void store_tile_v(float* __restrict__ tile, const f32
 #ifndef RBX_GEMM_PIPE
 #define RBX_GEMM_PIPE 1
 #endif
-#ifndef RBX_GEMM_PRIO
-#define RBX_GEMM_PRIO 0
-#endif
 
 // MFMA steps kk in [KLO, KHI) of one staged k tile for a wavefront's 2 x 2 tiles of 32 x 32: only the tiles named in
 // LIVE (bit 2 i + j) -- a wavefront whose 32-row / 32-column blocks lie beyond M / N skips
@@ -224,18 +221,12 @@ __device__ __forceinline__ void gemm_steady(const float* __restrict__ A, long lo
   for (; k0 + 3 * BK <= kend; k0 += BK) {
     tile_issue(A, pa, step_a, va);
     tile_issue(B, pb, step_b, vb);
-#if RBX_GEMM_PRIO
-    __builtin_amdgcn_s_setprio(RBX_GEMM_PRIO);
-#endif
     mfma_steps<0, BK / 2, LIVE>(As[cur], Bs[cur], wm, wn, li, lk, acc, wm + 32, wn + 32);
     __builtin_amdgcn_sched_barrier(0);
     tile_arrived(va, vb);
     store_tile_v<AK>(As[cur ^ 1], va);
     store_tile_v<BK_>(Bs[cur ^ 1], vb);
     mfma_steps<BK / 2, BK, LIVE>(As[cur], Bs[cur], wm, wn, li, lk, acc, wm + 32, wn + 32);
-#if RBX_GEMM_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __syncthreads();
     cur ^= 1;
   }
