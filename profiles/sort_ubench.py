@@ -1,5 +1,6 @@
-"""The id sort of the fused FM backward (rbx_fm_sort) on its own, at the bench shape: us per call, nothing beside it.
-    python profiles/sort_ubench.py          (RBX_SORT_LOOKBACK=0 for the histogram + scan form)"""
+"""The id sort of the fused FM backward (rbx_fm_sort) on its own, at the bench shape: us per call (eager launches, so the
+host's launch cost is in it), nothing beside it.  Run it under rocprofv3 --kernel-trace --stats for the kernels' own times.
+    python profiles/sort_ubench.py"""
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +26,7 @@ def main():
         res = model.presort(X, into=res)
     b.record()
     torch.cuda.synchronize()
-    print("rbx_fm_sort: %.1f us per call (RBX_SORT_LOOKBACK=%s)" % (a.elapsed_time(b) / n * 1e3, os.environ.get("RBX_SORT_LOOKBACK", "1")))
+    print("rbx_fm_sort: %.1f us per call" % (a.elapsed_time(b) / n * 1e3))
 
 
 if __name__ == "__main__":
