@@ -13,10 +13,16 @@
 // flags.  Tile 128x128x16 per 256-thread workgroup, 2x2 waves, each wave 2x2 MFMA tiles
 // of 32x32 (64 accumulator VGPRs).  Operands are staged k-major in LDS (As[k][m],
 // Bs[k][n]) so an MFMA operand read is 32 consecutive floats per half-wave: conflict
-// free; the next tile's global loads are issued before the current tile's MFMAs
-// (register double buffering, one barrier per k-tile).  The weight-gradient GEMM has a
-// tiny output and K = batch, so it is split along K across workgroups into a workspace
-// and reduced in a fixed order (deterministic, no float atomics).
+// free.  Steady state of the k loop (gemm_steady): the next tile's global loads are issued
+// first (inline assembly, no tests), parked in the other LDS buffer halfway through the
+// current tile's 32 MFMAs, one barrier per k tile, four wavefronts per SIMD; the last two
+// k tiles run the tested loop.  Tiles on the matrix edge take the same loop, skip the
+// 32 x 32 blocks that hold no output and share the live ones between their wavefronts; a
+// narrow tail of output columns rides in the same launch (narrow_tile).  The
+// weight-gradient GEMM has a tiny output and K = batch, so it is split along K across
+// workgroups (one flat launch, full tiles first) into a workspace and reduced in a fixed
+// order (deterministic, no float atomics).  What was measured on the way:
+// profiles/r02/gemm_variants.txt.
 #include <stdlib.h>
 #include "rbx_internal.h"
 
