@@ -86,7 +86,17 @@ __global__ __launch_bounds__(64 * kBnFinalWaves) void bn_stats_final_kernel(cons
   if (c < cols)
   {
     int b = zl;
-    for (; b + 7 * kBnFinalWaves < nblocks; b += 8 * kBnFinalWaves) {      // 8 partials in flight, merged in ascending order
+    for (; b + 15 * kBnFinalWaves < nblocks; b += 16 * kBnFinalWaves) {    // 16 partials in flight, merged in ascending order
+      Welford o[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float* src = partial + (static_cast<long long>(b + kBnFinalWaves * u) * cols + c) * 3;
+        o[u] = {src[0], src[1], src[2]};
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t.merge(o[u]);
+    }
+    for (; b + 7 * kBnFinalWaves < nblocks; b += 8 * kBnFinalWaves) {      // 8 partials in flight
       Welford o[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
