@@ -958,6 +958,30 @@ def test_cos_dot_fuses_the_normalisation_and_mirrors_the_gradient_layout():
     assert blk.grad.untyped_storage().data_ptr() == seen["ptr"]
 
 
+@pytest.mark.parametrize("B,N,D", [(1, 1, 4), (257, 5, 128), (130, 7, 256), (65, 3, 512), (300, 9, 20), (33, 4, 1024),
+                                   (4100, 6, 64), (100, 2, 6)])
+def test_cos_dot_row_widths(B, N, D):
+    """ops.cos_dot over the row widths its kernels split differently: float4 rows on one lane group (D = 4 .. 256), several
+    float4 per lane (D = 512, 1024), the scalar kernels (D % 4 != 0 or no power-of-two group), more candidates than one chunk
+    of four -- values and both gradients against float64, a zero row included."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(B + N + D)
+    u0 = torch.randn(B, D, generator=g)
+    v0 = torch.randn(B, N, D, generator=g)
+    v0[B // 2, N - 1] = 0.0
+    w = torch.randn(B, N, generator=g)
+    ur, vr = u0.double().requires_grad_(True), v0.double().requires_grad_(True)
+    outr = 3.0 * (ur.unsqueeze(1) * F.normalize(vr, p=2, dim=-1, eps=1e-12)).sum(-1)
+    (outr * w.double()).sum().backward()
+    u, v = u0.cuda().requires_grad_(True), v0.cuda().requires_grad_(True)
+    out = ops.cos_dot(u, v, eps=1e-12, scale=3.0)
+    (out * w.cuda()).sum().backward()
+    tol = 2e-5 * max(1.0, D ** 0.5 / 8)
+    assert_close(out, outr.float(), tol, "values")
+    assert_close(u.grad, ur.grad.float(), tol * max(1.0, N ** 0.5), "du")
+    assert_close(v.grad, vr.grad.float(), tol, "dv")
+
+
 def test_deepfm_input_stage_as_one_node_equals_the_three_readers():
     """ops.deepfm_input_stage (tower's first Linear + FM + first-order Linear over one gathered block; the block's gradient out
     of ONE GEMM, rbx_linear_dx_deepfm) against the three separate readers: predictions and every gradient, and against the
