@@ -608,17 +608,17 @@ def test_youtubednn_with_dense_user_features_matches_oracle():
         assert_close(p.grad, want[n].grad, TOL, "grad " + n)
 
 
-@pytest.mark.parametrize("L,D,causal,use_mask,p", [(200, 64, True, False, 0.5), (37, 32, True, False, 0.1),
-                                                   (64, 64, False, False, 0.3), (9, 8, False, True, 0.5),
-                                                   (23, 16, True, False, 0.25)])
-def test_attention_dropout_vs_restatement_with_the_kernels_mask(L, D, causal, use_mask, p):
+@pytest.mark.parametrize("L,D,causal,use_mask,p,BH", [(200, 64, True, False, 0.5, 6), (37, 32, True, False, 0.1, 6),
+                                                      (64, 64, False, False, 0.3, 6), (9, 8, False, True, 0.5, 6),
+                                                      (23, 16, True, False, 0.25, 6),
+                                                      (200, 64, True, False, 0.5, 260)])   # (the forward that loops over sequences)
+def test_attention_dropout_vs_restatement_with_the_kernels_mask(L, D, causal, use_mask, p, BH):
     """Dropout on the attention probabilities inside the fused kernels (nn.MultiheadAttention(dropout) of rechub SASRec,
     sasrec.py:29,56; `attention = self.dropout(attention)` of dot_product_attention.py:40-41): out = (keep o P / (1 - p)) V.
     The kernels' keep mask (a counter-based function, re-evaluated by the backward) is read back through
     rbx_attn_dropout_mask and injected into a torch fp64 restatement: output, returned probabilities and dQ / dK / dV."""
     from recbox_amd import ops
     g = torch.Generator().manual_seed(L + D)
-    BH = 6
     q, k, v = (torch.randn(BH, L, D, generator=g) for _ in range(3))
     R = torch.randn(BH, L, D, generator=g)
     mask = (torch.rand(BH, L, L, generator=g) > 0.2).float() if use_mask else None
@@ -651,6 +651,35 @@ def test_attention_dropout_vs_restatement_with_the_kernels_mask(L, D, causal, us
     assert_close(qc.grad, qd.grad, TOL, "dQ")
     assert_close(kc.grad, kd.grad, TOL, "dK")
     assert_close(vc.grad, vd.grad, TOL, "dV")
+
+
+@pytest.mark.parametrize("L", [192, 200, 256])
+def test_attention_forward_that_loops_over_sequences_equals_one_workgroup_per_sequence(L):
+    """More than 256 sequences of L > 160 at head_dim 64 take the forward kernel that keeps one workgroup per CU, loops over
+    the sequences and prefetches the next K, V into registers (6, 7 or 8 float4 per thread at L = 192, 200, 256); the same
+    sequences in two launches of at most 256 take the one-workgroup-per-sequence kernel.  Same arithmetic in the same order:
+    bit-identical outputs and gradients."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(L)
+    BH, D = 300, 64
+    q, k, v = (torch.randn(BH, 1, L, D, generator=g).cuda() for _ in range(3))
+    R = torch.randn(BH, 1, L, D, generator=g).cuda()
+
+    def run(lo, hi):
+        qq, kk, vv = (t[lo:hi].clone().requires_grad_(True) for t in (q, k, v))
+        o, _ = ops.attention(qq, kk, vv, scale=D ** -0.5, causal=True, fill=float("-inf"))
+        (o * R[lo:hi]).sum().backward()
+        return o.detach(), qq.grad, kk.grad, vv.grad
+
+    whole = run(0, BH)
+    parts = [run(0, 150), run(150, BH)]
+    for i, name in enumerate(("out", "dq", "dk", "dv")):
+        assert torch.equal(whole[i], torch.cat([p[i] for p in parts])), name
+    # and it is right: one sequence against float64
+    qd, kd, vd = (t[BH - 1, 0].double().cpu() for t in (q, k, v))
+    s = (qd @ kd.t()) * D ** -0.5
+    s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf"))
+    assert_close(whole[0][BH - 1, 0], (s.softmax(-1) @ vd).float(), TOL, "last sequence")
 
 
 def test_sasrec_trains_with_the_reference_default_dropout():
