@@ -138,6 +138,31 @@ def test_linear_matches_torch_fp32(M, N, K, act):
     assert_close(bc.grad, br.grad.float(), 1e-4 * max(1.0, M ** 0.5 / 16), "db")
 
 
+@pytest.mark.parametrize("M,N,K", [(4100, 168, 70), (300, 400, 64), (4224, 256, 48), (129, 130, 17), (8192, 64, 64)])
+def test_linear_epilogue_operands_on_every_tile_kind(M, N, K):
+    """The optional tail of the GEMM epilogue -- y = (act(x W^T + b) + residual) * row_scale[row] (rbx_linear_fwd_fused) and
+    dx = ((dy W) o [mask > 0]) + residual (rbx_linear_dx_fused) -- on interior tiles (operands fetched four outputs at a
+    time, untested), on edge tiles, and on a narrow column tail that rides in the main launch, against float64."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    rs = (torch.rand(M, generator=g) > 0.3).float() * 1.5
+    want = (torch.relu(x.double() @ w.double().t() + b.double()) + res.double()) * rs.double()[:, None]
+    got = ops._lin_fwd(x.cuda(), w.cuda(), b.cuda(), act=1, residual=res.cuda(), row_scale=rs.cuda())
+    assert_close(got, want.float(), 2e-5 * max(1.0, K ** 0.5 / 8), "fused forward")
+    dy = torch.randn(M, N, generator=g)
+    mask = torch.randn(M, K, generator=g)
+    res2 = torch.randn(M, K, generator=g)
+    want = (dy.double() @ w.double()) * (mask.double() > 0) + res2.double()
+    got = ops._lin_dx(dy.cuda(), w.cuda(), mask=mask.cuda(), residual=res2.cuda())
+    assert_close(got, want.float(), 2e-5 * max(1.0, N ** 0.5 / 8), "fused dx")
+    got = ops._lin_dx(dy.cuda(), w.cuda())
+    assert_close(got, (dy.double() @ w.double()).float(), 2e-5 * max(1.0, N ** 0.5 / 8), "plain dx")
+
+
 def test_sdpa_and_losses_golden():
     import recbox_amd.ranking.pytorch.layers as L
     fx = Fixture("attention_losses")
