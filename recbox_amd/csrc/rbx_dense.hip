@@ -172,8 +172,12 @@ __device__ __forceinline__ void tile_issue(const float* base, long long (&off)[N
   }
 }
 __device__ __forceinline__ void tile_arrived(f32x4 (&a)[NP], f32x4 (&b)[NP]) {
-  static_assert(NP == 2, "operand list below is written for two float4 per thread and operand");
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : : "memory");
+  static_assert(NP == 2 || NP == 4, "operand lists below are written for two / four float4 per thread and operand");
+  if constexpr (NP == 2)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[NP - 2]), "+v"(a[NP - 1]), "+v"(b[0]), "+v"(b[1]),
+                 "+v"(b[NP - 2]), "+v"(b[NP - 1]) : : "memory");
 }
 template <bool KCONTIG>
 __device__ __forceinline__ void store_tile_v(float* __restrict__ tile, const f32x4 (&v)[NP]) {
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
 // C[M,N] (+bias, act) = A(M,K) * B(K,N); with splits > 1 a workgroup computes one K slice of its tile
 // (then C points at the slice's private [M,N] buffer: C + z * M * N, no epilogue math).
 template <bool A_KCONTIG, bool B_KCONTIG>
-__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const float* __restrict__ A, const long long lda,
+__global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_f32_kernel(const float* __restrict__ A, const long long lda,
                                                        const float* __restrict__ B, const long long ldb,
                                                        float* __restrict__ C, const long long ldc, const int M,
                                                        const int N, const int K, const int k_per_split,
