@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 112          /* 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
+#define RBX_VERSION 113          /* 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+                                  * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
 
@@ -172,7 +173,16 @@ int rbx_pairmul_bwd(const float* d_left, const float* d_right, const float* d_do
  * emb[i].grad / lr[i].grad (dense; stored when accumulate == 0, added otherwise) and d_dbias[1].
  * phases: bit 0 = categorical tables (needs the sort), bit 1 = numeric weights + bias (does
  * not): a caller that sorts on another stream runs phase 2 first and phase 1 after the join; bit 2 = the
- * numeric-feature gradients and d_dbias are uninitialised memory: STORE them (no zero fill by the caller) instead of adding. */
+ * numeric-feature gradients and d_dbias are uninitialised memory: STORE them (no zero fill by the caller) instead of adding.
+ * Two tiers (round 3).  Tables of up to 16 384 rows ("tier A", admitted smallest first while their gradients stay under
+ * 4 MB; a rule over the tables alone, never the batch) skip the global sort: rbx_fm_sort leaves, per (feature, block of
+ * 2048 samples), the block's (row, sample) pairs sorted in LDS and a bitmap of the rows present; rbx_fm_bwd sums
+ * g_b S_b per (block, row), then ONE lane group per table row adds that row's block partials in ascending order and
+ * WRITES the row -- every row of a tier-A table is written by every backward (zeros where nothing was looked up), so
+ * these tables need no zero fill and rbx_fm_rezero skips them.  The other tables ("tier B") keep the sorted, segmented
+ * path.  All sums have a fixed order: gradients are bit-identical run to run.  With bit 0 set, bit 3 (8) leaves tier A
+ * out and bit 4 (16) leaves tier B out of this call: a caller with two streams runs the two tiers side by side (tier A
+ * needs rbx_fm_sort_phases bits 0 and 2 done, tier B bits 0 and 1).  Calls with emb == NULL are one tier (B). */
 int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                const float* d_lr_bias, const float* d_extra, int32_t n_extra, int32_t extra_stride,
                int32_t extra_lr_off, const int32_t* d_extra_index, int64_t extra_rows, float* d_logit,
@@ -261,6 +271,12 @@ int rbx_shard_combine_bwd(const rbx_shard_geom_t* geom, const float* d_dout, int
 size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch);
 int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                 void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream);
+/* rbx_fm_sort in pieces, for a caller that wants to order other work between them.  phases: bit 0 = id columns of any
+ * dtype / stride -> the workspace's int32 [feature][batch] matrix, range-checked (d_status) -- both tiers read it; bit 1 =
+ * tier B: (row, sample) pairs + segmented radix sort; bit 2 = tier A: the per-block sorts.  Bits 1 and 2 need bit 0 done
+ * on the same workspace (same call or an earlier one on the same stream).  rbx_fm_sort == all three. */
+int rbx_fm_sort_phases(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+                       void* d_workspace, size_t workspace_bytes, int32_t* d_status, int32_t phases, void* stream);
 int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                const float* d_dlogit, const float* d_sum, float* d_dbias, int32_t accumulate,
                int32_t phases, void* d_workspace, size_t workspace_bytes, void* stream);

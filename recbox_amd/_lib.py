@@ -82,6 +82,7 @@ SIGNATURES = {
     "rbx_route32": (ctypes.c_int, [_FP, _i32, _i64, _i32, _i64, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_fm_bwd_workspace_size": (_sz, [_FP, _FP, _i32, _i64]),
     "rbx_fm_sort": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P, _P]),
+    "rbx_fm_sort_phases": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P, _i32, _P]),
     "rbx_comm_bind": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "rbx_all_to_all": (ctypes.c_int, [_P, _P, _P, _sz, _i32, _P]),
     "rbx_embed_rezero": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P]),

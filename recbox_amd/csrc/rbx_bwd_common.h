@@ -27,7 +27,7 @@ constexpr int kMaxRadixBits = RBX_MAX_RADIX_BITS;
 #ifndef RBX_CHUNK
 #define RBX_CHUNK 40
 #endif
-constexpr int kChunk = RBX_CHUNK;
+constexpr int kChunk = RBX_CHUNK;                          // the LARGEST chunk; a plan with few pairs takes a shorter one (BwdPlan::chunk)
 constexpr unsigned kLocalBits = 26;                        // val = slot << 26 | (b*L + l)
 constexpr unsigned kLocalMask = (1u << kLocalBits) - 1u;
 constexpr int kNumSamples = 256;                            // samples per workgroup in the numeric-feature reduction
@@ -119,6 +119,7 @@ struct BwdPlan {
   // workspace layout (byte offsets)
   size_t off_keys[2], off_vals[2], off_hist, off_ssum, off_head, off_tail, off_flags, off_fin, off_num, bytes;
   unsigned n_tiles = 0, n_chunks = 0, num_blocks = 0;
+  int chunk = kChunk;          // sorted pairs per lane group of the reduce: kChunk, shorter (>= 16) when that leaves fewer than 32 768 chunks
   int sum_stride = 1;          // floats per chunk summary (max_dim + extra)
 };
 

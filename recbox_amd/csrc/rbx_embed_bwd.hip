@@ -19,6 +19,7 @@
 // No float atomics anywhere: run-to-run bit-identical gradients.
 // All phases stream their inputs once; the random traffic is the dY row gather
 // (L2/MALL resident for [B,F,D] <= 256 MiB) and one RMW per touched row.
+#include <stdlib.h>
 #include "rbx_segreduce.h"
 
 namespace rbx {
@@ -156,7 +157,19 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
       S.first_pass[g] = static_cast<unsigned char>(p->passes - need);
     }
   }
-  p->n_chunks = (p->n_lookups + kChunk - 1) / kChunk;
+  // Pairs per lane group of the reduce.  40 is the measured optimum when the batch yields ~100 000 chunks (1.7 M pairs at the
+  // Criteo shape: 666 workgroups, all resident).  With fewer pairs -- the 0.52 M of the eight large tables once the small ones
+  // take the sort-free path -- 40 left 205 workgroups on 256 CUs, each walking 5 dependent rounds of gathers: 69-80 us;
+  // 16 pairs per group: 49 us (profiles/r03).  Rule: at least 32 768 chunks, between 16 and 40 pairs, a multiple of 8.
+  {
+    static const int forced = [] { const char* e = getenv("RBX_REDUCE_CHUNK"); return e != nullptr ? atoi(e) : 0; }();
+    int c = static_cast<int>(p->n_lookups / 32768u) / 8 * 8;
+    if (c < 16) c = 16;
+    if (c > kChunk) c = kChunk;
+    if (forced >= 8 && forced <= kChunk) c = forced / 8 * 8;
+    p->chunk = c;
+  }
+  p->n_chunks = (p->n_lookups + p->chunk - 1) / p->chunk;
   p->num_blocks = static_cast<unsigned>((B + kNumSamples - 1) / kNumSamples);
   size_t o = 0;
   const size_t nl = align_up(static_cast<size_t>(p->n_lookups) * 4, 256);

@@ -24,7 +24,9 @@
 // g[b] (4 B) and S[b] (D*4 B) -- 4.3 MB at B=65 536, D=16, L2-resident -- instead of a
 // 163 MB dE tensor.  Numeric features x_f * w_f reduce over the batch:
 //     dw_f = sum_b g x S_b - w_f sum_b g x^2,   dw_lr_f = sum_b g x,   dbias = sum_b g.
+#include <stdlib.h>
 #include "rbx_segreduce.h"
+#include "rbx_tiera.h"
 
 namespace rbx {
 
@@ -259,6 +261,9 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
 }
 
 // ---- backward policy: contribution g_b * S_b, cnt += g_b; flush dW = A - cnt*w ------------
+#ifndef RBX_ABL
+#define RBX_ABL 0        // ablation mask for measurements only (profiles/scripts): 1 no LR-gradient store, 2 no w_r read,
+#endif                   // 4 no S gather, 8 no dW store -- a non-zero value computes WRONG gradients
 struct FmPolicy {
   static constexpr bool kHasCount = true;
   struct Args {
@@ -272,23 +277,24 @@ struct FmPolicy {
                                                     F& frag, float& cnt) {
     const float g = a.g[local];
     cnt = g;
-    if (a.ssum != nullptr) frag.fma_from(a.ssum + static_cast<size_t>(local) * a.D, fd.dim, lane_g, g);
+    if (!(RBX_ABL & 4) && a.ssum != nullptr) frag.fma_from(a.ssum + static_cast<size_t>(local) * a.D, fd.dim, lane_g, g);
   }
   template <class F>
   static __device__ __forceinline__ void prefetch(const Args&, const RedField& fd, unsigned row, int lane_g, F& pre) {
-    if (fd.grad != nullptr) pre.add_from_nt(fd.table + static_cast<size_t>(row) * fd.table_stride, fd.dim, lane_g);   // w_r
+    if (!(RBX_ABL & 2) && fd.grad != nullptr)
+      pre.add_from_nt(fd.table + static_cast<size_t>(row) * fd.table_stride, fd.dim, lane_g);   // w_r
   }
   template <class F>
   static __device__ __forceinline__ void flush(const Args& a, const RedField& fd, unsigned row, const F& acc, float cnt,
                                                const F& pre, int lane_g) {
-    if (fd.grad != nullptr) {
+    if (!(RBX_ABL & 8) && fd.grad != nullptr) {
       F out = acc;                                               // A - cnt * w_r
 #pragma unroll
       for (int q = 0; q < static_cast<int>(sizeof(out.a) / sizeof(float)); ++q) out.a[q] -= cnt * pre.a[q];
       float* dst = fd.grad + static_cast<size_t>(row) * fd.dim;
       if (a.accumulate) out.accumulate_into(dst, fd.dim, lane_g); else out.store_nt(dst, fd.dim, lane_g);
     }
-    if (fd.grad2 != nullptr && lane_g == 0) {
+    if (!(RBX_ABL & 1) && fd.grad2 != nullptr && lane_g == 0) {
       if (a.accumulate) fd.grad2[row] += cnt; else fd.grad2[row] = cnt;
     }
   }
@@ -595,14 +601,39 @@ static int dispatch_fm_fwd(const FmHost& h, int64_t B, const float* bias, const 
   }
 }
 
-// plan over the categorical features (keys from `lead`, grads from emb and lr)
+// Which tables take the sort-free path of rbx_tiera.h.  The rule looks at the tables only (rows, dim), never at the
+// batch: a persistent gradient buffer is cleared by the PREVIOUS step's plan (rbx_fm_rezero), which must agree with this
+// step's about who writes which table in full.  Tables are admitted in ascending row count while the gradients of the
+// admitted ones stay under 4 MB (the partial arrays are that times the number of 2048-sample blocks).
+static int fm_tier_a_max_vocab() {      // RBX_FM_TIER_A=0: every table through the global sort (A/B measurement)
+  static const int v = [] {
+    const char* e = getenv("RBX_FM_TIER_A");
+    if (e != nullptr && e[0] == '0') return 0;
+    const char* m = getenv("RBX_FM_TIER_A_VMAX");
+    // default 4096 rows: measured at the Criteo shape (profiles/r03), 2200 / 4096 / 16384 give 0.257 / 0.251 / 0.253 ms per
+    // step -- a table of 5 000-15 000 rows costs as much either way (block partials that hardly merge vs L2-resident rows in
+    // the sorted path), and the partial arrays of the 16384 setting are 3x the workspace
+    int x = (m != nullptr) ? atoi(m) : 4096;
+    if (x > kTaMaxVocab) x = kTaMaxVocab;
+    return x < 0 ? 0 : x;
+  }();
+  return v;
+}
+
+// plan over the categorical features (keys from `lead`, grads from emb and lr): the tables of tier A go to `ta`, the
+// others to the sort plan `p`, whose id columns are the rows of the compact id matrix (patched in by fm_bind_cid once
+// the workspace is known)
 static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t B, BwdPlan* p, FmNumPack* np,
-                   int* n_num) {
+                   int* n_num, TaPlan* ta, int* cid_of_key) {
   rbx_field_t tmp[RBX_MAX_FIELDS];
   const rbx_field_t* lead = (emb != nullptr) ? emb : lr;
   *n_num = 0;
   int n_cat = 0;
   int cat_src[RBX_MAX_FIELDS];
+  const int D = emb ? emb[0].dim : 1;
+  *ta = TaPlan();
+  ta->D = D;
+  ta->has_emb = emb != nullptr;
   for (int i = 0; i < n; ++i) {
     if (lead[i].kind == RBX_FIELD_NUMERIC) {
       FmNumField& f = np->f[(*n_num)++];
@@ -615,31 +646,137 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
       f.reserved = 0;
       continue;
     }
-    tmp[n_cat] = lead[i];
     // a feature whose tables are all frozen still needs no sort entry
     float* g1 = emb ? emb[i].grad : nullptr;
     float* g2 = lr ? lr[i].grad : nullptr;
     if (g1 == nullptr && g2 == nullptr) continue;
-    tmp[n_cat].grad = g1 ? g1 : g2;          // make_plan skips fields without a grad
-    tmp[n_cat].out_off = 0;
-    tmp[n_cat].table_stride = 0;             // (the plan's keys do not depend on the storage; the stride is set below)
-    cat_src[n_cat] = i;
-    ++n_cat;
+    cat_src[n_cat++] = i;
   }
-  if (n_cat == 0) {
+  // ---- tier split over the tables (features that share a table go together) ----
+  bool in_a[RBX_MAX_FIELDS];
+  for (int c = 0; c < n_cat; ++c) in_a[c] = false;
+  // (a call without embedding tables -- the LogisticRegression layer of a layer-composed model -- keeps the one-sort form:
+  //  its pairs can then be a copy of the FeatureEmbedding lookup's, rbx_sort_share)
+  const int vmax = (emb != nullptr && D <= kTaMaxDim && B > 0) ? fm_tier_a_max_vocab() : 0;
+  int tab_first[RBX_MAX_FIELDS], n_tabs = 0, tab_of[RBX_MAX_FIELDS];
+  for (int c = 0; c < n_cat; ++c) {
+    const rbx_field_t& a = lead[cat_src[c]];
+    int hit = -1;
+    for (int t = 0; t < n_tabs; ++t)
+      if (lead[cat_src[tab_first[t]]].table == a.table) hit = t;
+    if (hit < 0) { hit = n_tabs; tab_first[n_tabs++] = c; }
+    tab_of[c] = hit;
+  }
+  bool tab_a[RBX_MAX_FIELDS];
+  {
+    int order[RBX_MAX_FIELDS];
+    for (int t = 0; t < n_tabs; ++t) { order[t] = t; tab_a[t] = false; }
+    for (int x = 1; x < n_tabs; ++x)               // insertion sort by (vocab, first field): stable, tiny
+      for (int y = x; y > 0 && lead[cat_src[tab_first[order[y]]]].vocab < lead[cat_src[tab_first[order[y - 1]]]].vocab; --y) {
+        const int t = order[y]; order[y] = order[y - 1]; order[y - 1] = t;
+      }
+    long long budget = 1ll << 20;                   // floats of gradient the admitted tables may hold
+    for (int x = 0; x < n_tabs; ++x) {
+      const int t = order[x];
+      const rbx_field_t& a = lead[cat_src[tab_first[t]]];
+      if (a.vocab > vmax) break;
+      bool same = true;                             // (features of one table must agree on it, as make_plan demands)
+      for (int c = 0; c < n_cat; ++c)
+        if (tab_of[c] == t && lead[cat_src[c]].vocab != a.vocab) same = false;
+      const long long cost = static_cast<long long>(a.vocab) * (D + 1);
+      if (!same || cost > budget) continue;
+      budget -= cost;
+      tab_a[t] = true;
+    }
+    for (int c = 0; c < n_cat; ++c) in_a[c] = tab_a[tab_of[c]];
+  }
+  // ---- the compact id matrix: one row per categorical feature with a gradient (only when some table is in tier A;
+  //      otherwise the sort reads the id columns where they are, as rbx_embed_sort does) ----
+  bool tiered = false;
+  for (int t = 0; t < n_tabs; ++t) tiered = tiered || tab_a[t];
+  ta->n_cid = tiered ? n_cat : 0;
+  bool strided = false;
+  for (int c = 0; c < n_cat; ++c) {
+    const rbx_field_t& a = lead[cat_src[c]];
+    if (a.seq_len != 1 || a.pool != RBX_POOL_NONE) return fail(RBX_ERR_UNSUPPORTED, "fm: sequence features are not fused");
+    if (a.ids == nullptr) return fail(RBX_ERR_INVALID, "fm: feature %d: ids is NULL", cat_src[c]);
+    if (a.ids_dtype < RBX_I32 || a.ids_dtype > RBX_F64) return fail(RBX_ERR_INVALID, "fm: feature %d: bad ids_dtype", cat_src[c]);
+    if (a.vocab <= 0 || a.vocab > INT_MAX) return fail(RBX_ERR_INVALID, "fm: feature %d: bad vocab", cat_src[c]);
+    CidField& cf = ta->cid.f[c];
+    cf.ids = a.ids;
+    cf.stride_b = a.ids_stride_b;
+    cf.vocab = static_cast<int>(a.vocab);
+    cf.dtype = a.ids_dtype;
+    if (a.ids_stride_b != 1) strided = true;
+  }
+  ta->field_fast = strided;
+  ta->cid_ts = 32;                                 // samples per tile of compact_ids_kernel: a power of two, tile <= 2048 ids
+  while (ta->cid_ts < 256 && 2 * ta->cid_ts * n_cat <= 256 * kCidPerThread) ta->cid_ts *= 2;
+  ta->NB = static_cast<unsigned>((B + kTaBlock - 1) / kTaBlock);
+  // ---- tier A descriptors: fields grouped by table ----
+  ta->vec = emb != nullptr && (D % 4 == 0);
+  for (int t = 0; t < n_tabs; ++t) {
+    if (!tab_a[t]) continue;
+    const int i0 = cat_src[tab_first[t]];
+    TaTable& tb = ta->tab.t[ta->n_tab++];
+    tb.grad = emb ? emb[i0].grad : nullptr;
+    tb.grad2 = lr ? lr[i0].grad : nullptr;
+    tb.table = emb ? emb[i0].table : nullptr;
+    tb.stride = (emb && emb[i0].table_stride != 0) ? static_cast<int>(emb[i0].table_stride) : D;
+    tb.vocab = static_cast<int>(lead[i0].vocab);
+    tb.pad = (lead[i0].padding_idx == RBX_NO_ID || lead[i0].padding_idx < INT_MIN || lead[i0].padding_idx > INT_MAX)
+                 ? kNoId : static_cast<int>(lead[i0].padding_idx);
+    tb.f_begin = static_cast<short>(ta->n_fld);
+    tb.f_count = 0;
+    tb.row0 = ta->rows;
+    tb.reserved = 0;
+    ta->rows += static_cast<unsigned>(tb.vocab);
+    if (tb.stride % 4 != 0) ta->vec = false;
+    if (tb.grad != nullptr && (reinterpret_cast<uintptr_t>(tb.grad) & 15) != 0) ta->vec = false;
+    if (tb.table != nullptr && (reinterpret_cast<uintptr_t>(tb.table) & 15) != 0) ta->vec = false;
+    for (int c = 0; c < n_cat; ++c) {
+      if (tab_of[c] != t) continue;
+      TaField& fd = ta->fld.f[ta->n_fld++];
+      fd.cid_row = c;
+      fd.vocab = tb.vocab;
+      fd.frow0 = ta->frows;
+      fd.fword0 = ta->fwords;
+      ta->frows += static_cast<unsigned>(tb.vocab);
+      ta->fwords += static_cast<unsigned>((tb.vocab + 31) / 32);
+      ++tb.f_count;
+    }
+  }
+  ta_layout(ta, B);
+  // ---- tier B: the sort plan ----
+  int n_b = 0;
+  int b_src[RBX_MAX_FIELDS];
+  for (int c = 0; c < n_cat; ++c) {
+    if (in_a[c]) continue;
+    const int i = cat_src[c];
+    tmp[n_b] = lead[i];
+    float* g1 = emb ? emb[i].grad : nullptr;
+    float* g2 = lr ? lr[i].grad : nullptr;
+    tmp[n_b].grad = g1 ? g1 : g2;            // make_plan skips fields without a grad
+    tmp[n_b].out_off = 0;
+    tmp[n_b].table_stride = 0;               // (the plan's keys do not depend on the storage; the stride is set below)
+    b_src[n_b] = i;
+    cid_of_key[n_b] = c;
+    ++n_b;
+  }
+  const int ns = fm_num_samples(D, *n_num);
+  if (n_b == 0) {
+    *p = BwdPlan();
     p->n_lookups = 0;
     p->bytes = 256;
-    const int D0 = emb ? emb[0].dim : 1;
-    p->num_blocks = static_cast<unsigned>((B + fm_num_samples(D0, *n_num) - 1) / fm_num_samples(D0, *n_num));
+    p->num_blocks = static_cast<unsigned>((B + ns - 1) / ns);
     return RBX_OK;
   }
-  const int D = emb ? emb[0].dim : 1;
-  int rc = make_plan(tmp, n_cat, B, nullptr, 0, p, /*extra_dim=*/4);
+  int rc = make_plan(tmp, n_b, B, nullptr, 0, p, /*extra_dim=*/4);
   if (rc != RBX_OK) return rc;
-  if (p->n_cat != n_cat) return fail(RBX_ERR_INVALID, "fm: internal plan mismatch");
+  if (p->n_cat != n_b) return fail(RBX_ERR_INVALID, "fm: internal plan mismatch");
   p->vec = emb != nullptr && (D % 4 == 0);
-  for (int c = 0; c < n_cat; ++c) {
-    const int i = cat_src[c];
+  for (int c = 0; c < n_b; ++c) {
+    const int i = b_src[c];
     RedField& rf = p->red.f[c];
     rf.grad = emb ? emb[i].grad : nullptr;
     rf.grad2 = lr ? lr[i].grad : nullptr;
@@ -651,12 +788,48 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
     if (rf.table != nullptr && (reinterpret_cast<uintptr_t>(rf.table) & 15) != 0) p->vec = false;
   }
   p->max_dim = D;
-  p->num_blocks = static_cast<unsigned>((B + fm_num_samples(D, *n_num) - 1) / fm_num_samples(D, *n_num));
+  p->num_blocks = static_cast<unsigned>((B + ns - 1) / ns);
   return RBX_OK;
 }
 
 static size_t fm_num_bytes(const BwdPlan& p, int n_num, int D) {
   return static_cast<size_t>(p.num_blocks) * (n_num + 1) * (D + 2) * sizeof(float) + 256;
+}
+
+// Everything one fused FM backward needs, derived from the descriptor arrays alone.  Workspace layout:
+//   [ sort plan of tier B: p.bytes | numeric partials: fm_num_bytes | tier A region (compact ids first): ta.bytes ]
+struct FmFull {
+  BwdPlan p;
+  FmNumPack np;
+  TaPlan ta;
+  int n_num = 0;
+  int D = 1;
+  int cid_of_key[RBX_MAX_FIELDS];
+  size_t off_ta = 0, bytes = 0;
+};
+
+static int fm_full_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t B, FmFull* f) {
+  if (emb == nullptr && lr == nullptr) return fail(RBX_ERR_INVALID, "fm: both field arrays are NULL");
+  if (n <= 0 || n > RBX_MAX_FIELDS) return fail(RBX_ERR_INVALID, "fm: n_fields=%d not in [1,%d]", n, RBX_MAX_FIELDS);
+  int rc = fm_plan(emb, lr, n, B, &f->p, &f->np, &f->n_num, &f->ta, f->cid_of_key);
+  if (rc != RBX_OK) return rc;
+  f->D = emb ? emb[0].dim : 1;
+  f->off_ta = ta_align(f->p.bytes + fm_num_bytes(f->p, f->n_num, f->D));
+  f->bytes = f->off_ta + f->ta.bytes;
+  return RBX_OK;
+}
+
+// the sort plan reads its ids from the compact matrix inside THIS workspace
+static void fm_bind_cid(FmFull* f, char* ws, int64_t B) {
+  if (f->ta.n_cid == 0) return;
+  const int* cid = reinterpret_cast<const int*>(ws + f->off_ta + f->ta.off_cid);
+  for (int c = 0; c < f->p.n_cat; ++c) {
+    KeyField& kf = f->p.keys.f[c];
+    kf.ids = cid + static_cast<size_t>(f->cid_of_key[c]) * static_cast<size_t>(B);
+    kf.stride_b = 1;
+    kf.stride_l = 0;
+    kf.dtype = RBX_I32;
+  }
 }
 
 
@@ -666,14 +839,12 @@ extern "C" int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int3
                              void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace rbx;
   if (batch == 0) return RBX_OK;
-  BwdPlan p;
-  FmNumPack np;
-  int n_num = 0;
-  int rc = fm_plan(emb, lr, n_fields, batch, &p, &np, &n_num);
+  FmFull f;
+  int rc = fm_full_plan(emb, lr, n_fields, batch, &f);
   if (rc != RBX_OK) return rc;
-  if (p.n_lookups == 0) return RBX_OK;
-  if (d_workspace == nullptr || workspace_bytes < p.bytes) return fail(RBX_ERR_WORKSPACE, "fm_rezero: workspace too small");
-  return launch_rezero(p, static_cast<const char*>(d_workspace), as_stream(stream));
+  if (f.p.n_lookups == 0) return RBX_OK;          // (tier-A tables are written in full by every backward: nothing to clear)
+  if (d_workspace == nullptr || workspace_bytes < f.p.bytes) return fail(RBX_ERR_WORKSPACE, "fm_rezero: workspace too small");
+  return launch_rezero(f.p, static_cast<const char*>(d_workspace), as_stream(stream));
 }
 
 namespace rbx {
@@ -709,25 +880,42 @@ extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
 extern "C" size_t rbx_fm_bwd_workspace_size(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields,
                                             int64_t batch) {
   using namespace rbx;
-  BwdPlan p;
-  FmNumPack np;
-  int n_num = 0;
-  if (fm_plan(emb, lr, n_fields, batch, &p, &np, &n_num) != RBX_OK) return 0;
-  const int D = emb ? emb[0].dim : 1;
-  return p.bytes + fm_num_bytes(p, n_num, D);
+  FmFull f;
+  if (fm_full_plan(emb, lr, n_fields, batch, &f) != RBX_OK) return 0;
+  return f.bytes;
+}
+
+extern "C" int rbx_fm_sort_phases(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+                                  void* d_workspace, size_t workspace_bytes, int32_t* d_status, int32_t phases,
+                                  void* stream) {
+  using namespace rbx;
+  if (batch <= 0) return RBX_OK;
+  FmFull f;
+  int rc = fm_full_plan(emb, lr, n_fields, batch, &f);
+  if (rc != RBX_OK) return rc;
+  if (f.ta.n_cid == 0 && f.p.n_lookups == 0) return RBX_OK;
+  if (d_workspace == nullptr || workspace_bytes < f.bytes) return fail(RBX_ERR_WORKSPACE, "fm: workspace too small");
+  char* ws = static_cast<char*>(d_workspace);
+  hipStream_t s = as_stream(stream);
+  if (phases & 1) {      // ids of every dtype / stride -> int32 [feature][B], range-checked once; both tiers read that
+    rc = ta_launch_compact(f.ta, batch, ws + f.off_ta, d_status, s);
+    if (rc != RBX_OK) return rc;
+  }
+  if (phases & 4) {      // tier A: per-block sorts in LDS
+    rc = ta_launch_blocksort(f.ta, batch, ws + f.off_ta, s);
+    if (rc != RBX_OK) return rc;
+  }
+  if (phases & 2) {      // tier B: global segmented radix sort (a one-tier call reads the id columns where they are)
+    fm_bind_cid(&f, ws, batch);
+    rc = run_sort(f.p, ws, f.ta.n_cid == 0 ? d_status : nullptr, s);
+    if (rc != RBX_OK) return rc;
+  }
+  return RBX_OK;
 }
 
 extern "C" int rbx_fm_sort(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                            void* d_workspace, size_t workspace_bytes, int32_t* d_status, void* stream) {
-  using namespace rbx;
-  BwdPlan p;
-  FmNumPack np;
-  int n_num = 0;
-  int rc = fm_plan(emb, lr, n_fields, batch, &p, &np, &n_num);
-  if (rc != RBX_OK) return rc;
-  if (p.n_lookups == 0) return RBX_OK;
-  if (d_workspace == nullptr || workspace_bytes < p.bytes) return fail(RBX_ERR_WORKSPACE, "fm: workspace too small");
-  return run_sort(p, static_cast<char*>(d_workspace), d_status, as_stream(stream));
+  return rbx_fm_sort_phases(emb, lr, n_fields, batch, d_workspace, workspace_bytes, d_status, 7, stream);
 }
 
 namespace rbx {
@@ -765,9 +953,14 @@ __global__ __launch_bounds__(256) void copy_pairs_kernel(const unsigned* __restr
 
 static int plan_of(const rbx_field_t* a, const rbx_field_t* b, int n, int is_fm, int64_t B, BwdPlan* p) {
   if (is_fm) {
-    FmNumPack np;
-    int n_num = 0;
-    return fm_plan(a, b, n, B, p, &np, &n_num);
+    // a tiered fused FM sort is more than sorted pairs (compact ids, block sorts of the small tables) and its keys live
+    // in its own workspace: it is neither a source nor a destination of a copy
+    FmFull f;
+    const int rc = fm_full_plan(a, b, n, B, &f);
+    if (rc != RBX_OK) return rc;
+    if (f.ta.n_cid != 0) return RBX_ERR_UNSUPPORTED;
+    *p = f.p;
+    return RBX_OK;
   }
   return make_plan(a, n, B, nullptr, 0, p);
 }
@@ -783,6 +976,7 @@ extern "C" int rbx_sort_share(const rbx_field_t* src_a, const rbx_field_t* src_b
   BwdPlan src, dst;
   if (plan_of(src_a, src_b, src_n, src_is_fm, batch, &src) != RBX_OK) return RBX_ERR_UNSUPPORTED;
   int rc = plan_of(dst_a, dst_b, dst_n, dst_is_fm, batch, &dst);
+  if (rc == RBX_ERR_UNSUPPORTED) return rc;
   if (rc != RBX_OK) return rc;
   if (dst.n_lookups == 0 || !same_pairs(src, dst)) return RBX_ERR_UNSUPPORTED;
   if (dst_workspace_bytes < dst.bytes) return fail(RBX_ERR_WORKSPACE, "sort_share: workspace too small");
@@ -806,18 +1000,17 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
   if (d_dlogit == nullptr) return fail(RBX_ERR_INVALID, "fm: d_dlogit is NULL");
   if (emb != nullptr && d_sum == nullptr) return fail(RBX_ERR_INVALID, "fm: d_sum from the forward is required");
   if (batch == 0) return RBX_OK;
-  BwdPlan p;
-  FmNumPack np;
-  int n_num = 0;
-  int rc = fm_plan(emb, lr, n_fields, batch, &p, &np, &n_num);
+  FmFull f;
+  int rc = fm_full_plan(emb, lr, n_fields, batch, &f);
   if (rc != RBX_OK) return rc;
-  const int D = emb ? emb[0].dim : 1;
-  const size_t need = p.bytes + fm_num_bytes(p, n_num, D);
+  const BwdPlan& p = f.p;
+  const int D = f.D, n_num = f.n_num;
+  const size_t need = f.bytes;
   if (d_workspace == nullptr || workspace_bytes < need)
     return fail(RBX_ERR_WORKSPACE, "fm: workspace %zu B < required %zu B", workspace_bytes, need);
   char* ws = static_cast<char*>(d_workspace);
   hipStream_t s = as_stream(stream);
-  if (p.n_lookups > 0 && (phases & 1)) {
+  if (p.n_lookups > 0 && (phases & 1) && !(phases & 16)) {
     const int cur = p.passes & 1;
     const unsigned* keys = reinterpret_cast<const unsigned*>(ws + p.off_keys[cur]);
     const unsigned* vals = reinterpret_cast<const unsigned*>(ws + p.off_vals[cur]);
@@ -827,14 +1020,18 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
              : dispatch_reduce<FmPolicy, false>(p, args, keys, vals, ws, s);
     if (rc != RBX_OK) return rc;
   }
+  if ((phases & 1) && !(phases & 8)) {               // the tables of tier A: block partials, then every row written once
+    rc = ta_dispatch_bwd(f.ta, d_dlogit, emb ? d_sum : nullptr, accumulate, ws + f.off_ta, s);
+    if (rc != RBX_OK) return rc;
+  }
   if ((phases & 2) && (n_num > 0 || d_dbias != nullptr)) {
     float* partial = reinterpret_cast<float*>(ws + p.bytes);
     const int ns = fm_num_samples(D, n_num);
     const size_t lds = (static_cast<size_t>(ns) * (D + 1) + 2 * static_cast<size_t>(n_num) * (ns + 1)) * sizeof(float);
-    hipLaunchKernelGGL(fm_numeric_partial_kernel, dim3(p.num_blocks), dim3(256), lds, s, np, n_num,
+    hipLaunchKernelGGL(fm_numeric_partial_kernel, dim3(p.num_blocks), dim3(256), lds, s, f.np, n_num,
                        static_cast<long long>(batch), D, ns, d_dlogit, emb ? d_sum : nullptr, partial,
                        emb != nullptr && D % 4 == 0 && (reinterpret_cast<uintptr_t>(d_sum) & 15) == 0);
-    hipLaunchKernelGGL(fm_numeric_final_kernel, dim3(n_num + 1, D + 2), dim3(64), 0, s, np, n_num, D, p.num_blocks,
+    hipLaunchKernelGGL(fm_numeric_final_kernel, dim3(n_num + 1, D + 2), dim3(64), 0, s, f.np, n_num, D, p.num_blocks,
                        partial, d_dbias, (phases & 4) != 0);
     rc = check_launch("fm numeric kernels");
     if (rc != RBX_OK) return rc;

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256, RBX_REDUCE_WAVES) void segment_reduce_kernel(c
                                                              const unsigned sentinel, float* __restrict__ head,
                                                              float* __restrict__ tail, int* __restrict__ flags,
                                                              unsigned* __restrict__ fin, const int max_dim,
-                                                             const int sum_stride, const unsigned n_chunks) {
+                                                             const int sum_stride, const unsigned n_chunks,
+                                                             const unsigned chunk) {
   __shared__ RedField sf[RBX_MAX_FIELDS];
   {
     const int words = n_cat * static_cast<int>(sizeof(RedField) / 4);
@@ -54,8 +55,8 @@ __global__ __launch_bounds__(256, RBX_REDUCE_WAVES) void segment_reduce_kernel(c
   const int lane_g = threadIdx.x % G;
   const unsigned c = blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
   if (c >= n_chunks) return;
-  const unsigned s = c * kChunk;
-  const unsigned e = (s + kChunk < n) ? s + kChunk : n;
+  const unsigned s = c * chunk;
+  const unsigned e = (s + chunk < n) ? s + chunk : n;
   const unsigned key_before = (s > 0) ? keys[s - 1] : sentinel;
   const unsigned key_after = (e < n) ? keys[e] : sentinel;
   unsigned cur = keys[s];
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void segment_fixup_short_kernel(const RedPack 
                                                                   const float* __restrict__ tail,
                                                                   const int* __restrict__ flags,
                                                                   unsigned* __restrict__ fin, const int max_dim,
-                                                                  const int sum_stride, const unsigned n_chunks) {
+                                                                  const int sum_stride, const unsigned n_chunks,
+                                                                  const unsigned chunk) {
   using F = Frag<G, NV, VEC>;
   const int lane_g = threadIdx.x % G;
   const unsigned ngroups = gridDim.x * (blockDim.x / G);
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void segment_fixup_short_kernel(const RedPack 
       if (lane_g == 0) fin[kFinList + n_chunks + atomicAdd(fin + 1, 1u)] = c;
       continue;
     }
-    const unsigned s = c * kChunk;
+    const unsigned s = c * chunk;
     const unsigned key = keys[s];
     const RedField fd = P.f[vals[s] >> kLocalBits];
     F acc, pre;
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
                                                                  const float* __restrict__ tail,
                                                                  const int* __restrict__ flags,
                                                                  unsigned* __restrict__ fin, const int max_dim,
-                                                                 const int sum_stride, const unsigned n_chunks) {
+                                                                 const int sum_stride, const unsigned n_chunks,
+                                                                 const unsigned chunk) {
   using F = Frag<G, NV, VEC>;
   constexpr int NGB = 256 / G;          // lane groups per workgroup
   // chunks per lane group and step: a window of ~512 chunks whatever G is (independent loads, few barriers)
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
   const unsigned count = fin[1];
   for (unsigned idx = blockIdx.x; idx < count; idx += gridDim.x) {
     const unsigned c = fin[kFinList + n_chunks + idx];
-    const unsigned s = c * kChunk;
+    const unsigned s = c * chunk;
     const unsigned key = keys[s];
     const RedField fd = P.f[vals[s] >> kLocalBits];
     F acc, pre;
@@ -333,9 +336,11 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
   }
   // the last workgroup to get here clears the counters: the workspace is ready for another backward on the same
   // sorted ids (build_keys clears them for a new sort), and no memset node sits between the sort and the reduce
+  // (no fence: every workgroup has consumed the counters -- its loop bounds -- before it arrives here, and nothing but the
+  //  counters themselves is handed between workgroups; a __threadfence() per workgroup, an L2 write-back each on this
+  //  8-XCD part, made the EMPTY launch of a step without long runs cost 12-17 us)
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
     if (atomicAdd(fin + 2, 1u) == gridDim.x - 1) {
       fin[0] = 0;
       fin[1] = 0;
@@ -356,17 +361,19 @@ static int launch_reduce(const BwdPlan& p, const typename Policy::Args& args, co
   // fin[0..2] are zero here: build_keys clears them for a new sort, the long fix-up kernel when it is done
   hipLaunchKernelGGL((segment_reduce_kernel<Policy, G, NV, VEC>), dim3(blocks), dim3(256), 0, s, p.red, p.n_cat, args,
                      keys, vals, p.n_lookups, p.total_rows, head, tail, flags, fin, p.max_dim, p.sum_stride,
-                     p.n_chunks);
+                     p.n_chunks, static_cast<unsigned>(p.chunk));
   int rc = check_launch("segment_reduce_kernel");
   if (rc != RBX_OK) return rc;
   unsigned short_blocks = blocks;                           // one lane group per finalising chunk, grid-stride
   if (short_blocks > static_cast<unsigned>(kCUs * 8)) short_blocks = kCUs * 8;
   hipLaunchKernelGGL((segment_fixup_short_kernel<Policy, G, NV, VEC>), dim3(short_blocks), dim3(256), 0, s, p.red, args,
-                     keys, vals, head, tail, flags, fin, p.max_dim, p.sum_stride, p.n_chunks);
+                     keys, vals, head, tail, flags, fin, p.max_dim, p.sum_stride, p.n_chunks,
+                     static_cast<unsigned>(p.chunk));
   unsigned long_blocks = p.n_chunks;                        // one workgroup per long chain, grid-stride
   if (long_blocks > static_cast<unsigned>(kCUs * 2)) long_blocks = kCUs * 2;
   hipLaunchKernelGGL((segment_fixup_long_kernel<Policy, G, NV, VEC>), dim3(long_blocks), dim3(256), 0, s, p.red, args,
-                     keys, vals, head, tail, flags, fin, p.max_dim, p.sum_stride, p.n_chunks);
+                     keys, vals, head, tail, flags, fin, p.max_dim, p.sum_stride, p.n_chunks,
+                     static_cast<unsigned>(p.chunk));
   return check_launch("segment_fixup kernels");
 }
 

@@ -1,0 +1,576 @@
+// rbx_tiera.h -- the sort-free half of the fused FM backward: tables of up to 16 384 rows ("tier A").
+//
+// Reference behaviour replaced: autograd's embedding_dense_backward behind the nn.Embedding tables of
+// ranking/pytorch/layers/embeddings/feature_embedding.py:89-103 (dense [V, D] gradient, padding_idx row zero) for the
+// low-cardinality fields of a CTR batch.
+//
+// Why a second path.  At the Criteo shape 18 of the 26 tables have <= 15 000 rows; they carry 69 % of the (row, sample)
+// pairs, all of the long runs of equal rows (65 536 lookups on 3..30 rows), and 3 MB of gradient in total.  Sending them
+// through the global LSD radix sort made that sort (three dependent kernels per 8-bit pass, latency-bound) and the
+// run fix-up launches the critical path of the step.  Here nothing global is sorted:
+//
+//   compact_ids   (ids only)  id columns of any dtype / stride -> int32 [field][B], range-checked once
+//   ta_blocksort  (ids only)  one workgroup per (field, block of 2048 samples): stable LSD radix sort of the block's
+//                             (row, sample offset) pairs entirely in LDS; leaves the sorted pairs and a presence
+//                             bitmap [block][row]
+//   ta_reduce     (g, S)      same grid: segmented sum of g_b * S_b and g_b over the sorted pairs of the block, one
+//                             partial per (block, present row), written into a dense [block][row] array
+//   ta_final      (tables)    one lane group per table row: adds the row's partials over fields and blocks in ascending
+//                             order, subtracts w_r * sum g, and WRITES the row -- every row of a tier-A table is written
+//                             every step, so these tables need no re-zeroing and no fix-up launches
+//
+// Every sum has a fixed order (sample order inside a chunk of 32 sorted pairs, chunk order inside a block, block order
+// inside a table): gradients are bit-identical run to run, no float atomics.  The two ids-only kernels run on the side
+// stream beside the forward (rbx_fm_sort), the other two after the loss (rbx_fm_bwd).
+#pragma once
+#include "rbx_bwd_common.h"
+
+namespace rbx {
+
+constexpr int kTaBlock = 2048;                       // samples per (field, block) unit = one LDS sort tile
+constexpr int kTaOffBits = 11;
+constexpr unsigned kTaOffMask = (1u << kTaOffBits) - 1u;
+#ifndef RBX_TA_CHUNK
+#define RBX_TA_CHUNK 16
+#endif
+#ifndef RBX_TA_THREADS
+#define RBX_TA_THREADS 512
+#endif
+constexpr int kTaChunk = RBX_TA_CHUNK;               // sorted pairs one lane group walks in sequence
+constexpr int kTaChunks = kTaBlock / kTaChunk;       // 128
+constexpr int kTaThreads = RBX_TA_THREADS;           // of ta_reduce_kernel: 8 wavefronts per (field, block) unit
+constexpr int kTaMaxVocab = 16384;
+constexpr int kTaMaxDim = 64;
+constexpr unsigned kTaNone = 0xFFFFFFFEu;            // "no element" in the boundary-run list
+
+struct CidField {            // 24 B: how to read one categorical id column
+  const void* ids;
+  long long stride_b;
+  int vocab;
+  int dtype;
+};
+struct CidPack { CidField f[RBX_MAX_FIELDS]; };
+
+struct TaField {             // 16 B
+  int cid_row;               // row of the compact id matrix
+  int vocab;
+  unsigned frow0;            // rows of the tier-A fields before this one (partial-array addressing)
+  unsigned fword0;           // bitmap words per block of the fields before this one
+};
+struct TaFieldPack { TaField f[RBX_MAX_FIELDS]; };
+
+struct TaTable {             // 48 B
+  float* grad;               // [V, D] or NULL
+  float* grad2;              // [V] (LR weight gradient) or NULL
+  const float* table;        // [V, stride] embedding rows (dW = A - cnt * w) or NULL
+  int stride;
+  int vocab;
+  int pad;                   // padding_idx (kNoId when unset): that row's gradient is zero
+  short f_begin, f_count;    // its fields in the TaFieldPack (contiguous)
+  unsigned row0;             // rows of the tier-A tables before this one (grid mapping of ta_final)
+  int reserved;
+};
+struct TaTablePack { TaTable t[RBX_MAX_FIELDS]; };
+struct TaFieldRef { unsigned frow0, fword0; };   // what ta_final_kernel needs of a TaField
+struct TaFieldRefPack { TaFieldRef f[RBX_MAX_FIELDS]; };
+static_assert(sizeof(TaTablePack) + sizeof(TaFieldRefPack) + 128 <= 4096, "ta_final_kernel's arguments must fit the kernarg segment");
+
+// id of any dtype -> int32 row number; false when it lies outside [0, vocab) (NaN included).  An id that passes is
+// < 2^31, so one v_cvt_i32_f64 replaces the ~20 emulated instructions of static_cast<long long>(double).
+__device__ __forceinline__ bool ta_decode_id(long long raw, int dt, int vocab, int* id) {
+  switch (dt) {
+    case RBX_I32:
+      *id = static_cast<int>(raw);
+      return static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
+    case RBX_I64:
+      *id = static_cast<int>(raw);
+      return static_cast<unsigned long long>(raw) < static_cast<unsigned long long>(vocab);
+    case RBX_F32: {
+      const float f = __int_as_float(static_cast<int>(raw));
+      *id = __float2int_rz(f);                               // .long() truncates towards zero
+      return (f == f) && static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
+    }
+    default: {
+      const double d = __longlong_as_double(raw);
+      *id = __double2int_rz(d);
+      return (d == d) && static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
+    }
+  }
+}
+
+// ---- ids -> int32 [n][B] ----------------------------------------------------------------------------------------
+// A workgroup transposes a tile of `ts` samples x n columns through LDS; ts is sized so that the tile is at most 2048
+// ids: every thread issues ALL of its (up to 8) loads before it touches the first value -- one memory round trip per
+// workgroup, and B / ts workgroups (1024 at the Criteo shape) keep the chip busy.  (256-sample tiles walked in 7 batches
+// of 4 loads by 256 workgroups took 28 us for the same 21 MB.)  FIELD_FAST: consecutive threads read consecutive
+// COLUMNS of one sample (the reference's loader hands over one [B, cols] tensor: a sample's ids are neighbours in
+// memory); otherwise consecutive samples of one column (separate contiguous id tensors).  Either way the stores are `ts`
+// consecutive ints per column.  Out-of-range ids become -1 and raise the status word.
+constexpr int kCidPerThread = 8;
+template <bool FIELD_FAST>
+__global__ __launch_bounds__(256) void compact_ids_kernel(const CidPack P, const int n, const long long B, const int ts,
+                                                          int* __restrict__ cid, int* __restrict__ status) {
+  extern __shared__ int ta_lds[];
+  CidField* sf = reinterpret_cast<CidField*>(ta_lds);                       // [n]
+  int* tile = ta_lds + (RBX_MAX_FIELDS * sizeof(CidField)) / sizeof(int);   // [n][ts + 1]
+  {
+    const int words = n * static_cast<int>(sizeof(CidField) / 4);
+    const int* src = reinterpret_cast<const int*>(&P);
+    int* dst = reinterpret_cast<int*>(sf);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  const long long b0 = static_cast<long long>(blockIdx.x) * ts;
+  const int live = static_cast<int>((B - b0 < ts) ? (B - b0) : ts);
+  const int pitch = ts + 1;
+  const int total = n * ts;                             // <= 256 * kCidPerThread
+  constexpr int U = kCidPerThread;
+  long long raw[U];
+  int cc[U], ss[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int idx = u * 256 + threadIdx.x;
+    int c, s;
+    if (FIELD_FAST) { s = idx / n; c = idx - s * n; } else { c = idx / ts; s = idx - c * ts; }
+    cc[u] = c;
+    ss[u] = s;
+    raw[u] = 0;
+    if (idx < total && s < live) raw[u] = load_raw(sf[c].ids, (b0 + s) * sf[c].stride_b, sf[c].dtype);
+  }
+  bool bad = false;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int idx = u * 256 + threadIdx.x;
+    if (idx < total && ss[u] < live) {
+      int v;
+      if (!ta_decode_id(raw[u], sf[cc[u]].dtype, sf[cc[u]].vocab, &v)) {
+        v = -1;
+        bad = true;
+      }
+      tile[cc[u] * pitch + ss[u]] = v;
+    }
+  }
+  if (bad && status != nullptr) atomicOr(status, 1);
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int c = idx / ts, s = idx - c * ts;
+    if (s < live) cid[static_cast<size_t>(c) * B + b0 + s] = tile[c * pitch + s];
+  }
+}
+
+// ---- one stable 8-bit LSD pass over the 2048 keys of a workgroup, in LDS -------------------------------------------
+// Wave w owns the contiguous quarter [w*512, (w+1)*512) and walks it in 64-key steps, so key order == (wave, step,
+// lane) and the ranks respect it (same scheme as radix_scatter_kernel in rbx_embed_bwd.hip, without the global part).
+__device__ __forceinline__ void ta_radix_pass(unsigned (&key)[8], const int shift, unsigned (*wcnt)[256],
+                                              unsigned* dstart, unsigned* wtot, unsigned* out) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+  unsigned rank[8];
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const unsigned d = (key[s] >> shift) & 255u;
+    unsigned long long peers = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const unsigned before = __popcll(peers & lt);
+    // LDS ops of one wave issue in program order: every peer reads the running count before the run leader (lowest
+    // peer lane) bumps it.  volatile: no caching across steps.
+    volatile unsigned* wc = wcnt[wid];
+    const unsigned prev = wc[d];
+    rank[s] = prev + before;
+    if (before == 0) wc[d] = prev + __popcll(peers);
+  }
+  __syncthreads();
+  {
+    const int d = threadIdx.x;                       // one digit per thread: exclusive prefix over waves, then over digits
+    unsigned run = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned c = wcnt[w][d];
+      wcnt[w][d] = run;
+      run += c;
+    }
+    unsigned inc = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wtot[wid] = inc;
+    __syncthreads();
+    unsigned base = inc - run;
+    for (int w = 0; w < wid; ++w) base += wtot[w];
+    dstart[d] = base;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const unsigned d = (key[s] >> shift) & 255u;
+    out[dstart[d] + wcnt[wid][d] + rank[s]] = key[s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) key[s] = out[wid * 512 + s * 64 + lane];
+}
+
+// ---- ids only: sort one (field, block) unit by row, stable in the sample -------------------------------------------
+// key = row << 11 | sample offset inside the block; an id outside the table sorts behind every row (row = vocab), the
+// filler of a short last block behind that (all ones).  Only the row bits are sorted: the keys start in sample order
+// and the passes are stable.
+__global__ __launch_bounds__(256) void ta_blocksort_kernel(const TaFieldPack P, const int n_fld, const long long B,
+                                                           const int* __restrict__ cid, unsigned* __restrict__ sorted,
+                                                           unsigned* __restrict__ bitmap, const unsigned NB) {
+  __shared__ unsigned buf[kTaBlock];
+  __shared__ unsigned wcnt[4][256];
+  __shared__ unsigned dstart[256];
+  __shared__ unsigned wtot[4];
+  __shared__ unsigned bm[kTaMaxVocab / 32];
+  const int f = blockIdx.x % n_fld;
+  const unsigned k = blockIdx.x / n_fld;
+  const TaField fd = P.f[f];
+  const int V = fd.vocab;
+  const long long b0 = static_cast<long long>(k) * kTaBlock;
+  const unsigned n = static_cast<unsigned>((B - b0 < kTaBlock) ? (B - b0) : kTaBlock);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int words = (V + 31) >> 5;
+  for (int i = threadIdx.x; i < words; i += 256) bm[i] = 0;
+  const int* src = cid + static_cast<size_t>(fd.cid_row) * B + b0;
+  unsigned key[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const unsigned off = wid * 512 + s * 64 + lane;
+    key[s] = 0xFFFFFFFFu;
+    if (off < n) {
+      const int id = src[off];
+      const unsigned row = (id >= 0 && id < V) ? static_cast<unsigned>(id) : static_cast<unsigned>(V);
+      key[s] = (row << kTaOffBits) | off;
+    }
+  }
+  ta_radix_pass(key, kTaOffBits, wcnt, dstart, wtot, buf);
+  if (V > 255) ta_radix_pass(key, kTaOffBits + 8, wcnt, dstart, wtot, buf);   // rows 0..V (V = the out-of-range bucket)
+  unsigned* dst = sorted + static_cast<size_t>(blockIdx.x) * kTaBlock;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    dst[wid * 512 + s * 64 + lane] = key[s];
+    const unsigned row = key[s] >> kTaOffBits;
+    if (row < static_cast<unsigned>(V)) atomicOr(&bm[row >> 5], 1u << (row & 31u));
+  }
+  __syncthreads();
+  unsigned* bdst = bitmap + static_cast<size_t>(fd.fword0) * NB + static_cast<size_t>(k) * words;
+  for (int i = threadIdx.x; i < words; i += 256) bdst[i] = bm[i];
+}
+
+// ---- g, S: segmented sum over the sorted pairs of one (field, block) unit -------------------------------------------
+// Lane group j walks the chunks j, j + NG, ... of kTaChunk sorted pairs.  A run of equal rows that lies inside a chunk and is
+// neither its first nor its last run is complete: its sum goes straight to the partial array.  The first and the last
+// run of every chunk go to an LDS list of 128 elements (chunk order); after a barrier the element that starts a row's
+// stretch adds the following elements of the same row in list order and writes the partial.  (Chunks of 32 pairs walked
+// by 4 wavefronts per unit: 35 us at the Criteo shape -- 2.25 wavefronts per SIMD, each waiting for 4 dependent rounds of
+// gathers; 16 pairs and 8 wavefronts: half the rounds, twice the wavefronts.)  A row of the block is
+// written exactly once, absent rows are not written (the bitmap of ta_blocksort_kernel names the present ones).
+template <int G, bool VEC>
+__global__ __launch_bounds__(kTaThreads) void ta_reduce_kernel(const TaFieldPack P, const int n_fld, const unsigned NB,
+                                                        const float* __restrict__ g, const float* __restrict__ ssum,
+                                                        const int D, const unsigned* __restrict__ sorted,
+                                                        float* __restrict__ psum, float* __restrict__ pcnt) {
+  using F = Frag<G, 1, VEC>;
+  constexpr int NG = kTaThreads / G;
+  constexpr int NE = 2 * kTaChunks;
+  extern __shared__ float ta_red[];
+  float* esum = ta_red;                                        // [NE][D]
+  float* ecnt = esum + NE * D;                                 // [NE]
+  unsigned* erow = reinterpret_cast<unsigned*>(ecnt + NE);    // [NE]
+  const int f = blockIdx.x % n_fld;
+  const unsigned k = blockIdx.x / n_fld;
+  const TaField fd = P.f[f];
+  const unsigned V = static_cast<unsigned>(fd.vocab);
+  const size_t b0 = static_cast<size_t>(k) * kTaBlock;
+  const unsigned* src = sorted + static_cast<size_t>(blockIdx.x) * kTaBlock;
+  const size_t pbase = static_cast<size_t>(fd.frow0) * NB + static_cast<size_t>(k) * V;
+  float* ps = psum + pbase * D;
+  float* pc = pcnt + pbase;
+  const int lane_g = threadIdx.x % G, group = threadIdx.x / G;
+  constexpr int U = 8;
+  for (int c = group; c < kTaChunks; c += NG) {
+    const unsigned* e = src + c * kTaChunk;
+    unsigned cur = e[0] >> kTaOffBits;
+    F acc;
+    acc.zero();
+    float cnt = 0.f;
+    int nrun = 0;
+    for (int i0 = 0; i0 < kTaChunk; i0 += U) {
+      unsigned ent[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) ent[u] = e[i0 + u];
+      F rows[U];
+      float gg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        rows[u].zero();
+        gg[u] = 0.f;
+        if ((ent[u] >> kTaOffBits) < V) {
+          const size_t b = b0 + (ent[u] & kTaOffMask);
+          gg[u] = g[b];
+          if (ssum != nullptr) rows[u].fma_from(ssum + b * D, D, lane_g, gg[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned row = ent[u] >> kTaOffBits;
+        if (row != cur) {                                      // the run of `cur` ends in front of this pair
+          if (nrun == 0) {
+            acc.store(esum + (2 * c) * D, D, lane_g);
+            if (lane_g == 0) { ecnt[2 * c] = cnt; erow[2 * c] = cur; }
+          } else if (cur < V) {
+            acc.store(ps + static_cast<size_t>(cur) * D, D, lane_g);
+            if (lane_g == 0) pc[cur] = cnt;
+          }
+          ++nrun;
+          acc.zero();
+          cnt = 0.f;
+          cur = row;
+        }
+        frag_add(acc, rows[u]);
+        cnt += gg[u];
+      }
+    }
+    const int slot = (nrun == 0) ? 2 * c : 2 * c + 1;           // the run that is open at the end of the chunk
+    acc.store(esum + slot * D, D, lane_g);
+    if (lane_g == 0) {
+      ecnt[slot] = cnt;
+      erow[slot] = cur;
+      if (nrun == 0) erow[2 * c + 1] = kTaNone;
+    }
+  }
+  __syncthreads();
+  for (int i = group; i < NE; i += NG) {
+    const unsigned r = erow[i];
+    if (r == kTaNone || r >= V) continue;
+    int p = i - 1;
+    if (p >= 0 && erow[p] == kTaNone) --p;                      // (element 2c always exists: at most one gap)
+    if (p >= 0 && erow[p] == r) continue;                       // the stretch of this row started earlier
+    F acc;
+    acc.zero();
+    acc.add_from(esum + i * D, D, lane_g);
+    float cnt = ecnt[i];
+    for (int j = i + 1; j < NE; ++j) {
+      const unsigned rj = erow[j];
+      if (rj == kTaNone) continue;
+      if (rj != r) break;
+      acc.add_from(esum + j * D, D, lane_g);
+      cnt += ecnt[j];
+    }
+    acc.store(ps + static_cast<size_t>(r) * D, D, lane_g);
+    if (lane_g == 0) pc[r] = cnt;
+  }
+}
+
+// ---- tables: combine the block partials of every row, apply dW = A - cnt * w, write the row -----------------------
+// A row is served by KQ lane groups of G lanes: group q adds the partials of the blocks q, q + KQ, ... (fields in
+// order, blocks ascending, 8 bitmap words and then up to 8 partial rows in flight), the KQ sums meet in a fixed xor
+// butterfly.  (One lane group per row walking all blocks: 23 us at the Criteo shape, four dependent rounds of two
+// memory trips each at 3 wavefronts per SIMD.)
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void ta_final_kernel(const TaTablePack T, const TaFieldRefPack P, const int n_tab,
+                                                       const int n_fld, const unsigned NB, const int D,
+                                                       const unsigned total_rows, const float* __restrict__ psum,
+                                                       const float* __restrict__ pcnt,
+                                                       const unsigned* __restrict__ bitmap, const int accumulate,
+                                                       const bool has_emb) {
+  using F = Frag<G, 1, VEC>;
+  constexpr int KQ = (G >= 16) ? 1 : 16 / G;
+  constexpr int LR = G * KQ;                         // lanes per row
+  constexpr int NR = 256 / LR;                       // rows per workgroup
+  __shared__ TaTable st[RBX_MAX_FIELDS];
+  __shared__ TaFieldRef sfd[RBX_MAX_FIELDS];
+  {
+    const int* src = reinterpret_cast<const int*>(&T);
+    int* dst = reinterpret_cast<int*>(st);
+    for (int i = threadIdx.x; i < n_tab * static_cast<int>(sizeof(TaTable) / 4); i += 256) dst[i] = src[i];
+    const int* src2 = reinterpret_cast<const int*>(&P);
+    int* dst2 = reinterpret_cast<int*>(sfd);
+    for (int i = threadIdx.x; i < n_fld * static_cast<int>(sizeof(TaFieldRef) / 4); i += 256) dst2[i] = src2[i];
+  }
+  __syncthreads();
+  const int lane_r = threadIdx.x % LR;
+  const int lane_g = lane_r % G;
+  const unsigned kq = static_cast<unsigned>(lane_r / G);
+  const unsigned R = blockIdx.x * NR + threadIdx.x / LR;
+  if (R >= total_rows) return;                        // (all lanes of a row leave together: the shuffles below stay inside a row)
+  int lo = 0, hi = n_tab - 1;                         // last table with row0 <= R
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (st[mid].row0 <= R) lo = mid; else hi = mid - 1;
+  }
+  const TaTable& tb = st[lo];
+  const unsigned r = R - tb.row0;
+  const unsigned V = static_cast<unsigned>(tb.vocab);
+  F wrow;                                             // w_r, fetched ahead of the walk
+  wrow.zero();
+  if (kq == 0 && tb.grad != nullptr) wrow.add_from(tb.table + static_cast<size_t>(r) * tb.stride, D, lane_g);
+  F acc;
+  acc.zero();
+  float cnt = 0.f;
+  int any = 0;
+  constexpr int U = 8;
+  const unsigned words = (V + 31u) >> 5;
+  for (int f = tb.f_begin; f < tb.f_begin + tb.f_count; ++f) {
+    const TaFieldRef& fd = sfd[f];
+    const unsigned* bw = bitmap + static_cast<size_t>(fd.fword0) * NB + (r >> 5);
+    const size_t pbase = static_cast<size_t>(fd.frow0) * NB + r;
+    for (unsigned k0 = kq; k0 < NB; k0 += KQ * U) {
+      unsigned w[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned k = k0 + u * KQ;
+        w[u] = (k < NB) ? bw[static_cast<size_t>(k) * words] : 0u;
+      }
+      F part[U];
+      float pc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        part[u].zero();
+        pc[u] = 0.f;
+        if ((w[u] >> (r & 31u)) & 1u) {
+          const size_t idx = pbase + static_cast<size_t>(k0 + u * KQ) * V;
+          if (has_emb) part[u].add_from(psum + idx * D, D, lane_g);
+          pc[u] = pcnt[idx];
+          any = 1;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        frag_add(acc, part[u]);
+        cnt += pc[u];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = G; o < LR; o <<= 1) {                  // the KQ partial sums of the row, fixed butterfly (a + b == b + a bit for bit)
+#pragma unroll
+    for (int q = 0; q < static_cast<int>(sizeof(acc.a) / sizeof(float)); ++q) acc.a[q] += __shfl_xor(acc.a[q], o, 64);
+    cnt += __shfl_xor(cnt, o, 64);
+    any |= __shfl_xor(any, o, 64);
+  }
+  if (kq != 0) return;
+  if (static_cast<int>(r) == tb.pad) any = 0;         // nn.Embedding(padding_idx): that row's gradient stays zero
+  if (tb.grad != nullptr) {
+    F out;
+    out.zero();
+    if (any) {
+      out = acc;
+#pragma unroll
+      for (int q = 0; q < static_cast<int>(sizeof(out.a) / sizeof(float)); ++q) out.a[q] -= cnt * wrow.a[q];
+    }
+    float* dst = tb.grad + static_cast<size_t>(r) * D;
+    if (accumulate) out.accumulate_into(dst, D, lane_g); else out.store(dst, D, lane_g);
+  }
+  if (tb.grad2 != nullptr && lane_g == 0) {
+    const float v = any ? cnt : 0.f;
+    if (accumulate) tb.grad2[r] += v; else tb.grad2[r] = v;
+  }
+}
+
+// ---- host-side description of the tier-A part of one fused FM call -------------------------------------------------
+struct TaPlan {
+  int n_cid = 0;               // categorical fields with a gradient: rows of the compact id matrix
+  CidPack cid;
+  bool field_fast = false;     // how compact_ids_kernel walks a tile
+  int cid_ts = 256;            // samples per tile of compact_ids_kernel
+  int n_fld = 0, n_tab = 0;
+  TaFieldPack fld;
+  TaTablePack tab;
+  unsigned NB = 0;             // blocks of 2048 samples
+  unsigned rows = 0;           // rows of the tier-A tables
+  unsigned frows = 0;          // rows summed over the tier-A FIELDS (shared tables count once per field)
+  unsigned fwords = 0;         // bitmap words per block, summed over the fields
+  int D = 1;
+  bool has_emb = false, vec = false;
+  size_t off_cid = 0, off_sorted = 0, off_bitmap = 0, off_psum = 0, off_pcnt = 0, bytes = 0;   // relative to the region
+};
+
+static inline size_t ta_align(size_t v) { return (v + 255) / 256 * 256; }
+
+static inline void ta_layout(TaPlan* t, int64_t B) {
+  size_t o = 0;
+  t->off_cid = o; o += ta_align(static_cast<size_t>(t->n_cid) * static_cast<size_t>(B) * 4);
+  const size_t units = static_cast<size_t>(t->n_fld) * t->NB;
+  t->off_sorted = o; o += ta_align(units * kTaBlock * 4);
+  t->off_bitmap = o; o += ta_align(static_cast<size_t>(t->fwords) * t->NB * 4);
+  t->off_psum = o; o += ta_align(t->has_emb ? static_cast<size_t>(t->frows) * t->NB * t->D * 4 : 0);
+  t->off_pcnt = o; o += ta_align(static_cast<size_t>(t->frows) * t->NB * 4);
+  t->bytes = o;
+}
+
+static inline int ta_launch_compact(const TaPlan& t, int64_t B, char* region, int* d_status, hipStream_t s) {
+  if (t.n_cid == 0) return RBX_OK;
+  const int ts = t.cid_ts;
+  const size_t lds = RBX_MAX_FIELDS * sizeof(CidField) + static_cast<size_t>(t.n_cid) * (ts + 1) * 4;
+  const unsigned blocks = static_cast<unsigned>((B + ts - 1) / ts);
+  int* cid = reinterpret_cast<int*>(region + t.off_cid);
+  if (t.field_fast)
+    hipLaunchKernelGGL(compact_ids_kernel<true>, dim3(blocks), dim3(256), lds, s, t.cid, t.n_cid, static_cast<long long>(B),
+                       ts, cid, d_status);
+  else
+    hipLaunchKernelGGL(compact_ids_kernel<false>, dim3(blocks), dim3(256), lds, s, t.cid, t.n_cid, static_cast<long long>(B),
+                       ts, cid, d_status);
+  return check_launch("compact_ids_kernel");
+}
+
+static inline int ta_launch_blocksort(const TaPlan& t, int64_t B, char* region, hipStream_t s) {
+  if (t.n_fld == 0) return RBX_OK;
+  hipLaunchKernelGGL(ta_blocksort_kernel, dim3(t.n_fld * t.NB), dim3(256), 0, s, t.fld, t.n_fld, static_cast<long long>(B),
+                     reinterpret_cast<const int*>(region + t.off_cid), reinterpret_cast<unsigned*>(region + t.off_sorted),
+                     reinterpret_cast<unsigned*>(region + t.off_bitmap), t.NB);
+  return check_launch("ta_blocksort_kernel");
+}
+
+template <int G, bool VEC>
+static int ta_launch_bwd(const TaPlan& t, const float* g, const float* ssum, int accumulate, char* region, hipStream_t s) {
+  const size_t lds = (static_cast<size_t>(2 * kTaChunks) * t.D + 4 * kTaChunks) * 4;
+  float* psum = reinterpret_cast<float*>(region + t.off_psum);
+  float* pcnt = reinterpret_cast<float*>(region + t.off_pcnt);
+  hipLaunchKernelGGL((ta_reduce_kernel<G, VEC>), dim3(t.n_fld * t.NB), dim3(kTaThreads), lds, s, t.fld, t.n_fld, t.NB, g,
+                     t.has_emb ? ssum : nullptr, t.D, reinterpret_cast<const unsigned*>(region + t.off_sorted), psum, pcnt);
+  int rc = check_launch("ta_reduce_kernel");
+  if (rc != RBX_OK) return rc;
+  constexpr int NR = 256 / (G >= 16 ? G : 16);    // rows per workgroup of ta_final_kernel
+  const unsigned blocks = (t.rows + NR - 1) / NR;
+  TaFieldRefPack refs;
+  for (int i = 0; i < t.n_fld; ++i) refs.f[i] = {t.fld.f[i].frow0, t.fld.f[i].fword0};
+  hipLaunchKernelGGL((ta_final_kernel<G, VEC>), dim3(blocks), dim3(256), 0, s, t.tab, refs, t.n_tab, t.n_fld, t.NB, t.D,
+                     t.rows, psum, pcnt, reinterpret_cast<const unsigned*>(region + t.off_bitmap), accumulate, t.has_emb);
+  return check_launch("ta_final_kernel");
+}
+
+static inline int ta_dispatch_bwd(const TaPlan& t, const float* g, const float* ssum, int accumulate, char* region,
+                                  hipStream_t s) {
+  if (t.n_fld == 0) return RBX_OK;
+  const bool vec = t.vec && (ssum == nullptr || (reinterpret_cast<uintptr_t>(ssum) & 15) == 0);
+  const int units = vec ? t.D / 4 : t.D;
+  if (vec) {
+    switch (pow2_ceil(units)) {
+      case 1: return ta_launch_bwd<1, true>(t, g, ssum, accumulate, region, s);
+      case 2: return ta_launch_bwd<2, true>(t, g, ssum, accumulate, region, s);
+      case 4: return ta_launch_bwd<4, true>(t, g, ssum, accumulate, region, s);
+      case 8: return ta_launch_bwd<8, true>(t, g, ssum, accumulate, region, s);
+      default: return ta_launch_bwd<16, true>(t, g, ssum, accumulate, region, s);
+    }
+  }
+  switch (pow2_ceil(units)) {
+    case 1: return ta_launch_bwd<1, false>(t, g, ssum, accumulate, region, s);
+    case 2: return ta_launch_bwd<2, false>(t, g, ssum, accumulate, region, s);
+    case 4: return ta_launch_bwd<4, false>(t, g, ssum, accumulate, region, s);
+    case 8: return ta_launch_bwd<8, false>(t, g, ssum, accumulate, region, s);
+    case 16: return ta_launch_bwd<16, false>(t, g, ssum, accumulate, region, s);
+    case 32: return ta_launch_bwd<32, false>(t, g, ssum, accumulate, region, s);
+    default: return ta_launch_bwd<64, false>(t, g, ssum, accumulate, region, s);
+  }
+}
+
+}  // namespace rbx

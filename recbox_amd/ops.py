@@ -67,6 +67,10 @@ class config(object):
     # (ops.deepfm_input_stage): the block's gradient comes out of the tower's dx GEMM instead of four kernels
     fuse_deepfm_input = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_INPUT", "1") != "0"
     reuse_grad_buffers = {"0": False, "": False, "all": "all"}.get(os.environ.get("RECBOX_AMD_REUSE_GRADS", "0"), True)
+    # fused FM backward in two tiers (round 3; include/recbox_hip.h, rbx_fm_bwd): the small tables' block partials + row
+    # combine (tier A) on the current stream, the large tables' segmented reduce (tier B) on the side stream its sort ran on
+    # -- two chains of short, latency-bound kernels side by side instead of one after the other.
+    fm_two_chains = os.environ.get("RECBOX_AMD_FM_TWO_CHAINS", "1") != "0"
 
 
 def _require_cuda(t, what):
@@ -326,20 +330,32 @@ def _forget_sort(ws):
 
 
 class _EarlySort(object):
-    """Workspace + completion event of a sort launched from the forward."""
+    """Workspace + completion event of a sort launched from the forward.  ``first(ws, stream)``: a leading part of the work
+    that gets an event of its own (``event_first``) -- the fused FM op's id compaction + per-block sorts, which its tier-A
+    backward waits for while the rest of the sort is still under way."""
 
-    def __init__(self, device, ws_bytes, launch, ws=None):
+    def __init__(self, device, ws_bytes, launch, ws=None, first=None):
         cur = torch.cuda.current_stream(device)
         self.ws = ws if ws is not None else torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=device)
         self.ws_bytes = int(ws_bytes)
         self.event = None
+        self.event_first = None
+        self.side = None
         if torch.cuda.is_current_stream_capturing() and not config.fork_in_capture:
-            check(launch(self.ws, ctypes.c_void_p(cur.cuda_stream)))
+            st = ctypes.c_void_p(cur.cuda_stream)
+            if first is not None:
+                check(first(self.ws, st))
+            check(launch(self.ws, st))
             return
         side = _side_stream(device)
         side.wait_stream(cur)                       # ids (and the fresh workspace) are ready
-        check(launch(self.ws, ctypes.c_void_p(side.cuda_stream)))
+        st = ctypes.c_void_p(side.cuda_stream)
+        if first is not None:
+            check(first(self.ws, st))
+            self.event_first = side.record_event()
+        check(launch(self.ws, st))
         self.event = side.record_event()
+        self.side = side
         self.ws.record_stream(side)
 
     def join(self):
@@ -646,7 +662,7 @@ class _GradPool(object):
             return None
         return pool
 
-    def early_sort(self, ctx, device, ws_bytes, rezero, sort):
+    def early_sort(self, ctx, device, ws_bytes, rezero, sort, first=None):
         """Launch, on the side stream: ``rezero(stream)`` -- clear the rows the previous backward stored, its sorted ids
         are still in ``self.ws`` -- when there are any, then ``sort(ws, ws_bytes, stream)`` of this batch's ids over
         them.  Both return a C-ABI code.  (Clearing on a third stream beside the sort was measured slower -- 0.344 vs
@@ -658,14 +674,23 @@ class _GradPool(object):
             dirty = 0
         ws = self.workspace(ws_bytes)
 
+        # The re-zero goes FIRST: it reads the previous step's sorted pairs out of this workspace, and everything the new
+        # step writes -- laid out for ITS batch size -- may land on them.
+        def clear(st):
+            return rezero(st) if dirty else _lib.RBX_OK
+
         def launch(ws, st):
-            if dirty:
-                rc = rezero(st)
+            if first is None:
+                rc = clear(st)
                 if rc != _lib.RBX_OK:
                     return rc
             return sort(ws, self.ws_bytes, st)
 
-        ctx.sort = _EarlySort(device, self.ws_bytes, launch, ws=ws)
+        def lead(ws, st):
+            rc = clear(st)
+            return rc if rc != _lib.RBX_OK else first(ws, self.ws_bytes, st)
+
+        ctx.sort = _EarlySort(device, self.ws_bytes, launch, ws=ws, first=lead if first is not None else None)
         self.ticket += 1
         self.pending = True
         ctx.pool, ctx.ticket = self, self.ticket
@@ -769,10 +794,19 @@ class _FmFused(torch.autograd.Function):
             ws_bytes = lib.rbx_fm_bwd_workspace_size(ea, la, lead.n, B)
             pool = _GradPool.claim(_FmFused._pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev)
                                    if config.reuse_grad_buffers else None)
+
+            # ids -> compact int32 matrix + the per-block sorts of the small tables (tier A), with an event of their own;
+            # then the (row, sample) sort of the large tables (tier B; for a call without embedding tables: the whole sort)
+            def first(ws, nbytes, st):
+                return lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 1 | 4, st)
+
+            def rest(ws, nbytes, st):
+                return _enqueue_sort((ea, la, lead.n, 1), keep, B, ws, nbytes, st,
+                                     lambda: lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 2, st))
+
             if ws_bytes > 0 and pool is None:
-                ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: _enqueue_sort(
-                    (ea, la, lead.n, 1), keep, B, ws, ws_bytes, st,
-                    lambda: lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, st)))
+                ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: rest(ws, ws_bytes, st),
+                                      first=lambda ws, st: first(ws, ws_bytes, st))
             elif ws_bytes > 0:
                 def rezero(st):
                     rc = _FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st)
@@ -782,9 +816,7 @@ class _FmFused(torch.autograd.Function):
                         lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
                     return rc
 
-                pool.early_sort(ctx, dev, ws_bytes, rezero, lambda ws, nbytes, st: _enqueue_sort(
-                    (ea, la, lead.n, 1), keep, B, ws, nbytes, st,
-                    lambda: lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), nbytes, None, st)))
+                pool.early_sort(ctx, dev, ws_bytes, rezero, rest, first=first)
             # the forward reads the tables only: back to descriptors without gradient pointers
             if emb_plan is not None:
                 emb_plan.bind_params(emb_params)
@@ -945,7 +977,11 @@ class _FmFused(torch.autograd.Function):
             # numeric weights + bias do not need the sorted ids: run them while the sort may still be in flight
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws_early),
                                  ctx.sort.ws_bytes, _stream()))
-        if ctx.sort is not None and same:
+        two_chains = (config.fm_two_chains and ws_early is not None and isinstance(ctx.sort, _EarlySort)
+                      and ctx.sort.event_first is not None and emb_plan is not None)
+        if two_chains:
+            ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes           # (no join: each tier waits for its own part below)
+        elif ctx.sort is not None and same:
             ctx.sort.join()
             ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes
         else:
@@ -954,8 +990,28 @@ class _FmFused(torch.autograd.Function):
             check(lib.rbx_fm_sort(ea, la, lead.n, B, _ptr(ws), ws_bytes, None, _stream()))
         if getattr(ctx, "rezero_event", None) is not None:
             torch.cuda.current_stream(dev).wait_event(ctx.rezero_event)     # (presorted step: the re-zero ran on the side stream)
-        check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0,
-                             (1 if ws_early is not None else 3) | store, _ptr(ws), ws_bytes, _stream()))
+        if two_chains:
+            # Two chains of short kernels side by side.  RECBOX_AMD_FM_TIER_A_ON = "main" (default): tier A (block partials
+            # of the small tables, then every row written once) runs here, tier B (sorted pairs of the large tables ->
+            # segmented reduce + fix-ups) stays on the side stream behind its own sort.  "side": the other way round --
+            # measured slower in the replayed step (0.27-0.28 vs 0.25 ms, profiles/r03).
+            cur = torch.cuda.current_stream(dev)
+            side = ctx.sort.side
+            a_side = os.environ.get("RECBOX_AMD_FM_TIER_A_ON", "main") == "side"
+            side.wait_event(cur.record_event())            # dL/dlogit, S and the gradient buffers are ready
+            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (16 if a_side else 8) | store,
+                                 _ptr(ws), ws_bytes, ctypes.c_void_p(side.cuda_stream)))
+            side_done = side.record_event()
+            for t in [dlogit, ssum] + [g for g in grads if g is not None]:
+                if t is not None:
+                    t.record_stream(side)
+            cur.wait_event(ctx.sort.event if a_side else ctx.sort.event_first)
+            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (8 if a_side else 16) | store,
+                                 _ptr(ws), ws_bytes, _stream()))
+            cur.wait_event(side_done)
+        else:
+            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0,
+                                 (1 if ws_early is not None else 3) | store, _ptr(ws), ws_bytes, _stream()))
         if numeric_done is not None:
             torch.cuda.current_stream(dev).wait_event(numeric_done)
         if pool is not None:
