@@ -789,6 +789,7 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
   }
   p->max_dim = D;
   p->num_blocks = static_cast<unsigned>((B + ns - 1) / ns);
+  if (tiered) p->long_cap = 32;            // (runs of hundreds of pairs come from the small tables, which are not in this plan)
   return RBX_OK;
 }
 
@@ -1021,7 +1022,7 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
     if (rc != RBX_OK) return rc;
   }
   if ((phases & 1) && !(phases & 8)) {               // the tables of tier A: block partials, then every row written once
-    rc = ta_dispatch_bwd(f.ta, d_dlogit, emb ? d_sum : nullptr, accumulate, ws + f.off_ta, s);
+    rc = ta_dispatch_bwd(f.ta, batch, d_dlogit, emb ? d_sum : nullptr, accumulate, ws + f.off_ta, s);
     if (rc != RBX_OK) return rc;
   }
   if ((phases & 2) && (n_num > 0 || d_dbias != nullptr)) {

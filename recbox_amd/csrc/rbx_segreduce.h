@@ -370,7 +370,7 @@ static int launch_reduce(const BwdPlan& p, const typename Policy::Args& args, co
                      keys, vals, head, tail, flags, fin, p.max_dim, p.sum_stride, p.n_chunks,
                      static_cast<unsigned>(p.chunk));
   unsigned long_blocks = p.n_chunks;                        // one workgroup per long chain, grid-stride
-  if (long_blocks > static_cast<unsigned>(kCUs * 2)) long_blocks = kCUs * 2;
+  if (long_blocks > p.long_cap) long_blocks = p.long_cap;
   hipLaunchKernelGGL((segment_fixup_long_kernel<Policy, G, NV, VEC>), dim3(long_blocks), dim3(256), 0, s, p.red, args,
                      keys, vals, head, tail, flags, fin, p.max_dim, p.sum_stride, p.n_chunks,
                      static_cast<unsigned>(p.chunk));

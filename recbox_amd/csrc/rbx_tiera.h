@@ -370,6 +370,162 @@ __global__ __launch_bounds__(kTaThreads) void ta_reduce_kernel(const TaFieldPack
   }
 }
 
+// ---- the same for rows of up to 16 floats: the block's S rows staged in LDS ----------------------------------------
+// A (field, block) unit reads every S row of its block exactly once, in sorted-by-row (= random) order: 18 fields x
+// 65 536 gathers of 64 bytes at the Criteo shape, which the L2s (4 MB each, S is 4.2 MB) do not hold -- the gather
+// kernel above takes 43 us alone and slows whatever runs beside it.  Here a workgroup owns one block of 2048 samples and a
+// GROUP of fields: it streams the block's S rows (128 KB at D = 16) and g into LDS once, coalesced, then serves the fields
+// one after the other from LDS.  The boundary runs of a field's 128 chunks are combined by a segmented Hillis-Steele scan
+// over the 256-element list (8 steps; element i adds element i - d iff both carry the same row -- rows are sorted, so
+// equal rows are contiguous): a fixed tree over list positions, whatever the run lengths, instead of one lane group
+// walking the list of a 700-pair run.  157 KB of LDS: one such workgroup per CU (kernels with small LDS needs still fit
+// beside it).
+constexpr int kTaLdsMaxDim = 16;
+template <int G>
+__global__ __launch_bounds__(512) void ta_reduce_lds_kernel(const TaFieldPack P, const int n_fld, const int fpg,
+                                                            const int n_grp, const unsigned NB, const long long B,
+                                                            const float* __restrict__ g, const float* __restrict__ ssum,
+                                                            const int D, const unsigned* __restrict__ sorted,
+                                                            float* __restrict__ psum, float* __restrict__ pcnt) {
+  using F = Frag<G, 1, true>;
+  constexpr int NE = 2 * kTaChunks;                  // 256 boundary elements; 512 / G >= 128 lane groups
+  static_assert(kTaChunk == 16 && kTaChunks == 128, "ta_reduce_lds_kernel is written for 128 chunks of 16 pairs");
+  extern __shared__ __attribute__((aligned(16))) float ta_stage[];
+  float* sS = ta_stage;                              // [2048][D]
+  float* sg = sS + kTaBlock * D;                     // [2048]
+  float* esum = sg + kTaBlock;                       // [NE][D]
+  float* ecnt = esum + NE * D;                       // [NE]
+  unsigned* erow = reinterpret_cast<unsigned*>(ecnt + NE);   // [NE]
+  const unsigned k = blockIdx.x / n_grp;
+  const int grp = blockIdx.x % n_grp;
+  const size_t b0 = static_cast<size_t>(k) * kTaBlock;
+  const int n = static_cast<int>((static_cast<size_t>(B) - b0 < kTaBlock) ? (static_cast<size_t>(B) - b0) : kTaBlock);
+  // ---- stage S[b0 .. b0 + n) and g: every thread's loads in flight together ----
+  {
+    const int n4 = kTaBlock * D / 4, live4 = n * D / 4;            // float4 units
+    const float4* src = reinterpret_cast<const float4*>(ssum + b0 * D);
+    float4* dst = reinterpret_cast<float4*>(sS);
+    for (int base = 0; base < n4; base += 8 * 512) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 512 + threadIdx.x;
+        v[u] = (i < live4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * 512 + threadIdx.x;
+        if (i < n4) dst[i] = v[u];
+      }
+    }
+    for (int i = threadIdx.x; i < kTaBlock; i += 512) sg[i] = (i < n) ? g[b0 + i] : 0.f;
+  }
+  __syncthreads();
+  const int lane_g = threadIdx.x % G, group = threadIdx.x / G;
+  const int f_end = ((grp + 1) * fpg < n_fld) ? (grp + 1) * fpg : n_fld;
+  for (int f = grp * fpg; f < f_end; ++f) {
+    const TaField fd = P.f[f];
+    const unsigned V = static_cast<unsigned>(fd.vocab);
+    const unsigned* src = sorted + (static_cast<size_t>(k) * n_fld + f) * kTaBlock;
+    const size_t pbase = static_cast<size_t>(fd.frow0) * NB + static_cast<size_t>(k) * V;
+    float* ps = psum + pbase * D;
+    float* pc = pcnt + pbase;
+    if (group < kTaChunks) {
+      const int c = group;
+      const uint4* e4 = reinterpret_cast<const uint4*>(src + c * kTaChunk);
+      unsigned ent[kTaChunk];
+#pragma unroll
+      for (int q = 0; q < kTaChunk / 4; ++q) {
+        const uint4 t = e4[q];
+        ent[q * 4] = t.x; ent[q * 4 + 1] = t.y; ent[q * 4 + 2] = t.z; ent[q * 4 + 3] = t.w;
+      }
+      unsigned cur = ent[0] >> kTaOffBits;
+      F acc;
+      acc.zero();
+      float cnt = 0.f;
+      int nrun = 0;
+#pragma unroll
+      for (int u = 0; u < kTaChunk; ++u) {
+        const unsigned row = ent[u] >> kTaOffBits;
+        const unsigned off = ent[u] & kTaOffMask;
+        if (row != cur) {                                        // the run of `cur` ends in front of this pair
+          if (nrun == 0) {
+            acc.store(esum + (2 * c) * D, D, lane_g);
+            if (lane_g == 0) { ecnt[2 * c] = cnt; erow[2 * c] = cur; }
+          } else if (cur < V) {
+            acc.store(ps + static_cast<size_t>(cur) * D, D, lane_g);
+            if (lane_g == 0) pc[cur] = cnt;
+          }
+          ++nrun;
+          acc.zero();
+          cnt = 0.f;
+          cur = row;
+        }
+        if (row < V) {
+          const float gv = sg[off];
+          acc.fma_from(sS + off * D, D, lane_g, gv);
+          cnt += gv;
+        }
+      }
+      if (nrun == 0) {                                            // one run fills the chunk: its sum in 2c, nothing in 2c + 1
+        acc.store(esum + (2 * c) * D, D, lane_g);
+        F z;
+        z.zero();
+        z.store(esum + (2 * c + 1) * D, D, lane_g);
+        if (lane_g == 0) { ecnt[2 * c] = cnt; erow[2 * c] = cur; ecnt[2 * c + 1] = 0.f; erow[2 * c + 1] = cur; }
+      } else {
+        acc.store(esum + (2 * c + 1) * D, D, lane_g);
+        if (lane_g == 0) { ecnt[2 * c + 1] = cnt; erow[2 * c + 1] = cur; }
+      }
+    }
+    __syncthreads();
+    // ---- segmented inclusive scan over the NE boundary elements; lane group j holds elements j and j + 128 ----
+    F v0, v1;
+    v0.zero();
+    v1.zero();
+    float c0 = 0.f, c1 = 0.f;
+    unsigned r0 = kTaNone, r1 = kTaNone;
+    const int i0 = group, i1 = group + kTaChunks;
+    if (group < kTaChunks) {
+      v0.add_from(esum + i0 * D, D, lane_g);
+      v1.add_from(esum + i1 * D, D, lane_g);
+      c0 = ecnt[i0]; c1 = ecnt[i1];
+      r0 = erow[i0]; r1 = erow[i1];
+    }
+#pragma unroll 1
+    for (int d = 1; d < NE; d <<= 1) {
+      F a0, a1;
+      a0.zero();
+      a1.zero();
+      float ac0 = 0.f, ac1 = 0.f;
+      if (group < kTaChunks) {
+        if (i0 >= d && erow[i0 - d] == r0) { a0.add_from(esum + (i0 - d) * D, D, lane_g); ac0 = ecnt[i0 - d]; }
+        if (i1 >= d && erow[i1 - d] == r1) { a1.add_from(esum + (i1 - d) * D, D, lane_g); ac1 = ecnt[i1 - d]; }
+      }
+      __syncthreads();
+      if (group < kTaChunks) {
+        frag_add(v0, a0); c0 += ac0;
+        frag_add(v1, a1); c1 += ac1;
+        v0.store(esum + i0 * D, D, lane_g);
+        v1.store(esum + i1 * D, D, lane_g);
+        if (lane_g == 0) { ecnt[i0] = c0; ecnt[i1] = c1; }
+      }
+      __syncthreads();
+    }
+    if (group < kTaChunks) {                                       // the last element of a row's stretch holds the row's sum
+      if (r0 < V && erow[i0 + 1] != r0) {                         // (i0 + 1 <= 128 < NE)
+        v0.store(ps + static_cast<size_t>(r0) * D, D, lane_g);
+        if (lane_g == 0) pc[r0] = c0;
+      }
+      if (r1 < V && (i1 + 1 == NE || erow[i1 + 1] != r1)) {
+        v1.store(ps + static_cast<size_t>(r1) * D, D, lane_g);
+        if (lane_g == 0) pc[r1] = c1;
+      }
+    }
+    __syncthreads();                                               // the list is rewritten by the next field
+  }
+}
+
 // ---- tables: combine the block partials of every row, apply dW = A - cnt * w, write the row -----------------------
 // A row is served by KQ lane groups of G lanes: group q adds the partials of the blocks q, q + KQ, ... (fields in
 // order, blocks ascending, 8 bitmap words and then up to 8 partial rows in flight), the KQ sums meet in a fixed xor
@@ -530,15 +686,48 @@ static inline int ta_launch_blocksort(const TaPlan& t, int64_t B, char* region, 
   return check_launch("ta_blocksort_kernel");
 }
 
+static inline bool ta_use_lds() {          // RBX_TA_LDS=0: the gather form for every shape (A/B measurement)
+  static const bool on = [] { const char* e = getenv("RBX_TA_LDS"); return e == nullptr || e[0] != '0'; }();
+  return on;
+}
+
 template <int G, bool VEC>
-static int ta_launch_bwd(const TaPlan& t, const float* g, const float* ssum, int accumulate, char* region, hipStream_t s) {
-  const size_t lds = (static_cast<size_t>(2 * kTaChunks) * t.D + 4 * kTaChunks) * 4;
+static int ta_launch_bwd(const TaPlan& t, int64_t B, const float* g, const float* ssum, int accumulate, char* region,
+                         hipStream_t s) {
   float* psum = reinterpret_cast<float*>(region + t.off_psum);
   float* pcnt = reinterpret_cast<float*>(region + t.off_pcnt);
-  hipLaunchKernelGGL((ta_reduce_kernel<G, VEC>), dim3(t.n_fld * t.NB), dim3(kTaThreads), lds, s, t.fld, t.n_fld, t.NB, g,
-                     t.has_emb ? ssum : nullptr, t.D, reinterpret_cast<const unsigned*>(region + t.off_sorted), psum, pcnt);
-  int rc = check_launch("ta_reduce_kernel");
-  if (rc != RBX_OK) return rc;
+  const unsigned* sorted = reinterpret_cast<const unsigned*>(region + t.off_sorted);
+  int rc;
+  if constexpr (VEC && G <= 4) {
+    if (t.has_emb && ssum != nullptr && t.D <= kTaLdsMaxDim && kTaChunk == 16 && ta_use_lds()) {
+      // fields per workgroup: about one workgroup per CU
+      int fpg = static_cast<int>((static_cast<long long>(t.n_fld) * t.NB + kCUs - 1) / kCUs);
+      if (fpg < 1) fpg = 1;
+      if (fpg > 4) fpg = 4;
+      const int n_grp = (t.n_fld + fpg - 1) / fpg;
+      const size_t lds = (static_cast<size_t>(kTaBlock) * t.D + kTaBlock + static_cast<size_t>(2 * kTaChunks) * t.D +
+                          4 * kTaChunks) * 4;
+      static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+      if (!attr_set[G]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ta_reduce_lds_kernel<G>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[G] = true;
+      }
+      hipLaunchKernelGGL((ta_reduce_lds_kernel<G>), dim3(t.NB * n_grp), dim3(512), lds, s, t.fld, t.n_fld, fpg, n_grp, t.NB,
+                         static_cast<long long>(B), g, ssum, t.D, sorted, psum, pcnt);
+      rc = check_launch("ta_reduce_lds_kernel");
+      if (rc != RBX_OK) return rc;
+      goto combine;
+    }
+  }
+  {
+    const size_t lds = (static_cast<size_t>(2 * kTaChunks) * t.D + 4 * kTaChunks) * 4;
+    hipLaunchKernelGGL((ta_reduce_kernel<G, VEC>), dim3(t.n_fld * t.NB), dim3(kTaThreads), lds, s, t.fld, t.n_fld, t.NB, g,
+                       t.has_emb ? ssum : nullptr, t.D, sorted, psum, pcnt);
+    rc = check_launch("ta_reduce_kernel");
+    if (rc != RBX_OK) return rc;
+  }
+combine:
   constexpr int NR = 256 / (G >= 16 ? G : 16);    // rows per workgroup of ta_final_kernel
   const unsigned blocks = (t.rows + NR - 1) / NR;
   TaFieldRefPack refs;
@@ -548,28 +737,28 @@ static int ta_launch_bwd(const TaPlan& t, const float* g, const float* ssum, int
   return check_launch("ta_final_kernel");
 }
 
-static inline int ta_dispatch_bwd(const TaPlan& t, const float* g, const float* ssum, int accumulate, char* region,
-                                  hipStream_t s) {
+static inline int ta_dispatch_bwd(const TaPlan& t, int64_t B, const float* g, const float* ssum, int accumulate,
+                                  char* region, hipStream_t s) {
   if (t.n_fld == 0) return RBX_OK;
   const bool vec = t.vec && (ssum == nullptr || (reinterpret_cast<uintptr_t>(ssum) & 15) == 0);
   const int units = vec ? t.D / 4 : t.D;
   if (vec) {
     switch (pow2_ceil(units)) {
-      case 1: return ta_launch_bwd<1, true>(t, g, ssum, accumulate, region, s);
-      case 2: return ta_launch_bwd<2, true>(t, g, ssum, accumulate, region, s);
-      case 4: return ta_launch_bwd<4, true>(t, g, ssum, accumulate, region, s);
-      case 8: return ta_launch_bwd<8, true>(t, g, ssum, accumulate, region, s);
-      default: return ta_launch_bwd<16, true>(t, g, ssum, accumulate, region, s);
+      case 1: return ta_launch_bwd<1, true>(t, B, g, ssum, accumulate, region, s);
+      case 2: return ta_launch_bwd<2, true>(t, B, g, ssum, accumulate, region, s);
+      case 4: return ta_launch_bwd<4, true>(t, B, g, ssum, accumulate, region, s);
+      case 8: return ta_launch_bwd<8, true>(t, B, g, ssum, accumulate, region, s);
+      default: return ta_launch_bwd<16, true>(t, B, g, ssum, accumulate, region, s);
     }
   }
   switch (pow2_ceil(units)) {
-    case 1: return ta_launch_bwd<1, false>(t, g, ssum, accumulate, region, s);
-    case 2: return ta_launch_bwd<2, false>(t, g, ssum, accumulate, region, s);
-    case 4: return ta_launch_bwd<4, false>(t, g, ssum, accumulate, region, s);
-    case 8: return ta_launch_bwd<8, false>(t, g, ssum, accumulate, region, s);
-    case 16: return ta_launch_bwd<16, false>(t, g, ssum, accumulate, region, s);
-    case 32: return ta_launch_bwd<32, false>(t, g, ssum, accumulate, region, s);
-    default: return ta_launch_bwd<64, false>(t, g, ssum, accumulate, region, s);
+    case 1: return ta_launch_bwd<1, false>(t, B, g, ssum, accumulate, region, s);
+    case 2: return ta_launch_bwd<2, false>(t, B, g, ssum, accumulate, region, s);
+    case 4: return ta_launch_bwd<4, false>(t, B, g, ssum, accumulate, region, s);
+    case 8: return ta_launch_bwd<8, false>(t, B, g, ssum, accumulate, region, s);
+    case 16: return ta_launch_bwd<16, false>(t, B, g, ssum, accumulate, region, s);
+    case 32: return ta_launch_bwd<32, false>(t, B, g, ssum, accumulate, region, s);
+    default: return ta_launch_bwd<64, false>(t, B, g, ssum, accumulate, region, s);
   }
 }
 

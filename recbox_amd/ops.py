@@ -71,6 +71,13 @@ class config(object):
     # combine (tier A) on the current stream, the large tables' segmented reduce (tier B) on the side stream its sort ran on
     # -- two chains of short, latency-bound kernels side by side instead of one after the other.
     fm_two_chains = os.environ.get("RECBOX_AMD_FM_TWO_CHAINS", "1") != "0"
+    # Where the ids-only pieces of the tiered FM backward run.  "split" (default): the id compaction on the CURRENT stream in
+    # front of the forward kernel (10 us; the step's first kernel is then on the stream the previous step ended on), the
+    # per-block sorts of the small tables on the current stream inside the backward (in front of the block partials that
+    # read them), only the re-zero and the large tables' sort on the side stream -- the two chains come out equally long
+    # (~150 us of kernels each at the Criteo shape).  "side": everything ids-only on the side stream, as one chain in
+    # front of the large tables' reduce.
+    fm_ids_work = os.environ.get("RECBOX_AMD_FM_IDS_WORK", "split")
 
 
 def _require_cuda(t, what):
@@ -662,17 +669,22 @@ class _GradPool(object):
             return None
         return pool
 
-    def early_sort(self, ctx, device, ws_bytes, rezero, sort, first=None):
+    def early_sort(self, ctx, device, ws_bytes, rezero, sort, first=None, pre=None, batch=None):
         """Launch, on the side stream: ``rezero(stream)`` -- clear the rows the previous backward stored, its sorted ids
         are still in ``self.ws`` -- when there are any, then ``sort(ws, ws_bytes, stream)`` of this batch's ids over
         them.  Both return a C-ABI code.  (Clearing on a third stream beside the sort was measured slower -- 0.344 vs
         0.331 ms per FM step --, and so was clearing beside the forward kernel -- 0.309 vs 0.299 ms, the forward going
         from 46 to 61 us: the step is bound by the memory request rate, concurrent kernels only slow each other down.)"""
         dirty = self.dirty_batch
-        if dirty and self.ws_bytes < ws_bytes:          # a larger batch than ever before: clear, then regrow
+        # a larger batch than ever before: clear, then regrow.  ``pre`` (work of the new step on the CURRENT stream, written
+        # into the workspace in the layout of ITS batch size) may land on the previous step's sorted pairs unless the two
+        # layouts are the same: clear first then, too.
+        if dirty and (self.ws_bytes < ws_bytes or (pre is not None and dirty != batch)):
             check(rezero(_stream()))
             dirty = 0
         ws = self.workspace(ws_bytes)
+        if pre is not None:
+            check(pre(ws, self.ws_bytes))
 
         # The re-zero goes FIRST: it reads the previous step's sorted pairs out of this workspace, and everything the new
         # step writes -- laid out for ITS batch size -- may land on them.
@@ -795,18 +807,29 @@ class _FmFused(torch.autograd.Function):
             pool = _GradPool.claim(_FmFused._pool_for(lead, emb_plan, lr_plan, emb_params, lr_params, dev)
                                    if config.reuse_grad_buffers else None)
 
-            # ids -> compact int32 matrix + the per-block sorts of the small tables (tier A), with an event of their own;
-            # then the (row, sample) sort of the large tables (tier B; for a call without embedding tables: the whole sort)
+            # ids -> compact int32 matrix, the per-block sorts of the small tables (tier A), the (row, sample) sort of the
+            # large tables (tier B; for a call without embedding tables: the whole sort)
+            split = config.fm_ids_work == "split" and emb_plan is not None
+
             def first(ws, nbytes, st):
                 return lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 1 | 4, st)
+
+            def compact(ws, nbytes):                       # on the current stream, in front of the forward kernel
+                return lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 1, _stream())
 
             def rest(ws, nbytes, st):
                 return _enqueue_sort((ea, la, lead.n, 1), keep, B, ws, nbytes, st,
                                      lambda: lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 2, st))
 
             if ws_bytes > 0 and pool is None:
-                ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: rest(ws, ws_bytes, st),
-                                      first=lambda ws, st: first(ws, ws_bytes, st))
+                if split:
+                    ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=dev)
+                    check(compact(ws, ws_bytes))
+                    ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: rest(ws, ws_bytes, st), ws=ws)
+                    ctx.blocksort_pending = True
+                else:
+                    ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: rest(ws, ws_bytes, st),
+                                          first=lambda ws, st: first(ws, ws_bytes, st))
             elif ws_bytes > 0:
                 def rezero(st):
                     rc = _FmFused._rezero(pool, emb_plan, lr_plan, emb_params, lr_params, lead, st)
@@ -816,7 +839,11 @@ class _FmFused(torch.autograd.Function):
                         lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
                     return rc
 
-                pool.early_sort(ctx, dev, ws_bytes, rezero, rest, first=first)
+                if split:
+                    pool.early_sort(ctx, dev, ws_bytes, rezero, rest, pre=compact, batch=B)
+                    ctx.blocksort_pending = True
+                else:
+                    pool.early_sort(ctx, dev, ws_bytes, rezero, rest, first=first)
             # the forward reads the tables only: back to descriptors without gradient pointers
             if emb_plan is not None:
                 emb_plan.bind_params(emb_params)
@@ -957,6 +984,11 @@ class _FmFused(torch.autograd.Function):
                                            extra.shape[1], has_extra - 1, _ptr(extra_index), extra.shape[0], _ptr(dx),
                                            _stream()))
         ws_early = ctx.sort.ws if (ctx.sort is not None and same) else None
+        pending_blocksort = getattr(ctx, "blocksort_pending", False) and ws_early is not None
+        grads_ready = None
+        if (config.fm_two_chains and ws_early is not None and isinstance(ctx.sort, _EarlySort) and ctx.sort.side is not None
+                and emb_plan is not None):
+            grads_ready = torch.cuda.current_stream(dev).record_event()      # dL/dlogit, S, the gradient buffers: all here
         numeric_done = None
         beside = config.numeric_beside_reduce
         if beside == "presorted":
@@ -977,8 +1009,12 @@ class _FmFused(torch.autograd.Function):
             # numeric weights + bias do not need the sorted ids: run them while the sort may still be in flight
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws_early),
                                  ctx.sort.ws_bytes, _stream()))
-        two_chains = (config.fm_two_chains and ws_early is not None and isinstance(ctx.sort, _EarlySort)
-                      and ctx.sort.event_first is not None and emb_plan is not None)
+        if pending_blocksort:
+            # the per-block sorts of the small tables (ids only), deferred to here: on this stream, in front of the block
+            # partials that read them, they leave the side stream to the large tables' sort
+            check(lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ctx.sort.ws), ctx.sort.ws_bytes, None, 4, _stream()))
+            ctx.blocksort_pending = False
+        two_chains = grads_ready is not None and (ctx.sort.event_first is not None or pending_blocksort)
         if two_chains:
             ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes           # (no join: each tier waits for its own part below)
         elif ctx.sort is not None and same:
@@ -997,15 +1033,18 @@ class _FmFused(torch.autograd.Function):
             # measured slower in the replayed step (0.27-0.28 vs 0.25 ms, profiles/r03).
             cur = torch.cuda.current_stream(dev)
             side = ctx.sort.side
-            a_side = os.environ.get("RECBOX_AMD_FM_TIER_A_ON", "main") == "side"
-            side.wait_event(cur.record_event())            # dL/dlogit, S and the gradient buffers are ready
+            a_side = os.environ.get("RECBOX_AMD_FM_TIER_A_ON", "main") == "side" and ctx.sort.event_first is not None
+            side.wait_event(grads_ready)
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (16 if a_side else 8) | store,
                                  _ptr(ws), ws_bytes, ctypes.c_void_p(side.cuda_stream)))
             side_done = side.record_event()
             for t in [dlogit, ssum] + [g for g in grads if g is not None]:
                 if t is not None:
                     t.record_stream(side)
-            cur.wait_event(ctx.sort.event if a_side else ctx.sort.event_first)
+            if a_side:
+                cur.wait_event(ctx.sort.event)
+            elif ctx.sort.event_first is not None:
+                cur.wait_event(ctx.sort.event_first)
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (8 if a_side else 16) | store,
                                  _ptr(ws), ws_bytes, _stream()))
             cur.wait_event(side_done)
