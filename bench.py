@@ -348,6 +348,11 @@ def run_model_config(args, rank, world, dev):
     model.to(dev).train()
     init_weights_device(model, dev, 0, rank)
     params = list(model.parameters())
+    shard_store = getattr(getattr(model, "embedding", None), "store", None)
+    if sharded and shard_store is not None and not args.fresh_grads and hasattr(shard_store.local_ops, "persistent"):
+        # the shard's dense gradient: one buffer cleared by the previous step's rows instead of a fresh zero-filled
+        # [rows, D] tensor per step (5 GB at cfg 3 in a world of one, 640 MB per rank at W = 8)
+        shard_store.local_ops.persistent(shard_store.weight)
     x = dict((k, v.clone()) for k, v in batches[0].items())
 
     def refill(i):
@@ -579,6 +584,8 @@ def main():
     ap.add_argument("--path", choices=["fused", "layers"], default="fused",
                     help="fused: FM model body in rbx_fm_fwd/bwd; layers: drop-in layers composed as the reference does")
     ap.add_argument("--items", type=int, default=None, help="youtubednn: rows of the item table (10 M); sasrec: items (1 M)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="fm, one GPU: do not append the time-boxed youtubednn / deepfm / sasrec sub-runs under \"configs\"")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 4096 if args.config == "sasrec" else 65536
@@ -917,9 +924,40 @@ def main():
                 out["config"]["warning"] = "exchange capacity overflowed: rerun with a larger --capacity-factor"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.dim, B, args.dist, args.cpu_seconds)
+        if world == 1 and not sharded and not args.no_cpu_baseline and not args.no_extra_configs:
+            out["configs"] = extra_configs(args)
         print(json.dumps(out))
     if world > 1 or args.force_sharded:
         torch.distributed.destroy_process_group()
+
+
+def extra_configs(args):
+    """BASELINE.json configs[2..4] beside the headline line: each one is `python bench.py --config C` in a process of its
+    own (its tables -- 5 GB for the YoutubeDNN item table, plus the same again of dense gradient -- do not share this
+    process's allocator), time-boxed; the full JSON line of the sub-run (ms_per_step, value, roofline of ITS dominant kernel,
+    cpu_baseline) goes under its name.  A sub-run that fails or runs out of time leaves {"skipped": reason}."""
+    import subprocess
+    res = {}
+    budget = float(os.environ.get("RECBOX_BENCH_EXTRA_SECONDS", "75"))
+    for cfg in ("youtubednn", "deepfm", "sasrec"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--gpus", "1", "--steps", str(min(args.steps, 20)),
+               "--warmup", str(min(args.warmup, 5)), "--cpu-seconds", "6", "--dist", args.dist]
+        t0 = time.perf_counter()
+        try:
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=budget)
+            line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+            if proc.returncode != 0 or not line:
+                res[cfg] = {"skipped": "exit code %d: %s" % (proc.returncode, proc.stderr.strip().splitlines()[-1:] or "")}
+            else:
+                d = json.loads(line[-1])
+                res[cfg] = {k: d[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "dtype", "config", "roofline",
+                                              "cpu_baseline") if k in d}
+                res[cfg]["wall_s"] = round(time.perf_counter() - t0, 1)
+        except subprocess.TimeoutExpired:
+            res[cfg] = {"skipped": "did not finish within %.0f s" % budget}
+        except Exception as e:                                      # noqa: BLE001 (a broken sub-run must not cost the headline line)
+            res[cfg] = {"skipped": "%s: %s" % (type(e).__name__, e)}
+    return res
 
 
 if __name__ == "__main__":

@@ -219,6 +219,13 @@ def all_reduce_sum_(x, group=None, async_op=False):
     return _Done()
 
 
+def all_reduce_max_(x, group=None):
+    """In-place MAX over the ranks (status words, flags, batch-size checks)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)
+    return x
+
+
 def all_reduce_grads(params, group=None):
     """Data-parallel towers: one all-reduce (sum) per dense gradient."""
     _, W = world(group)

@@ -137,9 +137,17 @@ class ShardedFMStep(object):
         self.sorted_ws = None
         self.local_sorted = None
         self.graphs = None
-        if persistent_shard_grad and hasattr(tables.local_ops, "persistent"):
+        persistent = persistent_shard_grad and hasattr(tables.local_ops, "persistent")
+        if persistent:
             # the shard's dense gradient: one buffer cleared by row instead of a full zero fill per step
+            if graphs and warmup < 1:
+                # the row re-zero is part of the captured owner-side sort only if a step has run before the capture (the
+                # decision "are there rows to clear" is taken on the host, at capture time): without one, replays would
+                # never clear what the replays before them stored
+                raise ValueError("ShardedFMStep(graphs=True, persistent_shard_grad=True) needs warmup >= 1")
             tables.local_ops.persistent(tables.weight)
+        if self.W == 1:
+            self.pieces[-1] = lambda: None          # nothing to un-flatten without an all-reduce (and no empty graph to replay)
         if graphs:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -149,7 +157,14 @@ class ShardedFMStep(object):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graphs = []
+            keep = getattr(tables.local_ops, "_keep", None)
+            if persistent and keep is not None and self.W * cap > 0 and not keep.get("dirty"):
+                raise RuntimeError("ShardedFMStep: the warm-up left no rows to clear; the captured sort would never re-zero the "
+                                   "persistent shard gradient")
             for piece in self.pieces:
+                if self.W == 1 and piece is self.pieces[-1]:
+                    self.graphs.append(piece)           # (the no-op stays a no-op)
+                    continue
                 if piece == self._head:                 # the two id sorts are captured on their own streams first
                     gs = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gs, stream=self.side, capture_error_mode="thread_local"):

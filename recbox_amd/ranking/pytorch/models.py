@@ -55,6 +55,10 @@ class FM(nn.Module):
                                 presorted=presorted)
         if presorted is not None:
             raise ValueError("FM: presorted ids belong to the fused path")
+        if getattr(self, "_packed", False):
+            raise RuntimeError("FM: the tables of this model were re-homed by pack_tables() (rows of %s floats): only the fused "
+                               "forward reads that layout.  Use fused=True with the model's own feature set, or rebuild the "
+                               "model and load_state_dict() the checkpoint (it holds plain contiguous tables)" % "row_floats")
         logit = self.fm(X, self.embedding_layer(X))
         return (logit, None) if with_prob else logit
 
@@ -119,6 +123,17 @@ class FM(nn.Module):
             table.weight = nn.Parameter(packed[:, :D], requires_grad=w.requires_grad)
             lr[name].weight = nn.Parameter(packed[:, D:D + 1], requires_grad=l.requires_grad)
             packed_pairs += 1
+        if packed_pairs and not getattr(self, "_packed_state_hook", None):
+            # a packed parameter is a column view of the [V, row_floats] storage: torch.save of a view writes the WHOLE
+            # storage (twice per pair).  Checkpoints keep the reference's format -- plain contiguous [V, D] / [V, 1] tensors
+            # under the reference's keys -- whatever the in-memory layout is.
+            def contiguous_state(module, state, prefix, local_metadata):
+                for k, v in list(state.items()):
+                    if torch.is_tensor(v) and not v.is_contiguous():
+                        state[k] = v.contiguous()
+                return state
+            self._packed_state_hook = self._register_state_dict_hook(contiguous_state)
+        self._packed = bool(packed_pairs) or getattr(self, "_packed", False)
         return packed_pairs
 
 

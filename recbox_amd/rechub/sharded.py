@@ -8,8 +8,8 @@ scale that way.  Here
 * tables with ``vocab_size >= shard_min_vocab`` live in a ``ShardedStore`` (recbox_amd/sharded.py): ``owner = id % W``,
   ONE all-to-all each way per step, mean/sum-pooled sequences reduced at the owner (SURVEY.md 5.8);
 * everything else -- small tables, MLP towers, BatchNorm, the FM / LR heads -- is replicated and data-parallel: the
-  dense gradients are all-reduced as ONE flat buffer, issued the moment the embedding backward starts (the towers'
-  backward is complete by then) so that it overlaps the gradient exchange and the scatter-adds;
+  dense gradients are all-reduced as ONE flat buffer, issued the moment the last tower / head parameter has received its
+  gradient (counted by per-parameter hooks) so that it overlaps the gradient exchange and the scatter-adds;
 * BatchNorm statistics are PER REPLICA, as under the reference's ``nn.DataParallel`` (each replica normalises its own
   slice; ctr_trainer.py:43) -- not synchronised as RecBole's DDP path does (recbole/trainer/trainer.py:61).  Running
   statistics therefore differ slightly between ranks; checkpoint rank 0's, as DataParallel does.
@@ -173,11 +173,15 @@ class ShardedEmbeddingLayer(EmbeddingLayer):
 class DenseGradSync(object):
     """Data-parallel gradients of the replicated parameters.
 
-    ``early``: parameters whose gradients are complete when the embedding backward STARTS (towers, heads): packed into
-    one flat buffer and all-reduced asynchronously from the store's ``on_backward_start`` hook, overlapping the
-    gradient exchange and the scatter-adds.  ``late``: the replicated tables, whose gradients come out of the embedding
-    backward itself: one more flat all-reduce in ``finish()``.  ``finish()`` also un-flattens; call it after
-    ``loss.backward()``."""
+    ``early``: towers and heads.  Their gradients are packed into one flat buffer and all-reduced asynchronously THE MOMENT
+    THE LAST ONE OF THEM HAS ITS GRADIENT OF THIS BACKWARD (a post-accumulate hook per parameter counts arrivals), which is
+    normally while the embedding backward -- gradient exchange, scatter-adds -- is still under way, so the all-reduce runs
+    beside it.  Nothing is reduced on a guess: a gradient left over from an earlier step (``zero_grad(set_to_none=False)``)
+    of a parameter whose backward has not run yet never enters the buffer.  ``late``: the replicated tables, whose
+    gradients come out of the embedding backward itself: one more flat all-reduce in ``finish()``.  ``finish()`` also
+    un-flattens and picks up whatever did not go early (a head that took no part in this loss); call it after every
+    ``loss.backward()`` -- a second backward before it is refused (the first one's gradients are already summed over the
+    ranks in place)."""
 
     def __init__(self, early, late, group=None):
         self.early = [p for p in early if p.requires_grad]
@@ -185,15 +189,25 @@ class DenseGradSync(object):
         self.group = group
         self.world = comm.world(group)[1]
         self._pending = None
+        self._arrived = set()
+        self._hooks = []
+        if self.world > 1:
+            for p in self.early:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _on_grad(self, p):
+        if id(p) in self._arrived or self._pending is not None:
+            raise RuntimeError("DenseGradSync: a second backward reached a replicated parameter before sync_grads() "
+                               "finished the first one (call model.sync_grads() after every loss.backward())")
+        self._arrived.add(id(p))
+        if len(self._arrived) == len(self.early):
+            grads = [q.grad for q in self.early]
+            flat = torch._utils._flatten_dense_tensors(grads)
+            self._pending = (flat, grads, comm.all_reduce_sum_(flat, self.group, async_op=True))
 
     def start(self):
-        if self.world == 1 or not self.early:
-            return
-        grads = [p.grad for p in self.early]
-        if any(g is None for g in grads):             # e.g. a head that took no part in this loss: all-reduce later
-            return
-        flat = torch._utils._flatten_dense_tensors(grads)
-        self._pending = (flat, grads, comm.all_reduce_sum_(flat, self.group, async_op=True))
+        """(kept for callers of the earlier interface: the all-reduce now starts from the parameters' own hooks)"""
+        return
 
     def finish(self):
         if self.world == 1:
@@ -207,6 +221,7 @@ class DenseGradSync(object):
             self._pending = None
         else:
             params = self.early + params
+        self._arrived.clear()
         # every rank reduces the same layout: a parameter without a gradient on this rank contributes zeros
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
         if grads:
@@ -228,8 +243,6 @@ class _ShardedModelMixin(object):
             skip.add(id(emb.store.weight))
         towers = [p for p in self.parameters() if id(p) not in skip]
         self.grad_sync = DenseGradSync(towers, tables, emb.group)
-        if emb.store is not None:
-            emb.store.on_backward_start = self.grad_sync.start
 
     @property
     def world_size(self):

@@ -398,6 +398,17 @@ class HipShardOps(object):
 
     def __init__(self):
         self._plans = {}
+        # persistent(): ONE dense gradient buffer per shard, cleared by row (the rows the previous scatter stored, named by
+        # the sorted keys its presort left in that step's workspace: rbx_embed_rezero) instead of a fresh zero-filled
+        # [rows, D] tensor per step -- 5 GB at cfg 3 in a world of one, 640 MB at W = 8.  The gradient handed to autograd
+        # then ALIASES that buffer: valid until the next backward, every step must start from ``weight.grad is None``
+        # (zero_grad(set_to_none=True)), and nothing may write other rows into it in place.
+        self._keep = None
+
+    def persistent(self, weight):
+        """Switch this shard to one persistent gradient buffer (see __init__).  Returns self."""
+        self._keep = {"grad": None, "shape": tuple(weight.shape), "ws": None, "ws_bytes": 0, "dirty": 0}
+        return self
 
     def route(self, geom, call, row_ids, pool_ids, vocabs, base, overflow, status):
         """-> (send int32 [W * ichunk], slot int32 [B, T], inv fp32 [B])."""
@@ -505,10 +516,26 @@ class HipShardOps(object):
         from . import ops
         from ._lib import check, lib
         n = keys.numel()
-        grad = torch.zeros_like(weight)
+        keep = self._keep
+        kept = keep is not None and keep["shape"] == tuple(weight.shape) and n > 0
+        plan = self._plan(weight)
+        if kept:
+            if weight.grad is not None:
+                raise RuntimeError("recbox_amd.sharded: a persistent shard gradient needs weight.grad to be None at every "
+                                   "backward (zero_grad(set_to_none=True)): the gradient aliases one buffer")
+            if keep["grad"] is None:
+                keep["grad"] = torch.zeros_like(weight)                 # the only full fill
+            grad = keep["grad"]
+            if keep["dirty"]:
+                # the rows the previous backward stored are named by the sorted keys in ITS workspace (kept alive here)
+                plan.bind_inputs([keys])
+                plan.bind_params([weight.detach()], [grad])
+                check(lib.rbx_embed_rezero(plan.arr, 1, keep["dirty"], ops._ptr(keep["ws"]), keep["ws_bytes"], ops._stream()))
+                keep["dirty"] = 0
+        else:
+            grad = torch.zeros_like(weight)
         if n == 0:
             return grad
-        plan = self._plan(weight)
         plan.bind_inputs([keys])
         plan.bind_params([weight.detach()], [grad])
         ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
@@ -518,6 +545,12 @@ class HipShardOps(object):
             check(lib.rbx_embed_sort(plan.arr, 1, n, ops._ptr(ws), ws_bytes, None, ops._stream()))
         check(lib.rbx_embed_bwd_indexed(plan.arr, 1, n, ops._ptr(grecv), grecv.stride(0), ops._ptr(src), None, 0,
                                         ops._ptr(ws), ws_bytes, ops._stream()))
+        if kept:
+            keep["ws"], keep["ws_bytes"], keep["dirty"] = ws, ws_bytes, n
+            # autograd takes a gradient over as the parameter's .grad only when nobody else holds the TENSOR OBJECT -- handed
+            # the buffer itself it would clone all of it (5 GB at cfg 3: the step went from 3.4 to 5.2 ms); a fresh view is
+            # a new object over the same memory
+            return grad.view(grad.shape)
         return grad
 
 
@@ -532,6 +565,7 @@ class _ShardLookup(torch.autograd.Function):
         row_ids = ids[:call.T]
         pool_ids = ids[call.T] if call.P else None
         B = (row_ids[0] if call.T else pool_ids).shape[0]
+        store.check_batch(B)                   # the wire sizes are derived from B on every rank: it must be the same one
         geom = call.geometry(W, store.embedding_dim, B, store.capacity_factor)
         dev = weight.device
         had_block = block is not None
@@ -558,8 +592,13 @@ class _ShardLookup(torch.autograd.Function):
         got = torch.empty_like(back)
         comm.all_to_all_equal_into(got, back, group).wait()                           # rows / partial sums back
         lo.combine_fwd(geom, call, got, slot, inv, block)
-        if status is not None and int(status.item()) != 0:
-            raise IndexError("index out of range in self")
+        if status is not None:
+            # bit 0 is raised on the requester, bit 1 on the owner: the ranks agree on it before any of them raises, or the
+            # others would walk into the next collective alone
+            if W > 1:
+                comm.all_reduce_max_(status, group)
+            if int(status.item()) != 0:
+                raise IndexError("index out of range in self")
         ctx.store, ctx.call, ctx.geom = store, call, geom
         ctx.had_block = had_block
         ctx.sort = sort
@@ -590,7 +629,9 @@ class ShardedStore(nn.Module):
     """Tables of one embedding dimension, row-sharded together over the ranks of ``process_group``:
     ``owner(id) = id % W``; rank r keeps, back to back in ONE weight ``[rows_r, D]``, its rows ``id // W`` of every
     table (``base[r][t]`` = first of them).  Checkpoints hold one shard per rank.  A table has no ``padding_idx``
-    here (rechub's tables have none, initializers.py:17; the id mask of a pooled lookup is the feature's)."""
+    here (rechub's tables have none, initializers.py:17; the id mask of a pooled lookup is the feature's).
+    Every rank must call ``lookup`` with the SAME batch size (the wire format has static sizes derived from it): use
+    ``drop_last=True`` or pad the last batch; ``check_batch`` verifies it collectively the first time a size is seen."""
 
     def __init__(self, vocabs, embedding_dim, capacity_factor=1.25, process_group=None, local_ops=None):
         super().__init__()
@@ -609,12 +650,32 @@ class ShardedStore(nn.Module):
         nn.init.normal_(self.weight, std=1e-4)
         self.capacity_factor = float(capacity_factor)
         self.local_ops = local_ops if local_ops is not None else HipShardOps()
-        self.on_backward_start = None          # hook: the dense tower's gradients are complete (data-parallel all-reduce)
+        self.on_backward_start = None          # optional hook called when the exchange's backward starts
         self._bases = {}
+        self.check_batch_size = "once"
+        self._seen_batch = set()
 
     def check_ids(self):
         from . import ops
         return ops.config.check_ids
+
+    def check_batch(self, B):
+        """Every rank derives the static wire sizes of the exchange from ITS batch size: they only agree when all ranks
+        hold the same number of samples (``drop_last=True`` in the loader, or pad the last batch).  ``check_batch_size``:
+        "once" (default) checks a size collectively the first time THIS rank sees it -- a set-up error raises ValueError on
+        every rank at the first step instead of hanging in the all-to-all; it cannot see a size that changes on one rank only
+        (the other ranks do not enter the check).  "always" checks every call (one 16-byte all-reduce + host sync); False
+        never."""
+        mode = self.check_batch_size
+        if not mode or self.world_size == 1 or (mode == "once" and B in self._seen_batch):
+            return
+        t = torch.tensor([B, -B], dtype=torch.int64, device=self.weight.device)
+        comm.all_reduce_max_(t, self.group)
+        hi, lo = int(t[0].item()), -int(t[1].item())
+        if hi != lo:
+            raise ValueError("recbox_amd.sharded: the ranks hold different batch sizes (%d..%d, this rank %d); the exchange "
+                             "needs the same number of samples on every rank (drop_last=True)" % (lo, hi, B))
+        self._seen_batch.add(B)
 
     def early_sort(self, lo, weight, keys):
         """The owner's id sort needs the received row numbers only: side stream, joined before the scatter-add."""

@@ -251,14 +251,28 @@ def _store_worker(rank, world, port, result):
                 sl, owned = store.local_rows_of(t)
                 assert torch.allclose(store.weight.grad[sl], leaves[t].grad[owned], atol=1e-5), "shard grad, table %d" % t
             # an id outside [0, vocab) is an IndexError (the reference's nn.Embedding raises), on every rank or none
+            # -- also when only ONE rank holds the bad id (the others must not walk into the next collective alone)
             bad = [r.clone() for r in rows]
-            bad[2][0] = vocabs[1]
+            if rank == 0:
+                bad[2][0] = vocabs[1]
             try:
                 store.lookup(call, 32, bad, hist)
                 raised = False
             except IndexError:
                 raised = True
             assert raised
+            # ranks with different batch sizes: a ValueError on every rank, not a hang in the all-to-all
+            # ("once", the default, checks a batch size the first time a rank sees it -- a set-up error shows at the first
+            #  step; "always" also catches a size that changes on one rank only, at one tiny all-reduce + host sync per call)
+            n = B - 1 if rank == world - 1 else B
+            for mode, st in (("once", ShardedStore(vocabs, D, capacity_factor=3.0, local_ops=OracleShardOps())), ("always", store)):
+                st.check_batch_size = mode
+                try:
+                    st.lookup(call, 32, [r[:n] for r in rows], hist[:n])
+                    raised = False
+                except ValueError as e:
+                    raised = "different batch sizes" in str(e)
+                assert raised, mode
             # a history with more ids for one owner than its capacity raises the overflow flag (never silently dropped)
             tight = ShardedStore(vocabs, D, capacity_factor=1.0, local_ops=OracleShardOps())
             one_owner = torch.full((64, L), world if world < vocabs[0] else 0)      # every id -> owner 0
@@ -297,3 +311,66 @@ def test_sharded_store_single_process():
     (_store_reference(leaves, hist, rows, D) * R).sum().backward()
     assert torch.allclose(store.weight.grad[:vocabs[0]], leaves[0].grad, atol=1e-5)
     assert torch.allclose(store.weight.grad[vocabs[0]:], leaves[1].grad, atol=1e-5)
+
+
+# ---- DenseGradSync: the data-parallel all-reduce of tower / head gradients starts from the parameters' own hooks --------
+def _sync_worker(rank, world, port, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from recbox_amd.rechub.sharded import DenseGradSync
+        torch.manual_seed(0)
+        item, user, table = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3), torch.nn.Embedding(5, 3)
+        towers = list(item.parameters()) + list(user.parameters())
+        sync = DenseGradSync(towers, list(table.parameters()))
+        for step in range(3):
+            g = torch.Generator().manual_seed(10 * step + rank)
+            xi, xu = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
+            ids = torch.randint(0, 5, (6,), generator=g)
+            # gradients of an earlier step stay in place as zeros (zero_grad(set_to_none=False)): ADVICE r2's stale-gradient case
+            for p in towers + list(table.parameters()):
+                if p.grad is not None:
+                    p.grad.zero_()
+            # the item branch's backward completes long before the user branch's (detach + a second backward inside one
+            # autograd pass is not needed: autograd orders the two Linear nodes by their position in the graph)
+            loss = ((item(xi) * table(ids)).sum() + (user(xu) ** 2).sum()) / world
+            loss.backward()
+            if step == 1:
+                # a second backward before sync_grads() is refused instead of summing already-reduced gradients again
+                try:
+                    (user(xu).sum()).backward()
+                    refused = False
+                except RuntimeError as e:
+                    refused = "second backward" in str(e)
+                assert refused
+                sync._arrived.clear()                   # (restore: the refused backward left nothing behind but this)
+                if sync._pending is not None:
+                    sync._pending[2].wait()
+                    sync._pending = None
+                for p in towers + list(table.parameters()):
+                    p.grad = None
+                loss = ((item(xi) * table(ids)).sum() + (user(xu) ** 2).sum()) / world
+                loss.backward()
+            sync.finish()
+            # reference: the same loss summed over every rank's batch, on one process
+            ri, ru, rt = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3), torch.nn.Embedding(5, 3)
+            ri.load_state_dict(item.state_dict()); ru.load_state_dict(user.state_dict()); rt.load_state_dict(table.state_dict())
+            for r in range(world):
+                g = torch.Generator().manual_seed(10 * step + r)
+                xi, xu = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
+                ids = torch.randint(0, 5, (6,), generator=g)
+                (((ri(xi) * rt(ids)).sum() + (ru(xu) ** 2).sum()) / world).backward()
+            for a, b in zip(towers + list(table.parameters()), list(ri.parameters()) + list(ru.parameters()) + list(rt.parameters())):
+                assert torch.allclose(a.grad, b.grad, atol=1e-6), "step %d" % step
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dense_grad_sync_reduces_only_this_steps_gradients_gloo():
+    port = _free_port()
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_sync_worker, args=(2, port, result), nprocs=2, join=True)
+    assert dict(result) == {0: "ok", 1: "ok"}

@@ -228,6 +228,34 @@ def test_sharded_deepfm_world_of_one_equals_deepfm():
         assert_close(mine[n0], b0, 1e-5, n0)
 
 
+def test_persistent_shard_gradient_equals_fresh_over_steps():
+    """HipShardOps.persistent(): the shard's dense gradient lives in ONE buffer whose rows are cleared by the previous
+    step's sorted keys (rbx_embed_rezero) instead of a fresh zero-filled [rows, D] tensor per step -- three steps over
+    different batches leave bit-identical gradients to the fresh path; a step that does not start from grad None is refused."""
+    import torch.nn.functional as F
+    Fe = _rh()
+    from recbox_amd.rechub.sharded import ShardedYoutubeDNN
+    V, D, B, L, n_neg = 2003, 16, 257, 7, 3
+    models = []
+    for _ in range(2):
+        m = ShardedYoutubeDNN(*_youtube_feats(Fe, V, D, True), {"dims": [32, D]}, temperature=0.1, shard_min_vocab=500).cuda()
+        _seed_params(m)
+        models.append(m)
+    fresh, kept = models
+    kept.embedding.store.local_ops.persistent(kept.embedding.store.weight)
+    tgt = torch.zeros(B, dtype=torch.long, device="cuda")
+    for step in range(3):
+        x = {k: v.cuda() for k, v in _youtube_batch(B, V, L, n_neg, 20 + step).items()}
+        for m in models:
+            m.zero_grad(set_to_none=True)
+            F.cross_entropy(m(x), tgt).backward()
+            m.sync_grads()
+        for (n, p0), (_, p1) in zip(fresh.named_parameters(), kept.named_parameters()):
+            assert torch.equal(p1.grad, p0.grad), "step %d: %s" % (step, n)
+    with pytest.raises(RuntimeError, match="persistent shard gradient"):
+        F.cross_entropy(kept(x), tgt).backward()           # weight.grad still set
+
+
 def test_store_at_cfg3_size_properties():
     """BASELINE.json cfg 3 at full size on one GPU (10 M x 128 table, B = 65 536, history <= 50, 1 + 4 items): the pooled
     output of 200 sampled users against an index_select restatement on the device, the item rows exactly, and the
