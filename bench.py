@@ -369,6 +369,21 @@ def run_model_config(args, rank, world, dev):
             return _model_step(xb)
         return one_step
 
+    # --optimizer: the step continues into an optimiser step (not part of BASELINE's fwd+bwd metric: reported beside it).
+    # sparse_adam: recbox_amd.optim.SparseAdam on the embedding tables (only the rows the batch touched are read and
+    # written) + torch.optim.Adam on the rest; dense_adam: torch.optim.Adam on everything, the reference's loop
+    # (ranking_model.py:191-197) -- every row of every table and of its two moments per step.
+    opt_steps = []
+    if args.optimizer != "none" and not sharded:
+        from recbox_amd import optim as rb_optim
+        tables, rest = rb_optim.split_parameters(model)
+        if args.optimizer == "sparse_adam":
+            opt_steps = [rb_optim.SparseAdam(tables, lr=1e-3).step]
+            if rest:
+                opt_steps.append(torch.optim.Adam(rest, lr=1e-3, capturable=True).step)
+        else:
+            opt_steps = [torch.optim.Adam(params, lr=1e-3, capturable=True).step]
+
     def _model_step(xb):
         for p in params:
             p.grad = None
@@ -384,6 +399,8 @@ def run_model_config(args, rank, world, dev):
                     p.grad.copy_(r)
         else:
             loss.backward()
+        for st in opt_steps:
+            st()
         return loss
 
     eager_step = step_over(x)                 # reads the static buffers `x` (refill(i) copies batch i % K into them)
@@ -524,6 +541,9 @@ def run_model_config(args, rank, world, dev):
                                      else "fresh zero-filled grads every step"),
                       "global_batch": B * world, "parallelism": par},
            "roofline": roof}
+    if opt_steps:
+        out["config"]["workload"] = out["config"]["workload"].replace("no optimiser step", "+ optimiser step (%s)" % args.optimizer)
+        out["metric"] = "samples/sec fwd+bwd+update (beside the fwd+bwd metric of BASELINE.json)"
     if store is not None:
         out["config"]["exchange"] = "padded capacity_factor=%g, overflow=%s" % (factor, overflow)
     if world == 1 and not args.no_cpu_baseline:
@@ -584,6 +604,9 @@ def main():
     ap.add_argument("--path", choices=["fused", "layers"], default="fused",
                     help="fused: FM model body in rbx_fm_fwd/bwd; layers: drop-in layers composed as the reference does")
     ap.add_argument("--items", type=int, default=None, help="youtubednn: rows of the item table (10 M); sasrec: items (1 M)")
+    ap.add_argument("--optimizer", choices=["none", "sparse_adam", "dense_adam"], default="none",
+                    help="model configs, one GPU: append an optimiser step to every step (sparse_adam: only the touched rows of "
+                         "the tables, recbox_amd.optim; dense_adam: torch.optim.Adam over every parameter, as the reference does)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="fm, one GPU: do not append the time-boxed youtubednn / deepfm / sasrec sub-runs under \"configs\"")
     args = ap.parse_args()

@@ -301,6 +301,38 @@ int rbx_sort_share(const rbx_field_t* src_a, const rbx_field_t* src_b, int32_t s
 int rbx_embed_rezero(const rbx_field_t* fields, int32_t n_fields, int64_t batch, void* d_workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ---- opt-in sparse-row optimiser step (SURVEY.md 8b "or, opt-in, a sparse-row update path"; 2.2 K3).  The reference
+ * runs a dense torch.optim step over dense [V, D] gradients (ranking/pytorch/models/ranking_model.py:191-197,
+ * matching/pytorch/models/match_model.py:194-199).  After rbx_embed_sort + rbx_embed_bwd (rbx_fm_sort + rbx_fm_bwd) of a
+ * step, the workspace still holds the sorted (row, lookup) pairs: the head of every run of equal rows names one touched row,
+ * whose summed gradient sits in fields[i].grad.  These calls apply ONE optimiser step to exactly those rows of
+ * fields[i].table (written in place) and of the state tensors -- same shape as the gradient, d_state1[i] / d_state2[i] per
+ * feature i (HOST arrays of DEVICE pointers; features that share a table pass the same pointers):
+ *   RBX_OPT_SGD      w -= lr (g + weight_decay w)
+ *   RBX_OPT_ADAGRAD  state1 += g^2; w -= lr g / (sqrt(state1) + eps)          (torch.optim.Adagrad's sparse branch; the
+ *                    caller folds lr_decay into lr)
+ *   RBX_OPT_ADAM     state1 = beta1 state1 + (1 - beta1) g; state2 = beta2 state2 + (1 - beta2) g^2;
+ *                    w -= lr state1 / (sqrt(state2) + eps)   with lr = lr0 sqrt(1 - beta2^t) / (1 - beta1^t) folded in by
+ *                    the caller (torch.optim.SparseAdam: the moments of untouched rows do not decay)
+ * Rows the batch did not touch, padding_idx rows and masked lookups are neither read nor written.  The tier-A tables of
+ * the fused FM body (every row written by every backward) count a row as touched when some block's presence bitmap has it.
+ * Call between the backward and the next sort on that workspace. */
+typedef enum { RBX_OPT_SGD = 0, RBX_OPT_ADAGRAD = 1, RBX_OPT_ADAM = 2 } rbx_opt_kind_t;
+typedef struct rbx_opt {
+  int32_t kind;              /* rbx_opt_kind_t */
+  float   lr;                /* effective step size (bias correction / decay folded in) */
+  float   beta1, beta2;      /* Adam */
+  float   eps;
+  float   weight_decay;      /* L2 on the touched rows: g += weight_decay * w (0 for torch's sparse rules) */
+} rbx_opt_t;
+int rbx_embed_sparse_update(const rbx_field_t* fields, int32_t n_fields, int64_t batch, const void* d_workspace,
+                            size_t workspace_bytes, const rbx_opt_t* opt, float* const* d_state1, float* const* d_state2,
+                            void* stream);
+int rbx_fm_sparse_update(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
+                         const void* d_workspace, size_t workspace_bytes, const rbx_opt_t* opt,
+                         float* const* d_emb_state1, float* const* d_emb_state2, float* const* d_lr_state1,
+                         float* const* d_lr_state2, void* stream);
+
 /* ---- C2: the exchange itself on the caller's stream.  The reference has no sharded exchange (nn.DataParallel / DDP
  * only); recbox_amd/comm.py uses torch.distributed's all_to_all_single by default, which runs on RCCL's
  * own stream behind two event joins.  rbx_all_to_all is the same grouped ncclSend / ncclRecv sequence enqueued on

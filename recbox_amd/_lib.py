@@ -46,6 +46,14 @@ class rbx_shard_geom_t(ctypes.Structure):
                 ("cap_pool", ctypes.c_int64)]
 
 
+class rbx_opt_t(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
+                ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float)]
+
+
+OPT_SGD, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
+
+
 class rbx_rowcopy_t(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("row_bytes", ctypes.c_int64)]
 
@@ -54,6 +62,8 @@ _P = ctypes.c_void_p
 _FP = ctypes.POINTER(rbx_field_t)
 _RP = ctypes.POINTER(rbx_rowcopy_t)
 _GP = ctypes.POINTER(rbx_shard_geom_t)
+_OP = ctypes.POINTER(rbx_opt_t)
+_PP = ctypes.POINTER(ctypes.c_void_p)          # host array of device pointers
 _u64 = ctypes.c_uint64
 _i32, _i64, _sz, _f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
@@ -83,6 +93,8 @@ SIGNATURES = {
     "rbx_fm_bwd_workspace_size": (_sz, [_FP, _FP, _i32, _i64]),
     "rbx_fm_sort": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P, _P]),
     "rbx_fm_sort_phases": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P, _i32, _P]),
+    "rbx_embed_sparse_update": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _OP, _PP, _PP, _P]),
+    "rbx_fm_sparse_update": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _OP, _PP, _PP, _PP, _PP, _P]),
     "rbx_comm_bind": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "rbx_all_to_all": (ctypes.c_int, [_P, _P, _P, _sz, _i32, _P]),
     "rbx_embed_rezero": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P]),

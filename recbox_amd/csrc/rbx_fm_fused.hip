@@ -624,7 +624,7 @@ static int fm_tier_a_max_vocab() {      // RBX_FM_TIER_A=0: every table through 
 // others to the sort plan `p`, whose id columns are the rows of the compact id matrix (patched in by fm_bind_cid once
 // the workspace is known)
 static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t B, BwdPlan* p, FmNumPack* np,
-                   int* n_num, TaPlan* ta, int* cid_of_key) {
+                   int* n_num, TaPlan* ta, int* cid_of_key, int* key_src = nullptr, int* tab_src = nullptr) {
   rbx_field_t tmp[RBX_MAX_FIELDS];
   const rbx_field_t* lead = (emb != nullptr) ? emb : lr;
   *n_num = 0;
@@ -718,6 +718,7 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
   for (int t = 0; t < n_tabs; ++t) {
     if (!tab_a[t]) continue;
     const int i0 = cat_src[tab_first[t]];
+    if (tab_src != nullptr) tab_src[ta->n_tab] = i0;
     TaTable& tb = ta->tab.t[ta->n_tab++];
     tb.grad = emb ? emb[i0].grad : nullptr;
     tb.grad2 = lr ? lr[i0].grad : nullptr;
@@ -761,6 +762,7 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
     tmp[n_b].table_stride = 0;               // (the plan's keys do not depend on the storage; the stride is set below)
     b_src[n_b] = i;
     cid_of_key[n_b] = c;
+    if (key_src != nullptr) key_src[n_b] = i;
     ++n_b;
   }
   const int ns = fm_num_samples(D, *n_num);
@@ -817,6 +819,22 @@ static int fm_full_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, in
   f->D = emb ? emb[0].dim : 1;
   f->off_ta = ta_align(f->p.bytes + fm_num_bytes(f->p, f->n_num, f->D));
   f->bytes = f->off_ta + f->ta.bytes;
+  return RBX_OK;
+}
+
+// what rbx_fm_sparse_update (rbx_optim.hip) needs of a call's plan: the tier B sort plan, the tier A description, where the
+// tier A region starts, the workspace size, and which feature of the caller's arrays every plan slot / tier A table is
+int fm_update_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t B, BwdPlan* p, TaPlan* ta, size_t* off_ta,
+                   size_t* bytes, int* src_of_key, int* src_of_tab) {
+  if (emb == nullptr && lr == nullptr) return fail(RBX_ERR_INVALID, "fm: both field arrays are NULL");
+  if (n <= 0 || n > RBX_MAX_FIELDS) return fail(RBX_ERR_INVALID, "fm: n_fields=%d not in [1,%d]", n, RBX_MAX_FIELDS);
+  FmNumPack np;
+  int n_num = 0, cid_of_key[RBX_MAX_FIELDS];
+  const int rc = fm_plan(emb, lr, n, B, p, &np, &n_num, ta, cid_of_key, src_of_key, src_of_tab);
+  if (rc != RBX_OK) return rc;
+  const int D = emb ? emb[0].dim : 1;
+  *off_ta = ta_align(p->bytes + fm_num_bytes(*p, n_num, D));
+  *bytes = *off_ta + ta->bytes;
   return RBX_OK;
 }
 

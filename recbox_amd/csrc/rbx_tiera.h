@@ -222,6 +222,7 @@ __device__ __forceinline__ void ta_radix_pass(unsigned (&key)[8], const int shif
 // key = row << 11 | sample offset inside the block; an id outside the table sorts behind every row (row = vocab), the
 // filler of a short last block behind that (all ones).  Only the row bits are sorted: the keys start in sample order
 // and the passes are stable.
+template <int kUnused = 0>              // (a template only so that the header may be included by several translation units)
 __global__ __launch_bounds__(256) void ta_blocksort_kernel(const TaFieldPack P, const int n_fld, const long long B,
                                                            const int* __restrict__ cid, unsigned* __restrict__ sorted,
                                                            unsigned* __restrict__ bitmap, const unsigned NB) {
@@ -680,7 +681,7 @@ static inline int ta_launch_compact(const TaPlan& t, int64_t B, char* region, in
 
 static inline int ta_launch_blocksort(const TaPlan& t, int64_t B, char* region, hipStream_t s) {
   if (t.n_fld == 0) return RBX_OK;
-  hipLaunchKernelGGL(ta_blocksort_kernel, dim3(t.n_fld * t.NB), dim3(256), 0, s, t.fld, t.n_fld, static_cast<long long>(B),
+  hipLaunchKernelGGL(ta_blocksort_kernel<0>, dim3(t.n_fld * t.NB), dim3(256), 0, s, t.fld, t.n_fld, static_cast<long long>(B),
                      reinterpret_cast<const int*>(region + t.off_cid), reinterpret_cast<unsigned*>(region + t.off_sorted),
                      reinterpret_cast<unsigned*>(region + t.off_bitmap), t.NB);
   return check_launch("ta_blocksort_kernel");

@@ -71,6 +71,9 @@ class config(object):
     # combine (tier A) on the current stream, the large tables' segmented reduce (tier B) on the side stream its sort ran on
     # -- two chains of short, latency-bound kernels side by side instead of one after the other.
     fm_two_chains = os.environ.get("RECBOX_AMD_FM_TWO_CHAINS", "1") != "0"
+    # keep, after every embedding backward, a record of what names the rows it touched (the sorted ids in its workspace, the
+    # descriptors, the gradient tensors): what recbox_amd.optim's sparse-row optimisers step over.  Switched on by them.
+    track_touched_rows = False
     # Where the ids-only pieces of the tiered FM backward run.  "split" (default): the id compaction on the CURRENT stream in
     # front of the forward kernel (10 us; the step's first kernel is then on the stream the previous step ended on), the
     # per-block sorts of the small tables on the current stream inside the backward (in front of the block partials that
@@ -327,6 +330,31 @@ def _enqueue_sort(desc, keep, B, ws, nbytes, st, sort_call):
     return rc
 
 
+class TouchedRows(object):
+    """What one embedding backward left behind for a sparse-row optimiser step (recbox_amd.optim): ``kind`` "embed"
+    (rbx_embed_*) or "fm" (rbx_fm_*), the plan(s) and id tensors of the call, its parameter and gradient lists, and the
+    workspace whose sorted ids name every touched row.  Valid until the next sort on that workspace."""
+    __slots__ = ("kind", "plans", "inputs", "params", "grads", "ws", "ws_bytes", "B", "serial")
+
+
+touched = {}                 # id(parameter) -> TouchedRows of the last backward that produced its gradient
+_touched_serial = [0]
+
+
+def _note_touched(kind, plans, inputs, params, grads, ws, ws_bytes, B):
+    rec = TouchedRows()
+    # (aliases of the gradient tensors, not the objects handed to autograd: AccumulateGrad takes a gradient over as
+    #  ``p.grad`` only while nobody else holds the tensor object -- otherwise it clones it, 5 GB for cfg 3's table)
+    grads = tuple([g.detach() if g is not None else None for g in group] for group in grads)
+    rec.kind, rec.plans, rec.inputs, rec.params, rec.grads = kind, plans, list(inputs), params, grads
+    rec.ws, rec.ws_bytes, rec.B = ws, int(ws_bytes), int(B)
+    _touched_serial[0] += 1
+    rec.serial = _touched_serial[0]
+    for group in params:
+        for p in group:
+            touched[id(p)] = rec
+
+
 def _forget_sort(ws):
     """A backward has consumed the sort in ``ws``: the step is over, the next one sorts afresh (its ids may live in the
     same tensors with the same version counters only if nothing was written -- but a workspace handed back to the
@@ -494,6 +522,8 @@ class _EmbedLookup(torch.autograd.Function):
         if pool is not None:
             pool.done(B)
         _forget_sort(ws)
+        if config.track_touched_rows:
+            _note_touched("embed", (plan,), ctx.inputs, (list(params),), (list(grads),), ws, ws_bytes, B)
         return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
 
 
@@ -1059,6 +1089,9 @@ class _FmFused(torch.autograd.Function):
             else:
                 pool.done(B)
         _forget_sort(ws)
+        if config.track_touched_rows:
+            _note_touched("fm", (emb_plan, lr_plan), keep, (list(emb_params), list(lr_params)), (list(ge), list(gl)), ws,
+                          ws_bytes, B)
         return result()
 
 
