@@ -387,6 +387,28 @@ int rbx_batchnorm_bwd(const float* d_x, const float* d_dy, const float* d_y_relu
                       const float* d_gamma, const float* d_mean, const float* d_rstd, int32_t training, float* d_dx,
                       float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* The same in pieces, for a SYNCHRONISED BatchNorm over the ranks of a data-parallel job (torch.nn.SyncBatchNorm: RecBole's
+ * DDP path converts every BatchNorm of the model, third_party/recbole/trainer/trainer.py:60-64; rechub's nn.DataParallel
+ * keeps per-replica statistics, ctr_trainer.py:43 -- the default here).  The caller's collectives sit between the calls:
+ *   rbx_batchnorm_stats       d_raw[3, cols] = this rank's (count, mean, M2 = sum (x - mean)^2) per column;
+ *                             all-gather, merge (Chan), derive mean / rstd and the running statistics;
+ *   rbx_batchnorm_apply       y = (x - mean) rstd gamma + beta (+ ReLU) with the GLOBAL d_mean / d_rstd;
+ *   rbx_batchnorm_bwd_reduce  this rank's d_dgamma = sum dy xhat, d_dbeta = sum dy (the parameter gradients: the job's
+ *                             gradient all-reduce sums them over the ranks like every other replicated parameter);
+ *                             all-reduce a COPY of the two for the next call;
+ *   rbx_batchnorm_bwd_dx      dx = gamma rstd (dy - dbeta / N - xhat dgamma / N) with the GLOBAL sums and
+ *                             N = total_rows = rows of all ranks together. */
+int rbx_batchnorm_stats(const float* d_x, int64_t rows, int32_t cols, float* d_raw, void* d_workspace,
+                        size_t workspace_bytes, void* stream);
+int rbx_batchnorm_apply(const float* d_x, int64_t rows, int32_t cols, const float* d_gamma, const float* d_beta,
+                        const float* d_mean, const float* d_rstd, int32_t relu, float* d_y, void* stream);
+int rbx_batchnorm_bwd_reduce(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
+                             const float* d_mean, const float* d_rstd, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                             size_t workspace_bytes, void* stream);
+int rbx_batchnorm_bwd_dx(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
+                         const float* d_gamma, const float* d_mean, const float* d_rstd, const float* d_dgamma,
+                         const float* d_dbeta, int64_t total_rows, float* d_dx, void* stream);
+
 /* ---- LayerNorm over the last dimension (the five nn.LayerNorm(D, eps=1e-8) of a SASRec block stack,
  * third_party/rechub/models/matching/sasrec.py:52-63,81-94).  x [rows, dim] contiguous; biased variance, eps inside
  * the square root (torch semantics); d_mean / d_rstd [rows] are kept for the backward.  Backward:

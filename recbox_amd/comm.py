@@ -219,6 +219,23 @@ def all_reduce_sum_(x, group=None, async_op=False):
     return _Done()
 
 
+def all_gather_rows(x, group=None):
+    """x [r, c] on every rank -> [W * r, c], rank order (the statistics of a synchronised BatchNorm).  gloo gathers host
+    memory only: device rows are staged through the host there (tests on one GPU; the production backend is RCCL)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x.clone()
+    W = dist.get_world_size(group)
+    x = x.contiguous()
+    if dist.get_backend(group) == "nccl":
+        out = x.new_empty((W * x.shape[0],) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(out, x, group=group)
+        return out
+    host = x.cpu()
+    parts = [torch.empty_like(host) for _ in range(W)]
+    dist.all_gather(parts, host, group=group)
+    return torch.cat(parts, dim=0).to(x.device)
+
+
 def all_reduce_max_(x, group=None):
     """In-place MAX over the ranks (status words, flags, batch-size checks)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

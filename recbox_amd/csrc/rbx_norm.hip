@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * kBnFinalWaves) void bn_stats_final_kernel(cons
                                                              const float eps, const float momentum,
                                                              float* __restrict__ running_mean,
                                                              float* __restrict__ running_var, float* __restrict__ mean,
-                                                             float* __restrict__ rstd) {
+                                                             float* __restrict__ rstd, float* __restrict__ raw) {
   __shared__ Welford red[kBnFinalWaves][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
   Welford t = {0.f, 0.f, 0.f};
@@ -118,6 +118,12 @@ __global__ __launch_bounds__(64 * kBnFinalWaves) void bn_stats_final_kernel(cons
   t = red[0][threadIdx.x];
 #pragma unroll
   for (int z = 1; z < kBnFinalWaves; ++z) t.merge(red[z][threadIdx.x]);
+  if (raw != nullptr) {                                          // this rank's share of a synchronised BatchNorm: n, mean, M2
+    raw[c] = t.n;
+    raw[cols + c] = t.mean;
+    raw[2 * cols + c] = t.m2;
+    return;
+  }
   const float var = t.m2 / t.n;                                  // biased: what normalises the batch
   mean[c] = t.mean;
   rstd[c] = 1.0f / sqrtf(var + eps);
@@ -312,12 +318,11 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                                         const float* __restrict__ dgamma, const int training,
-                                                        float* __restrict__ dx) {
+                                                        float* __restrict__ dx, const float inv_m) {
   constexpr int W = VEC ? 4 : 1;
   constexpr int U = 2;
   const long long total = rows * cols / W;
   const long long step = static_cast<long long>(gridDim.x) * blockDim.x;
-  const float inv_m = 1.0f / static_cast<float>(rows);
   long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if ((step * W) % cols == 0) {                             // fixed columns per lane (bn_grid): statistics in registers
     if (i >= total) return;
@@ -460,7 +465,7 @@ extern "C" int rbx_batchnorm_fwd(const float* d_x, int64_t rows, int32_t cols, c
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, static_cast<long long>(rows),
                        cols, partial);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((cols + 63) / 64), dim3(64 * kBnFinalWaves), 0, s, partial, nb, cols, eps, momentum, d_running_mean,
-                       d_running_var, d_mean, d_rstd);
+                       d_running_var, d_mean, d_rstd, static_cast<float*>(nullptr));
   } else {
     if (!d_running_mean || !d_running_var) return fail(RBX_ERR_INVALID, "batchnorm: eval mode needs the running statistics");
     hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cb), dim3(256), 0, s, d_running_mean, d_running_var, cols, eps, d_mean,
@@ -478,6 +483,37 @@ extern "C" int rbx_batchnorm_fwd(const float* d_x, int64_t rows, int32_t cols, c
   return check_launch("batchnorm forward kernels");
 }
 
+namespace rbx {
+static int bn_bwd_reduce(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
+                         const float* d_mean, const float* d_rstd, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                         size_t workspace_bytes, hipStream_t s) {
+  if (d_workspace == nullptr || workspace_bytes < rbx_batchnorm_workspace_size(rows, cols))
+    return fail(RBX_ERR_WORKSPACE, "batchnorm_bwd: workspace too small");
+  float* partial = static_cast<float*>(d_workspace);
+  const int nb = bn_blocks(rows);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, d_dy, d_y_relu,
+                     static_cast<long long>(rows), cols, d_mean, d_rstd, partial);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, nb, cols, d_dbeta, d_dgamma);
+  return check_launch("batchnorm backward reductions");
+}
+
+static int bn_bwd_dx(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
+                     const float* d_gamma, const float* d_mean, const float* d_rstd, const float* d_dgamma,
+                     const float* d_dbeta, int32_t training, int64_t total_rows, float* d_dx, hipStream_t s) {
+  const bool vec = bn_vec(cols, d_x, d_dy, d_dx);
+  const long long total = static_cast<long long>(rows) * cols / (vec ? 4 : 1);
+  const unsigned blocks = bn_grid(total, cols, vec ? 4 : 1);
+  const float inv_m = 1.0f / static_cast<float>(total_rows);
+  if (vec)
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(blocks), dim3(256), 0, s, d_x, d_dy, d_y_relu,
+                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx, inv_m);
+  else
+    hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(blocks), dim3(256), 0, s, d_x, d_dy, d_y_relu,
+                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx, inv_m);
+  return check_launch("batchnorm backward dx");
+}
+}  // namespace rbx
+
 extern "C" int rbx_batchnorm_bwd(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
                                  const float* d_gamma, const float* d_mean, const float* d_rstd, int32_t training,
                                  float* d_dx, float* d_dgamma,
@@ -487,26 +523,70 @@ extern "C" int rbx_batchnorm_bwd(const float* d_x, const float* d_dy, const floa
   if (rows == 0) return RBX_OK;
   if (!d_x || !d_dy || !d_mean || !d_rstd || !d_dgamma || !d_dbeta)
     return fail(RBX_ERR_INVALID, "batchnorm_bwd: NULL tensor (d_dgamma / d_dbeta are scratch even when unused)");
+  hipStream_t s = as_stream(stream);
+  int rc = bn_bwd_reduce(d_x, d_dy, d_y_relu, rows, cols, d_mean, d_rstd, d_dgamma, d_dbeta, d_workspace, workspace_bytes, s);
+  if (rc != RBX_OK || d_dx == nullptr) return rc;
+  return bn_bwd_dx(d_x, d_dy, d_y_relu, rows, cols, d_gamma, d_mean, d_rstd, d_dgamma, d_dbeta, training, rows, d_dx, s);
+}
+
+// ---- the pieces of a SYNCHRONISED BatchNorm (torch.nn.SyncBatchNorm; RecBole's DDP path converts every BatchNorm of the
+// model, third_party/recbole/trainer/trainer.py:60-64): the statistics of one normalisation come from the batches of all
+// ranks, so the collectives sit between these calls (recbox_amd/ops.py: _SyncBatchNorm).
+extern "C" int rbx_batchnorm_stats(const float* d_x, int64_t rows, int32_t cols, float* d_raw, void* d_workspace,
+                                   size_t workspace_bytes, void* stream) {
+  using namespace rbx;
+  if (rows <= 0 || cols <= 0) return fail(RBX_ERR_INVALID, "batchnorm_stats: bad shape");
+  if (!d_x || !d_raw) return fail(RBX_ERR_INVALID, "batchnorm_stats: NULL tensor");
   if (d_workspace == nullptr || workspace_bytes < rbx_batchnorm_workspace_size(rows, cols))
-    return fail(RBX_ERR_WORKSPACE, "batchnorm_bwd: workspace too small");
+    return fail(RBX_ERR_WORKSPACE, "batchnorm_stats: workspace too small");
   hipStream_t s = as_stream(stream);
   float* partial = static_cast<float*>(d_workspace);
   const int nb = bn_blocks(rows);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, d_dy, d_y_relu,
-                     static_cast<long long>(rows), cols, d_mean, d_rstd, partial);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, nb, cols, d_dbeta, d_dgamma);
-  if (d_dx != nullptr) {
-    const bool vec = bn_vec(cols, d_x, d_dy, d_dx);
-    const long long total = static_cast<long long>(rows) * cols / (vec ? 4 : 1);
-    const unsigned blocks = bn_grid(total, cols, vec ? 4 : 1);
-    if (vec)
-      hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(blocks), dim3(256), 0, s, d_x, d_dy, d_y_relu,
-                         static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx);
-    else
-      hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(blocks), dim3(256), 0, s, d_x, d_dy, d_y_relu,
-                         static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx);
-  }
-  return check_launch("batchnorm backward kernels");
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, static_cast<long long>(rows),
+                     cols, partial);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((cols + 63) / 64), dim3(64 * kBnFinalWaves), 0, s, partial, nb, cols, 0.f, 0.f,
+                     static_cast<float*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr),
+                     static_cast<float*>(nullptr), d_raw);
+  return check_launch("batchnorm statistics kernels");
+}
+
+extern "C" int rbx_batchnorm_apply(const float* d_x, int64_t rows, int32_t cols, const float* d_gamma, const float* d_beta,
+                                   const float* d_mean, const float* d_rstd, int32_t relu, float* d_y, void* stream) {
+  using namespace rbx;
+  if (rows < 0 || cols <= 0) return fail(RBX_ERR_INVALID, "batchnorm_apply: bad shape");
+  if (rows == 0) return RBX_OK;
+  if (!d_x || !d_y || !d_mean || !d_rstd) return fail(RBX_ERR_INVALID, "batchnorm_apply: NULL tensor");
+  const bool vec = bn_vec(cols, d_x, d_y, d_y);
+  const long long total = static_cast<long long>(rows) * cols / (vec ? 4 : 1);
+  const unsigned blocks = bn_grid(total, cols, vec ? 4 : 1);
+  hipStream_t s = as_stream(stream);
+  if (vec)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, s, d_x, static_cast<long long>(rows), cols, d_mean,
+                       d_rstd, d_gamma, d_beta, relu, d_y);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, s, d_x, static_cast<long long>(rows), cols, d_mean,
+                       d_rstd, d_gamma, d_beta, relu, d_y);
+  return check_launch("batchnorm apply kernel");
+}
+
+extern "C" int rbx_batchnorm_bwd_reduce(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows,
+                                        int32_t cols, const float* d_mean, const float* d_rstd, float* d_dgamma,
+                                        float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream) {
+  using namespace rbx;
+  if (rows <= 0 || cols <= 0) return fail(RBX_ERR_INVALID, "batchnorm_bwd_reduce: bad shape");
+  if (!d_x || !d_dy || !d_mean || !d_rstd || !d_dgamma || !d_dbeta) return fail(RBX_ERR_INVALID, "batchnorm_bwd_reduce: NULL tensor");
+  return bn_bwd_reduce(d_x, d_dy, d_y_relu, rows, cols, d_mean, d_rstd, d_dgamma, d_dbeta, d_workspace, workspace_bytes,
+                       as_stream(stream));
+}
+
+extern "C" int rbx_batchnorm_bwd_dx(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
+                                    const float* d_gamma, const float* d_mean, const float* d_rstd, const float* d_dgamma,
+                                    const float* d_dbeta, int64_t total_rows, float* d_dx, void* stream) {
+  using namespace rbx;
+  if (rows <= 0 || cols <= 0 || total_rows < rows) return fail(RBX_ERR_INVALID, "batchnorm_bwd_dx: bad shape");
+  if (!d_x || !d_dy || !d_mean || !d_rstd || !d_dgamma || !d_dbeta || !d_dx) return fail(RBX_ERR_INVALID, "batchnorm_bwd_dx: NULL tensor");
+  return bn_bwd_dx(d_x, d_dy, d_y_relu, rows, cols, d_gamma, d_mean, d_rstd, d_dgamma, d_dbeta, 1, total_rows, d_dx,
+                   as_stream(stream));
 }
 
 // ---- LayerNorm over the last dimension ----------------------------------------------------------------------

@@ -80,7 +80,7 @@ def run_sequential(seq, x):
             fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
             x = ops.linear(x, m.weight, m.bias, "relu" if fuse else None)
             i += 2 if fuse else 1
-        elif type(m) is nn.BatchNorm1d and x.dim() == 2:
+        elif type(m) in (nn.BatchNorm1d, nn.SyncBatchNorm) and x.dim() == 2:
             fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
             x = ops.batch_norm(x, m, relu=fuse)
             i += 2 if fuse else 1

@@ -1661,15 +1661,81 @@ class _BatchNorm(torch.autograd.Function):
                 dbeta if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None, None, None)
 
 
+class _SyncBatchNorm(torch.autograd.Function):
+    """BatchNorm over the batches of ALL ranks of ``group`` (torch.nn.SyncBatchNorm's arithmetic: RecBole's DDP path,
+    third_party/recbole/trainer/trainer.py:60-64): every rank's (count, mean, M2) per column are gathered and merged with
+    Chan's formula in rank order, y uses the global mean / rstd; backward all-reduces (sum dy, sum dy xhat) for dx and
+    returns THIS rank's sums as the gradients of weight / bias (the job's gradient all-reduce adds them up like every other
+    replicated parameter).  Every rank must hold the same number of rows."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stats, momentum, eps, relu, group):
+        from . import comm
+        _require_cuda(x, "x")
+        x = x.contiguous().float()
+        rows, cols = x.shape
+        dev = x.device
+        W = comm.world(group)[1]
+        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        raw = torch.empty((3, cols), dtype=torch.float32, device=dev)
+        check(lib.rbx_batchnorm_stats(_ptr(x), rows, cols, _ptr(raw), _ptr(ws), ws_bytes, _stream()))
+        allraw = comm.all_gather_rows(raw.view(1, 3 * cols), group).view(W, 3, cols)
+        n, mean_r, m2_r = allraw[:, 0], allraw[:, 1], allraw[:, 2]
+        total = n.sum(dim=0)
+        mean = (n * mean_r).sum(dim=0) / total
+        m2 = m2_r.sum(dim=0) + (n * (mean_r - mean) ** 2).sum(dim=0)
+        rstd = torch.rsqrt(m2 / total + eps)
+        if stats.running_mean is not None:
+            stats.running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            stats.running_var.mul_(1.0 - momentum).add_(m2 / (total - 1.0).clamp(min=1.0), alpha=momentum)
+        y = torch.empty_like(x)
+        check(lib.rbx_batchnorm_apply(_ptr(x), rows, cols, _ptr(weight), _ptr(bias), _ptr(mean), _ptr(rstd), 1 if relu else 0,
+                                      _ptr(y), _stream()))
+        ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
+        ctx.group, ctx.world, ctx.has_bias = group, W, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import comm
+        x, weight, mean, rstd, y_relu = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        rows, cols = x.shape
+        dev = x.device
+        sums = torch.empty((2, cols), dtype=torch.float32, device=dev)         # [dgamma | dbeta] of this rank
+        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        check(lib.rbx_batchnorm_bwd_reduce(_ptr(x), _ptr(dy), _ptr(y_relu), rows, cols, _ptr(mean), _ptr(rstd), _ptr(sums[0]),
+                                           _ptr(sums[1]), _ptr(ws), ws_bytes, _stream()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            glob = sums.clone()
+            comm.all_reduce_sum_(glob, ctx.group)
+            dx = torch.empty_like(x)
+            check(lib.rbx_batchnorm_bwd_dx(_ptr(x), _ptr(dy), _ptr(y_relu), rows, cols, _ptr(weight), _ptr(mean), _ptr(rstd),
+                                           _ptr(glob[0]), _ptr(glob[1]), rows * ctx.world, _ptr(dx), _stream()))
+        return (dx, sums[0] if (weight is not None and ctx.needs_input_grad[1]) else None,
+                sums[1] if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None, None, None)
+
+
 def batch_norm(x, module, relu=False):
     """``module(x)`` for an nn.BatchNorm1d on [rows, cols] input (optionally followed by ReLU), with torch's
-    bookkeeping: running statistics, num_batches_tracked, momentum=None = cumulative average, eval mode."""
+    bookkeeping: running statistics, num_batches_tracked, momentum=None = cumulative average, eval mode.
+    An ``nn.SyncBatchNorm`` (``torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)``) in training mode inside an
+    initialised process group normalises with the statistics of all ranks' batches (``_SyncBatchNorm``)."""
     training = module.training or module.running_mean is None
     momentum = 0.0 if module.momentum is None else module.momentum
     if module.training and module.track_running_stats and module.num_batches_tracked is not None:
         module.num_batches_tracked.add_(1)
         if module.momentum is None:
             momentum = 1.0 / float(module.num_batches_tracked)
+    if isinstance(module, torch.nn.SyncBatchNorm) and training:
+        from . import comm
+        group = getattr(module, "process_group", None)
+        if comm.world(group)[1] > 1:
+            return _SyncBatchNorm.apply(x, module.weight, module.bias, _BnStats(module), float(momentum), float(module.eps),
+                                        relu, group)
     return _BatchNorm.apply(x, module.weight, module.bias, _BnStats(module), training, float(momentum), float(module.eps),
                             relu)
 

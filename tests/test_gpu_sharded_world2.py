@@ -287,3 +287,51 @@ def test_sharded_models_on_one_gpu_equal_single_gpu_models(which, bn_mode, world
     tables sharded) with 2 / 3 ranks: every HIP piece of the N>1 step with a real exchange (rows staged through the host
     over gloo) == the single-GPU model on the global batch."""
     assert _spawn(_model_worker, world, which, bn_mode) == {r: "ok" for r in range(world)}
+
+
+# ---- SyncBatchNorm: the statistics of one normalisation come from the batches of all ranks ------------------------
+def _syncbn_worker(rank, world, port, result):
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        from conftest import assert_close
+        from recbox_amd.rechub.basic.layers import MLP
+        torch.cuda.set_device(0)
+        rows, cols = 96, 40                                    # per-rank rows
+        g = torch.Generator().manual_seed(5)
+        X = (torch.randn(world * rows, cols, generator=g) * 2 + 1).cuda()              # the GLOBAL batch, same on every rank
+        R = torch.randn(world * rows, 1, generator=g).cuda()
+        torch.manual_seed(1)
+        ref = MLP(cols, output_layer=True, dims=[24, 16], activation="relu").cuda().train()          # BatchNorm1d: global batch
+        dut = MLP(cols, output_layer=True, dims=[24, 16], activation="relu").cuda()
+        dut.load_state_dict(ref.state_dict())
+        dut = torch.nn.SyncBatchNorm.convert_sync_batchnorm(dut).train()          # RecBole's conversion (trainer.py:60-64)
+        assert sum(isinstance(m, torch.nn.SyncBatchNorm) for m in dut.modules()) == 2
+        xg = X.clone().requires_grad_()
+        out_ref = ref(xg)                                       # (one training forward each: the running statistics move once)
+        (out_ref * R).sum().backward()
+        mine = slice(rank * rows, (rank + 1) * rows)
+        xr = X[mine].clone().requires_grad_()
+        out = dut(xr)
+        assert_close(out, out_ref[mine].detach(), 1e-5, "SyncBatchNorm output == BatchNorm over the global batch")
+        (out * R[mine]).sum().backward()
+        assert_close(xr.grad, xg.grad[mine], 1e-5, "dx")
+        for (n, p), (_, q) in zip(dut.named_parameters(), ref.named_parameters()):
+            gsum = p.grad.clone()
+            dist.all_reduce(gsum)                               # the job's gradient all-reduce (sum)
+            assert_close(gsum, q.grad, 2e-5, "grad " + n)
+        ref_b, dut_b = dict(ref.named_buffers()), dict(dut.named_buffers())
+        for n, b in ref_b.items():                              # running statistics: those of the global batch, on every rank
+            if b.dtype.is_floating_point:
+                assert_close(dut_b[n], b, 1e-5, n)
+        dut.eval()                                              # eval mode: running statistics, no collective
+        assert_close(dut(X[mine]), ref.eval()(X[mine]), 1e-5, "eval")
+        result.put((rank, "ok"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sync_batch_norm_over_ranks_equals_batch_norm_over_the_global_batch(world):
+    """torch.nn.SyncBatchNorm.convert_sync_batchnorm(model) on a rechub MLP: outputs, dx, parameter gradients (summed over the
+    ranks) and running statistics equal BatchNorm1d on the global batch; rbx_batchnorm_stats / _apply / _bwd_reduce / _bwd_dx."""
+    assert _spawn(_syncbn_worker, world) == {r: "ok" for r in range(world)}
