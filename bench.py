@@ -912,8 +912,11 @@ def main():
             if args.dim == 16 and (args.path == "fused" or sharded):
                 # what this GPU delivers on random 64-byte rows at all (a kernel that only gathers them): the ceiling the
                 # D = 16 forward can be held against; 128-byte rows and wider reach 5.8-6.0 TB/s
-                roof["row_gather_ceiling"] = {"GB/s": 3038.6, "frac_of_peak": 3038.6 / 8000.0,
-                                              "source": "profiles/r01_gather_yardstick.txt (profiles/ubench/gather_ubench.hip)"}
+                roof["row_gather_ceiling"] = {"GB/s": 3070.5, "frac_of_peak": 3070.5 / 8000.0,
+                                              "source": "profiles/r03/gather_ceiling.txt (profiles/ubench/gather_ceiling.hip: random "
+                                                        "64-byte rows reach 46.9-48.0 G rows/s at every queue depth, through registers "
+                                                        "and through LDS-DMA alike -- the rate of random 128-byte rows, 6.0-6.1 TB/s of "
+                                                        "lines beside a 6.3-6.5 TB/s read-only stream)"}
             ams = alone_timer.mean_ms()
             if ams:
                 roof["frac_alone"] = per_sample * B / (ams * 1e-3) / 1e9 / 8000.0
