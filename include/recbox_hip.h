@@ -387,6 +387,19 @@ int rbx_batchnorm_bwd(const float* d_x, const float* d_dy, const float* d_y_relu
                       const float* d_gamma, const float* d_mean, const float* d_rstd, int32_t training, float* d_dx,
                       float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* nn.PReLU behind the BatchNorm of a tower layer (rechub MLP with activation="prelu": Linear -> BatchNorm1d -> PReLU ->
+ * Dropout, third_party/rechub/basic/layers.py:255-263, activation.py:44-45; DSSM's towers in BASELINE cfg 1) in the same
+ * passes: y = z > 0 ? z : a z on the normalised value z, a = d_slope[0] (slope_n == 1: nn.PReLU()) or one per column
+ * (slope_n == cols).  Backward rebuilds z from x (its sign is the mask -- y's is not when a <= 0):
+ * dz = z > 0 ? dy : a dy, d_dslope_cols[c] = sum dy z over z <= 0 (sum it over c for the single-parameter form). */
+int rbx_batchnorm_prelu_fwd(const float* d_x, int64_t rows, int32_t cols, const float* d_gamma, const float* d_beta,
+                            const float* d_slope, int32_t slope_n, float eps, int32_t training, float momentum,
+                            float* d_running_mean, float* d_running_var, float* d_mean, float* d_rstd, float* d_y,
+                            void* d_workspace, size_t workspace_bytes, void* stream);
+int rbx_batchnorm_prelu_bwd(const float* d_x, const float* d_dy, int64_t rows, int32_t cols, const float* d_gamma,
+                            const float* d_beta, const float* d_slope, int32_t slope_n, const float* d_mean,
+                            const float* d_rstd, int32_t training, float* d_dx, float* d_dgamma, float* d_dbeta,
+                            float* d_dslope_cols, void* d_workspace, size_t workspace_bytes, void* stream);
 /* The same in pieces, for a SYNCHRONISED BatchNorm over the ranks of a data-parallel job (torch.nn.SyncBatchNorm: RecBole's
  * DDP path converts every BatchNorm of the model, third_party/recbole/trainer/trainer.py:60-64; rechub's nn.DataParallel
  * keeps per-replica statistics, ctr_trainer.py:43 -- the default here).  The caller's collectives sit between the calls:

@@ -117,6 +117,8 @@ SIGNATURES = {
     "rbx_batchnorm_workspace_size": (_sz, [_i64, _i32]),
     "rbx_batchnorm_fwd": (ctypes.c_int, [_P, _i64, _i32, _P, _P, _f32, _i32, _f32, _P, _P, _i32, _P, _P, _P, _P, _sz, _P]),
     "rbx_batchnorm_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _P, _P, _P, _i32, _P, _P, _P, _P, _sz, _P]),
+    "rbx_batchnorm_prelu_fwd": (ctypes.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _f32, _i32, _f32, _P, _P, _P, _P, _P, _P, _sz, _P]),
+    "rbx_batchnorm_prelu_bwd": (ctypes.c_int, [_P, _P, _i64, _i32, _P, _P, _P, _i32, _P, _P, _i32, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_batchnorm_stats": (ctypes.c_int, [_P, _i64, _i32, _P, _P, _sz, _P]),
     "rbx_batchnorm_apply": (ctypes.c_int, [_P, _i64, _i32, _P, _P, _P, _P, _i32, _P, _P]),
     "rbx_batchnorm_bwd_reduce": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _P, _P, _P, _P, _P, _sz, _P]),

@@ -152,7 +152,9 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const long long rows, const int cols,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const int relu, float* __restrict__ y) {
+                                                       const int relu, float* __restrict__ y,
+                                                       const float* __restrict__ slope, const int slope_n) {
+  // slope != NULL: PReLU behind the normalisation (y = z > 0 ? z : a z; one a, or one per column) in the same pass
   constexpr int W = VEC ? 4 : 1;
   constexpr int U = 4;
   const long long total = rows * cols / W;
@@ -161,13 +163,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   if ((step * W) % cols == 0) {
     if (i >= total) return;
     const int c = static_cast<int>((i * W) % cols);
-    float m[W], rs[W], g[W], b[W];
+    float m[W], rs[W], g[W], b[W], a[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       m[k] = mean[c + k];
       rs[k] = rstd[c + k];
       g[k] = gamma != nullptr ? gamma[c + k] : 1.f;
       b[k] = beta != nullptr ? beta[c + k] : 0.f;
+      a[k] = slope != nullptr ? slope[slope_n > 1 ? c + k : 0] : 0.f;
     }
     auto one = [&](const float (&v)[W], const long long e) {
       float o[W];
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       for (int k = 0; k < W; ++k) {
         o[k] = (v[k] - m[k]) * rs[k] * g[k] + b[k];
         if (relu && o[k] < 0.f) o[k] = 0.f;
+        if (slope != nullptr && o[k] < 0.f) o[k] *= a[k];
       }
       if constexpr (VEC) *reinterpret_cast<float4*>(y + e) = make_float4(o[0], o[1], o[2], o[3]);
       else y[e] = o[0];
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       const float b = beta != nullptr ? beta[c + k] : 0.f;
       o[k] = (v[k] - mean[c + k]) * rstd[c + k] * g + b;
       if (relu && o[k] < 0.f) o[k] = 0.f;
+      if (slope != nullptr && o[k] < 0.f) o[k] *= slope[slope_n > 1 ? c + k : 0];
     }
     if constexpr (VEC) *reinterpret_cast<float4*>(y + e) = make_float4(o[0], o[1], o[2], o[3]);
     else y[e] = o[0];
@@ -230,17 +235,41 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // partial[(rb * cols + c) * 2 + {0,1}] = (sum dy, sum dy * xhat) over the row block
+// PReLU behind the normalisation (slope != NULL; gamma / beta rebuild z = xhat gamma + beta, whose sign is the mask):
+// dz = z > 0 ? dy : a dy takes dy's place, and a third partial, sum dy z over z <= 0 (d slope), goes to `partial3`
+// [(rb * cols + c)].
+struct BnPrelu {
+  const float* slope;      // NULL: no PReLU
+  int n;                   // 1, or cols
+  const float* gamma;
+  const float* beta;
+};
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ y_relu, const long long rows,
                                                              const int cols,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, const BnPrelu pr,
+                                                             float* __restrict__ partial3) {
   __shared__ float red[2][4][64];
+  __shared__ float red3[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const long long r0 = static_cast<long long>(blockIdx.y) * kBnRows;
   const long long r1 = (r0 + kBnRows < rows) ? r0 + kBnRows : rows;
-  float s0 = 0.f, s1 = 0.f;
-  if (c < cols) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (c < cols && pr.slope != nullptr) {
+    const float m = mean[c], rs = rstd[c];
+    const float gm = pr.gamma != nullptr ? pr.gamma[c] : 1.f, bt = pr.beta != nullptr ? pr.beta[c] : 0.f;
+    const float a = pr.slope[pr.n > 1 ? c : 0];
+    for (long long r = r0 + (threadIdx.x >> 6); r < r1; r += 4) {
+      const float gy = dy[r * cols + c];
+      const float xhat = (x[r * cols + c] - m) * rs;
+      const float z = xhat * gm + bt;
+      const float g = z > 0.f ? gy : a * gy;
+      s0 += g;
+      s1 += g * xhat;
+      if (!(z > 0.f)) s2 += gy * z;
+    }
+  } else if (c < cols) {
     const float m = mean[c], rs = rstd[c];
     long long r = r0 + (threadIdx.x >> 6);
     for (; r + 12 < r1; r += 16) {                           // 4 rows in flight, added in ascending order
@@ -268,19 +297,34 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
   red[0][threadIdx.x >> 6][threadIdx.x & 63] = s0;
   red[1][threadIdx.x >> 6][threadIdx.x & 63] = s1;
+  red3[threadIdx.x >> 6][threadIdx.x & 63] = s2;
   __syncthreads();
   if (threadIdx.x < 64 && c < cols) {
     float* dst = partial + (static_cast<long long>(blockIdx.y) * cols + c) * 2;
     dst[0] = (red[0][0][threadIdx.x] + red[0][1][threadIdx.x]) + (red[0][2][threadIdx.x] + red[0][3][threadIdx.x]);
     dst[1] = (red[1][0][threadIdx.x] + red[1][1][threadIdx.x]) + (red[1][2][threadIdx.x] + red[1][3][threadIdx.x]);
+    if (partial3 != nullptr)
+      partial3[static_cast<long long>(blockIdx.y) * cols + c] =
+          (red3[0][threadIdx.x] + red3[1][threadIdx.x]) + (red3[2][threadIdx.x] + red3[3][threadIdx.x]);
   }
 }
 
 // a workgroup owns 64 columns; its 4 wavefronts take every 4th row block and meet in LDS (fixed order)
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, const int nblocks, const int cols,
-                                                           float* __restrict__ dbeta, float* __restrict__ dgamma) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                           const float* __restrict__ partial3, float* __restrict__ dslope) {
   __shared__ float red[2][4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
+  if (partial3 != nullptr && dslope != nullptr) {            // d slope per column (PReLU): same walk, its own buffer
+    __shared__ float r3[4][64];
+    float s2 = 0.f;
+    if (c < cols)
+      for (int b = zl; b < nblocks; b += 4) s2 += partial3[static_cast<long long>(b) * cols + c];
+    r3[zl][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (zl == 0 && c < cols) dslope[c] = (r3[0][threadIdx.x] + r3[1][threadIdx.x]) + (r3[2][threadIdx.x] + r3[3][threadIdx.x]);
+    __syncthreads();
+  }
   float s0 = 0.f, s1 = 0.f;
   if (c < cols) {
     int b = zl;
@@ -318,7 +362,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                                         const float* __restrict__ dgamma, const int training,
-                                                        float* __restrict__ dx, const float inv_m) {
+                                                        float* __restrict__ dx, const float inv_m, const BnPrelu pr) {
   constexpr int W = VEC ? 4 : 1;
   constexpr int U = 2;
   const long long total = rows * cols / W;
@@ -327,7 +371,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
   if ((step * W) % cols == 0) {                             // fixed columns per lane (bn_grid): statistics in registers
     if (i >= total) return;
     const int c = static_cast<int>((i * W) % cols);
-    float m[W], rs[W], g[W], db[W], dg[W];
+    float m[W], rs[W], g[W], db[W], dg[W], bt[W], sl[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
       m[k] = mean[c + k];
@@ -335,6 +379,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
       g[k] = gamma != nullptr ? gamma[c + k] : 1.f;
       db[k] = dbeta[c + k];
       dg[k] = dgamma[c + k];
+      bt[k] = (pr.slope != nullptr && pr.beta != nullptr) ? pr.beta[c + k] : 0.f;
+      sl[k] = pr.slope != nullptr ? pr.slope[pr.n > 1 ? c + k : 0] : 0.f;
     }
     auto load = [&](const float* __restrict__ src, const long long e, float (&v)[W]) {
       if constexpr (VEC) {
@@ -349,6 +395,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
 #pragma unroll
       for (int k = 0; k < W; ++k) {
         if (y_relu != nullptr && !(yv[k] > 0.f)) gv[k] = 0.f;
+        if (pr.slope != nullptr && !((xv[k] - m[k]) * rs[k] * g[k] + bt[k] > 0.f)) gv[k] *= sl[k];
         if (training) {
           const float xhat = (xv[k] - m[k]) * rs[k];
           o[k] = g[k] * rs[k] * (gv[k] - db[k] * inv_m - xhat * dg[k] * inv_m);
@@ -409,6 +456,10 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
     for (int k = 0; k < W; ++k) {
       const float g = gamma != nullptr ? gamma[c + k] : 1.f;
       const float rs = rstd[c + k];
+      if (pr.slope != nullptr) {
+        const float z = (xv[k] - mean[c + k]) * rs * g + (pr.beta != nullptr ? pr.beta[c + k] : 0.f);
+        if (!(z > 0.f)) gv[k] *= pr.slope[pr.n > 1 ? c + k : 0];
+      }
       if (training) {
         const float xhat = (xv[k] - mean[c + k]) * rs;
         o[k] = g * rs * (gv[k] - dbeta[c + k] * inv_m - xhat * dgamma[c + k] * inv_m);
@@ -446,11 +497,11 @@ extern "C" size_t rbx_batchnorm_workspace_size(int64_t rows, int32_t cols) {
   return static_cast<size_t>(rbx::bn_blocks(rows)) * cols * 3 * sizeof(float) + 256;
 }
 
-extern "C" int rbx_batchnorm_fwd(const float* d_x, int64_t rows, int32_t cols, const float* d_gamma, const float* d_beta,
-                                 float eps, int32_t training, float momentum, float* d_running_mean, float* d_running_var,
-                                 int32_t relu, float* d_mean, float* d_rstd, float* d_y, void* d_workspace,
-                                 size_t workspace_bytes, void* stream) {
-  using namespace rbx;
+namespace rbx {
+static int bn_fwd_impl(const float* d_x, int64_t rows, int32_t cols, const float* d_gamma, const float* d_beta,
+                       float eps, int32_t training, float momentum, float* d_running_mean, float* d_running_var,
+                       int32_t relu, float* d_mean, float* d_rstd, float* d_y, void* d_workspace,
+                       size_t workspace_bytes, void* stream, const float* d_slope, int slope_n) {
   if (rows < 0 || cols <= 0) return fail(RBX_ERR_INVALID, "batchnorm: bad shape");
   if (rows == 0) return RBX_OK;
   if (!d_x || !d_y || !d_mean || !d_rstd) return fail(RBX_ERR_INVALID, "batchnorm: NULL tensor");
@@ -476,40 +527,67 @@ extern "C" int rbx_batchnorm_fwd(const float* d_x, int64_t rows, int32_t cols, c
   const unsigned blocks = bn_grid(total, cols, vec ? 4 : 1);
   if (vec)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, s, d_x,
-                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_beta, relu, d_y);
+                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_beta, relu, d_y, d_slope, slope_n);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, s, d_x,
-                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_beta, relu, d_y);
+                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_beta, relu, d_y, d_slope, slope_n);
   return check_launch("batchnorm forward kernels");
+}
+}  // namespace rbx
+
+extern "C" int rbx_batchnorm_fwd(const float* d_x, int64_t rows, int32_t cols, const float* d_gamma, const float* d_beta,
+                                 float eps, int32_t training, float momentum, float* d_running_mean, float* d_running_var,
+                                 int32_t relu, float* d_mean, float* d_rstd, float* d_y, void* d_workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return rbx::bn_fwd_impl(d_x, rows, cols, d_gamma, d_beta, eps, training, momentum, d_running_mean, d_running_var, relu,
+                          d_mean, d_rstd, d_y, d_workspace, workspace_bytes, stream, nullptr, 0);
+}
+
+// nn.PReLU behind the BatchNorm of a tower layer (third_party/rechub/basic/layers.py:255-263 with activation="prelu":
+// DSSM's towers, BASELINE cfg 1; activation.py:44-45) in the same passes: y = z > 0 ? z : a z with z the normalised
+// value, a = d_slope[0] (slope_n == 1, nn.PReLU()'s default) or one per column.
+extern "C" int rbx_batchnorm_prelu_fwd(const float* d_x, int64_t rows, int32_t cols, const float* d_gamma,
+                                       const float* d_beta, const float* d_slope, int32_t slope_n, float eps,
+                                       int32_t training, float momentum, float* d_running_mean, float* d_running_var,
+                                       float* d_mean, float* d_rstd, float* d_y, void* d_workspace, size_t workspace_bytes,
+                                       void* stream) {
+  if (d_slope == nullptr || (slope_n != 1 && slope_n != cols))
+    return rbx::fail(RBX_ERR_INVALID, "batchnorm_prelu: slope must hold 1 or cols values");
+  return rbx::bn_fwd_impl(d_x, rows, cols, d_gamma, d_beta, eps, training, momentum, d_running_mean, d_running_var, 0,
+                          d_mean, d_rstd, d_y, d_workspace, workspace_bytes, stream, d_slope, slope_n);
 }
 
 namespace rbx {
 static int bn_bwd_reduce(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
                          const float* d_mean, const float* d_rstd, float* d_dgamma, float* d_dbeta, void* d_workspace,
-                         size_t workspace_bytes, hipStream_t s) {
+                         size_t workspace_bytes, hipStream_t s, const BnPrelu pr = {nullptr, 0, nullptr, nullptr},
+                         float* d_dslope = nullptr) {
   if (d_workspace == nullptr || workspace_bytes < rbx_batchnorm_workspace_size(rows, cols))
     return fail(RBX_ERR_WORKSPACE, "batchnorm_bwd: workspace too small");
   float* partial = static_cast<float*>(d_workspace);
   const int nb = bn_blocks(rows);
+  float* partial3 = pr.slope != nullptr ? partial + static_cast<size_t>(nb) * cols * 2 : nullptr;   // (the workspace holds 3 per entry)
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, d_dy, d_y_relu,
-                     static_cast<long long>(rows), cols, d_mean, d_rstd, partial);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, nb, cols, d_dbeta, d_dgamma);
+                     static_cast<long long>(rows), cols, d_mean, d_rstd, partial, pr, partial3);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, nb, cols, d_dbeta, d_dgamma,
+                     static_cast<const float*>(partial3), d_dslope);
   return check_launch("batchnorm backward reductions");
 }
 
 static int bn_bwd_dx(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
                      const float* d_gamma, const float* d_mean, const float* d_rstd, const float* d_dgamma,
-                     const float* d_dbeta, int32_t training, int64_t total_rows, float* d_dx, hipStream_t s) {
+                     const float* d_dbeta, int32_t training, int64_t total_rows, float* d_dx, hipStream_t s,
+                     const BnPrelu pr = {nullptr, 0, nullptr, nullptr}) {
   const bool vec = bn_vec(cols, d_x, d_dy, d_dx);
   const long long total = static_cast<long long>(rows) * cols / (vec ? 4 : 1);
   const unsigned blocks = bn_grid(total, cols, vec ? 4 : 1);
   const float inv_m = 1.0f / static_cast<float>(total_rows);
   if (vec)
     hipLaunchKernelGGL(bn_bwd_dx_kernel<true>, dim3(blocks), dim3(256), 0, s, d_x, d_dy, d_y_relu,
-                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx, inv_m);
+                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx, inv_m, pr);
   else
     hipLaunchKernelGGL(bn_bwd_dx_kernel<false>, dim3(blocks), dim3(256), 0, s, d_x, d_dy, d_y_relu,
-                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx, inv_m);
+                       static_cast<long long>(rows), cols, d_mean, d_rstd, d_gamma, d_dbeta, d_dgamma, training, d_dx, inv_m, pr);
   return check_launch("batchnorm backward dx");
 }
 }  // namespace rbx
@@ -527,6 +605,26 @@ extern "C" int rbx_batchnorm_bwd(const float* d_x, const float* d_dy, const floa
   int rc = bn_bwd_reduce(d_x, d_dy, d_y_relu, rows, cols, d_mean, d_rstd, d_dgamma, d_dbeta, d_workspace, workspace_bytes, s);
   if (rc != RBX_OK || d_dx == nullptr) return rc;
   return bn_bwd_dx(d_x, d_dy, d_y_relu, rows, cols, d_gamma, d_mean, d_rstd, d_dgamma, d_dbeta, training, rows, d_dx, s);
+}
+
+// backward of rbx_batchnorm_prelu_fwd: d_dslope_cols[cols] = per-column sums of dy z over z <= 0 (the gradient of a
+// per-column slope; summed over the columns by the caller for nn.PReLU()'s single parameter)
+extern "C" int rbx_batchnorm_prelu_bwd(const float* d_x, const float* d_dy, int64_t rows, int32_t cols, const float* d_gamma,
+                                       const float* d_beta, const float* d_slope, int32_t slope_n, const float* d_mean,
+                                       const float* d_rstd, int32_t training, float* d_dx, float* d_dgamma, float* d_dbeta,
+                                       float* d_dslope_cols, void* d_workspace, size_t workspace_bytes, void* stream) {
+  using namespace rbx;
+  if (rows < 0 || cols <= 0) return fail(RBX_ERR_INVALID, "batchnorm_prelu_bwd: bad shape");
+  if (rows == 0) return RBX_OK;
+  if (!d_x || !d_dy || !d_mean || !d_rstd || !d_dgamma || !d_dbeta || !d_slope || !d_dslope_cols)
+    return fail(RBX_ERR_INVALID, "batchnorm_prelu_bwd: NULL tensor");
+  if (slope_n != 1 && slope_n != cols) return fail(RBX_ERR_INVALID, "batchnorm_prelu: slope must hold 1 or cols values");
+  hipStream_t s = as_stream(stream);
+  const BnPrelu pr = {d_slope, slope_n, d_gamma, d_beta};
+  int rc = bn_bwd_reduce(d_x, d_dy, nullptr, rows, cols, d_mean, d_rstd, d_dgamma, d_dbeta, d_workspace, workspace_bytes, s, pr,
+                         d_dslope_cols);
+  if (rc != RBX_OK || d_dx == nullptr) return rc;
+  return bn_bwd_dx(d_x, d_dy, nullptr, rows, cols, d_gamma, d_mean, d_rstd, d_dgamma, d_dbeta, training, rows, d_dx, s, pr);
 }
 
 // ---- the pieces of a SYNCHRONISED BatchNorm (torch.nn.SyncBatchNorm; RecBole's DDP path converts every BatchNorm of the
@@ -562,10 +660,10 @@ extern "C" int rbx_batchnorm_apply(const float* d_x, int64_t rows, int32_t cols,
   hipStream_t s = as_stream(stream);
   if (vec)
     hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, s, d_x, static_cast<long long>(rows), cols, d_mean,
-                       d_rstd, d_gamma, d_beta, relu, d_y);
+                       d_rstd, d_gamma, d_beta, relu, d_y, static_cast<const float*>(nullptr), 0);
   else
     hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, s, d_x, static_cast<long long>(rows), cols, d_mean,
-                       d_rstd, d_gamma, d_beta, relu, d_y);
+                       d_rstd, d_gamma, d_beta, relu, d_y, static_cast<const float*>(nullptr), 0);
   return check_launch("batchnorm apply kernel");
 }
 
@@ -877,7 +975,8 @@ extern "C" int rbx_layernorm_bwd(const float* d_x, const float* d_dy, int64_t ro
                                   const_cast<float*>(d_rstd), d_dx, s, fused, &nb);
     if (rc != RBX_OK) return rc;
     if (want_p) {
-      hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, fused, nb, dim, d_dbeta, d_dgamma);
+      hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, fused, nb, dim, d_dbeta, d_dgamma,
+                         static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
       return check_launch("layernorm parameter-gradient kernel");
     }
     return rc;
@@ -887,7 +986,8 @@ extern "C" int rbx_layernorm_bwd(const float* d_x, const float* d_dy, int64_t ro
     const int nb = ln_blocks(rows);
     hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3((dim + 63) / 64, nb), dim3(256), 0, s, d_x, d_dy, static_cast<long long>(rows),
                        dim, d_mean, d_rstd, kLnRows, partial);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, partial, nb, dim, d_dbeta, d_dgamma);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((dim + 63) / 64), dim3(256), 0, s, partial, nb, dim, d_dbeta, d_dgamma,
+                       static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
     rc = check_launch("layernorm parameter-gradient kernels");
   }
   return rc;

@@ -2,8 +2,9 @@
 ``nn.Linear`` so harness type tests / checkpoints keep working); this walker replaces
 their compute with the fp32-MFMA GEMM of ``rbx_linear_fwd/bwd`` and fuses a following
 ReLU into the GEMM epilogue; nn.BatchNorm1d on 2-D activations runs through
-``rbx_batchnorm_fwd/bwd`` (a following ReLU fused in).  Dropout / other activations
-are elementwise ATen kernels and run as the modules they are.
+``rbx_batchnorm_fwd/bwd`` (a following ReLU or PReLU fused in; nn.SyncBatchNorm modules
+normalise over all ranks).  Dropout with p = 0 launches nothing; other activations are
+elementwise ATen kernels and run as the modules they are.
 """
 from torch import nn
 
@@ -81,9 +82,13 @@ def run_sequential(seq, x):
             x = ops.linear(x, m.weight, m.bias, "relu" if fuse else None)
             i += 2 if fuse else 1
         elif type(m) in (nn.BatchNorm1d, nn.SyncBatchNorm) and x.dim() == 2:
-            fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-            x = ops.batch_norm(x, m, relu=fuse)
-            i += 2 if fuse else 1
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            fuse = type(nxt) is nn.ReLU
+            # nn.PReLU (one slope, or one per column) rides in the BatchNorm's passes too: rechub's towers with
+            # activation="prelu" (DSSM, BASELINE cfg 1) are Linear -> BatchNorm1d -> PReLU -> Dropout
+            prelu = nxt if (type(nxt) is nn.PReLU and nxt.weight.numel() in (1, x.shape[1])) else None
+            x = ops.batch_norm(x, m, relu=fuse, prelu=prelu)
+            i += 2 if (fuse or prelu is not None) else 1
         else:
             x = m(x)
             i += 1

@@ -1661,6 +1661,51 @@ class _BatchNorm(torch.autograd.Function):
                 dbeta if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None, None, None)
 
 
+class _BatchNormPReLU(torch.autograd.Function):
+    """nn.BatchNorm1d followed by nn.PReLU on [rows, cols] in the BatchNorm's own passes (rbx_batchnorm_prelu_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, stats, training, momentum, eps):
+        running_mean, running_var = stats.running_mean, stats.running_var
+        _require_cuda(x, "x")
+        x = x.contiguous().float()
+        rows, cols = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(cols, dtype=torch.float32, device=dev)
+        rstd = torch.empty(cols, dtype=torch.float32, device=dev)
+        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        slope_c = slope.detach().contiguous().float()
+        check(lib.rbx_batchnorm_prelu_fwd(_ptr(x), rows, cols, _ptr(weight), _ptr(bias), _ptr(slope_c), slope_c.numel(), eps,
+                                          1 if training else 0, momentum, _ptr(running_mean), _ptr(running_var), _ptr(mean),
+                                          _ptr(rstd), _ptr(y), _ptr(ws), ws_bytes, _stream()))
+        ctx.save_for_backward(x, weight, bias, slope_c, mean, rstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, slope, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        rows, cols = x.shape
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dgamma = torch.empty(cols, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(cols, dtype=torch.float32, device=dev)
+        dslope = torch.empty(cols, dtype=torch.float32, device=dev)
+        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        check(lib.rbx_batchnorm_prelu_bwd(_ptr(x), _ptr(dy), rows, cols, _ptr(weight), _ptr(bias), _ptr(slope), slope.numel(),
+                                          _ptr(mean), _ptr(rstd), 1 if ctx.training else 0, _ptr(dx), _ptr(dgamma),
+                                          _ptr(dbeta), _ptr(dslope), _ptr(ws), ws_bytes, _stream()))
+        ds = None
+        if ctx.needs_input_grad[3]:
+            ds = dslope if slope.numel() == cols else dslope.sum().reshape(1)
+        return (dx, dgamma if (weight is not None and ctx.needs_input_grad[1]) else None,
+                dbeta if (bias is not None and ctx.needs_input_grad[2]) else None, ds, None, None, None, None)
+
+
 class _SyncBatchNorm(torch.autograd.Function):
     """BatchNorm over the batches of ALL ranks of ``group`` (torch.nn.SyncBatchNorm's arithmetic: RecBole's DDP path,
     third_party/recbole/trainer/trainer.py:60-64): every rank's (count, mean, M2) per column are gathered and merged with
@@ -1719,7 +1764,7 @@ class _SyncBatchNorm(torch.autograd.Function):
                 sums[1] if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None, None, None)
 
 
-def batch_norm(x, module, relu=False):
+def batch_norm(x, module, relu=False, prelu=None):
     """``module(x)`` for an nn.BatchNorm1d on [rows, cols] input (optionally followed by ReLU), with torch's
     bookkeeping: running statistics, num_batches_tracked, momentum=None = cumulative average, eval mode.
     An ``nn.SyncBatchNorm`` (``torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)``) in training mode inside an
@@ -1734,8 +1779,13 @@ def batch_norm(x, module, relu=False):
         from . import comm
         group = getattr(module, "process_group", None)
         if comm.world(group)[1] > 1:
-            return _SyncBatchNorm.apply(x, module.weight, module.bias, _BnStats(module), float(momentum), float(module.eps),
-                                        relu, group)
+            y = _SyncBatchNorm.apply(x, module.weight, module.bias, _BnStats(module), float(momentum), float(module.eps),
+                                     relu, group)
+            return prelu(y) if prelu is not None else y
+    if prelu is not None:
+        # nn.PReLU behind the normalisation: one parameter, or one per column (num_parameters == cols)
+        return _BatchNormPReLU.apply(x, module.weight, module.bias, prelu.weight, _BnStats(module), training, float(momentum),
+                                     float(module.eps))
     return _BatchNorm.apply(x, module.weight, module.bias, _BnStats(module), training, float(momentum), float(module.eps),
                             relu)
 

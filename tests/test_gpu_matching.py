@@ -1068,3 +1068,69 @@ def test_deepfm_input_stage_as_one_node_equals_the_three_readers():
     assert_close(pa, fx["out"]["y"], TOL)
     for n in ga:
         assert_close(ga[n], fx["g"][n], TOL, "grad " + n)
+
+
+@pytest.mark.parametrize("rows,cols,per_column", [(257, 40, False), (257, 40, True), (4099, 401, False)])
+def test_batch_norm_with_fused_prelu_vs_torch(rows, cols, per_column):
+    """rbx_batchnorm_prelu_fwd/bwd == nn.BatchNorm1d -> nn.PReLU of torch CPU: outputs, dx, dgamma / dbeta, the slope's
+    gradient (one parameter, or one per column), running statistics; slopes of BOTH signs (with a <= 0 the sign of y no
+    longer tells the sign of the pre-activation: the kernels rebuild z from x); training and eval mode; and through a
+    rechub MLP(activation="prelu") tower (third_party/rechub/basic/layers.py:255-263), where the walker fuses the pair."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(rows + cols + int(per_column))
+    ref_bn, ref_act = torch.nn.BatchNorm1d(cols), torch.nn.PReLU(cols if per_column else 1)
+    with torch.no_grad():
+        ref_bn.weight.copy_(torch.rand(cols, generator=g) + 0.5)
+        ref_bn.bias.copy_(torch.randn(cols, generator=g) * 0.3)
+        ref_act.weight.copy_(torch.randn(ref_act.weight.shape, generator=g) * 0.5 if per_column else torch.tensor([-0.3]))
+    dut_bn, dut_act = torch.nn.BatchNorm1d(cols), torch.nn.PReLU(cols if per_column else 1)
+    dut_bn.load_state_dict(ref_bn.state_dict())
+    dut_act.load_state_dict(ref_act.state_dict())
+    dut_bn.cuda()
+    dut_act.cuda()
+    for step in range(3):
+        if step == 2:
+            ref_bn.eval()
+            dut_bn.eval()
+        x = torch.randn(rows, cols, generator=g) * 2.0 + 1.0
+        r = torch.randn(rows, cols, generator=g)
+        xr = x.clone().requires_grad_(True)
+        zr = ref_bn(xr)
+        yr = ref_act(zr)
+        (yr * r).sum().backward()
+        xc = x.cuda().requires_grad_(True)
+        yc = ops.batch_norm(xc, dut_bn, prelu=dut_act)
+        (yc * r.cuda()).sum().backward()
+        assert_close(yc, yr.detach(), 1e-5, "y")
+        keep = ~(zr.detach().abs() < 1e-5).any(dim=0)          # columns without a pre-activation within an ulp of zero
+        scale = max(1.0, rows ** 0.5 / 4)
+        assert_close(xc.grad.cpu()[:, keep], xr.grad[:, keep], 2e-4, "dx")
+        assert_close(dut_bn.weight.grad.cpu()[keep], ref_bn.weight.grad[keep], 1e-4 * scale, "dgamma")
+        assert_close(dut_bn.bias.grad.cpu()[keep], ref_bn.bias.grad[keep], 1e-4 * scale, "dbeta")
+        if per_column:
+            assert_close(dut_act.weight.grad.cpu()[keep], ref_act.weight.grad[keep], 1e-4 * scale, "dslope")
+        elif bool(keep.all()):
+            assert_close(dut_act.weight.grad, ref_act.weight.grad, 1e-4 * scale * cols ** 0.5, "dslope")
+        assert_close(dut_bn.running_mean, ref_bn.running_mean, 1e-6, "running_mean")
+        assert_close(dut_bn.running_var, ref_bn.running_var, 1e-5, "running_var")
+        for m in (ref_bn, ref_act, dut_bn, dut_act):
+            m.zero_grad()
+    if rows > 1000:
+        return
+    # the tower: Linear -> BatchNorm1d -> PReLU -> Dropout(0) twice + Linear(*, 1)
+    from recbox_amd.rechub.basic.layers import MLP
+    torch.manual_seed(0)
+    tower = MLP(cols, output_layer=True, dims=[24, 16], activation="prelu").cuda().train()
+    twin = torch.nn.Sequential(*[type(m)(*(([m.in_features, m.out_features]) if isinstance(m, torch.nn.Linear) else
+                                          ([m.num_features] if isinstance(m, torch.nn.BatchNorm1d) else
+                                           ([m.p] if isinstance(m, torch.nn.Dropout) else []))))
+                                 for m in tower.mlp]).train()
+    twin.load_state_dict(dict((k, v.cpu()) for k, v in tower.mlp.state_dict().items()))
+    x = torch.randn(rows, cols, generator=g)
+    out = tower(x.cuda())
+    want = twin(x)
+    assert_close(out, want.detach(), 1e-4, "MLP(prelu) output")
+    out.sum().backward()
+    want.sum().backward()
+    for (n, p), (_, q) in zip(tower.mlp.named_parameters(), twin.named_parameters()):
+        assert_close(p.grad, q.grad, 2e-4 * max(1.0, float(q.grad.abs().max())), "MLP(prelu) grad " + n)
