@@ -32,8 +32,8 @@ from .models.ranking import DeepFM
 class ShardedEmbeddingLayer(EmbeddingLayer):
     """``EmbeddingLayer`` whose large tables are row-sharded over the process group.
 
-    ``embed_dict`` holds the replicated tables (real ``nn.Embedding``, same names as on one GPU); ``store`` holds this
-    rank's rows of the sharded ones.  A layer call is one local gather launch for the replicated features plus one
+    ``embed_dict`` holds the replicated tables (real ``nn.Embedding``, same names as on one GPU); ``stores[str(dim)]``
+    (``store`` = the first) hold this rank's rows of the sharded ones, one store per embedding dimension.  A layer call is one local gather launch for the replicated features plus one
     exchange for the sharded ones, both writing into the same ``[B, width]`` block the single-GPU layer produces."""
 
     def __init__(self, features, shard_min_vocab=100000, capacity_factor=1.25, process_group=None, local_ops=None):
@@ -55,14 +55,23 @@ class ShardedEmbeddingLayer(EmbeddingLayer):
                 self.sharded_tables.append(fea.name)                 # (never materialised as a full table)
             else:
                 self.embed_dict[fea.name] = fea.get_embedding_layer()
+        # one ShardedStore per embedding dimension (a store keeps the rows of all its tables back to back in one
+        # [rows, D] weight).  ``store`` is the first of them -- the only one in the usual case of one dimension, and the
+        # name its weight has in checkpoints ("embedding.store.weight"); further dimensions register as ``store_<dim>``.
         self.store = None
-        if self.sharded_tables:
-            dims = set(by_name[n].embed_dim for n in self.sharded_tables)
-            if len(dims) != 1:
-                raise NotImplementedError("ShardedEmbeddingLayer: the sharded tables must share one embed_dim, got %s"
-                                          % sorted(dims))
-            self.store = ShardedStore([by_name[n].vocab_size for n in self.sharded_tables], dims.pop(),
-                                      capacity_factor=capacity_factor, process_group=process_group, local_ops=local_ops)
+        self.stores = {}                              # str(dim) -> store (a plain dict: the modules are registered above)
+        self._store_of, self._index_in = {}, {}
+        for k, dim in enumerate(sorted(set(by_name[n].embed_dim for n in self.sharded_tables))):
+            names = [n for n in self.sharded_tables if by_name[n].embed_dim == dim]
+            st = ShardedStore([by_name[n].vocab_size for n in names], dim, capacity_factor=capacity_factor,
+                              process_group=process_group, local_ops=local_ops if k == 0 else None)
+            if k == 0:
+                self.store = st
+            else:
+                setattr(self, "store_%d" % dim, st)
+            self.stores[str(dim)] = st
+            for t, n in enumerate(names):
+                self._store_of[n], self._index_in[n] = str(dim), t
 
     def table_of(self, fea):
         return fea.name if fea.shared_with is None else fea.shared_with
@@ -73,17 +82,18 @@ class ShardedEmbeddingLayer(EmbeddingLayer):
         cached = self._plans.get(key)
         if cached is None:
             cached = self._plans[key] = self._build(x, features, squeeze_dim)
-        local, call, order, n_sparse, width, seq_len, dim = cached
+        local, calls, n_sparse, width, seq_len, dim = cached
         B = x[features[0].name].shape[0]
         block = None
         if local is not None:
             block = local.run([x[lk.name] for lk in local.lookups], pad_rows=squeeze_dim)
-        if call is not None:
+        # one exchange per (store, pooled sequence): the single-row lookups of a store ride with its first call
+        for key, call, order in calls:
             rows = []
             for name, col in order["rows"]:
                 rows.append(x[name] if col is None else x[name][:, col])
             pool = x[order["pool"]] if order["pool"] is not None else None
-            block = self.store.lookup(call, width, rows, pool, block)
+            block = self.stores[key].lookup(call, width, rows, pool, block)
         if squeeze_dim:
             return block
         if seq_len is not None:
@@ -109,7 +119,7 @@ class ShardedEmbeddingLayer(EmbeddingLayer):
             raise ValueError("If keep the original shape:[batch_size, num_features, embed_dim], expected %s in feature "
                              "list, got %s" % ("SparseFeatures", features))
         lookups, offsets, off = [], [], 0
-        rows, row_src, pool, pool_src = [], [], None, None
+        per_store = {}                 # store key -> {"rows": [(t, off)], "row_src": [...], "pools": [(pool tuple, feature name)]}
         dims, seq_lens, concat = set(), set(), []
         for fea in sparse:
             tname = self.table_of(fea)
@@ -124,20 +134,18 @@ class ShardedEmbeddingLayer(EmbeddingLayer):
             if is_concat:
                 seq_lens.add(L)
             if tname in self.sharded_tables:
-                t = self.sharded_tables.index(tname)
+                key, t = self._store_of[tname], self._index_in[tname]
+                ent = per_store.setdefault(key, {"rows": [], "row_src": [], "pools": []})
                 if not is_seq:
-                    rows.append((t, off))
-                    row_src.append((fea.name, None))
+                    ent["rows"].append((t, off))
+                    ent["row_src"].append((fea.name, None))
                 elif is_concat:
                     for c in range(L):                       # every column is a single-row lookup
-                        rows.append((t, off + c * dim))
-                        row_src.append((fea.name, c))
+                        ent["rows"].append((t, off + c * dim))
+                        ent["row_src"].append((fea.name, c))
                 else:
-                    if pool is not None:
-                        raise NotImplementedError("one pooled sequence over sharded tables per layer call")
                     mask_id = fea.padding_idx if fea.padding_idx is not None else -1      # InputMask: id != -1
-                    pool = (t, off, L, fea.pooling, mask_id, 1e-16 if fea.pooling == "mean" else 0.0)
-                    pool_src = fea.name
+                    ent["pools"].append(((t, off, L, fea.pooling, mask_id, 1e-16 if fea.pooling == "mean" else 0.0), fea.name))
             else:
                 table = self.embed_dict[tname]
                 if not is_seq:
@@ -166,8 +174,20 @@ class ShardedEmbeddingLayer(EmbeddingLayer):
                                        "with pooled/sparse features)")
                 seq_len = seq_lens.pop()
         local = host.Plan(lookups, offsets=offsets, width=width) if lookups else None
-        call = ShardCall(rows, pool) if (rows or pool is not None) else None
-        return local, call, {"rows": row_src, "pool": pool_src}, len(sparse), width, seq_len, dim
+        # The wire format of one exchange carries any number of single-row lookups and at most ONE pooled sequence
+        # (include/recbox_hip.h, rbx_shard_geom_t): a layer call with several pooled sequences over sharded tables (the
+        # reference's EmbeddingLayer takes any mix, third_party/rechub/basic/layers.py:66-116) becomes several exchanges
+        # into the same output block -- the first one of a store also carries that store's single-row lookups.
+        calls = []
+        for key in sorted(per_store):
+            ent = per_store[key]
+            pools = ent["pools"] or [(None, None)]
+            for k, (pool, pool_src) in enumerate(pools):
+                rows = ent["rows"] if k == 0 else []
+                src = ent["row_src"] if k == 0 else []
+                if rows or pool is not None:
+                    calls.append((key, ShardCall(rows, pool), {"rows": src, "pool": pool_src}))
+        return local, calls, len(sparse), width, seq_len, dim
 
 
 class DenseGradSync(object):
@@ -239,8 +259,8 @@ class _ShardedModelMixin(object):
         emb = self.embedding
         tables = list(emb.embed_dict.parameters())
         skip = set(id(p) for p in tables)
-        if emb.store is not None:
-            skip.add(id(emb.store.weight))
+        for st in emb.stores.values():
+            skip.add(id(st.weight))
         towers = [p for p in self.parameters() if id(p) not in skip]
         self.grad_sync = DenseGradSync(towers, tables, emb.group)
 
@@ -253,14 +273,14 @@ class _ShardedModelMixin(object):
         self.grad_sync.finish()
 
     def replicated_parameters(self):
-        skip = id(self.embedding.store.weight) if self.embedding.store is not None else None
-        return [p for p in self.parameters() if id(p) != skip]
+        skip = set(id(st.weight) for st in self.embedding.stores.values())
+        return [p for p in self.parameters() if id(p) not in skip]
 
     def raise_if_overflowed(self):
         """Collective (call it from every rank, once per step or every N steps): RuntimeError on every rank when any
         rank's exchange ran out of slots since the last call (recbox_amd.sharded.raise_if_overflowed)."""
-        if self.embedding.store is not None:
-            self.embedding.store.raise_if_overflowed()
+        for st in self.embedding.stores.values():
+            st.raise_if_overflowed()
 
 
 class ShardedYoutubeDNN(_ShardedModelMixin, YoutubeDNN):

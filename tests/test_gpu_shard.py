@@ -228,6 +228,53 @@ def test_sharded_deepfm_world_of_one_equals_deepfm():
         assert_close(mine[n0], b0, 1e-5, n0)
 
 
+def test_sharded_layer_with_several_pooled_sequences_and_two_dims_equals_embedding_layer():
+    """The reference's EmbeddingLayer takes any mix of features (third_party/rechub/basic/layers.py:66-116): a layer call
+    with TWO pooled sequences over sharded tables (mean and sum pooled, sharing the id table) and sharded tables of two
+    embedding dimensions -- one exchange per (store, pooled sequence), all into one output block -- equals the single-GPU
+    layer: the [B, width] block bit for bit on the single rows and to 1e-6 on the pooled ones, every table gradient."""
+    Fe = _rh()
+    from recbox_amd.rechub.basic.layers import EmbeddingLayer
+    from recbox_amd.rechub.sharded import ShardedEmbeddingLayer
+
+    def feats():
+        return [Fe.SparseFeature("a", 1000, 16), Fe.SequenceFeature("h1", 1000, 16, pooling="mean", shared_with="a"),
+                Fe.SequenceFeature("h2", 1000, 16, pooling="sum", shared_with="a"), Fe.SparseFeature("b", 2000, 32),
+                Fe.SparseFeature("s", 10, 16), Fe.DenseFeature("d")]
+
+    B = 133
+    g = torch.Generator().manual_seed(11)
+    fr, fd = feats(), feats()
+    ref = EmbeddingLayer(fr).cuda()
+    dut = ShardedEmbeddingLayer(fd, shard_min_vocab=500).cuda()
+    assert dut.sharded_tables == ["a", "b"] and sorted(dut.stores) == ["16", "32"]
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+        dut.embed_dict["s"].weight.copy_(ref.embed_dict["s"].weight)
+    dut.stores["16"].load_full_tables([ref.embed_dict["a"].weight.detach()])
+    dut.stores["32"].load_full_tables([ref.embed_dict["b"].weight.detach()])
+    lens1, lens2 = torch.randint(0, 6, (B,), generator=g), torch.randint(1, 8, (B,), generator=g)
+    x = {"a": torch.randint(0, 1000, (B,), generator=g), "b": torch.randint(0, 2000, (B,), generator=g),
+         "s": torch.randint(0, 10, (B,), generator=g), "d": torch.rand(B, generator=g),
+         "h1": torch.randint(1, 1000, (B, 5), generator=g) * (torch.arange(5)[None, :] < lens1[:, None]),
+         "h2": torch.randint(1, 1000, (B, 7), generator=g) * (torch.arange(7)[None, :] < lens2[:, None])}
+    x = {k: v.cuda() for k, v in x.items()}
+    for f in fr + fd:                                    # rechub masks pooled sequences with the feature's padding_idx
+        if isinstance(f, Fe.SequenceFeature):
+            f.padding_idx = 0
+    want = ref(x, fr, squeeze_dim=True)
+    got = dut(x, fd, squeeze_dim=True)
+    assert got.shape == want.shape
+    assert_close(got, want, 1e-6, "block")
+    R = torch.randn(want.shape, generator=g).cuda()
+    (want * R).sum().backward()
+    (got * R).sum().backward()
+    assert_close(dut.stores["16"].weight.grad, ref.embed_dict["a"].weight.grad, 1e-5, "table a (single rows + two pooled sequences)")
+    assert_close(dut.stores["32"].weight.grad, ref.embed_dict["b"].weight.grad, 1e-5, "table b")
+    assert_close(dut.embed_dict["s"].weight.grad, ref.embed_dict["s"].weight.grad, 1e-5, "replicated table")
+
+
 def test_persistent_shard_gradient_equals_fresh_over_steps():
     """HipShardOps.persistent(): the shard's dense gradient lives in ONE buffer whose rows are cleared by the previous
     step's sorted keys (rbx_embed_rezero) instead of a fresh zero-filled [rows, D] tensor per step -- three steps over
