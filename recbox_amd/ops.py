@@ -709,7 +709,12 @@ class _GradPool(object):
         # a larger batch than ever before: clear, then regrow.  ``pre`` (work of the new step on the CURRENT stream, written
         # into the workspace in the layout of ITS batch size) may land on the previous step's sorted pairs unless the two
         # layouts are the same: clear first then, too.
-        if dirty and (self.ws_bytes < ws_bytes or (pre is not None and dirty != batch)):
+        # With ``pre`` (the tiered FM step) the re-zero runs HERE, on the current stream in front of the forward kernel, by
+        # default: beside the forward its 0.5 M random row stores slowed that kernel from 43 to 55 us (its rate is what
+        # bench.py reports against the roofline) for a step only 1.3 % shorter (0.2355 vs 0.2386 ms; profiles/r03);
+        # RECBOX_AMD_FM_REZERO_ON=side puts it back beside the forward.
+        if dirty and (self.ws_bytes < ws_bytes or (pre is not None and dirty != batch)
+                      or (pre is not None and os.environ.get("RECBOX_AMD_FM_REZERO_ON", "main") == "main")):
             check(rezero(_stream()))
             dirty = 0
         ws = self.workspace(ws_bytes)
@@ -870,8 +875,16 @@ class _FmFused(torch.autograd.Function):
                     return rc
 
                 if split:
-                    pool.early_sort(ctx, dev, ws_bytes, rezero, rest, pre=compact, batch=B)
-                    ctx.blocksort_pending = True
+                    early_blocks = os.environ.get("RECBOX_AMD_FM_BLOCKSORT_AT", "bwd") == "fwd"
+
+                    def pre(ws, nbytes):
+                        rc = compact(ws, nbytes)
+                        if rc == _lib.RBX_OK and early_blocks:
+                            rc = lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 4, _stream())
+                        return rc
+
+                    pool.early_sort(ctx, dev, ws_bytes, rezero, rest, pre=pre, batch=B)
+                    ctx.blocksort_pending = not early_blocks
                 else:
                     pool.early_sort(ctx, dev, ws_bytes, rezero, rest, first=first)
             # the forward reads the tables only: back to descriptors without gradient pointers
