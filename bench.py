@@ -921,10 +921,10 @@ def main():
             if ams:
                 roof["frac_alone"] = per_sample * B / (ams * 1e-3) / 1e9 / 8000.0
                 roof["kernel_ms_alone"] = ams
-                roof["note"] = ("frac / kernel_ms: the kernel as it runs in the step, BESIDE the id sort and re-zero of the "
-                                "backward on a second stream (recbox_amd.ops.config.sort_before_forward: the step is ~6 % "
-                                "faster that way, each kernel slower); frac_alone / kernel_ms_alone: the same launches with "
-                                "that side work enqueued after the forward")
+                roof["note"] = ("frac / kernel_ms: the kernel as it runs in the step, beside the large tables' id sort on a "
+                                "second stream (recbox_amd.ops.config.sort_before_forward; since round 3 the re-zero of the "
+                                "previous step's rows runs in front of the forward, not beside it); frac_alone / "
+                                "kernel_ms_alone: the same launches with the sort enqueued after the forward")
         out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
                "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",

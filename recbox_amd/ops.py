@@ -911,6 +911,23 @@ class _FmFused(torch.autograd.Function):
                                             _ptr(extra_index), x_rows, _ptr(logit), _ptr(prob), _ptr(ssum),
                                             _ptr(status), _stream())))
         _check_status(status)
+        if getattr(ctx, "blocksort_pending", False) and os.environ.get("RECBOX_AMD_FM_BLOCKSORT_AT", "after_fwd") == "after_fwd":
+            # the per-block sorts of the small tables (ids only) go BEHIND the forward kernel on this stream: they delay
+            # neither the forward nor -- the large tables' sort on the side stream is still under way -- the backward
+            # (in front of the forward: 0.256 vs 0.236 ms per step; inside the backward, in front of the block partials:
+            # those then ran beside the large tables' reduce, 56 us instead of 25)
+            # (the plan of the backward counts the tables that HAVE a gradient: bind the placeholders for this call)
+            if emb_plan is not None:
+                emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
+            if lr_plan is not None:
+                lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
+            check(lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ctx.sort.ws), ctx.sort.ws_bytes, None, 4, _stream()))
+            if emb_plan is not None:
+                emb_plan.bind_params(emb_params)
+            if lr_plan is not None:
+                lr_plan.bind_params(lr_params)
+            ctx.blocksort_pending = False
+            ctx.blocksort_done = True
         if adopt is not None:
             pool, started = adopt
 
@@ -1033,6 +1050,7 @@ class _FmFused(torch.autograd.Function):
                 and emb_plan is not None):
             grads_ready = torch.cuda.current_stream(dev).record_event()      # dL/dlogit, S, the gradient buffers: all here
         numeric_done = None
+        numeric_first = False
         beside = config.numeric_beside_reduce
         if beside == "presorted":
             beside = isinstance(ctx.sort, _Presorted)
@@ -1048,16 +1066,20 @@ class _FmFused(torch.autograd.Function):
             for t in [dlogit, ssum, gb] + [g for g in grads if g is not None]:
                 if t is not None:
                     t.record_stream(side)
-        elif ws_early is not None:
+        elif ws_early is not None and (grads_ready is None or os.environ.get("RECBOX_AMD_FM_NUMERIC", "last") != "last"):
             # numeric weights + bias do not need the sorted ids: run them while the sort may still be in flight
+            # (with the two chains of the tiered backward they go LAST on this stream instead, behind the small tables'
+            #  partials, which then run before the large tables' reduce has started on the other stream)
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws_early),
                                  ctx.sort.ws_bytes, _stream()))
+            numeric_first = True
         if pending_blocksort:
             # the per-block sorts of the small tables (ids only), deferred to here: on this stream, in front of the block
             # partials that read them, they leave the side stream to the large tables' sort
             check(lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ctx.sort.ws), ctx.sort.ws_bytes, None, 4, _stream()))
             ctx.blocksort_pending = False
-        two_chains = grads_ready is not None and (ctx.sort.event_first is not None or pending_blocksort)
+        two_chains = grads_ready is not None and (ctx.sort.event_first is not None or pending_blocksort
+                                                  or getattr(ctx, "blocksort_done", False))
         if two_chains:
             ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes           # (no join: each tier waits for its own part below)
         elif ctx.sort is not None and same:
@@ -1090,6 +1112,9 @@ class _FmFused(torch.autograd.Function):
                 cur.wait_event(ctx.sort.event_first)
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (8 if a_side else 16) | store,
                                  _ptr(ws), ws_bytes, _stream()))
+            if not numeric_first and not beside:
+                check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws), ws_bytes,
+                                     _stream()))
             cur.wait_event(side_done)
         else:
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0,
