@@ -1007,6 +1007,158 @@ __global__ __launch_bounds__(256) void tall_dw_kernel(const float* __restrict__ 
 
 static bool vec_ok(const float* p, long long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0; }
 
+// ---- K = 64, N = 64 over hundreds of thousands of rows: the weights live in REGISTERS ------------------------------------
+// SASRec's projections and FFN convolutions (sasrec.py:81-94,110-124) are [B*L, 64] x [64, 64]: 6.7 GFLOP against 420 MB of
+// activations, a streaming pass.  On the staged tile kernel above they ran at 3.3-3.6 TB/s (four k tiles of 16, a barrier
+// each, W re-staged per 128 rows).  Here a wavefront owns 32-row slabs and never meets the others.  The k index a lane
+// feeds to v_mfma_f32_32x32x2_f32 may be ANY pairing the two operands agree on: lane (m, h) = (lane % 32, lane / 32) holds
+// floats [32 h, 32 h + 32) of row m and MFMA step j takes k = 32 h + j against W(k, n), which sits in 2 x 32 registers per
+// lane for the whole kernel.  A slab is fetched as eight fully coalesced 1 KB requests (four rows each; per-lane 128-byte
+// reads of 64 different lines thrashed the L1: 8x the L2 traffic, slower than the tile kernel), turned into that layout
+// through a wavefront-private 8 KB of LDS (no barrier), and the next slab's requests are in flight under the current
+// slab's 64 MFMAs.  MFMA-bound rate: 64 x 64 cycles per slab and SIMD = 9.6 TB/s of traffic, above what HBM delivers.
+constexpr int kSlabWaves = 4;              // wavefronts per workgroup (independent of each other)
+constexpr int kSlabLd = 64 + 4;            // LDS row pitch of a slab (floats): b128 reads of 32 rows spread over the banks
+__device__ __forceinline__ void slab_issue(const float* A, long long lda, int r0, int M, int lane, f32x4 (&v)[8]) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {            // request p: rows r0 + 4 p .. + 3, lane l takes floats [4 (l % 16), + 4) of row l / 16
+    int r = r0 + 4 * p + (lane >> 4);
+    r = r < M ? r : M - 1;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[p]) : "v"(A + static_cast<long long>(r) * lda + 4 * (lane & 15)));
+  }
+}
+__device__ __forceinline__ void slab_arrived(f32x4 (&v)[8]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+               :
+               : "memory");
+}
+// registers of slab_issue -> the lane's half row, through the wavefront's LDS slab
+__device__ __forceinline__ void slab_turn(float* __restrict__ lds, int lane, const f32x4 (&v)[8], float (&a)[32]) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+    *reinterpret_cast<f32x4*>(lds + (4 * p + (lane >> 4)) * kSlabLd + 4 * (lane & 15)) = v[p];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float* src = lds + (lane & 31) * kSlabLd + 32 * (lane >> 5);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(src + 4 * q);
+    a[4 * q] = u[0]; a[4 * q + 1] = u[1]; a[4 * q + 2] = u[2]; a[4 * q + 3] = u[3];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();         // (the next slab_turn overwrites what these reads fetch)
+}
+template <bool B_KCONTIG, bool HAS_RES, bool HAS_MASK>
+__global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_k64n64_kernel(
+    const float* __restrict__ A, const long long lda, const float* __restrict__ B, const long long ldb, float* __restrict__ C,
+    const long long ldc, const int M, const float* __restrict__ bias, const int act, const Epi epi) {
+  __shared__ float slab[kSlabWaves][32 * kSlabLd];
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int nw = static_cast<int>(gridDim.x) * kSlabWaves;
+  const int slabs = (M + 31) >> 5;
+  int s = static_cast<int>(blockIdx.x) * kSlabWaves + (threadIdx.x >> 6);
+  if (s >= slabs) return;
+  float* lds = slab[threadIdx.x >> 6];
+  f32x4 nx[8];
+  slab_issue(A, lda, s * 32, M, lane, nx);
+  // W(k = 32 h + j, n = 32 t + m), t = 0, 1
+  float w0[32], w1[32];
+  if constexpr (B_KCONTIG) {               // B(k, n) = B[n * ldb + k]: 32 consecutive floats of rows m and 32 + m
+    const float4* p0 = reinterpret_cast<const float4*>(B + static_cast<long long>(m) * ldb + 32 * h);
+    const float4* p1 = reinterpret_cast<const float4*>(B + static_cast<long long>(32 + m) * ldb + 32 * h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 u = p0[q], v = p1[q];
+      w0[4 * q] = u.x; w0[4 * q + 1] = u.y; w0[4 * q + 2] = u.z; w0[4 * q + 3] = u.w;
+      w1[4 * q] = v.x; w1[4 * q + 1] = v.y; w1[4 * q + 2] = v.z; w1[4 * q + 3] = v.w;
+    }
+  } else {                                 // B(k, n) = B[k * ldb + n]
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const float* r = B + static_cast<long long>(32 * h + j) * ldb + m;
+      w0[j] = r[0];
+      w1[j] = r[32];
+    }
+  }
+  const float b0 = bias != nullptr ? bias[m] : 0.f, b1 = bias != nullptr ? bias[32 + m] : 0.f;
+  constexpr bool has_res = HAS_RES, has_mask = HAS_MASK;
+  const bool has_rs = epi.rowscale != nullptr;
+  float a[32];
+  slab_arrived(nx);
+  slab_turn(lds, lane, nx, a);
+  for (;;) {
+    const int r0 = s * 32;
+    int sn = s + nw;
+    const bool more = sn < slabs;
+    sn = more ? sn : s;                    // (the last round re-requests its own slab: no branch around the asm)
+    slab_issue(A, lda, sn * 32, M, lane, nx);
+    // the epilogue's operands are fetched now, under the MFMAs (output element (i, t): row r0 + (i & 3) + 8 (i >> 2) + 4 h,
+    // column 32 t + m)
+    f32x16 res0, res1, msk0, msk1;
+    float rs[16];
+    if constexpr (has_res) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int row = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        row = row < M ? row : M - 1;
+        const float* q = epi.res + static_cast<long long>(row) * epi.ldres + m;
+        res0[i] = q[0];
+        res1[i] = q[32];
+      }
+    }
+    if constexpr (has_mask) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int row = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        row = row < M ? row : M - 1;
+        const float* q = epi.mask + static_cast<long long>(row) * epi.ldmask + m;
+        msk0[i] = q[0];
+        msk1[i] = q[32];
+      }
+    }
+    if (has_rs) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        rs[i] = epi.rowscale[row < M ? row : M - 1];
+      }
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w0[j], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w1[j], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      float v0 = acc0[i] + b0, v1 = acc1[i] + b1;
+      if (act == 1) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+      if constexpr (has_mask) { v0 = msk0[i] > 0.f ? v0 : 0.f; v1 = msk1[i] > 0.f ? v1 : 0.f; }
+      if constexpr (has_res) { v0 += res0[i]; v1 += res1[i]; }
+      if (has_rs) { v0 *= rs[i]; v1 *= rs[i]; }
+      if (row < M) {
+        float* q = C + static_cast<long long>(row) * ldc + m;
+        q[0] = v0;
+        q[32] = v1;
+      }
+    }
+    slab_arrived(nx);
+    if (!more) break;
+    slab_turn(lds, lane, nx, a);
+    s = sn;
+  }
+}
+
+static int stream64_mode() {
+  static const int mode = [] { const char* e = getenv("RBX_GEMM_STREAM64"); return e ? atoi(e) : 1; }();
+  return mode;
+}
+
 // RBX_GEMM_WIDE=1 routes 64 < N <= 448 with N % 128 != 0 to the wide kernel, 2 also N = 128 / 256 / 384.  Off by default:
 // measured at cfg 4 (profiles/r02/gemm_variants.txt) the layer-1 forward takes 0.957 ms wide against 0.930 ms on the
 // 128 x 128 + narrow pair, the whole step 7.07 against 7.02 ms -- parity at best: the k-loop, not the tiling, is the limit.
@@ -1062,6 +1214,21 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
       if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
     }
     splits = best;
+  }
+  // 64 -> 64 over many rows: the streaming kernel with the weights in registers
+  if (AK && K == 64 && N == 64 && splits == 1 && epi.fm_x == nullptr && M >= 2048 && vec_ok(A, lda) &&
+      (!BK_ || vec_ok(B, ldb)) && stream64_mode() > 0) {
+    const int slabs = (M + 31) / 32;
+    int wgs = (slabs + kSlabWaves - 1) / kSlabWaves;
+    if (wgs > 2 * kCUs) wgs = 2 * kCUs;              // two workgroups of four wavefronts per CU: two wavefronts per SIMD
+    const dim3 grid(wgs), block(64 * kSlabWaves);
+#define RBX_K64(R, K_) hipLaunchKernelGGL((gemm_f32_k64n64_kernel<BK_, R, K_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, bias, act, epi)
+    if (epi.res != nullptr && epi.mask != nullptr) RBX_K64(true, true);
+    else if (epi.res != nullptr) RBX_K64(true, false);
+    else if (epi.mask != nullptr) RBX_K64(false, true);
+    else RBX_K64(false, false);
+#undef RBX_K64
+    return check_launch("gemm_f32_k64n64_kernel");
   }
   // one column tile of at most 416 columns and many rows: the wide kernel (no narrow companion, A read once)
   const int wmode = wide_mode();

@@ -107,7 +107,7 @@ def test_mlp_golden():
                                        (9000, 40, 24, "relu"), (8192, 16, 2496, None),
                                        # tall and narrow (SASRec's [B*L, 64] x [64, 64]): the streaming dW / db kernel,
                                        # full and ragged quadrants, a row count that is no multiple of anything
-                                       (20001, 64, 64, None), (8192, 33, 64, "relu"), (12345, 64, 20, None),
+                                       (20001, 64, 64, None), (20011, 64, 64, "relu"), (8192, 33, 64, "relu"), (12345, 64, 20, None),
                                        (9999, 7, 5, None), (10000, 192, 64, None), (8200, 130, 33, "relu"), (8192, 256, 64, None),
                                        # logit heads (n == 1): the streaming GEMV / outer-product / weighted column-sum kernels
                                        (70001, 1, 400, None), (5000, 1, 1664, None), (3001, 1, 37, "relu"), (2, 1, 7, None),
@@ -138,7 +138,8 @@ def test_linear_matches_torch_fp32(M, N, K, act):
     assert_close(bc.grad, br.grad.float(), 1e-4 * max(1.0, M ** 0.5 / 16), "db")
 
 
-@pytest.mark.parametrize("M,N,K", [(4100, 168, 70), (300, 400, 64), (4224, 256, 48), (129, 130, 17), (8192, 64, 64)])
+@pytest.mark.parametrize("M,N,K", [(4100, 168, 70), (300, 400, 64), (4224, 256, 48), (129, 130, 17), (8192, 64, 64),
+                                   (70007, 64, 64)])
 def test_linear_epilogue_operands_on_every_tile_kind(M, N, K):
     """The optional tail of the GEMM epilogue -- y = (act(x W^T + b) + residual) * row_scale[row] (rbx_linear_fwd_fused) and
     dx = ((dy W) o [mask > 0]) + residual (rbx_linear_dx_fused) -- on interior tiles (operands fetched four outputs at a
@@ -161,6 +162,16 @@ def test_linear_epilogue_operands_on_every_tile_kind(M, N, K):
     assert_close(got, want.float(), 2e-5 * max(1.0, N ** 0.5 / 8), "fused dx")
     got = ops._lin_dx(dy.cuda(), w.cuda())
     assert_close(got, (dy.double() @ w.double()).float(), 2e-5 * max(1.0, N ** 0.5 / 8), "plain dx")
+    # each operand alone (the 64 -> 64 streaming kernel is instantiated per operand set)
+    lin = x.double() @ w.double().t() + b.double()
+    got = ops._lin_fwd(x.cuda(), w.cuda(), b.cuda(), act=0, residual=res.cuda())
+    assert_close(got, (lin + res.double()).float(), 2e-5 * max(1.0, K ** 0.5 / 8), "forward + residual")
+    got = ops._lin_fwd(x.cuda(), w.cuda(), b.cuda(), act=1, row_scale=rs.cuda())
+    assert_close(got, (torch.relu(lin) * rs.double()[:, None]).float(), 2e-5 * max(1.0, K ** 0.5 / 8), "forward * row scale")
+    got = ops._lin_dx(dy.cuda(), w.cuda(), mask=mask.cuda())
+    assert_close(got, ((dy.double() @ w.double()) * (mask.double() > 0)).float(), 2e-5 * max(1.0, N ** 0.5 / 8), "masked dx")
+    got = ops._lin_dx(dy.cuda(), w.cuda(), residual=res2.cuda())
+    assert_close(got, ((dy.double() @ w.double()) + res2.double()).float(), 2e-5 * max(1.0, N ** 0.5 / 8), "dx + residual")
 
 
 def test_sdpa_and_losses_golden():
