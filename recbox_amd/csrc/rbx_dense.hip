@@ -1154,6 +1154,116 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_k64n64_kernel(
   }
 }
 
+// dW[64, 64] = g^T x and db = column sums of g over hundreds of thousands of rows, in the slab form of the kernel above:
+// a wavefront fetches 32-row slabs of g and x as fully coalesced 1 KB requests (the next slab's are in flight under the
+// current one's MFMAs), parks them in its own 2 x 8.5 KB of LDS and feeds v_mfma_f32_32x32x2_f32 from there --
+// A[i][kk] = g[r + kk][32 qi + i], B[kk][j] = x[r + kk][32 qj + j], 16 steps x 4 quadrants per slab -- so every byte of g
+// and x is requested from memory exactly once (tall_dw_kernel's four quadrant wavefronts each read a half of both: twice
+// the L1 traffic, dword requests; 3.5 TB/s).  The four wavefronts' sums meet in LDS in a fixed order; one [64, 64] (+ [64])
+// partial per workgroup goes to splitk_reduce_kernel.
+__global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const float* __restrict__ g, const long long ldg,
+                                                                      const float* __restrict__ x, const long long ldx,
+                                                                      const int M, float* __restrict__ dw_part,
+                                                                      float* __restrict__ db_part) {
+  __shared__ float lds[kSlabWaves * 2 * 32 * kSlabLd];
+  __shared__ float cs_lds[kSlabWaves][64];
+  static_assert(kSlabWaves * 2 * 32 * kSlabLd >= kSlabWaves * 64 * 64, "the slabs' LDS also holds the wavefronts' [64, 64] sums");
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
+  const int nw = static_cast<int>(gridDim.x) * kSlabWaves;
+  const int slabs = (M + 31) >> 5;
+  float* sg = lds + wid * 2 * 32 * kSlabLd;
+  float* sx = sg + 32 * kSlabLd;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  // coalesced registers -> LDS (rows beyond M carry zeros in g: their products and column sums vanish)
+  auto park = [&](int r0, const f32x4 (&vg)[8], const f32x4 (&vx)[8]) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int row = 4 * p + (lane >> 4);
+      f32x4 u = vg[p];
+      if (r0 + row >= M) u = f32x4{0.f, 0.f, 0.f, 0.f};
+      cs += u;
+      *reinterpret_cast<f32x4*>(sg + row * kSlabLd + 4 * (lane & 15)) = u;
+      *reinterpret_cast<f32x4*>(sx + row * kSlabLd + 4 * (lane & 15)) = vx[p];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  int s = static_cast<int>(blockIdx.x) * kSlabWaves + wid;
+  if (s < slabs) {
+    f32x4 ng[8], nx[8];
+    slab_issue(g, ldg, s * 32, M, lane, ng);
+    slab_issue(x, ldx, s * 32, M, lane, nx);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ng[0]), "+v"(ng[1]), "+v"(ng[2]), "+v"(ng[3]), "+v"(ng[4]), "+v"(ng[5]),
+                 "+v"(ng[6]), "+v"(ng[7]) : : "memory");
+    slab_arrived(nx);
+    park(s * 32, ng, nx);
+    for (;;) {
+      int sn = s + nw;
+      const bool more = sn < slabs;
+      sn = more ? sn : s;
+      slab_issue(g, ldg, sn * 32, M, lane, ng);
+      slab_issue(x, ldx, sn * 32, M, lane, nx);
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const float* rg = sg + (2 * jj + h) * kSlabLd + m;
+        const float* rx = sx + (2 * jj + h) * kSlabLd + m;
+        const float a0 = rg[0], a1 = rg[32], b0 = rx[0], b1 = rx[32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ng[0]), "+v"(ng[1]), "+v"(ng[2]), "+v"(ng[3]), "+v"(ng[4]), "+v"(ng[5]),
+                   "+v"(ng[6]), "+v"(ng[7]) : : "memory");
+      slab_arrived(nx);
+      if (!more) break;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();       // every lane has read the current slab
+      s = sn;
+      park(s * 32, ng, nx);
+    }
+  }
+  __syncthreads();                            // all slabs consumed: the LDS now takes the four [64, 64] sums
+  float* mine = lds + wid * 64 * 64;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        mine[(32 * a + (i & 3) + 8 * (i >> 2) + 4 * h) * 64 + 32 * b + m] = acc[a][b][i];
+  // column sums: lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same four columns of different rows
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float t = cs[c];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    if (lane < 16) cs_lds[wid][4 * lane + c] = t;
+  }
+  __syncthreads();
+  float* out = dw_part + static_cast<long long>(blockIdx.x) * 64 * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 64 * kSlabWaves) {
+    float t = lds[e];
+#pragma unroll
+    for (int w = 1; w < kSlabWaves; ++w) t += lds[w * 64 * 64 + e];
+    out[e] = t;
+  }
+  if (db_part != nullptr && threadIdx.x < 64) {
+    float t = cs_lds[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kSlabWaves; ++w) t += cs_lds[w][threadIdx.x];
+    db_part[static_cast<long long>(blockIdx.x) * 64 + threadIdx.x] = t;
+  }
+}
+
 static int stream64_mode() {
   static const int mode = [] { const char* e = getenv("RBX_GEMM_STREAM64"); return e ? atoi(e) : 1; }();
   return mode;
@@ -1456,6 +1566,17 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     // dx[m,k] = g[m,n] * W[n,k]: A = g (n contiguous = its K), B(kk=n, col=k) = W[n*k + k] (col contiguous)
     rc = run_gemm<true, false>(g, n, d_w, k, d_dx, M, k, n, nullptr, 0, nullptr, 0, s, dx_stride);
     if (rc != RBX_OK) return rc;
+  }
+  if (d_dw != nullptr && n == 64 && k == 64 && m >= 8192 && vec_ok(g, n) && vec_ok(d_x, x_stride) && stream64_mode() > 0 &&
+      dw_floats >= static_cast<size_t>(2 * kCUs) * 64 * 64) {
+    const int slabs = (M + 31) / 32;
+    int n_wg = (slabs + kSlabWaves - 1) / kSlabWaves;
+    if (n_wg > 2 * kCUs) n_wg = 2 * kCUs;
+    float* part = ws + dw_floats;
+    hipLaunchKernelGGL(tall_dw64_kernel, dim3(n_wg), dim3(64 * kSlabWaves), 0, s, g, static_cast<long long>(n), d_x,
+                       static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr);
+    launch_splitk_reduce(s, 64u, ws, 64LL * 64, n_wg, d_dw, d_db != nullptr ? part : nullptr, 64LL, d_db);
+    return check_launch("tall dW / db kernels (slab form)");
   }
   if (d_dw != nullptr && n <= 256 && k <= 64 && m >= 8192) {
     // tall and narrow: one streaming pass over g and x leaves dW and db partials per workgroup (tall_dw_kernel)

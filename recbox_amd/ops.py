@@ -74,6 +74,10 @@ class config(object):
     # keep, after every embedding backward, a record of what names the rows it touched (the sorted ids in its workspace, the
     # descriptors, the gradient tensors): what recbox_amd.optim's sparse-row optimisers step over.  Switched on by them.
     track_touched_rows = False
+    # a table read by two lookups of one step (SASRec's item table: embedding layer + gather_dot): the second backward node
+    # adds its rows into the dense gradient the first one returned instead of autograd adding two dense tensors
+    # (see _publish_grads below)
+    share_table_grads = os.environ.get("RECBOX_AMD_SHARE_TABLE_GRADS", "1") != "0"
     # Where the ids-only pieces of the tiered FM backward run.  "split" (default): the id compaction on the CURRENT stream in
     # front of the forward kernel (10 us; the step's first kernel is then on the stream the previous step ended on), the
     # per-block sorts of the small tables on the current stream inside the backward (in front of the block partials that
@@ -458,6 +462,8 @@ class _EmbedLookup(torch.autograd.Function):
         ctx.plan, ctx.inputs, ctx.row_scale, ctx.B = plan, keep, row_scale, B
         ctx.params = params
         ctx.sort = None
+        if train:
+            _note_readers(ctx, params)
         if B > 0 and train:
             # same descriptor set as the backward (placeholder grad pointers), sorted on the side stream
             plan.bind_params(params, [p if p.requires_grad else None for p in params])
@@ -501,9 +507,12 @@ class _EmbedLookup(torch.autograd.Function):
         want = [ctx.needs_input_grad[j] for j in need]
         want_now = [p.requires_grad for p in params]
         pool, grads = None, None
-        if getattr(ctx, "pool", None) is not None:
+        adopted = _adopt_grads(ctx, params, want) if B > 0 else None
+        if adopted is not None:
+            grads = adopted
+        elif getattr(ctx, "pool", None) is not None:
             pool, grads = ctx.pool.backward_grads(ctx, params, want, want_now == list(want) and B > 0)
-        if pool is None:
+        if grads is None:
             grads = _flat_zero_grads(params, want, dout.device)
         if B == 0:
             return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
@@ -518,12 +527,15 @@ class _EmbedLookup(torch.autograd.Function):
             check(lib.rbx_embed_sort(plan.arr, plan.n, B, _ptr(ws), ws_bytes, None, _stream()))
         # grads are views of a freshly zeroed buffer: accumulate=0 lets the kernel store instead of RMW
         check(lib.rbx_embed_bwd(plan.arr, plan.n, B, _ptr(dout), dout.stride(0) if B > 1 else plan.width,
-                                _ptr(ctx.row_scale), 0, _ptr(ws), ws_bytes, _stream()))
+                                _ptr(ctx.row_scale), 1 if adopted is not None else 0, _ptr(ws), ws_bytes, _stream()))
         if pool is not None:
             pool.done(B)
         _forget_sort(ws)
+        if adopted is not None:                        # the rows went into the gradient another node of this pass returned
+            return (None, None, None, None) + (None,) * len(ctx.inputs) + (None,) * len(params)
         if config.track_touched_rows:
             _note_touched("embed", (plan,), ctx.inputs, (list(params),), (list(grads),), ws, ws_bytes, B)
+        _publish_grads(ctx, params, grads)
         return (None, None, None, None) + (None,) * len(ctx.inputs) + tuple(grads)
 
 
@@ -643,6 +655,79 @@ def _carve(flat, params, sizes, offs):
         views = iter(torch._utils._unflatten_dense_tensors(flat[:end] if end != flat.numel() else flat, [p for p, _, _ in live]))
         return [next(views) if n else None for n in sizes]
     return [flat[o:o + n].view_as(p) if n else None for p, n, o in zip(params, sizes, offs)]
+
+
+# One table read by TWO lookups of a step (SASRec: the item sequence through the embedding layer and the positive / negative
+# candidates through gather_dot, sasrec.py:96-105) gets two dense [V, D] gradients that autograd then adds: two 256 MB zero
+# fills and a 768 MB aten::add per step at 1 M x 64.  With ``config.share_table_grads`` the backward node that runs FIRST
+# publishes the dense gradient it returns; the second one -- same backward pass (graph task), every table it wants a gradient
+# for published -- adds its rows INTO that tensor (rbx_*_bwd(accumulate=1): read-modify-write of the touched rows only, on
+# the same stream, fixed order) and returns None: AccumulateGrad then receives ONE tensor that already holds both sums.
+# The sum is formed in a different order than (a + b) of two separately rounded tensors: equal within rounding, and
+# bit-identical from run to run.
+_pending_grads = {}                 # id(parameter) -> (graph task id, alias of the published gradient)
+_table_readers = {}                 # id(parameter) -> WeakSet of the autograd nodes (ctx) of lookups that read it and have not run backward
+
+
+def _note_readers(ctx, params):
+    """Forward of a lookup in training mode: remember which nodes read which table.  A gradient is only published for a
+    table that still has ANOTHER reader waiting (a published tensor nobody adopts would keep a dense gradient alive)."""
+    if not config.share_table_grads:
+        return
+    import weakref
+    for p in params:
+        if p.requires_grad:
+            try:
+                _table_readers.setdefault(id(p), weakref.WeakSet()).add(ctx)
+            except TypeError:                                # a node type without weak references: no sharing for it
+                return
+
+
+def _other_readers(ctx, p):
+    readers = _table_readers.get(id(p))
+    if readers is None:
+        return 0
+    readers.discard(ctx)
+    return len(readers)
+
+
+def _graph_task():
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
+
+
+def _publish_grads(ctx, params, grads):
+    task = _graph_task()
+    if task < 0 or not config.share_table_grads:
+        return
+    for key in [k for k, ent in _pending_grads.items() if ent[0] != task]:
+        del _pending_grads[key]                              # left over from an earlier backward pass
+    for p, g in zip(params, grads):
+        if g is not None and _other_readers(ctx, p) > 0:
+            _pending_grads[id(p)] = (task, g.detach())       # (an alias: AccumulateGrad may still take ``g`` itself over)
+
+
+def _adopt_grads(ctx, params, want):
+    """The published gradients of ``params`` when EVERY wanted one has been published in this backward pass, else None."""
+    task = _graph_task()
+    if task < 0 or not config.share_table_grads or not any(want):
+        return None
+    if not _pending_grads:
+        return None
+    found = []
+    for p, w in zip(params, want):
+        if not w:
+            found.append(None)
+            continue
+        ent = _pending_grads.get(id(p))
+        if ent is None or ent[0] != task or ent[1].shape != p.shape:
+            return None
+        found.append(ent[1])
+    for p, w in zip(params, want):
+        if w:
+            del _pending_grads[id(p)]                        # one adopter per published gradient
+            _other_readers(ctx, p)
+    return found
 
 
 class _GradPool(object):
@@ -1482,6 +1567,8 @@ class _GatherDot(torch.autograd.Function):
         _check_status(status)
         ctx.plan, ctx.inputs, ctx.params, ctx.R, ctx.scale, ctx.x = plan, keep, params, R, scale, x
         ctx.sort = None
+        if train:
+            _note_readers(ctx, params)
         if R > 0 and train and any(p.requires_grad for p in params):
             plan.bind_params(params, [p if p.requires_grad else None for p in params])
             ws_bytes = lib.rbx_gatherdot_bwd_workspace_size(plan.arr, plan.n, R)
@@ -1497,7 +1584,8 @@ class _GatherDot(torch.autograd.Function):
         n_sets = len(ctx.inputs)
         want_x = ctx.needs_input_grad[4]
         want = [ctx.needs_input_grad[5 + n_sets + i] for i in range(len(params))]
-        grads = _flat_zero_grads(params, want, dout.device)
+        adopted = _adopt_grads(ctx, params, want) if R > 0 else None
+        grads = adopted if adopted is not None else _flat_zero_grads(params, want, dout.device)
         dx = torch.empty_like(x) if want_x else None
         head = (None, None, None, None, dx) + (None,) * n_sets
         if R == 0:
@@ -1514,7 +1602,11 @@ class _GatherDot(torch.autograd.Function):
                 ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dout.device)
                 check(lib.rbx_gatherdot_sort(plan.arr, plan.n, R, _ptr(ws), ws_bytes, None, _stream()))
         check(lib.rbx_gatherdot_bwd(plan.arr, plan.n, R, _ptr(x), x.stride(0), _ptr(dout), ctx.scale, _ptr(dx),
-                                    x.stride(0) if dx is None else dx.stride(0), 0, _ptr(ws), ws_bytes, _stream()))
+                                    x.stride(0) if dx is None else dx.stride(0), 1 if adopted is not None else 0,
+                                    _ptr(ws), ws_bytes, _stream()))
+        if adopted is not None:
+            return head + (None,) * len(params)
+        _publish_grads(ctx, params, grads)
         return head + tuple(grads)
 
 

@@ -757,6 +757,56 @@ def test_sasrec_trains_with_the_reference_default_dropout():
     assert_close(e, fx["out"]["pos_logits"], TOL)                           # dropout off == the dropout-free fixture
 
 
+def test_table_read_by_two_lookups_gets_one_gradient_tensor():
+    """SASRec's item table feeds the embedding layer (item sequence) and gather_dot (candidates).  With
+    ops.config.share_table_grads the second backward node adds its rows into the dense gradient the first one returned:
+    the same gradient as autograd's sum of two dense tensors (within rounding: another order of the same sums), identical
+    from run to run, and the parameter's gradient IS the tensor the first node made (no aten::add of two 256 MB tensors)."""
+    from recbox_amd import ops
+    Fe, La = _rh()
+    from recbox_amd.rechub.models.matching import SASRec
+    Sq = Fe.SequenceFeature
+    fx = Fixture("rechub_sasrec_d64")
+    X = _cuda(fx.tensors("in"))
+
+    def run(share):
+        fe = [Sq("seq", 97, 64, pooling="concat"), Sq("pos", 97, 64, pooling="concat", shared_with="seq"),
+              Sq("neg", 97, 64, pooling="concat", shared_with="seq")]
+        model = load_params(SASRec(fe, max_len=200, dropout_rate=0.0), fx["p"]).cuda().train()
+        old = ops.config.share_table_grads
+        ops.config.share_table_grads = share
+        made = []
+        real = ops._publish_grads
+
+        def spy(ctx, params, grads):
+            made.extend(g.data_ptr() for g in grads if g is not None)
+            return real(ctx, params, grads)
+        ops._publish_grads = spy
+        try:
+            pl, nl = model(X)
+            m = (X["pos"] != 0).float()
+            loss = -((F.logsigmoid(pl) + F.logsigmoid(-nl)) * m).sum() / m.sum()
+            loss.backward()
+        finally:
+            ops.config.share_table_grads = old
+            ops._publish_grads = real
+        table = model.item_emb.embed_dict["seq"].weight
+        return table.grad.clone(), table.grad.data_ptr() in made, {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    g_sum, _, all_sum = run(False)
+    g_one, same_tensor, all_one = run(True)
+    g_two, _, _ = run(True)
+    assert same_tensor                                   # AccumulateGrad received the first node's tensor alone
+    assert torch.equal(g_one, g_two)
+    assert_close(g_one, g_sum, 1e-6 * max(1.0, float(g_sum.abs().max())), "item table gradient")
+    assert_close(g_one, fx["g"]["item_emb.embed_dict.seq.weight"], TOL, "vs the live-reference fixture")
+    for n in all_sum:
+        if "item_emb" not in n:
+            assert torch.equal(all_sum[n], all_one[n]), n
+    assert not ops._pending_grads                        # every published gradient was adopted (the position table, read
+                                                         # once, was never published)
+
+
 def test_sasrec_sublayers_as_one_node_equal_the_composed_ops():
     """ops.sasrec_attention_sublayer / sasrec_ffn_sublayer (residual adds, timeline mask, ReLU backward and the gradient sums
     of tensors with two readers folded into GEMM epilogues) against the same block composed from layer_norm / linear /
