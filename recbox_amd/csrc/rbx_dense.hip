@@ -24,6 +24,7 @@
 // order (deterministic, no float atomics).  What was measured on the way:
 // profiles/r02/gemm_variants.txt.
 #include <stdlib.h>
+#include <type_traits>
 #include "rbx_internal.h"
 
 namespace rbx {
@@ -1017,15 +1018,30 @@ static bool vec_ok(const float* p, long long ld) { return (reinterpret_cast<uint
 // reads of 64 different lines thrashed the L1: 8x the L2 traffic, slower than the tile kernel), turned into that layout
 // through a wavefront-private 8 KB of LDS (no barrier), and the next slab's requests are in flight under the current
 // slab's 64 MFMAs.  MFMA-bound rate: 64 x 64 cycles per slab and SIMD = 9.6 TB/s of traffic, above what HBM delivers.
+#ifndef RBX_NT_STORE
+#define RBX_NT_STORE 0   /* measured on SASRec (profiles/r03): plain stores 10.27 ms, streamed stores 10.33 */
+#endif
+#ifndef RBX_NT_EPI
+#define RBX_NT_EPI 1
+#endif
 constexpr int kSlabWaves = 4;              // wavefronts per workgroup (independent of each other)
 constexpr int kSlabLd = 64 + 4;            // LDS row pitch of a slab (floats): b128 reads of 32 rows spread over the banks
-__device__ __forceinline__ void slab_issue(const float* A, long long lda, int r0, int M, int lane, f32x4 (&v)[8]) {
+// A slab = 32 rows of 64 floats, fetched as eight 1 KB requests: request p covers rows 4 p .. 4 p + 3, lane l takes floats
+// [4 (l % 16), + 4) of row 4 p + l / 16.  The per-lane byte offsets below are the same for every full slab (computed once);
+// the slab's first row comes in as a wave-uniform base (SGPR pair), so a request costs no vector arithmetic at all -- the
+// first version spent ~600 integer instructions per slab on 64-bit row addresses and per-row bounds tests, as long as
+// the 64 MFMAs themselves (profiles/r03: 70 % of the wavefront cycles were issue stalls, the MFMA pipes 0.43 busy).
+__device__ __forceinline__ void slab_offsets(long long ld, int rows_left, int lane, unsigned (&off)[8]) {
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {            // request p: rows r0 + 4 p .. + 3, lane l takes floats [4 (l % 16), + 4) of row l / 16
-    int r = r0 + 4 * p + (lane >> 4);
-    r = r < M ? r : M - 1;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[p]) : "v"(A + static_cast<long long>(r) * lda + 4 * (lane & 15)));
+  for (int p = 0; p < 8; ++p) {
+    int row = 4 * p + (lane >> 4);
+    row = row < rows_left ? row : rows_left - 1;         // (the last, partial slab re-reads its last row)
+    off[p] = static_cast<unsigned>((static_cast<long long>(row) * ld + 4 * (lane & 15)) * 4);
   }
+}
+__device__ __forceinline__ void slab_issue(const float* base, const unsigned (&off)[8], f32x4 (&v)[8]) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(v[p]) : "v"(off[p]), "s"(base));
 }
 __device__ __forceinline__ void slab_arrived(f32x4 (&v)[8]) {
   asm volatile("s_waitcnt vmcnt(0)"
@@ -1035,9 +1051,9 @@ __device__ __forceinline__ void slab_arrived(f32x4 (&v)[8]) {
 }
 // registers of slab_issue -> the lane's half row, through the wavefront's LDS slab
 __device__ __forceinline__ void slab_turn(float* __restrict__ lds, int lane, const f32x4 (&v)[8], float (&a)[32]) {
+  float* dst = lds + (lane >> 4) * kSlabLd + 4 * (lane & 15);
 #pragma unroll
-  for (int p = 0; p < 8; ++p)
-    *reinterpret_cast<f32x4*>(lds + (4 * p + (lane >> 4)) * kSlabLd + 4 * (lane & 15)) = v[p];
+  for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4*>(dst + 4 * p * kSlabLd) = v[p];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1050,19 +1066,32 @@ __device__ __forceinline__ void slab_turn(float* __restrict__ lds, int lane, con
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();         // (the next slab_turn overwrites what these reads fetch)
 }
-template <bool B_KCONTIG, bool HAS_RES, bool HAS_MASK>
+// element (i, t) of a wavefront's two 32 x 32 output tiles sits in row (i & 3) + 8 (i >> 2) + 4 h, column 32 t + m
+__device__ __forceinline__ constexpr int slab_row(int i) { return (i & 3) + 8 * (i >> 2); }
+
+// EPI: 1 residual, 2 mask, 4 row scale, 8 ReLU -- compile-time, so that a launch carries only its own epilogue
+template <bool B_KCONTIG, int EPI>
 __global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_k64n64_kernel(
     const float* __restrict__ A, const long long lda, const float* __restrict__ B, const long long ldb, float* __restrict__ C,
-    const long long ldc, const int M, const float* __restrict__ bias, const int act, const Epi epi) {
+    const long long ldc, const int M, const float* __restrict__ bias, const Epi epi) {
   __shared__ float slab[kSlabWaves][32 * kSlabLd];
   const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));      // wave-uniform, and known to be
   const int nw = static_cast<int>(gridDim.x) * kSlabWaves;
   const int slabs = (M + 31) >> 5;
-  int s = static_cast<int>(blockIdx.x) * kSlabWaves + (threadIdx.x >> 6);
+  int s = static_cast<int>(blockIdx.x) * kSlabWaves + wid;
   if (s >= slabs) return;
-  float* lds = slab[threadIdx.x >> 6];
+  float* lds = slab[wid];
+  unsigned off_full[8], off[8];
+  slab_offsets(lda, 32, lane, off_full);
   f32x4 nx[8];
-  slab_issue(A, lda, s * 32, M, lane, nx);
+  {
+    const int left = M - s * 32;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) off[p] = off_full[p];
+    if (left < 32) slab_offsets(lda, left, lane, off);
+    slab_issue(A + static_cast<long long>(s) * 32 * lda, off, nx);
+  }
   // W(k = 32 h + j, n = 32 t + m), t = 0, 1
   float w0[32], w1[32];
   if constexpr (B_KCONTIG) {               // B(k, n) = B[n * ldb + k]: 32 consecutive floats of rows m and 32 + m
@@ -1083,8 +1112,11 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_k64n64_kernel(
     }
   }
   const float b0 = bias != nullptr ? bias[m] : 0.f, b1 = bias != nullptr ? bias[32 + m] : 0.f;
-  constexpr bool has_res = HAS_RES, has_mask = HAS_MASK;
-  const bool has_rs = epi.rowscale != nullptr;
+  constexpr bool has_res = (EPI & 1) != 0, has_mask = (EPI & 2) != 0, has_rs = (EPI & 4) != 0, relu = (EPI & 8) != 0;
+  // per-lane parts of the epilogue's addresses (bytes): row 4 h of the slab, column m
+  const long long c_lane = (4LL * h * ldc + m) * 4;
+  const long long res_lane = has_res ? (4LL * h * epi.ldres + m) * 4 : 0;
+  const long long msk_lane = has_mask ? (4LL * h * epi.ldmask + m) * 4 : 0;
   float a[32];
   slab_arrived(nx);
   slab_turn(lds, lane, nx, a);
@@ -1093,36 +1125,56 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_k64n64_kernel(
     int sn = s + nw;
     const bool more = sn < slabs;
     sn = more ? sn : s;                    // (the last round re-requests its own slab: no branch around the asm)
-    slab_issue(A, lda, sn * 32, M, lane, nx);
-    // the epilogue's operands are fetched now, under the MFMAs (output element (i, t): row r0 + (i & 3) + 8 (i >> 2) + 4 h,
-    // column 32 t + m)
+    {
+      const int left = M - sn * 32;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) off[p] = off_full[p];
+      if (left < 32) slab_offsets(lda, left, lane, off);
+      slab_issue(A + static_cast<long long>(sn) * 32 * lda, off, nx);
+    }
+    const int left = M - r0;               // rows of this slab that exist (wave-uniform)
+    const bool full = left >= 32;
+    // the epilogue's operands are fetched now, under the MFMAs
     f32x16 res0, res1, msk0, msk1;
     float rs[16];
     if constexpr (has_res) {
+      const char* base = reinterpret_cast<const char*>(epi.res + static_cast<long long>(r0) * epi.ldres) + res_lane;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        int row = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        row = row < M ? row : M - 1;
-        const float* q = epi.res + static_cast<long long>(row) * epi.ldres + m;
+        const int k = (full || slab_row(i) + 4 * h < left) ? slab_row(i) : 0;
+        const float* q = reinterpret_cast<const float*>(base + static_cast<long long>(k) * epi.ldres * 4);
+#if RBX_NT_EPI
+        res0[i] = __builtin_nontemporal_load(q);
+        res1[i] = __builtin_nontemporal_load(q + 32);
+#else
         res0[i] = q[0];
         res1[i] = q[32];
+#endif
       }
     }
     if constexpr (has_mask) {
+      const char* base = reinterpret_cast<const char*>(epi.mask + static_cast<long long>(r0) * epi.ldmask) + msk_lane;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        int row = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        row = row < M ? row : M - 1;
-        const float* q = epi.mask + static_cast<long long>(row) * epi.ldmask + m;
+        const int k = (full || slab_row(i) + 4 * h < left) ? slab_row(i) : 0;
+        const float* q = reinterpret_cast<const float*>(base + static_cast<long long>(k) * epi.ldmask * 4);
+#if RBX_NT_EPI
+        msk0[i] = __builtin_nontemporal_load(q);
+        msk1[i] = __builtin_nontemporal_load(q + 32);
+#else
         msk0[i] = q[0];
         msk1[i] = q[32];
+#endif
       }
     }
-    if (has_rs) {
+    if constexpr (has_rs) {
+      const float* base = epi.rowscale + r0 + 4 * h;
+      if (full) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        rs[i] = epi.rowscale[row < M ? row : M - 1];
+        for (int i = 0; i < 16; ++i) rs[i] = base[slab_row(i)];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rs[i] = base[slab_row(i) + 4 * h < left ? slab_row(i) : 0];
       }
     }
     f32x16 acc0, acc1;
@@ -1133,20 +1185,29 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_k64n64_kernel(
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w0[j], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w1[j], acc1, 0, 0, 0);
     }
+    char* cbase = reinterpret_cast<char*>(C + static_cast<long long>(r0) * ldc) + c_lane;
+    auto finish = [&](auto guarded) {        // two copies of the epilogue: full slabs store without a test per row
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      float v0 = acc0[i] + b0, v1 = acc1[i] + b1;
-      if (act == 1) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-      if constexpr (has_mask) { v0 = msk0[i] > 0.f ? v0 : 0.f; v1 = msk1[i] > 0.f ? v1 : 0.f; }
-      if constexpr (has_res) { v0 += res0[i]; v1 += res1[i]; }
-      if (has_rs) { v0 *= rs[i]; v1 *= rs[i]; }
-      if (row < M) {
-        float* q = C + static_cast<long long>(row) * ldc + m;
-        q[0] = v0;
-        q[32] = v1;
+      for (int i = 0; i < 16; ++i) {
+        float v0 = acc0[i] + b0, v1 = acc1[i] + b1;
+        if constexpr (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+        if constexpr (has_mask) { v0 = msk0[i] > 0.f ? v0 : 0.f; v1 = msk1[i] > 0.f ? v1 : 0.f; }
+        if constexpr (has_res) { v0 += res0[i]; v1 += res1[i]; }
+        if constexpr (has_rs) { v0 *= rs[i]; v1 *= rs[i]; }
+        if (!decltype(guarded)::value || slab_row(i) + 4 * h < left) {
+          float* q = reinterpret_cast<float*>(cbase + static_cast<long long>(slab_row(i)) * ldc * 4);
+#if RBX_NT_STORE
+          __builtin_nontemporal_store(v0, q);
+          __builtin_nontemporal_store(v1, q + 32);
+#else
+          q[0] = v0;
+          q[32] = v1;
+#endif
+        }
       }
-    }
+    };
+    if (full) finish(std::false_type{});
+    else finish(std::true_type{});
     slab_arrived(nx);
     if (!more) break;
     slab_turn(lds, lane, nx, a);
@@ -1164,11 +1225,12 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_k64n64_kernel(
 __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const float* __restrict__ g, const long long ldg,
                                                                       const float* __restrict__ x, const long long ldx,
                                                                       const int M, float* __restrict__ dw_part,
-                                                                      float* __restrict__ db_part) {
+                                                                      float* __restrict__ db_part, const int abl) {
   __shared__ float lds[kSlabWaves * 2 * 32 * kSlabLd];
   __shared__ float cs_lds[kSlabWaves][64];
   static_assert(kSlabWaves * 2 * 32 * kSlabLd >= kSlabWaves * 64 * 64, "the slabs' LDS also holds the wavefronts' [64, 64] sums");
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int nw = static_cast<int>(gridDim.x) * kSlabWaves;
   const int slabs = (M + 31) >> 5;
   float* sg = lds + wid * 2 * 32 * kSlabLd;
@@ -1181,16 +1243,17 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
   f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  float* pg = sg + (lane >> 4) * kSlabLd + 4 * (lane & 15);
+  float* px = sx + (lane >> 4) * kSlabLd + 4 * (lane & 15);
   // coalesced registers -> LDS (rows beyond M carry zeros in g: their products and column sums vanish)
-  auto park = [&](int r0, const f32x4 (&vg)[8], const f32x4 (&vx)[8]) {
+  auto park = [&](int left, const f32x4 (&vg)[8], const f32x4 (&vx)[8]) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      const int row = 4 * p + (lane >> 4);
       f32x4 u = vg[p];
-      if (r0 + row >= M) u = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (left < 32 && 4 * p + (lane >> 4) >= left) u = f32x4{0.f, 0.f, 0.f, 0.f};
       cs += u;
-      *reinterpret_cast<f32x4*>(sg + row * kSlabLd + 4 * (lane & 15)) = u;
-      *reinterpret_cast<f32x4*>(sx + row * kSlabLd + 4 * (lane & 15)) = vx[p];
+      *reinterpret_cast<f32x4*>(pg + 4 * p * kSlabLd) = u;
+      *reinterpret_cast<f32x4*>(px + 4 * p * kSlabLd) = vx[p];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1198,24 +1261,38 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
   };
   int s = static_cast<int>(blockIdx.x) * kSlabWaves + wid;
   if (s < slabs) {
+    unsigned og_full[8], ox_full[8], og[8], ox[8];
+    slab_offsets(ldg, 32, lane, og_full);
+    slab_offsets(ldx, 32, lane, ox_full);
+    auto issue = [&](int sl, f32x4 (&vg)[8], f32x4 (&vx)[8]) {
+      const int left = M - sl * 32;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) { og[p] = og_full[p]; ox[p] = ox_full[p]; }
+      if (left < 32) {
+        slab_offsets(ldg, left, lane, og);
+        slab_offsets(ldx, left, lane, ox);
+      }
+      slab_issue(g + static_cast<long long>(sl) * 32 * ldg, og, vg);
+      slab_issue(x + static_cast<long long>(sl) * 32 * ldx, ox, vx);
+    };
     f32x4 ng[8], nx[8];
-    slab_issue(g, ldg, s * 32, M, lane, ng);
-    slab_issue(x, ldx, s * 32, M, lane, nx);
+    issue(s, ng, nx);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ng[0]), "+v"(ng[1]), "+v"(ng[2]), "+v"(ng[3]), "+v"(ng[4]), "+v"(ng[5]),
                  "+v"(ng[6]), "+v"(ng[7]) : : "memory");
     slab_arrived(nx);
-    park(s * 32, ng, nx);
+    park(M - s * 32, ng, nx);
+    const float* rg = sg + h * kSlabLd + m;
+    const float* rx = sx + h * kSlabLd + m;
     for (;;) {
       int sn = s + nw;
       const bool more = sn < slabs;
       sn = more ? sn : s;
-      slab_issue(g, ldg, sn * 32, M, lane, ng);
-      slab_issue(x, ldx, sn * 32, M, lane, nx);
+      issue(sn, ng, nx);
+      if (abl != 1)
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) {
-        const float* rg = sg + (2 * jj + h) * kSlabLd + m;
-        const float* rx = sx + (2 * jj + h) * kSlabLd + m;
-        const float a0 = rg[0], a1 = rg[32], b0 = rx[0], b1 = rx[32];
+        const float a0 = rg[2 * jj * kSlabLd], a1 = rg[2 * jj * kSlabLd + 32];
+        const float b0 = rx[2 * jj * kSlabLd], b1 = rx[2 * jj * kSlabLd + 32];
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -1228,7 +1305,7 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();       // every lane has read the current slab
       s = sn;
-      park(s * 32, ng, nx);
+      if (abl != 2) park(M - s * 32, ng, nx);
     }
   }
   __syncthreads();                            // all slabs consumed: the LDS now takes the four [64, 64] sums
@@ -1238,8 +1315,7 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        mine[(32 * a + (i & 3) + 8 * (i >> 2) + 4 * h) * 64 + 32 * b + m] = acc[a][b][i];
+      for (int i = 0; i < 16; ++i) mine[(32 * a + slab_row(i) + 4 * h) * 64 + 32 * b + m] = acc[a][b][i];
   // column sums: lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same four columns of different rows
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -1264,6 +1340,14 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
   }
 }
 
+static int dw64_abl() {
+  static const int v = [] { const char* e = getenv("RBX_DW64_ABL"); return e ? atoi(e) : 0; }();
+  return v;
+}
+static int dw64_wgs() {
+  static const int v = [] { const char* e = getenv("RBX_DW64_WGS"); return e ? atoi(e) : 0; }();
+  return v;
+}
 static int stream64_mode() {
   static const int mode = [] { const char* e = getenv("RBX_GEMM_STREAM64"); return e ? atoi(e) : 1; }();
   return mode;
@@ -1332,11 +1416,12 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     int wgs = (slabs + kSlabWaves - 1) / kSlabWaves;
     if (wgs > 2 * kCUs) wgs = 2 * kCUs;              // two workgroups of four wavefronts per CU: two wavefronts per SIMD
     const dim3 grid(wgs), block(64 * kSlabWaves);
-#define RBX_K64(R, K_) hipLaunchKernelGGL((gemm_f32_k64n64_kernel<BK_, R, K_>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, bias, act, epi)
-    if (epi.res != nullptr && epi.mask != nullptr) RBX_K64(true, true);
-    else if (epi.res != nullptr) RBX_K64(true, false);
-    else if (epi.mask != nullptr) RBX_K64(false, true);
-    else RBX_K64(false, false);
+    const int code = (epi.res != nullptr ? 1 : 0) | (epi.mask != nullptr ? 2 : 0) | (epi.rowscale != nullptr ? 4 : 0) | (act == 1 ? 8 : 0);
+#define RBX_K64(E) case E: hipLaunchKernelGGL((gemm_f32_k64n64_kernel<BK_, E>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, bias, epi); break
+    switch (code) {
+      RBX_K64(0); RBX_K64(1); RBX_K64(2); RBX_K64(3); RBX_K64(4); RBX_K64(5); RBX_K64(6); RBX_K64(7);
+      RBX_K64(8); RBX_K64(9); RBX_K64(10); RBX_K64(11); RBX_K64(12); RBX_K64(13); RBX_K64(14); RBX_K64(15);
+    }
 #undef RBX_K64
     return check_launch("gemm_f32_k64n64_kernel");
   }
@@ -1572,9 +1657,10 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     const int slabs = (M + 31) / 32;
     int n_wg = (slabs + kSlabWaves - 1) / kSlabWaves;
     if (n_wg > 2 * kCUs) n_wg = 2 * kCUs;
+    if (dw64_wgs() > 0 && n_wg > dw64_wgs()) n_wg = dw64_wgs();
     float* part = ws + dw_floats;
     hipLaunchKernelGGL(tall_dw64_kernel, dim3(n_wg), dim3(64 * kSlabWaves), 0, s, g, static_cast<long long>(n), d_x,
-                       static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr);
+                       static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr, dw64_abl());
     launch_splitk_reduce(s, 64u, ws, 64LL * 64, n_wg, d_dw, d_db != nullptr ? part : nullptr, 64LL, d_db);
     return check_launch("tall dW / db kernels (slab form)");
   }

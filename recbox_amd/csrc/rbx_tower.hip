@@ -578,7 +578,9 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
   for (long long i = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i < total; i += step) {
     if ((dim & 3) == 0) {                                  // a float4 never straddles two rows
       const float sc = s[i / dim];
-      const float4 v = *reinterpret_cast<const float4*>(x + i);
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const v4f vv = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(x + i));       // streamed once
+      const float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
       if (add != nullptr) a = *reinterpret_cast<const float4*>(add + i);
       *reinterpret_cast<float4*>(out + i) = make_float4((alpha * v.x + a.x) * sc, (alpha * v.y + a.y) * sc,
