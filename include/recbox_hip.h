@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 113          /* 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 114          /* 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -590,6 +590,23 @@ int rbx_linear_dx_deepfm(const float* d_dy, int64_t dy_stride, const float* d_w,
                          const float* d_x, int64_t x_stride, const float* d_fm_sum, int32_t fm_dim, int32_t fm_cols,
                          const float* d_fm_g, const float* d_lr_g, const float* d_lr_w, float* d_dx, int64_t dx_stride,
                          void* stream);
+
+/* f32 GEMM on the bf16 matrix cores (csrc/rbx_dense.hip, gemm_bx6_kernel): a weight matrix split ONCE per call into three
+ * bf16 planes w = h + m + l (|w - h - m - l| <= 2^-24 |w|), the activations split inside the kernel, six bf16 MFMA products
+ * per f32 product with f32 accumulation -- results at f32 rounding level (the same test tolerances), ~2.7x fewer matrix-core
+ * cycles than v_mfma_f32_32x32x2_f32.  No counterpart in the reference (its nn.Linear is one torch call):
+ *   rbx_split_bf16_size(rows, cols, transpose): bytes of the planes of a [rows, cols] matrix;
+ *   rbx_split_bf16: d_out[r][c / 8][q][c % 8] (q = 0..2 = h, m, l; c < cols rounded up to 32, zero-filled; transpose != 0:
+ *                   out row r is COLUMN r of d_src) -- an opaque layout for the kernel's tile loads; transpose = 0 serves
+ *                   y = x W^T (rbx_linear_fwd*), 1 serves dx = dy W (rbx_linear_dx*);
+ *   rbx_split_register(d_w, d_planes, rows, cols, transposed): from now on a rbx_linear_fwd* / rbx_linear_dx* call whose
+ *                   weight pointer is d_w (shape [rows, cols]) runs on the planes; rbx_split_unregister(d_w) ends that (the
+ *                   planes must stay valid until the GEMMs issued in between have run).  Host-side table, 16 slots,
+ *                   thread-safe; RBX_GEMM_BX6=0 in the environment ignores every registration. */
+size_t rbx_split_bf16_size(int32_t rows, int32_t cols, int32_t transpose);
+int rbx_split_bf16(const float* d_src, int64_t ld, int32_t rows, int32_t cols, int32_t transpose, void* d_out, void* stream);
+int rbx_split_register(const float* d_w, const void* d_planes, int32_t rows, int32_t cols, int32_t transposed);
+int rbx_split_unregister(const float* d_w);
 
 /* ---- K6: fused masked-softmax attention for short sequences (L <= 256, head_dim in {4..64}) ----
  * ranking/pytorch/layers/attentions/dot_product_attention.py:31-43 (ScaledDotProductAttention) and the

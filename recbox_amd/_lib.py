@@ -151,6 +151,10 @@ SIGNATURES = {
     "rbx_linear_dx_deepfm": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i32, _i32, _P, _P, _P, _P, _i64,
                                             _P]),
     "rbx_linear_bwd": (ctypes.c_int, [_P, _i64, _P, _P, _P, _i64, _i32, _i32, _i32, _P, _i64, _P, _P, _P, _sz, _P]),
+    "rbx_split_bf16_size": (_sz, [_i32, _i32, _i32]),
+    "rbx_split_bf16": (ctypes.c_int, [_P, _i64, _i32, _i32, _i32, _P, _P]),
+    "rbx_split_register": (ctypes.c_int, [_P, _P, _i32, _i32, _i32]),
+    "rbx_split_unregister": (ctypes.c_int, [_P]),
     "rbx_attn_fwd": (ctypes.c_int, [_P, _P, _P, _P, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _P, _P, _P, _P]),
     "rbx_attn_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _i64, _i32, _i32, _i32, _f32, _i32, _f32,
                                     _P, _P, _P, _P, _P]),

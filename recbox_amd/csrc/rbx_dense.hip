@@ -24,6 +24,7 @@
 // order (deterministic, no float atomics).  What was measured on the way:
 // profiles/r02/gemm_variants.txt.
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 #include "rbx_internal.h"
 
@@ -350,6 +351,108 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
                                         static_cast<int>(blockIdx.x) * BM, As, Bs);
 }
 
+// Epilogue of a 128 x 128 tile whose wavefronts hold 2 x 2 MFMA tiles of 32 x 32 (C/D layout: col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -- the same for the f32 and the bf16 MFMAs): shared by the kernels below.
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
+                                              const int li, const int lk, const int live, const int M, const int N,
+                                              float* __restrict__ C, const long long ldc, const float* __restrict__ bias,
+                                              const int act, const int splits, const Epi& epi) {
+  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const bool has_mask = epi.mask != nullptr, has_res = epi.res != nullptr, has_fm = epi.fm_x != nullptr,
+             has_lr = epi.lr_g != nullptr, has_rs = epi.rowscale != nullptr;
+  if (m0 + BM <= M && n0 + BN <= N && splits == 1 && !(has_fm && (has_mask || has_res || has_rs))) {
+    // Interior tile: no row / column tests, and the optional operands of the epilogue are fetched for four outputs at a
+    // time in one straight run of loads.  (With a test per output every element was its own basic block -- load, wait,
+    // store, 64 times per lane: the DeepFM dx GEMM took 330 us longer than the same GEMM without its epilogue.)
+    constexpr int CH = 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn + j * 32 + li;
+        const int row0 = m0 + wm + i * 32 + 4 * lk;
+        const float bv = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+        for (int h = 0; h < 16; h += CH) {
+          float add[CH];
+#pragma unroll
+          for (int q = 0; q < CH; ++q) add[q] = 0.f;
+          if (has_fm) {
+            if (col < epi.fm_cols) {
+              const int d = epi.fm_mask >= 0 ? (col & epi.fm_mask) : (col % epi.fm_dim);
+              const float lw = has_lr ? epi.lr_w[col] : 0.f;
+              float x[CH], sm[CH], g[CH], gl[CH];
+#pragma unroll
+              for (int q = 0; q < CH; ++q) {
+                const long long row = row0 + ((h + q) & 3) + 8 * ((h + q) >> 2);
+                x[q] = epi.fm_x[row * epi.fm_ldx + col];
+                sm[q] = epi.fm_s[row * epi.fm_dim + d];
+                g[q] = epi.fm_g[row];
+                gl[q] = has_lr ? epi.lr_g[row] : 0.f;
+              }
+#pragma unroll
+              for (int q = 0; q < CH; ++q) add[q] = g[q] * (sm[q] - x[q]) + gl[q] * lw;
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+              float v = acc[i][j][h + q] + bv;
+              if (act == 1) v = v > 0.f ? v : 0.f;
+              C[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * ldc + col] = v + add[q];
+            }
+          } else {
+            float keep[CH], sc[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { keep[q] = 1.f; sc[q] = 1.f; }
+            if (has_mask) {
+#pragma unroll
+              for (int q = 0; q < CH; ++q)
+                keep[q] = epi.mask[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * epi.ldmask + col];
+            }
+            if (has_res) {
+#pragma unroll
+              for (int q = 0; q < CH; ++q)
+                add[q] = epi.res[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * epi.ldres + col];
+            }
+            if (has_rs) {
+#pragma unroll
+              for (int q = 0; q < CH; ++q) sc[q] = epi.rowscale[row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)];
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+              float v = acc[i][j][h + q] + bv;
+              if (act == 1) v = v > 0.f ? v : 0.f;
+              if (has_mask) v = keep[q] > 0.f ? v : 0.f;
+              v += add[q];
+              if (has_rs) v *= sc[q];
+              C[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * ldc + col] = v;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn + j * 32 + li;
+      if (col >= N || ((live >> (2 * i + j)) & 1) == 0) continue;          // (a tile that is not live may lie over a neighbour's)
+      const float bv = (bias != nullptr && splits == 1) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row < M) {
+          float v = acc[i][j][r] + bv;
+          if (act == 1 && splits == 1) v = v > 0.f ? v : 0.f;
+          if (splits == 1) v = epi_apply(epi, v, row, col);
+          C[static_cast<long long>(row) * ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
 // C[M,N] (+bias, act) = A(M,K) * B(K,N); with splits > 1 a workgroup computes one K slice of its tile
 // (then C points at the slice's private [M,N] buffer: C + z * M * N, no epilogue math).
 template <bool A_KCONTIG, bool B_KCONTIG>
@@ -472,99 +575,202 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_f32_kernel(const f
     __syncthreads();
     cur ^= 1;
   }
-  // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const bool has_mask = epi.mask != nullptr, has_res = epi.res != nullptr, has_fm = epi.fm_x != nullptr,
-             has_lr = epi.lr_g != nullptr, has_rs = epi.rowscale != nullptr;
-  if (m0 + BM <= M && n0 + BN <= N && splits == 1 && !(has_fm && (has_mask || has_res || has_rs))) {
-    // Interior tile: no row / column tests, and the optional operands of the epilogue are fetched for four outputs at a
-    // time in one straight run of loads.  (With a test per output every element was its own basic block -- load, wait,
-    // store, 64 times per lane: the DeepFM dx GEMM took 330 us longer than the same GEMM without its epilogue.)
-    constexpr int CH = 4;
+  gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, splits, epi);
+}
+
+// ---- f32 GEMM on the bf16 matrix cores: operands split three ways, six products ---------------------------------------------
+// CDNA4 runs v_mfma_f32_32x32x2_f32 at the f32 VECTOR rate (157 TF); its bf16 MFMAs are 16x that (2.5 PF) and accumulate
+// in f32.  Every f32 x = h + m + l with bf16 h = rn(x), m = rn(x - h), l = rn(x - h - m) (3 x 8 significant bits:
+// |x - h - m - l| <= 2^-24 |x|), so
+//     a b = ah bh + (ah bm + am bh) + (ah bl + al bh + am bm) + O(2^-24 |a b|):
+// six v_mfma_f32_32x32x16_bf16 per 16 k (192 cycles) instead of eight f32 MFMAs (512 cycles), with an error per product of
+// the size of ONE f32 rounding -- the sums carry the same ~sqrt(K) 2^-24 as the f32 kernel's (tests: the same tolerances
+// against float64).  bf16 has f32's exponent range: nothing overflows that f32 would not; non-finite inputs come out as
+// NaN (inf - inf in the split), f32 denormals lose their low parts.
+// Form: y = x W^T and dx = dy W, i.e. A [M, K] row-major activations against weights.  The WEIGHTS are split once per call
+// by rbx_split_bf16 into three k-major bf16 planes (transposed for dx), which the caller registers for the duration of the
+// GEMM call (rbx_split_register); the activations are split on their way from registers to LDS (v_cvt_pk_bf16_f32, 4.5 VALU
+// ops per element beside the MFMAs).  LDS: three bf16 planes per operand, rows k-major in 80-byte pitch (conflict-free
+// b128 reads).  The weight-gradient GEMM (both operands batch-major activations) stays on the f32 MFMAs.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));      // a dwordx4 load needs dword alignment only
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int SBK = 32;                 // k per staged tile: two MFMA steps of 16
+constexpr int SLD = SBK + 8;            // LDS row pitch, bf16 elements
+constexpr int SPLANE = BM * SLD;        // one plane of one operand
+
+__device__ __forceinline__ void split2(f32x2_t x, unsigned& h, unsigned& m, unsigned& l) {
+  const bf16x2_t hb = __builtin_convertvector(x, bf16x2_t);
+  x -= __builtin_convertvector(hb, f32x2_t);
+  const bf16x2_t mb = __builtin_convertvector(x, bf16x2_t);
+  x -= __builtin_convertvector(mb, f32x2_t);
+  const bf16x2_t lb = __builtin_convertvector(x, bf16x2_t);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+// A tile [128, SBK] of f32 activations, global -> registers: thread t takes k = 4 (t % 8) .. + 3 of rows t / 8 + 32 p.
+// k beyond K reads as zero, rows beyond M are clamped (their products only reach outputs that are never stored).
+__device__ __forceinline__ void bx6_load_a(const float* __restrict__ A, long long lda, int m0, int k0, int M, int K,
+                                           f32x4u_t (&v)[4]) {
+  const int t = threadIdx.x;
+  const int k = k0 + (t & 7) * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+  for (int p = 0; p < 4; ++p) {
+    int r = m0 + (t >> 3) + 32 * p;
+    r = r < M ? r : M - 1;
+    const float* src = A + static_cast<long long>(r) * lda + k;
+    if (k + 3 < K) {
+      v[p] = *reinterpret_cast<const f32x4u_t*>(src);
+    } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn + j * 32 + li;
-        const int row0 = m0 + wm + i * 32 + 4 * lk;
-        const float bv = bias != nullptr ? bias[col] : 0.f;
-#pragma unroll
-        for (int h = 0; h < 16; h += CH) {
-          float add[CH];
-#pragma unroll
-          for (int q = 0; q < CH; ++q) add[q] = 0.f;
-          if (has_fm) {
-            if (col < epi.fm_cols) {
-              const int d = epi.fm_mask >= 0 ? (col & epi.fm_mask) : (col % epi.fm_dim);
-              const float lw = has_lr ? epi.lr_w[col] : 0.f;
-              float x[CH], sm[CH], g[CH], gl[CH];
-#pragma unroll
-              for (int q = 0; q < CH; ++q) {
-                const long long row = row0 + ((h + q) & 3) + 8 * ((h + q) >> 2);
-                x[q] = epi.fm_x[row * epi.fm_ldx + col];
-                sm[q] = epi.fm_s[row * epi.fm_dim + d];
-                g[q] = epi.fm_g[row];
-                gl[q] = has_lr ? epi.lr_g[row] : 0.f;
-              }
-#pragma unroll
-              for (int q = 0; q < CH; ++q) add[q] = g[q] * (sm[q] - x[q]) + gl[q] * lw;
-            }
-#pragma unroll
-            for (int q = 0; q < CH; ++q) {
-              float v = acc[i][j][h + q] + bv;
-              if (act == 1) v = v > 0.f ? v : 0.f;
-              C[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * ldc + col] = v + add[q];
-            }
-          } else {
-            float keep[CH], sc[CH];
-#pragma unroll
-            for (int q = 0; q < CH; ++q) { keep[q] = 1.f; sc[q] = 1.f; }
-            if (has_mask) {
-#pragma unroll
-              for (int q = 0; q < CH; ++q)
-                keep[q] = epi.mask[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * epi.ldmask + col];
-            }
-            if (has_res) {
-#pragma unroll
-              for (int q = 0; q < CH; ++q)
-                add[q] = epi.res[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * epi.ldres + col];
-            }
-            if (has_rs) {
-#pragma unroll
-              for (int q = 0; q < CH; ++q) sc[q] = epi.rowscale[row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)];
-            }
-#pragma unroll
-            for (int q = 0; q < CH; ++q) {
-              float v = acc[i][j][h + q] + bv;
-              if (act == 1) v = v > 0.f ? v : 0.f;
-              if (has_mask) v = keep[q] > 0.f ? v : 0.f;
-              v += add[q];
-              if (has_rs) v *= sc[q];
-              C[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * ldc + col] = v;
-            }
-          }
-        }
-      }
+      for (int j = 0; j < 4; ++j) v[p][j] = (k + j < K) ? src[j] : 0.f;
     }
-    return;
   }
+}
+__device__ __forceinline__ void bx6_store_a(unsigned short* __restrict__ tile, const f32x4u_t (&v)[4]) {
+  const int t = threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int p = 0; p < 4; ++p) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split2(f32x2_t{v[p][0], v[p][1]}, h0, m0, l0);
+    split2(f32x2_t{v[p][2], v[p][3]}, h1, m1, l1);
+    unsigned short* dst = tile + ((t >> 3) + 32 * p) * SLD + (t & 7) * 4;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + SPLANE) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(dst + 2 * SPLANE) = make_uint2(l0, l1);
+  }
+}
+// B tile [128 rows (output columns), SBK] of the pre-split weights.  Layout of the planes (rbx_split_bf16): per row, per group
+// of 8 k, the three planes' 16 bytes side by side -- [row][kp / 8][3][8] bf16, kp a multiple of SBK (zero-filled) -- so that a
+// row's share of a k tile is 192 contiguous bytes (with one [rows][kp] array per plane it was three 64-byte pieces: three
+// times the requests of the f32 original, and the kernel ran at 100 TF instead of 167).  Thread t takes the 16-byte chunks
+// t + 256 i, i < 6: chunk j = row j / 12, piece j % 12 = 3 (k group) + plane.
+__device__ __forceinline__ void bx6_load_b(const unsigned short* __restrict__ Bp, int kp, int n0, int k0, int N, u32x4_t (&v)[6]) {
+  const int t = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn + j * 32 + li;
-      if (col >= N || ((live >> (2 * i + j)) & 1) == 0) continue;          // (a tile that is not live may lie over a neighbour's)
-      const float bv = (bias != nullptr && splits == 1) ? bias[col] : 0.f;
+  for (int i = 0; i < 6; ++i) {
+    const int j = t + 256 * i;
+    int r = n0 + j / 12;
+    r = r < N ? r : N - 1;
+    v[i] = *reinterpret_cast<const u32x4_t*>(Bp + static_cast<long long>(r) * 3 * kp + (k0 >> 3) * 24 + (j % 12) * 8);
+  }
+}
+__device__ __forceinline__ void bx6_store_b(unsigned short* __restrict__ tile, const u32x4_t (&v)[6]) {
+  const int t = threadIdx.x;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row < M) {
-          float v = acc[i][j][r] + bv;
-          if (act == 1 && splits == 1) v = v > 0.f ? v : 0.f;
-          if (splits == 1) v = epi_apply(epi, v, row, col);
-          C[static_cast<long long>(row) * ldc + col] = v;
-        }
-      }
+  for (int i = 0; i < 6; ++i) {
+    const int j = t + 256 * i;
+    const int c = j % 12;
+    *reinterpret_cast<u32x4_t*>(tile + (c % 3) * SPLANE + (j / 12) * SLD + (c / 3) * 8) = v[i];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bx6_kernel(const float* __restrict__ A, const long long lda,
+                                                          const unsigned short* __restrict__ Bp, const int kp,
+                                                          float* __restrict__ C, const long long ldc, const int M, const int N,
+                                                          const int K, const float* __restrict__ bias, const int act,
+                                                          const int tiles_m, const int tiles_n, const Epi epi) {
+  __shared__ __attribute__((aligned(16))) unsigned short As[3 * SPLANE];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * SPLANE];
+  // XCD-aware tile order, as gemm_f32_kernel
+  int tm_i, tn_j;
+  {
+    const int total = tiles_m * tiles_n, L = static_cast<int>(blockIdx.x);
+    const int xcd = L % kXcds, slot = L / kXcds;
+    const int q = total / kXcds, rem = total % kXcds;
+    const int tile = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    tm_i = tile / tiles_n;
+    tn_j = tile % tiles_n;
+  }
+  const int m0 = tm_i * BM, n0 = tn_j * BN;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int li = lane & 31, lk = lane >> 5;
+  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+  int live;
+  {
+    const int rows = (M - m0 - wm + 31) / 32, cols = (N - n0 - wn + 31) / 32;      // 32-blocks of this wavefront with real output
+    const int r2 = rows > 2 ? 2 : rows, c2 = cols > 2 ? 2 : cols;
+    live = (r2 <= 0 || c2 <= 0) ? 0 : (r2 == 2 && c2 == 2) ? 15 : (r2 == 2) ? 5 : (c2 == 2) ? 3 : 1;
+    live = __builtin_amdgcn_readfirstlane(live);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x4u_t ra[4];
+  u32x4_t rb[6];
+  bx6_load_a(A, lda, m0, 0, M, K, ra);
+  bx6_load_b(Bp, kp, n0, 0, N, rb);
+  const unsigned short* ap = As + (wm + li) * SLD + 8 * lk;
+  const unsigned short* bp = Bs + (wn + li) * SLD + 8 * lk;
+  for (int k0 = 0; k0 < K; k0 += SBK) {
+    bx6_store_a(As, ra);
+    bx6_store_b(Bs, rb);
+    __syncthreads();
+    if (k0 + SBK < K) {                           // the next tile's reads fly under this tile's MFMAs
+      bx6_load_a(A, lda, m0, k0 + SBK, M, K, ra);
+      bx6_load_b(Bp, kp, n0, k0 + SBK, N, rb);
     }
+#pragma unroll
+    for (int ks = 0; ks < SBK / 16; ++ks) {
+      bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          a[i][q] = *reinterpret_cast<const bf16x8_t*>(ap + q * SPLANE + i * 32 * SLD + ks * 16);
+          b[i][q] = *reinterpret_cast<const bf16x8_t*>(bp + q * SPLANE + i * 32 * SLD + ks * 16);
+        }
+      // six products per output tile, the four tiles' chains interleaved (a dependent MFMA waits for its predecessor);
+      // terms in ascending size
+#define RBX_BX6_TERM(QA, QB)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
+    if ((live >> (2 * i + j)) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][QA], b[j][QB], acc[i][j], 0, 0, 0)
+      RBX_BX6_TERM(2, 0);
+      RBX_BX6_TERM(0, 2);
+      RBX_BX6_TERM(1, 1);
+      RBX_BX6_TERM(1, 0);
+      RBX_BX6_TERM(0, 1);
+      RBX_BX6_TERM(0, 0);
+#undef RBX_BX6_TERM
+    }
+    __syncthreads();
+  }
+  gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi);
+}
+
+// src [rows, cols] f32 (row pitch ld) -> bf16 planes h, m, l in the layout bx6_load_b reads: out[r][c / 8][q][c % 8],
+// c < cp = cols rounded up to a multiple of SBK (zero-filled); transpose: out row r is src COLUMN r.
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, const long long ld, const int rows,
+                                                         const int cols, const int transpose,
+                                                         unsigned short* __restrict__ out) {
+  const int orows = transpose ? cols : rows, ocols = transpose ? rows : cols;
+  const int cp = (ocols + SBK - 1) / SBK * SBK;
+  const long long total = static_cast<long long>(orows) * (cp / 2);          // pairs of output elements
+  for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int r = static_cast<int>(i / (cp / 2)), c = static_cast<int>(i % (cp / 2)) * 2;
+    f32x2_t x = {0.f, 0.f};
+    if (transpose) {
+      if (c < ocols) x[0] = src[static_cast<long long>(c) * ld + r];
+      if (c + 1 < ocols) x[1] = src[static_cast<long long>(c + 1) * ld + r];
+    } else {
+      if (c < ocols) x[0] = src[static_cast<long long>(r) * ld + c];
+      if (c + 1 < ocols) x[1] = src[static_cast<long long>(r) * ld + c + 1];
+    }
+    unsigned h, m, l;
+    split2(x, h, m, l);
+    unsigned* dst = reinterpret_cast<unsigned*>(out + static_cast<long long>(r) * 3 * cp + (c >> 3) * 24 + (c & 7));
+    dst[0] = h;
+    dst[4] = m;
+    dst[8] = l;
   }
 }
 
@@ -1348,6 +1554,29 @@ static int dw64_wgs() {
   static const int v = [] { const char* e = getenv("RBX_DW64_WGS"); return e ? atoi(e) : 0; }();
   return v;
 }
+static int bx6_mode() {
+  static const int v = [] { const char* e = getenv("RBX_GEMM_BX6"); return e ? atoi(e) : 1; }();
+  return v;
+}
+// weights whose bf16 planes the caller has made for the GEMM calls it is about to issue (rbx_split_register)
+struct SplitEntry {
+  const float* w;
+  const unsigned short* planes;
+  int rows, cols, transposed;
+};
+constexpr int kSplitSlots = 16;
+static SplitEntry g_split[kSplitSlots];
+static std::mutex g_split_mu;
+static bool split_find(const float* w, int transposed, int rows, int cols, SplitEntry* out) {
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  for (int i = 0; i < kSplitSlots; ++i)
+    if (g_split[i].w == w && g_split[i].planes != nullptr && g_split[i].transposed == transposed && g_split[i].rows == rows &&
+        g_split[i].cols == cols) {
+      *out = g_split[i];
+      return true;
+    }
+  return false;
+}
 static int stream64_mode() {
   static const int mode = [] { const char* e = getenv("RBX_GEMM_STREAM64"); return e ? atoi(e) : 1; }();
   return mode;
@@ -1424,6 +1653,16 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     }
 #undef RBX_K64
     return check_launch("gemm_f32_k64n64_kernel");
+  }
+  // weights with registered bf16 planes: the split-operand kernel on the bf16 matrix cores
+  if (AK && splits == 1 && bx6_mode() > 0) {
+    SplitEntry e;
+    if (split_find(B, BK_ ? 0 : 1, BK_ ? N : K, BK_ ? K : N, &e)) {
+      const int kp = (K + SBK - 1) / SBK * SBK;
+      hipLaunchKernelGGL(gemm_bx6_kernel, dim3(tn * tm), dim3(256), 0, s, A, lda, e.planes, kp, C, ldc, M, N, K, bias, act, tm,
+                         tn, epi);
+      return check_launch("gemm_bx6_kernel");
+    }
   }
   // one column tile of at most 416 columns and many rows: the wide kernel (no narrow companion, A read once)
   const int wmode = wide_mode();
@@ -1702,4 +1941,48 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     rc = check_launch("bias grad kernels");
   }
   return rc;
+}
+
+// ---- bf16 planes of a weight matrix for the split-operand GEMM (see gemm_bx6_kernel) -------------------------------------
+extern "C" size_t rbx_split_bf16_size(int32_t rows, int32_t cols, int32_t transpose) {
+  if (rows <= 0 || cols <= 0) return 0;
+  const long long orows = transpose ? cols : rows, ocols = transpose ? rows : cols;
+  const long long cp = (ocols + rbx::SBK - 1) / rbx::SBK * rbx::SBK;
+  return static_cast<size_t>(3 * orows * cp * 2);
+}
+
+extern "C" int rbx_split_bf16(const float* d_src, int64_t ld, int32_t rows, int32_t cols, int32_t transpose, void* d_out,
+                              void* stream) {
+  using namespace rbx;
+  if (rows <= 0 || cols <= 0) return RBX_OK;
+  if (d_src == nullptr || d_out == nullptr || ld < cols) return fail(RBX_ERR_INVALID, "split_bf16: bad arguments");
+  if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return fail(RBX_ERR_INVALID, "split_bf16: output must be 16-byte aligned");
+  const long long pairs = static_cast<long long>(rbx_split_bf16_size(rows, cols, transpose) / 12);
+  long long blocks = (pairs + 255) / 256;
+  if (blocks > kCUs * 8) blocks = kCUs * 8;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_src,
+                     static_cast<long long>(ld), rows, cols, transpose, static_cast<unsigned short*>(d_out));
+  return check_launch("split_bf16_kernel");
+}
+
+extern "C" int rbx_split_register(const float* d_w, const void* d_planes, int32_t rows, int32_t cols, int32_t transposed) {
+  using namespace rbx;
+  if (d_w == nullptr || d_planes == nullptr || rows <= 0 || cols <= 0) return fail(RBX_ERR_INVALID, "split_register: bad arguments");
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  int slot = -1;
+  for (int i = 0; i < kSplitSlots; ++i)
+    if (g_split[i].w == d_w && g_split[i].transposed == (transposed ? 1 : 0)) slot = i;
+  for (int i = 0; i < kSplitSlots && slot < 0; ++i)
+    if (g_split[i].planes == nullptr) slot = i;
+  if (slot < 0) return fail(RBX_ERR_UNSUPPORTED, "split_register: all %d slots are taken", kSplitSlots);
+  g_split[slot] = SplitEntry{d_w, static_cast<const unsigned short*>(d_planes), rows, cols, transposed ? 1 : 0};
+  return RBX_OK;
+}
+
+extern "C" int rbx_split_unregister(const float* d_w) {
+  using namespace rbx;
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  for (int i = 0; i < kSplitSlots; ++i)
+    if (g_split[i].w == d_w) g_split[i] = SplitEntry{nullptr, nullptr, 0, 0, 0};
+  return RBX_OK;
 }

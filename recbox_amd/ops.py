@@ -78,6 +78,10 @@ class config(object):
     # adds its rows into the dense gradient the first one returned instead of autograd adding two dense tensors
     # (see _publish_grads below)
     share_table_grads = os.environ.get("RECBOX_AMD_SHARE_TABLE_GRADS", "1") != "0"
+    # y = x W^T and dx = dy W of the towers on the bf16 matrix cores: W split once per call into three bf16 planes, the
+    # activations inside the kernel, six products per f32 product with f32 accumulation (csrc/rbx_dense.hip,
+    # gemm_bx6_kernel: f32-level results at ~2.7x fewer matrix-core cycles).  Off: every GEMM on v_mfma_f32_32x32x2_f32.
+    gemm_bx6 = os.environ.get("RECBOX_AMD_GEMM_BX6", "1") != "0"
     # Where the ids-only pieces of the tiered FM backward run.  "split" (default): the id compaction on the CURRENT stream in
     # front of the forward kernel (10 us; the step's first kernel is then on the stream the previous step ended on), the
     # per-block sorts of the small tables on the current stream inside the backward (in front of the block partials that
@@ -1374,6 +1378,24 @@ def _padded_rows(rows, cols, device):
     return torch.empty(0, dtype=torch.float32, device=device).set_(buf.untyped_storage(), 0, (rows, cols), (stride, 1))
 
 
+def _with_split_weights(w, M, transposed, call):
+    """Run ``call()`` -- GEMMs of [M, *] activations against the contiguous weight ``w`` [N, K] -- with the bf16 planes of
+    ``w`` registered (rbx_split_bf16 + rbx_split_register), when the shape is compute-bound enough to gain from the bf16
+    matrix cores; otherwise just ``call()``.  transposed = 0 serves y = x W^T, 1 serves dx = dy W."""
+    N, K = w.shape
+    red, out = (N, K) if transposed else (K, N)
+    if not (config.gemm_bx6 and M >= 4096 and red >= 256 and out >= 128 and w.is_contiguous()):
+        return call()
+    nbytes = lib.rbx_split_bf16_size(N, K, transposed)
+    planes = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(lib.rbx_split_bf16(_ptr(w), K, N, K, transposed, _ptr(planes), _stream()))
+    check(lib.rbx_split_register(_ptr(w), _ptr(planes), N, K, transposed))
+    try:
+        return call()
+    finally:
+        lib.rbx_split_unregister(_ptr(w))
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) via rbx_linear_fwd; act in {None, "relu"} is fused into the epilogue.  x may be a column
     block of a wider row-major activation (row stride > K): it is read, and its gradient written, in place."""
@@ -1390,9 +1412,10 @@ class _Linear(torch.autograd.Function):
         if w.shape[1] != K:
             raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, w.shape[1], N))
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        check(_timed(("linear_fwd", M, N, K),
-                     lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(bias), M, N, K, act,
-                                                _ptr(y), _stream())))
+        _with_split_weights(w, M, 0, lambda: check(_timed(
+            ("linear_fwd", M, N, K),
+            lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(bias), M, N, K, act,
+                                       _ptr(y), _stream()))))
         ctx.save_for_backward(x2, w, y if act == 1 else None)
         ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, shape
         return y.view(*shape[:-1], N)
@@ -1411,9 +1434,13 @@ class _Linear(torch.autograd.Function):
         db = torch.empty(N, dtype=torch.float32, device=dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, ctx.act)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
-        check(lib.rbx_linear_bwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act,
-                                 _ptr(dx), (dx.stride(0) if M > 1 else K) if dx is not None else K, _ptr(dw), _ptr(db),
-                                 _ptr(ws), ws_bytes, _stream()))
+        bwd = lambda: check(lib.rbx_linear_bwd(                                                            # noqa: E731
+            _ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx),
+            (dx.stride(0) if M > 1 else K) if dx is not None else K, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, _stream()))
+        if dx is not None:
+            _with_split_weights(w, M, 1, bwd)
+        else:
+            bwd()
         return (dx.view(ctx.shape) if dx is not None else None), dw, db, None
 
 
@@ -2476,13 +2503,16 @@ def _lin_fwd(x2, w, b, act=0, residual=None, row_scale=None):
     M, K = x2.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
-    if residual is None and row_scale is None:
-        check(_timed(("linear_fwd", M, N, K),
-                     lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w), _ptr(b), M, N, K, act, _ptr(y), _stream())))
-    else:
-        check(lib.rbx_linear_fwd_fused(_ptr(x2), x2.stride(0), _ptr(w), _ptr(b), M, N, K, act, _ptr(residual),
-                                       residual.stride(0) if residual is not None else N, _ptr(row_scale), _ptr(y), N,
-                                       _stream()))
+
+    def run():
+        if residual is None and row_scale is None:
+            check(_timed(("linear_fwd", M, N, K),
+                         lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w), _ptr(b), M, N, K, act, _ptr(y), _stream())))
+        else:
+            check(lib.rbx_linear_fwd_fused(_ptr(x2), x2.stride(0), _ptr(w), _ptr(b), M, N, K, act, _ptr(residual),
+                                           residual.stride(0) if residual is not None else N, _ptr(row_scale), _ptr(y), N,
+                                           _stream()))
+    _with_split_weights(w, M, 0, run)
     return y
 
 
@@ -2491,8 +2521,9 @@ def _lin_dx(dy2, w, mask=None, residual=None):
     M, N = dy2.shape
     K = w.shape[1]
     dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
-    check(lib.rbx_linear_dx_fused(_ptr(dy2), dy2.stride(0), _ptr(w), M, N, K, _ptr(mask), mask.stride(0) if mask is not None else K,
-                                  _ptr(residual), residual.stride(0) if residual is not None else K, _ptr(dx), K, _stream()))
+    _with_split_weights(w, M, 1, lambda: check(lib.rbx_linear_dx_fused(
+        _ptr(dy2), dy2.stride(0), _ptr(w), M, N, K, _ptr(mask), mask.stride(0) if mask is not None else K, _ptr(residual),
+        residual.stride(0) if residual is not None else K, _ptr(dx), K, _stream())))
     return dx
 
 
@@ -2672,8 +2703,9 @@ class _DeepFmInput(torch.autograd.Function):
         N = w1.shape[0]
         F_ = fm_cols // dim
         h = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        check(_timed(("linear_fwd", M, N, K),
-                     lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, 0, _ptr(h), _stream())))
+        _with_split_weights(w1, M, 0, lambda: check(_timed(
+            ("linear_fwd", M, N, K),
+            lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, 0, _ptr(h), _stream()))))
         y_fm = torch.empty((M, 1), dtype=torch.float32, device=x.device)
         ssum = torch.empty((M, dim), dtype=torch.float32, device=x.device)
         check(lib.rbx_fm_sum_fwd(_ptr(x2), x2.stride(0), M, F_, dim, _ptr(y_fm), _ptr(ssum), _stream()))
@@ -2719,8 +2751,9 @@ class _DeepFmInput(torch.autograd.Function):
         dx = None
         if need[0]:
             dx = _padded_rows(M, K, dev)
-            check(lib.rbx_linear_dx_deepfm(_ptr(dh2), N, _ptr(w1), M, N, K, _ptr(x2), x2.stride(0), _ptr(ssum), dim, fm_cols,
-                                           _ptr(gf), _ptr(gl), _ptr(lr_w), _ptr(dx), dx.stride(0), _stream()))
+            _with_split_weights(w1, M, 1, lambda: check(lib.rbx_linear_dx_deepfm(
+                _ptr(dh2), N, _ptr(w1), M, N, K, _ptr(x2), x2.stride(0), _ptr(ssum), dim, fm_cols, _ptr(gf), _ptr(gl),
+                _ptr(lr_w), _ptr(dx), dx.stride(0), _stream())))
             dx = dx.view(xshape) if len(xshape) != 2 else dx
         return dx, dw1, db1, dlr_w, dlr_b, None, None
 
