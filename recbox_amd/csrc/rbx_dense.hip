@@ -668,6 +668,52 @@ __device__ __forceinline__ void bx6_store_b(unsigned short* __restrict__ tile, c
   }
 }
 
+template <int LIVE>
+__device__ __forceinline__ void bx6_loop(const float* __restrict__ A, const long long lda, const unsigned short* __restrict__ Bp,
+                                         const int kp, const int m0, const int n0, const int M, const int N, const int K,
+                                         unsigned short* __restrict__ As, unsigned short* __restrict__ Bs, const int wm,
+                                         const int wn, const int li, const int lk, f32x16 (&acc)[2][2]) {
+  f32x4u_t ra[4];
+  u32x4_t rb[6];
+  bx6_load_a(A, lda, m0, 0, M, K, ra);
+  bx6_load_b(Bp, kp, n0, 0, N, rb);
+  const unsigned short* ap = As + (wm + li) * SLD + 8 * lk;
+  const unsigned short* bp = Bs + (wn + li) * SLD + 8 * lk;
+  for (int k0 = 0; k0 < K; k0 += SBK) {
+    bx6_store_a(As, ra);
+    bx6_store_b(Bs, rb);
+    if (k0 + SBK < K) {                           // the next tile's reads fly under the barrier and this tile's MFMAs
+      bx6_load_a(A, lda, m0, k0 + SBK, M, K, ra);
+      bx6_load_b(Bp, kp, n0, k0 + SBK, N, rb);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < SBK / 16; ++ks) {
+      bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {                 // (only the fragments some live tile needs: the others lie outside the tile)
+          if ((LIVE >> (2 * i)) & 3) a[i][q] = *reinterpret_cast<const bf16x8_t*>(ap + q * SPLANE + i * 32 * SLD + ks * 16);
+          if ((LIVE >> i) & 5) b[i][q] = *reinterpret_cast<const bf16x8_t*>(bp + q * SPLANE + i * 32 * SLD + ks * 16);
+        }
+      // six products per output tile, the four tiles' chains interleaved (a dependent MFMA waits for its predecessor);
+      // terms in ascending size
+#define RBX_BX6_TERM(QA, QB)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
+    if ((LIVE >> (2 * i + j)) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][QA], b[j][QB], acc[i][j], 0, 0, 0)
+      RBX_BX6_TERM(2, 0);
+      RBX_BX6_TERM(0, 2);
+      RBX_BX6_TERM(1, 1);
+      RBX_BX6_TERM(1, 0);
+      RBX_BX6_TERM(0, 1);
+      RBX_BX6_TERM(0, 0);
+#undef RBX_BX6_TERM
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_bx6_kernel(const float* __restrict__ A, const long long lda,
                                                           const unsigned short* __restrict__ Bp, const int kp,
                                                           float* __restrict__ C, const long long ldc, const int M, const int N,
@@ -689,12 +735,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bx6_kernel(const float* __restric
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int li = lane & 31, lk = lane >> 5;
-  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
-  int live;
+  // a wavefront's corner in the tile and its live 32 x 32 output tiles (bit 2 i + j), as gemm_f32_kernel: an edge tile with
+  // one or two 32-blocks of real rows (columns) deals them out over all four wavefronts (N = 400: the fourth column tile
+  // holds 16 columns)
+  int wm = (wid >> 1) * 64, wn = (wid & 1) * 64, live;
   {
-    const int rows = (M - m0 - wm + 31) / 32, cols = (N - n0 - wn + 31) / 32;      // 32-blocks of this wavefront with real output
-    const int r2 = rows > 2 ? 2 : rows, c2 = cols > 2 ? 2 : cols;
-    live = (r2 <= 0 || c2 <= 0) ? 0 : (r2 == 2 && c2 == 2) ? 15 : (r2 == 2) ? 5 : (c2 == 2) ? 3 : 1;
+    const int rb = (M - m0 + 31) / 32, cb = (N - n0 + 31) / 32;
+    int rows, cols;
+    if (rb == 1 && cb > 1) { wm = 0; wn = 32 * wid; rows = 1; cols = wid < cb ? 1 : 0; }
+    else if (cb == 1 && rb > 1) { wn = 0; wm = 32 * wid; cols = 1; rows = wid < rb ? 1 : 0; }
+    else if (rb == 2 && cb > 2) { wm = 32 * (wid & 1); wn = 64 * (wid >> 1); rows = 1; cols = cb - 2 * (wid >> 1); }
+    else if (cb == 2 && rb > 2) { wn = 32 * (wid & 1); wm = 64 * (wid >> 1); cols = 1; rows = rb - 2 * (wid >> 1); }
+    else { rows = rb - wm / 32; cols = cb - wn / 32; }
+    rows = rows > 2 ? 2 : rows;
+    cols = cols > 2 ? 2 : cols;
+    live = (rows <= 0 || cols <= 0) ? 0 : (rows == 2 && cols == 2) ? 15 : (rows == 2) ? 5 : (cols == 2) ? 3 : 1;
     live = __builtin_amdgcn_readfirstlane(live);
   }
   f32x16 acc[2][2];
@@ -704,45 +759,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bx6_kernel(const float* __restric
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  f32x4u_t ra[4];
-  u32x4_t rb[6];
-  bx6_load_a(A, lda, m0, 0, M, K, ra);
-  bx6_load_b(Bp, kp, n0, 0, N, rb);
-  const unsigned short* ap = As + (wm + li) * SLD + 8 * lk;
-  const unsigned short* bp = Bs + (wn + li) * SLD + 8 * lk;
-  for (int k0 = 0; k0 < K; k0 += SBK) {
-    bx6_store_a(As, ra);
-    bx6_store_b(Bs, rb);
-    __syncthreads();
-    if (k0 + SBK < K) {                           // the next tile's reads fly under this tile's MFMAs
-      bx6_load_a(A, lda, m0, k0 + SBK, M, K, ra);
-      bx6_load_b(Bp, kp, n0, k0 + SBK, N, rb);
-    }
-#pragma unroll
-    for (int ks = 0; ks < SBK / 16; ++ks) {
-      bf16x8_t a[2][3], b[2][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          a[i][q] = *reinterpret_cast<const bf16x8_t*>(ap + q * SPLANE + i * 32 * SLD + ks * 16);
-          b[i][q] = *reinterpret_cast<const bf16x8_t*>(bp + q * SPLANE + i * 32 * SLD + ks * 16);
-        }
-      // six products per output tile, the four tiles' chains interleaved (a dependent MFMA waits for its predecessor);
-      // terms in ascending size
-#define RBX_BX6_TERM(QA, QB)                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
-    if ((live >> (2 * i + j)) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][QA], b[j][QB], acc[i][j], 0, 0, 0)
-      RBX_BX6_TERM(2, 0);
-      RBX_BX6_TERM(0, 2);
-      RBX_BX6_TERM(1, 1);
-      RBX_BX6_TERM(1, 0);
-      RBX_BX6_TERM(0, 1);
-      RBX_BX6_TERM(0, 0);
-#undef RBX_BX6_TERM
-    }
-    __syncthreads();
-  }
+  // (one copy of the k loop per set of live output tiles: a test per MFMA is two scalar instructions beside each of them)
+  if (live == 15) bx6_loop<15>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 5) bx6_loop<5>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 3) bx6_loop<3>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 1) bx6_loop<1>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else bx6_loop<0>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
   gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi);
 }
 
