@@ -482,15 +482,21 @@ def run_model_config(args, rank, world, dev):
     el = time.perf_counter() - t0
     if step is not eager_step:
         # the replay cannot be bracketed: time the dominant kernel with HIP events over eager steps queued behind fills
-        n_timed = min(args.steps, 10)
-        ballast = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-        for _ in range(40):
-            ballast.zero_()
-        ops.kernel_timer = timer
-        for i in range(n_timed):
-            refill(args.warmup + args.steps + i)
-            eager_step()
-        torch.cuda.synchronize()
+        # (on the stream the captured steps' autograd nodes live on: a backward on another stream than a parameter's
+        #  AccumulateGrad node makes the engine sync the two and warn)
+        import contextlib
+        from recbox_amd import graph as graph_mod
+        on_stream = torch.cuda.stream(graph_mod._capture_stream()) if not sharded else contextlib.nullcontext()
+        with on_stream:
+            n_timed = min(args.steps, 10)
+            ballast = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            for _ in range(40):
+                ballast.zero_()
+            ops.kernel_timer = timer
+            for i in range(n_timed):
+                refill(args.warmup + args.steps + i)
+                eager_step()
+            torch.cuda.synchronize()
         del ballast
     ops.kernel_timer = None
     if world > 1:
@@ -846,35 +852,41 @@ def main():
         # Launched eagerly the step is host-bound (the GPU idles between kernels and the kernel would be timed on a
         # drained, down-clocked device), so the stream is first loaded with ~15 ms of fills: the eager launches then
         # queue up behind them and run back to back, as in the replay.  Events are in-stream: they bracket the kernel only.
-        n_timed = min(args.steps, 10)
-        ballast = torch.empty(1 << 28, dtype=torch.float32, device=dev)          # 1 GiB
-        for _ in range(80):
-            ballast.zero_()
-        ops.kernel_timer = timer
-        for i in range(n_timed):
-            refill(args.warmup + args.steps + i)
-            eager_step()
-        torch.cuda.synchronize()
-        if ops.config.sort_before_forward and not sharded:
-            # the same kernel WITHOUT the id sort / re-zero of the backward running beside it (they are enqueued after
-            # the forward instead): frac_alone, the kernel's own rate
+        # (on the stream the captured steps' autograd nodes live on: a backward on another stream than a parameter's
+        #  AccumulateGrad node makes the engine sync the two and warn)
+        import contextlib
+        from recbox_amd import graph as graph_mod
+        on_stream = torch.cuda.stream(graph_mod._capture_stream()) if not sharded else contextlib.nullcontext()
+        with on_stream:
+            n_timed = min(args.steps, 10)
+            ballast = torch.empty(1 << 28, dtype=torch.float32, device=dev)          # 1 GiB
             for _ in range(80):
                 ballast.zero_()
-            ops.config.sort_before_forward = False
-            ops.kernel_timer = alone_timer
+            ops.kernel_timer = timer
             for i in range(n_timed):
-                refill(args.warmup + args.steps + n_timed + i)
+                refill(args.warmup + args.steps + i)
                 eager_step()
             torch.cuda.synchronize()
-            ops.config.sort_before_forward = True
-        if K > 1:
-            # the same kernel on ONE batch replayed (rows of the previous launch still in the Infinity Cache): frac_warm
-            for _ in range(80):
-                ballast.zero_()
-            ops.kernel_timer = warm_timer
-            for i in range(n_timed):
-                eager_step()
-            torch.cuda.synchronize()
+            if ops.config.sort_before_forward and not sharded:
+                # the same kernel WITHOUT the id sort / re-zero of the backward running beside it (they are enqueued after
+                # the forward instead): frac_alone, the kernel's own rate
+                for _ in range(80):
+                    ballast.zero_()
+                ops.config.sort_before_forward = False
+                ops.kernel_timer = alone_timer
+                for i in range(n_timed):
+                    refill(args.warmup + args.steps + n_timed + i)
+                    eager_step()
+                torch.cuda.synchronize()
+                ops.config.sort_before_forward = True
+            if K > 1:
+                # the same kernel on ONE batch replayed (rows of the previous launch still in the Infinity Cache): frac_warm
+                for _ in range(80):
+                    ballast.zero_()
+                ops.kernel_timer = warm_timer
+                for i in range(n_timed):
+                    eager_step()
+                torch.cuda.synchronize()
         del ballast
     ops.kernel_timer = None
     if world > 1:

@@ -1,0 +1,11 @@
+#!/bin/bash
+cd /root/repo
+timeout 600 python bench.py --no-cpu-baseline --no-extra-configs 2>/tmp/err.txt | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('fm', round(d['ms_per_step'],4), round(d['roofline']['frac'],3))"
+grep -c "AccumulateGrad" /tmp/err.txt
+timeout 600 python bench.py --config youtubednn --no-cpu-baseline 2>/tmp/err2.txt | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('yt', round(d['ms_per_step'],4))"
+grep -c "AccumulateGrad" /tmp/err2.txt
+timeout 900 python -m pytest tests/test_gpu_ranking.py tests/test_gpu_optim.py -x -q 2>&1 | tail -3
