@@ -607,6 +607,7 @@ size_t rbx_split_bf16_size(int32_t rows, int32_t cols, int32_t transpose);
 int rbx_split_bf16(const float* d_src, int64_t ld, int32_t rows, int32_t cols, int32_t transpose, void* d_out, void* stream);
 int rbx_split_register(const float* d_w, const void* d_planes, int32_t rows, int32_t cols, int32_t transposed);
 int rbx_split_unregister(const float* d_w);
+uint64_t rbx_gemm_bx6_count(void);      /* GEMM calls that ran on the split-operand kernel so far (tests, logs) */
 
 /* ---- K6: fused masked-softmax attention for short sequences (L <= 256, head_dim in {4..64}) ----
  * ranking/pytorch/layers/attentions/dot_product_attention.py:31-43 (ScaledDotProductAttention) and the

@@ -28,6 +28,14 @@ RBX_FM_TIER_A=0 timeout 600 python bench.py --no-cpu-baseline > $out/bench_fm_on
 RBX_FM_TIER_A_VMAX=16384 timeout 600 python bench.py --no-cpu-baseline > $out/bench_fm_vmax16384.json 2>/dev/null; ms fm_vmax16384
 RECBOX_AMD_FM_REZERO_ON=side timeout 600 python bench.py --no-cpu-baseline > $out/bench_fm_rezero_beside.json 2>/dev/null; ms fm_rezero_beside
 RECBOX_AMD_FM_TWO_CHAINS=0 timeout 600 python bench.py --no-cpu-baseline > $out/bench_fm_one_chain.json 2>/dev/null; ms fm_one_chain
+# SASRec / DeepFM: what this round's kernels are worth, one switch at a time
+RBX_GEMM_STREAM64=0 timeout 600 python bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_sasrec_tile_gemm.json 2>/dev/null; ms sasrec_tile_gemm
+RECBOX_AMD_SHARE_TABLE_GRADS=0 timeout 600 python bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_sasrec_two_grads.json 2>/dev/null; ms sasrec_two_grads
+RECBOX_AMD_GEMM_BX6=0 timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_f32_mfma.json 2>/dev/null; ms deepfm_f32_mfma
+RECBOX_AMD_GEMM_BX6=0 timeout 600 python bench.py --config youtubednn --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_youtubednn_f32_mfma.json 2>/dev/null; ms youtubednn_f32_mfma
+for v in 1 0; do
+  RECBOX_AMD_GEMM_BX6=$v PYTHONPATH=/root/repo timeout 300 python profiles/gemm_shapes.py 2>&1 | grep -v amdgpu.ids > $out/gemm_shapes_bx6_$v.txt
+done
 for o in sparse_adam dense_adam; do
   timeout 900 python bench.py --config youtubednn --no-cpu-baseline --optimizer $o --steps 20 --warmup 5 > $out/bench_youtubednn_$o.json 2>/dev/null; ms youtubednn_$o
   timeout 900 python bench.py --config deepfm --no-cpu-baseline --optimizer $o --steps 20 --warmup 5 > $out/bench_deepfm_$o.json 2>/dev/null; ms deepfm_$o
@@ -46,6 +54,12 @@ prof youtubednn "--config youtubednn --steps 20 --warmup 5"
 prof deepfm "--config deepfm --steps 20 --warmup 5"
 prof sasrec "--config sasrec --steps 20 --warmup 5"
 prof youtubednn_sharded1 "--config youtubednn --force-sharded --steps 20 --warmup 5"
+# MFMA pipe utilisation of the tower / attention kernels
+for cfg in deepfm sasrec; do
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $out/pmc_mfma_$cfg -o b -- python /root/repo/bench.py --config $cfg --eager --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1)
+  python profiles/mfma_util.py $(find $out/pmc_mfma_$cfg -name "*.db" | head -1) > $out/mfma_util_$cfg.txt 2>&1
+  rm -rf $out/pmc_mfma_$cfg
+done
 # the pieces of the FM step, each alone
 python profiles/ubench/fm_bwd_parts.py 20 2>&1 | grep -v "Warn\|amdgpu.ids" > $out/fm_step_pieces_alone.txt
 rm -rf $out/prof

@@ -155,6 +155,7 @@ SIGNATURES = {
     "rbx_split_bf16": (ctypes.c_int, [_P, _i64, _i32, _i32, _i32, _P, _P]),
     "rbx_split_register": (ctypes.c_int, [_P, _P, _i32, _i32, _i32]),
     "rbx_split_unregister": (ctypes.c_int, [_P]),
+    "rbx_gemm_bx6_count": (ctypes.c_uint64, []),
     "rbx_attn_fwd": (ctypes.c_int, [_P, _P, _P, _P, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _P, _P, _P, _P]),
     "rbx_attn_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _i64, _i32, _i32, _i32, _f32, _i32, _f32,
                                     _P, _P, _P, _P, _P]),

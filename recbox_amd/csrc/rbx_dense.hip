@@ -24,6 +24,7 @@
 // order (deterministic, no float atomics).  What was measured on the way:
 // profiles/r02/gemm_variants.txt.
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include "rbx_internal.h"
@@ -1589,6 +1590,7 @@ struct SplitEntry {
 constexpr int kSplitSlots = 16;
 static SplitEntry g_split[kSplitSlots];
 static std::mutex g_split_mu;
+static std::atomic<unsigned long long> g_bx6_launches{0};     // observability: GEMMs that ran on the split-operand kernel
 static bool split_find(const float* w, int transposed, int rows, int cols, SplitEntry* out) {
   std::lock_guard<std::mutex> lock(g_split_mu);
   for (int i = 0; i < kSplitSlots; ++i)
@@ -1683,6 +1685,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
       const int kp = (K + SBK - 1) / SBK * SBK;
       hipLaunchKernelGGL(gemm_bx6_kernel, dim3(tn * tm), dim3(256), 0, s, A, lda, e.planes, kp, C, ldc, M, N, K, bias, act, tm,
                          tn, epi);
+      g_bx6_launches.fetch_add(1, std::memory_order_relaxed);
       return check_launch("gemm_bx6_kernel");
     }
   }
@@ -2000,6 +2003,8 @@ extern "C" int rbx_split_register(const float* d_w, const void* d_planes, int32_
   g_split[slot] = SplitEntry{d_w, static_cast<const unsigned short*>(d_planes), rows, cols, transposed ? 1 : 0};
   return RBX_OK;
 }
+
+extern "C" uint64_t rbx_gemm_bx6_count(void) { return rbx::g_bx6_launches.load(std::memory_order_relaxed); }
 
 extern "C" int rbx_split_unregister(const float* d_w) {
   using namespace rbx;

@@ -1396,6 +1396,11 @@ def _with_split_weights(w, M, transposed, call):
         lib.rbx_split_unregister(_ptr(w))
 
 
+def gemm_bx6_count():
+    """GEMM calls that have run on the split-operand bf16 kernel so far (observability: tests, logs)."""
+    return int(lib.rbx_gemm_bx6_count())
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) via rbx_linear_fwd; act in {None, "relu"} is fused into the epilogue.  x may be a column
     block of a wider row-major activation (row stride > K): it is read, and its gradient written, in place."""

@@ -174,6 +174,39 @@ def test_linear_epilogue_operands_on_every_tile_kind(M, N, K):
     assert_close(got, ((dy.double() @ w.double()) + res2.double()).float(), 2e-5 * max(1.0, N ** 0.5 / 8), "dx + residual")
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 400, 1677), (4100, 130, 257), (16384, 256, 512)])
+def test_split_bf16_gemm_runs_and_is_as_accurate_as_the_f32_mfma(M, N, K):
+    """y = x W^T and dx = dy W of a compute-bound tower layer run on the bf16 matrix cores (weights split into three bf16
+    planes by rbx_split_bf16, activations inside gemm_bx6_kernel, six products per f32 product): the launch counter moves,
+    and the error against float64 is of the size of the f32-MFMA kernel's own -- also for one-signed operands (ReLU
+    outputs against positive weights), where a biased split would show."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.rand(M, K, generator=g)                      # one-signed, like ReLU outputs
+    w = torch.rand(N, K, generator=g) / K
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    y64 = x.double() @ w.double().t() + b.double()
+    dx64 = dy.double() @ w.double()
+    xc, wc, bc, dyc = x.cuda(), w.cuda(), b.cuda(), dy.cuda()
+    old = ops.config.gemm_bx6
+    try:
+        ops.config.gemm_bx6 = False
+        y32, dx32 = ops._lin_fwd(xc, wc, bc), ops._lin_dx(dyc, wc)
+        ops.config.gemm_bx6 = True
+        n0 = ops.gemm_bx6_count()
+        y6, dx6 = ops._lin_fwd(xc, wc, bc), ops._lin_dx(dyc, wc)
+        assert ops.gemm_bx6_count() == n0 + int(K >= 256 and N >= 128) + int(N >= 256 and K >= 128)   # (ops._with_split_weights)
+    finally:
+        ops.config.gemm_bx6 = old
+    for name, got6, got32, want in (("y", y6, y32, y64), ("dx", dx6, dx32, dx64)):
+        e6 = float((got6.double().cpu() - want).abs().max())
+        e32 = float((got32.double().cpu() - want).abs().max())
+        scale = float(want.abs().max())
+        assert e6 <= max(4.0 * e32, 2e-6 * scale), (name, e6, e32, scale)
+        assert e6 <= 1e-5 * scale, (name, e6, scale)
+
+
 def test_sdpa_and_losses_golden():
     import recbox_amd.ranking.pytorch.layers as L
     fx = Fixture("attention_losses")
