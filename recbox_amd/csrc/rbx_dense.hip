@@ -1444,6 +1444,116 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_k64n64_kernel(
   }
 }
 
+// The same slab form for [M, 64] x [64 -> 128] (NT = 4: SASRec's fused K | V projection, sasrec.py:81-87 via
+// nn.MultiheadAttention's in_proj) and [M, 128] x [128 -> 64] (KH = 2: its dx): W no longer fits the registers beside the
+// slab, so it sits in LDS once per workgroup ([k][n], 33-35 KB) and an MFMA step reads its B operand from there (one b32
+// per lane: 32 consecutive floats per half-wave, conflict-free).  A 128-wide row is fetched as two 64-wide halves (each
+// request still covers whole 256-byte runs) and turned one after the other through the same 8.5 KB of LDS, their products
+// landing in the same accumulators.  Epilogue: bias, ReLU, residual.
+template <int KH, int NT, bool B_KCONTIG, bool HAS_RES>
+__global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_slabw_kernel(
+    const float* __restrict__ A, const long long lda, const float* __restrict__ B, const long long ldb, float* __restrict__ C,
+    const long long ldc, const int M, const float* __restrict__ bias, const int act, const Epi epi) {
+  constexpr int K = 64 * KH, N = 32 * NT, WLD = N + 4;
+  __shared__ float slab[kSlabWaves][32 * kSlabLd];
+  __shared__ float wl[K * WLD];
+  for (int e = threadIdx.x; e < K * N; e += 64 * kSlabWaves) {
+    int k, n;
+    if constexpr (B_KCONTIG) { n = e / K; k = e % K; }       // B(k, n) = B[n * ldb + k]
+    else { k = e / N; n = e % N; }                           // B(k, n) = B[k * ldb + n]
+    wl[k * WLD + n] = B_KCONTIG ? B[static_cast<long long>(n) * ldb + k] : B[static_cast<long long>(k) * ldb + n];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nw = static_cast<int>(gridDim.x) * kSlabWaves;
+  const int slabs = (M + 31) >> 5;
+  int s = static_cast<int>(blockIdx.x) * kSlabWaves + wid;
+  if (s >= slabs) return;
+  float* lds = slab[wid];
+  unsigned off_full[8], off[8];
+  slab_offsets(lda, 32, lane, off_full);
+  f32x4 nx[KH][8];
+  auto issue = [&](int sl) {
+    const int left = M - sl * 32;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) off[p] = off_full[p];
+    if (left < 32) slab_offsets(lda, left, lane, off);
+#pragma unroll
+    for (int hf = 0; hf < KH; ++hf) slab_issue(A + static_cast<long long>(sl) * 32 * lda + 64 * hf, off, nx[hf]);
+  };
+  auto arrived = [&]() {
+#pragma unroll
+    for (int hf = 0; hf < KH; ++hf) slab_arrived(nx[hf]);
+  };
+  issue(s);
+  float bv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bv[t] = bias != nullptr ? bias[32 * t + m] : 0.f;
+  const long long c_lane = (4LL * h * ldc + m) * 4;
+  const long long res_lane = HAS_RES ? (4LL * h * epi.ldres + m) * 4 : 0;
+  const float* wp = wl + 32 * h * WLD + m;
+  float a[KH][32];
+  arrived();
+#pragma unroll
+  for (int hf = 0; hf < KH; ++hf) slab_turn(lds, lane, nx[hf], a[hf]);
+  for (;;) {
+    const int r0 = s * 32;
+    int sn = s + nw;
+    const bool more = sn < slabs;
+    sn = more ? sn : s;
+    issue(sn);
+    const int left = M - r0;
+    const bool full = left >= 32;
+    f32x16 res[NT];
+    if constexpr (HAS_RES) {
+      const char* base = reinterpret_cast<const char*>(epi.res + static_cast<long long>(r0) * epi.ldres) + res_lane;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = (full || slab_row(i) + 4 * h < left) ? slab_row(i) : 0;
+        const float* q = reinterpret_cast<const float*>(base + static_cast<long long>(k) * epi.ldres * 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) res[t][i] = __builtin_nontemporal_load(q + 32 * t);
+      }
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+    for (int hf = 0; hf < KH; ++hf)
+#pragma unroll
+      for (int j = 0; j < 32; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[hf][j], wp[(64 * hf + j) * WLD + 32 * t], acc[t], 0, 0, 0);
+    char* cbase = reinterpret_cast<char*>(C + static_cast<long long>(r0) * ldc) + c_lane;
+    auto finish = [&](auto guarded) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (!decltype(guarded)::value || slab_row(i) + 4 * h < left) {
+          float* q = reinterpret_cast<float*>(cbase + static_cast<long long>(slab_row(i)) * ldc * 4);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            float v = acc[t][i] + bv[t];
+            if (act == 1) v = v > 0.f ? v : 0.f;
+            if constexpr (HAS_RES) v += res[t][i];
+            q[32 * t] = v;
+          }
+        }
+      }
+    };
+    if (full) finish(std::false_type{});
+    else finish(std::true_type{});
+    arrived();
+    if (!more) break;
+#pragma unroll
+    for (int hf = 0; hf < KH; ++hf) slab_turn(lds, lane, nx[hf], a[hf]);
+    s = sn;
+  }
+}
+
 // dW[64, 64] = g^T x and db = column sums of g over hundreds of thousands of rows, in the slab form of the kernel above:
 // a wavefront fetches 32-row slabs of g and x as fully coalesced 1 KB requests (the next slab's are in flight under the
 // current one's MFMAs), parks them in its own 2 x 8.5 KB of LDS and feeds v_mfma_f32_32x32x2_f32 from there --
@@ -1677,6 +1787,19 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     }
 #undef RBX_K64
     return check_launch("gemm_f32_k64n64_kernel");
+  }
+  // 64 -> 128 and 128 -> 64 over many rows: the slab kernel with the weights in LDS
+  if (AK && splits == 1 && epi.fm_x == nullptr && epi.mask == nullptr && epi.rowscale == nullptr && M >= 2048 &&
+      vec_ok(A, lda) && stream64_mode() > 0 && ((K == 64 && N == 128) || (K == 128 && N == 64))) {
+    const int slabs = (M + 31) / 32;
+    int wgs = (slabs + kSlabWaves - 1) / kSlabWaves;
+    if (wgs > 2 * kCUs) wgs = 2 * kCUs;
+    const dim3 grid(wgs), block(64 * kSlabWaves);
+#define RBX_SLABW(KH_, NT_, R) hipLaunchKernelGGL((gemm_f32_slabw_kernel<KH_, NT_, BK_, R>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, bias, act, epi)
+    if (K == 64) { if (epi.res != nullptr) RBX_SLABW(1, 4, true); else RBX_SLABW(1, 4, false); }
+    else { if (epi.res != nullptr) RBX_SLABW(2, 2, true); else RBX_SLABW(2, 2, false); }
+#undef RBX_SLABW
+    return check_launch("gemm_f32_slabw_kernel");
   }
   // weights with registered bf16 planes: the split-operand kernel on the bf16 matrix cores
   if (AK && splits == 1 && bx6_mode() > 0) {
@@ -1927,6 +2050,22 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
                        static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr, dw64_abl());
     launch_splitk_reduce(s, 64u, ws, 64LL * 64, n_wg, d_dw, d_db != nullptr ? part : nullptr, 64LL, d_db);
     return check_launch("tall dW / db kernels (slab form)");
+  }
+  if (d_dw != nullptr && n == 128 && k == 64 && m >= 8192 && vec_ok(g, n) && vec_ok(d_x, x_stride) && stream64_mode() > 0 &&
+      dw_floats >= static_cast<size_t>(2 * kCUs) * 64 * 64) {
+    // [m, 128]^T x [m, 64] (the fused K | V projection): the slab kernel once per 64-column half of g (x read twice: 840 MB
+    // of coalesced 1 KB requests against tall_dw_kernel<2>'s 630 MB of dword requests, 150 vs 199 us)
+    const int slabs = (M + 31) / 32;
+    int n_wg = (slabs + kSlabWaves - 1) / kSlabWaves;
+    if (n_wg > 2 * kCUs) n_wg = 2 * kCUs;
+    float* part = ws + dw_floats;
+    for (int half = 0; half < 2; ++half) {
+      hipLaunchKernelGGL(tall_dw64_kernel, dim3(n_wg), dim3(64 * kSlabWaves), 0, s, g + 64 * half, static_cast<long long>(n),
+                         d_x, static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr, 0);
+      launch_splitk_reduce(s, 64u, ws, 64LL * 64, n_wg, d_dw + static_cast<long long>(half) * 64 * k,
+                           d_db != nullptr ? part : nullptr, 64LL, d_db != nullptr ? d_db + 64 * half : nullptr);
+    }
+    return check_launch("tall dW / db kernels (slab form, two halves)");
   }
   if (d_dw != nullptr && n <= 256 && k <= 64 && m >= 8192) {
     // tall and narrow: one streaming pass over g and x leaves dW and db partials per workgroup (tall_dw_kernel)

@@ -107,7 +107,9 @@ def test_mlp_golden():
                                        (9000, 40, 24, "relu"), (8192, 16, 2496, None),
                                        # tall and narrow (SASRec's [B*L, 64] x [64, 64]): the streaming dW / db kernel,
                                        # full and ragged quadrants, a row count that is no multiple of anything
-                                       (20001, 64, 64, None), (20011, 64, 64, "relu"), (8192, 33, 64, "relu"), (12345, 64, 20, None),
+                                       (20001, 64, 64, None), (20011, 64, 64, "relu"), (8192, 33, 64, "relu"),
+                                       # 64 -> 128 and 128 -> 64 (the fused K | V projection and its dx): weights in LDS
+                                       (20011, 128, 64, "relu"), (70007, 64, 128, None), (12345, 64, 20, None),
                                        (9999, 7, 5, None), (10000, 192, 64, None), (8200, 130, 33, "relu"), (8192, 256, 64, None),
                                        # logit heads (n == 1): the streaming GEMV / outer-product / weighted column-sum kernels
                                        (70001, 1, 400, None), (5000, 1, 1664, None), (3001, 1, 37, "relu"), (2, 1, 7, None),
@@ -139,7 +141,7 @@ def test_linear_matches_torch_fp32(M, N, K, act):
 
 
 @pytest.mark.parametrize("M,N,K", [(4100, 168, 70), (300, 400, 64), (4224, 256, 48), (129, 130, 17), (8192, 64, 64),
-                                   (70007, 64, 64)])
+                                   (70007, 64, 64), (20011, 128, 64), (20011, 64, 128)])
 def test_linear_epilogue_operands_on_every_tile_kind(M, N, K):
     """The optional tail of the GEMM epilogue -- y = (act(x W^T + b) + residual) * row_scale[row] (rbx_linear_fwd_fused) and
     dx = ((dy W) o [mask > 0]) + residual (rbx_linear_dx_fused) -- on interior tiles (operands fetched four outputs at a
