@@ -117,7 +117,7 @@ struct BwdPlan {
   int max_dim = 1;
   bool vec = true;
   // workspace layout (byte offsets)
-  size_t off_keys[2], off_vals[2], off_hist, off_ssum, off_head, off_tail, off_flags, off_fin, off_num, bytes;
+  size_t off_keys[2], off_vals[2], off_hist, off_ssum, off_head, off_tail, off_flags, off_fin, off_long, off_num, bytes;
   unsigned n_tiles = 0, n_chunks = 0, num_blocks = 0;
   unsigned long_cap = kCUs * 2;  // workgroups of the long fix-up launch (one per long chain, grid-stride): every one of them
                                // arrives at one counter, so a plan that expects no long chains (fused FM with its small tables

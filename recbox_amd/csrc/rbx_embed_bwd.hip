@@ -184,7 +184,9 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
   p->off_head = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
   p->off_tail = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
   p->off_flags = o; o += align_up(static_cast<size_t>(p->n_chunks) * 4, 256);
-  p->off_fin = o; o += align_up((2 * static_cast<size_t>(p->n_chunks) + 3) * 4, 256);   // 3 counters, short list, long list
+  // 3 counters, short list, long list, arrival counters of long chains that several workgroups share
+  p->off_fin = o; o += align_up((2 * static_cast<size_t>(p->n_chunks) + 3 + kLongSlots) * 4, 256);
+  p->off_long = o; o += align_up(static_cast<size_t>(kLongSlots) * p->sum_stride * 4, 256);      // ... and their partials
   p->off_num = o; o += align_up(static_cast<size_t>(p->n_num) * p->num_blocks * p->max_dim * 4, 256);
   p->bytes = o + 256;
   return RBX_OK;

@@ -26,6 +26,8 @@ __device__ __forceinline__ void frag_add(F& a, const F& b) {
   for (int q = 0; q < static_cast<int>(sizeof(a.a) / sizeof(float)); ++q) a.a[q] += b.a[q];
 }
 
+constexpr unsigned kLongSlots = 512;  // long chains that may be shared between workgroups (one arrival counter + partials each)
+constexpr unsigned kLongSplit = 16;   // workgroups per long chain at most
 constexpr int kFinList = 3;      // fin[0] work-list length, fin[1] long-list length, fin[2] arrival counter, then the lists
 // Interior runs are written directly; a run that crosses the chunk border leaves a head /
 // tail summary and a flag, and the chunk where such a run ENDS is queued for the fix-up.
@@ -204,7 +206,11 @@ __global__ __launch_bounds__(256) void segment_fixup_short_kernel(const RedPack 
       if (!(flags[j] & kFlagPass)) { closed = true; break; }
     }
     if (!closed && c > 0) {
-      if (lane_g == 0) fin[kFinList + n_chunks + atomicAdd(fin + 1, 1u)] = c;
+      if (lane_g == 0) {
+        const unsigned pos = atomicAdd(fin + 1, 1u);
+        fin[kFinList + n_chunks + pos] = c;
+        if (pos < kLongSlots) fin[kFinList + 2 * n_chunks + pos] = 0;      // arrival counter of a chain shared by several workgroups
+      }
       continue;
     }
     const unsigned s = c * chunk;
@@ -227,12 +233,18 @@ __global__ __launch_bounds__(256) void segment_fixup_short_kernel(const RedPack 
   }
 }
 
-// pass 2: one WORKGROUP per long chain: its 256/G lane groups walk the pass-through chunks
+// pass 2: long chains, workgroup-cooperative: the 256/G lane groups of a workgroup walk the pass-through chunks
 // backwards 256/G tails per step (flags first, a ballot + LDS min finds where the run
 // started); partial sums are combined by a fixed xor butterfly inside each wave and a fixed
 // wave order across waves, so the result is order-deterministic.  A 21 845-lookup run
 // (V=3 at B=65 536) is 683 chunks = 2 window steps of 512 chunks at D=16 instead of 683 dependent loads;
 // a 370 000-lookup run (the pad id of SASRec's [4096, 200] id blocks) is 90 steps.
+// When the launch has more workgroups than long chains (a FEW hot rows: one item with 10^5 .. 10^6 non-zero gradients),
+// KW = min(16, workgroups / chains) of them share a chain: workgroup jw takes every KW-th window (a window belongs to the
+// chain iff the last sorted pair of its nearest chunk carries the chain's key: one load), leaves its partial in a slot of
+// its own, and the LAST one to arrive (one counter per chain, zeroed when the chain was listed) adds the KW partials in
+// slot order and flushes the row.  KW depends on the number of chains and the launch only, every partial on (chain, jw, KW)
+// only: the same bits from run to run, whichever workgroup finishes.
 template <class Policy, int G, int NV, bool VEC>
 __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P, const typename Policy::Args args,
                                                                  const unsigned* __restrict__ keys,
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
                                                                  const int* __restrict__ flags,
                                                                  unsigned* __restrict__ fin, const int max_dim,
                                                                  const int sum_stride, const unsigned n_chunks,
-                                                                 const unsigned chunk) {
+                                                                 const unsigned chunk, float* __restrict__ lpart) {
   using F = Frag<G, NV, VEC>;
   constexpr int NGB = 256 / G;          // lane groups per workgroup
   // chunks per lane group and step: a window of ~512 chunks whatever G is (independent loads, few barriers)
@@ -251,26 +263,61 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
   constexpr int kNone = 1 << 30;
   __shared__ int s_stop[4];
   __shared__ float s_part[4][G * NA + 1];
+  __shared__ unsigned s_last;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int gi = threadIdx.x / G, lane_g = threadIdx.x % G;
   const unsigned count = fin[1];
-  for (unsigned idx = blockIdx.x; idx < count; idx += gridDim.x) {
+  unsigned KW = 1;
+  if (count > 0 && count <= kLongSlots && count * 2 <= gridDim.x && lpart != nullptr) {
+    KW = gridDim.x / count;
+    KW = KW > kLongSplit ? kLongSplit : KW;
+    if (count * KW > kLongSlots) KW = 1;                   // (one partial slot per work item)
+  }
+  unsigned* lcnt = fin + kFinList + 2 * static_cast<size_t>(n_chunks);
+  const unsigned items = count * KW;
+  for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
+    const unsigned idx = item / KW, jw = item % KW;
     const unsigned c = fin[kFinList + n_chunks + idx];
     const unsigned s = c * chunk;
     const unsigned key = keys[s];
+    // how many of the KW workgroups this chain is worth: one per two windows (a chain of a few hundred chunks -- a table
+    // of three rows at B = 65 536 -- stays with one workgroup: partial slots, fences and the arrival counter cost more
+    // than its one or two window steps).  Its first chunk: lower bound over the chunks' last keys.
+    unsigned kw = 1;
+    if (KW > 1) {
+      if (threadIdx.x == 0) {
+        unsigned lo = 0, hi = c;
+        while (lo < hi) {
+          const unsigned mid = (lo + hi) >> 1;
+          if (keys[(static_cast<size_t>(mid) + 1) * chunk - 1] >= key) hi = mid;
+          else lo = mid + 1;
+        }
+        unsigned w = ((c - lo + NGB * R - 1) / (NGB * R)) / 2;
+        s_last = w < 1 ? 1u : (w > KW ? KW : w);
+      }
+      __syncthreads();
+      kw = s_last;
+      __syncthreads();
+      if (jw >= kw) continue;
+    }
     const RedField fd = P.f[vals[s] >> kLocalBits];
     F acc, pre;
     acc.zero();
     pre.zero();
     float cnt = 0.f;
-    if (gi == 0) {
-      Policy::prefetch(args, fd, key - fd.row_base, lane_g, pre);
+    if (gi == 0 && jw == 0) {
+      if (kw == 1) Policy::prefetch(args, fd, key - fd.row_base, lane_g, pre);
       const float* src = head + static_cast<size_t>(c) * sum_stride;
       acc.add_from(src, fd.dim, lane_g);
       if (Policy::kHasCount) cnt = src[max_dim];
     }
-    long long jbase = static_cast<long long>(c) - 1;
-    while (true) {
+    long long jbase = static_cast<long long>(c) - 1 - static_cast<long long>(jw) * (NGB * R);
+    bool adjoining = jw == 0;                 // the chain's own first window needs no test
+    while (jbase >= 0) {
+      // (with several workgroups per chain a window does not follow from the previous one's flags: it belongs to this
+      //  chain iff its nearest chunk ends in the chain's key)
+      if (!adjoining && keys[(static_cast<size_t>(jbase) + 1) * chunk - 1] != key) break;
+      adjoining = kw == 1;
       // lane group gi looks at the R chunks jbase - gi*R - r (r = 0..R-1): a window of NGB * R chunks per step
       int fl[R];
       int first_stop = kNone;                              // window distance of the first chunk that ends the walk
@@ -330,9 +377,38 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
       }
       __syncthreads();
       if (t != kNone) break;
-      jbase -= NGB * R;
+      jbase -= static_cast<long long>(kw) * (NGB * R);
     }
-    if (gi == 0) Policy::flush(args, fd, key - fd.row_base, acc, cnt, pre, lane_g);
+    if (kw == 1) {
+      if (gi == 0) Policy::flush(args, fd, key - fd.row_base, acc, cnt, pre, lane_g);
+      continue;
+    }
+    // several workgroups share this chain: leave the partial, the last one to arrive finishes the row
+    if (gi == 0) {
+      float* slot = lpart + static_cast<size_t>(item) * sum_stride;
+      acc.store(slot, fd.dim, lane_g);
+      if (Policy::kHasCount && lane_g == 0) slot[max_dim] = cnt;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(lcnt + idx, 1u) == kw - 1) ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      if (gi == 0) {
+        F tot;
+        tot.zero();
+        float tc = 0.f;
+        Policy::prefetch(args, fd, key - fd.row_base, lane_g, pre);
+        for (unsigned w = 0; w < kw; ++w) {                 // slot order: fixed
+          const float* slot = lpart + (static_cast<size_t>(idx) * KW + w) * sum_stride;
+          tot.add_from(slot, fd.dim, lane_g);
+          if (Policy::kHasCount) tc += slot[max_dim];
+        }
+        Policy::flush(args, fd, key - fd.row_base, tot, tc, pre, lane_g);
+      }
+    }
+    __syncthreads();
   }
   // the last workgroup to get here clears the counters: the workspace is ready for another backward on the same
   // sorted ids (build_keys clears them for a new sort), and no memset node sits between the sort and the reduce
@@ -373,7 +449,7 @@ static int launch_reduce(const BwdPlan& p, const typename Policy::Args& args, co
   if (long_blocks > p.long_cap) long_blocks = p.long_cap;
   hipLaunchKernelGGL((segment_fixup_long_kernel<Policy, G, NV, VEC>), dim3(long_blocks), dim3(256), 0, s, p.red, args,
                      keys, vals, head, tail, flags, fin, p.max_dim, p.sum_stride, p.n_chunks,
-                     static_cast<unsigned>(p.chunk));
+                     static_cast<unsigned>(p.chunk), reinterpret_cast<float*>(ws + p.off_long));
   return check_launch("segment_fixup kernels");
 }
 
