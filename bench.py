@@ -138,10 +138,10 @@ def cpu_baseline(dim, B, dist, budget_s):
 
 def measured_traffic(path, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/traffic_r01.json; FETCH_SIZE / WRITE_SIZE are collected in separate runs and
+    (profiles/r03/traffic_r03.json; FETCH_SIZE / WRITE_SIZE are collected in separate runs and
     corrected as MI355X_MICROARCH.md prescribes).  None when no measurement is on file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02", "traffic_r02.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r03", "traffic_r03.json")) as fh:
             rec = json.load(fh)
         ent = rec.get({"fused": "fm"}.get(path, path), {})
         if kernel is not None and ent.get("kernel") != kernel:
@@ -1016,8 +1016,8 @@ def extra_configs(args):
                 res[cfg] = {"skipped": "exit code %d: %s" % (proc.returncode, proc.stderr.strip().splitlines()[-1:] or "")}
             else:
                 d = json.loads(line[-1])
-                res[cfg] = {k: d[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "dtype", "config", "roofline",
-                                              "cpu_baseline") if k in d}
+                res[cfg] = {k: d[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "dtype", "dtype_note", "config",
+                                              "roofline", "cpu_baseline") if k in d}
                 res[cfg]["wall_s"] = round(time.perf_counter() - t0, 1)
         except subprocess.TimeoutExpired:
             res[cfg] = {"skipped": "did not finish within %.0f s" % budget}
