@@ -357,11 +357,11 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
 __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
                                               const int li, const int lk, const int live, const int M, const int N,
                                               float* __restrict__ C, const long long ldc, const float* __restrict__ bias,
-                                              const int act, const int splits, const Epi& epi) {
+                                              const int act, const int splits, const Epi& epi, const int tile_rows = BM) {
   // epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const bool has_mask = epi.mask != nullptr, has_res = epi.res != nullptr, has_fm = epi.fm_x != nullptr,
              has_lr = epi.lr_g != nullptr, has_rs = epi.rowscale != nullptr;
-  if (m0 + BM <= M && n0 + BN <= N && splits == 1 && !(has_fm && (has_mask || has_res || has_rs))) {
+  if (m0 + tile_rows <= M && n0 + BN <= N && splits == 1 && !(has_fm && (has_mask || has_res || has_rs))) {
     // Interior tile: no row / column tests, and the optional operands of the epilogue are fetched for four outputs at a
     // time in one straight run of loads.  (With a test per output every element was its own basic block -- load, wait,
     // store, 64 times per lane: the DeepFM dx GEMM took 330 us longer than the same GEMM without its epilogue.)
@@ -767,6 +767,194 @@ __global__ __launch_bounds__(256, 2) void gemm_bx6_kernel(const float* __restric
   else if (live == 1) bx6_loop<1>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
   else bx6_loop<0>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
   gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi);
+}
+
+// ---- the same GEMM with a 256 x 128 tile, pipelined ----------------------------------------------------------------------------
+// gemm_bx6_kernel above runs at 0.34-0.38 of the bf16 pipes whatever its loop looks like (a one-barrier, double-buffered
+// form of the same 128 x 128 tile measured 157 vs 160 TF): at six MFMAs per 16 k a 128 x 128 tile asks the L2 for 20 KB
+// (8 KB of f32 activations + 12 KB of weight planes) per 768 MFMA cycles -- 16 TB/s over the chip at full rate, more than
+// the L2s deliver; it is the plain-bf16 ladder of the guide again (128^2 tiles: 0.36 of peak).  Here a workgroup of EIGHT
+// wavefronts owns 256 rows x 128 columns (the weight tile amortised over twice the rows: 28 KB per 2 x the products), k tiles
+// of 16 in two LDS buffers, ONE barrier per tile: the tile after the current one is split and parked in the other buffer
+// between the two halves of the current tile's MFMAs, the loads of the tile after that issued right behind.
+#ifndef RBX_BXP_STAGES
+#define RBX_BXP_STAGES 2
+#endif
+constexpr int PBK = 16;                 // k per tile: one MFMA step
+constexpr int PLD = PBK + 8;            // LDS row pitch, bf16 elements (48 bytes: conflict-free b128 reads of 16 rows)
+constexpr int PBM = 256;                // rows of the workgroup's tile
+constexpr int PTHREADS = 512;
+constexpr int PPLANE_A = PBM * PLD, PPLANE_B = BN * PLD;
+constexpr int PBUF_A = 3 * PPLANE_A, PBUF_B = 3 * PPLANE_B;
+
+// A tile [256, 16]: thread t takes k = 4 (t % 4) .. + 3 of rows t / 4 and 128 + t / 4
+template <bool GUARD>
+__device__ __forceinline__ void bxp_load_a(const float* __restrict__ A, long long lda, int m0, int k0, int M, int K,
+                                           f32x4u_t (&v)[2]) {
+  const int t = threadIdx.x;
+  const int k = k0 + (t & 3) * 4;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    int r = m0 + (t >> 2) + 128 * p;
+    r = r < M ? r : M - 1;
+    const float* src = A + static_cast<long long>(r) * lda + k;
+    if (!GUARD || k + 3 < K) {
+      v[p] = *reinterpret_cast<const f32x4u_t*>(src);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[p][j] = (k + j < K) ? src[j] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void bxp_store_a(unsigned short* __restrict__ buf, const f32x4u_t (&v)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split2(f32x2_t{v[p][0], v[p][1]}, h0, m0, l0);
+    split2(f32x2_t{v[p][2], v[p][3]}, h1, m1, l1);
+    unsigned short* dst = buf + ((t >> 2) + 128 * p) * PLD + (t & 3) * 4;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + PPLANE_A) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(dst + 2 * PPLANE_A) = make_uint2(l0, l1);
+  }
+}
+// B tile [128 rows, 16 k] of the interleaved planes: 96 contiguous bytes per row = 768 chunks of 16 bytes; thread t takes
+// chunk t and, the first 256 threads, chunk 512 + t
+__device__ __forceinline__ void bxp_load_b(const unsigned short* __restrict__ Bp, int kp, int n0, int k0, int N, u32x4_t (&v)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = t + PTHREADS * i;
+    if (j < 768) {
+      int r = n0 + j / 6;
+      r = r < N ? r : N - 1;
+      v[i] = *reinterpret_cast<const u32x4_t*>(Bp + static_cast<long long>(r) * 3 * kp + (k0 >> 3) * 24 + (j % 6) * 8);
+    }
+  }
+}
+__device__ __forceinline__ void bxp_store_b(unsigned short* __restrict__ buf, const u32x4_t (&v)[2]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = t + PTHREADS * i;
+    if (j < 768) {
+      const int c = j % 6;
+      *reinterpret_cast<u32x4_t*>(buf + (c % 3) * PPLANE_B + (j / 6) * PLD + (c / 3) * 8) = v[i];
+    }
+  }
+}
+
+#define RBX_BXP_TERM(QA, QB)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
+    if ((LIVE >> (2 * i + j)) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][QA], b[j][QB], acc[i][j], 0, 0, 0)
+
+template <int LIVE>
+__device__ __forceinline__ void bxp_loop(const float* __restrict__ A, const long long lda, const unsigned short* __restrict__ Bp,
+                                         const int kp, const int m0, const int n0, const int M, const int N, const int K,
+                                         unsigned short* __restrict__ As, unsigned short* __restrict__ Bs, const int wm,
+                                         const int wn, const int li, const int lk, f32x16 (&acc)[2][2]) {
+  // NS register sets: the loads of a tile are issued NS iterations ahead of its split (one ahead: 46 % of the wavefront
+  // cycles parked (PMC), 158 TF at 8192^3; two: 184) -- set (t + 1) % NS holds tile t + 1 when iteration t starts
+  constexpr int NS = RBX_BXP_STAGES;
+  f32x4u_t ra[NS][2];
+  u32x4_t rb[NS][2];
+  const int kt = (K + PBK - 1) / PBK;              // tiles; the weight planes are zero-filled up to a multiple of 32
+  auto fetch = [&](int tile, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    if ((tile + 1) * PBK <= K) bxp_load_a<false>(A, lda, m0, tile * PBK, M, K, ra[set]);
+    else bxp_load_a<true>(A, lda, m0, tile * PBK, M, K, ra[set]);
+    bxp_load_b(Bp, kp, n0, tile * PBK, N, rb[set]);
+  };
+  fetch(0, std::integral_constant<int, 0>{});
+  bxp_store_a(As, ra[0]);
+  bxp_store_b(Bs, rb[0]);
+  if (kt > 1) fetch(1, std::integral_constant<int, 1 % NS>{});
+  if (NS > 1 && kt > 2) fetch(2, std::integral_constant<int, 2 % NS>{});
+  if (NS > 2 && kt > 3) fetch(3, std::integral_constant<int, 3 % NS>{});
+  __syncthreads();
+  const int aoff = (wm + li) * PLD + 8 * lk, boff = (wn + li) * PLD + 8 * lk;
+  auto step = [&](int t, int cur, auto set_c) {
+    constexpr int set = decltype(set_c)::value;    // the set that holds tile t + 1
+    const unsigned short* ap = As + cur * PBUF_A + aoff;
+    const unsigned short* bp = Bs + cur * PBUF_B + boff;
+    bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if ((LIVE >> (2 * i)) & 3) a[i][q] = *reinterpret_cast<const bf16x8_t*>(ap + q * PPLANE_A + i * 32 * PLD);
+        if ((LIVE >> i) & 5) b[i][q] = *reinterpret_cast<const bf16x8_t*>(bp + q * PPLANE_B + i * 32 * PLD);
+      }
+    RBX_BXP_TERM(2, 0);
+    RBX_BXP_TERM(0, 2);
+    RBX_BXP_TERM(1, 1);
+    if (t + 1 < kt) {                              // tile t + 1 -> the other buffer, in the shadow of this tile's MFMAs
+      bxp_store_a(As + (cur ^ 1) * PBUF_A, ra[set]);
+      bxp_store_b(Bs + (cur ^ 1) * PBUF_B, rb[set]);
+    }
+    if (t + 1 + NS < kt) fetch(t + 1 + NS, set_c); // the tile NS iterations ahead into the set just emptied
+    RBX_BXP_TERM(1, 0);
+    RBX_BXP_TERM(0, 1);
+    RBX_BXP_TERM(0, 0);
+    __syncthreads();
+  };
+  // unrolled by 2 NS (the LDS buffer alternates, the register set cycles)
+  int t = 0;
+  while (t < kt) {
+#define RBX_BXP_STEP(U)                                                            \
+    if (t < kt) { step(t, (U) & 1, std::integral_constant<int, ((U) + 1) % NS>{}); ++t; }
+    RBX_BXP_STEP(0) RBX_BXP_STEP(1) RBX_BXP_STEP(2) RBX_BXP_STEP(3) RBX_BXP_STEP(4) RBX_BXP_STEP(5)
+#undef RBX_BXP_STEP
+  }
+}
+#undef RBX_BXP_TERM
+
+__global__ __launch_bounds__(PTHREADS, 1) void gemm_bxp_kernel(const float* __restrict__ A, const long long lda,
+                                                               const unsigned short* __restrict__ Bp, const int kp,
+                                                               float* __restrict__ C, const long long ldc, const int M,
+                                                               const int N, const int K, const float* __restrict__ bias,
+                                                               const int act, const int tiles_m, const int tiles_n,
+                                                               const Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short bxp_lds[];          // 2 x (A 36 KB + B 18 KB) = 108 KB
+  unsigned short* As = bxp_lds;
+  unsigned short* Bs = bxp_lds + 2 * PBUF_A;
+  int tm_i, tn_j;
+  {
+    const int total = tiles_m * tiles_n, L = static_cast<int>(blockIdx.x);
+    const int xcd = L % kXcds, slot = L / kXcds;
+    const int q = total / kXcds, rem = total % kXcds;
+    const int tile = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    tm_i = tile / tiles_n;
+    tn_j = tile % tiles_n;
+  }
+  const int m0 = tm_i * PBM, n0 = tn_j * BN;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int li = lane & 31, lk = lane >> 5;
+  // eight wavefronts as 4 x 2, each 64 x 64 = 2 x 2 MFMA tiles; the live ones of an edge tile (bit 2 i + j)
+  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+  int live;
+  {
+    int rows = (M - m0 - wm + 31) / 32, cols = (N - n0 - wn + 31) / 32;
+    rows = rows > 2 ? 2 : rows;
+    cols = cols > 2 ? 2 : cols;
+    live = (rows <= 0 || cols <= 0) ? 0 : (rows == 2 && cols == 2) ? 15 : (rows == 2) ? 5 : (cols == 2) ? 3 : 1;
+    live = __builtin_amdgcn_readfirstlane(live);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (live == 15) bxp_loop<15>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 5) bxp_loop<5>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 3) bxp_loop<3>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 1) bxp_loop<1>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else bxp_loop<0>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi, PBM);
 }
 
 // src [rows, cols] f32 (row pitch ld) -> bf16 planes h, m, l in the layout bx6_load_b reads: out[r][c / 8][q][c % 8],
@@ -1806,8 +1994,19 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     SplitEntry e;
     if (split_find(B, BK_ ? 0 : 1, BK_ ? N : K, BK_ ? K : N, &e)) {
       const int kp = (K + SBK - 1) / SBK * SBK;
-      hipLaunchKernelGGL(gemm_bx6_kernel, dim3(tn * tm), dim3(256), 0, s, A, lda, e.planes, kp, C, ldc, M, N, K, bias, act, tm,
-                         tn, epi);
+      if (bx6_mode() == 2 || M < 2 * PBM) {           // RBX_GEMM_BX6=2: the 128 x 128 form (A/B measurements); few rows
+        hipLaunchKernelGGL(gemm_bx6_kernel, dim3(tn * tm), dim3(256), 0, s, A, lda, e.planes, kp, C, ldc, M, N, K, bias, act, tm,
+                           tn, epi);
+      } else {
+        static const bool attr_set = [] {
+          return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bxp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     2 * (PBUF_A + PBUF_B) * 2) == hipSuccess;
+        }();
+        (void)attr_set;
+        const int tm2 = (M + PBM - 1) / PBM;
+        hipLaunchKernelGGL(gemm_bxp_kernel, dim3(tn * tm2), dim3(PTHREADS), 2 * (PBUF_A + PBUF_B) * 2, s, A, lda, e.planes, kp, C,
+                           ldc, M, N, K, bias, act, tm2, tn, epi);
+      }
       g_bx6_launches.fetch_add(1, std::memory_order_relaxed);
       return check_launch("gemm_bx6_kernel");
     }
