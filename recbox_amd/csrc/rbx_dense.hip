@@ -957,6 +957,156 @@ __global__ __launch_bounds__(PTHREADS, 1) void gemm_bxp_kernel(const float* __re
   gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi, PBM);
 }
 
+// ---- the weight-gradient GEMM dW = dy^T x on the same pipes --------------------------------------------------------------------
+// Both operands are batch-major activations: A(i, kk) = dy[kk, i], B(kk, col) = x[kk, col] with the reduction index kk = the
+// sample.  Same 256 x 128 x 16 tiles, LDS layout, MFMA phase and prefetch depth as gemm_bxp_kernel; what differs is the
+// staging -- a lane reads ONE output row / column (dword loads: 64 consecutive floats of a sample's row per wavefront) for
+// pairs of consecutive samples, so that a pair is one packed bf16x2 word of a k-major LDS row (b32 stores) -- both operands
+// split in the kernel, and the K (batch) range split over workgroups into a workspace (splitk_reduce_kernel: fixed order).
+// A tile [256 i, 16 kk]: thread t takes i = t % 256 and the four sample pairs of kk in [8 (t / 256), + 8)
+__device__ __forceinline__ void bxt_load_a(const float* __restrict__ A, long long lda, int m0, int k0, int M, int kend,
+                                           float (&v)[8]) {
+  const int t = threadIdx.x;
+  int i = m0 + (t & 255);
+  i = i < M ? i : M - 1;
+  const int kk = k0 + 8 * (t >> 8);
+  const float* src = A + static_cast<long long>(kk) * lda + i;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (kk + e < kend) ? src[static_cast<long long>(e) * lda] : 0.f;
+}
+__device__ __forceinline__ void bxt_store_a(unsigned short* __restrict__ buf, const float (&v)[8]) {
+  const int t = threadIdx.x;
+  unsigned* dst = reinterpret_cast<unsigned*>(buf + (t & 255) * PLD + 8 * (t >> 8));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned h, m, l;
+    split2(f32x2_t{v[2 * j], v[2 * j + 1]}, h, m, l);
+    dst[j] = h;
+    dst[j + PPLANE_A / 2] = m;
+    dst[j + PPLANE_A] = l;
+  }
+}
+// B tile [128 col, 16 kk]: thread t takes col = t % 128 and the two sample pairs of kk in [4 (t / 128), + 4)
+__device__ __forceinline__ void bxt_load_b(const float* __restrict__ B, long long ldb, int n0, int k0, int N, int kend,
+                                           float (&v)[4]) {
+  const int t = threadIdx.x;
+  int c = n0 + (t & 127);
+  c = c < N ? c : N - 1;
+  const int kk = k0 + 4 * (t >> 7);
+  const float* src = B + static_cast<long long>(kk) * ldb + c;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (kk + e < kend) ? src[static_cast<long long>(e) * ldb] : 0.f;
+}
+__device__ __forceinline__ void bxt_store_b(unsigned short* __restrict__ buf, const float (&v)[4]) {
+  const int t = threadIdx.x;
+  unsigned* dst = reinterpret_cast<unsigned*>(buf + (t & 127) * PLD + 4 * (t >> 7));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    unsigned h, m, l;
+    split2(f32x2_t{v[2 * j], v[2 * j + 1]}, h, m, l);
+    dst[j] = h;
+    dst[j + PPLANE_B / 2] = m;
+    dst[j + PPLANE_B] = l;
+  }
+}
+
+#define RBX_BXT_TERM(QA, QB)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
+    if ((LIVE >> (2 * i + j)) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][QA], b[j][QB], acc[i][j], 0, 0, 0)
+
+template <int LIVE>
+__device__ __forceinline__ void bxt_loop(const float* __restrict__ A, const long long lda, const float* __restrict__ B,
+                                         const long long ldb, const int m0, const int n0, const int M, const int N,
+                                         const int kbeg, const int kend, unsigned short* __restrict__ As,
+                                         unsigned short* __restrict__ Bs, const int wm, const int wn, const int li, const int lk,
+                                         f32x16 (&acc)[2][2]) {
+  constexpr int NS = 2;
+  float ra[NS][8], rb[NS][4];
+  const int kt = (kend - kbeg + PBK - 1) / PBK;
+  auto fetch = [&](int tile, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    bxt_load_a(A, lda, m0, kbeg + tile * PBK, M, kend, ra[set]);
+    bxt_load_b(B, ldb, n0, kbeg + tile * PBK, N, kend, rb[set]);
+  };
+  fetch(0, std::integral_constant<int, 0>{});
+  bxt_store_a(As, ra[0]);
+  bxt_store_b(Bs, rb[0]);
+  if (kt > 1) fetch(1, std::integral_constant<int, 1>{});
+  if (kt > 2) fetch(2, std::integral_constant<int, 0>{});
+  __syncthreads();
+  const int aoff = (wm + li) * PLD + 8 * lk, boff = (wn + li) * PLD + 8 * lk;
+  auto step = [&](int t, int cur, auto set_c) {
+    constexpr int set = decltype(set_c)::value;    // the set that holds tile t + 1
+    const unsigned short* ap = As + cur * PBUF_A + aoff;
+    const unsigned short* bp = Bs + cur * PBUF_B + boff;
+    bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if ((LIVE >> (2 * i)) & 3) a[i][q] = *reinterpret_cast<const bf16x8_t*>(ap + q * PPLANE_A + i * 32 * PLD);
+        if ((LIVE >> i) & 5) b[i][q] = *reinterpret_cast<const bf16x8_t*>(bp + q * PPLANE_B + i * 32 * PLD);
+      }
+    RBX_BXT_TERM(2, 0);
+    RBX_BXT_TERM(0, 2);
+    RBX_BXT_TERM(1, 1);
+    if (t + 1 < kt) {
+      bxt_store_a(As + (cur ^ 1) * PBUF_A, ra[set]);
+      bxt_store_b(Bs + (cur ^ 1) * PBUF_B, rb[set]);
+    }
+    if (t + 1 + NS < kt) fetch(t + 1 + NS, set_c);
+    RBX_BXT_TERM(1, 0);
+    RBX_BXT_TERM(0, 1);
+    RBX_BXT_TERM(0, 0);
+    __syncthreads();
+  };
+  for (int t = 0; t < kt; t += 2) {
+    step(t, 0, std::integral_constant<int, 1>{});
+    if (t + 1 < kt) step(t + 1, 1, std::integral_constant<int, 0>{});
+  }
+}
+#undef RBX_BXT_TERM
+
+__global__ __launch_bounds__(PTHREADS, 1) void gemm_bxt_kernel(const float* __restrict__ A, const long long lda,
+                                                               const float* __restrict__ B, const long long ldb,
+                                                               float* __restrict__ C, const int M, const int N, const int K,
+                                                               const int k_per_split, const int tiles_n, const int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short bxp_lds[];
+  unsigned short* As = bxp_lds;
+  unsigned short* Bs = bxp_lds + 2 * PBUF_A;
+  const int tile = static_cast<int>(blockIdx.x) % n_tiles, z = static_cast<int>(blockIdx.x) / n_tiles;
+  const int m0 = (tile / tiles_n) * PBM, n0 = (tile % tiles_n) * BN;
+  const int kbeg = z * k_per_split;
+  const int kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+  C += static_cast<long long>(z) * M * N;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int li = lane & 31, lk = lane >> 5;
+  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+  int live;
+  {
+    int rows = (M - m0 - wm + 31) / 32, cols = (N - n0 - wn + 31) / 32;
+    rows = rows > 2 ? 2 : rows;
+    cols = cols > 2 ? 2 : cols;
+    live = (rows <= 0 || cols <= 0) ? 0 : (rows == 2 && cols == 2) ? 15 : (rows == 2) ? 5 : (cols == 2) ? 3 : 1;
+    live = __builtin_amdgcn_readfirstlane(live);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (live == 15) bxt_loop<15>(A, lda, B, ldb, m0, n0, M, N, kbeg, kend, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 5) bxt_loop<5>(A, lda, B, ldb, m0, n0, M, N, kbeg, kend, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 3) bxt_loop<3>(A, lda, B, ldb, m0, n0, M, N, kbeg, kend, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 1) bxt_loop<1>(A, lda, B, ldb, m0, n0, M, N, kbeg, kend, As, Bs, wm, wn, li, lk, acc);
+  else bxt_loop<0>(A, lda, B, ldb, m0, n0, M, N, kbeg, kend, As, Bs, wm, wn, li, lk, acc);
+  // partial [M, N] of this K slice: plain stores (splits = 2 selects the epilogue's no-bias, no-activation path)
+  gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, static_cast<long long>(N), nullptr, 0, 2, Epi{}, PBM);
+}
+
 // src [rows, cols] f32 (row pitch ld) -> bf16 planes h, m, l in the layout bx6_load_b reads: out[r][c / 8][q][c % 8],
 // c < cp = cols rounded up to a multiple of SBK (zero-filled); transpose: out row r is src COLUMN r.
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, const long long ld, const int rows,
@@ -1899,6 +2049,10 @@ static bool split_find(const float* w, int transposed, int rows, int cols, Split
     }
   return false;
 }
+static int dw_bx6_mode() {
+  static const int v = [] { const char* e = getenv("RBX_GEMM_BX6_DW"); return e ? atoi(e) : 1; }();
+  return v;
+}
 static int stream64_mode() {
   static const int mode = [] { const char* e = getenv("RBX_GEMM_STREAM64"); return e ? atoi(e) : 1; }();
   return mode;
@@ -1975,6 +2129,37 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     }
 #undef RBX_K64
     return check_launch("gemm_f32_k64n64_kernel");
+  }
+  // dW = dy^T x of a compute-bound tower layer: the split-operand kernel with transposed staging, K (the batch) split
+  if (!AK && !BK_ && bx6_mode() == 1 && dw_bx6_mode() > 0 && ws != nullptr && !has_epi && ldc == N && K >= 8192 && M >= 128 &&
+      N >= 128) {
+    const int tm2 = (M + PBM - 1) / PBM;
+    const int n_tiles = tm2 * tn;
+    int sp = kCUs / n_tiles;                           // one workgroup per CU (108 KB of LDS each): one round of the chip
+    if (4 * M < 3 * tm2 * PBM) sp = 0;                 // 256-row tiles less than 3/4 full (M = 128): the f32 kernel's 128-row tiles
+    const long long fit6 = static_cast<long long>(ws_floats / (static_cast<size_t>(M) * N));
+    if (sp > fit6) sp = static_cast<int>(fit6);
+    if (sp > K / 1024) sp = K / 1024;
+    if (sp >= 1) {
+      int kps6 = (K + sp - 1) / sp;
+      kps6 = (kps6 + PBK - 1) / PBK * PBK;
+      sp = (K + kps6 - 1) / kps6;
+      static const bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bxt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   2 * (PBUF_A + PBUF_B) * 2) == hipSuccess;
+      }();
+      (void)attr_set;
+      hipLaunchKernelGGL(gemm_bxt_kernel, dim3(n_tiles * sp), dim3(PTHREADS), 2 * (PBUF_A + PBUF_B) * 2, s, A, lda, B, ldb, ws, M,
+                         N, K, kps6, tn, n_tiles);
+      int rc6 = check_launch("gemm_bxt_kernel");
+      if (rc6 != RBX_OK) return rc6;
+      g_bx6_launches.fetch_add(1, std::memory_order_relaxed);
+      const long long n = static_cast<long long>(M) * N;
+      long long blocks = (n + 63) / 64;
+      if (blocks > kCUs * 8) blocks = kCUs * 8;
+      launch_splitk_reduce(s, static_cast<unsigned>(blocks), ws, n, sp, C);
+      return check_launch("splitk_reduce_kernel");
+    }
   }
   // 64 -> 128 and 128 -> 64 over many rows: the slab kernel with the weights in LDS
   if (AK && splits == 1 && epi.fm_x == nullptr && epi.mask == nullptr && epi.rowscale == nullptr && M >= 2048 &&

@@ -118,7 +118,10 @@ def test_mlp_golden():
                                        # split-K dW): 1, 2, 3 and 4 live 32-row / 32-column blocks, narrow tails of one and two
                                        # blocks riding in the main launch, cfg 4's [*, 1677] x [400, 1677] with K >= 4096 rows
                                        (4200, 400, 1677, None), (4130, 168, 198, "relu"), (4100, 228, 168, None),
-                                       (4099, 198, 400, None), (4160, 130, 140, None)])
+                                       (4099, 198, 400, None), (4160, 130, 140, None),
+                                       # batch >= 8192 with a compute-bound layer: dW on the split-operand kernel with
+                                       # transposed staging (K of that GEMM = the batch, split over workgroups), ragged everywhere
+                                       (16384, 400, 300, None), (16500, 130, 257, "relu"), (9001, 264, 1677, None)])
 def test_linear_matches_torch_fp32(M, N, K, act):
     """The MFMA GEMM (all three operand layouts, split-K weight grad) against torch fp32 on CPU."""
     from recbox_amd import ops
