@@ -461,7 +461,7 @@ def run_model_config(args, rank, world, dev):
         K1 = len(CRITEO_VOCABS) * 64 + N_DENSE
         want = lambda m: m[0] == "linear_fwd" and m[3] == K1                              # noqa: E731
         bx6 = ops.config.gemm_bx6 and os.environ.get("RBX_GEMM_BX6", "1") != "0"
-        kname = (("gemm_bx6_kernel: tower layer 1 forward, [B, %d] x [400, %d]^T as six v_mfma_f32_32x32x16_bf16 products of "
+        kname = (("gemm_bxp_kernel: tower layer 1 forward, [B, %d] x [400, %d]^T as six v_mfma_f32_32x32x16_bf16 products of "
                   "three-way split operands per f32 product, f32 accumulation" % (K1, K1)) if bx6 else
                  ("gemm_f32_kernel (+ narrow tail): tower layer 1 forward, [B, %d] x [400, %d]^T on v_mfma_f32_32x32x2_f32"
                   % (K1, K1)))

@@ -594,7 +594,9 @@ int rbx_linear_dx_deepfm(const float* d_dy, int64_t dy_stride, const float* d_w,
 /* f32 GEMM on the bf16 matrix cores (csrc/rbx_dense.hip, gemm_bx6_kernel): a weight matrix split ONCE per call into three
  * bf16 planes w = h + m + l (|w - h - m - l| <= 2^-24 |w|), the activations split inside the kernel, six bf16 MFMA products
  * per f32 product with f32 accumulation -- results at f32 rounding level (the same test tolerances), ~2.7x fewer matrix-core
- * cycles than v_mfma_f32_32x32x2_f32.  No counterpart in the reference (its nn.Linear is one torch call):
+ * cycles than v_mfma_f32_32x32x2_f32.  (rbx_linear_bwd's weight gradient dW = dy^T x takes the same route on its own when the
+ * batch has >= 8192 rows: both operands are activations, split inside gemm_bxt_kernel; RBX_GEMM_BX6_DW=0 keeps it on f32 MFMAs.)
+ * No counterpart in the reference (its nn.Linear is one torch call):
  *   rbx_split_bf16_size(rows, cols, transpose): bytes of the planes of a [rows, cols] matrix;
  *   rbx_split_bf16: d_out[r][c / 8][q][c % 8] (q = 0..2 = h, m, l; c < cols rounded up to 32, zero-filled; transpose != 0:
  *                   out row r is COLUMN r of d_src) -- an opaque layout for the kernel's tile loads; transpose = 0 serves

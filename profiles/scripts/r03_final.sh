@@ -31,10 +31,12 @@ RECBOX_AMD_FM_TWO_CHAINS=0 timeout 600 python bench.py --no-cpu-baseline > $out/
 # SASRec / DeepFM: what this round's kernels are worth, one switch at a time
 RBX_GEMM_STREAM64=0 timeout 600 python bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_sasrec_tile_gemm.json 2>/dev/null; ms sasrec_tile_gemm
 RECBOX_AMD_SHARE_TABLE_GRADS=0 timeout 600 python bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_sasrec_two_grads.json 2>/dev/null; ms sasrec_two_grads
-RECBOX_AMD_GEMM_BX6=0 timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_f32_mfma.json 2>/dev/null; ms deepfm_f32_mfma
-RECBOX_AMD_GEMM_BX6=0 timeout 600 python bench.py --config youtubednn --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_youtubednn_f32_mfma.json 2>/dev/null; ms youtubednn_f32_mfma
+RECBOX_AMD_GEMM_BX6=0 RBX_GEMM_BX6=0 timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_f32_mfma.json 2>/dev/null; ms deepfm_f32_mfma
+RBX_GEMM_BX6_DW=0 timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_dw_f32.json 2>/dev/null; ms deepfm_dw_f32
+RBX_GEMM_BX6=2 timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_bx6_128.json 2>/dev/null; ms deepfm_bx6_128
+RECBOX_AMD_GEMM_BX6=0 RBX_GEMM_BX6=0 timeout 600 python bench.py --config youtubednn --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_youtubednn_f32_mfma.json 2>/dev/null; ms youtubednn_f32_mfma
 for v in 1 0; do
-  RECBOX_AMD_GEMM_BX6=$v PYTHONPATH=/root/repo timeout 300 python profiles/gemm_shapes.py 2>&1 | grep -v amdgpu.ids > $out/gemm_shapes_bx6_$v.txt
+  RECBOX_AMD_GEMM_BX6=$v RBX_GEMM_BX6=$v PYTHONPATH=/root/repo timeout 300 python profiles/gemm_shapes.py 2>&1 | grep -v amdgpu.ids > $out/gemm_shapes_bx6_$v.txt
 done
 for o in sparse_adam dense_adam; do
   timeout 900 python bench.py --config youtubednn --no-cpu-baseline --optimizer $o --steps 20 --warmup 5 > $out/bench_youtubednn_$o.json 2>/dev/null; ms youtubednn_$o

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, BK == 16 ? 4 : 2) void gemm_f32_kernel(const f
 // by rbx_split_bf16 into three k-major bf16 planes (transposed for dx), which the caller registers for the duration of the
 // GEMM call (rbx_split_register); the activations are split on their way from registers to LDS (v_cvt_pk_bf16_f32, 4.5 VALU
 // ops per element beside the MFMAs).  LDS: three bf16 planes per operand, rows k-major in 80-byte pitch (conflict-free
-// b128 reads).  The weight-gradient GEMM (both operands batch-major activations) stays on the f32 MFMAs.
+// b128 reads).  The weight-gradient GEMM (both operands batch-major activations): gemm_bxt_kernel further down.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
