@@ -780,6 +780,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bx6_kernel(const float* __restric
 #ifndef RBX_BXP_STAGES
 #define RBX_BXP_STAGES 2
 #endif
+#ifndef RBX_BXP_SCHED
+#define RBX_BXP_SCHED 1
+#endif
 constexpr int PBK = 16;                 // k per tile: one MFMA step
 constexpr int PLD = PBK + 8;            // LDS row pitch, bf16 elements (48 bytes: conflict-free b128 reads of 16 rows)
 constexpr int PBM = 256;                // rows of the workgroup's tile
@@ -825,23 +828,21 @@ __device__ __forceinline__ void bxp_load_b(const unsigned short* __restrict__ Bp
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int j = t + PTHREADS * i;
-    if (j < 768) {
-      int r = n0 + j / 6;
-      r = r < N ? r : N - 1;
-      v[i] = *reinterpret_cast<const u32x4_t*>(Bp + static_cast<long long>(r) * 3 * kp + (k0 >> 3) * 24 + (j % 6) * 8);
-    }
+    int j = t + PTHREADS * i;
+    j = j < 768 ? j : t;                   // (the upper half of the second round repeats its first chunk: no branch)
+    int r = n0 + j / 6;
+    r = r < N ? r : N - 1;
+    v[i] = *reinterpret_cast<const u32x4_t*>(Bp + static_cast<long long>(r) * 3 * kp + (k0 >> 3) * 24 + (j % 6) * 8);
   }
 }
 __device__ __forceinline__ void bxp_store_b(unsigned short* __restrict__ buf, const u32x4_t (&v)[2]) {
   const int t = threadIdx.x;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int j = t + PTHREADS * i;
-    if (j < 768) {
-      const int c = j % 6;
-      *reinterpret_cast<u32x4_t*>(buf + (c % 3) * PPLANE_B + (j / 6) * PLD + (c / 3) * 8) = v[i];
-    }
+    int j = t + PTHREADS * i;
+    j = j < 768 ? j : t;
+    const int c = j % 6;
+    *reinterpret_cast<u32x4_t*>(buf + (c % 3) * PPLANE_B + (j / 6) * PLD + (c / 3) * 8) = v[i];
   }
 }
 
@@ -899,8 +900,61 @@ __device__ __forceinline__ void bxp_loop(const float* __restrict__ A, const long
     RBX_BXP_TERM(0, 0);
     __syncthreads();
   };
-  // unrolled by 2 NS (the LDS buffer alternates, the register set cycles)
+  // Steady state (every tile up to t + 1 + NS lies inside K: no tests): the same step as ONE basic block, with the order
+  // the instructions should issue in spelled out -- the twelve LDS reads first, then an MFMA with four of the split's VALU
+  // ops / one LDS store / one global load in each of its shadows (RBX_BXP_SCHED=0: the compiler's own order, which puts
+  // the whole split behind the MFMAs).
+  auto steady = [&](int t, int cur, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    const unsigned short* ap = As + cur * PBUF_A + aoff;
+    const unsigned short* bp = Bs + cur * PBUF_B + boff;
+    bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a[i][q] = *reinterpret_cast<const bf16x8_t*>(ap + q * PPLANE_A + i * 32 * PLD);
+        b[i][q] = *reinterpret_cast<const bf16x8_t*>(bp + q * PPLANE_B + i * 32 * PLD);
+      }
+    RBX_BXP_TERM(2, 0);
+    RBX_BXP_TERM(0, 2);
+    RBX_BXP_TERM(1, 1);
+    bxp_store_a(As + (cur ^ 1) * PBUF_A, ra[set]);
+    bxp_store_b(Bs + (cur ^ 1) * PBUF_B, rb[set]);
+    bxp_load_a<false>(A, lda, m0, (t + 1 + NS) * PBK, M, K, ra[set]);
+    bxp_load_b(Bp, kp, n0, (t + 1 + NS) * PBK, N, rb[set]);
+    RBX_BXP_TERM(1, 0);
+    RBX_BXP_TERM(0, 1);
+    RBX_BXP_TERM(0, 0);
+#if RBX_BXP_SCHED
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);                    // DS reads
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   // VALU
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                   // DS write
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // VMEM read
+    }
+#endif
+    __syncthreads();
+  };
   int t = 0;
+  if constexpr (LIVE == 15 && NS == 2) {
+    while ((t + 3 + NS) * PBK <= K) {              // two steps per round: tiles t + 1 + NS and t + 2 + NS are read without tests
+      steady(t, 0, std::integral_constant<int, 1>{});
+      steady(t + 1, 1, std::integral_constant<int, 0>{});
+      t += 2;
+    }
+  }
+  // the rest (and edge tiles): the tested step; t is even here, so LDS buffer and register set line up with U = 0
   while (t < kt) {
 #define RBX_BXP_STEP(U)                                                            \
     if (t < kt) { step(t, (U) & 1, std::integral_constant<int, ((U) + 1) % NS>{}); ++t; }
