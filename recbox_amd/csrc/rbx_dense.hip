@@ -1018,6 +1018,7 @@ __global__ __launch_bounds__(PTHREADS, 1) void gemm_bxp_kernel(const float* __re
 // pairs of consecutive samples, so that a pair is one packed bf16x2 word of a k-major LDS row (b32 stores) -- both operands
 // split in the kernel, and the K (batch) range split over workgroups into a workspace (splitk_reduce_kernel: fixed order).
 // A tile [256 i, 16 kk]: thread t takes i = t % 256 and the four sample pairs of kk in [8 (t / 256), + 8)
+template <bool GUARD>
 __device__ __forceinline__ void bxt_load_a(const float* __restrict__ A, long long lda, int m0, int k0, int M, int kend,
                                            float (&v)[8]) {
   const int t = threadIdx.x;
@@ -1026,7 +1027,7 @@ __device__ __forceinline__ void bxt_load_a(const float* __restrict__ A, long lon
   const int kk = k0 + 8 * (t >> 8);
   const float* src = A + static_cast<long long>(kk) * lda + i;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (kk + e < kend) ? src[static_cast<long long>(e) * lda] : 0.f;
+  for (int e = 0; e < 8; ++e) v[e] = (!GUARD || kk + e < kend) ? src[static_cast<long long>(e) * lda] : 0.f;
 }
 __device__ __forceinline__ void bxt_store_a(unsigned short* __restrict__ buf, const float (&v)[8]) {
   const int t = threadIdx.x;
@@ -1041,6 +1042,7 @@ __device__ __forceinline__ void bxt_store_a(unsigned short* __restrict__ buf, co
   }
 }
 // B tile [128 col, 16 kk]: thread t takes col = t % 128 and the two sample pairs of kk in [4 (t / 128), + 4)
+template <bool GUARD>
 __device__ __forceinline__ void bxt_load_b(const float* __restrict__ B, long long ldb, int n0, int k0, int N, int kend,
                                            float (&v)[4]) {
   const int t = threadIdx.x;
@@ -1049,7 +1051,7 @@ __device__ __forceinline__ void bxt_load_b(const float* __restrict__ B, long lon
   const int kk = k0 + 4 * (t >> 7);
   const float* src = B + static_cast<long long>(kk) * ldb + c;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = (kk + e < kend) ? src[static_cast<long long>(e) * ldb] : 0.f;
+  for (int e = 0; e < 4; ++e) v[e] = (!GUARD || kk + e < kend) ? src[static_cast<long long>(e) * ldb] : 0.f;
 }
 __device__ __forceinline__ void bxt_store_b(unsigned short* __restrict__ buf, const float (&v)[4]) {
   const int t = threadIdx.x;
@@ -1079,8 +1081,8 @@ __device__ __forceinline__ void bxt_loop(const float* __restrict__ A, const long
   const int kt = (kend - kbeg + PBK - 1) / PBK;
   auto fetch = [&](int tile, auto set_c) {
     constexpr int set = decltype(set_c)::value;
-    bxt_load_a(A, lda, m0, kbeg + tile * PBK, M, kend, ra[set]);
-    bxt_load_b(B, ldb, n0, kbeg + tile * PBK, N, kend, rb[set]);
+    bxt_load_a<true>(A, lda, m0, kbeg + tile * PBK, M, kend, ra[set]);
+    bxt_load_b<true>(B, ldb, n0, kbeg + tile * PBK, N, kend, rb[set]);
   };
   fetch(0, std::integral_constant<int, 0>{});
   bxt_store_a(As, ra[0]);
@@ -1114,7 +1116,55 @@ __device__ __forceinline__ void bxt_loop(const float* __restrict__ A, const long
     RBX_BXT_TERM(0, 0);
     __syncthreads();
   };
-  for (int t = 0; t < kt; t += 2) {
+  // steady state, as in bxp_loop: no tests, the issue order spelled out (18 LDS stores and 12 dword loads here)
+  auto steady = [&](int t, int cur, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    const unsigned short* ap = As + cur * PBUF_A + aoff;
+    const unsigned short* bp = Bs + cur * PBUF_B + boff;
+    bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a[i][q] = *reinterpret_cast<const bf16x8_t*>(ap + q * PPLANE_A + i * 32 * PLD);
+        b[i][q] = *reinterpret_cast<const bf16x8_t*>(bp + q * PPLANE_B + i * 32 * PLD);
+      }
+    RBX_BXT_TERM(2, 0);
+    RBX_BXT_TERM(0, 2);
+    RBX_BXT_TERM(1, 1);
+    bxt_store_a(As + (cur ^ 1) * PBUF_A, ra[set]);
+    bxt_store_b(Bs + (cur ^ 1) * PBUF_B, rb[set]);
+    bxt_load_a<false>(A, lda, m0, kbeg + (t + 1 + NS) * PBK, M, kend, ra[set]);
+    bxt_load_b<false>(B, ldb, n0, kbeg + (t + 1 + NS) * PBK, N, kend, rb[set]);
+    RBX_BXT_TERM(1, 0);
+    RBX_BXT_TERM(0, 1);
+    RBX_BXT_TERM(0, 0);
+#if RBX_BXP_SCHED
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+#endif
+    __syncthreads();
+  };
+  int t = 0;
+  if constexpr (LIVE == 15) {
+    while (kbeg + (t + 3 + NS) * PBK <= kend) {
+      steady(t, 0, std::integral_constant<int, 1>{});
+      steady(t + 1, 1, std::integral_constant<int, 0>{});
+      t += 2;
+    }
+  }
+  for (; t < kt; t += 2) {
     step(t, 0, std::integral_constant<int, 1>{});
     if (t + 1 < kt) step(t + 1, 1, std::integral_constant<int, 0>{});
   }
