@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 114          /* 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 115          /* 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -605,6 +605,27 @@ int rbx_linear_dx_deepfm(const float* d_dy, int64_t dy_stride, const float* d_w,
  *                   weight pointer is d_w (shape [rows, cols]) runs on the planes; rbx_split_unregister(d_w) ends that (the
  *                   planes must stay valid until the GEMMs issued in between have run).  Host-side table, 16 slots,
  *                   thread-safe; RBX_GEMM_BX6=0 in the environment ignores every registration. */
+/* BatchNorm statistics out of the GEMMs around a BatchNorm (rechub's towers: Linear -> BatchNorm1d -> act,
+ * third_party/rechub/basic/layers.py:250-266).  Both calls need d_w's planes registered (above) and m >= 512; otherwise they
+ * return RBX_ERR_UNSUPPORTED without launching and the caller takes the separate passes (rbx_linear_fwd + rbx_batchnorm_fwd ...).
+ *   rbx_linear_fwd_bnstats: y = x W^T + b and d_partial[(block, col)][3] = (n, mean, M2) of y over the rows of 64-row block
+ *       `block` (ceil(m / 64) blocks); then rbx_batchnorm_stats_from_partials (mean / rstd / running statistics) and
+ *       rbx_batchnorm_apply: two BatchNorm launches instead of three, y is not read for its statistics.
+ *   rbx_linear_dx_bnsums: dx = (dy W) o [a > 0] where a [m, k] is the ReLU output of a training-mode BatchNorm over d_bn_x
+ *       (its input) with d_bn_mean / d_bn_rstd and affine d_bn_gamma / d_bn_beta (NULL = 1 / 0; xhat of an unmasked element is
+ *       rebuilt from a, which the epilogue reads as the mask), and d_partial[(block, col)][2] = (sum dx, sum dx xhat); then
+ *       rbx_batchnorm_bwd_sums_from_partials (d_dgamma, d_dbeta) and rbx_batchnorm_bwd_dx with d_y_relu = NULL (the mask has
+ *       been applied). */
+int rbx_linear_fwd_bnstats(const float* d_x, int64_t x_stride, const float* d_w, const float* d_bias, int64_t m, int32_t n,
+                           int32_t k, float* d_y, float* d_partial, void* stream);
+int rbx_linear_dx_bnsums(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
+                         const float* d_a, int64_t a_stride, const float* d_bn_x, int64_t bn_x_stride, const float* d_bn_mean,
+                         const float* d_bn_rstd, const float* d_bn_gamma, const float* d_bn_beta, float* d_dx, int64_t dx_stride,
+                         float* d_partial, void* stream);
+int rbx_batchnorm_stats_from_partials(const float* d_partial, int32_t n_blocks, int32_t cols, float eps, float momentum,
+                                      float* d_running_mean, float* d_running_var, float* d_mean, float* d_rstd, void* stream);
+int rbx_batchnorm_bwd_sums_from_partials(const float* d_partial, int32_t n_blocks, int32_t cols, float* d_dgamma,
+                                         float* d_dbeta, void* stream);
 size_t rbx_split_bf16_size(int32_t rows, int32_t cols, int32_t transpose);
 int rbx_split_bf16(const float* d_src, int64_t ld, int32_t rows, int32_t cols, int32_t transpose, void* d_out, void* stream);
 int rbx_split_register(const float* d_w, const void* d_planes, int32_t rows, int32_t cols, int32_t transposed);

@@ -1,9 +1,10 @@
 #!/bin/bash
 cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_matching.py -x -q -k "linear or mlp or split_bf16 or deepfm" 2>&1 | tail -3
-PYTHONPATH=/root/repo timeout 300 python profiles/gemm_shapes.py 2>&1 | grep -v amdgpu.ids
-for i in 1 2; do
-timeout 300 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "
+for v in fwd bwd 0; do
+RECBOX_AMD_BN_IN_GEMM=$v timeout 300 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 2>/tmp/err.txt | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('deepfm', round(d['ms_per_step'],4))"
+d=json.loads(sys.stdin.readline()); print('deepfm bn_in_gemm=$v', round(d['ms_per_step'],4))" || tail -5 /tmp/err.txt
 done
+export TMPDIR=/tmp
+(cd /tmp && RECBOX_AMD_BN_IN_GEMM=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python /root/repo/bench.py --no-cpu-baseline --config deepfm --steps 20 --warmup 5 > /dev/null 2>&1)
+python profiles/topk.py $(find /tmp/prof -name "*.db" | head -1) 14 | cut -c1-120

@@ -151,6 +151,10 @@ SIGNATURES = {
     "rbx_linear_dx_deepfm": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i32, _i32, _P, _P, _P, _P, _i64,
                                             _P]),
     "rbx_linear_bwd": (ctypes.c_int, [_P, _i64, _P, _P, _P, _i64, _i32, _i32, _i32, _P, _i64, _P, _P, _P, _sz, _P]),
+    "rbx_linear_fwd_bnstats": (ctypes.c_int, [_P, _i64, _P, _P, _i64, _i32, _i32, _P, _P, _P]),
+    "rbx_linear_dx_bnsums": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i64, _P, _P, _P, _P, _P, _i64, _P, _P]),
+    "rbx_batchnorm_stats_from_partials": (ctypes.c_int, [_P, _i32, _i32, _f32, _f32, _P, _P, _P, _P, _P]),
+    "rbx_batchnorm_bwd_sums_from_partials": (ctypes.c_int, [_P, _i32, _i32, _P, _P, _P]),
     "rbx_split_bf16_size": (_sz, [_i32, _i32, _i32]),
     "rbx_split_bf16": (ctypes.c_int, [_P, _i64, _i32, _i32, _i32, _P, _P]),
     "rbx_split_register": (ctypes.c_int, [_P, _P, _i32, _i32, _i32]),

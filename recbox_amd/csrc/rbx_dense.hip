@@ -65,6 +65,19 @@ struct Epi {
   int fm_cols;
   int fm_dim;
   int fm_mask;            // fm_dim - 1 when fm_dim is a power of two (col & mask instead of col % dim), else -1
+  // BatchNorm statistics out of the GEMM that produces (or back-propagates into) the normalised tensor -- gemm_bxp_kernel
+  // only; one entry per (64-row block, column), reduced by the BatchNorm's own final kernels:
+  //   bn_mode 1 (forward, y = x W^T + b feeds a BatchNorm): bn_part[(block * N + col) * 3 + {0, 1, 2}] = (n, mean, M2) of y
+  //   bn_mode 2 (dx = dy W whose output is the gradient of a BatchNorm + ReLU output a): with g = dx o [mask > 0] (mask = a),
+  //           bn_part[(block * N + col) * 2 + {0, 1}] = (sum g, sum g xhat), xhat = (bn_x - bn_mean[col]) bn_rstd[col]
+  float* bn_part;
+  const float* bn_x;
+  long long bn_ldx;
+  const float* bn_mean;
+  const float* bn_rstd;
+  const float* bn_gamma;   // mode 2: xhat of an unmasked element is rebuilt from the mask tensor a = gamma xhat + beta that the
+  const float* bn_beta;    //         epilogue reads anyway (bn_x is only read in columns whose gamma is 0)
+  int bn_mode;
 };
 __device__ __forceinline__ float epi_fm_term(const Epi& e, int row, int col) {
   if (e.fm_x == nullptr || col >= e.fm_cols) return 0.f;
@@ -352,6 +365,10 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
                                         static_cast<int>(blockIdx.x) * BM, As, Bs);
 }
 
+#ifndef RBX_EPI_CH
+#define RBX_EPI_CH 4   // outputs whose epilogue operands are fetched in one run of loads
+#endif
+
 // Epilogue of a 128 x 128 tile whose wavefronts hold 2 x 2 MFMA tiles of 32 x 32 (C/D layout: col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -- the same for the f32 and the bf16 MFMAs): shared by the kernels below.
 __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
@@ -365,7 +382,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const i
     // Interior tile: no row / column tests, and the optional operands of the epilogue are fetched for four outputs at a
     // time in one straight run of loads.  (With a test per output every element was its own basic block -- load, wait,
     // store, 64 times per lane: the DeepFM dx GEMM took 330 us longer than the same GEMM without its epilogue.)
-    constexpr int CH = 4;
+    constexpr int CH = RBX_EPI_CH;
+    float bs0[2] = {0.f, 0.f}, bs1[2] = {0.f, 0.f};        // bn_mode 2: column sums of the masked output and of output x xhat
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -373,6 +391,14 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const i
         const int col = n0 + wn + j * 32 + li;
         const int row0 = m0 + wm + i * 32 + 4 * lk;
         const float bv = bias != nullptr ? bias[col] : 0.f;
+        float bn_ig = 0.f, bn_b = 0.f, bn_mu = 0.f, bn_rs = 0.f;
+        if (epi.bn_mode == 2) {
+          const float gm = epi.bn_gamma != nullptr ? epi.bn_gamma[col] : 1.f;
+          bn_ig = gm != 0.f ? 1.f / gm : 0.f;
+          bn_b = epi.bn_beta != nullptr ? epi.bn_beta[col] : 0.f;
+          bn_mu = epi.bn_mean[col];
+          bn_rs = epi.bn_rstd[col];
+        }
 #pragma unroll
         for (int h = 0; h < 16; h += CH) {
           float add[CH];
@@ -423,11 +449,37 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const i
               float v = acc[i][j][h + q] + bv;
               if (act == 1) v = v > 0.f ? v : 0.f;
               if (has_mask) v = keep[q] > 0.f ? v : 0.f;
+              if (epi.bn_mode == 2) {
+                bs0[j] += v;
+                bs1[j] += v * ((keep[q] - bn_b) * bn_ig);
+              }
               v += add[q];
               if (has_rs) v *= sc[q];
               C[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * ldc + col] = v;
             }
           }
+        }
+        // gamma = 0 in this column: a says nothing about xhat, which then comes from the BatchNorm's input (a loop of its
+        // own, so that the one above stays free of per-lane branches)
+        if (epi.bn_mode == 2 && bn_ig == 0.f) {
+          for (int r = 0; r < 16; ++r) {
+            const long long row = row0 + (r & 3) + 8 * (r >> 2);
+            float v = acc[i][j][r] + bv;
+            if (act == 1) v = v > 0.f ? v : 0.f;
+            if (has_mask) v = epi.mask[row * epi.ldmask + col] > 0.f ? v : 0.f;
+            bs1[j] += v * ((epi.bn_x[row * epi.bn_ldx + col] - bn_mu) * bn_rs);
+          }
+        }
+      }
+    }
+    if (epi.bn_mode == 2) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float t0 = bs0[j] + __shfl_xor(bs0[j], 32, 64), t1 = bs1[j] + __shfl_xor(bs1[j], 32, 64);
+        if (lk == 0) {
+          float* dst = epi.bn_part + (static_cast<long long>((m0 + wm) >> 6) * N + n0 + wn + j * 32 + li) * 2;
+          dst[0] = t0;
+          dst[1] = t1;
         }
       }
     }
@@ -964,6 +1016,73 @@ __device__ __forceinline__ void bxp_loop(const float* __restrict__ A, const long
 }
 #undef RBX_BXP_TERM
 
+// Column statistics of a wavefront's 64 rows x 64 columns for the BatchNorm behind (mode 1) / in front of (mode 2) this
+// GEMM: a lane holds 16 rows of one column per 32 x 32 tile (C/D layout), its partner lane ^ 32 the other 16.  Two passes
+// over registers (mean, then squared deviations), Chan's merge of the two halves; rows beyond M do not count.
+__device__ __forceinline__ void bxp_bn_stats(const f32x16 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
+                                             const int li, const int lk, const int live, const int M, const int N,
+                                             const float* __restrict__ bias, const Epi& epi) {
+  const long long block = (m0 + wm) >> 6;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn + 32 * j + li;
+    const bool col_live = col < N && ((live >> j) & 5) != 0;
+    if (epi.bn_mode == 1) {
+      const float bv = (bias != nullptr && col_live) ? bias[col] : 0.f;
+      float n = 0.f, sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row < M && ((live >> (2 * i + j)) & 1)) { n += 1.f; sum += acc[i][j][r] + bv; }
+        }
+      const float mean = n > 0.f ? sum / n : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row < M && ((live >> (2 * i + j)) & 1)) { const float d = acc[i][j][r] + bv - mean; m2 += d * d; }
+        }
+      const float on = __shfl_xor(n, 32, 64), omean = __shfl_xor(mean, 32, 64), om2 = __shfl_xor(m2, 32, 64);
+      if (lk == 0 && col_live) {
+        const float tot = n + on;
+        float tmean = mean, tm2 = m2;
+        if (on > 0.f && tot > 0.f) {
+          const float d = omean - mean;
+          tmean = mean + d * (on / tot);
+          tm2 = m2 + om2 + d * d * (n * on / tot);
+        }
+        float* dst = epi.bn_part + (block * N + col) * 3;
+        dst[0] = tot; dst[1] = tmean; dst[2] = tm2;
+      }
+    } else {
+      const float mu = col_live ? epi.bn_mean[col] : 0.f, rs = col_live ? epi.bn_rstd[col] : 0.f;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (row < M && col_live && ((live >> (2 * i + j)) & 1)) {
+            float g = acc[i][j][r];
+            if (epi.mask != nullptr && !(epi.mask[static_cast<long long>(row) * epi.ldmask + col] > 0.f)) g = 0.f;
+            s0 += g;
+            s1 += g * ((epi.bn_x[static_cast<long long>(row) * epi.bn_ldx + col] - mu) * rs);
+          }
+        }
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      if (lk == 0 && col_live) {
+        float* dst = epi.bn_part + (block * N + col) * 2;
+        dst[0] = s0; dst[1] = s1;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(PTHREADS, 1) void gemm_bxp_kernel(const float* __restrict__ A, const long long lda,
                                                                const unsigned short* __restrict__ Bp, const int kp,
                                                                float* __restrict__ C, const long long ldc, const int M,
@@ -1008,6 +1127,11 @@ __global__ __launch_bounds__(PTHREADS, 1) void gemm_bxp_kernel(const float* __re
   else if (live == 3) bxp_loop<3>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
   else if (live == 1) bxp_loop<1>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
   else bxp_loop<0>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  // statistics for the BatchNorm around this GEMM: forward (mode 1) from the accumulators; backward (mode 2) inside the
+  // epilogue's masked store loop on interior tiles (it reads the mask tensor anyway), by a pass of its own on edge tiles
+  const bool interior = m0 + PBM <= M && n0 + BN <= N;
+  if (epi.bn_mode != 0 && m0 + wm < M && (epi.bn_mode == 1 || !interior))
+    bxp_bn_stats(acc, m0, n0, wm, wn, li, lk, live, M, N, bias, epi);
   gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi, PBM);
 }
 
@@ -2192,7 +2316,8 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
                     const float* bias, int act, float* ws, size_t ws_floats, hipStream_t s, long long ldc = 0,
                     const Epi epi = Epi{}) {
   if (ldc == 0) ldc = N;
-  const bool has_epi = epi.res != nullptr || epi.mask != nullptr || epi.rowscale != nullptr || epi.fm_x != nullptr;
+  const bool has_epi = epi.res != nullptr || epi.mask != nullptr || epi.rowscale != nullptr || epi.fm_x != nullptr ||
+                       epi.bn_mode != 0;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   int splits = 1;
   const long long tiles = static_cast<long long>(tm) * tn;
@@ -2219,7 +2344,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     splits = best;
   }
   // 64 -> 64 over many rows: the streaming kernel with the weights in registers
-  if (AK && K == 64 && N == 64 && splits == 1 && epi.fm_x == nullptr && M >= 2048 && vec_ok(A, lda) &&
+  if (AK && K == 64 && N == 64 && splits == 1 && epi.fm_x == nullptr && epi.bn_mode == 0 && M >= 2048 && vec_ok(A, lda) &&
       (!BK_ || vec_ok(B, ldb)) && stream64_mode() > 0) {
     const int slabs = (M + 31) / 32;
     int wgs = (slabs + kSlabWaves - 1) / kSlabWaves;
@@ -2266,8 +2391,8 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     }
   }
   // 64 -> 128 and 128 -> 64 over many rows: the slab kernel with the weights in LDS
-  if (AK && splits == 1 && epi.fm_x == nullptr && epi.mask == nullptr && epi.rowscale == nullptr && M >= 2048 &&
-      vec_ok(A, lda) && stream64_mode() > 0 && ((K == 64 && N == 128) || (K == 128 && N == 64))) {
+  if (AK && splits == 1 && epi.fm_x == nullptr && epi.mask == nullptr && epi.rowscale == nullptr && epi.bn_mode == 0 &&
+      M >= 2048 && vec_ok(A, lda) && stream64_mode() > 0 && ((K == 64 && N == 128) || (K == 128 && N == 64))) {
     const int slabs = (M + 31) / 32;
     int wgs = (slabs + kSlabWaves - 1) / kSlabWaves;
     if (wgs > 2 * kCUs) wgs = 2 * kCUs;
@@ -2283,6 +2408,8 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     SplitEntry e;
     if (split_find(B, BK_ ? 0 : 1, BK_ ? N : K, BK_ ? K : N, &e)) {
       const int kp = (K + SBK - 1) / SBK * SBK;
+      if (epi.bn_mode != 0 && (bx6_mode() == 2 || M < 2 * PBM))
+        return fail(RBX_ERR_UNSUPPORTED, "linear: BatchNorm statistics come out of the 256-row split-operand kernel only");
       if (bx6_mode() == 2 || M < 2 * PBM) {           // RBX_GEMM_BX6=2: the 128 x 128 form (A/B measurements); few rows
         hipLaunchKernelGGL(gemm_bx6_kernel, dim3(tn * tm), dim3(256), 0, s, A, lda, e.planes, kp, C, ldc, M, N, K, bias, act, tm,
                            tn, epi);
@@ -2300,6 +2427,8 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
       return check_launch("gemm_bx6_kernel");
     }
   }
+  if (epi.bn_mode != 0)
+    return fail(RBX_ERR_UNSUPPORTED, "linear: BatchNorm statistics need the weight's bf16 planes registered (rbx_split_register)");
   // one column tile of at most 416 columns and many rows: the wide kernel (no narrow companion, A read once)
   const int wmode = wide_mode();
   if (splits == 1 && !has_epi && M >= 2048 && N > 64 && N <= 448 && wmode > 0 && (N % BN != 0 || wmode > 1)) {
@@ -2639,4 +2768,50 @@ extern "C" int rbx_split_unregister(const float* d_w) {
   for (int i = 0; i < kSplitSlots; ++i)
     if (g_split[i].w == d_w) g_split[i] = SplitEntry{nullptr, nullptr, 0, 0, 0};
   return RBX_OK;
+}
+
+// ---- BatchNorm statistics out of the GEMMs around a BatchNorm -----------------------------------------------
+// rechub's towers are Linear -> BatchNorm1d -> act (third_party/rechub/basic/layers.py:250-266).  Forward: the Linear's GEMM
+// leaves the per-(64-row block, column) (n, mean, M2) of its output, the BatchNorm starts at its final kernel
+// (rbx_batchnorm_stats_from_partials + rbx_batchnorm_apply: two launches instead of three, no read of y for the statistics).
+// Backward: the dx GEMM of the NEXT Linear, whose output is the gradient of this BatchNorm's ReLU output a, applies the ReLU
+// mask and leaves (sum g, sum g xhat) per block and column; the BatchNorm's backward is its final kernel + the dx pass
+// (rbx_batchnorm_bwd_sums_from_partials + rbx_batchnorm_bwd_dx).  Both need the weight's bf16 planes registered and >= 512
+// rows (the statistics live in gemm_bxp_kernel's epilogue); RBX_ERR_UNSUPPORTED otherwise: the caller takes the separate passes.
+extern "C" int rbx_linear_fwd_bnstats(const float* d_x, int64_t x_stride, const float* d_w, const float* d_bias, int64_t m,
+                                      int32_t n, int32_t k, float* d_y, float* d_partial, void* stream) {
+  using namespace rbx;
+  if (m <= 0 || m > INT_MAX || n <= 1 || k <= 0) return fail(RBX_ERR_INVALID, "linear_fwd_bnstats: bad shape");
+  if (!d_x || !d_w || !d_y || !d_partial) return fail(RBX_ERR_INVALID, "linear_fwd_bnstats: NULL tensor");
+  if (x_stride < k) return fail(RBX_ERR_INVALID, "linear_fwd_bnstats: x_stride < k");
+  Epi epi{};
+  epi.bn_mode = 1;
+  epi.bn_part = d_partial;
+  return run_gemm<true, true>(d_x, x_stride, d_w, k, d_y, static_cast<int>(m), n, k, d_bias, 0, nullptr, 0, as_stream(stream), n,
+                              epi);
+}
+
+extern "C" int rbx_linear_dx_bnsums(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
+                                    const float* d_a, int64_t a_stride, const float* d_bn_x, int64_t bn_x_stride,
+                                    const float* d_bn_mean, const float* d_bn_rstd, const float* d_bn_gamma,
+                                    const float* d_bn_beta, float* d_dx, int64_t dx_stride, float* d_partial, void* stream) {
+  using namespace rbx;
+  if (m <= 0 || m > INT_MAX || n <= 0 || k <= 1) return fail(RBX_ERR_INVALID, "linear_dx_bnsums: bad shape");
+  if (!d_dy || !d_w || !d_a || !d_bn_x || !d_bn_mean || !d_bn_rstd || !d_dx || !d_partial)
+    return fail(RBX_ERR_INVALID, "linear_dx_bnsums: NULL tensor");
+  if (dy_stride < n || a_stride < k || bn_x_stride < k || dx_stride < k)
+    return fail(RBX_ERR_INVALID, "linear_dx_bnsums: a row stride is shorter than its row");
+  Epi epi{};
+  epi.mask = d_a;
+  epi.ldmask = static_cast<long long>(a_stride);
+  epi.bn_mode = 2;
+  epi.bn_part = d_partial;
+  epi.bn_x = d_bn_x;
+  epi.bn_ldx = static_cast<long long>(bn_x_stride);
+  epi.bn_mean = d_bn_mean;
+  epi.bn_rstd = d_bn_rstd;
+  epi.bn_gamma = d_bn_gamma;
+  epi.bn_beta = d_bn_beta;
+  return run_gemm<true, false>(d_dy, dy_stride, d_w, k, d_dx, static_cast<int>(m), k, n, nullptr, 0, nullptr, 0, as_stream(stream),
+                               dx_stride, epi);
 }

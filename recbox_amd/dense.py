@@ -79,7 +79,10 @@ def run_sequential(seq, x):
         m = mods[i]
         if type(m) is nn.Linear:
             fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-            x = ops.linear(x, m.weight, m.bias, "relu" if fuse else None)
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            # a training-mode BatchNorm1d right behind: its column statistics come out of this GEMM's epilogue
+            bn_next = type(nxt) is nn.BatchNorm1d and x.dim() == 2 and (nxt.training or nxt.running_mean is None)
+            x = ops.linear(x, m.weight, m.bias, "relu" if fuse else None, bn_next=bn_next)
             i += 2 if fuse else 1
         elif type(m) in (nn.BatchNorm1d, nn.SyncBatchNorm) and x.dim() == 2:
             nxt = mods[i + 1] if i + 1 < len(mods) else None

@@ -82,6 +82,14 @@ class config(object):
     # activations inside the kernel, six products per f32 product with f32 accumulation (csrc/rbx_dense.hip,
     # gemm_bx6_kernel: f32-level results at ~2.7x fewer matrix-core cycles).  Off: every GEMM on v_mfma_f32_32x32x2_f32.
     gemm_bx6 = os.environ.get("RECBOX_AMD_GEMM_BX6", "1") != "0"
+    # Linear -> BatchNorm1d (-> ReLU) -> Linear of a tower: the BatchNorm's column statistics come out of the epilogue of the
+    # GEMM in front of it, its backward's column sums out of the dx GEMM behind it (rbx_linear_fwd_bnstats /
+    # rbx_linear_dx_bnsums; needs gemm_bx6 and >= 4096 rows).  Built, parity-tested and measured; OFF by default because it
+    # does not pay on this GEMM: "fwd" saves one read of the Linear's output per layer (23 us) and the step does not move
+    # (DeepFM 4.34-4.38 ms either way, four A/B pairs); "bwd" ("1" = both) is SLOWER -- the dx GEMM runs one workgroup per
+    # CU, so the mask tensor its epilogue has to wait for is exposed at the end of every tile (gemm_bxp_kernel 326 -> 370 us
+    # on average, DeepFM 4.32 -> 4.48 ms; profiles/r03/INDEX.md).
+    bn_in_gemm = {"0": False, "1": True, "fwd": "fwd", "bwd": "bwd"}.get(os.environ.get("RECBOX_AMD_BN_IN_GEMM", "0"), False)
     # Where the ids-only pieces of the tiered FM backward run.  "split" (default): the id compaction on the CURRENT stream in
     # front of the forward kernel (10 us; the step's first kernel is then on the stream the previous step ended on), the
     # per-block sorts of the small tables on the current stream inside the backward (in front of the block partials that
@@ -1378,14 +1386,27 @@ def _padded_rows(rows, cols, device):
     return torch.empty(0, dtype=torch.float32, device=device).set_(buf.untyped_storage(), 0, (rows, cols), (stride, 1))
 
 
+def _split_ok(w, M, transposed):
+    N, K = w.shape
+    red, out = (N, K) if transposed else (K, N)
+    return bool(config.gemm_bx6 and M >= 4096 and red >= 256 and out >= 128 and w.is_contiguous())
+
+
+# Hand-over between the autograd nodes of a tower (one entry each, consumed by the next node or overwritten):
+#   "fwd": a Linear whose output feeds a BatchNorm left that output's partial statistics   (ptr, shape, partial, blocks)
+#   "out": a BatchNorm + ReLU in training mode names its output a, input z and statistics  (ptr, shape, z, mean, rstd)
+#   "bwd": the Linear that read a left the masked gradient's partial sums beside its dx     (ptr, shape, partial, blocks)
+_bn_hint = {"fwd": None, "out": None, "bwd": None}
+bn_in_gemm_counts = {"fwd": 0, "bwd": 0}                    # observability (tests)
+
+
 def _with_split_weights(w, M, transposed, call):
     """Run ``call()`` -- GEMMs of [M, *] activations against the contiguous weight ``w`` [N, K] -- with the bf16 planes of
     ``w`` registered (rbx_split_bf16 + rbx_split_register), when the shape is compute-bound enough to gain from the bf16
     matrix cores; otherwise just ``call()``.  transposed = 0 serves y = x W^T, 1 serves dx = dy W."""
-    N, K = w.shape
-    red, out = (N, K) if transposed else (K, N)
-    if not (config.gemm_bx6 and M >= 4096 and red >= 256 and out >= 128 and w.is_contiguous()):
+    if not _split_ok(w, M, transposed):
         return call()
+    N, K = w.shape
     nbytes = lib.rbx_split_bf16_size(N, K, transposed)
     planes = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     check(lib.rbx_split_bf16(_ptr(w), K, N, K, transposed, _ptr(planes), _stream()))
@@ -1406,7 +1427,7 @@ class _Linear(torch.autograd.Function):
     block of a wider row-major activation (row stride > K): it is read, and its gradient written, in place."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, bn_next=False):
         _require_cuda(x, "linear input")
         _require_cuda(weight, "linear weight")
         shape = x.shape
@@ -1417,10 +1438,30 @@ class _Linear(torch.autograd.Function):
         if w.shape[1] != K:
             raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, w.shape[1], N))
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        _with_split_weights(w, M, 0, lambda: check(_timed(
-            ("linear_fwd", M, N, K),
-            lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(bias), M, N, K, act,
-                                       _ptr(y), _stream()))))
+        # is the input the ReLU output of a training-mode BatchNorm?  (its backward sums then come out of this node's dx GEMM)
+        src, _bn_hint["out"] = _bn_hint["out"], None
+        ctx.bn_src = None
+        if (src is not None and src[0] == x2.data_ptr() and src[1] == (M, K) and x2.stride(0) == K and act == 0
+                and config.bn_in_gemm in (True, "bwd") and _split_ok(w, M, 1)):
+            ctx.bn_src = src[2:]
+        partial = None
+        if bn_next and config.bn_in_gemm in (True, "fwd") and act == 0 and M > 1 and x2.stride(0) >= K and _split_ok(w, M, 0):
+            blocks = (M + 63) // 64
+            partial = torch.empty(blocks * N * 3, dtype=torch.float32, device=x.device)
+            rc = _with_split_weights(w, M, 0, lambda: _timed(
+                ("linear_fwd", M, N, K),
+                lambda: lib.rbx_linear_fwd_bnstats(_ptr(x2), x2.stride(0), _ptr(w), _ptr(bias), M, N, K, _ptr(y),
+                                                   _ptr(partial), _stream())))
+            if rc == _lib.RBX_ERR_UNSUPPORTED:
+                partial = None                         # (library switch off, too few rows for the 256-row kernel: separate passes)
+            else:
+                check(rc)
+                _bn_hint["fwd"] = (y.data_ptr(), (M, N), partial, blocks)
+        if partial is None:
+            _with_split_weights(w, M, 0, lambda: check(_timed(
+                ("linear_fwd", M, N, K),
+                lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(bias), M, N, K, act,
+                                           _ptr(y), _stream()))))
         ctx.save_for_backward(x2, w, y if act == 1 else None)
         ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, shape
         return y.view(*shape[:-1], N)
@@ -1439,6 +1480,21 @@ class _Linear(torch.autograd.Function):
         db = torch.empty(N, dtype=torch.float32, device=dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, ctx.act)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+        if dx is not None and ctx.bn_src is not None:
+            # x2 = relu(batchnorm(z)): dx masked by x2 > 0 and its column sums (sum g, sum g xhat) from the dx GEMM's epilogue
+            z, mean, rstd, gamma, beta = ctx.bn_src
+            blocks = (M + 63) // 64
+            dxc = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+            partial = torch.empty(blocks * K * 2, dtype=torch.float32, device=dy.device)
+            rc = _with_split_weights(w, M, 1, lambda: lib.rbx_linear_dx_bnsums(
+                _ptr(dy2), N, _ptr(w), M, N, K, _ptr(x2), K, _ptr(z), K, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                _ptr(dxc), K, _ptr(partial), _stream()))
+            if rc != _lib.RBX_ERR_UNSUPPORTED:
+                check(rc)
+                check(lib.rbx_linear_bwd(_ptr(x2), K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, None, K, _ptr(dw),
+                                         _ptr(db), _ptr(ws), ws_bytes, _stream()))
+                _bn_hint["bwd"] = (dxc.data_ptr(), (M, K), partial, blocks)
+                return dxc.view(ctx.shape), dw, db, None, None
         bwd = lambda: check(lib.rbx_linear_bwd(                                                            # noqa: E731
             _ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx),
             (dx.stride(0) if M > 1 else K) if dx is not None else K, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, _stream()))
@@ -1446,11 +1502,13 @@ class _Linear(torch.autograd.Function):
             _with_split_weights(w, M, 1, bwd)
         else:
             bwd()
-        return (dx.view(ctx.shape) if dx is not None else None), dw, db, None
+        return (dx.view(ctx.shape) if dx is not None else None), dw, db, None, None
 
 
-def linear(x, weight, bias=None, act=None):
-    return _Linear.apply(x, weight, bias, 1 if act == "relu" else 0)
+def linear(x, weight, bias=None, act=None, bn_next=False):
+    """``bn_next``: the caller feeds the result straight into a training-mode BatchNorm1d (``batch_norm``): the GEMM then
+    leaves that BatchNorm's partial column statistics beside its output."""
+    return _Linear.apply(x, weight, bias, 1 if act == "relu" else 0, bool(bn_next))
 
 
 class _L2Norm(torch.autograd.Function):
@@ -1797,11 +1855,22 @@ class _BatchNorm(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(cols, dtype=torch.float32, device=dev)
         rstd = torch.empty(cols, dtype=torch.float32, device=dev)
-        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-        check(lib.rbx_batchnorm_fwd(_ptr(x), rows, cols, _ptr(weight), _ptr(bias), eps, 1 if training else 0, momentum,
-                                    _ptr(running_mean), _ptr(running_var), 1 if relu else 0, _ptr(mean), _ptr(rstd),
-                                    _ptr(y), _ptr(ws), ws_bytes, _stream()))
+        hint, _bn_hint["fwd"] = _bn_hint["fwd"], None
+        if training and hint is not None and hint[0] == x.data_ptr() and hint[1] == (rows, cols) and rows > 1:
+            # the Linear in front of this BatchNorm left the partial statistics of x: final kernel + apply
+            check(lib.rbx_batchnorm_stats_from_partials(_ptr(hint[2]), hint[3], cols, eps, momentum, _ptr(running_mean),
+                                                        _ptr(running_var), _ptr(mean), _ptr(rstd), _stream()))
+            check(lib.rbx_batchnorm_apply(_ptr(x), rows, cols, _ptr(weight), _ptr(bias), _ptr(mean), _ptr(rstd),
+                                          1 if relu else 0, _ptr(y), _stream()))
+            bn_in_gemm_counts["fwd"] += 1
+        else:
+            ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            check(lib.rbx_batchnorm_fwd(_ptr(x), rows, cols, _ptr(weight), _ptr(bias), eps, 1 if training else 0, momentum,
+                                        _ptr(running_mean), _ptr(running_var), 1 if relu else 0, _ptr(mean), _ptr(rstd),
+                                        _ptr(y), _ptr(ws), ws_bytes, _stream()))
+        if training and relu and config.bn_in_gemm in (True, "bwd"):
+            _bn_hint["out"] = (y.data_ptr(), (rows, cols), x, mean, rstd, weight, bias)
         ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
         ctx.training, ctx.has_bias = training, bias is not None
         return y
@@ -1814,11 +1883,23 @@ class _BatchNorm(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
-        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
-        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
-        check(lib.rbx_batchnorm_bwd(_ptr(x), _ptr(dy), _ptr(y_relu), rows, cols, _ptr(weight), _ptr(mean), _ptr(rstd),
-                                    1 if ctx.training else 0, _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws_bytes,
-                                    _stream()))
+        hint, _bn_hint["bwd"] = _bn_hint["bwd"], None
+        if (hint is not None and hint[0] == dy.data_ptr() and hint[1] == (rows, cols) and ctx.training and y_relu is not None
+                and dx is not None):
+            # dy is ALREADY masked by the ReLU (the dx GEMM that produced it did that) and its column sums are on file
+            check(lib.rbx_batchnorm_bwd_sums_from_partials(_ptr(hint[2]), hint[3], cols, _ptr(dgamma), _ptr(dbeta), _stream()))
+            check(lib.rbx_batchnorm_bwd_dx(_ptr(x), _ptr(dy), None, rows, cols, _ptr(weight), _ptr(mean), _ptr(rstd),
+                                           _ptr(dgamma), _ptr(dbeta), rows, _ptr(dx), _stream()))
+            bn_in_gemm_counts["bwd"] += 1
+        else:
+            if hint is not None and hint[0] == dy.data_ptr():
+                # the gradient was masked by its producer but cannot be used that way here: the mask is idempotent, carry on
+                pass
+            ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+            check(lib.rbx_batchnorm_bwd(_ptr(x), _ptr(dy), _ptr(y_relu), rows, cols, _ptr(weight), _ptr(mean), _ptr(rstd),
+                                        1 if ctx.training else 0, _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws_bytes,
+                                        _stream()))
         return (dx, dgamma if (weight is not None and ctx.needs_input_grad[1]) else None,
                 dbeta if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None, None, None)
 
@@ -2699,7 +2780,7 @@ class _DeepFmInput(torch.autograd.Function):
     forward kept (rbx_fm_sum_fwd)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, lr_w, lr_b, fm_cols, dim):
+    def forward(ctx, x, w1, b1, lr_w, lr_b, fm_cols, dim, bn_next=False):
         _require_cuda(x, "DeepFM input block")
         x2 = _rows_view(x)
         w1 = w1.contiguous()
@@ -2708,9 +2789,23 @@ class _DeepFmInput(torch.autograd.Function):
         N = w1.shape[0]
         F_ = fm_cols // dim
         h = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        _with_split_weights(w1, M, 0, lambda: check(_timed(
-            ("linear_fwd", M, N, K),
-            lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, 0, _ptr(h), _stream()))))
+        partial = None
+        if bn_next and config.bn_in_gemm in (True, "fwd") and M > 1 and _split_ok(w1, M, 0):
+            blocks = (M + 63) // 64
+            partial = torch.empty(blocks * N * 3, dtype=torch.float32, device=x.device)
+            rc = _with_split_weights(w1, M, 0, lambda: _timed(
+                ("linear_fwd", M, N, K),
+                lambda: lib.rbx_linear_fwd_bnstats(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, _ptr(h), _ptr(partial),
+                                                   _stream())))
+            if rc == _lib.RBX_ERR_UNSUPPORTED:
+                partial = None
+            else:
+                check(rc)
+                _bn_hint["fwd"] = (h.data_ptr(), (M, N), partial, blocks)
+        if partial is None:
+            _with_split_weights(w1, M, 0, lambda: check(_timed(
+                ("linear_fwd", M, N, K),
+                lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, 0, _ptr(h), _stream()))))
         y_fm = torch.empty((M, 1), dtype=torch.float32, device=x.device)
         ssum = torch.empty((M, dim), dtype=torch.float32, device=x.device)
         check(lib.rbx_fm_sum_fwd(_ptr(x2), x2.stride(0), M, F_, dim, _ptr(y_fm), _ptr(ssum), _stream()))
@@ -2760,14 +2855,14 @@ class _DeepFmInput(torch.autograd.Function):
                 _ptr(dh2), N, _ptr(w1), M, N, K, _ptr(x2), x2.stride(0), _ptr(ssum), dim, fm_cols, _ptr(gf), _ptr(gl),
                 _ptr(lr_w), _ptr(dx), dx.stride(0), _stream())))
             dx = dx.view(xshape) if len(xshape) != 2 else dx
-        return dx, dw1, db1, dlr_w, dlr_b, None, None
+        return dx, dw1, db1, dlr_w, dlr_b, None, None, None
 
 
-def deepfm_input_stage(x, first_linear, lr_linear, fm_cols, dim):
+def deepfm_input_stage(x, first_linear, lr_linear, fm_cols, dim, bn_next=False):
     """(first_linear(x), FM(x[:, :fm_cols].view(B, -1, dim)), lr_linear(x[:, :fm_cols])) for DeepFM's gathered block
     x [B, K]: one autograd node, the block's gradient comes out of ONE GEMM (see _DeepFmInput)."""
     return _DeepFmInput.apply(x, first_linear.weight, first_linear.bias, lr_linear.weight, lr_linear.bias, int(fm_cols),
-                              int(dim))
+                              int(dim), bool(bn_next))
 
 
 def deepfm_input_stage_supported(x, fm_cols, dim):

@@ -212,6 +212,68 @@ def test_split_bf16_gemm_runs_and_is_as_accurate_as_the_f32_mfma(M, N, K):
         assert e6 <= 1e-5 * scale, (name, e6, scale)
 
 
+@pytest.mark.parametrize("M,affine", [(8192, False), (12345, False), (8192, True)])
+def test_tower_batchnorm_statistics_from_the_gemm_epilogues(M, affine):
+    """Linear -> BatchNorm1d -> ReLU -> Linear -> BatchNorm1d -> ReLU -> Linear(.., 1) in training mode (rechub's MLP,
+    basic/layers.py:250-266): the BatchNorms' column statistics come out of the Linear in front of them, their backward's
+    column sums out of the dx GEMM behind them (ops.config.bn_in_gemm; counters), and everything -- output, running
+    statistics, every gradient -- equals the same tower in torch float64 as closely as the separate passes do.  With
+    ``affine`` the BatchNorms carry gammas of either sign (some exactly zero) and random betas; an activation that is zero
+    to within float rounding may then fall on the other side of the ReLU than in float64, which moves one row of a gradient
+    by a visible amount, so that case is held to a relative error of the whole tensor instead of the largest element's."""
+    from recbox_amd import ops, dense
+    torch.manual_seed(M)
+    K = 300
+    mods = torch.nn.Sequential(torch.nn.Linear(K, 256), torch.nn.BatchNorm1d(256), torch.nn.ReLU(),
+                               torch.nn.Linear(256, 384), torch.nn.BatchNorm1d(384), torch.nn.ReLU(),
+                               torch.nn.Linear(384, 1))
+    with torch.no_grad():                       # affine terms of either sign, and columns whose gamma is exactly zero
+        for bn in ((mods[1], mods[4]) if affine else ()):
+            bn.weight.copy_(torch.randn_like(bn.weight))
+            bn.bias.copy_(0.5 * torch.randn_like(bn.bias))
+            bn.weight[::37] = 0.0
+            bn.weight[-1] = 0.0
+    ref = __import__("copy").deepcopy(mods).double()
+    x = torch.randn(M, K)
+    r = torch.randn(M, 1)
+    xr = x.double().requires_grad_(True)
+    (ref(xr) * r.double()).sum().backward()
+
+    def run(fused):
+        m = __import__("copy").deepcopy(mods).cuda().train()
+        xc = x.cuda().requires_grad_(True)
+        old = ops.config.bn_in_gemm
+        ops.config.bn_in_gemm = fused
+        before = dict(ops.bn_in_gemm_counts)
+        try:
+            y = dense.run_sequential(m, xc)
+            (y * r.cuda()).sum().backward()
+        finally:
+            ops.config.bn_in_gemm = old
+        took = {k: ops.bn_in_gemm_counts[k] - before[k] for k in before}
+        return m, xc, y, took
+
+    m1, x1, y1, took1 = run(True)
+    m0, x0, y0, took0 = run(False)
+    assert took1 == {"fwd": 2, "bwd": 1} and took0 == {"fwd": 0, "bwd": 0}, (took1, took0)
+    def same(got, want, what):
+        want = want.float()
+        if affine:
+            err = float((got.cpu() - want).norm()) / max(float(want.norm()), 1e-6)
+            assert err < 2e-3 or float((got.cpu() - want).abs().max()) < 1e-4, "%s: relative error %.2e" % (what, err)
+        else:
+            assert_close(got, want, 2e-4 * max(1.0, float(want.abs().max())), what)
+
+    for (n, p), (_, p1), (_, p0) in zip(ref.named_parameters(), m1.named_parameters(), m0.named_parameters()):
+        same(p1.grad, p.grad, "fused " + n)
+        same(p0.grad, p.grad, "separate " + n)
+    same(x1.grad, xr.grad, "dx fused")
+    for (n, b), (_, b1) in zip(ref.named_buffers(), m1.named_buffers()):
+        if b.dtype.is_floating_point:
+            assert_close(b1, b.float(), 1e-5 * max(1.0, float(b.abs().max())), "running " + n)
+    assert_close(y1, y0, 1e-4 * max(1.0, float(y0.abs().max())), "fused vs separate output")
+
+
 def test_sdpa_and_losses_golden():
     import recbox_amd.ranking.pytorch.layers as L
     fx = Fixture("attention_losses")
