@@ -117,6 +117,13 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, cons
   }
 }
 
+#ifndef RBX_ATTN_ABL
+#define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T
+#endif
+// (Measured and not kept, profiles/r03/INDEX.md: the LDS reads of a tile product issued four ahead of the MFMAs that use them
+//  -- the compiler reads every pair of A values into the same two registers, read / wait / two MFMAs -- with
+//  __builtin_amdgcn_sched_group_barrier: the forward kernel alone 456 vs 459 us, in the SASRec step 449 vs 420 us (more spills
+//  in the looping form).  The LDS round trip is not what the matrix core waits for; see profiles/ubench/attn_parts.hip.)
 // acc[row = li of `rows_lds`][col = lane] = sum_d rows_lds[row0 + li][d] * reg[d]   (column pairing as in load_tile_regs)
 template <int HD>
 __device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, int row0, const float (&reg)[HD / 2]) {
@@ -184,25 +191,88 @@ __device__ __forceinline__ long long attn_base(long long bh, int heads, int L, l
 // takes u+1 tile steps (query tile u in the forward / dQ kernels, key tile nT-1-u in the dK|dV kernel) -- SIMD s
 // (wavefronts s and s+4) gets the heavy tile nT-1-s and a light one: tile s when nT is even (nT+1 steps per SIMD), tile
 // s-1 when nT is odd (SIMD 0 keeps the heaviest tile alone: nT steps per SIMD.  L = 200 is 7 tiles: paired 6+0, 5+1, 4+2, 3
-// the SIMDs carried 8, 8, 8, 4 steps; 6, 5+0, 4+1, 3+2 is 7 each).  Two wavefronts per SIMD fill each other's latency gaps.
-#define RBX_FOR_WAVE_TILES(nT, wid, t)                                                                      \
-  for (int zz_once = 1, t = ((wid) < 4) ? (nT) - 1 - (wid) : (wid) - 4 - ((nT) & 1);                        \
-       zz_once && (((wid) < 4) ? ((wid) <= (nT) - 1 - (wid)) : (t >= 0 && t < (nT) - 1 - t));               \
-       zz_once = 0)
+// the SIMDs carried 8, 8, 8, 4 steps; 6, 5+0, 4+1, 3+2 is 7 each).
+//
+// Within a SIMD the steps are then dealt to its TWO wavefronts (`split`, causal only): wavefront s+4 takes the light tile
+// and the first x = (heavy - light) / 2 steps of the heavy one, wavefront s the rest of the heavy tile; the two partial
+// results of the heavy tile meet through LDS (a sum for dQ / dK / dV; (m, l, O^T) rescaled to the common maximum in the
+// forward) and wavefront s writes the tile.  At 7 tiles that is 4 + 3 steps on every SIMD where it was 7 + 0, 6 + 1, 5 + 2,
+// 4 + 3: a wavefront issues its MFMAs and its softmax arithmetic one after the other, so a SIMD whose second wavefront has
+// run out of work (or never had any) leaves the matrix core idle for half of every step -- the lone 7-step wavefront of
+// SIMD 0 was the length of every sequence.
+struct WavePlan {
+  int n;                       // jobs of this wavefront (0, 1 or 2)
+  int tile0, beg0, end0;       // job 0: cost index of the tile, its steps [beg, end)
+  int tile1, beg1, end1;       // job 1
+  int partial;                 // the job whose result is a partial for the SIMD's other wavefront (-1: none)
+  int merge;                   // this wavefront adds the other one's partial to its (only) job before it writes the tile
+  int simd;
+  __device__ __forceinline__ int tile(int j) const { return j == 0 ? tile0 : tile1; }   // (scalars, not arrays: an array
+  __device__ __forceinline__ int beg(int j) const { return j == 0 ? beg0 : beg1; }      //  indexed by the job would live
+  __device__ __forceinline__ int end(int j) const { return j == 0 ? end0 : end1; }      //  in scratch memory)
+};
+
+__device__ __forceinline__ WavePlan wave_plan(const int nT, const int wid, const int causal, const int split) {
+  WavePlan p;
+  p.n = 0; p.partial = -1; p.merge = 0; p.simd = wid & 3;
+  p.tile0 = p.tile1 = 0; p.beg0 = p.beg1 = 0; p.end0 = p.end1 = 0;
+  const int s = wid & 3;
+  const int uh = nT - 1 - s, ul = s - (nT & 1);
+  const bool heavy = s <= uh, light = ul >= 0 && ul < uh;
+  if (!heavy) return p;
+  const int sh = causal ? uh + 1 : nT, sl = light ? (causal ? ul + 1 : nT) : 0;
+  const int x = (split && causal && sh - sl >= 2) ? (sh - sl) / 2 : 0;
+  if (wid < 4) {
+    p.n = 1; p.tile0 = uh; p.beg0 = x; p.end0 = sh; p.merge = x > 0;
+  } else if (light) {
+    p.n = 1; p.tile0 = ul; p.end0 = sl;
+    if (x > 0) { p.n = 2; p.tile1 = uh; p.end1 = x; p.partial = 1; }
+  } else if (x > 0) {
+    p.n = 1; p.tile0 = uh; p.end0 = x; p.partial = 0;
+  }
+  return p;
+}
+
+// the accumulators of a tile through LDS, a register a row of 64 lanes (conflict free)
+template <int HD>
+__device__ __forceinline__ void park_acc(float* __restrict__ buf, const f32x16 (&acc)[HD / 32]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[(dt * 16 + r) * 64 + lane] = acc[dt][r];
+}
+template <int HD>
+__device__ __forceinline__ void add_parked(const float* __restrict__ buf, f32x16 (&acc)[HD / 32], const float mine = 1.f,
+                                           const float theirs = 1.f) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = acc[dt][r] * mine + buf[(dt * 16 + r) * 64 + lane] * theirs;
+}
+template <int HD>
+constexpr int merge_floats() { return HD * 32 + 128; }      // one SIMD's slot: O^T accumulators + (m, l) per lane
 
 // NPF > 0 (float4 per thread that hold one [Lp, HD] block: Lp * HD / 4 / 512): a workgroup per CU that loops over sequences (gridDim.x <= BH) and fetches the next sequence's K and V into registers
 // while it computes the current one; used where only one workgroup fits a CU anyway (K, V of a sequence > 80 KB of LDS).
+// `split`: 0 = every tile by one wavefront; 1 = the SIMDs' heavy tiles by both wavefronts, their partials meet in LDS slots
+// of their own behind K and V; 2 = the same through the K rows, once every wavefront is done with them (no LDS of its own:
+// the form for short sequences, where several workgroups share a CU).
 template <int HD, bool DROP, int NPF>
 __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float* __restrict__ Q0, const float* __restrict__ K0,
                                                             const float* __restrict__ V0, const int L,
                                                             const float scale, const int causal,
                                                             float* __restrict__ O0, float* __restrict__ LSE,
-                                                            const DropArgs drop, const AttnLd ld, const long long BH) {
+                                                            const DropArgs drop, const AttnLd ld, const long long BH,
+                                                            const int split) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Ks = lds;
   float* Vs = lds + Lp * (HD + 1);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+  const WavePlan pl = wave_plan(nT, wid, causal, split);
+  float* slot = (split == 1 ? Vs + Lp * (HD + 1) : lds) + pl.simd * merge_floats<HD>();
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
   constexpr bool PF = NPF > 0;
@@ -247,21 +317,37 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
         fetched = true;
       }
     };
-    RBX_FOR_WAVE_TILES(nT, wid, qt) {
-      const int i0 = qt * kT, qi = i0 + li;
+    // the state of the wavefront's last job outlives the loop: a partial to hand over, or the tile that takes one in
+    f32x16 oacc[HD / 32];
+    float m = -INFINITY, lsum = 0.f;
+    int i0 = 0, qi = li;
+    for (int jb = 0; jb < pl.n; ++jb) {
+      const int qt = pl.tile(jb);
+      i0 = qt * kT;
+      qi = i0 + li;
       float qreg[HD / 2];
       load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
-      fetch_next();                                            // (behind the wave's own operand loads: those return first)
-      f32x16 oacc[HD / 32];
+      if (!fetched) fetch_next();                              // (behind the wave's own operand loads: those return first)
 #pragma unroll
       for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-      float m = -INFINITY, lsum = 0.f;
-      const int kt_end = causal ? qt : nT - 1;
-      for (int kt = 0; kt <= kt_end; ++kt) {
+      m = -INFINITY;
+      lsum = 0.f;
+      for (int kt = pl.beg(jb); kt < pl.end(jb); ++kt) {
         const int j0 = kt * kT;
-        f32x16 s = tile_dot<HD>(Ks, j0, qreg);                 // S^T[key][query]
+        f32x16 s;
+        if constexpr ((RBX_ATTN_ABL & 1) != 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = qreg[r] * Ks[j0 + lane];
+        } else {
+          s = tile_dot<HD>(Ks, j0, qreg);                      // S^T[key][query]
+        }
+        if constexpr ((RBX_ATTN_ABL & 2) != 0) {
+          lsum += s[0];
+          tile_accumulate<HD>(Vs, j0, s, oacc);
+          continue;
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -296,13 +382,36 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
             for (int q = 0; q < 4; ++q) s[4 * g + q] = drop_keep(c, qi & 1, q, drop.thr16) ? s[4 * g + q] * drop.scale : 0.f;
           }
         }
-        tile_accumulate<HD>(Vs, j0, s, oacc);                  // O^T[d][query] += V^T P^T
+        if constexpr ((RBX_ATTN_ABL & 4) != 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[0][r] += s[r];
+        } else {
+          tile_accumulate<HD>(Vs, j0, s, oacc);                // O^T[d][query] += V^T P^T
+        }
       }
-      store_transposed<HD>(O, ld.o, i0, L, 1.0f / lsum, oacc);
-      if (half == 0 && qi < L) LSE[bh * L + qi] = m + __logf(lsum);
+      if (jb != pl.partial && !pl.merge) {
+        store_transposed<HD>(O, ld.o, i0, L, 1.0f / lsum, oacc);
+        if (half == 0 && qi < L) LSE[bh * L + qi] = m + __logf(lsum);
+      }
     }
     if (PF && !fetched) fetch_next();                          // (a wavefront without a tile still fetches its share)
-    if constexpr (PF) __syncthreads();                         // every wavefront is done with this sequence's K, V rows
+    if (split == 2) __syncthreads();                           // the slots lie over K: every wavefront is done with it
+    if (pl.partial >= 0) {
+      park_acc<HD>(slot, oacc);
+      slot[HD * 32 + lane] = m;
+      slot[HD * 32 + 64 + lane] = lsum;
+    }
+    if (PF || split != 0) __syncthreads();                     // every wavefront is done with this sequence's K, V rows
+    if (pl.merge) {
+      const float mo = slot[HD * 32 + lane], lo = slot[HD * 32 + 64 + lane];
+      const float mn = fmaxf(m, mo);
+      const float a = (m == -INFINITY) ? 0.f : __expf(m - mn), b = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+      add_parked<HD>(slot, oacc, a, b);
+      lsum = lsum * a + lo * b;
+      store_transposed<HD>(O, ld.o, i0, L, 1.0f / lsum, oacc);
+      if (half == 0 && qi < L) LSE[bh * L + qi] = mn + __logf(lsum);
+    }
+    if (split == 2) __syncthreads();                           // (the K rows are free for the next sequence's)
   }
 }
 
@@ -315,7 +424,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
                                                               const float* __restrict__ LSE, const int L,
                                                               const float scale, const int causal,
                                                               float* __restrict__ dQ, float* __restrict__ Dv,
-                                                              const DropArgs drop, const AttnLd ld) {
+                                                              const DropArgs drop, const AttnLd ld, const int split) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Ks = lds;
@@ -333,8 +442,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
-  RBX_FOR_WAVE_TILES(nT, wid, qt) {
-    const int i0 = qt * kT, qi = i0 + li;
+  const WavePlan pl = wave_plan(nT, wid, causal, split);
+  f32x16 dq[HD / 32];
+  int i0 = 0;
+  for (int jb = 0; jb < pl.n; ++jb) {
+    const int qt = pl.tile(jb);
+    i0 = qt * kT;
+    const int qi = i0 + li;
     float qreg[HD / 2], greg[HD / 2], oreg[HD / 2];
     load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
     load_tile_regs<HD>(dO, ld.go, i0, L, 1.0f, greg);
@@ -344,14 +458,12 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
     for (int s = 0; s < HD / 2; ++s) Di += greg[s] * oreg[s];
     Di += __shfl_xor(Di, 32, 64);
     const float lse = (qi < L) ? LSE[bh * L + qi] : 0.f;
-    if (half == 0 && qi < L) Dv[bh * L + qi] = Di;
-    f32x16 dq[HD / 32];
+    if (half == 0 && qi < L && jb != pl.partial) Dv[bh * L + qi] = Di;
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-    const int kt_end = causal ? qt : nT - 1;
-    for (int kt = 0; kt <= kt_end; ++kt) {
+    for (int kt = pl.beg(jb); kt < pl.end(jb); ++kt) {
       const int j0 = kt * kT;
       f32x16 s = tile_dot<HD>(Ks, j0, qreg);                 // S^T
       f32x16 dp = tile_dot<HD>(Vs, j0, greg);                // dP^T[key][query] = <V_key, dO_query>
@@ -374,7 +486,17 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
       }
       tile_accumulate<HD>(Ks, j0, s, dq);                    // dQ^T[d][query] += K^T dS^T
     }
-    store_transposed<HD>(dQ, ld.dq, i0, L, scale, dq);
+    if (jb != pl.partial && !pl.merge) store_transposed<HD>(dQ, ld.dq, i0, L, scale, dq);
+  }
+  if (split) {                                               // the two halves of the heavy tiles meet through the K rows
+    float* slot = lds + pl.simd * merge_floats<HD>();
+    __syncthreads();
+    if (pl.partial >= 0) park_acc<HD>(slot, dq);
+    __syncthreads();
+    if (pl.merge) {
+      add_parked<HD>(slot, dq);
+      store_transposed<HD>(dQ, ld.dq, i0, L, scale, dq);
+    }
   }
 }
 
@@ -387,7 +509,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
                                                                const float* __restrict__ Dv, const int L,
                                                                const float scale, const int causal,
                                                                float* __restrict__ dK, float* __restrict__ dV,
-                                                               const DropArgs drop, const AttnLd ld) {
+                                                               const DropArgs drop, const AttnLd ld, const int split) {
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Qs = lds;                          // scale * Q
@@ -411,19 +533,22 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
-  RBX_FOR_WAVE_TILES(nT, wid, ju) {
-    const int jt = nT - 1 - ju;                     // (key tile jt meets nT - jt query tiles: cost index ju)
-    const int j0 = jt * kT, kj = j0 + li;
+  const WavePlan pl = wave_plan(nT, wid, causal, split);
+  f32x16 dk[HD / 32], dv[HD / 32];
+  int j0 = 0;
+  for (int jb = 0; jb < pl.n; ++jb) {
+    const int jt = nT - 1 - pl.tile(jb);            // (key tile jt meets nT - jt query tiles: cost index nT - 1 - jt)
+    j0 = jt * kT;
+    const int kj = j0 + li;
     float kreg[HD / 2], vreg[HD / 2];
     load_tile_regs<HD>(K, ld.k, j0, L, 1.0f, kreg);
     load_tile_regs<HD>(V, ld.v, j0, L, 1.0f, vreg);
-    f32x16 dk[HD / 32], dv[HD / 32];
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
-    const int it_beg = causal ? jt : 0;
-    for (int it = it_beg; it < nT; ++it) {
+    const int it_beg = (causal ? jt : 0) + pl.beg(jb), it_end = (causal ? jt : 0) + pl.end(jb);
+    for (int it = it_beg; it < it_end; ++it) {
       const int i0 = it * kT;
       f32x16 s = tile_dot<HD>(Qs, i0, kreg);                 // S[query][key] (already scaled)
       f32x16 dp = tile_dot<HD>(Gs, i0, vreg);                // dP[query][key]
@@ -464,13 +589,40 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
       tile_accumulate<HD>(Gs, i0, p, dv);                    // dV^T[d][key] += dO^T P
       tile_accumulate<HD>(Qs, i0, s, dk);                    // dK^T[d][key] += (scale Q)^T dS
     }
-    store_transposed<HD>(dK, ld.dk, j0, L, 1.0f, dk);
-    store_transposed<HD>(dV, ld.dv, j0, L, 1.0f, dv);
+    if (jb != pl.partial && !pl.merge) {
+      store_transposed<HD>(dK, ld.dk, j0, L, 1.0f, dk);
+      store_transposed<HD>(dV, ld.dv, j0, L, 1.0f, dv);
+    }
+  }
+  if (split) {                 // the two halves of the heavy tiles meet through the Q rows: dV, then dK through the same slots
+    float* slot = lds + pl.simd * merge_floats<HD>();
+    __syncthreads();
+    if (pl.partial >= 0) park_acc<HD>(slot, dv);
+    __syncthreads();
+    if (pl.merge) {
+      add_parked<HD>(slot, dv);
+      store_transposed<HD>(dV, ld.dv, j0, L, 1.0f, dv);
+    }
+    __syncthreads();
+    if (pl.partial >= 0) park_acc<HD>(slot, dk);
+    __syncthreads();
+    if (pl.merge) {
+      add_parked<HD>(slot, dk);
+      store_transposed<HD>(dK, ld.dk, j0, L, 1.0f, dk);
+    }
   }
 }
 
 bool attn_mfma_supported(int lq, int lk, int hd, const float* mask, const float* probs) {
   return mask == nullptr && probs == nullptr && lq == lk && lq <= 256 && (hd == 32 || hd == 64);
+}
+
+// heavy tiles dealt to both wavefronts of their SIMD (wave_plan): causal sequences of at least three tiles (below that no
+// tile is two steps heavier than its partner); RBX_ATTN_SPLIT=0 keeps one wavefront per tile.  The four merge slots fit in
+// the operand rows they reuse: 4 * (32 HD + 128) floats <= 2 * 96 * (HD + 1) for HD = 32 and 64.
+static bool attn_split(int L, int causal) {
+  static const bool on = [] { const char* e = getenv("RBX_ATTN_SPLIT"); return e == nullptr || e[0] != '0'; }();
+  return on && causal != 0 && L > 2 * kT;
 }
 
 template <int HD>
@@ -484,14 +636,20 @@ static int run_fwd(const float* q, const float* k, const float* v, long long bh,
                    float* lse, const DropArgs& drop, const AttnLd& ld, hipStream_t s) {
   const size_t lds = lds_bytes<HD>(L, false);
   static const bool pf_on = [] { const char* e = getenv("RBX_ATTN_PREFETCH"); return e == nullptr || e[0] != '0'; }();
+  // (the looping form keeps the heavy tiles' partials in LDS slots of their own behind K and V: where those do not fit --
+  //  HD = 64, L > 224 -- neither form splits, so that a sequence gets the same arithmetic from both)
+  const size_t lds_split = lds + 4 * merge_floats<HD>() * sizeof(float);
+  const bool split_on = attn_split(L, causal) && lds_split <= 160 * 1024;
   if constexpr (HD == 64) {
     if (pf_on && lds > 80 * 1024 && bh > kCUs) {             // one workgroup per CU either way: loop over sequences, prefetch
       const int npf = ((L + kT - 1) / kT * kT) * (HD / 4) / kAttnThreads;      // 6, 7 or 8 at Lp = 192, 224, 256
+      const int split = split_on ? 1 : 0;
+      const size_t lds_pf = split ? lds_split : lds;
 #define RBX_ATTN_PF(N)                                                                                                  \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD, DROP, N>),                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                      \
-      hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD, DROP, N>), dim3(kCUs), dim3(kAttnThreads), lds, s, q, k, v, L, scale,   \
-                         causal, o, lse, drop, ld, bh)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pf));                   \
+      hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD, DROP, N>), dim3(kCUs), dim3(kAttnThreads), lds_pf, s, q, k, v, L, scale, \
+                         causal, o, lse, drop, ld, bh, split)
       if (npf == 6) { RBX_ATTN_PF(6); } else if (npf == 7) { RBX_ATTN_PF(7); } else { RBX_ATTN_PF(8); }
 #undef RBX_ATTN_PF
       return check_launch("attn_mfma_fwd_kernel");
@@ -500,7 +658,7 @@ static int run_fwd(const float* q, const float* k, const float* v, long long bh,
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_fwd_kernel<HD, DROP, 0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   hipLaunchKernelGGL((attn_mfma_fwd_kernel<HD, DROP, 0>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, q, k, v,
-                     L, scale, causal, o, lse, drop, ld, bh);
+                     L, scale, causal, o, lse, drop, ld, bh, split_on ? 2 : 0);
   return check_launch("attn_mfma_fwd_kernel");
 }
 
@@ -513,10 +671,11 @@ static int run_bwd(const float* q, const float* k, const float* v, const float* 
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(la));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_bwd_kv_kernel<HD, DROP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lb));
+  const int split = attn_split(L, causal) ? 1 : 0;
   hipLaunchKernelGGL((attn_mfma_bwd_q_kernel<HD, DROP>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), la, s, q, k, v, o,
-                     go, lse, L, scale, causal, dq, scratch, drop, ld);
+                     go, lse, L, scale, causal, dq, scratch, drop, ld, split);
   hipLaunchKernelGGL((attn_mfma_bwd_kv_kernel<HD, DROP>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lb, s, q, k, v, go,
-                     lse, scratch, L, scale, causal, dk, dv, drop, ld);
+                     lse, scratch, L, scale, causal, dk, dv, drop, ld, split);
   return check_launch("attn_mfma_bwd kernels");
 }
 
