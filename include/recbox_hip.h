@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 115          /* 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 116          /* 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -518,6 +518,17 @@ int rbx_cross_bwd(const float* d_x0, const float* d_h, const float* d_dout, int6
  * sasrec.py:68-77, 92) in one pass; its backward is the same call on the incoming gradient. */
 int rbx_rowscale(const float* d_x, const float* d_add, const float* d_scale, int64_t rows, int32_t dim, float alpha,
                  float* d_out, void* stream);
+/* The same prologue with the position rows read in place: sasrec.py:68-77 looks up positions = tile(arange(L), [B, 1]), i.e.
+ * the table's first L rows for every sequence.  rbx_rowscale_seq: d_add holds add_rows rows of `dim` floats that repeat every
+ * add_rows rows of x (rows % add_rows == 0).  rbx_seq_colsum: the gradient of those rows,
+ *   out[l, :] = sum_b scale[b * seq_len + l] * g[b, l, :]        (g [batch, seq_len, dim], out [seq_len, dim], overwritten),
+ * one streaming pass + a fixed-order sum of per-32-sequence partials (deterministic); the reference's embedding backward
+ * (index_add over B * L position ids) gives the same sums. */
+int rbx_rowscale_seq(const float* d_x, const float* d_add, int64_t add_rows, const float* d_scale, int64_t rows, int32_t dim,
+                     float alpha, float* d_out, void* stream);
+size_t rbx_seq_colsum_workspace_size(int64_t batch, int32_t seq_len, int32_t dim);
+int rbx_seq_colsum(const float* d_g, const float* d_scale, int64_t batch, int32_t seq_len, int32_t dim, float* d_out,
+                   void* d_workspace, size_t workspace_bytes, void* stream);
 /* out[r, c] = base[r, c] + (c < prefix_cols ? a[r, c] + b[r, c] : 0) for c < cols; base, a, b optional (NULL = zeros),
  * strides in floats.  The input gradient of a row block that one consumer reads whole and two more read through its
  * leading columns: DeepFM feeds the same embeddings to the tower (embeddings | dense values), to FM and to the
@@ -578,6 +589,18 @@ int rbx_linear_fwd_fused(const float* d_x, int64_t x_stride, const float* d_w, c
 int rbx_linear_dx_fused(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
                         const float* d_mask, int64_t mask_stride, const float* d_residual, int64_t residual_stride,
                         float* d_dx, int64_t dx_stride, void* stream);
+/* The `seqs *= ~timeline_mask` of a SASRec block (sasrec.py:92) in the backward of the Linear in front of it, without a pass
+ * that writes the scaled gradient g = diag(row_scale) dy:
+ *   rbx_linear_dx_scaled:   dx[m,k] = (((dy W) o [mask > 0]) + residual) * row_scale[row]
+ *   rbx_linear_dwdb_scaled: dW[n,k] = g^T x, db[n] = column sums of g (d_db may be NULL); workspace as rbx_linear_bwd's with
+ *                           act = 0.  RBX_ERR_UNSUPPORTED unless n = k = 64, m >= 8192 and the rows are 16-byte aligned (the
+ *                           slab kernel, tall_dw64_kernel): the caller then forms g itself (rbx_rowscale) and calls rbx_linear_bwd. */
+int rbx_linear_dx_scaled(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
+                         const float* d_mask, int64_t mask_stride, const float* d_residual, int64_t residual_stride,
+                         const float* d_row_scale, float* d_dx, int64_t dx_stride, void* stream);
+int rbx_linear_dwdb_scaled(const float* d_x, int64_t x_stride, const float* d_dy, int64_t dy_stride, const float* d_row_scale,
+                           int64_t m, int32_t n, int32_t k, float* d_dw, float* d_db, void* d_workspace,
+                           size_t workspace_bytes, void* stream);
 /* DeepFM (third_party/rechub/models/ranking/deepfm.py:34-42): one gathered block x [m, k] = [F * D embeddings | dense values] feeds
  * the tower's first Linear, the FM term over its leading fm_cols = F * D columns and the first-order Linear over the same
  * columns.  rbx_fm_sum_fwd: y_fm[b] = 0.5 sum_d (S_d^2 - sum_f e_fd^2) and S[b, d] = sum_f e[b, f, d] in one pass.

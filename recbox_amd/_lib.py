@@ -100,6 +100,9 @@ SIGNATURES = {
     "rbx_embed_rezero": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P]),
     "rbx_sort_share": (ctypes.c_int, [_FP, _FP, _i32, _i32, _P, _FP, _FP, _i32, _i32, _P, _sz, _i64, _P]),
     "rbx_rowscale": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _f32, _P, _P]),
+    "rbx_rowscale_seq": (ctypes.c_int, [_P, _P, _i64, _P, _i64, _i32, _f32, _P, _P]),
+    "rbx_seq_colsum_workspace_size": (_sz, [_i64, _i32, _i32]),
+    "rbx_seq_colsum": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _P, _P, _sz, _P]),
     "rbx_sum_prefix": (ctypes.c_int, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _i32, _P, _i64, _P]),
     "rbx_fm_rezero": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P]),
     "rbx_fm_bwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _P, _i32, _i32, _P, _sz, _P]),
@@ -147,6 +150,8 @@ SIGNATURES = {
     "rbx_linear_bwd_workspace_size": (_sz, [_i64, _i32, _i32, _i32]),
     "rbx_linear_fwd_fused": (ctypes.c_int, [_P, _i64, _P, _P, _i64, _i32, _i32, _i32, _P, _i64, _P, _P, _i64, _P]),
     "rbx_linear_dx_fused": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i64, _P, _i64, _P]),
+    "rbx_linear_dx_scaled": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i64, _P, _P, _i64, _P]),
+    "rbx_linear_dwdb_scaled": (ctypes.c_int, [_P, _i64, _P, _i64, _P, _i64, _i32, _i32, _P, _P, _P, _sz, _P]),
     "rbx_fm_sum_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _i32, _P, _P, _P]),
     "rbx_linear_dx_deepfm": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i32, _i32, _P, _P, _P, _P, _i64,
                                             _P]),

@@ -1963,14 +1963,13 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_k64n64_kernel(
       }
     }
     if constexpr (has_rs) {
-      const float* base = epi.rowscale + r0 + 4 * h;
-      if (full) {
+      // the slab's 32 row scales as ONE request (lane l: row l), dealt to the rows a lane finishes through the LDS crossbar:
+      // sixteen loads of two distinct words each per slab made the kernel 40 us slower (147 vs 107 us at 819 200 rows) --
+      // these kernels are bound by the number of memory requests, not by bytes
+      const int rr = r0 + (lane & 31);
+      const float mine = epi.rowscale[rr < M ? rr : M - 1];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) rs[i] = base[slab_row(i)];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rs[i] = base[slab_row(i) + 4 * h < left ? slab_row(i) : 0];
-      }
+      for (int i = 0; i < 16; ++i) rs[i] = __shfl(mine, slab_row(i) + 4 * h, 64);
     }
     f32x16 acc0, acc1;
 #pragma unroll
@@ -2127,10 +2126,14 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void gemm_f32_slabw_kernel(
 // and x is requested from memory exactly once (tall_dw_kernel's four quadrant wavefronts each read a half of both: twice
 // the L1 traffic, dword requests; 3.5 TB/s).  The four wavefronts' sums meet in LDS in a fixed order; one [64, 64] (+ [64])
 // partial per workgroup goes to splitk_reduce_kernel.
+// SCALED: row r of g counts row_scale[r] times (dW = (diag(s) g)^T x, db likewise): the `* ~timeline_mask` of a SASRec block
+// in the backward, without a pass that writes the scaled gradient (rbx_linear_dwdb_scaled).
+template <bool SCALED>
 __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const float* __restrict__ g, const long long ldg,
                                                                       const float* __restrict__ x, const long long ldx,
                                                                       const int M, float* __restrict__ dw_part,
-                                                                      float* __restrict__ db_part, const int abl) {
+                                                                      float* __restrict__ db_part, const int abl,
+                                                                      const float* __restrict__ row_scale) {
   __shared__ float lds[kSlabWaves * 2 * 32 * kSlabLd];
   __shared__ float cs_lds[kSlabWaves][64];
   static_assert(kSlabWaves * 2 * 32 * kSlabLd >= kSlabWaves * 64 * 64, "the slabs' LDS also holds the wavefronts' [64, 64] sums");
@@ -2151,10 +2154,11 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
   float* pg = sg + (lane >> 4) * kSlabLd + 4 * (lane & 15);
   float* px = sx + (lane >> 4) * kSlabLd + 4 * (lane & 15);
   // coalesced registers -> LDS (rows beyond M carry zeros in g: their products and column sums vanish)
-  auto park = [&](int left, const f32x4 (&vg)[8], const f32x4 (&vx)[8]) {
+  auto park = [&](int left, const f32x4 (&vg)[8], const f32x4 (&vx)[8], const float (&sc)[8]) {
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       f32x4 u = vg[p];
+      if constexpr (SCALED) u *= sc[p];
       if (left < 32 && 4 * p + (lane >> 4) >= left) u = f32x4{0.f, 0.f, 0.f, 0.f};
       cs += u;
       *reinterpret_cast<f32x4*>(pg + 4 * p * kSlabLd) = u;
@@ -2169,8 +2173,15 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
     unsigned og_full[8], ox_full[8], og[8], ox[8];
     slab_offsets(ldg, 32, lane, og_full);
     slab_offsets(ldx, 32, lane, ox_full);
-    auto issue = [&](int sl, f32x4 (&vg)[8], f32x4 (&vx)[8]) {
+    auto issue = [&](int sl, f32x4 (&vg)[8], f32x4 (&vx)[8], float (&sc)[8]) {
       const int left = M - sl * 32;
+      if constexpr (SCALED) {                 // (plain loads in front of the slab's: they are back long before the wait below)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int row = sl * 32 + 4 * p + (lane >> 4);
+          sc[p] = row_scale[row < M ? row : M - 1];
+        }
+      }
 #pragma unroll
       for (int p = 0; p < 8; ++p) { og[p] = og_full[p]; ox[p] = ox_full[p]; }
       if (left < 32) {
@@ -2181,18 +2192,19 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
       slab_issue(x + static_cast<long long>(sl) * 32 * ldx, ox, vx);
     };
     f32x4 ng[8], nx[8];
-    issue(s, ng, nx);
+    float nsc[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    issue(s, ng, nx, nsc);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ng[0]), "+v"(ng[1]), "+v"(ng[2]), "+v"(ng[3]), "+v"(ng[4]), "+v"(ng[5]),
                  "+v"(ng[6]), "+v"(ng[7]) : : "memory");
     slab_arrived(nx);
-    park(M - s * 32, ng, nx);
+    park(M - s * 32, ng, nx, nsc);
     const float* rg = sg + h * kSlabLd + m;
     const float* rx = sx + h * kSlabLd + m;
     for (;;) {
       int sn = s + nw;
       const bool more = sn < slabs;
       sn = more ? sn : s;
-      issue(sn, ng, nx);
+      issue(sn, ng, nx, nsc);
       if (abl != 1)
 #pragma unroll
       for (int jj = 0; jj < 16; ++jj) {
@@ -2210,7 +2222,7 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();       // every lane has read the current slab
       s = sn;
-      if (abl != 2) park(M - s * 32, ng, nx);
+      if (abl != 2) park(M - s * 32, ng, nx, nsc);
     }
   }
   __syncthreads();                            // all slabs consumed: the LDS now takes the four [64, 64] sums
@@ -2663,8 +2675,8 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     if (n_wg > 2 * kCUs) n_wg = 2 * kCUs;
     if (dw64_wgs() > 0 && n_wg > dw64_wgs()) n_wg = dw64_wgs();
     float* part = ws + dw_floats;
-    hipLaunchKernelGGL(tall_dw64_kernel, dim3(n_wg), dim3(64 * kSlabWaves), 0, s, g, static_cast<long long>(n), d_x,
-                       static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr, dw64_abl());
+    hipLaunchKernelGGL(tall_dw64_kernel<false>, dim3(n_wg), dim3(64 * kSlabWaves), 0, s, g, static_cast<long long>(n), d_x,
+                       static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr, dw64_abl(), nullptr);
     launch_splitk_reduce(s, 64u, ws, 64LL * 64, n_wg, d_dw, d_db != nullptr ? part : nullptr, 64LL, d_db);
     return check_launch("tall dW / db kernels (slab form)");
   }
@@ -2677,8 +2689,9 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     if (n_wg > 2 * kCUs) n_wg = 2 * kCUs;
     float* part = ws + dw_floats;
     for (int half = 0; half < 2; ++half) {
-      hipLaunchKernelGGL(tall_dw64_kernel, dim3(n_wg), dim3(64 * kSlabWaves), 0, s, g + 64 * half, static_cast<long long>(n),
-                         d_x, static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr, 0);
+      hipLaunchKernelGGL(tall_dw64_kernel<false>, dim3(n_wg), dim3(64 * kSlabWaves), 0, s, g + 64 * half,
+                         static_cast<long long>(n), d_x, static_cast<long long>(x_stride), M, ws,
+                         d_db != nullptr ? part : nullptr, 0, nullptr);
       launch_splitk_reduce(s, 64u, ws, 64LL * 64, n_wg, d_dw + static_cast<long long>(half) * 64 * k,
                            d_db != nullptr ? part : nullptr, 64LL, d_db != nullptr ? d_db + 64 * half : nullptr);
     }
@@ -2722,6 +2735,56 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     rc = check_launch("bias grad kernels");
   }
   return rc;
+}
+
+// dW[64, 64] = (diag(row_scale) dy)^T x and db = its column sums in the slab kernel, the scaled gradient never written
+// (the `seqs *= ~timeline_mask` of a SASRec block, sasrec.py:92, in the backward of the Linear in front of it)
+extern "C" int rbx_linear_dwdb_scaled(const float* d_x, int64_t x_stride, const float* d_dy, int64_t dy_stride,
+                                      const float* d_row_scale, int64_t m, int32_t n, int32_t k, float* d_dw, float* d_db,
+                                      void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (m == 0) return RBX_OK;
+  using namespace rbx;
+  if (!d_x || !d_dy || !d_row_scale || !d_dw) return fail(RBX_ERR_INVALID, "linear_dwdb_scaled: NULL tensor");
+  if (m < 0 || m > INT_MAX || x_stride < k || dy_stride < n) return fail(RBX_ERR_INVALID, "linear_dwdb_scaled: bad shape");
+  const size_t need = rbx_linear_bwd_workspace_size(m, n, k, 0);
+  if (d_workspace == nullptr || workspace_bytes < need) return fail(RBX_ERR_WORKSPACE, "linear_dwdb_scaled: workspace too small");
+  const size_t dw_floats = dw_ws_floats(n, k);
+  if (!(n == 64 && k == 64 && m >= 8192 && vec_ok(d_dy, dy_stride) && vec_ok(d_x, x_stride) &&
+        dw_floats >= static_cast<size_t>(2 * kCUs) * 64 * 64))
+    return fail(RBX_ERR_UNSUPPORTED, "linear_dwdb_scaled: only [m >= 8192, 64]^T x [m, 64] with 16-byte aligned rows");
+  hipStream_t s = as_stream(stream);
+  float* ws = static_cast<float*>(d_workspace);
+  const int M = static_cast<int>(m);
+  const int slabs = (M + 31) / 32;
+  int n_wg = (slabs + kSlabWaves - 1) / kSlabWaves;
+  if (n_wg > 2 * kCUs) n_wg = 2 * kCUs;
+  float* part = ws + dw_floats;
+  hipLaunchKernelGGL(tall_dw64_kernel<true>, dim3(n_wg), dim3(64 * kSlabWaves), 0, s, d_dy, static_cast<long long>(dy_stride),
+                     d_x, static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr, 0, d_row_scale);
+  launch_splitk_reduce(s, 64u, ws, 64LL * 64, n_wg, d_dw, d_db != nullptr ? part : nullptr, 64LL, d_db);
+  return check_launch("tall dW / db kernels (slab form, scaled rows)");
+}
+
+extern "C" int rbx_linear_dx_scaled(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
+                                    const float* d_mask, int64_t mask_stride, const float* d_residual,
+                                    int64_t residual_stride, const float* d_row_scale, float* d_dx, int64_t dx_stride,
+                                    void* stream) {
+  if (m == 0) return RBX_OK;
+  using namespace rbx;
+  if (d_dy == nullptr || d_w == nullptr || d_dx == nullptr || d_row_scale == nullptr)
+    return fail(RBX_ERR_INVALID, "linear_dx_scaled: NULL tensor");
+  if (m < 0 || n <= 0 || k <= 1 || m > INT_MAX) return fail(RBX_ERR_INVALID, "linear_dx_scaled: bad shape (k must be > 1)");
+  if (dy_stride < n || dx_stride < k || (d_mask != nullptr && mask_stride < k) ||
+      (d_residual != nullptr && residual_stride < k))
+    return fail(RBX_ERR_INVALID, "linear_dx_scaled: a row stride is shorter than its row");
+  Epi epi{};
+  epi.res = d_residual;
+  epi.ldres = static_cast<long long>(residual_stride);
+  epi.mask = d_mask;
+  epi.ldmask = static_cast<long long>(mask_stride);
+  epi.rowscale = d_row_scale;
+  return run_gemm<true, false>(d_dy, dy_stride, d_w, k, d_dx, static_cast<int>(m), k, n, nullptr, 0, nullptr, 0,
+                               as_stream(stream), dx_stride, epi);
 }
 
 // ---- bf16 planes of a weight matrix for the split-operand GEMM (see gemm_bx6_kernel) -------------------------------------

@@ -570,9 +570,11 @@ extern "C" int rbx_cross_bwd(const float* d_x0, const float* d_h, const float* d
 // `e *= sqrt(D); e += position_emb(...); e *= ~timeline_mask.unsqueeze(-1)` are three element-wise ATen passes, the
 // broadcast one over [B, L, 1] x [B, L, D] un-vectorised (159 us at [819200, 64] against 64 us for a plain pass); here one.
 namespace rbx {
+// add_period > 0: `add` holds add_period floats that repeat (the position rows [L, D] of every sequence of a [B, L, D] block)
 __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                        const float* __restrict__ s, const long long rows, const int dim,
-                                                       const float alpha, float* __restrict__ out) {
+                                                       const float alpha, float* __restrict__ out,
+                                                       const long long add_period) {
   const long long total = rows * dim;
   const long long step = static_cast<long long>(gridDim.x) * blockDim.x * 4;
   for (long long i = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i < total; i += step) {
@@ -582,12 +584,12 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
       const v4f vv = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(x + i));       // streamed once
       const float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (add != nullptr) a = *reinterpret_cast<const float4*>(add + i);
+      if (add != nullptr) a = *reinterpret_cast<const float4*>(add + (add_period > 0 ? i % add_period : i));
       *reinterpret_cast<float4*>(out + i) = make_float4((alpha * v.x + a.x) * sc, (alpha * v.y + a.y) * sc,
                                                         (alpha * v.z + a.z) * sc, (alpha * v.w + a.w) * sc);
     } else {
       for (long long j = i; j < i + 4 && j < total; ++j)
-        out[j] = (alpha * x[j] + (add != nullptr ? add[j] : 0.f)) * s[j / dim];
+        out[j] = (alpha * x[j] + (add != nullptr ? add[add_period > 0 ? j % add_period : j] : 0.f)) * s[j / dim];
     }
   }
 }
@@ -606,8 +608,117 @@ extern "C" int rbx_rowscale(const float* d_x, const float* d_add, const float* d
   if (blocks > kCUs * 32) blocks = kCUs * 32;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(rowscale_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_x, d_add, d_scale,
-                     static_cast<long long>(rows), dim, alpha, d_out);
+                     static_cast<long long>(rows), dim, alpha, d_out, 0LL);
   return check_launch("rowscale_kernel");
+}
+
+// ---- SASRec's input block with the position rows read in place -------------------------------------------------------------
+// sasrec.py:68-77: `positions = tile(arange(L), [B, 1]); seqs = item_emb(seq) * sqrt(D) + position_emb(positions);
+// seqs *= ~timeline_mask`.  The positions of every sequence are 0 .. L-1, so the looked-up block is the table's first L rows
+// B times over: the forward reads those rows (51 KB, cache resident) instead of a gathered [B, L, D] copy, and the table's
+// gradient dP[l, :] = sum_b keep[b, l] g[b, l, :] is a column sum over the batch of the incoming gradient -- one streaming
+// pass and a fixed-order sum of the block partials, where the generic embedding backward sorts B L equal-by-thousands ids and
+// reduces 200 rows of 4096 duplicates each (sort 55 us + reduce and fix-ups 140 us + the pass that wrote keep * g 83 us).
+namespace rbx {
+constexpr int kSeqSumRows = 32;                 // sequences per block partial
+
+template <int W>
+__global__ __launch_bounds__(256) void seq_colsum_partial_kernel(const float* __restrict__ g, const float* __restrict__ s,
+                                                                 const long long batch, const int L, const int dim,
+                                                                 float* __restrict__ partial) {
+  const long long cols = static_cast<long long>(L) * dim;
+  const long long c = (static_cast<long long>(blockIdx.x) * 256 + threadIdx.x) * W;
+  if (c >= cols) return;
+  const int l = static_cast<int>(c / dim);                          // (W = 4: dim % 4 == 0, the four columns share a row)
+  const long long b0 = static_cast<long long>(blockIdx.y) * kSeqSumRows;
+  const long long b1 = b0 + kSeqSumRows < batch ? b0 + kSeqSumRows : batch;
+  float acc[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) acc[k] = 0.f;
+  constexpr int U = 8;
+  for (long long b = b0; b < b1; b += U) {                          // U rows in flight, added in ascending order
+    float v[U][W], sc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long bb = b + u < b1 ? b + u : b1 - 1;
+      sc[u] = b + u < b1 ? s[bb * L + l] : 0.f;
+      if constexpr (W == 4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g + bb * cols + c));
+        v[u][0] = t[0]; v[u][1] = t[1]; v[u][2] = t[2]; v[u][3] = t[3];
+      } else {
+        v[u][0] = g[bb * cols + c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < W; ++k) acc[k] += sc[u] * v[u][k];
+  }
+#pragma unroll
+  for (int k = 0; k < W; ++k) partial[static_cast<long long>(blockIdx.y) * cols + c + k] = acc[k];
+}
+
+__global__ __launch_bounds__(256) void seq_colsum_final_kernel(const float* __restrict__ partial, const int n_blocks,
+                                                               const long long cols, float* __restrict__ out) {
+  const long long c = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float t = 0.f;
+  for (int k = 0; k < n_blocks; ++k) t += partial[static_cast<long long>(k) * cols + c];
+  out[c] = t;
+}
+}  // namespace rbx
+
+extern "C" int rbx_rowscale_seq(const float* d_x, const float* d_add, int64_t add_rows, const float* d_scale, int64_t rows,
+                                int32_t dim, float alpha, float* d_out, void* stream) {
+  using namespace rbx;
+  if (rows == 0 || dim == 0) return RBX_OK;
+  if (rows < 0 || dim < 0 || add_rows <= 0 || rows % add_rows != 0)
+    return fail(RBX_ERR_INVALID, "rowscale_seq: rows must be a multiple of add_rows > 0");
+  if (!d_x || !d_add || !d_scale || !d_out) return fail(RBX_ERR_INVALID, "rowscale_seq: NULL tensor");
+  if ((dim & 3) == 0 && (((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_out) |
+                           reinterpret_cast<uintptr_t>(d_add)) & 15) != 0))
+    return fail(RBX_ERR_INVALID, "rowscale_seq: tensors must be 16-byte aligned when dim is a multiple of 4");
+  long long blocks = (rows * dim / 4 + 255) / 256;
+  if (blocks > kCUs * 32) blocks = kCUs * 32;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(rowscale_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, as_stream(stream), d_x, d_add, d_scale,
+                     static_cast<long long>(rows), dim, alpha, d_out, static_cast<long long>(add_rows) * dim);
+  return check_launch("rowscale_kernel (periodic add)");
+}
+
+extern "C" size_t rbx_seq_colsum_workspace_size(int64_t batch, int32_t seq_len, int32_t dim) {
+  if (batch <= 0 || seq_len <= 0 || dim <= 0) return 0;
+  const size_t nb = static_cast<size_t>((batch + rbx::kSeqSumRows - 1) / rbx::kSeqSumRows);
+  return nb * static_cast<size_t>(seq_len) * dim * sizeof(float);
+}
+
+extern "C" int rbx_seq_colsum(const float* d_g, const float* d_scale, int64_t batch, int32_t seq_len, int32_t dim, float* d_out,
+                              void* d_workspace, size_t workspace_bytes, void* stream) {
+  using namespace rbx;
+  if (seq_len <= 0 || dim <= 0 || batch < 0) return fail(RBX_ERR_INVALID, "seq_colsum: bad shape");
+  if (!d_out) return fail(RBX_ERR_INVALID, "seq_colsum: NULL output");
+  hipStream_t s = as_stream(stream);
+  const long long cols = static_cast<long long>(seq_len) * dim;
+  if (batch == 0) {
+    (void)hipMemsetAsync(d_out, 0, cols * sizeof(float), s);
+    return check_launch("seq_colsum (empty batch)");
+  }
+  if (!d_g || !d_scale) return fail(RBX_ERR_INVALID, "seq_colsum: NULL tensor");
+  if (d_workspace == nullptr || workspace_bytes < rbx_seq_colsum_workspace_size(batch, seq_len, dim))
+    return fail(RBX_ERR_WORKSPACE, "seq_colsum: workspace too small");
+  const int nb = static_cast<int>((batch + kSeqSumRows - 1) / kSeqSumRows);
+  float* partial = static_cast<float*>(d_workspace);
+  const bool vec = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(d_g) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(seq_colsum_partial_kernel<4>, dim3(static_cast<unsigned>((cols / 4 + 255) / 256), nb), dim3(256), 0, s,
+                       d_g, d_scale, static_cast<long long>(batch), seq_len, dim, partial);
+  else
+    hipLaunchKernelGGL(seq_colsum_partial_kernel<1>, dim3(static_cast<unsigned>((cols + 255) / 256), nb), dim3(256), 0, s,
+                       d_g, d_scale, static_cast<long long>(batch), seq_len, dim, partial);
+  hipLaunchKernelGGL(seq_colsum_final_kernel, dim3(static_cast<unsigned>((cols + 255) / 256)), dim3(256), 0, s, partial, nb,
+                     cols, d_out);
+  return check_launch("seq_colsum kernels");
 }
 
 // ---- gradient of a row block that is read whole AND through its leading columns ---------------------------------

@@ -82,6 +82,12 @@ class config(object):
     # activations inside the kernel, six products per f32 product with f32 accumulation (csrc/rbx_dense.hip,
     # gemm_bx6_kernel: f32-level results at ~2.7x fewer matrix-core cycles).  Off: every GEMM on v_mfma_f32_32x32x2_f32.
     gemm_bx6 = os.environ.get("RECBOX_AMD_GEMM_BX6", "1") != "0"
+    # SASRec's FFN sub-layer backward: the `* ~timeline_mask` rows scaled inside the dW kernel and the dx epilogues
+    # (rbx_linear_dwdb_scaled / rbx_linear_dx_scaled) instead of by a pass that writes dout * keep
+    ffn_mask_in_gemms = os.environ.get("RECBOX_AMD_FFN_MASK_IN_GEMMS", "1") != "0"
+    # SASRec's position rows read in place and their gradient as a column sum over the batch (sasrec_input) instead of a
+    # lookup of tile(arange(L)) with the generic sort + segmented reduce behind it
+    seq_positions_in_place = os.environ.get("RECBOX_AMD_SEQ_POSITIONS", "1") != "0"
     # Linear -> BatchNorm1d (-> ReLU) -> Linear of a tower: the BatchNorm's column statistics come out of the epilogue of the
     # GEMM in front of it, its backward's column sums out of the dx GEMM behind it (rbx_linear_fwd_bnstats /
     # rbx_linear_dx_bnsums; needs gemm_bx6 and >= 4096 rows).  Built, parity-tested and measured; OFF by default because it
@@ -2150,6 +2156,51 @@ class _RowScale(torch.autograd.Function):
         return dx, dadd, None, None
 
 
+class _SeqInput(torch.autograd.Function):
+    """(alpha * e + P[l]) * keep[b, l] for e [B, L, D], P [L, D] (the first L rows of SASRec's position table, sasrec.py:68-77:
+    its positions are arange(L) for every sequence), keep [B, L] without gradient.  Backward: de = alpha keep g in one pass,
+    dP = sum_b keep g as a column sum over the batch (rbx_seq_colsum) -- no gathered [B, L, D] position block, no sort of
+    B L position ids."""
+
+    @staticmethod
+    def forward(ctx, e, pos, keep, alpha):
+        _require_cuda(e, "sequence block")
+        B, L, D = e.shape
+        x2 = e.contiguous().float().view(B * L, D)
+        p2 = pos.contiguous().float()
+        if tuple(p2.shape) != (L, D):
+            raise ValueError("sasrec_input: position rows must be [L, D] = [%d, %d], got %s" % (L, D, tuple(p2.shape)))
+        k1 = keep.contiguous().float().view(-1)
+        out = torch.empty_like(x2)
+        check(lib.rbx_rowscale_seq(_ptr(x2), _ptr(p2), L, _ptr(k1), B * L, D, float(alpha), _ptr(out), _stream()))
+        ctx.save_for_backward(k1)
+        ctx.alpha, ctx.shape = float(alpha), (B, L, D)
+        return out.view(B, L, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        (k1,) = ctx.saved_tensors
+        B, L, D = ctx.shape
+        g2 = g.contiguous().float().view(B * L, D)
+        de = dpos = None
+        if ctx.needs_input_grad[0]:
+            de = torch.empty_like(g2)
+            check(lib.rbx_rowscale(_ptr(g2), None, _ptr(k1), B * L, D, ctx.alpha, _ptr(de), _stream()))
+            de = de.view(B, L, D)
+        if ctx.needs_input_grad[1]:
+            dpos = torch.empty((L, D), dtype=torch.float32, device=g.device)
+            ws_bytes = lib.rbx_seq_colsum_workspace_size(B, L, D)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=g.device)
+            check(lib.rbx_seq_colsum(_ptr(g2), _ptr(k1), B, L, D, _ptr(dpos), _ptr(ws), ws_bytes, _stream()))
+        return de, dpos, None, None
+
+
+def sasrec_input(e, pos_rows, keep, alpha=1.0):
+    """``(alpha * e + pos_rows[None]) * keep[..., None]``: e [B, L, D], pos_rows [L, D] (e.g. ``position_emb.weight[:L]``),
+    keep [B, L] (no gradient)."""
+    return _SeqInput.apply(e, pos_rows, keep, alpha)
+
+
 def row_scale(x, scale, add=None, alpha=1.0):
     """``(alpha * x + add) * scale.unsqueeze(-1)`` in one pass (rbx_rowscale): ``scale`` holds one value per row of
     ``x`` [..., D] (a 0/1 timeline mask, say) and carries no gradient."""
@@ -2602,15 +2653,40 @@ def _lin_fwd(x2, w, b, act=0, residual=None, row_scale=None):
     return y
 
 
-def _lin_dx(dy2, w, mask=None, residual=None):
-    """dx = ((dy W) o [mask > 0]) + residual"""
+def _lin_dx(dy2, w, mask=None, residual=None, row_scale=None):
+    """dx = (((dy W) o [mask > 0]) + residual) * row_scale[:, None]"""
     M, N = dy2.shape
     K = w.shape[1]
     dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
+    if row_scale is not None:
+        _with_split_weights(w, M, 1, lambda: check(lib.rbx_linear_dx_scaled(
+            _ptr(dy2), dy2.stride(0), _ptr(w), M, N, K, _ptr(mask), mask.stride(0) if mask is not None else K, _ptr(residual),
+            residual.stride(0) if residual is not None else K, _ptr(row_scale), _ptr(dx), K, _stream())))
+        return dx
     _with_split_weights(w, M, 1, lambda: check(lib.rbx_linear_dx_fused(
         _ptr(dy2), dy2.stride(0), _ptr(w), M, N, K, _ptr(mask), mask.stride(0) if mask is not None else K, _ptr(residual),
         residual.stride(0) if residual is not None else K, _ptr(dx), K, _stream())))
     return dx
+
+
+def _dwdb_scaled_ok(x2, dy2):
+    """rbx_linear_dwdb_scaled's shapes (the slab kernel: [m >= 8192, 64]^T x [m, 64], 16-byte aligned rows)"""
+    return (dy2.shape[1] == 64 and x2.shape[1] == 64 and x2.shape[0] >= 8192 and x2.stride(0) % 4 == 0
+            and dy2.stride(0) % 4 == 0 and x2.data_ptr() % 16 == 0 and dy2.data_ptr() % 16 == 0)
+
+
+def _lin_dwdb_scaled(x2, dy2, row_scale, dw, db):
+    """dW = (diag(row_scale) dy)^T x into ``dw``, db = its column sums into ``db`` (either may be None)."""
+    if dw is None and db is None:
+        return
+    M, K = x2.shape
+    N = dy2.shape[1]
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=x2.device)
+    ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, 0)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device)
+    check(lib.rbx_linear_dwdb_scaled(_ptr(x2), x2.stride(0), _ptr(dy2), dy2.stride(0), _ptr(row_scale), M, N, K, _ptr(dw),
+                                     _ptr(db), _ptr(ws), ws_bytes, _stream()))
 
 
 def _lin_dwdb(x2, w, dy2, dw, db):
@@ -2730,11 +2806,12 @@ class _FfnSublayer(torch.autograd.Function):
     dropout (sasrec.py:89-92: ``seqs = forward_layernorm(seqs); seqs = forward_layer(seqs); seqs *= ~timeline_mask``)."""
 
     @staticmethod
-    def forward(ctx, e, ln_w, ln_b, eps, w1, b1, w2, b2, keep):
+    def forward(ctx, e, ln_w, ln_b, eps, w1, b1, w2, b2, keep, keep_is_mask=False):
         _require_cuda(e, "sequence block")
         B, L, E = e.shape
         x2 = e.contiguous().float().view(B * L, E)
         w1, w2 = w1.contiguous(), w2.contiguous()
+        ctx.keep_is_mask = bool(keep_is_mask) or keep.dtype == torch.bool
         k1 = keep.contiguous().float().view(-1)
         n, mean, rstd = _ln_fwd(x2, ln_w, ln_b, eps)
         h = _lin_fwd(n, w1, b1, act=1)
@@ -2750,26 +2827,36 @@ class _FfnSublayer(torch.autograd.Function):
         dev = dout.device
         need = ctx.needs_input_grad
         g0 = dout.contiguous().float().view(B * L, E)
-        g = torch.empty_like(g0)                                           # dL/d(pre-mask sum) = dout * keep
-        check(lib.rbx_rowscale(_ptr(g0), None, _ptr(k1), g0.shape[0], g0.shape[1], 1.0, _ptr(g), _stream()))
         H = w1.shape[0]
         dw2 = torch.empty_like(w2) if need[6] else None
         db2 = torch.empty(E, dtype=torch.float32, device=dev) if (has_b2 and need[7]) else None
-        _lin_dwdb(h, w2, g, dw2, db2)
-        dh = _lin_dx(g, w2, mask=h)                                        # ReLU backward of the hidden layer in the epilogue
         dw1 = torch.empty_like(w1) if need[4] else None
         db1 = torch.empty(H, dtype=torch.float32, device=dev) if (has_b1 and need[5]) else None
-        _lin_dwdb(n, w1, dh, dw1, db1)
-        dn = _lin_dx(dh, w1, residual=g)                                   # n feeds the FFN and the residual
+        if ctx.keep_is_mask and config.ffn_mask_in_gemms and _dwdb_scaled_ok(h, g0):
+            # keep is a 0 / 1 mask: g = dout * keep is never written -- the rows are scaled where dW2 reads them and in the
+            # epilogues of both dx GEMMs (keep * keep == keep makes (dh W1 + dout) * keep the same as dh W1 + g)
+            _lin_dwdb_scaled(h, g0, k1, dw2, db2)
+            dh = _lin_dx(g0, w2, mask=h, row_scale=k1)
+            _lin_dwdb(n, w1, dh, dw1, db1)
+            dn = _lin_dx(dh, w1, residual=g0, row_scale=k1)
+        else:
+            g = torch.empty_like(g0)                                       # dL/d(pre-mask sum) = dout * keep
+            check(lib.rbx_rowscale(_ptr(g0), None, _ptr(k1), g0.shape[0], g0.shape[1], 1.0, _ptr(g), _stream()))
+            _lin_dwdb(h, w2, g, dw2, db2)
+            dh = _lin_dx(g, w2, mask=h)                                    # ReLU backward of the hidden layer in the epilogue
+            _lin_dwdb(n, w1, dh, dw1, db1)
+            dn = _lin_dx(dh, w1, residual=g)                               # n feeds the FFN and the residual
         want_p = need[1] or (has_ln_b and need[2])
         de, dgamma, dbeta = _ln_bwd(x2, dn, ln_w, mean, rstd, want_p)
         return (de.view(B, L, E) if need[0] else None, dgamma if need[1] else None,
-                dbeta if (has_ln_b and need[2]) else None, None, dw1, db1, dw2, db2, None)
+                dbeta if (has_ln_b and need[2]) else None, None, dw1, db1, dw2, db2, None, None)
 
 
-def sasrec_ffn_sublayer(e, norm, w1, b1, w2, b2, keep):
-    """``n = norm(e); (n + relu(n w1^T + b1) w2^T + b2) * keep[..., None]`` for [B, L, E] blocks; keep [B, L] carries no gradient."""
-    return _FfnSublayer.apply(e, norm.weight, norm.bias, float(norm.eps), w1, b1, w2, b2, keep)
+def sasrec_ffn_sublayer(e, norm, w1, b1, w2, b2, keep, keep_is_mask=False):
+    """``n = norm(e); (n + relu(n w1^T + b1) w2^T + b2) * keep[..., None]`` for [B, L, E] blocks; keep [B, L] carries no gradient.
+    ``keep_is_mask``: every value of keep is 0 or 1 (SASRec's ``~timeline_mask``; implied by a bool tensor) -- the backward then
+    scales rows inside its GEMMs instead of in a pass of its own."""
+    return _FfnSublayer.apply(e, norm.weight, norm.bias, float(norm.eps), w1, b1, w2, b2, keep, keep_is_mask)
 
 
 class _DeepFmInput(torch.autograd.Function):

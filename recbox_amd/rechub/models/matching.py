@@ -185,6 +185,10 @@ class SASRec(torch.nn.Module):
         if isinstance(self.emb_dropout, torch.nn.Dropout) and self.emb_dropout.p > 0 and self.training:
             e = self.emb_dropout(e * scale + ops_position(self.position_emb, positions))
             e = ops.row_scale(e, keep)
+        elif (ops.config.seq_positions_in_place and e.dim() == 3 and self.position_emb.padding_idx is None
+              and self.position_emb.max_norm is None and ids.shape[1] <= self.position_emb.num_embeddings):
+            # positions are arange(L) for every sequence: the table's first L rows read in place, their gradient a column sum
+            e = ops.sasrec_input(e, self.position_emb.weight[:ids.shape[1]], keep, alpha=scale)
         else:      # (e * sqrt(D) + position) * ~mask in one pass (rbx_rowscale) instead of three element-wise kernels
             e = ops.row_scale(e, keep, add=ops_position(self.position_emb, positions), alpha=scale)
         for i in range(len(self.attention_layers)):
@@ -201,7 +205,7 @@ class SASRec(torch.nn.Module):
                 e = q + self._mha(mha, q, e)
             if ops.config.fuse_sublayers and e.dim() == 3 and not (self.training and (ffn.dropout1.p > 0 or ffn.dropout2.p > 0)):
                 e = ops.sasrec_ffn_sublayer(e, self.forward_layernorms[i], ffn.conv1.weight.squeeze(-1), ffn.conv1.bias,
-                                            ffn.conv2.weight.squeeze(-1), ffn.conv2.bias, keep)
+                                            ffn.conv2.weight.squeeze(-1), ffn.conv2.bias, keep, keep_is_mask=True)
             else:
                 e = ops.layer_norm(e, self.forward_layernorms[i])
                 # (ffn(e) + e) * ~mask: the residual add and the timeline mask in one pass

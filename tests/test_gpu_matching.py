@@ -954,6 +954,81 @@ def test_sasrec_sublayers_as_one_node_equal_the_composed_ops():
                 assert_close(ga[n], fx["g"][n], TOL, "grad " + n)
 
 
+@pytest.mark.parametrize("B,L,D", [(300, 200, 64), (37, 50, 64), (5, 7, 6), (1, 3, 4)])
+def test_sasrec_input_reads_position_rows_in_place(B, L, D):
+    """ops.sasrec_input == (alpha e + position_emb(tile(arange(L)))) * keep (sasrec.py:68-77) and its two gradients, against
+    torch float64; the position rows' gradient is a deterministic column sum over the batch (bit-identical when repeated)."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    e = torch.randn(B, L, D, generator=g)
+    table = torch.randn(L + 3, D, generator=g)
+    keep = (torch.rand(B, L, generator=g) > 0.25).float()
+    R = torch.randn(B, L, D, generator=g)
+    alpha = D ** 0.5
+    ed, td = e.double().requires_grad_(True), table.double().requires_grad_(True)
+    pos = torch.arange(L).unsqueeze(0).expand(B, -1)
+    want = (ed * alpha + torch.nn.functional.embedding(pos, td)) * keep.double().unsqueeze(-1)
+    (want * R.double()).sum().backward()
+
+    def run():
+        ec, tc = e.cuda().requires_grad_(True), table.cuda().requires_grad_(True)
+        out = ops.sasrec_input(ec, tc[:L], keep.cuda(), alpha=alpha)
+        (out * R.cuda()).sum().backward()
+        return out.detach(), ec.grad, tc.grad
+
+    out, de, dt = run()
+    assert_close(out, want.detach().float(), 1e-5 * max(1.0, float(want.abs().max())), "out")
+    assert_close(de, ed.grad.float(), 1e-5 * max(1.0, float(ed.grad.abs().max())), "de")
+    assert_close(dt, td.grad.float(), 1e-4 * max(1.0, float(td.grad.abs().max())), "d position rows")
+    assert float(dt[L:].abs().max()) == 0.0
+    again = run()
+    assert torch.equal(dt, again[2]) and torch.equal(de, again[1])
+
+
+def test_ffn_sublayer_backward_scales_masked_rows_inside_its_gemms():
+    """ops.sasrec_ffn_sublayer with a 0 / 1 keep mask at a size the slab kernels take (12 800 rows of 64): the backward that
+    scales the rows inside the dW kernel and the dx epilogues (rbx_linear_dwdb_scaled / rbx_linear_dx_scaled) against the one
+    that first writes dout * keep, and both against the block in torch float64."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, L, E = 64, 200, 64
+    e = torch.randn(B, L, E, generator=g)
+    keep = (torch.rand(B, L, generator=g) > 0.3)
+    R = torch.randn(B, L, E, generator=g)
+    norm = torch.nn.LayerNorm(E, eps=1e-8)
+    w1, b1, w2, b2 = (torch.randn(E, E, generator=g) * 0.2, torch.randn(E, generator=g) * 0.1,
+                      torch.randn(E, E, generator=g) * 0.2, torch.randn(E, generator=g) * 0.1)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(E, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(E, generator=g) * 0.1)
+
+    def reference():
+        nd = __import__("copy").deepcopy(norm).double()
+        ps = [t.double().requires_grad_(True) for t in (e, w1, b1, w2, b2)]
+        n = nd(ps[0])
+        out = (n + torch.relu(n @ ps[1].t() + ps[2]) @ ps[3].t() + ps[4]) * keep.double().unsqueeze(-1)
+        (out * R.double()).sum().backward()
+        return [out.detach()] + [p.grad for p in ps] + [nd.weight.grad, nd.bias.grad]
+
+    def run(in_gemms, as_mask):
+        nc = __import__("copy").deepcopy(norm).cuda()
+        ps = [t.cuda().requires_grad_(True) for t in (e, w1, b1, w2, b2)]
+        old = ops.config.ffn_mask_in_gemms
+        ops.config.ffn_mask_in_gemms = in_gemms
+        try:
+            out = ops.sasrec_ffn_sublayer(ps[0], nc, ps[1], ps[2], ps[3], ps[4], keep.cuda() if as_mask else keep.float().cuda())
+            (out * R.cuda()).sum().backward()
+        finally:
+            ops.config.ffn_mask_in_gemms = old
+        return [out.detach()] + [p.grad for p in ps] + [nc.weight.grad, nc.bias.grad]
+
+    want = reference()
+    names = ("out", "de", "dw1", "db1", "dw2", "db2", "dgamma", "dbeta")
+    for got in (run(True, True), run(True, False), run(False, True)):
+        for n, a, b in zip(names, got, want):
+            assert_close(a, b.float(), 2e-4 * max(1.0, float(b.abs().max())), n)
+
+
 def test_deepfm_cfg4_full_size_sampled_rows_vs_fp64_oracle():
     """BASELINE.json cfg 4 at full size (Criteo-sized tables, D = 64, MLP 3 x 400, B = 65 536): the predictions of 512
     sampled rows against the oracle's restatement evaluated in float64 on those rows (BatchNorm in eval mode, so that a
