@@ -31,6 +31,11 @@ RECBOX_AMD_FM_TWO_CHAINS=0 timeout 600 python bench.py --no-cpu-baseline > $out/
 # SASRec / DeepFM: what this round's kernels are worth, one switch at a time
 RBX_GEMM_STREAM64=0 timeout 600 python bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_sasrec_tile_gemm.json 2>/dev/null; ms sasrec_tile_gemm
 RECBOX_AMD_SHARE_TABLE_GRADS=0 timeout 600 python bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_sasrec_two_grads.json 2>/dev/null; ms sasrec_two_grads
+RBX_ATTN_SPLIT=0 timeout 600 python bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_sasrec_one_wave_per_tile.json 2>/dev/null; ms sasrec_one_wave_per_tile
+RECBOX_AMD_FFN_MASK_IN_GEMMS=0 timeout 600 python bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_sasrec_ffn_mask_pass.json 2>/dev/null; ms sasrec_ffn_mask_pass
+RECBOX_AMD_SEQ_POSITIONS=0 timeout 600 python bench.py --config sasrec --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_sasrec_position_lookup.json 2>/dev/null; ms sasrec_position_lookup
+RECBOX_AMD_BN_IN_GEMM=fwd timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_bn_fwd_in_gemm.json 2>/dev/null; ms deepfm_bn_fwd_in_gemm
+RECBOX_AMD_BN_IN_GEMM=1 timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_bn_in_gemm.json 2>/dev/null; ms deepfm_bn_in_gemm
 RECBOX_AMD_GEMM_BX6=0 RBX_GEMM_BX6=0 timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_f32_mfma.json 2>/dev/null; ms deepfm_f32_mfma
 RBX_GEMM_BX6_DW=0 timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_dw_f32.json 2>/dev/null; ms deepfm_dw_f32
 RBX_GEMM_BX6=2 timeout 600 python bench.py --config deepfm --no-cpu-baseline --steps 20 --warmup 5 > $out/bench_deepfm_bx6_128.json 2>/dev/null; ms deepfm_bx6_128
