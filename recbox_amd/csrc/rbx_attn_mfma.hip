@@ -95,38 +95,6 @@ __device__ __forceinline__ void commit_rows(float* __restrict__ lds, int rows, i
   }
 }
 
-// Two [rows, HD] blocks of a sequence into LDS with ALL of their loads in flight at once (up to 8 float4 per thread and
-// block: Lp <= 256), for the kernels that hold one sequence per workgroup and one workgroup per CU: nothing else hides these
-// loads, and stage_rows' four-at-a-time rounds were four dependent trips to memory at the head of every workgroup.
-template <int HD>
-__device__ __forceinline__ void stage_two_blocks(const float* ga, const long long lda, float* __restrict__ la, const float sa,
-                                                 const float* gb, const long long ldb, float* __restrict__ lb, const float sb,
-                                                 const int rows, const int rows_pad) {
-  constexpr int Q4 = HD / 4;
-  const int n = (rows_pad * Q4 + kAttnThreads - 1) / kAttnThreads;          // float4 per thread and block (<= 8)
-  attn_f4 va[8], vb[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) { va[u] = attn_f4{0.f, 0.f, 0.f, 0.f}; vb[u] = va[u]; }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    if (u < n) {
-      const int i = threadIdx.x + u * kAttnThreads;
-      int r = i / Q4;
-      const int c = i - r * Q4;
-      r = r < rows ? r : rows - 1;
-      const float* pa = ga + static_cast<long long>(r) * lda + c * 4;
-      const float* pb = gb + static_cast<long long>(r) * ldb + c * 4;
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(va[u]) : "v"(pa));
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vb[u]) : "v"(pb));
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]),
-               "+v"(va[7]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]),
-               "+v"(vb[7]) : : "memory");
-  commit_rows<HD, 8>(la, rows, rows_pad, sa, va);
-  commit_rows<HD, 8>(lb, rows, rows_pad, sb, vb);
-}
-
 // the wave's own tile as B operands: reg[s] = g[row0 + (lane & 31)][(lane >> 5) * HD/2 + s] * scale.
 // MFMA step s contracts over TWO columns, one per half-wave; which two is free as long as both operands agree, so the
 // halves take the two contiguous halves of a row (columns [0, HD/2) and [HD/2, HD)): a lane reads HD/8 float4 that it
@@ -149,9 +117,6 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, cons
   }
 }
 
-#ifndef RBX_ATTN_HOIST
-#define RBX_ATTN_HOIST 1   // backward kernels: the wavefront's first tile requested ahead of the staging of the LDS operands
-#endif
 #ifndef RBX_ATTN_ABL
 #define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T
 #endif
@@ -159,26 +124,6 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, cons
 //  -- the compiler reads every pair of A values into the same two registers, read / wait / two MFMAs -- with
 //  __builtin_amdgcn_sched_group_barrier: the forward kernel alone 456 vs 459 us, in the SASRec step 449 vs 420 us (more spills
 //  in the looping form).  The LDS round trip is not what the matrix core waits for; see profiles/ubench/attn_parts.hip.)
-// load_tile_regs in two halves -- the loads, and what uses them -- for a tile whose loads are issued ahead of a wait for
-// something else (the first tile of a backward workgroup, in flight together with the staging of its LDS operands)
-template <int HD>
-__device__ __forceinline__ void load_tile_raw(const float* __restrict__ g, const long long ld, int row0, int rows,
-                                              float4 (&v)[HD / 8]) {
-  const int lane = threadIdx.x & 63;
-  const int row = row0 + (lane & 31), half = lane >> 5;
-  const bool ok = row < rows;
-  const float4* src = reinterpret_cast<const float4*>(g + static_cast<long long>(ok ? row : 0) * ld + half * (HD / 2));
-#pragma unroll
-  for (int q = 0; q < HD / 8; ++q) v[q] = ok ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-template <int HD>
-__device__ __forceinline__ void finish_tile(const float4 (&v)[HD / 8], float scale, float (&reg)[HD / 2]) {
-#pragma unroll
-  for (int q = 0; q < HD / 8; ++q) {
-    reg[4 * q] = v[q].x * scale; reg[4 * q + 1] = v[q].y * scale; reg[4 * q + 2] = v[q].z * scale; reg[4 * q + 3] = v[q].w * scale;
-  }
-}
-
 // acc[row = li of `rows_lds`][col = lane] = sum_d rows_lds[row0 + li][d] * reg[d]   (column pairing as in load_tile_regs)
 template <int HD>
 __device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, int row0, const float (&reg)[HD / 2]) {
@@ -491,45 +436,23 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
   O += attn_base(bh, ld.heads, L, ld.o, HD);
   dO += attn_base(bh, ld.heads, L, ld.go, HD);
   dQ += attn_base(bh, ld.heads, L, ld.dq, HD);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
-  const WavePlan pl = wave_plan(nT, wid, causal, split);
-  // the wavefront's first tile is requested BEFORE the staging of K and V: one trip to memory for all of it
-  float4 q0[HD / 8], g0[HD / 8], o0[HD / 8];
-#pragma unroll
-  for (int q = 0; q < HD / 8; ++q) q0[q] = g0[q] = o0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto first_tile = [&]() {
-    if (pl.n > 0) {
-      load_tile_raw<HD>(Q, ld.q, pl.tile(0) * kT, L, q0);
-      load_tile_raw<HD>(dO, ld.go, pl.tile(0) * kT, L, g0);
-      load_tile_raw<HD>(O, ld.o, pl.tile(0) * kT, L, o0);
-    }
-  };
-  if (RBX_ATTN_HOIST) first_tile();
-  if (Lp <= 256) {
-    stage_two_blocks<HD>(K, ld.k, Ks, 1.0f, V, ld.v, Vs, 1.0f, L, Lp);
-  } else {
-    stage_rows<HD>(K, ld.k, Ks, L, Lp, 1.0f);
-    stage_rows<HD>(V, ld.v, Vs, L, Lp, 1.0f);
-  }
+  stage_rows<HD>(K, ld.k, Ks, L, Lp, 1.0f);
+  stage_rows<HD>(V, ld.v, Vs, L, Lp, 1.0f);
   __syncthreads();
-  if (!RBX_ATTN_HOIST) first_tile();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
+  const WavePlan pl = wave_plan(nT, wid, causal, split);
   f32x16 dq[HD / 32];
   int i0 = 0;
-  float qreg[HD / 2], greg[HD / 2], oreg[HD / 2];
-  finish_tile<HD>(q0, scale, qreg);
-  finish_tile<HD>(g0, 1.0f, greg);
-  finish_tile<HD>(o0, 1.0f, oreg);
   for (int jb = 0; jb < pl.n; ++jb) {
     const int qt = pl.tile(jb);
     i0 = qt * kT;
     const int qi = i0 + li;
-    if (jb > 0) {
-      load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
-      load_tile_regs<HD>(dO, ld.go, i0, L, 1.0f, greg);
-      load_tile_regs<HD>(O, ld.o, i0, L, 1.0f, oreg);
-    }
+    float qreg[HD / 2], greg[HD / 2], oreg[HD / 2];
+    load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
+    load_tile_regs<HD>(dO, ld.go, i0, L, 1.0f, greg);
+    load_tile_regs<HD>(O, ld.o, i0, L, 1.0f, oreg);
     float Di = 0.f;
 #pragma unroll
     for (int s = 0; s < HD / 2; ++s) Di += greg[s] * oreg[s];
@@ -600,54 +523,26 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
   dO += attn_base(bh, ld.heads, L, ld.go, HD);
   dK += attn_base(bh, ld.heads, L, ld.dk, HD);
   dV += attn_base(bh, ld.heads, L, ld.dv, HD);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
-  const WavePlan pl = wave_plan(nT, wid, causal, split);
-  float4 k0[HD / 8], v0[HD / 8];                    // the wavefront's first tile, requested ahead of the staging
-  float lse_mine = 0.f, d_mine = 0.f;
-#pragma unroll
-  for (int q = 0; q < HD / 8; ++q) k0[q] = v0[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto first_tile = [&]() {
-    if (pl.n > 0) {
-      load_tile_raw<HD>(K, ld.k, (nT - 1 - pl.tile(0)) * kT, L, k0);
-      load_tile_raw<HD>(V, ld.v, (nT - 1 - pl.tile(0)) * kT, L, v0);
-    }
-  };
-  if (RBX_ATTN_HOIST) first_tile();
-  if (static_cast<int>(threadIdx.x) < Lp && static_cast<int>(threadIdx.x) < L) {      // (Lp <= 256 < blockDim.x)
-    lse_mine = LSE[bh * L + threadIdx.x];
-    d_mine = Dv[bh * L + threadIdx.x];
-  }
-  if (Lp <= 256) {
-    stage_two_blocks<HD>(Q, ld.q, Qs, scale, dO, ld.go, Gs, 1.0f, L, Lp);
-    if (static_cast<int>(threadIdx.x) < Lp) {
-      Ls[threadIdx.x] = lse_mine;
-      Ds[threadIdx.x] = d_mine;
-    }
-  } else {
-    stage_rows<HD>(Q, ld.q, Qs, L, Lp, scale);
-    stage_rows<HD>(dO, ld.go, Gs, L, Lp, 1.0f);
-    for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
-      Ls[i] = (i < L) ? LSE[bh * L + i] : 0.f;
-      Ds[i] = (i < L) ? Dv[bh * L + i] : 0.f;
-    }
+  stage_rows<HD>(Q, ld.q, Qs, L, Lp, scale);
+  stage_rows<HD>(dO, ld.go, Gs, L, Lp, 1.0f);
+  for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
+    Ls[i] = (i < L) ? LSE[bh * L + i] : 0.f;
+    Ds[i] = (i < L) ? Dv[bh * L + i] : 0.f;
   }
   __syncthreads();
-  if (!RBX_ATTN_HOIST) first_tile();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
+  const WavePlan pl = wave_plan(nT, wid, causal, split);
   f32x16 dk[HD / 32], dv[HD / 32];
   int j0 = 0;
-  float kreg[HD / 2], vreg[HD / 2];
-  finish_tile<HD>(k0, 1.0f, kreg);
-  finish_tile<HD>(v0, 1.0f, vreg);
   for (int jb = 0; jb < pl.n; ++jb) {
     const int jt = nT - 1 - pl.tile(jb);            // (key tile jt meets nT - jt query tiles: cost index nT - 1 - jt)
     j0 = jt * kT;
     const int kj = j0 + li;
-    if (jb > 0) {
-      load_tile_regs<HD>(K, ld.k, j0, L, 1.0f, kreg);
-      load_tile_regs<HD>(V, ld.v, j0, L, 1.0f, vreg);
-    }
+    float kreg[HD / 2], vreg[HD / 2];
+    load_tile_regs<HD>(K, ld.k, j0, L, 1.0f, kreg);
+    load_tile_regs<HD>(V, ld.v, j0, L, 1.0f, vreg);
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
