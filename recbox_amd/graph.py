@@ -47,6 +47,12 @@ class GraphedStep(object):
         # start from ``p.grad = None`` for the embedding parameters, as a captured step does anyway.
         old = ops.config.reuse_grad_buffers
         ops.config.reuse_grad_buffers = "all" if "all" in (reuse_grads, old) else (bool(reuse_grads) or old)
+        # Several GraphedSteps over the same parameters (one per rotating batch) warm up on a side stream each: the
+        # parameters' AccumulateGrad nodes remember the first one, and autograd says so once per process ("stream does not
+        # match ..."; it adds the cross-stream wait itself).  Intended here, so the notice is off for warm-up and capture.
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -65,6 +71,8 @@ class GraphedStep(object):
             self.stream = getattr(torch.cuda.graph, "default_capture_stream", None) or side
         finally:
             ops.config.reuse_grad_buffers = old
+            if quiet is not None:
+                quiet(True)
         self.grads = [(p, p.grad) for p in params] if params is not None else None
 
     def pool(self):
