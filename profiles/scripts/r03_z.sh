@@ -1,6 +1,7 @@
 cd /root/repo; mkdir -p gpurun_out
-python -m pytest tests -x -q -m gpu -k "graph or replay or capture" 2>&1 | tail -3 > gpurun_out/graph_test.txt
-python bench.py --config deepfm --steps 20 --warmup 5 --no-cpu-baseline 2> gpurun_out/deepfm.err | cut -c1-200 >> gpurun_out/graph_test.txt
-grep -c "AccumulateGrad" gpurun_out/deepfm.err >> gpurun_out/graph_test.txt
-python bench.py --no-cpu-baseline 2> gpurun_out/fm.err | cut -c1-200 >> gpurun_out/graph_test.txt
-grep -c "AccumulateGrad" gpurun_out/fm.err >> gpurun_out/graph_test.txt
+export TMPDIR=/tmp
+python -m pytest tests -x -q -m gpu -k "attn or attention or sasrec or sdpa or mha or dropout" 2>&1 | tail -3 > gpurun_out/attn_test.txt
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p1 -o b -- python /root/repo/bench.py --config sasrec --steps 10 --warmup 3 --no-cpu-baseline > /tmp/log_1 2>&1)
+db=$(find /tmp/p1 -name "*.db" | head -1)
+python profiles/topk.py $db 13 2>&1 | grep -i "attn" > gpurun_out/attn_1.txt
+python bench.py --config sasrec --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null| python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'])" >> gpurun_out/attn_1.txt

@@ -15,24 +15,24 @@ int main(int argc, char** argv) {
   unsigned x = 12345u;
   for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = (static_cast<float>(x >> 8) / 8388608.f - 1.f); }
   float *q, *k, *v, *o, *lse;
-  hipMalloc(&q, n * 4); hipMalloc(&k, n * 4); hipMalloc(&v, n * 4); hipMalloc(&o, n * 4);
-  hipMalloc(&lse, static_cast<size_t>(BH) * L * 4);
-  hipMemcpy(q, h.data(), n * 4, hipMemcpyHostToDevice);
-  hipMemcpy(k, h.data(), n * 4, hipMemcpyHostToDevice);
-  hipMemcpy(v, h.data(), n * 4, hipMemcpyHostToDevice);
+  (void)hipMalloc(&q, n * 4); (void)hipMalloc(&k, n * 4); (void)hipMalloc(&v, n * 4); (void)hipMalloc(&o, n * 4);
+  (void)hipMalloc(&lse, static_cast<size_t>(BH) * L * 4);
+  (void)hipMemcpy(q, h.data(), n * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(k, h.data(), n * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(v, h.data(), n * 4, hipMemcpyHostToDevice);
   rbx::DropArgs drop{};
   hipEvent_t a, b;
-  hipEventCreate(&a); hipEventCreate(&b);
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
   for (int i = 0; i < 3; ++i) rbx::attn_mfma_fwd(q, k, v, BH, L, HD, 0.125f, 1, o, lse, drop, nullptr);
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
   const int reps = 20;
-  hipEventRecord(a);
+  (void)hipEventRecord(a);
   for (int i = 0; i < reps; ++i) rbx::attn_mfma_fwd(q, k, v, BH, L, HD, 0.125f, 1, o, lse, drop, nullptr);
-  hipEventRecord(b);
-  hipEventSynchronize(b);
+  (void)hipEventRecord(b);
+  (void)hipEventSynchronize(b);
   float ms = 0.f;
-  hipEventElapsedTime(&ms, a, b);
-  printf("ABL=%d SCHED=%d L=%d forward %.1f us (rc %s)\n", RBX_ATTN_ABL, RBX_ATTN_SCHED, L, ms * 1000.f / reps,
+  (void)hipEventElapsedTime(&ms, a, b);
+  printf("ABL=%d L=%d forward %.1f us (rc %s)\n", RBX_ATTN_ABL, L, ms * 1000.f / reps,
          hipGetErrorString(hipGetLastError()));
   return 0;
 }

@@ -118,7 +118,7 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, cons
 }
 
 #ifndef RBX_ATTN_ABL
-#define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T
+#define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T, 8 = the Q tile loads, 16 = the stores of unsplit tiles
 #endif
 // (Measured and not kept, profiles/r03/INDEX.md: the LDS reads of a tile product issued four ahead of the MFMAs that use them
 //  -- the compiler reads every pair of A values into the same two registers, read / wait / two MFMAs -- with
@@ -326,7 +326,12 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
       i0 = qt * kT;
       qi = i0 + li;
       float qreg[HD / 2];
-      load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
+      if constexpr ((RBX_ATTN_ABL & 8) != 0) {
+#pragma unroll
+        for (int q = 0; q < HD / 2; ++q) qreg[q] = scale * static_cast<float>(q + li);
+      } else {
+        load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
+      }
       if (!fetched) fetch_next();                              // (behind the wave's own operand loads: those return first)
 #pragma unroll
       for (int dt = 0; dt < HD / 32; ++dt)
@@ -389,6 +394,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
           tile_accumulate<HD>(Vs, j0, s, oacc);                // O^T[d][query] += V^T P^T
         }
       }
+      if ((RBX_ATTN_ABL & 16) != 0 && lsum != 12345.f) continue;            // (no O / LSE stores of unsplit tiles)
       if (jb != pl.partial && !pl.merge) {
         store_transposed<HD>(O, ld.o, i0, L, 1.0f / lsum, oacc);
         if (half == 0 && qi < L) LSE[bh * L + qi] = m + __logf(lsum);
