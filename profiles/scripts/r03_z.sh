@@ -1,17 +1,7 @@
 cd /root/repo; mkdir -p gpurun_out
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace -d /tmp/pf -o b -- python /root/repo/bench.py --config deepfm --steps 6 --warmup 2 --no-cpu-baseline > /tmp/log_f 2>&1)
-python - <<'P' > gpurun_out/fills.txt 2>&1
-import sqlite3, glob
-db = sqlite3.connect(glob.glob("/tmp/pf/**/*.db", recursive=True)[0])
-cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
-print(cols)
-gc = [c for c in cols if "grid" in c.lower() or "workgroup" in c.lower()]
-rows = db.execute("select name, start, end, %s from kernels order by start" % ", ".join(gc)).fetchall()
-last = None
-for i, r in enumerate(rows):
-    if "FillFunctor" in r[0] and (r[2] - r[1]) > 20000:
-        prev = rows[i - 1][0].split("(")[0][-50:] if i else ""
-        nxt = rows[i + 1][0].split("(")[0][-50:] if i + 1 < len(rows) else ""
-        print("%.1f us  grid %s   after %s   before %s" % ((r[2] - r[1]) / 1e3, r[3:], prev, nxt))
-P
+python -m pytest tests -x -q -m gpu -k "layer_norm or layernorm or sasrec or ln_ or norm" 2>&1 | tail -3 > gpurun_out/ln_test.txt
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/p1 -o b -- python /root/repo/bench.py --config sasrec --steps 10 --warmup 3 --no-cpu-baseline > /tmp/log_1 2>&1)
+db=$(find /tmp/p1 -name "*.db" | head -1)
+python profiles/topk.py $db 13 2>&1 | grep -i "ln_\|kernel " > gpurun_out/ln_prof.txt
+python bench.py --config sasrec --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null| python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'])" >> gpurun_out/ln_prof.txt

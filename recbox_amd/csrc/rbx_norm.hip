@@ -755,6 +755,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
   const float inv_d = 1.0f / static_cast<float>(dim);
+  // a lane's slice of gamma / beta, once: read where they are used, they were four pairs of loads with a wait each in every
+  // row of the loop -- ten memory requests per row where two (the row in, the row out) move all of its bytes
+  float gm[NA], bt[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int e = Row::index(i, dim, lane_g);
+    gm[i] = (e >= 0 && gamma != nullptr) ? gamma[e] : 1.f;
+    bt[i] = (e >= 0 && beta != nullptr) ? beta[e] : 0.f;
+  }
   for (long long r = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; r < rows; r += ngroups) {
     Row v;
     v.load(x + r * dim, dim, lane_g);
@@ -770,14 +779,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
     const float rs = 1.0f / sqrtf(group_sum<G>(q) * inv_d + eps);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int e = Row::index(i, dim, lane_g);
-      if (e >= 0) {
-        const float g = gamma != nullptr ? gamma[e] : 1.f;
-        const float b = beta != nullptr ? beta[e] : 0.f;
-        v.a[i] = (v.a[i] - m) * rs * g + b;
-      }
-    }
+    for (int i = 0; i < NA; ++i) v.a[i] = (v.a[i] - m) * rs * gm[i] + bt[i];      // (slots beyond dim are not stored)
     v.store(y + r * dim, dim, lane_g);
     if (lane_g == 0) {
       mean[r] = m;
@@ -800,9 +802,13 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict_
   // partial != NULL: the parameter gradients' block sums (sum dy, sum dy * xhat per column) fall out of the same pass --
   // dy and xhat are in registers anyway --, instead of a second kernel that reads x and dy again (210 + 210 MB at cfg 5).
   // A lane adds its rows in ascending order, the lane groups of the workgroup are added in a fixed order: deterministic.
-  float pb[NA], pg[NA];
+  float pb[NA], pg[NA], gm[NA];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) pb[i] = pg[i] = 0.f;
+  for (int i = 0; i < NA; ++i) {
+    pb[i] = pg[i] = 0.f;
+    const int e = Row::index(i, dim, lane_g);
+    gm[i] = (e >= 0 && gamma != nullptr) ? gamma[e] : 1.f;          // (once, not per row: see ln_fwd_kernel)
+  }
   for (long long r = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; r < rows; r += ngroups) {
     Row xv, gv;
     xv.load(x + r * dim, dim, lane_g);
@@ -810,16 +816,13 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict_
     const float m = mean[r], rs = rstd[r];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int e = Row::index(i, dim, lane_g);
-      if (e >= 0) {
-        xv.a[i] = (xv.a[i] - m) * rs;                      // xhat
-        pb[i] += gv.a[i];
-        pg[i] += gv.a[i] * xv.a[i];
-        gv.a[i] *= gamma != nullptr ? gamma[e] : 1.f;      // g = dy * gamma
-        s1 += gv.a[i];
-        s2 += gv.a[i] * xv.a[i];
-      }
+    for (int i = 0; i < NA; ++i) {                         // (slots beyond dim hold dy = 0: they add nothing)
+      xv.a[i] = (xv.a[i] - m) * rs;                        // xhat
+      pb[i] += gv.a[i];
+      pg[i] += gv.a[i] * xv.a[i];
+      gv.a[i] *= gm[i];                                    // g = dy * gamma
+      s1 += gv.a[i];
+      s2 += gv.a[i] * xv.a[i];
     }
     const float m1 = group_sum<G>(s1) * inv_d, m2 = group_sum<G>(s2) * inv_d;
 #pragma unroll

@@ -664,7 +664,15 @@ __global__ __launch_bounds__(256) void seq_colsum_final_kernel(const float* __re
   const long long c = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (c >= cols) return;
   float t = 0.f;
-  for (int k = 0; k < n_blocks; ++k) t += partial[static_cast<long long>(k) * cols + c];
+  int k = 0;
+  for (; k + 7 < n_blocks; k += 8) {                                // 8 partials in flight, added in ascending order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[static_cast<long long>(k + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  for (; k < n_blocks; ++k) t += partial[static_cast<long long>(k) * cols + c];
   out[c] = t;
 }
 }  // namespace rbx
