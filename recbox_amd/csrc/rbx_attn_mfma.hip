@@ -117,6 +117,9 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, cons
   }
 }
 
+#ifndef RBX_ATTN_QFIRST
+#define RBX_ATTN_QFIRST 1  // looping forward kernel: the K / V prefetch is issued once the wavefront's Q tile has arrived
+#endif
 #ifndef RBX_ATTN_ABL
 #define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T, 8 = the Q tile loads, 16 = the stores of unsplit tiles
 #endif
@@ -329,10 +332,22 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
       if constexpr ((RBX_ATTN_ABL & 8) != 0) {
 #pragma unroll
         for (int q = 0; q < HD / 2; ++q) qreg[q] = scale * static_cast<float>(q + li);
+        if (!fetched) fetch_next();
+      } else if constexpr (PF && HD == 64 && RBX_ATTN_QFIRST) {
+        // The next sequence's K and V are requested only once the wavefront's Q tile is THERE.  Requested behind the tile's
+        // loads (loads return in order, "the tile is back first") they were also waited for with it: the compiler's wait in
+        // front of the first MFMA is vmcnt(0) -- it does not count the prefetch's asm loads -- so every wavefront sat out its
+        // share of the prefetch before it computed anything (profiles/r03/attn_parts.txt: 65 of 436 us belong to the Q tile
+        // loads).  (The tile by asm loads and a counted wait, vmcnt(2 NPF), measured the same and is not safe: the
+        // compiler may spill a register whose load is still in flight -- NaNs in the dropout variant.)
+        load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
+        asm volatile("" : "+v"(qreg[0]), "+v"(qreg[4]), "+v"(qreg[8]), "+v"(qreg[12]), "+v"(qreg[16]), "+v"(qreg[20]),
+                     "+v"(qreg[24]), "+v"(qreg[28]) : : "memory");
+        if (!fetched) fetch_next();
       } else {
         load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
+        if (!fetched) fetch_next();                            // (behind the wave's own operand loads: those return first)
       }
-      if (!fetched) fetch_next();                              // (behind the wave's own operand loads: those return first)
 #pragma unroll
       for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
