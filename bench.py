@@ -137,11 +137,14 @@ def cpu_baseline(dim, B, dist, budget_s):
 
 
 def measured_traffic(path, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r03/traffic_r03.json; FETCH_SIZE / WRITE_SIZE are collected in separate runs and
-    corrected as MI355X_MICROARCH.md prescribes).  None when no measurement is on file."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/rNN/traffic_rNN.json, the newest round on file; FETCH_SIZE / WRITE_SIZE are collected in separate runs --
+    counters cannot ride in a timed run -- and corrected as MI355X_MICROARCH.md prescribes).  None when no measurement
+    is on file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03", "traffic_r03.json")) as fh:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "traffic_r[0-9][0-9].json")))
+        with open(files[-1]) as fh:
             rec = json.load(fh)
         ent = rec.get({"fused": "fm"}.get(path, path), {})
         if kernel is not None and ent.get("kernel") != kernel:
@@ -298,6 +301,33 @@ def model_cpu_baseline(cfg, args, budget_s):
             "sample": "%d steps of the same model (%s) on torch CPU ops, %d of %d hardware threads" % (n, what, threads, ncpu)}
 
 
+def shutdown_distributed(*holders):
+    """Leave the process group: drop every captured graph first (a graph that holds RCCL kernel nodes keeps the
+    communicator busy: destroy_process_group() hung behind one in rounds 2-3), synchronise, then destroy the group under a
+    watchdog -- a teardown that still hangs must not cost the line this process has already printed."""
+    import gc
+    import threading
+    from recbox_amd import comm
+    for h in holders:
+        rel = getattr(h, "release", None)
+        if rel is not None:
+            rel()
+    comm.direct.shutdown()
+    gc.collect()
+    torch.cuda.synchronize()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return
+    guard = threading.Timer(float(os.environ.get("RECBOX_BENCH_TEARDOWN_SECONDS", "20")), lambda: os._exit(0))
+    guard.daemon = True
+    guard.start()
+    try:
+        torch.distributed.destroy_process_group()
+    finally:
+        guard.cancel()
+
+
 def run_model_config(args, rank, world, dev):
     """configs[2..4].  N = 1: the single-GPU mirror, whole step replayed as one hipGraph (persistent dense gradients).
     N > 1 (or --force-sharded): youtubednn / deepfm in their sharded + data-parallel form (eager launches: the
@@ -433,6 +463,27 @@ def run_model_config(args, rank, world, dev):
             torch.cuda.synchronize()
             rotating_graphs = None
             step = eager_step
+    elif (sharded and not args.eager and args.sharded_graph in ("auto", "whole") and comm.direct.on
+          and comm.direct.capturable):
+        # the N > 1 step -- exchanges, all-reduces, the autograd nodes around them -- as ONE hipGraph per resident batch:
+        # every collective is an RCCL call on the capturing stream (comm.direct), so nothing is launched from Python
+        # inside the timed region (round 3 launched ~130 kernels per step eagerly, each collective on RCCL's own stream)
+        from recbox_amd.graph import GraphedStep
+        try:
+            rotating_graphs = []
+            for k in range(K):
+                rotating_graphs.append(GraphedStep(step_over(batches[k]), warmup=3 if k == 0 else 2, reuse_grads=False,
+                                                   params=params, capture_error_mode="thread_local",
+                                                   pool=rotating_graphs[0].pool() if rotating_graphs else None))
+            step = rotating_graphs[0]
+            graph_note = ("ONE hipGraph per resident batch, RCCL collectives inside (rbx_all_to_all / rbx_all_reduce on the "
+                          "step's stream)")
+        except Exception as exc:
+            print("[bench] hipGraph capture of the sharded step failed (%s: %s); launching it eagerly"
+                  % (type(exc).__name__, exc), file=sys.stderr)
+            torch.cuda.synchronize()
+            rotating_graphs = None
+            step = eager_step
 
     def run_step(i):
         if rotating_graphs is not None:
@@ -525,8 +576,9 @@ def run_model_config(args, rank, world, dev):
         if world > 1:
             torch.distributed.all_reduce(flag)
         overflow = bool(flag.item() > 0)
+    held = tuple(rotating_graphs or ()) + ((step,) if hasattr(step, "graph") else ())
     if rank != 0:
-        return
+        return held
     kms = timer.mean_ms()
     if kms:
         traffic = None
@@ -539,8 +591,17 @@ def run_model_config(args, rank, world, dev):
         if roof["unit"] == "GFLOP/s":                       # report TFLOP/s as the contract asks
             roof.update({"unit": "TFLOP/s", "achieved": roof["achieved"] / 1e3, "peak": roof["peak"] / 1e3})
         if "pipe" in roof:
-            roof["pipe"]["achieved"] = roof["achieved"] * roof["pipe"]["executed_per_algorithmic"]
-            roof["pipe"]["frac"] = roof["pipe"]["achieved"] / roof["pipe"]["peak"]
+            # the kernel runs on the bf16 matrix cores (six products per f32 product): `frac` prices the EXECUTED FLOPs against
+            # the pipe they execute on; the algorithmic-f32 rate and its ratio to the f32 MFMA peak (which can exceed 1: it is a
+            # speed-up over the f32 pipe, not a roofline) are side fields
+            pipe = roof.pop("pipe")
+            roof["f32_equivalent"] = {"achieved": roof["achieved"], "unit": "TFLOP/s of algorithmic f32 work",
+                                      "over_f32_mfma_peak": roof["achieved"] / roof["peak"], "f32_mfma_peak": roof["peak"]}
+            roof["achieved"] = roof["achieved"] * pipe["executed_per_algorithmic"]
+            roof["peak"] = pipe["peak"]
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["executed_per_algorithmic"] = pipe["executed_per_algorithmic"]
+            roof["unit"] = pipe["unit"]
     else:
         roof = None
     par = "dp1"
@@ -554,7 +615,7 @@ def run_model_config(args, rank, world, dev):
         par = "dp%d (replicated model, one flat all-reduce of every gradient)" % world
     out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
            "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%s; batch %d per GPU, %s ids (%s), %s, dense-grad autograd contract (%s), no optimiser step"
                                   % (MODEL_CONFIGS[cfg], B, args.dist,
@@ -563,7 +624,7 @@ def run_model_config(args, rank, world, dev):
                                      if K > 1 else "one batch replayed", graph_note,
                                      "persistent grad buffers, rows of the previous step re-zeroed" if persistent
                                      else "fresh zero-filled grads every step"),
-                      "global_batch": B * world, "parallelism": par},
+                      "global_batch": B * world, "batch_per_gpu": B, "parallelism": par},
            "roofline": roof}
     if cfg in ("deepfm", "youtubednn") and ops.config.gemm_bx6 and os.environ.get("RBX_GEMM_BX6", "1") != "0":
         # f32 in, f32 out, f32 accumulation, f32-level error (tests: the f32 kernel's tolerances): NOT a bf16 run
@@ -574,9 +635,10 @@ def run_model_config(args, rank, world, dev):
         out["metric"] = "samples/sec fwd+bwd+update (beside the fwd+bwd metric of BASELINE.json)"
     if store is not None:
         out["config"]["exchange"] = "padded capacity_factor=%g, overflow=%s" % (factor, overflow)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not sharded:
         out["cpu_baseline"] = model_cpu_baseline(cfg, args, args.cpu_seconds)
     print(json.dumps(out))
+    return held
 
 
 def main():
@@ -637,16 +699,50 @@ def main():
                          "the tables, recbox_amd.optim; dense_adam: torch.optim.Adam over every parameter, as the reference does)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="fm, one GPU: do not append the time-boxed youtubednn / deepfm / sasrec sub-runs under \"configs\"")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = --batch samples PER GPU (the default: per-GPU work fixed); strong = --global-batch "
+                         "samples split B/N per GPU (SURVEY.md 8d/8e: global B = 65 536, 8 192 per GPU at N = 8)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="--scaling strong: the global batch (default 65536; sasrec 4096)")
+    ap.add_argument("--sharded-graph", choices=["auto", "whole", "pieces", "eager"], default="auto",
+                    help="N > 1 / --force-sharded: how the step is launched.  whole = ONE hipGraph with the RCCL collectives "
+                         "inside (needs them on the step's stream: recbox_amd.comm.direct, checked collectively); pieces = "
+                         "hipGraph pieces with the collectives between them (fm only); eager = from Python; auto = whole "
+                         "when the check passes, else pieces (fm) / eager")
     args = ap.parse_args()
+    if args.scaling == "strong":
+        if args.batch is not None:
+            ap.error("--scaling strong takes --global-batch, not --batch")
+        gb = args.global_batch or (4096 if args.config == "sasrec" else 65536)
+        if gb % max(args.gpus, 1):
+            ap.error("--global-batch %d does not split over %d GPUs" % (gb, args.gpus))
+        args.batch = gb // max(args.gpus, 1)
     if args.batch is None:
         args.batch = 4096 if args.config == "sasrec" else 65536
 
+    one_gpu = os.environ.get("RECBOX_BENCH_ONE_GPU", "0") != "0"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` from a bare shell: start the N ranks the way the driver does (one process per GPU)
+        import socket
+        import subprocess
+        if not one_gpu and torch.cuda.device_count() < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but this box has %d GPU(s) (RECBOX_BENCH_ONE_GPU=1 puts every rank on "
+                             "cuda:0 over gloo: control flow only, its timings mean nothing)"
+                             % (args.gpus, torch.cuda.device_count()))
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d: pass the same N to both (the line's n_gpus "
+                         "is the number of ranks that ran)" % (world, args.gpus))
     # RECBOX_BENCH_ONE_GPU=1 (tests only): every rank on cuda:0 over gloo, to run the N>1 control flow of this script
     # on a single-GPU box (RCCL needs one GPU per rank); the numbers of such a run mean nothing
-    one_gpu = os.environ.get("RECBOX_BENCH_ONE_GPU", "0") != "0"
     local_rank = 0 if one_gpu else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -659,21 +755,24 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from recbox_amd import comm, ops
+    if args.force_sharded:
+        comm.force_world_of_one = True        # the world-of-one line issues every collective of the N > 1 step
+    if (world > 1 or args.force_sharded) and not one_gpu:
+        # every collective as an RCCL call on the step's own stream (rbx_all_to_all / rbx_all_reduce) instead of
+        # torch.distributed's on RCCL's stream: compared with torch.distributed once, on every rank, eagerly and replayed
+        # from a hipGraph, before it is used (comm.direct.self_check); --direct-rccl makes a failed check an error,
+        # RECBOX_AMD_DIRECT_RCCL=0 switches it off
+        if args.direct_rccl:
+            comm.direct.enable(True)
+        comm.direct.self_check(device=dev)
     if args.config != "fm":
-        run_model_config(args, rank, world, dev)
+        held = run_model_config(args, rank, world, dev) or ()
         if world > 1 or args.force_sharded:
-            torch.distributed.destroy_process_group()
+            shutdown_distributed(*held)
         return
 
-    from recbox_amd import comm, ops
     from recbox_amd.ranking.pytorch.models import FM, ShardedFM
-    if (world > 1 or args.force_sharded) and args.direct_rccl:
-        # the exchanges as grouped ncclSend / ncclRecv on the step's own stream (rbx_all_to_all) instead of
-        # torch.distributed's call on RCCL's stream; checked against it once, on every rank, before it is used.
-        # Opt-in: in a world of one it is within +-3 % of the torch.distributed path (0.63-0.67 vs 0.65-0.66 ms), and
-        # it has not run on more than one GPU.
-        comm.direct.enable(True)
-        comm.direct.self_check(device=dev)
     ops.config.check_ids = False              # no per-call host sync inside the timed region
     if args.sort_after_forward:
         ops.config.sort_before_forward = False
@@ -817,7 +916,9 @@ def main():
     elif sharded and cap_factor and model.tables is not None:
         # padded sync-free exchange: the step is eight hipGraph pieces with the RCCL collectives between them
         from recbox_amd.graph import ShardedFMStep
-        use_graphs = not args.eager
+        use_graphs = {"auto": "auto", "whole": "whole", "pieces": True, "eager": False}[args.sharded_graph]
+        if args.eager:
+            use_graphs = False
         for _ in range(4):
             try:
                 step = ShardedFMStep(model, X, y, graphs=use_graphs)
@@ -825,7 +926,7 @@ def main():
                 if not use_graphs:
                     raise
                 if rank == 0:
-                    print("[bench] piecewise graph capture failed (%s: %s); running the pieces eagerly"
+                    print("[bench] graph capture of the sharded step failed (%s: %s); running the pieces eagerly"
                           % (type(exc).__name__, exc), file=sys.stderr)
                 torch.cuda.synchronize()
                 use_graphs = False
@@ -834,10 +935,16 @@ def main():
             if not overflowed():
                 break
             cap_factor *= 2                   # skewed ids: some owner received more than its slots; start over
+            step.release()
             del step
             model = build_model()
-        graph_note = ("8 hipGraph pieces + RCCL collectives between them (%s)"
-                      % ("rbx_all_to_all on the step's stream" if comm.direct.on else "torch.distributed")) if use_graphs else "eager launches"
+        where = "rbx_all_to_all / rbx_all_reduce on the step's stream" if comm.direct.on else "torch.distributed"
+        if step.whole is not None:
+            graph_note = "ONE hipGraph: every piece and the four RCCL collectives (%s)" % where
+        elif step.graphs is not None:
+            graph_note = "8 hipGraph pieces + RCCL collectives between them (%s)" % where
+        else:
+            graph_note = "eager launches"
 
     def run_step(i):
         if rotating_graphs is not None:
@@ -928,12 +1035,17 @@ def main():
         # algorithmic bytes of the gather per sample: 26 rows x 64 B
         # + 26 ids x 8 B (float64 columns) + 13 dense values x 8 B + the [39,16] fp32 slot written
         n_sparse = len(CRITEO_VOCABS)
+        row_stream = n_sparse * args.dim * 4                # the table rows alone: what north_star's 60 % target is quoted on
+        per_sample_incl_s = None
         if args.path == "fused" or sharded:
-            # rows + float64 ids + float64 dense values + LR rows + logit + S kept for backward
-            per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 8 + n_sparse * 4 + 4 + args.dim * 4
+            # rows + ids (8 B each) + LR rows (26 x 4) + dense inputs (13 x 4) + the 4-byte logit = 2 032 B at
+            # D = 16.  What the kernel really moves on top of that -- the dense columns arrive as float64 (+52 B) and the S row
+            # it keeps for the backward (+64 B) -- is reported beside it as frac_incl_S, not in `frac`.
+            per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + n_sparse * 4 + N_DENSE * 4 + 4
+            per_sample_incl_s = per_sample + N_DENSE * 4 + args.dim * 4
             kname = "fm_fused_fwd_kernel<%d,1,true,3>" % (args.dim // 4)       # (3 = RBX_F64: the id columns' dtype)
         else:
-            per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 8 + n_fields * args.dim * 4
+            per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 4 + n_fields * args.dim * 4
             kname = "embed_fwd_kernel<%d,1,true>" % (args.dim // 4)
         kms = timer.mean_ms()
         roof = None
@@ -944,7 +1056,11 @@ def main():
                     "traffic": measured_traffic(args.path, kname) if (B == 65536 and args.dim == 16) else None,
                     "kernel": kname,
                     "kernel_ms": kms, "algorithmic_bytes_per_launch": per_sample * B,
+                    "algorithmic_bytes_per_sample": per_sample,
+                    "frac_row_stream": row_stream * B / (kms * 1e-3) / 1e9 / 8000.0,
                     "inputs": ("%d distinct batches in rotation" % K) if K > 1 else "one batch replayed"}
+            if per_sample_incl_s is not None:
+                roof["frac_incl_S"] = per_sample_incl_s * B / (kms * 1e-3) / 1e9 / 8000.0
             wms = warm_timer.mean_ms()
             if wms:
                 roof["frac_warm"] = per_sample * B / (wms * 1e-3) / 1e9 / 8000.0
@@ -953,6 +1069,7 @@ def main():
                 # what this GPU delivers on random 64-byte rows at all (a kernel that only gathers them): the ceiling the
                 # D = 16 forward can be held against; 128-byte rows and wider reach 5.8-6.0 TB/s
                 roof["row_gather_ceiling"] = {"GB/s": 3070.5, "frac_of_peak": 3070.5 / 8000.0,
+                                              "measured_in_this_run": False,
                                               "source": "profiles/r03/gather_ceiling.txt (profiles/ubench/gather_ceiling.hip: random "
                                                         "64-byte rows reach 46.9-48.0 G rows/s at every queue depth, through registers "
                                                         "and through LDS-DMA alike -- the rate of random 128-byte rows, 6.0-6.1 TB/s of "
@@ -967,7 +1084,7 @@ def main():
                                 "kernel_ms_alone: the same launches with the sort enqueued after the forward")
         out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
                "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
                                       "%s ids (%s), %s path%s, %s, dense-grad autograd contract (%s), no optimiser step"
@@ -980,7 +1097,7 @@ def main():
                                          if (not sharded and args.path == "fused" and args.pack_tables) else "", graph_note,
                                          "persistent grad buffer, rows of the previous step re-zeroed"
                                          if ops.config.reuse_grad_buffers else "fresh zero-filled grads every step"),
-                          "global_batch": B * world,
+                          "global_batch": B * world, "batch_per_gpu": B,
                           "parallelism": ("dp%d + row-sharded tables (all-to-all-v)" % world) if sharded else "dp1"},
                "roofline": roof}
         if sharded:
@@ -994,7 +1111,7 @@ def main():
             out["configs"] = extra_configs(args)
         print(json.dumps(out))
     if world > 1 or args.force_sharded:
-        torch.distributed.destroy_process_group()
+        shutdown_distributed(step)
 
 
 def extra_configs(args):
@@ -1005,8 +1122,12 @@ def extra_configs(args):
     import subprocess
     res = {}
     budget = float(os.environ.get("RECBOX_BENCH_EXTRA_SECONDS", "75"))
-    for cfg in ("youtubednn", "deepfm", "sasrec"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--gpus", "1", "--steps", str(min(args.steps, 20)),
+    # "fm_fresh_grads": the headline workload under autograd's literal contract -- new zero-filled dense gradients every step
+    # ("report with and without" the 357 MB fill) -- beside the persistent-buffer headline
+    runs = [("fm_fresh_grads", ["--config", "fm", "--fresh-grads", "--no-cpu-baseline", "--no-extra-configs"]),
+            ("youtubednn", ["--config", "youtubednn"]), ("deepfm", ["--config", "deepfm"]), ("sasrec", ["--config", "sasrec"])]
+    for cfg, extra in runs:
+        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--gpus", "1", "--steps", str(min(args.steps, 20)),
                "--warmup", str(min(args.warmup, 5)), "--cpu-seconds", "6", "--dist", args.dist]
         t0 = time.perf_counter()
         try:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 116          /* 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 117          /* 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -341,6 +341,19 @@ int rbx_fm_sparse_update(const rbx_field_t* emb, const rbx_field_t* lr, int32_t 
  * of the library the process has already loaded (ncclGroupStart, ncclGroupEnd, ncclSend, ncclRecv, ncclGetErrorString). */
 int rbx_comm_bind(void* fn_group_start, void* fn_group_end, void* fn_send, void* fn_recv, void* fn_error_string);
 int rbx_all_to_all(void* comm, const void* d_send, void* d_recv, size_t bytes_per_peer, int32_t world, void* stream);
+/* The other two collectives of the sharded step the same way (round 4): the flat all-reduce of the replicated /
+ * data-parallel gradients (the reference's counterpart is nn.DataParallel's gradient gather,
+ * third_party/rechub/trainers/ctr_trainer.py:41-43) and the all-gather of a synchronised BatchNorm's statistics, as
+ * ncclAllReduce / ncclAllGather on `stream` -- with all three on the step's own stream no collective crosses to RCCL's
+ * stream, and the whole step (collectives included) is one hipGraph capture.  dtype: RBX_I32 / RBX_I64 / RBX_F32 /
+ * RBX_F64; op: RBX_REDUCE_*; in place when d_send == d_recv.  rbx_comm_bind_collectives hands over ncclAllReduce and
+ * (optional, NULL) ncclAllGather of the loaded RCCL. */
+#define RBX_REDUCE_SUM 0
+#define RBX_REDUCE_MAX 2
+#define RBX_REDUCE_MIN 3
+int rbx_comm_bind_collectives(void* fn_all_reduce, void* fn_all_gather);
+int rbx_all_reduce(void* comm, const void* d_send, void* d_recv, size_t count, int32_t dtype, int32_t op, void* stream);
+int rbx_all_gather(void* comm, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream);
 
 /* ---- K5: two-tower scoring (third_party/rechub/models/matching/dssm.py:48,57,65,
  * youtube_dnn.py:47-48,56,65,70).  l2norm = F.normalize(x, p=2, dim=-1, eps): y = x / max(||x||, eps);

@@ -97,6 +97,9 @@ SIGNATURES = {
     "rbx_fm_sparse_update": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _OP, _PP, _PP, _PP, _PP, _P]),
     "rbx_comm_bind": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "rbx_all_to_all": (ctypes.c_int, [_P, _P, _P, _sz, _i32, _P]),
+    "rbx_comm_bind_collectives": (ctypes.c_int, [_P, _P]),
+    "rbx_all_reduce": (ctypes.c_int, [_P, _P, _P, _sz, _i32, _i32, _P]),
+    "rbx_all_gather": (ctypes.c_int, [_P, _P, _P, _sz, _P]),
     "rbx_embed_rezero": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P]),
     "rbx_sort_share": (ctypes.c_int, [_FP, _FP, _i32, _i32, _P, _FP, _FP, _i32, _i32, _P, _sz, _i64, _P]),
     "rbx_rowscale": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _f32, _P, _P]),

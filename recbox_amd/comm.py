@@ -11,10 +11,22 @@ import torch
 import torch.distributed as dist
 
 
+# bench.py --force-sharded / tests: issue the all-reduces of the N > 1 step in a world of one too (RCCL then runs them as
+# a local copy), so that a one-GPU box prices -- and exercises -- the step exactly as N > 1 ranks launch it
+force_world_of_one = os.environ.get("RECBOX_AMD_FORCE_COLLECTIVES", "0") != "0"
+
+
 def world(group=None):
     if not dist.is_available() or not dist.is_initialized():
         return 0, 1
     return dist.get_rank(group), dist.get_world_size(group)
+
+
+def multi(group=None):
+    """Does this process group need its reductions issued (more than one rank, or ``force_world_of_one``)?"""
+    if not dist.is_available() or not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or force_world_of_one
 
 
 def exchange_counts(send_counts, group=None):
@@ -75,7 +87,10 @@ def all_to_all_equal(x, group=None):
     x = x.contiguous()
     if dist.get_backend(group) == "nccl":
         out = torch.empty_like(x)
-        dist.all_to_all_single(out, x, group=group)
+        if direct.usable(x, group):
+            direct.all_to_all(out, x, group, False)
+        else:
+            dist.all_to_all_single(out, x, group=group)
         return out
     c = x.shape[0] // W
     return all_to_all_rows(x, [c] * W, [c] * W, group)
@@ -97,20 +112,39 @@ class _Joined(object):
         return True
 
 
+_RBX_DTYPE = {torch.int32: 0, torch.int64: 1, torch.float32: 2, torch.float64: 3}
+_RBX_OP = {"sum": 0, "max": 2, "min": 3}
+
+
 class _Direct(object):
-    """RCCL's grouped send/recv issued on the caller's stream through the C ABI (rbx_all_to_all), with the
-    communicator torch.distributed built.  Off unless ``RECBOX_AMD_DIRECT_RCCL=1`` / ``comm.direct.enable()``:
-    torch.distributed's own call stays the default and the fallback."""
+    """RCCL's collectives issued on the CALLER's stream through the C ABI (rbx_all_to_all = grouped ncclSend / ncclRecv,
+    rbx_all_reduce, rbx_all_gather), with the communicator torch.distributed built.  torch.distributed runs every
+    collective on RCCL's own stream behind two event joins (15-50 us of idle GPU apiece between short dependent pieces) and
+    its wrapper refuses hipGraph capture; issued here the collectives are ordinary nodes of the step's stream, so a whole
+    sharded step -- exchanges and all-reduces included -- captures into ONE hipGraph (recbox_amd.graph.GraphedStep).
+
+    ``RECBOX_AMD_DIRECT_RCCL``: "auto" (default) -- the first collective of a process group on a GPU tensor runs
+    ``self_check`` (every rank reaches it at the same call: collectives are issued in the same order everywhere), which
+    compares this path with torch.distributed's on a known pattern, eagerly AND replayed from a captured hipGraph, and
+    keeps it only if every rank agrees; "1" the same check, but a failure raises instead of falling back; "0" off."""
 
     def __init__(self):
-        self.on = os.environ.get("RECBOX_AMD_DIRECT_RCCL", "0") != "0"
+        self.mode = os.environ.get("RECBOX_AMD_DIRECT_RCCL", "auto").lower()
+        self.on = False
+        self.capturable = False
+        self.checked = set()
         self.bound = False
         self.comms = {}
         self.stream = None              # for exchanges that overlap with compute (async_op)
         self.keep = None
+        self.why = "not checked yet"
 
     def enable(self, on=True):
-        self.on = bool(on)
+        """Force the policy: True = "1" (check, raise on failure), False = off, "auto" = check, fall back on failure."""
+        self.mode = "auto" if on == "auto" else ("1" if on else "0")
+        self.checked.clear()
+        if not on:
+            self.on = self.capturable = False
 
     def _bind(self):
         import ctypes
@@ -124,6 +158,8 @@ class _Direct(object):
                 fns = [ctypes.cast(getattr(rccl, n), ctypes.c_void_p)
                        for n in ("ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString")]
                 _lib.check(_lib.lib.rbx_comm_bind(*fns))
+                _lib.check(_lib.lib.rbx_comm_bind_collectives(ctypes.cast(rccl.ncclAllReduce, ctypes.c_void_p),
+                                                              ctypes.cast(rccl.ncclAllGather, ctypes.c_void_p)))
                 self.keep, self.bound = rccl, True
                 return
             except (OSError, AttributeError) as exc:
@@ -141,6 +177,28 @@ class _Direct(object):
             self.comms[key] = ptr
         return ptr
 
+    def usable(self, x, group):
+        """Should a collective on ``x`` take this path?  Runs the one-time check of the group when due."""
+        if self.mode == "0" or not x.is_cuda:
+            return False
+        if not (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"):
+            return False
+        key = (id(group), x.device.index)
+        if key not in self.checked:
+            if torch.cuda.is_current_stream_capturing():
+                return self.on              # (the check syncs the host: a capture must come after a warm-up step)
+            self.self_check(group, x.device)
+        return self.on
+
+    def _streams(self, x, async_op):
+        cur = torch.cuda.current_stream(x.device)
+        if not async_op:
+            return cur, cur
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=x.device)
+        self.stream.wait_stream(cur)
+        return cur, self.stream
+
     def all_to_all(self, out, x, group, async_op):
         import ctypes
         from . import _lib
@@ -153,42 +211,124 @@ class _Direct(object):
         if nbytes % W:
             raise ValueError("all_to_all_equal_into: %d bytes do not split over %d ranks" % (nbytes, W))
         comm = self.comm_ptr(group, x.device)
-        cur = torch.cuda.current_stream(x.device)
-        st = cur
-        if async_op:
-            if self.stream is None:
-                self.stream = torch.cuda.Stream(device=x.device)
-            st = self.stream
-            st.wait_stream(cur)
+        cur, st = self._streams(x, async_op)
         _lib.check(_lib.lib.rbx_all_to_all(ctypes.c_void_p(comm), ctypes.c_void_p(x.data_ptr()),
                                            ctypes.c_void_p(out.data_ptr()), nbytes // W, W,
                                            ctypes.c_void_p(st.cuda_stream)))
         return _Joined(cur, st) if async_op else _Done()
 
+    def all_reduce(self, x, group, op="sum", async_op=False):
+        """In place over the ranks of ``group``; x: contiguous int32 / int64 / float32 / float64."""
+        import ctypes
+        from . import _lib
+        if not self.bound:
+            self._bind()
+        if not x.is_contiguous() or x.dtype not in _RBX_DTYPE:
+            raise ValueError("all_reduce: a contiguous int32 / int64 / float32 / float64 tensor")
+        comm = self.comm_ptr(group, x.device)
+        cur, st = self._streams(x, async_op)
+        _lib.check(_lib.lib.rbx_all_reduce(ctypes.c_void_p(comm), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()),
+                                           x.numel(), _RBX_DTYPE[x.dtype], _RBX_OP[op], ctypes.c_void_p(st.cuda_stream)))
+        return _Joined(cur, st) if async_op else _Done()
+
+    def all_gather(self, out, x, group):
+        import ctypes
+        from . import _lib
+        if not self.bound:
+            self._bind()
+        if not (x.is_contiguous() and out.is_contiguous()):
+            raise ValueError("all_gather: contiguous buffers")
+        comm = self.comm_ptr(group, x.device)
+        cur, st = self._streams(x, False)
+        _lib.check(_lib.lib.rbx_all_gather(ctypes.c_void_p(comm), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                           x.numel() * x.element_size(), ctypes.c_void_p(st.cuda_stream)))
+        return _Done()
 
     def self_check(self, group=None, device=None):
-        """One small exchange both ways (this path and torch.distributed's) on a known pattern; switches the direct
-        path off, with a warning, if it raises or differs.  Every rank must call it."""
+        """One small exchange + all-reduce + all-gather both ways (this path and torch.distributed's) on a known pattern,
+        eagerly and replayed from a captured hipGraph; keeps the direct path (``on``) only if every rank got identical
+        results, and marks it ``capturable`` only if the replays did too.  Collective: every rank must call it at the same
+        point (``usable`` does, at the first collective of a group)."""
         if not (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"):
-            return self.on
+            return False
         rank, W = dist.get_rank(group), dist.get_world_size(group)
         device = device or torch.device("cuda", torch.cuda.current_device())
+        self.checked.add((id(group), device.index))
+        if self.mode == "0":
+            self.on = self.capturable = False
+            return False
         x = (torch.arange(W * 6, dtype=torch.float32, device=device) + 1000.0 * rank).reshape(W * 3, 2)
         want = torch.empty_like(x)
         dist.all_to_all_single(want, x, group=group)
-        ok = torch.zeros(1, device=device)
+        r_want = x.clone()
+        dist.all_reduce(r_want, group=group)
+        m_want = torch.tensor([rank, -rank], dtype=torch.int64, device=device)
+        dist.all_reduce(m_want, op=dist.ReduceOp.MAX, group=group)
+        g_want = x.new_empty((W,) + tuple(x.shape))
+        dist.all_gather_into_tensor(g_want.view(-1), x.view(-1), group=group)
+        ok = torch.zeros(2, device=device)
+        err = None
         try:
             got = torch.empty_like(x)
             self.all_to_all(got, x, group, False)
             again = torch.empty_like(x)
             self.all_to_all(again, x, group, True).wait()
-            ok.fill_(1.0 if (torch.equal(got, want) and torch.equal(again, want)) else 0.0)
+            r_got = x.clone()
+            self.all_reduce(r_got, group)
+            r_async = x.clone()
+            self.all_reduce(r_async, group, async_op=True).wait()
+            m_got = torch.tensor([rank, -rank], dtype=torch.int64, device=device)
+            self.all_reduce(m_got, group, op="max")
+            g_got = torch.empty_like(g_want)
+            self.all_gather(g_got, x, group)
+            same = (torch.equal(got, want) and torch.equal(again, want) and torch.equal(r_got, r_want)
+                    and torch.equal(r_async, r_want) and torch.equal(m_got, m_want) and torch.equal(g_got, g_want))
+            ok[0] = 1.0 if same else 0.0
         except Exception as exc:                      # noqa: BLE001 -- any failure means "use torch.distributed"
-            import warnings
-            warnings.warn("recbox_amd.comm: direct RCCL exchange unavailable (%s: %s)" % (type(exc).__name__, exc))
+            err = exc
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks take the same path
-        self.on = bool(ok.item() > 0)
+        eager_ok = bool(ok[0].item() > 0)
+        cap_ok = False
+        if eager_ok and os.environ.get("RECBOX_AMD_DIRECT_RCCL_CAPTURE", "1") != "0":
+            # the same three collectives captured into a hipGraph and replayed twice on fresh inputs
+            try:
+                xs = x.clone()
+                a_out, r_buf = torch.empty_like(x), torch.empty_like(x)
+                side = torch.cuda.Stream(device=device)
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                        self.all_to_all(a_out, xs, group, False)
+                        r_buf.copy_(xs)
+                        self.all_reduce(r_buf, group, async_op=True).wait()
+                torch.cuda.current_stream(device).wait_stream(side)
+                good = True
+                for k in range(2):
+                    xs.copy_(x + 7.0 * k)
+                    graph.replay()
+                    a_want, rr_want = torch.empty_like(x), (x + 7.0 * k)
+                    dist.all_to_all_single(a_want, x + 7.0 * k, group=group)
+                    dist.all_reduce(rr_want, group=group)
+                    good = good and torch.equal(a_out, a_want) and torch.equal(r_buf, rr_want)
+                ok[1] = 1.0 if good else 0.0
+                self._check_graph = graph             # (kept: see ``shutdown`` -- a graph that holds RCCL nodes is released there)
+            except Exception as exc:                  # noqa: BLE001
+                err = err or exc
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            cap_ok = bool(ok[1].item() > 0)
+        self.on, self.capturable = eager_ok, cap_ok
+        self.why = ("ok" if eager_ok else "self-check failed%s" % ((": %s: %s" % (type(err).__name__, err)) if err else ""))
+        if not eager_ok:
+            if self.mode == "1":
+                raise RuntimeError("recbox_amd.comm: RECBOX_AMD_DIRECT_RCCL=1 but the direct RCCL path is unusable (%s)" % self.why)
+            import warnings
+            warnings.warn("recbox_amd.comm: direct RCCL collectives unavailable (%s); using torch.distributed" % self.why)
         return self.on
+
+    def shutdown(self):
+        """Release what holds RCCL kernels inside hipGraphs (the self-check's graph) before the process group goes away."""
+        self._check_graph = None
 
 
 direct = _Direct()
@@ -201,7 +341,7 @@ def all_to_all_equal_into(out, x, group=None, async_op=False):
     if not (dist.is_available() and dist.is_initialized()):
         out.copy_(x)
     elif dist.get_backend(group) == "nccl":
-        if direct.on:
+        if direct.usable(x, group):
             return direct.all_to_all(out, x, group, async_op)
         work = dist.all_to_all_single(out, x, group=group, async_op=async_op)
         if async_op:
@@ -211,8 +351,11 @@ def all_to_all_equal_into(out, x, group=None, async_op=False):
     return _Done()
 
 
-def all_reduce_sum_(x, group=None, async_op=False):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+def all_reduce_sum_(x, group=None, async_op=False, force=False):
+    """In-place SUM over the ranks (``force`` / ``force_world_of_one``: issued in a world of one too)."""
+    if multi(group) or (force and dist.is_available() and dist.is_initialized()):
+        if direct.usable(x, group) and x.is_contiguous() and x.dtype in _RBX_DTYPE:
+            return direct.all_reduce(x, group, "sum", async_op)
         work = dist.all_reduce(x, group=group, async_op=async_op)
         if async_op:
             return work
@@ -228,7 +371,10 @@ def all_gather_rows(x, group=None):
     x = x.contiguous()
     if dist.get_backend(group) == "nccl":
         out = x.new_empty((W * x.shape[0],) + tuple(x.shape[1:]))
-        dist.all_gather_into_tensor(out, x, group=group)
+        if direct.usable(x, group):
+            direct.all_gather(out, x, group)
+        else:
+            dist.all_gather_into_tensor(out, x, group=group)
         return out
     host = x.cpu()
     parts = [torch.empty_like(host) for _ in range(W)]
@@ -238,8 +384,11 @@ def all_gather_rows(x, group=None):
 
 def all_reduce_max_(x, group=None):
     """In-place MAX over the ranks (status words, flags, batch-size checks)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)
+    if multi(group):
+        if direct.usable(x, group) and x.is_contiguous() and x.dtype in _RBX_DTYPE:
+            direct.all_reduce(x, group, "max")
+        else:
+            dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group)
     return x
 
 
@@ -253,4 +402,4 @@ def all_reduce_grads(params, group=None):
             continue
         if p.grad is None:
             p.grad = torch.zeros_like(p)
-        dist.all_reduce(p.grad, group=group)
+        all_reduce_sum_(p.grad, group)

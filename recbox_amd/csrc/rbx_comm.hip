@@ -12,10 +12,24 @@ namespace rbx {
 typedef int (*nccl_group_fn)();
 typedef int (*nccl_p2p_fn)(void* buf, size_t count, int datatype, int peer, void* comm, hipStream_t stream);
 typedef const char* (*nccl_err_fn)(int);
+typedef int (*nccl_allreduce_fn)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t stream);
+typedef int (*nccl_allgather_fn)(const void* send, void* recv, size_t sendcount, int datatype, void* comm, hipStream_t stream);
 static nccl_group_fn g_group_start = nullptr, g_group_end = nullptr;
 static nccl_p2p_fn g_send = nullptr, g_recv = nullptr;
 static nccl_err_fn g_errstr = nullptr;
+static nccl_allreduce_fn g_allreduce = nullptr;
+static nccl_allgather_fn g_allgather = nullptr;
 constexpr int kNcclInt8 = 0;      // ncclInt8 / ncclChar
+// rbx dtype code (RBX_I32 ... RBX_F64) -> ncclDataType_t (ncclInt32 = 2, ncclInt64 = 4, ncclFloat32 = 7, ncclFloat64 = 8)
+static int nccl_type(int dtype) {
+  switch (dtype) {
+    case RBX_I32: return 2;
+    case RBX_I64: return 4;
+    case RBX_F32: return 7;
+    case RBX_F64: return 8;
+    default: return -1;
+  }
+}
 }  // namespace rbx
 
 extern "C" int rbx_comm_bind(void* fn_group_start, void* fn_group_end, void* fn_send, void* fn_recv, void* fn_error_string) {
@@ -48,5 +62,41 @@ extern "C" int rbx_all_to_all(void* comm, const void* d_send, void* d_recv, size
   const int rc_end = g_group_end();
   if (rc == 0) rc = rc_end;
   if (rc != 0) return fail(RBX_ERR_LAUNCH, "all_to_all: RCCL error %d (%s)", rc, g_errstr ? g_errstr(rc) : "?");
+  return RBX_OK;
+}
+
+extern "C" int rbx_comm_bind_collectives(void* fn_all_reduce, void* fn_all_gather) {
+  using namespace rbx;
+  if (!fn_all_reduce) return fail(RBX_ERR_INVALID, "comm_bind_collectives: ncclAllReduce is required");
+  g_allreduce = reinterpret_cast<nccl_allreduce_fn>(fn_all_reduce);
+  g_allgather = reinterpret_cast<nccl_allgather_fn>(fn_all_gather);
+  return RBX_OK;
+}
+
+extern "C" int rbx_all_reduce(void* comm, const void* d_send, void* d_recv, size_t count, int32_t dtype, int32_t op,
+                              void* stream) {
+  using namespace rbx;
+  if (g_allreduce == nullptr) return fail(RBX_ERR_INVALID, "all_reduce: rbx_comm_bind_collectives has not been called");
+  if (comm == nullptr) return fail(RBX_ERR_INVALID, "all_reduce: no communicator");
+  const int t = nccl_type(dtype);
+  if (t < 0) return fail(RBX_ERR_INVALID, "all_reduce: dtype %d", dtype);
+  if (op != RBX_REDUCE_SUM && op != RBX_REDUCE_MAX && op != RBX_REDUCE_MIN)
+    return fail(RBX_ERR_INVALID, "all_reduce: op %d", op);
+  if (count == 0) return RBX_OK;
+  if (d_send == nullptr || d_recv == nullptr) return fail(RBX_ERR_INVALID, "all_reduce: NULL buffer");
+  // RBX_REDUCE_SUM / MAX / MIN carry ncclRedOp_t's own values (ncclSum = 0, ncclMax = 2, ncclMin = 3)
+  const int rc = g_allreduce(d_send, d_recv, count, t, op, comm, as_stream(stream));
+  if (rc != 0) return fail(RBX_ERR_LAUNCH, "all_reduce: RCCL error %d (%s)", rc, g_errstr ? g_errstr(rc) : "?");
+  return RBX_OK;
+}
+
+extern "C" int rbx_all_gather(void* comm, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream) {
+  using namespace rbx;
+  if (g_allgather == nullptr) return fail(RBX_ERR_INVALID, "all_gather: rbx_comm_bind_collectives has not been given ncclAllGather");
+  if (comm == nullptr) return fail(RBX_ERR_INVALID, "all_gather: no communicator");
+  if (bytes_per_rank == 0) return RBX_OK;
+  if (d_send == nullptr || d_recv == nullptr) return fail(RBX_ERR_INVALID, "all_gather: NULL buffer");
+  const int rc = g_allgather(d_send, d_recv, bytes_per_rank, kNcclInt8, comm, as_stream(stream));
+  if (rc != 0) return fail(RBX_ERR_LAUNCH, "all_gather: RCCL error %d (%s)", rc, g_errstr ? g_errstr(rc) : "?");
   return RBX_OK;
 }

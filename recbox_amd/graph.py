@@ -78,6 +78,11 @@ class GraphedStep(object):
     def pool(self):
         return self.graph.pool()
 
+    def release(self):
+        """Drop the captured graph (a capture that holds RCCL kernel nodes must go before ``destroy_process_group()``)."""
+        self.graph = None
+        self.out = None
+
     def __call__(self):
         if ops._dropout_ticks:
             ops.bump_dropout_tick()          # a replay re-runs the captured seeds: the device tick makes the masks new
@@ -122,6 +127,9 @@ class ShardedFMStep(object):
     zero-filled in full -- consume it before the next call."""
 
     def __init__(self, model, X, y, graphs=True, warmup=2, loss_fn=None, persistent_shard_grad=True):
+        """graphs: False (eager pieces) / True (hipGraph pieces with the collectives between them) / "whole" (ONE hipGraph
+        holding the pieces AND the collectives: needs the collectives on the step's own stream, ``comm.direct`` usable and
+        capturable -- checked here, collectively; otherwise the pieces) / "auto" = "whole" when possible, else True."""
         from . import comm
         if model.tables is None or model.tables.capacity_factor is None:
             raise ValueError("ShardedFMStep needs row-sharded tables with the padded exchange (capacity_factor)")
@@ -159,9 +167,34 @@ class ShardedFMStep(object):
                 # never clear what the replays before them stored
                 raise ValueError("ShardedFMStep(graphs=True, persistent_shard_grad=True) needs warmup >= 1")
             tables.local_ops.persistent(tables.weight)
-        if self.W == 1:
+        self.multi = comm.multi(self.group)          # more than one rank (or a world of one told to issue its reductions)
+        if not self.multi:
             self.pieces[-1] = lambda: None          # nothing to un-flatten without an all-reduce (and no empty graph to replay)
-        if graphs:
+        self.whole = None
+        if graphs in ("whole", "auto"):
+            # every rank takes the same decision: usable() runs the collective self-check of the group when it is due
+            ok = bool(comm.direct.usable(self.back, self.group) and comm.direct.capturable)
+            if graphs == "whole" and not ok:
+                import warnings
+                warnings.warn("ShardedFMStep: the collectives cannot be captured on this stack (%s); hipGraph pieces instead"
+                              % comm.direct.why)
+            graphs = "whole" if ok else True
+        if graphs == "whole":
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(warmup, 1)):
+                    self._run(self.pieces)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            keep = getattr(tables.local_ops, "_keep", None)
+            if persistent and keep is not None and self.W * cap > 0 and not keep.get("dirty"):
+                raise RuntimeError("ShardedFMStep: the warm-up left no rows to clear; the captured sort would never re-zero the "
+                                   "persistent shard gradient")
+            self.whole = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.whole, capture_error_mode="thread_local"):
+                self._run(self.pieces)
+        elif graphs:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):           # allocator, plans, RCCL communicator: warm before capturing
@@ -175,7 +208,7 @@ class ShardedFMStep(object):
                 raise RuntimeError("ShardedFMStep: the warm-up left no rows to clear; the captured sort would never re-zero the "
                                    "persistent shard gradient")
             for piece in self.pieces:
-                if self.W == 1 and piece is self.pieces[-1]:
+                if not self.multi and piece is self.pieces[-1]:
                     self.graphs.append(piece)           # (the no-op stays a no-op)
                     continue
                 if piece == self._head:                 # the two id sorts are captured on their own streams first
@@ -209,7 +242,7 @@ class ShardedFMStep(object):
         # touched -- a persistent buffer that is re-zeroed by this rank's sorted ids (ops.config.reuse_grad_buffers)
         # would keep them.
         reuse = ops.config.reuse_grad_buffers
-        ops.config.reuse_grad_buffers = reuse and self.W == 1
+        ops.config.reuse_grad_buffers = reuse and not self.multi
         try:
             self.logit = self.model.logits(self.X, packed=self.back, packed_index=self.slot,
                                            presorted=self.local_sorted)
@@ -243,7 +276,7 @@ class ShardedFMStep(object):
             self.tables.local_ops.scatter_add(self.tables.weight, self.recv, self.d_recv, sorted_ws=self.sorted_ws))
 
     def _finish(self):
-        if self.flat is not None and self.W > 1:
+        if self.flat is not None and self.multi:
             o = 0
             for p, n in zip(self.replicated, self.sizes):
                 if p.grad is None:
@@ -274,7 +307,7 @@ class ShardedFMStep(object):
         grads_out = comm.all_to_all_equal_into(self.d_recv, self.dsend, group, async_op=True)
         cur.wait_stream(self.early)
         tail()                                    # overlaps with the gradient exchange
-        reduced = comm.all_reduce_sum_(self.flat, group, async_op=True) if self.flat is not None else None
+        reduced = comm.all_reduce_sum_(self.flat, group, async_op=True) if (self.flat is not None and self.multi) else None
         grads_out.wait()
         cur.wait_stream(self.side)
         settle()                                  # overlaps with the all-reduce of the replicated gradients
@@ -284,4 +317,14 @@ class ShardedFMStep(object):
         return self.loss
 
     def __call__(self):
+        if self.whole is not None:
+            self.whole.replay()
+            return self.loss
         return self._run(self.graphs if self.graphs is not None else self.pieces)
+
+    def release(self):
+        """Drop the captured graphs (they hold RCCL kernel nodes when the collectives were captured): call it -- and
+        synchronise -- before ``destroy_process_group()``."""
+        self.whole = None
+        self.graphs = None
+        self.presort_replay = self.localsort_replay = None

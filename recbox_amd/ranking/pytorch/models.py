@@ -205,8 +205,9 @@ class ShardedFM(nn.Module):
             lr_off = self.tables.lr_off
         # sync_grads() writes all-reduced rows (other ranks' batches) into the replicated tables' gradients in place:
         # they must be fresh tensors, not the row-re-zeroed persistent buffer of ops.config.reuse_grad_buffers
+        from ... import comm
         reuse = ops.config.reuse_grad_buffers
-        ops.config.reuse_grad_buffers = reuse and self.world_size == 1
+        ops.config.reuse_grad_buffers = reuse and not comm.multi(self.group)
         try:
             return ops.fm_fused(plan.plan, lplan.plan, values, [m.weight for m in plan.modules],
                                 [m.weight for m in lplan.modules], self.fm.lr_layer.bias, extra=packed,
@@ -219,9 +220,9 @@ class ShardedFM(nn.Module):
 
     def sync_grads(self):
         """All-reduce (sum) the dense gradients of the replicated parameters as ONE flat buffer."""
-        if self.world_size == 1:
+        from ... import comm
+        if not comm.multi(self.group):
             return
-        import torch.distributed as dist
         # every rank reduces the SAME layout: a parameter that received no gradient on this rank (an empty local batch, a
         # feature no sample of this rank used) contributes zeros -- ranks whose non-None sets differ would otherwise issue
         # all-reduces of different sizes and hang (ADVICE r1)
@@ -229,7 +230,7 @@ class ShardedFM(nn.Module):
         if not params:
             return
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-        dist.all_reduce(flat, group=self.group)
+        comm.all_reduce_sum_(flat, self.group)       # (on the step's own stream when comm.direct is usable: capturable)
         o = 0
         for p in params:
             g = flat[o:o + p.numel()].view_as(p)

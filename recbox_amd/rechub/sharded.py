@@ -208,10 +208,11 @@ class DenseGradSync(object):
         self.late = [p for p in late if p.requires_grad]
         self.group = group
         self.world = comm.world(group)[1]
+        self.active = comm.multi(group)         # (also in a world of one under comm.force_world_of_one)
         self._pending = None
         self._arrived = set()
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for p in self.early:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -230,7 +231,7 @@ class DenseGradSync(object):
         return
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         params = list(self.late)
         if self._pending is not None:

@@ -497,7 +497,10 @@ class HipShardOps(object):
         return plan
 
     def presort(self, weight, keys):
-        """The id sort of ``scatter`` needs the received row numbers only: it may run right after ``serve``."""
+        """The id sort of ``scatter`` needs the received row numbers only: it may run right after ``serve``.  With a
+        persistent gradient (``persistent``) the sorted keys live in ONE workspace from step to step: the rows the previous
+        backward stored -- still named by it -- are cleared first, then this step's keys are sorted over them (a captured
+        step replays exactly that: a workspace of the step's own would freeze the keys of the capture)."""
         from . import ops
         from ._lib import check, lib
         n = keys.numel()
@@ -505,6 +508,25 @@ class HipShardOps(object):
             return None
         plan = self._plan(weight)
         plan.bind_inputs([keys])
+        keep = self._keep
+        if keep is not None and keep["shape"] == tuple(weight.shape):
+            if keep.get("pending"):
+                raise RuntimeError("recbox_amd.sharded: a persistent shard gradient serves ONE lookup of its store per step "
+                                   "(a second exchange started before the first one's backward); use fresh gradients")
+            if keep["grad"] is None:
+                keep["grad"] = torch.zeros_like(weight)                 # the only full fill
+            plan.bind_params([weight.detach()], [keep["grad"]])
+            ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
+            if keep["dirty"]:
+                check(lib.rbx_embed_rezero(plan.arr, 1, keep["dirty"], ops._ptr(keep["ws"]), keep["ws_bytes"], ops._stream()))
+                keep["dirty"] = 0
+            if keep.get("own") is None or keep["own_bytes"] < ws_bytes:
+                keep["own"] = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
+                keep["own_bytes"] = ws_bytes
+            keep["ws"], keep["ws_bytes"] = keep["own"], keep["own_bytes"]
+            check(lib.rbx_embed_sort(plan.arr, 1, n, ops._ptr(keep["own"]), keep["own_bytes"], None, ops._stream()))
+            keep["pending"] = True
+            return keep["own"]
         plan.bind_params([weight.detach()], [weight.detach()])            # placeholder grad pointer: "trainable"
         ws_bytes = lib.rbx_embed_bwd_workspace_size(plan.arr, 1, n)
         ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
@@ -527,7 +549,8 @@ class HipShardOps(object):
                 keep["grad"] = torch.zeros_like(weight)                 # the only full fill
             grad = keep["grad"]
             if keep["dirty"]:
-                # the rows the previous backward stored are named by the sorted keys in ITS workspace (kept alive here)
+                # (a backward whose sort was not made ahead by ``presort``:) the rows the previous backward stored are named
+                # by the sorted keys in ITS workspace (kept alive here)
                 plan.bind_inputs([keys])
                 plan.bind_params([weight.detach()], [grad])
                 check(lib.rbx_embed_rezero(plan.arr, 1, keep["dirty"], ops._ptr(keep["ws"]), keep["ws_bytes"], ops._stream()))
@@ -543,10 +566,13 @@ class HipShardOps(object):
         if ws is None:
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=weight.device)
             check(lib.rbx_embed_sort(plan.arr, 1, n, ops._ptr(ws), ws_bytes, None, ops._stream()))
+        elif kept and ws is keep.get("own"):
+            ws_bytes = keep["own_bytes"]
         check(lib.rbx_embed_bwd_indexed(plan.arr, 1, n, ops._ptr(grecv), grecv.stride(0), ops._ptr(src), None, 0,
                                         ops._ptr(ws), ws_bytes, ops._stream()))
         if kept:
             keep["ws"], keep["ws_bytes"], keep["dirty"] = ws, ws_bytes, n
+            keep["pending"] = False
             # autograd takes a gradient over as the parameter's .grad only when nobody else holds the TENSOR OBJECT -- handed
             # the buffer itself it would clone all of it (5 GB at cfg 3: the step went from 3.4 to 5.2 ms); a fresh view is
             # a new object over the same memory
