@@ -409,7 +409,7 @@ def run_model_config(args, rank, world, dev):
         from recbox_amd import optim as rb_optim
         tables, rest = rb_optim.split_parameters(model)
         if args.optimizer == "sparse_adam":
-            opt_steps = [rb_optim.SparseAdam(tables, lr=1e-3).step]
+            opt_steps = [rb_optim.SparseAdam(tables, lr=1e-3, capturable=True).step]
             if rest:
                 opt_steps.append(torch.optim.Adam(rest, lr=1e-3, capturable=True).step)
         else:

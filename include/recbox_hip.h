@@ -324,7 +324,14 @@ typedef struct rbx_opt {
   float   beta1, beta2;      /* Adam */
   float   eps;
   float   weight_decay;      /* L2 on the touched rows: g += weight_decay * w (0 for torch's sparse rules) */
+  const float* d_step_size;  /* NULL, or a DEVICE float that overrides lr: a step captured into a hipGraph bakes every
+                              * by-value argument in, so a rule whose step size depends on the step count (Adam's bias
+                              * correction, Adagrad's lr_decay) reads it from memory that rbx_opt_advance updates in-graph */
 } rbx_opt_t;
+/* t = *d_t + 1 -> *d_t; *d_step_size = the rule's effective step size at step t: SGD lr; Adagrad lr / (1 + (t - 1) lr_decay);
+ * Adam lr sqrt(1 - beta2^t) / (1 - beta1^t).  One tiny launch per optimiser step; d_t is a float counter (exact to 2^24). */
+int rbx_opt_advance(int32_t kind, float lr, float beta1, float beta2, float lr_decay, float* d_t, float* d_step_size,
+                    void* stream);
 int rbx_embed_sparse_update(const rbx_field_t* fields, int32_t n_fields, int64_t batch, const void* d_workspace,
                             size_t workspace_bytes, const rbx_opt_t* opt, float* const* d_state1, float* const* d_state2,
                             void* stream);

@@ -48,7 +48,7 @@ class rbx_shard_geom_t(ctypes.Structure):
 
 class rbx_opt_t(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float),
-                ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float)]
+                ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float), ("d_step_size", ctypes.c_void_p)]
 
 
 OPT_SGD, OPT_ADAGRAD, OPT_ADAM = 0, 1, 2
@@ -94,6 +94,7 @@ SIGNATURES = {
     "rbx_fm_sort": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P, _P]),
     "rbx_fm_sort_phases": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P, _i32, _P]),
     "rbx_embed_sparse_update": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _OP, _PP, _PP, _P]),
+    "rbx_opt_advance": (ctypes.c_int, [_i32, _f32, _f32, _f32, _f32, _P, _P, _P]),
     "rbx_fm_sparse_update": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _OP, _PP, _PP, _PP, _PP, _P]),
     "rbx_comm_bind": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "rbx_all_to_all": (ctypes.c_int, [_P, _P, _P, _sz, _i32, _P]),

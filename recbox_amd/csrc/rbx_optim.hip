@@ -25,20 +25,31 @@ namespace rbx {
 struct OptArgs {
   int kind;
   float lr, beta1, beta2, eps, wd;
+  const float* d_lr;         // device step size overriding lr (a captured step: rbx_opt_advance keeps it current), or NULL
 };
 
 __device__ __forceinline__ void opt_apply(const OptArgs& o, float g, float& w, float& s1, float& s2) {
+  const float lr = o.d_lr != nullptr ? *o.d_lr : o.lr;          // (a uniform address: one scalar load)
   g += o.wd * w;
   if (o.kind == RBX_OPT_SGD) {
-    w -= o.lr * g;
+    w -= lr * g;
   } else if (o.kind == RBX_OPT_ADAGRAD) {
     s1 += g * g;
-    w -= o.lr * g / (sqrtf(s1) + o.eps);
+    w -= lr * g / (sqrtf(s1) + o.eps);
   } else {
     s1 = o.beta1 * s1 + (1.f - o.beta1) * g;
     s2 = o.beta2 * s2 + (1.f - o.beta2) * g * g;
-    w -= o.lr * s1 / (sqrtf(s2) + o.eps);
+    w -= lr * s1 / (sqrtf(s2) + o.eps);
   }
+}
+
+__global__ void opt_advance_kernel(int kind, float lr, float b1, float b2, float lr_decay, float* t_ptr, float* out) {
+  const float t = *t_ptr + 1.f;
+  *t_ptr = t;
+  float s = lr;
+  if (kind == RBX_OPT_ADAGRAD) s = lr / (1.f + (t - 1.f) * lr_decay);
+  else if (kind == RBX_OPT_ADAM) s = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  *out = s;
 }
 
 struct UpdField {            // 80 B
@@ -164,7 +175,16 @@ static int opt_validate(const rbx_opt_t* opt, OptArgs* o) {
   o->beta2 = opt->beta2;
   o->eps = opt->eps;
   o->wd = opt->weight_decay;
+  o->d_lr = opt->d_step_size;
   return RBX_OK;
+}
+
+extern "C" int rbx_opt_advance(int32_t kind, float lr, float beta1, float beta2, float lr_decay, float* d_t,
+                               float* d_step_size, void* stream) {
+  if (kind < RBX_OPT_SGD || kind > RBX_OPT_ADAM) return fail(RBX_ERR_INVALID, "opt_advance: unknown rule %d", kind);
+  if (d_t == nullptr || d_step_size == nullptr) return fail(RBX_ERR_INVALID, "opt_advance: NULL counter / step size");
+  opt_advance_kernel<<<1, 1, 0, as_stream(stream)>>>(kind, lr, beta1, beta2, lr_decay, d_t, d_step_size);
+  return check_launch("opt_advance_kernel");
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

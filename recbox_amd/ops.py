@@ -550,6 +550,11 @@ class _EmbedLookup(torch.autograd.Function):
             pool.done(B)
         _forget_sort(ws)
         if adopted is not None:                        # the rows went into the gradient another node of this pass returned
+            # ... whose record of touched rows (sparse-row optimisers) names only ITS lookup's rows: the gradient now also
+            # holds this lookup's, so the record must go -- the optimiser then steps the table over its non-zero rows
+            for p, w in zip(params, want):
+                if w:
+                    touched.pop(id(p), None)
             return (None, None, None, None) + (None,) * len(ctx.inputs) + (None,) * len(params)
         if config.track_touched_rows:
             _note_touched("embed", (plan,), ctx.inputs, (list(params),), (list(grads),), ws, ws_bytes, B)
@@ -1701,6 +1706,9 @@ class _GatherDot(torch.autograd.Function):
                                     x.stride(0) if dx is None else dx.stride(0), 1 if adopted is not None else 0,
                                     _ptr(ws), ws_bytes, _stream()))
         if adopted is not None:
+            for p, w in zip(params, want):       # (see _EmbedLookup.backward: the first node's record names its rows only)
+                if w:
+                    touched.pop(id(p), None)
             return head + (None,) * len(params)
         _publish_grads(ctx, params, grads)
         return head + tuple(grads)

@@ -48,13 +48,21 @@ def split_parameters(model):
 class _SparseRows(object):
     kind = None
 
-    def __init__(self, params, lr, weight_decay=0.0):
+    def __init__(self, params, lr, weight_decay=0.0, capturable=False):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError("optimizer got an empty parameter list")
         self.lr, self.weight_decay = float(lr), float(weight_decay)
         self.state = {}
         self.calls = {"rows": 0, "dense": 0}          # C-ABI sparse-row calls / dense fallbacks so far (tests read it)
+        # capturable: the step count and the step size derived from it (Adam's bias correction, Adagrad's lr_decay) live in
+        # DEVICE memory and advance inside the step (rbx_opt_advance), so that ``step()`` can be captured into a hipGraph and
+        # every replay takes the step size of ITS step -- by value (the default) a capture would freeze the step size of the
+        # capture step (at t = 3 about 0.2 of Adam's asymptotic one) for every replay, which is why ``step()`` refuses a
+        # capture without it.  One counter per optimiser: every table of it is then on the same step (torch.optim keeps one
+        # per parameter; the two agree whenever every table receives a gradient in every step, as in a captured step).
+        self.capturable = bool(capturable)
+        self._dev = None                              # {"t": float32[1], "step_size": float32[1]} on the tables' device
         ops.config.track_touched_rows = True
 
     # ---- per-rule pieces ------------------------------------------------------------------------------------------
@@ -86,7 +94,20 @@ class _SparseRows(object):
 
     def _opt_struct(self, t):
         b1, b2, eps = self._betas_eps()
-        return _lib.rbx_opt_t(self.kind, self._step_size(t), b1, b2, eps, self.weight_decay)
+        dptr = self._dev["step_size"].data_ptr() if self.capturable else None
+        return _lib.rbx_opt_t(self.kind, self._step_size(t), b1, b2, eps, self.weight_decay, dptr)
+
+    def _lr_decay(self):
+        return 0.0
+
+    def _advance(self, device):
+        """capturable: t += 1 and the step size of step t, on the device, in stream order (one 1-thread launch)."""
+        if self._dev is None:
+            self._dev = {"t": torch.zeros(1, dtype=torch.float32, device=device),
+                         "step_size": torch.zeros(1, dtype=torch.float32, device=device)}
+        b1, b2, _ = self._betas_eps()
+        check(lib.rbx_opt_advance(self.kind, self.lr, b1, b2, self._lr_decay(), ops._ptr(self._dev["t"]),
+                                  ops._ptr(self._dev["step_size"]), ops._stream()))
 
     @staticmethod
     def _ptr_array(n, ptrs):
@@ -98,6 +119,14 @@ class _SparseRows(object):
     @torch.no_grad()
     def step(self):
         mine = dict((id(p), p) for p in self.params if p.grad is not None)
+        if not mine:
+            return
+        if self.capturable:
+            self._advance(next(iter(mine.values())).device)
+        elif torch.cuda.is_available() and torch.cuda.is_current_stream_capturing() and self._step_size(1) != self._step_size(2):
+            raise RuntimeError("%s.step() inside a hipGraph capture: this rule's step size depends on the step count and is "
+                               "passed by value, so every replay would reuse the capture step's; build the optimiser with "
+                               "capturable=True (step count and step size then live on the device)" % type(self).__name__)
         done, recs = set(), {}
         for pid in mine:
             rec = ops.touched.get(pid)
@@ -108,8 +137,16 @@ class _SparseRows(object):
         for pid, p in mine.items():
             if pid not in done:
                 self._step_dense(p)
+        # the records name gradient tensors and sort workspaces: once stepped they would only keep a [V, D] gradient alive
+        # past zero_grad(set_to_none=True) (the next backward allocates its own before overwriting the record)
+        for pid in mine:
+            ops.touched.pop(pid, None)
 
     def _step_dense(self, p):
+        if self.capturable:
+            raise RuntimeError("%s(capturable=True): the table %s got its gradient outside embed_lookup / fm_fused (or from "
+                               "two lookups of one step); the dense fallback reads the step count on the host and cannot "
+                               "be captured" % (type(self).__name__, tuple(p.shape)))
         self.calls["dense"] += 1
         st = self._state_of(p)
         st["step"] += 1
@@ -185,8 +222,8 @@ class SparseSGD(_SparseRows):
     kind = _lib.OPT_SGD
     n_state = 0
 
-    def __init__(self, params, lr=1e-2, weight_decay=0.0):
-        super().__init__(params, lr, weight_decay)
+    def __init__(self, params, lr=1e-2, weight_decay=0.0, capturable=False):
+        super().__init__(params, lr, weight_decay, capturable)
 
     def _dense_rows(self, p, g, st, rows, t):
         g = g + self.weight_decay * p if self.weight_decay else g
@@ -200,9 +237,13 @@ class SparseAdagrad(_SparseRows):
     kind = _lib.OPT_ADAGRAD
     n_state = 1
 
-    def __init__(self, params, lr=1e-2, lr_decay=0.0, eps=1e-10, weight_decay=0.0, initial_accumulator_value=0.0):
-        super().__init__(params, lr, weight_decay)
+    def __init__(self, params, lr=1e-2, lr_decay=0.0, eps=1e-10, weight_decay=0.0, initial_accumulator_value=0.0,
+                 capturable=False):
+        super().__init__(params, lr, weight_decay, capturable)
         self.lr_decay, self.eps, self.init_acc = float(lr_decay), float(eps), float(initial_accumulator_value)
+
+    def _lr_decay(self):
+        return self.lr_decay
 
     def _state_of(self, p):
         new = id(p) not in self.state
@@ -235,8 +276,8 @@ class SparseAdam(_SparseRows):
     kind = _lib.OPT_ADAM
     n_state = 2
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        super().__init__(params, lr, weight_decay)
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
+        super().__init__(params, lr, weight_decay, capturable)
         self.b1, self.b2, self.eps = float(betas[0]), float(betas[1]), float(eps)
 
     def _step_size(self, t):

@@ -138,3 +138,126 @@ def test_sparse_adam_on_a_rechub_model_and_dense_fallback():
         assert opt.calls == {"rows": 3, "dense": 3}, opt.calls       # tables through their lookup's ids, the tower weight densely
     finally:
         ops.config.track_touched_rows = False
+
+
+def test_two_lookups_of_one_table_step_every_touched_row():
+    """a table read by TWO lookups of a step (rechub EmbeddingLayer called twice over the same tables; the
+    second backward node adopts the gradient the first one published, ops.config.share_table_grads) must be stepped over
+    the rows of BOTH lookups.  The first node's record of touched rows names only its own ids: the adopting node drops
+    it, and the optimiser steps the table over the non-zero rows of its dense gradient (== the torch rule)."""
+    from recbox_amd import ops, optim
+    from recbox_amd.rechub.basic.layers import EmbeddingLayer
+    Fe = _rh_features()
+    V, D, B = 503, 16, 64
+    feats = [Fe.SparseFeature("item", V, D), Fe.SparseFeature("cat", 37, D)]
+    layer = EmbeddingLayer(feats).cuda()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.normal_(0, 0.2)
+    tables, _ = optim.split_parameters(layer)
+    opt = optim.SparseAdam(tables, lr=0.01)
+    hp = {"lr": 0.01, "betas": (0.9, 0.999), "eps": 1e-8}
+    ref = dict((id(p), p.detach().clone()) for p in tables)
+    state = dict((id(p), {"step": 0, "m": torch.zeros_like(p), "v": torch.zeros_like(p)}) for p in tables)
+    assert ops.config.share_table_grads
+    try:
+        for k in range(3):
+            g = torch.Generator().manual_seed(70 + k)
+            # disjoint id ranges: the second lookup touches rows the first one never names
+            x1 = {"item": torch.randint(1, 200, (B,), generator=g).cuda(), "cat": torch.randint(1, 18, (B,), generator=g).cuda()}
+            x2 = {"item": torch.randint(200, V, (B,), generator=g).cuda(), "cat": torch.randint(18, 37, (B,), generator=g).cuda()}
+            opt.zero_grad()
+            a = layer(x1, feats, squeeze_dim=True)
+            b = layer(x2, [feats[0]], squeeze_dim=True)                 # its trainable tables: a subset of the first's
+            ((a * a).sum() + (b * b * 0.5).sum()).backward()
+            grads = dict((id(p), p.grad.detach().clone()) for p in tables)
+            item = [p for p in tables if p.shape[0] == V][0]
+            rows_touched = (grads[id(item)] != 0).any(dim=1).nonzero().reshape(-1)
+            assert int((rows_touched >= 200).sum()) > 0 and int((rows_touched < 200).sum()) > 0
+            opt.step()
+            for p in tables:
+                gr = grads[id(p)]
+                rows = (gr != 0).any(dim=1).nonzero().reshape(-1)
+                _reference_step("adam", ref[id(p)], gr, rows, state[id(p)], hp)
+                assert torch.allclose(p.detach(), ref[id(p)], atol=2e-6, rtol=0), \
+                    (k, tuple(p.shape), float((p.detach() - ref[id(p)]).abs().max()))
+        assert opt.calls["dense"] >= 3                                  # the shared table went the dense-rows way every step
+        assert not any(id(p) in ops.touched for p in tables)            # the step released its records (ADVICE r3, low)
+    finally:
+        ops.config.track_touched_rows = False
+
+
+def _rh_features():
+    from recbox_amd.rechub.basic import features as Fe
+    return Fe
+
+
+def test_capturable_sparse_adam_replays_with_the_step_size_of_each_step():
+    """SparseAdam.step captured into a hipGraph.  By value the bias-corrected step size of the CAPTURE step
+    would be replayed for ever; ``capturable=True`` keeps the step count and the step size on the device
+    (rbx_opt_advance in the graph).  Six replays of a captured fwd + bwd + update == six eager steps of the by-value
+    optimiser on the same batch; the by-value optimiser refuses to be captured."""
+    from recbox_amd import ops, optim
+    from recbox_amd.graph import GraphedStep
+    from recbox_amd.ranking.pytorch.models import FM
+    vocabs = [37, 5, 3001, 70000]
+    fm, X, y = _criteo_like(400, vocabs, 16, seed=9)
+    Xc, yc = _cuda(X), y.cuda()
+    old_check = ops.config.check_ids
+    ops.config.check_ids = False
+
+    def make():
+        torch.manual_seed(3)
+        m = FM(fm, 16, fused=True).cuda()
+        with torch.no_grad():
+            for p in m.parameters():
+                p.normal_(0, 0.1)
+        return m
+
+    try:
+        eager = make()
+        tables_e, rest_e = optim.split_parameters(eager)
+        opt_e = optim.SparseAdam(tables_e, lr=0.01)
+
+        def step_of(model, opt, rest):
+            def fn():
+                opt.zero_grad()
+                for p in rest:
+                    p.grad = None
+                loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(model.logits(Xc)), yc, reduction="mean")
+                loss.backward()
+                opt.step()
+                return loss
+            return fn
+
+        n_warm, n_replay = 3, 6
+        fn_e = step_of(eager, opt_e, rest_e)
+        for _ in range(n_warm + 1 + n_replay):           # GraphedStep: 3 warm-up calls + the capture (not executed) ...
+            fn_e()
+        graphed = make()
+        tables_g, rest_g = optim.split_parameters(graphed)
+        bad = optim.SparseAdam(tables_g, lr=0.01)
+        graphed.logits(Xc).sum().backward()              # (eagerly: the tables have gradients and a record of touched rows)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="capturable=True"):
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    bad.step()
+        torch.cuda.synchronize()
+        graphed = make()
+        tables_g, rest_g = optim.split_parameters(graphed)
+        opt_g = optim.SparseAdam(tables_g, lr=0.01, capturable=True)
+        step = GraphedStep(step_of(graphed, opt_g, rest_g), warmup=n_warm, reuse_grads=True)
+        # the capture pass itself does not execute, but it launched rbx_opt_advance into the graph only: the device counter
+        # stands at n_warm; the eager model above has taken n_warm + 1 + n_replay steps -> replay n_replay + 1 times
+        for _ in range(n_replay + 1):
+            step()
+        torch.cuda.synchronize()
+        assert float(opt_g._dev["t"]) == n_warm + 1 + n_replay
+        for pe, pg in zip(tables_e, tables_g):
+            assert torch.allclose(pe.detach(), pg.detach(), atol=5e-6, rtol=0), float((pe - pg).abs().max())
+    finally:
+        ops.config.check_ids = old_check
+        ops.config.track_touched_rows = False
