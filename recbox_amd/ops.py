@@ -1504,8 +1504,12 @@ class _Linear(torch.autograd.Function):
                 check(rc)
                 check(lib.rbx_linear_bwd(_ptr(x2), K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, None, K, _ptr(dw),
                                          _ptr(db), _ptr(ws), ws_bytes, _stream()))
-                _bn_hint["bwd"] = (dxc.data_ptr(), (M, K), partial, blocks)
-                return dxc.view(ctx.shape), dw, db, None, None
+                # (the version counter goes along: autograd's InputBuffer may ADD another consumer's gradient into dxc in
+                #  place when the BatchNorm's output fed more than this Linear -- same pointer and shape, but the partial
+                #  sums then cover only this Linear's share; an in-place add bumps the version)
+                out = dxc.view(ctx.shape)
+                _bn_hint["bwd"] = (dxc.data_ptr(), (M, K), partial, blocks, out, out._version)
+                return out, dw, db, None, None
         bwd = lambda: check(lib.rbx_linear_bwd(                                                            # noqa: E731
             _ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx),
             (dx.stride(0) if M > 1 else K) if dx is not None else K, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, _stream()))
@@ -1899,7 +1903,7 @@ class _BatchNorm(torch.autograd.Function):
         dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
         hint, _bn_hint["bwd"] = _bn_hint["bwd"], None
         if (hint is not None and hint[0] == dy.data_ptr() and hint[1] == (rows, cols) and ctx.training and y_relu is not None
-                and dx is not None):
+                and dx is not None and hint[4]._version == hint[5]):
             # dy is ALREADY masked by the ReLU (the dx GEMM that produced it did that) and its column sums are on file
             check(lib.rbx_batchnorm_bwd_sums_from_partials(_ptr(hint[2]), hint[3], cols, _ptr(dgamma), _ptr(dbeta), _stream()))
             check(lib.rbx_batchnorm_bwd_dx(_ptr(x), _ptr(dy), None, rows, cols, _ptr(weight), _ptr(mean), _ptr(rstd),
@@ -1924,6 +1928,7 @@ class _BatchNormPReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, slope, stats, training, momentum, eps):
         running_mean, running_var = stats.running_mean, stats.running_var
+        _bn_hint["fwd"] = None                    # (this path takes no statistics from a GEMM epilogue: drop a stale hand-over)
         _require_cuda(x, "x")
         x = x.contiguous().float()
         rows, cols = x.shape
@@ -1972,6 +1977,7 @@ class _SyncBatchNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stats, momentum, eps, relu, group):
+        _bn_hint["fwd"] = None                    # (per-rank partials are not what a synchronised BatchNorm normalises by)
         from . import comm
         _require_cuda(x, "x")
         x = x.contiguous().float()

@@ -233,26 +233,31 @@ class DenseGradSync(object):
     def finish(self):
         if not self.active:
             return
-        params = list(self.late)
+        # Every rank issues the SAME two collectives per step -- [early layout], then [late layout] -- whatever arrived
+        # where: a rank on which some tower parameter received no gradient (it then never fired from the hooks) reduces the
+        # early layout here, zeros standing in for what is missing, instead of one differently sized buffer.
         if self._pending is not None:
             flat, grads, work = self._pending
             work.wait()
             for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
                 g.copy_(r)
             self._pending = None
-        else:
-            params = self.early + params
+        elif self.early:
+            self._reduce(self.early)
         self._arrived.clear()
-        # every rank reduces the same layout: a parameter without a gradient on this rank contributes zeros
+        if self.late:
+            self._reduce(self.late)
+
+    def _reduce(self, params):
+        # a parameter without a gradient on this rank contributes zeros and receives the other ranks' sum
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
-        if grads:
-            flat = torch._utils._flatten_dense_tensors(grads)
-            comm.all_reduce_sum_(flat, self.group)
-            for p, g, r in zip(params, grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-                if p.grad is None:
-                    p.grad = r.clone()
-                else:
-                    g.copy_(r)
+        flat = torch._utils._flatten_dense_tensors(grads)
+        comm.all_reduce_sum_(flat, self.group)
+        for p, g, r in zip(params, grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            if p.grad is None:
+                p.grad = r.clone()
+            else:
+                g.copy_(r)
 
 
 class _ShardedModelMixin(object):

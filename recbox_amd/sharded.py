@@ -678,7 +678,7 @@ class ShardedStore(nn.Module):
         self.local_ops = local_ops if local_ops is not None else HipShardOps()
         self.on_backward_start = None          # optional hook called when the exchange's backward starts
         self._bases = {}
-        self.check_batch_size = "once"
+        self.check_batch_size = "auto"
         self._seen_batch = set()
 
     def check_ids(self):
@@ -688,11 +688,17 @@ class ShardedStore(nn.Module):
     def check_batch(self, B):
         """Every rank derives the static wire sizes of the exchange from ITS batch size: they only agree when all ranks
         hold the same number of samples (``drop_last=True`` in the loader, or pad the last batch).  ``check_batch_size``:
-        "once" (default) checks a size collectively the first time THIS rank sees it -- a set-up error raises ValueError on
+        "auto" (default): "always" for eager calls, nothing inside a hipGraph capture (see below).
+        "once" checks a size collectively the first time THIS rank sees it -- a set-up error raises ValueError on
         every rank at the first step instead of hanging in the all-to-all; it cannot see a size that changes on one rank only
         (the other ranks do not enter the check).  "always" checks every call (one 16-byte all-reduce + host sync); False
         never."""
         mode = self.check_batch_size
+        if mode == "auto":
+            # a captured step has ONE batch size by construction (checked in its warm-up); launched eagerly, a loader's short
+            # last batch on one rank only would walk into the all-to-all with other wire sizes than its peers: check every
+            # call there -- a check that only the rank seeing a NEW size enters is itself a mismatched collective (ADVICE r3)
+            mode = "once" if (self.weight.is_cuda and torch.cuda.is_current_stream_capturing()) else "always"
         if not mode or self.world_size == 1 or (mode == "once" and B in self._seen_batch):
             return
         t = torch.tensor([B, -B], dtype=torch.int64, device=self.weight.device)
