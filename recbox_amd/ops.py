@@ -774,6 +774,18 @@ class _GradPool(object):
         self.ticket = 0                       # bumped by every sort: a backward whose ticket is stale re-sorts
         self.pending = False                  # a forward holds the ticket and its backward has not run yet
         self.device = device
+        # Guard of the aliasing contract.  The gradients handed out alias ``flat``, and only the rows named
+        # by the step's sorted ids are ever cleared.  Anything else that lands in them IN PLACE -- autograd adding a second
+        # contribution to a table's gradient: the reference's own Lp regulariser over every "embedding_layer" parameter
+        # (ranking_model.py:72-87, match_model.py:71-89) writes ALL rows -- would stay there for ever.  A post-accumulate
+        # hook per pooled parameter counts the arrivals of a backward: a second one into a tensor that lives in ``flat``
+        # marks the pool ``polluted``, and from then on the buffer is cleared IN FULL before every step (correct dense
+        # gradients at the price of the fill; sticky -- a model that does it once does it every step, and a captured step
+        # takes the decision of its warm-up).
+        self.polluted = False
+        self._arrivals = {}                   # id(p) -> (graph task, number of gradient arrivals in it)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_accumulate)
+                       for p, n in zip(params, self.sizes) if n]
 
     @staticmethod
     def _key(params):
@@ -813,6 +825,7 @@ class _GradPool(object):
         them.  Both return a C-ABI code.  (Clearing on a third stream beside the sort was measured slower -- 0.344 vs
         0.331 ms per FM step --, and so was clearing beside the forward kernel -- 0.309 vs 0.299 ms, the forward going
         from 46 to 61 us: the step is bound by the memory request rate, concurrent kernels only slow each other down.)"""
+        self._clear_if_polluted()
         dirty = self.dirty_batch
         # a larger batch than ever before: clear, then regrow.  ``pre`` (work of the new step on the CURRENT stream, written
         # into the workspace in the layout of ITS batch size) may land on the previous step's sorted pairs unless the two
@@ -856,11 +869,34 @@ class _GradPool(object):
         if not (usable and ctx.ticket == self.ticket):
             ctx.sort = None                      # another forward has sorted over this workspace since: start over
             return None, None
+        task = _graph_task()
         for p, w in zip(params, want):
             if w and p.grad is not None:
+                seen = self._arrivals.get(id(p))
+                if seen is not None and seen[0] == task and task >= 0:
+                    # ANOTHER node of this same backward pass got there first (the regulariser's term runs before the
+                    # lookup's backward: it was built later): autograd will add this op's gradient into that tensor in
+                    # place -- fresh gradients for this backward, the persistent buffer stays clean
+                    self.pending = False
+                    return None, None
                 raise RuntimeError("recbox_amd: config.reuse_grad_buffers needs p.grad to be None at every backward "
                                    "(zero_grad(set_to_none=True)); the gradients alias one persistent buffer")
         return self, self.views(list(params), zero_loose=zero_loose)
+
+    def _on_accumulate(self, p):
+        task = _graph_task()
+        seen = self._arrivals.get(id(p))
+        k = seen[1] + 1 if (seen is not None and seen[0] == task) else 1
+        self._arrivals[id(p)] = (task, k)
+        if k > 1 and self.flat is not None and p.grad is not None:
+            lo = self.flat.data_ptr()
+            if lo <= p.grad.data_ptr() < lo + self.flat.numel() * 4:
+                self.polluted = True          # somebody added to a gradient that aliases the persistent buffer
+
+    def _clear_if_polluted(self):
+        if self.polluted and self.flat is not None and self.dirty_batch:
+            self.flat.zero_()                 # every row: what a second writer left behind is not named by any sorted id
+            self.dirty_batch = 0
 
     def done(self, B, ws=None, ws_bytes=0):
         self.dirty_batch = B                     # the rows named by the sorted ids in that workspace now hold this step's sums
@@ -872,6 +908,7 @@ class _GradPool(object):
         the previous backward stored -- its sorted ids are in ``dirty_ws``, another workspace -- on the side stream, beside the
         forward kernel; the backward waits for that before it stores."""
         ctx.rezero_event = None
+        self._clear_if_polluted()
         if self.dirty_batch:
             side = _side_stream(device)
             side.wait_event(started)                # (recorded before the forward kernel: the re-zero does not wait for it)

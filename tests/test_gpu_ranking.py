@@ -276,6 +276,81 @@ def _bce_step(model, X, y):
     return loss
 
 
+def test_embedding_regulariser_under_persistent_gradients_and_graph_replay():
+    """the reference's own harness adds an Lp term over every "embedding_layer" parameter to the loss
+    (ranking_model.py:72-87: ``add_regularization``) -- its backward writes ALL rows of a table's gradient, in place, into
+    whatever arrived first.  With persistent gradient buffers (GraphedStep's default) the op's tensor arrives first and
+    aliases the buffer of which only the looked-up rows are ever cleared: the guard (ops._GradPool: a post-accumulate hook
+    per pooled parameter) notices the second writer in the first warm-up step and clears the buffer in full from then on.
+    Replays of the captured step over rotating batches == eager steps with fresh gradients, never stale rows."""
+    from recbox_amd import ops
+    from recbox_amd.graph import GraphedStep
+    vocabs = CRITEO_SMALL_VOCABS + [70000]
+    fm, fresh, reuse = _fm_pair(43, vocabs)
+    lam = 0.03
+    old, old_check = ops.config.reuse_grad_buffers, ops.config.check_ids
+    ops.config.check_ids = False
+    try:
+        def step_of(model, Xc, yc):
+            params = list(model.parameters())
+            emb = [p for n, p in model.named_parameters() if "embedding_layer" in n]
+
+            def fn():
+                for p in params:
+                    p.grad = None
+                loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(model.logits(Xc)), yc, reduction="mean")
+                reg = sum((p ** 2).sum() for p in emb)                     # emb_reg with p = 2 (ranking_model.py:82-84)
+                (loss + lam / 2 * reg).backward()
+                return loss
+            return fn
+
+        batches = []
+        for k in range(3):
+            _, X, y = _criteo_like(600, vocabs, 16, seed=90 + k, zipf=bool(k % 2))
+            batches.append((_cuda(X), y.cuda()))
+        ops.config.reuse_grad_buffers = False
+        want = []
+        for Xc, yc in batches:
+            step_of(fresh, Xc, yc)()
+            want.append([p.grad.clone() for p in fresh.parameters()])
+        graphs = []
+        for Xc, yc in batches:
+            graphs.append(GraphedStep(step_of(reuse, Xc, yc), warmup=2, reuse_grads=True, params=list(reuse.parameters()),
+                                      pool=graphs[0].pool() if graphs else None))
+        for rnd in range(2):
+            for k in (0, 1, 2, 1, 0):
+                graphs[k]()
+                torch.cuda.synchronize()
+                worst = 0.0
+                for (n, p), g in zip(reuse.named_parameters(), want[k]):
+                    err = float((p.grad - g).abs().max())
+                    worst = max(worst, err)
+                    assert err <= 1e-6, "round %d batch %d: %s differs by %g (stale rows?)" % (rnd, k, n, err)
+        print("regulariser under persistent gradients: max |grad - fresh| = %.3g" % worst)
+        # the other order of arrival: a regulariser term built BEFORE the forward runs its backward AFTER the lookup's (the
+        # engine runs later-built nodes first), so the op's tensor arrives first -- it aliases the persistent buffer -- and
+        # the dense Lp gradient is then added INTO the buffer.  Two such steps, then clean ones: no row of an earlier
+        # step may survive
+        fm2, fresh2, reuse2 = _fm_pair(44, vocabs)
+
+        def reg_first_step(model, Xc, yc, with_reg):
+            model.zero_grad(set_to_none=True)
+            emb = [p for n, p in model.named_parameters() if "embedding_layer" in n]
+            reg = sum((p ** 2).sum() for p in emb) if with_reg else 0.0
+            loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(model.logits(Xc)), yc, reduction="mean")
+            (loss + lam / 2 * reg).backward()
+
+        for k, (Xc, yc) in enumerate(batches + batches[:2]):
+            ops.config.reuse_grad_buffers = False
+            reg_first_step(fresh2, Xc, yc, k < 2)
+            ops.config.reuse_grad_buffers = True
+            reg_first_step(reuse2, Xc, yc, k < 2)
+            for (n, p0), (_, p1) in zip(fresh2.named_parameters(), reuse2.named_parameters()):
+                assert float((p1.grad - p0.grad).abs().max()) <= 1e-6, "step %d: %s keeps rows of an earlier step" % (k, n)
+    finally:
+        ops.config.reuse_grad_buffers, ops.config.check_ids = old, old_check
+
+
 def test_reuse_grad_buffers_equals_fresh_grads():
     """ops.config.reuse_grad_buffers (persistent dense grads, rbx_fm_rezero clears only the rows the previous step wrote)
     leaves bit-identical gradients to the zero-filled path over steps with different ids and batch sizes (smaller,
