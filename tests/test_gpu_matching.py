@@ -1106,6 +1106,95 @@ def test_sasrec_cfg5_full_size_vs_oracle():
         assert_close(p.grad, want, tol, "grad " + n)
 
 
+def test_deepfm_training_step_in_the_benchmarked_mode_vs_fp64_oracle():
+    """What ``bench.py --config deepfm`` times, end to end against the oracle: DeepFM at the Criteo
+    table sizes, D = 64, the 3 x 400 tower at B = 8 192 -- large enough for the split-operand bf16 GEMMs (gemm_bxp / gemm_bxt:
+    K >= 256, N >= 128), BatchNorm in TRAINING mode (batch statistics, running statistics updated) and the fused input
+    stage (deepfm_input_stage) -- against ``RefDeepFM`` in float64 on the CPU: every prediction at 1e-4 absolute, the
+    BatchNorm running statistics after the step, every dense gradient and the rows of one 1 M-row table at 1e-4 of the
+    tensor's largest entry (sum-reduced loss: O(1) gradients)."""
+    import bench
+    from oracle import torch_ref as R
+    from recbox_amd import ops
+    from recbox_amd.rechub.models.ranking import DeepFM
+    B, D = 8192, 64
+    dense, sparse = bench._deepfm_features(D)
+    mlp = {"dims": [400, 400, 400], "dropout": 0.0, "activation": "relu"}
+    with torch.device("cuda"):
+        model = DeepFM(dense + sparse, sparse, mlp)
+    bench.init_weights_device(model, torch.device("cuda"), 0, 0, std=0.05)
+    ref = R.RefDeepFM(dense + sparse, sparse, mlp).double().train()
+    ref.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()
+                         for k, v in model.state_dict().items()})
+    model.train()
+    x = bench._deepfm_batch(B, 78, "uniform", "cuda")
+    xs = {k: (v.cpu().double() if v.is_floating_point() else v.cpu()) for k, v in x.items()}
+    before = ops.gemm_bx6_count()
+    pred = model(x)
+    F.binary_cross_entropy(pred, x["label"], reduction="sum").backward()
+    if ops.config.gemm_bx6:
+        assert ops.gemm_bx6_count() > before, "the split-operand GEMMs did not run at the tower's shapes"
+    want = ref(xs)
+    F.binary_cross_entropy(want, xs["label"], reduction="sum").backward()
+    assert_close(pred, want, TOL, "training-mode predictions, all %d rows" % B)
+    for (n, b), (_, b0) in zip(model.named_buffers(), ref.named_buffers()):
+        if b.is_floating_point():
+            assert_close(b, b0, TOL, "BatchNorm buffer " + n)
+    wantp = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        if "embed_dict" in n and p.shape[0] > 100000 and "C2" not in n:
+            continue                                # (one 1 M-row table is enough)
+        w = wantp[n].grad
+        tol = TOL * max(1.0, float(w.abs().max()))
+        if "embed_dict" in n and p.shape[0] > 100000:
+            rows = torch.unique(xs["C2"])
+            assert_close(p.grad[rows.cuda()], w[rows], tol, "rows of the 1 M-row table " + n)
+            untouched = torch.ones(p.shape[0], dtype=torch.bool)
+            untouched[rows] = False
+            assert float(p.grad[untouched.cuda()].abs().max()) == 0.0
+            continue
+        assert_close(p.grad, w, tol, "grad " + n)
+
+
+def test_sasrec_at_the_benchmarked_batch_on_sampled_sequences_vs_oracle():
+    """``bench.py --config sasrec`` runs B = 4096; the oracle comparison above runs B = 512.  SASRec has
+    no coupling between the sequences of a batch (LayerNorm is per position), so the model is run at B = 4096 -- the
+    launch shapes the bench times -- and compared with the oracle on 192 sampled sequences: both logit blocks at 1e-4, and,
+    with the loss restricted to those sequences, the gradients of every block parameter and of the touched item rows."""
+    import bench
+    from oracle import torch_ref as R
+    from recbox_amd.rechub.models.matching import SASRec
+    V, D, L, B, S = 1_000_000, 64, 200, 4096, 192
+    feats = bench._sasrec_features(V, D)
+    with torch.device("cuda"):
+        model = SASRec(feats, max_len=L, dropout_rate=0.0, num_blocks=2, num_heads=1)
+    bench.init_weights_device(model, torch.device("cuda"), 0, 0, std=0.1)
+    model.train()
+    x = bench._sasrec_batch(B, V, L, 6, "cuda")
+    g = torch.Generator().manual_seed(8)
+    pick = torch.randperm(B, generator=g)[:S].sort().values
+    ref = R.RefSASRec(feats, max_len=L, dropout_rate=0.0, num_blocks=2, num_heads=1).train()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    xc = {k: v[pick.cuda()].cpu() for k, v in x.items()}
+    pl, nl = model(x)
+    pl0, nl0 = ref(xc)
+    assert_close(pl[pick.cuda()], pl0, TOL, "pos logits of the sampled sequences (model run at B = 4096)")
+    assert_close(nl[pick.cuda()], nl0, TOL, "neg logits of the sampled sequences")
+    w = torch.zeros(B, L, device="cuda")
+    w[pick.cuda()] = (x["seq"][pick.cuda()] != 0).float()
+    (-((F.logsigmoid(pl) + F.logsigmoid(-nl)) * w).sum()).backward()
+    (-((F.logsigmoid(pl0) + F.logsigmoid(-nl0)) * w[pick.cuda()].cpu()).sum()).backward()
+    wantp = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        want = wantp[n].grad
+        tol = TOL * max(1.0, float(want.abs().max()))
+        if n.endswith("embed_dict.seq.weight"):
+            rows = torch.unique(torch.cat([xc["seq"].reshape(-1), xc["pos"].reshape(-1), xc["neg"].reshape(-1)]))[:20000]
+            assert_close(p.grad[rows.cuda()], want[rows], tol, "item rows")
+            continue
+        assert_close(p.grad, want, tol, "grad " + n)
+
+
 @pytest.mark.parametrize("rows,n", [(1, 5), (257, 5), (65536, 5), (1000, 1), (300, 101)])
 def test_softmax_cross_entropy_epilogue_vs_torch(rows, n):
     """K7's loss epilogue (rbx_softmax_ce_*): -log softmax(y)[:, 0] mean (softmax_crossentropy_loss.py:19-22) and the
