@@ -312,7 +312,11 @@ class _Direct(object):
                     dist.all_reduce(rr_want, group=group)
                     good = good and torch.equal(a_out, a_want) and torch.equal(r_buf, rr_want)
                 ok[1] = 1.0 if good else 0.0
-                self._check_graph = graph             # (kept: see ``shutdown`` -- a graph that holds RCCL nodes is released there)
+                # a hipGraph that holds RCCL kernel nodes must be gone before the communicator is destroyed:
+                # destroy_process_group() hangs behind a live one (profiles/r04/teardown.txt: "keep" hangs, "release" leaves
+                # in 0.4 s) -- so this one goes right away, and GraphedStep / ShardedFMStep have ``release()``
+                torch.cuda.synchronize(device)
+                del graph
             except Exception as exc:                  # noqa: BLE001
                 err = err or exc
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
@@ -327,8 +331,11 @@ class _Direct(object):
         return self.on
 
     def shutdown(self):
-        """Release what holds RCCL kernels inside hipGraphs (the self-check's graph) before the process group goes away."""
-        self._check_graph = None
+        """Before ``destroy_process_group()``: forget the communicators (the next group gets its own check).  Graphs that
+        captured collectives are the caller's to release first (``GraphedStep.release`` / ``ShardedFMStep.release``)."""
+        self.comms.clear()
+        self.checked.clear()
+        self.on = self.capturable = False
 
 
 direct = _Direct()
@@ -360,6 +367,72 @@ def all_reduce_sum_(x, group=None, async_op=False, force=False):
         if async_op:
             return work
     return _Done()
+
+
+def _storage_spans(tensors, max_gap=16, min_cover=0.9):
+    """Group gradient tensors by the storage they live in: [(span, members)] where ``span`` is ONE contiguous 1-D view of
+    the storage range the members occupy -- when they are contiguous, tile the range up to alignment gaps of a few
+    elements and share dtype -- else (None, [tensor]).  The dense gradients of one lookup are views of one flat buffer
+    (ops._flat_zero_grads): reducing the span in place needs no flatten / un-flatten copies (65 copy kernels per FM step)."""
+    by = {}
+    for t in tensors:
+        by.setdefault((t.untyped_storage().data_ptr(), t.dtype), []).append(t)
+    out = []
+    for (_, dtype), ts in by.items():
+        ok = all(t.is_contiguous() for t in ts)
+        if ok and len(ts) > 1:
+            ts = sorted(ts, key=lambda t: t.storage_offset())
+            lo, hi = ts[0].storage_offset(), max(t.storage_offset() + t.numel() for t in ts)
+            end = lo
+            for t in ts:
+                if t.storage_offset() < end or t.storage_offset() - end > max_gap:
+                    ok = False
+                    break
+                end = t.storage_offset() + t.numel()
+            if ok and sum(t.numel() for t in ts) >= min_cover * (hi - lo):
+                span = torch.empty(0, dtype=dtype, device=ts[0].device).set_(ts[0].untyped_storage(), lo, (hi - lo,))
+                out.append((span, ts))
+                continue
+        for t in ts:
+            out.append((None, [t]))
+    return out
+
+
+def all_reduce_coalesced_(tensors, group=None, async_op=False):
+    """In-place SUM of every tensor over the ranks, with as few collectives as their memory layout allows: tensors that are
+    views of one flat buffer are reduced as ONE span of it, in place (no flatten, no copy back); loose tensors are packed
+    into one flat buffer and copied back on ``wait()``.  Every rank must pass the same layout.  Returns a handle."""
+    if not tensors or not multi(group):
+        return _Done()
+    spans = _storage_spans([t for t in tensors])
+    loose = [ts[0] for span, ts in spans if span is None]
+    handles = []
+    for span, ts in spans:
+        if span is not None:
+            handles.append(all_reduce_sum_(span, group, async_op))
+    back = None
+    if len(loose) == 1 and loose[0].is_contiguous():
+        handles.append(all_reduce_sum_(loose[0], group, async_op))
+    elif loose:
+        flat = torch._utils._flatten_dense_tensors(loose)
+        handles.append(all_reduce_sum_(flat, group, async_op))
+        back = (flat, loose)
+    return _Coalesced(handles, back)
+
+
+class _Coalesced(object):
+    def __init__(self, handles, back):
+        self.handles, self.back = handles, back
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        if self.back is not None:
+            flat, loose = self.back
+            for t, r in zip(loose, torch._utils._unflatten_dense_tensors(flat, loose)):
+                t.copy_(r)
+            self.back = None
+        return True
 
 
 def all_gather_rows(x, group=None):

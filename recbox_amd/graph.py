@@ -119,7 +119,7 @@ class ShardedFMStep(object):
 
     Capturing a collective inside a hipGraph is not dependable on this stack (round 1: the capture of a
     torch.distributed all_to_all_single hung), so the graphs stop at the collectives; the host cost per step is
-    6 graph launches + 4 collectives instead of ~150 eager kernel launches.  ``graphs=False`` runs the same
+    5 graph launches + 4 collectives instead of ~150 eager kernel launches (``graphs="whole"``: ONE launch).  ``graphs=False`` runs the same
     pieces eagerly (tests, debugging).  Inputs ``X`` (dict of static tensors) and ``y`` are read in place:
     refill them before every call.  After a call, ``.grad`` of every parameter is what
     ``(bce(model(X), y) / world).backward(); model.sync_grads()`` leaves.  ``persistent_shard_grad``: the dense gradient of
@@ -158,6 +158,7 @@ class ShardedFMStep(object):
         self.sorted_ws = None
         self.local_sorted = None
         self.graphs = None
+        self.reduced = None
         persistent = persistent_shard_grad and hasattr(tables.local_ops, "persistent")
         if persistent:
             # the shard's dense gradient: one buffer cleared by row instead of a full zero fill per step
@@ -208,8 +209,8 @@ class ShardedFMStep(object):
                 raise RuntimeError("ShardedFMStep: the warm-up left no rows to clear; the captured sort would never re-zero the "
                                    "persistent shard gradient")
             for piece in self.pieces:
-                if not self.multi and piece is self.pieces[-1]:
-                    self.graphs.append(piece)           # (the no-op stays a no-op)
+                if piece is self.pieces[-1]:
+                    self.graphs.append(piece)           # (the join of the asynchronous all-reduce: a stream wait, not a graph)
                     continue
                 if piece == self._head:                 # the two id sorts are captured on their own streams first
                     gs = torch.cuda.CUDAGraph()
@@ -261,8 +262,13 @@ class ShardedFMStep(object):
 
     def _tail(self):
         self.logit.backward(self.dlogit)          # fused backward of the replicated tables / numeric weights / bias
-        self.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                               for p in self.replicated]) if self.replicated else None
+        # every gradient of the fused backward is a view of ONE flat buffer (ops._flat_zero_grads): the all-reduce takes
+        # that buffer as it lies (comm.all_reduce_coalesced_) -- no torch.cat before it, no per-parameter copy after it
+        # (round 3's _finish: 65 copy kernels per step, invisible in a world of one that skipped the reduction)
+        for p in self.replicated:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        self.flat = [p.grad for p in self.replicated]
 
     def _localsort(self):
         # ids of the replicated tables -> sorted (row, sample) pairs for the fused backward; needs X only
@@ -276,13 +282,9 @@ class ShardedFMStep(object):
             self.tables.local_ops.scatter_add(self.tables.weight, self.recv, self.d_recv, sorted_ws=self.sorted_ws))
 
     def _finish(self):
-        if self.flat is not None and self.multi:
-            o = 0
-            for p, n in zip(self.replicated, self.sizes):
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                p.grad.copy_(self.flat[o:o + n].view_as(p))
-                o += n
+        if self.reduced is not None:
+            self.reduced.wait()                   # (loose gradients, if any, are copied back here)
+            self.reduced = None
 
     # ---- the step ------------------------------------------------------------------------------------------
     def _run(self, pieces):
@@ -307,12 +309,10 @@ class ShardedFMStep(object):
         grads_out = comm.all_to_all_equal_into(self.d_recv, self.dsend, group, async_op=True)
         cur.wait_stream(self.early)
         tail()                                    # overlaps with the gradient exchange
-        reduced = comm.all_reduce_sum_(self.flat, group, async_op=True) if (self.flat is not None and self.multi) else None
+        self.reduced = comm.all_reduce_coalesced_(self.flat, group, async_op=True) if (self.flat and self.multi) else None
         grads_out.wait()
         cur.wait_stream(self.side)
         settle()                                  # overlaps with the all-reduce of the replicated gradients
-        if reduced is not None:
-            reduced.wait()
         finish()
         return self.loss
 

@@ -714,6 +714,31 @@ def _other_readers(ctx, p):
     return len(readers)
 
 
+# Data-parallel gradient buckets (recbox_amd.rechub.sharded.DenseGradSync): a replicated tower / head parameter registers
+# a view of ONE flat buffer as the place its gradient should be written; the backward of Linear / BatchNorm / the DeepFM
+# input stage then writes there instead of into a tensor of its own, autograd takes the view over as ``p.grad``, and the
+# all-reduce runs over the flat buffer in place -- no flatten before it, no copy back after it (DDP's
+# gradient_as_bucket_view, without the in-place add).  Keyed by the parameter's data pointer; one taker per step.
+_grad_views = {}
+
+
+class _GradView(object):
+    __slots__ = ("view", "taken")
+
+    def __init__(self, view):
+        self.view, self.taken = view, False
+
+
+def _grad_dest(key, shape, device):
+    """The registered destination of the gradient of the parameter at ``key`` (a fresh tensor object over the bucket's
+    memory: AccumulateGrad takes a gradient over only when nobody else holds the object), or a new tensor."""
+    ent = _grad_views.get(key) if key else None
+    if ent is not None and not ent.taken and tuple(ent.view.shape) == tuple(shape) and ent.view.device == device:
+        ent.taken = True
+        return ent.view.view(ent.view.shape)
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+
+
 def _graph_task():
     f = getattr(torch._C, "_current_graph_task_id", None)
     return f() if f is not None else -1
@@ -1147,13 +1172,21 @@ class _FmFused(torch.autograd.Function):
         if getattr(ctx, "pool", None) is not None:
             pool, grads = ctx.pool.backward_grads(ctx, list(emb_params) + list(lr_params), want_e + want_l, same and B > 0,
                                                   zero_loose=False)
+        gb = None
         if pool is None:
-            grads = _flat_zero_grads(list(emb_params) + list(lr_params), want_e + want_l, dev)
+            # ONE zero-filled buffer for every gradient of the call, the bias's included: a data-parallel caller reduces the
+            # whole buffer in place as one span (comm.all_reduce_coalesced_), no flatten / un-flatten copies
+            with_b = [bias] if (want_b and bias is not None and bias.numel() == 1) else []
+            grads = _flat_zero_grads(list(emb_params) + list(lr_params) + with_b, want_e + want_l + [True] * len(with_b), dev)
+            if with_b:
+                gb = grads[-1].view(1)
+                grads = grads[:n_emb + n_lr]
         ge, gl = grads[:n_emb], grads[n_emb:]
         # persistent gradients: the numeric-feature weights and the bias are STORED by the numeric kernels (phases bit 2),
         # their buffers need no fill (two 4 us fill kernels in a chain of small kernels)
         store = 4 if pool is not None else 0
-        gb = (torch.empty if store else torch.zeros)(1, dtype=torch.float32, device=dev) if want_b else None
+        if gb is None and want_b:
+            gb = (torch.empty if store else torch.zeros)(1, dtype=torch.float32, device=dev)
         # indexed: only the referenced wire slots are written, the empty ones must read as zero
         dx = (torch.empty_like(extra) if extra_index is None else torch.zeros_like(extra)) if want_x else None
         head = (None,) * base
@@ -1512,6 +1545,7 @@ class _Linear(torch.autograd.Function):
                                            _ptr(y), _stream()))))
         ctx.save_for_backward(x2, w, y if act == 1 else None)
         ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, shape
+        ctx.grad_keys = (weight.data_ptr() if weight.is_contiguous() else 0, bias.data_ptr() if bias is not None else 0)
         return y.view(*shape[:-1], N)
 
     @staticmethod
@@ -1524,8 +1558,8 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:       # 2-D inputs get 16-byte aligned gradient rows (float4 stores, aligned re-reads)
             dx = _padded_rows(M, K, dy.device) if len(ctx.shape) == 2 else torch.empty((M, K), dtype=torch.float32,
                                                                                       device=dy.device)
-        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
-        db = torch.empty(N, dtype=torch.float32, device=dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = _grad_dest(ctx.grad_keys[0], w.shape, dy.device) if ctx.needs_input_grad[1] else None
+        db = _grad_dest(ctx.grad_keys[1], (N,), dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, ctx.act)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
         if dx is not None and ctx.bn_src is not None:
@@ -1928,6 +1962,7 @@ class _BatchNorm(torch.autograd.Function):
             _bn_hint["out"] = (y.data_ptr(), (rows, cols), x, mean, rstd, weight, bias)
         ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
         ctx.training, ctx.has_bias = training, bias is not None
+        ctx.grad_keys = (weight.data_ptr() if weight is not None else 0, bias.data_ptr() if bias is not None else 0)
         return y
 
     @staticmethod
@@ -1936,8 +1971,9 @@ class _BatchNorm(torch.autograd.Function):
         dy = dy.contiguous().float()
         rows, cols = x.shape
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
+        keys = ctx.grad_keys
+        dgamma = _grad_dest(keys[0] if (weight is not None and ctx.needs_input_grad[1]) else 0, (cols,), x.device)
+        dbeta = _grad_dest(keys[1] if (ctx.has_bias and ctx.needs_input_grad[2]) else 0, (cols,), x.device)
         hint, _bn_hint["bwd"] = _bn_hint["bwd"], None
         if (hint is not None and hint[0] == dy.data_ptr() and hint[1] == (rows, cols) and ctx.training and y_relu is not None
                 and dx is not None and hint[4]._version == hint[5]):
@@ -2951,6 +2987,8 @@ class _DeepFmInput(torch.autograd.Function):
         check(lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(lr_w), _ptr(lr_b), M, 1, fm_cols, 0, _ptr(y_lr), _stream()))
         ctx.save_for_backward(x2, w1, lr_w, ssum)
         ctx.meta = (fm_cols, dim, b1 is not None, lr_b is not None, tuple(x.shape))
+        ctx.grad_keys = (w1.data_ptr() if w1.is_contiguous() else 0, b1.data_ptr() if b1 is not None else 0,
+                         lr_w.data_ptr() if lr_w.is_contiguous() else 0, lr_b.data_ptr() if lr_b is not None else 0)
         return h, y_fm, y_lr
 
     @staticmethod
@@ -2973,11 +3011,12 @@ class _DeepFmInput(torch.autograd.Function):
 
         dh2 = dh.contiguous().float() if dh is not None else torch.zeros((M, N), dtype=torch.float32, device=dev)
         gf, gl = col(g_fm, "fm"), col(g_lr, "lr")
-        dw1 = torch.empty_like(w1) if need[1] else None
-        db1 = torch.empty(N, dtype=torch.float32, device=dev) if (has_b1 and need[2]) else None
+        keys = getattr(ctx, "grad_keys", (0, 0, 0, 0))
+        dw1 = _grad_dest(keys[0], w1.shape, dev) if need[1] else None
+        db1 = _grad_dest(keys[1], (N,), dev) if (has_b1 and need[2]) else None
         _lin_dwdb(x2, w1, dh2, dw1, db1)
-        dlr_w = torch.empty_like(lr_w) if need[3] else None
-        dlr_b = torch.empty(1, dtype=torch.float32, device=dev) if (has_lr_b and need[4]) else None
+        dlr_w = _grad_dest(keys[2], lr_w.shape, dev) if need[3] else None
+        dlr_b = _grad_dest(keys[3], (1,), dev) if (has_lr_b and need[4]) else None
         if dlr_w is not None or dlr_b is not None:           # the logit head's streaming kernels (n = 1)
             xl = x2[:, :fm_cols]
             gl2 = gl.view(M, 1)

@@ -229,16 +229,11 @@ class ShardedFM(nn.Module):
         params = [p for p in self.replicated_parameters() if p.requires_grad]
         if not params:
             return
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-        comm.all_reduce_sum_(flat, self.group)       # (on the step's own stream when comm.direct is usable: capturable)
-        o = 0
         for p in params:
-            g = flat[o:o + p.numel()].view_as(p)
             if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            o += p.numel()
+                p.grad = torch.zeros_like(p)
+        # (the fused backward's gradients are views of one flat buffer: reduced in place as one span, no copies)
+        comm.all_reduce_coalesced_([p.grad for p in params], self.group).wait()
 
 
 class _SubFeatureMap(object):

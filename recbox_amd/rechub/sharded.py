@@ -212,9 +212,29 @@ class DenseGradSync(object):
         self._pending = None
         self._arrived = set()
         self._hooks = []
+        self.bucket = None
+        self._views = []
         if self.active:
             for p in self.early:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            self._make_bucket()
+
+    def _make_bucket(self):
+        """ONE flat buffer for the tower / head gradients; every parameter's slot is registered with the ops as the place
+        its gradient is to be WRITTEN (ops._grad_views), so that the all-reduce runs over the buffer in place.  A gradient
+        that arrives elsewhere (an op without the hook-up, a second use of the parameter) is copied in and back."""
+        from .. import ops
+        ps = [p for p in self.early if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()]
+        if not ps:
+            return
+        sizes = [(p.numel() + 3) // 4 * 4 for p in ps]                     # 16-byte aligned slots
+        self.bucket = torch.zeros(sum(sizes), dtype=torch.float32, device=ps[0].device)
+        o = 0
+        for p, n in zip(ps, sizes):
+            view = self.bucket[o:o + p.numel()].view(p.shape)
+            ops._grad_views[p.data_ptr()] = ops._GradView(view)
+            self._views.append((p, view))
+            o += n
 
     def _on_grad(self, p):
         if id(p) in self._arrived or self._pending is not None:
@@ -222,42 +242,68 @@ class DenseGradSync(object):
                                "finished the first one (call model.sync_grads() after every loss.backward())")
         self._arrived.add(id(p))
         if len(self._arrived) == len(self.early):
-            grads = [q.grad for q in self.early]
-            flat = torch._utils._flatten_dense_tensors(grads)
-            self._pending = (flat, grads, comm.all_reduce_sum_(flat, self.group, async_op=True))
+            self._pending = self._start(self.early)
+
+    def _start(self, params):
+        """Asynchronous all-reduce of the gradients of ``params`` (zeros for a missing one); returns what finish() needs."""
+        copied, loose = [], []
+        in_bucket = dict((id(p), v) for p, v in self._views)
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            v = in_bucket.get(id(p))
+            if v is None:
+                loose.append(p.grad)
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)                     # did not land in its slot: carried by the bucket, copied back afterwards
+                copied.append((p, v))
+        handles = []
+        if self.bucket is not None and any(id(p) in in_bucket for p in params):
+            handles.append(comm.all_reduce_sum_(self.bucket, self.group, async_op=True))
+        if loose:
+            handles.append(comm.all_reduce_coalesced_(loose, self.group, async_op=True))
+        return handles, copied
 
     def start(self):
         """(kept for callers of the earlier interface: the all-reduce now starts from the parameters' own hooks)"""
         return
 
+    def abandon(self):
+        """Drop the state of a backward that will not be finished (a refused second backward, an exception in the step):
+        waits for an all-reduce already under way, forgets the arrivals."""
+        if self._pending is not None:
+            for h in self._pending[0]:
+                h.wait()
+            self._pending = None
+        self._arrived.clear()
+
     def finish(self):
         if not self.active:
             return
-        # Every rank issues the SAME two collectives per step -- [early layout], then [late layout] -- whatever arrived
+        # Every rank issues the SAME collectives per step -- the early layout, then the late layout -- whatever arrived
         # where: a rank on which some tower parameter received no gradient (it then never fired from the hooks) reduces the
-        # early layout here, zeros standing in for what is missing, instead of one differently sized buffer (ADVICE r3).
+        # early layout here, zeros standing in for what is missing (ADVICE r3).
+        if self._pending is None and self.early:
+            self._pending = self._start(self.early)
         if self._pending is not None:
-            flat, grads, work = self._pending
-            work.wait()
-            for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-                g.copy_(r)
+            handles, copied = self._pending
+            for h in handles:
+                h.wait()
+            for p, v in copied:
+                p.grad.copy_(v)
             self._pending = None
-        elif self.early:
-            self._reduce(self.early)
         self._arrived.clear()
+        from .. import ops
+        for p, _ in self._views:
+            ent = ops._grad_views.get(p.data_ptr())
+            if ent is not None:
+                ent.taken = False
         if self.late:
-            self._reduce(self.late)
-
-    def _reduce(self, params):
-        # a parameter without a gradient on this rank contributes zeros and receives the other ranks' sum
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
-        flat = torch._utils._flatten_dense_tensors(grads)
-        comm.all_reduce_sum_(flat, self.group)
-        for p, g, r in zip(params, grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-            if p.grad is None:
-                p.grad = r.clone()
-            else:
-                g.copy_(r)
+            # the replicated tables: their dense gradients are views of the lookup's one flat buffer -- reduced as a span
+            for p in self.late:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            comm.all_reduce_coalesced_([p.grad for p in self.late], self.group).wait()
 
 
 class _ShardedModelMixin(object):

@@ -344,10 +344,7 @@ def _sync_worker(rank, world, port, result):
                 except RuntimeError as e:
                     refused = "second backward" in str(e)
                 assert refused
-                sync._arrived.clear()                   # (restore: the refused backward left nothing behind but this)
-                if sync._pending is not None:
-                    sync._pending[2].wait()
-                    sync._pending = None
+                sync.abandon()                          # (restore: the refused backward left nothing behind but this)
                 for p in towers + list(table.parameters()):
                     p.grad = None
                 loss = ((item(xi) * table(ids)).sum() + (user(xu) ** 2).sum()) / world

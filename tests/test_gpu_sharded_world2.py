@@ -127,29 +127,85 @@ def _rccl_worker(rank, world, port, result):
         Xc, yc = _cuda(X), y.cuda()
         grads = []
         ops.config.check_ids = False
-        for use_direct in (False, True):
+        comm.force_world_of_one = True                     # the all-reduce of the replicated gradients is issued too
+        steps = []
+        for use_direct, mode in ((False, True), (True, True), (True, "whole")):
             comm.direct.enable(use_direct)
             torch.manual_seed(1)
             model = ShardedFM(fm, D, shard_min_vocab=300, capacity_factor=1.5).cuda()
             with torch.no_grad():
                 for p in model.parameters():
                     p.copy_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.1)
-            step = ShardedFMStep(model, Xc, yc, graphs=True)
-            for _ in range(2):
+            step = ShardedFMStep(model, Xc, yc, graphs=mode)
+            if mode == "whole":
+                assert comm.direct.capturable and step.whole is not None      # ONE hipGraph, the four collectives inside
+            for _ in range(3):
                 loss = step()
             torch.cuda.synchronize()
             grads.append([loss.clone()] + [p.grad.clone() for p in model.parameters()])
-        for a, b in zip(*grads):
-            assert torch.equal(a, b)
+            steps.append(step)
+        for other in grads[1:]:
+            for a, b in zip(grads[0], other):
+                assert torch.equal(a, b)
+        # the sharded rechub model, whole step (exchanges + all-reduces inside) as one hipGraph == launched eagerly
+        import torch.nn.functional as F
+        from recbox_amd.graph import GraphedStep
+        from recbox_amd.rechub.sharded import ShardedYoutubeDNN
+        from test_gpu_shard import _rh, _seed_params, _youtube_batch, _youtube_feats
+        Fe = _rh()
+        V, Dm, B, L, n_neg = 1501, 16, 96, 7, 3
+        got = []
+        for graphed in (False, True):
+            model = ShardedYoutubeDNN(*_youtube_feats(Fe, V, Dm), {"dims": [32, Dm]}, temperature=0.1, shard_min_vocab=500,
+                                      capacity_factor=2.0).cuda()
+            _seed_params(model)
+            model.embedding.store.local_ops.persistent(model.embedding.store.weight)
+            params = list(model.parameters())
+            batches = [{k: v.cuda() for k, v in _youtube_batch(B, V, L, n_neg, 60 + k).items()} for k in range(2)]
+            tgt = torch.zeros(B, dtype=torch.long, device="cuda")
+
+            def step_over(x):
+                def fn():
+                    for p in params:
+                        p.grad = None
+                    loss = F.cross_entropy(model(x), tgt)
+                    loss.backward()
+                    model.sync_grads()
+                    return loss
+                return fn
+            fns = [step_over(x) for x in batches]
+            if graphed:
+                fns = [GraphedStep(f, warmup=2, reuse_grads=False, params=params, capture_error_mode="thread_local")
+                       for f in fns]
+                steps.extend(fns)
+            else:
+                for f in fns:                                  # (the graphed model has taken its warm-up steps: same here)
+                    f(); f()
+            res = []
+            for k in (0, 1, 0):
+                loss = fns[k]()
+                torch.cuda.synchronize()
+                res.append([loss.detach().clone()] + [p.grad.clone() for p in params])
+            got.append(res)
+        for ra, rb in zip(*got):
+            for a, b in zip(ra, rb):
+                assert_close(a, b, 1e-6, "sharded YoutubeDNN: whole-step graph vs eager")
+        for st in steps:                                       # graphs that hold RCCL nodes go before the communicator does
+            st.release()
+        torch.cuda.synchronize()
         result.put((rank, "ok"))
     finally:
+        comm.force_world_of_one = False
+        comm.direct.shutdown()
         dist.destroy_process_group()
 
 
 def test_direct_rccl_exchange_equals_torch_distributed():
-    """rbx_all_to_all (grouped ncclSend/ncclRecv on the step's own stream through the communicator of the process
-    group) in a world of one THROUGH RCCL: the same bytes as torch.distributed's all_to_all_single, and a graphed
-    ShardedFMStep leaves bit-identical loss and gradients on either path.  More than one rank needs one GPU each."""
+    """rbx_all_to_all / rbx_all_reduce (RCCL calls on the step's own stream through the communicator of the process group)
+    in a world of one THROUGH RCCL: the same bytes as torch.distributed's collectives, eagerly and replayed from a hipGraph
+    (comm.direct.self_check); a ShardedFMStep leaves bit-identical loss and gradients as hipGraph pieces on either path
+    and as ONE hipGraph holding the collectives; the sharded YoutubeDNN step captured whole == launched eagerly; and the
+    process group is destroyed cleanly once the graphs are released.  More than one rank needs one GPU each."""
     assert _spawn(_rccl_worker, 1) == {0: "ok"}
 
 
