@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 117          /* 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 118          /* 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -285,6 +285,14 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
  * shape, of which a batch touches 36 MB): with the workspace of the PREVIOUS rbx_fm_sort (same fields, same batch)
  * and emb[i].grad / lr[i].grad = the buffers that step's rbx_fm_bwd stored into, write zeros to exactly the rows it
  * touched.  Call it before the next rbx_fm_sort reuses the workspace. */
+/* Round 4: the fused FM backward has a third tier (csrc/rbx_tierc.h): a table of ONE one-id-per-sample field that is too
+ * large for tier A (rows > 4096, < 2^21, dim a multiple of 4 up to 64) is reduced WITHOUT a global sort -- a workgroup per
+ * (table, hash partition) scans the compact id column, sorts its ~1024 pairs in LDS and writes its rows; rbx_fm_rezero
+ * clears the rows named by the workgroups' row lists.  Same gradients as the sorted path up to summation order,
+ * bit-identical from run to run.  rbx_fm_tier_c(0) switches the tier off for the process (the sparse-row updates walk
+ * sorted ids and refuse a call with tier C tables), 1 on, a negative value only reads; returns the previous setting.
+ * Change it between steps only: rbx_fm_sort / _bwd / _rezero of one step must see the same setting. */
+int rbx_fm_tier_c(int32_t enable);
 int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                   void* d_workspace, size_t workspace_bytes, void* stream);
 /* Two lookups over the SAME id tensors with the same table layout (the embedding tables of FeatureEmbedding and the dim-1
@@ -354,11 +362,12 @@ int rbx_all_to_all(void* comm, const void* d_send, void* d_recv, size_t bytes_pe
  * ncclAllReduce / ncclAllGather on `stream` -- with all three on the step's own stream no collective crosses to RCCL's
  * stream, and the whole step (collectives included) is one hipGraph capture.  dtype: RBX_I32 / RBX_I64 / RBX_F32 /
  * RBX_F64; op: RBX_REDUCE_*; in place when d_send == d_recv.  rbx_comm_bind_collectives hands over ncclAllReduce and
- * (optional, NULL) ncclAllGather of the loaded RCCL. */
+ * (optional, NULL) ncclAllGather and ncclCommUserRank of the loaded RCCL; with the latter rbx_all_to_all moves the block
+ * a rank keeps for itself by a device-to-device copy instead of RCCL's self send / recv. */
 #define RBX_REDUCE_SUM 0
 #define RBX_REDUCE_MAX 2
 #define RBX_REDUCE_MIN 3
-int rbx_comm_bind_collectives(void* fn_all_reduce, void* fn_all_gather);
+int rbx_comm_bind_collectives(void* fn_all_reduce, void* fn_all_gather, void* fn_comm_user_rank);
 int rbx_all_reduce(void* comm, const void* d_send, void* d_recv, size_t count, int32_t dtype, int32_t op, void* stream);
 int rbx_all_gather(void* comm, const void* d_send, void* d_recv, size_t bytes_per_rank, void* stream);
 

@@ -98,7 +98,7 @@ SIGNATURES = {
     "rbx_fm_sparse_update": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _OP, _PP, _PP, _PP, _PP, _P]),
     "rbx_comm_bind": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "rbx_all_to_all": (ctypes.c_int, [_P, _P, _P, _sz, _i32, _P]),
-    "rbx_comm_bind_collectives": (ctypes.c_int, [_P, _P]),
+    "rbx_comm_bind_collectives": (ctypes.c_int, [_P, _P, _P]),
     "rbx_all_reduce": (ctypes.c_int, [_P, _P, _P, _sz, _i32, _i32, _P]),
     "rbx_all_gather": (ctypes.c_int, [_P, _P, _P, _sz, _P]),
     "rbx_embed_rezero": (ctypes.c_int, [_FP, _i32, _i64, _P, _sz, _P]),
@@ -108,6 +108,7 @@ SIGNATURES = {
     "rbx_seq_colsum_workspace_size": (_sz, [_i64, _i32, _i32]),
     "rbx_seq_colsum": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _P, _P, _sz, _P]),
     "rbx_sum_prefix": (ctypes.c_int, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _i32, _P, _i64, _P]),
+    "rbx_fm_tier_c": (ctypes.c_int, [_i32]),
     "rbx_fm_rezero": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P]),
     "rbx_fm_bwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _P, _i32, _i32, _P, _sz, _P]),
     "rbx_gatherdot_fwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _f32, _P, _P, _P]),

@@ -159,7 +159,8 @@ class _Direct(object):
                        for n in ("ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclGetErrorString")]
                 _lib.check(_lib.lib.rbx_comm_bind(*fns))
                 _lib.check(_lib.lib.rbx_comm_bind_collectives(ctypes.cast(rccl.ncclAllReduce, ctypes.c_void_p),
-                                                              ctypes.cast(rccl.ncclAllGather, ctypes.c_void_p)))
+                                                              ctypes.cast(rccl.ncclAllGather, ctypes.c_void_p),
+                                                              ctypes.cast(rccl.ncclCommUserRank, ctypes.c_void_p)))
                 self.keep, self.bound = rccl, True
                 return
             except (OSError, AttributeError) as exc:

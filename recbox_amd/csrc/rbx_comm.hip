@@ -14,11 +14,13 @@ typedef int (*nccl_p2p_fn)(void* buf, size_t count, int datatype, int peer, void
 typedef const char* (*nccl_err_fn)(int);
 typedef int (*nccl_allreduce_fn)(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t stream);
 typedef int (*nccl_allgather_fn)(const void* send, void* recv, size_t sendcount, int datatype, void* comm, hipStream_t stream);
+typedef int (*nccl_rank_fn)(void* comm, int* rank);
 static nccl_group_fn g_group_start = nullptr, g_group_end = nullptr;
 static nccl_p2p_fn g_send = nullptr, g_recv = nullptr;
 static nccl_err_fn g_errstr = nullptr;
 static nccl_allreduce_fn g_allreduce = nullptr;
 static nccl_allgather_fn g_allgather = nullptr;
+static nccl_rank_fn g_userrank = nullptr;
 constexpr int kNcclInt8 = 0;      // ncclInt8 / ncclChar
 // rbx dtype code (RBX_I32 ... RBX_F64) -> ncclDataType_t (ncclInt32 = 2, ncclInt64 = 4, ncclFloat32 = 7, ncclFloat64 = 8)
 static int nccl_type(int dtype) {
@@ -52,10 +54,22 @@ extern "C" int rbx_all_to_all(void* comm, const void* d_send, void* d_recv, size
   if (bytes_per_peer == 0) return RBX_OK;
   if (d_send == nullptr || d_recv == nullptr) return fail(RBX_ERR_INVALID, "all_to_all: NULL buffer");
   hipStream_t s = as_stream(stream);
-  int rc = g_group_start();
   const char* sp = static_cast<const char*>(d_send);
   char* rp = static_cast<char*>(d_recv);
+  // The block a rank keeps for itself does not go through RCCL: its self send / recv is a generic copy kernel that moves
+  // ~1 TB/s (200 us for the 201 MB block of cfg 3 in a world of one, profiles/r04), the runtime's device-to-device copy
+  // 2-3x that.  Needs the rank of this process in the communicator (ncclCommUserRank, bound by rbx_comm_bind_collectives).
+  int self = -1;
+  if (g_userrank != nullptr && g_userrank(comm, &self) != 0) self = -1;
+  if (self >= 0 && self < world) {
+    if (hipMemcpyAsync(rp + static_cast<size_t>(self) * bytes_per_peer, sp + static_cast<size_t>(self) * bytes_per_peer,
+                       bytes_per_peer, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return fail(RBX_ERR_LAUNCH, "all_to_all: device-to-device copy of the rank's own block failed");
+    if (world == 1) return RBX_OK;
+  }
+  int rc = g_group_start();
   for (int peer = 0; peer < world && rc == 0; ++peer) {
+    if (peer == self) continue;
     rc = g_send(const_cast<char*>(sp) + static_cast<size_t>(peer) * bytes_per_peer, bytes_per_peer, kNcclInt8, peer, comm, s);
     if (rc == 0) rc = g_recv(rp + static_cast<size_t>(peer) * bytes_per_peer, bytes_per_peer, kNcclInt8, peer, comm, s);
   }
@@ -65,11 +79,12 @@ extern "C" int rbx_all_to_all(void* comm, const void* d_send, void* d_recv, size
   return RBX_OK;
 }
 
-extern "C" int rbx_comm_bind_collectives(void* fn_all_reduce, void* fn_all_gather) {
+extern "C" int rbx_comm_bind_collectives(void* fn_all_reduce, void* fn_all_gather, void* fn_comm_user_rank) {
   using namespace rbx;
   if (!fn_all_reduce) return fail(RBX_ERR_INVALID, "comm_bind_collectives: ncclAllReduce is required");
   g_allreduce = reinterpret_cast<nccl_allreduce_fn>(fn_all_reduce);
   g_allgather = reinterpret_cast<nccl_allgather_fn>(fn_all_gather);
+  g_userrank = reinterpret_cast<nccl_rank_fn>(fn_comm_user_rank);
   return RBX_OK;
 }
 
