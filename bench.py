@@ -429,7 +429,7 @@ def run_model_config(args, rank, world, dev):
                 for p, r in zip(dp_flat, torch._utils._unflatten_dense_tensors(flat, [p.grad for p in dp_flat])):
                     p.grad.copy_(r)
         else:
-            loss.backward()
+            ops.backward(loss)
         for st in opt_steps:
             st()
         return loss
@@ -835,7 +835,7 @@ def main():
                 (loss / world).backward()     # global-mean loss: shard owners sum contributions of every rank
                 model.sync_grads()            # replicated small tables / numeric weights / bias: one all-reduce
             else:
-                loss.backward()
+                ops.backward(loss)            # == loss.backward() with the constant 1 as its gradient (no ones_like fill)
             return loss
         return one_step
 
@@ -858,7 +858,7 @@ def main():
             with torch.cuda.stream(side):
                 model.presort(X_next, into=nxt)
             loss = loss_fn(prob, yk, reduction="mean")
-            loss.backward()
+            ops.backward(loss)
             cur.wait_stream(side)
             return loss
         return one_step

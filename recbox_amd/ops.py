@@ -2413,6 +2413,31 @@ class _BceMean(torch.autograd.Function):
         return dp.view(ctx.shape), None
 
 
+_unit_grads = {}
+
+
+def unit_grad(device):
+    """THE scalar 1.0 of ``device`` (one persistent tensor).  ``loss.backward()`` makes autograd fill a fresh ones_like(loss)
+    -- an 8 us launch in a step of twenty-odd 5-15 us kernels -- and the loss's backward then multiplies dL/dlogit by it
+    (another launch); handed this tensor (``ops.backward(loss)``), the fused loss recognises it by its address and returns
+    dL/dlogit as the forward already wrote it."""
+    dev = torch.device(device)
+    if dev.index is None and dev.type == "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
+    one = _unit_grads.get(dev)
+    if one is None:
+        one = _unit_grads[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    return one
+
+
+def backward(loss):
+    """``loss.backward()`` for a scalar fp32 loss, without the fill of autograd's implicit gradient (see ``unit_grad``)."""
+    if loss.dim() == 0 and loss.dtype == torch.float32 and loss.is_cuda:
+        loss.backward(gradient=unit_grad(loss.device))
+    else:
+        loss.backward()
+
+
 class _SigmoidBceMean(torch.autograd.Function):
     """mean BCE of sigmoid(logit): the loss, and dL/dlogit for an upstream gradient of 1, in ONE pass with the fixed-order
     final sum folded in (rbx_sigmoid_bce_mean_onepass); the backward multiplies by the upstream scalar on the device."""
@@ -2449,6 +2474,9 @@ class _SigmoidBceMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
+        one = _unit_grads.get(g.device)
+        if one is not None and g.data_ptr() == one.data_ptr() and g.dim() == 0:
+            return dx.view(ctx.shape), None          # upstream gradient IS the constant 1 (ops.backward): nothing to scale
         g = g.contiguous().float().view(1)
         out = torch.empty_like(dx)
         check(lib.rbx_scale_by_scalar(_ptr(dx), _ptr(g), dx.numel(), _ptr(out), _stream()))

@@ -328,6 +328,27 @@ def test_fm_tier_c_equals_the_sorted_path(B, mode):
         ops.config.check_ids = old_check
 
 
+def test_ops_backward_equals_loss_backward_bit_for_bit():
+    """``ops.backward(loss)`` hands autograd the persistent constant 1 as the loss's gradient (no ones_like fill, and the
+    fused sigmoid + BCE returns dL/dlogit unscaled): the same gradients as ``loss.backward()``, bit for bit."""
+    from recbox_amd import ops
+    from recbox_amd.ranking.pytorch.torch_utils import get_loss
+    vocabs = CRITEO_SMALL_VOCABS + [70000]
+    fm, a, b = _fm_pair(47, vocabs)
+    _, X, y = _criteo_like(777, vocabs, 16, seed=5)
+    Xc, yc = _cuda(X), y.cuda()
+    loss_fn = get_loss("binary_crossentropy")
+    for model, how in ((a, "autograd"), (b, "ops")):
+        model.zero_grad(set_to_none=True)
+        loss = loss_fn(model(Xc)["y_pred"], yc, reduction="mean")
+        if how == "ops":
+            ops.backward(loss)
+        else:
+            loss.backward()
+    for (n, p0), (_, p1) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p0.grad, p1.grad), n
+
+
 def test_embedding_regulariser_under_persistent_gradients_and_graph_replay():
     """the reference's own harness adds an Lp term over every "embedding_layer" parameter to the loss
     (ranking_model.py:72-87: ``add_regularization``) -- its backward writes ALL rows of a table's gradient, in place, into
