@@ -785,7 +785,8 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
   {
     int log_p = 0;
     while (log_p < kTcMaxLogP && ((B + (1ll << log_p) - 1) >> log_p) > kTcTarget) ++log_p;
-    tc->cap = static_cast<unsigned>(2 * (((B + (1ll << log_p) - 1) >> log_p) + 1) + 64);
+    tc->log_p = log_p;
+    tc->NB = static_cast<unsigned>((B + kTcList - 1) / kTcList);
     for (int t = 0; t < n_tabs; ++t) {
       if (!tab_c[t]) continue;
       const int c0 = tab_first[t];
@@ -800,10 +801,10 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
                    ? kNoId : static_cast<int>(lead[i0].padding_idx);
       tb.cid_row = c0;
       tb.part0 = tc->n_parts;
-      tb.log_p = log_p;
+      tb.reserved = 0;
       tc->n_parts += 1u << log_p;
     }
-    tc_layout(tc);
+    tc_layout(tc, B);
   }
   // ---- tier B: the sort plan ----
   int n_b = 0;
@@ -936,8 +937,8 @@ extern "C" int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int3
   // (tier-A tables are written in full by every backward: nothing to clear)
   if (f.p.n_lookups == 0 && f.tc.n_tab == 0) return RBX_OK;
   if (d_workspace == nullptr || workspace_bytes < f.bytes) return fail(RBX_ERR_WORKSPACE, "fm_rezero: workspace too small");
-  if (f.tc.n_tab != 0) {                            // tier C: the rows named by the workgroups' row lists
-    rc = tc_dispatch_rezero(f.tc, static_cast<char*>(d_workspace) + f.off_tc, as_stream(stream));
+  if (f.tc.n_tab != 0) {                            // tier C: the rows named by the bucket arrays of the last partition pass
+    rc = tc_dispatch_rezero(f.tc, batch, static_cast<char*>(d_workspace) + f.off_tc, as_stream(stream));
     if (rc != RBX_OK) return rc;
   }
   if (f.p.n_lookups == 0) return RBX_OK;
@@ -1005,6 +1006,10 @@ extern "C" int rbx_fm_sort_phases(const rbx_field_t* emb, const rbx_field_t* lr,
   if ((phases & 2) && f.p.n_lookups > 0) {      // tier B: global segmented radix sort (a one-tier call reads the id columns where they are)
     fm_bind_cid(&f, ws, batch);
     rc = run_sort(f.p, ws, f.ta.n_cid == 0 ? d_status : nullptr, s);
+    if (rc != RBX_OK) return rc;
+  }
+  if ((phases & 2) && f.tc.n_tab > 0) {         // tier C: one partition pass (count, scan, scatter) into the bucket arrays
+    rc = tc_launch_partition(f.tc, batch, reinterpret_cast<const int*>(ws + f.off_ta + f.ta.off_cid), ws + f.off_tc, s);
     if (rc != RBX_OK) return rc;
   }
   return RBX_OK;
@@ -1119,8 +1124,7 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
   }
   if (f.tc.n_tab > 0 && (phases & 1) && !(phases & 16)) {   // the tables of tier C: scan, sort in LDS, reduce -- one launch
     if ((reinterpret_cast<uintptr_t>(d_sum) & 15) != 0) return fail(RBX_ERR_INVALID, "fm: d_sum must be 16-byte aligned");
-    rc = tc_dispatch_bwd(f.tc, batch, reinterpret_cast<const int*>(ws + f.off_ta + f.ta.off_cid), d_dlogit, d_sum, accumulate,
-                         ws + f.off_tc, s);
+    rc = tc_dispatch_bwd(f.tc, batch, d_dlogit, d_sum, accumulate, ws + f.off_tc, s);
     if (rc != RBX_OK) return rc;
   }
   if ((phases & 1) && !(phases & 8)) {               // the tables of tier A: block partials, then every row written once
