@@ -2,7 +2,7 @@
 # round 4: tier C second form (partition pass + bucket reduce): tests, bench on / off, timeline; DeepFM training test detail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-out=$GRAFT_REPO_ROOT/gpurun_out/r04e
+out=$GRAFT_REPO_ROOT/gpurun_out/r04f
 mkdir -p $out
 timeout 900 python -m pytest tests/test_gpu_ranking.py tests/test_gpu_optim.py tests/test_gpu_cabi_vs_c_oracle.py -q -m gpu -x > $out/tests_fm.log 2>&1
 echo "fm tests exit $?" | tee -a $out/summary.txt; tail -4 $out/tests_fm.log | tee -a $out/summary.txt
@@ -16,7 +16,7 @@ RBX_FM_TIER_C=0 timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-co
 timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline --dist zipf > $out/bench_fm_zipf.json 2>/dev/null; ms fm_zipf
 RBX_FM_TIER_C=0 timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline --dist zipf > $out/bench_fm_zipf_tierc_off.json 2>/dev/null; ms fm_zipf_tierc_off
 RECBOX_AMD_FM_TWO_CHAINS=0 timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline > $out/bench_fm_one_chain.json 2>/dev/null; ms fm_one_chain
-RECBOX_AMD_FM_TIER_A_ON=side timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline > $out/bench_fm_tier_a_side.json 2>/dev/null; ms fm_tier_a_side
+RECBOX_AMD_FM_BLOCKSORT_AT=side timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline > $out/bench_fm_blocksort_side.json 2>/dev/null; ms fm_blocksort_side
 prof() { # name, bench args, anchor kernel, occurrence
   rm -rf $out/prof
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof -o b -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-configs $2 > $out/prof_$1.log 2>&1)

@@ -183,10 +183,16 @@ __global__ __launch_bounds__(256) void tc_scatter_kernel(const TcPack P, const l
                                                          const unsigned* __restrict__ hist, const unsigned* __restrict__ start,
                                                          unsigned* __restrict__ rows, unsigned* __restrict__ smp) {
   __shared__ unsigned wcnt[4][256];
+  __shared__ unsigned first[256];                    // where this block's run of partition d starts in the bucket array
   const int t = blockIdx.y;
   const unsigned k = blockIdx.x;
   const TcTable tb = P.t[t];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const unsigned np = 1u << log_p;
+  {                                                  // (requested first: the ids' and these loads' latencies overlap)
+    const unsigned d = threadIdx.x < np ? threadIdx.x : 0u;
+    first[threadIdx.x] = start[static_cast<size_t>(t) * np + d] + hist[(static_cast<size_t>(t) * NB + k) * np + d];
+  }
   int id[8];
   unsigned dg[8], rank[8];
   tc_load_digits(tb, cid, B, k, log_p, id, dg);
@@ -202,15 +208,12 @@ __global__ __launch_bounds__(256) void tc_scatter_kernel(const TcPack P, const l
     }
   }
   __syncthreads();
-  const unsigned np = 1u << log_p;
-  const unsigned* h = hist + (static_cast<size_t>(t) * NB + k) * np;
-  const unsigned* st = start + static_cast<size_t>(t) * np;
   unsigned* rdst = rows + static_cast<size_t>(t) * B;
   unsigned* sdst = smp + static_cast<size_t>(t) * B;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     if (dg[s] == 255u) continue;
-    const unsigned pos = st[dg[s]] + h[dg[s]] + wcnt[wid][dg[s]] + rank[s];
+    const unsigned pos = first[dg[s]] + wcnt[wid][dg[s]] + rank[s];
     rdst[pos] = static_cast<unsigned>(id[s]);
     sdst[pos] = static_cast<unsigned>(static_cast<unsigned long long>(k) * kTcList + wid * 512 + s * 64 + lane);
   }
@@ -282,15 +285,21 @@ __global__ __launch_bounds__(256, 2) void tc_reduce_kernel(const TcPack P, const
     const unsigned n = (n_all - c0 < static_cast<unsigned>(kTcList)) ? n_all - c0 : static_cast<unsigned>(kTcList);
     const bool rmw = accumulate != 0 || c0 > 0;
     // ---- the fill: keys row' << 11 | position into registers, samples into LDS ----
-    unsigned key[8];
+    // (no branch in front of a load -- the compiler waits for a load inside the block that issues it: all sixteen of a
+    //  thread are requested, at a clamped position, before the first is looked at)
+    unsigned key[8], rv[8], sv[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const unsigned off = wid * 512 + s * 64 + lane;
-      key[s] = 0xFFFFFFFFu;
-      if (off < n) {
-        key[s] = ((rsrc[c0 + off] >> log_p) << kTcIdxBits) | off;
-        lb[off] = ssrc[c0 + off];
-      }
+      const unsigned at = c0 + (off < n ? off : 0u);
+      rv[s] = rsrc[at];
+      sv[s] = ssrc[at];
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const unsigned off = wid * 512 + s * 64 + lane;
+      key[s] = (off < n) ? (((rv[s] >> log_p) << kTcIdxBits) | off) : 0xFFFFFFFFu;
+      if (off < n) lb[off] = sv[s];
     }
     for (int q = 0; q < passes; ++q) ta_radix_pass(key, kTcIdxBits + 8 * q, wcnt, dstart, wtot, buf);
     // (ta_radix_pass ends on a barrier: buf holds the keys in sorted order, fillers behind the n real ones)
@@ -305,24 +314,25 @@ __global__ __launch_bounds__(256, 2) void tc_reduce_kernel(const TcPack P, const
       int nrun = 0;
       bool have_w = false;
       constexpr int U = 8;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const int ec = (lane_g * 4 < D) ? lane_g * 4 : 0;             // (a lane beyond the row reads its head: never stored)
       for (int i0 = 0; i0 < kTcChunk; i0 += U) {
         unsigned row[U];
         float gg[U];
-        F sr[U], wr[U];
-        // every load of the batch is requested before the first use (no branch in front of a load: a filler entry reads
-        // sample 0 / row 0 and is discarded)
+        v4f sr[U], wr[U];
+        // every load of the batch is requested before the first use: plain loads at clamped addresses, no branch and no
+        // arithmetic on a loaded value in between (the compiler waits for a load inside the block that issues it -- the
+        // first version of this loop ran load / wait / load / wait, one round trip per pair: 214 us per launch)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const unsigned k = e[i0 + u];
           const bool live = k != 0xFFFFFFFFu;
           row[u] = live ? (((k >> kTcIdxBits) << log_p) | part) : kTcNoRow;
-          const unsigned b = live ? lb[k & kTcIdxMask] : 0u;
+          const unsigned b = lb[live ? (k & kTcIdxMask) : 0u];
           gg[u] = g[b];
-          sr[u].zero();
-          sr[u].fma_from(ssum + static_cast<size_t>(b) * D, D, lane_g, 1.0f);
-          wr[u].zero();
-          wr[u].add_from_nt(tb.table + static_cast<size_t>(live ? row[u] : 0u) * tb.stride, D, lane_g);
-          if (!live) gg[u] = 0.f;
+          sr[u] = *reinterpret_cast<const v4f*>(ssum + static_cast<size_t>(b) * D + ec);
+          wr[u] = __builtin_nontemporal_load(
+              reinterpret_cast<const v4f*>(tb.table + static_cast<size_t>(live ? row[u] : 0u) * tb.stride + ec));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -340,10 +350,15 @@ __global__ __launch_bounds__(256, 2) void tc_reduce_kernel(const TcPack P, const
             cur = row[u];
             have_w = false;
           }
-          if (!have_w) { wcur = wr[u]; have_w = true; }
+          if (!have_w) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc.a[q] += gg[u] * sr[u].a[q];
-          cnt += gg[u];
+            for (int q = 0; q < 4; ++q) wcur.a[q] = wr[u][q];
+            have_w = true;
+          }
+          const float gu = (row[u] != kTcNoRow) ? gg[u] : 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc.a[q] += gu * sr[u][q];
+          cnt += gu;
         }
       }
       const int slot = (nrun == 0) ? 2 * c : 2 * c + 1;          // the run that is open at the end of the chunk

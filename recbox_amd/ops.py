@@ -1022,16 +1022,22 @@ class _FmFused(torch.autograd.Function):
             def compact(ws, nbytes):                       # on the current stream, in front of the forward kernel
                 return lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 1, _stream())
 
+            # RECBOX_AMD_FM_BLOCKSORT_AT=side: the small tables' per-block sorts ride on the side stream too (with tier C the
+            # side stream only carries one partition pass of ~20 us: both fit beside the forward kernel)
+            blocks_on_side = split and os.environ.get("RECBOX_AMD_FM_BLOCKSORT_AT", "after_fwd") == "side"
+
             def rest(ws, nbytes, st):
                 return _enqueue_sort((ea, la, lead.n, 1), keep, B, ws, nbytes, st,
-                                     lambda: lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 2, st))
+                                     lambda: lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None,
+                                                                    (2 | 4) if blocks_on_side else 2, st))
 
             if ws_bytes > 0 and pool is None:
                 if split:
                     ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=dev)
                     check(compact(ws, ws_bytes))
                     ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: rest(ws, ws_bytes, st), ws=ws)
-                    ctx.blocksort_pending = True
+                    ctx.blocksort_pending = not blocks_on_side
+                    ctx.blocksort_on_side = blocks_on_side
                 else:
                     ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: rest(ws, ws_bytes, st),
                                           first=lambda ws, st: first(ws, ws_bytes, st))
@@ -1054,7 +1060,8 @@ class _FmFused(torch.autograd.Function):
                         return rc
 
                     pool.early_sort(ctx, dev, ws_bytes, rezero, rest, pre=pre, batch=B)
-                    ctx.blocksort_pending = not early_blocks
+                    ctx.blocksort_pending = not early_blocks and not blocks_on_side
+                    ctx.blocksort_on_side = blocks_on_side
                 else:
                     pool.early_sort(ctx, dev, ws_bytes, rezero, rest, first=first)
             # the forward reads the tables only: back to descriptors without gradient pointers
@@ -1256,8 +1263,9 @@ class _FmFused(torch.autograd.Function):
             # partials that read them, they leave the side stream to the large tables' sort
             check(lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ctx.sort.ws), ctx.sort.ws_bytes, None, 4, _stream()))
             ctx.blocksort_pending = False
+        on_side = getattr(ctx, "blocksort_on_side", False)
         two_chains = grads_ready is not None and (ctx.sort.event_first is not None or pending_blocksort
-                                                  or getattr(ctx, "blocksort_done", False))
+                                                  or getattr(ctx, "blocksort_done", False) or on_side)
         if two_chains:
             ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes           # (no join: each tier waits for its own part below)
         elif ctx.sort is not None and same:
@@ -1284,8 +1292,8 @@ class _FmFused(torch.autograd.Function):
             for t in [dlogit, ssum] + [g for g in grads if g is not None]:
                 if t is not None:
                     t.record_stream(side)
-            if a_side:
-                cur.wait_event(ctx.sort.event)
+            if a_side or on_side:
+                cur.wait_event(ctx.sort.event)             # (the block sorts tier A reads ran on the side stream)
             elif ctx.sort.event_first is not None:
                 cur.wait_event(ctx.sort.event_first)
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (8 if a_side else 16) | store,
