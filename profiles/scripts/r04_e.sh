@@ -2,7 +2,7 @@
 # round 4: tier C second form (partition pass + bucket reduce): tests, bench on / off, timeline; DeepFM training test detail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-out=$GRAFT_REPO_ROOT/gpurun_out/r04f
+out=$GRAFT_REPO_ROOT/gpurun_out/r04g
 mkdir -p $out
 timeout 900 python -m pytest tests/test_gpu_ranking.py tests/test_gpu_optim.py tests/test_gpu_cabi_vs_c_oracle.py -q -m gpu -x > $out/tests_fm.log 2>&1
 echo "fm tests exit $?" | tee -a $out/summary.txt; tail -4 $out/tests_fm.log | tee -a $out/summary.txt

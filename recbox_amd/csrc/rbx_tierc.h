@@ -396,7 +396,10 @@ __global__ __launch_bounds__(256, 2) void tc_reduce_kernel(const TcPack P, const
       }
       tc_finish_row<G>(tb, r, acc, cnt, w, D, lane_g, rmw);
     }
-    __threadfence();                 // the rows stored by this fill are visible to the read-modify-writes of the next one
+    // The read-modify-writes of a later fill see the rows this fill stored: both come from this workgroup -- one CU, one
+    // L2 -- so the barrier (which waits for the workgroup's outstanding stores) orders them, and the later loads go around
+    // the L1 (tc_load_coherent).  NOT __threadfence(): a device-scope release makes every workgroup write its XCD's L2
+    // back -- 768 workgroups doing that were 185 of the first two forms' 200 us per launch (profiles/r04/INDEX.md).
     __syncthreads();
   }
 }

@@ -1123,6 +1123,17 @@ def test_deepfm_training_step_in_the_benchmarked_mode_vs_fp64_oracle():
     with torch.device("cuda"):
         model = DeepFM(dense + sparse, sparse, mlp)
     bench.init_weights_device(model, torch.device("cuda"), 0, 0, std=0.05)
+    # BatchNorm scales near their default 1 (not N(0, 0.05)): with |gamma| ~ 0.05 the pre-ReLU values crowd around zero and
+    # a handful of the 3.3 M units per layer land within fp32 rounding of the kink -- the fp64 reference then switches a
+    # unit the fp32 step does not, and ONE such unit moves a column's dgamma / dbeta by 1e-2 and everything below it by
+    # 1e-3 (observed, identically with the f32 and the split-bf16 GEMMs: profiles/r04/INDEX.md); that is the ReLU's
+    # discontinuity, not a kernel's error
+    gb = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_((1.0 + 0.1 * torch.randn(m.num_features, generator=gb)).cuda())
+                m.bias.copy_((0.1 * torch.randn(m.num_features, generator=gb)).cuda())
     ref = R.RefDeepFM(dense + sparse, sparse, mlp).double().train()
     ref.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()
                          for k, v in model.state_dict().items()})
