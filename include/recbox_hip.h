@@ -293,6 +293,12 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
  * sorted ids and refuse a call with tier C tables), 1 on, a negative value only reads; returns the previous setting.
  * Change it between steps only: rbx_fm_sort / _bwd / _rezero of one step must see the same setting. */
 int rbx_fm_tier_c(int32_t enable);
+/* With persistent gradient buffers the rows a backward stored have to be cleared before the next one (rbx_fm_rezero).  When
+ * every sorted table of the call is on tier C (returns 1) the partition pass of the NEXT step can do it while it overwrites
+ * the bucket arrays that name those rows: pass phases | 8 to rbx_fm_sort_phases INSTEAD of calling rbx_fm_rezero -- same
+ * batch size, same workspace, and a backward has run on it since the last clear.  The re-zero launch then leaves the
+ * step's critical path (it ran in front of the forward kernel; the pass runs beside it). */
+int rbx_fm_rezero_fusable(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch);
 int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                   void* d_workspace, size_t workspace_bytes, void* stream);
 /* Two lookups over the SAME id tensors with the same table layout (the embedding tables of FeatureEmbedding and the dim-1

@@ -2,7 +2,7 @@
 # round 4: tier C second form (partition pass + bucket reduce): tests, bench on / off, timeline; DeepFM training test detail
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-out=$GRAFT_REPO_ROOT/gpurun_out/r04g
+out=$GRAFT_REPO_ROOT/gpurun_out/r04h
 mkdir -p $out
 timeout 900 python -m pytest tests/test_gpu_ranking.py tests/test_gpu_optim.py tests/test_gpu_cabi_vs_c_oracle.py -q -m gpu -x > $out/tests_fm.log 2>&1
 echo "fm tests exit $?" | tee -a $out/summary.txt; tail -4 $out/tests_fm.log | tee -a $out/summary.txt
@@ -15,7 +15,7 @@ timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-b
 RBX_FM_TIER_C=0 timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline > $out/bench_fm_tierc_off.json 2>/dev/null; ms fm_tierc_off
 timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline --dist zipf > $out/bench_fm_zipf.json 2>/dev/null; ms fm_zipf
 RBX_FM_TIER_C=0 timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline --dist zipf > $out/bench_fm_zipf_tierc_off.json 2>/dev/null; ms fm_zipf_tierc_off
-RECBOX_AMD_FM_TWO_CHAINS=0 timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline > $out/bench_fm_one_chain.json 2>/dev/null; ms fm_one_chain
+RECBOX_AMD_FM_BLOCKSORT_AT=side RECBOX_AMD_FM_REZERO_ON=main timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline > $out/bench_fm_blocksort_side_rezero_main.json 2>/dev/null; ms fm_blocksort_side_rezero_main
 RECBOX_AMD_FM_BLOCKSORT_AT=side timeout 300 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline > $out/bench_fm_blocksort_side.json 2>/dev/null; ms fm_blocksort_side
 prof() { # name, bench args, anchor kernel, occurrence
   rm -rf $out/prof
@@ -26,4 +26,4 @@ prof() { # name, bench args, anchor kernel, occurrence
   rm -rf $out/prof
 }
 prof fm "--steps 20 --warmup 5" compact_ids 30
-prof fm_zipf "--steps 20 --warmup 5 --dist zipf" compact_ids 30
+BS=side; (export RECBOX_AMD_FM_BLOCKSORT_AT=side; prof fm_blocksort_side "--steps 20 --warmup 5" compact_ids 30)

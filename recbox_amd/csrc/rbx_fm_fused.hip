@@ -920,6 +920,14 @@ static void fm_bind_cid(FmFull* f, char* ws, int64_t B) {
 
 }  // namespace rbx
 
+extern "C" int rbx_fm_rezero_fusable(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch) {
+  using namespace rbx;
+  if (batch <= 0) return 0;
+  FmFull f;
+  if (fm_full_plan(emb, lr, n_fields, batch, &f) != RBX_OK) return 0;
+  return (f.tc.n_tab > 0 && f.p.n_lookups == 0) ? 1 : 0;
+}
+
 extern "C" int rbx_fm_tier_c(int32_t enable) {
   using namespace rbx;
   const int was = fm_tier_c_on() ? 1 : 0;
@@ -1008,8 +1016,12 @@ extern "C" int rbx_fm_sort_phases(const rbx_field_t* emb, const rbx_field_t* lr,
     rc = run_sort(f.p, ws, f.ta.n_cid == 0 ? d_status : nullptr, s);
     if (rc != RBX_OK) return rc;
   }
+  if ((phases & 8) && (f.p.n_lookups > 0 || f.tc.n_tab == 0))
+    return fail(RBX_ERR_INVALID, "fm_sort: phases bit 3 (clear the previous step's rows inside the partition pass) needs every "
+                                 "sorted table on tier C (rbx_fm_rezero_fusable)");
   if ((phases & 2) && f.tc.n_tab > 0) {         // tier C: one partition pass (count, scan, scatter) into the bucket arrays
-    rc = tc_launch_partition(f.tc, batch, reinterpret_cast<const int*>(ws + f.off_ta + f.ta.off_cid), ws + f.off_tc, s);
+    rc = tc_launch_partition(f.tc, batch, reinterpret_cast<const int*>(ws + f.off_ta + f.ta.off_cid), ws + f.off_tc,
+                             (phases & 8) ? 1 : 0, s);
     if (rc != RBX_OK) return rc;
   }
   return RBX_OK;

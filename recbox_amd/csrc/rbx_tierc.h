@@ -71,8 +71,8 @@ struct TcPlan {
   unsigned NB = 0;           // blocks of 2048 samples
   int D = 1;
   // region layout (bytes, relative): hist u32 [n_tab][NB][P] (after tc_scan: the start of every (block, partition) run),
-  // start u32 [n_tab][P], count u32 [n_tab][P], rows u32 [n_tab][B], smp u32 [n_tab][B]
-  size_t off_hist = 0, off_start = 0, off_count = 0, off_rows = 0, off_smp = 0, bytes = 0;
+  // start u32 [n_tab][P], count u32 [n_tab][P], prev u32 [n_tab], rows u32 [n_tab][B], smp u32 [n_tab][B]
+  size_t off_hist = 0, off_start = 0, off_count = 0, off_prev = 0, off_rows = 0, off_smp = 0, bytes = 0;
 };
 
 static inline void tc_layout(TcPlan* t, int64_t B) {
@@ -81,6 +81,7 @@ static inline void tc_layout(TcPlan* t, int64_t B) {
   t->off_hist = o; o += ta_align(static_cast<size_t>(t->n_tab) * t->NB * P * 4);
   t->off_start = o; o += ta_align(static_cast<size_t>(t->n_tab) * P * 4);
   t->off_count = o; o += ta_align(static_cast<size_t>(t->n_tab) * P * 4);
+  t->off_prev = o; o += ta_align(static_cast<size_t>(t->n_tab) * 4);      // pairs the PREVIOUS partition pass placed, per table
   t->off_rows = o; o += ta_align(static_cast<size_t>(t->n_tab) * static_cast<size_t>(B) * 4);
   t->off_smp = o; o += ta_align(static_cast<size_t>(t->n_tab) * static_cast<size_t>(B) * 4);
   t->bytes = t->n_tab ? o : 0;
@@ -149,11 +150,15 @@ __global__ __launch_bounds__(256) void tc_count_kernel(const TcPack P, const lon
 // one workgroup per table: hist[t][k][p] -> where the run of (block k, partition p) starts inside ITS PARTITION's bucket
 // (blocks in order); start[t][p] = first pair of partition p inside the table's bucket array, count[t][p]
 __global__ __launch_bounds__(256) void tc_scan_kernel(const int log_p, const unsigned NB, unsigned* __restrict__ hist,
-                                                      unsigned* __restrict__ start, unsigned* __restrict__ count) {
+                                                      unsigned* __restrict__ start, unsigned* __restrict__ count,
+                                                      unsigned* __restrict__ prev, const int keep_prev) {
   __shared__ unsigned tot[256];
   const int t = blockIdx.x;
   const unsigned np = 1u << log_p;
   const unsigned p = threadIdx.x;
+  if (threadIdx.x == 0)      // how many pairs the previous pass placed (tc_scatter clears their rows while it overwrites them)
+    prev[t] = keep_prev ? start[static_cast<size_t>(t) * np + np - 1] + count[static_cast<size_t>(t) * np + np - 1] : 0u;
+  __syncthreads();
   unsigned* h = hist + static_cast<size_t>(t) * NB * np;
   unsigned run = 0;
   if (p < np) {
@@ -181,7 +186,9 @@ __global__ __launch_bounds__(256) void tc_scan_kernel(const int log_p, const uns
 __global__ __launch_bounds__(256) void tc_scatter_kernel(const TcPack P, const long long B, const int log_p,
                                                          const unsigned NB, const int* __restrict__ cid,
                                                          const unsigned* __restrict__ hist, const unsigned* __restrict__ start,
-                                                         unsigned* __restrict__ rows, unsigned* __restrict__ smp) {
+                                                         const unsigned* __restrict__ count, const unsigned* __restrict__ prev,
+                                                         unsigned* __restrict__ rows, unsigned* __restrict__ smp,
+                                                         const int clear_prev, const int D) {
   __shared__ unsigned wcnt[4][256];
   __shared__ unsigned first[256];                    // where this block's run of partition d starts in the bucket array
   const int t = blockIdx.y;
@@ -210,12 +217,40 @@ __global__ __launch_bounds__(256) void tc_scatter_kernel(const TcPack P, const l
   __syncthreads();
   unsigned* rdst = rows + static_cast<size_t>(t) * B;
   unsigned* sdst = smp + static_cast<size_t>(t) * B;
+  // clear_prev (persistent gradient buffers): the bucket array still names the rows the PREVIOUS backward stored.  Every
+  // position this pass overwrites is read first and that row cleared here -- beside the forward kernel, instead of a
+  // re-zero launch of its own at the end of the step's critical path; positions the previous pass filled and this one
+  // does not reach (it placed fewer pairs) are cleared by the table's first block.
+  const unsigned n_prev = clear_prev ? prev[t] : 0u;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  unsigned pos[8], old[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    if (dg[s] == 255u) continue;
-    const unsigned pos = first[dg[s]] + wcnt[wid][dg[s]] + rank[s];
-    rdst[pos] = static_cast<unsigned>(id[s]);
-    sdst[pos] = static_cast<unsigned>(static_cast<unsigned long long>(k) * kTcList + wid * 512 + s * 64 + lane);
+    pos[s] = (dg[s] == 255u) ? 0xFFFFFFFFu : first[dg[s]] + wcnt[wid][dg[s]] + rank[s];
+    old[s] = (pos[s] < n_prev) ? rdst[pos[s]] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (old[s] != 0xFFFFFFFFu) {
+      float4* g4 = reinterpret_cast<float4*>(tb.grad + static_cast<size_t>(old[s]) * D);
+      for (int q = 0; q < D / 4; ++q) g4[q] = z;
+      if (tb.grad2 != nullptr) tb.grad2[old[s]] = 0.f;
+    }
+  }
+  if (clear_prev && k == 0) {
+    const unsigned n_now = start[static_cast<size_t>(t) * np + np - 1] + count[static_cast<size_t>(t) * np + np - 1];
+    for (unsigned i = n_now + threadIdx.x; i < n_prev; i += 256) {
+      const unsigned r = rdst[i];
+      float4* g4 = reinterpret_cast<float4*>(tb.grad + static_cast<size_t>(r) * D);
+      for (int q = 0; q < D / 4; ++q) g4[q] = z;
+      if (tb.grad2 != nullptr) tb.grad2[r] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (pos[s] == 0xFFFFFFFFu) continue;
+    rdst[pos[s]] = static_cast<unsigned>(id[s]);
+    sdst[pos[s]] = static_cast<unsigned>(static_cast<unsigned long long>(k) * kTcList + wid * 512 + s * 64 + lane);
   }
 }
 
@@ -426,16 +461,21 @@ __global__ __launch_bounds__(256) void tc_rezero_kernel(const TcPack P, const lo
 }
 
 // ---- launches ---------------------------------------------------------------------------------------------------------
-static inline int tc_launch_partition(const TcPlan& t, int64_t B, const int* cid, char* region, hipStream_t s) {
+static inline int tc_launch_partition(const TcPlan& t, int64_t B, const int* cid, char* region, int clear_prev,
+                                      hipStream_t s) {
   if (t.n_tab == 0) return RBX_OK;
   unsigned* hist = reinterpret_cast<unsigned*>(region + t.off_hist);
   hipLaunchKernelGGL(tc_count_kernel, dim3(t.NB, t.n_tab), dim3(256), 0, s, t.tab, static_cast<long long>(B), t.log_p, t.NB,
                      cid, hist);
   hipLaunchKernelGGL(tc_scan_kernel, dim3(t.n_tab), dim3(256), 0, s, t.log_p, t.NB, hist,
-                     reinterpret_cast<unsigned*>(region + t.off_start), reinterpret_cast<unsigned*>(region + t.off_count));
+                     reinterpret_cast<unsigned*>(region + t.off_start), reinterpret_cast<unsigned*>(region + t.off_count),
+                     reinterpret_cast<unsigned*>(region + t.off_prev), clear_prev);
   hipLaunchKernelGGL(tc_scatter_kernel, dim3(t.NB, t.n_tab), dim3(256), 0, s, t.tab, static_cast<long long>(B), t.log_p,
                      t.NB, cid, hist, reinterpret_cast<const unsigned*>(region + t.off_start),
-                     reinterpret_cast<unsigned*>(region + t.off_rows), reinterpret_cast<unsigned*>(region + t.off_smp));
+                     reinterpret_cast<const unsigned*>(region + t.off_count),
+                     reinterpret_cast<const unsigned*>(region + t.off_prev),
+                     reinterpret_cast<unsigned*>(region + t.off_rows), reinterpret_cast<unsigned*>(region + t.off_smp),
+                     clear_prev, t.D);
   return check_launch("tier-C partition kernels");
 }
 

@@ -844,7 +844,7 @@ class _GradPool(object):
             return None
         return pool
 
-    def early_sort(self, ctx, device, ws_bytes, rezero, sort, first=None, pre=None, batch=None):
+    def early_sort(self, ctx, device, ws_bytes, rezero, sort, first=None, pre=None, batch=None, fusable=None):
         """Launch, on the side stream: ``rezero(stream)`` -- clear the rows the previous backward stored, its sorted ids
         are still in ``self.ws`` -- when there are any, then ``sort(ws, ws_bytes, stream)`` of this batch's ids over
         them.  Both return a C-ABI code.  (Clearing on a third stream beside the sort was measured slower -- 0.344 vs
@@ -859,8 +859,18 @@ class _GradPool(object):
         # default: beside the forward its 0.5 M random row stores slowed that kernel from 43 to 55 us (its rate is what
         # bench.py reports against the roofline) for a step only 1.3 % shorter (0.2355 vs 0.2386 ms; profiles/r03);
         # RECBOX_AMD_FM_REZERO_ON=side puts it back beside the forward.
+        where = os.environ.get("RECBOX_AMD_FM_REZERO_ON", "fused")
+        self.fuse_rezero = False
+        if (dirty and pre is not None and dirty == batch and self.ws_bytes >= ws_bytes and where == "fused"
+                and fusable is not None and fusable()):
+            # every sorted table of the call is on tier C: its partition pass (side stream, beside the forward kernel) clears
+            # the rows the previous backward stored while it overwrites the bucket arrays that name them -- no re-zero
+            # launch of its own (15 us + a cross-queue wait at the head of the step's critical path)
+            self.fuse_rezero = True
+            self.dirty_batch = 0
+            dirty = 0
         if dirty and (self.ws_bytes < ws_bytes or (pre is not None and dirty != batch)
-                      or (pre is not None and os.environ.get("RECBOX_AMD_FM_REZERO_ON", "main") == "main")):
+                      or (pre is not None and where in ("main", "fused"))):
             check(rezero(_stream()))
             dirty = 0
         ws = self.workspace(ws_bytes)
@@ -1027,9 +1037,24 @@ class _FmFused(torch.autograd.Function):
             blocks_on_side = split and os.environ.get("RECBOX_AMD_FM_BLOCKSORT_AT", "after_fwd") == "side"
 
             def rest(ws, nbytes, st):
+                which = (2 | 4) if blocks_on_side else 2
+                if pool is not None and getattr(pool, "fuse_rezero", False):
+                    # the partition pass also CLEARS the rows the previous backward stored: it needs the real gradient
+                    # pointers (the descriptors carry the parameters themselves as "has a gradient" placeholders)
+                    pool.fuse_rezero = False
+                    grads = pool.bind_views(list(emb_params) + list(lr_params))
+                    if emb_plan is not None:
+                        emb_plan.bind_params(emb_params, grads[:len(emb_params)])
+                    if lr_plan is not None:
+                        lr_plan.bind_params(lr_params, grads[len(emb_params):])
+                    rc = lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, which | 8, st)
+                    if emb_plan is not None:
+                        emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
+                    if lr_plan is not None:
+                        lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
+                    return rc
                 return _enqueue_sort((ea, la, lead.n, 1), keep, B, ws, nbytes, st,
-                                     lambda: lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None,
-                                                                    (2 | 4) if blocks_on_side else 2, st))
+                                     lambda: lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, which, st))
 
             if ws_bytes > 0 and pool is None:
                 if split:
@@ -1059,7 +1084,8 @@ class _FmFused(torch.autograd.Function):
                             rc = lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 4, _stream())
                         return rc
 
-                    pool.early_sort(ctx, dev, ws_bytes, rezero, rest, pre=pre, batch=B)
+                    pool.early_sort(ctx, dev, ws_bytes, rezero, rest, pre=pre, batch=B,
+                                    fusable=lambda: bool(lib.rbx_fm_rezero_fusable(ea, la, lead.n, B)))
                     ctx.blocksort_pending = not early_blocks and not blocks_on_side
                     ctx.blocksort_on_side = blocks_on_side
                 else:

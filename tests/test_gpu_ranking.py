@@ -328,6 +328,34 @@ def test_fm_tier_c_equals_the_sorted_path(B, mode):
         ops.config.check_ids = old_check
 
 
+def test_tier_c_partition_pass_clears_the_previous_steps_rows():
+    """Persistent gradient buffers with every sorted table on tier C: no re-zero launch -- the partition pass of the next step
+    reads the row each bucket position names before it overwrites it and clears that row (rbx_fm_sort_phases, phases | 8).
+    Steps of ONE batch size whose numbers of real lookups differ (the second batch is 90 % padding: the previous pass
+    placed more pairs than this one reaches; then back) == fresh zero-filled gradients, bit for bit."""
+    from recbox_amd import ops
+    vocabs = [37, 5000, 70000, 1000000, 4099]
+    fm, fresh, reuse = _fm_pair(48, vocabs)
+    old = ops.config.reuse_grad_buffers
+    B = 3000
+    try:
+        g = torch.Generator().manual_seed(3)
+        for k in range(5):
+            _, X, y = _criteo_like(B, vocabs, 16, seed=300 + k, zipf=bool(k % 2))
+            if k in (1, 3):
+                for i in range(len(vocabs)):
+                    X["C%d" % (i + 1)] = X["C%d" % (i + 1)] * (torch.rand(B, generator=g) < 0.1)
+            Xc, yc = _cuda(X), y.cuda()
+            ops.config.reuse_grad_buffers = False
+            _bce_step(fresh, Xc, yc)
+            ops.config.reuse_grad_buffers = True
+            _bce_step(reuse, Xc, yc)
+            for (n, p0), (_, p1) in zip(fresh.named_parameters(), reuse.named_parameters()):
+                assert torch.equal(p1.grad, p0.grad), "step %d: %s" % (k, n)
+    finally:
+        ops.config.reuse_grad_buffers = old
+
+
 def test_ops_backward_equals_loss_backward_bit_for_bit():
     """``ops.backward(loss)`` hands autograd the persistent constant 1 as the loss's gradient (no ones_like fill, and the
     fused sigmoid + BCE returns dL/dlogit unscaled): the same gradients as ``loss.backward()``, bit for bit."""
