@@ -288,9 +288,12 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
 /* Round 4: the fused FM backward has a third tier (csrc/rbx_tierc.h): a table of ONE one-id-per-sample field that is too
  * large for tier A (rows > 4096, < 2^21, dim a multiple of 4 up to 64) is reduced WITHOUT a global sort -- a workgroup per
  * (table, hash partition) scans the compact id column, sorts its ~1024 pairs in LDS and writes its rows; rbx_fm_rezero
- * clears the rows named by the workgroups' row lists.  Same gradients as the sorted path up to summation order,
- * bit-identical from run to run.  rbx_fm_tier_c(0) switches the tier off for the process (the sparse-row updates walk
- * sorted ids and refuse a call with tier C tables), 1 on, a negative value only reads; returns the previous setting.
+ * clears the rows named by the bucket arrays of the partition pass.  Same gradients as the sorted path up to summation
+ * order, bit-identical from run to run.  OFF by default (RBX_FM_TIER_C=1 / rbx_fm_tier_c(1) switch it on): measured at
+ * the Criteo shape it is a draw -- 12 kernels per step instead of 23, the same random-line traffic, a slower forward
+ * kernel beside its partition pass (csrc/rbx_fm_fused.hip, profiles/r04/INDEX.md).  rbx_fm_tier_c(0) switches the tier
+ * off (the sparse-row updates walk sorted ids and refuse a call with tier C tables), a negative value only reads;
+ * returns the previous setting.
  * Change it between steps only: rbx_fm_sort / _bwd / _rezero of one step must see the same setting. */
 int rbx_fm_tier_c(int32_t enable);
 /* With persistent gradient buffers the rows a backward stored have to be cleared before the next one (rbx_fm_rezero).  When

@@ -621,14 +621,19 @@ static int fm_tier_a_max_vocab() {      // RBX_FM_TIER_A=0: every table through 
   return v;
 }
 
-// Tier C (rbx_tierc.h): the remaining tables of one-id-per-sample fields without a global sort.  A process-wide switch,
-// because every entry point derives the SAME plan from the descriptors alone: RBX_FM_TIER_C=0 / rbx_fm_tier_c(0) send
-// those tables through the sorted path again (A/B measurements; the sparse-row optimisers, which walk sorted ids).
+// Tier C (rbx_tierc.h): the remaining tables of one-id-per-sample fields without a global multi-pass sort.  A process-wide
+// switch, because every entry point derives the SAME plan from the descriptors alone (RBX_FM_TIER_C / rbx_fm_tier_c).
+// OFF by default: built, parity-tested (bit-identical on repeat, == the sorted path to 1e-6) and measured at the Criteo
+// shape (profiles/r04/INDEX.md) -- the step has 12-13 kernels instead of 23 and runs at 0.230-0.238 ms against 0.237-0.239
+// with the tier off: within run-to-run noise, because both forms move the same random 64-byte lines (w_r read, dW store,
+// dLR store, two clears: five line operations per pair, ~85 us of the ~47 G lines/s this GPU delivers) and the partition
+// pass beside the forward kernel slows THAT kernel from 42 to 47-52 us (roofline.frac 0.40 -> 0.32-0.35); with
+// log-uniform ids it is slower (0.31-0.32 vs 0.27 ms: a hot id's bucket is several 2048-pair fills of one workgroup).
 static int g_tier_c = -1;
 static bool fm_tier_c_on() {
   if (g_tier_c < 0) {
     const char* e = getenv("RBX_FM_TIER_C");
-    g_tier_c = (e != nullptr && e[0] == '0') ? 0 : 1;
+    g_tier_c = (e != nullptr && e[0] == '1') ? 1 : 0;
   }
   return g_tier_c != 0;
 }

@@ -859,13 +859,15 @@ class _GradPool(object):
         # default: beside the forward its 0.5 M random row stores slowed that kernel from 43 to 55 us (its rate is what
         # bench.py reports against the roofline) for a step only 1.3 % shorter (0.2355 vs 0.2386 ms; profiles/r03);
         # RECBOX_AMD_FM_REZERO_ON=side puts it back beside the forward.
-        where = os.environ.get("RECBOX_AMD_FM_REZERO_ON", "fused")
+        where = os.environ.get("RECBOX_AMD_FM_REZERO_ON", "main")      # "fused": measured slower, see below
         self.fuse_rezero = False
         if (dirty and pre is not None and dirty == batch and self.ws_bytes >= ws_bytes and where == "fused"
                 and fusable is not None and fusable()):
             # every sorted table of the call is on tier C: its partition pass (side stream, beside the forward kernel) clears
             # the rows the previous backward stored while it overwrites the bucket arrays that name them -- no re-zero
-            # launch of its own (15 us + a cross-queue wait at the head of the step's critical path)
+            # launch of its own.  Opt-in (RECBOX_AMD_FM_REZERO_ON=fused): measured 0.238-0.283 ms per step against
+            # 0.235 with the launch in front of the forward -- the 0.8 M row stores beside the forward kernel take it from
+            # 47 to 52-74 us (profiles/r04/INDEX.md)
             self.fuse_rezero = True
             self.dirty_batch = 0
             dirty = 0

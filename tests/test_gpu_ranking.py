@@ -328,19 +328,26 @@ def test_fm_tier_c_equals_the_sorted_path(B, mode):
         ops.config.check_ids = old_check
 
 
-def test_tier_c_partition_pass_clears_the_previous_steps_rows():
-    """Persistent gradient buffers with every sorted table on tier C: no re-zero launch -- the partition pass of the next step
-    reads the row each bucket position names before it overwrites it and clears that row (rbx_fm_sort_phases, phases | 8).
-    Steps of ONE batch size whose numbers of real lookups differ (the second batch is 90 % padding: the previous pass
-    placed more pairs than this one reaches; then back) == fresh zero-filled gradients, bit for bit."""
+@pytest.mark.parametrize("where", ["main", "fused"])
+def test_tier_c_clears_the_previous_steps_rows(where):
+    """Persistent gradient buffers with the sorted tables on tier C (rbx_fm_tier_c(1)): the rows the previous backward
+    stored are cleared from the bucket arrays of its partition pass -- by tc_rezero_kernel in front of the forward
+    ("main", rbx_fm_rezero) or by the NEXT partition pass itself, which reads the row each bucket position names before it
+    overwrites it ("fused": rbx_fm_sort_phases, phases | 8).  Steps of ONE batch size whose numbers of real lookups differ
+    (the second batch is 90 % padding: the previous pass placed more pairs than this one reaches; then back), then other
+    batch sizes == fresh zero-filled gradients, bit for bit."""
+    import os
     from recbox_amd import ops
+    from recbox_amd._lib import lib
     vocabs = [37, 5000, 70000, 1000000, 4099]
     fm, fresh, reuse = _fm_pair(48, vocabs)
     old = ops.config.reuse_grad_buffers
-    B = 3000
+    was = lib.rbx_fm_tier_c(1)
+    env = os.environ.get("RECBOX_AMD_FM_REZERO_ON")
+    os.environ["RECBOX_AMD_FM_REZERO_ON"] = where
     try:
         g = torch.Generator().manual_seed(3)
-        for k in range(5):
+        for k, B in enumerate([3000, 3000, 3000, 3000, 3000, 700, 5000, 5000]):
             _, X, y = _criteo_like(B, vocabs, 16, seed=300 + k, zipf=bool(k % 2))
             if k in (1, 3):
                 for i in range(len(vocabs)):
@@ -354,6 +361,11 @@ def test_tier_c_partition_pass_clears_the_previous_steps_rows():
                 assert torch.equal(p1.grad, p0.grad), "step %d: %s" % (k, n)
     finally:
         ops.config.reuse_grad_buffers = old
+        lib.rbx_fm_tier_c(was)
+        if env is None:
+            os.environ.pop("RECBOX_AMD_FM_REZERO_ON", None)
+        else:
+            os.environ["RECBOX_AMD_FM_REZERO_ON"] = env
 
 
 def test_ops_backward_equals_loss_backward_bit_for_bit():

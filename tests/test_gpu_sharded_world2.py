@@ -209,10 +209,13 @@ def test_direct_rccl_exchange_equals_torch_distributed():
     assert _spawn(_rccl_worker, 1) == {0: "ok"}
 
 
-def test_bench_script_runs_its_two_rank_path():
-    """bench.py launched as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with both
-    ranks on this box's single GPU over gloo (RECBOX_BENCH_ONE_GPU=1): the N>1 control flow of the script -- sharded
-    model, piecewise-graphed step, overflow check, barrier + max-over-ranks timing, one JSON line from rank 0."""
+@pytest.mark.parametrize("how", ["driver", "bare_shell_strong"])
+def test_bench_script_runs_its_two_rank_path(how):
+    """bench.py with N = 2, both ranks on this box's single GPU over gloo (RECBOX_BENCH_ONE_GPU=1): the N>1 control flow of
+    the script -- sharded model, piecewise-graphed step, overflow check, barrier + max-over-ranks timing, one JSON line
+    from rank 0.  "driver": launched as the driver launches it (torch.distributed.run, one process per rank), weak
+    scaling.  "bare_shell_strong": ``python bench.py --gpus 2 --scaling strong`` from a bare shell -- the script starts its
+    own ranks, and the global batch is split B / N per GPU; ``n_gpus`` is the number of ranks that ran."""
     import json
     import os
     import subprocess
@@ -220,17 +223,30 @@ def test_bench_script_runs_its_two_rank_path():
     from test_distributed_gloo import _free_port
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RECBOX_BENCH_ONE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--batch", "8192"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if how == "driver":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+               "--warmup", "1", "--batch", "8192"]
+    else:
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling",
+               "strong", "--global-batch", "16384"]
     out = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
-    assert rec["value"] > 0 and rec["config"]["global_batch"] == 2 * 8192
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["scaling"] == ("weak" if how == "driver" else "strong")
+    assert rec["value"] > 0 and rec["config"]["global_batch"] == 2 * 8192 and rec["config"]["batch_per_gpu"] == 8192
     assert "row-sharded" in rec["config"]["parallelism"] and "overflow=False" in rec["config"]["exchange"]
+    # a launch whose WORLD_SIZE disagrees with --gpus is refused instead of printing a line for another N
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                         cwd=root, env=dict(env, WORLD_SIZE="2", RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=120) if how == "driver" else None
+    if bad is not None:
+        assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
 
 
 # ---- BASELINE.json configs 3 and 4 in their multi-GPU form: ranks sharing ONE GPU over gloo ------------------------------
