@@ -384,6 +384,26 @@ def run_model_config(args, rank, world, dev):
         # the shard's dense gradient: one buffer cleared by the previous step's rows instead of a fresh zero-filled
         # [rows, D] tensor per step (5 GB at cfg 3 in a world of one, 640 MB per rank at W = 8)
         shard_store.local_ops.persistent(shard_store.weight)
+    if sharded and shard_store is not None:
+        # The padded exchange has `capacity_factor` x (a perfectly balanced share) slots per peer; a lookup that finds none
+        # raises the store's overflow flag.  Every resident batch is routed once before anything is captured: if any rank
+        # overflowed, the factor of every store doubles (the wire sizes derive from it at each call) and the probe repeats.
+        stores = list(model.embedding.stores.values())
+        for _ in range(4):
+            with torch.no_grad():
+                for b in batches:
+                    model(b)
+            flag = torch.stack([st.overflow.float().reshape(()) for st in stores]).max().reshape(1).clone()
+            if world > 1:
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            for st in stores:
+                st.overflow.zero_()
+            if float(flag.item()) == 0:
+                break
+            factor *= 2
+            for st in stores:
+                st.capacity_factor = float(factor)
+        note["capacity_factor"] = factor
     x = dict((k, v.clone()) for k, v in batches[0].items())
 
     def refill(i):

@@ -1511,3 +1511,44 @@ def test_batch_norm_with_fused_prelu_vs_torch(rows, cols, per_column):
     want.sum().backward()
     for (n, p), (_, q) in zip(tower.mlp.named_parameters(), twin.named_parameters()):
         assert_close(p.grad, q.grad, TOL * max(1.0, float(q.grad.abs().max())), "MLP(prelu) grad " + n)
+
+
+def test_hip_path_vs_second_oracle_recbole_layers():
+    """The HIP path against the SECOND oracle (RecBole's FM and attention layers, fixture from the live reference:
+    oracle/gen_golden_recbole.py; third_party/recbole/model/layers.py:127-205,380-470): the FM term and vector through
+    rbx_interaction_*, and the attention layer composed from the path's own ops -- rbx_linear for the four projections,
+    rbx_attn (causal, 2 heads of 16) and rbx_layernorm -- outputs and every gradient at 1e-4."""
+    from recbox_amd import ops
+    fx = Fixture("recbole_layers")
+    fm = fx.tensors("fm", "cuda")
+    table = fm["p.table"].clone().requires_grad_()
+    e = table[fm["in.ids"] + fm["in.offsets"].unsqueeze(0)]
+    out = ops.interaction(e, "product_sum")
+    assert_close(out, fm["out.sum"], TOL, "FM term")
+    assert_close(ops.interaction(e.detach(), "bi_interaction"), fm["out.vec"], TOL, "FM vector")
+    (out * fm["in.R"]).sum().backward()
+    assert_close(table.grad, fm["g.table"], TOL, "FM table gradient")
+    m = fx.tensors("mha", "cuda")
+    heads = int(m["in.heads"])
+    x = m["in.x"].clone().requires_grad_()
+    p = dict((k[2:], v.clone().requires_grad_()) for k, v in m.items() if k.startswith("p."))
+    B, L, H = x.shape
+    hd = H // heads
+
+    def split(t):
+        return t.view(B, L, heads, hd).transpose(1, 2).reshape(B * heads, L, hd)
+    q = split(ops.linear(x, p["query.weight"], p["query.bias"]))
+    k = split(ops.linear(x, p["key.weight"], p["key.bias"]))
+    v = split(ops.linear(x, p["value.weight"], p["value.bias"]))
+    o = ops.attention(q, k, v, scale=1.0 / hd ** 0.5, causal=True)
+    o = o[0] if isinstance(o, tuple) else o
+    ctx = o.view(B, heads, L, hd).transpose(1, 2).reshape(B, L, H)
+    ln = torch.nn.LayerNorm(H, eps=1e-12).cuda()
+    ln.weight, ln.bias = torch.nn.Parameter(p["LayerNorm.weight"].detach().clone()), torch.nn.Parameter(p["LayerNorm.bias"].detach().clone())
+    y = ops.layer_norm(ops.linear(ctx, p["dense.weight"], p["dense.bias"]) + x, ln)
+    assert_close(y, m["out.y"], TOL, "attention layer output")
+    (y * m["in.R"]).sum().backward()
+    assert_close(x.grad, m["g.x"], TOL, "attention layer dx")
+    for name, t in p.items():
+        got = {"LayerNorm.weight": ln.weight.grad, "LayerNorm.bias": ln.bias.grad}.get(name, t.grad)
+        assert_close(got, m["g." + name], TOL, "attention layer grad " + name)

@@ -375,3 +375,45 @@ def test_attention_and_losses():
     assert_close(l, fx["out"]["sigmoid_ce"], TOL)
     l.backward()
     assert_close(yp.grad, fx["g"]["sigmoid_ce"], TOL)
+
+
+def test_second_oracle_recbole_fm_and_attention_layers():
+    """the oracle against a SECOND statement of the same arithmetic -- RecBole's ``FMEmbedding`` +
+    ``BaseFactorizationMachine`` and the ``MultiHeadAttention`` layer of its ``TransformerEncoder``
+    (third_party/recbole/model/layers.py:127-205,380-470; fixture: oracle/gen_golden_recbole.py from the live reference).
+    The FM term of both of the oracle's interaction functions, and a plain-torch restatement of the attention layer in
+    the op sequence the HIP path composes (projections, causal softmax attention per head, output projection, residual,
+    LayerNorm eps 1e-12), equal the fixture: outputs and every gradient."""
+    import torch
+    from oracle import torch_ref as R
+    fx = Fixture("recbole_layers")
+    fm = fx.tensors("fm")
+    table = fm["p.table"].clone().requires_grad_()
+    e = table[fm["in.ids"] + fm["in.offsets"].unsqueeze(0)]
+    for got in (R.inner_product_interaction(e, "product_sum"), R.rechub_fm(e, True)):
+        assert_close(got, fm["out.sum"], 1e-5, "FM term")
+    assert_close(R.inner_product_interaction(e, "bi_interaction"), fm["out.vec"], 1e-5, "FM vector")
+    (R.rechub_fm(e, True) * fm["in.R"]).sum().backward()
+    assert_close(table.grad, fm["g.table"], 1e-5, "FM table gradient")
+    m = fx.tensors("mha")
+    heads = int(m["in.heads"])
+    x = m["in.x"].clone().requires_grad_()
+    p = dict((k[2:], v.clone().requires_grad_()) for k, v in m.items() if k.startswith("p."))
+    B, L, H = x.shape
+    hd = H // heads
+
+    def split(t):
+        return t.view(B, L, heads, hd).transpose(1, 2)
+    q = split(torch.nn.functional.linear(x, p["query.weight"], p["query.bias"]))
+    k = split(torch.nn.functional.linear(x, p["key.weight"], p["key.bias"]))
+    v = split(torch.nn.functional.linear(x, p["value.weight"], p["value.bias"]))
+    s = (q @ k.transpose(-1, -2)) / hd ** 0.5
+    s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), -1e9)
+    ctx = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, H)
+    y = torch.nn.functional.layer_norm(torch.nn.functional.linear(ctx, p["dense.weight"], p["dense.bias"]) + x, (H,),
+                                       p["LayerNorm.weight"], p["LayerNorm.bias"], 1e-12)
+    assert_close(y, m["out.y"], 1e-5, "attention layer output")
+    (y * m["in.R"]).sum().backward()
+    assert_close(x.grad, m["g.x"], 1e-5, "attention layer dx")
+    for name, t in p.items():
+        assert_close(t.grad, m["g." + name], 1e-5, "attention layer grad " + name)
