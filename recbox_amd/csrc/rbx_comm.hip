@@ -32,6 +32,32 @@ static int nccl_type(int dtype) {
     default: return -1;
   }
 }
+// The block a rank keeps for itself, moved by a kernel of this library: inside a captured step a hipMemcpyAsync becomes a
+// memcpy NODE, which the graph runtime runs on a queue of its own -- in the replayed sharded FM step the 46 MB copy of the
+// rows' way back started 74 us after the kernel it depends on had finished (profiles/r04/fm_sharded1_replay_timeline.txt);
+// a kernel node stays on the queue of its neighbours.
+__global__ __launch_bounds__(256) void copy_block_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const size_t n16,
+                                                         const unsigned char* __restrict__ src_tail,
+                                                         unsigned char* __restrict__ dst_tail, const int tail) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0 && static_cast<int>(threadIdx.x) < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+static int copy_block(const char* src, char* dst, size_t bytes, hipStream_t s) {
+  if ((reinterpret_cast<uintptr_t>(src) & 15) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15) != 0)
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s) == hipSuccess ? RBX_OK : RBX_ERR_LAUNCH;
+  const size_t n16 = bytes / 16;
+  const int tail = static_cast<int>(bytes - n16 * 16);
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > static_cast<size_t>(kCUs) * 16) blocks = static_cast<size_t>(kCUs) * 16;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(copy_block_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                     reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), n16,
+                     reinterpret_cast<const unsigned char*>(src + n16 * 16), reinterpret_cast<unsigned char*>(dst + n16 * 16),
+                     tail);
+  return check_launch("copy_block_kernel");
+}
 }  // namespace rbx
 
 extern "C" int rbx_comm_bind(void* fn_group_start, void* fn_group_end, void* fn_send, void* fn_recv, void* fn_error_string) {
@@ -57,13 +83,12 @@ extern "C" int rbx_all_to_all(void* comm, const void* d_send, void* d_recv, size
   const char* sp = static_cast<const char*>(d_send);
   char* rp = static_cast<char*>(d_recv);
   // The block a rank keeps for itself does not go through RCCL: its self send / recv is a generic copy kernel that moves
-  // ~1 TB/s (200 us for the 201 MB block of cfg 3 in a world of one, profiles/r04), the runtime's device-to-device copy
-  // 2-3x that.  Needs the rank of this process in the communicator (ncclCommUserRank, bound by rbx_comm_bind_collectives).
+  // ~1 TB/s (200 us for the 201 MB block of cfg 3 in a world of one, profiles/r04), a plain copy kernel 3-4x that.  Needs the rank of this process in the communicator (ncclCommUserRank, bound by rbx_comm_bind_collectives).
   int self = -1;
   if (g_userrank != nullptr && g_userrank(comm, &self) != 0) self = -1;
   if (self >= 0 && self < world) {
-    if (hipMemcpyAsync(rp + static_cast<size_t>(self) * bytes_per_peer, sp + static_cast<size_t>(self) * bytes_per_peer,
-                       bytes_per_peer, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    if (copy_block(sp + static_cast<size_t>(self) * bytes_per_peer, rp + static_cast<size_t>(self) * bytes_per_peer,
+                   bytes_per_peer, s) != RBX_OK)
       return fail(RBX_ERR_LAUNCH, "all_to_all: device-to-device copy of the rank's own block failed");
     if (world == 1) return RBX_OK;
   }
