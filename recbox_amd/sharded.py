@@ -613,7 +613,7 @@ class _ShardLookup(torch.autograd.Function):
         back, keys, src = lo.serve(geom, recv, weight.detach(), status)
         # the owner's id sort needs only the received row numbers: it runs beside the rows' way back
         sort = None
-        if ctx.needs_input_grad[4]:
+        if ctx.needs_input_grad[4] and getattr(store, "_grad_mode", True):     # (a forward under torch.no_grad() sorts nothing)
             sort = store.early_sort(lo, weight, keys)
         got = torch.empty_like(back)
         comm.all_to_all_equal_into(got, back, group).wait()                           # rows / partial sums back
@@ -746,4 +746,5 @@ class ShardedStore(nn.Module):
     def lookup(self, call, width, row_ids, pool_ids=None, block=None):
         """Fill the slots of ``call`` in ``block`` [B, width] (None: a new block) and return it."""
         ids = list(row_ids) + ([pool_ids] if call.P else [])
+        self._grad_mode = torch.is_grad_enabled()        # (inside Function.forward grad mode is always off: told from here)
         return _ShardLookup.apply(self, call, width, block, self.weight, *ids)
