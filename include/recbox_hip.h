@@ -664,7 +664,7 @@ int rbx_linear_dx_deepfm(const float* d_dy, int64_t dy_stride, const float* d_w,
  *                   y = x W^T (rbx_linear_fwd*), 1 serves dx = dy W (rbx_linear_dx*);
  *   rbx_split_register(d_w, d_planes, rows, cols, transposed): from now on a rbx_linear_fwd* / rbx_linear_dx* call whose
  *                   weight pointer is d_w (shape [rows, cols]) runs on the planes; rbx_split_unregister(d_w) ends that (the
- *                   planes must stay valid until the GEMMs issued in between have run).  Host-side table, 16 slots,
+ *                   planes must stay valid until the GEMMs issued in between have run).  Host-side table, 256 slots,
  *                   thread-safe; RBX_GEMM_BX6=0 in the environment ignores every registration. */
 /* BatchNorm statistics out of the GEMMs around a BatchNorm (rechub's towers: Linear -> BatchNorm1d -> act,
  * third_party/rechub/basic/layers.py:250-266).  Both calls need d_w's planes registered (above) and m >= 512; otherwise they

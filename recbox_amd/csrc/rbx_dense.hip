@@ -2275,7 +2275,7 @@ struct SplitEntry {
   const unsigned short* planes;
   int rows, cols, transposed;
 };
-constexpr int kSplitSlots = 16;
+constexpr int kSplitSlots = 256;   // registrations live for the duration of ONE call (a tower layer); 256 concurrent ones (threads x towers) before a GEMM falls back to the f32 kernel
 static SplitEntry g_split[kSplitSlots];
 static std::mutex g_split_mu;
 static std::atomic<unsigned long long> g_bx6_launches{0};     // observability: GEMMs that ran on the split-operand kernel
