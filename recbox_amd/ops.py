@@ -723,16 +723,23 @@ _grad_views = {}
 
 
 class _GradView(object):
-    __slots__ = ("view", "taken")
+    __slots__ = ("view", "taken", "owner")
 
-    def __init__(self, view):
+    def __init__(self, view, param=None):
+        import weakref
         self.view, self.taken = view, False
+        # the entry is keyed by an ADDRESS: it is only good while the parameter that registered it is alive (a later tensor
+        # may be given the same memory)
+        self.owner = weakref.ref(param) if param is not None else None
 
 
 def _grad_dest(key, shape, device):
     """The registered destination of the gradient of the parameter at ``key`` (a fresh tensor object over the bucket's
     memory: AccumulateGrad takes a gradient over only when nobody else holds the object), or a new tensor."""
     ent = _grad_views.get(key) if key else None
+    if ent is not None and ent.owner is not None and ent.owner() is None:
+        del _grad_views[key]                       # its parameter is gone
+        ent = None
     if ent is not None and not ent.taken and tuple(ent.view.shape) == tuple(shape) and ent.view.device == device:
         ent.taken = True
         return ent.view.view(ent.view.shape)

@@ -232,7 +232,7 @@ class DenseGradSync(object):
         o = 0
         for p, n in zip(ps, sizes):
             view = self.bucket[o:o + p.numel()].view(p.shape)
-            ops._grad_views[p.data_ptr()] = ops._GradView(view)
+            ops._grad_views[p.data_ptr()] = ops._GradView(view, p)
             self._views.append((p, view))
             o += n
 
