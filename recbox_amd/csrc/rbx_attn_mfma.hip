@@ -123,23 +123,123 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, cons
 #ifndef RBX_ATTN_ABL
 #define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T, 8 = the Q tile loads, 16 = the stores of unsplit tiles
 #endif
-// (Measured and not kept, profiles/r03/INDEX.md: the LDS reads of a tile product issued four ahead of the MFMAs that use them
-//  -- the compiler reads every pair of A values into the same two registers, read / wait / two MFMAs -- with
-//  __builtin_amdgcn_sched_group_barrier: the forward kernel alone 456 vs 459 us, in the SASRec step 449 vs 420 us (more spills
-//  in the looping form).  The LDS round trip is not what the matrix core waits for; see profiles/ubench/attn_parts.hip.)
-// acc[row = li of `rows_lds`][col = lane] = sum_d rows_lds[row0 + li][d] * reg[d]   (column pairing as in load_tile_regs)
+#ifndef RBX_ATTN_BF16X6
+#define RBX_ATTN_BF16X6 2  // which kernels run their tile products on the bf16 matrix cores, operands split three ways: bit 0 the
+#endif                     // forward kernels, bit 1 the dQ kernel, bit 2 the dK | dV kernel (0: v_mfma_f32_32x32x2_f32 everywhere)
+// f32 products on the bf16 pipes (the recipe of rbx_dense.hip's gemm_bx6_kernel): x = h + m + l with bf16 h = rn(x), m = rn(x - h),
+// l = rn(x - h - m); a b = ah bh + (ah bm + am bh) + (ah bl + al bh + am bm) + O(2^-24 |a b|): six v_mfma_f32_32x32x16_bf16 per
+// 16 k (192 pipe cycles) where eight v_mfma_f32_32x32x2_f32 take 512, at an error per product of ONE f32 rounding -- the parity
+// tests keep their tolerances.  The operands stay f32 in LDS and in global memory (same layouts, same staging): a lane splits the
+// eight values of its A fragment between the LDS read and the MFMAs (4.5 VALU operations per element, on the vector pipe that the
+// f32 form left idle), the wavefront's own tile is split once per tile.  A 32x32x16 step contracts over 8 k per half-wave where
+// the f32 step took one: WHICH eight is free as long as both operands agree, so the halves keep the pairing of load_tile_regs
+// (k = half * HD/2 + 8 step + e) and, in tile_accumulate, register r of the weights keeps row tile_row(r, half).
+typedef __bf16 abf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 abf16x8_t __attribute__((ext_vector_type(8)));
+typedef float af32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned au32x4_t __attribute__((ext_vector_type(4)));
+struct Split8 {
+  abf16x8_t h, m, l;
+};
+__device__ __forceinline__ void attn_split2(af32x2_t x, unsigned& h, unsigned& m, unsigned& l) {
+  const abf16x2_t hb = __builtin_convertvector(x, abf16x2_t);
+  x -= __builtin_convertvector(hb, af32x2_t);
+  const abf16x2_t mb = __builtin_convertvector(x, abf16x2_t);
+  x -= __builtin_convertvector(mb, af32x2_t);
+  const abf16x2_t lb = __builtin_convertvector(x, abf16x2_t);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
+  au32x4_t h, m, l;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned hh, mm, ll;
+    attn_split2(af32x2_t{x[2 * p], x[2 * p + 1]}, hh, mm, ll);
+    h[p] = hh; m[p] = mm; l[p] = ll;
+  }
+  Split8 o;
+  o.h = __builtin_bit_cast(abf16x8_t, h);
+  o.m = __builtin_bit_cast(abf16x8_t, m);
+  o.l = __builtin_bit_cast(abf16x8_t, l);
+  return o;
+}
+// acc += A B to one f32 rounding per product; two chains so that consecutive MFMAs do not wait for each other
+__device__ __forceinline__ void mfma6(f32x16& c0, f32x16& c1, const Split8& a, const Split8& b) {
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c1, 0, 0, 0);
+}
+// c0 += A0 B, c1 += A1 B, the two chains interleaved
+__device__ __forceinline__ void mfma6x2(f32x16& c0, f32x16& c1, const Split8& a0, const Split8& a1, const Split8& b) {
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b.h, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.l, b.h, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b.l, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b.l, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b.m, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b.m, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b.h, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b.h, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b.m, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b.m, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b.h, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b.h, c1, 0, 0, 0);
+}
+
+// the wavefront's own tile (load_tile_regs) in the form the tile products take it
+template <int HD, bool X6>
+struct TileOp {
+  const float* v;            // f32 form: the registers load_tile_regs filled, as they are
+};
 template <int HD>
-__device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, int row0, const float (&reg)[HD / 2]) {
+struct TileOp<HD, true> {
+  Split8 p[HD / 16];
+};
+template <int HD, bool X6>
+__device__ __forceinline__ void make_op(const float (&reg)[HD / 2], TileOp<HD, X6>& op) {
+  if constexpr (X6) {
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = reg[8 * s + e];
+      op.p[s] = split8(x);
+    }
+  } else {
+    op.v = reg;
+  }
+}
+
+// (Measured and not kept, profiles/r03/INDEX.md: the LDS reads of a tile product issued four ahead of the MFMAs that use them
+//  with __builtin_amdgcn_sched_group_barrier: the forward kernel alone 456 vs 459 us.  profiles/r04: s_setprio 1 around the
+//  tile products: forward 395.7 vs 394.2 us, backward 1285.8 vs 1284.4 us.)
+// acc[row = li of `rows_lds`][col = lane] = sum_d rows_lds[row0 + li][d] * reg[d]   (column pairing as in load_tile_regs)
+template <int HD, bool X6>
+__device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, int row0, const TileOp<HD, X6>& op) {
   const int lane = threadIdx.x & 63;
   const float* a = rows_lds + (row0 + (lane & 31)) * (HD + 1) + (lane >> 5) * (HD / 2);
   // two accumulator chains (even / odd k steps): a single chain makes every MFMA wait for the previous one
   f32x16 acc, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+  if constexpr (X6) {
 #pragma unroll
-  for (int s = 0; s < HD / 2; s += 2) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], reg[s], acc, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s + 1], reg[s + 1], acc1, 0, 0, 0);
+    for (int s = 0; s < HD / 16; ++s) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = a[8 * s + e];
+      mfma6(acc, acc1, split8(x), op.p[s]);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < HD / 2; s += 2) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], op.v[s], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s + 1], op.v[s + 1], acc1, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
@@ -147,16 +247,44 @@ __device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, i
 }
 
 // out[dt][row = d][col = lane] += sum_r rows_lds[row0 + tile_row(r)][dt*32 + li] * w[r]
-template <int HD>
+template <int HD, bool X6>
 __device__ __forceinline__ void tile_accumulate(const float* __restrict__ rows_lds, int row0, const f32x16& w,
                                                 f32x16 (&out)[HD / 32]) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, half = lane >> 5;
+  if constexpr (X6) {
+  static_assert(HD == 32 || HD == 64, "one or two column tiles");
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = w[8 * s + e];
+    const Split8 b = split8(x);
+    Split8 a[HD / 32];
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = rows_lds[(row0 + tile_row(8 * s + e, half)) * (HD + 1) + dt * 32 + li];
+      a[dt] = split8(x);
+    }
+    if constexpr (HD == 64) {
+      mfma6x2(out[0], out[1], a[0], a[1], b);
+    } else {
+      f32x16 t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = 0.f;
+      mfma6(out[0], t, a[0], b);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[0][r] += t[r];
+    }
+  }
+  } else {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float* a = rows_lds + (row0 + tile_row(r, half)) * (HD + 1) + li;
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt) out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt * 32], w[r], out[dt], 0, 0, 0);
+  }
   }
 }
 
@@ -354,6 +482,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
       m = -INFINITY;
       lsum = 0.f;
+      constexpr bool X6 = HD == 64 && (RBX_ATTN_BF16X6 & 1) != 0;
+      TileOp<HD, X6> qop;
+      make_op<HD, X6>(qreg, qop);
       for (int kt = pl.beg(jb); kt < pl.end(jb); ++kt) {
         const int j0 = kt * kT;
         f32x16 s;
@@ -361,11 +492,11 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = qreg[r] * Ks[j0 + lane];
         } else {
-          s = tile_dot<HD>(Ks, j0, qreg);                      // S^T[key][query]
+          s = tile_dot<HD, X6>(Ks, j0, qop);                   // S^T[key][query]
         }
         if constexpr ((RBX_ATTN_ABL & 2) != 0) {
           lsum += s[0];
-          tile_accumulate<HD>(Vs, j0, s, oacc);
+          tile_accumulate<HD, X6>(Vs, j0, s, oacc);
           continue;
         }
         float mx = -INFINITY;
@@ -406,7 +537,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[0][r] += s[r];
         } else {
-          tile_accumulate<HD>(Vs, j0, s, oacc);                // O^T[d][query] += V^T P^T
+          tile_accumulate<HD, X6>(Vs, j0, s, oacc);            // O^T[d][query] += V^T P^T
         }
       }
       if ((RBX_ATTN_ABL & 16) != 0 && lsum != 12345.f) continue;            // (no O / LSE stores of unsplit tiles)
@@ -484,10 +615,17 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
     for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+    // (profiles/r04: the dQ kernel alone 569 us on the bf16 pipes vs 623 us; the dK | dV kernel 744 vs 695 us -- its four operand
+    //  sets spill --, the forward 425 vs 412 us: the splits make the kernels VALU-bound where the f32 MFMAs made them wait
+    //  for the matrix pipe)
+    constexpr bool X6 = HD == 64 && (RBX_ATTN_BF16X6 & 2) != 0;
+    TileOp<HD, X6> qop, gop;
+    make_op<HD, X6>(qreg, qop);
+    make_op<HD, X6>(greg, gop);
     for (int kt = pl.beg(jb); kt < pl.end(jb); ++kt) {
       const int j0 = kt * kT;
-      f32x16 s = tile_dot<HD>(Ks, j0, qreg);                 // S^T
-      f32x16 dp = tile_dot<HD>(Vs, j0, greg);                // dP^T[key][query] = <V_key, dO_query>
+      f32x16 s = tile_dot<HD, X6>(Ks, j0, qop);              // S^T
+      f32x16 dp = tile_dot<HD, X6>(Vs, j0, gop);             // dP^T[key][query] = <V_key, dO_query>
       if (DROP) {                                            // d(dropped P) -> dP: the same mask and scale
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -505,7 +643,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
         const float p = vis ? __expf(s[r] - lse) : 0.f;
         s[r] = p * (dp[r] - Di);                             // dS^T
       }
-      tile_accumulate<HD>(Ks, j0, s, dq);                    // dQ^T[d][query] += K^T dS^T
+      tile_accumulate<HD, X6>(Ks, j0, s, dq);                // dQ^T[d][query] += K^T dS^T
     }
     if (jb != pl.partial && !pl.merge) store_transposed<HD>(dQ, ld.dq, i0, L, scale, dq);
   }
@@ -569,10 +707,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
 #pragma unroll
       for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
     const int it_beg = (causal ? jt : 0) + pl.beg(jb), it_end = (causal ? jt : 0) + pl.end(jb);
+    constexpr bool X6 = HD == 64 && (RBX_ATTN_BF16X6 & 4) != 0;
+    TileOp<HD, X6> kop, vop;
+    make_op<HD, X6>(kreg, kop);
+    make_op<HD, X6>(vreg, vop);
     for (int it = it_beg; it < it_end; ++it) {
       const int i0 = it * kT;
-      f32x16 s = tile_dot<HD>(Qs, i0, kreg);                 // S[query][key] (already scaled)
-      f32x16 dp = tile_dot<HD>(Gs, i0, vreg);                // dP[query][key]
+      f32x16 s = tile_dot<HD, X6>(Qs, i0, kop);              // S[query][key] (already scaled)
+      f32x16 dp = tile_dot<HD, X6>(Gs, i0, vop);             // dP[query][key]
       f32x16 p;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -601,14 +743,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = p[r] * (dp[r] - Ds[i0 + tile_row(r, half)]);     // dS
-        tile_accumulate<HD>(Gs, i0, pd, dv);                 // dV^T[d][key] += dO^T (dropped P)
-        tile_accumulate<HD>(Qs, i0, s, dk);
+        tile_accumulate<HD, X6>(Gs, i0, pd, dv);             // dV^T[d][key] += dO^T (dropped P)
+        tile_accumulate<HD, X6>(Qs, i0, s, dk);
         continue;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = p[r] * (dp[r] - Ds[i0 + tile_row(r, half)]);       // dS
-      tile_accumulate<HD>(Gs, i0, p, dv);                    // dV^T[d][key] += dO^T P
-      tile_accumulate<HD>(Qs, i0, s, dk);                    // dK^T[d][key] += (scale Q)^T dS
+      tile_accumulate<HD, X6>(Gs, i0, p, dv);                // dV^T[d][key] += dO^T P
+      tile_accumulate<HD, X6>(Qs, i0, s, dk);                // dK^T[d][key] += (scale Q)^T dS
     }
     if (jb != pl.partial && !pl.merge) {
       store_transposed<HD>(dK, ld.dk, j0, L, 1.0f, dk);
@@ -638,6 +780,10 @@ bool attn_mfma_supported(int lq, int lk, int hd, const float* mask, const float*
   return mask == nullptr && probs == nullptr && lq == lk && lq <= 256 && (hd == 32 || hd == 64);
 }
 
+}  // namespace rbx
+#include "rbx_attn_stream.h"
+namespace rbx {
+
 // heavy tiles dealt to both wavefronts of their SIMD (wave_plan): causal sequences of at least three tiles (below that no
 // tile is two steps heavier than its partner); RBX_ATTN_SPLIT=0 keeps one wavefront per tile.  The four merge slots fit in
 // the operand rows they reuse: 4 * (32 HD + 128) floats <= 2 * 96 * (HD + 1) for HD = 32 and 64.
@@ -655,6 +801,18 @@ static size_t lds_bytes(int L, bool phase_b) {
 template <int HD, bool DROP>
 static int run_fwd(const float* q, const float* k, const float* v, long long bh, int L, float scale, int causal, float* o,
                    float* lse, const DropArgs& drop, const AttnLd& ld, hipStream_t s) {
+  if constexpr (HD == 64) {
+    // K / V streamed through a ring of 32-key tiles, a pair of sequences per workgroup (rbx_attn_stream.h)
+    static const bool stream_on = [] { const char* e = getenv("RBX_ATTN_STREAM"); return e == nullptr || e[0] != '0'; }();
+    const int nT = (L + kT - 1) / kT;
+    if (stream_on && causal != 0 && nT >= 3 && nT <= 7) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_fwd_kernel<DROP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kStreamLds));
+      hipLaunchKernelGGL((attn_stream_fwd_kernel<DROP>), dim3(static_cast<unsigned>((bh + 1) / 2)), dim3((nT + 1) * 64),
+                         kStreamLds, s, q, k, v, L, scale, o, lse, drop, ld, bh);
+      return check_launch("attn_stream_fwd_kernel");
+    }
+  }
   const size_t lds = lds_bytes<HD>(L, false);
   static const bool pf_on = [] { const char* e = getenv("RBX_ATTN_PREFETCH"); return e == nullptr || e[0] != '0'; }();
   // (the looping form keeps the heavy tiles' partials in LDS slots of their own behind K and V: where those do not fit --
