@@ -124,8 +124,9 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, cons
 #define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T, 8 = the Q tile loads, 16 = the stores of unsplit tiles
 #endif
 #ifndef RBX_ATTN_BF16X6
-#define RBX_ATTN_BF16X6 2  // which kernels run their tile products on the bf16 matrix cores, operands split three ways: bit 0 the
-#endif                     // forward kernels, bit 1 the dQ kernel, bit 2 the dK | dV kernel (0: v_mfma_f32_32x32x2_f32 everywhere)
+#define RBX_ATTN_BF16X6 44 // which tile products run on the bf16 matrix cores, operands split three ways: bits 0, 1 the forward
+#endif                     // kernels' tile_dot / tile_accumulate, bits 2, 3 the dQ kernel's, bits 4, 5 the dK | dV kernel's
+                           // (0: v_mfma_f32_32x32x2_f32 everywhere)
 // f32 products on the bf16 pipes (the recipe of rbx_dense.hip's gemm_bx6_kernel): x = h + m + l with bf16 h = rn(x), m = rn(x - h),
 // l = rn(x - h - m); a b = ah bh + (ah bm + am bh) + (ah bl + al bh + am bm) + O(2^-24 |a b|): six v_mfma_f32_32x32x16_bf16 per
 // 16 k (192 pipe cycles) where eight v_mfma_f32_32x32x2_f32 take 512, at an error per product of ONE f32 rounding -- the parity
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
       m = -INFINITY;
       lsum = 0.f;
-      constexpr bool X6 = HD == 64 && (RBX_ATTN_BF16X6 & 1) != 0;
+      constexpr bool X6 = HD == 64 && (RBX_ATTN_BF16X6 & 1) != 0, XA = HD == 64 && (RBX_ATTN_BF16X6 & 2) != 0;
       TileOp<HD, X6> qop;
       make_op<HD, X6>(qreg, qop);
       for (int kt = pl.beg(jb); kt < pl.end(jb); ++kt) {
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
         }
         if constexpr ((RBX_ATTN_ABL & 2) != 0) {
           lsum += s[0];
-          tile_accumulate<HD, X6>(Vs, j0, s, oacc);
+          tile_accumulate<HD, XA>(Vs, j0, s, oacc);
           continue;
         }
         float mx = -INFINITY;
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[0][r] += s[r];
         } else {
-          tile_accumulate<HD, X6>(Vs, j0, s, oacc);            // O^T[d][query] += V^T P^T
+          tile_accumulate<HD, XA>(Vs, j0, s, oacc);            // O^T[d][query] += V^T P^T
         }
       }
       if ((RBX_ATTN_ABL & 16) != 0 && lsum != 12345.f) continue;            // (no O / LSE stores of unsplit tiles)
@@ -615,10 +616,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
     for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
-    // (profiles/r04: the dQ kernel alone 569 us on the bf16 pipes vs 623 us; the dK | dV kernel 744 vs 695 us -- its four operand
-    //  sets spill --, the forward 425 vs 412 us: the splits make the kernels VALU-bound where the f32 MFMAs made them wait
-    //  for the matrix pipe)
-    constexpr bool X6 = HD == 64 && (RBX_ATTN_BF16X6 & 2) != 0;
+    // (profiles/r04/attn_forms.txt, kernels alone at 4096 x 200 x 64: this kernel 579 us with all three products on the bf16
+    //  pipes, 599 / 606 with the tile_dots / the tile_accumulate only, 622 f32; the dK | dV kernel 679 with its two
+    //  tile_accumulates, 772 with its two tile_dots (both: 744, its four operand sets spill), 704 f32; the streamed forward
+    //  348 f32, 354 with tile_accumulate, 504 with tile_dot.  A lane's splits cost ~10 VALU operations per pair of elements:
+    //  ~900 per tile step here, the kernels become VALU-bound where the f32 MFMAs had them wait for the matrix pipe.  Planes
+    //  split ONCE per tile instead of once per wavefront need the tiled (streamed) form: DESIGN.md section 8.)
+    constexpr bool X6 = HD == 64 && (RBX_ATTN_BF16X6 & 4) != 0, XA = HD == 64 && (RBX_ATTN_BF16X6 & 8) != 0;
     TileOp<HD, X6> qop, gop;
     make_op<HD, X6>(qreg, qop);
     make_op<HD, X6>(greg, gop);
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
         const float p = vis ? __expf(s[r] - lse) : 0.f;
         s[r] = p * (dp[r] - Di);                             // dS^T
       }
-      tile_accumulate<HD, X6>(Ks, j0, s, dq);                // dQ^T[d][query] += K^T dS^T
+      tile_accumulate<HD, XA>(Ks, j0, s, dq);                // dQ^T[d][query] += K^T dS^T
     }
     if (jb != pl.partial && !pl.merge) store_transposed<HD>(dQ, ld.dq, i0, L, scale, dq);
   }
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
 #pragma unroll
       for (int r = 0; r < 16; ++r) dk[dt][r] = dv[dt][r] = 0.f;
     const int it_beg = (causal ? jt : 0) + pl.beg(jb), it_end = (causal ? jt : 0) + pl.end(jb);
-    constexpr bool X6 = HD == 64 && (RBX_ATTN_BF16X6 & 4) != 0;
+    constexpr bool X6 = HD == 64 && (RBX_ATTN_BF16X6 & 16) != 0, XA = HD == 64 && (RBX_ATTN_BF16X6 & 32) != 0;
     TileOp<HD, X6> kop, vop;
     make_op<HD, X6>(kreg, kop);
     make_op<HD, X6>(vreg, vop);
@@ -743,14 +747,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = p[r] * (dp[r] - Ds[i0 + tile_row(r, half)]);     // dS
-        tile_accumulate<HD, X6>(Gs, i0, pd, dv);             // dV^T[d][key] += dO^T (dropped P)
-        tile_accumulate<HD, X6>(Qs, i0, s, dk);
+        tile_accumulate<HD, XA>(Gs, i0, pd, dv);             // dV^T[d][key] += dO^T (dropped P)
+        tile_accumulate<HD, XA>(Qs, i0, s, dk);
         continue;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = p[r] * (dp[r] - Ds[i0 + tile_row(r, half)]);       // dS
-      tile_accumulate<HD, X6>(Gs, i0, p, dv);                // dV^T[d][key] += dO^T P
-      tile_accumulate<HD, X6>(Qs, i0, s, dk);                // dK^T[d][key] += (scale Q)^T dS
+      tile_accumulate<HD, XA>(Gs, i0, p, dv);                // dV^T[d][key] += dO^T P
+      tile_accumulate<HD, XA>(Qs, i0, s, dk);                // dK^T[d][key] += (scale Q)^T dS
     }
     if (jb != pl.partial && !pl.merge) {
       store_transposed<HD>(dK, ld.dk, j0, L, 1.0f, dk);

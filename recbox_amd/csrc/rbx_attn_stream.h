@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_fwd_kernel(const float* __
   const int t = wid;
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
-  constexpr bool X6 = (RBX_ATTN_BF16X6 & 1) != 0;
+  constexpr bool X6 = (RBX_ATTN_BF16X6 & 1) != 0, XA = (RBX_ATTN_BF16X6 & 2) != 0;
   TileOp<HD, X6> qop;
   float qsplit[HD / 2];                                      // (f32 form: these registers ARE the operand)
   bool fresh = true;                                         // qsplit holds a tile that qop does not yet
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(512, 4) void attn_stream_fwd_kernel(const float* __
           for (int q = 0; q < 4; ++q) s[4 * g + q] = drop_keep(c, qi & 1, q, drop.thr16) ? s[4 * g + q] * drop.scale : 0.f;
         }
       }
-      tile_accumulate_sw<X6>(Vt, s, oacc);                      // O^T[d][query] += V^T P^T
+      tile_accumulate_sw<XA>(Vt, s, oacc);                      // O^T[d][query] += V^T P^T
       if (it == t || it == nT) {                             // the tile is complete
         float* O = O0 + attn_base(bh, ld.heads, L, ld.o, HD);
         store_transposed<HD>(O, ld.o, i0, L, 1.0f / lsum, oacc);

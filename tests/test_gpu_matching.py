@@ -789,12 +789,47 @@ def test_attention_dropout_vs_restatement_with_the_kernels_mask(L, D, causal, us
     assert_close(vc.grad, vd.grad, TOL, "dV")
 
 
+@pytest.mark.parametrize("L,BH", [(65, 7), (96, 301), (129, 6), (200, 7), (224, 5)])
+def test_streamed_attention_forward_pairs_of_sequences_vs_float64(L, BH):
+    """Causal sequences of 3..7 key tiles at head_dim 64 take the forward kernel that streams K and V through a ring of
+    32-key tiles (rbx_attn_stream.h): a workgroup serves a PAIR of sequences -- the even one walks its key tiles upwards, the
+    odd one downwards -- and an odd count leaves the last workgroup with one sequence.  Output, log-sum-exp (through the
+    backward kernels, which rebuild P from it) and gradients against float64, for the first, the last and a middle sequence."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(7 * L + BH)
+    D = 64
+    q, k, v = (torch.randn(BH, 1, L, D, generator=g) for _ in range(3))
+    R = torch.randn(BH, 1, L, D, generator=g)
+    qc, kc, vc = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    o, _ = ops.attention(qc, kc, vc, scale=D ** -0.5, causal=True, fill=float("-inf"))
+    (o * R.cuda()).sum().backward()
+    tri = torch.tril(torch.ones(L, L, dtype=torch.bool))
+    for b in sorted({0, 1, BH // 2, BH - 2, BH - 1}):
+        qd, kd, vd = (t[b, 0].double().requires_grad_(True) for t in (q, k, v))
+        s = ((qd @ kd.t()) * D ** -0.5).masked_fill(~tri, float("-inf"))
+        want = s.softmax(-1) @ vd
+        (want * R[b, 0].double()).sum().backward()
+        assert_close(o[b, 0], want.float(), TOL, "out of sequence %d" % b)
+        assert_close(qc.grad[b, 0], qd.grad.float(), TOL, "dq of sequence %d" % b)
+        assert_close(kc.grad[b, 0], kd.grad.float(), TOL, "dk of sequence %d" % b)
+        assert_close(vc.grad[b, 0], vd.grad.float(), TOL, "dv of sequence %d" % b)
+    # a sequence's result does not depend on its neighbour: the same rows as the even and as the odd member of a pair
+    q2 = torch.cat([q[:1], q[:1], q[1:2]]).cuda()
+    k2 = torch.cat([k[:1], k[:1], k[1:2]]).cuda()
+    v2 = torch.cat([v[:1], v[:1], v[1:2]]).cuda()
+    o2, _ = ops.attention(q2, k2, v2, scale=D ** -0.5, causal=True, fill=float("-inf"))
+    assert_close(o2[1], o2[0], 2e-6, "the same sequence walked upwards and downwards")
+    assert torch.equal(o2[0], o.detach()[0])
+
+
 @pytest.mark.parametrize("L", [192, 200, 256])
 def test_attention_forward_that_loops_over_sequences_equals_one_workgroup_per_sequence(L):
     """More than 256 sequences of L > 160 at head_dim 64 take the forward kernel that keeps one workgroup per CU, loops over
     the sequences and prefetches the next K, V into registers (6, 7 or 8 float4 per thread at L = 192, 200, 256); the same
     sequences in two launches of at most 256 take the one-workgroup-per-sequence kernel.  Same arithmetic in the same order:
-    bit-identical outputs and gradients."""
+    bit-identical outputs and gradients.  (Since round 4 the causal L = 192 and 200 cases run the streamed kernel of
+    rbx_attn_stream.h whatever the count -- the split below keeps every sequence's place in its pair --, L = 256 the two
+    resident forms.)"""
     from recbox_amd import ops
     g = torch.Generator().manual_seed(L)
     BH, D = 300, 64
