@@ -44,7 +44,7 @@ prof fm_tier_c "RBX_FM_TIER_C=1 RECBOX_AMD_FM_BLOCKSORT_AT=side" "--steps 20 --w
 prof fm_sharded1 "X=1" "--config fm --force-sharded --steps 20 --warmup 5" route_count 14
 prof youtubednn "X=1" "--config youtubednn --steps 20 --warmup 5" embed_seq 12
 prof deepfm "X=1" "--config deepfm --steps 20 --warmup 5" deepfm 12
-prof sasrec "X=1" "--config sasrec --steps 20 --warmup 5" attn_mfma_fwd 12
+prof sasrec "X=1" "--config sasrec --steps 20 --warmup 5" embed_seq 12
 prof youtubednn_sharded1 "X=1" "--config youtubednn --force-sharded --steps 20 --warmup 5" "shard_count_kernel<true>" 14
 prof deepfm_sharded1 "X=1" "--config deepfm --force-sharded --steps 20 --warmup 5" "shard_count_kernel<false>" 14
 # HBM traffic of the FM kernels from the PMC counters, separate passes, tier C off (the default) and on
@@ -55,4 +55,8 @@ for tc in 0 1; do
     rm -rf $out/pmc_fm_$c
   done
 done
+# matrix-pipe utilisation of SASRec's kernels (one PMC pass, eager launches)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $out/pmc_mfma_sasrec -o b -- python $GRAFT_REPO_ROOT/bench.py --config sasrec --eager --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1)
+timeout 120 python profiles/mfma_util.py $(find $out/pmc_mfma_sasrec -name "*.db" | head -1) attn gemm tall_dw < /dev/null > $out/mfma_util_sasrec.txt 2>&1
+rm -rf $out/pmc_mfma_sasrec
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee -a $out/summary.txt
