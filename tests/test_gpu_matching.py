@@ -822,6 +822,34 @@ def test_streamed_attention_forward_pairs_of_sequences_vs_float64(L, BH):
     assert torch.equal(o2[0], o.detach()[0])
 
 
+def test_streamed_and_resident_attention_forward_agree():
+    """RBX_ATTN_STREAM=0 (read once by the library: a child process) keeps the resident kernels for the shapes the streamed
+    forward serves: the two forms agree to rounding on the same seeded inputs, with and without dropout (same mask words)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, sys\n"
+        "from recbox_amd import ops\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "q, k, v = (torch.randn(9, 1, 200, 64, generator=g).cuda() for _ in range(3))\n"
+        "o, _ = ops.attention(q, k, v, scale=0.125, causal=True, fill=float('-inf'))\n"
+        "od, _ = ops.attention(q, k, v, scale=0.125, causal=True, fill=float('-inf'), dropout_p=0.25, seed=5)\n"
+        "torch.save({'o': o.cpu(), 'od': od.cpu()}, sys.argv[1])\n")
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for form in ("0", "1"):
+            path = os.path.join(tmp, "o%s.pt" % form)
+            env = dict(os.environ, RBX_ATTN_STREAM=form)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            outs[form] = torch.load(path)
+    assert_close(outs["1"]["o"], outs["0"]["o"], 2e-6, "streamed vs resident forward")
+    assert_close(outs["1"]["od"], outs["0"]["od"], 4e-6, "streamed vs resident forward, dropout 0.25")
+    assert not torch.equal(outs["1"]["od"], outs["1"]["o"])
+
+
 @pytest.mark.parametrize("L", [192, 200, 256])
 def test_attention_forward_that_loops_over_sequences_equals_one_workgroup_per_sequence(L):
     """More than 256 sequences of L > 160 at head_dim 64 take the forward kernel that keeps one workgroup per CU, loops over
