@@ -786,6 +786,7 @@ bool attn_mfma_supported(int lq, int lk, int hd, const float* mask, const float*
 
 }  // namespace rbx
 #include "rbx_attn_stream.h"
+#include "rbx_attn_planes.h"
 namespace rbx {
 
 // heavy tiles dealt to both wavefronts of their SIMD (wave_plan): causal sequences of at least three tiles (below that no
@@ -807,9 +808,18 @@ static int run_fwd(const float* q, const float* k, const float* v, long long bh,
                    float* lse, const DropArgs& drop, const AttnLd& ld, hipStream_t s) {
   if constexpr (HD == 64) {
     // K / V streamed through a ring of 32-key tiles, a pair of sequences per workgroup (rbx_attn_stream.h)
-    static const bool stream_on = [] { const char* e = getenv("RBX_ATTN_STREAM"); return e == nullptr || e[0] != '0'; }();
+    // RBX_ATTN_STREAM: 0 the resident kernels, 1 (default) the streamed f32 tiles, 2 bf16 planes where they apply (7 tiles)
+    static const int stream_mode = [] { const char* e = getenv("RBX_ATTN_STREAM"); return e == nullptr ? 1 : atoi(e); }();
     const int nT = (L + kT - 1) / kT;
-    if (stream_on && causal != 0 && nT >= 3 && nT <= 7) {
+    if (stream_mode == 2 && causal != 0 && nT == 7) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_planes_fwd_kernel<DROP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPlanesLds));
+      const long long pairs = (bh + 1) / 2;
+      hipLaunchKernelGGL((attn_planes_fwd_kernel<DROP>), dim3(static_cast<unsigned>(pairs < kCUs ? pairs : kCUs)), dim3(512),
+                         kPlanesLds, s, q, k, v, L, scale, o, lse, drop, ld, bh);
+      return check_launch("attn_planes_fwd_kernel");
+    }
+    if (stream_mode != 0 && causal != 0 && nT >= 3 && nT <= 7) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_fwd_kernel<DROP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kStreamLds));
       hipLaunchKernelGGL((attn_stream_fwd_kernel<DROP>), dim3(static_cast<unsigned>((bh + 1) / 2)), dim3((nT + 1) * 64),

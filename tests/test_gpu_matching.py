@@ -824,7 +824,8 @@ def test_streamed_attention_forward_pairs_of_sequences_vs_float64(L, BH):
 
 def test_streamed_and_resident_attention_forward_agree():
     """RBX_ATTN_STREAM=0 (read once by the library: a child process) keeps the resident kernels for the shapes the streamed
-    forward serves: the two forms agree to rounding on the same seeded inputs, with and without dropout (same mask words)."""
+    forward serves, 2 selects the bf16-plane form (rbx_attn_planes.h; 7 key tiles): the three forms agree to rounding on
+    the same seeded inputs, with and without dropout (same mask words)."""
     import os
     import subprocess
     import sys
@@ -839,7 +840,7 @@ def test_streamed_and_resident_attention_forward_agree():
     import tempfile
     outs = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for form in ("0", "1"):
+        for form in ("0", "1", "2"):
             path = os.path.join(tmp, "o%s.pt" % form)
             env = dict(os.environ, RBX_ATTN_STREAM=form)
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300,
@@ -847,6 +848,9 @@ def test_streamed_and_resident_attention_forward_agree():
             outs[form] = torch.load(path)
     assert_close(outs["1"]["o"], outs["0"]["o"], 2e-6, "streamed vs resident forward")
     assert_close(outs["1"]["od"], outs["0"]["od"], 4e-6, "streamed vs resident forward, dropout 0.25")
+    # RBX_ATTN_STREAM=2 (opt-in): K / V tiles as bf16 planes split once per tile, column fragments by ds_read_b64_tr_b16
+    assert_close(outs["2"]["o"], outs["0"]["o"], 2e-6, "bf16-plane vs resident forward")
+    assert_close(outs["2"]["od"], outs["0"]["od"], 4e-6, "bf16-plane vs resident forward, dropout 0.25")
     assert not torch.equal(outs["1"]["od"], outs["1"]["o"])
 
 
