@@ -12,7 +12,7 @@
 // probabilities p[r] are ALREADY the B operand of the next product O^T = V^T P^T (B[k][col]: k
 // selected by the half-wave, col = lane & 31) -- register r of S^T feeds MFMA step r of O^T.
 // The per-row operands (K, V, or Q, dO in the second backward phase) sit in LDS as row-major
-// [L][HD + 1] (odd stride: both "lanes = rows" and "lanes = columns" reads are conflict free);
+// [L][HD + kPad] (kPad = 1, odd stride: both "lanes = rows" and "lanes = columns" reads are conflict free);
 // the per-lane operands (the Q / dO / K / V tile of the wave) live in registers.
 //   forward : lane = query.  S^T -> online softmax -> O^T accumulators (rescaled per lane).
 //   backward A (lane = query): S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - D) -> dQ^T += K^T dS^T.
@@ -27,11 +27,18 @@ namespace rbx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kT = 32;                      // tile edge (queries or keys)
+#ifndef RBX_ATTN_PAD
+#define RBX_ATTN_PAD 1     // floats of padding per LDS row of the resident kernels: 1 = odd pitch, scalar LDS accesses; 4 = 16-byte
+#endif                     // aligned rows: b128 stores when a block is staged, b128 loads of a lane's row in tile_dot (a quarter
+                           // of the LDS instructions of a tile_dot).  Measured, profiles/r04/INDEX.md: dQ kernel 555 vs 567 us,
+                           // dK | dV 661 vs 663, resident forward 427 vs 408 (spills): the LDS round trips are not what these
+                           // kernels wait for.
+constexpr int kPad = RBX_ATTN_PAD;
 constexpr int kAttnThreads = 512;           // 8 wavefronts: two per SIMD, so one hides the other's MFMA / LDS latency
 
 __device__ __forceinline__ int tile_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// [rows][HD] global -> LDS [rows_pad][HD + 1], scaled, zero beyond `rows`.  float4 global reads, four
+// [rows][HD] global -> LDS [rows_pad][HD + kPad], scaled, zero beyond `rows`.  float4 global reads, four
 // in flight per thread (one workgroup per CU: nothing else hides this latency); the odd LDS row stride
 // forces scalar LDS writes.
 template <int HD>
@@ -53,8 +60,12 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, const lo
       const int i = i0 + u * kAttnThreads;
       if (i < total) {
         const int r = i / Q4, d = (i - r * Q4) * 4;
-        float* dst = lds + r * (HD + 1) + d;
-        dst[0] = v[u].x * scale; dst[1] = v[u].y * scale; dst[2] = v[u].z * scale; dst[3] = v[u].w * scale;
+        float* dst = lds + r * (HD + kPad) + d;
+        if constexpr (kPad == 4) {
+          *reinterpret_cast<float4*>(dst) = make_float4(v[u].x * scale, v[u].y * scale, v[u].z * scale, v[u].w * scale);
+        } else {
+          dst[0] = v[u].x * scale; dst[1] = v[u].y * scale; dst[2] = v[u].z * scale; dst[3] = v[u].w * scale;
+        }
       }
     }
   }
@@ -89,8 +100,12 @@ __device__ __forceinline__ void commit_rows(float* __restrict__ lds, int rows, i
     if (i < total) {
       const int r = i / Q4, d = (i - r * Q4) * 4;
       const float k = r < rows ? scale : 0.f;
-      float* dst = lds + r * (HD + 1) + d;
-      dst[0] = v[u][0] * k; dst[1] = v[u][1] * k; dst[2] = v[u][2] * k; dst[3] = v[u][3] * k;
+      float* dst = lds + r * (HD + kPad) + d;
+      if constexpr (kPad == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[u][0] * k, v[u][1] * k, v[u][2] * k, v[u][3] * k);
+      } else {
+        dst[0] = v[u][0] * k; dst[1] = v[u][1] * k; dst[2] = v[u][2] * k; dst[3] = v[u][3] * k;
+      }
     }
   }
 }
@@ -222,7 +237,7 @@ __device__ __forceinline__ void make_op(const float (&reg)[HD / 2], TileOp<HD, X
 template <int HD, bool X6>
 __device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, int row0, const TileOp<HD, X6>& op) {
   const int lane = threadIdx.x & 63;
-  const float* a = rows_lds + (row0 + (lane & 31)) * (HD + 1) + (lane >> 5) * (HD / 2);
+  const float* a = rows_lds + (row0 + (lane & 31)) * (HD + kPad) + (lane >> 5) * (HD / 2);
   // two accumulator chains (even / odd k steps): a single chain makes every MFMA wait for the previous one
   f32x16 acc, acc1;
 #pragma unroll
@@ -231,9 +246,23 @@ __device__ __forceinline__ f32x16 tile_dot(const float* __restrict__ rows_lds, i
 #pragma unroll
     for (int s = 0; s < HD / 16; ++s) {
       float x[8];
+      if constexpr (kPad == 4) {
+        const float4 u0 = *reinterpret_cast<const float4*>(a + 8 * s), u1 = *reinterpret_cast<const float4*>(a + 8 * s + 4);
+        x[0] = u0.x; x[1] = u0.y; x[2] = u0.z; x[3] = u0.w; x[4] = u1.x; x[5] = u1.y; x[6] = u1.z; x[7] = u1.w;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = a[8 * s + e];
+        for (int e = 0; e < 8; ++e) x[e] = a[8 * s + e];
+      }
       mfma6(acc, acc1, split8(x), op.p[s]);
+    }
+  } else if constexpr (kPad == 4) {
+#pragma unroll
+    for (int s = 0; s < HD / 2; s += 4) {
+      const float4 u = *reinterpret_cast<const float4*>(a + s);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, op.v[s], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, op.v[s + 1], acc1, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, op.v[s + 2], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, op.v[s + 3], acc1, 0, 0, 0);
     }
   } else {
 #pragma unroll
@@ -265,7 +294,7 @@ __device__ __forceinline__ void tile_accumulate(const float* __restrict__ rows_l
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = rows_lds[(row0 + tile_row(8 * s + e, half)) * (HD + 1) + dt * 32 + li];
+      for (int e = 0; e < 8; ++e) x[e] = rows_lds[(row0 + tile_row(8 * s + e, half)) * (HD + kPad) + dt * 32 + li];
       a[dt] = split8(x);
     }
     if constexpr (HD == 64) {
@@ -282,7 +311,7 @@ __device__ __forceinline__ void tile_accumulate(const float* __restrict__ rows_l
   } else {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float* a = rows_lds + (row0 + tile_row(r, half)) * (HD + 1) + li;
+    const float* a = rows_lds + (row0 + tile_row(r, half)) * (HD + kPad) + li;
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt) out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt * 32], w[r], out[dt], 0, 0, 0);
   }
@@ -401,10 +430,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_fwd_kernel(const float
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Ks = lds;
-  float* Vs = lds + Lp * (HD + 1);
+  float* Vs = lds + Lp * (HD + kPad);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   const WavePlan pl = wave_plan(nT, wid, causal, split);
-  float* slot = (split == 1 ? Vs + Lp * (HD + 1) : lds) + pl.simd * merge_floats<HD>();
+  float* slot = (split == 1 ? Vs + Lp * (HD + kPad) : lds) + pl.simd * merge_floats<HD>();
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
   constexpr bool PF = NPF > 0;
@@ -581,7 +610,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Ks = lds;
-  float* Vs = lds + Lp * (HD + 1);
+  float* Vs = lds + Lp * (HD + kPad);
   const long long bh = blockIdx.x;
   Q += attn_base(bh, ld.heads, L, ld.q, HD);
   K += attn_base(bh, ld.heads, L, ld.k, HD);
@@ -676,8 +705,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
   extern __shared__ float lds[];
   const int nT = (L + kT - 1) / kT, Lp = nT * kT;
   float* Qs = lds;                          // scale * Q
-  float* Gs = Qs + Lp * (HD + 1);           // dO
-  float* Ls = Gs + Lp * (HD + 1);           // lse[Lp]
+  float* Gs = Qs + Lp * (HD + kPad);           // dO
+  float* Ls = Gs + Lp * (HD + kPad);           // lse[Lp]
   float* Ds = Ls + Lp;                      // D[Lp]
   const long long bh = blockIdx.x;
   Q += attn_base(bh, ld.heads, L, ld.q, HD);
@@ -791,7 +820,7 @@ namespace rbx {
 
 // heavy tiles dealt to both wavefronts of their SIMD (wave_plan): causal sequences of at least three tiles (below that no
 // tile is two steps heavier than its partner); RBX_ATTN_SPLIT=0 keeps one wavefront per tile.  The four merge slots fit in
-// the operand rows they reuse: 4 * (32 HD + 128) floats <= 2 * 96 * (HD + 1) for HD = 32 and 64.
+// the operand rows they reuse: 4 * (32 HD + 128) floats <= 2 * 96 * (HD + kPad) for HD = 32 and 64.
 static bool attn_split(int L, int causal) {
   static const bool on = [] { const char* e = getenv("RBX_ATTN_SPLIT"); return e == nullptr || e[0] != '0'; }();
   return on && causal != 0 && L > 2 * kT;
@@ -800,7 +829,7 @@ static bool attn_split(int L, int causal) {
 template <int HD>
 static size_t lds_bytes(int L, bool phase_b) {
   const int Lp = (L + kT - 1) / kT * kT;
-  return (static_cast<size_t>(2) * Lp * (HD + 1) + (phase_b ? 2 * Lp : 0)) * sizeof(float);
+  return (static_cast<size_t>(2) * Lp * (HD + kPad) + (phase_b ? 2 * Lp : 0)) * sizeof(float);
 }
 
 template <int HD, bool DROP>
