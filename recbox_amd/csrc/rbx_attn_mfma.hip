@@ -71,6 +71,56 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ g, const lo
   }
 }
 
+// Two blocks of a long sequence at once (more than 6 x 512 float4 each: head_dim 64, L > 192): all 16 requests of a thread in
+// flight before the first LDS write, at clamped addresses with no branch around a load.  stage_rows above keeps four in flight
+// and staged K, then V: four dependent round trips per sequence -- 63-71 us of the backward kernels' 566 / 666 us
+// (profiles/r04/attn_bwd_parts.txt) with one workgroup per CU and nothing else to hide them.
+template <int HD>
+__device__ __forceinline__ void stage_rows_pair(const float* __restrict__ ga, const long long lda, float* __restrict__ la,
+                                                const float sa, const float* __restrict__ gb, const long long ldb,
+                                                float* __restrict__ lb, const float sb, int rows, int rows_pad) {
+  constexpr int Q4 = HD / 4, N = 8;
+  const int total = rows_pad * Q4;
+  float4 va[N], vb[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    int i = threadIdx.x + u * kAttnThreads;
+    i = i < total ? i : total - 1;
+    int r = i / Q4;
+    const int c = (i - r * Q4) * 4;
+    r = r < rows ? r : rows - 1;
+    va[u] = *reinterpret_cast<const float4*>(ga + r * lda + c);
+    vb[u] = *reinterpret_cast<const float4*>(gb + r * ldb + c);
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u) {
+    const int i = threadIdx.x + u * kAttnThreads;
+    if (i < total) {
+      const int r = i / Q4, d = (i - r * Q4) * 4;
+      const float ka = r < rows ? sa : 0.f, kb = r < rows ? sb : 0.f;
+      float* da = la + r * (HD + kPad) + d;
+      float* db = lb + r * (HD + kPad) + d;
+      da[0] = va[u].x * ka; da[1] = va[u].y * ka; da[2] = va[u].z * ka; da[3] = va[u].w * ka;
+      db[0] = vb[u].x * kb; db[1] = vb[u].y * kb; db[2] = vb[u].z * kb; db[3] = vb[u].w * kb;
+    }
+  }
+}
+#ifndef RBX_ATTN_STAGE_PAIR
+#define RBX_ATTN_STAGE_PAIR 1
+#endif
+template <int HD>
+__device__ __forceinline__ void stage_two(const float* __restrict__ ga, const long long lda, float* __restrict__ la, const float sa,
+                                          const float* __restrict__ gb, const long long ldb, float* __restrict__ lb,
+                                          const float sb, int rows, int rows_pad) {
+  const int total = rows_pad * (HD / 4);
+  if (RBX_ATTN_STAGE_PAIR && total > 6 * kAttnThreads && total <= 8 * kAttnThreads) {
+    stage_rows_pair<HD>(ga, lda, la, sa, gb, ldb, lb, sb, rows, rows_pad);
+  } else {
+    stage_rows<HD>(ga, lda, la, rows, rows_pad, sa);
+    stage_rows<HD>(gb, ldb, lb, rows, rows_pad, sb);
+  }
+}
+
 // The same block of the NEXT sequence, fetched into registers while the current one is being computed (a workgroup that
 // loops over sequences: one workgroup per CU means nothing else hides these loads -- the forward at L = 200 spent about as
 // long waiting for K and V as multiplying them).  Issued as inline assembly so that the compiler cannot sink the loads to
@@ -132,11 +182,31 @@ __device__ __forceinline__ void load_tile_regs(const float* __restrict__ g, cons
   }
 }
 
+// the same tile with NO arithmetic on the loaded values and rows beyond `rows` read from row rows - 1 (finite values that the
+// masks of the backward kernels keep out of every result): nothing uses the registers here, so the loads stay in flight until
+// their first use -- the backward kernels request their first tile BEFORE they stage the sequence's rows into LDS.
+template <int HD>
+__device__ __forceinline__ void load_tile_clamped(const float* __restrict__ g, const long long ld, int row0, int rows,
+                                                  float (&reg)[HD / 2]) {
+  const int lane = threadIdx.x & 63;
+  int row = row0 + (lane & 31);
+  row = row < rows ? row : rows - 1;
+  const float4* src = reinterpret_cast<const float4*>(g + static_cast<long long>(row) * ld + (lane >> 5) * (HD / 2));
+#pragma unroll
+  for (int q = 0; q < HD / 8; ++q) {
+    const float4 v = src[q];
+    reg[4 * q] = v.x; reg[4 * q + 1] = v.y; reg[4 * q + 2] = v.z; reg[4 * q + 3] = v.w;
+  }
+}
+#ifndef RBX_ATTN_EARLY_TILE
+#define RBX_ATTN_EARLY_TILE 0   // backward kernels: 1 = the first job's own tiles are requested in front of the staging (measured slower)
+#endif
+
 #ifndef RBX_ATTN_QFIRST
 #define RBX_ATTN_QFIRST 1  // looping forward kernel: the K / V prefetch is issued once the wavefront's Q tile has arrived
 #endif
 #ifndef RBX_ATTN_ABL
-#define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T, 8 = the Q tile loads, 16 = the stores of unsplit tiles
+#define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T, 8 = the Q tile loads, 16 = the stores of unsplit tiles; the backward kernels without 32 = the staging of a sequence's rows, 64 = the loads of a wavefront's own tiles
 #endif
 #ifndef RBX_ATTN_BF16X6
 #define RBX_ATTN_BF16X6 44 // which tile products run on the bf16 matrix cores, operands split three ways: bits 0, 1 the forward
@@ -618,23 +688,40 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_q_kernel(const flo
   O += attn_base(bh, ld.heads, L, ld.o, HD);
   dO += attn_base(bh, ld.heads, L, ld.go, HD);
   dQ += attn_base(bh, ld.heads, L, ld.dq, HD);
-  stage_rows<HD>(K, ld.k, Ks, L, Lp, 1.0f);
-  stage_rows<HD>(V, ld.v, Vs, L, Lp, 1.0f);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+  const WavePlan pl = wave_plan(nT, wid, causal, split);
+  // The wavefront's own tiles (Q, dO, O rows of its query tile).  Alone the kernel ran 566 us; 495 without the staging below,
+  // 426 without these loads, 337 without both (profiles/r04/attn_bwd_parts.txt): exposed round trips, one workgroup per CU.
+  // The branch-free loader took 24 us of that; requesting the first job's tiles in FRONT of the staging
+  // (RBX_ATTN_EARLY_TILE=1) keeps 96 registers live across it and spills (702 us).
+  float qreg[HD / 2], greg[HD / 2], oreg[HD / 2];
+  auto load_job = [&](const int jb) {
+    const int r0 = pl.tile(jb) * kT;
+    if constexpr ((RBX_ATTN_ABL & 64) != 0) {                // (... and without its own tiles' loads)
+#pragma unroll
+      for (int q = 0; q < HD / 2; ++q) { qreg[q] = 0.01f * q + lane; greg[q] = 0.02f * q; oreg[q] = 0.5f; }
+    } else {
+      load_tile_clamped<HD>(Q, ld.q, r0, L, qreg);
+      load_tile_clamped<HD>(dO, ld.go, r0, L, greg);
+      load_tile_clamped<HD>(O, ld.o, r0, L, oreg);
+    }
+  };
+  if (RBX_ATTN_EARLY_TILE && pl.n > 0) load_job(0);
+  if constexpr ((RBX_ATTN_ABL & 32) == 0) {                 // (profiles/ubench/attn_stream.hip: the kernel without its staging)
+    stage_two<HD>(K, ld.k, Ks, 1.0f, V, ld.v, Vs, 1.0f, L, Lp);
+  }
+  __syncthreads();
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
-  const WavePlan pl = wave_plan(nT, wid, causal, split);
   f32x16 dq[HD / 32];
   int i0 = 0;
   for (int jb = 0; jb < pl.n; ++jb) {
     const int qt = pl.tile(jb);
     i0 = qt * kT;
     const int qi = i0 + li;
-    float qreg[HD / 2], greg[HD / 2], oreg[HD / 2];
-    load_tile_regs<HD>(Q, ld.q, i0, L, scale, qreg);
-    load_tile_regs<HD>(dO, ld.go, i0, L, 1.0f, greg);
-    load_tile_regs<HD>(O, ld.o, i0, L, 1.0f, oreg);
+    if (!RBX_ATTN_EARLY_TILE || jb > 0) load_job(jb);
+#pragma unroll
+    for (int q = 0; q < HD / 2; ++q) qreg[q] *= scale;
     float Di = 0.f;
 #pragma unroll
     for (int s = 0; s < HD / 2; ++s) Di += greg[s] * oreg[s];
@@ -715,26 +802,37 @@ __global__ __launch_bounds__(kAttnThreads) void attn_mfma_bwd_kv_kernel(const fl
   dO += attn_base(bh, ld.heads, L, ld.go, HD);
   dK += attn_base(bh, ld.heads, L, ld.dk, HD);
   dV += attn_base(bh, ld.heads, L, ld.dv, HD);
-  stage_rows<HD>(Q, ld.q, Qs, L, Lp, scale);
-  stage_rows<HD>(dO, ld.go, Gs, L, Lp, 1.0f);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
+  const WavePlan pl = wave_plan(nT, wid, causal, split);
+  float kreg[HD / 2], vreg[HD / 2];                          // the wavefront's own K and V tile (as in the dQ kernel: 666 us
+  auto load_job = [&](const int jb) {                        //  alone, 603 / 596 / 508 without the staging / these loads / both)
+    const int r0 = (nT - 1 - pl.tile(jb)) * kT;
+    if constexpr ((RBX_ATTN_ABL & 64) != 0) {
+#pragma unroll
+      for (int q = 0; q < HD / 2; ++q) { kreg[q] = 0.01f * q + lane; vreg[q] = 0.02f * q; }
+    } else {
+      load_tile_clamped<HD>(K, ld.k, r0, L, kreg);
+      load_tile_clamped<HD>(V, ld.v, r0, L, vreg);
+    }
+  };
+  if (RBX_ATTN_EARLY_TILE && pl.n > 0) load_job(0);
+  if constexpr ((RBX_ATTN_ABL & 32) == 0) {
+    stage_two<HD>(Q, ld.q, Qs, scale, dO, ld.go, Gs, 1.0f, L, Lp);
+  }
   for (int i = threadIdx.x; i < Lp; i += blockDim.x) {
     Ls[i] = (i < L) ? LSE[bh * L + i] : 0.f;
     Ds[i] = (i < L) ? Dv[bh * L + i] : 0.f;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 31, half = lane >> 5;
   unsigned dk0 = 0, dk1 = 0;
   if (DROP) drop_seed(drop, &dk0, &dk1);
-  const WavePlan pl = wave_plan(nT, wid, causal, split);
   f32x16 dk[HD / 32], dv[HD / 32];
   int j0 = 0;
   for (int jb = 0; jb < pl.n; ++jb) {
     const int jt = nT - 1 - pl.tile(jb);            // (key tile jt meets nT - jt query tiles: cost index nT - 1 - jt)
     j0 = jt * kT;
     const int kj = j0 + li;
-    float kreg[HD / 2], vreg[HD / 2];
-    load_tile_regs<HD>(K, ld.k, j0, L, 1.0f, kreg);
-    load_tile_regs<HD>(V, ld.v, j0, L, 1.0f, vreg);
+    if (!RBX_ATTN_EARLY_TILE || jb > 0) load_job(jb);
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
