@@ -158,6 +158,40 @@ struct Frag {
     }
   }
   __device__ __forceinline__ void add_from(const float* row, int dim, int lane_g) { fma_from(row, dim, lane_g, 1.0f); }
+  // The row as it is: no arithmetic on the loaded values and no branch around a load -- lanes beyond `dim` re-read the row's
+  // last vector (every consumer stores lanes below `dim` only).  fma_from's `if (e < dim) a += w * load` is a branch per load
+  // with the wait for it inside: a batch of U lookups written with it is U dependent round trips (segment_reduce_kernel).
+  __device__ __forceinline__ void load_from(const float* row, int dim, int lane_g) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      int e = (lane_g + u * G) * W;
+      e = e < dim ? e : dim - W;
+      if constexpr (VEC) {
+        const float4 t = *reinterpret_cast<const float4*>(row + e);
+        a[u * 4 + 0] = t.x; a[u * 4 + 1] = t.y; a[u * 4 + 2] = t.z; a[u * 4 + 3] = t.w;
+      } else {
+        a[u] = row[e];
+      }
+    }
+  }
+  __device__ __forceinline__ void load_from_nt(const float* row, int dim, int lane_g) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      int e = (lane_g + u * G) * W;
+      e = e < dim ? e : dim - W;
+      if constexpr (VEC) {
+        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(row + e));
+        a[u * 4 + 0] = t.x; a[u * 4 + 1] = t.y; a[u * 4 + 2] = t.z; a[u * 4 + 3] = t.w;
+      } else {
+        a[u] = __builtin_nontemporal_load(row + e);
+      }
+    }
+  }
+  __device__ __forceinline__ void scale(float w) {
+#pragma unroll
+    for (int i = 0; i < NV * W; ++i) a[i] *= w;
+  }
   // streaming variants: rows that are touched once per call should not evict the L2-resident
   // gather operands (S, g), so they use the non-temporal cache policy
   __device__ __forceinline__ void add_from_nt(const float* row, int dim, int lane_g) {

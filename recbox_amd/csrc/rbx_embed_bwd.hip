@@ -563,6 +563,25 @@ struct GenericPolicy {
   static __device__ __forceinline__ void prefetch(const Args& a, const RedField& fd, unsigned row, int lane_g, F& pre) {
     if (a.accumulate) pre.add_from(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);   // old grad (RMW)
   }
+  // the two-phase form (segment_reduce_kernel): loads only, then frag *= weight(w)
+  template <class F>
+  static __device__ __forceinline__ void fetch(const Args& a, const RedField& fd, unsigned local, int lane_g, F& frag, float& w) {
+    const unsigned L = static_cast<unsigned>(fd.seq_len);
+    const unsigned b = local / L;
+    const unsigned l = local - b * L;
+    const long long brow = (a.index != nullptr) ? static_cast<long long>(a.index[b]) : static_cast<long long>(b);
+    const float* src = a.dout + brow * a.stride_b + fd.out_off +
+                       (fd.pool == RBX_POOL_CONCAT ? static_cast<long long>(l) * fd.dim : 0ll);
+    w = 1.0f;
+    if (fd.pool == RBX_POOL_MEAN_VALUE || fd.pool == RBX_POOL_MEAN_ID)
+      w = a.row_scale[static_cast<long long>(fd.slot) * a.B + b];
+    frag.load_from(src, fd.dim, lane_g);
+  }
+  static __device__ __forceinline__ float weight(const Args&, float w) { return w; }
+  template <class F>
+  static __device__ __forceinline__ void prefetch_raw(const Args& a, const RedField& fd, unsigned row, int lane_g, F& pre) {
+    if (a.accumulate) pre.load_from(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);   // old grad (RMW)
+  }
   template <class F>
   static __device__ __forceinline__ void flush(const Args&, const RedField& fd, unsigned row, const F& acc, float,
                                                const F& pre, int lane_g) {

@@ -285,6 +285,19 @@ struct FmPolicy {
     if (!(RBX_ABL & 2) && fd.grad != nullptr)
       pre.add_from_nt(fd.table + static_cast<size_t>(row) * fd.table_stride, fd.dim, lane_g);   // w_r
   }
+  // the two-phase form of contribute / prefetch (segment_reduce_kernel): loads only, then frag *= weight(w)
+  template <class F>
+  static __device__ __forceinline__ void fetch(const Args& a, const RedField& fd, unsigned local, int lane_g, F& frag, float& w) {
+    w = a.g[local];
+    if (!(RBX_ABL & 4) && a.ssum != nullptr) frag.load_from(a.ssum + static_cast<size_t>(local) * a.D, fd.dim, lane_g);
+    else frag.zero();
+  }
+  static __device__ __forceinline__ float weight(const Args&, float w) { return w; }
+  template <class F>
+  static __device__ __forceinline__ void prefetch_raw(const Args&, const RedField& fd, unsigned row, int lane_g, F& pre) {
+    if (!(RBX_ABL & 2) && fd.grad != nullptr)
+      pre.load_from_nt(fd.table + static_cast<size_t>(row) * fd.table_stride, fd.dim, lane_g);   // w_r
+  }
   template <class F>
   static __device__ __forceinline__ void flush(const Args& a, const RedField& fd, unsigned row, const F& acc, float cnt,
                                                const F& pre, int lane_g) {

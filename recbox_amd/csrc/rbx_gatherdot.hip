@@ -212,6 +212,20 @@ struct DotPolicy {
   static __device__ __forceinline__ void prefetch(const Args& a, const RedField& fd, unsigned row, int lane_g, F& pre) {
     if (a.accumulate) pre.add_from(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);
   }
+  // the two-phase form (segment_reduce_kernel): loads only, then frag *= weight(w)
+  template <class F>
+  static __device__ __forceinline__ void fetch(const Args& a, const RedField& fd, unsigned local, int lane_g, F& frag, float& w) {
+    const unsigned L = static_cast<unsigned>(fd.seq_len);
+    const unsigned r = local / L;
+    const unsigned l = local - r * L;
+    w = a.g[static_cast<long long>(r) * a.n_out + a.col0[fd.slot] + l];
+    frag.load_from(a.x + static_cast<long long>(r) * a.xs, fd.dim, lane_g);
+  }
+  static __device__ __forceinline__ float weight(const Args& a, float w) { return a.scale * w; }
+  template <class F>
+  static __device__ __forceinline__ void prefetch_raw(const Args& a, const RedField& fd, unsigned row, int lane_g, F& pre) {
+    if (a.accumulate) pre.load_from(fd.grad + static_cast<size_t>(row) * fd.dim, fd.dim, lane_g);
+  }
   template <class F>
   static __device__ __forceinline__ void flush(const Args&, const RedField& fd, unsigned row, const F& acc, float,
                                                const F& pre, int lane_g) {

@@ -99,6 +99,40 @@ __global__ __launch_bounds__(256, RBX_REDUCE_WAVES) void segment_reduce_kernel(c
     kk[U] = (i0 + U < e) ? keys[i0 + U] : key_after;          // key that follows the batch
     F rows[U], pre[U];
     float rc[U];
+#ifndef RBX_REDUCE_BATCHED
+#define RBX_REDUCE_BATCHED 1
+#endif
+#if RBX_REDUCE_BATCHED
+    // Every load of the batch first, with NO use in between, then the arithmetic.  Written as "if (valid) rows[u] += w * load"
+    // the batch was U dependent round trips: the compiler waits for a load inside the block that uses it (the ISA of the first
+    // form: load, s_waitcnt vmcnt(0), eight times over).  The loads stay under `valid` -- a padding entry of the sharded
+    // stores' exchange buffers carries no lookup whose addresses could be read -- which costs a branch but no wait.
+    float wu[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rows[u].zero();
+      wu[u] = 0.f;
+      if (kk[u] != sentinel && i0 + u < e)
+        Policy::fetch(args, sf[vv[u] >> kLocalBits], vv[u] & kLocalMask, lane_g, rows[u], wu[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      pre[u].zero();
+      if (kk[u] != sentinel && i0 + u < e) {
+        // a run ends after this lookup: fetch what flush() will need NOW (raw: nothing here uses it), so that the random
+        // row read overlaps the other loads of the batch instead of serialising the walk
+        const unsigned nxt = (i0 + u + 1 < e) ? kk[u + 1] : key_after;
+        if (nxt != kk[u]) Policy::prefetch_raw(args, sf[vv[u] >> kLocalBits], kk[u] - sf[vv[u] >> kLocalBits].row_base, lane_g, pre[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool valid = kk[u] != sentinel && i0 + u < e;
+      const float w = Policy::weight(args, wu[u]);
+      if (valid) rows[u].scale(w); else rows[u].zero();
+      rc[u] = (valid && Policy::kHasCount) ? w : 0.f;
+    }
+#else
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       rows[u].zero();
@@ -113,6 +147,7 @@ __global__ __launch_bounds__(256, RBX_REDUCE_WAVES) void segment_reduce_kernel(c
         if (nxt != kk[u]) Policy::prefetch(args, fd, kk[u] - fd.row_base, lane_g, pre[u]);
       }
     }
+#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (i0 + u >= e) break;
