@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 118          /* 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 119          /* 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -778,6 +778,25 @@ int rbx_pool_fwd(const float* d_emb, const float* d_mask, int64_t batch, int32_t
                  int32_t numer_masked, int32_t denom, float eps, float* d_out, float* d_inv, void* stream);
 int rbx_pool_bwd(const float* d_dout, const float* d_mask, const float* d_inv, int64_t batch, int32_t seq_len,
                  int32_t dim, int32_t numer_masked, float* d_demb, void* stream);
+
+/* ---- the row-local chains of a SASRec block as single passes over [m, 64] ------------------------------------------
+ * third_party/rechub/models/matching/sasrec.py:81-94 (one block of seq_forward) and :110-124 (PointWiseFeedForward).
+ * Everything of a block except the attention is local to a row of the [B L, 64] activation; these entry points carry a
+ * 32-row slab through the whole chain in registers (csrc/rbx_seqblock.hip) instead of one pass per LayerNorm /
+ * projection / residual.  embed_dim is 64 (cfg 5); all activations contiguous with 16-byte aligned bases; biases and
+ * LayerNorm parameters may be NULL (0 / 1).
+ *   rbx_seqblock_qkv_fwd:  q = LayerNorm(x) (mean, rstd written); Q = q Wq^T + bq; KV[:, :64] = x Wk^T + bk;
+ *                          KV[:, 64:] = x Wv^T + bv, in_w [192, 64] / in_b [192] = nn.MultiheadAttention's in_proj.
+ *   rbx_seqblock_ffn_fwd:  with d_attn != NULL first x = res + attn Wo^T + bo (WRITTEN to d_x: `Q + mha_outputs`),
+ *                          otherwise d_x is the input; then n = LayerNorm(x) (written to d_n unless NULL),
+ *                          h = relu(n W1^T + b1), out = (n + h W2^T + b2) * keep[row] (keep NULL: 1). */
+int rbx_seqblock_qkv_fwd(const float* d_x, int64_t m, const float* d_ln_w, const float* d_ln_b, float eps,
+                         const float* d_in_w, const float* d_in_b, float* d_mean, float* d_rstd, float* d_q, float* d_Q,
+                         float* d_KV, void* stream);
+int rbx_seqblock_ffn_fwd(const float* d_attn, const float* d_res, const float* d_wo, const float* d_bo, float* d_x, int64_t m,
+                         const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w1, const float* d_b1,
+                         const float* d_w2, const float* d_b2, const float* d_keep, float* d_mean, float* d_rstd, float* d_n,
+                         float* d_h, float* d_out, void* stream);
 
 #ifdef __cplusplus
 }

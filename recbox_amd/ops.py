@@ -63,6 +63,9 @@ class config(object):
     # SASRec blocks as two autograd nodes (attention sub-layer, feed-forward sub-layer) whose residual adds, timeline mask, ReLU
     # backward and gradient sums run in GEMM epilogues instead of passes of their own (ops.sasrec_attention_sublayer / _ffn_)
     fuse_sublayers = os.environ.get("RECBOX_AMD_FUSE_SUBLAYERS", "1") != "0"
+    # a SASRec block (embed_dim 64, no FFN dropout) as ONE autograd node whose row-local chains are single passes
+    # (csrc/rbx_seqblock.hip: LayerNorm + in-projections; out-projection + residual + LayerNorm + FFN + residual + mask)
+    seqblock_chains = os.environ.get("RECBOX_AMD_SEQBLOCK", "1") != "0"
     # DeepFM: the tower's first Linear, the FM term and the first-order Linear over one gathered block as one autograd node
     # (ops.deepfm_input_stage): the block's gradient comes out of the tower's dx GEMM instead of four kernels
     fuse_deepfm_input = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_INPUT", "1") != "0"
@@ -3015,6 +3018,111 @@ def sasrec_ffn_sublayer(e, norm, w1, b1, w2, b2, keep, keep_is_mask=False):
     ``keep_is_mask``: every value of keep is 0 or 1 (SASRec's ``~timeline_mask``; implied by a bool tensor) -- the backward then
     scales rows inside its GEMMs instead of in a pass of its own."""
     return _FfnSublayer.apply(e, norm.weight, norm.bias, float(norm.eps), w1, b1, w2, b2, keep, keep_is_mask)
+
+
+class _SeqBlock(torch.autograd.Function):
+    """One SASRec block (sasrec.py:81-92) on [B, L, 64] without FFN dropout as ONE autograd node.  Forward: rbx_seqblock_qkv_fwd
+    (LayerNorm + the three in-projections), the packed attention, rbx_seqblock_ffn_fwd (out-projection + residual + LayerNorm +
+    conv1 + ReLU + conv2 + residual + timeline mask): 3 launches where the two sub-layer nodes took 8."""
+
+    @staticmethod
+    def forward(ctx, e, ln1_w, ln1_b, eps1, in_w, in_b, out_w, out_b, heads, p_drop, seed, ln2_w, ln2_b, eps2, w1, b1, w2, b2,
+                keep):
+        _require_cuda(e, "sequence block")
+        B, L, E = e.shape
+        M = B * L
+        dev = e.device
+        x2 = e.contiguous().float().view(M, E)
+        in_w, out_w, w1, w2 = in_w.contiguous(), out_w.contiguous(), w1.contiguous(), w2.contiguous()
+        k1 = keep.contiguous().float().view(-1)
+        hd = E // heads
+        f32 = dict(dtype=torch.float32, device=dev)
+        q, Q, KV = torch.empty((M, E), **f32), torch.empty((M, E), **f32), torch.empty((M, 2 * E), **f32)
+        mean1, rstd1 = torch.empty(M, **f32), torch.empty(M, **f32)
+        check(lib.rbx_seqblock_qkv_fwd(_ptr(x2), M, _ptr(ln1_w), _ptr(ln1_b), eps1, _ptr(in_w), _ptr(in_b), _ptr(mean1),
+                                       _ptr(rstd1), _ptr(q), _ptr(Q), _ptr(KV), _stream()))
+        O = torch.empty((M, E), **f32)
+        lse = torch.empty((B * heads, L), **f32)
+        tick = dropout_tick(dev) if p_drop > 0 else None
+        scale = hd ** -0.5
+        kptr = ctypes.c_void_p(KV.data_ptr())
+        vptr = ctypes.c_void_p(KV.data_ptr() + 4 * E)
+        check(lib.rbx_attn_packed_fwd(_ptr(Q), E, kptr, 2 * E, vptr, 2 * E, B, heads, L, hd, float(scale), 1, float(p_drop),
+                                      int(seed), _ptr(tick), _ptr(O), E, _ptr(lse), _stream()))
+        y, n, h, out = (torch.empty((M, E), **f32) for _ in range(4))
+        mean2, rstd2 = torch.empty(M, **f32), torch.empty(M, **f32)
+        check(lib.rbx_seqblock_ffn_fwd(_ptr(O), _ptr(q), _ptr(out_w), _ptr(out_b), _ptr(y), M, _ptr(ln2_w), _ptr(ln2_b), eps2,
+                                       _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(k1), _ptr(mean2), _ptr(rstd2), _ptr(n),
+                                       _ptr(h), _ptr(out), _stream()))
+        ctx.save_for_backward(x2, ln1_w, mean1, rstd1, q, in_w, Q, KV, O, lse, out_w, y, ln2_w, mean2, rstd2, n, w1, h, w2, k1)
+        ctx.meta = (B, L, E, heads, hd, float(scale), float(p_drop), int(seed), tick, in_b is not None, out_b is not None,
+                    ln1_b is not None, ln2_b is not None, b1 is not None, b2 is not None)
+        return out.view(B, L, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, ln1_w, mean1, rstd1, q, in_w, Q, KV, O, lse, out_w, y, ln2_w, mean2, rstd2, n, w1, h, w2, k1) = ctx.saved_tensors
+        (B, L, E, heads, hd, scale, p_drop, seed, tick, has_in_b, has_out_b, has_ln1_b, has_ln2_b, has_b1, has_b2) = ctx.meta
+        dev = dout.device
+        need = ctx.needs_input_grad
+        f32 = dict(dtype=torch.float32, device=dev)
+        g0 = dout.contiguous().float().view(B * L, E)
+        # ---- feed-forward sub-layer (rows scaled by the 0 / 1 timeline mask inside the GEMMs)
+        dw2 = torch.empty_like(w2) if need[16] else None
+        db2 = torch.empty(E, **f32) if (has_b2 and need[17]) else None
+        dw1 = torch.empty_like(w1) if need[14] else None
+        db1 = torch.empty(E, **f32) if (has_b1 and need[15]) else None
+        _lin_dwdb_scaled(h, g0, k1, dw2, db2)
+        dh = _lin_dx(g0, w2, mask=h, row_scale=k1)
+        _lin_dwdb(n, w1, dh, dw1, db1)
+        dn = _lin_dx(dh, w1, residual=g0, row_scale=k1)
+        want2 = need[11] or (has_ln2_b and need[12])
+        g, dgamma2, dbeta2 = _ln_bwd(y, dn, ln2_w, mean2, rstd2, want2)
+        # ---- attention sub-layer
+        d_out_w = torch.empty_like(out_w) if need[6] else None
+        d_out_b = torch.empty(E, **f32) if (has_out_b and need[7]) else None
+        _lin_dwdb(O, out_w, g, d_out_w, d_out_b)
+        dO = _lin_dx(g, out_w)
+        dQ = torch.empty_like(Q)
+        dKV = torch.empty_like(KV)
+        scratch = torch.empty((B * heads, L), **f32)
+        kptr = ctypes.c_void_p(KV.data_ptr())
+        vptr = ctypes.c_void_p(KV.data_ptr() + 4 * E)
+        dkptr = ctypes.c_void_p(dKV.data_ptr())
+        dvptr = ctypes.c_void_p(dKV.data_ptr() + 4 * E)
+        check(_timed(("attn_bwd", B * heads, L, hd),
+                     lambda: lib.rbx_attn_packed_bwd(_ptr(Q), E, kptr, 2 * E, vptr, 2 * E, _ptr(O), E, _ptr(dO), E, _ptr(lse),
+                                                     B, heads, L, hd, scale, 1, p_drop, seed, _ptr(tick), _ptr(dQ), E, dkptr,
+                                                     2 * E, dvptr, 2 * E, _ptr(scratch), _stream())))
+        d_in_w = torch.empty_like(in_w) if need[4] else None
+        d_in_b = torch.empty(3 * E, **f32) if (has_in_b and need[5]) else None
+        _lin_dwdb(q, in_w[:E], dQ, d_in_w[:E] if d_in_w is not None else None, d_in_b[:E] if d_in_b is not None else None)
+        _lin_dwdb(x2, in_w[E:], dKV, d_in_w[E:] if d_in_w is not None else None, d_in_b[E:] if d_in_b is not None else None)
+        dq = _lin_dx(dQ, in_w[:E], residual=g)
+        want1 = need[1] or (has_ln1_b and need[2])
+        de_ln, dgamma1, dbeta1 = _ln_bwd(x2, dq, ln1_w, mean1, rstd1, want1)
+        de = _lin_dx(dKV, in_w[E:], residual=de_ln) if need[0] else None
+        return (de.view(B, L, E) if de is not None else None, dgamma1 if need[1] else None,
+                dbeta1 if (has_ln1_b and need[2]) else None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None,
+                dgamma2 if need[11] else None, dbeta2 if (has_ln2_b and need[12]) else None, None, dw1, db1, dw2, db2, None)
+
+
+def seqblock_supported(e, mha, ffn_has_dropout, keep_is_mask=True):
+    """The shapes rbx_seqblock_* cover: [B, L, 64] float blocks with the packed attention available, no dropout in the FFN."""
+    if not (config.seqblock_chains and e.dim() == 3 and e.shape[2] == 64 and e.dtype == torch.float32 and e.is_cuda):
+        return False
+    if mha.in_proj_weight is None or mha.embed_dim != 64 or ffn_has_dropout or not keep_is_mask:
+        return False
+    return attention_packed_supported(e.shape[1], 64 // mha.num_heads) and e.shape[0] * e.shape[1] >= 8192
+
+
+def sasrec_block(e, norm1, mha, norm2, w1, b1, w2, b2, keep, dropout_p=0.0, seed=None):
+    """One block of seq_forward (sasrec.py:81-92) for [B, L, 64]; keep [B, L] is the 0 / 1 ``~timeline_mask``."""
+    if dropout_p and seed is None:
+        seed = _draw_seed()
+    return _SeqBlock.apply(e, norm1.weight, norm1.bias, float(norm1.eps), mha.in_proj_weight, mha.in_proj_bias,
+                           mha.out_proj.weight, mha.out_proj.bias, int(mha.num_heads), float(dropout_p or 0.0), int(seed or 0),
+                           norm2.weight, norm2.bias, float(norm2.eps), w1, b1, w2, b2, keep)
 
 
 class _DeepFmInput(torch.autograd.Function):

@@ -194,6 +194,14 @@ class SASRec(torch.nn.Module):
         for i in range(len(self.attention_layers)):
             mha, ffn = self.attention_layers[i], self.forward_layers[i]
             E, H = mha.embed_dim, mha.num_heads
+            ffn_drop = self.training and (ffn.dropout1.p > 0 or ffn.dropout2.p > 0)
+            if ops.config.fuse_sublayers and ops.seqblock_supported(e, mha, ffn_drop):
+                # the whole block as one autograd node: LayerNorm + in-projections, attention, out-projection + residual +
+                # LayerNorm + FFN + residual + mask -- three launches forward (csrc/rbx_seqblock.hip)
+                e = ops.sasrec_block(e, self.attention_layernorms[i], mha, self.forward_layernorms[i],
+                                     ffn.conv1.weight.squeeze(-1), ffn.conv1.bias, ffn.conv2.weight.squeeze(-1), ffn.conv2.bias,
+                                     keep, dropout_p=mha.dropout if self.training else 0.0)
+                continue
             if (ops.config.fuse_sublayers and e.dim() == 3 and mha.in_proj_weight is not None
                     and ops.attention_packed_supported(e.shape[1], E // H)):
                 # LayerNorm, the three projections, the attention and the residual as ONE autograd node: the residual add

@@ -1,0 +1,165 @@
+"""GPU parity of the sequence-block chains (csrc/rbx_seqblock.hip): one SASRec block of
+third_party/rechub/models/matching/sasrec.py:81-92 (+ PointWiseFeedForward :110-124) restated in torch float64 on the CPU
+against the C-ABI entry points and against the one-node block of recbox_amd.ops -- outputs, saved statistics, every
+gradient; full slabs, a ragged last slab and fewer rows than one slab."""
+import copy
+import ctypes
+
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+E = 64
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _params(seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    return dict(ln1_w=torch.rand(E, generator=g) + 0.5, ln1_b=r(E) * 0.1, in_w=r(3 * E, E) * 0.15, in_b=r(3 * E) * 0.1,
+                out_w=r(E, E) * 0.15, out_b=r(E) * 0.1, ln2_w=torch.rand(E, generator=g) + 0.5, ln2_b=r(E) * 0.1,
+                w1=r(E, E) * 0.2, b1=r(E) * 0.1, w2=r(E, E) * 0.2, b2=r(E) * 0.1), g
+
+
+def _ln(x, w, b, eps=1e-8):
+    return torch.nn.functional.layer_norm(x, (E,), w, b, eps)
+
+
+@pytest.mark.parametrize("M", [19, 32, 9000, 20480])
+def test_qkv_chain_vs_float64(M):
+    """rbx_seqblock_qkv_fwd: q = LayerNorm(x), Q = q Wq^T + bq, K | V = x [Wk; Wv]^T + [bk; bv] (sasrec.py:82-84)."""
+    from recbox_amd._lib import lib
+    P, g = _params(1)
+    x = torch.randn(M, E, generator=g)
+    d = {k: v.cuda() for k, v in P.items()}
+    xc = x.cuda()
+    f = lambda *s: torch.full(s, float("nan"), device="cuda")
+    mean, rstd, q, Q, KV = f(M), f(M), f(M, E), f(M, E), f(M, 2 * E)
+    rc = lib.rbx_seqblock_qkv_fwd(_p(xc), M, _p(d["ln1_w"]), _p(d["ln1_b"]), 1e-8, _p(d["in_w"]), _p(d["in_b"]), _p(mean),
+                                  _p(rstd), _p(q), _p(Q), _p(KV), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    x64 = x.double()
+    q64 = _ln(x64, P["ln1_w"].double(), P["ln1_b"].double())
+    assert_close(q, q64, TOL, "q")
+    assert_close(Q, q64 @ P["in_w"][:E].double().t() + P["in_b"][:E].double(), TOL, "Q")
+    assert_close(KV, x64 @ P["in_w"][E:].double().t() + P["in_b"][E:].double(), TOL, "K|V")
+    assert_close(mean, x64.mean(1), TOL, "mean")
+    assert_close(rstd, (x64.var(1, unbiased=False) + 1e-8).rsqrt(), TOL, "rstd")
+
+
+@pytest.mark.parametrize("M,pro,with_n", [(19, True, True), (9000, True, True), (20480, True, False), (9000, False, True),
+                                         (33, False, False)])
+def test_ffn_chain_vs_float64(M, pro, with_n):
+    """rbx_seqblock_ffn_fwd with and without the out-projection prologue; parameters present or NULL."""
+    from recbox_amd._lib import lib
+    P, g = _params(2)
+    attn, res = torch.randn(M, E, generator=g), torch.randn(M, E, generator=g)
+    keep = (torch.rand(M, generator=g) > 0.3).float()
+    d = {k: v.cuda() for k, v in P.items()}
+    attn_c, res_c, keep_c = attn.cuda(), res.cuda(), keep.cuda()          # (held: the entry points take raw pointers)
+    f = lambda *s: torch.full(s, float("nan"), device="cuda")
+    mean, rstd, h, out = f(M), f(M), f(M, E), f(M, E)
+    n = f(M, E) if with_n else None
+    nob = not with_n                                       # the variant without n also runs without biases
+    if pro:
+        x = f(M, E)
+        rc = lib.rbx_seqblock_ffn_fwd(_p(attn_c), _p(res_c), _p(d["out_w"]), None if nob else _p(d["out_b"]), _p(x), M,
+                                      _p(d["ln2_w"]), _p(d["ln2_b"]), 1e-8, _p(d["w1"]), None if nob else _p(d["b1"]),
+                                      _p(d["w2"]), None if nob else _p(d["b2"]), _p(keep_c), _p(mean), _p(rstd), _p(n),
+                                      _p(h), _p(out), None)
+        x64 = res.double() + attn.double() @ P["out_w"].double().t() + (0 if nob else P["out_b"].double())
+        assert_close(x, x64, TOL, "x")
+    else:
+        x = res_c
+        rc = lib.rbx_seqblock_ffn_fwd(None, None, None, None, _p(x), M, None, None, 1e-8, _p(d["w1"]),
+                                      None if nob else _p(d["b1"]), _p(d["w2"]), None if nob else _p(d["b2"]), None, _p(mean),
+                                      _p(rstd), _p(n), _p(h), _p(out), None)
+        x64 = res.double()
+        keep = torch.ones(M)
+    assert rc == 0
+    torch.cuda.synchronize()
+    lw, lb = (P["ln2_w"].double(), P["ln2_b"].double()) if pro else (None, None)
+    n64 = _ln(x64, lw, lb)
+    h64 = torch.relu(n64 @ P["w1"].double().t() + (0 if nob else P["b1"].double()))
+    o64 = (n64 + h64 @ P["w2"].double().t() + (0 if nob else P["b2"].double())) * keep.double().unsqueeze(1)
+    if n is not None:
+        assert_close(n, n64, TOL, "n")
+    assert_close(h, h64, TOL, "h")
+    assert_close(out, o64, TOL, "out")
+    assert_close(mean, x64.mean(1), TOL, "mean")
+
+
+def _block64(e, P, keep, heads):
+    """sasrec.py:81-92 in float64 (batch-first; causal mask; no dropout)."""
+    B, L, _ = e.shape
+    hd = E // heads
+    q = _ln(e, P["ln1_w"], P["ln1_b"])
+    Q = q @ P["in_w"][:E].t() + P["in_b"][:E]
+    K = e @ P["in_w"][E:2 * E].t() + P["in_b"][E:2 * E]
+    V = e @ P["in_w"][2 * E:].t() + P["in_b"][2 * E:]
+    sp = lambda t: t.view(B, L, heads, hd).transpose(1, 2)
+    s = (sp(Q) @ sp(K).transpose(-1, -2)) * hd ** -0.5
+    s = s.masked_fill(~torch.tril(torch.ones(L, L, dtype=torch.bool)), float("-inf"))
+    o = (torch.softmax(s, -1) @ sp(V)).transpose(1, 2).reshape(B, L, E)
+    x = q + o @ P["out_w"].t() + P["out_b"]
+    n = _ln(x, P["ln2_w"], P["ln2_b"])
+    return (n + torch.relu(n @ P["w1"].t() + P["b1"]) @ P["w2"].t() + P["b2"]) * keep.unsqueeze(-1)
+
+
+@pytest.mark.parametrize("B,L,heads", [(64, 200, 1), (45, 200, 2), (300, 30, 1)])
+def test_block_as_one_node_vs_float64_and_vs_the_sublayer_nodes(B, L, heads):
+    """ops.sasrec_block (rbx_seqblock_* forward and backward) against the float64 restatement and against the two sub-layer
+    nodes it replaces: output and every gradient (a ragged last slab at B L = 9000)."""
+    from recbox_amd import ops
+    P, g = _params(3)
+    e = torch.randn(B, L, E, generator=g)
+    keep = (torch.rand(B, L, generator=g) > 0.3).float()
+    R = torch.randn(B, L, E, generator=g)
+    names = list(P)
+
+    P64 = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    e64 = e.double().requires_grad_(True)
+    out64 = _block64(e64, P64, keep.double(), heads)
+    (out64 * R.double()).sum().backward()
+
+    def run(chains):
+        mha = torch.nn.MultiheadAttention(E, heads, 0.0)
+        n1, n2 = torch.nn.LayerNorm(E, eps=1e-8), torch.nn.LayerNorm(E, eps=1e-8)
+        with torch.no_grad():
+            mha.in_proj_weight.copy_(P["in_w"]); mha.in_proj_bias.copy_(P["in_b"])
+            mha.out_proj.weight.copy_(P["out_w"]); mha.out_proj.bias.copy_(P["out_b"])
+            n1.weight.copy_(P["ln1_w"]); n1.bias.copy_(P["ln1_b"]); n2.weight.copy_(P["ln2_w"]); n2.bias.copy_(P["ln2_b"])
+        mha, n1, n2 = mha.cuda(), n1.cuda(), n2.cuda()
+        ffn = [P[k].clone().cuda().requires_grad_(True) for k in ("w1", "b1", "w2", "b2")]
+        ec = e.clone().cuda().requires_grad_(True)
+        kc = keep.cuda()
+        if chains:
+            assert ops.seqblock_supported(ec, mha, False)
+            out = ops.sasrec_block(ec, n1, mha, n2, ffn[0], ffn[1], ffn[2], ffn[3], kc)
+        else:
+            x = ops.sasrec_attention_sublayer(ec, n1, mha)
+            out = ops.sasrec_ffn_sublayer(x, n2, ffn[0], ffn[1], ffn[2], ffn[3], kc, keep_is_mask=True)
+        (out * R.cuda()).sum().backward()
+        grads = dict(ln1_w=n1.weight.grad, ln1_b=n1.bias.grad, in_w=mha.in_proj_weight.grad, in_b=mha.in_proj_bias.grad,
+                     out_w=mha.out_proj.weight.grad, out_b=mha.out_proj.bias.grad, ln2_w=n2.weight.grad, ln2_b=n2.bias.grad,
+                     w1=ffn[0].grad, b1=ffn[1].grad, w2=ffn[2].grad, b2=ffn[3].grad)
+        return out.detach(), ec.grad, grads
+
+    out, de, grads = run(True)
+    assert_close(out, out64, TOL, "out")
+    assert_close(de, e64.grad, TOL * max(1.0, float(e64.grad.abs().max())), "de")
+    for k in names:
+        w = P64[k].grad
+        assert_close(grads[k], w, TOL * max(1.0, float(w.abs().max())), "d" + k)
+    out_s, de_s, grads_s = run(False)
+    assert_close(out, out_s, 1e-5, "out vs sub-layer nodes")
+    assert_close(de, de_s, 1e-5 * max(1.0, float(de_s.abs().max())), "de vs sub-layer nodes")
+    for k in names:
+        assert_close(grads[k], grads_s[k], 1e-5 * max(1.0, float(grads_s[k].abs().max())), "d%s vs sub-layer nodes" % k)
