@@ -789,7 +789,11 @@ int rbx_pool_bwd(const float* d_dout, const float* d_mask, const float* d_inv, i
  *                          KV[:, 64:] = x Wv^T + bv, in_w [192, 64] / in_b [192] = nn.MultiheadAttention's in_proj.
  *   rbx_seqblock_ffn_fwd:  with d_attn != NULL first x = res + attn Wo^T + bo (WRITTEN to d_x: `Q + mha_outputs`),
  *                          otherwise d_x is the input; then n = LayerNorm(x) (written to d_n unless NULL),
- *                          h = relu(n W1^T + b1), out = (n + h W2^T + b2) * keep[row] (keep NULL: 1). */
+ *                          h = relu(n W1^T + b1), out = (n + h W2^T + b2) * keep[row] (keep NULL: 1).
+ *   rbx_seqblock_ffn_bwd:  the backward of the second chain from its LayerNorm on, one pass: with g = dout * keep[row],
+ *                          dW2 = g^T h, db2 = colsum g, dh = (g W2) o [h > 0], dW1 = dh^T n, db1 = colsum dh, dn = dh W1 + g,
+ *                          and the LayerNorm backward of dn (dgamma, dbeta, d_dx); n is rebuilt from x, mean, rstd, gamma,
+ *                          beta.  Parameter gradients (any may be NULL) are OVERWRITTEN, summed in a fixed order. */
 int rbx_seqblock_qkv_fwd(const float* d_x, int64_t m, const float* d_ln_w, const float* d_ln_b, float eps,
                          const float* d_in_w, const float* d_in_b, float* d_mean, float* d_rstd, float* d_q, float* d_Q,
                          float* d_KV, void* stream);
@@ -797,6 +801,11 @@ int rbx_seqblock_ffn_fwd(const float* d_attn, const float* d_res, const float* d
                          const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w1, const float* d_b1,
                          const float* d_w2, const float* d_b2, const float* d_keep, float* d_mean, float* d_rstd, float* d_n,
                          float* d_h, float* d_out, void* stream);
+size_t rbx_seqblock_ffn_bwd_workspace_size(int64_t m);
+int rbx_seqblock_ffn_bwd(const float* d_dout, const float* d_keep, const float* d_h, const float* d_x, const float* d_mean,
+                         const float* d_rstd, int64_t m, const float* d_ln_w, const float* d_ln_b, const float* d_w1,
+                         const float* d_w2, float* d_dx, float* d_dw1, float* d_db1, float* d_dw2, float* d_db2,
+                         float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

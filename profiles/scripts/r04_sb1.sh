@@ -2,10 +2,10 @@
 # sequence-block chains: parity + SASRec step A/B on one box + kernel stats
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
-python -m pytest tests/test_gpu_seqblock.py -x -q 2>&1 | tail -25 > $out/sb_tests.log
+python -m pytest tests/test_gpu_seqblock.py -q 2>&1 | tail -40 > $out/sb_tests.log
 python -m pytest tests/test_gpu_matching.py -x -q -k "sasrec" 2>&1 | tail -8 >> $out/sb_tests.log
 B="--config sasrec --steps 20 --warmup 5 --no-cpu-baseline"
-RECBOX_AMD_SEQBLOCK=0 timeout 300 python bench.py $B > $out/sb_bench_off.json 2> $out/sb_bench_off.err
+RECBOX_AMD_SEQBLOCK_BWD=0 timeout 300 python bench.py $B > $out/sb_bench_off.json 2> $out/sb_bench_off.err
 timeout 300 python bench.py $B > $out/sb_bench_on.json 2> $out/sb_bench_on.err
 rm -rf $out/prof
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof -o b -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-configs --config sasrec --steps 10 --warmup 3 > $out/prof_sb.log 2>&1)

@@ -42,7 +42,7 @@ constexpr int kSbW = 64 * 64;               // floats of a staged weight
 // Wmat[32 t + lane % 32][pi(4 g + e, lane / 32)]: what lane feeds to step 4 g + e of output tile t.
 __device__ __forceinline__ void sb_stage_weight(float* __restrict__ wl, const float* __restrict__ W, const long long ld,
                                                 const bool trans) {
-  for (int idx = threadIdx.x; idx < kSbW; idx += 64 * kSbWaves) {
+  for (int idx = threadIdx.x; idx < kSbW; idx += static_cast<int>(blockDim.x)) {
     const int e = idx & 3, lane = (idx >> 2) & 63, g = (idx >> 8) & 7, t = idx >> 11;
     const int out = 32 * t + (lane & 31);
     const int in = 32 * (g >> 2) + 8 * (g & 3) + 4 * (lane >> 5) + e;
@@ -73,6 +73,14 @@ __device__ __forceinline__ void sb_offsets(const long long ld, const int rows_le
 __device__ __forceinline__ void sb_issue(const float* base, const unsigned (&off)[8], f32x4 (&v)[8]) {
 #pragma unroll
   for (int p = 0; p < 8; ++p) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(v[p]) : "v"(off[p]), "s"(base));
+}
+// The same request with the accumulation registers as its destination (gfx950 loads into AGPRs directly): a kernel that
+// lives on the whole 512-register file parks values in AGPRs on its own, and the compiler -- which does not know that an
+// inline-asm load is still in flight -- was seen copying the freshly "defined" VGPRs there right behind the request
+// (profiles/scripts/check_inflight.py).  Registers that start out as AGPRs are left where they are until they are used.
+__device__ __forceinline__ void sb_issue_a(const float* base, const unsigned (&off)[8], f32x4 (&v)[8]) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=a"(v[p]) : "v"(off[p]), "s"(base));
 }
 __device__ __forceinline__ void sb_arrived(f32x4 (&v)[8]) {
   asm volatile("s_waitcnt vmcnt(0)"
@@ -370,6 +378,309 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
   sb_arrived(nx);
 }
 
+// ---- backward of the feed-forward sub-layer as ONE pass ----------------------------------------------------------------
+// dout -> g = dout * keep;  dW2 += g^T h, db2 += colsum g;  dh = (g W2) o [h > 0];  dW1 += dh^T n, db1 += colsum dh;
+// dn = dh W1 + g;  LayerNorm backward of dn (dgamma, dbeta, dx).  As separate launches: two dW slab passes, two dx GEMMs,
+// the LayerNorm backward and its final kernel -- 13 reads and 3 writes of [M, 64]; here dout, h and x are read once and dx
+// is written once.  The chain (dh, dn, dx) stays in the row layout; the weight-gradient products contract over ROWS, so
+// their operands are wanted in the column layout (lane = column, register s <-> row rho(s, h) = (s & 3) + 8 (s >> 2) + 4 h:
+// the layout the natural MFMA product hands out) -- a tensor gets there by one trip through the wavefront's LDS slab
+// (8 b128 writes, 32 b32 reads: nothing beside the 64 MFMAs of a product).  n = xhat gamma + beta is rebuilt from the
+// block input and the saved statistics, so the forward does not have to store it.  Four products per slab and four
+// [M, 64] streams: the matrix pipe (f32: 43 us per product at cfg 5) and HBM are balanced.  One wavefront per SIMD with the
+// whole 512-register file: 128 accumulators for dW1 | dW2 and three slabs of prefetch live through the loop.
+// Partial sums: per workgroup (its four wavefronts added through LDS in a fixed order), reduced by sb_reduce_kernel in
+// a fixed order -- deterministic, no float atomics.
+constexpr int kSbBwdWaves = 4;
+constexpr int kSbFfnPart = 2 * kSbW + 4 * 64;          // dW2 | dW1 | db2 | db1 | dgamma | dbeta
+
+__device__ __forceinline__ void sb_row_to_lds(float* __restrict__ lds, const int lane, const float (&a)[32]) {
+  float* dst = lds + (lane & 31) * kSbLd + 4 * (lane >> 5);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    f32x4 u;
+    u[0] = a[4 * g]; u[1] = a[4 * g + 1]; u[2] = a[4 * g + 2]; u[3] = a[4 * g + 3];
+    *reinterpret_cast<f32x4*>(dst + 32 * (g >> 2) + 8 * (g & 3)) = u;
+  }
+}
+// c[16 t + s] = tile[rho(s, h)][32 t + m]
+__device__ __forceinline__ void sb_lds_to_col(const float* __restrict__ lds, const int lane, float (&c)[32]) {
+  const float* src = lds + 4 * (lane >> 5) * kSbLd + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) c[16 * t + s] = src[((s & 3) + 8 * (s >> 2)) * kSbLd + 32 * t];
+}
+// row layout registers -> column layout registers through the slab
+__device__ __forceinline__ void sb_row_to_col(float* __restrict__ lds, const int lane, const float (&a)[32], float (&c)[32]) {
+  sb_row_to_lds(lds, lane, a);
+  sb_wave_sync();
+  sb_lds_to_col(lds, lane, c);
+  sb_wave_sync();
+}
+// acc[tn][tk] += G^T X over the slab's 32 rows (operands in the column layout)
+__device__ __forceinline__ void sb_dw_acc(const float (&gc)[32], const float (&xc)[32], f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[s], xc[s], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[s], xc[16 + s], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[16 + s], xc[s], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[16 + s], xc[16 + s], acc[1][1], 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void sb_arrived3(f32x4 (&a)[8], f32x4 (&b)[8], f32x4 (&c)[8]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]), "+a"(a[6]), "+a"(a[7]), "+a"(b[0]),
+                 "+a"(b[1]), "+a"(b[2]), "+a"(b[3]), "+a"(b[4]), "+a"(b[5]), "+a"(b[6]), "+a"(b[7]), "+a"(c[0]), "+a"(c[1]),
+                 "+a"(c[2]), "+a"(c[3]), "+a"(c[4]), "+a"(c[5]), "+a"(c[6]), "+a"(c[7])
+               :
+               : "memory");
+}
+// a wavefront's accumulators into the workgroup's LDS sum (first: store, later: add)
+__device__ __forceinline__ void sb_acc_to_lds(float* __restrict__ red, const int lane, const f32x16 (&acc)[2][2], const bool first) {
+  const int m = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* d = red + (32 * tn + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + 32 * tk + m;
+        *d = first ? acc[tn][tk][r] : *d + acc[tn][tk][r];
+      }
+}
+__device__ __forceinline__ void sb_colsum_to_lds(float* __restrict__ red, const int lane, const float (&v)[2], const bool first) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float w = v[t] + __shfl_xor(v[t], 32, 64);
+    if (lane < 32) red[32 * t + lane] = first ? w : red[32 * t + lane] + w;
+  }
+}
+
+struct SbFfnBwdArgs {
+  const float *g0, *keep, *h, *x, *mean, *rstd, *ln_w, *ln_b, *w1, *w2;
+  float *dx, *part;
+  int M;
+};
+
+__global__ __launch_bounds__(64 * kSbBwdWaves, 1) void sb_ffn_bwd_kernel(const SbFfnBwdArgs A) {
+  extern __shared__ float sb_lds[];
+  float* w2t = sb_lds;                         // dh = g W2:  Wmat[k][n] = W2[n][k]
+  float* w1t = w2t + kSbW;                     // dn = dh W1
+  float* vec = w1t + kSbW;                     // gamma, beta
+  float* slabs = vec + 2 * 64;
+  sb_stage_weight(w2t, A.w2, 64, true);
+  sb_stage_weight(w1t, A.w1, 64, true);
+  sb_stage_vec(vec, A.ln_w, 1.f);
+  sb_stage_vec(vec + 64, A.ln_b, 0.f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nw = static_cast<int>(gridDim.x) * kSbBwdWaves;
+  const int slabs_n = (A.M + 31) >> 5;
+  int s = static_cast<int>(blockIdx.x) * kSbBwdWaves + wid;
+  float* lds = slabs + wid * 3 * kSbSlab;       // the wavefront's scratch slab, then g and xhat parked for the slab's lifetime
+  float* lds_g = lds + kSbSlab;
+  float* lds_x = lds_g + kSbSlab;
+  f32x16 acc2[2][2], acc1[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc2[a][b][i] = 0.f; acc1[a][b][i] = 0.f; }
+  float db2[2] = {0.f, 0.f}, db1[2] = {0.f, 0.f}, dgm[2] = {0.f, 0.f}, dbt[2] = {0.f, 0.f};
+  const float gmc[2] = {vec[m], vec[32 + m]}, btc[2] = {vec[64 + m], vec[96 + m]};      // column layout: columns 32 t + m
+  if (s < slabs_n) {
+    unsigned off64[8], off[8];
+    sb_offsets(64, 32, lane, off64);
+    f32x4 ng[8], nh[8], nx[8];
+    {
+      const int left = A.M - s * 32;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) off[p] = off64[p];
+      if (left < 32) sb_offsets(64, left, lane, off);
+      const long long o = static_cast<long long>(s) * 32 * 64;
+      sb_issue_a(A.g0 + o, off, ng);
+      sb_issue_a(A.h + o, off, nh);
+      sb_issue_a(A.x + o, off, nx);
+    }
+    for (;;) {
+      const int r0 = s * 32;
+      const int left = A.M - r0;
+      int sn = s + nw;
+      const bool more = sn < slabs_n;
+      sn = more ? sn : s;
+      const int rr = r0 + m < A.M ? r0 + m : A.M - 1;
+      const float kp = (m < left) ? (A.keep != nullptr ? A.keep[rr] : 1.f) : 0.f;      // rows beyond the end add nothing
+      const float mu = A.mean[rr], rs = A.rstd[rr];
+      float g[32], xc[32];
+      unsigned hmask = 0u;
+      sb_arrived3(ng, nh, nx);
+      sb_turn_in(lds, lane, ng, g);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) g[r] *= kp;
+      {
+        float gc[32], hr[32], hc[32];
+        sb_row_to_lds(lds_g, lane, g);                   // (kept there: read back for dn = dh W1 + g)
+        sb_wave_sync();
+        sb_lds_to_col(lds_g, lane, gc);
+        sb_turn_in(lds, lane, nh, hr);                   // (the slab keeps the tile: the column layout is read from it)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) hmask |= (hr[r] > 0.f ? 1u : 0u) << r;
+        sb_lds_to_col(lds, lane, hc);
+        sb_wave_sync();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) db2[t] += gc[16 * t + q];
+        sb_dw_acc(gc, hc, acc2);
+      }
+      {
+        float xh[32];
+        sb_turn_in(lds, lane, nx, xh);
+#pragma unroll
+        for (int r = 0; r < 32; ++r) xh[r] = (xh[r] - mu) * rs;
+        sb_row_to_lds(lds_x, lane, xh);                  // (kept there: the LayerNorm backward reads it at the end)
+        sb_wave_sync();
+        sb_lds_to_col(lds_x, lane, xc);
+      }
+      {
+        const int ln = A.M - sn * 32;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) off[p] = off64[p];
+        if (ln < 32) sb_offsets(64, ln, lane, off);
+        const long long o = static_cast<long long>(sn) * 32 * 64;
+        sb_issue_a(A.g0 + o, off, ng);
+        sb_issue_a(A.h + o, off, nh);
+        sb_issue_a(A.x + o, off, nx);
+      }
+      float dh[32];
+      sb_gemm_row(w2t, lane, g, dh);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) dh[r] = ((hmask >> r) & 1u) ? dh[r] : 0.f;
+      {
+        float dc[32];
+        sb_row_to_col(lds, lane, dh, dc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) db1[t] += dc[16 * t + q];
+        // dW1 += dh^T n with n = xhat gamma + beta rebuilt per operand
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float n0 = xc[q] * gmc[0] + btc[0], n1 = xc[16 + q] * gmc[1] + btc[1];
+          acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[q], n0, acc1[0][0], 0, 0, 0);
+          acc1[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[q], n1, acc1[0][1], 0, 0, 0);
+          acc1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[16 + q], n0, acc1[1][0], 0, 0, 0);
+          acc1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[16 + q], n1, acc1[1][1], 0, 0, 0);
+        }
+      }
+      float dn[32];
+      sb_gemm_row(w1t, lane, dh, dn);
+      {
+        const float* src = lds_g + m * kSbLd + 4 * h;
+#pragma unroll
+        for (int gq = 0; gq < 8; ++gq) {
+          const f32x4 u = *reinterpret_cast<const f32x4*>(src + 32 * (gq >> 2) + 8 * (gq & 3));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dn[4 * gq + e] += u[e];
+        }
+      }
+      {
+        float dc[32];
+        sb_row_to_col(lds, lane, dn, dc);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            dbt[t] += dc[16 * t + q];
+            dgm[t] += dc[16 * t + q] * xc[16 * t + q];
+          }
+      }
+      // LayerNorm backward of the row (rbx_norm.hip's arithmetic)
+      float xh[32];
+      {
+        const float* src = lds_x + m * kSbLd + 4 * h;
+#pragma unroll
+        for (int gq = 0; gq < 8; ++gq) {
+          const f32x4 u = *reinterpret_cast<const f32x4*>(src + 32 * (gq >> 2) + 8 * (gq & 3));
+          xh[4 * gq] = u[0]; xh[4 * gq + 1] = u[1]; xh[4 * gq + 2] = u[2]; xh[4 * gq + 3] = u[3];
+        }
+      }
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int gq = 0; gq < 8; ++gq) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(vec + 32 * (gq >> 2) + 8 * (gq & 3) + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dn[4 * gq + e] *= gm[e];
+          s1 += dn[4 * gq + e];
+          s2 += dn[4 * gq + e] * xh[4 * gq + e];
+        }
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const float m1 = s1 * (1.0f / 64.0f), m2 = s2 * (1.0f / 64.0f);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) dn[r] = rs * (dn[r] - m1 - xh[r] * m2);
+      sb_store(lds, lane, dn, A.dx + static_cast<long long>(r0) * 64, off64, left);
+      if (!more) break;
+      s = sn;
+    }
+    sb_arrived3(ng, nh, nx);
+  }
+  __syncthreads();                               // every wavefront is done with the weights: the LDS becomes the sum
+  float* red = sb_lds;
+  for (int w = 0; w < kSbBwdWaves; ++w) {
+    if (wid == w) {
+      sb_acc_to_lds(red, lane, acc2, w == 0);
+      sb_acc_to_lds(red + kSbW, lane, acc1, w == 0);
+      sb_colsum_to_lds(red + 2 * kSbW, lane, db2, w == 0);
+      sb_colsum_to_lds(red + 2 * kSbW + 64, lane, db1, w == 0);
+      sb_colsum_to_lds(red + 2 * kSbW + 128, lane, dgm, w == 0);
+      sb_colsum_to_lds(red + 2 * kSbW + 192, lane, dbt, w == 0);
+    }
+    __syncthreads();
+  }
+  float* dst = A.part + static_cast<long long>(blockIdx.x) * kSbFfnPart;
+  for (int i = threadIdx.x; i < kSbFfnPart; i += 64 * kSbBwdWaves) dst[i] = red[i];
+}
+
+// out segment j (offset seg_off[j], length seg_len[j]) = sum over the workgroups' partials, in order
+struct SbReduceArgs {
+  const float* part;
+  int nparts, stride, nseg;
+  int seg_off[8], seg_len[8];
+  float* dst[8];
+};
+__global__ __launch_bounds__(256) void sb_reduce_kernel(const SbReduceArgs A) {
+  const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= A.stride) return;
+  float* d = nullptr;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (j < A.nseg && i >= A.seg_off[j] && i < A.seg_off[j] + A.seg_len[j] && A.dst[j] != nullptr) d = A.dst[j] + (i - A.seg_off[j]);
+  if (d == nullptr) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int p = 0;
+  for (; p + 4 <= A.nparts; p += 4) {
+    s0 += A.part[static_cast<long long>(p) * A.stride + i];
+    s1 += A.part[static_cast<long long>(p + 1) * A.stride + i];
+    s2 += A.part[static_cast<long long>(p + 2) * A.stride + i];
+    s3 += A.part[static_cast<long long>(p + 3) * A.stride + i];
+  }
+  for (; p < A.nparts; ++p) s0 += A.part[static_cast<long long>(p) * A.stride + i];
+  *d = (s0 + s1) + (s2 + s3);
+}
+
+static int sb_bwd_grid(long long m) {
+  const long long slabs = (m + 31) / 32;
+  long long wgs = (slabs + kSbBwdWaves - 1) / kSbBwdWaves;
+  if (wgs > kCUs) wgs = kCUs;
+  return static_cast<int>(wgs < 1 ? 1 : wgs);
+}
+
 static bool sb_aligned(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int sb_grid(long long m) {
@@ -431,4 +742,49 @@ extern "C" int rbx_seqblock_ffn_fwd(const float* d_attn, const float* d_res, con
   if (pro) hipLaunchKernelGGL(sb_ffn_fwd_kernel<true>, dim3(sb_grid(m)), dim3(64 * kSbWaves), lds, as_stream(stream), a);
   else hipLaunchKernelGGL(sb_ffn_fwd_kernel<false>, dim3(sb_grid(m)), dim3(64 * kSbWaves), lds, as_stream(stream), a);
   return check_launch("sb_ffn_fwd_kernel");
+}
+
+extern "C" size_t rbx_seqblock_ffn_bwd_workspace_size(int64_t m) {
+  return m <= 0 ? 0 : sizeof(float) * static_cast<size_t>(sb_bwd_grid(m)) * kSbFfnPart;
+}
+
+extern "C" int rbx_seqblock_ffn_bwd(const float* d_dout, const float* d_keep, const float* d_h, const float* d_x,
+                                    const float* d_mean, const float* d_rstd, int64_t m, const float* d_ln_w,
+                                    const float* d_ln_b, const float* d_w1, const float* d_w2, float* d_dx, float* d_dw1,
+                                    float* d_db1, float* d_dw2, float* d_db2, float* d_dgamma, float* d_dbeta,
+                                    void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (m < 0 || m > (1LL << 30)) return fail(RBX_ERR_INVALID, "rbx_seqblock_ffn_bwd: m = %lld", static_cast<long long>(m));
+  if (m == 0) return RBX_OK;
+  if (!d_dout || !d_h || !d_x || !d_mean || !d_rstd || !d_w1 || !d_w2 || !d_dx)
+    return fail(RBX_ERR_INVALID, "rbx_seqblock_ffn_bwd: NULL operand");
+  if (!sb_aligned(d_dout) || !sb_aligned(d_h) || !sb_aligned(d_x) || !sb_aligned(d_dx))
+    return fail(RBX_ERR_UNSUPPORTED, "rbx_seqblock_ffn_bwd: activations must be 16-byte aligned");
+  const size_t need = rbx_seqblock_ffn_bwd_workspace_size(m);
+  if (d_workspace == nullptr || workspace_bytes < need)
+    return fail(RBX_ERR_WORKSPACE, "rbx_seqblock_ffn_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+  const int grid = sb_bwd_grid(m);
+  SbFfnBwdArgs a{d_dout, d_keep, d_h, d_x, d_mean, d_rstd, d_ln_w, d_ln_b, d_w1, d_w2, d_dx, static_cast<float*>(d_workspace),
+                 static_cast<int>(m)};
+  const size_t lds = sizeof(float) * (2 * kSbW + 2 * 64 + 3 * kSbBwdWaves * kSbSlab);
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_ffn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds)) != hipSuccess)
+      return fail(RBX_ERR_LAUNCH, "rbx_seqblock_ffn_bwd: %zu bytes of LDS refused", lds);
+    once = true;
+  }
+  hipLaunchKernelGGL(sb_ffn_bwd_kernel, dim3(grid), dim3(64 * kSbBwdWaves), lds, as_stream(stream), a);
+  int rc = check_launch("sb_ffn_bwd_kernel");
+  if (rc != RBX_OK) return rc;
+  SbReduceArgs r{};
+  r.part = static_cast<const float*>(d_workspace);
+  r.nparts = grid;
+  r.stride = kSbFfnPart;
+  r.nseg = 6;
+  const int offs[6] = {0, kSbW, 2 * kSbW, 2 * kSbW + 64, 2 * kSbW + 128, 2 * kSbW + 192};
+  const int lens[6] = {kSbW, kSbW, 64, 64, 64, 64};
+  float* dsts[6] = {d_dw2, d_dw1, d_db2, d_db1, d_dgamma, d_dbeta};
+  for (int j = 0; j < 6; ++j) { r.seg_off[j] = offs[j]; r.seg_len[j] = lens[j]; r.dst[j] = dsts[j]; }
+  hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbFfnPart + 255) / 256), dim3(256), 0, as_stream(stream), r);
+  return check_launch("sb_reduce_kernel");
 }

@@ -66,6 +66,9 @@ class config(object):
     # a SASRec block (embed_dim 64, no FFN dropout) as ONE autograd node whose row-local chains are single passes
     # (csrc/rbx_seqblock.hip: LayerNorm + in-projections; out-projection + residual + LayerNorm + FFN + residual + mask)
     seqblock_chains = os.environ.get("RECBOX_AMD_SEQBLOCK", "1") != "0"
+    # ... and the backward of its feed-forward half as one pass (rbx_seqblock_ffn_bwd) instead of two dW passes, two dx GEMMs
+    # and the LayerNorm backward; the forward then does not store the LayerNorm output
+    seqblock_bwd = os.environ.get("RECBOX_AMD_SEQBLOCK_BWD", "1") != "0"
     # DeepFM: the tower's first Linear, the FM term and the first-order Linear over one gathered block as one autograd node
     # (ops.deepfm_input_stage): the block's gradient comes out of the tower's dx GEMM instead of four kernels
     fuse_deepfm_input = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_INPUT", "1") != "0"
@@ -3049,19 +3052,22 @@ class _SeqBlock(torch.autograd.Function):
         vptr = ctypes.c_void_p(KV.data_ptr() + 4 * E)
         check(lib.rbx_attn_packed_fwd(_ptr(Q), E, kptr, 2 * E, vptr, 2 * E, B, heads, L, hd, float(scale), 1, float(p_drop),
                                       int(seed), _ptr(tick), _ptr(O), E, _ptr(lse), _stream()))
-        y, n, h, out = (torch.empty((M, E), **f32) for _ in range(4))
+        y, h, out = (torch.empty((M, E), **f32) for _ in range(3))
+        n = None if config.seqblock_bwd else torch.empty((M, E), **f32)       # (the one-pass backward rebuilds it)
         mean2, rstd2 = torch.empty(M, **f32), torch.empty(M, **f32)
         check(lib.rbx_seqblock_ffn_fwd(_ptr(O), _ptr(q), _ptr(out_w), _ptr(out_b), _ptr(y), M, _ptr(ln2_w), _ptr(ln2_b), eps2,
                                        _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(k1), _ptr(mean2), _ptr(rstd2), _ptr(n),
                                        _ptr(h), _ptr(out), _stream()))
-        ctx.save_for_backward(x2, ln1_w, mean1, rstd1, q, in_w, Q, KV, O, lse, out_w, y, ln2_w, mean2, rstd2, n, w1, h, w2, k1)
+        ctx.save_for_backward(x2, ln1_w, mean1, rstd1, q, in_w, Q, KV, O, lse, out_w, y, ln2_w, mean2, rstd2, n, w1, h, w2, k1,
+                              ln2_b)
         ctx.meta = (B, L, E, heads, hd, float(scale), float(p_drop), int(seed), tick, in_b is not None, out_b is not None,
                     ln1_b is not None, ln2_b is not None, b1 is not None, b2 is not None)
         return out.view(B, L, E)
 
     @staticmethod
     def backward(ctx, dout):
-        (x2, ln1_w, mean1, rstd1, q, in_w, Q, KV, O, lse, out_w, y, ln2_w, mean2, rstd2, n, w1, h, w2, k1) = ctx.saved_tensors
+        (x2, ln1_w, mean1, rstd1, q, in_w, Q, KV, O, lse, out_w, y, ln2_w, mean2, rstd2, n, w1, h, w2, k1,
+         ln2_b) = ctx.saved_tensors
         (B, L, E, heads, hd, scale, p_drop, seed, tick, has_in_b, has_out_b, has_ln1_b, has_ln2_b, has_b1, has_b2) = ctx.meta
         dev = dout.device
         need = ctx.needs_input_grad
@@ -3072,12 +3078,23 @@ class _SeqBlock(torch.autograd.Function):
         db2 = torch.empty(E, **f32) if (has_b2 and need[17]) else None
         dw1 = torch.empty_like(w1) if need[14] else None
         db1 = torch.empty(E, **f32) if (has_b1 and need[15]) else None
-        _lin_dwdb_scaled(h, g0, k1, dw2, db2)
-        dh = _lin_dx(g0, w2, mask=h, row_scale=k1)
-        _lin_dwdb(n, w1, dh, dw1, db1)
-        dn = _lin_dx(dh, w1, residual=g0, row_scale=k1)
         want2 = need[11] or (has_ln2_b and need[12])
-        g, dgamma2, dbeta2 = _ln_bwd(y, dn, ln2_w, mean2, rstd2, want2)
+        if n is None:
+            M = B * L
+            g = torch.empty((M, E), **f32)
+            dgamma2 = torch.empty(E, **f32) if want2 else None
+            dbeta2 = torch.empty(E, **f32) if want2 else None
+            ws_bytes = lib.rbx_seqblock_ffn_bwd_workspace_size(M)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            check(lib.rbx_seqblock_ffn_bwd(_ptr(g0), _ptr(k1), _ptr(h), _ptr(y), _ptr(mean2), _ptr(rstd2), M, _ptr(ln2_w),
+                                           _ptr(ln2_b), _ptr(w1), _ptr(w2), _ptr(g), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+                                           _ptr(dgamma2), _ptr(dbeta2), _ptr(ws), ws_bytes, _stream()))
+        else:
+            _lin_dwdb_scaled(h, g0, k1, dw2, db2)
+            dh = _lin_dx(g0, w2, mask=h, row_scale=k1)
+            _lin_dwdb(n, w1, dh, dw1, db1)
+            dn = _lin_dx(dh, w1, residual=g0, row_scale=k1)
+            g, dgamma2, dbeta2 = _ln_bwd(y, dn, ln2_w, mean2, rstd2, want2)
         # ---- attention sub-layer
         d_out_w = torch.empty_like(out_w) if need[6] else None
         d_out_b = torch.empty(E, **f32) if (has_out_b and need[7]) else None

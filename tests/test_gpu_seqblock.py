@@ -96,6 +96,49 @@ def test_ffn_chain_vs_float64(M, pro, with_n):
     assert_close(mean, x64.mean(1), TOL, "mean")
 
 
+@pytest.mark.parametrize("M", [19, 64, 9000, 40960])
+def test_ffn_backward_chain_vs_float64(M):
+    """rbx_seqblock_ffn_bwd: one pass from dout to the gradient of the LayerNorm input and all six parameter gradients."""
+    from recbox_amd._lib import lib
+    P, g = _params(4)
+    x = torch.randn(M, E, generator=g)
+    dout = torch.randn(M, E, generator=g)
+    keep = (torch.rand(M, generator=g) > 0.3).float()
+    ps = {k: P[k].double().requires_grad_(True) for k in ("ln2_w", "ln2_b", "w1", "b1", "w2", "b2")}
+    x64 = x.double().requires_grad_(True)
+    n64 = _ln(x64, ps["ln2_w"], ps["ln2_b"])
+    h64 = torch.relu(n64 @ ps["w1"].t() + ps["b1"])
+    out = (n64 + h64 @ ps["w2"].t() + ps["b2"]) * keep.double().unsqueeze(1)
+    (out * dout.double()).sum().backward()
+    d = {k: v.cuda() for k, v in P.items()}
+    xc, dc, kc, hc = x.cuda(), dout.cuda(), keep.cuda(), h64.detach().float().cuda()
+    mean, rstd = x64.detach().mean(1).float().cuda(), (x64.detach().var(1, unbiased=False) + 1e-8).rsqrt().float().cuda()
+    f = lambda *s: torch.full(s, float("nan"), device="cuda")
+    dx, dw1, db1, dw2, db2, dg, db = f(M, E), f(E, E), f(E), f(E, E), f(E), f(E), f(E)
+    nbytes = lib.rbx_seqblock_ffn_bwd_workspace_size(M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    for rep in range(2):                                    # (twice: the sums are formed in a fixed order)
+        rc = lib.rbx_seqblock_ffn_bwd(_p(dc), _p(kc), _p(hc), _p(xc), _p(mean), _p(rstd), M, _p(d["ln2_w"]), _p(d["ln2_b"]),
+                                      _p(d["w1"]), _p(d["w2"]), _p(dx), _p(dw1), _p(db1), _p(dw2), _p(db2), _p(dg), _p(db),
+                                      _p(ws), nbytes, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = [t.clone() for t in (dx, dw1, db1, dw2, db2, dg, db)]
+        if rep == 0:
+            first = got
+    for a, b in zip(first, got):
+        assert torch.equal(a, b)
+    want = [x64.grad, ps["w1"].grad, ps["b1"].grad, ps["w2"].grad, ps["b2"].grad, ps["ln2_w"].grad, ps["ln2_b"].grad]
+    for name, a, b in zip(("dx", "dw1", "db1", "dw2", "db2", "dgamma", "dbeta"), got, want):
+        assert_close(a, b, TOL * max(1.0, float(b.abs().max())), name)
+    # parameter gradients are optional
+    rc = lib.rbx_seqblock_ffn_bwd(_p(dc), _p(kc), _p(hc), _p(xc), _p(mean), _p(rstd), M, _p(d["ln2_w"]), _p(d["ln2_b"]),
+                                  _p(d["w1"]), _p(d["w2"]), _p(dx), None, None, None, None, None, None, _p(ws), nbytes, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dx, got[0])
+
+
 def _block64(e, P, keep, heads):
     """sasrec.py:81-92 in float64 (batch-first; causal mask; no dropout)."""
     B, L, _ = e.shape
@@ -113,8 +156,8 @@ def _block64(e, P, keep, heads):
     return (n + torch.relu(n @ P["w1"].t() + P["b1"]) @ P["w2"].t() + P["b2"]) * keep.unsqueeze(-1)
 
 
-@pytest.mark.parametrize("B,L,heads", [(64, 200, 1), (45, 200, 2), (300, 30, 1)])
-def test_block_as_one_node_vs_float64_and_vs_the_sublayer_nodes(B, L, heads):
+@pytest.mark.parametrize("B,L,heads,one_pass_bwd", [(64, 200, 1, True), (45, 200, 2, True), (300, 30, 1, True), (45, 200, 1, False)])
+def test_block_as_one_node_vs_float64_and_vs_the_sublayer_nodes(B, L, heads, one_pass_bwd):
     """ops.sasrec_block (rbx_seqblock_* forward and backward) against the float64 restatement and against the two sub-layer
     nodes it replaces: output and every gradient (a ragged last slab at B L = 9000)."""
     from recbox_amd import ops
@@ -140,13 +183,18 @@ def test_block_as_one_node_vs_float64_and_vs_the_sublayer_nodes(B, L, heads):
         ffn = [P[k].clone().cuda().requires_grad_(True) for k in ("w1", "b1", "w2", "b2")]
         ec = e.clone().cuda().requires_grad_(True)
         kc = keep.cuda()
-        if chains:
-            assert ops.seqblock_supported(ec, mha, False)
-            out = ops.sasrec_block(ec, n1, mha, n2, ffn[0], ffn[1], ffn[2], ffn[3], kc)
-        else:
-            x = ops.sasrec_attention_sublayer(ec, n1, mha)
-            out = ops.sasrec_ffn_sublayer(x, n2, ffn[0], ffn[1], ffn[2], ffn[3], kc, keep_is_mask=True)
-        (out * R.cuda()).sum().backward()
+        old = ops.config.seqblock_bwd
+        ops.config.seqblock_bwd = one_pass_bwd
+        try:
+            if chains:
+                assert ops.seqblock_supported(ec, mha, False)
+                out = ops.sasrec_block(ec, n1, mha, n2, ffn[0], ffn[1], ffn[2], ffn[3], kc)
+            else:
+                x = ops.sasrec_attention_sublayer(ec, n1, mha)
+                out = ops.sasrec_ffn_sublayer(x, n2, ffn[0], ffn[1], ffn[2], ffn[3], kc, keep_is_mask=True)
+            (out * R.cuda()).sum().backward()
+        finally:
+            ops.config.seqblock_bwd = old
         grads = dict(ln1_w=n1.weight.grad, ln1_b=n1.bias.grad, in_w=mha.in_proj_weight.grad, in_b=mha.in_proj_bias.grad,
                      out_w=mha.out_proj.weight.grad, out_b=mha.out_proj.bias.grad, ln2_w=n2.weight.grad, ln2_b=n2.bias.grad,
                      w1=ffn[0].grad, b1=ffn[1].grad, w2=ffn[2].grad, b2=ffn[3].grad)
