@@ -793,7 +793,10 @@ int rbx_pool_bwd(const float* d_dout, const float* d_mask, const float* d_inv, i
  *   rbx_seqblock_ffn_bwd:  the backward of the second chain from its LayerNorm on, one pass: with g = dout * keep[row],
  *                          dW2 = g^T h, db2 = colsum g, dh = (g W2) o [h > 0], dW1 = dh^T n, db1 = colsum dh, dn = dh W1 + g,
  *                          and the LayerNorm backward of dn (dgamma, dbeta, d_dx); n is rebuilt from x, mean, rstd, gamma,
- *                          beta.  Parameter gradients (any may be NULL) are OVERWRITTEN, summed in a fixed order. */
+ *                          beta.  Parameter gradients (any may be NULL) are OVERWRITTEN, summed in a fixed order.
+ *   rbx_seqblock_attn_in_bwd: behind the attention's backward, one pass: dq = dQ Wq + g (g = the gradient arriving over
+ *                          the residual), dgamma / dbeta and the LayerNorm backward of dq, de = that + dK Wk + dV Wv
+ *                          (d_dKV [m, 128] = dK | dV).  The three in-projection weight gradients are not part of it. */
 int rbx_seqblock_qkv_fwd(const float* d_x, int64_t m, const float* d_ln_w, const float* d_ln_b, float eps,
                          const float* d_in_w, const float* d_in_b, float* d_mean, float* d_rstd, float* d_q, float* d_Q,
                          float* d_KV, void* stream);
@@ -806,6 +809,10 @@ int rbx_seqblock_ffn_bwd(const float* d_dout, const float* d_keep, const float* 
                          const float* d_rstd, int64_t m, const float* d_ln_w, const float* d_ln_b, const float* d_w1,
                          const float* d_w2, float* d_dx, float* d_dw1, float* d_db1, float* d_dw2, float* d_db2,
                          float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream);
+size_t rbx_seqblock_attn_in_bwd_workspace_size(int64_t m);
+int rbx_seqblock_attn_in_bwd(const float* d_dQ, const float* d_dKV, const float* d_g, const float* d_x, const float* d_mean,
+                             const float* d_rstd, int64_t m, const float* d_ln_w, const float* d_in_w, float* d_de,
+                             float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

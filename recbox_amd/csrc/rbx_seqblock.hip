@@ -25,6 +25,7 @@
 // Forward kernels (this file): sb_qkv_fwd (LayerNorm + the three in-projections: 1 read, 4 writes instead of
 // 3 reads + 4 writes in three launches) and sb_ffn_fwd (out-projection + residual + LayerNorm + conv1 + ReLU + conv2 +
 // residual + mask: 2 reads, 4 writes instead of 7 reads + 5 writes in four launches).
+#include <stdlib.h>
 #include "rbx_internal.h"
 
 namespace rbx {
@@ -88,6 +89,22 @@ __device__ __forceinline__ void sb_arrived(f32x4 (&v)[8]) {
                :
                : "memory");
 }
+__device__ __forceinline__ void sb_issue_word(const float* base, const unsigned off, float& v) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base));
+}
+__device__ __forceinline__ void sb_arrived1(f32x4 (&v)[8], float& u) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(u)
+               :
+               : "memory");
+}
+__device__ __forceinline__ void sb_arrived2(f32x4 (&v)[8], f32x4 (&w)[8], float& u) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(w[0]),
+                 "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(u)
+               :
+               : "memory");
+}
 __device__ __forceinline__ void sb_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -127,6 +144,31 @@ __device__ __forceinline__ void sb_store(float* __restrict__ lds, const int lane
 #pragma unroll
     for (int p = 0; p < 8; ++p)
       if (4 * p + (lane >> 4) < left) *reinterpret_cast<f32x4*>(cb + off[p]) = *reinterpret_cast<const f32x4*>(src + 4 * p * kSbLd);
+  }
+  sb_wave_sync();
+}
+
+// the same for a tensor of pitch 64 with the requests' offsets rebuilt from the lane's part (request p = lane_off + 1024 p
+// bytes: constants the stores fold into their offset fields, no array of eight offsets kept alive through a long loop)
+__device__ __forceinline__ void sb_store_lin(float* __restrict__ lds, const int lane, const float (&a)[32], float* base,
+                                             const unsigned lane_off, const int left) {
+  float* dst = lds + (lane & 31) * kSbLd + 4 * (lane >> 5);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    f32x4 u;
+    u[0] = a[4 * g]; u[1] = a[4 * g + 1]; u[2] = a[4 * g + 2]; u[3] = a[4 * g + 3];
+    *reinterpret_cast<f32x4*>(dst + 32 * (g >> 2) + 8 * (g & 3)) = u;
+  }
+  sb_wave_sync();
+  const float* src = lds + (lane >> 4) * kSbLd + 4 * (lane & 15);
+  char* cb = reinterpret_cast<char*>(base) + lane_off;
+  if (left >= 32) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4*>(cb + 1024 * p) = *reinterpret_cast<const f32x4*>(src + 4 * p * kSbLd);
+  } else {
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      if (4 * p + (lane >> 4) < left) *reinterpret_cast<f32x4*>(cb + 1024 * p) = *reinterpret_cast<const f32x4*>(src + 4 * p * kSbLd);
   }
   sb_wave_sync();
 }
@@ -228,9 +270,9 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_qkv_fwd_kernel(const SbQk
     if (left < 32) sb_offsets(64, left, lane, off);
     sb_issue(A.x + static_cast<long long>(s) * 32 * 64, off, nx);
   }
+  sb_arrived(nx);
   for (;;) {
     float x[32];
-    sb_arrived(nx);
     sb_turn_in(lds, lane, nx, x);
     const int r0 = s * 32;
     const int left = A.M - r0;
@@ -261,11 +303,11 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_qkv_fwd_kernel(const SbQk
     sb_store(lds, lane, x, A.q + static_cast<long long>(r0) * 64, off64, left);
     sb_gemm_row(wq, lane, x, y);
     sb_add_vec(y, vec + 128, h);
+    sb_arrived(nx);          // in front of the last store: behind it the wait (vmcnt counts stores) would hold the next slab
     sb_store(lds, lane, y, A.Q + static_cast<long long>(r0) * 64, off64, left);
     if (!more) break;
     s = sn;
   }
-  sb_arrived(nx);
 }
 
 struct SbFfnArgs {
@@ -308,6 +350,8 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
   sb_offsets(64, 32, lane, off64);
   const float* in0 = PRO ? A.attn : A.x;
   f32x4 nx[8], nr[8];
+  float nkp;                                    // the rows' keep travels with the slab's requests
+  const float* keep_p = A.keep != nullptr ? A.keep : in0;
   {
     const int left = A.M - s * 32;
 #pragma unroll
@@ -315,7 +359,10 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
     if (left < 32) sb_offsets(64, left, lane, off);
     sb_issue(in0 + static_cast<long long>(s) * 32 * 64, off, nx);
     if constexpr (PRO) sb_issue(A.res + static_cast<long long>(s) * 32 * 64, off, nr);
+    sb_issue_word(keep_p, 4u * static_cast<unsigned>(s * 32 + m < A.M ? s * 32 + m : A.M - 1), nkp);
   }
+  if constexpr (PRO) sb_arrived2(nx, nr, nkp);
+  else sb_arrived1(nx, nkp);
   for (;;) {
     float x[32];
     const int r0 = s * 32;
@@ -325,7 +372,6 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
     sn = more ? sn : s;
     if constexpr (PRO) {
       float o[32];
-      sb_arrived(nx);                          // (vmcnt(0): both tensors have arrived)
       sb_turn_in(lds, lane, nx, o);
       sb_turn_in(lds, lane, nr, x);
       {
@@ -343,7 +389,6 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
       for (int r = 0; r < 32; ++r) x[r] += y[r];
       sb_store(lds, lane, x, A.x + static_cast<long long>(r0) * 64, off64, left);
     } else {
-      sb_arrived(nx);
       sb_turn_in(lds, lane, nx, x);
       const int ln = A.M - sn * 32;
 #pragma unroll
@@ -351,8 +396,8 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
       if (ln < 32) sb_offsets(64, ln, lane, off);
       sb_issue(in0 + static_cast<long long>(sn) * 32 * 64, off, nx);
     }
-    const int rr = r0 + m;
-    const float kp = A.keep != nullptr ? A.keep[rr < A.M ? rr : A.M - 1] : 1.f;
+    const float kp = A.keep != nullptr ? nkp : 1.f;
+    sb_issue_word(keep_p, 4u * static_cast<unsigned>(sn * 32 + m < A.M ? sn * 32 + m : A.M - 1), nkp);
     float mu, rs;
     sb_layernorm(x, vec, vec + 64, h, A.eps, &mu, &rs);
     if (h == 0 && m < left) {
@@ -371,11 +416,12 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
     sb_add_vec(y, vec + 192, h);
 #pragma unroll
     for (int r = 0; r < 32; ++r) y[r] = (y[r] + x[r]) * kp;
+    if constexpr (PRO) sb_arrived2(nx, nr, nkp);   // in front of the last store (see sb_qkv_fwd_kernel)
+    else sb_arrived1(nx, nkp);
     sb_store(lds, lane, y, A.out + static_cast<long long>(r0) * 64, off64, left);
     if (!more) break;
     s = sn;
   }
-  sb_arrived(nx);
 }
 
 // ---- backward of the feed-forward sub-layer as ONE pass ----------------------------------------------------------------
@@ -428,11 +474,11 @@ __device__ __forceinline__ void sb_dw_acc(const float (&gc)[32], const float (&x
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[16 + s], xc[16 + s], acc[1][1], 0, 0, 0);
   }
 }
-__device__ __forceinline__ void sb_arrived3(f32x4 (&a)[8], f32x4 (&b)[8], f32x4 (&c)[8]) {
+__device__ __forceinline__ void sb_arrived3(f32x4 (&a)[8], f32x4 (&b)[8], f32x4 (&c)[8], float& u0, float& u1, float& u2) {
   asm volatile("s_waitcnt vmcnt(0)"
                : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]), "+a"(a[6]), "+a"(a[7]), "+a"(b[0]),
-                 "+a"(b[1]), "+a"(b[2]), "+a"(b[3]), "+a"(b[4]), "+a"(b[5]), "+a"(b[6]), "+a"(b[7]), "+a"(c[0]), "+a"(c[1]),
-                 "+a"(c[2]), "+a"(c[3]), "+a"(c[4]), "+a"(c[5]), "+a"(c[6]), "+a"(c[7])
+                 "+a"(b[1]), "+a"(b[2]), "+a"(b[3]), "+a"(b[4]), "+a"(b[5]), "+a"(b[6]), "+a"(b[7]), "+v"(c[0]), "+v"(c[1]),
+                 "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(u0), "+v"(u1), "+v"(u2)
                :
                : "memory");
 }
@@ -463,6 +509,10 @@ struct SbFfnBwdArgs {
   int M;
 };
 
+// ORDER 1: the two chain products are written in FRONT of the LDS trips that do not depend on them (dh = g W2 before the
+// column-layout trips of g and h, dn = dh W1 before dh's), so that the scheduler has independent work to put between
+// the MFMAs of a product: one wavefront per SIMD hides nothing by itself.
+template <int ORDER>
 __global__ __launch_bounds__(64 * kSbBwdWaves, 1) void sb_ffn_bwd_kernel(const SbFfnBwdArgs A) {
   extern __shared__ float sb_lds[];
   float* w2t = sb_lds;                         // dh = g W2:  Wmat[k][n] = W2[n][k]
@@ -492,34 +542,43 @@ __global__ __launch_bounds__(64 * kSbBwdWaves, 1) void sb_ffn_bwd_kernel(const S
   float db2[2] = {0.f, 0.f}, db1[2] = {0.f, 0.f}, dgm[2] = {0.f, 0.f}, dbt[2] = {0.f, 0.f};
   const float gmc[2] = {vec[m], vec[32 + m]}, btc[2] = {vec[64 + m], vec[96 + m]};      // column layout: columns 32 t + m
   if (s < slabs_n) {
-    unsigned off64[8], off[8];
-    sb_offsets(64, 32, lane, off64);
+    const unsigned lane_part = static_cast<unsigned>(16 * (lane & 15));
+    const unsigned lane_off = static_cast<unsigned>(256 * (lane >> 4)) + lane_part;      // request p: lane_off + 1024 p
     f32x4 ng[8], nh[8], nx[8];
+    float nkp, nmu, nrs;                                  // the rows' keep / mean / rstd travel with the slab's requests
+    const float* keep_p = A.keep != nullptr ? A.keep : A.mean;
     {
+      // a ragged last slab re-reads its last row: min() with that row's offset clamps a request (row * 256 + lane part)
+      unsigned off[8];
       const int left = A.M - s * 32;
+      const unsigned lim = static_cast<unsigned>((left < 32 ? left : 32) - 1) * 256u + lane_part;
 #pragma unroll
-      for (int p = 0; p < 8; ++p) off[p] = off64[p];
-      if (left < 32) sb_offsets(64, left, lane, off);
+      for (int p = 0; p < 8; ++p) off[p] = lane_off + 1024u * p < lim ? lane_off + 1024u * p : lim;
       const long long o = static_cast<long long>(s) * 32 * 64;
       sb_issue_a(A.g0 + o, off, ng);
       sb_issue_a(A.h + o, off, nh);
-      sb_issue_a(A.x + o, off, nx);
+      sb_issue(A.x + o, off, nx);
+      const unsigned ro = 4u * static_cast<unsigned>(s * 32 + m < A.M ? s * 32 + m : A.M - 1);
+      sb_issue_word(keep_p, ro, nkp);
+      sb_issue_word(A.mean, ro, nmu);
+      sb_issue_word(A.rstd, ro, nrs);
     }
+    sb_arrived3(ng, nh, nx, nkp, nmu, nrs);
     for (;;) {
       const int r0 = s * 32;
       const int left = A.M - r0;
       int sn = s + nw;
       const bool more = sn < slabs_n;
       sn = more ? sn : s;
-      const int rr = r0 + m < A.M ? r0 + m : A.M - 1;
-      const float kp = (m < left) ? (A.keep != nullptr ? A.keep[rr] : 1.f) : 0.f;      // rows beyond the end add nothing
-      const float mu = A.mean[rr], rs = A.rstd[rr];
+      const float kp = (m < left) ? (A.keep != nullptr ? nkp : 1.f) : 0.f;             // rows beyond the end add nothing
+      const float mu = nmu, rs = nrs;
       float g[32], xc[32];
       unsigned hmask = 0u;
-      sb_arrived3(ng, nh, nx);
       sb_turn_in(lds, lane, ng, g);
 #pragma unroll
       for (int r = 0; r < 32; ++r) g[r] *= kp;
+      float dh[32], dn[32];
+      if constexpr (ORDER == 1) sb_gemm_row(w2t, lane, g, dh);
       {
         float gc[32], hr[32], hc[32];
         sb_row_to_lds(lds_g, lane, g);                   // (kept there: read back for dn = dh W1 + g)
@@ -546,19 +605,24 @@ __global__ __launch_bounds__(64 * kSbBwdWaves, 1) void sb_ffn_bwd_kernel(const S
         sb_lds_to_col(lds_x, lane, xc);
       }
       {
+        unsigned off[8];
         const int ln = A.M - sn * 32;
+        const unsigned lim = static_cast<unsigned>((ln < 32 ? ln : 32) - 1) * 256u + lane_part;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) off[p] = off64[p];
-        if (ln < 32) sb_offsets(64, ln, lane, off);
+        for (int p = 0; p < 8; ++p) off[p] = lane_off + 1024u * p < lim ? lane_off + 1024u * p : lim;
         const long long o = static_cast<long long>(sn) * 32 * 64;
         sb_issue_a(A.g0 + o, off, ng);
         sb_issue_a(A.h + o, off, nh);
-        sb_issue_a(A.x + o, off, nx);
+        sb_issue(A.x + o, off, nx);
+        const unsigned ro = 4u * static_cast<unsigned>(sn * 32 + m < A.M ? sn * 32 + m : A.M - 1);
+        sb_issue_word(keep_p, ro, nkp);
+        sb_issue_word(A.mean, ro, nmu);
+        sb_issue_word(A.rstd, ro, nrs);
       }
-      float dh[32];
-      sb_gemm_row(w2t, lane, g, dh);
+      if constexpr (ORDER == 0) sb_gemm_row(w2t, lane, g, dh);
 #pragma unroll
       for (int r = 0; r < 32; ++r) dh[r] = ((hmask >> r) & 1u) ? dh[r] : 0.f;
+      if constexpr (ORDER == 1) sb_gemm_row(w1t, lane, dh, dn);
       {
         float dc[32];
         sb_row_to_col(lds, lane, dh, dc);
@@ -576,8 +640,7 @@ __global__ __launch_bounds__(64 * kSbBwdWaves, 1) void sb_ffn_bwd_kernel(const S
           acc1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[16 + q], n1, acc1[1][1], 0, 0, 0);
         }
       }
-      float dn[32];
-      sb_gemm_row(w1t, lane, dh, dn);
+      if constexpr (ORDER == 0) sb_gemm_row(w1t, lane, dh, dn);
       {
         const float* src = lds_g + m * kSbLd + 4 * h;
 #pragma unroll
@@ -624,11 +687,13 @@ __global__ __launch_bounds__(64 * kSbBwdWaves, 1) void sb_ffn_bwd_kernel(const S
       const float m1 = s1 * (1.0f / 64.0f), m2 = s2 * (1.0f / 64.0f);
 #pragma unroll
       for (int r = 0; r < 32; ++r) dn[r] = rs * (dn[r] - m1 - xh[r] * m2);
-      sb_store(lds, lane, dn, A.dx + static_cast<long long>(r0) * 64, off64, left);
+      // the next slab's streams are waited for HERE, in front of the store: behind it, the wait (vmcnt counts stores
+      // too) would hold the next slab until this one's rows are in L2
+      sb_arrived3(ng, nh, nx, nkp, nmu, nrs);
+      sb_store_lin(lds, lane, dn, A.dx + static_cast<long long>(r0) * 64, lane_off, left);
       if (!more) break;
       s = sn;
     }
-    sb_arrived3(ng, nh, nx);
   }
   __syncthreads();                               // every wavefront is done with the weights: the LDS becomes the sum
   float* red = sb_lds;
@@ -647,6 +712,149 @@ __global__ __launch_bounds__(64 * kSbBwdWaves, 1) void sb_ffn_bwd_kernel(const S
   for (int i = threadIdx.x; i < kSbFfnPart; i += 64 * kSbBwdWaves) dst[i] = red[i];
 }
 
+// ---- backward of the attention sub-layer's input side as ONE pass ----------------------------------------------------------
+// Behind the attention's backward: dq = dQ Wq + g (q = LayerNorm(e) feeds the query projection and the residual),
+// de = LayerNormBackward(dq) + dK Wk + dV Wv (e feeds the LayerNorm and the key / value projection), dgamma, dbeta.
+// As separate launches: a dx GEMM, the LayerNorm backward + its final kernel, the 128 -> 64 slab GEMM -- 8 reads and 3
+// writes of [M, 64]; here dQ, dK | dV, g and e are read once and de is written once (the three weight gradients stay
+// with the slab dW kernels).  No accumulators to speak of, so two wavefronts per SIMD share the pipes; a slab's five
+// requests are issued together and waited for one by one (vmcnt counts down in order), the first product runs while the
+// rest is still on its way.
+constexpr int kSbLnPart = 128;                         // dgamma | dbeta
+
+template <int N>
+__device__ __forceinline__ void sb_wait_tile(f32x4 (&v)[8]) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+               : "n"(N)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void sb_wait_tile2(f32x4 (&v)[8], float& u0, float& u1) {
+  asm volatile("s_waitcnt vmcnt(%10)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(u0), "+v"(u1)
+               : "n"(N)
+               : "memory");
+}
+
+struct SbAttnInBwdArgs {
+  const float *dQ, *dKV, *g, *x, *mean, *rstd, *ln_w, *in_w;
+  float *de, *part;
+  int M;
+};
+
+__global__ __launch_bounds__(64 * kSbWaves, 1) void sb_attn_in_bwd_kernel(const SbAttnInBwdArgs A) {
+  extern __shared__ float sb_lds[];
+  float* wq = sb_lds;                          // dq = dQ Wq: Wmat[k][n] = Wq[n][k]
+  float* wk = wq + kSbW;
+  float* wv = wk + kSbW;
+  float* vec = wv + kSbW;                      // gamma
+  float* slabs = vec + 64;
+  sb_stage_weight(wq, A.in_w, 64, true);
+  sb_stage_weight(wk, A.in_w + 64 * 64, 64, true);
+  sb_stage_weight(wv, A.in_w + 2 * 64 * 64, 64, true);
+  sb_stage_vec(vec, A.ln_w, 1.f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nw = static_cast<int>(gridDim.x) * kSbWaves;
+  const int slabs_n = (A.M + 31) >> 5;
+  float* lds = slabs + wid * kSbSlab;
+  float dgm[2] = {0.f, 0.f}, dbt[2] = {0.f, 0.f};
+  const unsigned lane_part = static_cast<unsigned>(16 * (lane & 15));
+  const unsigned lane_off = static_cast<unsigned>(256 * (lane >> 4)) + lane_part;        // request p: lane_off + 1024 p
+  for (int s = static_cast<int>(blockIdx.x) * kSbWaves + wid; s < slabs_n; s += nw) {
+    const int r0 = s * 32;
+    const int left = A.M - r0;
+    f32x4 tq[8], tg[8], tx[8], tk[8], tv[8];
+    float mu, rs;
+    unsigned off[8];
+    const unsigned lim = static_cast<unsigned>((left < 32 ? left : 32) - 1) * 256u + lane_part;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) off[p] = lane_off + 1024u * p < lim ? lane_off + 1024u * p : lim;
+    const long long o = static_cast<long long>(r0) * 64;
+    {
+      const unsigned ro = 4u * static_cast<unsigned>(r0 + m < A.M ? r0 + m : A.M - 1);
+      sb_issue_word(A.mean, ro, mu);
+      sb_issue_word(A.rstd, ro, rs);
+      sb_issue(A.dQ + o, off, tq);
+      sb_issue(A.g + o, off, tg);
+      sb_issue(A.x + o, off, tx);
+    }
+    float a[32], dq[32], xh[32];
+    sb_wait_tile2<16>(tq, mu, rs);
+    sb_turn_in(lds, lane, tq, a);
+    sb_gemm_row(wq, lane, a, dq);
+    sb_wait_tile<8>(tg);
+    sb_turn_in(lds, lane, tg, a);
+    {
+      // dK | dV are requested once two of the first three slabs have left their registers (160 registers of requests in
+      // flight at once spilled); they arrive behind x: vmcnt counts down in order
+#pragma unroll
+      for (int p = 0; p < 8; ++p) off[p] = 2u * off[p] - lane_part;      // the same rows at a pitch of 128 floats
+      sb_issue(A.dKV + 2 * o, off, tk);
+      sb_issue(A.dKV + 2 * o + 64, off, tv);
+    }
+    const bool live = m < left;                           // rows beyond the end add nothing to the column sums
+#pragma unroll
+    for (int r = 0; r < 32; ++r) dq[r] = live ? dq[r] + a[r] : 0.f;
+    sb_wait_tile<16>(tx);                                 // (the 16 requests of dK | dV may still be out)
+    sb_turn_in(lds, lane, tx, xh);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) xh[r] = (xh[r] - mu) * rs;
+    {
+      float dc[32], xc[32];
+      sb_row_to_col(lds, lane, dq, dc);
+      sb_row_to_col(lds, lane, xh, xc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          dbt[t] += dc[16 * t + q];
+          dgm[t] += dc[16 * t + q] * xc[16 * t + q];
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(vec + 32 * (gq >> 2) + 8 * (gq & 3) + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dq[4 * gq + e] *= gm[e];
+        s1 += dq[4 * gq + e];
+        s2 += dq[4 * gq + e] * xh[4 * gq + e];
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float m1 = s1 * (1.0f / 64.0f), m2 = s2 * (1.0f / 64.0f);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) dq[r] = rs * (dq[r] - m1 - xh[r] * m2);
+    float y[32];
+    sb_wait_tile<8>(tk);
+    sb_turn_in(lds, lane, tk, a);
+    sb_gemm_row(wk, lane, a, y);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) dq[r] += y[r];
+    sb_wait_tile<0>(tv);
+    sb_turn_in(lds, lane, tv, a);
+    sb_gemm_row(wv, lane, a, y);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) dq[r] += y[r];
+    sb_store_lin(lds, lane, dq, A.de + static_cast<long long>(r0) * 64, lane_off, left);
+  }
+  __syncthreads();
+  float* red = sb_lds;
+  for (int w = 0; w < kSbWaves; ++w) {
+    if (wid == w) {
+      sb_colsum_to_lds(red, lane, dgm, w == 0);
+      sb_colsum_to_lds(red + 64, lane, dbt, w == 0);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < kSbLnPart) A.part[static_cast<long long>(blockIdx.x) * kSbLnPart + threadIdx.x] = red[threadIdx.x];
+}
+
 // out segment j (offset seg_off[j], length seg_len[j]) = sum over the workgroups' partials, in order
 struct SbReduceArgs {
   const float* part;
@@ -655,23 +863,26 @@ struct SbReduceArgs {
   float* dst[8];
 };
 __global__ __launch_bounds__(256) void sb_reduce_kernel(const SbReduceArgs A) {
-  const int i = static_cast<int>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= A.stride) return;
+  // 32 outputs per workgroup, the partials dealt to 8 groups of lanes (group pg adds partials pg, pg + 8, ... in order),
+  // the 8 group sums added in order: fixed association, 264 workgroups instead of 33 long chains of dependent adds
+  __shared__ float red[8][32];
+  const int o = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int i = static_cast<int>(blockIdx.x) * 32 + o;
+  float acc = 0.f;
+  if (i < A.stride)
+    for (int p = pg; p < A.nparts; p += 8) acc += A.part[static_cast<long long>(p) * A.stride + i];
+  red[pg][o] = acc;
+  __syncthreads();
+  if (pg != 0 || i >= A.stride) return;
   float* d = nullptr;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     if (j < A.nseg && i >= A.seg_off[j] && i < A.seg_off[j] + A.seg_len[j] && A.dst[j] != nullptr) d = A.dst[j] + (i - A.seg_off[j]);
   if (d == nullptr) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int p = 0;
-  for (; p + 4 <= A.nparts; p += 4) {
-    s0 += A.part[static_cast<long long>(p) * A.stride + i];
-    s1 += A.part[static_cast<long long>(p + 1) * A.stride + i];
-    s2 += A.part[static_cast<long long>(p + 2) * A.stride + i];
-    s3 += A.part[static_cast<long long>(p + 3) * A.stride + i];
-  }
-  for (; p < A.nparts; ++p) s0 += A.part[static_cast<long long>(p) * A.stride + i];
-  *d = (s0 + s1) + (s2 + s3);
+  float t = red[0][o];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) t += red[k][o];
+  *d = t;
 }
 
 static int sb_bwd_grid(long long m) {
@@ -766,14 +977,17 @@ extern "C" int rbx_seqblock_ffn_bwd(const float* d_dout, const float* d_keep, co
   SbFfnBwdArgs a{d_dout, d_keep, d_h, d_x, d_mean, d_rstd, d_ln_w, d_ln_b, d_w1, d_w2, d_dx, static_cast<float*>(d_workspace),
                  static_cast<int>(m)};
   const size_t lds = sizeof(float) * (2 * kSbW + 2 * 64 + 3 * kSbBwdWaves * kSbSlab);
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_ffn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(lds)) != hipSuccess)
+  static int order = -1;
+  if (order < 0) {
+    const char* e = getenv("RBX_SB_BWD_ORDER");
+    const int want = (e != nullptr && e[0] == '1') ? 1 : 0;   // measured: 353 vs 339 us (profiles/r04/INDEX.md)
+    const void* fn = want ? reinterpret_cast<const void*>(sb_ffn_bwd_kernel<1>) : reinterpret_cast<const void*>(sb_ffn_bwd_kernel<0>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
       return fail(RBX_ERR_LAUNCH, "rbx_seqblock_ffn_bwd: %zu bytes of LDS refused", lds);
-    once = true;
+    order = want;
   }
-  hipLaunchKernelGGL(sb_ffn_bwd_kernel, dim3(grid), dim3(64 * kSbBwdWaves), lds, as_stream(stream), a);
+  if (order) hipLaunchKernelGGL(sb_ffn_bwd_kernel<1>, dim3(grid), dim3(64 * kSbBwdWaves), lds, as_stream(stream), a);
+  else hipLaunchKernelGGL(sb_ffn_bwd_kernel<0>, dim3(grid), dim3(64 * kSbBwdWaves), lds, as_stream(stream), a);
   int rc = check_launch("sb_ffn_bwd_kernel");
   if (rc != RBX_OK) return rc;
   SbReduceArgs r{};
@@ -785,6 +999,49 @@ extern "C" int rbx_seqblock_ffn_bwd(const float* d_dout, const float* d_keep, co
   const int lens[6] = {kSbW, kSbW, 64, 64, 64, 64};
   float* dsts[6] = {d_dw2, d_dw1, d_db2, d_db1, d_dgamma, d_dbeta};
   for (int j = 0; j < 6; ++j) { r.seg_off[j] = offs[j]; r.seg_len[j] = lens[j]; r.dst[j] = dsts[j]; }
-  hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbFfnPart + 255) / 256), dim3(256), 0, as_stream(stream), r);
+  hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbFfnPart + 31) / 32), dim3(256), 0, as_stream(stream), r);
+  return check_launch("sb_reduce_kernel");
+}
+
+extern "C" size_t rbx_seqblock_attn_in_bwd_workspace_size(int64_t m) {
+  return m <= 0 ? 0 : sizeof(float) * static_cast<size_t>(sb_grid(m)) * kSbLnPart;
+}
+
+extern "C" int rbx_seqblock_attn_in_bwd(const float* d_dQ, const float* d_dKV, const float* d_g, const float* d_x,
+                                        const float* d_mean, const float* d_rstd, int64_t m, const float* d_ln_w,
+                                        const float* d_in_w, float* d_de, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                                        size_t workspace_bytes, void* stream) {
+  if (m < 0 || m > (1LL << 30)) return fail(RBX_ERR_INVALID, "rbx_seqblock_attn_in_bwd: m = %lld", static_cast<long long>(m));
+  if (m == 0) return RBX_OK;
+  if (!d_dQ || !d_dKV || !d_g || !d_x || !d_mean || !d_rstd || !d_in_w || !d_de)
+    return fail(RBX_ERR_INVALID, "rbx_seqblock_attn_in_bwd: NULL operand");
+  if (!sb_aligned(d_dQ) || !sb_aligned(d_dKV) || !sb_aligned(d_g) || !sb_aligned(d_x) || !sb_aligned(d_de))
+    return fail(RBX_ERR_UNSUPPORTED, "rbx_seqblock_attn_in_bwd: activations must be 16-byte aligned");
+  const size_t need = rbx_seqblock_attn_in_bwd_workspace_size(m);
+  if (d_workspace == nullptr || workspace_bytes < need)
+    return fail(RBX_ERR_WORKSPACE, "rbx_seqblock_attn_in_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+  const int grid = sb_grid(m);
+  SbAttnInBwdArgs a{d_dQ, d_dKV, d_g, d_x, d_mean, d_rstd, d_ln_w, d_in_w, d_de, static_cast<float*>(d_workspace),
+                    static_cast<int>(m)};
+  const size_t lds = sizeof(float) * (3 * kSbW + 64 + kSbWaves * kSbSlab);
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_attn_in_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds)) != hipSuccess)
+      return fail(RBX_ERR_LAUNCH, "rbx_seqblock_attn_in_bwd: %zu bytes of LDS refused", lds);
+    once = true;
+  }
+  hipLaunchKernelGGL(sb_attn_in_bwd_kernel, dim3(grid), dim3(64 * kSbWaves), lds, as_stream(stream), a);
+  int rc = check_launch("sb_attn_in_bwd_kernel");
+  if (rc != RBX_OK) return rc;
+  if (d_dgamma == nullptr && d_dbeta == nullptr) return RBX_OK;
+  SbReduceArgs r{};
+  r.part = static_cast<const float*>(d_workspace);
+  r.nparts = grid;
+  r.stride = kSbLnPart;
+  r.nseg = 2;
+  r.seg_off[0] = 0; r.seg_len[0] = 64; r.dst[0] = d_dgamma;
+  r.seg_off[1] = 64; r.seg_len[1] = 64; r.dst[1] = d_dbeta;
+  hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbLnPart + 31) / 32), dim3(256), 0, as_stream(stream), r);
   return check_launch("sb_reduce_kernel");
 }

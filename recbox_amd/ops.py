@@ -3115,10 +3115,20 @@ class _SeqBlock(torch.autograd.Function):
         d_in_b = torch.empty(3 * E, **f32) if (has_in_b and need[5]) else None
         _lin_dwdb(q, in_w[:E], dQ, d_in_w[:E] if d_in_w is not None else None, d_in_b[:E] if d_in_b is not None else None)
         _lin_dwdb(x2, in_w[E:], dKV, d_in_w[E:] if d_in_w is not None else None, d_in_b[E:] if d_in_b is not None else None)
-        dq = _lin_dx(dQ, in_w[:E], residual=g)
         want1 = need[1] or (has_ln1_b and need[2])
-        de_ln, dgamma1, dbeta1 = _ln_bwd(x2, dq, ln1_w, mean1, rstd1, want1)
-        de = _lin_dx(dKV, in_w[E:], residual=de_ln) if need[0] else None
+        if config.seqblock_bwd:
+            M = B * L
+            de = torch.empty((M, E), **f32)
+            dgamma1 = torch.empty(E, **f32) if want1 else None
+            dbeta1 = torch.empty(E, **f32) if want1 else None
+            ws_bytes = lib.rbx_seqblock_attn_in_bwd_workspace_size(M)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            check(lib.rbx_seqblock_attn_in_bwd(_ptr(dQ), _ptr(dKV), _ptr(g), _ptr(x2), _ptr(mean1), _ptr(rstd1), M, _ptr(ln1_w),
+                                               _ptr(in_w), _ptr(de), _ptr(dgamma1), _ptr(dbeta1), _ptr(ws), ws_bytes, _stream()))
+        else:
+            dq = _lin_dx(dQ, in_w[:E], residual=g)
+            de_ln, dgamma1, dbeta1 = _ln_bwd(x2, dq, ln1_w, mean1, rstd1, want1)
+            de = _lin_dx(dKV, in_w[E:], residual=de_ln) if need[0] else None
         return (de.view(B, L, E) if de is not None else None, dgamma1 if need[1] else None,
                 dbeta1 if (has_ln1_b and need[2]) else None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None,
                 dgamma2 if need[11] else None, dbeta2 if (has_ln2_b and need[12]) else None, None, dw1, db1, dw2, db2, None)

@@ -139,6 +139,41 @@ def test_ffn_backward_chain_vs_float64(M):
     assert torch.equal(dx, got[0])
 
 
+@pytest.mark.parametrize("M", [19, 64, 9000, 40960])
+def test_attention_input_backward_chain_vs_float64(M):
+    """rbx_seqblock_attn_in_bwd: dq = dQ Wq + g, LayerNorm backward, + dK Wk + dV Wv, dgamma / dbeta."""
+    from recbox_amd._lib import lib
+    P, gen = _params(5)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    x, dQ, dKV, g = r(M, E), r(M, E), r(M, 2 * E), r(M, E)
+    lw = P["ln1_w"].double().requires_grad_(True)
+    lb = P["ln1_b"].double().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    W = P["in_w"].double()
+    q = _ln(x64, lw, lb)
+    # the scalar whose gradient is the chain: q feeds Q = q Wq^T (gradient dQ) and the residual (gradient g); e feeds K | V
+    ((q @ W[:E].t()) * dQ.double()).sum().add((q * g.double()).sum()).add(((x64 @ W[E:].t()) * dKV.double()).sum()).backward()
+    d = {k: v.cuda() for k, v in P.items()}
+    xc, qc, kvc, gc = x.cuda(), dQ.cuda(), dKV.cuda(), g.cuda()
+    mean = x64.detach().mean(1).float().cuda()
+    rstd = (x64.detach().var(1, unbiased=False) + 1e-8).rsqrt().float().cuda()
+    f = lambda *s: torch.full(s, float("nan"), device="cuda")
+    de, dg, db = f(M, E), f(E), f(E)
+    nbytes = lib.rbx_seqblock_attn_in_bwd_workspace_size(M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    outs = []
+    for rep in range(2):
+        rc = lib.rbx_seqblock_attn_in_bwd(_p(qc), _p(kvc), _p(gc), _p(xc), _p(mean), _p(rstd), M, _p(d["ln1_w"]), _p(d["in_w"]),
+                                          _p(de), _p(dg), _p(db), _p(ws), nbytes, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (de, dg, db)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    for name, a, b in zip(("de", "dgamma", "dbeta"), outs[1], (x64.grad, lw.grad, lb.grad)):
+        assert_close(a, b, TOL * max(1.0, float(b.abs().max())), name)
+
+
 def _block64(e, P, keep, heads):
     """sasrec.py:81-92 in float64 (batch-first; causal mask; no dropout)."""
     B, L, _ = e.shape
