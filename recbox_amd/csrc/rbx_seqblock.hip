@@ -855,6 +855,95 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_attn_in_bwd_kernel(const 
   if (threadIdx.x < kSbLnPart) A.part[static_cast<long long>(blockIdx.x) * kSbLnPart + threadIdx.x] = red[threadIdx.x];
 }
 
+// ---- backward of the out-projection as ONE pass: dO = g Wo, dWo = g^T O, dbo = colsum g ------------------------------------
+// (a dW slab pass + a dx GEMM before: g read twice.)  64 accumulators: two wavefronts per SIMD still fit.
+constexpr int kSbOutPart = kSbW + 64;                  // dWo | dbo
+
+struct SbAttnOutBwdArgs {
+  const float *g, *O, *wo;
+  float *dO, *part;
+  int M;
+};
+
+__global__ __launch_bounds__(64 * kSbWaves, 1) void sb_attn_out_bwd_kernel(const SbAttnOutBwdArgs A) {
+  extern __shared__ float sb_lds[];
+  float* wot = sb_lds;                         // dO = g Wo: Wmat[k][n] = Wo[n][k]
+  float* slabs = wot + kSbW + 64;              // (+ 64: the workgroup's sum, kSbOutPart floats, ends in front of the slabs)
+  sb_stage_weight(wot, A.wo, 64, true);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, m = lane & 31;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nw = static_cast<int>(gridDim.x) * kSbWaves;
+  const int slabs_n = (A.M + 31) >> 5;
+  float* lds = slabs + wid * kSbSlab;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  float dbo[2] = {0.f, 0.f};
+  const unsigned lane_part = static_cast<unsigned>(16 * (lane & 15));
+  const unsigned lane_off = static_cast<unsigned>(256 * (lane >> 4)) + lane_part;
+  for (int s = static_cast<int>(blockIdx.x) * kSbWaves + wid; s < slabs_n; s += nw) {
+    const int r0 = s * 32;
+    const int left = A.M - r0;
+    f32x4 tg[8], to[8];
+    {
+      unsigned off[8];
+      const unsigned lim = static_cast<unsigned>((left < 32 ? left : 32) - 1) * 256u + lane_part;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) off[p] = lane_off + 1024u * p < lim ? lane_off + 1024u * p : lim;
+      const long long o = static_cast<long long>(r0) * 64;
+      sb_issue(A.g + o, off, tg);
+      sb_issue(A.O + o, off, to);
+    }
+    float g[32], gc[32], oc[32];
+    sb_wait_tile<8>(tg);
+    sb_turn_in(lds, lane, tg, g);
+    if (left < 32) {                                      // rows beyond the end add nothing (wave-uniform test)
+      const bool live = m < left;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) g[r] = live ? g[r] : 0.f;
+      sb_row_to_lds(lds, lane, g);
+      sb_wave_sync();
+    }
+    sb_lds_to_col(lds, lane, gc);                         // (the slab still holds the tile)
+    sb_wave_sync();
+    {
+      float y[32];
+      sb_gemm_row(wot, lane, g, y);
+      sb_wait_tile<0>(to);                                // in front of the store (vmcnt counts stores too)
+      sb_store_lin(lds, lane, y, A.dO + static_cast<long long>(r0) * 64, lane_off, left);
+    }
+    {
+      float* dst = lds + (lane >> 4) * kSbLd + 4 * (lane & 15);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4*>(dst + 4 * p * kSbLd) = to[p];
+      sb_wave_sync();
+      sb_lds_to_col(lds, lane, oc);
+      sb_wave_sync();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dbo[t] += gc[16 * t + q];
+    sb_dw_acc(gc, oc, acc);
+  }
+  __syncthreads();
+  float* red = sb_lds;
+  for (int w = 0; w < kSbWaves; ++w) {
+    if (wid == w) {
+      sb_acc_to_lds(red, lane, acc, w == 0);
+      sb_colsum_to_lds(red + kSbW, lane, dbo, w == 0);
+    }
+    __syncthreads();
+  }
+  float* dstp = A.part + static_cast<long long>(blockIdx.x) * kSbOutPart;
+  for (int i = threadIdx.x; i < kSbOutPart; i += 64 * kSbWaves) dstp[i] = red[i];
+}
+
 // out segment j (offset seg_off[j], length seg_len[j]) = sum over the workgroups' partials, in order
 struct SbReduceArgs {
   const float* part;
@@ -1043,5 +1132,45 @@ extern "C" int rbx_seqblock_attn_in_bwd(const float* d_dQ, const float* d_dKV, c
   r.seg_off[0] = 0; r.seg_len[0] = 64; r.dst[0] = d_dgamma;
   r.seg_off[1] = 64; r.seg_len[1] = 64; r.dst[1] = d_dbeta;
   hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbLnPart + 31) / 32), dim3(256), 0, as_stream(stream), r);
+  return check_launch("sb_reduce_kernel");
+}
+
+extern "C" size_t rbx_seqblock_attn_out_bwd_workspace_size(int64_t m) {
+  return m <= 0 ? 0 : sizeof(float) * static_cast<size_t>(sb_grid(m)) * kSbOutPart;
+}
+
+extern "C" int rbx_seqblock_attn_out_bwd(const float* d_g, const float* d_O, int64_t m, const float* d_wo, float* d_dO,
+                                         float* d_dwo, float* d_dbo, void* d_workspace, size_t workspace_bytes,
+                                         void* stream) {
+  if (m < 0 || m > (1LL << 30)) return fail(RBX_ERR_INVALID, "rbx_seqblock_attn_out_bwd: m = %lld", static_cast<long long>(m));
+  if (m == 0) return RBX_OK;
+  if (!d_g || !d_O || !d_wo || !d_dO) return fail(RBX_ERR_INVALID, "rbx_seqblock_attn_out_bwd: NULL operand");
+  if (!sb_aligned(d_g) || !sb_aligned(d_O) || !sb_aligned(d_dO))
+    return fail(RBX_ERR_UNSUPPORTED, "rbx_seqblock_attn_out_bwd: activations must be 16-byte aligned");
+  const size_t need = rbx_seqblock_attn_out_bwd_workspace_size(m);
+  if (d_workspace == nullptr || workspace_bytes < need)
+    return fail(RBX_ERR_WORKSPACE, "rbx_seqblock_attn_out_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+  const int grid = sb_grid(m);
+  SbAttnOutBwdArgs a{d_g, d_O, d_wo, d_dO, static_cast<float*>(d_workspace), static_cast<int>(m)};
+  const size_t lds = sizeof(float) * (kSbW + 64 + kSbWaves * kSbSlab);
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_attn_out_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds)) != hipSuccess)
+      return fail(RBX_ERR_LAUNCH, "rbx_seqblock_attn_out_bwd: %zu bytes of LDS refused", lds);
+    once = true;
+  }
+  hipLaunchKernelGGL(sb_attn_out_bwd_kernel, dim3(grid), dim3(64 * kSbWaves), lds, as_stream(stream), a);
+  int rc = check_launch("sb_attn_out_bwd_kernel");
+  if (rc != RBX_OK) return rc;
+  if (d_dwo == nullptr && d_dbo == nullptr) return RBX_OK;
+  SbReduceArgs r{};
+  r.part = static_cast<const float*>(d_workspace);
+  r.nparts = grid;
+  r.stride = kSbOutPart;
+  r.nseg = 2;
+  r.seg_off[0] = 0; r.seg_len[0] = kSbW; r.dst[0] = d_dwo;
+  r.seg_off[1] = kSbW; r.seg_len[1] = 64; r.dst[1] = d_dbo;
+  hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbOutPart + 31) / 32), dim3(256), 0, as_stream(stream), r);
   return check_launch("sb_reduce_kernel");
 }

@@ -56,6 +56,8 @@ class config(object):
     # third stream and 0.314 behind the sort on the second, vs 0.261): a replayed graph runs on TWO hardware queues whatever
     # the capture's streams were, and with a third branch the runtime put the reduce behind the sort chain
     # (profiles/r02/fm_replay_timeline_numeric_beside.txt).  Off.
+    # ... or behind the large tables' reduce on the side stream (the shorter of the two chains of the tiered backward)
+    fm_numeric_on_side = os.environ.get("RECBOX_AMD_FM_NUMERIC_ON", "main") == "side"
     numeric_beside_reduce = {"0": False, "1": True, "presorted": "presorted"}[os.environ.get("RECBOX_AMD_NUMERIC_BESIDE", "0")]
     # binary_cross_entropy of a sigmoid_output(): one pass over the logits (+ final sum) and one scale kernel in the backward
     # instead of sigmoid / BCE partial / final / BCE backward / sigmoid backward -- 8 launches of ~5 us in a row
@@ -1329,6 +1331,14 @@ class _FmFused(torch.autograd.Function):
             side.wait_event(grads_ready)
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (16 if a_side else 8) | store,
                                  _ptr(ws), ws_bytes, ctypes.c_void_p(side.cuda_stream)))
+            numeric_on_side = (not numeric_first and not beside and config.fm_numeric_on_side)
+            if numeric_on_side:
+                # the numeric weights + bias behind the SHORTER of the two chains (the large tables' reduce ends ~15 us
+                # before the small tables' row writes, profiles/r04/fm_replay_timeline.txt)
+                check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws), ws_bytes,
+                                     ctypes.c_void_p(side.cuda_stream)))
+                if gb is not None:
+                    gb.record_stream(side)
             side_done = side.record_event()
             for t in [dlogit, ssum] + [g for g in grads if g is not None]:
                 if t is not None:
@@ -1339,7 +1349,7 @@ class _FmFused(torch.autograd.Function):
                 cur.wait_event(ctx.sort.event_first)
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (8 if a_side else 16) | store,
                                  _ptr(ws), ws_bytes, _stream()))
-            if not numeric_first and not beside:
+            if not numeric_first and not beside and not numeric_on_side:
                 check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws), ws_bytes,
                                      _stream()))
             cur.wait_event(side_done)
@@ -3098,8 +3108,15 @@ class _SeqBlock(torch.autograd.Function):
         # ---- attention sub-layer
         d_out_w = torch.empty_like(out_w) if need[6] else None
         d_out_b = torch.empty(E, **f32) if (has_out_b and need[7]) else None
-        _lin_dwdb(O, out_w, g, d_out_w, d_out_b)
-        dO = _lin_dx(g, out_w)
+        if config.seqblock_bwd:
+            dO = torch.empty((B * L, E), **f32)
+            ws_bytes = lib.rbx_seqblock_attn_out_bwd_workspace_size(B * L)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            check(lib.rbx_seqblock_attn_out_bwd(_ptr(g), _ptr(O), B * L, _ptr(out_w), _ptr(dO), _ptr(d_out_w), _ptr(d_out_b),
+                                                _ptr(ws), ws_bytes, _stream()))
+        else:
+            _lin_dwdb(O, out_w, g, d_out_w, d_out_b)
+            dO = _lin_dx(g, out_w)
         dQ = torch.empty_like(Q)
         dKV = torch.empty_like(KV)
         scratch = torch.empty((B * heads, L), **f32)

@@ -226,7 +226,10 @@ class SASRec(torch.nn.Module):
         candidate row once and never writes the two [B, L, D] candidate tensors (nor their gradients)."""
         seq_f, cand_f = self.features[0], self.features[1:]
         seq_embed = self.item_emb(x, [seq_f])                 # [B, 1, L, D]
-        seq_output = self.seq_forward(x, seq_embed[:, 0])
+        # (a view, not seq_embed[:, 0]: the backward of a select is a zero fill + a copy of the whole [B, L, D] gradient --
+        #  117 us per step at cfg 5, profiles/r04/INDEX.md; a view's backward is a view)
+        seq_output = self.seq_forward(x, seq_embed.view(seq_embed.shape[0], seq_embed.shape[2], seq_embed.shape[3])
+                                      if seq_embed.dim() == 4 and seq_embed.shape[1] == 1 else seq_embed[:, 0])
         B, L, D = seq_output.shape
         tables = [self.item_emb.embed_dict[f.name if f.shared_with is None else f.shared_with].weight for f in cand_f]
         logits = ops.gather_dot(seq_output.reshape(B * L, D), [x[f.name].reshape(-1) for f in cand_f], tables)

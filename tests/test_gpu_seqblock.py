@@ -174,6 +174,29 @@ def test_attention_input_backward_chain_vs_float64(M):
         assert_close(a, b, TOL * max(1.0, float(b.abs().max())), name)
 
 
+@pytest.mark.parametrize("M", [19, 64, 9000, 40960])
+def test_out_projection_backward_vs_float64(M):
+    """rbx_seqblock_attn_out_bwd: dO = g Wo, dWo = g^T O, dbo = colsum g."""
+    from recbox_amd._lib import lib
+    P, gen = _params(6)
+    g, O = torch.randn(M, E, generator=gen), torch.randn(M, E, generator=gen)
+    gc, oc, wc = g.cuda(), O.cuda(), P["out_w"].cuda()
+    f = lambda *s: torch.full(s, float("nan"), device="cuda")
+    dO, dw, db = f(M, E), f(E, E), f(E)
+    nbytes = lib.rbx_seqblock_attn_out_bwd_workspace_size(M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    outs = []
+    for rep in range(2):
+        assert lib.rbx_seqblock_attn_out_bwd(_p(gc), _p(oc), M, _p(wc), _p(dO), _p(dw), _p(db), _p(ws), nbytes, None) == 0
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (dO, dw, db)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    g64, O64, W = g.double(), O.double(), P["out_w"].double()
+    for name, a, b in zip(("dO", "dWo", "dbo"), outs[1], (g64 @ W, g64.t() @ O64, g64.sum(0))):
+        assert_close(a, b, TOL * max(1.0, float(b.abs().max())), name)
+
+
 def _block64(e, P, keep, heads):
     """sasrec.py:81-92 in float64 (batch-first; causal mask; no dropout)."""
     B, L, _ = e.shape
