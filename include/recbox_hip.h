@@ -796,7 +796,9 @@ int rbx_pool_bwd(const float* d_dout, const float* d_mask, const float* d_inv, i
  *                          beta.  Parameter gradients (any may be NULL) are OVERWRITTEN, summed in a fixed order.
  *   rbx_seqblock_attn_in_bwd: behind the attention's backward, one pass: dq = dQ Wq + g (g = the gradient arriving over
  *                          the residual), dgamma / dbeta and the LayerNorm backward of dq, de = that + dK Wk + dV Wv
- *                          (d_dKV [m, 128] = dK | dV).  The three in-projection weight gradients are not part of it. */
+ *                          (d_dKV [m, 128] = dK | dV), stored as de * row_scale[row] * alpha when d_row_scale != NULL (the backward of SASRec's
+ *                          input stage `(alpha e + position) * keep`, sasrec.py:68-77, folded into the first block).  The
+ *                          three in-projection weight gradients are not part of it. */
 /*   rbx_seqblock_attn_out_bwd: the out-projection's backward, one pass: dO = g Wo, dWo = g^T O, dbo = colsum g. */
 int rbx_seqblock_qkv_fwd(const float* d_x, int64_t m, const float* d_ln_w, const float* d_ln_b, float eps,
                          const float* d_in_w, const float* d_in_b, float* d_mean, float* d_rstd, float* d_q, float* d_Q,
@@ -812,8 +814,9 @@ int rbx_seqblock_ffn_bwd(const float* d_dout, const float* d_keep, const float* 
                          float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream);
 size_t rbx_seqblock_attn_in_bwd_workspace_size(int64_t m);
 int rbx_seqblock_attn_in_bwd(const float* d_dQ, const float* d_dKV, const float* d_g, const float* d_x, const float* d_mean,
-                             const float* d_rstd, int64_t m, const float* d_ln_w, const float* d_in_w, float* d_de,
-                             float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, void* stream);
+                             const float* d_rstd, int64_t m, const float* d_ln_w, const float* d_in_w,
+                             const float* d_row_scale, float alpha, float* d_de, float* d_dgamma, float* d_dbeta,
+                             void* d_workspace, size_t workspace_bytes, void* stream);
 size_t rbx_seqblock_attn_out_bwd_workspace_size(int64_t m);
 int rbx_seqblock_attn_out_bwd(const float* d_g, const float* d_O, int64_t m, const float* d_wo, float* d_dO, float* d_dwo,
                               float* d_dbo, void* d_workspace, size_t workspace_bytes, void* stream);

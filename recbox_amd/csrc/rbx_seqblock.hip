@@ -741,7 +741,17 @@ struct SbAttnInBwdArgs {
   const float *dQ, *dKV, *g, *x, *mean, *rstd, *ln_w, *in_w;
   float *de, *part;
   int M;
+  const float* row_scale;      // optional: de is stored as de * row_scale[row] * alpha (the backward of SASRec's input stage,
+  float alpha;                 // (alpha e + position) * keep, sasrec.py:68-77, folded into the block in front of it)
 };
+template <int N>
+__device__ __forceinline__ void sb_wait_tile3(f32x4 (&v)[8], float& u0, float& u1, float& u2) {
+  asm volatile("s_waitcnt vmcnt(%11)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(u0), "+v"(u1),
+                 "+v"(u2)
+               : "n"(N)
+               : "memory");
+}
 
 __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_attn_in_bwd_kernel(const SbAttnInBwdArgs A) {
   extern __shared__ float sb_lds[];
@@ -767,7 +777,7 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_attn_in_bwd_kernel(const 
     const int r0 = s * 32;
     const int left = A.M - r0;
     f32x4 tq[8], tg[8], tx[8], tk[8], tv[8];
-    float mu, rs;
+    float mu, rs, rsc;
     unsigned off[8];
     const unsigned lim = static_cast<unsigned>((left < 32 ? left : 32) - 1) * 256u + lane_part;
 #pragma unroll
@@ -777,12 +787,13 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_attn_in_bwd_kernel(const 
       const unsigned ro = 4u * static_cast<unsigned>(r0 + m < A.M ? r0 + m : A.M - 1);
       sb_issue_word(A.mean, ro, mu);
       sb_issue_word(A.rstd, ro, rs);
+      sb_issue_word(A.row_scale != nullptr ? A.row_scale : A.mean, ro, rsc);
       sb_issue(A.dQ + o, off, tq);
       sb_issue(A.g + o, off, tg);
       sb_issue(A.x + o, off, tx);
     }
     float a[32], dq[32], xh[32];
-    sb_wait_tile2<16>(tq, mu, rs);
+    sb_wait_tile3<16>(tq, mu, rs, rsc);
     sb_turn_in(lds, lane, tq, a);
     sb_gemm_row(wq, lane, a, dq);
     sb_wait_tile<8>(tg);
@@ -839,8 +850,9 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_attn_in_bwd_kernel(const 
     sb_wait_tile<0>(tv);
     sb_turn_in(lds, lane, tv, a);
     sb_gemm_row(wv, lane, a, y);
+    const float osc = A.row_scale != nullptr ? rsc * A.alpha : 1.f;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) dq[r] += y[r];
+    for (int r = 0; r < 32; ++r) dq[r] = (dq[r] + y[r]) * osc;
     sb_store_lin(lds, lane, dq, A.de + static_cast<long long>(r0) * 64, lane_off, left);
   }
   __syncthreads();
@@ -1098,8 +1110,9 @@ extern "C" size_t rbx_seqblock_attn_in_bwd_workspace_size(int64_t m) {
 
 extern "C" int rbx_seqblock_attn_in_bwd(const float* d_dQ, const float* d_dKV, const float* d_g, const float* d_x,
                                         const float* d_mean, const float* d_rstd, int64_t m, const float* d_ln_w,
-                                        const float* d_in_w, float* d_de, float* d_dgamma, float* d_dbeta, void* d_workspace,
-                                        size_t workspace_bytes, void* stream) {
+                                        const float* d_in_w, const float* d_row_scale, float alpha, float* d_de,
+                                        float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes,
+                                        void* stream) {
   if (m < 0 || m > (1LL << 30)) return fail(RBX_ERR_INVALID, "rbx_seqblock_attn_in_bwd: m = %lld", static_cast<long long>(m));
   if (m == 0) return RBX_OK;
   if (!d_dQ || !d_dKV || !d_g || !d_x || !d_mean || !d_rstd || !d_in_w || !d_de)
@@ -1111,7 +1124,7 @@ extern "C" int rbx_seqblock_attn_in_bwd(const float* d_dQ, const float* d_dKV, c
     return fail(RBX_ERR_WORKSPACE, "rbx_seqblock_attn_in_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
   const int grid = sb_grid(m);
   SbAttnInBwdArgs a{d_dQ, d_dKV, d_g, d_x, d_mean, d_rstd, d_ln_w, d_in_w, d_de, static_cast<float*>(d_workspace),
-                    static_cast<int>(m)};
+                    static_cast<int>(m), d_row_scale, alpha};
   const size_t lds = sizeof(float) * (3 * kSbW + 64 + kSbWaves * kSbSlab);
   static bool once = false;
   if (!once) {

@@ -3040,7 +3040,7 @@ class _SeqBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, e, ln1_w, ln1_b, eps1, in_w, in_b, out_w, out_b, heads, p_drop, seed, ln2_w, ln2_b, eps2, w1, b1, w2, b2,
-                keep):
+                keep, pos, alpha):
         _require_cuda(e, "sequence block")
         B, L, E = e.shape
         M = B * L
@@ -3048,6 +3048,16 @@ class _SeqBlock(torch.autograd.Function):
         x2 = e.contiguous().float().view(M, E)
         in_w, out_w, w1, w2 = in_w.contiguous(), out_w.contiguous(), w1.contiguous(), w2.contiguous()
         k1 = keep.contiguous().float().view(-1)
+        if pos is not None:
+            # SASRec's input stage in front of the FIRST block (sasrec.py:68-77): e is the raw item block, the block's input
+            # (alpha e + pos[l]) * keep; its backward rides in the store of rbx_seqblock_attn_in_bwd (no pass of its own)
+            p2 = pos.contiguous().float()
+            if tuple(p2.shape) != (L, E):
+                raise ValueError("sasrec_block: position rows must be [L, D] = [%d, %d], got %s" % (L, E, tuple(p2.shape)))
+            raw = x2
+            x2 = torch.empty_like(raw)
+            check(lib.rbx_rowscale_seq(_ptr(raw), _ptr(p2), L, _ptr(k1), M, E, float(alpha), _ptr(x2), _stream()))
+        ctx.input_stage = (pos is not None, float(alpha))
         hd = E // heads
         f32 = dict(dtype=torch.float32, device=dev)
         q, Q, KV = torch.empty((M, E), **f32), torch.empty((M, E), **f32), torch.empty((M, 2 * E), **f32)
@@ -3133,7 +3143,9 @@ class _SeqBlock(torch.autograd.Function):
         _lin_dwdb(q, in_w[:E], dQ, d_in_w[:E] if d_in_w is not None else None, d_in_b[:E] if d_in_b is not None else None)
         _lin_dwdb(x2, in_w[E:], dKV, d_in_w[E:] if d_in_w is not None else None, d_in_b[E:] if d_in_b is not None else None)
         want1 = need[1] or (has_ln1_b and need[2])
-        if config.seqblock_bwd:
+        staged, alpha = ctx.input_stage
+        dpos = None
+        if config.seqblock_bwd or staged:
             M = B * L
             de = torch.empty((M, E), **f32)
             dgamma1 = torch.empty(E, **f32) if want1 else None
@@ -3141,14 +3153,23 @@ class _SeqBlock(torch.autograd.Function):
             ws_bytes = lib.rbx_seqblock_attn_in_bwd_workspace_size(M)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             check(lib.rbx_seqblock_attn_in_bwd(_ptr(dQ), _ptr(dKV), _ptr(g), _ptr(x2), _ptr(mean1), _ptr(rstd1), M, _ptr(ln1_w),
-                                               _ptr(in_w), _ptr(de), _ptr(dgamma1), _ptr(dbeta1), _ptr(ws), ws_bytes, _stream()))
+                                               _ptr(in_w), _ptr(k1) if staged else None, alpha if staged else 1.0, _ptr(de),
+                                               _ptr(dgamma1), _ptr(dbeta1), _ptr(ws), ws_bytes, _stream()))
+            if staged and need[19]:
+                # dpos[l] = sum_b keep de = (sum_b keep * (de keep alpha)) / alpha for a 0 / 1 keep
+                dpos = torch.empty((L, E), **f32)
+                cs_bytes = lib.rbx_seq_colsum_workspace_size(B, L, E)
+                cs = torch.empty(max(cs_bytes, 1), dtype=torch.uint8, device=dev)
+                check(lib.rbx_seq_colsum(_ptr(de), _ptr(k1), B, L, E, _ptr(dpos), _ptr(cs), cs_bytes, _stream()))
+                dpos.mul_(1.0 / alpha)
         else:
             dq = _lin_dx(dQ, in_w[:E], residual=g)
             de_ln, dgamma1, dbeta1 = _ln_bwd(x2, dq, ln1_w, mean1, rstd1, want1)
             de = _lin_dx(dKV, in_w[E:], residual=de_ln) if need[0] else None
         return (de.view(B, L, E) if de is not None else None, dgamma1 if need[1] else None,
                 dbeta1 if (has_ln1_b and need[2]) else None, None, d_in_w, d_in_b, d_out_w, d_out_b, None, None, None,
-                dgamma2 if need[11] else None, dbeta2 if (has_ln2_b and need[12]) else None, None, dw1, db1, dw2, db2, None)
+                dgamma2 if need[11] else None, dbeta2 if (has_ln2_b and need[12]) else None, None, dw1, db1, dw2, db2, None,
+                dpos, None)
 
 
 def seqblock_supported(e, mha, ffn_has_dropout, keep_is_mask=True):
@@ -3160,13 +3181,18 @@ def seqblock_supported(e, mha, ffn_has_dropout, keep_is_mask=True):
     return attention_packed_supported(e.shape[1], 64 // mha.num_heads) and e.shape[0] * e.shape[1] >= 8192
 
 
-def sasrec_block(e, norm1, mha, norm2, w1, b1, w2, b2, keep, dropout_p=0.0, seed=None):
-    """One block of seq_forward (sasrec.py:81-92) for [B, L, 64]; keep [B, L] is the 0 / 1 ``~timeline_mask``."""
+def sasrec_block(e, norm1, mha, norm2, w1, b1, w2, b2, keep, dropout_p=0.0, seed=None, input_stage=None):
+    """One block of seq_forward (sasrec.py:81-92) for [B, L, 64]; keep [B, L] is the 0 / 1 ``~timeline_mask``.
+    ``input_stage = (pos_rows [L, 64], alpha)``: e is the RAW item block and the block first forms its input
+    ``(alpha * e + pos_rows[None]) * keep[..., None]`` (sasrec.py:68-77, as ops.sasrec_input does); alpha != 0."""
     if dropout_p and seed is None:
         seed = _draw_seed()
+    pos, alpha = (None, 1.0) if input_stage is None else input_stage
+    if pos is not None and not alpha:
+        raise ValueError("sasrec_block: the input stage's alpha must not be 0")
     return _SeqBlock.apply(e, norm1.weight, norm1.bias, float(norm1.eps), mha.in_proj_weight, mha.in_proj_bias,
                            mha.out_proj.weight, mha.out_proj.bias, int(mha.num_heads), float(dropout_p or 0.0), int(seed or 0),
-                           norm2.weight, norm2.bias, float(norm2.eps), w1, b1, w2, b2, keep)
+                           norm2.weight, norm2.bias, float(norm2.eps), w1, b1, w2, b2, keep, pos, float(alpha))
 
 
 class _DeepFmInput(torch.autograd.Function):

@@ -182,17 +182,28 @@ class SASRec(torch.nn.Module):
         positions = torch.arange(ids.shape[1], device=ids.device).unsqueeze(0).expand(ids.shape[0], -1)
         keep = (ids != 0).to(e.dtype)                         # ~timeline_mask, one value per (sample, position)
         scale = self.features[0].embed_dim ** 0.5
+        input_stage = None
         if isinstance(self.emb_dropout, torch.nn.Dropout) and self.emb_dropout.p > 0 and self.training:
             e = self.emb_dropout(e * scale + ops_position(self.position_emb, positions))
             e = ops.row_scale(e, keep)
         elif (ops.config.seq_positions_in_place and e.dim() == 3 and self.position_emb.padding_idx is None
               and self.position_emb.max_norm is None and ids.shape[1] <= self.position_emb.num_embeddings):
             # positions are arange(L) for every sequence: the table's first L rows read in place, their gradient a column sum
-            e = ops.sasrec_input(e, self.position_emb.weight[:ids.shape[1]], keep, alpha=scale)
+            first = self.attention_layers[0] if len(self.attention_layers) else None
+            ffn0 = self.forward_layers[0] if len(self.forward_layers) else None
+            if (first is not None and ops.config.fuse_sublayers and ops.config.seqblock_bwd
+                    and not (self.training and (ffn0.dropout1.p > 0 or ffn0.dropout2.p > 0))
+                    and ops.seqblock_supported(e, first, False)):
+                # ... and the stage itself belongs to the first block's node: its backward (de * keep * sqrt(D)) rides in
+                # the store of the block's last backward pass instead of a pass of its own over [B L, D]
+                input_stage = (self.position_emb.weight[:ids.shape[1]], scale)
+            else:
+                e = ops.sasrec_input(e, self.position_emb.weight[:ids.shape[1]], keep, alpha=scale)
         else:      # (e * sqrt(D) + position) * ~mask in one pass (rbx_rowscale) instead of three element-wise kernels
             e = ops.row_scale(e, keep, add=ops_position(self.position_emb, positions), alpha=scale)
         for i in range(len(self.attention_layers)):
             mha, ffn = self.attention_layers[i], self.forward_layers[i]
+            stage, input_stage = input_stage, None
             E, H = mha.embed_dim, mha.num_heads
             ffn_drop = self.training and (ffn.dropout1.p > 0 or ffn.dropout2.p > 0)
             if ops.config.fuse_sublayers and ops.seqblock_supported(e, mha, ffn_drop):
@@ -200,7 +211,7 @@ class SASRec(torch.nn.Module):
                 # LayerNorm + FFN + residual + mask -- three launches forward (csrc/rbx_seqblock.hip)
                 e = ops.sasrec_block(e, self.attention_layernorms[i], mha, self.forward_layernorms[i],
                                      ffn.conv1.weight.squeeze(-1), ffn.conv1.bias, ffn.conv2.weight.squeeze(-1), ffn.conv2.bias,
-                                     keep, dropout_p=mha.dropout if self.training else 0.0)
+                                     keep, dropout_p=mha.dropout if self.training else 0.0, input_stage=stage)
                 continue
             if (ops.config.fuse_sublayers and e.dim() == 3 and mha.in_proj_weight is not None
                     and ops.attention_packed_supported(e.shape[1], E // H)):

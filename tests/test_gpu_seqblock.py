@@ -164,7 +164,7 @@ def test_attention_input_backward_chain_vs_float64(M):
     outs = []
     for rep in range(2):
         rc = lib.rbx_seqblock_attn_in_bwd(_p(qc), _p(kvc), _p(gc), _p(xc), _p(mean), _p(rstd), M, _p(d["ln1_w"]), _p(d["in_w"]),
-                                          _p(de), _p(dg), _p(db), _p(ws), nbytes, None)
+                                          None, 1.0, _p(de), _p(dg), _p(db), _p(ws), nbytes, None)
         assert rc == 0
         torch.cuda.synchronize()
         outs.append([t.clone() for t in (de, dg, db)])
@@ -172,6 +172,14 @@ def test_attention_input_backward_chain_vs_float64(M):
         assert torch.equal(a, b)
     for name, a, b in zip(("de", "dgamma", "dbeta"), outs[1], (x64.grad, lw.grad, lb.grad)):
         assert_close(a, b, TOL * max(1.0, float(b.abs().max())), name)
+    # the input stage's backward folded into the store: de * keep[row] * alpha
+    keep = (torch.rand(M, generator=gen) > 0.3).float()
+    kc = keep.cuda()
+    rc = lib.rbx_seqblock_attn_in_bwd(_p(qc), _p(kvc), _p(gc), _p(xc), _p(mean), _p(rstd), M, _p(d["ln1_w"]), _p(d["in_w"]),
+                                      _p(kc), 8.0, _p(de), _p(dg), _p(db), _p(ws), nbytes, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(de, outs[1][0] * kc.unsqueeze(1) * 8.0) and torch.equal(dg, outs[1][1])
 
 
 @pytest.mark.parametrize("M", [19, 64, 9000, 40960])
@@ -269,3 +277,44 @@ def test_block_as_one_node_vs_float64_and_vs_the_sublayer_nodes(B, L, heads, one
     assert_close(de, de_s, 1e-5 * max(1.0, float(de_s.abs().max())), "de vs sub-layer nodes")
     for k in names:
         assert_close(grads[k], grads_s[k], 1e-5 * max(1.0, float(grads_s[k].abs().max())), "d%s vs sub-layer nodes" % k)
+
+
+@pytest.mark.parametrize("B,L", [(64, 200), (45, 200)])
+def test_input_stage_inside_the_first_block_equals_the_two_nodes(B, L):
+    """ops.sasrec_block(input_stage=(pos_rows, alpha)) -- SASRec's ``(sqrt(D) e + position) * ~timeline_mask`` (sasrec.py:68-77)
+    formed by the first block's node, its backward folded into the store of the block's last backward pass -- against
+    ops.sasrec_input followed by ops.sasrec_block: output, the gradient of the raw item block, of the position rows and of
+    every parameter."""
+    from recbox_amd import ops
+    P, g = _params(7)
+    e = torch.randn(B, L, E, generator=g) * 0.1
+    pos = torch.randn(L + 3, E, generator=g) * 0.1
+    keep = (torch.rand(B, L, generator=g) > 0.3).float()
+    R = torch.randn(B, L, E, generator=g)
+
+    def run(inside):
+        mha = torch.nn.MultiheadAttention(E, 1, 0.0)
+        n1, n2 = torch.nn.LayerNorm(E, eps=1e-8), torch.nn.LayerNorm(E, eps=1e-8)
+        with torch.no_grad():
+            mha.in_proj_weight.copy_(P["in_w"]); mha.in_proj_bias.copy_(P["in_b"])
+            mha.out_proj.weight.copy_(P["out_w"]); mha.out_proj.bias.copy_(P["out_b"])
+            n1.weight.copy_(P["ln1_w"]); n1.bias.copy_(P["ln1_b"]); n2.weight.copy_(P["ln2_w"]); n2.bias.copy_(P["ln2_b"])
+        mha, n1, n2 = mha.cuda(), n1.cuda(), n2.cuda()
+        ffn = [P[k].clone().cuda().requires_grad_(True) for k in ("w1", "b1", "w2", "b2")]
+        ec = e.clone().cuda().requires_grad_(True)
+        pc = pos.clone().cuda().requires_grad_(True)
+        kc = keep.cuda()
+        if inside:
+            out = ops.sasrec_block(ec, n1, mha, n2, ffn[0], ffn[1], ffn[2], ffn[3], kc, input_stage=(pc[:L], 8.0))
+        else:
+            x = ops.sasrec_input(ec, pc[:L], kc, alpha=8.0)
+            out = ops.sasrec_block(x, n1, mha, n2, ffn[0], ffn[1], ffn[2], ffn[3], kc)
+        (out * R.cuda()).sum().backward()
+        return [out.detach(), ec.grad, pc.grad, n1.weight.grad, n1.bias.grad, mha.in_proj_weight.grad, mha.in_proj_bias.grad,
+                mha.out_proj.weight.grad, n2.weight.grad] + [t.grad for t in ffn]
+
+    a, b = run(True), run(False)
+    names = ("out", "de_raw", "dpos", "dln1_w", "dln1_b", "din_w", "din_b", "dout_w", "dln2_w", "dw1", "db1", "dw2", "db2")
+    for n, x, y in zip(names, a, b):
+        assert_close(x, y, 1e-5 * max(1.0, float(y.abs().max())), n)
+    assert float(a[2][L:].abs().max()) == 0.0                   # rows of the position table beyond L receive nothing
