@@ -647,6 +647,10 @@ int rbx_linear_dwdb_scaled(const float* d_x, int64_t x_stride, const float* d_dy
  * instead of three kernels writing three [m, fm_cols] gradients and a fourth adding them (d_lr_g / d_lr_w may be NULL). */
 int rbx_fm_sum_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch, int32_t n_fields, int32_t dim, float* d_out,
                    float* d_sum, void* stream);
+/* ... with the first-order Linear over the same n_fields * dim columns in the same pass (third_party/rechub/models/ranking/
+ * deepfm.py:37: LR reads the block FM reads): d_lr_out[b] = <x[b, :n_fields * dim], d_lr_w> + d_lr_b[0] (d_lr_b may be NULL). */
+int rbx_fm_sum_lr_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch, int32_t n_fields, int32_t dim, float* d_out,
+                      float* d_sum, const float* d_lr_w, const float* d_lr_b, float* d_lr_out, void* stream);
 int rbx_linear_dx_deepfm(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
                          const float* d_x, int64_t x_stride, const float* d_fm_sum, int32_t fm_dim, int32_t fm_cols,
                          const float* d_fm_g, const float* d_lr_g, const float* d_lr_w, float* d_dx, int64_t dx_stride,

@@ -313,34 +313,62 @@ namespace rbx {
 template <int G>
 __global__ __launch_bounds__(256) void fm_sum_fwd_kernel(const float* __restrict__ emb, const long long sb, const long long B,
                                                          const int F, const int D, float* __restrict__ out,
-                                                         float* __restrict__ sum) {
+                                                         float* __restrict__ sum, const float* __restrict__ lr_w,
+                                                         const float* __restrict__ lr_b, float* __restrict__ lr_out) {
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
   const int e = lane_g * 4;
+  // lr_w != NULL: the first-order Linear over the same F D columns (deepfm.py:37: LR reads the block FM reads) rides in this
+  // pass -- y_lr[b] = <x[b, :F D], lr_w> + lr_b -- instead of a logit-head kernel that reads the 436 MB block once more
+  const float bias = (lr_w != nullptr && lr_b != nullptr) ? lr_b[0] : 0.f;
   for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / G) + threadIdx.x / G; b < B; b += ngroups) {
     const float* base = emb + b * sb;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lr = 0.f;
     if (e < D) {
+      if (lr_w != nullptr) {
 #pragma unroll 8
-      for (int f = 0; f < F; ++f) {
-        const float4 t = *reinterpret_cast<const float4*>(base + f * D + e);
-        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        q.x += t.x * t.x; q.y += t.y * t.y; q.z += t.z * t.z; q.w += t.w * t.w;
+        for (int f = 0; f < F; ++f) {
+          const float4 t = *reinterpret_cast<const float4*>(base + f * D + e);
+          const float4 w = *reinterpret_cast<const float4*>(lr_w + f * D + e);
+          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+          q.x += t.x * t.x; q.y += t.y * t.y; q.z += t.z * t.z; q.w += t.w * t.w;
+          lr += (t.x * w.x + t.y * w.y) + (t.z * w.z + t.w * w.w);
+        }
+      } else {
+#pragma unroll 8
+        for (int f = 0; f < F; ++f) {
+          const float4 t = *reinterpret_cast<const float4*>(base + f * D + e);
+          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+          q.x += t.x * t.x; q.y += t.y * t.y; q.z += t.z * t.z; q.w += t.w * t.w;
+        }
       }
       *reinterpret_cast<float4*>(sum + b * D + e) = s;
     }
     float t = 0.5f * ((s.x * s.x - q.x) + (s.y * s.y - q.y) + (s.z * s.z - q.z) + (s.w * s.w - q.w));
     t = group_sum<G>(t);
-    if (lane_g == 0) out[b] = t;
+    if (lr_w != nullptr) lr = group_sum<G>(lr);
+    if (lane_g == 0) {
+      out[b] = t;
+      if (lr_w != nullptr) lr_out[b] = lr + bias;
+    }
   }
 }
 }  // namespace rbx
 
 extern "C" int rbx_fm_sum_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch, int32_t n_fields, int32_t dim,
                               float* d_out, float* d_sum, void* stream) {
+  return rbx_fm_sum_lr_fwd(d_emb, emb_stride_b, batch, n_fields, dim, d_out, d_sum, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int rbx_fm_sum_lr_fwd(const float* d_emb, int64_t emb_stride_b, int64_t batch, int32_t n_fields, int32_t dim,
+                                 float* d_out, float* d_sum, const float* d_lr_w, const float* d_lr_b, float* d_lr_out,
+                                 void* stream) {
   using namespace rbx;
   if (batch == 0) return RBX_OK;
   if (!d_emb || !d_out || !d_sum) return fail(RBX_ERR_INVALID, "fm_sum: NULL tensor");
+  if (d_lr_w != nullptr && (d_lr_out == nullptr || (reinterpret_cast<uintptr_t>(d_lr_w) & 15) != 0))
+    return fail(RBX_ERR_INVALID, "fm_sum: the first-order weights need an output and a 16-byte aligned base");
   if (batch < 0 || n_fields <= 0 || dim <= 0 || emb_stride_b < static_cast<int64_t>(n_fields) * dim)
     return fail(RBX_ERR_INVALID, "fm_sum: bad shape");
   if (dim % 4 != 0 || dim > 256 || emb_stride_b % 4 != 0 ||
@@ -352,7 +380,8 @@ extern "C" int rbx_fm_sum_fwd(const float* d_emb, int64_t emb_stride_b, int64_t 
   if (blocks > kCUs * 8) blocks = kCUs * 8;
   hipStream_t s = as_stream(stream);
 #define CALL(GG) hipLaunchKernelGGL((fm_sum_fwd_kernel<GG>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, d_emb, \
-                                    static_cast<long long>(emb_stride_b), static_cast<long long>(batch), n_fields, dim, d_out, d_sum)
+                                    static_cast<long long>(emb_stride_b), static_cast<long long>(batch), n_fields, dim, d_out, d_sum, \
+                                    d_lr_w, d_lr_b, d_lr_out)
   switch (g) {
     case 1: CALL(1); break;
     case 2: CALL(2); break;

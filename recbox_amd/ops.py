@@ -74,6 +74,8 @@ class config(object):
     # DeepFM: the tower's first Linear, the FM term and the first-order Linear over one gathered block as one autograd node
     # (ops.deepfm_input_stage): the block's gradient comes out of the tower's dx GEMM instead of four kernels
     fuse_deepfm_input = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_INPUT", "1") != "0"
+    # ... and inside it the first-order Linear in the FM term's pass over the block (rbx_fm_sum_lr_fwd)
+    fuse_deepfm_lr = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_LR", "1") != "0"
     reuse_grad_buffers = {"0": False, "": False, "all": "all"}.get(os.environ.get("RECBOX_AMD_REUSE_GRADS", "0"), True)
     # fused FM backward in two tiers (round 3; include/recbox_hip.h, rbx_fm_bwd): the small tables' block partials + row
     # combine (tier A) on the current stream, the large tables' segmented reduce (tier B) on the side stream its sort ran on
@@ -3231,9 +3233,14 @@ class _DeepFmInput(torch.autograd.Function):
                 lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, 0, _ptr(h), _stream()))))
         y_fm = torch.empty((M, 1), dtype=torch.float32, device=x.device)
         ssum = torch.empty((M, dim), dtype=torch.float32, device=x.device)
-        check(lib.rbx_fm_sum_fwd(_ptr(x2), x2.stride(0), M, F_, dim, _ptr(y_fm), _ptr(ssum), _stream()))
         y_lr = torch.empty((M, 1), dtype=torch.float32, device=x.device)
-        check(lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(lr_w), _ptr(lr_b), M, 1, fm_cols, 0, _ptr(y_lr), _stream()))
+        if config.fuse_deepfm_lr and lr_w.data_ptr() % 16 == 0 and fm_cols == F_ * dim:
+            # FM term and first-order Linear in ONE pass over the block's F D columns (the logit-head kernel read it again)
+            check(lib.rbx_fm_sum_lr_fwd(_ptr(x2), x2.stride(0), M, F_, dim, _ptr(y_fm), _ptr(ssum), _ptr(lr_w), _ptr(lr_b),
+                                        _ptr(y_lr), _stream()))
+        else:
+            check(lib.rbx_fm_sum_fwd(_ptr(x2), x2.stride(0), M, F_, dim, _ptr(y_fm), _ptr(ssum), _stream()))
+            check(lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(lr_w), _ptr(lr_b), M, 1, fm_cols, 0, _ptr(y_lr), _stream()))
         ctx.save_for_backward(x2, w1, lr_w, ssum)
         ctx.meta = (fm_cols, dim, b1 is not None, lr_b is not None, tuple(x.shape))
         ctx.grad_keys = (w1.data_ptr() if w1.is_contiguous() else 0, b1.data_ptr() if b1 is not None else 0,
