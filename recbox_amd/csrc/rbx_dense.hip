@@ -1135,6 +1135,241 @@ __global__ __launch_bounds__(PTHREADS, 1) void gemm_bxp_kernel(const float* __re
   gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi, PBM);
 }
 
+// ---- the same 256 x 128 tile with k tiles of 32: half the barriers ----------------------------------------------------------------
+// gemm_bxp_kernel meets one barrier per 24 MFMAs of a wavefront and its wavefronts spend ~30 % of their cycles there
+// (profiles/r03).  Two MFMA k steps per tile halve the barriers per product; the tile then needs 2 x (48 + 24) KB only if the
+// LDS rows lose their padding (the 80-byte pitch of the 16-k form would be 184 KB at 32 k): rows of 64 bytes, the 16-byte chunk
+// index XORed with (row >> 2) & 3 on both sides -- sixteen consecutive rows of one chunk column then spread over the four
+// chunk positions of four row groups, conflict-free for the b128 fragment reads as the padded form was.
+// RBX_GEMM_BXQ=1 selects it (read once); the default is decided by measurement (profiles/r04/INDEX.md).
+constexpr int QBK = 32;
+constexpr int QLD = 32;                 // bf16 per LDS row
+constexpr int QPLANE_A = PBM * QLD, QPLANE_B = BN * QLD;
+constexpr int QBUF_A = 3 * QPLANE_A, QBUF_B = 3 * QPLANE_B;
+
+// A tile [256, 32]: thread t takes k = 4 (t % 8) .. + 3 of rows t / 8 + 64 p
+template <bool GUARD>
+__device__ __forceinline__ void bxq_load_a(const float* __restrict__ A, long long lda, int m0, int k0, int M, int K,
+                                           f32x4u_t (&v)[4]) {
+  const int t = threadIdx.x;
+  const int k = k0 + (t & 7) * 4;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    int r = m0 + (t >> 3) + 64 * p;
+    r = r < M ? r : M - 1;
+    const float* src = A + static_cast<long long>(r) * lda + k;
+    if (!GUARD || k + 3 < K) {
+      v[p] = *reinterpret_cast<const f32x4u_t*>(src);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[p][j] = (k + j < K) ? src[j] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void bxq_store_a(unsigned short* __restrict__ buf, const f32x4u_t (&v)[4]) {
+  const int t = threadIdx.x;
+  const int col = ((((t & 7) >> 1) ^ ((t >> 5) & 3)) << 3) + ((t & 1) << 2);      // (row >> 2) & 3 == (t >> 5) & 3 for every p
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split2(f32x2_t{v[p][0], v[p][1]}, h0, m0, l0);
+    split2(f32x2_t{v[p][2], v[p][3]}, h1, m1, l1);
+    unsigned short* dst = buf + ((t >> 3) + 64 * p) * QLD + col;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + QPLANE_A) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(dst + 2 * QPLANE_A) = make_uint2(l0, l1);
+  }
+}
+// B tile [128 rows, 32 k] of the interleaved planes: 192 contiguous bytes per row = 12 chunks of 16 bytes (group of 8 k x plane);
+// 1536 chunks, three per thread
+__device__ __forceinline__ void bxq_load_b(const unsigned short* __restrict__ Bp, int kp, int n0, int k0, int N, u32x4_t (&v)[3]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = t + PTHREADS * i;
+    int r = n0 + j / 12;
+    r = r < N ? r : N - 1;
+    v[i] = *reinterpret_cast<const u32x4_t*>(Bp + static_cast<long long>(r) * 3 * kp + (k0 >> 3) * 24 + (j % 12) * 8);
+  }
+}
+__device__ __forceinline__ void bxq_store_b(unsigned short* __restrict__ buf, const u32x4_t (&v)[3]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = t + PTHREADS * i;
+    const int row = j / 12, c = j % 12;
+    *reinterpret_cast<u32x4_t*>(buf + (c % 3) * QPLANE_B + row * QLD + (((c / 3) ^ ((row >> 2) & 3)) << 3)) = v[i];
+  }
+}
+
+#define RBX_BXQ_TERM(S, QA, QB)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
+    if ((LIVE >> (2 * i + j)) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][i][QA], b[S][j][QB], acc[i][j], 0, 0, 0)
+
+template <int LIVE>
+__device__ __forceinline__ void bxq_loop(const float* __restrict__ A, const long long lda, const unsigned short* __restrict__ Bp,
+                                         const int kp, const int m0, const int n0, const int M, const int N, const int K,
+                                         unsigned short* __restrict__ As, unsigned short* __restrict__ Bs, const int wm,
+                                         const int wn, const int li, const int lk, f32x16 (&acc)[2][2]) {
+  // ONE register set: the loads of tile t + 2 are issued while tile t runs (48 MFMAs ahead of their split -- the lead the
+  // 16-k form gets from two sets; a second set here is 28 registers the two fragment sets need)
+  f32x4u_t ra[4];
+  u32x4_t rb[3];
+  const int kt = (K + QBK - 1) / QBK;
+  auto fetch = [&](int tile) {
+    if ((tile + 1) * QBK <= K) bxq_load_a<false>(A, lda, m0, tile * QBK, M, K, ra);
+    else bxq_load_a<true>(A, lda, m0, tile * QBK, M, K, ra);
+    bxq_load_b(Bp, kp, n0, tile * QBK, N, rb);
+  };
+  fetch(0);
+  bxq_store_a(As, ra);
+  bxq_store_b(Bs, rb);
+  if (kt > 1) fetch(1);
+  __syncthreads();
+  // fragment of k step S: logical chunk 2 S + lk, physical (2 S + lk) ^ ((row >> 2) & 3) with row % 16 == li % 16
+  const int sw = (li >> 2) & 3;
+  const int aoff = (wm + li) * QLD, boff = (wn + li) * QLD;
+  const int c0 = ((lk ^ sw) << 3), c1 = (((2 + lk) ^ sw) << 3);
+  auto frags = [&](int cur, bf16x8_t (&a)[2][2][3], bf16x8_t (&b)[2][2][3], bool all) {
+    const unsigned short* ap = As + cur * QBUF_A + aoff;
+    const unsigned short* bp = Bs + cur * QBUF_B + boff;
+#pragma unroll
+    for (int S = 0; S < 2; ++S)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int co = S ? c1 : c0;
+          if (all || ((LIVE >> (2 * i)) & 3)) a[S][i][q] = *reinterpret_cast<const bf16x8_t*>(ap + q * QPLANE_A + i * 32 * QLD + co);
+          if (all || ((LIVE >> i) & 5)) b[S][i][q] = *reinterpret_cast<const bf16x8_t*>(bp + q * QPLANE_B + i * 32 * QLD + co);
+        }
+  };
+  auto step = [&](int t, int cur) {
+    bf16x8_t a[2][2][3], b[2][2][3];
+    frags(cur, a, b, false);
+    RBX_BXQ_TERM(0, 2, 0);
+    RBX_BXQ_TERM(0, 0, 2);
+    RBX_BXQ_TERM(0, 1, 1);
+    if (t + 1 < kt) {
+      bxq_store_a(As + (cur ^ 1) * QBUF_A, ra);
+      bxq_store_b(Bs + (cur ^ 1) * QBUF_B, rb);
+    }
+    if (t + 2 < kt) fetch(t + 2);
+    RBX_BXQ_TERM(0, 1, 0);
+    RBX_BXQ_TERM(0, 0, 1);
+    RBX_BXQ_TERM(0, 0, 0);
+    RBX_BXQ_TERM(1, 2, 0);
+    RBX_BXQ_TERM(1, 0, 2);
+    RBX_BXQ_TERM(1, 1, 1);
+    RBX_BXQ_TERM(1, 1, 0);
+    RBX_BXQ_TERM(1, 0, 1);
+    RBX_BXQ_TERM(1, 0, 0);
+    __syncthreads();
+  };
+  auto steady = [&](int t, int cur) {
+    bf16x8_t a[2][2][3], b[2][2][3];
+    frags(cur, a, b, true);
+    RBX_BXQ_TERM(0, 2, 0);
+    RBX_BXQ_TERM(0, 0, 2);
+    RBX_BXQ_TERM(0, 1, 1);
+    bxq_store_a(As + (cur ^ 1) * QBUF_A, ra);
+    bxq_store_b(Bs + (cur ^ 1) * QBUF_B, rb);
+    bxq_load_a<false>(A, lda, m0, (t + 2) * QBK, M, K, ra);
+    bxq_load_b(Bp, kp, n0, (t + 2) * QBK, N, rb);
+    RBX_BXQ_TERM(0, 1, 0);
+    RBX_BXQ_TERM(0, 0, 1);
+    RBX_BXQ_TERM(0, 0, 0);
+    RBX_BXQ_TERM(1, 2, 0);
+    RBX_BXQ_TERM(1, 0, 2);
+    RBX_BXQ_TERM(1, 1, 1);
+    RBX_BXQ_TERM(1, 1, 0);
+    RBX_BXQ_TERM(1, 0, 1);
+    RBX_BXQ_TERM(1, 0, 0);
+#if RBX_BXP_SCHED
+    __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);                    // DS reads
+#pragma unroll
+    for (int g = 0; g < 24; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   // VALU
+    }
+#pragma unroll
+    for (int g = 0; g < 15; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                   // DS write
+    }
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // VMEM read
+    }
+#endif
+    __syncthreads();
+  };
+  int t = 0;
+  if constexpr (LIVE == 15) {
+    while ((t + 4) * QBK <= K) {                   // two steps per round: tiles t + 2 and t + 3 are read without tests
+      steady(t, 0);
+      steady(t + 1, 1);
+      t += 2;
+    }
+  }
+  while (t < kt) {                                 // the rest (and edge tiles): the tested step; t is even here
+    step(t, 0);
+    ++t;
+    if (t < kt) { step(t, 1); ++t; }
+  }
+}
+#undef RBX_BXQ_TERM
+
+__global__ __launch_bounds__(PTHREADS, 1) void gemm_bxq_kernel(const float* __restrict__ A, const long long lda,
+                                                               const unsigned short* __restrict__ Bp, const int kp,
+                                                               float* __restrict__ C, const long long ldc, const int M,
+                                                               const int N, const int K, const float* __restrict__ bias,
+                                                               const int act, const int tiles_m, const int tiles_n,
+                                                               const Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short bxp_lds[];          // 2 x (A 48 KB + B 24 KB) = 144 KB
+  unsigned short* As = bxp_lds;
+  unsigned short* Bs = bxp_lds + 2 * QBUF_A;
+  int tm_i, tn_j;
+  {
+    const int total = tiles_m * tiles_n, L = static_cast<int>(blockIdx.x);
+    const int xcd = L % kXcds, slot = L / kXcds;
+    const int q = total / kXcds, rem = total % kXcds;
+    const int tile = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    tm_i = tile / tiles_n;
+    tn_j = tile % tiles_n;
+  }
+  const int m0 = tm_i * PBM, n0 = tn_j * BN;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int li = lane & 31, lk = lane >> 5;
+  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
+  int live;
+  {
+    int rows = (M - m0 - wm + 31) / 32, cols = (N - n0 - wn + 31) / 32;
+    rows = rows > 2 ? 2 : rows;
+    cols = cols > 2 ? 2 : cols;
+    live = (rows <= 0 || cols <= 0) ? 0 : (rows == 2 && cols == 2) ? 15 : (rows == 2) ? 5 : (cols == 2) ? 3 : 1;
+    live = __builtin_amdgcn_readfirstlane(live);
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (live == 15) bxq_loop<15>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 5) bxq_loop<5>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 3) bxq_loop<3>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else if (live == 1) bxq_loop<1>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  else bxq_loop<0>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
+  const bool interior = m0 + PBM <= M && n0 + BN <= N;
+  if (epi.bn_mode != 0 && m0 + wm < M && (epi.bn_mode == 1 || !interior))
+    bxp_bn_stats(acc, m0, n0, wm, wn, li, lk, live, M, N, bias, epi);
+  gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi, PBM);
+}
+
 // ---- the weight-gradient GEMM dW = dy^T x on the same pipes --------------------------------------------------------------------
 // Both operands are batch-major activations: A(i, kk) = dy[kk, i], B(kk, col) = x[kk, col] with the reduction index kk = the
 // sample.  Same 256 x 128 x 16 tiles, LDS layout, MFMA phase and prefetch depth as gemm_bxp_kernel; what differs is the
@@ -2432,8 +2667,18 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
         }();
         (void)attr_set;
         const int tm2 = (M + PBM - 1) / PBM;
-        hipLaunchKernelGGL(gemm_bxp_kernel, dim3(tn * tm2), dim3(PTHREADS), 2 * (PBUF_A + PBUF_B) * 2, s, A, lda, e.planes, kp, C,
-                           ldc, M, N, K, bias, act, tm2, tn, epi);
+        static const bool bxq = [] {
+          const char* en = getenv("RBX_GEMM_BXQ");
+          return en != nullptr && atoi(en) == 1 &&
+                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bxq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     2 * (QBUF_A + QBUF_B) * 2) == hipSuccess;
+        }();
+        if (bxq)
+          hipLaunchKernelGGL(gemm_bxq_kernel, dim3(tn * tm2), dim3(PTHREADS), 2 * (QBUF_A + QBUF_B) * 2, s, A, lda, e.planes, kp,
+                             C, ldc, M, N, K, bias, act, tm2, tn, epi);
+        else
+          hipLaunchKernelGGL(gemm_bxp_kernel, dim3(tn * tm2), dim3(PTHREADS), 2 * (PBUF_A + PBUF_B) * 2, s, A, lda, e.planes, kp,
+                             C, ldc, M, N, K, bias, act, tm2, tn, epi);
       }
       g_bx6_launches.fetch_add(1, std::memory_order_relaxed);
       return check_launch("gemm_bx6_kernel");
