@@ -3180,6 +3180,8 @@ def seqblock_supported(e, mha, ffn_has_dropout, keep_is_mask=True):
         return False
     if mha.in_proj_weight is None or mha.embed_dim != 64 or ffn_has_dropout or not keep_is_mask:
         return False
+    if getattr(mha, "bias_k", None) is not None or getattr(mha, "bias_v", None) is not None or getattr(mha, "add_zero_attn", False):
+        return False                                   # (extra key / value rows: not what the packed attention computes)
     return attention_packed_supported(e.shape[1], 64 // mha.num_heads) and e.shape[0] * e.shape[1] >= 8192
 
 
