@@ -803,7 +803,10 @@ int rbx_pool_bwd(const float* d_dout, const float* d_mask, const float* d_inv, i
  *                          (d_dKV [m, 128] = dK | dV), stored as de * row_scale[row] * alpha when d_row_scale != NULL (the backward of SASRec's
  *                          input stage `(alpha e + position) * keep`, sasrec.py:68-77, folded into the first block).  The
  *                          three in-projection weight gradients are not part of it. */
-/*   rbx_seqblock_attn_out_bwd: the out-projection's backward, one pass: dO = g Wo, dWo = g^T O, dbo = colsum g. */
+/*   rbx_seqblock_inproj_dw: the three in-projection weight gradients in one pass: d_dw [192, 64] = dQ^T q | dK^T x | dV^T x
+ *                          (nn.MultiheadAttention.in_proj_weight's layout), d_db [192] = their column sums; q = LayerNorm(x)
+ *                          is rebuilt from x, mean, rstd, gamma, beta.  Either output may be NULL.
+ *   rbx_seqblock_attn_out_bwd: the out-projection's backward, one pass: dO = g Wo, dWo = g^T O, dbo = colsum g. */
 int rbx_seqblock_qkv_fwd(const float* d_x, int64_t m, const float* d_ln_w, const float* d_ln_b, float eps,
                          const float* d_in_w, const float* d_in_b, float* d_mean, float* d_rstd, float* d_q, float* d_Q,
                          float* d_KV, void* stream);
@@ -824,6 +827,10 @@ int rbx_seqblock_attn_in_bwd(const float* d_dQ, const float* d_dKV, const float*
 size_t rbx_seqblock_attn_out_bwd_workspace_size(int64_t m);
 int rbx_seqblock_attn_out_bwd(const float* d_g, const float* d_O, int64_t m, const float* d_wo, float* d_dO, float* d_dwo,
                               float* d_dbo, void* d_workspace, size_t workspace_bytes, void* stream);
+size_t rbx_seqblock_inproj_dw_workspace_size(int64_t m);
+int rbx_seqblock_inproj_dw(const float* d_dQ, const float* d_dKV, const float* d_x, const float* d_mean, const float* d_rstd,
+                           int64_t m, const float* d_ln_w, const float* d_ln_b, float* d_dw, float* d_db, void* d_workspace,
+                           size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -956,6 +956,189 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_attn_out_bwd_kernel(const
   for (int i = threadIdx.x; i < kSbOutPart; i += 64 * kSbWaves) dstp[i] = red[i];
 }
 
+// ---- the three in-projection weight gradients as ONE pass: dWq = dQ^T q, dWk = dK^T e, dWv = dV^T e (+ their column sums) -----
+// Three slab dW launches read e twice and the stored q once; here e is read once and q = LayerNorm(e) is rebuilt in the
+// column layout from the saved statistics (16 rows per lane: their mean / rstd come through a 64-float LDS vector).
+// 192 accumulators: one wavefront per SIMD, dQ and e prefetched into AGPRs, dK and dV into VGPRs.
+constexpr int kSbInPart = 3 * kSbW + 3 * 64;           // dWq | dWk | dWv | dbq | dbk | dbv
+
+struct SbInDwArgs {
+  const float *dQ, *dKV, *x, *mean, *rstd, *ln_w, *ln_b;
+  float* part;
+  int M;
+};
+__device__ __forceinline__ void sb_arrived4(f32x4 (&a)[8], f32x4 (&b)[8], f32x4 (&c)[8], f32x4 (&d)[8], float& u0, float& u1) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(a[4]), "+a"(a[5]), "+a"(a[6]), "+a"(a[7]), "+a"(b[0]),
+                 "+a"(b[1]), "+a"(b[2]), "+a"(b[3]), "+a"(b[4]), "+a"(b[5]), "+a"(b[6]), "+a"(b[7])
+               :
+               : "memory");
+  asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(d[0]),
+                    "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(u0), "+v"(u1)
+               :
+               : "memory");
+}
+// request registers -> the slab -> column layout (the row layout is not wanted here)
+__device__ __forceinline__ void sb_req_to_col(float* __restrict__ lds, const int lane, const f32x4 (&v)[8], float (&c)[32]) {
+  float* dst = lds + (lane >> 4) * kSbLd + 4 * (lane & 15);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4*>(dst + 4 * p * kSbLd) = v[p];
+  sb_wave_sync();
+  sb_lds_to_col(lds, lane, c);
+  sb_wave_sync();
+}
+
+__global__ __launch_bounds__(64 * kSbBwdWaves, 1) void sb_inproj_dw_kernel(const SbInDwArgs A) {
+  extern __shared__ float sb_lds[];
+  float* vec = sb_lds;                         // gamma, beta
+  float* stats = vec + 128;                    // per wavefront: mean[32] | rstd[32] of the slab's rows
+  float* slabs = sb_lds + kSbInPart;           // (the workgroup's sum takes the front of the LDS at the end)
+  sb_stage_vec(vec, A.ln_w, 1.f);
+  sb_stage_vec(vec + 64, A.ln_b, 0.f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int nw = static_cast<int>(gridDim.x) * kSbBwdWaves;
+  const int slabs_n = (A.M + 31) >> 5;
+  int s = static_cast<int>(blockIdx.x) * kSbBwdWaves + wid;
+  float* lds = slabs + wid * kSbSlab;
+  float* st = stats + wid * 64;
+  f32x16 aq[2][2], ak[2][2], av[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { aq[a][b][i] = 0.f; ak[a][b][i] = 0.f; av[a][b][i] = 0.f; }
+  float dbq[2] = {0.f, 0.f}, dbk[2] = {0.f, 0.f}, dbv[2] = {0.f, 0.f};
+  const float gmc[2] = {vec[m], vec[32 + m]}, btc[2] = {vec[64 + m], vec[96 + m]};
+  if (s < slabs_n) {
+    const unsigned lane_part = static_cast<unsigned>(16 * (lane & 15));
+    const unsigned lane_off = static_cast<unsigned>(256 * (lane >> 4)) + lane_part;
+    f32x4 nq[8], nx[8], nk[8], nv[8];
+    float nmu, nrs;
+    // which = 0: e + the rows' statistics, 1: dQ, 2: dK, 3: dV -- each stream is requested again as soon as its registers
+    // are free, so the requests of the next slab run under this slab's three products
+    auto issue = [&](int sl, int which) {
+      unsigned off[8];
+      const int left = A.M - sl * 32;
+      const unsigned lim = static_cast<unsigned>((left < 32 ? left : 32) - 1) * 256u + lane_part;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        off[p] = lane_off + 1024u * p < lim ? lane_off + 1024u * p : lim;
+        if (which >= 2) off[p] = 2u * off[p] - lane_part;  // the same rows at a pitch of 128 floats
+      }
+      const long long o = static_cast<long long>(sl) * 32 * 64;
+      if (which == 0) {
+        const unsigned ro = 4u * static_cast<unsigned>(sl * 32 + m < A.M ? sl * 32 + m : A.M - 1);
+        sb_issue_a(A.x + o, off, nx);
+        sb_issue_word(A.mean, ro, nmu);
+        sb_issue_word(A.rstd, ro, nrs);
+      } else if (which == 1) {
+        sb_issue_a(A.dQ + o, off, nq);
+      } else if (which == 2) {
+        sb_issue(A.dKV + 2 * o, off, nk);
+      } else {
+        sb_issue(A.dKV + 2 * o + 64, off, nv);
+      }
+    };
+    issue(s, 0); issue(s, 1); issue(s, 2); issue(s, 3);
+    sb_arrived4(nq, nx, nk, nv, nmu, nrs);
+    for (;;) {
+      const int left = A.M - s * 32;
+      int sn = s + nw;
+      const bool more = sn < slabs_n;
+      sn = more ? sn : s;
+      float xc[32], mu[16], rs[16];
+      // the rows' statistics in the column layout: register q <-> rows 8 (q >> 2) + 4 h + (q & 3)
+      if (lane < 32) {
+        st[lane] = nmu;
+        st[32 + lane] = lane < left ? nrs : 0.f;          // rows beyond the end: xhat = 0 -- and their dQ / dK / dV are zeroed below
+      }
+      sb_req_to_col(lds, lane, nx, xc);                   // (its wave syncs also publish the statistics)
+      issue(sn, 0);
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(st + 8 * q4 + 4 * h);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(st + 32 + 8 * q4 + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mu[4 * q4 + e] = a[e]; rs[4 * q4 + e] = b[e]; }
+      }
+      // rows beyond the end of a ragged last slab re-read the last row: their gradients must not count
+      float live[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) live[q] = ((q & 3) + 8 * (q >> 2) + 4 * h) < left ? 1.f : 0.f;
+      {
+        float dc[32];
+        sb_req_to_col(lds, lane, nq, dc);
+        issue(sn, 1);
+        if (left < 32) {
+#pragma unroll
+          for (int q = 0; q < 32; ++q) dc[q] *= live[q & 15];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) dbq[t] += dc[16 * t + q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float q0 = (xc[q] - mu[q]) * rs[q] * gmc[0] + btc[0], q1 = (xc[16 + q] - mu[q]) * rs[q] * gmc[1] + btc[1];
+          aq[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[q], q0, aq[0][0], 0, 0, 0);
+          aq[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[q], q1, aq[0][1], 0, 0, 0);
+          aq[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[16 + q], q0, aq[1][0], 0, 0, 0);
+          aq[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[16 + q], q1, aq[1][1], 0, 0, 0);
+        }
+      }
+      {
+        float dc[32];
+        sb_req_to_col(lds, lane, nk, dc);
+        issue(sn, 2);
+        if (left < 32) {
+#pragma unroll
+          for (int q = 0; q < 32; ++q) dc[q] *= live[q & 15];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) dbk[t] += dc[16 * t + q];
+        sb_dw_acc(dc, xc, ak);
+      }
+      {
+        float dc[32];
+        sb_req_to_col(lds, lane, nv, dc);
+        issue(sn, 3);
+        if (left < 32) {
+#pragma unroll
+          for (int q = 0; q < 32; ++q) dc[q] *= live[q & 15];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) dbv[t] += dc[16 * t + q];
+        sb_dw_acc(dc, xc, av);
+      }
+      sb_arrived4(nq, nx, nk, nv, nmu, nrs);
+      if (!more) break;
+      s = sn;
+    }
+  }
+  __syncthreads();
+  float* red = sb_lds;
+  for (int w = 0; w < kSbBwdWaves; ++w) {
+    if (wid == w) {
+      sb_acc_to_lds(red, lane, aq, w == 0);
+      sb_acc_to_lds(red + kSbW, lane, ak, w == 0);
+      sb_acc_to_lds(red + 2 * kSbW, lane, av, w == 0);
+      sb_colsum_to_lds(red + 3 * kSbW, lane, dbq, w == 0);
+      sb_colsum_to_lds(red + 3 * kSbW + 64, lane, dbk, w == 0);
+      sb_colsum_to_lds(red + 3 * kSbW + 128, lane, dbv, w == 0);
+    }
+    __syncthreads();
+  }
+  float* dst = A.part + static_cast<long long>(blockIdx.x) * kSbInPart;
+  for (int i = threadIdx.x; i < kSbInPart; i += 64 * kSbBwdWaves) dst[i] = red[i];
+}
+
 // out segment j (offset seg_off[j], length seg_len[j]) = sum over the workgroups' partials, in order
 struct SbReduceArgs {
   const float* part;
@@ -1185,5 +1368,45 @@ extern "C" int rbx_seqblock_attn_out_bwd(const float* d_g, const float* d_O, int
   r.seg_off[0] = 0; r.seg_len[0] = kSbW; r.dst[0] = d_dwo;
   r.seg_off[1] = kSbW; r.seg_len[1] = 64; r.dst[1] = d_dbo;
   hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbOutPart + 31) / 32), dim3(256), 0, as_stream(stream), r);
+  return check_launch("sb_reduce_kernel");
+}
+
+extern "C" size_t rbx_seqblock_inproj_dw_workspace_size(int64_t m) {
+  return m <= 0 ? 0 : sizeof(float) * static_cast<size_t>(sb_bwd_grid(m)) * kSbInPart;
+}
+
+extern "C" int rbx_seqblock_inproj_dw(const float* d_dQ, const float* d_dKV, const float* d_x, const float* d_mean,
+                                      const float* d_rstd, int64_t m, const float* d_ln_w, const float* d_ln_b, float* d_dw,
+                                      float* d_db, void* d_workspace, size_t workspace_bytes, void* stream) {
+  if (m < 0 || m > (1LL << 30)) return fail(RBX_ERR_INVALID, "rbx_seqblock_inproj_dw: m = %lld", static_cast<long long>(m));
+  if (m == 0) return RBX_OK;
+  if (!d_dQ || !d_dKV || !d_x || !d_mean || !d_rstd) return fail(RBX_ERR_INVALID, "rbx_seqblock_inproj_dw: NULL operand");
+  if (!sb_aligned(d_dQ) || !sb_aligned(d_dKV) || !sb_aligned(d_x))
+    return fail(RBX_ERR_UNSUPPORTED, "rbx_seqblock_inproj_dw: activations must be 16-byte aligned");
+  const size_t need = rbx_seqblock_inproj_dw_workspace_size(m);
+  if (d_workspace == nullptr || workspace_bytes < need)
+    return fail(RBX_ERR_WORKSPACE, "rbx_seqblock_inproj_dw: workspace %zu < %zu bytes", workspace_bytes, need);
+  const int grid = sb_bwd_grid(m);
+  SbInDwArgs a{d_dQ, d_dKV, d_x, d_mean, d_rstd, d_ln_w, d_ln_b, static_cast<float*>(d_workspace), static_cast<int>(m)};
+  const size_t lds = sizeof(float) * (kSbInPart + kSbBwdWaves * kSbSlab);
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_inproj_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds)) != hipSuccess)
+      return fail(RBX_ERR_LAUNCH, "rbx_seqblock_inproj_dw: %zu bytes of LDS refused", lds);
+    once = true;
+  }
+  hipLaunchKernelGGL(sb_inproj_dw_kernel, dim3(grid), dim3(64 * kSbBwdWaves), lds, as_stream(stream), a);
+  int rc = check_launch("sb_inproj_dw_kernel");
+  if (rc != RBX_OK) return rc;
+  if (d_dw == nullptr && d_db == nullptr) return RBX_OK;
+  SbReduceArgs r{};
+  r.part = static_cast<const float*>(d_workspace);
+  r.nparts = grid;
+  r.stride = kSbInPart;
+  r.nseg = 2;
+  r.seg_off[0] = 0; r.seg_len[0] = 3 * kSbW; r.dst[0] = d_dw;            // [192, 64] = dWq | dWk | dWv, in_proj_weight's layout
+  r.seg_off[1] = 3 * kSbW; r.seg_len[1] = 192; r.dst[1] = d_db;
+  hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbInPart + 31) / 32), dim3(256), 0, as_stream(stream), r);
   return check_launch("sb_reduce_kernel");
 }

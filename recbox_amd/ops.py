@@ -71,6 +71,8 @@ class config(object):
     # ... and the backward of its feed-forward half as one pass (rbx_seqblock_ffn_bwd) instead of two dW passes, two dx GEMMs
     # and the LayerNorm backward; the forward then does not store the LayerNorm output
     seqblock_bwd = os.environ.get("RECBOX_AMD_SEQBLOCK_BWD", "1") != "0"
+    # ... and the three in-projection weight gradients as one pass (rbx_seqblock_inproj_dw) instead of three slab dW launches
+    seqblock_dw3 = os.environ.get("RECBOX_AMD_SEQBLOCK_DW3", "1") != "0"
     # DeepFM: the tower's first Linear, the FM term and the first-order Linear over one gathered block as one autograd node
     # (ops.deepfm_input_stage): the block's gradient comes out of the tower's dx GEMM instead of four kernels
     fuse_deepfm_input = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_INPUT", "1") != "0"
@@ -3081,7 +3083,7 @@ class _SeqBlock(torch.autograd.Function):
                                        _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(k1), _ptr(mean2), _ptr(rstd2), _ptr(n),
                                        _ptr(h), _ptr(out), _stream()))
         ctx.save_for_backward(x2, ln1_w, mean1, rstd1, q, in_w, Q, KV, O, lse, out_w, y, ln2_w, mean2, rstd2, n, w1, h, w2, k1,
-                              ln2_b)
+                              ln2_b, ln1_b)
         ctx.meta = (B, L, E, heads, hd, float(scale), float(p_drop), int(seed), tick, in_b is not None, out_b is not None,
                     ln1_b is not None, ln2_b is not None, b1 is not None, b2 is not None)
         return out.view(B, L, E)
@@ -3089,7 +3091,7 @@ class _SeqBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (x2, ln1_w, mean1, rstd1, q, in_w, Q, KV, O, lse, out_w, y, ln2_w, mean2, rstd2, n, w1, h, w2, k1,
-         ln2_b) = ctx.saved_tensors
+         ln2_b, ln1_b) = ctx.saved_tensors
         (B, L, E, heads, hd, scale, p_drop, seed, tick, has_in_b, has_out_b, has_ln1_b, has_ln2_b, has_b1, has_b2) = ctx.meta
         dev = dout.device
         need = ctx.needs_input_grad
@@ -3142,8 +3144,15 @@ class _SeqBlock(torch.autograd.Function):
                                                      2 * E, dvptr, 2 * E, _ptr(scratch), _stream())))
         d_in_w = torch.empty_like(in_w) if need[4] else None
         d_in_b = torch.empty(3 * E, **f32) if (has_in_b and need[5]) else None
-        _lin_dwdb(q, in_w[:E], dQ, d_in_w[:E] if d_in_w is not None else None, d_in_b[:E] if d_in_b is not None else None)
-        _lin_dwdb(x2, in_w[E:], dKV, d_in_w[E:] if d_in_w is not None else None, d_in_b[E:] if d_in_b is not None else None)
+        if config.seqblock_bwd and config.seqblock_dw3 and (d_in_w is not None or d_in_b is not None):
+            # dWq | dWk | dWv (+ biases) in ONE pass: e read once, q rebuilt from the saved statistics
+            ws_bytes = lib.rbx_seqblock_inproj_dw_workspace_size(B * L)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            check(lib.rbx_seqblock_inproj_dw(_ptr(dQ), _ptr(dKV), _ptr(x2), _ptr(mean1), _ptr(rstd1), B * L, _ptr(ln1_w),
+                                             _ptr(ln1_b), _ptr(d_in_w), _ptr(d_in_b), _ptr(ws), ws_bytes, _stream()))
+        else:
+            _lin_dwdb(q, in_w[:E], dQ, d_in_w[:E] if d_in_w is not None else None, d_in_b[:E] if d_in_b is not None else None)
+            _lin_dwdb(x2, in_w[E:], dKV, d_in_w[E:] if d_in_w is not None else None, d_in_b[E:] if d_in_b is not None else None)
         want1 = need[1] or (has_ln1_b and need[2])
         staged, alpha = ctx.input_stage
         dpos = None

@@ -205,6 +205,35 @@ def test_out_projection_backward_vs_float64(M):
         assert_close(a, b, TOL * max(1.0, float(b.abs().max())), name)
 
 
+@pytest.mark.parametrize("M", [19, 64, 9000, 40960])
+def test_in_projection_weight_gradients_in_one_pass_vs_float64(M):
+    """rbx_seqblock_inproj_dw: dWq = dQ^T LayerNorm(x), dWk | dWv = (dK | dV)^T x, and the three bias gradients."""
+    from recbox_amd._lib import lib
+    P, gen = _params(8)
+    r = lambda *s: torch.randn(*s, generator=gen)
+    x, dQ, dKV = r(M, E), r(M, E), r(M, 2 * E)
+    x64 = x.double()
+    q64 = _ln(x64, P["ln1_w"].double(), P["ln1_b"].double())
+    want_w = torch.cat([dQ.double().t() @ q64, dKV.double().t() @ x64], 0)
+    want_b = torch.cat([dQ.double().sum(0), dKV.double().sum(0)], 0)
+    d = {k: v.cuda() for k, v in P.items()}
+    xc, qc, kvc = x.cuda(), dQ.cuda(), dKV.cuda()
+    mean, rstd = x64.mean(1).float().cuda(), (x64.var(1, unbiased=False) + 1e-8).rsqrt().float().cuda()
+    f = lambda *s: torch.full(s, float("nan"), device="cuda")
+    dw, db = f(3 * E, E), f(3 * E)
+    nbytes = lib.rbx_seqblock_inproj_dw_workspace_size(M)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    outs = []
+    for rep in range(2):
+        assert lib.rbx_seqblock_inproj_dw(_p(qc), _p(kvc), _p(xc), _p(mean), _p(rstd), M, _p(d["ln1_w"]), _p(d["ln1_b"]), _p(dw),
+                                          _p(db), _p(ws), nbytes, None) == 0
+        torch.cuda.synchronize()
+        outs.append([dw.clone(), db.clone()])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert_close(dw, want_w, TOL * max(1.0, float(want_w.abs().max())), "d in_proj_weight")
+    assert_close(db, want_b, TOL * max(1.0, float(want_b.abs().max())), "d in_proj_bias")
+
+
 def _block64(e, P, keep, heads):
     """sasrec.py:81-92 in float64 (batch-first; causal mask; no dropout)."""
     B, L, _ = e.shape
