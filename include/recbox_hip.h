@@ -789,9 +789,11 @@ int rbx_pool_bwd(const float* d_dout, const float* d_mask, const float* d_inv, i
  * 32-row slab through the whole chain in registers (csrc/rbx_seqblock.hip) instead of one pass per LayerNorm /
  * projection / residual.  embed_dim is 64 (cfg 5); all activations contiguous with 16-byte aligned bases; biases and
  * LayerNorm parameters may be NULL (0 / 1).
- *   rbx_seqblock_qkv_fwd:  q = LayerNorm(x) (mean, rstd written); Q = q Wq^T + bq; KV[:, :64] = x Wk^T + bk;
+ *   rbx_seqblock_qkv_fwd:  q = LayerNorm(x) (mean, rstd written; q itself only when d_q != NULL); Q = q Wq^T + bq; KV[:, :64] = x Wk^T + bk;
  *                          KV[:, 64:] = x Wv^T + bv, in_w [192, 64] / in_b [192] = nn.MultiheadAttention's in_proj.
- *   rbx_seqblock_ffn_fwd:  with d_attn != NULL first x = res + attn Wo^T + bo (WRITTEN to d_x: `Q + mha_outputs`),
+ *   rbx_seqblock_ffn_fwd:  with d_attn != NULL first x = res + attn Wo^T + bo (WRITTEN to d_x: `Q + mha_outputs`; with
+ *                          d_res_mean / d_res_rstd != NULL d_res is the block input e and res = LayerNorm(e) is rebuilt
+ *                          from them and d_res_ln_w / _b, so that rbx_seqblock_qkv_fwd need not store q),
  *                          otherwise d_x is the input; then n = LayerNorm(x) (written to d_n unless NULL),
  *                          h = relu(n W1^T + b1), out = (n + h W2^T + b2) * keep[row] (keep NULL: 1).
  *   rbx_seqblock_ffn_bwd:  the backward of the second chain from its LayerNorm on, one pass: with g = dout * keep[row],
@@ -813,7 +815,8 @@ int rbx_seqblock_qkv_fwd(const float* d_x, int64_t m, const float* d_ln_w, const
 int rbx_seqblock_ffn_fwd(const float* d_attn, const float* d_res, const float* d_wo, const float* d_bo, float* d_x, int64_t m,
                          const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w1, const float* d_b1,
                          const float* d_w2, const float* d_b2, const float* d_keep, float* d_mean, float* d_rstd, float* d_n,
-                         float* d_h, float* d_out, void* stream);
+                         float* d_h, float* d_out, const float* d_res_mean, const float* d_res_rstd, const float* d_res_ln_w,
+                         const float* d_res_ln_b, void* stream);
 size_t rbx_seqblock_ffn_bwd_workspace_size(int64_t m);
 int rbx_seqblock_ffn_bwd(const float* d_dout, const float* d_keep, const float* d_h, const float* d_x, const float* d_mean,
                          const float* d_rstd, int64_t m, const float* d_ln_w, const float* d_ln_b, const float* d_w1,

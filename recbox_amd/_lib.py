@@ -159,7 +159,7 @@ SIGNATURES = {
     "rbx_linear_dx_scaled": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i64, _P, _P, _i64, _P]),
     "rbx_seqblock_qkv_fwd": (ctypes.c_int, [_P, _i64, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rbx_seqblock_ffn_fwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _i64, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P,
-                                            _P, _P]),
+                                            _P, _P, _P, _P, _P, _P]),
     "rbx_seqblock_ffn_bwd_workspace_size": (_sz, [_i64]),
     "rbx_seqblock_ffn_bwd": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _i64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_seqblock_attn_in_bwd_workspace_size": (_sz, [_i64]),

@@ -98,10 +98,10 @@ __device__ __forceinline__ void sb_arrived1(f32x4 (&v)[8], float& u) {
                :
                : "memory");
 }
-__device__ __forceinline__ void sb_arrived2(f32x4 (&v)[8], f32x4 (&w)[8], float& u) {
+__device__ __forceinline__ void sb_arrived2(f32x4 (&v)[8], f32x4 (&w)[8], float& u, float& u1, float& u2) {
   asm volatile("s_waitcnt vmcnt(0)"
                : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(w[0]),
-                 "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(u)
+                 "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(u), "+v"(u1), "+v"(u2)
                :
                : "memory");
 }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_qkv_fwd_kernel(const SbQk
       A.mean[r0 + m] = mu;
       A.rstd[r0 + m] = rs;
     }
-    sb_store(lds, lane, x, A.q + static_cast<long long>(r0) * 64, off64, left);
+    if (A.q != nullptr) sb_store(lds, lane, x, A.q + static_cast<long long>(r0) * 64, off64, left);
     sb_gemm_row(wq, lane, x, y);
     sb_add_vec(y, vec + 128, h);
     sb_arrived(nx);          // in front of the last store: behind it the wait (vmcnt counts stores) would hold the next slab
@@ -318,6 +318,9 @@ struct SbFfnArgs {
   float eps;
   float *mean, *rstd, *n, *h, *out;           // n may be NULL (not stored)
   int M;
+  // res_mean != NULL: `res` is the BLOCK INPUT e and the residual is q = LayerNorm(e), rebuilt from these statistics and
+  // parameters (sasrec.py:82,86: Q = attention_layernorm(seqs) ... seqs = Q + mha) -- the first chain then need not store q
+  const float *res_mean, *res_rstd, *res_ln_w, *res_ln_b;
 };
 
 // [x = res + attn Wo^T + bo;]  n = LayerNorm(x); h = relu(n W1^T + b1); out = (n + h W2^T + b2) * keep[row]
@@ -328,8 +331,8 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
   float* w1 = sb_lds;
   float* w2 = w1 + kSbW;
   float* wo = w2 + kSbW;                       // (PRO only)
-  float* vec = PRO ? wo + kSbW : wo;           // gamma, beta, b1, b2, bo
-  float* slabs = vec + 5 * 64;
+  float* vec = PRO ? wo + kSbW : wo;           // gamma, beta, b1, b2, bo, the residual LayerNorm's gamma, beta
+  float* slabs = vec + 7 * 64;
   sb_stage_weight(w1, A.w1, 64, false);
   sb_stage_weight(w2, A.w2, 64, false);
   if constexpr (PRO) sb_stage_weight(wo, A.wo, 64, false);
@@ -338,6 +341,8 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
   sb_stage_vec(vec + 128, A.b1, 0.f);
   sb_stage_vec(vec + 192, A.b2, 0.f);
   sb_stage_vec(vec + 256, PRO ? A.bo : nullptr, 0.f);
+  sb_stage_vec(vec + 320, PRO ? A.res_ln_w : nullptr, 1.f);
+  sb_stage_vec(vec + 384, PRO ? A.res_ln_b : nullptr, 0.f);
   __syncthreads();
   const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
@@ -349,9 +354,12 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
   unsigned off64[8], off[8];
   sb_offsets(64, 32, lane, off64);
   const float* in0 = PRO ? A.attn : A.x;
+  const bool rebuild = PRO && A.res_mean != nullptr;
   f32x4 nx[8], nr[8];
-  float nkp;                                    // the rows' keep travels with the slab's requests
+  float nkp, nrmu = 0.f, nrrs = 0.f;            // the rows' keep (and the residual's statistics) travel with the slab's requests
   const float* keep_p = A.keep != nullptr ? A.keep : in0;
+  const float* rmu_p = rebuild ? A.res_mean : in0;
+  const float* rrs_p = rebuild ? A.res_rstd : in0;
   {
     const int left = A.M - s * 32;
 #pragma unroll
@@ -360,8 +368,12 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
     sb_issue(in0 + static_cast<long long>(s) * 32 * 64, off, nx);
     if constexpr (PRO) sb_issue(A.res + static_cast<long long>(s) * 32 * 64, off, nr);
     sb_issue_word(keep_p, 4u * static_cast<unsigned>(s * 32 + m < A.M ? s * 32 + m : A.M - 1), nkp);
+    if constexpr (PRO) {
+      sb_issue_word(rmu_p, 4u * static_cast<unsigned>(s * 32 + m < A.M ? s * 32 + m : A.M - 1), nrmu);
+      sb_issue_word(rrs_p, 4u * static_cast<unsigned>(s * 32 + m < A.M ? s * 32 + m : A.M - 1), nrrs);
+    }
   }
-  if constexpr (PRO) sb_arrived2(nx, nr, nkp);
+  if constexpr (PRO) sb_arrived2(nx, nr, nkp, nrmu, nrrs);
   else sb_arrived1(nx, nkp);
   for (;;) {
     float x[32];
@@ -374,6 +386,16 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
       float o[32];
       sb_turn_in(lds, lane, nx, o);
       sb_turn_in(lds, lane, nr, x);
+      if (rebuild) {                           // the residual is LayerNorm(e): its rows' statistics are two L2-resident words
+        const float rmu = nrmu, rrs = nrrs;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const int c = 32 * (g >> 2) + 8 * (g & 3) + 4 * h;
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(vec + 320 + c), bt = *reinterpret_cast<const f32x4*>(vec + 384 + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[4 * g + e] = (x[4 * g + e] - rmu) * rrs * gm[e] + bt[e];
+        }
+      }
       {
         const int ln = A.M - sn * 32;
 #pragma unroll
@@ -398,6 +420,10 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
     }
     const float kp = A.keep != nullptr ? nkp : 1.f;
     sb_issue_word(keep_p, 4u * static_cast<unsigned>(sn * 32 + m < A.M ? sn * 32 + m : A.M - 1), nkp);
+    if constexpr (PRO) {
+      sb_issue_word(rmu_p, 4u * static_cast<unsigned>(sn * 32 + m < A.M ? sn * 32 + m : A.M - 1), nrmu);
+      sb_issue_word(rrs_p, 4u * static_cast<unsigned>(sn * 32 + m < A.M ? sn * 32 + m : A.M - 1), nrrs);
+    }
     float mu, rs;
     sb_layernorm(x, vec, vec + 64, h, A.eps, &mu, &rs);
     if (h == 0 && m < left) {
@@ -416,7 +442,7 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_fwd_kernel(const SbFf
     sb_add_vec(y, vec + 192, h);
 #pragma unroll
     for (int r = 0; r < 32; ++r) y[r] = (y[r] + x[r]) * kp;
-    if constexpr (PRO) sb_arrived2(nx, nr, nkp);   // in front of the last store (see sb_qkv_fwd_kernel)
+    if constexpr (PRO) sb_arrived2(nx, nr, nkp, nrmu, nrrs);   // in front of the last store (see sb_qkv_fwd_kernel)
     else sb_arrived1(nx, nkp);
     sb_store(lds, lane, y, A.out + static_cast<long long>(r0) * 64, off64, left);
     if (!more) break;
@@ -1194,7 +1220,7 @@ extern "C" int rbx_seqblock_qkv_fwd(const float* d_x, int64_t m, const float* d_
                                     float* d_Q, float* d_KV, void* stream) {
   if (m < 0 || m > (1LL << 30)) return fail(RBX_ERR_INVALID, "rbx_seqblock_qkv_fwd: m = %lld", static_cast<long long>(m));
   if (m == 0) return RBX_OK;
-  if (!d_x || !d_in_w || !d_mean || !d_rstd || !d_q || !d_Q || !d_KV)
+  if (!d_x || !d_in_w || !d_mean || !d_rstd || !d_Q || !d_KV)
     return fail(RBX_ERR_INVALID, "rbx_seqblock_qkv_fwd: NULL operand");
   if (!sb_aligned(d_x) || !sb_aligned(d_q) || !sb_aligned(d_Q) || !sb_aligned(d_KV))
     return fail(RBX_ERR_UNSUPPORTED, "rbx_seqblock_qkv_fwd: activations must be 16-byte aligned");
@@ -1214,8 +1240,12 @@ extern "C" int rbx_seqblock_qkv_fwd(const float* d_x, int64_t m, const float* d_
 extern "C" int rbx_seqblock_ffn_fwd(const float* d_attn, const float* d_res, const float* d_wo, const float* d_bo, float* d_x,
                                     int64_t m, const float* d_ln_w, const float* d_ln_b, float eps, const float* d_w1,
                                     const float* d_b1, const float* d_w2, const float* d_b2, const float* d_keep,
-                                    float* d_mean, float* d_rstd, float* d_n, float* d_h, float* d_out, void* stream) {
+                                    float* d_mean, float* d_rstd, float* d_n, float* d_h, float* d_out,
+                                    const float* d_res_mean, const float* d_res_rstd, const float* d_res_ln_w,
+                                    const float* d_res_ln_b, void* stream) {
   if (m < 0 || m > (1LL << 30)) return fail(RBX_ERR_INVALID, "rbx_seqblock_ffn_fwd: m = %lld", static_cast<long long>(m));
+  if ((d_res_mean != nullptr) != (d_res_rstd != nullptr) || (d_res_mean != nullptr && d_attn == nullptr))
+    return fail(RBX_ERR_INVALID, "rbx_seqblock_ffn_fwd: the rebuilt residual needs mean AND rstd, and the prologue");
   if (m == 0) return RBX_OK;
   if (!d_x || !d_w1 || !d_w2 || !d_mean || !d_rstd || !d_h || !d_out)
     return fail(RBX_ERR_INVALID, "rbx_seqblock_ffn_fwd: NULL operand");
@@ -1225,8 +1255,8 @@ extern "C" int rbx_seqblock_ffn_fwd(const float* d_attn, const float* d_res, con
       !sb_aligned(d_res))
     return fail(RBX_ERR_UNSUPPORTED, "rbx_seqblock_ffn_fwd: activations must be 16-byte aligned");
   SbFfnArgs a{d_attn, d_res, d_wo, d_bo, d_x, d_ln_w, d_ln_b, d_w1, d_b1, d_w2, d_b2, d_keep, eps,
-              d_mean, d_rstd, d_n, d_h, d_out, static_cast<int>(m)};
-  const size_t lds = sizeof(float) * ((pro ? 3 : 2) * kSbW + 5 * 64 + kSbWaves * kSbSlab);
+              d_mean, d_rstd, d_n, d_h, d_out, static_cast<int>(m), d_res_mean, d_res_rstd, d_res_ln_w, d_res_ln_b};
+  const size_t lds = sizeof(float) * ((pro ? 3 : 2) * kSbW + 7 * 64 + kSbWaves * kSbSlab);
   static bool once[2] = {false, false};
   const void* fn = pro ? reinterpret_cast<const void*>(sb_ffn_fwd_kernel<true>) : reinterpret_cast<const void*>(sb_ffn_fwd_kernel<false>);
   if (!once[pro]) {

@@ -3064,7 +3064,11 @@ class _SeqBlock(torch.autograd.Function):
         ctx.input_stage = (pos is not None, float(alpha))
         hd = E // heads
         f32 = dict(dtype=torch.float32, device=dev)
-        q, Q, KV = torch.empty((M, E), **f32), torch.empty((M, E), **f32), torch.empty((M, 2 * E), **f32)
+        # q = LayerNorm(e) is stored only for the backward forms that read it (the slab dW kernel of dWq): the one-pass forms
+        # rebuild it from e and the statistics, and so does the second chain for its residual
+        keep_q = not (config.seqblock_bwd and config.seqblock_dw3)
+        q = torch.empty((M, E), **f32) if keep_q else None
+        Q, KV = torch.empty((M, E), **f32), torch.empty((M, 2 * E), **f32)
         mean1, rstd1 = torch.empty(M, **f32), torch.empty(M, **f32)
         check(lib.rbx_seqblock_qkv_fwd(_ptr(x2), M, _ptr(ln1_w), _ptr(ln1_b), eps1, _ptr(in_w), _ptr(in_b), _ptr(mean1),
                                        _ptr(rstd1), _ptr(q), _ptr(Q), _ptr(KV), _stream()))
@@ -3079,9 +3083,14 @@ class _SeqBlock(torch.autograd.Function):
         y, h, out = (torch.empty((M, E), **f32) for _ in range(3))
         n = None if config.seqblock_bwd else torch.empty((M, E), **f32)       # (the one-pass backward rebuilds it)
         mean2, rstd2 = torch.empty(M, **f32), torch.empty(M, **f32)
-        check(lib.rbx_seqblock_ffn_fwd(_ptr(O), _ptr(q), _ptr(out_w), _ptr(out_b), _ptr(y), M, _ptr(ln2_w), _ptr(ln2_b), eps2,
-                                       _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(k1), _ptr(mean2), _ptr(rstd2), _ptr(n),
-                                       _ptr(h), _ptr(out), _stream()))
+        if keep_q:
+            check(lib.rbx_seqblock_ffn_fwd(_ptr(O), _ptr(q), _ptr(out_w), _ptr(out_b), _ptr(y), M, _ptr(ln2_w), _ptr(ln2_b), eps2,
+                                           _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(k1), _ptr(mean2), _ptr(rstd2), _ptr(n),
+                                           _ptr(h), _ptr(out), None, None, None, None, _stream()))
+        else:
+            check(lib.rbx_seqblock_ffn_fwd(_ptr(O), _ptr(x2), _ptr(out_w), _ptr(out_b), _ptr(y), M, _ptr(ln2_w), _ptr(ln2_b), eps2,
+                                           _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(k1), _ptr(mean2), _ptr(rstd2), _ptr(n),
+                                           _ptr(h), _ptr(out), _ptr(mean1), _ptr(rstd1), _ptr(ln1_w), _ptr(ln1_b), _stream()))
         ctx.save_for_backward(x2, ln1_w, mean1, rstd1, q, in_w, Q, KV, O, lse, out_w, y, ln2_w, mean2, rstd2, n, w1, h, w2, k1,
                               ln2_b, ln1_b)
         ctx.meta = (B, L, E, heads, hd, float(scale), float(p_drop), int(seed), tick, in_b is not None, out_b is not None,
@@ -3144,7 +3153,7 @@ class _SeqBlock(torch.autograd.Function):
                                                      2 * E, dvptr, 2 * E, _ptr(scratch), _stream())))
         d_in_w = torch.empty_like(in_w) if need[4] else None
         d_in_b = torch.empty(3 * E, **f32) if (has_in_b and need[5]) else None
-        if config.seqblock_bwd and config.seqblock_dw3 and (d_in_w is not None or d_in_b is not None):
+        if q is None or (config.seqblock_bwd and config.seqblock_dw3 and (d_in_w is not None or d_in_b is not None)):
             # dWq | dWk | dWv (+ biases) in ONE pass: e read once, q rebuilt from the saved statistics
             ws_bytes = lib.rbx_seqblock_inproj_dw_workspace_size(B * L)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

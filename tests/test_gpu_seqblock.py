@@ -73,14 +73,14 @@ def test_ffn_chain_vs_float64(M, pro, with_n):
         rc = lib.rbx_seqblock_ffn_fwd(_p(attn_c), _p(res_c), _p(d["out_w"]), None if nob else _p(d["out_b"]), _p(x), M,
                                       _p(d["ln2_w"]), _p(d["ln2_b"]), 1e-8, _p(d["w1"]), None if nob else _p(d["b1"]),
                                       _p(d["w2"]), None if nob else _p(d["b2"]), _p(keep_c), _p(mean), _p(rstd), _p(n),
-                                      _p(h), _p(out), None)
+                                      _p(h), _p(out), None, None, None, None, None)
         x64 = res.double() + attn.double() @ P["out_w"].double().t() + (0 if nob else P["out_b"].double())
         assert_close(x, x64, TOL, "x")
     else:
         x = res_c
         rc = lib.rbx_seqblock_ffn_fwd(None, None, None, None, _p(x), M, None, None, 1e-8, _p(d["w1"]),
                                       None if nob else _p(d["b1"]), _p(d["w2"]), None if nob else _p(d["b2"]), None, _p(mean),
-                                      _p(rstd), _p(n), _p(h), _p(out), None)
+                                      _p(rstd), _p(n), _p(h), _p(out), None, None, None, None, None)
         x64 = res.double()
         keep = torch.ones(M)
     assert rc == 0
@@ -232,6 +232,37 @@ def test_in_projection_weight_gradients_in_one_pass_vs_float64(M):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert_close(dw, want_w, TOL * max(1.0, float(want_w.abs().max())), "d in_proj_weight")
     assert_close(db, want_b, TOL * max(1.0, float(want_b.abs().max())), "d in_proj_bias")
+
+
+@pytest.mark.parametrize("M", [19, 9000])
+def test_ffn_chain_rebuilds_the_residual_from_the_block_input(M):
+    """rbx_seqblock_ffn_fwd with d_res = the block input e and its LayerNorm statistics: the same outputs as with the stored
+    q = LayerNorm(e) as the residual; rbx_seqblock_qkv_fwd without a q output."""
+    from recbox_amd._lib import lib
+    P, g = _params(9)
+    e, attn = torch.randn(M, E, generator=g), torch.randn(M, E, generator=g)
+    keep = (torch.rand(M, generator=g) > 0.3).float()
+    d = {k: v.cuda() for k, v in P.items()}
+    ec, ac, kc = e.cuda(), attn.cuda(), keep.cuda()
+    f = lambda *s: torch.full(s, float("nan"), device="cuda")
+    mean1, rstd1, q, Q, KV = f(M), f(M), f(M, E), f(M, E), f(M, 2 * E)
+    assert lib.rbx_seqblock_qkv_fwd(_p(ec), M, _p(d["ln1_w"]), _p(d["ln1_b"]), 1e-8, _p(d["in_w"]), _p(d["in_b"]), _p(mean1),
+                                    _p(rstd1), _p(q), _p(Q), _p(KV), None) == 0
+    Q2, KV2 = f(M, E), f(M, 2 * E)
+    assert lib.rbx_seqblock_qkv_fwd(_p(ec), M, _p(d["ln1_w"]), _p(d["ln1_b"]), 1e-8, _p(d["in_w"]), _p(d["in_b"]), _p(mean1),
+                                    _p(rstd1), None, _p(Q2), _p(KV2), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(Q, Q2) and torch.equal(KV, KV2)
+    outs = []
+    for res, stats in ((q, (None, None, None, None)), (ec, (_p(mean1), _p(rstd1), _p(d["ln1_w"]), _p(d["ln1_b"])))):
+        x, mean, rstd, h, out = f(M, E), f(M), f(M), f(M, E), f(M, E)
+        assert lib.rbx_seqblock_ffn_fwd(_p(ac), _p(res), _p(d["out_w"]), _p(d["out_b"]), _p(x), M, _p(d["ln2_w"]), _p(d["ln2_b"]),
+                                        1e-8, _p(d["w1"]), _p(d["b1"]), _p(d["w2"]), _p(d["b2"]), _p(kc), _p(mean), _p(rstd),
+                                        None, _p(h), _p(out), stats[0], stats[1], stats[2], stats[3], None) == 0
+        torch.cuda.synchronize()
+        outs.append((x, h, out))
+    for name, a, b in zip(("x", "h", "out"), outs[1], outs[0]):
+        assert_close(a, b, 1e-5, name)
 
 
 def _block64(e, P, keep, heads):
