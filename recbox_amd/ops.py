@@ -3153,7 +3153,9 @@ class _SeqBlock(torch.autograd.Function):
                                                      2 * E, dvptr, 2 * E, _ptr(scratch), _stream())))
         d_in_w = torch.empty_like(in_w) if need[4] else None
         d_in_b = torch.empty(3 * E, **f32) if (has_in_b and need[5]) else None
-        if q is None or (config.seqblock_bwd and config.seqblock_dw3 and (d_in_w is not None or d_in_b is not None)):
+        if d_in_w is None and d_in_b is None:
+            pass                                          # (frozen in-projection: nothing to compute)
+        elif q is None or (config.seqblock_bwd and config.seqblock_dw3):
             # dWq | dWk | dWv (+ biases) in ONE pass: e read once, q rebuilt from the saved statistics
             ws_bytes = lib.rbx_seqblock_inproj_dw_workspace_size(B * L)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
