@@ -834,6 +834,13 @@ size_t rbx_seqblock_inproj_dw_workspace_size(int64_t m);
 int rbx_seqblock_inproj_dw(const float* d_dQ, const float* d_dKV, const float* d_x, const float* d_mean, const float* d_rstd,
                            int64_t m, const float* d_ln_w, const float* d_ln_b, float* d_dw, float* d_db, void* d_workspace,
                            size_t workspace_bytes, void* stream);
+/* rbx_seqblock_ffn_bwd without dW2 / db2 (the caller forms them with rbx_linear_dwdb_scaled): three products and 64
+ * accumulators, two wavefronts per SIMD. */
+size_t rbx_seqblock_ffn_bwd3_workspace_size(int64_t m);
+int rbx_seqblock_ffn_bwd3(const float* d_dout, const float* d_keep, const float* d_h, const float* d_x, const float* d_mean,
+                          const float* d_rstd, int64_t m, const float* d_ln_w, const float* d_ln_b, const float* d_w1,
+                          const float* d_w2, float* d_dx, float* d_dw1, float* d_db1, float* d_dgamma, float* d_dbeta,
+                          void* d_workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

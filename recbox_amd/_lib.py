@@ -168,6 +168,8 @@ SIGNATURES = {
     "rbx_seqblock_attn_out_bwd": (ctypes.c_int, [_P, _P, _i64, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_seqblock_inproj_dw_workspace_size": (_sz, [_i64]),
     "rbx_seqblock_inproj_dw": (ctypes.c_int, [_P, _P, _P, _P, _P, _i64, _P, _P, _P, _P, _P, _sz, _P]),
+    "rbx_seqblock_ffn_bwd3_workspace_size": (_sz, [_i64]),
+    "rbx_seqblock_ffn_bwd3": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _i64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_linear_dwdb_scaled": (ctypes.c_int, [_P, _i64, _P, _i64, _P, _i64, _i32, _i32, _P, _P, _P, _sz, _P]),
     "rbx_fm_sum_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _i32, _P, _P, _P]),
     "rbx_fm_sum_lr_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _i32, _P, _P, _P, _P, _P, _P]),

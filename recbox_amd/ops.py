@@ -73,6 +73,9 @@ class config(object):
     seqblock_bwd = os.environ.get("RECBOX_AMD_SEQBLOCK_BWD", "1") != "0"
     # ... and the three in-projection weight gradients as one pass (rbx_seqblock_inproj_dw) instead of three slab dW launches
     seqblock_dw3 = os.environ.get("RECBOX_AMD_SEQBLOCK_DW3", "1") != "0"
+    # the FFN backward as the slab dW kernel for dW2 + a three-product pass at two wavefronts per SIMD (rbx_seqblock_ffn_bwd3)
+    # instead of the four-product pass at one
+    seqblock_ffn_bwd3 = os.environ.get("RECBOX_AMD_SEQBLOCK_FFN3", "0") != "0"
     # DeepFM: the tower's first Linear, the FM term and the first-order Linear over one gathered block as one autograd node
     # (ops.deepfm_input_stage): the block's gradient comes out of the tower's dx GEMM instead of four kernels
     fuse_deepfm_input = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_INPUT", "1") != "0"
@@ -3117,11 +3120,20 @@ class _SeqBlock(torch.autograd.Function):
             g = torch.empty((M, E), **f32)
             dgamma2 = torch.empty(E, **f32) if want2 else None
             dbeta2 = torch.empty(E, **f32) if want2 else None
-            ws_bytes = lib.rbx_seqblock_ffn_bwd_workspace_size(M)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            check(lib.rbx_seqblock_ffn_bwd(_ptr(g0), _ptr(k1), _ptr(h), _ptr(y), _ptr(mean2), _ptr(rstd2), M, _ptr(ln2_w),
-                                           _ptr(ln2_b), _ptr(w1), _ptr(w2), _ptr(g), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
-                                           _ptr(dgamma2), _ptr(dbeta2), _ptr(ws), ws_bytes, _stream()))
+            if config.seqblock_ffn_bwd3 and _dwdb_scaled_ok(h, g0):
+                # dW2 | db2 by the slab dW kernel, the rest (three products, 64 accumulators) at two wavefronts per SIMD
+                _lin_dwdb_scaled(h, g0, k1, dw2, db2)
+                ws_bytes = lib.rbx_seqblock_ffn_bwd3_workspace_size(M)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                check(lib.rbx_seqblock_ffn_bwd3(_ptr(g0), _ptr(k1), _ptr(h), _ptr(y), _ptr(mean2), _ptr(rstd2), M, _ptr(ln2_w),
+                                                _ptr(ln2_b), _ptr(w1), _ptr(w2), _ptr(g), _ptr(dw1), _ptr(db1), _ptr(dgamma2),
+                                                _ptr(dbeta2), _ptr(ws), ws_bytes, _stream()))
+            else:
+                ws_bytes = lib.rbx_seqblock_ffn_bwd_workspace_size(M)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                check(lib.rbx_seqblock_ffn_bwd(_ptr(g0), _ptr(k1), _ptr(h), _ptr(y), _ptr(mean2), _ptr(rstd2), M, _ptr(ln2_w),
+                                               _ptr(ln2_b), _ptr(w1), _ptr(w2), _ptr(g), _ptr(dw1), _ptr(db1), _ptr(dw2),
+                                               _ptr(db2), _ptr(dgamma2), _ptr(dbeta2), _ptr(ws), ws_bytes, _stream()))
         else:
             _lin_dwdb_scaled(h, g0, k1, dw2, db2)
             dh = _lin_dx(g0, w2, mask=h, row_scale=k1)
