@@ -104,11 +104,16 @@ class _Done(object):
 
 
 class _Joined(object):
+    """Handle of a collective issued on the side stream: ``wait()`` orders the ISSUING stream behind the collective itself
+    (an event recorded right after it), not behind whatever was enqueued on the side stream later."""
+
     def __init__(self, cur, side):
-        self.cur, self.side = cur, side
+        self.cur = cur
+        self.done = torch.cuda.Event()
+        self.done.record(side)
 
     def wait(self):
-        torch.cuda.current_stream().wait_stream(self.side)
+        self.cur.wait_event(self.done)
         return True
 
 
@@ -134,7 +139,6 @@ class _Direct(object):
         self.capturable = False
         self.checked = set()
         self.bound = False
-        self.comms = {}
         self.stream = None              # for exchanges that overlap with compute (async_op)
         self.keep = None
         self.why = "not checked yet"
@@ -167,27 +171,39 @@ class _Direct(object):
                 err = exc
         raise RuntimeError("recbox_amd.comm: cannot bind RCCL (%s)" % (err,))
 
+    @staticmethod
+    def _live_ptr(group, device):
+        """The RCCL communicator torch.distributed holds for ``group`` on ``device`` RIGHT NOW (0 = none yet).  Read on
+        every use -- two pybind calls -- instead of cached: a communicator pointer kept across
+        ``destroy_process_group()`` / ``init_process_group()`` would dangle, and ``id(group)`` (``id(None)`` for the
+        default group) says nothing about which group is meant."""
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        try:
+            return int(pg._get_backend(torch.device("cuda", device.index))._comm_ptr())
+        except (RuntimeError, AttributeError):
+            return 0
+
     def comm_ptr(self, group, device):
-        key = (id(group), device.index)
-        ptr = self.comms.get(key)
-        if ptr is None:
-            pg = group if group is not None else dist.distributed_c10d._get_default_group()
-            ptr = int(pg._get_backend(torch.device("cuda", device.index))._comm_ptr())
-            if ptr == 0:
-                raise RuntimeError("recbox_amd.comm: the process group has no RCCL communicator yet")
-            self.comms[key] = ptr
+        ptr = self._live_ptr(group, device)
+        if ptr == 0:
+            raise RuntimeError("recbox_amd.comm: the process group has no RCCL communicator yet")
         return ptr
 
     def usable(self, x, group):
-        """Should a collective on ``x`` take this path?  Runs the one-time check of the group when due."""
+        """Should a collective on ``x`` take this path?  Runs the one-time check of the group when due.  A group is known
+        by (device, its live communicator): a re-created default group has a new communicator and gets a new check."""
         if self.mode == "0" or not x.is_cuda:
             return False
-        if not (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"):
+        if not (dist.is_available() and dist.is_initialized()):
+            self.checked.clear()                # whatever was checked belonged to a group that is gone
+            self.on = self.capturable = False
             return False
-        key = (id(group), x.device.index)
-        if key not in self.checked:
+        if dist.get_backend(group) != "nccl":
+            return False
+        ptr = self._live_ptr(group, x.device)
+        if ptr == 0 or (x.device.index, ptr) not in self.checked:
             if torch.cuda.is_current_stream_capturing():
-                return self.on              # (the check syncs the host: a capture must come after a warm-up step)
+                return self.on and ptr != 0     # (the check syncs the host: a capture must come after a warm-up step)
             self.self_check(group, x.device)
         return self.on
 
@@ -254,7 +270,6 @@ class _Direct(object):
             return False
         rank, W = dist.get_rank(group), dist.get_world_size(group)
         device = device or torch.device("cuda", torch.cuda.current_device())
-        self.checked.add((id(group), device.index))
         if self.mode == "0":
             self.on = self.capturable = False
             return False
@@ -267,6 +282,7 @@ class _Direct(object):
         dist.all_reduce(m_want, op=dist.ReduceOp.MAX, group=group)
         g_want = x.new_empty((W,) + tuple(x.shape))
         dist.all_gather_into_tensor(g_want.view(-1), x.view(-1), group=group)
+        self.checked.add((device.index, self._live_ptr(group, device)))     # (the collectives above created it)
         ok = torch.zeros(2, device=device)
         err = None
         try:
@@ -334,7 +350,6 @@ class _Direct(object):
     def shutdown(self):
         """Before ``destroy_process_group()``: forget the communicators (the next group gets its own check).  Graphs that
         captured collectives are the caller's to release first (``GraphedStep.release`` / ``ShardedFMStep.release``)."""
-        self.comms.clear()
         self.checked.clear()
         self.on = self.capturable = False
 

@@ -755,7 +755,12 @@ def _grad_dest(key, shape, device):
     if ent is not None and ent.owner is not None and ent.owner() is None:
         del _grad_views[key]                       # its parameter is gone
         ent = None
-    if ent is not None and not ent.taken and tuple(ent.view.shape) == tuple(shape) and ent.view.device == device:
+    # Only while the parameter has NO gradient yet: with a gradient that survived the last step
+    # (zero_grad(set_to_none=False), accumulation) autograd ADDS what the backward returns to ``p.grad`` -- which is the
+    # bucket's memory since the step that took the view over -- so a backward that wrote into the slot again would be added
+    # to itself (2 g from the second step on).  A fresh tensor then; the sum lands in the slot through ``p.grad``.
+    if (ent is not None and not ent.taken and ent.owner is not None and ent.owner().grad is None
+            and tuple(ent.view.shape) == tuple(shape) and ent.view.device == device):
         ent.taken = True
         return ent.view.view(ent.view.shape)
     return torch.empty(tuple(shape), dtype=torch.float32, device=device)

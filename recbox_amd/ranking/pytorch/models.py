@@ -221,6 +221,9 @@ class ShardedFM(nn.Module):
     def sync_grads(self):
         """All-reduce (sum) the dense gradients of the replicated parameters as ONE flat buffer."""
         from ... import comm
+        end = getattr(getattr(self.tables, "local_ops", None), "end_step", None)
+        if end is not None:
+            end()                                   # step boundary of the owners' persistent gradient buffer
         if not comm.multi(self.group):
             return
         # every rank reduces the SAME layout: a parameter that received no gradient on this rank (an empty local batch, a

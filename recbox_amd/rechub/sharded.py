@@ -201,7 +201,13 @@ class DenseGradSync(object):
     gradients come out of the embedding backward itself: one more flat all-reduce in ``finish()``.  ``finish()`` also
     un-flattens and picks up whatever did not go early (a head that took no part in this loss); call it after every
     ``loss.backward()`` -- a second backward before it is refused (the first one's gradients are already summed over the
-    ranks in place)."""
+    ranks in place).
+
+    Gradients that survive a step (``zero_grad(set_to_none=False)``, accumulation over several backward + ``finish()``
+    rounds without ``zero_grad``): autograd adds this backward's LOCAL gradient to what ``p.grad`` holds -- the sum over
+    the ranks of the earlier rounds, identical on every rank -- and the all-reduce would count that W times.  The first
+    gradient of a backward therefore divides every surviving tower / head gradient by W (one fused launch; exact for the
+    power-of-two worlds of a node, one rounding otherwise), so that sum_r (prior / W + g_r) = prior + sum_r g_r."""
 
     def __init__(self, early, late, group=None):
         self.early = [p for p in early if p.requires_grad]
@@ -214,8 +220,10 @@ class DenseGradSync(object):
         self._hooks = []
         self.bucket = None
         self._views = []
+        self._prescaled = False
         if self.active:
             for p in self.early:
+                self._hooks.append(p.register_hook(self._before_grad))
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             self._make_bucket()
 
@@ -235,6 +243,23 @@ class DenseGradSync(object):
             ops._grad_views[p.data_ptr()] = ops._GradView(view, p)
             self._views.append((p, view))
             o += n
+
+    def _prescale(self):
+        if self._prescaled:
+            return
+        self._prescaled = True
+        if self.world > 1:
+            left = [p.grad for p in self.early if p.grad is not None]
+            if left:
+                with torch.no_grad():
+                    torch._foreach_div_(left, float(self.world))
+
+    def _before_grad(self, grad):
+        """Tensor hook of every tower / head parameter: runs when its gradient of this backward exists, before autograd
+        accumulates it.  The first one of a backward pre-divides the surviving gradients (class docstring)."""
+        if self._pending is None:
+            self._prescale()
+        return None
 
     def _on_grad(self, p):
         if id(p) in self._arrived or self._pending is not None:
@@ -276,6 +301,7 @@ class DenseGradSync(object):
                 h.wait()
             self._pending = None
         self._arrived.clear()
+        self._prescaled = False
 
     def finish(self):
         if not self.active:
@@ -284,6 +310,7 @@ class DenseGradSync(object):
         # where: a rank on which some tower parameter received no gradient (it then never fired from the hooks) reduces the
         # early layout here, zeros standing in for what is missing.
         if self._pending is None and self.early:
+            self._prescale()                    # (no tower gradient arrived in this backward: nothing divided them yet)
             self._pending = self._start(self.early)
         if self._pending is not None:
             handles, copied = self._pending
@@ -293,6 +320,7 @@ class DenseGradSync(object):
                 p.grad.copy_(v)
             self._pending = None
         self._arrived.clear()
+        self._prescaled = False
         from .. import ops
         for p, _ in self._views:
             ent = ops._grad_views.get(p.data_ptr())
@@ -323,6 +351,10 @@ class _ShardedModelMixin(object):
     def sync_grads(self):
         """After ``(loss / world_size).backward()``: finish the all-reduces of the replicated gradients."""
         self.grad_sync.finish()
+        for st in self.embedding.stores.values():           # step boundary for the owners' persistent gradient buffers
+            end = getattr(st.local_ops, "end_step", None)
+            if end is not None:
+                end()
 
     def replicated_parameters(self):
         skip = set(id(st.weight) for st in self.embedding.stores.values())

@@ -410,6 +410,13 @@ class HipShardOps(object):
         self._keep = {"grad": None, "shape": tuple(weight.shape), "ws": None, "ws_bytes": 0, "dirty": 0}
         return self
 
+    def end_step(self):
+        """Step boundary (``sync_grads()`` calls it): a sort left pending by a forward whose backward never ran -- a step
+        skipped after a NaN loss, an exception, a grad-enabled evaluation -- is forgotten instead of refusing every later
+        lookup.  The rows that forward's sort named were not stored into: nothing to clear."""
+        if self._keep is not None:
+            self._keep["pending"] = False
+
     def route(self, geom, call, row_ids, pool_ids, vocabs, base, overflow, status):
         """-> (send int32 [W * ichunk], slot int32 [B, T], inv fp32 [B])."""
         from . import ops
@@ -512,7 +519,10 @@ class HipShardOps(object):
         if keep is not None and keep["shape"] == tuple(weight.shape):
             if keep.get("pending"):
                 raise RuntimeError("recbox_amd.sharded: a persistent shard gradient serves ONE lookup of its store per step "
-                                   "(a second exchange started before the first one's backward); use fresh gradients")
+                                   "(a second exchange started before the first one's backward); use fresh gradients.  "
+                                   "If the earlier forward was abandoned without its backward (a skipped step, an "
+                                   "exception, a grad-enabled evaluation), call model.sync_grads() or "
+                                   "store.local_ops.end_step() at the step boundary")
             if keep["grad"] is None:
                 keep["grad"] = torch.zeros_like(weight)                 # the only full fill
             plan.bind_params([weight.detach()], [keep["grad"]])
@@ -689,6 +699,9 @@ class ShardedStore(nn.Module):
         """Every rank derives the static wire sizes of the exchange from ITS batch size: they only agree when all ranks
         hold the same number of samples (``drop_last=True`` in the loader, or pad the last batch).  ``check_batch_size``:
         "auto" (default): "always" for eager calls, nothing inside a hipGraph capture (see below).
+        (That is one 16-byte all-reduce and a host synchronisation per store per eagerly launched step -- the price of not
+        hanging in the exchange; a loop whose loader guarantees equal batches -- ``drop_last=True`` -- should set
+        ``store.check_batch_size = "once"``; captured steps pay nothing either way.)
         "once" checks a size collectively the first time THIS rank sees it -- a set-up error raises ValueError on
         every rank at the first step instead of hanging in the all-to-all; it cannot see a size that changes on one rank only
         (the other ranks do not enter the check).  "always" checks every call (one 16-byte all-reduce + host sync); False

@@ -365,6 +365,50 @@ def _sync_worker(rank, world, port, result):
         dist.destroy_process_group()
 
 
+def _accum_worker(rank, world, port, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from recbox_amd.rechub.sharded import DenseGradSync
+        torch.manual_seed(0)
+        item, user = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+        towers = list(item.parameters()) + list(user.parameters())
+        sync = DenseGradSync(towers, [])
+        ri, ru = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+        ri.load_state_dict(item.state_dict()); ru.load_state_dict(user.state_dict())
+        for step in range(3):                               # three backward + finish rounds, no zero_grad in between
+            g = torch.Generator().manual_seed(10 * step + rank)
+            xi, xu = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
+            if step == 1:
+                loss = (item(xi) ** 2).sum() / world        # the user tower takes no part in this round
+            else:
+                loss = ((item(xi) ** 2).sum() + (user(xu) ** 2).sum()) / world
+            loss.backward()
+            sync.finish()
+            for r in range(world):
+                g = torch.Generator().manual_seed(10 * step + r)
+                xi, xu = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
+                if step == 1:
+                    ((ri(xi) ** 2).sum() / world).backward()
+                else:
+                    (((ri(xi) ** 2).sum() + (ru(xu) ** 2).sum()) / world).backward()
+            for a, b in zip(towers, list(ri.parameters()) + list(ru.parameters())):
+                assert torch.allclose(a.grad, b.grad, atol=1e-6), "round %d" % step
+        result[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dense_grad_sync_accumulates_over_rounds_gloo():
+    """Gradients that survive a round (no zero_grad between backward + finish rounds) are not counted W times."""
+    port = _free_port()
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_accum_worker, args=(2, port, result), nprocs=2, join=True)
+    assert dict(result) == {0: "ok", 1: "ok"}
+
+
 def test_dense_grad_sync_reduces_only_this_steps_gradients_gloo():
     port = _free_port()
     mgr = mp.Manager()

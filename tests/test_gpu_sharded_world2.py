@@ -209,6 +209,79 @@ def test_direct_rccl_exchange_equals_torch_distributed():
     assert _spawn(_rccl_worker, 1) == {0: "ok"}
 
 
+def _keepgrad_worker(rank, world, port, result):
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                            device_id=torch.device("cuda", 0))
+    try:
+        import torch.nn.functional as F
+        from conftest import assert_close
+        from recbox_amd import comm
+        from recbox_amd.rechub.sharded import ShardedYoutubeDNN
+        from test_gpu_shard import _rh, _seed_params, _youtube_batch, _youtube_feats
+        torch.cuda.set_device(0)
+        comm.force_world_of_one = True
+        Fe = _rh()
+        V, Dm, B, L, n_neg = 1501, 16, 96, 7, 3
+        model = ShardedYoutubeDNN(*_youtube_feats(Fe, V, Dm), {"dims": [32, Dm]}, temperature=0.1, shard_min_vocab=500,
+                                  capacity_factor=2.0).cuda()
+        _seed_params(model)
+        assert model.grad_sync.bucket is not None              # the CUDA path: tower gradients are written into bucket views
+        towers = model.grad_sync.early
+        batches = [{k: v.cuda() for k, v in _youtube_batch(B, V, L, n_neg, 80 + k).items()} for k in range(2)]
+        tgt = torch.zeros(B, dtype=torch.long, device="cuda")
+
+        def backward(x):
+            F.cross_entropy(model(x), tgt).backward()
+            model.sync_grads()
+
+        want = []
+        for x in batches:                                      # reference: every step starts without gradients
+            model.zero_grad(set_to_none=True)
+            backward(x)
+            torch.cuda.synchronize()
+            want.append([p.grad.clone() for p in towers])
+        # (a) zero_grad(set_to_none=False): p.grad stays the bucket view of the first step, zeroed in place
+        model.zero_grad(set_to_none=True)
+        for k, x in enumerate(batches + batches):
+            backward(x)
+            torch.cuda.synchronize()
+            for p, w in zip(towers, want[k % 2]):
+                assert_close(p.grad, w, 1e-6, "set_to_none=False, step %d" % k)
+            model.zero_grad(set_to_none=False)
+        # (b) accumulation: two backward + sync rounds without zero_grad
+        model.zero_grad(set_to_none=True)
+        backward(batches[0])
+        backward(batches[1])
+        torch.cuda.synchronize()
+        for p, a, b in zip(towers, *want):
+            assert_close(p.grad, a + b, 1e-6, "two backward + sync rounds without zero_grad")
+        # (c) a new default group WITHOUT comm.direct.shutdown(): the collectives must find the new communicator
+        x = torch.arange(64, dtype=torch.float32, device="cuda")
+        comm.all_reduce_sum_(x, force=True)
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (port + 1), rank=rank, world_size=world,
+                                device_id=torch.device("cuda", 0))
+        y = torch.arange(64, dtype=torch.float32, device="cuda")
+        comm.all_reduce_sum_(y, force=True)
+        out = torch.empty_like(y)
+        comm.all_to_all_equal_into(out, y)
+        torch.cuda.synchronize()
+        assert torch.equal(y, x) and torch.equal(out, y)
+        result.put((rank, "ok"))
+    finally:
+        comm.force_world_of_one = False
+        comm.direct.shutdown()
+        dist.destroy_process_group()
+
+
+def test_surviving_gradients_and_a_recreated_group():
+    """tower gradients written into DenseGradSync's bucket views stay right when ``p.grad`` survives a step
+    (zero_grad(set_to_none=False): no 2 g from the second step on; accumulation over two backward + sync rounds = the
+    sum), and the direct RCCL path follows a destroyed + re-created default process group without an explicit shutdown."""
+    assert _spawn(_keepgrad_worker, 1) == {0: "ok"}
+
+
 @pytest.mark.parametrize("how", ["driver", "bare_shell_strong"])
 def test_bench_script_runs_its_two_rank_path(how):
     """bench.py with N = 2, both ranks on this box's single GPU over gloo (RECBOX_BENCH_ONE_GPU=1): the N>1 control flow of
