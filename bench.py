@@ -1063,7 +1063,11 @@ def main():
             # it keeps for the backward (+64 B) -- is reported beside it as frac_incl_S, not in `frac`.
             per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + n_sparse * 4 + N_DENSE * 4 + 4
             per_sample_incl_s = per_sample + N_DENSE * 4 + args.dim * 4
-            kname = "fm_fused_fwd_kernel<%d,1,true,3>" % (args.dim // 4)       # (3 = RBX_F64: the id columns' dtype)
+            # the flat float64 batch tensor at dim 16 runs rbx_fm_quad.hip's kernel (10 column slots per lane for the 39
+            # features, 20 rows in flight, 3 = RBX_F64); anything else -- or ops.fm_quad_kernel(False) -- the general one
+            quad = args.dim == 16 and not sharded and ops.fm_quad_kernel()
+            kname = ("fm_quad_fwd_kernel<%d,20,3>" % ((n_fields + 3) // 4)) if quad else \
+                    ("fm_fused_fwd_kernel<%d,1,true,3>" % (args.dim // 4))
         else:
             per_sample = n_sparse * args.dim * 4 + n_sparse * 8 + N_DENSE * 4 + n_fields * args.dim * 4
             kname = "embed_fwd_kernel<%d,1,true>" % (args.dim // 4)
@@ -1088,12 +1092,11 @@ def main():
             if args.dim == 16 and (args.path == "fused" or sharded):
                 # what this GPU delivers on random 64-byte rows at all (a kernel that only gathers them): the ceiling the
                 # D = 16 forward can be held against; 128-byte rows and wider reach 5.8-6.0 TB/s
-                roof["row_gather_ceiling"] = {"GB/s": 3070.5, "frac_of_peak": 3070.5 / 8000.0,
-                                              "measured_in_this_run": False,
-                                              "source": "profiles/r03/gather_ceiling.txt (profiles/ubench/gather_ceiling.hip: random "
-                                                        "64-byte rows reach 46.9-48.0 G rows/s at every queue depth, through registers "
-                                                        "and through LDS-DMA alike -- the rate of random 128-byte rows, 6.0-6.1 TB/s of "
-                                                        "lines beside a 6.3-6.5 TB/s read-only stream)"}
+                # NOT a ceiling of this workload: 14 of the 26 tables are cache-resident.  What bounds the kernel
+                # is the CU's vector memory path -- profiles/r05/fm_fwd_limiter.md
+                roof["limiter"] = ("per-CU vector memory path: ~64 L1 misses in flight x 550 cycles of L2 / fabric latency "
+                                   "(TCP_TCC_READ_REQ / _LATENCY), one tag lookup per cycle, issue slots: "
+                                   "profiles/r05/fm_fwd_limiter.md; with every lookup hitting L1 the kernel takes 16 us")
             ams = alone_timer.mean_ms()
             if ams:
                 roof["frac_alone"] = per_sample * B / (ams * 1e-3) / 1e9 / 8000.0

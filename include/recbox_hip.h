@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 119          /* 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 120          /* 0.1.20: rbx_fm_quad (rbx_fm_fwd's kernel for ids that are columns of one batch tensor); 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -296,6 +296,13 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
  * returns the previous setting.
  * Change it between steps only: rbx_fm_sort / _bwd / _rezero of one step must see the same setting. */
 int rbx_fm_tier_c(int32_t enable);
+/* Round 5: rbx_fm_fwd has a second kernel (csrc/rbx_fm_quad.hip) for the wire format of the reference's ranking loader --
+ * every feature's ids / values the columns, in feature order, of ONE row-major batch tensor of one dtype
+ * (ranking/pytorch/dataloaders/h5_dataloader.py:36-47, ranking_model.py:106-116), dim 16, both field arrays given, the
+ * tables within 4 GiB of each other, no extra rows.  Same results as the general kernel, operation for operation.  Taken
+ * automatically; rbx_fm_quad(0) forces the general kernel (A/B measurements, tests), a negative value only reads; returns
+ * the previous setting (RBX_FM_QUAD=0 in the environment: off from the start). */
+int rbx_fm_quad(int32_t enable);
 /* With persistent gradient buffers the rows a backward stored have to be cleared before the next one (rbx_fm_rezero).  When
  * every sorted table of the call is on tier C (returns 1) the partition pass of the NEXT step can do it while it overwrites
  * the bucket arrays that name those rows: pass phases | 8 to rbx_fm_sort_phases INSTEAD of calling rbx_fm_rezero -- same

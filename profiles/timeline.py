@@ -1,18 +1,25 @@
-"""Timeline of ONE hipGraph replay out of a rocprofv3 --kernel-trace rocpd database: start offset, duration and queue of
+"""Timeline of ONE hipGraph replay out of a rocprofv3 --kernel-trace rocpd database (or its -f csv *_kernel_trace.csv): start offset, duration and queue of
 every kernel between two consecutive launches of an anchor kernel (default: the first kernel of the step).
     python profiles/timeline.py <results.db> [anchor-substring] [which-occurrence]
 """
+import csv
 import sqlite3
 import sys
 
 
 def main():
-    db = sqlite3.connect(sys.argv[1])
     anchor = sys.argv[2] if len(sys.argv) > 2 else "rezero_rows"
     which = int(sys.argv[3]) if len(sys.argv) > 3 else -5
-    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
-    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
-    rows = db.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")).fetchall()
+    if sys.argv[1].endswith(".csv"):                   # rocprofv3 --kernel-trace -f csv: *_kernel_trace.csv
+        qcol = "Queue_Id"
+        with open(sys.argv[1]) as fh:
+            rows = sorted(((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", ""))
+                           for r in csv.DictReader(fh)), key=lambda r: r[1])
+    else:
+        db = sqlite3.connect(sys.argv[1])
+        cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+        qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+        rows = db.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")).fetchall()
     marks = [i for i, r in enumerate(rows) if anchor in r[0]]
     a, b = marks[which], marks[which + 1]
     t0 = rows[a][1]

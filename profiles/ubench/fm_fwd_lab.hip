@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -274,6 +275,240 @@ __global__ __launch_bounds__(LDS ? 1024 : 256) void fm_quad(const Meta M, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ g4: lane group of 4, DPP quad broadcast
+// A sample = 4 lanes (float4 each: the fewest instructions per sample), 16 samples per wavefront.  Lane j of a group reads
+// the sample's columns j, 4 + j, 8 + j, ... (consecutive lanes = consecutive columns: a group's loads of one step cover 32
+// contiguous bytes, the NI steps of a sample its whole batch row, fetched from memory once), decodes ITS columns -- row byte
+// offset from `arena`, LR byte offset; an invalid id or a column past F points at the zero vector at offset 0 -- and issues
+// its columns' LR loads.  The feature loop then needs no per-feature state at all: `quad_perm` broadcasts the owner lane's
+// offset to the group (folded into the address add), UB rows in flight per lane, features summed in feature order.
+template <int J>
+__device__ __forceinline__ unsigned qbcast(unsigned v) {
+  return static_cast<unsigned>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), J | (J << 2) | (J << 4) | (J << 6), 0xF, 0xF, true));
+}
+template <int J>
+__device__ __forceinline__ float qbcastf(float v) { return __uint_as_float(qbcast<J>(__float_as_uint(v))); }
+
+template <int F0, int U, int UB>
+__device__ __forceinline__ void g4_issue(const unsigned (&o)[16], const unsigned lane16, const char* __restrict__ arena,
+                                         float4 (&e)[UB]) {
+  if constexpr (U < UB) {
+    constexpr int f = F0 + U;
+    const unsigned off = qbcast<(f & 3)>(o[f >> 2]) + lane16;
+    e[U] = *reinterpret_cast<const float4*>(arena + static_cast<size_t>(off));
+    g4_issue<F0, U + 1, UB>(o, lane16, arena, e);
+  }
+}
+template <int F0, int U, int UB>
+__device__ __forceinline__ void g4_use(const float (&x)[16], const float4 (&e)[UB], float (&s)[4], float (&q)[4]) {
+  if constexpr (U < UB) {
+    constexpr int f = F0 + U;
+    const float xb = qbcastf<(f & 3)>(x[f >> 2]);
+    const float t0 = e[U].x * xb, t1 = e[U].y * xb, t2 = e[U].z * xb, t3 = e[U].w * xb;
+    s[0] += t0; q[0] += t0 * t0;
+    s[1] += t1; q[1] += t1 * t1;
+    s[2] += t2; q[2] += t2 * t2;
+    s[3] += t3; q[3] += t3 * t3;
+    g4_use<F0, U + 1, UB>(x, e, s, q);
+  }
+}
+template <int F0, int NF, int UB>
+__device__ __forceinline__ void g4_batches(const unsigned (&o)[16], const float (&x)[16], const unsigned lane16,
+                                           const char* __restrict__ arena, float (&s)[4], float (&q)[4]) {
+  if constexpr (F0 < NF) {
+    constexpr int N = (NF - F0 < UB) ? NF - F0 : UB;
+    float4 e[N];
+    g4_issue<F0, 0, N>(o, lane16, arena, e);
+    g4_use<F0, 0, N>(x, e, s, q);
+    __builtin_amdgcn_sched_barrier(0);
+    g4_batches<F0 + N, NF, UB>(o, x, lane16, arena, s, q);
+  }
+}
+
+template <int NI, int UB, int WPE>
+__global__ __launch_bounds__(256, WPE) void fm_g4(const Meta M, const char* __restrict__ arena, const int F,
+                                                  const double* __restrict__ X, const int ldx, const long long B,
+                                                  const float* __restrict__ bias, float* __restrict__ logit,
+                                                  float* __restrict__ prob, float* __restrict__ ssum) {
+  __shared__ int s_voc[64];
+  __shared__ unsigned s_eo[64], s_es[64], s_lo[64], s_ls[64];
+  if (threadIdx.x < 64) {
+    s_voc[threadIdx.x] = M.vocab[threadIdx.x];
+    s_eo[threadIdx.x] = M.emb_off[threadIdx.x];
+    s_es[threadIdx.x] = M.emb_stride[threadIdx.x];
+    s_lo[threadIdx.x] = M.lr_off[threadIdx.x];
+    s_ls[threadIdx.x] = M.lr_stride[threadIdx.x];
+  }
+  __syncthreads();
+  const int lane_g = threadIdx.x & 3;
+  const unsigned lane16 = lane_g * 16;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / 4);
+  for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / 4) + threadIdx.x / 4; b < B; b += ngroups) {
+    const double* xr = X + b * ldx;
+    double c[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * i + lane_g;
+      c[i] = xr[col < F ? col : F - 1];
+    }
+    unsigned o[16];
+    float x[16], l1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * i + lane_g;
+      const int voc = s_voc[col];
+      const int v = __double2int_rz(c[i]);
+      const bool ok = (c[i] == c[i]) && static_cast<unsigned>(v) < static_cast<unsigned>(voc);     // false for numeric / padding columns
+      const bool num = voc == 0 && col < F;
+      const unsigned id = ok ? static_cast<unsigned>(v) : 0u;
+      x[i] = num ? static_cast<float>(c[i]) : 1.f;
+      o[i] = (ok || num) ? s_eo[col] + id * s_es[col] : 0u;             // invalid id / padding column: the zero vector
+      const unsigned lro = (ok || num) ? s_lo[col] + id * s_ls[col] : 0u;
+      l1[i] = *reinterpret_cast<const float*>(arena + static_cast<size_t>(lro));
+    }
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    g4_batches<0, 4 * NI, UB>(o, x, lane16, arena, s, q);
+    float lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) lr += l1[i] * x[i];
+    float fm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fm += (s[i] * s[i] - q[i]) * 0.5f;
+    const float total = group_sum4(fm + lr);
+    if (lane_g == 0) {
+      const float z = total + bias[0];
+      logit[b] = z;
+      prob[b] = 1.f / (1.f + expf(-z));
+    }
+    *reinterpret_cast<float4*>(ssum + b * 16 + lane_g * 4) = make_float4(s[0], s[1], s[2], s[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ g4l: g4 + small arrays in LDS
+// As g4, with the arrays that cost a cache-line lookup per sample but hold few bytes -- the numeric features' weight vectors
+// and LR weights, the rows and LR weights of the smallest tables -- copied into LDS by the workgroup's prologue (a copy list of
+// 16-byte units: LDS unit u <- arena + src[u]), so that their lookups leave the vector memory path.  `emb_mask` / `lr_mask`:
+// bit c set = column c's rows / LR weights are read from LDS (its offsets in the metadata are then LDS byte offsets).
+struct MetaL {
+  Meta m;
+  unsigned long long emb_mask, lr_mask;
+  const unsigned* copy_src;
+  int n_units;
+};
+
+template <int F0, int U, int UB>
+__device__ __forceinline__ void g4l_issue(const unsigned (&o)[16], const unsigned lane16, const char* __restrict__ arena,
+                                          const char* img, const unsigned long long emb_mask, float4 (&e)[UB]) {
+  if constexpr (U < UB) {
+    constexpr int f = F0 + U;
+    const unsigned off = qbcast<(f & 3)>(o[f >> 2]) + lane16;
+    if ((emb_mask >> f) & 1ull) e[U] = *reinterpret_cast<const float4*>(img + off);
+    else e[U] = *reinterpret_cast<const float4*>(arena + static_cast<size_t>(off));
+    g4l_issue<F0, U + 1, UB>(o, lane16, arena, img, emb_mask, e);
+  }
+}
+template <int F0, int NF, int UB>
+__device__ __forceinline__ void g4l_batches(const unsigned (&o)[16], const float (&x)[16], const unsigned lane16,
+                                            const char* __restrict__ arena, const char* img,
+                                            const unsigned long long emb_mask, float (&s)[4], float (&q)[4]) {
+  if constexpr (F0 < NF) {
+    constexpr int N = (NF - F0 < UB) ? NF - F0 : UB;
+    float4 e[N];
+    g4l_issue<F0, 0, N>(o, lane16, arena, img, emb_mask, e);
+    g4_use<F0, 0, N>(x, e, s, q);
+    __builtin_amdgcn_sched_barrier(0);
+    g4l_batches<F0 + N, NF, UB>(o, x, lane16, arena, img, emb_mask, s, q);
+  }
+}
+
+template <int NI, int UB, int BS, int WPE>
+__global__ __launch_bounds__(BS, WPE) void fm_g4l(const MetaL ML, const char* __restrict__ arena, const int F,
+                                                  const double* __restrict__ X, const int ldx, const long long B,
+                                                  const float* __restrict__ bias, float* __restrict__ logit,
+                                                  float* __restrict__ prob, float* __restrict__ ssum) {
+  extern __shared__ char dyn[];
+  int* s_voc = reinterpret_cast<int*>(dyn);
+  unsigned* s_eo = reinterpret_cast<unsigned*>(dyn) + 64;
+  unsigned* s_es = s_eo + 64;
+  unsigned* s_lo = s_es + 64;
+  unsigned* s_ls = s_lo + 64;
+  char* img = dyn + 5 * 64 * 4;
+  if (threadIdx.x < 64) {
+    s_voc[threadIdx.x] = ML.m.vocab[threadIdx.x];
+    s_eo[threadIdx.x] = ML.m.emb_off[threadIdx.x];
+    s_es[threadIdx.x] = ML.m.emb_stride[threadIdx.x];
+    s_lo[threadIdx.x] = ML.m.lr_off[threadIdx.x];
+    s_ls[threadIdx.x] = ML.m.lr_stride[threadIdx.x];
+  }
+  {
+    constexpr int CU_ = 6;                     // units per thread per sweep: index loads, then data loads, then LDS stores
+    for (int base = 0; base < ML.n_units; base += CU_ * BS) {
+      unsigned so[CU_];
+#pragma unroll
+      for (int u = 0; u < CU_; ++u) {
+        const int i = base + u * BS + threadIdx.x;
+        so[u] = ML.copy_src[i < ML.n_units ? i : ML.n_units - 1];
+      }
+      float4 v[CU_];
+#pragma unroll
+      for (int u = 0; u < CU_; ++u) v[u] = *reinterpret_cast<const float4*>(arena + static_cast<size_t>(so[u]));
+#pragma unroll
+      for (int u = 0; u < CU_; ++u) {
+        const int i = base + u * BS + threadIdx.x;
+        if (i < ML.n_units) reinterpret_cast<float4*>(img)[i] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  const int lane_g = threadIdx.x & 3;
+  const unsigned lane16 = lane_g * 16;
+  const unsigned long long emb_mask = ML.emb_mask, lr_mask = ML.lr_mask;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (BS / 4);
+  for (long long b = static_cast<long long>(blockIdx.x) * (BS / 4) + threadIdx.x / 4; b < B; b += ngroups) {
+    const double* xr = X + b * ldx;
+    double c[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * i + lane_g;
+      c[i] = xr[col < F ? col : F - 1];
+    }
+    unsigned o[16];
+    float x[16], l1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * i + lane_g;
+      const int voc = s_voc[col];
+      const int v = __double2int_rz(c[i]);
+      const bool ok = (c[i] == c[i]) && static_cast<unsigned>(v) < static_cast<unsigned>(voc);
+      const bool num = voc == 0 && col < F;
+      const bool use = ok || num;
+      const unsigned id = ok ? static_cast<unsigned>(v) : 0u;
+      x[i] = num ? static_cast<float>(c[i]) : 1.f;
+      const bool e_lds = (emb_mask >> col) & 1ull, l_lds = (lr_mask >> col) & 1ull;
+      // an invalid id / a column past F reads the zero vector: LDS unit 0 and arena offset 0 both hold one
+      o[i] = use ? s_eo[col] + id * s_es[col] : 0u;
+      const unsigned lro = use ? s_lo[col] + id * s_ls[col] : 0u;
+      l1[i] = l_lds ? *reinterpret_cast<const float*>(img + lro) : *reinterpret_cast<const float*>(arena + static_cast<size_t>(lro));
+      (void)e_lds;
+    }
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    g4l_batches<0, 4 * NI, UB>(o, x, lane16, arena, img, emb_mask, s, q);
+    float lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) lr += l1[i] * x[i];
+    float fm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fm += (s[i] * s[i] - q[i]) * 0.5f;
+    const float total = group_sum4(fm + lr);
+    if (lane_g == 0) {
+      const float z = total + bias[0];
+      logit[b] = z;
+      prob[b] = 1.f / (1.f + expf(-z));
+    }
+    *reinterpret_cast<float4*>(ssum + b * 16 + lane_g * 4) = make_float4(s[0], s[1], s[2], s[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static const int kRot = 8;            // distinct batches replayed in rotation (as bench.py does)
 
@@ -413,6 +648,44 @@ int main(int argc, char** argv) {
     m.upload();
     return m;
   };
+
+  // plan of the g4l forms: arrays (rows of a table / its LR weights) ascending by bytes into an LDS budget; numeric first
+  struct LPlan { MetaL dev; int lds_bytes; int n_emb, n_lr; };
+  auto make_l = [&](int budget_bytes) {
+    MetaHost m;
+    m.vocab.assign(64, 0); m.eo.assign(64, 0); m.es.assign(64, 0); m.lo.assign(64, 0); m.ls.assign(64, 0);
+    struct Arr { size_t bytes; int f; int lr; };
+    std::vector<Arr> arrs;
+    for (int f = 0; f < kF; ++f) {
+      const size_t rows = f < 13 ? 1 : kCard[f - 13] + 1;
+      arrs.push_back({rows * 64, f, 0});
+      arrs.push_back({(rows * 4 + 15) / 16 * 16, f, 1});
+      m.vocab[f] = f < 13 ? 0 : static_cast<int>(rows);
+      m.eo[f] = static_cast<unsigned>(emb_at[f]); m.es[f] = 64;
+      m.lo[f] = static_cast<unsigned>(lr_at[f]); m.ls[f] = 4;
+    }
+    std::sort(arrs.begin(), arrs.end(), [](const Arr& a, const Arr& b) { return a.bytes < b.bytes; });
+    std::vector<unsigned> src;
+    for (int u = 0; u < 4; ++u) src.push_back(0);          // LDS units 0..3: zeros (arena offset 0..63 is a zero vector)
+    unsigned long long em = 0, lm = 0;
+    int ne = 0, nl = 0;
+    for (const Arr& a : arrs) {
+      if (src.size() * 16 + a.bytes > static_cast<size_t>(budget_bytes)) break;
+      const unsigned at_lds = static_cast<unsigned>(src.size() * 16);
+      const size_t from = a.lr ? lr_at[a.f] : emb_at[a.f];
+      for (size_t u = 0; u < a.bytes / 16; ++u) src.push_back(static_cast<unsigned>(from + u * 16));
+      if (a.lr) { m.lo[a.f] = at_lds; lm |= 1ull << a.f; ++nl; } else { m.eo[a.f] = at_lds; em |= 1ull << a.f; ++ne; }
+    }
+    m.upload();
+    unsigned* d_src;
+    CK(hipMalloc(&d_src, src.size() * 4));
+    CK(hipMemcpy(d_src, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    LPlan p;
+    p.dev = MetaL{m.dev, em, lm, d_src, static_cast<int>(src.size())};
+    p.lds_bytes = static_cast<int>(src.size() * 16) + 5 * 64 * 4;
+    p.n_emb = ne; p.n_lr = nl;
+    return p;
+  };
   struct Var { int kernel; int flags; const char* name; int grid; bool check; };
   std::vector<Var> vars = {
       {0, 0, "v0 lane group of 4, 8 features in flight, ids in place (round 4 form)", 1024, true},
@@ -422,6 +695,21 @@ int main(int argc, char** argv) {
       {1, 1, "v1p quad packed, 8192 waves", 2048, true},
       {2, 2, "v2 quad + small tables in LDS, 256 workgroups x 1024", 256, true},
       {2, 3, "v2p quad + small tables in LDS + the rest packed", 256, true},
+      {3, 0, "g4: lane group of 4 + quad broadcast, 10 rows in flight, 1024 workgroups", 1024, true},
+      {4, 0, "g4: 14 rows in flight, 1024 workgroups", 1024, true},
+      {5, 0, "g4: 20 rows in flight (3 waves/SIMD), 1024 workgroups", 1024, true},
+      {6, 0, "g4: 8 rows in flight (5 waves/SIMD), 1024 workgroups", 1024, true},
+      {20, 2, "g4l: numeric weights only in LDS (2 KB), 256-thread workgroups x 768", 768, true},
+      {20, 48, "g4l: 48 KB of small arrays in LDS, 256-thread workgroups x 768 (3 per CU)", 768, true},
+      {21, 48, "g4l: 48 KB in LDS, 768-thread workgroups x 256 (1 per CU)", 256, true},
+      {21, 150, "g4l: 150 KB in LDS, 768-thread workgroups x 256 (1 per CU)", 256, true},
+      {22, 48, "g4l: 48 KB in LDS, 10 in flight, 512-thread workgroups x 512 (2 per CU)", 512, true},
+      {23, 150, "g4l: 150 KB in LDS, 10 in flight, 1024-thread workgroups x 256", 256, true},
+      {21, 20, "g4l: 20 KB in LDS, 768-thread workgroups x 256", 256, true},
+      {7, 0, "g4: 10 rows in flight, 3 waves/SIMD register budget", 1024, true},
+      {8, 0, "g4: 13 rows in flight, 3 waves/SIMD register budget", 1024, true},
+      {3, 0, "g4: 10 rows in flight, 2048 workgroups (8 samples per lane group slot)", 2048, true},
+      {3, 16 + 64, "abl: g4 (10 in flight) without LR and row misses", 1024, false},
       {1, 16, "abl: v1 without LR misses", 4096, false},
       {1, 16 + 32, "abl: v1 without LR misses and without the five 1 M-row + 2 next tables' row misses", 4096, false},
       {1, 16 + 64, "abl: v1 without LR and row misses (batch stream + S store only)", 4096, false},
@@ -435,7 +723,16 @@ int main(int argc, char** argv) {
   for (const Var& v : vars) {
     const int my = vi++;
     if (only >= 0 && my != only) continue;
-    MetaHost m = make(v.flags, v.kernel == 2);
+    MetaHost m = make(v.kernel >= 20 ? 0 : v.flags, v.kernel == 2);
+    LPlan lp{};
+    if (v.kernel >= 20) {
+      lp = make_l(v.flags * 1024);
+      printf("     LDS plan: budget %d KB -> %d bytes, rows of %d columns and LR weights of %d columns resident\n", v.flags, lp.lds_bytes, lp.n_emb, lp.n_lr);
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fm_g4l<10, 20, 256, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fm_g4l<10, 20, 768, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fm_g4l<10, 10, 512, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fm_g4l<10, 10, 1024, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     float4* d_image = nullptr;
     const int lds_bytes = static_cast<int>(image.size() * 4);
     if (v.kernel == 2) {
@@ -448,6 +745,16 @@ int main(int argc, char** argv) {
       auto launch = [&](int r) {
         if (v.kernel == 0) fm_v0<<<v.grid, 256>>>(p0[z][r], kF, B, bias, logit, prob, ssum);
         else if (v.kernel == 1) fm_quad<false, 3><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum, nullptr, 0);
+        else if (v.kernel == 3) fm_g4<10, 10, 4><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 4) fm_g4<10, 14, 4><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 5) fm_g4<10, 20, 3><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 7) fm_g4<10, 10, 3><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 8) fm_g4<10, 13, 3><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 6) fm_g4<10, 8, 5><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 20) fm_g4l<10, 20, 256, 3><<<v.grid, 256, lp.lds_bytes>>>(lp.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 21) fm_g4l<10, 20, 768, 3><<<v.grid, 768, lp.lds_bytes>>>(lp.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 22) fm_g4l<10, 10, 512, 4><<<v.grid, 512, lp.lds_bytes>>>(lp.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 23) fm_g4l<10, 10, 1024, 4><<<v.grid, 1024, lp.lds_bytes>>>(lp.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else fm_quad<true, 3><<<v.grid, 1024, lds_bytes>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum, d_image, lds_bytes);
       };
       double ez = 0, es = 0;

@@ -31,54 +31,6 @@
 
 namespace rbx {
 
-struct FmField {            // 48 B
-  const void* ids;
-  const float* emb;         // [V, D] table or numeric weight [D]; NULL when there is no second-order part
-  const float* lr;          // [V] (dim-1 table) or numeric weight [1]; NULL when there is no first-order part
-  long long stride_b;
-  int vocab;
-  unsigned char dtype, kind, r0, r1;
-  int emb_stride;           // floats between rows of emb / lr: D and 1 for contiguous tables; equal (e.g. 32) when both
-  int lr_stride;            // live in one packed [V, stride] storage -- then a lookup touches ONE 128-byte line
-};
-struct FmPack { FmField f[RBX_MAX_FIELDS]; };
-
-// Uniform-dtype fast path of the forward (DT = the one ids dtype every feature of the call has; -1 = mixed: the generic code).
-// The generic path converts a float64 id with static_cast<long long>(double) -- ~20 emulated instructions, there is no
-// 64-bit convert on gfx950 -- keeps ids in 64-bit registers and branches on the dtype of every feature; with 39 features per
-// sample the forward was bound by instruction issue, not by memory (every experiment on its memory side came out flat:
-// profiles/r02/sort_variants.txt).  Here: one v_cvt_i32_f64 (an id is < 2^31 once it passes the range check; NaN and
-// out-of-range values fail it exactly as in the generic path), 32-bit ids, no dtype switch.
-template <int DT>
-__device__ __forceinline__ long long fm_load_raw(const void* p, long long idx) {
-  if constexpr (DT == RBX_I64 || DT == RBX_F64) return static_cast<const long long*>(p)[idx];
-  else return static_cast<long long>(static_cast<const int*>(p)[idx]);
-}
-template <int DT>
-__device__ __forceinline__ bool fm_decode_id(long long raw, int vocab, int* id) {
-  if constexpr (DT == RBX_I32) {
-    *id = static_cast<int>(raw);
-    return static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
-  } else if constexpr (DT == RBX_I64) {
-    *id = static_cast<int>(raw);
-    return static_cast<unsigned long long>(raw) < static_cast<unsigned long long>(vocab);
-  } else if constexpr (DT == RBX_F32) {
-    const float f = __int_as_float(static_cast<int>(raw));
-    *id = __float2int_rz(f);                                // .long() truncates towards zero; saturates beyond int32
-    return (f == f) && static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
-  } else {
-    const double d = __longlong_as_double(raw);
-    *id = __double2int_rz(d);
-    return (d == d) && static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
-  }
-}
-template <int DT>
-__device__ __forceinline__ float fm_decode_value(long long raw) {
-  if constexpr (DT == RBX_I32 || DT == RBX_I64) return static_cast<float>(raw);
-  else if constexpr (DT == RBX_F32) return __int_as_float(static_cast<int>(raw));
-  else return static_cast<float>(__longlong_as_double(raw));
-}
-
 template <int G, int NV, bool VEC, int DT>
 __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const int F, const long long B, const int D,
                                                            const bool has_emb, const bool has_lr,
@@ -180,11 +132,13 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
       for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-          const float t = e[u][i] * x[u];
-          s[i] += t;
-          q[i] += t * t;
+          // (explicitly rounded operations: the compiler may not contract them differently here and in rbx_fm_quad.hip,
+          // whose results are tested bit for bit against this kernel's)
+          const float t = mul_rn(e[u][i], x[u]);
+          s[i] = add_rn(s[i], t);
+          q[i] = fma_rn(t, t, q[i]);
         }
-        lr += l1[u] * x[u];
+        lr = fma_rn(l1[u], x[u], lr);
       }
     }
     // rows that were fetched elsewhere (row-sharded tables: the owners sent them back).  Without an index the
@@ -238,8 +192,8 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
     }
     float fm = 0.f;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) fm += (s[i] * s[i] - q[i]) * 0.5f;
-    float total = group_sum<G>(fm + lr);
+    for (int i = 0; i < NA; ++i) fm = fma_rn(fma_rn(s[i], s[i], -q[i]), 0.5f, fm);
+    float total = group_sum<G>(add_rn(fm, lr));
     if (lane_g == 0) {
       const float z = total + (bias != nullptr ? bias[0] : 0.f);
       logit[b] = z;
@@ -994,6 +948,11 @@ extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
                   extra_lr_off, need);
     if (d_extra_index != nullptr && extra_rows <= 0) return fail(RBX_ERR_INVALID, "fm: indexed extra rows need extra_rows > 0");
     if (h.vec && (extra_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(d_extra) & 15) != 0)) h.vec = false;
+  }
+  if (n_extra == 0 && h.vec) {          // every feature a column of one batch tensor, dim 16: rbx_fm_quad.hip
+    rc = fm_quad_fwd(h.pack, h.F, h.D, h.has_emb, h.has_lr, fm_fast_dtype() ? h.uniform_dt : -1, batch, d_lr_bias, d_logit,
+                     d_prob, d_sum, d_status, as_stream(stream));
+    if (rc != 1) return rc;
   }
   return h.vec ? dispatch_fm_fwd<true>(h, batch, d_lr_bias, d_extra, n_extra, extra_stride, extra_lr_off, d_extra_index,
                                        extra_rows, d_logit, d_prob, d_sum, d_status, as_stream(stream))

@@ -88,6 +88,18 @@ __device__ __forceinline__ float decode_value(long long raw, int dt) {
   }
 }
 
+// Individually rounded f32 operations the compiler may NOT contract into fused multiply-adds (HIP's __fmul_rn / __fadd_rn
+// are plain `*` / `+` and contract like any other): two kernels written with them perform the same roundings.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float fma_rn(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 template <int W>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -151,5 +163,59 @@ inline int pow2_ceil(int v) {
   while (p < v) p <<= 1;
   return p;
 }
+
+// ---- the fused FM forward's per-feature descriptor and id decoding (rbx_fm_fused.hip, rbx_fm_quad.hip) ----------------
+struct FmField {            // 48 B
+  const void* ids;
+  const float* emb;         // [V, D] table or numeric weight [D]; NULL when there is no second-order part
+  const float* lr;          // [V] (dim-1 table) or numeric weight [1]; NULL when there is no first-order part
+  long long stride_b;
+  int vocab;
+  unsigned char dtype, kind, r0, r1;
+  int emb_stride;           // floats between rows of emb / lr: D and 1 for contiguous tables; equal (e.g. 32) when both
+  int lr_stride;            // live in one packed [V, stride] storage -- then a lookup touches ONE 128-byte line
+};
+struct FmPack { FmField f[RBX_MAX_FIELDS]; };
+
+// Uniform-dtype fast path of the forward (DT = the one ids dtype every feature of the call has; -1 = mixed: the generic code).
+// The generic path converts a float64 id with static_cast<long long>(double) -- ~20 emulated instructions, there is no
+// 64-bit convert on gfx950 -- keeps ids in 64-bit registers and branches on the dtype of every feature; with 39 features per
+// sample the forward was bound by instruction issue, not by memory (every experiment on its memory side came out flat:
+// profiles/r02/sort_variants.txt).  Here: one v_cvt_i32_f64 (an id is < 2^31 once it passes the range check; NaN and
+// out-of-range values fail it exactly as in the generic path), 32-bit ids, no dtype switch.
+template <int DT>
+__device__ __forceinline__ long long fm_load_raw(const void* p, long long idx) {
+  if constexpr (DT == RBX_I64 || DT == RBX_F64) return static_cast<const long long*>(p)[idx];
+  else return static_cast<long long>(static_cast<const int*>(p)[idx]);
+}
+template <int DT>
+__device__ __forceinline__ bool fm_decode_id(long long raw, int vocab, int* id) {
+  if constexpr (DT == RBX_I32) {
+    *id = static_cast<int>(raw);
+    return static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
+  } else if constexpr (DT == RBX_I64) {
+    *id = static_cast<int>(raw);
+    return static_cast<unsigned long long>(raw) < static_cast<unsigned long long>(vocab);
+  } else if constexpr (DT == RBX_F32) {
+    const float f = __int_as_float(static_cast<int>(raw));
+    *id = __float2int_rz(f);                                // .long() truncates towards zero; saturates beyond int32
+    return (f == f) && static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
+  } else {
+    const double d = __longlong_as_double(raw);
+    *id = __double2int_rz(d);
+    return (d == d) && static_cast<unsigned>(*id) < static_cast<unsigned>(vocab);
+  }
+}
+template <int DT>
+__device__ __forceinline__ float fm_decode_value(long long raw) {
+  if constexpr (DT == RBX_I32 || DT == RBX_I64) return static_cast<float>(raw);
+  else if constexpr (DT == RBX_F32) return __int_as_float(static_cast<int>(raw));
+  else return static_cast<float>(__longlong_as_double(raw));
+}
+
+// rbx_fm_quad.hip: the forward for ids that are the columns of one batch tensor (dim 16).  RBX_OK = launched, 1 = not a
+// call of that shape (launch the general kernel), < 0 = error.
+int fm_quad_fwd(const FmPack& pack, int F, int D, bool has_emb, bool has_lr, int uniform_dt, long long B, const float* bias,
+                float* logit, float* prob, float* ssum, int* status, hipStream_t s);
 
 }  // namespace rbx

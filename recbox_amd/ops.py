@@ -460,6 +460,12 @@ def _check_status(status):
         raise IndexError("index out of range in self")
 
 
+def fm_quad_kernel(enable=None):
+    """rbx_fm_fwd's kernel for ids that are the columns of one batch tensor (csrc/rbx_fm_quad.hip): read (``None``) or set the
+    switch; returns the previous setting.  Off = the general kernel for every call (A/B measurements, tests)."""
+    return bool(lib.rbx_fm_quad(-1 if enable is None else int(bool(enable))))
+
+
 def check_deferred_ids():
     """Raise IndexError if any lookup since the last call met an id outside its table while ``config.check_ids`` was off
     (one device-to-host read per device; the words are cleared)."""

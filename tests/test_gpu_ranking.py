@@ -1504,3 +1504,107 @@ def test_tables_of_mixed_sizes_sort_in_their_own_number_of_passes():
             want.index_add_(0, ids[k], g)
             assert torch.equal(out[:, k * D:(k + 1) * D], m.weight.detach()[ids[k]])
         assert (m.weight.grad.double() - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item()), t
+
+
+# ---- round 5: rbx_fm_fwd's kernel for ids that are the columns of one batch tensor (csrc/rbx_fm_quad.hip) ----------------
+def _flat_fm_case(n_num, vocabs, B, seed, dtype=torch.float64, integer_values=False):
+    """An FM over ``n_num`` numeric + len(vocabs) categorical features and the flat [B, F + 1] batch tensor the reference's
+    loader would deliver for it (h5_dataloader.py:36-47), label in the last column."""
+    from recbox_amd.ranking.features import FeatureMap
+    from recbox_amd.ranking.pytorch.models import FM
+    g = torch.Generator().manual_seed(seed)
+    fm = FeatureMap("t", "/tmp")
+    fm.features = OrderedDict()
+    for i in range(n_num):
+        fm.features["I%d" % (i + 1)] = {"source": "", "type": "numeric"}
+    for i, v in enumerate(vocabs):
+        fm.features["C%d" % (i + 1)] = {"source": "", "type": "categorical", "vocab_size": v + 1, "padding_idx": 0}
+    fm.labels, fm.num_fields = ["y"], n_num + len(vocabs)
+    fm.set_column_index()
+    cols = []
+    for i in range(n_num):
+        x = torch.rand(B, generator=g, dtype=torch.float64)
+        cols.append(torch.floor(x * 7) if integer_values else x)
+    for v in vocabs:
+        cols.append(torch.randint(0, v + 1, (B,), generator=g).double())
+    cols.append((torch.rand(B, generator=g) < 0.25).double())
+    batch = torch.stack(cols, dim=1).to(dtype).cuda()
+    model = FM(fm, 16).cuda()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * 0.1).cuda())
+    return fm, model, batch
+
+
+@pytest.mark.parametrize("n_num,n_cat,B,dtype", [
+    (13, 26, 65536, torch.float64), (13, 26, 1000, torch.float32), (13, 26, 5, torch.int64), (13, 26, 257, torch.int32),
+    (0, 1, 1, torch.float64), (3, 9, 333, torch.float64), (2, 62, 4097, torch.float64), (0, 4, 64, torch.int32),
+    (5, 8, 100, torch.float64), (16, 0, 77, torch.float32), (1, 15, 63, torch.int64)])
+def test_fm_quad_forward_equals_the_general_kernel(n_num, n_cat, B, dtype):
+    """rbx_fm_fwd on a flat batch tensor (dim 16) runs fm_quad_fwd_kernel (lane group of 4 per sample, the owner lane decodes
+    its columns, DPP quad broadcast of the row offsets); it performs the general kernel's floating-point operations in the
+    same order: logits, sigmoid outputs, the kept sums S (through the gradients) are BIT-identical with the path forced back
+    (rbx_fm_quad(0)), for every id dtype, feature counts 1 .. 64 and batch sizes off the tile size."""
+    from recbox_amd._lib import lib
+    from recbox_amd.ranking.pytorch.models import inputs_from_batch
+    vocabs = (CRITEO_SMALL_VOCABS * 3)[:n_cat]
+    integer = dtype in (torch.int32, torch.int64)
+    fm, model, batch = _flat_fm_case(n_num, vocabs, B, seed=B + n_cat, dtype=dtype, integer_values=integer)
+    y = batch[:, -1:].float()
+    was = lib.rbx_fm_quad(-1)
+    res = []
+    try:
+        for on in (1, 0):
+            lib.rbx_fm_quad(on)
+            model.zero_grad(set_to_none=True)
+            logit = model.logits(inputs_from_batch(fm, batch))
+            out = model(batch)["y_pred"]
+            loss = torch.nn.functional.binary_cross_entropy(torch.sigmoid(logit), y, reduction="sum")
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append([logit.detach().clone(), out.detach().clone()] + [p.grad.clone() for p in model.parameters()])
+    finally:
+        lib.rbx_fm_quad(was)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # and against the float64 restatement of the model on the same inputs
+    from oracle import torch_ref as R
+    ref = R.RefFMModel(fm, 16)
+    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    X = OrderedDict((k, v.double().cpu()) for k, v in inputs_from_batch(fm, batch).items() if k != "y")
+    assert_close(res[0][0], ref(X), TOL, "quad logit vs oracle")
+
+
+def test_fm_quad_out_of_range_ids_read_as_zero_rows_and_raise():
+    """An id outside its table (too large, negative, NaN) reads as a zero row in both kernels and sets the status word
+    (ops.config.check_ids turns it into the reference's IndexError); with the check off the logits agree bit for bit."""
+    from recbox_amd import ops
+    from recbox_amd._lib import lib
+    from recbox_amd.ranking.pytorch.models import inputs_from_batch
+    fm, model, batch = _flat_fm_case(2, [5, 9, 1000], 130, seed=9)
+    bad = batch.clone()
+    bad[3, 2] = 6.0          # C1 has 6 rows (0..5)
+    bad[64, 3] = -1.0
+    bad[129, 4] = float("nan")
+    was, chk = lib.rbx_fm_quad(-1), ops.config.check_ids
+    try:
+        outs = []
+        for on in (1, 0):
+            lib.rbx_fm_quad(on)
+            ops.config.check_ids = True
+            with pytest.raises(IndexError):
+                model.logits(inputs_from_batch(fm, bad))
+                torch.cuda.synchronize()
+            ops.config.check_ids = False
+            with torch.no_grad():
+                outs.append(model.logits(inputs_from_batch(fm, bad)).clone())
+            with pytest.raises(IndexError):
+                ops.check_deferred_ids()                 # reported late when the check is off
+        assert torch.equal(outs[0], outs[1])
+        good = outs[0][torch.tensor([i for i in range(130) if i not in (3, 64, 129)]).cuda()]
+        with torch.no_grad():
+            ref = model.logits(inputs_from_batch(fm, batch))[torch.tensor([i for i in range(130) if i not in (3, 64, 129)]).cuda()]
+        assert torch.equal(good, ref)
+    finally:
+        lib.rbx_fm_quad(was)
+        ops.config.check_ids = chk
