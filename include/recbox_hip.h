@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 120          /* 0.1.20: rbx_fm_quad (rbx_fm_fwd's kernel for ids that are columns of one batch tensor); 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 121          /* 0.1.21: rbx_prelu_* / rbx_dropout / rbx_dice_* (csrc/rbx_act.hip); 0.1.20: rbx_fm_quad (rbx_fm_fwd's kernel for ids that are columns of one batch tensor); 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -466,6 +466,32 @@ int rbx_batchnorm_bwd_reduce(const float* d_x, const float* d_dy, const float* d
 int rbx_batchnorm_bwd_dx(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
                          const float* d_gamma, const float* d_mean, const float* d_rstd, const float* d_dgamma,
                          const float* d_dbeta, int64_t total_rows, float* d_dx, void* stream);
+
+/* ---- the towers' activations that are not fused into a GEMM epilogue or a BatchNorm pass (csrc/rbx_act.hip; round 5).
+ * x, y, dy, dx: [rows, cols] row-major f32.  rbx_act_workspace_size: bytes for the column reductions of the calls that take a
+ * workspace (partials per block of 256 rows, merged in block order: results repeat bit for bit).
+ * nn.PReLU standing alone (core/pytorch/layers/mlp.py:25-37, ranking/pytorch/layers/blocks/mlp_block.py:42-58 with
+ *   hidden_activations="PReLU" and no BatchNorm in front): n_slope = 1 or cols; backward dx = dy (x > 0 ? 1 : a) and
+ *   d_dslope[n_slope] = sum dy x [x <= 0] (NULL skips either).
+ * nn.Dropout(p), training (the same towers' dropout_rates, third_party/rechub/basic/layers.py:255-263): y = x keep / (1 - p)
+ *   with keep(i) a counter-based function of (seed + *d_seed_add, i) (Philox4x32-10) -- the SAME call on dy is the backward,
+ *   nothing is stored; not torch's random stream: equal in distribution to the reference, not bit for bit.
+ * Dice (core/pytorch/layers/activations.py:23-33): p = sigmoid((x - mean) rstd) with the statistics of a non-affine
+ *   BatchNorm1d (training: batch statistics, biased variance, running statistics updated with `momentum` when given;
+ *   evaluation: the running statistics), y = p x + alpha (1 - p) x, alpha [cols].  d_mean / d_rstd [cols] are outputs kept for
+ *   the backward, which returns dx (through the statistics too, in training) and d_dalpha[cols] (NULL skips either). */
+size_t rbx_act_workspace_size(int64_t rows, int32_t cols);
+int rbx_prelu_fwd(const float* d_x, int64_t rows, int32_t cols, const float* d_slope, int32_t n_slope, float* d_y,
+                  void* stream);
+int rbx_prelu_bwd(const float* d_x, const float* d_dy, int64_t rows, int32_t cols, const float* d_slope, int32_t n_slope,
+                  float* d_dx, float* d_dslope, void* d_workspace, size_t workspace_bytes, void* stream);
+int rbx_dropout(const float* d_x, int64_t n, float p, uint64_t seed, const uint64_t* d_seed_add, float* d_y, void* stream);
+int rbx_dice_fwd(const float* d_x, int64_t rows, int32_t cols, const float* d_alpha, float eps, int32_t training,
+                 float momentum, float* d_running_mean, float* d_running_var, float* d_mean, float* d_rstd, float* d_y,
+                 void* d_workspace, size_t workspace_bytes, void* stream);
+int rbx_dice_bwd(const float* d_x, const float* d_dy, int64_t rows, int32_t cols, const float* d_alpha, const float* d_mean,
+                 const float* d_rstd, int32_t training, float* d_dx, float* d_dalpha, void* d_workspace,
+                 size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm over the last dimension (the five nn.LayerNorm(D, eps=1e-8) of a SASRec block stack,
  * third_party/rechub/models/matching/sasrec.py:52-63,81-94).  x [rows, dim] contiguous; biased variance, eps inside

@@ -3,17 +3,20 @@
 their compute with the fp32-MFMA GEMM of ``rbx_linear_fwd/bwd`` and fuses a following
 ReLU into the GEMM epilogue; nn.BatchNorm1d on 2-D activations runs through
 ``rbx_batchnorm_fwd/bwd`` (a following ReLU or PReLU fused in; nn.SyncBatchNorm modules
-normalise over all ranks).  Dropout with p = 0 launches nothing; other activations are
-elementwise ATen kernels and run as the modules they are.
+normalise over all ranks).  nn.PReLU standing alone, nn.Dropout in training mode and Dice run
+``rbx_prelu_*`` / ``rbx_dropout`` / ``rbx_dice_*`` (csrc/rbx_act.hip); Dropout with p = 0 or in
+evaluation launches nothing; Sigmoid / Tanh / Softmax heads are elementwise ATen kernels.
 """
 from torch import nn
 
 from . import ops
 
 
-def activation_by_name(name):
-    """'ReLU' / 'relu' / nn.Module -> module (as recbox.utils.torch_utils.set_activation
-    and fuxictr.pytorch.torch_utils.get_activation do)."""
+def activation_by_name(name, width=None):
+    """'ReLU' / 'relu' / nn.Module -> module.  ``width`` None: recbox.utils.torch_utils.set_activation (utils/torch_utils.py:
+    74-85: relu / sigmoid / tanh by any case, every other name ``getattr(nn, name)()``).  ``width`` = the layer's units:
+    fuxictr's get_activation (ranking/pytorch/torch_utils.py:85-110; 0 = called without units), which also knows "softmax" (dim -1), "prelu" -- ONE SLOPE
+    PER UNIT, nn.PReLU(units, init=0.1) -- and "dice" (Dice(units))."""
     if name is None or isinstance(name, nn.Module):
         return name
     if isinstance(name, str):
@@ -24,10 +27,15 @@ def activation_by_name(name):
             return nn.Sigmoid()
         if low == "tanh":
             return nn.Tanh()
-        if low == "softmax":
-            return nn.Softmax(dim=-1)
-        if low == "prelu":
-            return nn.PReLU()
+        if width is not None:                     # (0 = fuxictr's flavour without units: an output activation)
+            if low == "softmax":
+                return nn.Softmax(dim=-1)
+            if low in ("prelu", "dice"):
+                assert width > 0, "activation=%s needs the layer's units (get_activation(activation, hidden_units))" % name
+                if low == "prelu":
+                    return nn.PReLU(int(width), init=0.1)
+                from .ranking.pytorch.layers.attentions import Dice
+                return Dice(int(width))
         if low in ("none", ""):
             return None
         return getattr(nn, name)()
@@ -40,7 +48,7 @@ def _broadcast(value, n):
 
 
 def tower_modules(in_dim, widths, activations, dropouts, batch_norm, bias, out_dim=None, out_activation=None,
-                  norm_after_activation=False):
+                  norm_after_activation=False, width_aware=False):
     """The children of a tower's ``nn.Sequential`` in the order the reference registers them (so ``mlp.<i>.weight``
     checkpoint keys line up): per hidden layer Linear, [BatchNorm1d], [activation], [BatchNorm1d when it comes after
     the activation], [Dropout]; then the optional output Linear and output activation."""
@@ -58,7 +66,7 @@ def tower_modules(in_dim, widths, activations, dropouts, batch_norm, bias, out_d
         fan_in = width
         if batch_norm and not norm_after_activation:
             yield nn.BatchNorm1d(width)
-        module = activation_by_name(act)
+        module = activation_by_name(act, width if width_aware else None)
         if module:
             yield module
         if batch_norm and norm_after_activation:
@@ -68,7 +76,7 @@ def tower_modules(in_dim, widths, activations, dropouts, batch_norm, bias, out_d
     if out_dim is not None:
         yield nn.Linear(fan_in, out_dim, bias=bias)
     if out_activation is not None:
-        yield activation_by_name(out_activation)
+        yield activation_by_name(out_activation, 0 if width_aware else None)
 
 
 def run_sequential(seq, x):
@@ -95,7 +103,13 @@ def run_sequential(seq, x):
             prelu = nxt if (type(nxt) is nn.PReLU and nxt.weight.numel() in (1, x.shape[1])) else None
             x = ops.batch_norm(x, m, relu=fuse, prelu=prelu)
             i += 2 if (fuse or prelu is not None) else 1
+        elif type(m) is nn.PReLU:                 # standing alone (behind a BatchNorm1d it rode in the BatchNorm's passes)
+            x = ops.prelu(x, m)
+            i += 1
+        elif type(m) is nn.Dropout:
+            x = ops.dropout(x, m.p, m.training) if x.is_cuda else m(x)
+            i += 1
         else:
-            x = m(x)
+            x = m(x)                              # Dice modules route themselves (ops.dice); Sigmoid / Tanh / ...: ATen
             i += 1
     return x

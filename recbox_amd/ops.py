@@ -2203,6 +2203,125 @@ def batch_norm(x, module, relu=False, prelu=None):
                             relu)
 
 
+class _PReLU(torch.autograd.Function):
+    """nn.PReLU on [rows, cols] (one slope, or one per column) through rbx_prelu_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        _require_cuda(x, "x")
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        rows, cols = x2.shape
+        sl = slope.detach().contiguous().float()
+        y = torch.empty_like(x2)
+        check(lib.rbx_prelu_fwd(_ptr(x2), rows, cols, _ptr(sl), sl.numel(), _ptr(y), _stream()))
+        ctx.save_for_backward(x2, sl)
+        ctx.shape = shape
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, sl = ctx.saved_tensors
+        rows, cols = x2.shape
+        dy2 = dy.reshape(rows, cols).contiguous().float()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        ds = torch.empty(sl.numel(), dtype=torch.float32, device=x2.device) if ctx.needs_input_grad[1] else None
+        ws_bytes = lib.rbx_act_workspace_size(rows, cols) if ds is not None else 0
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x2.device)
+        check(lib.rbx_prelu_bwd(_ptr(x2), _ptr(dy2), rows, cols, _ptr(sl), sl.numel(), _ptr(dx), _ptr(ds), _ptr(ws), ws_bytes,
+                                _stream()))
+        return (dx.view(ctx.shape) if dx is not None else None), ds
+
+
+def prelu(x, module):
+    """``module(x)`` for an nn.PReLU that stands alone (behind a BatchNorm1d it rides in ``batch_norm``): one slope for any
+    shape, or one per column of a 2-D input (torch applies ``num_parameters`` > 1 along dim 1)."""
+    n = module.weight.numel()
+    if x.is_cuda and x.numel() > 0 and (n == 1 or (x.dim() == 2 and n == x.shape[1])):
+        return _PReLU.apply(x, module.weight)
+    return module(x)
+
+
+class _Dropout(torch.autograd.Function):
+    """y = x keep / (1 - p); the backward applies the same counter-based mask to dy (rbx_dropout): nothing is stored."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _require_cuda(x, "x")
+        x2 = x.contiguous().float()
+        y = torch.empty_like(x2)
+        tick = dropout_tick(x.device)
+        check(lib.rbx_dropout(_ptr(x2), x2.numel(), float(p), int(seed), _ptr(tick), _ptr(y), _stream()))
+        ctx.meta = (float(p), int(seed), tick)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, tick = ctx.meta
+        dy2 = dy.contiguous().float()
+        dx = torch.empty_like(dy2)
+        check(lib.rbx_dropout(_ptr(dy2), dy2.numel(), p, seed, _ptr(tick), _ptr(dx), _stream()))
+        return dx, None, None
+
+
+def dropout(x, p, training=True, seed=None):
+    """F.dropout(x, p, training) of a tower (nn.Dropout modules stay the reference's): evaluation or p = 0 launches nothing.
+    The mask comes from Philox keyed by ``seed`` (default: 64 bits of torch's default CPU generator, so ``torch.manual_seed``
+    reproduces it) -- the reference's distribution, not torch's random stream."""
+    if not training or not p or x.numel() == 0:
+        return x
+    if p >= 1.0:
+        return x * 0.0
+    return _Dropout.apply(x, float(p), _draw_seed() if seed is None else int(seed))
+
+
+class _Dice(torch.autograd.Function):
+    """Dice (core/pytorch/layers/activations.py:23-33) on [rows, cols] through rbx_dice_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, stats, training, momentum, eps):
+        _require_cuda(x, "x")
+        x2 = x.contiguous().float()
+        rows, cols = x2.shape
+        dev = x.device
+        y = torch.empty_like(x2)
+        mean = torch.empty(cols, dtype=torch.float32, device=dev)
+        rstd = torch.empty(cols, dtype=torch.float32, device=dev)
+        ws_bytes = lib.rbx_act_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        al = alpha.detach().contiguous().float()
+        check(lib.rbx_dice_fwd(_ptr(x2), rows, cols, _ptr(al), eps, 1 if training else 0, momentum, _ptr(stats.running_mean),
+                               _ptr(stats.running_var), _ptr(mean), _ptr(rstd), _ptr(y), _ptr(ws), ws_bytes, _stream()))
+        ctx.save_for_backward(x2, al, mean, rstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, al, mean, rstd = ctx.saved_tensors
+        rows, cols = x2.shape
+        dy2 = dy.contiguous().float()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        da = torch.empty(cols, dtype=torch.float32, device=x2.device) if ctx.needs_input_grad[1] else None
+        ws_bytes = lib.rbx_act_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x2.device)
+        check(lib.rbx_dice_bwd(_ptr(x2), _ptr(dy2), rows, cols, _ptr(al), _ptr(mean), _ptr(rstd), 1 if ctx.training else 0,
+                               _ptr(dx), _ptr(da), _ptr(ws), ws_bytes, _stream()))
+        return dx, da, None, None, None, None
+
+
+def dice(x, bn, alpha):
+    """Dice over a 2-D input: ``bn`` the module's non-affine nn.BatchNorm1d (its running statistics and counters are kept as
+    torch keeps them), ``alpha`` its per-column parameter."""
+    training = bn.training or bn.running_mean is None
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    return _Dice.apply(x, alpha, _BnStats(bn), training, float(momentum), float(bn.eps))
+
+
 class _BnStats(object):
     """The running-statistics buffers of a BatchNorm module, handed to the autograd Function as a plain object
     (they are updated in place and take no part in differentiation)."""

@@ -77,7 +77,8 @@ class MultiHeadTargetAttention(nn.Module):
 
 class Dice(nn.Module):
     """DIN's data-adaptive activation (activations.py:23-32): p = sigmoid(BN(x)) with a non-affine BatchNorm
-    (eps 1e-9, momentum 0.01), y = p x + alpha (1 - p) x.  The BatchNorm runs on rbx_batchnorm_fwd/bwd."""
+    (eps 1e-9, momentum 0.01), y = p x + alpha (1 - p) x: rbx_dice_fwd/bwd on 2-D GPU input (statistics, gate and both
+    gradients in the library's passes), the reference's composition elsewhere."""
 
     def __init__(self, input_dim, eps=1e-9):
         super(Dice, self).__init__()
@@ -85,7 +86,9 @@ class Dice(nn.Module):
         self.alpha = nn.Parameter(torch.zeros(input_dim))
 
     def forward(self, X):
-        p = torch.sigmoid(ops.batch_norm(X, self.bn) if X.dim() == 2 else self.bn(X))
+        if X.dim() == 2 and X.is_cuda and X.shape[0] > 0:
+            return ops.dice(X, self.bn, self.alpha)
+        p = torch.sigmoid(self.bn(X))
         return p * X + self.alpha * (1 - p) * X
 
 

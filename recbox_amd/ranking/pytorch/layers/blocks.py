@@ -54,7 +54,8 @@ class MLP_Block(nn.Module):
         self.mlp = nn.Sequential(*dense.tower_modules(input_dim, hidden_units, hidden_activations, dropout_rates,
                                                       batch_norm, use_bias, out_dim=output_dim,
                                                       out_activation=output_activation,
-                                                      norm_after_activation=not norm_before_activation))
+                                                      norm_after_activation=not norm_before_activation,
+                                                      width_aware=True))
 
     def forward(self, inputs):
         return dense.run_sequential(self.mlp, inputs)
