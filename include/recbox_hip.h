@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 121          /* 0.1.21: rbx_prelu_* / rbx_dropout / rbx_dice_* (csrc/rbx_act.hip); 0.1.20: rbx_fm_quad (rbx_fm_fwd's kernel for ids that are columns of one batch tensor); 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 122          /* 0.1.22: rbx_cin_outer_*; 0.1.21: rbx_prelu_* / rbx_dropout / rbx_dice_* (csrc/rbx_act.hip); 0.1.20: rbx_fm_quad (rbx_fm_fwd's kernel for ids that are columns of one batch tensor); 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -466,6 +466,16 @@ int rbx_batchnorm_bwd_reduce(const float* d_x, const float* d_dy, const float* d
 int rbx_batchnorm_bwd_dx(const float* d_x, const float* d_dy, const float* d_y_relu, int64_t rows, int32_t cols,
                          const float* d_gamma, const float* d_mean, const float* d_rstd, const float* d_dgamma,
                          const float* d_dbeta, int64_t total_rows, float* d_dx, void* stream);
+
+/* ---- xDeepFM's CIN outer product (ranking/pytorch/layers/interactions/compressed_interaction_net.py:35-48; csrc/rbx_cin.hip):
+ * d_z[(b, d), h * m + j] = x0[b, h, d] * xk[(b, d), j], rows = batch * dim, in the A layout of the GEMM that runs the 1x1
+ * Conv1d over the channel axis.  d_x0 [batch, n_fields, dim] (the embedding layer's output as it is); d_xk [batch * dim, m]
+ * (the previous layer's GEMM output as it is) or NULL for the first layer (X_k = X_0, m == n_fields).  Backward: d_dx0
+ * [batch, n_fields, dim] (both uses of X_0 when d_xk is NULL) and d_dxk [batch * dim, m]; NULL skips either. */
+int rbx_cin_outer_fwd(const float* d_x0, const float* d_xk, int64_t batch, int32_t n_fields, int32_t m, int32_t dim,
+                      float* d_z, void* stream);
+int rbx_cin_outer_bwd(const float* d_x0, const float* d_xk, const float* d_dz, int64_t batch, int32_t n_fields, int32_t m,
+                      int32_t dim, float* d_dx0, float* d_dxk, void* stream);
 
 /* ---- the towers' activations that are not fused into a GEMM epilogue or a BatchNorm pass (csrc/rbx_act.hip; round 5).
  * x, y, dy, dx: [rows, cols] row-major f32.  rbx_act_workspace_size: bytes for the column reductions of the calls that take a

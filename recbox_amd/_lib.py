@@ -133,6 +133,8 @@ SIGNATURES = {
     "rbx_batchnorm_apply": (ctypes.c_int, [_P, _i64, _i32, _P, _P, _P, _P, _i32, _P, _P]),
     "rbx_batchnorm_bwd_reduce": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_batchnorm_bwd_dx": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _P, _P, _P, _P, _P, _i64, _P, _P]),
+    "rbx_cin_outer_fwd": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _i32, _P, _P]),
+    "rbx_cin_outer_bwd": (ctypes.c_int, [_P, _P, _P, _i64, _i32, _i32, _i32, _P, _P, _P]),
     "rbx_act_workspace_size": (_sz, [_i64, _i32]),
     "rbx_prelu_fwd": (ctypes.c_int, [_P, _i64, _i32, _P, _i32, _P, _P]),
     "rbx_prelu_bwd": (ctypes.c_int, [_P, _P, _i64, _i32, _P, _i32, _P, _P, _P, _sz, _P]),

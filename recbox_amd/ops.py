@@ -2203,6 +2203,42 @@ def batch_norm(x, module, relu=False, prelu=None):
                             relu)
 
 
+class _CinOuter(torch.autograd.Function):
+    """z[(b, d), h M + m] = x0[b, h, d] xk[(b, d), m] (rbx_cin_outer_fwd/bwd); ``xk`` None = the first layer (X_k = X_0)."""
+
+    @staticmethod
+    def forward(ctx, x0, xk):
+        _require_cuda(x0, "x0")
+        x0 = x0.contiguous().float()
+        B, F, D = x0.shape
+        own = xk is None
+        if not own:
+            xk = xk.contiguous().float()
+        M = F if own else xk.shape[1]
+        z = torch.empty((B * D, F * M), dtype=torch.float32, device=x0.device)
+        check(lib.rbx_cin_outer_fwd(_ptr(x0), _ptr(xk), B, F, M, D, _ptr(z), _stream()))
+        ctx.save_for_backward(x0, xk if not own else x0)
+        ctx.own, ctx.M = own, M
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x0, xk = ctx.saved_tensors
+        B, F, D = x0.shape
+        dz = dz.contiguous().float()
+        dx0 = torch.empty_like(x0) if ctx.needs_input_grad[0] else None
+        dxk = torch.empty((B * D, ctx.M), dtype=torch.float32, device=x0.device) \
+            if (not ctx.own and ctx.needs_input_grad[1]) else None
+        check(lib.rbx_cin_outer_bwd(_ptr(x0), None if ctx.own else _ptr(xk), _ptr(dz), B, F, ctx.M, D, _ptr(dx0), _ptr(dxk),
+                                    _stream()))
+        return dx0, dxk
+
+
+def cin_outer(x0, xk=None):
+    """The outer-product tensor of a CIN layer in the layout of the GEMM that follows (csrc/rbx_cin.hip)."""
+    return _CinOuter.apply(x0, xk)
+
+
 class _PReLU(torch.autograd.Function):
     """nn.PReLU on [rows, cols] (one slope, or one per column) through rbx_prelu_fwd/bwd."""
 

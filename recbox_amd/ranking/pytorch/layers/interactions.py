@@ -179,9 +179,9 @@ class CompressedInteractionNet(nn.Module):
 
     Layer k: Z[b, (h, m), d] = X_0[b, h, d] * X_k[b, m, d], X_{k+1}[b, o, d] = sum_c W[o, c] Z[b, c, d] + bias[o].  The 1x1
     convolution is a GEMM over the channel axis for every (b, d): it runs as ONE fp32-MFMA product
-    [B*D, F*H_k] x [F*H_k, H_{k+1}] (rbx_linear_fwd) on the outer-product tensor laid out with d next to b.  The outer
-    product itself is still materialised (an element-wise ATen kernel), as in the reference -- generating its tiles in LDS
-    inside the GEMM is the next step for this layer."""
+    [B*D, F*H_k] x [F*H_k, H_{k+1}] (rbx_linear_fwd) on the outer-product tensor laid out with d next to b, which
+    rbx_cin_outer_fwd/bwd (csrc/rbx_cin.hip) writes straight from the embedding layer's [B, F, D] block and the previous
+    layer's GEMM output -- materialised once, as in the reference, but with no transposes, broadcasts or reshapes of its own."""
 
     def __init__(self, num_fields, cin_hidden_units, output_dim=1):
         super(CompressedInteractionNet, self).__init__()
@@ -195,13 +195,19 @@ class CompressedInteractionNet(nn.Module):
 
     def forward(self, feature_emb):
         B, F, D = feature_emb.shape
+        hip = feature_emb.is_cuda and B > 0
         x0 = feature_emb.transpose(1, 2)                        # [B, D, F]: the GEMM wants channels last
         xk = x0
+        flat = None                                             # the previous layer's GEMM output as it is: [(b, d), H_k]
         pooled = []
         for k in range(len(self.cin_hidden_units)):
             conv = self.cin_layer["layer_" + str(k + 1)]
-            z = (x0.unsqueeze(3) * xk.unsqueeze(2)).reshape(B * D, F * xk.shape[2])      # [(b, d), (h, m)]
-            xk = ops.linear(z, conv.weight.squeeze(-1), conv.bias).view(B, D, -1)        # [B, D, H_{k+1}]
+            if hip:
+                z = ops.cin_outer(feature_emb, flat)                                         # [(b, d), (h, m)]
+            else:
+                z = (x0.unsqueeze(3) * xk.unsqueeze(2)).reshape(B * D, F * xk.shape[2])
+            flat = ops.linear(z, conv.weight.squeeze(-1), conv.bias)
+            xk = flat.view(B, D, -1)                                                      # [B, D, H_{k+1}]
             pooled.append(xk.sum(dim=1))                                                  # sum over d -> [B, H_{k+1}]
         return ops.linear(torch.cat(pooled, dim=-1), self.fc.weight, self.fc.bias)
 

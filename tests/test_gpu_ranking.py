@@ -1608,3 +1608,27 @@ def test_fm_quad_out_of_range_ids_read_as_zero_rows_and_raise():
     finally:
         lib.rbx_fm_quad(was)
         ops.config.check_ids = chk
+
+
+@pytest.mark.parametrize("B,F,D,M", [(1, 2, 4, None), (33, 5, 8, None), (33, 5, 8, 7), (257, 39, 16, None), (64, 39, 16, 24)])
+def test_cin_outer_product_kernel_vs_the_einsum(B, F, D, M):
+    """rbx_cin_outer_fwd/bwd against compressed_interaction_net.py:41-43 (einsum + view), laid out for the channel GEMM:
+    z[(b, d), h M + m]; M None = the first layer (X_k = X_0: both uses of X_0 receive gradient)."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(B + F)
+    x0 = torch.randn(B, F, D, generator=g, dtype=torch.float64)
+    xk = None if M is None else torch.randn(B * D, M, generator=g, dtype=torch.float64)
+    R = torch.randn(B * D, F * (M or F), generator=g, dtype=torch.float64)
+    a = x0.clone().requires_grad_()
+    k = None if xk is None else xk.clone().requires_grad_()
+    kk = a if k is None else k.view(B, D, -1).transpose(1, 2)                  # [B, M, D]
+    want = torch.einsum("bhd,bmd->bhmd", a, kk).reshape(B, -1, D).transpose(1, 2).reshape(B * D, -1)
+    (want * R).sum().backward()
+    ad = x0.float().cuda().requires_grad_()
+    kd = None if xk is None else xk.float().cuda().requires_grad_()
+    z = ops.cin_outer(ad, kd)
+    assert_close(z, want.float(), 1e-5, "z")
+    (z * R.float().cuda()).sum().backward()
+    assert_close(ad.grad, a.grad.float(), 1e-4, "dx0")
+    if kd is not None:
+        assert_close(kd.grad, k.grad.float(), 1e-4, "dxk")
