@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 122          /* 0.1.22: rbx_cin_outer_*; 0.1.21: rbx_prelu_* / rbx_dropout / rbx_dice_* (csrc/rbx_act.hip); 0.1.20: rbx_fm_quad (rbx_fm_fwd's kernel for ids that are columns of one batch tensor); 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 123          /* 0.1.23: rbx_fm_tier_c / rbx_fm_rezero_fusable, rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials removed (variants that lost their A/B); 0.1.22: rbx_cin_outer_*; 0.1.21: rbx_prelu_* / rbx_dropout / rbx_dice_* (csrc/rbx_act.hip); 0.1.20: rbx_fm_quad (rbx_fm_fwd's kernel for ids that are columns of one batch tensor); 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -285,17 +285,8 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
  * shape, of which a batch touches 36 MB): with the workspace of the PREVIOUS rbx_fm_sort (same fields, same batch)
  * and emb[i].grad / lr[i].grad = the buffers that step's rbx_fm_bwd stored into, write zeros to exactly the rows it
  * touched.  Call it before the next rbx_fm_sort reuses the workspace. */
-/* Round 4: the fused FM backward has a third tier (csrc/rbx_tierc.h): a table of ONE one-id-per-sample field that is too
- * large for tier A (rows > 4096, < 2^21, dim a multiple of 4 up to 64) is reduced WITHOUT a global sort -- a workgroup per
- * (table, hash partition) scans the compact id column, sorts its ~1024 pairs in LDS and writes its rows; rbx_fm_rezero
- * clears the rows named by the bucket arrays of the partition pass.  Same gradients as the sorted path up to summation
- * order, bit-identical from run to run.  OFF by default (RBX_FM_TIER_C=1 / rbx_fm_tier_c(1) switch it on): measured at
- * the Criteo shape it is a draw -- 12 kernels per step instead of 23, the same random-line traffic, a slower forward
- * kernel beside its partition pass (csrc/rbx_fm_fused.hip, profiles/r04/INDEX.md).  rbx_fm_tier_c(0) switches the tier
- * off (the sparse-row updates walk sorted ids and refuse a call with tier C tables), a negative value only reads;
- * returns the previous setting.
- * Change it between steps only: rbx_fm_sort / _bwd / _rezero of one step must see the same setting. */
-int rbx_fm_tier_c(int32_t enable);
+/* (Round 4's sort-free third tier -- rbx_fm_tier_c, rbx_fm_rezero_fusable, rbx_fm_sort_phases bit 3 -- measured a draw on uniform
+ * ids and a loss on skewed ones in two rounds running and was removed in round 5: docs/history/.) */
 /* Round 5: rbx_fm_fwd has a second kernel (csrc/rbx_fm_quad.hip) for the wire format of the reference's ranking loader --
  * every feature's ids / values the columns, in feature order, of ONE row-major batch tensor of one dtype
  * (ranking/pytorch/dataloaders/h5_dataloader.py:36-47, ranking_model.py:106-116), dim 16, both field arrays given, the
@@ -303,12 +294,6 @@ int rbx_fm_tier_c(int32_t enable);
  * automatically; rbx_fm_quad(0) forces the general kernel (A/B measurements, tests), a negative value only reads; returns
  * the previous setting (RBX_FM_QUAD=0 in the environment: off from the start). */
 int rbx_fm_quad(int32_t enable);
-/* With persistent gradient buffers the rows a backward stored have to be cleared before the next one (rbx_fm_rezero).  When
- * every sorted table of the call is on tier C (returns 1) the partition pass of the NEXT step can do it while it overwrites
- * the bucket arrays that name those rows: pass phases | 8 to rbx_fm_sort_phases INSTEAD of calling rbx_fm_rezero -- same
- * batch size, same workspace, and a backward has run on it since the last clear.  The re-zero launch then leaves the
- * step's critical path (it ran in front of the forward kernel; the pass runs beside it). */
-int rbx_fm_rezero_fusable(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch);
 int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                   void* d_workspace, size_t workspace_bytes, void* stream);
 /* Two lookups over the SAME id tensors with the same table layout (the embedding tables of FeatureEmbedding and the dim-1
@@ -713,27 +698,6 @@ int rbx_linear_dx_deepfm(const float* d_dy, int64_t dy_stride, const float* d_w,
  *                   weight pointer is d_w (shape [rows, cols]) runs on the planes; rbx_split_unregister(d_w) ends that (the
  *                   planes must stay valid until the GEMMs issued in between have run).  Host-side table, 256 slots,
  *                   thread-safe; RBX_GEMM_BX6=0 in the environment ignores every registration. */
-/* BatchNorm statistics out of the GEMMs around a BatchNorm (rechub's towers: Linear -> BatchNorm1d -> act,
- * third_party/rechub/basic/layers.py:250-266).  Both calls need d_w's planes registered (above) and m >= 512; otherwise they
- * return RBX_ERR_UNSUPPORTED without launching and the caller takes the separate passes (rbx_linear_fwd + rbx_batchnorm_fwd ...).
- *   rbx_linear_fwd_bnstats: y = x W^T + b and d_partial[(block, col)][3] = (n, mean, M2) of y over the rows of 64-row block
- *       `block` (ceil(m / 64) blocks); then rbx_batchnorm_stats_from_partials (mean / rstd / running statistics) and
- *       rbx_batchnorm_apply: two BatchNorm launches instead of three, y is not read for its statistics.
- *   rbx_linear_dx_bnsums: dx = (dy W) o [a > 0] where a [m, k] is the ReLU output of a training-mode BatchNorm over d_bn_x
- *       (its input) with d_bn_mean / d_bn_rstd and affine d_bn_gamma / d_bn_beta (NULL = 1 / 0; xhat of an unmasked element is
- *       rebuilt from a, which the epilogue reads as the mask), and d_partial[(block, col)][2] = (sum dx, sum dx xhat); then
- *       rbx_batchnorm_bwd_sums_from_partials (d_dgamma, d_dbeta) and rbx_batchnorm_bwd_dx with d_y_relu = NULL (the mask has
- *       been applied). */
-int rbx_linear_fwd_bnstats(const float* d_x, int64_t x_stride, const float* d_w, const float* d_bias, int64_t m, int32_t n,
-                           int32_t k, float* d_y, float* d_partial, void* stream);
-int rbx_linear_dx_bnsums(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
-                         const float* d_a, int64_t a_stride, const float* d_bn_x, int64_t bn_x_stride, const float* d_bn_mean,
-                         const float* d_bn_rstd, const float* d_bn_gamma, const float* d_bn_beta, float* d_dx, int64_t dx_stride,
-                         float* d_partial, void* stream);
-int rbx_batchnorm_stats_from_partials(const float* d_partial, int32_t n_blocks, int32_t cols, float eps, float momentum,
-                                      float* d_running_mean, float* d_running_var, float* d_mean, float* d_rstd, void* stream);
-int rbx_batchnorm_bwd_sums_from_partials(const float* d_partial, int32_t n_blocks, int32_t cols, float* d_dgamma,
-                                         float* d_dbeta, void* stream);
 size_t rbx_split_bf16_size(int32_t rows, int32_t cols, int32_t transpose);
 int rbx_split_bf16(const float* d_src, int64_t ld, int32_t rows, int32_t cols, int32_t transpose, void* d_out, void* stream);
 int rbx_split_register(const float* d_w, const void* d_planes, int32_t rows, int32_t cols, int32_t transposed);
@@ -877,14 +841,6 @@ size_t rbx_seqblock_inproj_dw_workspace_size(int64_t m);
 int rbx_seqblock_inproj_dw(const float* d_dQ, const float* d_dKV, const float* d_x, const float* d_mean, const float* d_rstd,
                            int64_t m, const float* d_ln_w, const float* d_ln_b, float* d_dw, float* d_db, void* d_workspace,
                            size_t workspace_bytes, void* stream);
-/* rbx_seqblock_ffn_bwd without dW2 / db2 (the caller forms them with rbx_linear_dwdb_scaled): three products and 64
- * accumulators, two wavefronts per SIMD. */
-size_t rbx_seqblock_ffn_bwd3_workspace_size(int64_t m);
-int rbx_seqblock_ffn_bwd3(const float* d_dout, const float* d_keep, const float* d_h, const float* d_x, const float* d_mean,
-                          const float* d_rstd, int64_t m, const float* d_ln_w, const float* d_ln_b, const float* d_w1,
-                          const float* d_w2, float* d_dx, float* d_dw1, float* d_db1, float* d_dgamma, float* d_dbeta,
-                          void* d_workspace, size_t workspace_bytes, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

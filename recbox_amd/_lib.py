@@ -108,9 +108,7 @@ SIGNATURES = {
     "rbx_seq_colsum_workspace_size": (_sz, [_i64, _i32, _i32]),
     "rbx_seq_colsum": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _P, _P, _sz, _P]),
     "rbx_sum_prefix": (ctypes.c_int, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _i32, _P, _i64, _P]),
-    "rbx_fm_tier_c": (ctypes.c_int, [_i32]),
     "rbx_fm_quad": (ctypes.c_int, [_i32]),
-    "rbx_fm_rezero_fusable": (ctypes.c_int, [_FP, _FP, _i32, _i64]),
     "rbx_fm_rezero": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P]),
     "rbx_fm_bwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _P, _i32, _i32, _P, _sz, _P]),
     "rbx_gatherdot_fwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _f32, _P, _P, _P]),
@@ -177,18 +175,12 @@ SIGNATURES = {
     "rbx_seqblock_attn_out_bwd": (ctypes.c_int, [_P, _P, _i64, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_seqblock_inproj_dw_workspace_size": (_sz, [_i64]),
     "rbx_seqblock_inproj_dw": (ctypes.c_int, [_P, _P, _P, _P, _P, _i64, _P, _P, _P, _P, _P, _sz, _P]),
-    "rbx_seqblock_ffn_bwd3_workspace_size": (_sz, [_i64]),
-    "rbx_seqblock_ffn_bwd3": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _i64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _sz, _P]),
     "rbx_linear_dwdb_scaled": (ctypes.c_int, [_P, _i64, _P, _i64, _P, _i64, _i32, _i32, _P, _P, _P, _sz, _P]),
     "rbx_fm_sum_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _i32, _P, _P, _P]),
     "rbx_fm_sum_lr_fwd": (ctypes.c_int, [_P, _i64, _i64, _i32, _i32, _P, _P, _P, _P, _P, _P]),
     "rbx_linear_dx_deepfm": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i32, _i32, _P, _P, _P, _P, _i64,
                                             _P]),
     "rbx_linear_bwd": (ctypes.c_int, [_P, _i64, _P, _P, _P, _i64, _i32, _i32, _i32, _P, _i64, _P, _P, _P, _sz, _P]),
-    "rbx_linear_fwd_bnstats": (ctypes.c_int, [_P, _i64, _P, _P, _i64, _i32, _i32, _P, _P, _P]),
-    "rbx_linear_dx_bnsums": (ctypes.c_int, [_P, _i64, _P, _i64, _i32, _i32, _P, _i64, _P, _i64, _P, _P, _P, _P, _P, _i64, _P, _P]),
-    "rbx_batchnorm_stats_from_partials": (ctypes.c_int, [_P, _i32, _i32, _f32, _f32, _P, _P, _P, _P, _P]),
-    "rbx_batchnorm_bwd_sums_from_partials": (ctypes.c_int, [_P, _i32, _i32, _P, _P, _P]),
     "rbx_split_bf16_size": (_sz, [_i32, _i32, _i32]),
     "rbx_split_bf16": (ctypes.c_int, [_P, _i64, _i32, _i32, _i32, _P, _P]),
     "rbx_split_register": (ctypes.c_int, [_P, _P, _i32, _i32, _i32]),

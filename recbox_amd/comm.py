@@ -306,7 +306,7 @@ class _Direct(object):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)          # all ranks take the same path
         eager_ok = bool(ok[0].item() > 0)
         cap_ok = False
-        if eager_ok and os.environ.get("RECBOX_AMD_DIRECT_RCCL_CAPTURE", "1") != "0":
+        if eager_ok:
             # the same three collectives captured into a hipGraph and replayed twice on fresh inputs
             try:
                 xs = x.clone()

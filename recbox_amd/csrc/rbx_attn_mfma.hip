@@ -27,9 +27,7 @@ namespace rbx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kT = 32;                      // tile edge (queries or keys)
-#ifndef RBX_ATTN_PAD
 #define RBX_ATTN_PAD 1     // floats of padding per LDS row of the resident kernels: 1 = odd pitch, scalar LDS accesses; 4 = 16-byte
-#endif                     // aligned rows: b128 stores when a block is staged, b128 loads of a lane's row in tile_dot (a quarter
                            // of the LDS instructions of a tile_dot).  Measured, profiles/r04/INDEX.md: dQ kernel 555 vs 567 us,
                            // dK | dV 661 vs 663, resident forward 427 vs 408 (spills): the LDS round trips are not what these
                            // kernels wait for.
@@ -105,9 +103,7 @@ __device__ __forceinline__ void stage_rows_pair(const float* __restrict__ ga, co
     }
   }
 }
-#ifndef RBX_ATTN_STAGE_PAIR
 #define RBX_ATTN_STAGE_PAIR 1
-#endif
 template <int HD>
 __device__ __forceinline__ void stage_two(const float* __restrict__ ga, const long long lda, float* __restrict__ la, const float sa,
                                           const float* __restrict__ gb, const long long ldb, float* __restrict__ lb,
@@ -198,19 +194,11 @@ __device__ __forceinline__ void load_tile_clamped(const float* __restrict__ g, c
     reg[4 * q] = v.x; reg[4 * q + 1] = v.y; reg[4 * q + 2] = v.z; reg[4 * q + 3] = v.w;
   }
 }
-#ifndef RBX_ATTN_EARLY_TILE
 #define RBX_ATTN_EARLY_TILE 0   // backward kernels: 1 = the first job's own tiles are requested in front of the staging (measured slower)
-#endif
 
-#ifndef RBX_ATTN_QFIRST
 #define RBX_ATTN_QFIRST 1  // looping forward kernel: the K / V prefetch is issued once the wavefront's Q tile has arrived
-#endif
-#ifndef RBX_ATTN_ABL
 #define RBX_ATTN_ABL 0     // profiles/ubench/attn_parts.hip: the forward kernel without 1 = S^T, 2 = the softmax, 4 = O^T += V^T P^T, 8 = the Q tile loads, 16 = the stores of unsplit tiles; the backward kernels without 32 = the staging of a sequence's rows, 64 = the loads of a wavefront's own tiles
-#endif
-#ifndef RBX_ATTN_BF16X6
 #define RBX_ATTN_BF16X6 44 // which tile products run on the bf16 matrix cores, operands split three ways: bits 0, 1 the forward
-#endif                     // kernels' tile_dot / tile_accumulate, bits 2, 3 the dQ kernel's, bits 4, 5 the dK | dV kernel's
                            // (0: v_mfma_f32_32x32x2_f32 everywhere)
 // f32 products on the bf16 pipes (the recipe of rbx_dense.hip's gemm_bx6_kernel): x = h + m + l with bf16 h = rn(x), m = rn(x - h),
 // l = rn(x - h - m); a b = ah bh + (ah bm + am bh) + (ah bl + al bh + am bm) + O(2^-24 |a b|): six v_mfma_f32_32x32x16_bf16 per
@@ -917,11 +905,10 @@ bool attn_mfma_supported(int lq, int lk, int hd, const float* mask, const float*
 namespace rbx {
 
 // heavy tiles dealt to both wavefronts of their SIMD (wave_plan): causal sequences of at least three tiles (below that no
-// tile is two steps heavier than its partner); RBX_ATTN_SPLIT=0 keeps one wavefront per tile.  The four merge slots fit in
+// tile is two steps heavier than its partner).  The four merge slots fit in
 // the operand rows they reuse: 4 * (32 HD + 128) floats <= 2 * 96 * (HD + kPad) for HD = 32 and 64.
 static bool attn_split(int L, int causal) {
-  static const bool on = [] { const char* e = getenv("RBX_ATTN_SPLIT"); return e == nullptr || e[0] != '0'; }();
-  return on && causal != 0 && L > 2 * kT;
+  return causal != 0 && L > 2 * kT;
 }
 
 template <int HD>
@@ -935,10 +922,11 @@ static int run_fwd(const float* q, const float* k, const float* v, long long bh,
                    float* lse, const DropArgs& drop, const AttnLd& ld, hipStream_t s) {
   if constexpr (HD == 64) {
     // K / V streamed through a ring of 32-key tiles, a pair of sequences per workgroup (rbx_attn_stream.h)
-    // RBX_ATTN_STREAM: 0 the resident kernels, 1 (default) the streamed f32 tiles, 2 bf16 planes where they apply (7 tiles)
-    static const int stream_mode = [] { const char* e = getenv("RBX_ATTN_STREAM"); return e == nullptr ? 1 : atoi(e); }();
     const int nT = (L + kT - 1) / kT;
-    if (stream_mode == 2 && causal != 0 && nT == 7) {
+    if (causal != 0 && nT == 7) {
+      // seven tiles (192 < L <= 224: BASELINE cfg 5's L = 200): K / V as three bf16 planes split once per tile by the loader
+      // (rbx_attn_planes.h): 339 vs 373 us at L = 200, 4096 sequences, the same 1e-7 error against float64
+      // (profiles/r04/attn_planes.txt); the default since round 5
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_planes_fwd_kernel<DROP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kPlanesLds));
       const long long pairs = (bh + 1) / 2;
@@ -946,7 +934,7 @@ static int run_fwd(const float* q, const float* k, const float* v, long long bh,
                          kPlanesLds, s, q, k, v, L, scale, o, lse, drop, ld, bh);
       return check_launch("attn_planes_fwd_kernel");
     }
-    if (stream_mode != 0 && causal != 0 && nT >= 3 && nT <= 7) {
+    if (causal != 0 && nT >= 3 && nT <= 7) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_stream_fwd_kernel<DROP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kStreamLds));
       hipLaunchKernelGGL((attn_stream_fwd_kernel<DROP>), dim3(static_cast<unsigned>((bh + 1) / 2)), dim3((nT + 1) * 64),
@@ -955,13 +943,12 @@ static int run_fwd(const float* q, const float* k, const float* v, long long bh,
     }
   }
   const size_t lds = lds_bytes<HD>(L, false);
-  static const bool pf_on = [] { const char* e = getenv("RBX_ATTN_PREFETCH"); return e == nullptr || e[0] != '0'; }();
   // (the looping form keeps the heavy tiles' partials in LDS slots of their own behind K and V: where those do not fit --
   //  HD = 64, L > 224 -- neither form splits, so that a sequence gets the same arithmetic from both)
   const size_t lds_split = lds + 4 * merge_floats<HD>() * sizeof(float);
   const bool split_on = attn_split(L, causal) && lds_split <= 160 * 1024;
   if constexpr (HD == 64) {
-    if (pf_on && lds > 80 * 1024 && bh > kCUs) {             // one workgroup per CU either way: loop over sequences, prefetch
+    if (lds > 80 * 1024 && bh > kCUs) {             // one workgroup per CU either way: loop over sequences, prefetch
       const int npf = ((L + kT - 1) / kT * kT) * (HD / 4) / kAttnThreads;      // 6, 7 or 8 at Lp = 192, 224, 256
       const int split = split_on ? 1 : 0;
       const size_t lds_pf = split ? lds_split : lds;

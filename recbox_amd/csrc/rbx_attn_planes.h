@@ -19,9 +19,7 @@
 
 namespace rbx {
 
-#ifndef RBX_PL_ABL
 #define RBX_PL_ABL 0   // profiles/ubench/attn_stream.hip: 1 = no tile streaming inside the loop, 2 = no tile steps, 4 = no wait before commit
-#endif
 constexpr int kPlBytes = 4096;                     // one plane of one tile
 constexpr int kPlTile = 3 * kPlBytes;              // h, m, l
 constexpr int kPlStage = 4 * kPlTile;              // K_A, V_A, K_B, V_B

@@ -7,9 +7,7 @@
 namespace rbx {
 
 constexpr int kSortThreads = 256;
-#ifndef RBX_SORT_ITEMS
 #define RBX_SORT_ITEMS 8
-#endif
 constexpr int kSortItems = RBX_SORT_ITEMS;                 // per thread
 constexpr int kSortTile = kSortThreads * kSortItems;       // 2048 pairs per workgroup
 constexpr int kRadix = 256;                                // bins of an 8-bit digit (the sort also runs 10- and 11-bit digits)
@@ -17,16 +15,12 @@ constexpr int kRadix = 256;                                // bins of an 8-bit d
 // the Criteo shape and LOST: a 2048-pair tile then scatters into 1024 buckets of ~2 pairs (8-byte runs instead of
 // 32-byte ones) and its per-digit steps are 4x longer -- radix_scatter 32.5 us per pass instead of 17.8, the sort 114 us
 // instead of 105 (profiles/r02/sort_variants.txt).  The kernels stay templated on the digit width.
-#ifndef RBX_MAX_RADIX_BITS
 #define RBX_MAX_RADIX_BITS 8
-#endif
 constexpr int kMaxRadixBits = RBX_MAX_RADIX_BITS;
 // sorted pairs per lane group in the reduce.  Measured on the Criteo shape (profiles/r02/reduce_variants.txt): the kernel
 // sits at 77-86 us whatever the chunk, the lookups in flight and the occupancy are -- 40 pairs with 3 waves per SIMD
 // (no register spill, 666 workgroups: all resident at once) is the best of them at 80 us; 16, 48, 56 and 64 are slower.
-#ifndef RBX_CHUNK
 #define RBX_CHUNK 40
-#endif
 constexpr int kChunk = RBX_CHUNK;                          // the LARGEST chunk; a plan with few pairs takes a shorter one (BwdPlan::chunk)
 constexpr unsigned kLocalBits = 26;                        // val = slot << 26 | (b*L + l)
 constexpr unsigned kLocalMask = (1u << kLocalBits) - 1u;

@@ -33,9 +33,7 @@ namespace rbx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef RBX_GEMM_BK
 #define RBX_GEMM_BK 16
-#endif
 constexpr int BM = 128, BN = 128, BK = RBX_GEMM_BK;
 constexpr int kXcds = 8;         // MI355X: 8 accelerator complex dies, 32 CUs and one L2 each
 constexpr int LDT = BM + 4;     // LDS row stride (floats): keeps b128 stores aligned, spreads k rows over banks
@@ -65,19 +63,6 @@ struct Epi {
   int fm_cols;
   int fm_dim;
   int fm_mask;            // fm_dim - 1 when fm_dim is a power of two (col & mask instead of col % dim), else -1
-  // BatchNorm statistics out of the GEMM that produces (or back-propagates into) the normalised tensor -- gemm_bxp_kernel
-  // only; one entry per (64-row block, column), reduced by the BatchNorm's own final kernels:
-  //   bn_mode 1 (forward, y = x W^T + b feeds a BatchNorm): bn_part[(block * N + col) * 3 + {0, 1, 2}] = (n, mean, M2) of y
-  //   bn_mode 2 (dx = dy W whose output is the gradient of a BatchNorm + ReLU output a): with g = dx o [mask > 0] (mask = a),
-  //           bn_part[(block * N + col) * 2 + {0, 1}] = (sum g, sum g xhat), xhat = (bn_x - bn_mean[col]) bn_rstd[col]
-  float* bn_part;
-  const float* bn_x;
-  long long bn_ldx;
-  const float* bn_mean;
-  const float* bn_rstd;
-  const float* bn_gamma;   // mode 2: xhat of an unmasked element is rebuilt from the mask tensor a = gamma xhat + beta that the
-  const float* bn_beta;    //         epilogue reads anyway (bn_x is only read in columns whose gamma is 0)
-  int bn_mode;
 };
 __device__ __forceinline__ float epi_fm_term(const Epi& e, int row, int col) {
   if (e.fm_x == nullptr || col >= e.fm_cols) return 0.f;
@@ -205,9 +190,7 @@ __device__ __forceinline__ void store_tile_v(float* __restrict__ tile, const f32
   store_tile<KCONTIG>(tile, reg);
 }
 
-#ifndef RBX_GEMM_PIPE
 #define RBX_GEMM_PIPE 1
-#endif
 
 // MFMA steps kk in [KLO, KHI) of one staged k tile for a wavefront's 2 x 2 tiles of 32 x 32: only the tiles named in
 // LIVE (bit 2 i + j) -- a wavefront whose 32-row / 32-column blocks lie beyond M / N skips
@@ -365,9 +348,7 @@ __global__ __launch_bounds__(256) void gemm_f32_narrow_kernel(const float* __res
                                         static_cast<int>(blockIdx.x) * BM, As, Bs);
 }
 
-#ifndef RBX_EPI_CH
 #define RBX_EPI_CH 4   // outputs whose epilogue operands are fetched in one run of loads
-#endif
 
 // Epilogue of a 128 x 128 tile whose wavefronts hold 2 x 2 MFMA tiles of 32 x 32 (C/D layout: col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) -- the same for the f32 and the bf16 MFMAs): shared by the kernels below.
@@ -383,7 +364,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const i
     // time in one straight run of loads.  (With a test per output every element was its own basic block -- load, wait,
     // store, 64 times per lane: the DeepFM dx GEMM took 330 us longer than the same GEMM without its epilogue.)
     constexpr int CH = RBX_EPI_CH;
-    float bs0[2] = {0.f, 0.f}, bs1[2] = {0.f, 0.f};        // bn_mode 2: column sums of the masked output and of output x xhat
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -391,14 +371,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const i
         const int col = n0 + wn + j * 32 + li;
         const int row0 = m0 + wm + i * 32 + 4 * lk;
         const float bv = bias != nullptr ? bias[col] : 0.f;
-        float bn_ig = 0.f, bn_b = 0.f, bn_mu = 0.f, bn_rs = 0.f;
-        if (epi.bn_mode == 2) {
-          const float gm = epi.bn_gamma != nullptr ? epi.bn_gamma[col] : 1.f;
-          bn_ig = gm != 0.f ? 1.f / gm : 0.f;
-          bn_b = epi.bn_beta != nullptr ? epi.bn_beta[col] : 0.f;
-          bn_mu = epi.bn_mean[col];
-          bn_rs = epi.bn_rstd[col];
-        }
 #pragma unroll
         for (int h = 0; h < 16; h += CH) {
           float add[CH];
@@ -449,37 +421,11 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const i
               float v = acc[i][j][h + q] + bv;
               if (act == 1) v = v > 0.f ? v : 0.f;
               if (has_mask) v = keep[q] > 0.f ? v : 0.f;
-              if (epi.bn_mode == 2) {
-                bs0[j] += v;
-                bs1[j] += v * ((keep[q] - bn_b) * bn_ig);
-              }
               v += add[q];
               if (has_rs) v *= sc[q];
               C[static_cast<long long>(row0 + ((h + q) & 3) + 8 * ((h + q) >> 2)) * ldc + col] = v;
             }
           }
-        }
-        // gamma = 0 in this column: a says nothing about xhat, which then comes from the BatchNorm's input (a loop of its
-        // own, so that the one above stays free of per-lane branches)
-        if (epi.bn_mode == 2 && bn_ig == 0.f) {
-          for (int r = 0; r < 16; ++r) {
-            const long long row = row0 + (r & 3) + 8 * (r >> 2);
-            float v = acc[i][j][r] + bv;
-            if (act == 1) v = v > 0.f ? v : 0.f;
-            if (has_mask) v = epi.mask[row * epi.ldmask + col] > 0.f ? v : 0.f;
-            bs1[j] += v * ((epi.bn_x[row * epi.bn_ldx + col] - bn_mu) * bn_rs);
-          }
-        }
-      }
-    }
-    if (epi.bn_mode == 2) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float t0 = bs0[j] + __shfl_xor(bs0[j], 32, 64), t1 = bs1[j] + __shfl_xor(bs1[j], 32, 64);
-        if (lk == 0) {
-          float* dst = epi.bn_part + (static_cast<long long>((m0 + wm) >> 6) * N + n0 + wn + j * 32 + li) * 2;
-          dst[0] = t0;
-          dst[1] = t1;
         }
       }
     }
@@ -829,12 +775,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bx6_kernel(const float* __restric
 // wavefronts owns 256 rows x 128 columns (the weight tile amortised over twice the rows: 28 KB per 2 x the products), k tiles
 // of 16 in two LDS buffers, ONE barrier per tile: the tile after the current one is split and parked in the other buffer
 // between the two halves of the current tile's MFMAs, the loads of the tile after that issued right behind.
-#ifndef RBX_BXP_STAGES
 #define RBX_BXP_STAGES 2
-#endif
-#ifndef RBX_BXP_SCHED
 #define RBX_BXP_SCHED 1
-#endif
 constexpr int PBK = 16;                 // k per tile: one MFMA step
 constexpr int PLD = PBK + 8;            // LDS row pitch, bf16 elements (48 bytes: conflict-free b128 reads of 16 rows)
 constexpr int PBM = 256;                // rows of the workgroup's tile
@@ -1016,73 +958,6 @@ __device__ __forceinline__ void bxp_loop(const float* __restrict__ A, const long
 }
 #undef RBX_BXP_TERM
 
-// Column statistics of a wavefront's 64 rows x 64 columns for the BatchNorm behind (mode 1) / in front of (mode 2) this
-// GEMM: a lane holds 16 rows of one column per 32 x 32 tile (C/D layout), its partner lane ^ 32 the other 16.  Two passes
-// over registers (mean, then squared deviations), Chan's merge of the two halves; rows beyond M do not count.
-__device__ __forceinline__ void bxp_bn_stats(const f32x16 (&acc)[2][2], const int m0, const int n0, const int wm, const int wn,
-                                             const int li, const int lk, const int live, const int M, const int N,
-                                             const float* __restrict__ bias, const Epi& epi) {
-  const long long block = (m0 + wm) >> 6;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn + 32 * j + li;
-    const bool col_live = col < N && ((live >> j) & 5) != 0;
-    if (epi.bn_mode == 1) {
-      const float bv = (bias != nullptr && col_live) ? bias[col] : 0.f;
-      float n = 0.f, sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          if (row < M && ((live >> (2 * i + j)) & 1)) { n += 1.f; sum += acc[i][j][r] + bv; }
-        }
-      const float mean = n > 0.f ? sum / n : 0.f;
-      float m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          if (row < M && ((live >> (2 * i + j)) & 1)) { const float d = acc[i][j][r] + bv - mean; m2 += d * d; }
-        }
-      const float on = __shfl_xor(n, 32, 64), omean = __shfl_xor(mean, 32, 64), om2 = __shfl_xor(m2, 32, 64);
-      if (lk == 0 && col_live) {
-        const float tot = n + on;
-        float tmean = mean, tm2 = m2;
-        if (on > 0.f && tot > 0.f) {
-          const float d = omean - mean;
-          tmean = mean + d * (on / tot);
-          tm2 = m2 + om2 + d * d * (n * on / tot);
-        }
-        float* dst = epi.bn_part + (block * N + col) * 3;
-        dst[0] = tot; dst[1] = tmean; dst[2] = tm2;
-      }
-    } else {
-      const float mu = col_live ? epi.bn_mean[col] : 0.f, rs = col_live ? epi.bn_rstd[col] : 0.f;
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          if (row < M && col_live && ((live >> (2 * i + j)) & 1)) {
-            float g = acc[i][j][r];
-            if (epi.mask != nullptr && !(epi.mask[static_cast<long long>(row) * epi.ldmask + col] > 0.f)) g = 0.f;
-            s0 += g;
-            s1 += g * ((epi.bn_x[static_cast<long long>(row) * epi.bn_ldx + col] - mu) * rs);
-          }
-        }
-      s0 += __shfl_xor(s0, 32, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      if (lk == 0 && col_live) {
-        float* dst = epi.bn_part + (block * N + col) * 2;
-        dst[0] = s0; dst[1] = s1;
-      }
-    }
-  }
-}
-
 __global__ __launch_bounds__(PTHREADS, 1) void gemm_bxp_kernel(const float* __restrict__ A, const long long lda,
                                                                const unsigned short* __restrict__ Bp, const int kp,
                                                                float* __restrict__ C, const long long ldc, const int M,
@@ -1127,246 +1002,6 @@ __global__ __launch_bounds__(PTHREADS, 1) void gemm_bxp_kernel(const float* __re
   else if (live == 3) bxp_loop<3>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
   else if (live == 1) bxp_loop<1>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
   else bxp_loop<0>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
-  // statistics for the BatchNorm around this GEMM: forward (mode 1) from the accumulators; backward (mode 2) inside the
-  // epilogue's masked store loop on interior tiles (it reads the mask tensor anyway), by a pass of its own on edge tiles
-  const bool interior = m0 + PBM <= M && n0 + BN <= N;
-  if (epi.bn_mode != 0 && m0 + wm < M && (epi.bn_mode == 1 || !interior))
-    bxp_bn_stats(acc, m0, n0, wm, wn, li, lk, live, M, N, bias, epi);
-  gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi, PBM);
-}
-
-// ---- the same 256 x 128 tile with k tiles of 32: half the barriers ----------------------------------------------------------------
-// gemm_bxp_kernel meets one barrier per 24 MFMAs of a wavefront and its wavefronts spend ~30 % of their cycles there
-// (profiles/r03).  Two MFMA k steps per tile halve the barriers per product; the tile then needs 2 x (48 + 24) KB only if the
-// LDS rows lose their padding (the 80-byte pitch of the 16-k form would be 184 KB at 32 k): rows of 64 bytes, the 16-byte chunk
-// index XORed with (row >> 2) & 3 on both sides -- sixteen consecutive rows of one chunk column then spread over the four
-// chunk positions of four row groups, conflict-free for the b128 fragment reads as the padded form was.
-// RBX_GEMM_BXQ=1 selects it (read once); the default is decided by measurement (profiles/r04/INDEX.md).
-constexpr int QBK = 32;
-constexpr int QLD = 32;                 // bf16 per LDS row
-constexpr int QPLANE_A = PBM * QLD, QPLANE_B = BN * QLD;
-constexpr int QBUF_A = 3 * QPLANE_A, QBUF_B = 3 * QPLANE_B;
-
-// A tile [256, 32]: thread t takes k = 4 (t % 8) .. + 3 of rows t / 8 + 64 p
-template <bool GUARD>
-__device__ __forceinline__ void bxq_load_a(const float* __restrict__ A, long long lda, int m0, int k0, int M, int K,
-                                           f32x4u_t (&v)[4]) {
-  const int t = threadIdx.x;
-  const int k = k0 + (t & 7) * 4;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    int r = m0 + (t >> 3) + 64 * p;
-    r = r < M ? r : M - 1;
-    const float* src = A + static_cast<long long>(r) * lda + k;
-    if (!GUARD || k + 3 < K) {
-      v[p] = *reinterpret_cast<const f32x4u_t*>(src);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[p][j] = (k + j < K) ? src[j] : 0.f;
-    }
-  }
-}
-__device__ __forceinline__ void bxq_store_a(unsigned short* __restrict__ buf, const f32x4u_t (&v)[4]) {
-  const int t = threadIdx.x;
-  const int col = ((((t & 7) >> 1) ^ ((t >> 5) & 3)) << 3) + ((t & 1) << 2);      // (row >> 2) & 3 == (t >> 5) & 3 for every p
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split2(f32x2_t{v[p][0], v[p][1]}, h0, m0, l0);
-    split2(f32x2_t{v[p][2], v[p][3]}, h1, m1, l1);
-    unsigned short* dst = buf + ((t >> 3) + 64 * p) * QLD + col;
-    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(dst + QPLANE_A) = make_uint2(m0, m1);
-    *reinterpret_cast<uint2*>(dst + 2 * QPLANE_A) = make_uint2(l0, l1);
-  }
-}
-// B tile [128 rows, 32 k] of the interleaved planes: 192 contiguous bytes per row = 12 chunks of 16 bytes (group of 8 k x plane);
-// 1536 chunks, three per thread
-__device__ __forceinline__ void bxq_load_b(const unsigned short* __restrict__ Bp, int kp, int n0, int k0, int N, u32x4_t (&v)[3]) {
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int j = t + PTHREADS * i;
-    int r = n0 + j / 12;
-    r = r < N ? r : N - 1;
-    v[i] = *reinterpret_cast<const u32x4_t*>(Bp + static_cast<long long>(r) * 3 * kp + (k0 >> 3) * 24 + (j % 12) * 8);
-  }
-}
-__device__ __forceinline__ void bxq_store_b(unsigned short* __restrict__ buf, const u32x4_t (&v)[3]) {
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int j = t + PTHREADS * i;
-    const int row = j / 12, c = j % 12;
-    *reinterpret_cast<u32x4_t*>(buf + (c % 3) * QPLANE_B + row * QLD + (((c / 3) ^ ((row >> 2) & 3)) << 3)) = v[i];
-  }
-}
-
-#define RBX_BXQ_TERM(S, QA, QB)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
-    if ((LIVE >> (2 * i + j)) & 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S][i][QA], b[S][j][QB], acc[i][j], 0, 0, 0)
-
-template <int LIVE>
-__device__ __forceinline__ void bxq_loop(const float* __restrict__ A, const long long lda, const unsigned short* __restrict__ Bp,
-                                         const int kp, const int m0, const int n0, const int M, const int N, const int K,
-                                         unsigned short* __restrict__ As, unsigned short* __restrict__ Bs, const int wm,
-                                         const int wn, const int li, const int lk, f32x16 (&acc)[2][2]) {
-  // ONE register set: the loads of tile t + 2 are issued while tile t runs (48 MFMAs ahead of their split -- the lead the
-  // 16-k form gets from two sets; a second set here is 28 registers the two fragment sets need)
-  f32x4u_t ra[4];
-  u32x4_t rb[3];
-  const int kt = (K + QBK - 1) / QBK;
-  auto fetch = [&](int tile) {
-    if ((tile + 1) * QBK <= K) bxq_load_a<false>(A, lda, m0, tile * QBK, M, K, ra);
-    else bxq_load_a<true>(A, lda, m0, tile * QBK, M, K, ra);
-    bxq_load_b(Bp, kp, n0, tile * QBK, N, rb);
-  };
-  fetch(0);
-  bxq_store_a(As, ra);
-  bxq_store_b(Bs, rb);
-  if (kt > 1) fetch(1);
-  __syncthreads();
-  // fragment of k step S: logical chunk 2 S + lk, physical (2 S + lk) ^ ((row >> 2) & 3) with row % 16 == li % 16
-  const int sw = (li >> 2) & 3;
-  const int aoff = (wm + li) * QLD, boff = (wn + li) * QLD;
-  const int c0 = ((lk ^ sw) << 3), c1 = (((2 + lk) ^ sw) << 3);
-  auto frags = [&](int cur, bf16x8_t (&a)[2][2][3], bf16x8_t (&b)[2][2][3], bool all) {
-    const unsigned short* ap = As + cur * QBUF_A + aoff;
-    const unsigned short* bp = Bs + cur * QBUF_B + boff;
-#pragma unroll
-    for (int S = 0; S < 2; ++S)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int co = S ? c1 : c0;
-          if (all || ((LIVE >> (2 * i)) & 3)) a[S][i][q] = *reinterpret_cast<const bf16x8_t*>(ap + q * QPLANE_A + i * 32 * QLD + co);
-          if (all || ((LIVE >> i) & 5)) b[S][i][q] = *reinterpret_cast<const bf16x8_t*>(bp + q * QPLANE_B + i * 32 * QLD + co);
-        }
-  };
-  auto step = [&](int t, int cur) {
-    bf16x8_t a[2][2][3], b[2][2][3];
-    frags(cur, a, b, false);
-    RBX_BXQ_TERM(0, 2, 0);
-    RBX_BXQ_TERM(0, 0, 2);
-    RBX_BXQ_TERM(0, 1, 1);
-    if (t + 1 < kt) {
-      bxq_store_a(As + (cur ^ 1) * QBUF_A, ra);
-      bxq_store_b(Bs + (cur ^ 1) * QBUF_B, rb);
-    }
-    if (t + 2 < kt) fetch(t + 2);
-    RBX_BXQ_TERM(0, 1, 0);
-    RBX_BXQ_TERM(0, 0, 1);
-    RBX_BXQ_TERM(0, 0, 0);
-    RBX_BXQ_TERM(1, 2, 0);
-    RBX_BXQ_TERM(1, 0, 2);
-    RBX_BXQ_TERM(1, 1, 1);
-    RBX_BXQ_TERM(1, 1, 0);
-    RBX_BXQ_TERM(1, 0, 1);
-    RBX_BXQ_TERM(1, 0, 0);
-    __syncthreads();
-  };
-  auto steady = [&](int t, int cur) {
-    bf16x8_t a[2][2][3], b[2][2][3];
-    frags(cur, a, b, true);
-    RBX_BXQ_TERM(0, 2, 0);
-    RBX_BXQ_TERM(0, 0, 2);
-    RBX_BXQ_TERM(0, 1, 1);
-    bxq_store_a(As + (cur ^ 1) * QBUF_A, ra);
-    bxq_store_b(Bs + (cur ^ 1) * QBUF_B, rb);
-    bxq_load_a<false>(A, lda, m0, (t + 2) * QBK, M, K, ra);
-    bxq_load_b(Bp, kp, n0, (t + 2) * QBK, N, rb);
-    RBX_BXQ_TERM(0, 1, 0);
-    RBX_BXQ_TERM(0, 0, 1);
-    RBX_BXQ_TERM(0, 0, 0);
-    RBX_BXQ_TERM(1, 2, 0);
-    RBX_BXQ_TERM(1, 0, 2);
-    RBX_BXQ_TERM(1, 1, 1);
-    RBX_BXQ_TERM(1, 1, 0);
-    RBX_BXQ_TERM(1, 0, 1);
-    RBX_BXQ_TERM(1, 0, 0);
-#if RBX_BXP_SCHED
-    __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);                    // DS reads
-#pragma unroll
-    for (int g = 0; g < 24; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   // VALU
-    }
-#pragma unroll
-    for (int g = 0; g < 15; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                   // DS write
-    }
-#pragma unroll
-    for (int g = 0; g < 7; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // VMEM read
-    }
-#endif
-    __syncthreads();
-  };
-  int t = 0;
-  if constexpr (LIVE == 15) {
-    while ((t + 4) * QBK <= K) {                   // two steps per round: tiles t + 2 and t + 3 are read without tests
-      steady(t, 0);
-      steady(t + 1, 1);
-      t += 2;
-    }
-  }
-  while (t < kt) {                                 // the rest (and edge tiles): the tested step; t is even here
-    step(t, 0);
-    ++t;
-    if (t < kt) { step(t, 1); ++t; }
-  }
-}
-#undef RBX_BXQ_TERM
-
-__global__ __launch_bounds__(PTHREADS, 1) void gemm_bxq_kernel(const float* __restrict__ A, const long long lda,
-                                                               const unsigned short* __restrict__ Bp, const int kp,
-                                                               float* __restrict__ C, const long long ldc, const int M,
-                                                               const int N, const int K, const float* __restrict__ bias,
-                                                               const int act, const int tiles_m, const int tiles_n,
-                                                               const Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short bxp_lds[];          // 2 x (A 48 KB + B 24 KB) = 144 KB
-  unsigned short* As = bxp_lds;
-  unsigned short* Bs = bxp_lds + 2 * QBUF_A;
-  int tm_i, tn_j;
-  {
-    const int total = tiles_m * tiles_n, L = static_cast<int>(blockIdx.x);
-    const int xcd = L % kXcds, slot = L / kXcds;
-    const int q = total / kXcds, rem = total % kXcds;
-    const int tile = xcd * q + (xcd < rem ? xcd : rem) + slot;
-    tm_i = tile / tiles_n;
-    tn_j = tile % tiles_n;
-  }
-  const int m0 = tm_i * PBM, n0 = tn_j * BN;
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int li = lane & 31, lk = lane >> 5;
-  const int wm = (wid >> 1) * 64, wn = (wid & 1) * 64;
-  int live;
-  {
-    int rows = (M - m0 - wm + 31) / 32, cols = (N - n0 - wn + 31) / 32;
-    rows = rows > 2 ? 2 : rows;
-    cols = cols > 2 ? 2 : cols;
-    live = (rows <= 0 || cols <= 0) ? 0 : (rows == 2 && cols == 2) ? 15 : (rows == 2) ? 5 : (cols == 2) ? 3 : 1;
-    live = __builtin_amdgcn_readfirstlane(live);
-  }
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  if (live == 15) bxq_loop<15>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
-  else if (live == 5) bxq_loop<5>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
-  else if (live == 3) bxq_loop<3>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
-  else if (live == 1) bxq_loop<1>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
-  else bxq_loop<0>(A, lda, Bp, kp, m0, n0, M, N, K, As, Bs, wm, wn, li, lk, acc);
-  const bool interior = m0 + PBM <= M && n0 + BN <= N;
-  if (epi.bn_mode != 0 && m0 + wm < M && (epi.bn_mode == 1 || !interior))
-    bxp_bn_stats(acc, m0, n0, wm, wn, li, lk, live, M, N, bias, epi);
   gemm_epilogue(acc, m0, n0, wm, wn, li, lk, live, M, N, C, ldc, bias, act, 1, epi, PBM);
 }
 
@@ -1599,167 +1234,6 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 }
 
 static bool vec_ok(const float* p, long long ld);
-
-// Wide companion for ONE column tile of up to 448 columns (N = 400: the towers of cfg 4; 256 / 128: cfg 3): the
-// 128 x 128 kernel covers N = 400 as three full column tiles plus a 16-column narrow launch that costs 18 % of the
-// main kernel's time for 4 % of the columns (it re-reads all of A).  Here a 512-thread workgroup owns 128 rows x ALL
-// columns: wavefront w computes rows (w & 3) * 32 .. + 32 against column tiles (w >> 2) * NH .. + NH (NH = 7 at N <= 448:
-// 112 accumulator registers, two wavefronts per SIMD); A is read once, B (the weights, L2-resident) once per workgroup.
-// (First version: 256 threads, 13 tiles per wavefront in AGPRs, one wavefront per SIMD -- 1.09 ms for the layer-1 forward of
-//  cfg 4 against 0.93 ms on the 128 x 128 + narrow pair: nothing hides the barrier and the LDS latency of a lone wavefront.)
-constexpr int kWideThreads = 512;
-
-template <int NH>
-struct WideGeom {
-  static constexpr int BNW = 64 * NH;                   // columns of the tile (two column halves of NH MFMA tiles)
-  static constexpr int LDW = BNW + 4;                   // LDS row stride of the B tile
-  static constexpr int PB = (BNW * BK / 4 + kWideThreads - 1) / kWideThreads;   // float4 loads per thread, B tile
-  static constexpr int PA = (BM * BK / 4 + kWideThreads - 1) / kWideThreads;    // float4 loads per thread, A tile
-};
-
-// ROWS x BK operand tile, 512 threads.  KCONTIG: element (r, k) at base[r * ld + k]; else at base[k * ld + r].
-template <bool KCONTIG, int ROWS, int P>
-__device__ __forceinline__ void wide_load(const float* __restrict__ base, long long ld, int r0, int k0, int R, int K, bool vec_ok,
-                                          float (&reg)[4 * P]) {
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int idx = t + kWideThreads * p;
-    if (idx >= ROWS * BK / 4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) reg[p * 4 + j] = 0.f;
-      continue;
-    }
-    if constexpr (KCONTIG) {
-      const int r = r0 + idx / KT;
-      const int k = k0 + (idx % KT) * 4;
-      const float* src = base + static_cast<long long>(r) * ld + k;
-      if (vec_ok && r < R && k + 3 < K) {
-        const float4 v = *reinterpret_cast<const float4*>(src);
-        reg[p * 4 + 0] = v.x; reg[p * 4 + 1] = v.y; reg[p * 4 + 2] = v.z; reg[p * 4 + 3] = v.w;
-      } else if (r < R && k + 3 < K) {
-        reg[p * 4 + 0] = src[0]; reg[p * 4 + 1] = src[1]; reg[p * 4 + 2] = src[2]; reg[p * 4 + 3] = src[3];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) reg[p * 4 + j] = (r < R && k + j < K) ? src[j] : 0.f;
-      }
-    } else {
-      const int k = k0 + idx / (ROWS / 4);
-      const int r = r0 + (idx % (ROWS / 4)) * 4;
-      const float* src = base + static_cast<long long>(k) * ld + r;
-      if (vec_ok && k < K && r + 3 < R) {
-        const float4 v = *reinterpret_cast<const float4*>(src);
-        reg[p * 4 + 0] = v.x; reg[p * 4 + 1] = v.y; reg[p * 4 + 2] = v.z; reg[p * 4 + 3] = v.w;
-      } else if (k < K && r + 3 < R) {
-        reg[p * 4 + 0] = src[0]; reg[p * 4 + 1] = src[1]; reg[p * 4 + 2] = src[2]; reg[p * 4 + 3] = src[3];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) reg[p * 4 + j] = (k < K && r + j < R) ? src[j] : 0.f;
-      }
-    }
-  }
-}
-
-template <bool KCONTIG, int ROWS, int LD, int P>
-__device__ __forceinline__ void wide_store(float* __restrict__ tile, const float (&reg)[4 * P]) {
-  const int t = threadIdx.x;
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const int idx = t + kWideThreads * p;
-    if (idx >= ROWS * BK / 4) continue;
-    if constexpr (KCONTIG) {
-      const int r = idx / KT;
-      const int k = (idx % KT) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tile[(k + j) * LD + r] = reg[p * 4 + j];
-    } else {
-      const int k = idx / (ROWS / 4);
-      const int r = (idx % (ROWS / 4)) * 4;
-      *reinterpret_cast<float4*>(&tile[k * LD + r]) = make_float4(reg[p * 4], reg[p * 4 + 1], reg[p * 4 + 2], reg[p * 4 + 3]);
-    }
-  }
-}
-
-template <bool A_KCONTIG, bool B_KCONTIG, int NH>
-__global__ __launch_bounds__(kWideThreads) void gemm_f32_wide_kernel(const float* __restrict__ A, const long long lda,
-                                                            const float* __restrict__ B, const long long ldb,
-                                                            float* __restrict__ C, const long long ldc, const int M,
-                                                            const int N, const int K, const float* __restrict__ bias,
-                                                            const int act, const bool vec_a, const bool vec_b) {
-  using G = WideGeom<NH>;
-  constexpr int LDW = G::LDW, PA = G::PA, PB = G::PB, BNW = G::BNW;
-  extern __shared__ float wide_lds[];
-  float* As0 = wide_lds;                                  // [2][BK * LDT]
-  float* Bs0 = wide_lds + 2 * BK * LDT;                   // [2][BK * LDW]
-  const int m0 = blockIdx.x * BM;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wm = (wid & 3) * 32;
-  const int wn = (wid >> 2) * NH * 32;
-  const int li = lane & 31, lk = lane >> 5;
-  // column tiles of this wavefront that hold real columns (wave-uniform: the rest are skipped, not computed on padding)
-  int live = (N - wn + 31) / 32;
-  live = live < 0 ? 0 : (live > NH ? NH : live);
-  f32x16 acc[NH];
-#pragma unroll
-  for (int j = 0; j < NH; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  float ra[4 * PA], rb[4 * PB];
-  wide_load<A_KCONTIG, BM, PA>(A, lda, m0, 0, M, K, vec_a, ra);
-  wide_load<B_KCONTIG, BNW, PB>(B, ldb, 0, 0, N, K, vec_b, rb);
-  wide_store<A_KCONTIG, BM, LDT, PA>(As0, ra);
-  wide_store<B_KCONTIG, BNW, LDW, PB>(Bs0, rb);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    const bool more = k0 + BK < K;
-    if (more) {                                    // the next k-tile's loads fly under this tile's MFMAs
-      wide_load<A_KCONTIG, BM, PA>(A, lda, m0, k0 + BK, M, K, vec_a, ra);
-      wide_load<B_KCONTIG, BNW, PB>(B, ldb, 0, k0 + BK, N, K, vec_b, rb);
-    }
-    const float* as = As0 + cur * BK * LDT;
-    const float* bs = Bs0 + cur * BK * LDW + wn;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = as[(kk + lk) * LDT + wm + li];
-#pragma unroll
-      for (int j = 0; j < NH; ++j)
-        if (j < live) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bs[(kk + lk) * LDW + j * 32 + li], acc[j], 0, 0, 0);
-    }
-    if (more) {
-      wide_store<A_KCONTIG, BM, LDT, PA>(As0 + (cur ^ 1) * BK * LDT, ra);
-      wide_store<B_KCONTIG, BNW, LDW, PB>(Bs0 + (cur ^ 1) * BK * LDW, rb);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-#pragma unroll
-  for (int j = 0; j < NH; ++j) {
-    const int col = wn + j * 32 + li;
-    if (j >= live || col >= N) continue;
-    const float bv = bias != nullptr ? bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (row < M) {
-        float v = acc[j][r] + bv;
-        if (act == 1) v = v > 0.f ? v : 0.f;
-        C[static_cast<long long>(row) * ldc + col] = v;
-      }
-    }
-  }
-}
-
-template <bool AK, bool BK_, int NH>
-static void launch_wide(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
-                        int K, const float* bias, int act, hipStream_t s) {
-  const size_t lds = static_cast<size_t>(2) * BK * (LDT + WideGeom<NH>::LDW) * sizeof(float);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_wide_kernel<AK, BK_, NH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  hipLaunchKernelGGL((gemm_f32_wide_kernel<AK, BK_, NH>), dim3((M + BM - 1) / BM), dim3(kWideThreads), lds, s, A, lda, B, ldb, C,
-                     ldc, M, N, K, bias, act, vec_ok(A, lda), vec_ok(B, ldb));
-}
 
 // C[i] = sum_z part[z][i] in a fixed order.  A workgroup owns 64 outputs; its 4 wavefronts take every 4th slice
 // (4 independent partial sums each, so the loads overlap) and meet in LDS.  The earlier one-thread-per-output
@@ -2048,12 +1522,8 @@ static bool vec_ok(const float* p, long long ld) { return (reinterpret_cast<uint
 // reads of 64 different lines thrashed the L1: 8x the L2 traffic, slower than the tile kernel), turned into that layout
 // through a wavefront-private 8 KB of LDS (no barrier), and the next slab's requests are in flight under the current
 // slab's 64 MFMAs.  MFMA-bound rate: 64 x 64 cycles per slab and SIMD = 9.6 TB/s of traffic, above what HBM delivers.
-#ifndef RBX_NT_STORE
 #define RBX_NT_STORE 0   /* measured on SASRec (profiles/r03): plain stores 10.27 ms, streamed stores 10.33 */
-#endif
-#ifndef RBX_NT_EPI
 #define RBX_NT_EPI 1
-#endif
 constexpr int kSlabWaves = 4;              // wavefronts per workgroup (independent of each other)
 constexpr int kSlabLd = 64 + 4;            // LDS row pitch of a slab (floats): b128 reads of 32 rows spread over the banks
 // A slab = 32 rows of 64 floats, fetched as eight 1 KB requests: request p covers rows 4 p .. 4 p + 3, lane l takes floats
@@ -2492,16 +1962,10 @@ __global__ __launch_bounds__(64 * kSlabWaves, 2) void tall_dw64_kernel(const flo
   }
 }
 
-static int dw64_abl() {
-  static const int v = [] { const char* e = getenv("RBX_DW64_ABL"); return e ? atoi(e) : 0; }();
-  return v;
-}
-static int dw64_wgs() {
-  static const int v = [] { const char* e = getenv("RBX_DW64_WGS"); return e ? atoi(e) : 0; }();
-  return v;
-}
+// RBX_GEMM_BX6=0: every GEMM on v_mfma_f32_32x32x2_f32 (exact f32 products; A/B measurements, debugging); default 1: weights
+// with registered bf16 planes run the split-operand kernels on the bf16 matrix cores
 static int bx6_mode() {
-  static const int v = [] { const char* e = getenv("RBX_GEMM_BX6"); return e ? atoi(e) : 1; }();
+  static const int v = [] { const char* e = getenv("RBX_GEMM_BX6"); return (e != nullptr && atoi(e) == 0) ? 0 : 1; }();
   return v;
 }
 // weights whose bf16 planes the caller has made for the GEMM calls it is about to issue (rbx_split_register)
@@ -2524,47 +1988,13 @@ static bool split_find(const float* w, int transposed, int rows, int cols, Split
     }
   return false;
 }
-static int dw_bx6_mode() {
-  static const int v = [] { const char* e = getenv("RBX_GEMM_BX6_DW"); return e ? atoi(e) : 1; }();
-  return v;
-}
-static int stream64_mode() {
-  static const int mode = [] { const char* e = getenv("RBX_GEMM_STREAM64"); return e ? atoi(e) : 1; }();
-  return mode;
-}
-
-// RBX_GEMM_WIDE=1 routes 64 < N <= 448 with N % 128 != 0 to the wide kernel, 2 also N = 128 / 256 / 384.  Off by default:
-// measured at cfg 4 (profiles/r02/gemm_variants.txt) the layer-1 forward takes 0.957 ms wide against 0.930 ms on the
-// 128 x 128 + narrow pair, the whole step 7.07 against 7.02 ms -- parity at best: the k-loop, not the tiling, is the limit.
-// Unused dynamic LDS that limits the 128 x 128 kernel to THREE workgroups per CU (3 x (33.8 + 8) KB fit, a fourth does not)
-// when that makes the launch whole rounds of the resident set: 1536 tiles (cfg 4's [65536, 1677] x [1677, 400]) are 1.5 rounds
-// of 1024 resident workgroups but exactly 2 rounds of 768.  RBX_GEMM_ROUNDS=0 switches it off.
-static size_t gemm_lds_pad(long long wgs) {
-  static const int mode = [] { const char* e = getenv("RBX_GEMM_ROUNDS"); return e ? atoi(e) : 0; }();
-  if (mode == 0) return 0;
-  if (mode == 2) return 8192;                       // always three per CU
-  const long long r4 = (wgs + 4 * kCUs - 1) / (4 * kCUs), r3 = (wgs + 3 * kCUs - 1) / (3 * kCUs);
-  const double e4 = static_cast<double>(wgs) / (r4 * 4.0 * kCUs), e3 = static_cast<double>(wgs) / (r3 * 3.0 * kCUs);
-  return (e3 > e4 + 0.1) ? 8192 : 0;
-}
-
-static int wide_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("RBX_GEMM_WIDE");
-    mode = (e != nullptr) ? atoi(e) : 0;
-  }
-  return mode;
-}
-
 // generic driver: C[M,N] = op(A) op(B)
 template <bool AK, bool BK_>
 static int run_gemm(const float* A, long long lda, const float* B, long long ldb, float* C, int M, int N, int K,
                     const float* bias, int act, float* ws, size_t ws_floats, hipStream_t s, long long ldc = 0,
                     const Epi epi = Epi{}) {
   if (ldc == 0) ldc = N;
-  const bool has_epi = epi.res != nullptr || epi.mask != nullptr || epi.rowscale != nullptr || epi.fm_x != nullptr ||
-                       epi.bn_mode != 0;
+  const bool has_epi = epi.res != nullptr || epi.mask != nullptr || epi.rowscale != nullptr || epi.fm_x != nullptr;
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   int splits = 1;
   const long long tiles = static_cast<long long>(tm) * tn;
@@ -2591,8 +2021,8 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     splits = best;
   }
   // 64 -> 64 over many rows: the streaming kernel with the weights in registers
-  if (AK && K == 64 && N == 64 && splits == 1 && epi.fm_x == nullptr && epi.bn_mode == 0 && M >= 2048 && vec_ok(A, lda) &&
-      (!BK_ || vec_ok(B, ldb)) && stream64_mode() > 0) {
+  if (AK && K == 64 && N == 64 && splits == 1 && epi.fm_x == nullptr && M >= 2048 && vec_ok(A, lda) &&
+      (!BK_ || vec_ok(B, ldb)) && true) {
     const int slabs = (M + 31) / 32;
     int wgs = (slabs + kSlabWaves - 1) / kSlabWaves;
     if (wgs > 2 * kCUs) wgs = 2 * kCUs;              // two workgroups of four wavefronts per CU: two wavefronts per SIMD
@@ -2607,7 +2037,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     return check_launch("gemm_f32_k64n64_kernel");
   }
   // dW = dy^T x of a compute-bound tower layer: the split-operand kernel with transposed staging, K (the batch) split
-  if (!AK && !BK_ && bx6_mode() == 1 && dw_bx6_mode() > 0 && ws != nullptr && !has_epi && ldc == N && K >= 8192 && M >= 128 &&
+  if (!AK && !BK_ && bx6_mode() == 1 && ws != nullptr && !has_epi && ldc == N && K >= 8192 && M >= 128 &&
       N >= 128) {
     const int tm2 = (M + PBM - 1) / PBM;
     const int n_tiles = tm2 * tn;
@@ -2638,8 +2068,8 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     }
   }
   // 64 -> 128 and 128 -> 64 over many rows: the slab kernel with the weights in LDS
-  if (AK && splits == 1 && epi.fm_x == nullptr && epi.mask == nullptr && epi.rowscale == nullptr && epi.bn_mode == 0 &&
-      M >= 2048 && vec_ok(A, lda) && stream64_mode() > 0 && ((K == 64 && N == 128) || (K == 128 && N == 64))) {
+  if (AK && splits == 1 && epi.fm_x == nullptr && epi.mask == nullptr && epi.rowscale == nullptr &&
+      M >= 2048 && vec_ok(A, lda) && true && ((K == 64 && N == 128) || (K == 128 && N == 64))) {
     const int slabs = (M + 31) / 32;
     int wgs = (slabs + kSlabWaves - 1) / kSlabWaves;
     if (wgs > 2 * kCUs) wgs = 2 * kCUs;
@@ -2655,9 +2085,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     SplitEntry e;
     if (split_find(B, BK_ ? 0 : 1, BK_ ? N : K, BK_ ? K : N, &e)) {
       const int kp = (K + SBK - 1) / SBK * SBK;
-      if (epi.bn_mode != 0 && (bx6_mode() == 2 || M < 2 * PBM))
-        return fail(RBX_ERR_UNSUPPORTED, "linear: BatchNorm statistics come out of the 256-row split-operand kernel only");
-      if (bx6_mode() == 2 || M < 2 * PBM) {           // RBX_GEMM_BX6=2: the 128 x 128 form (A/B measurements); few rows
+      if (M < 2 * PBM) {                               // few rows: the 128 x 128 form
         hipLaunchKernelGGL(gemm_bx6_kernel, dim3(tn * tm), dim3(256), 0, s, A, lda, e.planes, kp, C, ldc, M, N, K, bias, act, tm,
                            tn, epi);
       } else {
@@ -2667,32 +2095,12 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
         }();
         (void)attr_set;
         const int tm2 = (M + PBM - 1) / PBM;
-        static const bool bxq = [] {
-          const char* en = getenv("RBX_GEMM_BXQ");
-          return en != nullptr && atoi(en) == 1 &&
-                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bxq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     2 * (QBUF_A + QBUF_B) * 2) == hipSuccess;
-        }();
-        if (bxq)
-          hipLaunchKernelGGL(gemm_bxq_kernel, dim3(tn * tm2), dim3(PTHREADS), 2 * (QBUF_A + QBUF_B) * 2, s, A, lda, e.planes, kp,
-                             C, ldc, M, N, K, bias, act, tm2, tn, epi);
-        else
-          hipLaunchKernelGGL(gemm_bxp_kernel, dim3(tn * tm2), dim3(PTHREADS), 2 * (PBUF_A + PBUF_B) * 2, s, A, lda, e.planes, kp,
-                             C, ldc, M, N, K, bias, act, tm2, tn, epi);
+        hipLaunchKernelGGL(gemm_bxp_kernel, dim3(tn * tm2), dim3(PTHREADS), 2 * (PBUF_A + PBUF_B) * 2, s, A, lda, e.planes, kp,
+                           C, ldc, M, N, K, bias, act, tm2, tn, epi);
       }
       g_bx6_launches.fetch_add(1, std::memory_order_relaxed);
       return check_launch("gemm_bx6_kernel");
     }
-  }
-  if (epi.bn_mode != 0)
-    return fail(RBX_ERR_UNSUPPORTED, "linear: BatchNorm statistics need the weight's bf16 planes registered (rbx_split_register)");
-  // one column tile of at most 416 columns and many rows: the wide kernel (no narrow companion, A read once)
-  const int wmode = wide_mode();
-  if (splits == 1 && !has_epi && M >= 2048 && N > 64 && N <= 448 && wmode > 0 && (N % BN != 0 || wmode > 1)) {
-    if (N <= 128) launch_wide<AK, BK_, 2>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, s);
-    else if (N <= 256) launch_wide<AK, BK_, 4>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, s);
-    else launch_wide<AK, BK_, 7>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, s);
-    return check_launch("gemm_f32_wide_kernel");
   }
   int kps = (K + splits - 1) / splits;
   kps = (kps + BK - 1) / BK * BK;
@@ -2700,21 +2108,17 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
   float* dst = (splits > 1) ? ws : C;
   // the last partial column tile: when it is at most 64 columns wide (and K is not split) it goes to the narrow kernel
   const int tail = N % BN;
-#ifndef RBX_GEMM_NARROW_TAIL
 #define RBX_GEMM_NARROW_TAIL 1
-#endif
   // RBX_GEMM_NARROW_TAIL=1: a tail of at most 64 columns behind full column tiles goes to the narrow kernel (a second
   // launch that re-reads A); 0: the main kernel's edge-tile path takes it in the same launch (A comes from the L2).
   // Measured at cfg 4 (N = 400 = 3 x 128 + 16, profiles/r02/gemm_variants.txt): layer-1 forward 820 us with the narrow
   // launch, 856 in one launch (a fourth workgroup slot per row block for 4 % of the columns); 400 x 400: 214 vs 230.
   const int tn_full = (splits == 1 && tail > 0 && tail <= 64 && (RBX_GEMM_NARROW_TAIL || N < BN)) ? N / BN : tn;
-#ifndef RBX_GEMM_NARROW_INSIDE
 #define RBX_GEMM_NARROW_INSIDE 1
-#endif
   const bool inside = RBX_GEMM_NARROW_INSIDE && tn_full > 0 && tn_full < tn;       // the narrow tail rides in the main launch
   if (tn_full > 0)
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(tn_full * tm * splits + (inside ? tm : 0)), dim3(256),
-                       gemm_lds_pad(tn_full * tm * splits), s, A, lda, B, ldb, dst,
+                       0, s, A, lda, B, ldb, dst,
                        (splits > 1) ? static_cast<long long>(N) : ldc, M, N, K, kps, bias, act, vec_ok(A, lda),
                        vec_ok(B, ldb), tm, tn_full, splits, inside ? tm : 0, tail <= 32 ? 1 : 2, epi);
   if (tn_full < tn && !inside) {
@@ -2826,13 +2230,10 @@ extern "C" int rbx_linear_dx_deepfm(const float* d_dy, int64_t dy_stride, const 
 }
 
 // split-K scratch of the weight gradient: room for 2 x CUs slices of [n, k], at most 64 MiB
-// workgroups of tall_dw_kernel at most (each leaves an [n, k] partial): RBX_TALL_WGS, default 4 per CU -- measured on
+// workgroups of tall_dw_kernel at most (each leaves an [n, k] partial): 4 per CU -- measured on
 // SASRec's [819 200, 64] x [819 200, 64] weight gradients: 158 us with 512 workgroups, 118 with 1024, 124 with 2048 (and the
 // reduce over the partials grows with them).
-static int tall_wgs_max() {
-  static const int v = [] { const char* e = getenv("RBX_TALL_WGS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 4 * rbx::kCUs; }();
-  return v;
-}
+static int tall_wgs_max() { return 4 * rbx::kCUs; }
 
 static size_t dw_ws_floats(int32_t n, int32_t k) {
   const size_t slices = static_cast<size_t>(tall_wgs_max() > 2 * rbx::kCUs ? tall_wgs_max() : 2 * rbx::kCUs);
@@ -2913,19 +2314,18 @@ extern "C" int rbx_linear_bwd(const float* d_x, int64_t x_stride, const float* d
     rc = run_gemm<true, false>(g, n, d_w, k, d_dx, M, k, n, nullptr, 0, nullptr, 0, s, dx_stride);
     if (rc != RBX_OK) return rc;
   }
-  if (d_dw != nullptr && n == 64 && k == 64 && m >= 8192 && vec_ok(g, n) && vec_ok(d_x, x_stride) && stream64_mode() > 0 &&
+  if (d_dw != nullptr && n == 64 && k == 64 && m >= 8192 && vec_ok(g, n) && vec_ok(d_x, x_stride) && true &&
       dw_floats >= static_cast<size_t>(2 * kCUs) * 64 * 64) {
     const int slabs = (M + 31) / 32;
     int n_wg = (slabs + kSlabWaves - 1) / kSlabWaves;
     if (n_wg > 2 * kCUs) n_wg = 2 * kCUs;
-    if (dw64_wgs() > 0 && n_wg > dw64_wgs()) n_wg = dw64_wgs();
     float* part = ws + dw_floats;
     hipLaunchKernelGGL(tall_dw64_kernel<false>, dim3(n_wg), dim3(64 * kSlabWaves), 0, s, g, static_cast<long long>(n), d_x,
-                       static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr, dw64_abl(), nullptr);
+                       static_cast<long long>(x_stride), M, ws, d_db != nullptr ? part : nullptr, 0, nullptr);
     launch_splitk_reduce(s, 64u, ws, 64LL * 64, n_wg, d_dw, d_db != nullptr ? part : nullptr, 64LL, d_db);
     return check_launch("tall dW / db kernels (slab form)");
   }
-  if (d_dw != nullptr && n == 128 && k == 64 && m >= 8192 && vec_ok(g, n) && vec_ok(d_x, x_stride) && stream64_mode() > 0 &&
+  if (d_dw != nullptr && n == 128 && k == 64 && m >= 8192 && vec_ok(g, n) && vec_ok(d_x, x_stride) && true &&
       dw_floats >= static_cast<size_t>(2 * kCUs) * 64 * 64) {
     // [m, 128]^T x [m, 64] (the fused K | V projection): the slab kernel once per 64-column half of g (x read twice: 840 MB
     // of coalesced 1 KB requests against tall_dw_kernel<2>'s 630 MB of dword requests, 150 vs 199 us)
@@ -3076,50 +2476,4 @@ extern "C" int rbx_split_unregister(const float* d_w) {
   for (int i = 0; i < kSplitSlots; ++i)
     if (g_split[i].w == d_w) g_split[i] = SplitEntry{nullptr, nullptr, 0, 0, 0};
   return RBX_OK;
-}
-
-// ---- BatchNorm statistics out of the GEMMs around a BatchNorm -----------------------------------------------
-// rechub's towers are Linear -> BatchNorm1d -> act (third_party/rechub/basic/layers.py:250-266).  Forward: the Linear's GEMM
-// leaves the per-(64-row block, column) (n, mean, M2) of its output, the BatchNorm starts at its final kernel
-// (rbx_batchnorm_stats_from_partials + rbx_batchnorm_apply: two launches instead of three, no read of y for the statistics).
-// Backward: the dx GEMM of the NEXT Linear, whose output is the gradient of this BatchNorm's ReLU output a, applies the ReLU
-// mask and leaves (sum g, sum g xhat) per block and column; the BatchNorm's backward is its final kernel + the dx pass
-// (rbx_batchnorm_bwd_sums_from_partials + rbx_batchnorm_bwd_dx).  Both need the weight's bf16 planes registered and >= 512
-// rows (the statistics live in gemm_bxp_kernel's epilogue); RBX_ERR_UNSUPPORTED otherwise: the caller takes the separate passes.
-extern "C" int rbx_linear_fwd_bnstats(const float* d_x, int64_t x_stride, const float* d_w, const float* d_bias, int64_t m,
-                                      int32_t n, int32_t k, float* d_y, float* d_partial, void* stream) {
-  using namespace rbx;
-  if (m <= 0 || m > INT_MAX || n <= 1 || k <= 0) return fail(RBX_ERR_INVALID, "linear_fwd_bnstats: bad shape");
-  if (!d_x || !d_w || !d_y || !d_partial) return fail(RBX_ERR_INVALID, "linear_fwd_bnstats: NULL tensor");
-  if (x_stride < k) return fail(RBX_ERR_INVALID, "linear_fwd_bnstats: x_stride < k");
-  Epi epi{};
-  epi.bn_mode = 1;
-  epi.bn_part = d_partial;
-  return run_gemm<true, true>(d_x, x_stride, d_w, k, d_y, static_cast<int>(m), n, k, d_bias, 0, nullptr, 0, as_stream(stream), n,
-                              epi);
-}
-
-extern "C" int rbx_linear_dx_bnsums(const float* d_dy, int64_t dy_stride, const float* d_w, int64_t m, int32_t n, int32_t k,
-                                    const float* d_a, int64_t a_stride, const float* d_bn_x, int64_t bn_x_stride,
-                                    const float* d_bn_mean, const float* d_bn_rstd, const float* d_bn_gamma,
-                                    const float* d_bn_beta, float* d_dx, int64_t dx_stride, float* d_partial, void* stream) {
-  using namespace rbx;
-  if (m <= 0 || m > INT_MAX || n <= 0 || k <= 1) return fail(RBX_ERR_INVALID, "linear_dx_bnsums: bad shape");
-  if (!d_dy || !d_w || !d_a || !d_bn_x || !d_bn_mean || !d_bn_rstd || !d_dx || !d_partial)
-    return fail(RBX_ERR_INVALID, "linear_dx_bnsums: NULL tensor");
-  if (dy_stride < n || a_stride < k || bn_x_stride < k || dx_stride < k)
-    return fail(RBX_ERR_INVALID, "linear_dx_bnsums: a row stride is shorter than its row");
-  Epi epi{};
-  epi.mask = d_a;
-  epi.ldmask = static_cast<long long>(a_stride);
-  epi.bn_mode = 2;
-  epi.bn_part = d_partial;
-  epi.bn_x = d_bn_x;
-  epi.bn_ldx = static_cast<long long>(bn_x_stride);
-  epi.bn_mean = d_bn_mean;
-  epi.bn_rstd = d_bn_rstd;
-  epi.bn_gamma = d_bn_gamma;
-  epi.bn_beta = d_bn_beta;
-  return run_gemm<true, false>(d_dy, dy_stride, d_w, k, d_dx, static_cast<int>(m), k, n, nullptr, 0, nullptr, 0, as_stream(stream),
-                               dx_stride, epi);
 }

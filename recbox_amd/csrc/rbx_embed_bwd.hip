@@ -162,11 +162,9 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
   // take the sort-free path -- 40 left 205 workgroups on 256 CUs, each walking 5 dependent rounds of gathers: 69-80 us;
   // 16 pairs per group: 49 us (profiles/r03).  Rule: at least 32 768 chunks, between 16 and 40 pairs, a multiple of 8.
   {
-    static const int forced = [] { const char* e = getenv("RBX_REDUCE_CHUNK"); return e != nullptr ? atoi(e) : 0; }();
     int c = static_cast<int>(p->n_lookups / 32768u) / 8 * 8;
     if (c < 16) c = 16;
     if (c > kChunk) c = kChunk;
-    if (forced >= 8 && forced <= kChunk) c = forced / 8 * 8;
     p->chunk = c;
   }
   p->n_chunks = (p->n_lookups + p->chunk - 1) / p->chunk;

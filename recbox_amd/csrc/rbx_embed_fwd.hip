@@ -192,15 +192,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const FieldPack P, const
 // contiguous bytes per sample and evens out ragged lengths inside a wave.  Summation order is fixed by
 // (R, list order) -> deterministic, and equal to sequence order when R == 1.
 template <int G, int R, int NV, bool VEC>
-#ifndef RBX_SEQ_WAVES
 #define RBX_SEQ_WAVES 4
-#endif
-#ifndef RBX_SEQ_SG16
 #define RBX_SEQ_SG16 32
-#endif
-#ifndef RBX_SEQ_U
 #define RBX_SEQ_U 4
-#endif
 __global__ __launch_bounds__(256, RBX_SEQ_WAVES) void embed_seq_kernel(const FieldPack P, const int F, const long long B,
                                                         float* __restrict__ out, const long long stride_b,
                                                         float* __restrict__ row_scale,
@@ -208,9 +202,7 @@ __global__ __launch_bounds__(256, RBX_SEQ_WAVES) void embed_seq_kernel(const Fie
   constexpr int W = G / R;                                // lanes that hold one row
   using Frag = RowFrag<W, NV, VEC>;
   constexpr int U = (NV * (VEC ? 4 : 1) <= 4) ? RBX_SEQ_U : 4;   // rows in flight per lane
-#ifndef RBX_SEQ_IPL16
 #define RBX_SEQ_IPL16 4
-#endif
   constexpr int IPL = (G >= 32) ? 4 : RBX_SEQ_IPL16;                  // ids per lane per chunk (chunk = 128..256 lookups)
   constexpr int C = G * IPL;                              // lookups per chunk
   constexpr int GPB = 256 / G;
@@ -341,9 +333,7 @@ static int launch_fwd(bool seq, const FieldPack& pack, int F, int64_t B, float* 
   const int groups_per_block = 256 / (seq ? SG : G);
   long long blocks = (npairs + groups_per_block - 1) / groups_per_block;
   if (seq) blocks = ((B + 64 / SG - 1) / (64 / SG) * F + 3) / 4;          // 4 wave tasks per workgroup
-#ifndef RBX_FWD_BLOCKS_PER_CU
 #define RBX_FWD_BLOCKS_PER_CU 32   // 8 left the one-id gather latency-bound: [B,39,16] at B=65536 took 130 us, 100 us with 32 (64: 105)
-#endif
   const long long cap = static_cast<long long>(kCUs) * (seq ? 64 : RBX_FWD_BLOCKS_PER_CU);   // sequences: one pair per group, many waves
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;

@@ -27,7 +27,6 @@
 #include <stdlib.h>
 #include "rbx_segreduce.h"
 #include "rbx_tiera.h"
-#include "rbx_tierc.h"
 
 namespace rbx {
 
@@ -46,9 +45,7 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
   // SLOWER (94 vs 58 us at B=65 536) -- the gather is bound by the random-row request rate, not latency.
   // More wavefronts do not help either: a sample's feature batches dealt to 2 / 4 neighbouring lane groups (2x / 4x
   // the wavefronts, partial sums joined by a shuffle) took 102 / 149 us instead of 46.
-#ifndef RBX_FM_U
 #define RBX_FM_U 8
-#endif
   constexpr int U = (NA <= 4) ? RBX_FM_U : 4;
   const int lane_g = threadIdx.x % G;
   const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / G);
@@ -216,9 +213,7 @@ __global__ __launch_bounds__(256) void fm_fused_fwd_kernel(const FmPack P, const
 }
 
 // ---- backward policy: contribution g_b * S_b, cnt += g_b; flush dW = A - cnt*w ------------
-#ifndef RBX_ABL
 #define RBX_ABL 0        // ablation mask for measurements only (profiles/scripts): 1 no LR-gradient store, 2 no w_r read,
-#endif                   // 4 no S gather, 8 no dW store -- a non-zero value computes WRONG gradients
 struct FmPolicy {
   static constexpr bool kHasCount = true;
   struct Args {
@@ -460,10 +455,7 @@ __global__ __launch_bounds__(256) void fm_extra_bwd_kernel(const float* __restri
 }
 
 // ---- host side -------------------------------------------------------------------------------
-static bool fm_fast_dtype() {                // RBX_FM_FAST_DTYPE=0: the generic forward for every call (A/B measurement)
-  static const bool on = [] { const char* e = getenv("RBX_FM_FAST_DTYPE"); return e == nullptr || e[0] != '0'; }();
-  return on;
-}
+static bool fm_fast_dtype() { return true; }   // (the generic decode for every call was the A/B arm: profiles/r02)
 
 struct FmHost {
   int F = 0, D = 0;
@@ -573,43 +565,18 @@ static int dispatch_fm_fwd(const FmHost& h, int64_t B, const float* bias, const 
 // batch: a persistent gradient buffer is cleared by the PREVIOUS step's plan (rbx_fm_rezero), which must agree with this
 // step's about who writes which table in full.  Tables are admitted in ascending row count while the gradients of the
 // admitted ones stay under 4 MB (the partial arrays are that times the number of 2048-sample blocks).
-static int fm_tier_a_max_vocab() {      // RBX_FM_TIER_A=0: every table through the global sort (A/B measurement)
-  static const int v = [] {
-    const char* e = getenv("RBX_FM_TIER_A");
-    if (e != nullptr && e[0] == '0') return 0;
-    const char* m = getenv("RBX_FM_TIER_A_VMAX");
-    // default 4096 rows: measured at the Criteo shape (profiles/r03), 2200 / 4096 / 16384 give 0.257 / 0.251 / 0.253 ms per
-    // step -- a table of 5 000-15 000 rows costs as much either way (block partials that hardly merge vs L2-resident rows in
-    // the sorted path), and the partial arrays of the 16384 setting are 3x the workspace
-    int x = (m != nullptr) ? atoi(m) : 4096;
-    if (x > kTaMaxVocab) x = kTaMaxVocab;
-    return x < 0 ? 0 : x;
-  }();
-  return v;
-}
-
-// Tier C (rbx_tierc.h): the remaining tables of one-id-per-sample fields without a global multi-pass sort.  A process-wide
-// switch, because every entry point derives the SAME plan from the descriptors alone (RBX_FM_TIER_C / rbx_fm_tier_c).
-// OFF by default: built, parity-tested (bit-identical on repeat, == the sorted path to 1e-6) and measured at the Criteo
-// shape (profiles/r04/INDEX.md) -- the step has 12-13 kernels instead of 23 and runs at 0.230-0.238 ms against 0.237-0.239
-// with the tier off: within run-to-run noise, because both forms move the same random 64-byte lines (w_r read, dW store,
-// dLR store, two clears: five line operations per pair, ~85 us of the ~47 G lines/s this GPU delivers) and the partition
-// pass beside the forward kernel slows THAT kernel from 42 to 47-52 us (roofline.frac 0.40 -> 0.32-0.35); with
-// log-uniform ids it is slower (0.31-0.32 vs 0.27 ms: a hot id's bucket is several 2048-pair fills of one workgroup).
-static int g_tier_c = -1;
-static bool fm_tier_c_on() {
-  if (g_tier_c < 0) {
-    const char* e = getenv("RBX_FM_TIER_C");
-    g_tier_c = (e != nullptr && e[0] == '1') ? 1 : 0;
-  }
-  return g_tier_c != 0;
+static int fm_tier_a_max_vocab() {
+  // 4096 rows: measured at the Criteo shape (profiles/r03), 2200 / 4096 / 16384 give 0.257 / 0.251 / 0.253 ms per step -- a
+  // table of 5 000-15 000 rows costs as much either way (block partials that hardly merge vs L2-resident rows in the sorted
+  // path), and the partial arrays of the 16384 setting are 3x the workspace
+  return 4096 < kTaMaxVocab ? 4096 : kTaMaxVocab;
 }
 
 // plan over the categorical features (keys from `lead`, grads from emb and lr): the tables of tier A go to `ta`, the
 // others to the sort plan `p`, whose id columns are the rows of the compact id matrix (patched in by fm_bind_cid once
 // the workspace is known)
 static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t B, BwdPlan* p, FmNumPack* np,
-                   int* n_num, TaPlan* ta, TcPlan* tc, int* cid_of_key, int* key_src = nullptr, int* tab_src = nullptr) {
+                   int* n_num, TaPlan* ta, int* cid_of_key, int* key_src = nullptr, int* tab_src = nullptr) {
   rbx_field_t tmp[RBX_MAX_FIELDS];
   const rbx_field_t* lead = (emb != nullptr) ? emb : lr;
   *n_num = 0;
@@ -619,8 +586,6 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
   *ta = TaPlan();
   ta->D = D;
   ta->has_emb = emb != nullptr;
-  *tc = TcPlan();
-  tc->D = D;
   for (int i = 0; i < n; ++i) {
     if (lead[i].kind == RBX_FIELD_NUMERIC) {
       FmNumField& f = np->f[(*n_num)++];
@@ -677,28 +642,10 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
     }
     for (int c = 0; c < n_cat; ++c) in_a[c] = tab_a[tab_of[c]];
   }
-  // ---- tier C: what is left, when it is a table of ONE one-id-per-sample field whose rows the float4 kernels can take ----
-  bool tab_c[RBX_MAX_FIELDS], in_c[RBX_MAX_FIELDS];
-  for (int t = 0; t < n_tabs; ++t) tab_c[t] = false;
-  if (emb != nullptr && fm_tier_c_on() && D % 4 == 0 && D <= 64 && B > 0 && B < (1ll << 31)) {
-    for (int t = 0; t < n_tabs; ++t) {
-      if (tab_a[t]) continue;
-      int users = 0;
-      for (int c = 0; c < n_cat; ++c) users += (tab_of[c] == t) ? 1 : 0;
-      const int i0 = cat_src[tab_first[t]];
-      const rbx_field_t& a = lead[i0];
-      const int stride = (emb[i0].table_stride != 0) ? static_cast<int>(emb[i0].table_stride) : D;
-      if (users != 1 || a.seq_len != 1 || a.pool != RBX_POOL_NONE || a.vocab <= 0 || a.vocab > kTcMaxVocab) continue;
-      if (emb[i0].grad == nullptr || emb[i0].table == nullptr || stride % 4 != 0) continue;
-      if ((reinterpret_cast<uintptr_t>(emb[i0].grad) & 15) != 0 || (reinterpret_cast<uintptr_t>(emb[i0].table) & 15) != 0) continue;
-      tab_c[t] = true;
-    }
-  }
-  for (int c = 0; c < n_cat; ++c) in_c[c] = tab_c[tab_of[c]];
   // ---- the compact id matrix: one row per categorical feature with a gradient (only when some table is in tier A;
   //      otherwise the sort reads the id columns where they are, as rbx_embed_sort does) ----
   bool tiered = false;
-  for (int t = 0; t < n_tabs; ++t) tiered = tiered || tab_a[t] || tab_c[t];
+  for (int t = 0; t < n_tabs; ++t) tiered = tiered || tab_a[t];
   ta->n_cid = tiered ? n_cat : 0;
   bool strided = false;
   for (int c = 0; c < n_cat; ++c) {
@@ -753,36 +700,11 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
     }
   }
   ta_layout(ta, B);
-  // ---- tier C descriptors: 2^log_p partitions per table, ~kTcTarget pairs each ----
-  {
-    int log_p = 0;
-    while (log_p < kTcMaxLogP && ((B + (1ll << log_p) - 1) >> log_p) > kTcTarget) ++log_p;
-    tc->log_p = log_p;
-    tc->NB = static_cast<unsigned>((B + kTcList - 1) / kTcList);
-    for (int t = 0; t < n_tabs; ++t) {
-      if (!tab_c[t]) continue;
-      const int c0 = tab_first[t];
-      const int i0 = cat_src[c0];
-      TcTable& tb = tc->tab.t[tc->n_tab++];
-      tb.grad = emb[i0].grad;
-      tb.grad2 = lr ? lr[i0].grad : nullptr;
-      tb.table = emb[i0].table;
-      tb.stride = (emb[i0].table_stride != 0) ? static_cast<int>(emb[i0].table_stride) : D;
-      tb.vocab = static_cast<int>(lead[i0].vocab);
-      tb.pad = (lead[i0].padding_idx == RBX_NO_ID || lead[i0].padding_idx < INT_MIN || lead[i0].padding_idx > INT_MAX)
-                   ? kNoId : static_cast<int>(lead[i0].padding_idx);
-      tb.cid_row = c0;
-      tb.part0 = tc->n_parts;
-      tb.reserved = 0;
-      tc->n_parts += 1u << log_p;
-    }
-    tc_layout(tc, B);
-  }
   // ---- tier B: the sort plan ----
   int n_b = 0;
   int b_src[RBX_MAX_FIELDS];
   for (int c = 0; c < n_cat; ++c) {
-    if (in_a[c] || in_c[c]) continue;
+    if (in_a[c]) continue;
     const int i = cat_src[c];
     tmp[n_b] = lead[i];
     float* g1 = emb ? emb[i].grad : nullptr;
@@ -830,28 +752,25 @@ static size_t fm_num_bytes(const BwdPlan& p, int n_num, int D) {
 }
 
 // Everything one fused FM backward needs, derived from the descriptor arrays alone.  Workspace layout:
-//   [ sort plan of tier B: p.bytes | numeric partials: fm_num_bytes | tier A region (compact ids first): ta.bytes |
-//     tier C region (row-list counts, row lists): tc.bytes ]
+//   [ sort plan of tier B: p.bytes | numeric partials: fm_num_bytes | tier A region (compact ids first): ta.bytes ]
 struct FmFull {
   BwdPlan p;
   FmNumPack np;
   TaPlan ta;
-  TcPlan tc;
   int n_num = 0;
   int D = 1;
   int cid_of_key[RBX_MAX_FIELDS];
-  size_t off_ta = 0, off_tc = 0, bytes = 0;
+  size_t off_ta = 0, bytes = 0;
 };
 
 static int fm_full_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t B, FmFull* f) {
   if (emb == nullptr && lr == nullptr) return fail(RBX_ERR_INVALID, "fm: both field arrays are NULL");
   if (n <= 0 || n > RBX_MAX_FIELDS) return fail(RBX_ERR_INVALID, "fm: n_fields=%d not in [1,%d]", n, RBX_MAX_FIELDS);
-  int rc = fm_plan(emb, lr, n, B, &f->p, &f->np, &f->n_num, &f->ta, &f->tc, f->cid_of_key);
+  int rc = fm_plan(emb, lr, n, B, &f->p, &f->np, &f->n_num, &f->ta, f->cid_of_key);
   if (rc != RBX_OK) return rc;
   f->D = emb ? emb[0].dim : 1;
   f->off_ta = ta_align(f->p.bytes + fm_num_bytes(f->p, f->n_num, f->D));
-  f->off_tc = ta_align(f->off_ta + f->ta.bytes);
-  f->bytes = f->off_tc + f->tc.bytes;
+  f->bytes = f->off_ta + f->ta.bytes;
   return RBX_OK;
 }
 
@@ -862,14 +781,9 @@ int fm_update_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
   if (emb == nullptr && lr == nullptr) return fail(RBX_ERR_INVALID, "fm: both field arrays are NULL");
   if (n <= 0 || n > RBX_MAX_FIELDS) return fail(RBX_ERR_INVALID, "fm: n_fields=%d not in [1,%d]", n, RBX_MAX_FIELDS);
   FmNumPack np;
-  TcPlan tc;
   int n_num = 0, cid_of_key[RBX_MAX_FIELDS];
-  const int rc = fm_plan(emb, lr, n, B, p, &np, &n_num, ta, &tc, cid_of_key, src_of_key, src_of_tab);
+  const int rc = fm_plan(emb, lr, n, B, p, &np, &n_num, ta, cid_of_key, src_of_key, src_of_tab);
   if (rc != RBX_OK) return rc;
-  if (tc.n_tab != 0)
-    return fail(RBX_ERR_UNSUPPORTED, "fm sparse update: %d table(s) of this call took the sort-free tier C path, which keeps no "
-                                     "sorted ids to walk; call rbx_fm_tier_c(0) before the first step (recbox_amd.optim does)",
-                tc.n_tab);
   const int D = emb ? emb[0].dim : 1;
   *off_ta = ta_align(p->bytes + fm_num_bytes(*p, n_num, D));
   *bytes = *off_ta + ta->bytes;
@@ -892,21 +806,6 @@ static void fm_bind_cid(FmFull* f, char* ws, int64_t B) {
 
 }  // namespace rbx
 
-extern "C" int rbx_fm_rezero_fusable(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch) {
-  using namespace rbx;
-  if (batch <= 0) return 0;
-  FmFull f;
-  if (fm_full_plan(emb, lr, n_fields, batch, &f) != RBX_OK) return 0;
-  return (f.tc.n_tab > 0 && f.p.n_lookups == 0) ? 1 : 0;
-}
-
-extern "C" int rbx_fm_tier_c(int32_t enable) {
-  using namespace rbx;
-  const int was = fm_tier_c_on() ? 1 : 0;
-  if (enable >= 0) g_tier_c = enable ? 1 : 0;
-  return was;
-}
-
 extern "C" int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                              void* d_workspace, size_t workspace_bytes, void* stream) {
   using namespace rbx;
@@ -915,18 +814,10 @@ extern "C" int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int3
   int rc = fm_full_plan(emb, lr, n_fields, batch, &f);
   if (rc != RBX_OK) return rc;
   // (tier-A tables are written in full by every backward: nothing to clear)
-  if (f.p.n_lookups == 0 && f.tc.n_tab == 0) return RBX_OK;
-  if (d_workspace == nullptr || workspace_bytes < f.bytes) return fail(RBX_ERR_WORKSPACE, "fm_rezero: workspace too small");
-  if (f.tc.n_tab != 0) {                            // tier C: the rows named by the bucket arrays of the last partition pass
-    rc = tc_dispatch_rezero(f.tc, batch, static_cast<char*>(d_workspace) + f.off_tc, as_stream(stream));
-    if (rc != RBX_OK) return rc;
-  }
   if (f.p.n_lookups == 0) return RBX_OK;
+  if (d_workspace == nullptr || workspace_bytes < f.bytes) return fail(RBX_ERR_WORKSPACE, "fm_rezero: workspace too small");
   return launch_rezero(f.p, static_cast<const char*>(d_workspace), as_stream(stream));
 }
-
-namespace rbx {
-}  // namespace rbx
 
 extern "C" int rbx_fm_fwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                           const float* d_lr_bias, const float* d_extra, int32_t n_extra, int32_t extra_stride,
@@ -991,14 +882,6 @@ extern "C" int rbx_fm_sort_phases(const rbx_field_t* emb, const rbx_field_t* lr,
   if ((phases & 2) && f.p.n_lookups > 0) {      // tier B: global segmented radix sort (a one-tier call reads the id columns where they are)
     fm_bind_cid(&f, ws, batch);
     rc = run_sort(f.p, ws, f.ta.n_cid == 0 ? d_status : nullptr, s);
-    if (rc != RBX_OK) return rc;
-  }
-  if ((phases & 8) && (f.p.n_lookups > 0 || f.tc.n_tab == 0))
-    return fail(RBX_ERR_INVALID, "fm_sort: phases bit 3 (clear the previous step's rows inside the partition pass) needs every "
-                                 "sorted table on tier C (rbx_fm_rezero_fusable)");
-  if ((phases & 2) && f.tc.n_tab > 0) {         // tier C: one partition pass (count, scan, scatter) into the bucket arrays
-    rc = tc_launch_partition(f.tc, batch, reinterpret_cast<const int*>(ws + f.off_ta + f.ta.off_cid), ws + f.off_tc,
-                             (phases & 8) ? 1 : 0, s);
     if (rc != RBX_OK) return rc;
   }
   return RBX_OK;
@@ -1109,11 +992,6 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
     const bool vec = p.vec && ((reinterpret_cast<uintptr_t>(d_sum) & 15) == 0);
     rc = vec ? dispatch_reduce<FmPolicy, true>(p, args, keys, vals, ws, s)
              : dispatch_reduce<FmPolicy, false>(p, args, keys, vals, ws, s);
-    if (rc != RBX_OK) return rc;
-  }
-  if (f.tc.n_tab > 0 && (phases & 1) && !(phases & 16)) {   // the tables of tier C: scan, sort in LDS, reduce -- one launch
-    if ((reinterpret_cast<uintptr_t>(d_sum) & 15) != 0) return fail(RBX_ERR_INVALID, "fm: d_sum must be 16-byte aligned");
-    rc = tc_dispatch_bwd(f.tc, batch, d_dlogit, d_sum, accumulate, ws + f.off_tc, s);
     if (rc != RBX_OK) return rc;
   }
   if ((phases & 1) && !(phases & 8)) {               // the tables of tier A: block partials, then every row written once

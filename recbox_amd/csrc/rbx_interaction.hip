@@ -16,9 +16,7 @@
 // Modes 2/3 stage the sample's [F, D] block in LDS (one wavefront per sample).
 #include "rbx_internal.h"
 
-#ifndef RBX_FM_ROW_UNROLL
 #define RBX_FM_ROW_UNROLL 4   // rows of a sample in flight per lane group: backward 120 -> 108 us at [65536, 39, 16] (8: 119)
-#endif
 
 namespace rbx {
 

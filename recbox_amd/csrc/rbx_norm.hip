@@ -1003,26 +1003,3 @@ extern "C" int rbx_layernorm_bwd(const float* d_x, const float* d_dy, int64_t ro
   }
   return rc;
 }
-
-// ---- a BatchNorm whose partial statistics came out of the neighbouring GEMM (rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums,
-// csrc/rbx_dense.hip): the final kernels alone.  d_partial as those calls leave it: n_blocks x cols entries of 3 (n, mean, M2)
-// resp. 2 (sum g, sum g xhat) floats.
-extern "C" int rbx_batchnorm_stats_from_partials(const float* d_partial, int32_t n_blocks, int32_t cols, float eps,
-                                                 float momentum, float* d_running_mean, float* d_running_var, float* d_mean,
-                                                 float* d_rstd, void* stream) {
-  using namespace rbx;
-  if (n_blocks <= 0 || cols <= 0 || !d_partial || !d_mean || !d_rstd) return fail(RBX_ERR_INVALID, "batchnorm_stats_from_partials: bad arguments");
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((cols + 63) / 64), dim3(64 * kBnFinalWaves), 0, as_stream(stream), d_partial,
-                     n_blocks, cols, eps, momentum, d_running_mean, d_running_var, d_mean, d_rstd, static_cast<float*>(nullptr));
-  return check_launch("bn_stats_final_kernel");
-}
-
-extern "C" int rbx_batchnorm_bwd_sums_from_partials(const float* d_partial, int32_t n_blocks, int32_t cols, float* d_dgamma,
-                                                    float* d_dbeta, void* stream) {
-  using namespace rbx;
-  if (n_blocks <= 0 || cols <= 0 || !d_partial || !d_dgamma || !d_dbeta)
-    return fail(RBX_ERR_INVALID, "batchnorm_bwd_sums_from_partials: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, as_stream(stream), d_partial, n_blocks, cols,
-                     d_dbeta, d_dgamma, static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
-  return check_launch("bn_bwd_final_kernel");
-}

@@ -32,9 +32,7 @@ constexpr int kFinList = 3;      // fin[0] work-list length, fin[1] long-list le
 // Interior runs are written directly; a run that crosses the chunk border leaves a head /
 // tail summary and a flag, and the chunk where such a run ENDS is queued for the fix-up.
 // waves per SIMD the register budget is sized for: at 4 (128 VGPRs) the FM policy spilled 28 bytes per lane to scratch
-#ifndef RBX_REDUCE_WAVES
 #define RBX_REDUCE_WAVES 3
-#endif
 template <class Policy, int G, int NV, bool VEC>
 __global__ __launch_bounds__(256, RBX_REDUCE_WAVES) void segment_reduce_kernel(const RedPack P, const int n_cat,
                                                              const typename Policy::Args args,
@@ -70,9 +68,7 @@ __global__ __launch_bounds__(256, RBX_REDUCE_WAVES) void segment_reduce_kernel(c
   pre_last.zero();
   float cnt = 0.f;
   bool head_done = false;
-#ifndef RBX_REDUCE_U
 #define RBX_REDUCE_U 8
-#endif
   // lookups in flight per lane group: 8 for rows of up to 32 floats (the FM tables; 16 measured slower), 4 for wider rows
   // (D = 64 / 128: cfg 4 5.32 -> 5.29 ms, cfg 3 1.93 -> 1.82 ms with 4 instead of 8; with 16 cfg 3 took 2.87 ms)
   constexpr int U = (G * NV * F::W <= 32) ? RBX_REDUCE_U : 4;
@@ -99,9 +95,7 @@ __global__ __launch_bounds__(256, RBX_REDUCE_WAVES) void segment_reduce_kernel(c
     kk[U] = (i0 + U < e) ? keys[i0 + U] : key_after;          // key that follows the batch
     F rows[U], pre[U];
     float rc[U];
-#ifndef RBX_REDUCE_BATCHED
 #define RBX_REDUCE_BATCHED 1
-#endif
 #if RBX_REDUCE_BATCHED
     // Every load of the batch first, with NO use in between, then the arithmetic.  Written as "if (valid) rows[u] += w * load"
     // the batch was U dependent round trips: the compiler waits for a load inside the block that uses it (the ISA of the first

@@ -893,143 +893,6 @@ __global__ __launch_bounds__(64 * kSbWaves, 1) void sb_attn_in_bwd_kernel(const 
   if (threadIdx.x < kSbLnPart) A.part[static_cast<long long>(blockIdx.x) * kSbLnPart + threadIdx.x] = red[threadIdx.x];
 }
 
-// ---- the feed-forward half's backward WITHOUT dW2: 64 accumulators, two wavefronts per SIMD --------------------------------------
-// sb_ffn_bwd_kernel is one wavefront per SIMD because dW1 | dW2 are 128 accumulators (matrix pipe 0.52 busy).  dW2 = g^T h reads
-// only what exists before the backward starts, so it can stay with the slab dW kernel (rbx_linear_dwdb_scaled: 81 us); what is
-// left -- dh, dn, dW1, the LayerNorm backward: three products, 64 accumulators -- fits two wavefronts per SIMD, which hide each
-// other's LDS trips.  A slab's requests are issued in two groups and waited for one by one (as in sb_attn_in_bwd_kernel).
-constexpr int kSbFfn3Part = kSbW + 3 * 64;             // dW1 | db1 | dgamma | dbeta
-
-__global__ __launch_bounds__(64 * kSbWaves, 1) void sb_ffn_bwd3_kernel(const SbFfnBwdArgs A) {
-  extern __shared__ float sb_lds[];
-  float* w2t = sb_lds;
-  float* w1t = w2t + kSbW;
-  float* vec = w1t + kSbW;                     // gamma, beta
-  float* slabs = vec + 2 * 64;
-  sb_stage_weight(w2t, A.w2, 64, true);
-  sb_stage_weight(w1t, A.w1, 64, true);
-  sb_stage_vec(vec, A.ln_w, 1.f);
-  sb_stage_vec(vec + 64, A.ln_b, 0.f);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, m = lane & 31, h = lane >> 5;
-  const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-  const int nw = static_cast<int>(gridDim.x) * kSbWaves;
-  const int slabs_n = (A.M + 31) >> 5;
-  float* lds = slabs + wid * kSbSlab;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-  float db1[2] = {0.f, 0.f}, dgm[2] = {0.f, 0.f}, dbt[2] = {0.f, 0.f};
-  const float gmc[2] = {vec[m], vec[32 + m]}, btc[2] = {vec[64 + m], vec[96 + m]};
-  const unsigned lane_part = static_cast<unsigned>(16 * (lane & 15));
-  const unsigned lane_off = static_cast<unsigned>(256 * (lane >> 4)) + lane_part;
-  const float* keep_p = A.keep != nullptr ? A.keep : A.mean;
-  for (int s = static_cast<int>(blockIdx.x) * kSbWaves + wid; s < slabs_n; s += nw) {
-    const int r0 = s * 32;
-    const int left = A.M - r0;
-    f32x4 tg[8], th[8], tx[8];
-    float nkp, mu, rs;
-    unsigned off[8];
-    const unsigned lim = static_cast<unsigned>((left < 32 ? left : 32) - 1) * 256u + lane_part;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) off[p] = lane_off + 1024u * p < lim ? lane_off + 1024u * p : lim;
-    const long long o = static_cast<long long>(r0) * 64;
-    {
-      const unsigned ro = 4u * static_cast<unsigned>(r0 + m < A.M ? r0 + m : A.M - 1);
-      sb_issue_word(keep_p, ro, nkp);
-      sb_issue_word(A.mean, ro, mu);
-      sb_issue_word(A.rstd, ro, rs);
-      sb_issue(A.g0 + o, off, tg);
-      sb_issue(A.h + o, off, th);
-    }
-    float g[32], dh[32], dn[32];
-    sb_wait_tile3<8>(tg, nkp, mu, rs);
-    const float kp = (m < left) ? (A.keep != nullptr ? nkp : 1.f) : 0.f;      // rows beyond the end add nothing
-    sb_turn_in(lds, lane, tg, g);
-    sb_issue(A.x + o, off, tx);                           // (behind h: vmcnt counts down in order)
-#pragma unroll
-    for (int r = 0; r < 32; ++r) g[r] *= kp;
-    sb_gemm_row(w2t, lane, g, dh);
-    {
-      float hr[32];
-      sb_wait_tile<8>(th);                                // (x's eight requests may still be out)
-      sb_turn_in(lds, lane, th, hr);
-#pragma unroll
-      for (int r = 0; r < 32; ++r) dh[r] = hr[r] > 0.f ? dh[r] : 0.f;
-    }
-    sb_gemm_row(w1t, lane, dh, dn);
-#pragma unroll
-    for (int r = 0; r < 32; ++r) dn[r] += g[r];
-    float xh[32], xc[32];
-    {
-      float dc[32];
-      sb_row_to_col(lds, lane, dh, dc);
-      sb_wait_tile<0>(tx);
-      sb_turn_in(lds, lane, tx, xh);
-#pragma unroll
-      for (int r = 0; r < 32; ++r) xh[r] = (xh[r] - mu) * rs;
-      sb_row_to_col(lds, lane, xh, xc);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) db1[t] += dc[16 * t + q];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float n0 = xc[q] * gmc[0] + btc[0], n1 = xc[16 + q] * gmc[1] + btc[1];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[q], n0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[q], n1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[16 + q], n0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc[16 + q], n1, acc[1][1], 0, 0, 0);
-      }
-    }
-    {
-      float dc[32];
-      sb_row_to_col(lds, lane, dn, dc);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          dbt[t] += dc[16 * t + q];
-          dgm[t] += dc[16 * t + q] * xc[16 * t + q];
-        }
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int gq = 0; gq < 8; ++gq) {
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(vec + 32 * (gq >> 2) + 8 * (gq & 3) + 4 * h);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        dn[4 * gq + e] *= gm[e];
-        s1 += dn[4 * gq + e];
-        s2 += dn[4 * gq + e] * xh[4 * gq + e];
-      }
-    }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    const float m1 = s1 * (1.0f / 64.0f), m2 = s2 * (1.0f / 64.0f);
-#pragma unroll
-    for (int r = 0; r < 32; ++r) dn[r] = rs * (dn[r] - m1 - xh[r] * m2);
-    sb_store_lin(lds, lane, dn, A.dx + static_cast<long long>(r0) * 64, lane_off, left);
-  }
-  __syncthreads();
-  float* red = sb_lds;
-  for (int w = 0; w < kSbWaves; ++w) {
-    if (wid == w) {
-      sb_acc_to_lds(red, lane, acc, w == 0);
-      sb_colsum_to_lds(red + kSbW, lane, db1, w == 0);
-      sb_colsum_to_lds(red + kSbW + 64, lane, dgm, w == 0);
-      sb_colsum_to_lds(red + kSbW + 128, lane, dbt, w == 0);
-    }
-    __syncthreads();
-  }
-  float* dst = A.part + static_cast<long long>(blockIdx.x) * kSbFfn3Part;
-  for (int i = threadIdx.x; i < kSbFfn3Part; i += 64 * kSbWaves) dst[i] = red[i];
-}
-
 // ---- backward of the out-projection as ONE pass: dO = g Wo, dWo = g^T O, dbo = colsum g ------------------------------------
 // (a dW slab pass + a dx GEMM before: g read twice.)  64 accumulators: two wavefronts per SIMD still fit.
 constexpr int kSbOutPart = kSbW + 64;                  // dWo | dbo
@@ -1428,17 +1291,14 @@ extern "C" int rbx_seqblock_ffn_bwd(const float* d_dout, const float* d_keep, co
   SbFfnBwdArgs a{d_dout, d_keep, d_h, d_x, d_mean, d_rstd, d_ln_w, d_ln_b, d_w1, d_w2, d_dx, static_cast<float*>(d_workspace),
                  static_cast<int>(m)};
   const size_t lds = sizeof(float) * (2 * kSbW + 2 * 64 + 3 * kSbBwdWaves * kSbSlab);
-  static int order = -1;
-  if (order < 0) {
-    const char* e = getenv("RBX_SB_BWD_ORDER");
-    const int want = (e != nullptr && e[0] == '1') ? 1 : 0;   // measured: 353 vs 339 us (profiles/r04/INDEX.md)
-    const void* fn = want ? reinterpret_cast<const void*>(sb_ffn_bwd_kernel<1>) : reinterpret_cast<const void*>(sb_ffn_bwd_kernel<0>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+  static bool attr = false;                 // (the other order of the four products measured 353 vs 339 us: profiles/r04/INDEX.md)
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_ffn_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds)) != hipSuccess)
       return fail(RBX_ERR_LAUNCH, "rbx_seqblock_ffn_bwd: %zu bytes of LDS refused", lds);
-    order = want;
+    attr = true;
   }
-  if (order) hipLaunchKernelGGL(sb_ffn_bwd_kernel<1>, dim3(grid), dim3(64 * kSbBwdWaves), lds, as_stream(stream), a);
-  else hipLaunchKernelGGL(sb_ffn_bwd_kernel<0>, dim3(grid), dim3(64 * kSbBwdWaves), lds, as_stream(stream), a);
+  hipLaunchKernelGGL(sb_ffn_bwd_kernel<0>, dim3(grid), dim3(64 * kSbBwdWaves), lds, as_stream(stream), a);
   int rc = check_launch("sb_ffn_bwd_kernel");
   if (rc != RBX_OK) return rc;
   SbReduceArgs r{};
@@ -1575,51 +1435,5 @@ extern "C" int rbx_seqblock_inproj_dw(const float* d_dQ, const float* d_dKV, con
   r.seg_off[0] = 0; r.seg_len[0] = 3 * kSbW; r.dst[0] = d_dw;            // [192, 64] = dWq | dWk | dWv, in_proj_weight's layout
   r.seg_off[1] = 3 * kSbW; r.seg_len[1] = 192; r.dst[1] = d_db;
   hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbInPart + 31) / 32), dim3(256), 0, as_stream(stream), r);
-  return check_launch("sb_reduce_kernel");
-}
-
-// The same backward without dW2 / db2 (the caller forms them with rbx_linear_dwdb_scaled): sb_ffn_bwd3_kernel
-extern "C" size_t rbx_seqblock_ffn_bwd3_workspace_size(int64_t m) {
-  return m <= 0 ? 0 : sizeof(float) * static_cast<size_t>(sb_grid(m)) * kSbFfn3Part;
-}
-
-extern "C" int rbx_seqblock_ffn_bwd3(const float* d_dout, const float* d_keep, const float* d_h, const float* d_x,
-                                     const float* d_mean, const float* d_rstd, int64_t m, const float* d_ln_w,
-                                     const float* d_ln_b, const float* d_w1, const float* d_w2, float* d_dx, float* d_dw1,
-                                     float* d_db1, float* d_dgamma, float* d_dbeta, void* d_workspace,
-                                     size_t workspace_bytes, void* stream) {
-  if (m < 0 || m > (1LL << 30)) return fail(RBX_ERR_INVALID, "rbx_seqblock_ffn_bwd3: m = %lld", static_cast<long long>(m));
-  if (m == 0) return RBX_OK;
-  if (!d_dout || !d_h || !d_x || !d_mean || !d_rstd || !d_w1 || !d_w2 || !d_dx)
-    return fail(RBX_ERR_INVALID, "rbx_seqblock_ffn_bwd3: NULL operand");
-  if (!sb_aligned(d_dout) || !sb_aligned(d_h) || !sb_aligned(d_x) || !sb_aligned(d_dx))
-    return fail(RBX_ERR_UNSUPPORTED, "rbx_seqblock_ffn_bwd3: activations must be 16-byte aligned");
-  const size_t need = rbx_seqblock_ffn_bwd3_workspace_size(m);
-  if (d_workspace == nullptr || workspace_bytes < need)
-    return fail(RBX_ERR_WORKSPACE, "rbx_seqblock_ffn_bwd3: workspace %zu < %zu bytes", workspace_bytes, need);
-  const int grid = sb_grid(m);
-  SbFfnBwdArgs a{d_dout, d_keep, d_h, d_x, d_mean, d_rstd, d_ln_w, d_ln_b, d_w1, d_w2, d_dx, static_cast<float*>(d_workspace),
-                 static_cast<int>(m)};
-  const size_t lds = sizeof(float) * (2 * kSbW + 2 * 64 + kSbWaves * kSbSlab);
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_ffn_bwd3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(lds)) != hipSuccess)
-      return fail(RBX_ERR_LAUNCH, "rbx_seqblock_ffn_bwd3: %zu bytes of LDS refused", lds);
-    once = true;
-  }
-  hipLaunchKernelGGL(sb_ffn_bwd3_kernel, dim3(grid), dim3(64 * kSbWaves), lds, as_stream(stream), a);
-  int rc = check_launch("sb_ffn_bwd3_kernel");
-  if (rc != RBX_OK) return rc;
-  SbReduceArgs r{};
-  r.part = static_cast<const float*>(d_workspace);
-  r.nparts = grid;
-  r.stride = kSbFfn3Part;
-  r.nseg = 4;
-  const int offs[4] = {0, kSbW, kSbW + 64, kSbW + 128};
-  const int lens[4] = {kSbW, 64, 64, 64};
-  float* dsts[4] = {d_dw1, d_db1, d_dgamma, d_dbeta};
-  for (int j = 0; j < 4; ++j) { r.seg_off[j] = offs[j]; r.seg_len[j] = lens[j]; r.dst[j] = dsts[j]; }
-  hipLaunchKernelGGL(sb_reduce_kernel, dim3((kSbFfn3Part + 31) / 32), dim3(256), 0, as_stream(stream), r);
   return check_launch("sb_reduce_kernel");
 }

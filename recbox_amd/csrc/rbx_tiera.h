@@ -30,12 +30,8 @@ namespace rbx {
 constexpr int kTaBlock = 2048;                       // samples per (field, block) unit = one LDS sort tile
 constexpr int kTaOffBits = 11;
 constexpr unsigned kTaOffMask = (1u << kTaOffBits) - 1u;
-#ifndef RBX_TA_CHUNK
 #define RBX_TA_CHUNK 16
-#endif
-#ifndef RBX_TA_THREADS
 #define RBX_TA_THREADS 512
-#endif
 constexpr int kTaChunk = RBX_TA_CHUNK;               // sorted pairs one lane group walks in sequence
 constexpr int kTaChunks = kTaBlock / kTaChunk;       // 128
 constexpr int kTaThreads = RBX_TA_THREADS;           // of ta_reduce_kernel: 8 wavefronts per (field, block) unit
@@ -687,10 +683,7 @@ static inline int ta_launch_blocksort(const TaPlan& t, int64_t B, char* region, 
   return check_launch("ta_blocksort_kernel");
 }
 
-static inline bool ta_use_lds() {          // RBX_TA_LDS=0: the gather form for every shape (A/B measurement)
-  static const bool on = [] { const char* e = getenv("RBX_TA_LDS"); return e == nullptr || e[0] != '0'; }();
-  return on;
-}
+static inline bool ta_use_lds() { return true; }     // (the gather form for every shape was the A/B arm: profiles/r03)
 
 template <int G, bool VEC>
 static int ta_launch_bwd(const TaPlan& t, int64_t B, const float* g, const float* ssum, int accumulate, char* region,

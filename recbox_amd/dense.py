@@ -87,13 +87,7 @@ def run_sequential(seq, x):
         m = mods[i]
         if type(m) is nn.Linear:
             fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-            nxt = mods[i + 1] if i + 1 < len(mods) else None
-            # a training-mode BatchNorm1d right behind: its column statistics come out of this GEMM's epilogue
-            # (not when an nn.PReLU follows the BatchNorm: that pair runs in rbx_batchnorm_prelu_*, which computes its own)
-            nxt2 = mods[i + 2] if i + 2 < len(mods) else None
-            bn_next = (type(nxt) is nn.BatchNorm1d and x.dim() == 2 and (nxt.training or nxt.running_mean is None)
-                       and type(nxt2) is not nn.PReLU)
-            x = ops.linear(x, m.weight, m.bias, "relu" if fuse else None, bn_next=bn_next)
+            x = ops.linear(x, m.weight, m.bias, "relu" if fuse else None)
             i += 2 if fuse else 1
         elif type(m) in (nn.BatchNorm1d, nn.SyncBatchNorm) and x.dim() == 2:
             nxt = mods[i + 1] if i + 1 < len(mods) else None

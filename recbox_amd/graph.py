@@ -154,11 +154,8 @@ class ShardedFMStep(object):
         self.comm = comm
         self.pieces = [self._route, self._serve, self._head, self._tail, self._settle, self._finish]
         self.early = torch.cuda.Stream(device=dev)       # id sort of the replicated tables: beside route / exchange / serve
-        # the owner-side id sort runs beside the rows' way back and the local forward: on a stream of its own, or
-        # (RECBOX_AMD_SHARDED_ONE_SIDE=1) behind the replicated tables' sort on `early` -- two branches instead of three in
-        # the captured graph
-        import os
-        self.side = self.early if os.environ.get("RECBOX_AMD_SHARDED_ONE_SIDE", "0") != "0" else torch.cuda.Stream(device=dev)
+        # the owner-side id sort runs beside the rows' way back and the local forward, on a stream of its own
+        self.side = torch.cuda.Stream(device=dev)
         self.sorted_ws = None
         self.local_sorted = None
         self.graphs = None

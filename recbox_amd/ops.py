@@ -31,7 +31,7 @@ class config(object):
     check_ids = os.environ.get("RECBOX_AMD_CHECK_IDS", "1") != "0"
     # fork the id sort onto the side stream even while a hipGraph is being captured (the
     # fork/join becomes graph edges, so the sort overlaps the forward on replay too)
-    fork_in_capture = os.environ.get("RECBOX_AMD_FORK_IN_CAPTURE", "1") != "0"
+    fork_in_capture = True
     # fused FM: keep ONE persistent dense gradient buffer per table set and, instead of zero-filling a new one every
     # step (379 MB at the Criteo shape), clear only the rows the previous step wrote (rbx_fm_rezero, 36 MB).  The
     # gradients handed to autograd then ALIAS that buffer: they are valid until the next training forward of the same
@@ -47,18 +47,9 @@ class config(object):
     # Two lookups of one step over the same id tensors and table layout (FeatureEmbedding and LogisticRegression of a
     # CTR model) sort identical (row, sample) pairs for their backward: the second one copies the first one's result
     # (rbx_sort_share checks the descriptors) instead of sorting again.
-    share_sorts = os.environ.get("RECBOX_AMD_SHARE_SORTS", "1") != "0"
+    share_sorts = True
     # with check_ids off: keep one persistent status word per device that the kernels OR into (check_deferred_ids() reads it)
     defer_id_check = os.environ.get("RECBOX_AMD_DEFER_IDS", "1") != "0"
-    # fused FM backward: run the batch reductions of the numeric-feature weights and the bias (~35 us at the bench shape) on
-    # the side stream beside the segmented reduce instead of in front of it ("presorted": only in steps whose sort was made
-    # ahead).  Measured SLOWER inside the captured step every time (0.336 vs 0.297 ms; with the prefetched sort 0.294 on a
-    # third stream and 0.314 behind the sort on the second, vs 0.261): a replayed graph runs on TWO hardware queues whatever
-    # the capture's streams were, and with a third branch the runtime put the reduce behind the sort chain
-    # (profiles/r02/fm_replay_timeline_numeric_beside.txt).  Off.
-    # ... or behind the large tables' reduce on the side stream (the shorter of the two chains of the tiered backward)
-    fm_numeric_on_side = os.environ.get("RECBOX_AMD_FM_NUMERIC_ON", "main") == "side"
-    numeric_beside_reduce = {"0": False, "1": True, "presorted": "presorted"}[os.environ.get("RECBOX_AMD_NUMERIC_BESIDE", "0")]
     # binary_cross_entropy of a sigmoid_output(): one pass over the logits (+ final sum) and one scale kernel in the backward
     # instead of sigmoid / BCE partial / final / BCE backward / sigmoid backward -- 8 launches of ~5 us in a row
     fuse_sigmoid_bce = os.environ.get("RECBOX_AMD_FUSE_SIGMOID_BCE", "1") != "0"
@@ -70,54 +61,32 @@ class config(object):
     seqblock_chains = os.environ.get("RECBOX_AMD_SEQBLOCK", "1") != "0"
     # ... and the backward of its feed-forward half as one pass (rbx_seqblock_ffn_bwd) instead of two dW passes, two dx GEMMs
     # and the LayerNorm backward; the forward then does not store the LayerNorm output
-    seqblock_bwd = os.environ.get("RECBOX_AMD_SEQBLOCK_BWD", "1") != "0"
+    seqblock_bwd = True
     # ... and the three in-projection weight gradients as one pass (rbx_seqblock_inproj_dw) instead of three slab dW launches
-    seqblock_dw3 = os.environ.get("RECBOX_AMD_SEQBLOCK_DW3", "1") != "0"
-    # the FFN backward as the slab dW kernel for dW2 + a three-product pass at two wavefronts per SIMD (rbx_seqblock_ffn_bwd3)
-    # instead of the four-product pass at one
-    seqblock_ffn_bwd3 = os.environ.get("RECBOX_AMD_SEQBLOCK_FFN3", "0") != "0"
+    seqblock_dw3 = True
     # DeepFM: the tower's first Linear, the FM term and the first-order Linear over one gathered block as one autograd node
     # (ops.deepfm_input_stage): the block's gradient comes out of the tower's dx GEMM instead of four kernels
     fuse_deepfm_input = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_INPUT", "1") != "0"
     # ... and inside it the first-order Linear in the FM term's pass over the block (rbx_fm_sum_lr_fwd)
-    fuse_deepfm_lr = os.environ.get("RECBOX_AMD_FUSE_DEEPFM_LR", "1") != "0"
+    fuse_deepfm_lr = True
     reuse_grad_buffers = {"0": False, "": False, "all": "all"}.get(os.environ.get("RECBOX_AMD_REUSE_GRADS", "0"), True)
-    # fused FM backward in two tiers (round 3; include/recbox_hip.h, rbx_fm_bwd): the small tables' block partials + row
-    # combine (tier A) on the current stream, the large tables' segmented reduce (tier B) on the side stream its sort ran on
-    # -- two chains of short, latency-bound kernels side by side instead of one after the other.
-    fm_two_chains = os.environ.get("RECBOX_AMD_FM_TWO_CHAINS", "1") != "0"
     # keep, after every embedding backward, a record of what names the rows it touched (the sorted ids in its workspace, the
     # descriptors, the gradient tensors): what recbox_amd.optim's sparse-row optimisers step over.  Switched on by them.
     track_touched_rows = False
     # a table read by two lookups of one step (SASRec's item table: embedding layer + gather_dot): the second backward node
     # adds its rows into the dense gradient the first one returned instead of autograd adding two dense tensors
     # (see _publish_grads below)
-    share_table_grads = os.environ.get("RECBOX_AMD_SHARE_TABLE_GRADS", "1") != "0"
+    share_table_grads = True
     # y = x W^T and dx = dy W of the towers on the bf16 matrix cores: W split once per call into three bf16 planes, the
     # activations inside the kernel, six products per f32 product with f32 accumulation (csrc/rbx_dense.hip,
     # gemm_bx6_kernel: f32-level results at ~2.7x fewer matrix-core cycles).  Off: every GEMM on v_mfma_f32_32x32x2_f32.
     gemm_bx6 = os.environ.get("RECBOX_AMD_GEMM_BX6", "1") != "0"
     # SASRec's FFN sub-layer backward: the `* ~timeline_mask` rows scaled inside the dW kernel and the dx epilogues
     # (rbx_linear_dwdb_scaled / rbx_linear_dx_scaled) instead of by a pass that writes dout * keep
-    ffn_mask_in_gemms = os.environ.get("RECBOX_AMD_FFN_MASK_IN_GEMMS", "1") != "0"
+    ffn_mask_in_gemms = True
     # SASRec's position rows read in place and their gradient as a column sum over the batch (sasrec_input) instead of a
     # lookup of tile(arange(L)) with the generic sort + segmented reduce behind it
-    seq_positions_in_place = os.environ.get("RECBOX_AMD_SEQ_POSITIONS", "1") != "0"
-    # Linear -> BatchNorm1d (-> ReLU) -> Linear of a tower: the BatchNorm's column statistics come out of the epilogue of the
-    # GEMM in front of it, its backward's column sums out of the dx GEMM behind it (rbx_linear_fwd_bnstats /
-    # rbx_linear_dx_bnsums; needs gemm_bx6 and >= 4096 rows).  Built, parity-tested and measured; OFF by default because it
-    # does not pay on this GEMM: "fwd" saves one read of the Linear's output per layer (23 us) and the step does not move
-    # (DeepFM 4.34-4.38 ms either way, four A/B pairs); "bwd" ("1" = both) is SLOWER -- the dx GEMM runs one workgroup per
-    # CU, so the mask tensor its epilogue has to wait for is exposed at the end of every tile (gemm_bxp_kernel 326 -> 370 us
-    # on average, DeepFM 4.32 -> 4.48 ms; profiles/r03/INDEX.md).
-    bn_in_gemm = {"0": False, "1": True, "fwd": "fwd", "bwd": "bwd"}.get(os.environ.get("RECBOX_AMD_BN_IN_GEMM", "0"), False)
-    # Where the ids-only pieces of the tiered FM backward run.  "split" (default): the id compaction on the CURRENT stream in
-    # front of the forward kernel (10 us; the step's first kernel is then on the stream the previous step ended on), the
-    # per-block sorts of the small tables on the current stream inside the backward (in front of the block partials that
-    # read them), only the re-zero and the large tables' sort on the side stream -- the two chains come out equally long
-    # (~150 us of kernels each at the Criteo shape).  "side": everything ids-only on the side stream, as one chain in
-    # front of the large tables' reduce.
-    fm_ids_work = os.environ.get("RECBOX_AMD_FM_IDS_WORK", "split")
+    seq_positions_in_place = True
 
 
 def _require_cuda(t, what):
@@ -877,7 +846,7 @@ class _GradPool(object):
             return None
         return pool
 
-    def early_sort(self, ctx, device, ws_bytes, rezero, sort, first=None, pre=None, batch=None, fusable=None):
+    def early_sort(self, ctx, device, ws_bytes, rezero, sort, first=None, pre=None, batch=None):
         """Launch, on the side stream: ``rezero(stream)`` -- clear the rows the previous backward stored, its sorted ids
         are still in ``self.ws`` -- when there are any, then ``sort(ws, ws_bytes, stream)`` of this batch's ids over
         them.  Both return a C-ABI code.  (Clearing on a third stream beside the sort was measured slower -- 0.344 vs
@@ -888,24 +857,10 @@ class _GradPool(object):
         # a larger batch than ever before: clear, then regrow.  ``pre`` (work of the new step on the CURRENT stream, written
         # into the workspace in the layout of ITS batch size) may land on the previous step's sorted pairs unless the two
         # layouts are the same: clear first then, too.
-        # With ``pre`` (the tiered FM step) the re-zero runs HERE, on the current stream in front of the forward kernel, by
-        # default: beside the forward its 0.5 M random row stores slowed that kernel from 43 to 55 us (its rate is what
-        # bench.py reports against the roofline) for a step only 1.3 % shorter (0.2355 vs 0.2386 ms; profiles/r03);
-        # RECBOX_AMD_FM_REZERO_ON=side puts it back beside the forward.
-        where = os.environ.get("RECBOX_AMD_FM_REZERO_ON", "main")      # "fused": measured slower, see below
-        self.fuse_rezero = False
-        if (dirty and pre is not None and dirty == batch and self.ws_bytes >= ws_bytes and where == "fused"
-                and fusable is not None and fusable()):
-            # every sorted table of the call is on tier C: its partition pass (side stream, beside the forward kernel) clears
-            # the rows the previous backward stored while it overwrites the bucket arrays that name them -- no re-zero
-            # launch of its own.  Opt-in (RECBOX_AMD_FM_REZERO_ON=fused): measured 0.238-0.283 ms per step against
-            # 0.235 with the launch in front of the forward -- the 0.8 M row stores beside the forward kernel take it from
-            # 47 to 52-74 us (profiles/r04/INDEX.md)
-            self.fuse_rezero = True
-            self.dirty_batch = 0
-            dirty = 0
-        if dirty and (self.ws_bytes < ws_bytes or (pre is not None and dirty != batch)
-                      or (pre is not None and where in ("main", "fused"))):
+        # With ``pre`` (the tiered FM step) the re-zero runs HERE, on the current stream in front of the forward kernel:
+        # beside the forward its 0.5 M random row stores slowed that kernel from 43 to 55 us for a step only 1.3 % shorter
+        # (0.2355 vs 0.2386 ms; profiles/r03), and inside a partition pass beside it they cost more than they saved (r04).
+        if dirty and (self.ws_bytes < ws_bytes or pre is not None):
             check(rezero(_stream()))
             dirty = 0
         ws = self.workspace(ws_bytes)
@@ -1059,7 +1014,10 @@ class _FmFused(torch.autograd.Function):
 
             # ids -> compact int32 matrix, the per-block sorts of the small tables (tier A), the (row, sample) sort of the
             # large tables (tier B; for a call without embedding tables: the whole sort)
-            split = config.fm_ids_work == "split" and emb_plan is not None
+            # the id compaction on the CURRENT stream in front of the forward kernel (10 us; the step's first kernel is then
+            # on the stream the previous step ended on), the per-block sorts of the small tables behind the forward kernel,
+            # only the large tables' sort on the side stream: the two chains come out about equally long
+            split = emb_plan is not None
 
             def first(ws, nbytes, st):
                 return lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 1 | 4, st)
@@ -1067,37 +1025,16 @@ class _FmFused(torch.autograd.Function):
             def compact(ws, nbytes):                       # on the current stream, in front of the forward kernel
                 return lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 1, _stream())
 
-            # RECBOX_AMD_FM_BLOCKSORT_AT=side: the small tables' per-block sorts ride on the side stream too (with tier C the
-            # side stream only carries one partition pass of ~20 us: both fit beside the forward kernel)
-            blocks_on_side = split and os.environ.get("RECBOX_AMD_FM_BLOCKSORT_AT", "after_fwd") == "side"
-
             def rest(ws, nbytes, st):
-                which = (2 | 4) if blocks_on_side else 2
-                if pool is not None and getattr(pool, "fuse_rezero", False):
-                    # the partition pass also CLEARS the rows the previous backward stored: it needs the real gradient
-                    # pointers (the descriptors carry the parameters themselves as "has a gradient" placeholders)
-                    pool.fuse_rezero = False
-                    grads = pool.bind_views(list(emb_params) + list(lr_params))
-                    if emb_plan is not None:
-                        emb_plan.bind_params(emb_params, grads[:len(emb_params)])
-                    if lr_plan is not None:
-                        lr_plan.bind_params(lr_params, grads[len(emb_params):])
-                    rc = lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, which | 8, st)
-                    if emb_plan is not None:
-                        emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
-                    if lr_plan is not None:
-                        lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
-                    return rc
                 return _enqueue_sort((ea, la, lead.n, 1), keep, B, ws, nbytes, st,
-                                     lambda: lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, which, st))
+                                     lambda: lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 2, st))
 
             if ws_bytes > 0 and pool is None:
                 if split:
                     ws = torch.empty(max(int(ws_bytes), 1), dtype=torch.uint8, device=dev)
                     check(compact(ws, ws_bytes))
                     ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: rest(ws, ws_bytes, st), ws=ws)
-                    ctx.blocksort_pending = not blocks_on_side
-                    ctx.blocksort_on_side = blocks_on_side
+                    ctx.blocksort_pending = True
                 else:
                     ctx.sort = _EarlySort(dev, ws_bytes, lambda ws, st: rest(ws, ws_bytes, st),
                                           first=lambda ws, st: first(ws, ws_bytes, st))
@@ -1111,18 +1048,8 @@ class _FmFused(torch.autograd.Function):
                     return rc
 
                 if split:
-                    early_blocks = os.environ.get("RECBOX_AMD_FM_BLOCKSORT_AT", "bwd") == "fwd"
-
-                    def pre(ws, nbytes):
-                        rc = compact(ws, nbytes)
-                        if rc == _lib.RBX_OK and early_blocks:
-                            rc = lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ws), nbytes, None, 4, _stream())
-                        return rc
-
-                    pool.early_sort(ctx, dev, ws_bytes, rezero, rest, pre=pre, batch=B,
-                                    fusable=lambda: bool(lib.rbx_fm_rezero_fusable(ea, la, lead.n, B)))
-                    ctx.blocksort_pending = not early_blocks and not blocks_on_side
-                    ctx.blocksort_on_side = blocks_on_side
+                    pool.early_sort(ctx, dev, ws_bytes, rezero, rest, pre=compact, batch=B)
+                    ctx.blocksort_pending = True
                 else:
                     pool.early_sort(ctx, dev, ws_bytes, rezero, rest, first=first)
             # the forward reads the tables only: back to descriptors without gradient pointers
@@ -1149,7 +1076,7 @@ class _FmFused(torch.autograd.Function):
                                             _ptr(extra_index), x_rows, _ptr(logit), _ptr(prob), _ptr(ssum),
                                             _ptr(status), _stream())))
         _check_status(status)
-        if getattr(ctx, "blocksort_pending", False) and os.environ.get("RECBOX_AMD_FM_BLOCKSORT_AT", "after_fwd") == "after_fwd":
+        if getattr(ctx, "blocksort_pending", False):
             # the per-block sorts of the small tables (ids only) go BEHIND the forward kernel on this stream: they delay
             # neither the forward nor -- the large tables' sort on the side stream is still under way -- the backward
             # (in front of the forward: 0.256 vs 0.236 ms per step; inside the backward, in front of the block partials:
@@ -1292,30 +1219,14 @@ class _FmFused(torch.autograd.Function):
         ws_early = ctx.sort.ws if (ctx.sort is not None and same) else None
         pending_blocksort = getattr(ctx, "blocksort_pending", False) and ws_early is not None
         grads_ready = None
-        if (config.fm_two_chains and ws_early is not None and isinstance(ctx.sort, _EarlySort) and ctx.sort.side is not None
-                and emb_plan is not None):
+        if ws_early is not None and isinstance(ctx.sort, _EarlySort) and ctx.sort.side is not None and emb_plan is not None:
             grads_ready = torch.cuda.current_stream(dev).record_event()      # dL/dlogit, S, the gradient buffers: all here
-        numeric_done = None
         numeric_first = False
-        beside = config.numeric_beside_reduce
-        if beside == "presorted":
-            beside = isinstance(ctx.sort, _Presorted)
-        if ws_early is not None and beside:
-            # numeric weights + bias need dL/dlogit and S only: they go to a stream of their own and so run BESIDE the
-            # segmented reduce instead of in front of it
-            cur = torch.cuda.current_stream(dev)
-            side = _side_stream(dev, int(os.environ.get("RECBOX_AMD_NUMERIC_STREAM", "0")))
-            side.wait_stream(cur)
-            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws_early),
-                                 ctx.sort.ws_bytes, ctypes.c_void_p(side.cuda_stream)))
-            numeric_done = side.record_event()
-            for t in [dlogit, ssum, gb] + [g for g in grads if g is not None]:
-                if t is not None:
-                    t.record_stream(side)
-        elif ws_early is not None and (grads_ready is None or os.environ.get("RECBOX_AMD_FM_NUMERIC", "last") != "last"):
+        if ws_early is not None and grads_ready is None:
             # numeric weights + bias do not need the sorted ids: run them while the sort may still be in flight
             # (with the two chains of the tiered backward they go LAST on this stream instead, behind the small tables'
-            #  partials, which then run before the large tables' reduce has started on the other stream)
+            #  partials, which then run before the large tables' reduce has started on the other stream; on a stream of their
+            #  own beside the reduce they were slower every time: a replayed graph runs on two hardware queues, r02 / r04)
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws_early),
                                  ctx.sort.ws_bytes, _stream()))
             numeric_first = True
@@ -1324,9 +1235,8 @@ class _FmFused(torch.autograd.Function):
             # partials that read them, they leave the side stream to the large tables' sort
             check(lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ctx.sort.ws), ctx.sort.ws_bytes, None, 4, _stream()))
             ctx.blocksort_pending = False
-        on_side = getattr(ctx, "blocksort_on_side", False)
         two_chains = grads_ready is not None and (ctx.sort.event_first is not None or pending_blocksort
-                                                  or getattr(ctx, "blocksort_done", False) or on_side)
+                                                  or getattr(ctx, "blocksort_done", False))
         if two_chains:
             ws, ws_bytes = ctx.sort.ws, ctx.sort.ws_bytes           # (no join: each tier waits for its own part below)
         elif ctx.sort is not None and same:
@@ -1339,43 +1249,29 @@ class _FmFused(torch.autograd.Function):
         if getattr(ctx, "rezero_event", None) is not None:
             torch.cuda.current_stream(dev).wait_event(ctx.rezero_event)     # (presorted step: the re-zero ran on the side stream)
         if two_chains:
-            # Two chains of short kernels side by side.  RECBOX_AMD_FM_TIER_A_ON = "main" (default): tier A (block partials
-            # of the small tables, then every row written once) runs here, tier B (sorted pairs of the large tables ->
-            # segmented reduce + fix-ups) stays on the side stream behind its own sort.  "side": the other way round --
-            # measured slower in the replayed step (0.27-0.28 vs 0.25 ms, profiles/r03).
+            # Two chains of short kernels side by side: tier A (block partials of the small tables, then every row written
+            # once) runs here, tier B (sorted pairs of the large tables -> segmented reduce + fix-ups) stays on the side
+            # stream behind its own sort (the other way round: 0.27-0.28 vs 0.25 ms in the replayed step, profiles/r03).
             cur = torch.cuda.current_stream(dev)
             side = ctx.sort.side
-            a_side = os.environ.get("RECBOX_AMD_FM_TIER_A_ON", "main") == "side" and ctx.sort.event_first is not None
             side.wait_event(grads_ready)
-            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (16 if a_side else 8) | store,
+            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | 8 | store,
                                  _ptr(ws), ws_bytes, ctypes.c_void_p(side.cuda_stream)))
-            numeric_on_side = (not numeric_first and not beside and config.fm_numeric_on_side)
-            if numeric_on_side:
-                # the numeric weights + bias behind the SHORTER of the two chains (the large tables' reduce ends ~15 us
-                # before the small tables' row writes, profiles/r04/fm_replay_timeline.txt)
-                check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws), ws_bytes,
-                                     ctypes.c_void_p(side.cuda_stream)))
-                if gb is not None:
-                    gb.record_stream(side)
             side_done = side.record_event()
             for t in [dlogit, ssum] + [g for g in grads if g is not None]:
                 if t is not None:
                     t.record_stream(side)
-            if a_side or on_side:
-                cur.wait_event(ctx.sort.event)             # (the block sorts tier A reads ran on the side stream)
-            elif ctx.sort.event_first is not None:
+            if ctx.sort.event_first is not None:
                 cur.wait_event(ctx.sort.event_first)
-            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | (8 if a_side else 16) | store,
+            check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | 16 | store,
                                  _ptr(ws), ws_bytes, _stream()))
-            if not numeric_first and not beside and not numeric_on_side:
+            if not numeric_first:
                 check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws), ws_bytes,
                                      _stream()))
             cur.wait_event(side_done)
         else:
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0,
                                  (1 if ws_early is not None else 3) | store, _ptr(ws), ws_bytes, _stream()))
-        if numeric_done is not None:
-            torch.cuda.current_stream(dev).wait_event(numeric_done)
         if pool is not None:
             if isinstance(ctx.sort, _Presorted):
                 pool.done(B, ws, ws_bytes)
@@ -1550,14 +1446,6 @@ def _split_ok(w, M, transposed):
     return bool(config.gemm_bx6 and M >= 4096 and red >= 256 and out >= 128 and w.is_contiguous())
 
 
-# Hand-over between the autograd nodes of a tower (one entry each, consumed by the next node or overwritten):
-#   "fwd": a Linear whose output feeds a BatchNorm left that output's partial statistics   (ptr, shape, partial, blocks)
-#   "out": a BatchNorm + ReLU in training mode names its output a, input z and statistics  (ptr, shape, z, mean, rstd)
-#   "bwd": the Linear that read a left the masked gradient's partial sums beside its dx     (ptr, shape, partial, blocks)
-_bn_hint = {"fwd": None, "out": None, "bwd": None}
-bn_in_gemm_counts = {"fwd": 0, "bwd": 0}                    # observability (tests)
-
-
 def _with_split_weights(w, M, transposed, call):
     """Run ``call()`` -- GEMMs of [M, *] activations against the contiguous weight ``w`` [N, K] -- with the bf16 planes of
     ``w`` registered (rbx_split_bf16 + rbx_split_register), when the shape is compute-bound enough to gain from the bf16
@@ -1585,7 +1473,7 @@ class _Linear(torch.autograd.Function):
     block of a wider row-major activation (row stride > K): it is read, and its gradient written, in place."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, bn_next=False):
+    def forward(ctx, x, weight, bias, act):
         _require_cuda(x, "linear input")
         _require_cuda(weight, "linear weight")
         shape = x.shape
@@ -1596,30 +1484,10 @@ class _Linear(torch.autograd.Function):
         if w.shape[1] != K:
             raise RuntimeError("mat1 and mat2 shapes cannot be multiplied (%dx%d and %dx%d)" % (M, K, w.shape[1], N))
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        # is the input the ReLU output of a training-mode BatchNorm?  (its backward sums then come out of this node's dx GEMM)
-        src, _bn_hint["out"] = _bn_hint["out"], None
-        ctx.bn_src = None
-        if (src is not None and src[0] == x2.data_ptr() and src[1] == (M, K) and x2.stride(0) == K and act == 0
-                and config.bn_in_gemm in (True, "bwd") and _split_ok(w, M, 1)):
-            ctx.bn_src = src[2:]
-        partial = None
-        if bn_next and config.bn_in_gemm in (True, "fwd") and act == 0 and M > 1 and x2.stride(0) >= K and _split_ok(w, M, 0):
-            blocks = (M + 63) // 64
-            partial = torch.empty(blocks * N * 3, dtype=torch.float32, device=x.device)
-            rc = _with_split_weights(w, M, 0, lambda: _timed(
-                ("linear_fwd", M, N, K),
-                lambda: lib.rbx_linear_fwd_bnstats(_ptr(x2), x2.stride(0), _ptr(w), _ptr(bias), M, N, K, _ptr(y),
-                                                   _ptr(partial), _stream())))
-            if rc == _lib.RBX_ERR_UNSUPPORTED:
-                partial = None                         # (library switch off, too few rows for the 256-row kernel: separate passes)
-            else:
-                check(rc)
-                _bn_hint["fwd"] = (y.data_ptr(), (M, N), partial, blocks)
-        if partial is None:
-            _with_split_weights(w, M, 0, lambda: check(_timed(
-                ("linear_fwd", M, N, K),
-                lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(bias), M, N, K, act,
-                                           _ptr(y), _stream()))))
+        _with_split_weights(w, M, 0, lambda: check(_timed(
+            ("linear_fwd", M, N, K),
+            lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(bias), M, N, K, act,
+                                       _ptr(y), _stream()))))
         ctx.save_for_backward(x2, w, y if act == 1 else None)
         ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, shape
         ctx.grad_keys = (weight.data_ptr() if weight.is_contiguous() else 0, bias.data_ptr() if bias is not None else 0)
@@ -1639,25 +1507,6 @@ class _Linear(torch.autograd.Function):
         db = _grad_dest(ctx.grad_keys[1], (N,), dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, ctx.act)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
-        if dx is not None and ctx.bn_src is not None:
-            # x2 = relu(batchnorm(z)): dx masked by x2 > 0 and its column sums (sum g, sum g xhat) from the dx GEMM's epilogue
-            z, mean, rstd, gamma, beta = ctx.bn_src
-            blocks = (M + 63) // 64
-            dxc = torch.empty((M, K), dtype=torch.float32, device=dy.device)
-            partial = torch.empty(blocks * K * 2, dtype=torch.float32, device=dy.device)
-            rc = _with_split_weights(w, M, 1, lambda: lib.rbx_linear_dx_bnsums(
-                _ptr(dy2), N, _ptr(w), M, N, K, _ptr(x2), K, _ptr(z), K, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
-                _ptr(dxc), K, _ptr(partial), _stream()))
-            if rc != _lib.RBX_ERR_UNSUPPORTED:
-                check(rc)
-                check(lib.rbx_linear_bwd(_ptr(x2), K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, None, K, _ptr(dw),
-                                         _ptr(db), _ptr(ws), ws_bytes, _stream()))
-                # (the version counter goes along: autograd's InputBuffer may ADD another consumer's gradient into dxc in
-                #  place when the BatchNorm's output fed more than this Linear -- same pointer and shape, but the partial
-                #  sums then cover only this Linear's share; an in-place add bumps the version)
-                out = dxc.view(ctx.shape)
-                _bn_hint["bwd"] = (dxc.data_ptr(), (M, K), partial, blocks, out, out._version)
-                return out, dw, db, None, None
         bwd = lambda: check(lib.rbx_linear_bwd(                                                            # noqa: E731
             _ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx),
             (dx.stride(0) if M > 1 else K) if dx is not None else K, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, _stream()))
@@ -1665,13 +1514,11 @@ class _Linear(torch.autograd.Function):
             _with_split_weights(w, M, 1, bwd)
         else:
             bwd()
-        return (dx.view(ctx.shape) if dx is not None else None), dw, db, None, None
+        return (dx.view(ctx.shape) if dx is not None else None), dw, db, None
 
 
-def linear(x, weight, bias=None, act=None, bn_next=False):
-    """``bn_next``: the caller feeds the result straight into a training-mode BatchNorm1d (``batch_norm``): the GEMM then
-    leaves that BatchNorm's partial column statistics beside its output."""
-    return _Linear.apply(x, weight, bias, 1 if act == "relu" else 0, bool(bn_next))
+def linear(x, weight, bias=None, act=None):
+    return _Linear.apply(x, weight, bias, 1 if act == "relu" else 0)
 
 
 class _L2Norm(torch.autograd.Function):
@@ -2021,22 +1868,11 @@ class _BatchNorm(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(cols, dtype=torch.float32, device=dev)
         rstd = torch.empty(cols, dtype=torch.float32, device=dev)
-        hint, _bn_hint["fwd"] = _bn_hint["fwd"], None
-        if training and hint is not None and hint[0] == x.data_ptr() and hint[1] == (rows, cols) and rows > 1:
-            # the Linear in front of this BatchNorm left the partial statistics of x: final kernel + apply
-            check(lib.rbx_batchnorm_stats_from_partials(_ptr(hint[2]), hint[3], cols, eps, momentum, _ptr(running_mean),
-                                                        _ptr(running_var), _ptr(mean), _ptr(rstd), _stream()))
-            check(lib.rbx_batchnorm_apply(_ptr(x), rows, cols, _ptr(weight), _ptr(bias), _ptr(mean), _ptr(rstd),
-                                          1 if relu else 0, _ptr(y), _stream()))
-            bn_in_gemm_counts["fwd"] += 1
-        else:
-            ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
-            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-            check(lib.rbx_batchnorm_fwd(_ptr(x), rows, cols, _ptr(weight), _ptr(bias), eps, 1 if training else 0, momentum,
-                                        _ptr(running_mean), _ptr(running_var), 1 if relu else 0, _ptr(mean), _ptr(rstd),
-                                        _ptr(y), _ptr(ws), ws_bytes, _stream()))
-        if training and relu and config.bn_in_gemm in (True, "bwd"):
-            _bn_hint["out"] = (y.data_ptr(), (rows, cols), x, mean, rstd, weight, bias)
+        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        check(lib.rbx_batchnorm_fwd(_ptr(x), rows, cols, _ptr(weight), _ptr(bias), eps, 1 if training else 0, momentum,
+                                    _ptr(running_mean), _ptr(running_var), 1 if relu else 0, _ptr(mean), _ptr(rstd),
+                                    _ptr(y), _ptr(ws), ws_bytes, _stream()))
         ctx.save_for_backward(x, weight, mean, rstd, y if relu else None)
         ctx.training, ctx.has_bias = training, bias is not None
         ctx.grad_keys = (weight.data_ptr() if weight is not None else 0, bias.data_ptr() if bias is not None else 0)
@@ -2051,23 +1887,11 @@ class _BatchNorm(torch.autograd.Function):
         keys = ctx.grad_keys
         dgamma = _grad_dest(keys[0] if (weight is not None and ctx.needs_input_grad[1]) else 0, (cols,), x.device)
         dbeta = _grad_dest(keys[1] if (ctx.has_bias and ctx.needs_input_grad[2]) else 0, (cols,), x.device)
-        hint, _bn_hint["bwd"] = _bn_hint["bwd"], None
-        if (hint is not None and hint[0] == dy.data_ptr() and hint[1] == (rows, cols) and ctx.training and y_relu is not None
-                and dx is not None and hint[4]._version == hint[5]):
-            # dy is ALREADY masked by the ReLU (the dx GEMM that produced it did that) and its column sums are on file
-            check(lib.rbx_batchnorm_bwd_sums_from_partials(_ptr(hint[2]), hint[3], cols, _ptr(dgamma), _ptr(dbeta), _stream()))
-            check(lib.rbx_batchnorm_bwd_dx(_ptr(x), _ptr(dy), None, rows, cols, _ptr(weight), _ptr(mean), _ptr(rstd),
-                                           _ptr(dgamma), _ptr(dbeta), rows, _ptr(dx), _stream()))
-            bn_in_gemm_counts["bwd"] += 1
-        else:
-            if hint is not None and hint[0] == dy.data_ptr():
-                # the gradient was masked by its producer but cannot be used that way here: the mask is idempotent, carry on
-                pass
-            ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
-            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
-            check(lib.rbx_batchnorm_bwd(_ptr(x), _ptr(dy), _ptr(y_relu), rows, cols, _ptr(weight), _ptr(mean), _ptr(rstd),
-                                        1 if ctx.training else 0, _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws_bytes,
-                                        _stream()))
+        ws_bytes = lib.rbx_batchnorm_workspace_size(rows, cols)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=x.device)
+        check(lib.rbx_batchnorm_bwd(_ptr(x), _ptr(dy), _ptr(y_relu), rows, cols, _ptr(weight), _ptr(mean), _ptr(rstd),
+                                    1 if ctx.training else 0, _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws_bytes,
+                                    _stream()))
         return (dx, dgamma if (weight is not None and ctx.needs_input_grad[1]) else None,
                 dbeta if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None, None, None)
 
@@ -2078,7 +1902,6 @@ class _BatchNormPReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, slope, stats, training, momentum, eps):
         running_mean, running_var = stats.running_mean, stats.running_var
-        _bn_hint["fwd"] = None                    # (this path takes no statistics from a GEMM epilogue: drop a stale hand-over)
         _require_cuda(x, "x")
         x = x.contiguous().float()
         rows, cols = x.shape
@@ -2127,7 +1950,6 @@ class _SyncBatchNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stats, momentum, eps, relu, group):
-        _bn_hint["fwd"] = None                    # (per-rank partials are not what a synchronised BatchNorm normalises by)
         from . import comm
         _require_cuda(x, "x")
         x = x.contiguous().float()
@@ -3286,20 +3108,11 @@ class _SeqBlock(torch.autograd.Function):
             g = torch.empty((M, E), **f32)
             dgamma2 = torch.empty(E, **f32) if want2 else None
             dbeta2 = torch.empty(E, **f32) if want2 else None
-            if config.seqblock_ffn_bwd3 and _dwdb_scaled_ok(h, g0):
-                # dW2 | db2 by the slab dW kernel, the rest (three products, 64 accumulators) at two wavefronts per SIMD
-                _lin_dwdb_scaled(h, g0, k1, dw2, db2)
-                ws_bytes = lib.rbx_seqblock_ffn_bwd3_workspace_size(M)
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                check(lib.rbx_seqblock_ffn_bwd3(_ptr(g0), _ptr(k1), _ptr(h), _ptr(y), _ptr(mean2), _ptr(rstd2), M, _ptr(ln2_w),
-                                                _ptr(ln2_b), _ptr(w1), _ptr(w2), _ptr(g), _ptr(dw1), _ptr(db1), _ptr(dgamma2),
-                                                _ptr(dbeta2), _ptr(ws), ws_bytes, _stream()))
-            else:
-                ws_bytes = lib.rbx_seqblock_ffn_bwd_workspace_size(M)
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                check(lib.rbx_seqblock_ffn_bwd(_ptr(g0), _ptr(k1), _ptr(h), _ptr(y), _ptr(mean2), _ptr(rstd2), M, _ptr(ln2_w),
-                                               _ptr(ln2_b), _ptr(w1), _ptr(w2), _ptr(g), _ptr(dw1), _ptr(db1), _ptr(dw2),
-                                               _ptr(db2), _ptr(dgamma2), _ptr(dbeta2), _ptr(ws), ws_bytes, _stream()))
+            ws_bytes = lib.rbx_seqblock_ffn_bwd_workspace_size(M)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            check(lib.rbx_seqblock_ffn_bwd(_ptr(g0), _ptr(k1), _ptr(h), _ptr(y), _ptr(mean2), _ptr(rstd2), M, _ptr(ln2_w),
+                                           _ptr(ln2_b), _ptr(w1), _ptr(w2), _ptr(g), _ptr(dw1), _ptr(db1), _ptr(dw2),
+                                           _ptr(db2), _ptr(dgamma2), _ptr(dbeta2), _ptr(ws), ws_bytes, _stream()))
         else:
             _lin_dwdb_scaled(h, g0, k1, dw2, db2)
             dh = _lin_dx(g0, w2, mask=h, row_scale=k1)
@@ -3405,7 +3218,7 @@ class _DeepFmInput(torch.autograd.Function):
     forward kept (rbx_fm_sum_fwd)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, lr_w, lr_b, fm_cols, dim, bn_next=False):
+    def forward(ctx, x, w1, b1, lr_w, lr_b, fm_cols, dim):
         _require_cuda(x, "DeepFM input block")
         x2 = _rows_view(x)
         w1 = w1.contiguous()
@@ -3414,23 +3227,9 @@ class _DeepFmInput(torch.autograd.Function):
         N = w1.shape[0]
         F_ = fm_cols // dim
         h = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        partial = None
-        if bn_next and config.bn_in_gemm in (True, "fwd") and M > 1 and _split_ok(w1, M, 0):
-            blocks = (M + 63) // 64
-            partial = torch.empty(blocks * N * 3, dtype=torch.float32, device=x.device)
-            rc = _with_split_weights(w1, M, 0, lambda: _timed(
-                ("linear_fwd", M, N, K),
-                lambda: lib.rbx_linear_fwd_bnstats(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, _ptr(h), _ptr(partial),
-                                                   _stream())))
-            if rc == _lib.RBX_ERR_UNSUPPORTED:
-                partial = None
-            else:
-                check(rc)
-                _bn_hint["fwd"] = (h.data_ptr(), (M, N), partial, blocks)
-        if partial is None:
-            _with_split_weights(w1, M, 0, lambda: check(_timed(
-                ("linear_fwd", M, N, K),
-                lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, 0, _ptr(h), _stream()))))
+        _with_split_weights(w1, M, 0, lambda: check(_timed(
+            ("linear_fwd", M, N, K),
+            lambda: lib.rbx_linear_fwd(_ptr(x2), x2.stride(0), _ptr(w1), _ptr(b1), M, N, K, 0, _ptr(h), _stream()))))
         y_fm = torch.empty((M, 1), dtype=torch.float32, device=x.device)
         ssum = torch.empty((M, dim), dtype=torch.float32, device=x.device)
         y_lr = torch.empty((M, 1), dtype=torch.float32, device=x.device)
@@ -3488,14 +3287,14 @@ class _DeepFmInput(torch.autograd.Function):
                 _ptr(dh2), N, _ptr(w1), M, N, K, _ptr(x2), x2.stride(0), _ptr(ssum), dim, fm_cols, _ptr(gf), _ptr(gl),
                 _ptr(lr_w), _ptr(dx), dx.stride(0), _stream())))
             dx = dx.view(xshape) if len(xshape) != 2 else dx
-        return dx, dw1, db1, dlr_w, dlr_b, None, None, None
+        return dx, dw1, db1, dlr_w, dlr_b, None, None
 
 
-def deepfm_input_stage(x, first_linear, lr_linear, fm_cols, dim, bn_next=False):
+def deepfm_input_stage(x, first_linear, lr_linear, fm_cols, dim):
     """(first_linear(x), FM(x[:, :fm_cols].view(B, -1, dim)), lr_linear(x[:, :fm_cols])) for DeepFM's gathered block
     x [B, K]: one autograd node, the block's gradient comes out of ONE GEMM (see _DeepFmInput)."""
     return _DeepFmInput.apply(x, first_linear.weight, first_linear.bias, lr_linear.weight, lr_linear.bias, int(fm_cols),
-                              int(dim), bool(bn_next))
+                              int(dim))
 
 
 def deepfm_input_stage_supported(x, fm_cols, dim):

@@ -64,8 +64,6 @@ class _SparseRows(object):
         self.capturable = bool(capturable)
         self._dev = None                              # {"t": float32[1], "step_size": float32[1]} on the tables' device
         ops.config.track_touched_rows = True
-        # the row updates of a fused FM call walk the backward's SORTED ids; its sort-free tier C (round 4) keeps none
-        lib.rbx_fm_tier_c(0)
 
     # ---- per-rule pieces ------------------------------------------------------------------------------------------
     n_state = 0

@@ -38,10 +38,7 @@ class DeepFM(torch.nn.Module):
             if (ops.config.fuse_deepfm_input and len(mods) > 0 and type(mods[0]) is torch.nn.Linear
                     and not self.linear.sigmoid and ops.deepfm_input_stage_supported(input_deep, self.fm_dims, dim)):
                 # the three readers of the block as ONE autograd node: its gradient comes out of the tower's dx GEMM
-                bn = mods[1] if len(mods) > 1 else None          # the tower's first BatchNorm takes its statistics from that GEMM
-                bn_next = type(bn) is torch.nn.BatchNorm1d and (bn.training or bn.running_mean is None)
-                h, y_fm, y_linear = ops.deepfm_input_stage(input_deep, mods[0], self.linear.fc, self.fm_dims, dim,
-                                                           bn_next=bn_next)
+                h, y_fm, y_linear = ops.deepfm_input_stage(input_deep, mods[0], self.linear.fc, self.fm_dims, dim)
                 y_deep = dense.run_sequential(mods[1:], h)
                 return ops.sigmoid_output((y_linear + y_fm + y_deep).squeeze(1))
             if input_deep.is_cuda and input_deep.dim() == 2:

@@ -261,6 +261,16 @@ class DenseGradSync(object):
             self._prescale()
         return None
 
+    def close(self):
+        """Remove the hooks and the registered gradient destinations (a model that moves to another device re-installs)."""
+        from .. import ops
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p, _ in self._views:
+            ops._grad_views.pop(p.data_ptr(), None)
+        self._views, self.bucket = [], None
+
     def _on_grad(self, p):
         if id(p) in self._arrived or self._pending is not None:
             raise RuntimeError("DenseGradSync: a second backward reached a replicated parameter before sync_grads() "
@@ -335,7 +345,18 @@ class DenseGradSync(object):
 
 
 class _ShardedModelMixin(object):
+    def _apply(self, fn, *args, **kwargs):
+        # .cuda() / .to(): the parameters' storage changes -- the gradient bucket and its registered views are per device
+        # (built on the CPU there is no bucket at all: the tower gradients would then be packed and copied back every step)
+        out = super(_ShardedModelMixin, self)._apply(fn, *args, **kwargs)
+        if getattr(self, "grad_sync", None) is not None:
+            self._install_sync()
+        return out
+
     def _install_sync(self):
+        old = getattr(self, "grad_sync", None)
+        if old is not None:
+            old.close()
         emb = self.embedding
         tables = list(emb.embed_dict.parameters())
         skip = set(id(p) for p in tables)

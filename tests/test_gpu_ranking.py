@@ -276,98 +276,6 @@ def _bce_step(model, X, y):
     return loss
 
 
-@pytest.mark.parametrize("B,mode", [(1, "uniform"), (300, "uniform"), (5000, "zipf"), (65536, "uniform"), (65536, "zipf"),
-                                    (9000, "one_id"), (4097, "padding")])
-def test_fm_tier_c_equals_the_sorted_path(B, mode):
-    """Round 4: the fused FM backward's sort-free tier C (csrc/rbx_tierc.h: scan + LDS sort + reduce per (table, hash
-    partition)) against the sorted path it replaces (rbx_fm_tier_c(0)), for tables of 5 000 .. 1 000 000 rows: uniform ids
-    (unique rows), log-uniform ids (hot rows: runs of thousands -> the whole-workgroup long-run sums), ONE id for every
-    sample (a partition selects all B pairs: several list fills, read-modify-write), a batch that is mostly padding.
-    Same gradients up to summation order (1e-6 of the tensor's largest entry), bit-identical on repeat, and rows no
-    sample looked up are exactly zero."""
-    from recbox_amd import ops
-    from recbox_amd._lib import lib
-    vocabs = [37, 5000, 70000, 1000000, 300000, 4099]
-    fm, X, y = _criteo_like(B, vocabs, 16, seed=200 + B, zipf=(mode == "zipf"))
-    if mode == "one_id":
-        for i, v in enumerate(vocabs):
-            X["C%d" % (i + 1)] = torch.full((B,), float(min(v, 4321)), dtype=torch.float64)
-    if mode == "padding":
-        g = torch.Generator().manual_seed(7)
-        for i in range(len(vocabs)):
-            keep = torch.rand(B, generator=g) < 0.1
-            X["C%d" % (i + 1)] = X["C%d" % (i + 1)] * keep                       # 90 % padding ids (0)
-    Xc, yc = _cuda(X), y.cuda()
-    _, a, b = _fm_pair(45, vocabs)
-    old_check = ops.config.check_ids
-    ops.config.check_ids = False
-    was = lib.rbx_fm_tier_c(-1)
-    try:
-        grads = {}
-        for name, model, on in (("sorted", a, 0), ("tier_c", b, 1), ("tier_c_again", b, 1)):
-            lib.rbx_fm_tier_c(on)
-            _bce_step(model, Xc, yc)
-            torch.cuda.synchronize()
-            grads[name] = [p.grad.clone() for p in model.parameters()]
-        worst = 0.0
-        for (n, p), g0, g1, g2 in zip(a.named_parameters(), grads["sorted"], grads["tier_c"], grads["tier_c_again"]):
-            assert torch.equal(g1, g2), "tier C is not bit-identical on repeat: " + n
-            err = float((g0 - g1).abs().max()) / max(1.0, float(g0.abs().max()))
-            worst = max(worst, err)
-            assert err <= 1e-6, "%s: tier C differs from the sorted path by %g of the largest entry" % (n, err)
-        # rows nobody looked up are exactly zero (nothing strays outside a workgroup's own rows)
-        for i, v in enumerate(vocabs):
-            table = b.embedding_layer.embedding_layer.embedding_layers["C%d" % (i + 1)].weight
-            touched = torch.zeros(v + 1, dtype=torch.bool, device="cuda")
-            touched[Xc["C%d" % (i + 1)].long()] = True
-            touched[0] = False                                                   # padding_idx: no gradient
-            assert float(table.grad[~touched].abs().max()) == 0.0, "C%d" % (i + 1)
-        print("tier C vs sorted path (B = %d, %s): %.3g of the largest entry" % (B, mode, worst))
-    finally:
-        lib.rbx_fm_tier_c(was)
-        ops.config.check_ids = old_check
-
-
-@pytest.mark.parametrize("where", ["main", "fused"])
-def test_tier_c_clears_the_previous_steps_rows(where):
-    """Persistent gradient buffers with the sorted tables on tier C (rbx_fm_tier_c(1)): the rows the previous backward
-    stored are cleared from the bucket arrays of its partition pass -- by tc_rezero_kernel in front of the forward
-    ("main", rbx_fm_rezero) or by the NEXT partition pass itself, which reads the row each bucket position names before it
-    overwrites it ("fused": rbx_fm_sort_phases, phases | 8).  Steps of ONE batch size whose numbers of real lookups differ
-    (the second batch is 90 % padding: the previous pass placed more pairs than this one reaches; then back), then other
-    batch sizes == fresh zero-filled gradients, bit for bit."""
-    import os
-    from recbox_amd import ops
-    from recbox_amd._lib import lib
-    vocabs = [37, 5000, 70000, 1000000, 4099]
-    fm, fresh, reuse = _fm_pair(48, vocabs)
-    old = ops.config.reuse_grad_buffers
-    was = lib.rbx_fm_tier_c(1)
-    env = os.environ.get("RECBOX_AMD_FM_REZERO_ON")
-    os.environ["RECBOX_AMD_FM_REZERO_ON"] = where
-    try:
-        g = torch.Generator().manual_seed(3)
-        for k, B in enumerate([3000, 3000, 3000, 3000, 3000, 700, 5000, 5000]):
-            _, X, y = _criteo_like(B, vocabs, 16, seed=300 + k, zipf=bool(k % 2))
-            if k in (1, 3):
-                for i in range(len(vocabs)):
-                    X["C%d" % (i + 1)] = X["C%d" % (i + 1)] * (torch.rand(B, generator=g) < 0.1)
-            Xc, yc = _cuda(X), y.cuda()
-            ops.config.reuse_grad_buffers = False
-            _bce_step(fresh, Xc, yc)
-            ops.config.reuse_grad_buffers = True
-            _bce_step(reuse, Xc, yc)
-            for (n, p0), (_, p1) in zip(fresh.named_parameters(), reuse.named_parameters()):
-                assert torch.equal(p1.grad, p0.grad), "step %d: %s" % (k, n)
-    finally:
-        ops.config.reuse_grad_buffers = old
-        lib.rbx_fm_tier_c(was)
-        if env is None:
-            os.environ.pop("RECBOX_AMD_FM_REZERO_ON", None)
-        else:
-            os.environ["RECBOX_AMD_FM_REZERO_ON"] = env
-
-
 def test_ops_backward_equals_loss_backward_bit_for_bit():
     """``ops.backward(loss)`` hands autograd the persistent constant 1 as the loss's gradient (no ones_like fill, and the
     fused sigmoid + BCE returns dL/dlogit unscaled): the same gradients as ``loss.backward()``, bit for bit."""

@@ -282,8 +282,7 @@ def _block64(e, P, keep, heads):
     return (n + torch.relu(n @ P["w1"].t() + P["b1"]) @ P["w2"].t() + P["b2"]) * keep.unsqueeze(-1)
 
 
-@pytest.mark.parametrize("B,L,heads,one_pass_bwd", [(64, 200, 1, True), (45, 200, 2, True), (300, 30, 1, True), (45, 200, 1, False),
-                                                    (45, 200, 1, "ffn3"), (64, 200, 2, "ffn3")])
+@pytest.mark.parametrize("B,L,heads,one_pass_bwd", [(64, 200, 1, True), (45, 200, 2, True), (300, 30, 1, True), (45, 200, 1, False)])
 def test_block_as_one_node_vs_float64_and_vs_the_sublayer_nodes(B, L, heads, one_pass_bwd):
     """ops.sasrec_block (rbx_seqblock_* forward and backward) against the float64 restatement and against the two sub-layer
     nodes it replaces: output and every gradient (a ragged last slab at B L = 9000)."""
@@ -310,9 +309,8 @@ def test_block_as_one_node_vs_float64_and_vs_the_sublayer_nodes(B, L, heads, one
         ffn = [P[k].clone().cuda().requires_grad_(True) for k in ("w1", "b1", "w2", "b2")]
         ec = e.clone().cuda().requires_grad_(True)
         kc = keep.cuda()
-        old, old3 = ops.config.seqblock_bwd, ops.config.seqblock_ffn_bwd3
+        old = ops.config.seqblock_bwd
         ops.config.seqblock_bwd = bool(one_pass_bwd)
-        ops.config.seqblock_ffn_bwd3 = one_pass_bwd == "ffn3"      # (dW2 by the slab kernel + the three-product pass)
         try:
             if chains:
                 assert ops.seqblock_supported(ec, mha, False)
@@ -322,7 +320,7 @@ def test_block_as_one_node_vs_float64_and_vs_the_sublayer_nodes(B, L, heads, one
                 out = ops.sasrec_ffn_sublayer(x, n2, ffn[0], ffn[1], ffn[2], ffn[3], kc, keep_is_mask=True)
             (out * R.cuda()).sum().backward()
         finally:
-            ops.config.seqblock_bwd, ops.config.seqblock_ffn_bwd3 = old, old3
+            ops.config.seqblock_bwd = old
         grads = dict(ln1_w=n1.weight.grad, ln1_b=n1.bias.grad, in_w=mha.in_proj_weight.grad, in_b=mha.in_proj_bias.grad,
                      out_w=mha.out_proj.weight.grad, out_b=mha.out_proj.bias.grad, ln2_w=n2.weight.grad, ln2_b=n2.bias.grad,
                      w1=ffn[0].grad, b1=ffn[1].grad, w2=ffn[2].grad, b2=ffn[3].grad)
