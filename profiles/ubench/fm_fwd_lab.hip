@@ -384,6 +384,89 @@ __global__ __launch_bounds__(256, WPE) void fm_g4(const Meta M, const char* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------ g4n: numeric features off the memory path
+// g4 with the first NNUM columns numeric (compile-time here: what the form can gain): their weight vectors and LR weights sit
+// in LDS, their contribution x_f w_f is accumulated first (feature order), no row / LR lookup is issued for them.
+template <int F, int NNUM>
+__device__ __forceinline__ void g4n_numeric(const float (&x)[16], const float4* s_w, const int lane_g, float (&s)[4], float (&q)[4]) {
+  if constexpr (F < NNUM) {
+    const float xb = qbcastf<(F & 3)>(x[F >> 2]);
+    const float4 w = s_w[F * 4 + lane_g];
+    const float t0 = w.x * xb, t1 = w.y * xb, t2 = w.z * xb, t3 = w.w * xb;
+    s[0] += t0; q[0] += t0 * t0;
+    s[1] += t1; q[1] += t1 * t1;
+    s[2] += t2; q[2] += t2 * t2;
+    s[3] += t3; q[3] += t3 * t3;
+    g4n_numeric<F + 1, NNUM>(x, s_w, lane_g, s, q);
+  }
+}
+
+template <int NI, int UB, int WPE, int NNUM>
+__global__ __launch_bounds__(256, WPE) void fm_g4n(const Meta M, const char* __restrict__ arena, const int F,
+                                                   const double* __restrict__ X, const int ldx, const long long B,
+                                                   const float* __restrict__ bias, float* __restrict__ logit,
+                                                   float* __restrict__ prob, float* __restrict__ ssum) {
+  __shared__ int s_voc[64];
+  __shared__ unsigned s_eo[64], s_es[64], s_lo[64], s_ls[64];
+  __shared__ float4 s_w[16 * 4];
+  __shared__ float s_wl[16];
+  if (threadIdx.x < 64) {
+    s_voc[threadIdx.x] = M.vocab[threadIdx.x];
+    s_eo[threadIdx.x] = M.emb_off[threadIdx.x];
+    s_es[threadIdx.x] = M.emb_stride[threadIdx.x];
+    s_lo[threadIdx.x] = M.lr_off[threadIdx.x];
+    s_ls[threadIdx.x] = M.lr_stride[threadIdx.x];
+    if (threadIdx.x < NNUM * 4)
+      s_w[threadIdx.x] = *reinterpret_cast<const float4*>(arena + M.emb_off[threadIdx.x >> 2] + (threadIdx.x & 3) * 16);
+    if (threadIdx.x < NNUM) s_wl[threadIdx.x] = *reinterpret_cast<const float*>(arena + M.lr_off[threadIdx.x]);
+  }
+  __syncthreads();
+  const int lane_g = threadIdx.x & 3;
+  const unsigned lane16 = lane_g * 16;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / 4);
+  for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / 4) + threadIdx.x / 4; b < B; b += ngroups) {
+    const double* xr = X + b * ldx;
+    double c[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * i + lane_g;
+      c[i] = xr[col < F ? col : F - 1];
+    }
+    unsigned o[16];
+    float x[16], l1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * i + lane_g;
+      const int voc = s_voc[col];
+      const int v = __double2int_rz(c[i]);
+      const bool ok = (c[i] == c[i]) && static_cast<unsigned>(v) < static_cast<unsigned>(voc);
+      const bool num = col < NNUM;
+      const unsigned id = ok ? static_cast<unsigned>(v) : 0u;
+      x[i] = num ? static_cast<float>(c[i]) : 1.f;
+      o[i] = ok ? s_eo[col] + id * s_es[col] : 0u;
+      const unsigned lro = ok ? s_lo[col] + id * s_ls[col] : 0u;
+      if (num) l1[i] = s_wl[col];
+      else l1[i] = *reinterpret_cast<const float*>(arena + static_cast<size_t>(lro));
+    }
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    g4n_numeric<0, NNUM>(x, s_w, lane_g, s, q);
+    g4_batches<NNUM, 4 * NI, UB>(o, x, lane16, arena, s, q);
+    float lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) lr += l1[i] * x[i];
+    float fm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fm += (s[i] * s[i] - q[i]) * 0.5f;
+    const float total = group_sum4(fm + lr);
+    if (lane_g == 0) {
+      const float z = total + bias[0];
+      logit[b] = z;
+      prob[b] = 1.f / (1.f + expf(-z));
+    }
+    *reinterpret_cast<float4*>(ssum + b * 16 + lane_g * 4) = make_float4(s[0], s[1], s[2], s[3]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ g4l: g4 + small arrays in LDS
 // As g4, with the arrays that cost a cache-line lookup per sample but hold few bytes -- the numeric features' weight vectors
 // and LR weights, the rows and LR weights of the smallest tables -- copied into LDS by the workgroup's prologue (a copy list of
@@ -706,6 +789,10 @@ int main(int argc, char** argv) {
       {22, 48, "g4l: 48 KB in LDS, 10 in flight, 512-thread workgroups x 512 (2 per CU)", 512, true},
       {23, 150, "g4l: 150 KB in LDS, 10 in flight, 1024-thread workgroups x 256", 256, true},
       {21, 20, "g4l: 20 KB in LDS, 768-thread workgroups x 256", 256, true},
+      {9, 0, "g4n: numeric weights in LDS, no lookups for them; 20 rows in flight, 3 waves/SIMD", 1024, true},
+      {10, 0, "g4n: 14 rows in flight, 4 waves/SIMD", 1024, true},
+      {11, 0, "g4n: all 27 rows in one batch, 3 waves/SIMD", 1024, true},
+      {9, 16 + 64, "abl: g4n without LR and row misses", 1024, false},
       {7, 0, "g4: 10 rows in flight, 3 waves/SIMD register budget", 1024, true},
       {8, 0, "g4: 13 rows in flight, 3 waves/SIMD register budget", 1024, true},
       {3, 0, "g4: 10 rows in flight, 2048 workgroups (8 samples per lane group slot)", 2048, true},
@@ -750,6 +837,9 @@ int main(int argc, char** argv) {
         else if (v.kernel == 5) fm_g4<10, 20, 3><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 7) fm_g4<10, 10, 3><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 8) fm_g4<10, 13, 3><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 9) fm_g4n<10, 20, 3, 13><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 10) fm_g4n<10, 14, 4, 13><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 11) fm_g4n<10, 27, 3, 13><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 6) fm_g4<10, 8, 5><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 20) fm_g4l<10, 20, 256, 3><<<v.grid, 256, lp.lds_bytes>>>(lp.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 21) fm_g4l<10, 20, 768, 3><<<v.grid, 768, lp.lds_bytes>>>(lp.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);

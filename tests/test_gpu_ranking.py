@@ -204,8 +204,10 @@ def test_fm_matches_oracle_seeded(B, zipf):
     assert_close(loss1, loss0, TOL, "loss")
     for (n0, p0), (n1, p1) in zip(ref.named_parameters(), dut.named_parameters()):
         assert n0 == n1
-        # mean-reduced BCE scales grads by 1/B; compare at the scale of the summed gradient
-        assert_close(p1.grad * B, p0.grad * B, TOL * max(1.0, B / 64), "grad " + n0)
+        # mean-reduced BCE scales grads by 1/B: compared at the scale of the summed gradient, to 1e-4 of the tensor's largest
+        # entry (a hot row of a 3-row table sums thousands of contributions; until round 4 this was an absolute B / 64 slack)
+        want = p0.grad * B
+        assert_close(p1.grad * B, want, TOL * max(1.0, float(want.abs().max())), "grad " + n0)
 
 
 def test_fused_fm_model_golden():
@@ -251,9 +253,9 @@ def test_fused_fm_matches_layer_path_and_oracle(B, zipf):
         outs.append(logit)
     assert_close(outs[1], outs[0], TOL, "fused logit vs oracle")
     assert_close(outs[2], outs[0], TOL, "layer-path logit vs oracle")
-    scale = max(1.0, B / 64.0)          # summed loss: gradients of hot rows grow with B
     for (n0, p0), (_, p1), (_, p2) in zip(ref.named_parameters(), fused.named_parameters(),
                                           plain.named_parameters()):
+        scale = max(1.0, float(p0.grad.abs().max()))     # summed loss: 1e-4 of the tensor's largest entry (hot rows grow with B)
         assert_close(p1.grad, p0.grad, TOL * scale, "fused grad " + n0)
         assert_close(p2.grad, p0.grad, TOL * scale, "layer grad " + n0)
 
