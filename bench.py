@@ -719,9 +719,10 @@ def main():
                          "the tables, recbox_amd.optim; dense_adam: torch.optim.Adam over every parameter, as the reference does)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="fm, one GPU: do not append the time-boxed youtubednn / deepfm / sasrec sub-runs under \"configs\"")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = --batch samples PER GPU (the default: per-GPU work fixed); strong = --global-batch "
-                         "samples split B/N per GPU (SURVEY.md 8d/8e: global B = 65 536, 8 192 per GPU at N = 8)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: weak = --batch samples PER GPU (per-GPU work fixed: the default of fm, deepfm, sasrec); strong "
+                         "= --global-batch samples split B/N per GPU (the default of youtubednn: SURVEY.md 8d states cfg 3 as "
+                         "GLOBAL B = 65 536, 8 192 per GPU at N = 8)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="--scaling strong: the global batch (default 65536; sasrec 4096)")
     ap.add_argument("--sharded-graph", choices=["auto", "whole", "pieces", "eager"], default="auto",
@@ -730,6 +731,8 @@ def main():
                          "hipGraph pieces with the collectives between them (fm only); eager = from Python; auto = whole "
                          "when the check passes, else pieces (fm) / eager")
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = "strong" if (args.config == "youtubednn" and args.gpus > 1 and args.batch is None) else "weak"
     if args.scaling == "strong":
         if args.batch is not None:
             ap.error("--scaling strong takes --global-batch, not --batch")
