@@ -1,18 +1,25 @@
-"""Refresh the FM entries of profiles/rNN/traffic_rNN.json from the per-dispatch PMC averages that profiles/pmc.py printed
-(pmc_fm_tierc{0,1}_{FETCH,WRITE}_SIZE.txt of the same directory): hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB
-(MI355X_MICROARCH.md, HBM section: gfx950 tallies 128-byte requests at 64 bytes).
-    python profiles/traffic.py profiles/r04"""
+"""Write / refresh profiles/rNN/traffic_rNN.json from the per-dispatch PMC averages that profiles/pmc.py printed
+(pmc_<config>_{FETCH,WRITE}_SIZE.txt of the same directory; separate rocprofv3 --pmc passes):
+hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md, HBM section: gfx950 tallies 128-byte
+requests at 64 bytes).  An entry whose "kernel" lists several kernels (one C-ABI call that launches two) sums them.
+    python profiles/traffic.py profiles/r05"""
 import json
 import os
 import re
 import sys
 
-KEYS = {  # entry -> (tier-C setting of the pass, kernel substring)
-    "fm": (0, "fm_fused_fwd_kernel"), "fm_segment_reduce_tier_b": (0, "segment_reduce_kernel<rbx::FmPolicy"),
-    "fm_rezero": (0, "rezero_rows_kernel"), "fm_ta_reduce": (0, "ta_reduce_lds_kernel"), "fm_ta_final": (0, "ta_final_kernel"),
-    "fm_compact_ids": (0, "compact_ids_kernel"), "fm_tier_c_reduce": (1, "tc_reduce_kernel"),
-    "fm_tier_c_scatter": (1, "tc_scatter_kernel"), "fm_tier_c_count": (1, "tc_count_kernel"),
-    "fm_tier_c_rezero": (1, "tc_rezero_kernel"),
+# entry -> (config of the pass, kernel substrings, the name bench.py's roofline uses or a description, algorithmic bytes or None)
+KEYS = {
+    "fm": ("fm", ["fm_quad_fwd_kernel"], "fm_quad_fwd_kernel<10,20,3>", 133169152),
+    "fm_segment_reduce_tier_b": ("fm", ["segment_reduce_kernel<rbx::FmPolicy"],
+                                 "segment_reduce_kernel<FmPolicy,4,1,true> (the 12 large tables)", 132000000),
+    "fm_rezero": ("fm", ["rezero_rows_kernel"], "rezero_rows_kernel<true>", None),
+    "fm_ta_reduce": ("fm", ["ta_reduce_lds_kernel"], "ta_reduce_lds_kernel<4>", None),
+    "fm_ta_final": ("fm", ["ta_final_kernel"], "ta_final_kernel<4,true>", None),
+    "fm_compact_ids": ("fm", ["compact_ids_kernel"], "compact_ids_kernel<true>", None),
+    "fm_radix_scatter": ("fm", ["radix_scatter_kernel"], "radix_scatter_kernel<8> (one of three passes)", None),
+    "youtubednn": ("youtubednn", ["embed_seq_kernel", "embed_fwd_kernel"],
+                   "embed_seq_kernel<64,2,1,true> + embed_fwd_kernel<32,1,true> (one rbx_embed_fwd call)", 1240834022),
 }
 
 
@@ -29,19 +36,32 @@ def main():
     d = sys.argv[1]
     tag = os.path.basename(os.path.normpath(d))
     path = os.path.join(d, "traffic_%s.json" % tag)
-    doc = json.load(open(path))
-    vals = {(tc, c): read(os.path.join(d, "pmc_fm_tierc%d_%s.txt" % (tc, c))) for tc in (0, 1) for c in ("FETCH_SIZE", "WRITE_SIZE")}
-    for key, (tc, sub) in KEYS.items():
-        f = [v for k, v in vals[(tc, "FETCH_SIZE")].items() if sub in k]
-        w = [v for k, v in vals[(tc, "WRITE_SIZE")].items() if sub in k]
-        if key in doc and f and w:
-            doc[key]["FETCH_SIZE_KB_raw"] = f[0]
-            doc[key]["WRITE_SIZE_KB"] = w[0]
-            doc[key]["hbm_bytes_per_launch"] = int(round((2 * f[0] + w[0]) * 1024))
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc["_how"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in SEPARATE passes (profiles/scripts/%s_final.sh: "
+                   "bench.py --no-cpu-baseline [--config C] --eager --steps 5 --warmup 3), per-dispatch averages via profiles/pmc.py "
+                   "(pmc_<config>_{FETCH,WRITE}_SIZE.txt); FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, "
+                   "HBM section), WRITE_SIZE as is; unit KiB; 8 distinct batches rotated." % tag)
+    cache = {}
+    for key, (cfg, subs, name, algo) in KEYS.items():
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            f = os.path.join(d, "pmc_%s_%s.txt" % (cfg, c))
+            if (cfg, c) not in cache:
+                cache[(cfg, c)] = read(f) if os.path.exists(f) else {}
+        fs = [sum(v for k, v in cache[(cfg, "FETCH_SIZE")].items() if s in k) for s in subs]
+        ws = [sum(v for k, v in cache[(cfg, "WRITE_SIZE")].items() if s in k) for s in subs]
+        if not all(fs) or not all(ws):
+            continue
+        ent = doc.setdefault(key, {})
+        ent["kernel"] = name
+        ent["FETCH_SIZE_KB_raw"] = round(sum(fs), 1)
+        ent["WRITE_SIZE_KB"] = round(sum(ws), 1)
+        ent["hbm_bytes_per_launch"] = int(round((2 * sum(fs) + sum(ws)) * 1024))
+        if algo:
+            ent["algorithmic_bytes_per_launch"] = algo
     json.dump(doc, open(path, "w"), indent=1)
     for key in KEYS:
         if key in doc:
-            print(key, doc[key]["hbm_bytes_per_launch"])
+            print(key, doc[key]["hbm_bytes_per_launch"], doc[key].get("algorithmic_bytes_per_launch"))
 
 
 if __name__ == "__main__":
