@@ -10,6 +10,8 @@ constexpr int kSortThreads = 256;
 #define RBX_SORT_ITEMS 8
 constexpr int kSortItems = RBX_SORT_ITEMS;                 // per thread
 constexpr int kSortTile = kSortThreads * kSortItems;       // 2048 pairs per workgroup
+constexpr int kChainTiles = 64;                            // (BwdPlan::chained)
+constexpr int kChainPasses = 4;                            // 32-bit keys in digits of >= 8 bits
 constexpr int kRadix = 256;                                // bins of an 8-bit digit (the sort also runs 10- and 11-bit digits)
 // Widest digit the plan may choose.  10- and 11-bit digits (2 passes instead of 3 for 1 M-row tables) were measured on
 // the Criteo shape and LOST: a 2048-pair tile then scatters into 1024 buckets of ~2 pairs (8-byte runs instead of
@@ -112,6 +114,12 @@ struct BwdPlan {
   bool vec = true;
   // workspace layout (byte offsets)
   size_t off_keys[2], off_vals[2], off_hist, off_ssum, off_head, off_tail, off_flags, off_fin, off_long, off_num, bytes;
+  // Round 5: when no segment has more than kChainTiles tiles, the sort is 1 + passes launches -- build_keys counts the digits
+  // of EVERY pass per tile (a segment's digit totals do not depend on the order of its pairs), and a scatter workgroup gets
+  // the start of its runs from those totals plus the counts the tiles in front of it in its segment publish as they go
+  // (off_hist then holds [pass][tile][digit] counts of build_keys, the same again for the published counts, and
+  // [pass][tile] flags) -- instead of 1 + 3 x passes with histogram and scan kernels in between.
+  bool chained = false;
   unsigned n_tiles = 0, n_chunks = 0, num_blocks = 0;
   unsigned long_cap = kCUs * 2;  // workgroups of the long fix-up launch (one per long chain, grid-stride): every one of them
                                // arrives at one counter, so a plan that expects no long chains (fused FM with its small tables

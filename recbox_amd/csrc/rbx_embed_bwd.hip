@@ -145,6 +145,10 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
     S.tile0[S.n] = tiles;
     S.lk0[S.n] = lk;
     p->n_tiles = tiles;
+    unsigned max_nt = 0;
+    for (int g = 0; g < S.n; ++g)
+      if (S.tile0[g + 1] - S.tile0[g] > max_nt) max_nt = S.tile0[g + 1] - S.tile0[g];
+    p->chained = max_nt <= static_cast<unsigned>(kChainTiles);
     int bits = 1;
     while ((1ull << bits) <= max_rows) ++bits;     // 2^bits > rows of the largest segment: the all-ones key is free for masked lookups
     p->passes = (bits + kMaxRadixBits - 1) / kMaxRadixBits;
@@ -176,7 +180,11 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
   p->off_vals[0] = o; o += nl;
   p->off_vals[1] = o; o += nl;
   const size_t radix = static_cast<size_t>(1) << p->radix_bits;
-  p->off_hist = o; o += align_up(static_cast<size_t>(p->n_tiles) * radix * 4 + 4, 256);
+  static const bool chain_on = [] { const char* e = getenv("RBX_SORT_CHAINED"); return e == nullptr || e[0] != '0'; }();
+  p->chained = chain_on && p->chained && p->passes <= kChainPasses && p->radix_bits == 8;
+  p->off_hist = o;
+  o += p->chained ? align_up((2 * static_cast<size_t>(p->n_tiles) * radix + p->n_tiles) * p->passes * 4, 256)
+                  : align_up(static_cast<size_t>(p->n_tiles) * radix * 4 + 4, 256);
   p->off_ssum = o; o += align_up((static_cast<size_t>(p->n_tiles) * radix / 4096 + 2) * 4, 256);
   p->sum_stride = p->max_dim + extra_dim;
   p->off_head = o; o += align_up(static_cast<size_t>(p->n_chunks) * p->sum_stride * 4, 256);
@@ -203,8 +211,10 @@ __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack 
                                                          const unsigned sentinel, unsigned* __restrict__ keys0,
                                                          unsigned* __restrict__ vals0, unsigned* __restrict__ keys1,
                                                          unsigned* __restrict__ vals1, int* __restrict__ status,
-                                                         unsigned* __restrict__ fin, unsigned* __restrict__ hist) {
+                                                         unsigned* __restrict__ fin, unsigned* __restrict__ hist,
+                                                         const int chain_passes, const unsigned n_tiles) {
   constexpr int R = 1 << RB;
+  constexpr int kCP = (RB == 8) ? kChainPasses : 1;      // (the chained sort runs 8-bit digits only)
   if (blockIdx.x == 0 && threadIdx.x == 0) {          // fix-up work-list length and arrival counter (rbx_segreduce.h)
     fin[0] = 0;
     fin[1] = 0;
@@ -219,8 +229,8 @@ __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack 
   }
   // one workgroup per sort tile, so that the tile's histogram of the FIRST radix digit falls out of the same pass
   // (the keys are in registers anyway): the first radix_hist_kernel launch of the sort is not needed
-  __shared__ unsigned cnt[R];
-  for (int d = threadIdx.x; d < R; d += kSortThreads) cnt[d] = 0;
+  __shared__ unsigned cnt[kCP][R];
+  for (int d = threadIdx.x; d < kCP * R; d += kSortThreads) (&cnt[0][0])[d] = 0;
   __syncthreads();
   int seg;
   unsigned tile0, tile_n;
@@ -258,7 +268,26 @@ __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack 
     }
     keys[j] = key;
     vals[j] = (static_cast<unsigned>(lo) << kLocalBits) | local;
-    if (fp == 0) atomicAdd(&cnt[seg_digit<RB>(key, sentinel, row0, 0)], 1u);
+    if (chain_passes > 0) {
+      // BwdPlan::chained: this tile's count of every digit the segment will be sorted by
+#pragma unroll
+      for (int k = 0; k < kCP; ++k)
+        if (fp + k < chain_passes) atomicAdd(&cnt[k][seg_digit<RB>(key, sentinel, row0, k * RB)], 1u);
+    } else if (fp == 0) {
+      atomicAdd(&cnt[0][seg_digit<RB>(key, sentinel, row0, 0)], 1u);
+    }
+  }
+  if (chain_passes > 0) {
+    // [pass][tile][digit] counts, then the same again (what the scatter workgroups publish), then [pass][tile] flags
+    __syncthreads();
+    const size_t plane = static_cast<size_t>(n_tiles) * R;
+    unsigned* flags = hist + 2 * plane * chain_passes;
+    for (int k = 0; fp + k < chain_passes; ++k) {
+      unsigned* h = hist + plane * (fp + k) + static_cast<size_t>(blockIdx.x) * R;
+      for (int d = threadIdx.x; d < R; d += kSortThreads) h[d] = cnt[k < kCP ? k : 0][d];
+      if (threadIdx.x == 0) flags[static_cast<size_t>(fp + k) * n_tiles + blockIdx.x] = 0u;
+    }
+    return;
   }
   if (fp != 0) return;
   __syncthreads();
@@ -266,7 +295,7 @@ __global__ __launch_bounds__(kSortThreads) void build_keys_kernel(const KeyPack 
   // (digit, tile), the global position of its first pair
   const unsigned t_in = blockIdx.x - S.tile0[seg], nt = S.tile0[seg + 1] - S.tile0[seg];
   unsigned* h = hist + static_cast<size_t>(S.tile0[seg]) * R + t_in;
-  for (int d = threadIdx.x; d < R; d += kSortThreads) h[static_cast<size_t>(d) * nt] = cnt[d];
+  for (int d = threadIdx.x; d < R; d += kSortThreads) h[static_cast<size_t>(d) * nt] = cnt[0][d];
 }
 
 // ---- radix sort: per-tile digit histogram ----------------------------------------
@@ -365,7 +394,7 @@ __global__ __launch_bounds__(1024) void radix_scan_sums_kernel(unsigned* __restr
 // ---- stable scatter of one tile -----------------------------------------------------
 // Wave w owns the contiguous quarter [w*512, (w+1)*512) of the tile and walks it in
 // 64-item steps, so tile order == (wave, step, lane) and ranks respect it.
-template <int RB>
+template <int RB, bool CHAIN>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsigned* __restrict__ keys_in,
                                                                      const unsigned* __restrict__ vals_in,
                                                                      unsigned* __restrict__ keys_out,
@@ -373,7 +402,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
                                                                      const unsigned sentinel, const int pass,
                                                                      const unsigned* __restrict__ hist,
                                                                      const unsigned* __restrict__ slice_sum,
-                                                                     const unsigned n_slices, const bool raw_sums) {
+                                                                     const unsigned n_slices, const bool raw_sums,
+                                                                     unsigned* __restrict__ chain, const int passes,
+                                                                     const unsigned n_tiles) {
   constexpr int R = 1 << RB;
   constexpr int DPT = R / kSortThreads;              // digits per thread in the per-digit steps
   constexpr int kWaves = kSortThreads / 64;
@@ -399,7 +430,48 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
   const size_t hbase = hfirst + t_in;
   const unsigned seg_lk0 = S.lk0[seg];
   for (int i = threadIdx.x; i < kWaves * R; i += kSortThreads) (&wcnt[0][0])[i] = 0;
-  if (raw_sums) {
+  // BwdPlan::chained.  Start of this tile's run of digit d = pairs of the segment with a smaller digit (from build_keys'
+  // per-tile counts of this pass's digit: a total does not depend on the order) + pairs with digit d in the tiles in front
+  // of this one -- in the segment's first pass those are build_keys' counts too (the order is still the original one),
+  // later they are what those tiles publish below.
+  unsigned chain_excl[DPT], chain_before[DPT];
+  const size_t plane = static_cast<size_t>(n_tiles) * R;
+  const bool first_of_seg = pass == S.first_pass[seg];
+  if constexpr (CHAIN) {
+    __shared__ unsigned ctot[kWaves];
+    const unsigned* T = chain + plane * pass + static_cast<size_t>(S.tile0[seg]) * R;
+    unsigned tot[DPT];
+    unsigned mine = 0;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+      const int d = threadIdx.x * DPT + q;
+      unsigned a = 0, b = 0;
+#pragma unroll 8
+      for (unsigned t = 0; t < nt; ++t) {
+        const unsigned c = T[static_cast<size_t>(t) * R + d];
+        a += c;
+        b += (t < t_in) ? c : 0u;
+      }
+      tot[q] = a;
+      chain_before[q] = b;
+      mine += a;
+    }
+    unsigned inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) ctot[wid] = inc;
+    __syncthreads();
+    unsigned run = inc - mine;
+    for (int w = 0; w < wid; ++w) run += ctot[w];
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+      chain_excl[q] = run;
+      run += tot[q];
+    }
+  } else if (raw_sums) {
     // slice_sum holds the slice TOTALS as radix_scan_local_kernel left them (at most kMaxFusedSlices of them): every
     // workgroup scans them itself (a few dozen values at the bench shape) instead of waiting for a separate
     // one-workgroup kernel per pass
@@ -504,6 +576,41 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
     for (int q = 0; q < DPT; ++q) {
       dstart[threadIdx.x * DPT + q] = base;
       base += runs[q];
+    }
+    if constexpr (CHAIN) {
+      if (!first_of_seg) {
+        // publish this tile's counts, then wait for the tiles in front of it in the segment (lower workgroup indices:
+        // dispatched before this one, so they are running or done) and add theirs up
+        unsigned* L = chain + plane * (passes + pass);
+        unsigned* flags = chain + 2 * plane * passes + static_cast<size_t>(pass) * n_tiles;
+        // (everything that crosses workgroups here is an agent-scope atomic access -- written through to / read from the
+        //  memory side, where the eight L2s agree: a release / acquire pair would write back and invalidate a whole L2 per
+        //  workgroup.  The counts are acknowledged -- vmcnt(0) -- before the barrier, the flag goes out after it.)
+#pragma unroll
+        for (int q = 0; q < DPT; ++q)
+          __hip_atomic_store(L + static_cast<size_t>(blockIdx.x) * R + threadIdx.x * DPT + q, runs[q], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < t_in) {
+          const unsigned* f = flags + S.tile0[seg] + threadIdx.x;
+          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        const unsigned* Ls = L + static_cast<size_t>(S.tile0[seg]) * R;
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+          unsigned b = 0;
+#pragma unroll 8
+          for (unsigned t = 0; t < t_in; ++t)
+            b += __hip_atomic_load(Ls + static_cast<size_t>(t) * R + threadIdx.x * DPT + q, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+          chain_before[q] = b;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < DPT; ++q) gbase[threadIdx.x * DPT + q] = seg_lk0 + chain_excl[q] + chain_before[q];
     }
   }
   __syncthreads();
@@ -663,12 +770,23 @@ static int run_sort_rb(const BwdPlan& p, char* ws, int* d_status, hipStream_t s)
   unsigned* vals[2] = {reinterpret_cast<unsigned*>(ws + p.off_vals[0]), reinterpret_cast<unsigned*>(ws + p.off_vals[1])};
   unsigned* hist = reinterpret_cast<unsigned*>(ws + p.off_hist);
   unsigned* ssum = reinterpret_cast<unsigned*>(ws + p.off_ssum);
+  const bool chained = p.chained && RB == 8;
   hipLaunchKernelGGL(build_keys_kernel<RB>, dim3(p.n_tiles), dim3(kSortThreads), 0, s, p.keys, p.n_cat, p.segs, p.total_rows,
-                     keys[0], vals[0], keys[1], vals[1], d_status, reinterpret_cast<unsigned*>(ws + p.off_fin), hist);
+                     keys[0], vals[0], keys[1], vals[1], d_status, reinterpret_cast<unsigned*>(ws + p.off_fin), hist,
+                     chained ? p.passes : 0, p.n_tiles);
   int rc = check_launch("build_keys_kernel");
   if (rc != RBX_OK) return rc;
   int cur = 0;
   for (int pass = 0; pass < p.passes; ++pass) {
+    if (chained) {
+      hipLaunchKernelGGL((radix_scatter_kernel<RB, true>), dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], vals[cur],
+                         keys[cur ^ 1], vals[cur ^ 1], p.segs, p.total_rows, pass, static_cast<const unsigned*>(nullptr),
+                         static_cast<const unsigned*>(nullptr), 0u, false, hist, p.passes, p.n_tiles);
+      rc = check_launch("radix pass (chained)");
+      if (rc != RBX_OK) return rc;
+      cur ^= 1;
+      continue;
+    }
     if (pass > 0)        // (pass 0's histograms come out of build_keys_kernel)
       hipLaunchKernelGGL(radix_hist_kernel<RB>, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], p.segs, p.total_rows,
                          pass, hist);
@@ -677,8 +795,9 @@ static int run_sort_rb(const BwdPlan& p, char* ws, int* d_status, hipStream_t s)
     hipLaunchKernelGGL(radix_scan_local_kernel, dim3(n_slices), dim3(1024), 0, s, hist, hist_len, ssum);
     const bool raw_sums = n_slices <= static_cast<unsigned>(kMaxFusedSlices);
     if (!raw_sums) hipLaunchKernelGGL(radix_scan_sums_kernel, dim3(1), dim3(1024), 0, s, ssum, n_slices);
-    hipLaunchKernelGGL(radix_scatter_kernel<RB>, dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], vals[cur],
-                       keys[cur ^ 1], vals[cur ^ 1], p.segs, p.total_rows, pass, hist, ssum, n_slices, raw_sums);
+    hipLaunchKernelGGL((radix_scatter_kernel<RB, false>), dim3(p.n_tiles), dim3(kSortThreads), 0, s, keys[cur], vals[cur],
+                       keys[cur ^ 1], vals[cur ^ 1], p.segs, p.total_rows, pass, hist, ssum, n_slices, raw_sums,
+                       static_cast<unsigned*>(nullptr), p.passes, p.n_tiles);
     rc = check_launch("radix pass");
     if (rc != RBX_OK) return rc;
     cur ^= 1;
