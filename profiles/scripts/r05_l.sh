@@ -5,10 +5,10 @@ O=gpurun_out/r05l
 mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_ranking.py tests/test_gpu_cabi_vs_c_oracle.py tests/test_gpu_edge_cases.py -x -q -m gpu 2>&1 | tail -3 | tee $O/tests.txt
-for rep in 1 2; do
+for rep in 1 2 3; do
 for d in uniform zipf; do
     n=fm_${d}_$rep
-    timeout 200 python bench.py --steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline --dist $d > $O/bench_$n.json 2> $O/bench_$n.err
+    timeout 200 python bench.py --steps 100 --warmup 10 --no-extra-configs --no-cpu-baseline --dist $d > $O/bench_$n.json 2> $O/bench_$n.err
     python - <<PY | tee -a $O/ab.txt
 import json
 try:

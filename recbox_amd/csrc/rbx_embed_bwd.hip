@@ -183,7 +183,8 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
   static const bool chain_on = [] { const char* e = getenv("RBX_SORT_CHAINED"); return e == nullptr || e[0] != '0'; }();
   p->chained = chain_on && p->chained && p->passes <= kChainPasses && p->radix_bits == 8;
   p->off_hist = o;
-  o += p->chained ? align_up((2 * static_cast<size_t>(p->n_tiles) * radix + p->n_tiles) * p->passes * 4, 256)
+  o += p->chained ? align_up((2 * static_cast<size_t>(p->n_tiles) * radix + p->n_tiles + static_cast<size_t>(p->segs.n) * radix) *
+                             p->passes * 4, 256)
                   : align_up(static_cast<size_t>(p->n_tiles) * radix * 4 + 4, 256);
   p->off_ssum = o; o += align_up((static_cast<size_t>(p->n_tiles) * radix / 4096 + 2) * 4, 256);
   p->sum_stride = p->max_dim + extra_dim;
@@ -440,21 +441,46 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const unsig
   if constexpr (CHAIN) {
     __shared__ unsigned ctot[kWaves];
     const unsigned* T = chain + plane * pass + static_cast<size_t>(S.tile0[seg]) * R;
+    // (after the flags: [pass][segment][digit] totals, written in the segment's first pass by its first tile for the passes
+    //  that follow -- one row to read there instead of one per tile)
+    unsigned* G = chain + (2 * plane + n_tiles) * passes;
     unsigned tot[DPT];
     unsigned mine = 0;
+    if (first_of_seg) {
 #pragma unroll
-    for (int q = 0; q < DPT; ++q) {
-      const int d = threadIdx.x * DPT + q;
-      unsigned a = 0, b = 0;
+      for (int q = 0; q < DPT; ++q) {
+        const int d = threadIdx.x * DPT + q;
+        unsigned a = 0, b = 0;
 #pragma unroll 8
-      for (unsigned t = 0; t < nt; ++t) {
-        const unsigned c = T[static_cast<size_t>(t) * R + d];
-        a += c;
-        b += (t < t_in) ? c : 0u;
+        for (unsigned t = 0; t < nt; ++t) {
+          const unsigned c = T[static_cast<size_t>(t) * R + d];
+          a += c;
+          b += (t < t_in) ? c : 0u;
+        }
+        tot[q] = a;
+        chain_before[q] = b;
+        mine += a;
       }
-      tot[q] = a;
-      chain_before[q] = b;
-      mine += a;
+      if (t_in == 0) {
+        for (int k = pass + 1; k < passes; ++k) {
+          const unsigned* Tk = chain + plane * k + static_cast<size_t>(S.tile0[seg]) * R;
+#pragma unroll
+          for (int q = 0; q < DPT; ++q) {
+            const int d = threadIdx.x * DPT + q;
+            unsigned a = 0;
+#pragma unroll 8
+            for (unsigned t = 0; t < nt; ++t) a += Tk[static_cast<size_t>(t) * R + d];
+            G[(static_cast<size_t>(k) * S.n + seg) * R + d] = a;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < DPT; ++q) {
+        tot[q] = G[(static_cast<size_t>(pass) * S.n + seg) * R + threadIdx.x * DPT + q];
+        chain_before[q] = 0;
+        mine += tot[q];
+      }
     }
     unsigned inc = mine;
 #pragma unroll
