@@ -110,11 +110,11 @@ class ShardedFMStep(object):
         all-to-all rows back                                              RCCL
         head       fused FM forward (remote rows read at their wire slots),
                    loss, dL/dlogit, dL/d(remote rows) written to the slots [graph]
-        all-to-all dL/d(rows) to the owners                               RCCL, asynchronous ...
-        tail       fused backward of the replicated tables, flat grads    [graph]  ... overlapped with this
-        all-reduce of the flat gradient of the replicated parameters      RCCL, asynchronous ...
-        settle     owners scatter-add into their shard's dense grad
-                   (rbx_embed_sort + rbx_embed_bwd)                       [graph]  ... overlapped with this
+        all-to-all dL/d(rows) to the owners                               RCCL      } side stream, behind presort,
+        settle     owners scatter-add into their shard's dense grad                 } beside the tail (round 5)
+                   (rbx_embed_sort + rbx_embed_bwd)                       [graph]
+        tail       fused backward of the replicated tables, flat grads    [graph]
+        all-reduce of the flat gradient of the replicated parameters      RCCL, asynchronous
         finish     replicated grads un-flattened                          [graph]
 
     Capturing a collective inside a hipGraph is not dependable on this stack (round 1: the capture of a
@@ -302,18 +302,30 @@ class ShardedFMStep(object):
         serve()
         # the owners' id sort needs only the row numbers: it runs on a side stream beside the rows' way back and
         # the local forward, and is joined right before the owner-side scatter-add
-        self.side.wait_stream(cur)
+        # (enqueued BEHIND the rows' way back: in a replayed graph a kernel that waits for another hardware queue starts late --
+        #  with the sort captured first, the exchange started 76 us after the gather it depends on, profiles/r05)
+        served = cur.record_event()
+        comm.all_to_all_equal_into(self.back, self.vecs, group)
+        self.side.wait_event(served)
         with torch.cuda.stream(self.side):
             (self.presort_replay if pieces is self.graphs else self._presort)()
-        comm.all_to_all_equal_into(self.back, self.vecs, group)
         head()
-        grads_out = comm.all_to_all_equal_into(self.d_recv, self.dsend, group, async_op=True)
+        # Round 5: the owners' half of the backward -- dL/d(rows) to the owners, scatter-add into the shard's gradient -- goes
+        # to the side stream, behind the owners' id sort that is already there, and runs BESIDE the fused backward of the
+        # replicated tables on this stream (before: exchange -> tail -> settle in a row on this one; world of one through
+        # RCCL: 0.446 -> 0.402 ms, profiles/r05/sharded_owner_beside.txt)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            self.dsend.record_stream(self.side)
+            comm.all_to_all_equal_into(self.d_recv, self.dsend, group)
+            settle()
+            g = self.tables.weight.grad
+            if g is not None:
+                g.record_stream(cur)
         cur.wait_stream(self.early)
-        tail()                                    # overlaps with the gradient exchange
+        tail()
         self.reduced = comm.all_reduce_coalesced_(self.flat, group, async_op=True) if (self.flat and self.multi) else None
-        grads_out.wait()
         cur.wait_stream(self.side)
-        settle()                                  # overlaps with the all-reduce of the replicated gradients
         finish()
         return self.loss
 
