@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RBX_VERSION 123          /* 0.1.23: rbx_fm_tier_c / rbx_fm_rezero_fusable, rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials removed (variants that lost their A/B); 0.1.22: rbx_cin_outer_*; 0.1.21: rbx_prelu_* / rbx_dropout / rbx_dice_* (csrc/rbx_act.hip); 0.1.20: rbx_fm_quad (rbx_fm_fwd's kernel for ids that are columns of one batch tensor); 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
+#define RBX_VERSION 124          /* 0.1.24: rbx_sort_chained (the id sort in 1 + passes launches); 0.1.23: rbx_fm_tier_c / rbx_fm_rezero_fusable, rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials removed (variants that lost their A/B); 0.1.22: rbx_cin_outer_*; 0.1.21: rbx_prelu_* / rbx_dropout / rbx_dice_* (csrc/rbx_act.hip); 0.1.20: rbx_fm_quad (rbx_fm_fwd's kernel for ids that are columns of one batch tensor); 0.1.19: rbx_seqblock_* (the row-local chains of a SASRec block as single passes); 0.1.18: rbx_fm_tier_c (the fused FM backward's sort-free tier C), rbx_opt_advance, rbx_opt_t.d_step_size, rbx_comm_bind_collectives takes ncclCommUserRank; 0.1.17: rbx_all_reduce / rbx_all_gather / rbx_comm_bind_collectives (every collective of the sharded step on the caller's stream); 0.1.16: rbx_linear_dx_scaled / rbx_linear_dwdb_scaled, rbx_rowscale_seq / rbx_seq_colsum; 0.1.15: rbx_linear_fwd_bnstats / rbx_linear_dx_bnsums / rbx_batchnorm_*_from_partials; 0.1.14: rbx_split_bf16 / _register / _unregister (f32 GEMM on the bf16 matrix cores); 0.1.13: rbx_fm_sort_phases, rbx_fm_bwd phases bits 3 / 4 (round 3: the fused FM backward in
                                   * two tiers); 0.1.11: rbx_fm_fwd grew d_prob; 0.1.10: rbx_field_t grew table_stride (round 2) */
 #define RBX_MAX_FIELDS 64        /* fields per call */
 #define RBX_NO_ID INT64_MIN      /* "no such id" for padding_idx / mask_id */
@@ -294,6 +294,13 @@ int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, 
  * automatically; rbx_fm_quad(0) forces the general kernel (A/B measurements, tests), a negative value only reads; returns
  * the previous setting (RBX_FM_QUAD=0 in the environment: off from the start). */
 int rbx_fm_quad(int32_t enable);
+/* Round 5: the id sort behind every backward (rbx_embed_sort, rbx_fm_sort, ...) runs as 1 + passes launches when no table
+ * group of the call has more than 64 sort tiles (131 072 lookups): the pairs kernel counts every pass's digit per tile, and a
+ * scatter workgroup takes the start of its runs from those counts plus what the tiles in front of it publish
+ * (csrc/rbx_embed_bwd.hip, BwdPlan::chained).  rbx_sort_chained(0) forces the histogram / scan / scatter launches per pass
+ * for every call (A/B measurements, tests; the results are the same pairs in the same order); a negative value only reads;
+ * returns the previous setting.  The workspace sizes depend on the setting: size and call with the same one. */
+int rbx_sort_chained(int32_t enable);
 int rbx_fm_rezero(const rbx_field_t* emb, const rbx_field_t* lr, int32_t n_fields, int64_t batch,
                   void* d_workspace, size_t workspace_bytes, void* stream);
 /* Two lookups over the SAME id tensors with the same table layout (the embedding tables of FeatureEmbedding and the dim-1

@@ -109,6 +109,7 @@ SIGNATURES = {
     "rbx_seq_colsum": (ctypes.c_int, [_P, _P, _i64, _i32, _i32, _P, _P, _sz, _P]),
     "rbx_sum_prefix": (ctypes.c_int, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _i32, _P, _i64, _P]),
     "rbx_fm_quad": (ctypes.c_int, [_i32]),
+    "rbx_sort_chained": (ctypes.c_int, [_i32]),
     "rbx_fm_rezero": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _sz, _P]),
     "rbx_fm_bwd": (ctypes.c_int, [_FP, _FP, _i32, _i64, _P, _P, _P, _i32, _i32, _P, _sz, _P]),
     "rbx_gatherdot_fwd": (ctypes.c_int, [_FP, _i32, _i64, _P, _i64, _f32, _P, _P, _P]),

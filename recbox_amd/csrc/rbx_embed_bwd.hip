@@ -26,6 +26,16 @@ namespace rbx {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// BwdPlan::chained on (the default; RBX_SORT_CHAINED=0 or rbx_sort_chained(0): histogram + scan + scatter launches per pass)
+static int g_sort_chained = -1;
+static bool sort_chained_on() {
+  if (g_sort_chained < 0) {
+    const char* e = getenv("RBX_SORT_CHAINED");
+    g_sort_chained = (e != nullptr && e[0] == '0') ? 0 : 1;
+  }
+  return g_sort_chained != 0;
+}
+
 int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, int64_t stride_b, BwdPlan* p,
               int extra_dim) {
   if (fields == nullptr || n <= 0 || n > RBX_MAX_FIELDS) return fail(RBX_ERR_INVALID, "bad field array");
@@ -180,8 +190,7 @@ int make_plan(const rbx_field_t* fields, int n, int64_t B, const float* dout, in
   p->off_vals[0] = o; o += nl;
   p->off_vals[1] = o; o += nl;
   const size_t radix = static_cast<size_t>(1) << p->radix_bits;
-  static const bool chain_on = [] { const char* e = getenv("RBX_SORT_CHAINED"); return e == nullptr || e[0] != '0'; }();
-  p->chained = chain_on && p->chained && p->passes <= kChainPasses && p->radix_bits == 8;
+  p->chained = sort_chained_on() && p->chained && p->passes <= kChainPasses && p->radix_bits == 8;
   p->off_hist = o;
   o += p->chained ? align_up((2 * static_cast<size_t>(p->n_tiles) * radix + p->n_tiles + static_cast<size_t>(p->segs.n) * radix) *
                              p->passes * 4, 256)
@@ -781,6 +790,12 @@ __global__ __launch_bounds__(64) void numeric_final_kernel(const NumPack P, cons
 }
 
 }  // namespace rbx
+
+extern "C" int rbx_sort_chained(int32_t enable) {
+  const int was = rbx::sort_chained_on() ? 1 : 0;
+  if (enable >= 0) rbx::g_sort_chained = enable ? 1 : 0;
+  return was;
+}
 
 extern "C" size_t rbx_embed_bwd_workspace_size(const rbx_field_t* fields, int32_t n_fields, int64_t batch) {
   rbx::BwdPlan p;

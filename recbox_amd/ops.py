@@ -435,6 +435,13 @@ def fm_quad_kernel(enable=None):
     return bool(lib.rbx_fm_quad(-1 if enable is None else int(bool(enable))))
 
 
+def sort_chained(enable=None):
+    """The id sort of the backward kernels in 1 + passes launches (csrc/rbx_embed_bwd.hip, BwdPlan::chained): read (``None``) or
+    set the switch; returns the previous setting.  Off = histogram / scan / scatter launches per pass (A/B measurements, tests).
+    Workspaces are sized for the setting in force: flip it between steps, not between a sort and its backward."""
+    return bool(lib.rbx_sort_chained(-1 if enable is None else int(bool(enable))))
+
+
 def check_deferred_ids():
     """Raise IndexError if any lookup since the last call met an id outside its table while ``config.check_ids`` was off
     (one device-to-host read per device; the words are cleared)."""

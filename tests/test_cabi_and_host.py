@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(raw, n), "librecbox_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "recbox_amd/_lib.py has no ctypes signature for %s" % n
     assert sorted(_lib.SIGNATURES) == names          # and nothing bound that the header does not declare
-    assert _lib.lib.rbx_version() == 123
+    assert _lib.lib.rbx_version() == 124
     assert ctypes.sizeof(_lib.rbx_field_t) == 104    # matches the C layout (8-byte aligned; table_stride appended in round 2)
 
 

@@ -90,3 +90,49 @@ def test_hot_rows_with_nonzero_gradients_are_summed_by_several_workgroups(D, R):
     # f32 sums of up to 700 000 terms of size ~0.5: a few 1e-7 of the sum of magnitudes; one lost window of 512 chunks
     # (>= 8192 terms) would be off by tens
     assert float((a.double().cpu() - want).abs().max()) <= 5e-7 * R
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L", [(100, 1), (2048, 3), (65536, 2), (4096, 31), (9000, 7)])
+def test_chained_sort_leaves_the_same_gradients_as_the_launch_per_pass_sort(B, L):
+    """The id sort of the backward in 1 + passes launches (rbx_sort_chained, BwdPlan::chained: tiles of a table group chained
+    by published counts) against the histogram / scan / scatter launches per pass: the same sorted pairs, hence BIT-identical
+    gradients -- tables that sort in 1, 2, 3 and 4 passes in one call (200 / 30 000 / 3 000 000 / 20 000 000 rows: the
+    shorter ones join the sort in a later pass), one id and pooled sequences per sample, 1 .. 64 tiles per table group
+    (65 536 x 2 lookups = exactly 64 tiles, the largest chained group; 4096 x 31 = 62), ids drawn so that runs of equal ids
+    cross tile borders -- and both against float64 index_add."""
+    from recbox_amd import _embed_host as host, ops
+    from recbox_amd._lib import FIELD_CATEGORICAL, POOL_NONE, POOL_SUM_ID
+    g = torch.Generator().manual_seed(B * 131 + L)
+    vocabs, D = [200, 30_000, 3_000_000, 20_000_000], 4
+    tables = [torch.nn.Embedding(v, D).cuda() for v in vocabs]
+    ids = []
+    for v in vocabs:
+        t = torch.randint(0, v, (B, L), generator=g)
+        hot = torch.rand(B, L, generator=g) < 0.3               # 30 % of the lookups on 5 rows: long runs of equal keys
+        t[hot] = torch.randint(0, 5, (int(hot.sum()),), generator=g) * (v // 7)
+        ids.append(t if L > 1 else t[:, 0])
+    lookups = [host.Lookup("f%d" % i, FIELD_CATEGORICAL, tables[i], D, pool=POOL_SUM_ID if L > 1 else POOL_NONE, seq_len=L,
+                           mask_id=-1 if L > 1 else None)
+               for i in range(len(vocabs))]
+    plan = host.Plan(lookups)
+    gout = torch.randn(B, plan.width, generator=g)
+    was = ops.sort_chained()
+    grads = {}
+    try:
+        for mode in (True, False):
+            ops.sort_chained(mode)
+            for t in tables:
+                t.weight.grad = None
+            out = plan.run([i.cuda() for i in ids])
+            out.backward(gout.cuda())
+            grads[mode] = [t.weight.grad.clone() for t in tables]
+    finally:
+        ops.sort_chained(was)
+    for k, (a, b) in enumerate(zip(grads[True], grads[False])):
+        assert torch.equal(a, b), "table %d" % k
+        idk = ids[k].reshape(B, L)
+        want = torch.zeros(vocabs[k], D, dtype=torch.float64)
+        want.index_add_(0, idk.reshape(-1), gout[:, k * D:(k + 1) * D].double().repeat_interleave(L, dim=0))
+        err = float((a.double().cpu() - want).abs().max())
+        assert err <= 1e-5 * max(1.0, float(want.abs().max())), "table %d: %g" % (k, err)
