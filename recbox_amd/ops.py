@@ -361,6 +361,25 @@ def _note_touched(kind, plans, inputs, params, grads, ws, ws_bytes, B):
             touched[id(p)] = rec
 
 
+touched_ids = {}             # id(parameter) -> (data_ptr of its gradient, [id tensors of every lookup that wrote into it])
+
+
+def _note_ids(plan, inputs, params, grads, want):
+    """A lookup over ``plan`` has written rows into ``grads`` (its own, or -- adopted -- the gradient another node of this
+    backward pass published): remember the id tensors per table, so that a sparse-row optimiser can step a table that
+    several lookups of one step feed (SASRec's item table: the sequence lookup and the pos / neg candidates of gather_dot)
+    over the union of their rows instead of scanning the dense gradient for non-zero rows."""
+    for k, (p, g, w) in enumerate(zip(params, grads, want)):
+        if not w or g is None:
+            continue
+        ids = [t for sp, t in zip(plan.specs, inputs) if sp.kind == _lib.FIELD_CATEGORICAL and sp.param == k]
+        ent = touched_ids.get(id(p))
+        if ent is not None and ent[0] == g.data_ptr():
+            ent[1].extend(ids)
+        else:
+            touched_ids[id(p)] = (g.data_ptr(), ids)
+
+
 def _forget_sort(ws):
     """A backward has consumed the sort in ``ws``: the step is over, the next one sorts afresh (its ids may live in the
     same tensors with the same version counters only if nothing was written -- but a workspace handed back to the
@@ -546,9 +565,12 @@ class _EmbedLookup(torch.autograd.Function):
         if pool is not None:
             pool.done(B)
         _forget_sort(ws)
+        if config.track_touched_rows:
+            _note_ids(plan, ctx.inputs, params, grads, want)
         if adopted is not None:                        # the rows went into the gradient another node of this pass returned
             # ... whose record of touched rows (sparse-row optimisers) names only ITS lookup's rows: the gradient now also
-            # holds this lookup's, so the record must go -- the optimiser then steps the table over its non-zero rows
+            # holds this lookup's, so the record must go -- the optimiser then steps the table over the union of the
+            # lookups' rows (touched_ids)
             for p, w in zip(params, want):
                 if w:
                     touched.pop(id(p), None)
@@ -1721,6 +1743,8 @@ class _GatherDot(torch.autograd.Function):
         check(lib.rbx_gatherdot_bwd(plan.arr, plan.n, R, _ptr(x), x.stride(0), _ptr(dout), ctx.scale, _ptr(dx),
                                     x.stride(0) if dx is None else dx.stride(0), 1 if adopted is not None else 0,
                                     _ptr(ws), ws_bytes, _stream()))
+        if config.track_touched_rows:
+            _note_ids(plan, ctx.inputs, params, grads, want)
         if adopted is not None:
             for p, w in zip(params, want):       # (see _EmbedLookup.backward: the first node's record names its rows only)
                 if w:

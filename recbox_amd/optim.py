@@ -19,8 +19,10 @@ Rules (the sparse branches of torch.optim, so that results can be checked agains
   SparseAdagrad  s += g^2;  w -= clr g / (sqrt(s) + eps), clr = lr / (1 + (t - 1) lr_decay)      (torch.optim.Adagrad)
   SparseAdam     lazy Adam: the moments of untouched rows do not decay                            (torch.optim.SparseAdam)
 Dense stays the default and the parity surface of the layers; nothing here changes what ``p.grad`` is after a backward.
-A parameter that got its gradient from something else than ``embed_lookup`` / ``fm_fused`` (or from two lookups in one
-step) is stepped densely over its non-zero gradient rows with the same rule.
+A table that several lookups of one step feed (SASRec's item table: the sequence lookup and gather_dot's candidates) is
+stepped with the same rule over the union of their rows (the lookups leave their id tensors: ``ops.touched_ids``); a
+parameter that got its gradient from something else than ``embed_lookup`` / ``gather_dot`` / ``fm_fused`` is stepped over
+the non-zero rows of its dense gradient.
 """
 import ctypes
 import math
@@ -141,6 +143,7 @@ class _SparseRows(object):
         # past zero_grad(set_to_none=True) (the next backward allocates its own before overwriting the record)
         for pid in mine:
             ops.touched.pop(pid, None)
+            ops.touched_ids.pop(pid, None)
 
     def _step_dense(self, p):
         if self.capturable:
@@ -152,7 +155,17 @@ class _SparseRows(object):
         st["step"] += 1
         g = p.grad
         if g.dim() >= 2 and g.shape[0] > 1:
-            rows = (g.reshape(g.shape[0], -1) != 0).any(dim=1).nonzero().reshape(-1)
+            ent = ops.touched_ids.get(id(p))
+            if ent is not None and ent[0] == g.data_ptr() and ent[1]:
+                # every lookup that wrote into this gradient left its id tensors: the union of their rows, cut to the rows
+                # that did receive a gradient (padding / masked ids do not) -- the same set the scan below finds, without
+                # reading the [V, D] gradient
+                self.calls["union"] = self.calls.get("union", 0) + 1
+                rows = torch.unique(torch.cat([t.reshape(-1).long() for t in ent[1]]))
+                rows = rows[(rows >= 0) & (rows < g.shape[0])]
+                rows = rows[(g.reshape(g.shape[0], -1).index_select(0, rows) != 0).any(dim=1)]
+            else:
+                rows = (g.reshape(g.shape[0], -1) != 0).any(dim=1).nonzero().reshape(-1)
         else:
             rows = None
         self._dense_rows(p, g, st, rows, st["step"])
