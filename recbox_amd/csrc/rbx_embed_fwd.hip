@@ -192,9 +192,16 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const FieldPack P, const
 // contiguous bytes per sample and evens out ragged lengths inside a wave.  Summation order is fixed by
 // (R, list order) -> deterministic, and equal to sequence order when R == 1.
 template <int G, int R, int NV, bool VEC>
+#ifndef RBX_SEQ_WAVES
 #define RBX_SEQ_WAVES 4
+#endif
 #define RBX_SEQ_SG16 32
+#ifndef RBX_SEQ_SG32
+#define RBX_SEQ_SG32 64
+#endif
+#ifndef RBX_SEQ_U
 #define RBX_SEQ_U 4
+#endif
 __global__ __launch_bounds__(256, RBX_SEQ_WAVES) void embed_seq_kernel(const FieldPack P, const int F, const long long B,
                                                         float* __restrict__ out, const long long stride_b,
                                                         float* __restrict__ row_scale,
@@ -329,7 +336,7 @@ template <int G, int NV, bool VEC>
 static int launch_fwd(bool seq, const FieldPack& pack, int F, int64_t B, float* out, int64_t stride_b,
                       float* row_scale, int* status, hipStream_t s) {
   const long long npairs = B * F;
-  constexpr int SG = (G <= 8) ? 16 : ((G == 16) ? RBX_SEQ_SG16 : 64);   // lanes per (sample, sequence feature)
+  constexpr int SG = (G <= 8) ? 16 : ((G == 16) ? RBX_SEQ_SG16 : ((G == 32) ? RBX_SEQ_SG32 : 64));   // lanes per (sample, sequence feature)
   const int groups_per_block = 256 / (seq ? SG : G);
   long long blocks = (npairs + groups_per_block - 1) / groups_per_block;
   if (seq) blocks = ((B + 64 / SG - 1) / (64 / SG) * F + 3) / 4;          // 4 wave tasks per workgroup
