@@ -33,11 +33,11 @@ prof() { # name, bench args, anchor kernel, occurrence
   if [ $1 = fm ]; then python profiles/kernel_slice.py $db fm_quad_fwd 24 60 > $out/fm_fwd_kernel_by_phase.txt 2>&1; fi
   rm -rf $out/prof $out/prof_$1.log
 }
-prof fm "--steps 20 --warmup 5" compact_ids -6
-prof fm_sharded1 "--config fm --force-sharded --steps 20 --warmup 5" route_count -6
-prof youtubednn "--config youtubednn --steps 20 --warmup 5" embed_seq -6
-prof deepfm "--config deepfm --steps 20 --warmup 5" "embed_fwd_kernel<16" -6
-prof sasrec "--config sasrec --steps 20 --warmup 5" embed_seq -6
+prof fm "--steps 20 --warmup 5" compact_ids 30
+prof fm_sharded1 "--config fm --force-sharded --steps 20 --warmup 5" route_count 14
+prof youtubednn "--config youtubednn --steps 20 --warmup 5" embed_seq 12
+prof deepfm "--config deepfm --steps 20 --warmup 5" "embed_fwd_kernel<16" 15
+prof sasrec "--config sasrec --steps 20 --warmup 5" embed_seq 15
 # HBM traffic from the PMC counters, separate passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md)
 for cfg in fm youtubednn; do
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -193,7 +193,7 @@ def test_table_fed_by_a_lookup_and_gather_dot_steps_over_the_union_of_their_rows
     """VERDICT r4 (missing #6): SASRec's item table feeds the sequence lookup AND gather_dot's pos / neg candidates in one
     step (matching/pytorch/models/match_model.py:192-198 steps it with one dense optimiser step).  Both backward nodes
     leave their id tensors (ops.touched_ids); the sparse-row optimiser steps the union of their rows that received a
-    gradient -- padding ids do not -- without scanning the [V, D] gradient, and equals the torch rule on those rows."""
+    gradient (gather_dot's padding ids do not) without scanning the [V, D] gradient, and equals the torch rule on those rows."""
     from recbox_amd import ops, optim
     from recbox_amd.rechub.basic.layers import EmbeddingLayer
     Fe = _rh_features()
@@ -213,7 +213,7 @@ def test_table_fed_by_a_lookup_and_gather_dot_steps_over_the_union_of_their_rows
         for k in range(3):
             g = torch.Generator().manual_seed(170 + k)
             ids = torch.randint(1, 1500, (B,), generator=g)
-            ids[: 5 + k] = 0                                           # padding ids: no gradient for row 0
+            ids[: 5 + k] = 0                                           # (rechub's lookup trains its padding row: layers.py:66-116)
             cand = torch.randint(1500, V, (B, 3), generator=g)         # rows the lookup never names
             cand[0, 0] = 0
             opt.zero_grad()
@@ -222,7 +222,7 @@ def test_table_fed_by_a_lookup_and_gather_dot_steps_over_the_union_of_their_rows
             ((logits * logits).sum() + 0.5 * (e * e).sum()).backward()
             gr = table.grad.detach().clone()
             rows = (gr != 0).any(dim=1).nonzero().reshape(-1)
-            assert int((rows >= 1500).sum()) > 0 and int((rows < 1500).sum()) > 0 and float(gr[0].abs().max()) == 0.0
+            assert int((rows >= 1500).sum()) > 0 and int((rows < 1500).sum()) > 0
             opt.step()
             _reference_step("adagrad", ref, gr, rows, state, hp)
             assert torch.allclose(table.detach(), ref, atol=2e-6, rtol=0), (k, float((table.detach() - ref).abs().max()))
