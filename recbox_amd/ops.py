@@ -7,6 +7,7 @@ CPU tensor or a missing library raises.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -26,6 +27,12 @@ class config(object):
     # the forward kernel itself slows from 47 to 63-73 us beside the re-zero / key-build kernels (all of them load the
     # memory system), but the chain is 20 us shorter.  On by default.
     sort_before_forward = os.environ.get("RECBOX_AMD_SORT_FIRST", "1") != "0"
+    # tower layers (ops.linear, DeepFM's input stage): the input's gradient dx first, then dW / db on a side stream -- they
+    # run beside whatever consumes dx (the embedding lookup's backward: segmented reduce + fix-ups, HBM / latency bound; the
+    # BatchNorm backward of the layer below), joined when the backward pass ends.  DeepFM 4.27 -> 4.13 ms, YoutubeDNN
+    # 1.75 -> 1.65 ms (profiles/r05/dw_beside_ab.txt).  Not used for parameters that already hold a gradient (autograd would
+    # add in place) or that a gradient bucket watches (sharded models).
+    dw_beside_lookup = os.environ.get("RECBOX_AMD_DW_BESIDE", "1") != "0"
     # The reference raises IndexError for an out-of-range id (nn.Embedding on CPU).
     # The kernels flag it on device; checking the flag costs one sync per call.
     check_ids = os.environ.get("RECBOX_AMD_CHECK_IDS", "1") != "0"
@@ -1507,6 +1514,32 @@ def gemm_bx6_count():
     return int(lib.rbx_gemm_bx6_count())
 
 
+def _beside_ok(ctx, wanted, keys):
+    """config.dw_beside_lookup for this backward node: only for parameters whose gradient autograd merely stores (no gradient
+    yet: an in-place sum would read what the side stream is still writing) and that no gradient bucket watches (DenseGradSync
+    starts its all-reduce from the parameters' hooks)."""
+    if not (wanted and config.dw_beside_lookup and config.fork_in_capture):
+        return False
+    owners = [r() for r in getattr(ctx, "owners", ())]
+    return (len(owners) > 0 and all(p is not None and p.grad is None for p in owners)
+            and not any(k and _grad_views.get(k) is not None for k in keys))
+
+
+def _run_beside(dev, fn, tensors):
+    """``fn()`` on the second side stream behind everything enqueued so far; the current stream waits for it when the backward
+    pass ends (autograd's end-of-pass callback: in a captured step that is the join of the fork)."""
+    cur = torch.cuda.current_stream(dev)
+    side = _side_stream(dev, 1)
+    side.wait_event(cur.record_event())
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    done = side.record_event()
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_event(done))
+
+
 class _Linear(torch.autograd.Function):
     """y = act(x W^T + b) via rbx_linear_fwd; act in {None, "relu"} is fused into the epilogue.  x may be a column
     block of a wider row-major activation (row stride > K): it is read, and its gradient written, in place."""
@@ -1530,6 +1563,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, w, y if act == 1 else None)
         ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, shape
         ctx.grad_keys = (weight.data_ptr() if weight.is_contiguous() else 0, bias.data_ptr() if bias is not None else 0)
+        ctx.owners = [weakref.ref(t) for t in (weight, bias) if t is not None and t.requires_grad]
         return y.view(*shape[:-1], N)
 
     @staticmethod
@@ -1545,14 +1579,20 @@ class _Linear(torch.autograd.Function):
         dw = _grad_dest(ctx.grad_keys[0], w.shape, dy.device) if ctx.needs_input_grad[1] else None
         db = _grad_dest(ctx.grad_keys[1], (N,), dy.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, ctx.act)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
-        bwd = lambda: check(lib.rbx_linear_bwd(                                                            # noqa: E731
-            _ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx),
-            (dx.stride(0) if M > 1 else K) if dx is not None else K, _ptr(dw), _ptr(db), _ptr(ws), ws_bytes, _stream()))
-        if dx is not None:
-            _with_split_weights(w, M, 1, bwd)
+
+        def bwd_of(dx_, dw_, db_):
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+            return lambda: check(lib.rbx_linear_bwd(
+                _ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx_),
+                (dx_.stride(0) if M > 1 else K) if dx_ is not None else K, _ptr(dw_), _ptr(db_), _ptr(ws), ws_bytes, _stream()))
+        if _beside_ok(ctx, dx is not None and (dw is not None or db is not None) and M >= 4096, ctx.grad_keys):
+            # dx first; dW / db on the side stream beside whatever consumes dx (config.dw_beside_lookup, see _DeepFmInput)
+            _with_split_weights(w, M, 1, bwd_of(dx, None, None))
+            _run_beside(dy.device, bwd_of(None, dw, db), (x2, w, y, dy2, dw, db))
+        elif dx is not None:
+            _with_split_weights(w, M, 1, bwd_of(dx, dw, db))
         else:
-            bwd()
+            bwd_of(dx, dw, db)()
         return (dx.view(ctx.shape) if dx is not None else None), dw, db, None
 
 
@@ -3261,6 +3301,7 @@ class _DeepFmInput(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, lr_w, lr_b, fm_cols, dim):
         _require_cuda(x, "DeepFM input block")
+        ctx.owners = [weakref.ref(t) for t in (w1, b1, lr_w, lr_b) if t is not None and t.requires_grad]
         x2 = _rows_view(x)
         w1 = w1.contiguous()
         lr_w = lr_w.contiguous()
@@ -3310,17 +3351,26 @@ class _DeepFmInput(torch.autograd.Function):
         keys = getattr(ctx, "grad_keys", (0, 0, 0, 0))
         dw1 = _grad_dest(keys[0], w1.shape, dev) if need[1] else None
         db1 = _grad_dest(keys[1], (N,), dev) if (has_b1 and need[2]) else None
-        _lin_dwdb(x2, w1, dh2, dw1, db1)
         dlr_w = _grad_dest(keys[2], lr_w.shape, dev) if need[3] else None
         dlr_b = _grad_dest(keys[3], (1,), dev) if (has_lr_b and need[4]) else None
-        if dlr_w is not None or dlr_b is not None:           # the logit head's streaming kernels (n = 1)
-            xl = x2[:, :fm_cols]
-            gl2 = gl.view(M, 1)
-            tmp_w = dlr_w if dlr_w is not None else torch.empty_like(lr_w)
-            ws_bytes = lib.rbx_linear_bwd_workspace_size(M, 1, fm_cols, 0)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            check(lib.rbx_linear_bwd(_ptr(xl), x2.stride(0), _ptr(lr_w), None, _ptr(gl2), M, 1, fm_cols, 0, None, fm_cols,
-                                     _ptr(tmp_w), _ptr(dlr_b), _ptr(ws), ws_bytes, _stream()))
+
+        def weight_grads():
+            _lin_dwdb(x2, w1, dh2, dw1, db1)
+            if dlr_w is not None or dlr_b is not None:           # the logit head's streaming kernels (n = 1)
+                xl = x2[:, :fm_cols]
+                gl2 = gl.view(M, 1)
+                tmp_w = dlr_w if dlr_w is not None else torch.empty_like(lr_w)
+                ws_bytes = lib.rbx_linear_bwd_workspace_size(M, 1, fm_cols, 0)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                check(lib.rbx_linear_bwd(_ptr(xl), x2.stride(0), _ptr(lr_w), None, _ptr(gl2), M, 1, fm_cols, 0, None, fm_cols,
+                                         _ptr(tmp_w), _ptr(dlr_b), _ptr(ws), ws_bytes, _stream()))
+
+        # dx first and the weight gradients beside whatever consumes dx (config.dw_beside_lookup): only for parameters whose
+        # gradient autograd merely stores (no gradient yet: an in-place sum would read what the side stream is still
+        # writing) and that no gradient bucket watches (DenseGradSync starts its all-reduce from the parameters' hooks)
+        beside = _beside_ok(ctx, need[0], keys)
+        if not beside:
+            weight_grads()
         dx = None
         if need[0]:
             dx = _padded_rows(M, K, dev)
@@ -3328,6 +3378,8 @@ class _DeepFmInput(torch.autograd.Function):
                 _ptr(dh2), N, _ptr(w1), M, N, K, _ptr(x2), x2.stride(0), _ptr(ssum), dim, fm_cols, _ptr(gf), _ptr(gl),
                 _ptr(lr_w), _ptr(dx), dx.stride(0), _stream())))
             dx = dx.view(xshape) if len(xshape) != 2 else dx
+        if beside:
+            _run_beside(dev, weight_grads, (x2, w1, lr_w, dh2, gl, dw1, db1, dlr_w, dlr_b))
         return dx, dw1, db1, dlr_w, dlr_b, None, None
 
 

@@ -212,6 +212,60 @@ def test_split_bf16_gemm_runs_and_is_as_accurate_as_the_f32_mfma(M, N, K):
         assert e6 <= 1e-5 * scale, (name, e6, scale)
 
 
+def test_weight_gradients_beside_the_next_backward_node_are_the_same_bits():
+    """ops.config.dw_beside_lookup (round 5): a tower layer's dW / db on a side stream beside whatever consumes its dx, joined
+    at the end of the backward pass -- the same kernels on the same data: bit-identical gradients to the in-line order, eager
+    and replayed from a hipGraph; a parameter that still holds a gradient takes the in-line path (autograd adds in place)."""
+    from recbox_amd import dense, ops
+    from recbox_amd.graph import GraphedStep
+    torch.manual_seed(5)
+    M, K = 8192, 300
+    mods = torch.nn.Sequential(torch.nn.Linear(K, 256), torch.nn.BatchNorm1d(256), torch.nn.ReLU(),
+                               torch.nn.Linear(256, 384), torch.nn.BatchNorm1d(384), torch.nn.ReLU(),
+                               torch.nn.Linear(384, 1)).cuda().train()
+    x = torch.randn(M, K, device="cuda", requires_grad=True)
+    r = torch.randn(M, 1, device="cuda")
+
+    def step(accumulate=False):
+        if not accumulate:
+            for p in mods.parameters():
+                p.grad = None
+            x.grad = None
+        (dense.run_sequential(mods, x) * r).sum().backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in mods.parameters()] + [x.grad.clone()]
+
+    old, old_check = ops.config.dw_beside_lookup, ops.config.check_ids
+    try:
+        ops.config.check_ids = False
+        ops.config.dw_beside_lookup = False
+        want = step()
+        want2 = step(accumulate=True)
+        ops.config.dw_beside_lookup = True
+        got = step()
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+        got2 = step(accumulate=True)                     # gradients survive: the in-line path, sums as before
+        for a, b in zip(got2, want2):
+            assert torch.equal(a, b)
+
+        def one():
+            for p in mods.parameters():
+                p.grad = None
+            x.grad = None
+            loss = (dense.run_sequential(mods, x) * r).sum()
+            loss.backward()
+            return loss
+        g = GraphedStep(one, warmup=2)
+        for _ in range(3):
+            g()
+        torch.cuda.synchronize()
+        for a, b in zip([p.grad for p in mods.parameters()] + [x.grad], want):
+            assert torch.equal(a, b)
+    finally:
+        ops.config.dw_beside_lookup, ops.config.check_ids = old, old_check
+
+
 @pytest.mark.parametrize("M,affine", [(8192, False), (12345, False), (8192, True)])
 def test_tower_with_batchnorms_vs_float64(M, affine):
     """Linear -> BatchNorm1d -> ReLU -> Linear -> BatchNorm1d -> ReLU -> Linear(.., 1) in training mode (rechub's MLP,
