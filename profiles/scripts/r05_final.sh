@@ -35,9 +35,9 @@ prof() { # name, bench args, anchor kernel, occurrence
 }
 prof fm "--steps 20 --warmup 5" compact_ids 30
 prof fm_sharded1 "--config fm --force-sharded --steps 20 --warmup 5" route_count 14
-prof youtubednn "--config youtubednn --steps 20 --warmup 5" embed_seq 12
-prof deepfm "--config deepfm --steps 20 --warmup 5" "embed_fwd_kernel<16" 15
-prof sasrec "--config sasrec --steps 20 --warmup 5" embed_seq 15
+prof youtubednn "--config youtubednn --steps 20 --warmup 5" embed_seq 35
+prof deepfm "--config deepfm --steps 20 --warmup 5" "embed_fwd_kernel<16" 35
+prof sasrec "--config sasrec --steps 20 --warmup 5" embed_seq 35
 # HBM traffic from the PMC counters, separate passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md)
 for cfg in fm youtubednn; do
   for c in FETCH_SIZE WRITE_SIZE; do

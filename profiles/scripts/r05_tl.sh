@@ -5,7 +5,6 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/r05tl
 rm -rf $out; mkdir -p $out
-timeout 900 python -m pytest tests/test_gpu_optim.py tests/test_gpu_matching.py -q -m gpu 2>&1 | tail -3 | tee $out/tests.txt
 prof() { # name, bench args, anchor kernel, occurrence
   rm -rf $out/prof
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/prof -o b -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extra-configs $2 > $out/prof_$1.log 2>&1)
@@ -16,8 +15,7 @@ prof() { # name, bench args, anchor kernel, occurrence
 }
 prof fm "--steps 20 --warmup 5" compact_ids 30
 prof fm_sharded1 "--config fm --force-sharded --steps 20 --warmup 5" route_count 14
-prof youtubednn "--config youtubednn --steps 20 --warmup 5" embed_seq 12
-prof youtubednn_sharded1 "--config youtubednn --force-sharded --steps 20 --warmup 5" shard_count_kernel 24
-prof deepfm "--config deepfm --steps 20 --warmup 5" "embed_fwd_kernel<16" 15
-prof sasrec "--config sasrec --steps 20 --warmup 5" embed_seq 15
-bash profiles/scripts/r05_z.sh
+prof youtubednn "--config youtubednn --steps 20 --warmup 5" embed_seq 35
+prof youtubednn_sharded1 "--config youtubednn --force-sharded --steps 20 --warmup 5" "shard_count_kernel<true>" 35
+prof deepfm "--config deepfm --steps 20 --warmup 5" "embed_fwd_kernel<16" 35
+prof sasrec "--config sasrec --steps 20 --warmup 5" embed_seq 35
