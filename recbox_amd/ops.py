@@ -31,7 +31,7 @@ class config(object):
     # run beside whatever consumes dx (the embedding lookup's backward: segmented reduce + fix-ups, HBM / latency bound; the
     # BatchNorm backward of the layer below), joined when the backward pass ends.  DeepFM 4.27 -> 4.13 ms, YoutubeDNN
     # 1.75 -> 1.65 ms (profiles/r05/dw_beside_ab.txt).  Not used for parameters that already hold a gradient (autograd would
-    # add in place) or that a gradient bucket watches (sharded models).
+    # add in place); a reader of gradients inside the pass calls join_beside() first (rechub.sharded.DenseGradSync).
     dw_beside_lookup = os.environ.get("RECBOX_AMD_DW_BESIDE", "1") != "0"
     # The reference raises IndexError for an out-of-range id (nn.Embedding on CPU).
     # The kernels flag it on device; checking the flag costs one sync per call.
@@ -1514,15 +1514,24 @@ def gemm_bx6_count():
     return int(lib.rbx_gemm_bx6_count())
 
 
+_beside_events = []            # completion events of weight-gradient work on the side stream that nothing has waited for yet
+
+
+def join_beside():
+    """The current stream waits for the weight gradients still under way on the side stream (config.dw_beside_lookup): for a
+    reader of parameter gradients INSIDE the backward pass -- DenseGradSync starts its all-reduce from the parameters' hooks.
+    (Readers behind the pass need nothing: the pass's end-of-pass callback has joined.)"""
+    for dev, ev in _beside_events:
+        torch.cuda.current_stream(dev).wait_event(ev)
+
+
 def _beside_ok(ctx, wanted, keys):
     """config.dw_beside_lookup for this backward node: only for parameters whose gradient autograd merely stores (no gradient
-    yet: an in-place sum would read what the side stream is still writing) and that no gradient bucket watches (DenseGradSync
-    starts its all-reduce from the parameters' hooks)."""
+    yet: an in-place sum would read what the side stream is still writing)."""
     if not (wanted and config.dw_beside_lookup and config.fork_in_capture):
         return False
     owners = [r() for r in getattr(ctx, "owners", ())]
-    return (len(owners) > 0 and all(p is not None and p.grad is None for p in owners)
-            and not any(k and _grad_views.get(k) is not None for k in keys))
+    return len(owners) > 0 and all(p is not None and p.grad is None for p in owners)
 
 
 def _run_beside(dev, fn, tensors):
@@ -1537,7 +1546,15 @@ def _run_beside(dev, fn, tensors):
         if t is not None:
             t.record_stream(side)
     done = side.record_event()
-    torch.autograd.Variable._execution_engine.queue_callback(lambda: torch.cuda.current_stream(dev).wait_event(done))
+    _beside_events.append((dev, done))
+
+    def joined():
+        torch.cuda.current_stream(dev).wait_event(done)
+        try:
+            _beside_events.remove((dev, done))
+        except ValueError:
+            pass
+    torch.autograd.Variable._execution_engine.queue_callback(joined)
 
 
 class _Linear(torch.autograd.Function):
@@ -1581,10 +1598,15 @@ class _Linear(torch.autograd.Function):
         ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, ctx.act)
 
         def bwd_of(dx_, dw_, db_):
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
-            return lambda: check(lib.rbx_linear_bwd(
-                _ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx_),
-                (dx_.stride(0) if M > 1 else K) if dx_ is not None else K, _ptr(dw_), _ptr(db_), _ptr(ws), ws_bytes, _stream()))
+            def run():
+                # (the workspace is allocated by whoever runs this, on ITS stream: handed from the current stream to the
+                #  side stream it would be free for reuse here while the kernels there still write it)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dy.device)
+                check(lib.rbx_linear_bwd(
+                    _ptr(x2), x2.stride(0) if M > 1 else K, _ptr(w), _ptr(y), _ptr(dy2), M, N, K, ctx.act, _ptr(dx_),
+                    (dx_.stride(0) if M > 1 else K) if dx_ is not None else K, _ptr(dw_), _ptr(db_), _ptr(ws), ws_bytes,
+                    _stream()))
+            return run
         if _beside_ok(ctx, dx is not None and (dw is not None or db is not None) and M >= 4096, ctx.grad_keys):
             # dx first; dW / db on the side stream beside whatever consumes dx (config.dw_beside_lookup, see _DeepFmInput)
             _with_split_weights(w, M, 1, bwd_of(dx, None, None))

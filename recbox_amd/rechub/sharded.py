@@ -281,6 +281,9 @@ class DenseGradSync(object):
 
     def _start(self, params):
         """Asynchronous all-reduce of the gradients of ``params`` (zeros for a missing one); returns what finish() needs."""
+        from .. import ops
+        if params and params[0].is_cuda:
+            ops.join_beside()                       # weight gradients still being written on the side stream (dw_beside_lookup)
         copied, loose = [], []
         in_bucket = dict((id(p), v) for p, v in self._views)
         for p in params:
