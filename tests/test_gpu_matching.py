@@ -1274,6 +1274,49 @@ def test_sasrec_cfg5_full_size_vs_oracle():
         assert_close(p.grad, want, tol, "grad " + n)
 
 
+def test_deepfm_step_with_weight_gradients_beside_the_lookup_backward_is_the_same_bits():
+    """ops.config.dw_beside_lookup on DeepFM at the benchmarked shape (B = 8 192, D = 64, 3 x 400): the input stage's dW1 / db1
+    and first-order gradients and every tower layer's dW / db run on the side stream beside the embedding lookup's backward /
+    the BatchNorm backward below -- every gradient (dense tables included) bit-identical to the in-line order, over two steps
+    with different batches (the second one re-uses the allocator's blocks the first one freed)."""
+    import bench
+    from recbox_amd import ops
+    from recbox_amd.rechub.models.ranking import DeepFM
+    B, D = 8192, 64
+    dense, sparse = bench._deepfm_features(D)
+    mlp = {"dims": [400, 400, 400], "dropout": 0.0, "activation": "relu"}
+    with torch.device("cuda"):
+        model = DeepFM(dense + sparse, sparse, mlp)
+    bench.init_weights_device(model, torch.device("cuda"), 0, 0, std=0.05)
+    model.train()
+    old = ops.config.dw_beside_lookup
+    got = {}
+    try:
+        for beside in (False, True):
+            ops.config.dw_beside_lookup = beside
+            grads = []
+            for k in range(2):
+                x = bench._deepfm_batch(B, 90 + k, "uniform", "cuda")
+                for p in model.parameters():
+                    p.grad = None
+                ops.binary_cross_entropy(model(x), x["label"]).backward()
+                torch.cuda.synchronize()
+                grads.append([p.grad.clone() if p.grad is not None else None for p in model.parameters()])
+            got[beside] = grads
+            with torch.no_grad():                                   # (the BatchNorm running statistics moved: same start for both)
+                for m in model.modules():
+                    if isinstance(m, torch.nn.BatchNorm1d):
+                        m.reset_running_stats()
+    finally:
+        ops.config.dw_beside_lookup = old
+    names = [n for n, _ in model.named_parameters()]
+    for k in range(2):
+        for n, a, b in zip(names, got[True][k], got[False][k]):
+            assert (a is None) == (b is None), n
+            if a is not None:
+                assert torch.equal(a, b), "step %d: %s" % (k, n)
+
+
 def test_deepfm_training_step_in_the_benchmarked_mode_vs_fp64_oracle():
     """What ``bench.py --config deepfm`` times, end to end against the oracle: DeepFM at the Criteo
     table sizes, D = 64, the 3 x 400 tower at B = 8 192 -- large enough for the split-operand bf16 GEMMs (gemm_bxp / gemm_bxt:
