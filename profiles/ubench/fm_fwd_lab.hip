@@ -384,6 +384,95 @@ __global__ __launch_bounds__(256, WPE) void fm_g4(const Meta M, const char* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------ g4s: g4 + scalar-path prefetch into L2
+// The vector memory path of a CU holds ~64 misses; the SCALAR data cache is a second path into the same L2.  After the
+// decode, the wavefront walks the columns named by `pmask` (rows) / `lmask` (LR weights) and issues one s_load_dword per
+// (sample, column) at the row's address: the line travels HBM -> L2 on the scalar cache's account, and the vector load that
+// follows finds it in L2 (~250 cycles) instead of holding a miss slot for the HBM latency (~900).  The loaded dword is
+// discarded (s101: a register the compiler never allocates here; lgkmcnt holds 15 in flight per wavefront).
+template <int C>
+__device__ __forceinline__ void spf_col(const unsigned (&o)[16], const char* __restrict__ arena) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const unsigned off = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(o[C >> 2]), j * 4 + (C & 3)));
+    asm volatile("s_load_dword s101, %0, %1" :: "s"(arena), "s"(off) : "s101");
+  }
+}
+template <int C, int NC>
+__device__ __forceinline__ void spf_all(const unsigned long long mask, const unsigned (&o)[16], const char* __restrict__ arena) {
+  if constexpr (C < NC) {
+    if ((mask >> C) & 1ull) spf_col<C>(o, arena);
+    spf_all<C + 1, NC>(mask, o, arena);
+  }
+}
+
+template <int NI, int UB, int WPE>
+__global__ __launch_bounds__(256, WPE) void fm_g4s(const Meta M, const char* __restrict__ arena, const int F,
+                                                   const double* __restrict__ X, const int ldx, const long long B,
+                                                   const float* __restrict__ bias, float* __restrict__ logit,
+                                                   float* __restrict__ prob, float* __restrict__ ssum,
+                                                   const unsigned long long pmask, const unsigned long long lmask) {
+  __shared__ int s_voc[64];
+  __shared__ unsigned s_eo[64], s_es[64], s_lo[64], s_ls[64];
+  if (threadIdx.x < 64) {
+    s_voc[threadIdx.x] = M.vocab[threadIdx.x];
+    s_eo[threadIdx.x] = M.emb_off[threadIdx.x];
+    s_es[threadIdx.x] = M.emb_stride[threadIdx.x];
+    s_lo[threadIdx.x] = M.lr_off[threadIdx.x];
+    s_ls[threadIdx.x] = M.lr_stride[threadIdx.x];
+  }
+  __syncthreads();
+  const int lane_g = threadIdx.x & 3;
+  const unsigned lane16 = lane_g * 16;
+  const long long ngroups = static_cast<long long>(gridDim.x) * (blockDim.x / 4);
+  for (long long b = static_cast<long long>(blockIdx.x) * (blockDim.x / 4) + threadIdx.x / 4; b < B; b += ngroups) {
+    const double* xr = X + b * ldx;
+    double c[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * i + lane_g;
+      c[i] = xr[col < F ? col : F - 1];
+    }
+    unsigned o[16], lo[16];
+    float x[16], l1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * i + lane_g;
+      const int voc = s_voc[col];
+      const int v = __double2int_rz(c[i]);
+      const bool ok = (c[i] == c[i]) && static_cast<unsigned>(v) < static_cast<unsigned>(voc);
+      const bool num = voc == 0 && col < F;
+      const unsigned id = ok ? static_cast<unsigned>(v) : 0u;
+      x[i] = num ? static_cast<float>(c[i]) : 1.f;
+      o[i] = (ok || num) ? s_eo[col] + id * s_es[col] : 0u;
+      lo[i] = (ok || num) ? s_lo[col] + id * s_ls[col] : 0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    spf_all<0, 4 * NI>(pmask, o, arena);
+    spf_all<0, 4 * NI>(lmask, lo, arena);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) l1[i] = *reinterpret_cast<const float*>(arena + static_cast<size_t>(lo[i]));
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    g4_batches<0, 4 * NI, UB>(o, x, lane16, arena, s, q);
+    float lr = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) lr += l1[i] * x[i];
+    float fm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fm += (s[i] * s[i] - q[i]) * 0.5f;
+    const float total = group_sum4(fm + lr);
+    if (lane_g == 0) {
+      const float z = total + bias[0];
+      logit[b] = z;
+      prob[b] = 1.f / (1.f + expf(-z));
+    }
+    *reinterpret_cast<float4*>(ssum + b * 16 + lane_g * 4) = make_float4(s[0], s[1], s[2], s[3]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)");
+}
+
 // ------------------------------------------------------------------------------------------------ g4n: numeric features off the memory path
 // g4 with the first NNUM columns numeric (compile-time here: what the form can gain): their weight vectors and LR weights sit
 // in LDS, their contribution x_f w_f is accumulated first (feature order), no row / LR lookup is issued for them.
@@ -798,6 +887,21 @@ int main(int argc, char** argv) {
       {3, 0, "g4: 10 rows in flight, 2048 workgroups (8 samples per lane group slot)", 2048, true},
       {3, 16 + 64, "abl: g4 (10 in flight) without LR and row misses", 1024, false},
       {1, 16, "abl: v1 without LR misses", 4096, false},
+      {40, 0, "g4: 20 in flight, 2 waves/SIMD, 512 workgroups (every wavefront two passes)", 512, true},
+      {41, 0, "g4: 40 in flight, 2 waves/SIMD, 512 workgroups", 512, true},
+      {42, 0, "g4: 27 in flight, 2 waves/SIMD, 512 workgroups", 512, true},
+      {5, 0, "g4: 20 in flight, 3 waves/SIMD, 768 workgroups", 768, true},
+      {5, 0, "g4: 20 in flight, 3 waves/SIMD, 512 workgroups", 512, true},
+      {5, 0, "g4: 20 in flight, 3 waves/SIMD, 4096 workgroups", 4096, true},
+      {43, 0, "g4: 20 in flight, 2 waves/SIMD, 1024 workgroups", 1024, true},
+      {44, 0, "g4: 14 in flight, 4 waves/SIMD, 1024 workgroups of 256 = one pass of 16 waves/CU", 1024, true},
+      {30, 0, "g4s: g4 (20 in flight) + scalar prefetch of the 1 M-row tables' rows", 1024, true},
+      {31, 0, "g4s: + their LR weights", 1024, true},
+      {32, 0, "g4s: rows + LR of the 8 tables of > 90 000 rows", 1024, true},
+      {33, 0, "g4s: rows + LR of the 12 tables of > 5 000 rows", 1024, true},
+      {34, 0, "g4s: LR only, 12 tables", 1024, true},
+      {35, 0, "g4s: rows of 8 tables, LR of 12", 1024, true},
+      {36, 0, "g4s (10 in flight, 4 waves/SIMD): rows + LR of 8 tables", 1024, true},
       {1, 16 + 32, "abl: v1 without LR misses and without the five 1 M-row + 2 next tables' row misses", 4096, false},
       {1, 16 + 64, "abl: v1 without LR and row misses (batch stream + S store only)", 4096, false},
       {1, 64, "abl: v1 with LR misses only", 4096, false},
@@ -840,6 +944,24 @@ int main(int argc, char** argv) {
         else if (v.kernel == 9) fm_g4n<10, 20, 3, 13><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 10) fm_g4n<10, 14, 4, 13><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 11) fm_g4n<10, 27, 3, 13><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel >= 30 && v.kernel <= 36) {
+          auto mk = [&](int thr) { unsigned long long mm = 0; for (int f = 13; f < kF; ++f) if (kCard[f - 13] > thr) mm |= 1ull << f; return mm; };
+          const unsigned long long m1 = mk(900000), m8 = mk(90000), m12 = mk(5000);
+          unsigned long long pm = 0, lm = 0;
+          if (v.kernel == 30) pm = m1;
+          if (v.kernel == 31) pm = lm = m1;
+          if (v.kernel == 32 || v.kernel == 36) pm = lm = m8;
+          if (v.kernel == 33) pm = lm = m12;
+          if (v.kernel == 34) lm = m12;
+          if (v.kernel == 35) { pm = m8; lm = m12; }
+          if (v.kernel == 36) fm_g4s<10, 10, 4><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum, pm, lm);
+          else fm_g4s<10, 20, 3><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum, pm, lm);
+        }
+        else if (v.kernel == 40) fm_g4<10, 20, 2><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 41) fm_g4<10, 40, 2><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 42) fm_g4<10, 27, 2><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 43) fm_g4<10, 20, 2><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
+        else if (v.kernel == 44) fm_g4<10, 14, 4><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 6) fm_g4<10, 8, 5><<<v.grid, 256>>>(m.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 20) fm_g4l<10, 20, 256, 3><<<v.grid, 256, lp.lds_bytes>>>(lp.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);
         else if (v.kernel == 21) fm_g4l<10, 20, 768, 3><<<v.grid, 768, lp.lds_bytes>>>(lp.dev, arena, kF, X[z][r], kLd, B, bias, logit, prob, ssum);

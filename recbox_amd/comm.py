@@ -113,7 +113,12 @@ class _Joined(object):
         self.done.record(side)
 
     def wait(self):
-        self.cur.wait_event(self.done)
+        # torch's Work.wait() contract: the stream current at wait() is ordered behind the collective -- and the issuing
+        # stream too when that is another one (DenseGradSync issues from an autograd hook, waits in finish(): ADVICE r5)
+        now = torch.cuda.current_stream(self.cur.device)
+        now.wait_event(self.done)
+        if now != self.cur:
+            self.cur.wait_event(self.done)
         return True
 
 
@@ -201,11 +206,16 @@ class _Direct(object):
         if dist.get_backend(group) != "nccl":
             return False
         ptr = self._live_ptr(group, x.device)
-        if ptr == 0 or (x.device.index, ptr) not in self.checked:
+        if (x.device.index, ptr) not in self.checked:
+            # (ptr == 0 -- no communicator yet, or a torch build without _comm_ptr -- is a state like any other: checked
+            #  once, not on every collective; a communicator that appears later is a new pointer and gets its check)
             if torch.cuda.is_current_stream_capturing():
                 return self.on and ptr != 0     # (the check syncs the host: a capture must come after a warm-up step)
             self.self_check(group, x.device)
-        return self.on
+            self.checked.add((x.device.index, ptr))
+            if self._live_ptr(group, x.device) == 0:
+                self.on = self.capturable = False       # nothing to issue on: torch.distributed's own path
+        return self.on and self._live_ptr(group, x.device) != 0
 
     def _streams(self, x, async_op):
         cur = torch.cuda.current_stream(x.device)

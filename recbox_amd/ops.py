@@ -368,23 +368,35 @@ def _note_touched(kind, plans, inputs, params, grads, ws, ws_bytes, B):
             touched[id(p)] = rec
 
 
-touched_ids = {}             # id(parameter) -> (data_ptr of its gradient, [id tensors of every lookup that wrote into it])
+touched_ids = {}             # id(parameter) -> (data_ptr of its gradient, [id tensors of every lookup that wrote into it], pass)
+_ids_pass = [0, False]       # serial of the backward pass under way; has its end-of-pass callback been queued?
+
+
+def _ids_pass_over():
+    _ids_pass[0] += 1
+    _ids_pass[1] = False
 
 
 def _note_ids(plan, inputs, params, grads, want):
     """A lookup over ``plan`` has written rows into ``grads`` (its own, or -- adopted -- the gradient another node of this
     backward pass published): remember the id tensors per table, so that a sparse-row optimiser can step a table that
     several lookups of one step feed (SASRec's item table: the sequence lookup and the pos / neg candidates of gather_dot)
-    over the union of their rows instead of scanning the dense gradient for non-zero rows."""
+    over the union of their rows instead of scanning the dense gradient for non-zero rows.  A list grows only within ONE
+    backward pass: the first lookup of the next pass starts it afresh even when the gradient sits at the same address
+    (``zero_grad(set_to_none=False)``, the caching allocator) and nobody stepped the table in between -- a table that some
+    other optimiser steps, or a frozen one, would otherwise pin every step's id tensors."""
+    if not _ids_pass[1]:
+        _ids_pass[1] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_ids_pass_over)
     for k, (p, g, w) in enumerate(zip(params, grads, want)):
         if not w or g is None:
             continue
         ids = [t for sp, t in zip(plan.specs, inputs) if sp.kind == _lib.FIELD_CATEGORICAL and sp.param == k]
         ent = touched_ids.get(id(p))
-        if ent is not None and ent[0] == g.data_ptr():
+        if ent is not None and ent[0] == g.data_ptr() and ent[2] == _ids_pass[0]:
             ent[1].extend(ids)
         else:
-            touched_ids[id(p)] = (g.data_ptr(), ids)
+            touched_ids[id(p)] = (g.data_ptr(), ids, _ids_pass[0])
 
 
 def _forget_sort(ws):
@@ -1525,13 +1537,42 @@ def join_beside():
         torch.cuda.current_stream(dev).wait_event(ev)
 
 
+_beside_seen = {}              # id(parameter) -> the parameter, for every owner a backward node of this pass has served
+
+
+def _pass_over():
+    _beside_seen.clear()
+
+
+def _hooked(p):
+    """Does anything watch this parameter's gradient from inside the pass?  Tensor hooks and post-accumulate hooks are
+    visible here; a watcher that joins the side stream itself (DenseGradSync) marks its parameters ``_rbx_joins_beside``.
+    (Hooks on the AccumulateGrad NODE -- DistributedDataParallel's -- are not visible from Python: a DDP-wrapped model sets
+    config.dw_beside_lookup = False, docs in INTEGRATION.md.)"""
+    if getattr(p, "_rbx_joins_beside", False):
+        return False
+    return bool(getattr(p, "_backward_hooks", None)) or bool(getattr(p, "_post_accumulate_grad_hooks", None))
+
+
 def _beside_ok(ctx, wanted, keys):
-    """config.dw_beside_lookup for this backward node: only for parameters whose gradient autograd merely stores (no gradient
-    yet: an in-place sum would read what the side stream is still writing)."""
+    """config.dw_beside_lookup for this backward node: only when autograd merely STORES what the node returns for each of its
+    parameters, i.e. every owner is a leaf (a non-leaf weight's gradient flows on into Slice / Select / Permute nodes that
+    read it on the current stream), holds no gradient yet (an in-place sum would read what the side stream is still
+    writing), is not watched by a hook that does not join, and is served by no other node of this pass (autograd would sum
+    the two contributions on the current stream).  A parameter met a second time in one pass joins the side stream first."""
+    owners = [r() for r in getattr(ctx, "owners", ())]
+    live = [p for p in owners if p is not None]
+    again = any(id(p) in _beside_seen for p in live)
+    if live and not _beside_seen:
+        torch.autograd.Variable._execution_engine.queue_callback(_pass_over)
+    for p in live:
+        _beside_seen[id(p)] = p
+    if again:
+        join_beside()
+        return False
     if not (wanted and config.dw_beside_lookup and config.fork_in_capture):
         return False
-    owners = [r() for r in getattr(ctx, "owners", ())]
-    return len(owners) > 0 and all(p is not None and p.grad is None for p in owners)
+    return len(owners) > 0 and all(p is not None and p.is_leaf and p.grad is None and not _hooked(p) for p in owners)
 
 
 def _run_beside(dev, fn, tensors):

@@ -207,7 +207,9 @@ class DenseGradSync(object):
     rounds without ``zero_grad``): autograd adds this backward's LOCAL gradient to what ``p.grad`` holds -- the sum over
     the ranks of the earlier rounds, identical on every rank -- and the all-reduce would count that W times.  The first
     gradient of a backward therefore divides every surviving tower / head gradient by W (one fused launch; exact for the
-    power-of-two worlds of a node, one rounding otherwise), so that sum_r (prior / W + g_r) = prior + sum_r g_r."""
+    power-of-two worlds of a node, one rounding otherwise), so that sum_r (prior / W + g_r) = prior + sum_r g_r.  The
+    replicated tables (``late``) are divided in the same launch: their hooks fire the division too, so it runs before any
+    gradient of this backward is added whichever parameter comes first."""
 
     def __init__(self, early, late, group=None):
         self.early = [p for p in early if p.requires_grad]
@@ -225,6 +227,10 @@ class DenseGradSync(object):
             for p in self.early:
                 self._hooks.append(p.register_hook(self._before_grad))
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                p._rbx_joins_beside = True      # (_start joins the side stream before it reads gradients: ops._hooked)
+            for p in self.late:
+                # a table gradient that survived the last round is divided like the towers' before this backward adds to it
+                self._hooks.append(p.register_hook(self._before_grad))
             self._make_bucket()
 
     def _make_bucket(self):
@@ -249,7 +255,7 @@ class DenseGradSync(object):
             return
         self._prescaled = True
         if self.world > 1:
-            left = [p.grad for p in self.early if p.grad is not None]
+            left = [p.grad for p in self.early + self.late if p.grad is not None]
             if left:
                 with torch.no_grad():
                     torch._foreach_div_(left, float(self.world))
@@ -267,6 +273,9 @@ class DenseGradSync(object):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.early:
+            if getattr(p, "_rbx_joins_beside", False):
+                del p._rbx_joins_beside
         for p, _ in self._views:
             ops._grad_views.pop(p.data_ptr(), None)
         self._views, self.bucket = [], None
@@ -322,8 +331,8 @@ class DenseGradSync(object):
         # Every rank issues the SAME collectives per step -- the early layout, then the late layout -- whatever arrived
         # where: a rank on which some tower parameter received no gradient (it then never fired from the hooks) reduces the
         # early layout here, zeros standing in for what is missing.
+        self._prescale()                        # (no gradient at all arrived in this backward: nothing divided them yet)
         if self._pending is None and self.early:
-            self._prescale()                    # (no tower gradient arrived in this backward: nothing divided them yet)
             self._pending = self._start(self.early)
         if self._pending is not None:
             handles, copied = self._pending

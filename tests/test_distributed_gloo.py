@@ -372,29 +372,31 @@ def _accum_worker(rank, world, port, result):
     try:
         from recbox_amd.rechub.sharded import DenseGradSync
         torch.manual_seed(0)
-        item, user = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+        item, user, table = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3), torch.nn.Embedding(5, 3)
         towers = list(item.parameters()) + list(user.parameters())
-        sync = DenseGradSync(towers, [])
-        ri, ru = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
-        ri.load_state_dict(item.state_dict()); ru.load_state_dict(user.state_dict())
-        for step in range(3):                               # three backward + finish rounds, no zero_grad in between
+        sync = DenseGradSync(towers, list(table.parameters()))      # the table: a replicated ("late") parameter, ADVICE r5
+        ri, ru, rt = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3), torch.nn.Embedding(5, 3)
+        ri.load_state_dict(item.state_dict()); ru.load_state_dict(user.state_dict()); rt.load_state_dict(table.state_dict())
+
+        def loss_of(it, us, tb, xi, xu, ids, step):
+            if step == 1:
+                return (it(xi) ** 2).sum() / world          # neither the user tower nor the table takes part in this round
+            if step == 3:
+                return (tb(ids) ** 2).sum() / world         # only the table: no tower hook fires before its gradient
+            return ((it(xi) * tb(ids)).sum() + (us(xu) ** 2).sum()) / world
+        for step in range(5):                               # five backward + finish rounds, no zero_grad in between
             g = torch.Generator().manual_seed(10 * step + rank)
             xi, xu = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
-            if step == 1:
-                loss = (item(xi) ** 2).sum() / world        # the user tower takes no part in this round
-            else:
-                loss = ((item(xi) ** 2).sum() + (user(xu) ** 2).sum()) / world
-            loss.backward()
+            ids = torch.randint(0, 5, (6,), generator=g)
+            loss_of(item, user, table, xi, xu, ids, step).backward()
             sync.finish()
             for r in range(world):
                 g = torch.Generator().manual_seed(10 * step + r)
                 xi, xu = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
-                if step == 1:
-                    ((ri(xi) ** 2).sum() / world).backward()
-                else:
-                    (((ri(xi) ** 2).sum() + (ru(xu) ** 2).sum()) / world).backward()
-            for a, b in zip(towers, list(ri.parameters()) + list(ru.parameters())):
-                assert torch.allclose(a.grad, b.grad, atol=1e-6), "round %d" % step
+                ids = torch.randint(0, 5, (6,), generator=g)
+                loss_of(ri, ru, rt, xi, xu, ids, step).backward()
+            for a, b in zip(towers + [table.weight], list(ri.parameters()) + list(ru.parameters()) + [rt.weight]):
+                assert torch.allclose(a.grad, b.grad, atol=1e-5), "round %d" % step
         result[rank] = "ok"
     finally:
         dist.destroy_process_group()

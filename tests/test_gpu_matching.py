@@ -266,6 +266,97 @@ def test_weight_gradients_beside_the_next_backward_node_are_the_same_bits():
         ops.config.dw_beside_lookup, ops.config.check_ids = old, old_check
 
 
+def test_weight_gradients_of_non_leaf_shared_and_hooked_weights_stay_in_line():
+    """the side stream for dW / db (ops.config.dw_beside_lookup) is only for LEAF parameters that autograd merely
+    stores.  A non-leaf weight (a slice / permute of a parameter: CrossNetMix's experts, the in-projection halves of
+    nn.MultiheadAttention), a leaf served by two nodes of one pass, and a parameter watched by a tensor hook all compute in
+    line: no launch on the side stream for them, gradients the bits of the in-line order, repeatably."""
+    from recbox_amd import ops
+    from recbox_amd.ranking.pytorch.layers.interactions import CrossNetMix
+    torch.manual_seed(11)
+    M, K = 8192, 96
+    x = torch.randn(M, K, device="cuda", requires_grad=True)
+    r = torch.randn(M, K, device="cuda")
+    W = torch.nn.Parameter(torch.randn(2 * K, K, device="cuda") * 0.1)
+    b = torch.nn.Parameter(torch.randn(2 * K, device="cuda") * 0.1)
+    shared = torch.nn.Linear(K, K).cuda()
+    hooked = torch.nn.Linear(K, K).cuda()
+    seen = []
+    hooked.weight.register_hook(lambda g: seen.append(float(g.abs().sum())))
+    mix = CrossNetMix(K, layer_num=2, low_rank=16, num_experts=3).cuda()
+    params = [W, b] + list(shared.parameters()) + list(hooked.parameters()) + list(mix.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        x.grad = None
+        h = ops.linear(x, W[:K], b[:K]) + ops.linear(x, W[K:], b[K:])                  # non-leaf halves of one parameter
+        h = ops.linear(torch.tanh(ops.linear(h, shared.weight, shared.bias)), shared.weight, shared.bias)     # one leaf, two nodes
+        h = ops.linear(h, hooked.weight, hooked.bias)
+        h = mix(h)
+        (h * r).sum().backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in params] + [x.grad.clone()]
+
+    calls = []
+    real = ops._run_beside
+    old = ops.config.dw_beside_lookup
+    try:
+        ops.config.dw_beside_lookup = False
+        want = step()
+        ops.config.dw_beside_lookup = True
+        ops._run_beside = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        for _ in range(3):
+            got = step()
+            for a, w in zip(got, want):
+                assert torch.equal(a, w)
+        # what went beside: only gate / bias-free leaves of CrossNetMix that are served once?  none here is -- the gate
+        # weights are concatenated (non-leaf), U / V / C permuted or selected, `shared` is served twice (the FIRST node may
+        # go beside; the second joins before it returns), `hooked` has a hook
+        assert len(calls) <= 3 * 1, calls
+        assert len(seen) == 4 and all(v == seen[0] for v in seen)
+        assert not ops._beside_seen                                      # (cleared by the end-of-pass callback)
+    finally:
+        ops._run_beside = real
+        ops.config.dw_beside_lookup = old
+
+
+def test_sasrec_in_projection_gradients_with_long_batches_equal_the_in_line_order():
+    """rechub SASRec's `_mha` hands slices of in_proj_weight to ops.linear when the fused block chain is off; with
+    B L >= 4096 those (non-leaf) weights must not take the side stream: gradients equal the in-line order bit for bit."""
+    from recbox_amd import ops
+    from recbox_amd.rechub.basic.features import SequenceFeature, SparseFeature
+    from recbox_amd.rechub.models.matching import SASRec
+    torch.manual_seed(3)
+    V, D, L, B = 500, 32, 64, 128                                     # B L = 8192 rows per projection
+    feats = [SequenceFeature("seq", V, D, pooling="concat", padding_idx=0),
+             SequenceFeature("pos", V, D, pooling="concat", shared_with="seq"),
+             SequenceFeature("neg", V, D, pooling="concat", shared_with="seq")]
+    model = SASRec(feats, max_len=L, dropout_rate=0.0, num_blocks=2, num_heads=1).cuda().train()
+    g = torch.Generator().manual_seed(4)
+    batch = {k: torch.randint(1, V, (B, L), generator=g).cuda() for k in ("seq", "pos", "neg")}
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        pos, neg = model(batch)
+        (pos.sum() - neg.sum()).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() if p.grad is not None else None for p in model.parameters()]
+
+    old = (ops.config.dw_beside_lookup, ops.config.fuse_sublayers)
+    try:
+        ops.config.fuse_sublayers = False                               # the layer-by-layer path: _mha -> ops.linear(w[:E]) ...
+        ops.config.dw_beside_lookup = False
+        want = step()
+        ops.config.dw_beside_lookup = True
+        for _ in range(3):
+            for a, w in zip(step(), want):
+                assert (a is None and w is None) or torch.equal(a, w)
+    finally:
+        ops.config.dw_beside_lookup, ops.config.fuse_sublayers = old
+
+
 @pytest.mark.parametrize("M,affine", [(8192, False), (12345, False), (8192, True)])
 def test_tower_with_batchnorms_vs_float64(M, affine):
     """Linear -> BatchNorm1d -> ReLU -> Linear -> BatchNorm1d -> ReLU -> Linear(.., 1) in training mode (rechub's MLP,
