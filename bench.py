@@ -693,6 +693,8 @@ def main():
                          "0/1 = replay one batch.  FM on one GPU: one captured step per resident batch; elsewhere (and "
                          "with --rotate-by-copy) batch i %% K is copied into the static input buffer before each step, "
                          "inside the timed region")
+    ap.add_argument("--steps-per-graph", type=int, default=1,
+                    help="FM, one GPU: capture this many consecutive steps (one per resident batch) in each hipGraph")
     ap.add_argument("--prefetch-sort", action="store_true",
                     help="FM, one GPU: while step i runs, the ids of batch i + 1 are sorted on the side stream (FM.presort: a "
                          "loop whose loader is one batch ahead), so that the sort no longer sits in front of the backward's "
@@ -895,6 +897,7 @@ def main():
     step = eager_step
     graph_note = "eager launches"
     rotating_graphs = None
+    steps_per_launch = 1
     if not args.eager and not sharded:
         # one hipGraph holds the whole step (same kernels, same C ABI); the batch lives in static buffers
         from recbox_amd.graph import GraphedStep
@@ -917,16 +920,31 @@ def main():
                     sorted_ids = [model.presort(Xk) for Xk, _ in inputs_of]      # (also the primer of the first step)
                     for k in range(K):                    # the captured re-zero of step k clears the rows step k - 1 wrote
                         sorted_ids[k].previous = sorted_ids[k - 1]
-                for k in range(K):
-                    Xk, yk = inputs_of[k]
-                    fn = (prefetching_step(Xk, yk, sorted_ids[k], inputs_of[(k + 1) % K][0], sorted_ids[(k + 1) % K])
-                          if prefetch else step_over(Xk, yk))
+                S = max(1, int(args.steps_per_graph))
+                if S > 1 and (prefetch or K % S or args.steps % S):
+                    raise SystemExit("--steps-per-graph must divide --rotate and --steps (and excludes --prefetch-sort)")
+                steps_per_launch = S
+                for k in range(0, K, S):
+                    if S > 1:
+                        fns = [step_over(*inputs_of[k + j]) for j in range(S)]
+
+                        def fn(fns=fns):
+                            out = None
+                            for f in fns:
+                                out = f()
+                            return out
+                    else:
+                        Xk, yk = inputs_of[k]
+                        fn = (prefetching_step(Xk, yk, sorted_ids[k], inputs_of[(k + 1) % K][0], sorted_ids[(k + 1) % K])
+                              if prefetch else step_over(Xk, yk))
                     rotating_graphs.append(GraphedStep(fn, warmup=3 if k == 0 else 2,
                                                        reuse_grads=ops.config.reuse_grad_buffers, params=params,
                                                        pool=rotating_graphs[0].pool() if rotating_graphs else None))
                 step = rotating_graphs[0]
                 graph_note = "hipGraph replay (one captured step per resident batch%s)" % (
                     "; the id sort of batch i + 1 runs beside step i, as with a loader one batch ahead" if prefetch else "")
+                if S > 1:
+                    graph_note = "hipGraph replay (%d consecutive steps, one per resident batch, per captured graph)" % S
             else:
                 step = GraphedStep(eager_step, warmup=3, reuse_grads=ops.config.reuse_grad_buffers)
                 graph_note = "hipGraph replay"
@@ -971,11 +989,14 @@ def main():
 
     def run_step(i):
         if rotating_graphs is not None:
-            rotating_graphs[i % K]()
+            if i % steps_per_launch == 0:
+                rotating_graphs[(i // steps_per_launch) % len(rotating_graphs)]()
         else:
             refill(i)
             step()
 
+    if steps_per_launch > 1:                  # (whole launches only: the warm-up rounds up)
+        args.warmup = (args.warmup + steps_per_launch - 1) // steps_per_launch * steps_per_launch
     for i in range(args.warmup):
         run_step(i)
     # dominant kernel = the embedding gather: fm_fused_fwd (fused path) or the [B, 39, 16] embed_fwd (layer path)

@@ -1,6 +1,8 @@
 """Timeline of ONE hipGraph replay out of a rocprofv3 --kernel-trace rocpd database (or its -f csv *_kernel_trace.csv): start offset, duration and queue of
 every kernel between two consecutive launches of an anchor kernel (default: the first kernel of the step).
-    python profiles/timeline.py <results.db> [anchor-substring] [which-occurrence]
+    python profiles/timeline.py <results.db> [anchor-substring] [which-occurrence] [steps]
+(steps > 1: that many consecutive anchor intervals in one listing -- the boundaries between steps of one captured graph and
+between two graphs.)
 """
 import csv
 import sqlite3
@@ -21,10 +23,11 @@ def main():
         qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
         rows = db.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")).fetchall()
     marks = [i for i, r in enumerate(rows) if anchor in r[0]]
-    a, b = marks[which], marks[which + 1]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    a, b = marks[which], marks[which + steps]
     t0 = rows[a][1]
-    print("# one step: %d kernels, %.1f us from the first start to the next step's first start" %
-          (b - a, (rows[b][1] - t0) / 1e3))
+    print("# %s: %d kernels, %.1f us from the first start to the next step's first start" %
+          ("one step" if steps == 1 else "%d steps" % steps, b - a, (rows[b][1] - t0) / 1e3))
     print("%-60s %9s %9s %9s  %s" % ("kernel", "start_us", "dur_us", "end_us", "queue"))
     for r in rows[a:b]:
         name = r[0].split("(")[0].replace("void ", "")[:60]

@@ -427,6 +427,17 @@ __global__ __launch_bounds__(64) void fm_numeric_final_kernel(const FmNumPack P,
   }
 }
 
+// The numeric partials in the form tier A's launch computes them (rbx_tiera.h: ta_numeric_block), as a launch of their own:
+// for the callers that run the numeric reductions apart from tier A (ahead of a sort still in flight, no tier-A table at
+// all).  Same units, same summation order: the two placements leave the same bits.
+__global__ __launch_bounds__(512) void fm_numeric_blocks_kernel(const TaNumPack N, const long long B, const int D,
+                                                                const float* __restrict__ g,
+                                                                const float* __restrict__ ssum,
+                                                                float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float num_stage[];
+  ta_numeric_block(N, blockIdx.x, gridDim.x, B, g, ssum, D, num_stage, partial);
+}
+
 // d row(b,t) = [ g_b (S_b - e[b,t,:]) | ... g_b at the LR slot ... | 0 ]  in the rows' own packed layout
 // (these rows belong to another rank: the gradient block is sent back to it as is)
 __global__ __launch_bounds__(256) void fm_extra_bwd_kernel(const float* __restrict__ g, const float* __restrict__ ssum,
@@ -994,18 +1005,48 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
              : dispatch_reduce<FmPolicy, false>(p, args, keys, vals, ws, s);
     if (rc != RBX_OK) return rc;
   }
+  // numeric partials in 512-sample units (ta_numeric_block) -- inside tier A's first launch when this call runs tier A too
+  TaNumPack np;
+  np.n = 0;
+  const bool num_blocks_form = (phases & 2) && emb != nullptr && n_num > 0 && n_num <= kTaNumMax && D % 4 == 0 &&
+                               (reinterpret_cast<uintptr_t>(d_sum) & 15) == 0;
+  np.reserved = 0;
+  if (num_blocks_form) {
+    np.n = n_num;
+    for (int i = 0; i < n_num; ++i) {
+      np.ids[i] = f.np.f[i].ids; np.stride_b[i] = f.np.f[i].stride_b; np.dtype[i] = f.np.f[i].dtype;
+    }
+  }
+  bool num_fused = false;                            // ... they rode in tier A's first launch
   if ((phases & 1) && !(phases & 8)) {               // the tables of tier A: block partials, then every row written once
-    rc = ta_dispatch_bwd(f.ta, batch, d_dlogit, emb ? d_sum : nullptr, accumulate, ws + f.off_ta, s);
+    rc = ta_dispatch_bwd(f.ta, batch, d_dlogit, emb ? d_sum : nullptr, accumulate, ws + f.off_ta, s,
+                         np.n > 0 ? &np : nullptr, reinterpret_cast<float*>(ws + p.bytes), &num_fused);
     if (rc != RBX_OK) return rc;
   }
   if ((phases & 2) && (n_num > 0 || d_dbias != nullptr)) {
     float* partial = reinterpret_cast<float*>(ws + p.bytes);
-    const int ns = fm_num_samples(D, n_num);
-    const size_t lds = (static_cast<size_t>(ns) * (D + 1) + 2 * static_cast<size_t>(n_num) * (ns + 1)) * sizeof(float);
-    hipLaunchKernelGGL(fm_numeric_partial_kernel, dim3(p.num_blocks), dim3(256), lds, s, f.np, n_num,
-                       static_cast<long long>(batch), D, ns, d_dlogit, emb ? d_sum : nullptr, partial,
-                       emb != nullptr && D % 4 == 0 && (reinterpret_cast<uintptr_t>(d_sum) & 15) == 0);
-    hipLaunchKernelGGL(fm_numeric_final_kernel, dim3(n_num + 1, D + 2), dim3(64), 0, s, f.np, n_num, D, p.num_blocks,
+    unsigned nblk = p.num_blocks;
+    if (num_blocks_form) {
+      nblk = static_cast<unsigned>((batch + kTaNumBlock - 1) / kTaNumBlock);
+      if (!num_fused) {
+        const size_t lds = ta_num_lds_bytes(n_num, D);
+        static bool attr_set = false;
+        if (!attr_set) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fm_numeric_blocks_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(fm_numeric_blocks_kernel, dim3(nblk), dim3(512), lds, s, np, static_cast<long long>(batch), D,
+                           d_dlogit, d_sum, partial);
+      }
+    } else {
+      const int ns = fm_num_samples(D, n_num);
+      const size_t lds = (static_cast<size_t>(ns) * (D + 1) + 2 * static_cast<size_t>(n_num) * (ns + 1)) * sizeof(float);
+      hipLaunchKernelGGL(fm_numeric_partial_kernel, dim3(p.num_blocks), dim3(256), lds, s, f.np, n_num,
+                         static_cast<long long>(batch), D, ns, d_dlogit, emb ? d_sum : nullptr, partial,
+                         emb != nullptr && D % 4 == 0 && (reinterpret_cast<uintptr_t>(d_sum) & 15) == 0);
+    }
+    hipLaunchKernelGGL(fm_numeric_final_kernel, dim3(n_num + 1, D + 2), dim3(64), 0, s, f.np, n_num, D, nblk,
                        partial, d_dbias, (phases & 4) != 0);
     rc = check_launch("fm numeric kernels");
     if (rc != RBX_OK) return rc;

@@ -367,6 +367,104 @@ __global__ __launch_bounds__(kTaThreads) void ta_reduce_kernel(const TaFieldPack
   }
 }
 
+// ---- numeric features of the fused FM backward as extra workgroups of ta_reduce_lds_kernel's launch -------------------
+// The batch reductions of the numeric features' weights (sum_b g_b x_bf S_b, sum g x^2, sum g x) and of the bias (sum g) were
+// a launch of their own at the tail of the backward's main chain (fm_numeric_partial_kernel, ~21 us: the chain then ended
+// with the large tables' chain on the other hardware queue, and the next step's first kernel paid a cross-queue edge).
+// Here they are the LAST workgroups of tier A's first launch: that launch holds one 157 KB workgroup per CU and at the
+// Criteo shape 224 of them, so the numeric workgroups -- one per 512 samples, ~5 us each -- flow through the CUs the
+// tables leave free while the tables' workgroups run.  A workgroup issues every x load of its samples at once (the
+// columns of a sample's row, feature fastest), stages the samples' S rows and g meanwhile, then thread (o, h) sums
+// output o over half h of the samples in sample order (four interleaved sums), the halves meet in a fixed order.
+// Partial layout as fm_numeric_partial_kernel's ([output][block]): fm_numeric_final_kernel reads it.
+constexpr int kTaNumMax = 32;               // numeric features this form serves (kernarg space: 20 B each)
+constexpr int kTaNumBlock = 512;            // samples per numeric workgroup
+struct TaNumPack {
+  const void* ids[kTaNumMax];
+  long long stride_b[kTaNumMax];
+  int dtype[kTaNumMax];
+  int n;
+  int reserved;
+};
+static inline size_t ta_num_lds_bytes(int n_num, int D) {
+  return (static_cast<size_t>(kTaNumBlock) * D + kTaNumBlock + static_cast<size_t>(n_num) * (kTaNumBlock + 1) + 256) * 4;
+}
+
+__device__ __forceinline__ void ta_numeric_block(const TaNumPack& N, const unsigned k, const unsigned nblk, const long long B,
+                                                 const float* __restrict__ g, const float* __restrict__ ssum, const int D,
+                                                 float* lds, float* __restrict__ partial) {
+  constexpr int SB = kTaNumBlock, SP = SB + 1;
+  const int n_num = N.n;
+  float* sS = lds;                                  // [SB][D]
+  float* sg = sS + SB * D;                          // [SB]
+  float* sx = sg + SB;                              // [n_num][SB + 1]
+  float* meet = sx + n_num * SP;                    // [256]
+  const size_t b0 = static_cast<size_t>(k) * SB;
+  const int n = static_cast<int>((static_cast<size_t>(B) - b0 < SB) ? (static_cast<size_t>(B) - b0) : SB);
+  const int tid = static_cast<int>(threadIdx.x);    // == the thread's sample (SB == the workgroup's 512 threads)
+  // every x load of the thread's sample in flight at once; the feature index is a compile-time constant (a lane-varying
+  // index into the by-value pack would send it to scratch), the columns of a row share its cache lines
+  long long raw[kTaNumMax];
+#pragma unroll
+  for (int f = 0; f < kTaNumMax; ++f) {
+    raw[f] = 0;
+    if (f < n_num && tid < n) raw[f] = load_raw(N.ids[f], static_cast<long long>(b0 + tid) * N.stride_b[f], N.dtype[f]);
+  }
+  {
+    const int n4 = SB * D / 4, live4 = n * D / 4;
+    const float4* src = reinterpret_cast<const float4*>(ssum + b0 * D);
+    for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(sS)[i] = (i < live4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    sg[tid] = (tid < n) ? g[b0 + tid] : 0.f;
+  }
+#pragma unroll
+  for (int f = 0; f < kTaNumMax; ++f)
+    if (f < n_num) sx[f * SP + tid] = (tid < n) ? decode_value(raw[f], N.dtype[f]) : 0.f;
+  __syncthreads();
+  const int stride = D + 2;
+  const int n_out = n_num * stride + 1;
+  const int h = tid >> 8;
+  // outputs in rounds of 256: thread (o, h) sums output o over half h of the samples, four interleaved sums
+  for (int o0 = 0; o0 < n_out; o0 += 256) {
+    const int o = o0 + (tid & 255);
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (o < n_out) {
+      const int f = o / stride, slot = o - f * stride;
+      const int i0 = h * (SB / 2);
+      const float* gg = sg + i0;
+      if (f == n_num) {
+        for (int i = 0; i < SB / 2; i += 4) { t0 += gg[i]; t1 += gg[i + 1]; t2 += gg[i + 2]; t3 += gg[i + 3]; }
+      } else {
+        const float* a = sx + f * SP + i0;
+        if (slot < D) {
+          const float* c = sS + static_cast<size_t>(i0) * D + slot;
+          for (int i = 0; i < SB / 2; i += 4) {
+            t0 += gg[i] * a[i] * c[i * D];
+            t1 += gg[i + 1] * a[i + 1] * c[(i + 1) * D];
+            t2 += gg[i + 2] * a[i + 2] * c[(i + 2) * D];
+            t3 += gg[i + 3] * a[i + 3] * c[(i + 3) * D];
+          }
+        } else if (slot == D) {
+          for (int i = 0; i < SB / 2; i += 4) {
+            t0 += gg[i] * a[i] * a[i];
+            t1 += gg[i + 1] * a[i + 1] * a[i + 1];
+            t2 += gg[i + 2] * a[i + 2] * a[i + 2];
+            t3 += gg[i + 3] * a[i + 3] * a[i + 3];
+          }
+        } else {
+          for (int i = 0; i < SB / 2; i += 4) {
+            t0 += gg[i] * a[i]; t1 += gg[i + 1] * a[i + 1]; t2 += gg[i + 2] * a[i + 2]; t3 += gg[i + 3] * a[i + 3];
+          }
+        }
+      }
+    }
+    const float mine = (t0 + t1) + (t2 + t3);
+    if (h == 1) meet[tid & 255] = mine;
+    __syncthreads();
+    if (h == 0 && o < n_out) partial[static_cast<size_t>(o) * nblk + k] = mine + meet[tid & 255];
+    __syncthreads();                                 // `meet` is rewritten by the next round
+  }
+}
+
 // ---- the same for rows of up to 16 floats: the block's S rows staged in LDS ----------------------------------------
 // A (field, block) unit reads every S row of its block exactly once, in sorted-by-row (= random) order: 18 fields x
 // 65 536 gathers of 64 bytes at the Criteo shape, which the L2s (4 MB each, S is 4.2 MB) do not hold -- the gather
@@ -383,7 +481,8 @@ __global__ __launch_bounds__(512) void ta_reduce_lds_kernel(const TaFieldPack P,
                                                             const int n_grp, const unsigned NB, const long long B,
                                                             const float* __restrict__ g, const float* __restrict__ ssum,
                                                             const int D, const unsigned* __restrict__ sorted,
-                                                            float* __restrict__ psum, float* __restrict__ pcnt) {
+                                                            float* __restrict__ psum, float* __restrict__ pcnt,
+                                                            const TaNumPack N, float* __restrict__ num_partial) {
   using F = Frag<G, 1, true>;
   constexpr int NE = 2 * kTaChunks;                  // 256 boundary elements; 512 / G >= 128 lane groups
   static_assert(kTaChunk == 16 && kTaChunks == 128, "ta_reduce_lds_kernel is written for 128 chunks of 16 pairs");
@@ -393,8 +492,14 @@ __global__ __launch_bounds__(512) void ta_reduce_lds_kernel(const TaFieldPack P,
   float* esum = sg + kTaBlock;                       // [NE][D]
   float* ecnt = esum + NE * D;                       // [NE]
   unsigned* erow = reinterpret_cast<unsigned*>(ecnt + NE);   // [NE]
-  const unsigned k = blockIdx.x / n_grp;
-  const int grp = blockIdx.x % n_grp;
+  const unsigned n_tabwg = NB * static_cast<unsigned>(n_grp);
+  if (blockIdx.x >= n_tabwg) {       // the launch's last workgroups: the numeric features (N.n > 0).  (Dispatched FIRST they
+    ta_numeric_block(N, blockIdx.x - n_tabwg, gridDim.x - n_tabwg, B, g, ssum, D, ta_stage, num_partial);    // shorten this
+    return;                          // launch, 51 vs 57 us, and the step not at all: profiles/r06/fm_numeric_in_tier_a.txt)
+  }
+  const unsigned bid = blockIdx.x;
+  const unsigned k = bid / n_grp;
+  const int grp = bid % n_grp;
   const size_t b0 = static_cast<size_t>(k) * kTaBlock;
   const int n = static_cast<int>((static_cast<size_t>(B) - b0 < kTaBlock) ? (static_cast<size_t>(B) - b0) : kTaBlock);
   // ---- stage S[b0 .. b0 + n) and g: every thread's loads in flight together ----
@@ -687,7 +792,7 @@ static inline bool ta_use_lds() { return true; }     // (the gather form for eve
 
 template <int G, bool VEC>
 static int ta_launch_bwd(const TaPlan& t, int64_t B, const float* g, const float* ssum, int accumulate, char* region,
-                         hipStream_t s) {
+                         hipStream_t s, const TaNumPack* num, float* num_partial, bool* num_done) {
   float* psum = reinterpret_cast<float*>(region + t.off_psum);
   float* pcnt = reinterpret_cast<float*>(region + t.off_pcnt);
   const unsigned* sorted = reinterpret_cast<const unsigned*>(region + t.off_sorted);
@@ -707,8 +812,21 @@ static int ta_launch_bwd(const TaPlan& t, int64_t B, const float* g, const float
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[G] = true;
       }
-      hipLaunchKernelGGL((ta_reduce_lds_kernel<G>), dim3(t.NB * n_grp), dim3(512), lds, s, t.fld, t.n_fld, fpg, n_grp, t.NB,
-                         static_cast<long long>(B), g, ssum, t.D, sorted, psum, pcnt);
+      TaNumPack none;
+      none.n = 0;
+      none.reserved = 0;
+      size_t lds_num = lds;
+      const bool with_num = num != nullptr && num->n > 0 && num->n <= kTaNumMax && num_partial != nullptr;
+      unsigned n_numblk = 0;
+      if (with_num) {
+        n_numblk = static_cast<unsigned>((B + kTaNumBlock - 1) / kTaNumBlock);
+        const size_t need = ta_num_lds_bytes(num->n, t.D);
+        if (need > lds_num) lds_num = need;          // (<= 100 KB; only a small dim with many numeric features gets here)
+      }
+      hipLaunchKernelGGL((ta_reduce_lds_kernel<G>), dim3(t.NB * n_grp + n_numblk), dim3(512), lds_num, s, t.fld,
+                         t.n_fld, fpg, n_grp, t.NB, static_cast<long long>(B), g, ssum, t.D, sorted, psum, pcnt,
+                         with_num ? *num : none, num_partial);
+      if (with_num && num_done != nullptr) *num_done = true;
       rc = check_launch("ta_reduce_lds_kernel");
       if (rc != RBX_OK) return rc;
       goto combine;
@@ -731,28 +849,31 @@ combine:
   return check_launch("ta_final_kernel");
 }
 
+// num / num_partial / num_done: the fused FM backward's numeric reductions as extra workgroups of the LDS form's launch
+// (ta_numeric_block); *num_done says whether they were taken (the caller otherwise launches fm_numeric_partial_kernel).
 static inline int ta_dispatch_bwd(const TaPlan& t, int64_t B, const float* g, const float* ssum, int accumulate,
-                                  char* region, hipStream_t s) {
+                                  char* region, hipStream_t s, const TaNumPack* num = nullptr, float* num_partial = nullptr,
+                                  bool* num_done = nullptr) {
   if (t.n_fld == 0) return RBX_OK;
   const bool vec = t.vec && (ssum == nullptr || (reinterpret_cast<uintptr_t>(ssum) & 15) == 0);
   const int units = vec ? t.D / 4 : t.D;
   if (vec) {
     switch (pow2_ceil(units)) {
-      case 1: return ta_launch_bwd<1, true>(t, B, g, ssum, accumulate, region, s);
-      case 2: return ta_launch_bwd<2, true>(t, B, g, ssum, accumulate, region, s);
-      case 4: return ta_launch_bwd<4, true>(t, B, g, ssum, accumulate, region, s);
-      case 8: return ta_launch_bwd<8, true>(t, B, g, ssum, accumulate, region, s);
-      default: return ta_launch_bwd<16, true>(t, B, g, ssum, accumulate, region, s);
+      case 1: return ta_launch_bwd<1, true>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+      case 2: return ta_launch_bwd<2, true>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+      case 4: return ta_launch_bwd<4, true>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+      case 8: return ta_launch_bwd<8, true>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+      default: return ta_launch_bwd<16, true>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
     }
   }
   switch (pow2_ceil(units)) {
-    case 1: return ta_launch_bwd<1, false>(t, B, g, ssum, accumulate, region, s);
-    case 2: return ta_launch_bwd<2, false>(t, B, g, ssum, accumulate, region, s);
-    case 4: return ta_launch_bwd<4, false>(t, B, g, ssum, accumulate, region, s);
-    case 8: return ta_launch_bwd<8, false>(t, B, g, ssum, accumulate, region, s);
-    case 16: return ta_launch_bwd<16, false>(t, B, g, ssum, accumulate, region, s);
-    case 32: return ta_launch_bwd<32, false>(t, B, g, ssum, accumulate, region, s);
-    default: return ta_launch_bwd<64, false>(t, B, g, ssum, accumulate, region, s);
+    case 1: return ta_launch_bwd<1, false>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+    case 2: return ta_launch_bwd<2, false>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+    case 4: return ta_launch_bwd<4, false>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+    case 8: return ta_launch_bwd<8, false>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+    case 16: return ta_launch_bwd<16, false>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+    case 32: return ta_launch_bwd<32, false>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
+    default: return ta_launch_bwd<64, false>(t, B, g, ssum, accumulate, region, s, num, num_partial, num_done);
   }
 }
 

@@ -1124,23 +1124,11 @@ class _FmFused(torch.autograd.Function):
                                             _ptr(extra_index), x_rows, _ptr(logit), _ptr(prob), _ptr(ssum),
                                             _ptr(status), _stream())))
         _check_status(status)
-        if getattr(ctx, "blocksort_pending", False):
-            # the per-block sorts of the small tables (ids only) go BEHIND the forward kernel on this stream: they delay
-            # neither the forward nor -- the large tables' sort on the side stream is still under way -- the backward
-            # (in front of the forward: 0.256 vs 0.236 ms per step; inside the backward, in front of the block partials:
-            # those then ran beside the large tables' reduce, 56 us instead of 25)
-            # (the plan of the backward counts the tables that HAVE a gradient: bind the placeholders for this call)
-            if emb_plan is not None:
-                emb_plan.bind_params(emb_params, [p if p.requires_grad else None for p in emb_params])
-            if lr_plan is not None:
-                lr_plan.bind_params(lr_params, [p if p.requires_grad else None for p in lr_params])
-            check(lib.rbx_fm_sort_phases(ea, la, lead.n, B, _ptr(ctx.sort.ws), ctx.sort.ws_bytes, None, 4, _stream()))
-            if emb_plan is not None:
-                emb_plan.bind_params(emb_params)
-            if lr_plan is not None:
-                lr_plan.bind_params(lr_params)
-            ctx.blocksort_pending = False
-            ctx.blocksort_done = True
+        # (the per-block sorts of the small tables -- ids only -- stay pending: the backward runs them on this stream BEHIND
+        #  the loss, in front of the block partials that read them.  Behind the forward kernel, where they ran through round
+        #  5, they stood between the forward and the loss: the large tables' reduce on the other hardware queue waits for
+        #  dL/dlogit plus a ~12 us edge between queues, and its sort is done by then -- 0.6 % (uniform) to 2 % (Zipf ids) of
+        #  the step, profiles/r06/fm_blocksort_behind_loss.txt.)
         if adopt is not None:
             pool, started = adopt
 
@@ -1315,11 +1303,12 @@ class _FmFused(torch.autograd.Function):
             def chain_a():
                 if ctx.sort.event_first is not None:
                     cur.wait_event(ctx.sort.event_first)
-                check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 1 | 16 | store,
-                                     _ptr(ws), ws_bytes, _stream()))
-                if not numeric_first:
-                    check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0, 2 | store, _ptr(ws),
-                                         ws_bytes, _stream()))
+                # tier A and -- in the same call -- the numeric features' reductions: their partial sums ride in tier A's first
+                # launch (csrc/rbx_tiera.h: ta_numeric_block), only the small final kernel follows the tables' (round 6: a
+                # launch of ~21 us left the tail of this chain, which now ends before the large tables' chain on the other
+                # hardware queue: the next step's first kernel no longer waits for an edge between queues)
+                check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0,
+                                     1 | 16 | (0 if numeric_first else 2) | store, _ptr(ws), ws_bytes, _stream()))
 
             # tier A is captured FIRST: in the replayed graph the first successor of the loss kernel stays on its hardware
             # queue (5 us behind it instead of 15), and tier B has to wait for its sort on the other queue anyway
