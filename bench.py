@@ -693,8 +693,11 @@ def main():
                          "0/1 = replay one batch.  FM on one GPU: one captured step per resident batch; elsewhere (and "
                          "with --rotate-by-copy) batch i %% K is copied into the static input buffer before each step, "
                          "inside the timed region")
-    ap.add_argument("--steps-per-graph", type=int, default=1,
-                    help="FM, one GPU: capture this many consecutive steps (one per resident batch) in each hipGraph")
+    ap.add_argument("--steps-per-graph", type=int, default=None,
+                    help="FM, one GPU: capture this many consecutive steps (one per resident batch) in each hipGraph.  Default: 4 "
+                         "when --rotate and --steps are multiples of 4 (a replay then costs its ~12 us of graph-to-graph "
+                         "latency once per four steps: profiles/r06/fm_steps_per_graph.txt), else 1; the line of 1 is always "
+                         "reported beside it (configs.fm_one_step_per_graph)")
     ap.add_argument("--prefetch-sort", action="store_true",
                     help="FM, one GPU: while step i runs, the ids of batch i + 1 are sorted on the side stream (FM.presort: a "
                          "loop whose loader is one batch ahead), so that the sort no longer sits in front of the backward's "
@@ -920,6 +923,8 @@ def main():
                     sorted_ids = [model.presort(Xk) for Xk, _ in inputs_of]      # (also the primer of the first step)
                     for k in range(K):                    # the captured re-zero of step k clears the rows step k - 1 wrote
                         sorted_ids[k].previous = sorted_ids[k - 1]
+                if args.steps_per_graph is None:
+                    args.steps_per_graph = 4 if (not prefetch and K % 4 == 0 and args.steps % 4 == 0) else 1
                 S = max(1, int(args.steps_per_graph))
                 if S > 1 and (prefetch or K % S or args.steps % S):
                     raise SystemExit("--steps-per-graph must divide --rotate and --steps (and excludes --prefetch-sort)")
@@ -995,9 +1000,10 @@ def main():
             refill(i)
             step()
 
+    warmup_done = args.warmup
     if steps_per_launch > 1:                  # (whole launches only: the warm-up rounds up)
-        args.warmup = (args.warmup + steps_per_launch - 1) // steps_per_launch * steps_per_launch
-    for i in range(args.warmup):
+        warmup_done = (args.warmup + steps_per_launch - 1) // steps_per_launch * steps_per_launch
+    for i in range(warmup_done):
         run_step(i)
     # dominant kernel = the embedding gather: fm_fused_fwd (fused path) or the [B, 39, 16] embed_fwd (layer path)
     if args.path == "fused" or sharded:
@@ -1014,7 +1020,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        run_step(args.warmup + i)
+        run_step(warmup_done + i)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -1131,7 +1137,8 @@ def main():
                                 "kernel_ms_alone: the same launches with the sort enqueued after the forward")
         out = {"metric": "samples/sec fwd+bwd, Criteo-shaped batch 65 536; embedding HBM GB/s vs roofline",
                "value": B * world * args.steps / el, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
+               "warmup": args.warmup, "warmup_done": warmup_done, "steps_per_graph": steps_per_launch,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "FM (recbox.ranking) Criteo-shaped 26 sparse + 13 dense, dim %d, batch %d per GPU, "
                                       "%s ids (%s), %s path%s, %s, dense-grad autograd contract (%s), no optimiser step"
@@ -1171,7 +1178,8 @@ def extra_configs(args):
     budget = float(os.environ.get("RECBOX_BENCH_EXTRA_SECONDS", "75"))
     # "fm_fresh_grads": the headline workload under autograd's literal contract -- new zero-filled dense gradients every step
     # ("report with and without" the 357 MB fill) -- beside the persistent-buffer headline
-    runs = [("fm_fresh_grads", ["--config", "fm", "--fresh-grads", "--no-cpu-baseline", "--no-extra-configs"]),
+    runs = [("fm_one_step_per_graph", ["--config", "fm", "--steps-per-graph", "1", "--no-cpu-baseline", "--no-extra-configs"]),
+            ("fm_fresh_grads", ["--config", "fm", "--fresh-grads", "--no-cpu-baseline", "--no-extra-configs"]),
             ("youtubednn", ["--config", "youtubednn"]), ("deepfm", ["--config", "deepfm"]), ("sasrec", ["--config", "sasrec"])]
     for cfg, extra in runs:
         cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--gpus", "1", "--steps", str(min(args.steps, 20)),
