@@ -1258,7 +1258,9 @@ class _FmFused(torch.autograd.Function):
         if ws_early is not None and isinstance(ctx.sort, _EarlySort) and ctx.sort.side is not None and emb_plan is not None:
             grads_ready = torch.cuda.current_stream(dev).record_event()      # dL/dlogit, S, the gradient buffers: all here
         numeric_first = False
-        if ws_early is not None and grads_ready is None:
+        # (a sort made ahead of the step -- fm_presort, ordered before this backward by its caller -- is not in flight: the
+        #  numeric part then stays in the one call below, where its partial sums ride in tier A's launch)
+        if ws_early is not None and grads_ready is None and not isinstance(ctx.sort, _Presorted):
             # numeric weights + bias do not need the sorted ids: run them while the sort may still be in flight
             # (with the two chains of the tiered backward they go LAST on this stream instead, behind the small tables'
             #  partials, which then run before the large tables' reduce has started on the other stream; on a stream of their
@@ -1318,7 +1320,7 @@ class _FmFused(torch.autograd.Function):
             cur.wait_event(side_done)
         else:
             check(lib.rbx_fm_bwd(ea, la, lead.n, B, _ptr(dlogit), _ptr(ssum), _ptr(gb), 0,
-                                 (1 if ws_early is not None else 3) | store, _ptr(ws), ws_bytes, _stream()))
+                                 (1 if numeric_first else 3) | store, _ptr(ws), ws_bytes, _stream()))
         if pool is not None:
             if isinstance(ctx.sort, _Presorted):
                 pool.done(B, ws, ws_bytes)
