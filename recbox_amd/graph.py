@@ -23,6 +23,12 @@ class GraphedStep(object):
             static_batch.copy_(batch, non_blocking=True)
             loss = step()           # replays fwd+bwd; parameter .grad tensors are static: consume them
                                     # (optimizer step) before the next replay
+
+    ``fn`` may run SEVERAL steps in a row, each over its own static batch (a loader that keeps S batches resident): a replay
+    then pays the graph-to-graph latency of the runtime -- ~12 us more than the gap between two steps inside one graph on
+    MI355X, 5 % of the FM step -- once per S steps (``bench.py --steps-per-graph``, profiles/r06/fm_steps_per_graph.txt).
+    What consumes the gradients (an optimiser step) then belongs inside ``fn`` too: after a replay ``p.grad`` holds the
+    LAST step's gradients.
     """
 
     def __init__(self, fn, warmup=3, capture_error_mode="global", reuse_grads=True, check_every=0, params=None,

@@ -657,6 +657,45 @@ def test_one_graph_per_resident_batch_replayed_in_rotation():
         ops.config.check_ids = old
 
 
+def test_several_steps_in_one_captured_graph_leave_the_last_steps_gradients():
+    """bench.py --steps-per-graph (round 6): S consecutive steps, one per resident batch, captured in ONE hipGraph (a replay pays
+    the graph-to-graph latency once per S steps).  Every step inside the graph ends with both backward chains joined, the next
+    one clears exactly the rows its predecessor stored: after a replay the loss and every p.grad are those of the eager step on
+    the LAST batch of the group, whichever group ran before it -- two groups of two and of three batches, replayed in any order."""
+    from recbox_amd import ops
+    from recbox_amd.graph import GraphedStep
+    vocabs = CRITEO_SMALL_VOCABS + [70000]
+    fm, eager, graphed = _fm_pair(59, vocabs)
+    B = 600
+    data = []
+    for k in range(5):
+        _, X, y = _criteo_like(B, vocabs, 16, seed=140 + k, zipf=(k in (1, 4)))
+        data.append((_cuda(X), y.cuda()))
+    params = list(graphed.parameters())
+    groups = [(0, 1), (2, 3, 4)]
+    old = ops.config.check_ids
+    ops.config.check_ids = False
+    try:
+        steps = []
+        for grp in groups:
+            def fn(grp=grp):
+                out = None
+                for k in grp:
+                    out = _bce_step(graphed, data[k][0], data[k][1])
+                return out
+            steps.append(GraphedStep(fn, warmup=2, params=params, pool=steps[0].pool() if steps else None))
+        for g in (0, 1, 1, 0, 1):
+            loss = steps[g]()
+            k = groups[g][-1]
+            want = _bce_step(eager, data[k][0], data[k][1])
+            torch.cuda.synchronize()
+            assert_close(loss.reshape(1), want.reshape(1), 1e-6, "loss")
+            for (n, p0), (_, p1) in zip(eager.named_parameters(), graphed.named_parameters()):
+                assert torch.equal(p1.grad, p0.grad), "group %d: %s" % (g, n)
+    finally:
+        ops.config.check_ids = old
+
+
 def test_id_sort_made_one_step_ahead_eager_and_captured():
     """FM.presort / forward(presorted=...): the id sort of batch i + 1 runs on the side stream while step i runs (what a loop
     whose loader is one batch ahead does), with persistent gradients.  Eagerly the gradient pool remembers whose rows to
