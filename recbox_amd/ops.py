@@ -369,7 +369,7 @@ def _note_touched(kind, plans, inputs, params, grads, ws, ws_bytes, B):
 
 
 touched_ids = {}             # id(parameter) -> (data_ptr of its gradient, [id tensors of every lookup that wrote into it], pass)
-_ids_pass = [0, False]       # serial of the backward pass under way; has its end-of-pass callback been queued?
+_ids_pass = [0, False, None] # serial of the backward pass under way; end-of-pass callback queued?; autograd graph task id of that pass
 
 
 def _ids_pass_over():
@@ -385,8 +385,11 @@ def _note_ids(plan, inputs, params, grads, want):
     backward pass: the first lookup of the next pass starts it afresh even when the gradient sits at the same address
     (``zero_grad(set_to_none=False)``, the caching allocator) and nobody stepped the table in between -- a table that some
     other optimiser steps, or a frozen one, would otherwise pin every step's id tensors."""
+    now = _pass_id()
+    if _ids_pass[1] and now is not None and _ids_pass[2] != now:
+        _ids_pass_over()               # the pass that armed this ended in an exception: its callback never ran
     if not _ids_pass[1]:
-        _ids_pass[1] = True
+        _ids_pass[1], _ids_pass[2] = True, now
         torch.autograd.Variable._execution_engine.queue_callback(_ids_pass_over)
     for k, (p, g, w) in enumerate(zip(params, grads, want)):
         if not w or g is None:
@@ -1529,10 +1532,18 @@ def join_beside():
 
 
 _beside_seen = {}              # id(parameter) -> the parameter, for every owner a backward node of this pass has served
+_beside_pass = [None]          # the autograd graph task the entries belong to
+
+
+def _pass_id():
+    """Identity of the backward pass under way (autograd's graph task id; -1 outside a pass)."""
+    get = getattr(torch._C, "_current_graph_task_id", None)
+    return get() if get is not None else None
 
 
 def _pass_over():
     _beside_seen.clear()
+    _beside_pass[0] = None
 
 
 def _hooked(p):
@@ -1553,8 +1564,12 @@ def _beside_ok(ctx, wanted, keys):
     the two contributions on the current stream).  A parameter met a second time in one pass joins the side stream first."""
     owners = [r() for r in getattr(ctx, "owners", ())]
     live = [p for p in owners if p is not None]
+    now = _pass_id()
+    if _beside_seen and now is not None and _beside_pass[0] != now:
+        _beside_seen.clear()           # left behind by a pass that ended in an exception (its callback never ran)
     again = any(id(p) in _beside_seen for p in live)
     if live and not _beside_seen:
+        _beside_pass[0] = now
         torch.autograd.Variable._execution_engine.queue_callback(_pass_over)
     for p in live:
         _beside_seen[id(p)] = p

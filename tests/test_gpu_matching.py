@@ -321,6 +321,50 @@ def test_weight_gradients_of_non_leaf_shared_and_hooked_weights_stay_in_line():
         ops.config.dw_beside_lookup = old
 
 
+def test_a_backward_pass_that_raises_leaves_no_state_behind_for_the_next_one():
+    """The per-pass registries of ops (parameters served in this pass, id lists of this pass) are cleared by autograd's
+    end-of-pass callback -- which never runs for a pass that ends in an exception.  The next pass recognises the leftovers by
+    the graph task id and starts clean: the side stream is used again and the gradients are the in-line ones."""
+    from recbox_amd import ops
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(64, 48).cuda()
+    x = torch.randn(8192, 64, device="cuda", requires_grad=True)
+    calls = []
+    real = ops._run_beside
+    old = ops.config.dw_beside_lookup
+    try:
+        ops.config.dw_beside_lookup = False
+        ops.linear(x, lin.weight, lin.bias).sum().backward()
+        want = [lin.weight.grad.clone(), lin.bias.grad.clone()]
+        ops.config.dw_beside_lookup = True
+        ops._run_beside = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        lin.zero_grad(set_to_none=True)
+        with pytest.raises(RuntimeError, match="boom"):
+            ops.linear(Boom.apply(x), lin.weight, lin.bias).sum().backward()      # the Linear's node ran, then the pass died
+        torch.cuda.synchronize()
+        ops.join_beside()
+        lin.zero_grad(set_to_none=True)
+        n0 = len(calls)
+        ops.linear(x, lin.weight, lin.bias).sum().backward()
+        torch.cuda.synchronize()
+        assert len(calls) == n0 + 1                                   # not mistaken for a parameter met twice in one pass
+        assert torch.equal(lin.weight.grad, want[0]) and torch.equal(lin.bias.grad, want[1])
+        assert not ops._beside_seen
+    finally:
+        ops._run_beside = real
+        ops.config.dw_beside_lookup = old
+
+
 def test_sasrec_in_projection_gradients_with_long_batches_equal_the_in_line_order():
     """rechub SASRec's `_mha` hands slices of in_proj_weight to ops.linear when the fused block chain is off; with
     B L >= 4096 those (non-leaf) weights must not take the side stream: gradients equal the in-line order bit for bit."""
