@@ -33,6 +33,11 @@ class config(object):
     # 1.75 -> 1.65 ms (profiles/r05/dw_beside_ab.txt).  Not used for parameters that already hold a gradient (autograd would
     # add in place); a reader of gradients inside the pass calls join_beside() first (rechub.sharded.DenseGradSync).
     dw_beside_lookup = os.environ.get("RECBOX_AMD_DW_BESIDE", "1") != "0"
+    # ... and, in DeepFM's input stage (the LAST node of its backward pass), the streaming parts of that side work -- the bias
+    # gradient's column sums, the first-order head -- enqueued there BEFORE dx is computed: they run beside the dx GEMM
+    # (matrix-pipe bound) instead of behind the dW GEMM at the tail of the pass: DeepFM 4.12 -> 4.03 ms (round 6,
+    # profiles/r06/db_before_dx_ab.txt; between two tower layers the same order costs 3 %: not done in ops.linear)
+    db_before_dx = True
     # The reference raises IndexError for an out-of-range id (nn.Embedding on CPU).
     # The kernels flag it on device; checking the flag costs one sync per call.
     check_ids = os.environ.get("RECBOX_AMD_CHECK_IDS", "1") != "0"
@@ -1656,6 +1661,8 @@ class _Linear(torch.autograd.Function):
             return run
         if _beside_ok(ctx, dx is not None and (dw is not None or db is not None) and M >= 4096, ctx.grad_keys):
             # dx first; dW / db on the side stream beside whatever consumes dx (config.dw_beside_lookup, see _DeepFmInput)
+            # (db's column sums ahead of dx, as _DeepFmInput does: YoutubeDNN 1.687 -> 1.745 ms -- between two tower layers the
+            #  stream of dy slows the dx GEMM and nothing waits for the side stream's tail: profiles/r06/db_before_dx_ab.txt)
             _with_split_weights(w, M, 1, bwd_of(dx, None, None))
             _run_beside(dy.device, bwd_of(None, dw, db), (x2, w, y, dy2, dw, db))
         elif dx is not None:
@@ -3008,6 +3015,22 @@ def _lin_dwdb_scaled(x2, dy2, row_scale, dw, db):
                                      _ptr(db), _ptr(ws), ws_bytes, _stream()))
 
 
+def _lin_db(x2, w, dy2, db):
+    """db = colsum(dy) alone (rbx_linear_bwd without dW: the column-sum kernels of its general path)."""
+    M, K = x2.shape
+    N = dy2.shape[1]
+    ws_bytes = lib.rbx_linear_bwd_workspace_size(M, N, K, 0)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device)
+    check(lib.rbx_linear_bwd(_ptr(x2), x2.stride(0), _ptr(w), None, _ptr(dy2), M, N, K, 0, None, K, None, _ptr(db),
+                             _ptr(ws), ws_bytes, _stream()))
+
+
+def _db_apart_ok(M, N, K):
+    """Does rbx_linear_bwd compute db by its column-sum kernels for this shape (the same bits alone as beside dW)?  The tall
+    / narrow forms (k <= 64) and the logit head (n = 1) produce it inside the dW pass."""
+    return config.db_before_dx and N > 1 and K > 64
+
+
 def _lin_dwdb(x2, w, dy2, dw, db):
     """dW = dy^T x into ``dw`` [N, K], db = colsum(dy) into ``db`` [N] (either may be None)."""
     if dw is None and db is None:
@@ -3429,9 +3452,13 @@ class _DeepFmInput(torch.autograd.Function):
         dlr_w = _grad_dest(keys[2], lr_w.shape, dev) if need[3] else None
         dlr_b = _grad_dest(keys[3], (1,), dev) if (has_lr_b and need[4]) else None
 
-        def weight_grads():
-            _lin_dwdb(x2, w1, dh2, dw1, db1)
-            if dlr_w is not None or dlr_b is not None:           # the logit head's streaming kernels (n = 1)
+        def weight_grads(gemm=True, streams=True):
+            apart = db1 is not None and dw1 is not None and _db_apart_ok(M, N, K)
+            if gemm:
+                _lin_dwdb(x2, w1, dh2, dw1, None if apart else db1)
+            if streams and apart:
+                _lin_db(x2, w1, dh2, db1)
+            if streams and (dlr_w is not None or dlr_b is not None):           # the logit head's streaming kernels (n = 1)
                 xl = x2[:, :fm_cols]
                 gl2 = gl.view(M, 1)
                 tmp_w = dlr_w if dlr_w is not None else torch.empty_like(lr_w)
@@ -3446,6 +3473,9 @@ class _DeepFmInput(torch.autograd.Function):
         beside = _beside_ok(ctx, need[0], keys)
         if not beside:
             weight_grads()
+        elif config.db_before_dx:
+            # the streams of the side work (db, the first-order head) ahead of dx: beside the dx GEMM, not behind the dW GEMM
+            _run_beside(dev, lambda: weight_grads(gemm=False), (x2, w1, lr_w, dh2, gl, db1, dlr_w, dlr_b))
         dx = None
         if need[0]:
             dx = _padded_rows(M, K, dev)
@@ -3454,7 +3484,8 @@ class _DeepFmInput(torch.autograd.Function):
                 _ptr(lr_w), _ptr(dx), dx.stride(0), _stream())))
             dx = dx.view(xshape) if len(xshape) != 2 else dx
         if beside:
-            _run_beside(dev, weight_grads, (x2, w1, lr_w, dh2, gl, dw1, db1, dlr_w, dlr_b))
+            _run_beside(dev, (lambda: weight_grads(streams=False)) if config.db_before_dx else weight_grads,
+                        (x2, w1, lr_w, dh2, gl, dw1, db1, dlr_w, dlr_b))
         return dx, dw1, db1, dlr_w, dlr_b, None, None
 
 
