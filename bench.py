@@ -1126,7 +1126,9 @@ def main():
                 # is the CU's vector memory path -- profiles/r05/fm_fwd_limiter.md
                 roof["limiter"] = ("per-CU vector memory path: ~64 L1 misses in flight x 550 cycles of L2 / fabric latency "
                                    "(TCP_TCC_READ_REQ / _LATENCY), one tag lookup per cycle, issue slots: "
-                                   "profiles/r05/fm_fwd_limiter.md; with every lookup hitting L1 the kernel takes 16 us")
+                                   "profiles/r05/fm_fwd_limiter.md; with every lookup hitting L1 the kernel takes 16 us; "
+                                   "a scalar-cache prefetch path, balanced occupancy forms and the translation counters "
+                                   "change nothing: profiles/r06/fm_fwd_round6.md")
             ams = alone_timer.mean_ms()
             if ams:
                 roof["frac_alone"] = per_sample * B / (ams * 1e-3) / 1e9 / 8000.0
