@@ -580,6 +580,9 @@ static int fm_tier_a_max_vocab() {
   // 4096 rows: measured at the Criteo shape (profiles/r03), 2200 / 4096 / 16384 give 0.257 / 0.251 / 0.253 ms per step -- a
   // table of 5 000-15 000 rows costs as much either way (block partials that hardly merge vs L2-resident rows in the sorted
   // path), and the partial arrays of the 16384 setting are 3x the workspace
+  // (round 6, with the large tables' chain bounding the step: 2200 / 4096 / 6000 / 13000 / 16384 rows give 0.191 / 0.190 /
+  //  0.204 / 0.207 / 0.213 ms on uniform ids and 0.234 / 0.227 / 0.231 / 0.222 / 0.215 on Zipf-like ids:
+  //  profiles/r06/fm_tier_a_row_limit.txt)
   return 4096 < kTaMaxVocab ? 4096 : kTaMaxVocab;
 }
 
