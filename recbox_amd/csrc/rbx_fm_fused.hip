@@ -1011,8 +1011,10 @@ extern "C" int rbx_fm_bwd(const rbx_field_t* emb, const rbx_field_t* lr, int32_t
   // numeric partials in 512-sample units (ta_numeric_block) -- inside tier A's first launch when this call runs tier A too
   TaNumPack np;
   np.n = 0;
+  // (512 samples' S rows + x columns must fit a workgroup's LDS with room for a second one: dims up to ~40; wider rows keep
+  //  fm_numeric_partial_kernel, whose sample count shrinks with the dim)
   const bool num_blocks_form = (phases & 2) && emb != nullptr && n_num > 0 && n_num <= kTaNumMax && D % 4 == 0 &&
-                               (reinterpret_cast<uintptr_t>(d_sum) & 15) == 0;
+                               (reinterpret_cast<uintptr_t>(d_sum) & 15) == 0 && ta_num_lds_bytes(n_num, D) <= 96 * 1024;
   np.reserved = 0;
   if (num_blocks_form) {
     np.n = n_num;

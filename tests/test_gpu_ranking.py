@@ -260,6 +260,37 @@ def test_fused_fm_matches_layer_path_and_oracle(B, zipf):
         assert_close(p2.grad, p0.grad, TOL * scale, "layer grad " + n0)
 
 
+@pytest.mark.parametrize("dim", [8, 32, 64, 128])
+def test_fused_fm_of_other_dims_matches_the_oracle(dim):
+    """The fused FM body at embedding dims other than the benchmark's 16: the general forward kernel, the sorted backward for
+    every table (tier A is for rows of up to 16 floats) and the numeric features' reductions in whichever form fits the
+    workgroup's LDS (512-sample units up to dim ~40, fm_numeric_partial_kernel beyond) -- logits and every gradient against
+    the float64-free oracle restatement of the model."""
+    from oracle import torch_ref as R
+    from recbox_amd.ranking.pytorch.models import FM
+    B = 1500
+    fm, X, y = _criteo_like(B, CRITEO_SMALL_VOCABS + [20000], dim, seed=300 + dim, zipf=(dim == 32))
+    ref = R.RefFMModel(fm, dim)
+    g = torch.Generator().manual_seed(dim)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        for m in ref.modules():
+            if isinstance(m, torch.nn.Embedding) and m.padding_idx is not None:
+                m.weight[m.padding_idx].zero_()
+    fused = FM(fm, dim, fused=True)
+    fused.load_state_dict(ref.state_dict())
+    fused.cuda()
+    outs = []
+    for model, inp, lab in ((ref, X, y), (fused, _cuda(X), y.cuda())):
+        logit = model.logits(inp) if hasattr(model, "logits") else model(inp)
+        torch.nn.functional.binary_cross_entropy(torch.sigmoid(logit), lab, reduction="sum").backward()
+        outs.append(logit)
+    assert_close(outs[1], outs[0], TOL * max(1.0, float(outs[0].detach().abs().max())), "fused logit vs oracle")
+    for (n0, p0), (_, p1) in zip(ref.named_parameters(), fused.named_parameters()):
+        assert_close(p1.grad, p0.grad, TOL * max(1.0, float(p0.grad.abs().max())), "fused grad " + n0)
+
+
 def _fm_pair(seed, vocabs=None, dim=16):
     from recbox_amd.ranking.pytorch.models import FM
     fm, _, _ = _criteo_like(4, vocabs or (CRITEO_SMALL_VOCABS + [70000]), dim, seed=seed)
