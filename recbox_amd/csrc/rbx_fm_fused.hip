@@ -757,7 +757,10 @@ static int fm_plan(const rbx_field_t* emb, const rbx_field_t* lr, int n, int64_t
   }
   p->max_dim = D;
   p->num_blocks = static_cast<unsigned>((B + ns - 1) / ns);
-  if (tiered) p->long_cap = 32;            // (runs of hundreds of pairs come from the small tables, which are not in this plan)
+  // (the long fix-up launch keeps the plan's 2 x CUs workgroups: through round 5 the tiered plan launched 32 -- "runs of
+  //  hundreds of pairs come from the small tables" -- which holds for uniform ids only: Zipf-like ids leave ~300 long chains in
+  //  the large tables, ten per workgroup in a row, 56 us at the end of the step's critical chain.  Workgroups without a
+  //  chain now leave at once, so the empty launch of a uniform batch costs the same: profiles/r06/fm_long_fixup_cap.txt)
   return RBX_OK;
 }
 

@@ -304,6 +304,12 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
   }
   unsigned* lcnt = fin + kFinList + 2 * static_cast<size_t>(n_chunks);
   const unsigned items = count * KW;
+  // Workgroups without an item leave at once and are not waited for (round 6): the launch is sized for a batch WITH long
+  // chains (Zipf-like ids: ~300 of them at the Criteo shape, which 32 workgroups walked ten in a row -- 56 us at the end of
+  // the step's critical chain) and costs a batch without any what one workgroup costs.  (A workgroup that reads the counters
+  // after the reset below sees no chains and leaves: the reset happens only after every workgroup WITH an item has arrived.)
+  const unsigned needed = items == 0 ? 1u : (items < gridDim.x ? items : gridDim.x);
+  if (blockIdx.x >= needed) return;
   for (unsigned item = blockIdx.x; item < items; item += gridDim.x) {
     const unsigned idx = item / KW, jw = item % KW;
     const unsigned c = fin[kFinList + n_chunks + idx];
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(256) void segment_fixup_long_kernel(const RedPack P
   //  8-XCD part, made the EMPTY launch of a step without long runs cost 12-17 us)
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (atomicAdd(fin + 2, 1u) == gridDim.x - 1) {
+    if (atomicAdd(fin + 2, 1u) == needed - 1) {
       fin[0] = 0;
       fin[1] = 0;
       fin[2] = 0;
