@@ -666,7 +666,7 @@ def main():
     ap.add_argument("--config", choices=["fm"] + sorted(MODEL_CONFIGS), default="fm",
                     help="fm = BASELINE.json configs[1] (the headline metric); the others are configs[2..4]")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=48)      # (a multiple of 4 and 8: --steps-per-graph)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 65536; sasrec 4096)")
     ap.add_argument("--dim", type=int, default=16)
@@ -1182,12 +1182,14 @@ def extra_configs(args):
     budget = float(os.environ.get("RECBOX_BENCH_EXTRA_SECONDS", "75"))
     # "fm_fresh_grads": the headline workload under autograd's literal contract -- new zero-filled dense gradients every step
     # ("report with and without" the 357 MB fill) -- beside the persistent-buffer headline
+    # "fm_zipf": SURVEY.md 8(d) asks for both id distributions; the headline is the worst-case one (uniform)
     runs = [("fm_one_step_per_graph", ["--config", "fm", "--steps-per-graph", "1", "--no-cpu-baseline", "--no-extra-configs"]),
+            ("fm_zipf", ["--config", "fm", "--no-cpu-baseline", "--no-extra-configs", "--dist", "zipf"]),
             ("fm_fresh_grads", ["--config", "fm", "--fresh-grads", "--no-cpu-baseline", "--no-extra-configs"]),
             ("youtubednn", ["--config", "youtubednn"]), ("deepfm", ["--config", "deepfm"]), ("sasrec", ["--config", "sasrec"])]
     for cfg, extra in runs:
-        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--gpus", "1", "--steps", str(min(args.steps, 20)),
-               "--warmup", str(min(args.warmup, 5)), "--cpu-seconds", "6", "--dist", args.dist]
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(min(args.steps, 20)),
+               "--warmup", str(min(args.warmup, 5)), "--cpu-seconds", "6", "--dist", args.dist] + extra
         t0 = time.perf_counter()
         try:
             proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=budget)

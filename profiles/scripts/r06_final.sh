@@ -11,14 +11,14 @@ timeout 2400 python -m pytest tests -q -m gpu > $out/gpu_tests.log 2>&1
 echo "gpu tests exit $?" | tee -a $out/summary.txt; tail -3 $out/gpu_tests.log | tee -a $out/summary.txt
 cp gpurun_out/parity_errors.txt $out/parity_errors.txt 2>/dev/null
 ms() { python -c "import json,sys; d=json.loads([l for l in open('$out/bench_$1.json') if l.startswith('{')][-1]); r=d.get('roofline') or {}; print('$1', round(d['ms_per_step'],4), r.get('kernel'), r.get('kernel_ms'), r.get('frac'))" 2>&1 | tail -1 | tee -a $out/summary.txt; }
-timeout 900 python bench.py > $out/bench_fm.json 2> $out/bench_fm.err; ms fm
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_fm.json 2> $out/bench_fm.err; ms fm
 for cfg in youtubednn deepfm sasrec; do
   timeout 600 python bench.py --config $cfg --steps 20 --warmup 5 > $out/bench_$cfg.json 2>/dev/null; ms $cfg
 done
 for cfg in fm youtubednn deepfm; do
   timeout 300 python bench.py --config $cfg --force-sharded --steps 30 --warmup 5 --no-cpu-baseline > $out/bench_${cfg}_sharded1.json 2> $out/bench_${cfg}_sharded1.err; ms ${cfg}_sharded1
 done
-B="--steps 50 --warmup 10 --no-extra-configs --no-cpu-baseline"
+B="--steps 48 --warmup 8 --no-extra-configs --no-cpu-baseline"
 timeout 300 python bench.py $B > $out/bench_fm_again.json 2>/dev/null; ms fm_again
 timeout 300 python bench.py $B --steps-per-graph 1 > $out/bench_fm_one_step_per_graph.json 2>/dev/null; ms fm_one_step_per_graph
 timeout 300 python bench.py $B --steps-per-graph 1 --dist zipf > $out/bench_fm_zipf_one_step_per_graph.json 2>/dev/null; ms fm_zipf_one_step_per_graph
