@@ -2007,7 +2007,10 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     // got 9 slices (455 k steps each) where the 42 full ones fill the chip with 12 (341 steps)).
     const long long n_full = static_cast<long long>(M / BM) * (N / BN);
     const long long sized = n_full > 0 ? n_full : tiles;
-    const int max_splits = K / 512;
+    // (slices of at least 512 reduction rows; a SHORT reduction -- K < 32 768: the weight gradient of a tower at the per-GPU
+    //  batch of an 8-GPU strong-scaling run -- may be cut into slices of 128, or its handful of workgroups walk the whole
+    //  batch on a few CUs: [128, 256] x 8 192 rows took 54 us in 32 workgroups, profiles/r06/small_batches.txt)
+    const int max_splits = K >= 32768 ? K / 512 : K / 128;
     const long long fit = static_cast<long long>(ws_floats / (static_cast<size_t>(M) * N));
     int best = 1;
     double best_eff = 0.0;
@@ -2045,7 +2048,7 @@ static int run_gemm(const float* A, long long lda, const float* B, long long ldb
     if (4 * M < 3 * tm2 * PBM) sp = 0;                 // 256-row tiles less than 3/4 full (M = 128): the f32 kernel's 128-row tiles
     const long long fit6 = static_cast<long long>(ws_floats / (static_cast<size_t>(M) * N));
     if (sp > fit6) sp = static_cast<int>(fit6);
-    if (sp > K / 1024) sp = K / 1024;
+    if (sp > K / (K >= 32768 ? 1024 : 256)) sp = K / (K >= 32768 ? 1024 : 256);      // (short reductions: see the f32 kernel's rule above)
     if (sp >= 1) {
       int kps6 = (K + sp - 1) / sp;
       kps6 = (kps6 + PBK - 1) / PBK * PBK;
