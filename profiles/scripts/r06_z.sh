@@ -1,12 +1,12 @@
 #!/bin/bash
-# round 6: split-K slices of the towers' weight-gradient GEMMs at short reductions (K < 32 768: slices of 128 / 256 rows allowed; "new") against round 5's rule ("old")
+# round 6: A/B of two library builds at small batches (see profiles/r06/small_batches.txt)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=$GRAFT_REPO_ROOT/gpurun_out/r06z
 mkdir -p $O
 export TMPDIR=/tmp
 for rep in 1 2 3; do
 for lib in new old; do
-for a in "--config youtubednn --batch 8192" "--config deepfm --batch 8192" "--config youtubednn --batch 16384" "--config youtubednn"; do
+for a in "--config youtubednn --batch 8192" "--config deepfm --batch 8192" "--config youtubednn --batch 16384"; do
   export RECBOX_HIP_LIB=$GRAFT_REPO_ROOT/profiles/ubench/ab/$lib.so
   timeout 300 python bench.py $a --steps 40 --warmup 8 --no-cpu-baseline > $O/x.json 2> $O/x.err
   python - "$a" <<PY

@@ -19,7 +19,10 @@
 
 namespace rbx {
 
-constexpr int kBnRows = 256;      // rows per workgroup of the reduction sweeps
+constexpr int kBnRows = 256;      // rows per workgroup of the reduction sweeps (a thread walks rows / 4 of them, four in flight)
+// ... of a SHORT batch (fewer than 32 768 rows: the per-GPU batch of an 8-GPU strong-scaling run): 64, or the sweep is 128
+// workgroups of sixteen dependent round trips each -- bn_bwd_partial took 24-38 us for 8 MB (profiles/r06/small_batches.txt)
+static inline int bn_rows(long long rows) { return rows >= 32768 ? kBnRows : 64; }
 
 struct Welford {
   float n, mean, m2;
@@ -41,11 +44,11 @@ struct Welford {
 
 // grid (ceil(cols/64), ceil(rows/kBnRows)); partial[(rb * cols + c) * 3 + {0,1,2}] = (n, mean, M2)
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, const long long rows, const int cols,
-                                                               float* __restrict__ partial) {
+                                                               float* __restrict__ partial, const int rpb) {
   __shared__ Welford red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const long long r0 = static_cast<long long>(blockIdx.y) * kBnRows;
-  const long long r1 = (r0 + kBnRows < rows) ? r0 + kBnRows : rows;
+  const long long r0 = static_cast<long long>(blockIdx.y) * rpb;
+  const long long r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
   Welford w = {0.f, 0.f, 0.f};
   if (c < cols) {
     long long r = r0 + (threadIdx.x >> 6);
@@ -249,12 +252,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const int cols,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              float* __restrict__ partial, const BnPrelu pr,
-                                                             float* __restrict__ partial3) {
+                                                             float* __restrict__ partial3, const int rpb) {
   __shared__ float red[2][4][64];
   __shared__ float red3[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const long long r0 = static_cast<long long>(blockIdx.y) * kBnRows;
-  const long long r1 = (r0 + kBnRows < rows) ? r0 + kBnRows : rows;
+  const long long r0 = static_cast<long long>(blockIdx.y) * rpb;
+  const long long r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if (c < cols && pr.slope != nullptr) {
     const float m = mean[c], rs = rstd[c];
@@ -485,7 +488,7 @@ static unsigned bn_grid(long long total_vecs, int cols, int w) {
   return static_cast<unsigned>(blocks);
 }
 
-static int bn_blocks(int64_t rows) { return static_cast<int>((rows + kBnRows - 1) / kBnRows); }
+static int bn_blocks(int64_t rows) { return static_cast<int>((rows + bn_rows(rows) - 1) / bn_rows(rows)); }
 static bool bn_vec(int cols, const void* a, const void* b, const void* c) {
   return cols % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
@@ -514,7 +517,7 @@ static int bn_fwd_impl(const float* d_x, int64_t rows, int32_t cols, const float
     float* partial = static_cast<float*>(d_workspace);
     const int nb = bn_blocks(rows);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, static_cast<long long>(rows),
-                       cols, partial);
+                       cols, partial, bn_rows(rows));
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((cols + 63) / 64), dim3(64 * kBnFinalWaves), 0, s, partial, nb, cols, eps, momentum, d_running_mean,
                        d_running_var, d_mean, d_rstd, static_cast<float*>(nullptr));
   } else {
@@ -568,7 +571,7 @@ static int bn_bwd_reduce(const float* d_x, const float* d_dy, const float* d_y_r
   const int nb = bn_blocks(rows);
   float* partial3 = pr.slope != nullptr ? partial + static_cast<size_t>(nb) * cols * 2 : nullptr;   // (the workspace holds 3 per entry)
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, d_dy, d_y_relu,
-                     static_cast<long long>(rows), cols, d_mean, d_rstd, partial, pr, partial3);
+                     static_cast<long long>(rows), cols, d_mean, d_rstd, partial, pr, partial3, bn_rows(rows));
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, nb, cols, d_dbeta, d_dgamma,
                      static_cast<const float*>(partial3), d_dslope);
   return check_launch("batchnorm backward reductions");
@@ -641,7 +644,7 @@ extern "C" int rbx_batchnorm_stats(const float* d_x, int64_t rows, int32_t cols,
   float* partial = static_cast<float*>(d_workspace);
   const int nb = bn_blocks(rows);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((cols + 63) / 64, nb), dim3(256), 0, s, d_x, static_cast<long long>(rows),
-                     cols, partial);
+                     cols, partial, bn_rows(rows));
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3((cols + 63) / 64), dim3(64 * kBnFinalWaves), 0, s, partial, nb, cols, 0.f, 0.f,
                      static_cast<float*>(nullptr), static_cast<float*>(nullptr), static_cast<float*>(nullptr),
                      static_cast<float*>(nullptr), d_raw);
